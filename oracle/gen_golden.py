@@ -1,0 +1,406 @@
+"""oracle/gen_golden.py -- TEST INFRASTRUCTURE ONLY.  Runs in the BUILD CONTAINER only (needs /root/reference).
+
+Pins the HamGNN-level *wiring* of the oracle (instruction enumeration, slot sort/permutation, head-to-vector
+interleave, gate split, CG merge loop order, reorder / symmetrise / mask tables) against the reference's OWN
+Python modules: /root/reference/hamgnn/{nn,models,utils,physics}/*.py are imported unmodified from where they
+lie, with the un-installed third-party packages replaced by throw-away stubs:
+    e3nn            -> oracle/e3.py (the restatement under test; e3nn==0.5.0 is not installable here)
+    torch_scatter   -> index_add_ sum
+    easydict / opt_einsum / pymatgen / torch_geometric / ase / ...  -> permissive dummies (never on the arithmetic path)
+The same random state_dict is loaded into the reference module and into oracle/hamgnn_ref.py, both are run on the
+same seeded graph, must agree to ~1e-12 (fp64), and {weights, inputs, outputs} are written to tests/golden/*.npz
+(data only; no reference source is copied).  It also extracts the head's basis tables (index_change, minus_index,
+basis_def, row shells) as JSON *data*.
+
+Usage:  python -m oracle.gen_golden        (from the repo root)
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.abc
+import importlib.machinery
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from . import e3  # noqa: E402
+from . import hamgnn_ref as R  # noqa: E402
+
+
+# ----------------------------------------------------------------------------------------------- stub machinery
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Dummy()
+
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return _Dummy()
+
+    def __class_getitem__(cls, k):
+        return cls
+
+
+class _Permissive(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return type(k, (_Dummy,), {})
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    TOPS = ("ase", "pymatgen", "torch_geometric", "torch_scatter", "torch_runstats", "easydict", "opt_einsum",
+            "opt_einsum_fx", "pytorch_lightning", "lmdb", "numba", "natsort", "e3nn", "tensorboard", "matplotlib")
+
+    def find_spec(self, name, path=None, target=None):
+        if name.split(".")[0] in self.TOPS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Permissive(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+_Z = {s: i + 1 for i, s in enumerate(
+    "H He Li Be B C N O F Ne Na Mg Al Si P S Cl Ar K Ca Sc Ti V Cr Mn Fe Co Ni Cu Zn Ga Ge As Se Br Kr Rb Sr Y Zr Nb Mo Tc "
+    "Ru Rh Pd Ag Cd In Sn Sb Te I Xe Cs Ba La Ce Pr Nd Pm Sm Eu Gd Tb Dy Ho Er Tm Yb Lu Hf Ta W Re Os Ir Pt Au Hg Tl Pb Bi "
+    "Po At Rn".split())}
+
+
+class _ElementMeta(type):
+    def __getitem__(cls, sym):
+        return types.SimpleNamespace(Z=_Z[sym], symbol=sym)
+
+
+class _Element(metaclass=_ElementMeta):
+    def __init__(self, sym):
+        self.Z, self.symbol = _Z[sym], sym
+
+
+class _EasyDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def install_stubs():
+    sys.meta_path.insert(0, _StubFinder())
+    import e3nn  # noqa  (permissive)
+    for name, ns in (("e3nn.o3", e3.o3), ("e3nn.nn", e3.nn)):
+        m = importlib.import_module(name)
+        for k, v in vars(ns).items():
+            setattr(m, k, v)
+    sys.modules["e3nn"].o3 = sys.modules["e3nn.o3"]
+    sys.modules["e3nn"].nn = sys.modules["e3nn.nn"]
+    importlib.import_module("e3nn.util.jit").compile_mode = e3.compile_mode
+    importlib.import_module("torch_scatter").scatter = lambda src, index, dim=0, dim_size=None, reduce="sum": R.scatter_sum(
+        src, index, dim_size if dim_size is not None else int(index.max()) + 1)
+    importlib.import_module("easydict").EasyDict = _EasyDict
+    importlib.import_module("opt_einsum").contract = torch.einsum
+    importlib.import_module("pymatgen.core.periodic_table").Element = _Element
+    # fake (non-executed) packages so that only the hot-path files of the reference are executed
+    for pkg in ("hamgnn", "hamgnn.nn", "hamgnn.models", "hamgnn.utils", "hamgnn.physics", "hamgnn.toolbox",
+                "hamgnn.toolbox.nequip", "hamgnn.toolbox.nequip.nn", "hamgnn.toolbox.nequip.nn.embedding",
+                "hamgnn.toolbox.nequip.data"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, *pkg.split("."))]
+        sys.modules[pkg] = m
+    for pkg in ("hamgnn.toolbox.mace", "hamgnn.toolbox.nequip.utils", "hamgnn.toolbox.nequip.data.transforms",
+                "hamgnn.toolbox.nequip.nn.radial_basis", "hamgnn.toolbox.nequip.nn.cutoffs"):
+        m = _Permissive(pkg)
+        m.__path__ = []
+        sys.modules[pkg] = m
+    sys.meta_path.insert(0, _PrefixStub("hamgnn.toolbox.mace"))
+    # the few real nequip-derived files on the path
+    data = sys.modules["hamgnn.toolbox.nequip.data"]
+    data.AtomicDataDict = importlib.import_module("hamgnn.toolbox.nequip.data.AtomicDataDict")
+    nn_ = sys.modules["hamgnn.toolbox.nequip.nn"]
+    nn_.GraphModuleMixin = importlib.import_module("hamgnn.toolbox.nequip.nn._graph_mixin").GraphModuleMixin
+    nn_.AtomwiseLinear = importlib.import_module("hamgnn.toolbox.nequip.nn._atomwise").AtomwiseLinear
+    emb = sys.modules["hamgnn.toolbox.nequip.nn.embedding"]
+    emb.OneHotAtomEncoding = importlib.import_module("hamgnn.toolbox.nequip.nn.embedding._one_hot").OneHotAtomEncoding
+    emb.SphericalHarmonicEdgeAttrs = importlib.import_module("hamgnn.toolbox.nequip.nn.embedding._edge").SphericalHarmonicEdgeAttrs
+    emb.Embedding_block_q = _Dummy
+
+
+class _PrefixStub(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def __init__(self, prefix):
+        self.prefix = prefix
+
+    def find_spec(self, name, path=None, target=None):
+        if name.startswith(self.prefix + "."):
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = _Permissive(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+# ----------------------------------------------------------------------------------------------- synthetic graph
+class Graph(dict):
+    """attribute- and key-addressable graph (stand-in for torch_geometric Data)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def to_dict(self):
+        return dict(self)
+
+
+def tiny_graph(seed=0, n_atoms=3, cutoff=6.5, zs=(14, 8, 14), cell_a=7.3, dtype=torch.float64):
+    """Small periodic cell with jitter; all pairs within `cutoff` incl. periodic images; centre-major; inv_edge_idx."""
+    g = torch.Generator().manual_seed(seed)
+    cell = torch.eye(3, dtype=dtype) * cell_a + 0.3 * torch.randn(3, 3, generator=g, dtype=dtype)
+    frac = torch.rand(n_atoms, 3, generator=g, dtype=dtype)
+    pos = frac @ cell
+    edges = []
+    rng = range(-2, 3)
+    for j in range(n_atoms):
+        for i in range(n_atoms):
+            for a in rng:
+                for b in rng:
+                    for c in rng:
+                        if i == j and (a, b, c) == (0, 0, 0):
+                            continue
+                        sh = torch.tensor([a, b, c], dtype=dtype) @ cell
+                        d = (pos[i] + sh - pos[j]).norm().item()
+                        if d < cutoff:
+                            edges.append((j, i, a, b, c))
+    key = {e: k for k, e in enumerate(edges)}
+    inv = [key[(i, j, -a, -b, -c)] for (j, i, a, b, c) in edges]
+    ei = torch.tensor([[e[0] for e in edges], [e[1] for e in edges]], dtype=torch.long)
+    cs = torch.tensor([[e[2], e[3], e[4]] for e in edges], dtype=torch.long)
+    G = Graph(z=torch.tensor(zs[:n_atoms], dtype=torch.long), pos=pos, cell=cell[None], edge_index=ei, cell_shift=cs,
+              nbr_shift=cs.to(dtype) @ cell, inv_edge_idx=torch.tensor(inv, dtype=torch.long),
+              batch=torch.zeros(n_atoms, dtype=torch.long), node_counts=torch.tensor([n_atoms]))
+    return G
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def _save(name, **groups):
+    flat = {}
+    for gname, d in groups.items():
+        for k, v in _np(d).items():
+            flat[f"{gname}/{k}"] = v
+    os.makedirs(GOLD, exist_ok=True)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **flat)
+    print(f"  wrote tests/golden/{name}.npz  ({os.path.getsize(os.path.join(GOLD, name + '.npz')) / 1024:.0f} KiB)")
+
+
+def _check(a, b, what, tol=1e-10):
+    err = (a - b).abs().max().item() / max(1e-30, b.abs().max().item())
+    print(f"  {what:55s} rel.err = {err:.2e}")
+    assert err < tol, what
+    return err
+
+
+# ----------------------------------------------------------------------------------------------- main
+def main():
+    torch.set_default_dtype(torch.float64)
+    install_stubs()
+    ref_mp = importlib.import_module("hamgnn.nn.message_passing")
+    ref_ib = importlib.import_module("hamgnn.nn.interaction_blocks")
+    ref_cv = importlib.import_module("hamgnn.nn.convolution")
+    ref_em = importlib.import_module("hamgnn.nn.embeddings")
+    ref_conv = importlib.import_module("hamgnn.models.hamgnn_conv")
+    ref_out = importlib.import_module("hamgnn.models.hamgnn_output")
+
+    # ---- basis tables (data) ------------------------------------------------------------------------------
+    tables = {}
+    for ham_type, naos in (("openmx", (13, 14, 19, 26)), ("siesta", (13, 19)), ("abacus", (13, 27, 40))):
+        for nao in naos:
+            h = ref_out.HamGNNPlusPlusOut.__new__(ref_out.HamGNNPlusPlusOut)
+            torch.nn.Module.__init__(h)
+            h.nao_max, h.ham_type = nao, ham_type
+            h._initialize_basis_information()
+            ic = getattr(h, "index_change", None)
+            mi = getattr(h, "minus_index", None)
+            tables[f"{ham_type}_{nao}"] = {
+                "row": str(h.row),
+                "index_change": ic.tolist() if ic is not None else None,
+                "minus_index": mi.tolist() if mi is not None else None,
+                "basis_def": {str(int(k)): [int(x) for x in v] for k, v in h.basis_def.items()},
+            }
+    os.makedirs(GOLD, exist_ok=True)
+    with open(os.path.join(GOLD, "basis_tables.json"), "w") as f:
+        json.dump(tables, f, separators=(",", ":"), sort_keys=True)
+    print("wrote tests/golden/basis_tables.json:", sorted(tables))
+
+    # radii table used by the synthetic generator (hamgnn/models/base_model.py:25-61) -- data
+    ref_bm = importlib.import_module("hamgnn.models.base_model")
+    with open(os.path.join(GOLD, "atomic_radii.json"), "w") as f:
+        json.dump(ref_bm.ATOMIC_RADII, f, separators=(",", ":"), sort_keys=True)
+
+    mini = "8x0e+4x0o+4x1o+2x1e+2x2o+3x2e+2x3o"
+    sh_irreps = "0e+1o+2e+3o"
+    cfg = _EasyDict(HamGNN_pre=_EasyDict(
+        num_types=20, irreps_edge_sh=sh_irreps, edge_sh_normalization="component", edge_sh_normalize=True,
+        build_internal_graph=False, cutoff=8.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=mini,
+        use_kan=False, radial_MLP=[16, 16], correlation=2, num_hidden_features=16, radius_type="openmx",
+        use_corr_prod=False, legacy_edge_update=False, lite_mode=False))
+
+    G = tiny_graph(seed=3, n_atoms=3, zs=(14, 8, 14))
+    E = G.edge_index.shape[1]
+    print(f"tiny graph: N={len(G.z)} E={E}")
+    gen = torch.Generator().manual_seed(11)
+
+    # ---- 1. MessagePackBlock ---------------------------------------------------------------------------------
+    print("MessagePackBlock")
+    for lite in (False, True):
+        torch.manual_seed(5)
+        ref = ref_mp.MessagePackBlock(mini, mini, sh_irreps, mini, "8x0e", radial_MLP=[16, 16], lite_mode=lite)
+        mine = R.MessagePackBlock(mini, mini, sh_irreps, mini, "8x0e", radial_MLP=[16, 16], lite_mode=lite)
+        sd = {k: v for k, v in ref.state_dict().items()}
+        missing = mine.load_state_dict(sd, strict=False)
+        assert not missing.missing_keys, missing
+        D = e3.Irreps(mini).dim
+        src, dst, ef = (torch.randn(E, D, generator=gen) for _ in range(3))
+        sh, rbf, _ = R.edge_geometry(G.pos, G.edge_index, G.nbr_shift, sh_irreps, 8.0, 8)
+        yr, ym = ref(src, dst, ef, sh, rbf), mine(src, dst, ef, sh, rbf)
+        _check(ym, yr, f"MessagePackBlock lite={lite}")
+        if not lite:
+            assert [tuple(i[:3]) for i in ref.node_instructions] == [tuple(i[:3]) for i in mine.node_instructions]
+            _save("message_pack_block", weights=sd, inputs=dict(src=src, dst=dst, edge_feats=ef, sh=sh, rbf=rbf),
+                  outputs=dict(out=yr), meta=dict(irreps=np.array(mini), irreps_sh=np.array(sh_irreps), radial_MLP=np.array([16, 16]),
+                                                  num_radial=np.array(8)))
+        else:
+            _save("message_pack_block_lite", weights=sd, inputs=dict(src=src, dst=dst, edge_feats=ef, sh=sh, rbf=rbf), outputs=dict(out=yr))
+
+    # ---- 2. ResidualBlock --------------------------------------------------------------------------------------
+    print("ResidualBlock")
+    torch.manual_seed(6)
+    ref = ref_ib.ResidualBlock(mini, mini)
+    mine = R.ResidualBlock(mini, mini)
+    mine.load_state_dict(ref.state_dict(), strict=False)
+    x = torch.randn(7, e3.Irreps(mini).dim, generator=gen)
+    _check(mine(x), ref(x), "ResidualBlock")
+    assert str(ref.equivariant_nonlin.irreps_in) == str(mine.equivariant_nonlin.irreps_in)
+    _save("residual_block", weights=ref.state_dict(), inputs=dict(x=x), outputs=dict(out=ref(x)),
+          meta=dict(gate_irreps_in=np.array(str(ref.equivariant_nonlin.irreps_in))))
+
+    # ---- 3. full backbone (embedding + conv + pair layers) -------------------------------------------------------
+    print("HamGNNConvE3 (2 layers)")
+    torch.manual_seed(7)
+    ref = ref_conv.HamGNNConvE3(cfg)
+    mine = R.HamGNNConvE3(dict(cfg))
+    sd = ref.state_dict()
+    res = mine.load_state_dict(sd, strict=False)
+    assert not res.missing_keys, res.missing_keys
+    g_ref = Graph(G)
+    rep_ref = ref(g_ref)
+    rep_mine = mine(G)
+    _check(rep_mine["node_attr"], rep_ref["node_attr"], "backbone node_attr")
+    _check(rep_mine["edge_attr"], rep_ref["edge_attr"], "backbone edge_attr")
+    _check(R.edge_geometry(G.pos, G.edge_index, G.nbr_shift, sh_irreps, 8.0, 8)[0], g_ref["edge_attrs"], "edge SH")
+    _check(R.edge_geometry(G.pos, G.edge_index, G.nbr_shift, sh_irreps, 8.0, 8)[1], g_ref["edge_embedding"], "edge rbf")
+    learn = {k: v for k, v in sd.items() if k in dict(mine.named_parameters())}
+    _save("backbone", weights=learn,
+          graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
+          outputs=dict(node_attr=rep_ref["node_attr"], edge_attr=rep_ref["edge_attr"], edge_attrs=g_ref["edge_attrs"],
+                       edge_embedding=g_ref["edge_embedding"]),
+          meta=dict(cfg=np.array(json.dumps(dict(cfg["HamGNN_pre"])))))
+
+    # legacy_edge_update variant (Uni-HamGNN): layer 0 has no skip and keeps edge feats
+    cfg2 = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, legacy_edge_update=True).items() if k != 'radius_scale'}))
+    torch.manual_seed(8)
+    ref2, mine2 = ref_conv.HamGNNConvE3(cfg2), R.HamGNNConvE3(dict(cfg2))
+    mine2.load_state_dict(ref2.state_dict(), strict=False)
+    r2 = ref2(Graph(G))
+    _check(mine2(G)["edge_attr"], r2["edge_attr"], "backbone legacy_edge_update edge_attr")
+
+    # ---- 4. head, non-SOC (openmx nao 14/19/26, abacus 13 with minus_index) -----------------------------------------
+    print("HamGNNPlusPlusOut")
+    D = e3.Irreps(mini).dim
+    N = len(G.z)
+    node_attr, edge_attr = torch.randn(N, D, generator=gen), torch.randn(E, D, generator=gen)
+    for ham_type, nao, zs in (("openmx", 19, (14, 8, 42)), ("openmx", 14, (14, 8, 1)), ("openmx", 26, (14, 8, 79)), ("abacus", 13, (6, 1, 8))):
+        Gh = Graph(G)
+        Gh.z = torch.tensor(zs)
+        n2 = nao * nao
+        for k, n in (("Hon0", N), ("Hoff0", E), ("Hon", N), ("Hoff", E), ("Son", N), ("Soff", E)):
+            Gh[k] = 0.1 * torch.randn(n, n2, generator=gen)
+        torch.manual_seed(9)
+        ref = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type=ham_type, ham_only=True,
+                                        symmetrize=True, add_H0=True, soc_switch=False, calculate_band_energy=False,
+                                        calculate_sparsity=False)
+        mine = R.HamGNNPlusPlusOut(mini, mini, nao_max=nao, ham_type=ham_type, symmetrize=True, add_H0=True)
+        sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("cg_calculator")}
+        res = mine.load_state_dict(sd, strict=False)
+        assert not res.missing_keys, res.missing_keys
+        out_ref = ref(Graph(Gh), {"node_attr": node_attr, "edge_attr": edge_attr})
+        out_mine = mine(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})
+        _check(out_mine["hamiltonian"], out_ref["hamiltonian"], f"head {ham_type} nao={nao} hamiltonian")
+        assert str(ref.hamiltonian_irreps) == str(mine.hamiltonian_irreps)
+        if (ham_type, nao) in (("openmx", 19), ("abacus", 13)):
+            _save(f"head_{ham_type}_{nao}", weights=sd, graph={k: Gh[k] for k in ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0")},
+                  inputs=dict(node_attr=node_attr, edge_attr=edge_attr), outputs=dict(hamiltonian=out_ref["hamiltonian"]))
+
+    # ---- 5. head, SOC so3 (openmx nao 19) --------------------------------------------------------------------------
+    nao = 19
+    Gs = Graph(G)
+    Gs.z = torch.tensor((14, 8, 42))
+    n2, m2 = nao * nao, 4 * nao * nao
+    for k, n, w in (("Hon0", N, m2), ("Hoff0", E, m2), ("iHon0", N, m2), ("iHoff0", E, m2), ("Hon", N, m2), ("Hoff", E, m2),
+                    ("iHon", N, m2), ("iHoff", E, m2), ("Son", N, n2), ("Soff", E, n2)):
+        Gs[k] = 0.1 * torch.randn(n, w, generator=gen)
+    Gs["Lon"], Gs["Loff"] = torch.randn(N, n2, 3, generator=gen), torch.randn(E, n2, 3, generator=gen)
+    Gs["Hon_nonsoc"], Gs["Hoff_nonsoc"] = torch.randn(N, n2, generator=gen), torch.randn(E, n2, generator=gen)
+    for nonsoc in (False, True):
+        torch.manual_seed(10)
+        ref = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type="openmx", ham_only=True,
+                                        symmetrize=True, add_H0=True, soc_switch=True, soc_basis="so3", add_H_nonsoc=nonsoc,
+                                        calculate_band_energy=False, calculate_sparsity=False)
+        mine = R.HamGNNPlusPlusOut(mini, mini, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True, soc_switch=True,
+                                   soc_basis="so3", add_H_nonsoc=nonsoc)
+        sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("cg_calculator")}
+        res = mine.load_state_dict(sd, strict=False)
+        assert not res.missing_keys, res.missing_keys
+        gin = Graph({k: (v.clone() if torch.is_tensor(v) else v) for k, v in Gs.items()})
+        out_ref = ref(gin, {"node_attr": node_attr, "edge_attr": edge_attr})
+        out_mine = mine(Gs, {"node_attr": node_attr, "edge_attr": edge_attr})
+        _check(out_mine["hamiltonian_real"], out_ref["hamiltonian_real"], f"head SOC so3 add_H_nonsoc={nonsoc} real")
+        _check(out_mine["hamiltonian_imag"], out_ref["hamiltonian_imag"], f"head SOC so3 add_H_nonsoc={nonsoc} imag")
+        if not nonsoc:
+            keys = ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0", "iHon0", "iHoff0", "Lon", "Loff")
+            _save("head_soc_so3_openmx_19", weights=sd, graph={k: Gs[k] for k in keys}, inputs=dict(node_attr=node_attr, edge_attr=edge_attr),
+                  outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"], hamiltonian_imag=out_ref["hamiltonian_imag"]))
+    print("ALL WIRING CHECKS PASSED")
+
+
+if __name__ == "__main__":
+    main()

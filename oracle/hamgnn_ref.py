@@ -1,0 +1,488 @@
+"""oracle/hamgnn_ref.py -- TEST INFRASTRUCTURE ONLY (CPU oracle).  Never imported by the product path.
+
+Unfused pure-torch restatement (one einsum per e3nn instruction, materialised ``mid`` tensors, index_add scatter)
+of the HamGNN hot path on top of oracle/e3.py.  Parameter/attribute names equal the reference's so state_dicts
+are interchangeable with the reference modules (oracle/gen_golden.py checks exactly that, in this container).
+
+Each class cites the reference code it follows (paths relative to /root/reference):
+  tp_instructions                  hamgnn/nn/message_passing.py:136-171  (== tensor_products.py:115-150)
+  LinearScaleWithWeights           hamgnn/nn/tensor_products.py:25-47
+  RadialTensorProduct              hamgnn/nn/tensor_products.py:51-189   (TensorProductWithMemoryOptimizationWithWeight)
+  MessagePackBlock                 hamgnn/nn/message_passing.py:26-231
+  ResidualBlock                    hamgnn/nn/interaction_blocks.py:264-358 ; irreps2gate hamgnn/utils/irreps_utils.py:33-65
+  ConvBlockE3                      hamgnn/nn/convolution.py:22-160
+  PairInteractionBlock             hamgnn/nn/interaction_blocks.py:30-164
+  PairInteractionEmbeddingBlock    hamgnn/nn/embeddings.py:215-337
+  edge geometry                    hamgnn/toolbox/nequip/nn/embedding/_edge.py:59-67 ; hamgnn/nn/embeddings.py:73-100 ;
+                                   hamgnn/utils/basis_functions.py:177-208 ; hamgnn/utils/cutoff_functions.py:35-61
+  HamGNNConvE3                     hamgnn/models/hamgnn_conv.py:88-284
+  HamLayer / HamGNNPlusPlusOut     hamgnn/models/hamgnn_output.py:38-58, 96-343, 851-891, 1056-1096, 1187-1285,
+                                   2288-2365, 2916-3000, 3026-3144 (SOC so3), 3772-3799, 3966-4003
+
+PARITY STATUS: "parity unpinned" against e3nn (see oracle/e3.py header); HamGNN-level wiring pinned by
+tests/golden/*.npz generated from the reference's own modules (oracle/gen_golden.py).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import e3
+from .e3 import Irreps, Irrep, Linear, TensorProduct, FullyConnectedNet, Gate
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def ssp(x):
+    return torch.nn.functional.softplus(x) - math.log(2.0)
+
+
+ssp.__name__ = "ShiftedSoftPlus"
+ACTS = {"abs": torch.abs, "tanh": torch.tanh, "ssp": ssp, "silu": torch.nn.functional.silu}
+
+
+def scatter_sum(src, index, dim_size):
+    out = src.new_zeros((dim_size,) + src.shape[1:])
+    return out.index_add_(0, index, src)
+
+
+# ---------------------------------------------------------------------------------------------- tensor products
+
+
+def tp_instructions(irreps1, irreps2, target, mode="uvw", trainable=True):
+    irreps1, irreps2, target = Irreps(irreps1), Irreps(irreps2), Irreps(target)
+    slots, ins = [], []
+    for i, (mul_in, ir_in) in enumerate(irreps1):
+        for j, (_, ir_sh) in enumerate(irreps2):
+            prod = ir_in * ir_sh
+            for mul_out, ir_out in target:
+                if ir_out in prod:
+                    ins.append((i, j, len(slots), mode, trainable))
+                    slots.append((mul_out if mode == "uvw" else mul_in, ir_out))
+    mid, perm, _ = Irreps(slots).sort()
+    ins = sorted([(a, b, perm[c], m, t) for a, b, c, m, t in ins], key=lambda x: x[2])
+    return mid, ins
+
+
+class LinearScaleWithWeights(nn.Module):
+    def __init__(self, irreps_in, irreps_out):
+        super().__init__()
+        irreps_in = Irreps(irreps_in)
+        self.tp = TensorProduct(irreps_in, "1x0e", irreps_in, [(i, 0, i, "uvu", True) for i in range(len(irreps_in))],
+                                shared_weights=False, internal_weights=False)
+        self.weight_numel = self.tp.weight_numel
+        self.linear_out = Linear(irreps_in, irreps_out)
+
+    def forward(self, x, weight):
+        return self.linear_out(self.tp(x, torch.ones_like(x[:, :1]), weight))
+
+
+class RadialTensorProduct(nn.Module):
+    def __init__(self, irreps_input_1, irreps_input_2, irreps_out, irreps_scalar, radial_MLP, lite_mode=False):
+        super().__init__()
+        mode = "uvu" if lite_mode else "uvw"
+        self.irreps_mid, self.instructions = tp_instructions(irreps_input_1, irreps_input_2, irreps_out, mode, not lite_mode)
+        self.tensor_product = TensorProduct(irreps_input_1, irreps_input_2, self.irreps_mid, self.instructions,
+                                            internal_weights=True, shared_weights=True)
+        self.linear_scaler = LinearScaleWithWeights(self.irreps_mid.simplify(), irreps_out)
+        self.weight_generator = FullyConnectedNet([Irreps(irreps_scalar).num_irreps] + list(radial_MLP) + [self.linear_scaler.weight_numel],
+                                                  torch.nn.functional.silu)
+
+    def forward(self, x, y, scalars):
+        return self.linear_scaler(self.tensor_product(x, y), self.weight_generator(scalars))
+
+
+def heads_to_vector(irreps, x):
+    """[E, 2, D] -> per irrep block [src block, dst block]  (hamgnn/nn/attention_utils.py:85-119)."""
+    parts, i = [], 0
+    for mul, ir in Irreps(irreps):
+        n = mul * ir.dim
+        parts.append(x[:, :, i:i + n].reshape(x.shape[0], -1))
+        i += n
+    return torch.cat(parts, dim=1)
+
+
+class MessagePackBlock(nn.Module):
+    def __init__(self, irreps_node_feats, irreps_edge_feats, irreps_local_env_edge, irreps_out, irreps_edge_scalars,
+                 radial_MLP=(64, 64), lite_mode=False):
+        super().__init__()
+        self.irreps_node_feats = Irreps(irreps_node_feats)
+        irreps_edge_feats, irreps_sh, irreps_out = Irreps(irreps_edge_feats), Irreps(irreps_local_env_edge), Irreps(irreps_out)
+        self.lite_mode = lite_mode
+        mode = "uvu" if lite_mode else "uvw"
+        comb = Irreps([(max(1, int(mul * 2)), ir) for mul, ir in self.irreps_node_feats])
+        self.mid_node_irreps, self.node_instructions = tp_instructions(comb, irreps_sh, irreps_out, mode, not lite_mode)
+        self.mid_edge_irreps, self.edge_instructions = tp_instructions(irreps_edge_feats, irreps_sh, irreps_out, mode, not lite_mode)
+        self.node_tensor_product = TensorProduct(comb, irreps_sh, self.mid_node_irreps, self.node_instructions,
+                                                 internal_weights=True, shared_weights=True)
+        self.edge_tensor_product = TensorProduct(irreps_edge_feats, irreps_sh, self.mid_edge_irreps, self.edge_instructions,
+                                                 internal_weights=True, shared_weights=True)
+        n_in = Irreps(irreps_edge_scalars).num_irreps
+        if lite_mode:
+            self.node_linear_scaler = Linear(self.mid_node_irreps.simplify(), irreps_out)
+            self.edge_linear_scaler = Linear(self.mid_edge_irreps.simplify(), irreps_out)
+            self.combine_messages = LinearScaleWithWeights(irreps_out.simplify(), irreps_out)
+            self.weight_generator_combine = FullyConnectedNet([n_in] + list(radial_MLP) + [self.combine_messages.weight_numel],
+                                                              torch.nn.functional.silu)
+        else:
+            self.node_linear_scaler = LinearScaleWithWeights(self.mid_node_irreps.simplify(), irreps_out)
+            self.edge_linear_scaler = LinearScaleWithWeights(self.mid_edge_irreps.simplify(), irreps_out)
+            self.node_weight_generator = FullyConnectedNet([n_in] + list(radial_MLP) + [self.node_linear_scaler.weight_numel],
+                                                           torch.nn.functional.silu)
+            self.edge_weight_generator = FullyConnectedNet([n_in] + list(radial_MLP) + [self.edge_linear_scaler.weight_numel],
+                                                           torch.nn.functional.silu)
+            self.node_linear_out = Linear(irreps_out, irreps_out)
+            self.edge_linear_out = Linear(irreps_out, irreps_out)
+
+    def forward(self, src, dst, edge_feats, sh, rbf):
+        node_inter = heads_to_vector(self.irreps_node_feats, torch.stack([src, dst], dim=-2))
+        if self.lite_mode:
+            a = self.node_linear_scaler(self.node_tensor_product(node_inter, sh))
+            b = self.edge_linear_scaler(self.edge_tensor_product(edge_feats, sh))
+            return self.combine_messages(a + b, self.weight_generator_combine(rbf))
+        a = self.node_linear_scaler(self.node_tensor_product(node_inter, sh), self.node_weight_generator(rbf))
+        b = self.edge_linear_scaler(self.edge_tensor_product(edge_feats, sh), self.edge_weight_generator(rbf))
+        return self.node_linear_out(a) + self.edge_linear_out(b)
+
+
+# ---------------------------------------------------------------------------------------------- gate / residual
+
+
+def irreps2gate(irreps, act_scalars={1: "ssp", -1: "tanh"}, act_gates={1: "ssp", -1: "abs"}):
+    irreps = Irreps(irreps)
+    scalars = Irreps([(m, ir) for m, ir in irreps if ir.l == 0]).simplify()
+    gated = Irreps([(m, ir) for m, ir in irreps if ir.l != 0]).simplify()
+    gates = Irreps([(m, "0e") for m, _ in gated]).simplify() if gated.dim > 0 else Irreps([])
+    return scalars, gates, gated, [ACTS[act_scalars[ir.p]] for _, ir in scalars], [ACTS[act_gates[ir.p]] for _, ir in gates]
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, irreps_in, feature_irreps_hidden, resnet=True):
+        super().__init__()
+        s, g, gd, a_s, a_g = irreps2gate(feature_irreps_hidden)
+        self.equivariant_nonlin = Gate(s, a_s, g, a_g, gd)
+        self.linear1 = Linear(irreps_in, self.equivariant_nonlin.irreps_in)
+        self.linear2 = Linear(self.equivariant_nonlin.irreps_out, irreps_in)
+        self.resnet = resnet
+
+    def forward(self, x):
+        y = self.linear2(self.equivariant_nonlin(self.linear1(x)))
+        return x + y if self.resnet else y
+
+
+# ---------------------------------------------------------------------------------------------- backbone blocks
+
+
+class ConvBlockE3(nn.Module):
+    def __init__(self, irreps_in, irreps_out, irreps_edge_attrs, irreps_edge_embed, radial_MLP, lite_mode=False):
+        super().__init__()
+        self.residual = ResidualBlock(irreps_in, irreps_out)
+        self.conv_tp = MessagePackBlock(irreps_in, irreps_in, irreps_edge_attrs, irreps_out, irreps_edge_embed, radial_MLP, lite_mode)
+        self.skip_linear = Linear(irreps_in, irreps_out)
+
+    def forward(self, g):
+        sender, receiver = g["edge_index"]
+        x = g["node_features"]
+        skip = self.skip_linear(x)
+        msg = self.conv_tp(x[sender], x[receiver], g["edge_features"], g["edge_attrs"], g["edge_embedding"])
+        agg = scatter_sum(msg, receiver, x.shape[0])
+        g["node_features"] = self.residual(agg) + skip
+        return g["node_features"]
+
+
+class PairInteractionBlock(nn.Module):
+    def __init__(self, irreps_node_feats, irreps_edge_attrs, irreps_edge_embed, irreps_edge_feats, radial_MLP,
+                 use_skip_connections=True, legacy_edge_update=False, lite_mode=False):
+        super().__init__()
+        self.use_skip_connections, self.legacy_edge_update = use_skip_connections, legacy_edge_update
+        self.linear_up_src = Linear(irreps_node_feats, irreps_node_feats)
+        self.linear_up_tar = Linear(irreps_node_feats, irreps_node_feats)
+        self.conv_tp = MessagePackBlock(irreps_node_feats, irreps_edge_feats, irreps_edge_attrs, irreps_edge_feats,
+                                        irreps_edge_embed, radial_MLP, lite_mode)
+        if use_skip_connections:
+            self.skip_linear = Linear(irreps_edge_feats, irreps_edge_feats)
+
+    def forward(self, g):
+        src, dst = g["edge_index"]
+        x, f = g["node_features"], g["edge_features"]
+        mix = self.conv_tp(self.linear_up_src(x)[src], self.linear_up_tar(x)[dst], f, g["edge_attrs"], g["edge_embedding"])
+        if self.use_skip_connections:
+            f = mix + self.skip_linear(f)
+        elif not self.legacy_edge_update:
+            f = mix
+        g["edge_features"] = f
+        return f
+
+
+class PairInteractionEmbeddingBlock(nn.Module):
+    def __init__(self, irreps_node_attrs, irreps_edge_attrs, irreps_edge_embed, irreps_edge_feats, radial_MLP, lite_mode=False):
+        super().__init__()
+        self.linear_up_src = Linear(irreps_node_attrs, irreps_node_attrs)
+        self.linear_up_dst = Linear(irreps_node_attrs, irreps_node_attrs)
+        self.conv_tp = RadialTensorProduct(irreps_node_attrs, irreps_edge_attrs, irreps_edge_feats, irreps_edge_embed, radial_MLP, lite_mode)
+
+    def forward(self, g):
+        src, dst = g["edge_index"]
+        a = g["node_features"]
+        x = self.linear_up_src(a[src]) + self.linear_up_dst(a[dst])
+        g["edge_features"] = self.conv_tp(x, g["edge_attrs"], g["edge_embedding"])
+        return g["edge_features"]
+
+
+class _Holder(nn.Module):
+    pass
+
+
+def edge_geometry(pos, edge_index, nbr_shift, irreps_sh, cutoff, num_radial, sh_normalize=True, sh_normalization="component"):
+    """edge_attrs (SH of v[[1,2,0]]), edge_embedding (Bessel * cosine cutoff), lengths.  j = row 0, i = row 1."""
+    j, i = edge_index
+    vec = (pos[i] + nbr_shift) - pos[j]
+    unit = torch.nn.functional.normalize(vec, dim=-1)
+    sh = e3.spherical_harmonics(Irreps(irreps_sh).ls, unit[:, [1, 2, 0]], sh_normalize, sh_normalization)
+    r = vec.norm(dim=-1)
+    freqs = torch.arange(1, num_radial + 1, dtype=pos.dtype) * math.pi / cutoff
+    rbf = torch.sin(r[:, None] * freqs[None, :]) / r[:, None]
+    fc = 0.5 * (torch.cos(r * math.pi / cutoff) + 1.0) * (r < cutoff).to(pos.dtype)
+    return sh, rbf * fc[:, None], r
+
+
+class HamGNNConvE3(nn.Module):
+    """cfg: mapping/namespace with the reference's HamGNN_pre keys (hamgnn/models/hamgnn_conv.py:89-147)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        c = cfg if isinstance(cfg, dict) else vars(cfg)
+        c = c.get("HamGNN_pre", c)
+        self.num_types = c["num_types"]
+        self.irreps_edge_sh = Irreps(c["irreps_edge_sh"])
+        self.cutoff, self.num_radial, self.num_layers = float(c["cutoff"]), c["num_radial"], c["num_layers"]
+        self.sh_normalization = c.get("edge_sh_normalization", "component")
+        self.sh_normalize = c.get("edge_sh_normalize", True)
+        self.irreps_node_features = Irreps(c["irreps_node_features"])
+        self.legacy_edge_update = c.get("legacy_edge_update", False)
+        self.lite_mode = c.get("lite_mode", False)
+        assert c.get("rbf_func", "bessel").lower() == "bessel" and not c.get("use_kan", False)
+        assert not c.get("use_corr_prod", False) and not c.get("build_internal_graph", False)
+        mlp = list(c["radial_MLP"])
+        attrs = Irreps([(self.num_types, (0, 1))])
+        emb = Irreps([(self.num_radial, (0, 1))])
+        D = self.irreps_node_features
+        self.pair_embedding = PairInteractionEmbeddingBlock(attrs, self.irreps_edge_sh, emb, D, mlp, self.lite_mode)
+        self.chemical_embedding = _Holder()
+        self.chemical_embedding.linear = Linear(attrs, D)
+        self.convolutions = nn.ModuleList()
+        self.pair_interactions = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.convolutions.append(ConvBlockE3(D, D, self.irreps_edge_sh, emb, mlp, self.lite_mode))
+            skip = (i > 0) if self.legacy_edge_update else True
+            self.pair_interactions.append(PairInteractionBlock(D, self.irreps_edge_sh, emb, D, mlp, skip, self.legacy_edge_update, self.lite_mode))
+
+    def forward(self, data):
+        dtype = self.chemical_embedding.linear.weight.dtype
+        g = {"edge_index": data.edge_index}
+        one_hot = torch.nn.functional.one_hot(data.z, self.num_types).to(dtype)
+        g["node_attrs"] = g["node_features"] = one_hot
+        sh, rbf, r = edge_geometry(data.pos.to(dtype), data.edge_index, data.nbr_shift.to(dtype), self.irreps_edge_sh, self.cutoff,
+                                   self.num_radial, self.sh_normalize, self.sh_normalization)
+        g["edge_attrs"], g["edge_embedding"] = sh, rbf
+        self.pair_embedding(g)
+        g["node_features"] = self.chemical_embedding.linear(g["node_features"])
+        for conv, pair in zip(self.convolutions, self.pair_interactions):
+            conv(g)
+            pair(g)
+        return {"node_attr": g["node_features"], "edge_attr": g["edge_features"]}
+
+
+# ---------------------------------------------------------------------------------------------- read-out head
+
+
+def load_basis_tables():
+    """Basis tables extracted (as data) from the reference by oracle/gen_golden.py -> tests/golden/basis_tables.json."""
+    with open(os.path.join(_GOLDEN, "basis_tables.json")) as f:
+        return json.load(f)
+
+
+class HamLayer(nn.Module):
+    def __init__(self, irreps_in, irreps_out):
+        super().__init__()
+        self.residual_block = ResidualBlock(irreps_in, irreps_in)
+        self.linear_transform = Linear(irreps_in, irreps_out)
+
+    def forward(self, x):
+        return self.linear_transform(self.residual_block(x))
+
+
+class HamGNNPlusPlusOut(nn.Module):
+    """Non-SOC branch and SOC/so3 branch of the reference head; ham_only=True; band/k-space code out of scope."""
+
+    def __init__(self, irreps_in_node, irreps_in_edge, nao_max=19, ham_type="openmx", symmetrize=True, add_H0=True,
+                 soc_switch=False, soc_basis="so3", add_H_nonsoc=False, zero_point_shift=False):
+        super().__init__()
+        self.nao_max, self.ham_type = nao_max, ham_type.lower()
+        self.symmetrize, self.add_H0, self.soc_switch, self.add_H_nonsoc = symmetrize, add_H0, soc_switch, add_H_nonsoc
+        self.zero_point_shift = zero_point_shift
+        self.soc_basis = soc_basis.lower() if self.ham_type == "openmx" or not soc_switch else "su2"
+        assert not soc_switch or self.soc_basis == "so3", "oracle covers so3 only"
+        t = load_basis_tables()[f"{self.ham_type}_{nao_max}"]
+        self.row = self.col = Irreps(t["row"])
+        self.index_change = torch.tensor(t["index_change"]) if t["index_change"] is not None else None
+        self.minus_index = torch.tensor(t["minus_index"]) if t.get("minus_index") is not None else None
+        self.basis_def = {int(k): v for k, v in t["basis_def"].items()}
+        irr = Irreps([])
+        for _, li in self.row:
+            for _, lj in self.col:
+                for L in range(abs(li.l - lj.l), li.l + lj.l + 1):
+                    irr = irr + Irrep(L, (-1) ** (li.l + lj.l))
+        self.hamiltonian_irreps = irr
+        self.onsite_hamiltonian_network = HamLayer(irreps_in_node, irr)
+        self.offsite_hamiltonian_network = HamLayer(irreps_in_edge, irr)
+        if soc_switch:
+            ksi = Irreps([(nao_max ** 2, (0, 1))])
+            self.onsite_ksi_network = HamLayer(irreps_in_node, ksi)
+            self.offsite_ksi_network = HamLayer(irreps_in_edge, ksi)
+
+    # -- pieces
+    def merge_tensor_components(self, coeff):
+        Z = coeff.shape[0]
+        H = coeff.new_zeros(Z, self.nao_max, self.nao_max)
+        off, r0 = 0, 0
+        for _, li in self.row:
+            c0 = 0
+            for _, lj in self.col:
+                for L in range(abs(li.l - lj.l), li.l + lj.l + 1):
+                    cg = math.sqrt(2 * L + 1) * e3.wigner_3j(li.l, lj.l, L, dtype=coeff.dtype)
+                    H[:, r0:r0 + li.dim, c0:c0 + lj.dim] += torch.einsum("abm,zm->zab", cg, coeff[:, off:off + 2 * L + 1])
+                    off += 2 * L + 1
+                c0 += lj.dim
+            r0 += li.dim
+        return H.reshape(Z, -1)
+
+    def reorder_matrix(self, M):
+        M = M.reshape(-1, self.nao_max, self.nao_max)
+        if self.index_change is not None:
+            M = M[:, self.index_change[:, None], self.index_change[None, :]]
+        if self.minus_index is not None:
+            M = M.clone()
+            M[:, self.minus_index, :] = -M[:, self.minus_index, :]
+            M[:, :, self.minus_index] = -M[:, :, self.minus_index]
+        return M.reshape(-1, self.nao_max ** 2)
+
+    def _sym(self, M, inv=None, sign=1.0, dim=None):
+        if not self.symmetrize:
+            return M
+        d = dim or self.nao_max
+        A = M.reshape(-1, d, d)
+        B = (A if inv is None else A[inv]).transpose(1, 2)
+        return (0.5 * (A + sign * B)).reshape(-1, d * d)
+
+    def orbital_mask(self, z, edge_index):
+        table = torch.zeros(99, self.nao_max, dtype=torch.float64)
+        for Z, idx in self.basis_def.items():
+            table[Z, idx] = 1
+        m = table[z]
+        src, dst = edge_index
+        on = (m[:, :, None] * m[:, None, :]).reshape(-1, self.nao_max ** 2)
+        off = (m[src][:, :, None] * m[dst][:, None, :]).reshape(-1, self.nao_max ** 2)
+        return on, off
+
+    def ksi_average(self, ksi):
+        """symmetrize_orbital_coefficients (hamgnn_output.py:2367-2431): mean over each (row shell, col shell) block."""
+        K = ksi.reshape(-1, self.nao_max, self.nao_max).clone()
+        r0 = 0
+        for _, li in self.row:
+            c0 = 0
+            for _, lj in self.col:
+                blk = K[:, r0:r0 + li.dim, c0:c0 + lj.dim]
+                K[:, r0:r0 + li.dim, c0:c0 + lj.dim] = blk.mean(dim=(1, 2), keepdim=True).expand_as(blk)
+                c0 += lj.dim
+            r0 += li.dim
+        return K.reshape(-1, self.nao_max ** 2)
+
+    @staticmethod
+    def global_inverse_edges(data):
+        src = data.edge_index[0]
+        if getattr(data, "batch", None) is None:
+            return data.inv_edge_idx
+        b = data.batch[src]
+        counts = scatter_sum(torch.ones_like(src), b, int(data.batch.max()) + 1)
+        offs = torch.cumsum(counts, 0) - counts
+        return data.inv_edge_idx + offs[b]
+
+    @staticmethod
+    def cat_by_crystal(data, on, off):
+        if getattr(data, "batch", None) is None or int(data.batch.max()) == 0:
+            return torch.cat([on, off], 0)
+        src = data.edge_index[0]
+        nG = int(data.batch.max()) + 1
+        nn_ = scatter_sum(torch.ones_like(data.batch), data.batch, nG).tolist()
+        ne = scatter_sum(torch.ones_like(src), data.batch[src], nG).tolist()
+        out = []
+        for a, b in zip(torch.split(on, nn_), torch.split(off, ne)):
+            out += [a, b]
+        return torch.cat(out, 0)
+
+    def forward(self, data, rep):
+        node_attr, edge_attr = rep["node_attr"], rep["edge_attr"]
+        for Z in data.z.unique().tolist():
+            if Z not in self.basis_def:
+                raise ValueError(f"element Z={Z} missing from basis_def")
+        inv = self.global_inverse_edges(data)
+        on = self._sym(self.reorder_matrix(self.merge_tensor_components(self.onsite_hamiltonian_network(node_attr))))
+        off = self._sym(self.reorder_matrix(self.merge_tensor_components(self.offsite_hamiltonian_network(edge_attr))), inv)
+        m_on, m_off = self.orbital_mask(data.z, data.edge_index)
+        m_on, m_off = m_on.to(on.dtype), m_off.to(on.dtype)
+        if not self.soc_switch:
+            if self.add_H0:
+                on, off = on + data.Hon0, off + data.Hoff0
+            on, off = on * m_on, off * m_off
+            H = self.cat_by_crystal(data, on, off)
+            if self.zero_point_shift:
+                S = self.cat_by_crystal(data, data.Son, data.Soff)
+                Href = self.cat_by_crystal(data, data.Hon, data.Hoff)
+                sel = S > 1e-6
+                H = H - ((H - Href)[sel].sum() / S[sel].sum()) * S
+            return {"hamiltonian": H, "H_on": on, "H_off": off}
+        # ---- SOC / so3 (hamgnn_output.py:3026-3144, 3603-3625)
+        n = self.nao_max
+        Hon0, Hoff0 = data.Hon0, data.Hoff0
+        if self.add_H_nonsoc:
+            on, off = data.Hon_nonsoc, data.Hoff_nonsoc
+
+            def zero_diag(h0):
+                h0 = h0.reshape(-1, 2 * n, 2 * n).clone()
+                h0[:, :n, :n] = 0
+                h0[:, n:, n:] = 0
+                return h0.reshape(-1, (2 * n) ** 2)
+            Hon0, Hoff0 = zero_diag(Hon0), zero_diag(Hoff0)
+        else:
+            on, off = on * m_on, off * m_off
+        ksi_on = self.ksi_average(self.onsite_ksi_network(node_attr))
+        ksi_off = self.ksi_average(self.offsite_ksi_network(edge_attr))
+
+        def spin_blocks(h, ksi, L, inv_):
+            A = lambda k: self._sym(ksi * L[:, :, k], inv_, -1.0).reshape(-1, n, n)
+            h3 = h.reshape(-1, n, n)
+            real = h.new_zeros(h3.shape[0], 2 * n, 2 * n)
+            imag = h.new_zeros(h3.shape[0], 2 * n, 2 * n)
+            real[:, :n, :n] = h3
+            real[:, n:, n:] = h3
+            real[:, :n, n:] = A(1)
+            real[:, n:, :n] = A(1)
+            imag[:, :n, :n] = A(2)
+            imag[:, n:, n:] = -A(2)
+            imag[:, :n, n:] = A(0)
+            imag[:, n:, :n] = -A(0)
+            return real.reshape(-1, (2 * n) ** 2), imag.reshape(-1, (2 * n) ** 2)
+
+        on_r, on_i = spin_blocks(on, ksi_on, data.Lon, None)
+        off_r, off_i = spin_blocks(off, ksi_off, data.Loff, inv)
+        if self.add_H0:
+            on_r, off_r = on_r + Hon0, off_r + Hoff0
+            on_i, off_i = on_i + data.iHon0, off_i + data.iHoff0
+        Hr, Hi = self.cat_by_crystal(data, on_r, off_r), self.cat_by_crystal(data, on_i, off_i)
+        return {"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi}
