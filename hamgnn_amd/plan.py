@@ -1,0 +1,386 @@
+"""Plan builder for the fused edge kernel (host side, numpy; PRODUCT code -- never imports oracle/).
+
+Turns the reference's modules/parameters (flat e3nn weight layouts, reference names) into the data the HIP kernel
+``hg_tp_fused`` (csrc/tp_fused.hip) executes:
+
+  * a *planar* feature layout: per irrep (mul, l, p) a block [2l+1][mulp] with mulp = ceil4(mul); channel index fastest,
+  * SEGMENTS (one per output irrep) and ITEMS (one per (input irrep, output irrep) super-path row chunk), and
+  * one flat fp32 weight buffer holding, for every item, operands already in MFMA 16x16x4-f32 *fragment order*:
+        A1  [nsrc][ksteps][rtm][64]   uvw weights * path coefficient                (GEMM1: rows = stacked (l_sh, w) channels)
+        W3  [hsteps][rtm][64]         last radial-MLP layer columns of those rows   (per-edge scale via MFMA)
+        CF  [rtm][nc][4][4]           aligned-frame CG coefficient per (row, m)
+        A2  [rto][rtm][4][64]         Linear(mid->out) folded with the trailing o3.Linear(out->out)   (GEMM2)
+
+Math (per edge, edge-aligned frame, see hamgnn_amd/so3.py): for a path p=(i, l_sh, k) of the reference's uvw tensor
+product (hamgnn/nn/message_passing.py:136-171) followed by LinearScaleWithWeights (tensor_products.py:25-47) and the
+out linear (message_passing.py:133-134, 229):
+    out'_k[w'', m] += sum_w L'_k[(p,w), w''] * s_e[(p,w)] * coef_p[m] * sum_u (c_p W_p[u,w]) x'_i[u, src_p(m)]
+MFMA lane conventions (v_mfma_f32_16x16x4_f32):  A[i = lane&15][k = lane>>4],  B[k = lane>>4][j = lane&15],
+C/D: col = lane&15, row = 4*(lane>>4) + reg.  Edges are the MFMA *columns*; channels are rows; results chain
+GEMM1 -> scale -> GEMM2 without any cross-lane movement (C regs feed the next B operand with a permuted K order).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import so3
+from .so3 import Irreps
+
+# item types
+IT_TP = 0        # GEMM1 -> radial scale * CG coef -> GEMM2 -> add into segment tile
+IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, add into tile
+# segment flags
+SEG_UNROTATE = 1     # epilogue applies D^l(R_e)^T (messages go back to the global frame before the node scatter)
+
+ITEM_I32 = 20        # int32 words per item record
+SEG_I32 = 8          # int32 words per segment record
+MAX_SRC = 4
+
+
+def ceil_div(a, b):
+    return -(-a // b)
+
+
+def rtm_max(nc):
+    return 4 if nc <= 3 else 2
+
+
+class PlanarLayout:
+    def __init__(self, irreps):
+        self.irreps = Irreps(irreps)
+        self.off, self.mulp = [], []
+        o = 0
+        for mul, l, p in self.irreps:
+            mp = ceil_div(mul, 4) * 4
+            self.off.append(o)
+            self.mulp.append(mp)
+            o += (2 * l + 1) * mp
+        self.dim = o
+
+    def index_map(self):
+        """planar index of every e3nn-layout element: e3nn flat index -> planar flat index."""
+        idx = np.zeros(self.irreps.dim, dtype=np.int64)
+        e = 0
+        for (mul, l, p), off, mp in zip(self.irreps, self.off, self.mulp):
+            for u in range(mul):
+                for a in range(2 * l + 1):
+                    idx[e] = off + a * mp + u
+                    e += 1
+        return idx
+
+    def to_planar(self, x):
+        out = np.zeros(x.shape[:-1] + (self.dim,), dtype=x.dtype)
+        out[..., self.index_map()] = x
+        return out
+
+    def from_planar(self, xp):
+        return xp[..., self.index_map()]
+
+
+def wigner_offsets(lmax):
+    offs, o = [], 0
+    for l in range(lmax + 1):
+        offs.append(o)
+        o += (2 * l + 1) ** 2
+    return offs, o
+
+
+# ------------------------------------------------------------------------------------------------ instruction tables
+
+
+def tp_instructions(irreps1: Irreps, irreps2: Irreps, target: Irreps):
+    """Reference rule (message_passing.py:147-171): one uvw path per (i, j, target entry with ir in ir_i x ir_j); output
+    slots stably sorted by irrep; instructions re-ordered by sorted slot.  Returns list of (i, j, k_target, slot)."""
+    slots, ins = [], []
+    for i, (mi, li, pi) in enumerate(irreps1):
+        for j, (_, lj, pj) in enumerate(irreps2):
+            for k, (mk, lk, pk) in enumerate(target):
+                if pk == pi * pj and abs(li - lj) <= lk <= li + lj:
+                    ins.append((i, j, k, len(slots)))
+                    slots.append((mk, lk, pk))
+    _, perm = Irreps(slots).sort()
+    ins = sorted([(i, j, k, perm[s]) for i, j, k, s in ins], key=lambda t: t[3])
+    return ins
+
+
+# ------------------------------------------------------------------------------------------------ program container
+
+
+@dataclass
+class Program:
+    out_layout: PlanarLayout
+    hidden: int = 0                                   # radial hidden width H (multiple of 4) or 0
+    segs: List[List[int]] = field(default_factory=list)
+    seg_items: List[List[List[int]]] = field(default_factory=list)    # per segment: item records (kept contiguous per segment)
+    chunks: List[np.ndarray] = field(default_factory=list)
+    _woff: int = 0
+    tile_floats: int = 0                              # max LDS tile floats per 64 edges (for launch config)
+    flops_per_row: float = 0.0                        # algorithmic (unpadded) flops per edge/row
+    mfma_per_wave: int = 0                            # issued MFMAs per 16-row wave tile (padded)
+
+    def add_weights(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        off = self._woff
+        self.chunks.append(arr)
+        self._woff += arr.size
+        pad = (-self._woff) % 4                       # keep 16-byte alignment of every operand block
+        if pad:
+            self.chunks.append(np.zeros(pad, np.float32))
+            self._woff += pad
+        return off
+
+    def finalize(self):
+        self.weights = np.concatenate(self.chunks) if self.chunks else np.zeros(4, np.float32)
+        items = []
+        for seg, lst in zip(self.segs, self.seg_items):
+            seg[5] = len(items)
+            items += lst
+            seg[6] = len(items)
+        self.seg_table = np.asarray(self.segs, dtype=np.int32).reshape(-1, SEG_I32)
+        self.item_table = np.asarray(items, dtype=np.int32).reshape(-1, ITEM_I32)
+        del self.chunks
+        return self
+
+
+def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int) -> np.ndarray:
+    """mat[k, row] -> fragments [ksteps][rtm][64], lane L holds mat[4s + (L>>4)][16 rt + (L&15)] (zero padded)."""
+    K, Rr = mat_kxr.shape
+    P = np.zeros((ksteps * 4, rtm * 16), dtype=np.float64)
+    P[:K, :Rr] = mat_kxr
+    # [s, g, rt, r] -> [s, rt, g, r]
+    return P.reshape(ksteps, 4, rtm, 16).transpose(0, 2, 1, 3).reshape(ksteps, rtm, 64)
+
+
+def _add_segment(prog: Program, lk, mul_k, out_index, flags):
+    lay = prog.out_layout
+    rto = ceil_div(mul_k, 16)
+    prog.segs.append([lk, mul_k, rto, lay.off[out_index], lay.mulp[out_index], 0, 0, flags])
+    prog.seg_items.append([])
+    prog.tile_floats = max(prog.tile_floats, rto * 16 * ((2 * lk + 1) * 64 + 4))
+    return len(prog.segs) - 1
+
+
+def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0):
+    assert len(srcs) in (1, 2)
+    rec = [typ, srcs[0], srcs[1] if len(srcs) == 2 else -1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp,
+           a1, w3, cf, a2, nrows, row_off, 0, 0, 0]
+    assert len(rec) == ITEM_I32
+    prog.seg_items[seg].append(rec)
+    nc = 2 * mm + 1
+    rto = prog.segs[seg][2]
+    n = len(srcs) * ksteps * rtm * nc
+    if typ == IT_TP:
+        n += (prog.hidden // 4) * rtm + rto * rtm * 4 * nc
+    prog.mfma_per_wave += n
+
+
+# ------------------------------------------------------------------------------------------------ builders
+
+
+def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
+                 irreps_sh: Irreps, irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray,
+                 lin_out_w: Optional[np.ndarray], mlp: int):
+    """Items of ONE reference tensor-product branch (node or edge) of a MessagePackBlock / embedding TP.
+
+    in_layout : planar layout of ONE source row (irreps of the un-doubled features); nsrc = 2 for the node branch
+                (reference input = (2 mul) x ir with the first mul channels from src, the rest from dst: attention_utils.py:85-119).
+    tp_weight : flat o3.TensorProduct.weight;  w3: last radial layer [H, n_chan] already divided by sqrt(H);
+    lin_scale_w: flat LinearScaleWithWeights.linear_out.weight;  lin_out_w: flat trailing o3.Linear(out->out) or None.
+    """
+    irr_in = Irreps([(m * nsrc, l, p) for m, l, p in in_layout.irreps])
+    ins = tp_instructions(irr_in, irreps_sh, irreps_out)
+    # flat TP weight offsets follow the instruction (slot) order; radial channels follow the sorted mid layout
+    woff, choff = [], []
+    wo = co = 0
+    for (i, j, k, slot) in ins:
+        woff.append(wo)
+        choff.append(co)
+        wo += irr_in[i][0] * irreps_out[k][0]
+        co += irreps_out[k][0]
+    assert wo == tp_weight.size, (wo, tp_weight.size)
+    assert co == w3.shape[1], (co, w3.shape)
+    # Linear(mid.simplify() -> irreps_out): simplified mid has one entry per distinct out irrep, in sorted order
+    irs = [(l, p) for _, l, p in irreps_out]
+    assert len(set(irs)) == len(irs), "duplicate irreps in the TP target are not supported by the planner"
+    by_k: Dict[int, List[int]] = {}
+    for n, (i, j, k, slot) in enumerate(ins):
+        by_k.setdefault(k, []).append(n)
+    # weight offsets of the Linear blocks: paths ordered by (i_in over sorted simplified mid, i_out)
+    order = sorted(by_k, key=lambda k: ((irreps_out[k][1], irreps_out[k][2]), k))
+    lin_off, lo = {}, 0
+    for k in order:
+        fan = sum(irreps_out[k][0] for _ in by_k[k])
+        lin_off[k] = (lo, fan)
+        lo += fan * irreps_out[k][0]
+    assert lo == lin_scale_w.size, (lo, lin_scale_w.size)
+    lo_off, o = {}, 0
+    for k, (mk, lk, pk) in enumerate(irreps_out):                       # o3.Linear(out->out): one path per irrep
+        lo_off[k] = o
+        o += mk * mk
+    if lin_out_w is not None:
+        assert o == lin_out_w.size
+
+    H = prog.hidden
+    for k in order:
+        mk, lk, pk = irreps_out[k]
+        seg = seg_of_k[k]
+        off, fan = lin_off[k]
+        L = lin_scale_w[off:off + fan * mk].reshape(fan, mk).astype(np.float64) / math.sqrt(fan)
+        if lin_out_w is not None:
+            Lo = lin_out_w[lo_off[k]:lo_off[k] + mk * mk].reshape(mk, mk).astype(np.float64) / math.sqrt(mk)
+            L = L @ Lo
+        ch0 = choff[by_k[k][0]]
+        # group the paths into k by input irrep i  (super-path (i,k): all l_sh stacked along rows)
+        by_i: Dict[int, List[int]] = {}
+        for n in by_k[k]:
+            by_i.setdefault(ins[n][0], []).append(n)
+        for i, plist in by_i.items():
+            mi2, li, pi = irr_in[i]
+            mi = mi2 // nsrc
+            mm = min(li, lk)
+            nc = 2 * mm + 1
+            par = None
+            rows_W, rows_ch, rows_cf, rows_L = [], [], [], []
+            for n in plist:
+                _, j, _, _ = ins[n]
+                lj = irreps_sh[j][1]
+                src_c, coef_c = so3.aligned_path(li, lj, lk)
+                this_par = (li + lj + lk) % 2
+                assert par is None or par == this_par
+                par = this_par
+                cpath = math.sqrt((2 * lk + 1) / (mi2 * irreps_sh[j][0]))
+                W = tp_weight[woff[n]:woff[n] + mi2 * mk].reshape(mi2, mk).astype(np.float64) * cpath
+                cf = np.array([coef_c[lk + m] for m in range(-mm, mm + 1)])
+                for w in range(mk):
+                    rows_W.append(W[:, w])
+                    rows_ch.append(choff[n] + w)
+                    rows_cf.append(cf)
+                    rows_L.append(L[choff[n] - ch0 + w])
+                prog.flops_per_row += 2.0 * mi2 * mk * nc + 2.0 * H * mk + 2.0 * mk * mk * nc + 2.0 * mk * nc
+            rows_W, rows_cf, rows_L = np.array(rows_W), np.array(rows_cf), np.array(rows_L)
+            nrows = len(rows_ch)
+            chunk = rtm_max(nc) * 16
+            ksteps = in_layout.mulp[i] // 4
+            for r0 in range(0, nrows, chunk):
+                r1 = min(nrows, r0 + chunk)
+                rtm = ceil_div(r1 - r0, 16)
+                a1 = []
+                for s_ in range(nsrc):
+                    Wk = rows_W[r0:r1, s_ * mi:(s_ + 1) * mi].T                      # [u, row]
+                    a1.append(_frag_A(Wk, ksteps, rtm))
+                a1_off = prog.add_weights(np.stack(a1))
+                w3_off = prog.add_weights(_frag_A(w3[:, rows_ch[r0:r1]], H // 4, rtm))
+                cfp = np.zeros((rtm * 16, nc))
+                cfp[:r1 - r0] = rows_cf[r0:r1]
+                cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))       # [rt][c][g][r]
+                rto = prog.segs[seg][2]
+                Lp = np.zeros((rtm * 16, rto * 16))
+                Lp[:r1 - r0, :mk] = rows_L[r0:r1]
+                # A2[rt'][rt][r][lane]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
+                a2 = Lp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 2, 1, 4).reshape(rto, rtm, 4, 64)
+                a2_off = prog.add_weights(a2)
+                _add_item(prog, seg, IT_TP, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, par, ksteps, rtm, mlp,
+                          a1_off, w3_off, cf_off, a2_off, r1 - r0)
+
+
+def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, src: int, irreps_out: Irreps,
+                     weight: np.ndarray, extra_scale: float = 1.0):
+    """Items of one o3.Linear(irreps_in -> irreps_out) (e3nn: paths ordered by (i_in, i_out), 1/sqrt(fan_in))."""
+    irr_in = in_layout.irreps
+    paths = [(i, k) for i, (_, li, pi) in enumerate(irr_in) for k, (_, lk, pk) in enumerate(irreps_out) if (li, pi) == (lk, pk)]
+    fan = {}
+    for i, k in paths:
+        fan[k] = fan.get(k, 0) + irr_in[i][0]
+    off = 0
+    for i, k in paths:
+        mi, li, _ = irr_in[i]
+        mk = irreps_out[k][0]
+        W = weight[off:off + mi * mk].reshape(mi, mk).astype(np.float64) * (extra_scale / math.sqrt(fan[k]))
+        off += mi * mk
+        seg = seg_of_k[k]
+        rto = prog.segs[seg][2]
+        ksteps = in_layout.mulp[i] // 4
+        # rows chunked like TP items so that the per-wave register budget is the same
+        nc = 2 * li + 1
+        chunk = rtm_max(nc) * 16
+        for r0 in range(0, mk, chunk):
+            r1 = min(mk, r0 + chunk)
+            rtm = ceil_div(r1 - r0, 16)
+            a1_off = prog.add_weights(_frag_A(W[:, r0:r1], ksteps, rtm)[None])
+            _add_item(prog, seg, IT_LIN, [src], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0,
+                      a1_off, 0, 0, 0, r1 - r0, row_off=r0)
+        prog.flops_per_row += 2.0 * mi * mk * nc
+    assert off == weight.size, (off, weight.size)
+
+
+def new_program(irreps_out, hidden=0, flags_of=lambda k, ir: 0) -> Tuple[Program, Dict[int, int]]:
+    lay = PlanarLayout(irreps_out)
+    prog = Program(out_layout=lay, hidden=hidden)
+    seg_of_k = {}
+    for k, (mk, lk, pk) in enumerate(lay.irreps):
+        seg_of_k[k] = _add_segment(prog, lk, mk, k, flags_of(k, (mk, lk, pk)))
+    return prog, seg_of_k
+
+
+# ------------------------------------------------------------------------------------------------ high-level builders
+
+SRC_XS, SRC_XD, SRC_F = 0, 1, 2          # source slots of the fused kernel: rotated src-node rows, dst-node rows, edge rows
+
+
+def _last_layer(sd, prefix):
+    ks = sorted(k for k in sd if k.startswith(prefix + ".layer") and k.endswith(".weight"))
+    return ks, np.asarray(sd[ks[-1]], dtype=np.float64)
+
+
+def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool,
+                               skip_weight: Optional[np.ndarray] = None) -> Program:
+    """MessagePackBlock (non-lite, message_passing.py:216-229) [+ the PairInteractionBlock skip o3.Linear on the edge
+    features, interaction_blocks.py:151-152] as ONE fused-kernel program.  `sd`: reference-named arrays of the block."""
+    irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
+    _, w3n = _last_layer(sd, "node_weight_generator")
+    _, w3e = _last_layer(sd, "edge_weight_generator")
+    H = w3n.shape[0]
+    assert H % 4 == 0 and w3e.shape[0] == H
+    prog, seg_of_k = new_program(irreps_out, H, lambda k, ir: SEG_UNROTATE if unrotate else 0)
+    add_tp_items(prog, seg_of_k, PlanarLayout(irreps_node), 2, [SRC_XS, SRC_XD], irreps_sh, irreps_out,
+                 np.asarray(sd["node_tensor_product.weight"]), w3n / math.sqrt(H),
+                 np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]), mlp=0)
+    add_tp_items(prog, seg_of_k, PlanarLayout(irreps_edge), 1, [SRC_F], irreps_sh, irreps_out,
+                 np.asarray(sd["edge_tensor_product.weight"]), w3e / math.sqrt(H),
+                 np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]), mlp=1)
+    if skip_weight is not None:
+        add_linear_items(prog, seg_of_k, PlanarLayout(irreps_edge), SRC_F, irreps_out, np.asarray(skip_weight))
+    return prog.finalize()
+
+
+def build_embedding_program(sd: Dict[str, np.ndarray], num_types, irreps_sh, irreps_out) -> Program:
+    """PairInteractionEmbeddingBlock.conv_tp (embeddings.py:328-334, tensor_products.py:170-189): source slot 0 holds
+    x = Lin_src(onehot[src]) + Lin_dst(onehot[dst])  (num_types x 0e; identical in every frame)."""
+    irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
+    _, w3 = _last_layer(sd, "weight_generator")
+    H = w3.shape[0]
+    prog, seg_of_k = new_program(irreps_out, H)
+    add_tp_items(prog, seg_of_k, PlanarLayout([(num_types, 0, 1)]), 1, [SRC_XS], irreps_sh, irreps_out,
+                 np.asarray(sd["tensor_product.weight"]), w3 / math.sqrt(H), np.asarray(sd["linear_scaler.linear_out.weight"]), None, mlp=0)
+    return prog.finalize()
+
+
+def build_linear_program(weight: np.ndarray, irreps_in, irreps_out) -> Program:
+    irreps_in, irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+    prog, seg_of_k = new_program(irreps_out, 0)
+    add_linear_items(prog, seg_of_k, PlanarLayout(irreps_in), 0, irreps_out, np.asarray(weight))
+    return prog.finalize()
+
+
+def radial_hidden_weights(sd: Dict[str, np.ndarray], prefix: str, act_cst: float):
+    """All but the last layer of an e3nn FullyConnectedNet, with 1/sqrt(h_in) folded in.  Returns [(W [h_in,h_out])...]."""
+    ks, _ = _last_layer(sd, prefix)
+    out = []
+    for k in ks[:-1]:
+        W = np.asarray(sd[k], dtype=np.float64)
+        out.append((W / math.sqrt(W.shape[0])).astype(np.float32))
+    return out

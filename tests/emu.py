@@ -1,0 +1,107 @@
+"""Numpy emulator of the device algorithms, consuming EXACTLY the packed buffers/tables hamgnn_amd/plan.py hands to the
+HIP kernels (MFMA fragment order, segment/item records).  Dev/test tool: lets the CPU suite validate the planner and
+the kernel algorithm against the oracle without a GPU.  The HIP kernels in hamgnn_amd/csrc mirror these loops."""
+import math
+
+import numpy as np
+
+from hamgnn_amd import plan as P
+from hamgnn_amd import so3
+
+SILU_CST = 1.6791767923989418
+
+
+def edge_wigner_all(n, lmax):
+    """[E, sum (2l+1)^2] packed D^l(R_e), l = 0..lmax (row-major per l)."""
+    offs, tot = P.wigner_offsets(lmax)
+    out = np.zeros((n.shape[0], tot))
+    for e in range(n.shape[0]):
+        for l in range(lmax + 1):
+            out[e, offs[l]:offs[l] + (2 * l + 1) ** 2] = so3.edge_wigner(l, n[e]).reshape(-1)
+    return out
+
+
+def rotate_rows(xp, layout, D, lmax, transpose=False):
+    """x'[e][i][a][u] = sum_b D^l[a][b] x[e][i][b][u] on planar rows."""
+    offs, _ = P.wigner_offsets(lmax)
+    out = np.zeros_like(xp)
+    for (mul, l, p), off, mp in zip(layout.irreps, layout.off, layout.mulp):
+        n = 2 * l + 1
+        Dl = D[:, offs[l]:offs[l] + n * n].reshape(-1, n, n)
+        if transpose:
+            Dl = Dl.transpose(0, 2, 1)
+        blk = xp[:, off:off + n * mp].reshape(-1, n, mp)
+        out[:, off:off + n * mp] = np.einsum("eab,ebu->eau", Dl, blk).reshape(-1, n * mp)
+    return out
+
+
+def radial_hidden(rbf, layers):
+    h = rbf
+    for W in layers:
+        z = h @ W.astype(np.float64)
+        h = z / (1 + np.exp(-z)) * SILU_CST
+    return h
+
+
+def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
+    """srcs: list of planar [E, dim] arrays (slot order).  Returns planar out [E, out_layout.dim]."""
+    E = srcs[0].shape[0]
+    Wt = prog.weights.astype(dtype)
+    out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
+    H = prog.hidden
+    woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
+    for e0 in range(0, E, 16):
+        ne = min(16, E - e0)
+        cols = np.arange(e0, e0 + ne)
+        for seg in prog.seg_table:
+            lk, mul_k, rto, out_off, out_mulp, ib, ie, flags = (int(v) for v in seg)
+            nco = 2 * lk + 1
+            tile = np.zeros((rto * 16, nco, 16), dtype=dtype)
+            for it in prog.item_table[ib:ie]:
+                (typ, s0, s1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off) = (int(v) for v in it[:17])
+                nc = 2 * mm + 1
+                nsrc = 2 if s1 >= 0 else 1
+                A1 = Wt[a1:a1 + nsrc * ksteps * rtm * 64].reshape(nsrc, ksteps, rtm, 4, 16)      # [src][s][rt][k][i]
+                mid = np.zeros((rtm, nc, 16, 16), dtype=dtype)
+                for si, sidx in enumerate([s0, s1][:nsrc]):
+                    X = srcs[sidx]
+                    for c in range(nc):
+                        m = c - mm
+                        a = li + (-m if neg else m)
+                        for s in range(ksteps):
+                            B = np.zeros((4, 16), dtype=dtype)
+                            B[:, :ne] = X[cols, in_off + a * in_mulp + 4 * s:in_off + a * in_mulp + 4 * s + 4].T
+                            for rt in range(rtm):
+                                mid[rt, c] += A1[si, s, rt].T @ B
+                if typ == P.IT_TP:
+                    W3 = Wt[w3:w3 + (H // 4) * rtm * 64].reshape(H // 4, rtm, 4, 16)
+                    S = np.zeros((rtm, 16, 16), dtype=dtype)
+                    hh = h2[mlp]
+                    for s in range(H // 4):
+                        B = np.zeros((4, 16), dtype=dtype)
+                        B[:, :ne] = hh[cols, 4 * s:4 * s + 4].T
+                        for rt in range(rtm):
+                            S[rt] += W3[s, rt].T @ B
+                    CF = Wt[cf:cf + rtm * nc * 16].reshape(rtm, nc, 16)                           # [rt][c][row = 4g + r]
+                    mid = mid * S[:, None, :, :] * CF[:, :, :, None]
+                    A2 = Wt[a2:a2 + rto * rtm * 4 * 64].reshape(rto, rtm, 4, 4, 16)               # [rt'][rt][r][k][i]
+                    for rtp in range(rto):
+                        for c in range(nc):
+                            acc = np.zeros((16, 16), dtype=dtype)
+                            for rt in range(rtm):
+                                for r in range(4):
+                                    Bm = mid[rt, c][r::4, :]                                     # rows 4k + r, k = 0..3
+                                    acc += A2[rtp, rt, r].T @ Bm
+                            tile[16 * rtp:16 * rtp + 16, lk - mm + c] += acc
+                else:
+                    for rt in range(rtm):
+                        r0 = row_off + 16 * rt
+                        tile[r0:r0 + 16, lk - mm:lk + mm + 1] += mid[rt].transpose(1, 0, 2)
+            t = tile[:mul_k, :, :ne]                                                              # [w, m, e]
+            if flags & P.SEG_UNROTATE:
+                Dl = D[cols, woffs[lk]:woffs[lk] + nco * nco].reshape(ne, nco, nco)
+                t = np.einsum("ema,wme->wae", Dl, t)                                              # out[a] = sum_m D[m][a] t[m]
+            blk = np.zeros((ne, nco, out_mulp), dtype=dtype)
+            blk[:, :, :mul_k] = t.transpose(2, 1, 0)
+            out[cols, out_off:out_off + nco * out_mulp] = blk.reshape(ne, -1)
+    return out
