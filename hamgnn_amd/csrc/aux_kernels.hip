@@ -1,0 +1,330 @@
+// aux_kernels.hip -- the memory-bound / small kernels around the fused edge kernel (gfx950).
+// See include/hamgnn_hip.h for the reference op cluster each entry point replaces.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "hg_common.h"
+
+static thread_local char g_err[512] = "";
+
+int hg_fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "unknown");
+    return code;
+}
+int hg_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+extern "C" const char* hg_last_error(void) { return g_err; }
+extern "C" int hg_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------ edge geometry
+// angles of R_e = Rx(beta) Ry(alpha) taking the e3nn-order unit vector n = (v_y, v_z, v_x)/|v| onto the pole (0,1,0);
+// Bessel * cosine-cutoff radial basis evaluated in fp64 (phase n*pi*r/rc by Chebyshev recurrence) and rounded once.
+__global__ void geometry_kernel(const float* __restrict__ pos, const int64_t* __restrict__ ei, const float* __restrict__ shift,
+                                int64_t E, float cutoff, int R, float4* __restrict__ ang, float* __restrict__ rbf,
+                                float* __restrict__ len) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t j = ei[e], i = ei[E + e];
+    const double vx = (double)pos[3 * i + 0] + (double)shift[3 * e + 0] - (double)pos[3 * j + 0];
+    const double vy = (double)pos[3 * i + 1] + (double)shift[3 * e + 1] - (double)pos[3 * j + 1];
+    const double vz = (double)pos[3 * i + 2] + (double)shift[3 * e + 2] - (double)pos[3 * j + 2];
+    const double r = sqrt(vx * vx + vy * vy + vz * vz);
+    const double inv = r > 0 ? 1.0 / r : 0.0;
+    const double nx = vy * inv, ny = vz * inv, nz = vx * inv;            // e3nn axis order = physical (y, z, x)
+    const double rho = sqrt(nx * nx + nz * nz);
+    double ca = 1.0, sa = 0.0;
+    if (rho > 1e-12) { ca = nz / rho; sa = -nx / rho; }
+    ang[e] = make_float4((float)ca, (float)sa, (float)ny, (float)(-rho));
+    if (len) len[e] = (float)r;
+    if (rbf) {
+        const double th = M_PI * r / (double)cutoff;
+        double s1, c1;
+        sincos(th, &s1, &c1);
+        const double fc = (r < (double)cutoff) ? 0.5 * (c1 + 1.0) * inv : 0.0;
+        double sn = 0.0, cn = 1.0;
+        for (int n = 0; n < R; ++n) {
+            const double s2 = sn * c1 + cn * s1, c2 = cn * c1 - sn * s1;
+            sn = s2; cn = c2;
+            rbf[e * R + n] = (float)(sn * fc);
+        }
+    }
+}
+
+// D^l(R_e) = J Z(beta) J^T Z(alpha): one thread per (edge, row a).  (hamgnn_amd/so3.py:edge_wigner is the host twin.)
+template <int L>
+__global__ void wigner_kernel(const float4* __restrict__ ang, int64_t E, const float* __restrict__ J, const float* __restrict__ sgn,
+                              float* __restrict__ wig, int nW, int off) {
+    constexpr int N = 2 * L + 1;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * N) return;
+    const int64_t e = idx / N;
+    const int a = (int)(idx - e * N);
+    const float4 q = ang[e];
+    float ca[L + 1], sa[L + 1], cb[L + 1], sb[L + 1];
+    ca[0] = cb[0] = 1.f; sa[0] = sb[0] = 0.f;
+#pragma unroll
+    for (int m = 1; m <= L; ++m) {
+        ca[m] = ca[m - 1] * q.x - sa[m - 1] * q.y; sa[m] = sa[m - 1] * q.x + ca[m - 1] * q.y;
+        cb[m] = cb[m - 1] * q.z - sb[m - 1] * q.w; sb[m] = sb[m - 1] * q.z + cb[m - 1] * q.w;
+    }
+    float t1[N], t2[N];
+    t1[L] = J[a * N + L];
+#pragma unroll
+    for (int m = 1; m <= L; ++m) {
+        const float jp = J[a * N + L + m], jm = J[a * N + L - m], s = sgn[m] * sb[m];
+        t1[L + m] = jp * cb[m] - s * jm;
+        t1[L - m] = jm * cb[m] + s * jp;
+    }
+#pragma unroll
+    for (int c = 0; c < N; ++c) {
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < N; ++b) acc = fmaf(t1[b], J[c * N + b], acc);
+        t2[c] = acc;
+    }
+    float* __restrict__ o = wig + e * nW + off + a * N;
+    o[L] = t2[L];
+#pragma unroll
+    for (int m = 1; m <= L; ++m) {
+        const float s = sgn[m] * sa[m];
+        o[L + m] = t2[L + m] * ca[m] - s * t2[L - m];
+        o[L - m] = t2[L - m] * ca[m] + s * t2[L + m];
+    }
+}
+
+extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, const float* nbr_shift, int64_t E, float cutoff,
+                                int num_radial, int lmax_wig, const float* jtab, float* rbf, float* wig, float* edge_len,
+                                float* ang_scratch, void* stream) {
+    if (E <= 0) return 0;
+    if (lmax_wig > 6) return hg_fail(-2, "hg_edge_geometry: lmax_wig > 6 not instantiated");
+    hipStream_t st = (hipStream_t)stream;
+    int nW = 0, nJ = 0;
+    for (int l = 0; l <= lmax_wig; ++l) nW += (2 * l + 1) * (2 * l + 1);
+    nJ = nW;
+    float4* ang = reinterpret_cast<float4*>(ang_scratch);
+    geometry_kernel<<<dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st>>>(pos, edge_index, nbr_shift, E, cutoff, num_radial, ang, rbf, edge_len);
+    if (wig) {
+        int off = 0, soff = nJ;
+        for (int l = 0; l <= lmax_wig; ++l) {
+            const int N = 2 * l + 1;
+            const unsigned grid = (unsigned)((E * N + 255) / 256);
+            const float* J = jtab + off;
+            const float* sg = jtab + soff;
+            switch (l) {
+                case 0: wigner_kernel<0><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+                case 1: wigner_kernel<1><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+                case 2: wigner_kernel<2><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+                case 3: wigner_kernel<3><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+                case 4: wigner_kernel<4><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+                case 5: wigner_kernel<5><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+                case 6: wigner_kernel<6><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+            }
+            off += N * N;
+            soff += l + 1;
+        }
+    }
+    return hg_check_launch("hg_edge_geometry");
+}
+
+// ------------------------------------------------------------------------------------------------ radial hidden layers
+#define RH_TE 16
+__global__ __launch_bounds__(256) void radial_hidden_kernel(const float* __restrict__ rbf, int64_t E, const float* __restrict__ W,
+                                                            int d0, int d1, int d2, int d3, int nlayers, float cst,
+                                                            float* __restrict__ out, int maxd) {
+    extern __shared__ float sm[];
+    float* buf0 = sm;
+    float* buf1 = sm + RH_TE * (maxd + 1);
+    const int64_t e0 = (int64_t)blockIdx.x * RH_TE;
+    const int dims[4] = {d0, d1, d2, d3};
+    for (int i = threadIdx.x; i < RH_TE * d0; i += blockDim.x) {
+        const int e = i / d0, k = i - e * d0;
+        buf0[e * (maxd + 1) + k] = (e0 + e < E) ? rbf[(e0 + e) * d0 + k] : 0.f;
+    }
+    __syncthreads();
+    const float* w = W;
+    float* in = buf0;
+    float* ot = buf1;
+    for (int l = 0; l < nlayers; ++l) {
+        const int di = dims[l], dn = dims[l + 1];
+        for (int i = threadIdx.x; i < RH_TE * dn; i += blockDim.x) {
+            const int e = i / dn, j = i - e * dn;
+            float acc = 0.f;
+            for (int k = 0; k < di; ++k) acc = fmaf(in[e * (maxd + 1) + k], w[k * dn + j], acc);
+            ot[e * (maxd + 1) + j] = cst * acc / (1.f + __expf(-acc));
+        }
+        __syncthreads();
+        w += di * dn;
+        float* t = in; in = ot; ot = t;
+    }
+    const int dl = dims[nlayers];
+    for (int i = threadIdx.x; i < RH_TE * dl; i += blockDim.x) {
+        const int e = i / dl, j = i - e * dl;
+        if (e0 + e < E) out[(e0 + e) * dl + j] = in[e * (maxd + 1) + j];
+    }
+}
+
+extern "C" int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const int32_t* dims, int nlayers, float act_cst,
+                                float* h_out, void* stream) {
+    if (E <= 0) return 0;
+    if (nlayers < 1 || nlayers > 3) return hg_fail(-2, "hg_radial_hidden: 1..3 hidden layers supported");
+    int d[4] = {0, 0, 0, 0}, maxd = 0;
+    for (int i = 0; i <= nlayers; ++i) { d[i] = dims[i]; if (d[i] > maxd) maxd = d[i]; }
+    const size_t lds = 2 * RH_TE * (size_t)(maxd + 1) * sizeof(float);
+    radial_hidden_kernel<<<dim3((unsigned)((E + RH_TE - 1) / RH_TE)), 256, lds, (hipStream_t)stream>>>(rbf, E, weights, d[0], d[1], d[2], d[3], nlayers, act_cst, h_out, maxd);
+    return hg_check_launch("hg_radial_hidden");
+}
+
+// ------------------------------------------------------------------------------------------------ gather + rotate
+__global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restrict__ x, int64_t xs, const int64_t* __restrict__ idx,
+                                                            const float* __restrict__ wig, int nW, const HgWigOff wo,
+                                                            const int4* __restrict__ tab, int Dp, int64_t E, int transpose,
+                                                            float* __restrict__ out, int64_t os) {
+    const int64_t e = blockIdx.x;
+    const int64_t row = idx ? idx[e] : e;
+    const float* __restrict__ xr = x + row * xs;
+    const float* __restrict__ D = wig + e * nW;
+    for (int p = threadIdx.x; p < Dp; p += blockDim.x) {
+        const int4 t = tab[p];                       // {l, a, base_in, mulp}
+        float acc = 0.f;
+        if (t.x >= 0) {
+            const int n = 2 * t.x + 1;
+            const float* __restrict__ Dl = D + wo.o[t.x];
+            if (!transpose) for (int b = 0; b < n; ++b) acc = fmaf(Dl[t.y * n + b], xr[t.z + b * t.w], acc);
+            else            for (int b = 0; b < n; ++b) acc = fmaf(Dl[b * n + t.y], xr[t.z + b * t.w], acc);
+        }
+        out[e * os + p] = acc;
+    }
+}
+
+extern "C" int hg_rotate_gather(const float* x, int64_t x_stride, const int64_t* idx, const float* wig, int nW, const int32_t* wig_off,
+                                const int32_t* elem_tab, int Dp, int64_t E, int transpose, float* out, int64_t out_stride, void* stream) {
+    if (E <= 0) return 0;
+    HgWigOff wo;
+    for (int i = 0; i < 8; ++i) wo.o[i] = wig_off[i];
+    rotate_gather_kernel<<<dim3((unsigned)E), 256, 0, (hipStream_t)stream>>>(x, x_stride, idx, wig, nW, wo, (const int4*)elem_tab, Dp, E, transpose, out, out_stride);
+    return hg_check_launch("hg_rotate_gather");
+}
+
+// ------------------------------------------------------------------------------------------------ segmented node scatter
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ msg, int64_t ms, const int64_t* __restrict__ rowptr,
+                                                          const int64_t* __restrict__ perm, int Dp, float* __restrict__ out, int64_t os) {
+    const int64_t n = blockIdx.x;
+    const int64_t q0 = rowptr[n], q1 = rowptr[n + 1];
+    for (int p = threadIdx.x; p < Dp; p += blockDim.x) {
+        float acc = 0.f;
+        for (int64_t q = q0; q < q1; ++q) acc += msg[perm[q] * ms + p];
+        out[n * os + p] = acc;
+    }
+}
+
+extern "C" int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_t* rowptr, const int64_t* perm, int64_t N, int Dp,
+                              float* out, int64_t out_stride, void* stream) {
+    if (N <= 0) return 0;
+    segment_sum_kernel<<<dim3((unsigned)N), 256, 0, (hipStream_t)stream>>>(msg, msg_stride, rowptr, perm, Dp, out, out_stride);
+    return hg_check_launch("hg_segment_sum");
+}
+
+// ------------------------------------------------------------------------------------------------ gate / adds / layout
+__device__ __forceinline__ float hg_act(float x, int id, const float* __restrict__ cst) {
+    switch (id) {
+        case 1: return cst[1] * ((x > 20.f ? x : log1pf(__expf(x))) - 0.6931471805599453f);     // shifted softplus
+        case 2: return cst[2] * tanhf(x);
+        case 3: return cst[3] * x / (1.f + __expf(-x));
+        case 4: return cst[4] * fabsf(x);
+        default: return x;
+    }
+}
+
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, int64_t xs, const int4* __restrict__ tab, int Dout,
+                                                   const float* __restrict__ cst, int64_t rows, float* __restrict__ out, int64_t os) {
+    const int64_t r = blockIdx.x;
+    const float* __restrict__ xr = x + r * xs;
+    for (int p = threadIdx.x; p < Dout; p += blockDim.x) {
+        const int4 t = tab[p];                       // {src, act, gate, gate_act}
+        float v = 0.f;
+        if (t.x >= 0) {
+            v = hg_act(xr[t.x], t.y, cst);
+            if (t.z >= 0) v *= hg_act(xr[t.z], t.w, cst);
+        }
+        out[r * os + p] = v;
+    }
+}
+
+extern "C" int hg_gate(const float* x, int64_t x_stride, const int32_t* tab, int Dout, const float* consts, int64_t rows, float* out,
+                       int64_t out_stride, void* stream) {
+    if (rows <= 0) return 0;
+    gate_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(x, x_stride, (const int4*)tab, Dout, consts, rows, out, out_stride);
+    return hg_check_launch("hg_gate");
+}
+
+__global__ void add_rows_kernel(const float* __restrict__ a, int64_t sa, const float* __restrict__ b, int64_t sb,
+                                const float* __restrict__ c, int64_t sc, int64_t rows, int D, float* __restrict__ out, int64_t so) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int64_t r = i / D;
+    const int p = (int)(i - r * D);
+    float v = a[r * sa + p] + b[r * sb + p];
+    if (c) v += c[r * sc + p];
+    out[r * so + p] = v;
+}
+
+extern "C" int hg_add_rows(const float* a, int64_t sa, const float* b, int64_t sb, const float* c, int64_t sc, int64_t rows, int D,
+                           float* out, int64_t so, void* stream) {
+    if (rows <= 0) return 0;
+    add_rows_kernel<<<dim3((unsigned)((rows * D + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a, sa, b, sb, c, sc, rows, D, out, so);
+    return hg_check_launch("hg_add_rows");
+}
+
+__global__ void to_planar_kernel(const float* __restrict__ x, int64_t rows, int D, const int* __restrict__ map, float* __restrict__ out, int Dp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int64_t r = i / D;
+    const int k = (int)(i - r * D);
+    out[r * Dp + map[k]] = x[i];
+}
+__global__ void from_planar_kernel(const float* __restrict__ xp, int64_t rows, int Dp, const int* __restrict__ map, float* __restrict__ out, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const int64_t r = i / D;
+    const int k = (int)(i - r * D);
+    out[i] = xp[r * Dp + map[k]];
+}
+extern "C" int hg_to_planar(const float* x, int64_t rows, int D, const int32_t* map, float* out, int Dp, void* stream) {
+    if (rows <= 0) return 0;
+    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)rows * Dp, (hipStream_t)stream);
+    to_planar_kernel<<<dim3((unsigned)((rows * D + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, rows, D, map, out, Dp);
+    return hg_check_launch("hg_to_planar");
+}
+extern "C" int hg_from_planar(const float* xp, int64_t rows, int Dp, const int32_t* map, float* out, int D, void* stream) {
+    if (rows <= 0) return 0;
+    from_planar_kernel<<<dim3((unsigned)((rows * D + 255) / 256)), 256, 0, (hipStream_t)stream>>>(xp, rows, Dp, map, out, D);
+    return hg_check_launch("hg_from_planar");
+}
+
+__global__ void embed_lookup_kernel(const float* __restrict__ Ta, const float* __restrict__ Tb, const int64_t* __restrict__ z,
+                                    const int64_t* __restrict__ ia, const int64_t* __restrict__ ib, int64_t rows, int T, int Tp,
+                                    float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * Tp) return;
+    const int64_t r = i / Tp;
+    const int t = (int)(i - r * Tp);
+    float v = 0.f;
+    if (t < T) {
+        v = Ta[z[ia ? ia[r] : r] * T + t];
+        if (Tb) v += Tb[z[ib[r]] * T + t];
+    }
+    out[i] = v;
+}
+extern "C" int hg_embed_lookup(const float* Ta, const float* Tb, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b,
+                               int64_t rows, int T, int Tp, float* out, void* stream) {
+    if (rows <= 0) return 0;
+    embed_lookup_kernel<<<dim3((unsigned)((rows * Tp + 255) / 256)), 256, 0, (hipStream_t)stream>>>(Ta, Tb, z, idx_a, idx_b, rows, T, Tp, out);
+    return hg_check_launch("hg_embed_lookup");
+}

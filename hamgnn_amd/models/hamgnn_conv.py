@@ -1,0 +1,126 @@
+"""HamGNNConvE3 -- MI355X drop-in for the reference backbone (hamgnn/models/hamgnn_conv.py:88-284): same constructor
+config keys, same parameter names, same return dict {node_attr [N,D], edge_attr [E,D]} (e3nn layout, global frame).
+Underneath: planar feature rows, per-edge Wigner frames and the fused MFMA edge kernel (csrc/tp_fused.hip)."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import nn as hnn
+from .. import ops
+from .. import plan as P
+from ..so3 import Irreps
+
+
+class Representation(dict):
+    """EasyDict-like result: key and attribute access (reference returns an EasyDict, hamgnn_conv.py:278-284)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def _cfg_get(c, k, default=None):
+    if isinstance(c, dict):
+        return c.get(k, default)
+    return getattr(c, k, default)
+
+
+class HamGNNConvE3(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        c = _cfg_get(config, "HamGNN_pre", config)
+        g = lambda k, d=None: _cfg_get(c, k, d)
+        self.num_types = g("num_types")
+        self.irreps_edge_sh = Irreps(g("irreps_edge_sh"))
+        self.cutoff = float(g("cutoff"))
+        self.num_radial = g("num_radial")
+        self.num_layers = g("num_layers")
+        self.irreps_node_features = Irreps(g("irreps_node_features"))
+        self.radial_MLP = list(g("radial_MLP"))
+        self.legacy_edge_update = bool(g("legacy_edge_update", False))
+        if str(g("rbf_func", "bessel")).lower() != "bessel":
+            raise ValueError(f"Unsupported radial basis function on the MI355X path: {g('rbf_func')}")
+        for k in ("use_kan", "use_corr_prod", "build_internal_graph", "lite_mode", "apply_charge_doping"):
+            if g(k, False):
+                raise NotImplementedError(f"HamGNN_pre.{k}=True is outside the MI355X hot-path scope of this round (SURVEY 8f)")
+        if g("edge_sh_normalization", "component") != "component" or not g("edge_sh_normalize", True):
+            raise NotImplementedError("only component-normalised, normalised edge SH are supported")
+        for _, l, p in self.irreps_edge_sh:
+            assert p == (-1) ** l
+        D, sh, R, mlp = self.irreps_node_features, self.irreps_edge_sh, self.num_radial, self.radial_MLP
+        self.lmax = max(D.lmax, sh.lmax)
+        self.pair_embedding = hnn.PairInteractionEmbeddingBlock(self.num_types, sh, D, R, mlp)
+        self.chemical_embedding = nn.Module()
+        self.chemical_embedding.linear = hnn.E3Linear(Irreps([(self.num_types, 0, 1)]), D)
+        self.convolutions = nn.ModuleList()
+        self.pair_interactions = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.convolutions.append(hnn.ConvBlockE3(D, sh, R, mlp))
+            skip = (i > 0) if self.legacy_edge_update else True
+            self.pair_interactions.append(hnn.PairInteractionBlock(D, sh, R, mlp, skip, self.legacy_edge_update))
+        self.layout = P.PlanarLayout(D)
+        self._compiled_for = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def compile(self, device):
+        """(Re)pack all weights into MFMA fragment order and upload.  Call again after changing parameters."""
+        dev = torch.device(device)
+        self.pair_embedding.compile(dev)
+        for c, p in zip(self.convolutions, self.pair_interactions):
+            c.compile(dev)
+            p.compile(dev)
+        lay = self.layout
+        self._imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(dev)
+        self._rot_tab = torch.from_numpy(P.rotate_table(lay)).to(dev)
+        self._jtab = torch.from_numpy(P.wigner_jtab(self.lmax)).to(dev)
+        # chemical embedding = row look-up of o3.Linear(num_types x 0e -> D) applied to one-hot rows (planar table)
+        T = self.num_types
+        W = self.chemical_embedding.linear.weight.detach().cpu().double().numpy()
+        table = np.zeros((T, lay.dim))
+        off = 0
+        for k, (mk, lk, pk) in enumerate(self.irreps_node_features):
+            if (lk, pk) == (0, 1):
+                table[:, lay.off[k]:lay.off[k] + mk] = W[off:off + T * mk].reshape(T, mk) / math.sqrt(T)
+                off += T * mk
+        assert off == W.size
+        self._chem = torch.from_numpy(table.astype(np.float32)).to(dev)
+        self._compiled_for = dev
+        return self
+
+    def forward(self, data):
+        dev = data.pos.device
+        if self._compiled_for != dev:
+            self.compile(dev)
+        N = data.z.shape[0]
+        z = data.z.contiguous()
+        geo = ops.Geometry(data.pos, data.edge_index, data.nbr_shift, self.cutoff, self.num_radial, self.lmax, self._jtab)
+        Dp = self.layout.dim
+        f = self.pair_embedding.run(z, geo)                                          # [E, Dp] edge-aligned frame
+        node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)          # [N, Dp]
+        rowptr, perm = geo.receiver_csr(N)
+        for conv, pair in zip(self.convolutions, self.pair_interactions):
+            # ---- ConvBlockE3.forward (convolution.py:116-160)
+            skip = conv.skip_linear(node)
+            xs = ops.rotate_gather(node, geo.src, geo, self._rot_tab)
+            xd = ops.rotate_gather(node, geo.dst, geo, self._rot_tab)
+            msg = conv.conv_tp.run(xs, xd, f, geo)                                   # global frame (un-rotated in the epilogue)
+            agg = ops.segment_sum(msg, rowptr, perm, N)
+            node = conv.residual(agg, extra=skip)
+            # ---- PairInteractionBlock.forward (interaction_blocks.py:130-164)
+            xs = ops.rotate_gather(pair.linear_up_src(node), geo.src, geo, self._rot_tab)
+            xd = ops.rotate_gather(pair.linear_up_tar(node), geo.dst, geo, self._rot_tab)
+            mix = pair.conv_tp.run(xs, xd, f, geo)                                   # stays in the edge frame (+ fused skip linear)
+            if pair.use_skip_connections or not pair.legacy_edge_update:
+                f = mix
+        rep = Representation()
+        rep["node_attr"] = ops.from_planar(node, self._imap)
+        rep["edge_attr"] = ops.from_planar(ops.rotate_gather(f, None, geo, self._rot_tab, transpose=True), self._imap)
+        # extras for the MI355X head: skip the layout/frame round trip
+        rep["_node_planar"], rep["_edge_planar_rot"], rep["_geometry"] = node, f, geo
+        return rep

@@ -1,0 +1,173 @@
+"""HamGNNPlusPlusOut -- MI355X drop-in for the reference pair read-out head (hamgnn/models/hamgnn_output.py:96-123 ctor,
+:2916-4021 forward).  Same constructor keywords, parameter names ({onsite,offsite}_hamiltonian_network.{residual_block,
+linear_transform}, ..._ksi_network, ..._overlap_network) and result dict.  In scope this round: the non-SOC branch
+(:3772-3799) incl. overlap networks, SOC/so3 (:3026-3144), masks, symmetrisation, H0, per-crystal concatenation,
+sparsity ratio.  Out of scope (raise NotImplementedError): band/k-space code, spin-constrained / collinear branches,
+SOC/su2, forces."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import basis as B
+from .. import nn as hnn
+from .. import ops
+from .. import plan as P
+from ..so3 import Irreps
+
+
+class HamGNNPlusPlusOut(nn.Module):
+    def __init__(self, irreps_in_node=None, irreps_in_edge=None, nao_max=14, return_forces=False, create_graph=False,
+                 ham_type="openmx", ham_only=False, symmetrize=True, include_triplet=False, calculate_band_energy=False,
+                 num_k=8, k_path=None, band_num_control=None, soc_switch=True, nonlinearity_type="gate",
+                 export_reciprocal_values=False, add_H0=False, soc_basis="so3", spin_constrained=False, use_learned_weight=True,
+                 minMagneticMoment=0.5, collinear_spin=False, zero_point_shift=False, add_H_nonsoc=False,
+                 get_nonzero_mask_tensor=False, calculate_sparsity=True):
+        super().__init__()
+        self.derivative, self.create_graph = return_forces, create_graph
+        self.nao_max, self.ham_type, self.ham_only = nao_max, ham_type.lower(), ham_only
+        self.symmetrize, self.soc_switch, self.add_H0 = symmetrize, soc_switch, add_H0
+        self.soc_basis = soc_basis.lower()
+        if soc_switch and self.ham_type != "openmx":
+            self.soc_basis = "su2"                                           # hamgnn_output.py:151-153
+        self.zero_point_shift, self.add_H_nonsoc = zero_point_shift, add_H_nonsoc
+        self.calculate_sparsity = calculate_sparsity
+        for flag, name in ((return_forces, "return_forces"), (calculate_band_energy, "calculate_band_energy"),
+                           (spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
+                           (export_reciprocal_values, "export_reciprocal_values"), (zero_point_shift, "zero_point_shift"),
+                           (get_nonzero_mask_tensor, "get_nonzero_mask_tensor"), (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
+            if flag:
+                raise NotImplementedError(f"HamGNNPlusPlusOut({name}) is outside the MI355X hot-path scope of this round")
+        if soc_switch and self.soc_basis != "so3":
+            raise NotImplementedError("SOC basis 'su2' (SIESTA/ABACUS SOC) is not built yet; 'so3' is")
+        t = B.basis_table(self.ham_type, nao_max)
+        self.row = self.col = Irreps(t["row"])
+        self.index_change, self.minus_index, self.basis_def = t["index_change"], t["minus_index"], t["basis_def"]
+        self.hamiltonian_irreps = P.ham_irreps(self.row)
+        self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
+        self.offsite_hamiltonian_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
+        if soc_switch:
+            ksi = Irreps([(nao_max ** 2, 0, 1)])
+            self.onsite_ksi_network = hnn.HamLayer(irreps_in_node, ksi)
+            self.offsite_ksi_network = hnn.HamLayer(irreps_in_edge, ksi)
+        if not ham_only:
+            self.onsite_overlap_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
+            self.offsite_overlap_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
+        self.node_layout = P.PlanarLayout(irreps_in_node)
+        self.edge_layout = P.PlanarLayout(irreps_in_edge)
+        self._compiled_for = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def compile(self, device):
+        dev = torch.device(device)
+        for m in self.children():
+            if isinstance(m, hnn.HamLayer):
+                m.compile(dev)
+        net = self.onsite_hamiltonian_network
+        st, ptr, idx, val = P.ham_merge_tables(self.row, self.nao_max, self.index_change, self.minus_index, net.girr, net.slot_pos)
+        self._slot = torch.from_numpy(st).to(dev)
+        self._cg = tuple(torch.from_numpy(a).to(dev) for a in (ptr, idx, val))
+        mask = np.zeros((119, self.nao_max), dtype=np.float32)
+        for Z, orb in self.basis_def.items():
+            mask[Z, orb] = 1.0
+        self._mask = torch.from_numpy(mask).to(dev)
+        norb = np.full(256, self.nao_max, dtype=np.int64)
+        defined = np.zeros(256, dtype=bool)
+        for Z, orb in self.basis_def.items():
+            norb[Z], defined[Z] = len(orb), True
+        self._norb, self._defined = torch.from_numpy(norb).to(dev), torch.from_numpy(defined).to(dev)
+        self._n_imap = torch.from_numpy(self.node_layout.index_map().astype(np.int32)).to(dev)
+        self._e_imap = torch.from_numpy(self.edge_layout.index_map().astype(np.int32)).to(dev)
+        self._rot_tab = torch.from_numpy(P.rotate_table(self.edge_layout)).to(dev)
+        self._lmax = max(self.edge_layout.irreps.lmax, self.hamiltonian_irreps.lmax)
+        self._jtab = torch.from_numpy(P.wigner_jtab(self._lmax)).to(dev)
+        self._compiled_for = dev
+        return self
+
+    # -- index preparation (integer plumbing; hamgnn_output.py:2874-2914, 2985-2990, 1187-1229, 2784-2872)
+    def _validate(self, data):
+        if data.get("_hg_validated", False) if isinstance(data, dict) else False:
+            return
+        ok = bool(self._defined[data.z].all().item())
+        if not ok:
+            missing = [int(z) for z in data.z.unique().cpu().tolist() if z not in self.basis_def]
+            raise ValueError("The following elements are missing from basis_def: " + ", ".join(f"Z={z}" for z in missing))
+        if isinstance(data, dict):
+            dict.__setitem__(data, "_hg_validated", True)
+
+    @staticmethod
+    def _global_inverse(data):
+        src = data.edge_index[0]
+        batch = getattr(data, "batch", None)
+        if batch is None:
+            return data.inv_edge_idx.contiguous(), None
+        b = batch[src]
+        counts = torch.bincount(b, minlength=int(data.node_counts.shape[0]) if hasattr(data, "node_counts") else 0)
+        offs = torch.cumsum(counts, 0) - counts
+        return (data.inv_edge_idx + offs[b]).contiguous(), counts
+
+    @staticmethod
+    def _cat_by_crystal(data, on, off, edge_counts):
+        if edge_counts is None or edge_counts.numel() <= 1:
+            return torch.cat([on, off], 0)
+        nn_ = data.node_counts.tolist()
+        ne = edge_counts.tolist()
+        out = []
+        for a, b in zip(torch.split(on, nn_), torch.split(off, ne)):
+            out += [a, b]
+        return torch.cat(out, 0)
+
+    def calculate_sparsity_ratio(self, data):
+        z = data.z
+        n2 = self.nao_max ** 2
+        src, dst = data.edge_index
+        ni = self._norb[z]
+        both = self._defined[z[src]] & self._defined[z[dst]]
+        eff = (ni * ni).sum() + torch.where(both, ni[src] * ni[dst], torch.full_like(src, n2)).sum()
+        total = float((z.numel() + src.numel()) * n2)
+        return (total / eff.to(torch.float64)).to(torch.float32)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _blocks(self, net_on, net_off, node_pl, edge_rot, geo, data, inv, H0_on, H0_off):
+        n, n2 = self.nao_max, self.nao_max ** 2
+        src, dst = geo.src, geo.dst
+        z = data.z.contiguous()
+        raw_on = ops.ham_merge(net_on(node_pl), None, self._slot, *self._cg, n2)
+        on = ops.ham_finish(raw_on, None, H0_on, self._mask, z, None, None, n, 1.0, self.symmetrize)
+        raw_off = ops.ham_merge(net_off(edge_rot), geo, self._slot, *self._cg, n2)
+        off = ops.ham_finish(raw_off, inv, H0_off, self._mask, z, src, dst, n, 1.0, self.symmetrize)
+        return on, off
+
+    def forward(self, data, graph_representation=None):
+        rep = graph_representation
+        dev = data.z.device
+        if self._compiled_for != dev:
+            self.compile(dev)
+        self._validate(data)
+        geo = rep.get("_geometry") if hasattr(rep, "get") else None
+        if geo is None or geo.lmax < self._lmax:
+            c = 1.0  # cutoff / radial basis are irrelevant for the frames
+            geo = ops.Geometry(data.pos, data.edge_index, data.nbr_shift, c, 1, self._lmax, self._jtab)
+        node_pl = rep.get("_node_planar") if hasattr(rep, "get") else None
+        if node_pl is None:
+            node_pl = ops.to_planar(rep["node_attr"], self._n_imap, self.node_layout.dim)
+        edge_rot = rep.get("_edge_planar_rot") if hasattr(rep, "get") else None
+        if edge_rot is None:
+            edge_rot = ops.rotate_gather(ops.to_planar(rep["edge_attr"], self._e_imap, self.edge_layout.dim), None, geo, self._rot_tab)
+        inv, edge_counts = self._global_inverse(data)
+        f32c = lambda t: t.contiguous().float()
+        result = {}
+        if not self.ham_only:
+            s_on, s_off = self._blocks(self.onsite_overlap_network, self.offsite_overlap_network, node_pl, edge_rot, geo, data, inv, None, None)
+            result["overlap"] = self._cat_by_crystal(data, s_on, s_off, edge_counts)
+        if self.soc_switch:
+            raise NotImplementedError("SOC/so3 assembly kernel lands next (oracle + fixtures already cover it)")
+        H0_on = f32c(data.Hon0) if self.add_H0 else None
+        H0_off = f32c(data.Hoff0) if self.add_H0 else None
+        on, off = self._blocks(self.onsite_hamiltonian_network, self.offsite_hamiltonian_network, node_pl, edge_rot, geo, data, inv, H0_on, H0_off)
+        result.update({"hamiltonian": self._cat_by_crystal(data, on, off, edge_counts), "band_energy": None, "wavefunction": None,
+                       "band_gap": None, "H_sym": None})
+        if self.calculate_sparsity:
+            result["sparsity_ratio"] = self.calculate_sparsity_ratio(data)
+        return result

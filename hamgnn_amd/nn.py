@@ -1,0 +1,241 @@
+"""Host-side mirror of the reference's hot-path modules (hamgnn/nn/*.py): same attribute / parameter names and flat
+e3nn weight layouts (so reference state_dicts load unchanged), but `forward` drives the hand-written HIP kernels through
+the C ABI.  Weights are (re)packed into MFMA fragment order by `compile()`; inference-only in this round.
+
+Reference classes mirrored here: o3.Linear / o3.TensorProduct / FullyConnectedNet parameter holders [e3nn 0.5.0];
+LinearScaleWithWeights (tensor_products.py:25-47), TensorProductWithMemoryOptimizationWithWeight (:51-189),
+MessagePackBlock (message_passing.py:26-231), ResidualBlock (interaction_blocks.py:264-358), ConvBlockE3
+(convolution.py:22-160), PairInteractionBlock (interaction_blocks.py:30-164), PairInteractionEmbeddingBlock
+(embeddings.py:215-337), HamLayer (models/hamgnn_output.py:38-58)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from . import plan as P
+from .so3 import Irreps
+
+
+def _np_sd(module: nn.Module) -> Dict[str, np.ndarray]:
+    return {k: v.detach().cpu().double().numpy() for k, v in module.state_dict().items()}
+
+
+class E3Linear(nn.Module):
+    """o3.Linear parameter holder: flat weight, paths ordered (i_in, i_out), each (mul_in, mul_out) row-major."""
+
+    def __init__(self, irreps_in, irreps_out):
+        super().__init__()
+        self.irreps_in, self.irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+        n = sum(mi * mo for (mi, li, pi) in self.irreps_in for (mo, lo, po) in self.irreps_out if (li, pi) == (lo, po))
+        self.weight = nn.Parameter(torch.randn(n))
+        self._dp = None
+
+    def compile(self, device):
+        self._dp = ops.DeviceProgram(P.build_linear_program(self.weight.detach().cpu().double().numpy(), self.irreps_in, self.irreps_out), device)
+        return self
+
+    def forward(self, x_planar: torch.Tensor) -> torch.Tensor:
+        if self._dp is None:
+            self.compile(x_planar.device)
+        return ops.tp_fused(self._dp, [x_planar], x_planar.shape[0])
+
+
+class E3TensorProduct(nn.Module):
+    """o3.TensorProduct(uvw, internal shared weights) parameter holder; instructions by the reference rule."""
+
+    def __init__(self, irreps_in1, irreps_sh, irreps_target):
+        super().__init__()
+        i1, i2, io = Irreps(irreps_in1), Irreps(irreps_sh), Irreps(irreps_target)
+        self.ins = P.tp_instructions(i1, i2, io)
+        self.weight_numel = sum(i1[i][0] * i2[j][0] * io[k][0] for i, j, k, _ in self.ins)
+        self.mid_num_irreps = sum(io[k][0] for _, _, k, _ in self.ins)
+        self.mid_fan = {}
+        for _, _, k, _ in self.ins:
+            self.mid_fan[k] = self.mid_fan.get(k, 0) + io[k][0]
+        self.weight = nn.Parameter(torch.randn(self.weight_numel))
+
+
+class _FCLayer(nn.Module):
+    def __init__(self, h_in, h_out):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(h_in, h_out))
+
+
+class FullyConnectedNet(nn.Module):
+    def __init__(self, hs):
+        super().__init__()
+        self.hs = list(hs)
+        for i, (a, b) in enumerate(zip(hs, hs[1:])):
+            setattr(self, f"layer{i}", _FCLayer(a, b))
+
+    def hidden_layers(self, device):
+        n = len(self.hs) - 1
+        out = []
+        for i in range(n - 1):
+            W = getattr(self, f"layer{i}").weight.detach().double()
+            out.append((W / math.sqrt(W.shape[0])).float().contiguous().to(device))
+        return out
+
+
+class _LinOutHolder(nn.Module):
+    def __init__(self, tp: E3TensorProduct, irreps_out: Irreps):
+        super().__init__()
+        n = sum(tp.mid_fan[k] * irreps_out[k][0] for k in tp.mid_fan)
+        self.weight = nn.Parameter(torch.randn(n))
+
+
+class LinearScaleWithWeights(nn.Module):
+    def __init__(self, tp: E3TensorProduct, irreps_out: Irreps):
+        super().__init__()
+        self.weight_numel = tp.mid_num_irreps
+        self.linear_out = _LinOutHolder(tp, irreps_out)
+
+
+class MessagePackBlock(nn.Module):
+    def __init__(self, irreps_node_feats, irreps_edge_feats, irreps_local_env_edge, irreps_out, num_radial, radial_MLP=(64, 64),
+                 lite_mode=False):
+        super().__init__()
+        if lite_mode:
+            raise NotImplementedError("lite_mode (uvu) is not built for the MI355X path yet (SURVEY 8f); the oracle covers it")
+        self.irreps_node, self.irreps_edge = Irreps(irreps_node_feats), Irreps(irreps_edge_feats)
+        self.irreps_sh, self.irreps_out = Irreps(irreps_local_env_edge), Irreps(irreps_out)
+        comb = Irreps([(max(1, 2 * m), l, p) for m, l, p in self.irreps_node])
+        self.node_tensor_product = E3TensorProduct(comb, self.irreps_sh, self.irreps_out)
+        self.edge_tensor_product = E3TensorProduct(self.irreps_edge, self.irreps_sh, self.irreps_out)
+        self.node_linear_scaler = LinearScaleWithWeights(self.node_tensor_product, self.irreps_out)
+        self.edge_linear_scaler = LinearScaleWithWeights(self.edge_tensor_product, self.irreps_out)
+        self.node_weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.node_linear_scaler.weight_numel])
+        self.edge_weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.edge_linear_scaler.weight_numel])
+        self.node_linear_out = E3Linear(self.irreps_out, self.irreps_out)
+        self.edge_linear_out = E3Linear(self.irreps_out, self.irreps_out)
+        self._dp = None
+
+    def compile(self, device, unrotate: bool, skip_weight=None):
+        sd = _np_sd(self)
+        prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
+        self._dp = ops.DeviceProgram(prog, device)
+        self._hn = self.node_weight_generator.hidden_layers(device)
+        self._he = self.edge_weight_generator.hidden_layers(device)
+        return self
+
+    def run(self, xs_rot, xd_rot, f_rot, geo: ops.Geometry):
+        """xs_rot/xd_rot/f_rot: planar rows in the edge-aligned frame.  Returns planar [E, Dp] (global frame if unrotate)."""
+        cst = float(P.ACT_CONSTS[P.ACT_SILU])
+        hn = ops.radial_hidden(geo.rbf, self._hn, cst)
+        he = ops.radial_hidden(geo.rbf, self._he, cst)
+        return ops.tp_fused(self._dp, [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, irreps_in, feature_irreps_hidden, resnet=True):
+        super().__init__()
+        self.irreps_in = Irreps(irreps_in)
+        self.gate_in, self.gate_out, self._tab_np = P.gate_tables(feature_irreps_hidden)
+        self.linear1 = E3Linear(self.irreps_in, self.gate_in)
+        self.linear2 = E3Linear(self.gate_out, self.irreps_in)
+        self.resnet = resnet
+        self._tab = None
+
+    def compile(self, device):
+        self.linear1.compile(device)
+        self.linear2.compile(device)
+        self._tab = torch.from_numpy(self._tab_np).to(device)
+        self._cst = torch.from_numpy(P.ACT_CONSTS).to(device)
+        return self
+
+    def forward(self, x_planar, extra=None):
+        """x + Lin2(Gate(Lin1(x))) [+ extra]  on planar rows."""
+        if self._tab is None:
+            self.compile(x_planar.device)
+        y = self.linear2(ops.gate(self.linear1(x_planar), self._tab, self._cst))
+        if self.resnet:
+            return ops.add_rows(x_planar, y, extra)
+        return y if extra is None else ops.add_rows(y, extra)
+
+
+class ConvBlockE3(nn.Module):
+    def __init__(self, irreps, irreps_sh, num_radial, radial_MLP):
+        super().__init__()
+        self.residual = ResidualBlock(irreps, irreps)
+        self.conv_tp = MessagePackBlock(irreps, irreps, irreps_sh, irreps, num_radial, radial_MLP)
+        self.skip_linear = E3Linear(irreps, irreps)
+
+    def compile(self, device):
+        self.residual.compile(device)
+        self.conv_tp.compile(device, unrotate=True)
+        self.skip_linear.compile(device)
+
+
+class PairInteractionBlock(nn.Module):
+    def __init__(self, irreps, irreps_sh, num_radial, radial_MLP, use_skip_connections=True, legacy_edge_update=False):
+        super().__init__()
+        self.use_skip_connections, self.legacy_edge_update = use_skip_connections, legacy_edge_update
+        self.linear_up_src = E3Linear(irreps, irreps)
+        self.linear_up_tar = E3Linear(irreps, irreps)
+        self.conv_tp = MessagePackBlock(irreps, irreps, irreps_sh, irreps, num_radial, radial_MLP)
+        if use_skip_connections:
+            self.skip_linear = E3Linear(irreps, irreps)
+
+    def compile(self, device):
+        self.linear_up_src.compile(device)
+        self.linear_up_tar.compile(device)
+        skip = self.skip_linear.weight.detach().cpu().double().numpy() if self.use_skip_connections else None
+        self.conv_tp.compile(device, unrotate=False, skip_weight=skip)       # skip o3.Linear fused as extra items
+
+
+class _EmbTP(nn.Module):
+    """TensorProductWithMemoryOptimizationWithWeight parameter holder (tensor_products.py:51-189)."""
+
+    def __init__(self, irreps_in, irreps_sh, irreps_out, num_radial, radial_MLP):
+        super().__init__()
+        self.tensor_product = E3TensorProduct(irreps_in, irreps_sh, irreps_out)
+        self.linear_scaler = LinearScaleWithWeights(self.tensor_product, Irreps(irreps_out))
+        self.weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.linear_scaler.weight_numel])
+
+
+class PairInteractionEmbeddingBlock(nn.Module):
+    def __init__(self, num_types, irreps_sh, irreps_out, num_radial, radial_MLP):
+        super().__init__()
+        self.num_types = num_types
+        attrs = Irreps([(num_types, 0, 1)])
+        self.irreps_sh, self.irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
+        self.linear_up_src = E3Linear(attrs, attrs)
+        self.linear_up_dst = E3Linear(attrs, attrs)
+        self.conv_tp = _EmbTP(attrs, self.irreps_sh, self.irreps_out, num_radial, radial_MLP)
+
+    def compile(self, device):
+        T = self.num_types
+        s = 1.0 / math.sqrt(T)
+        self._Ts = (self.linear_up_src.weight.detach().double().reshape(T, T) * s).float().contiguous().to(device)
+        self._Td = (self.linear_up_dst.weight.detach().double().reshape(T, T) * s).float().contiguous().to(device)
+        self._dp = ops.DeviceProgram(P.build_embedding_program(_np_sd(self.conv_tp), T, self.irreps_sh, self.irreps_out), device)
+        self._h = self.conv_tp.weight_generator.hidden_layers(device)
+        self._Tp = P.PlanarLayout([(T, 0, 1)]).dim
+
+    def run(self, z, geo: ops.Geometry):
+        x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, self.num_types, self._Tp)
+        h = ops.radial_hidden(geo.rbf, self._h, float(P.ACT_CONSTS[P.ACT_SILU]))
+        return ops.tp_fused(self._dp, [x], geo.E, h, None, geo)                # edge features, edge-aligned frame
+
+
+class HamLayer(nn.Module):
+    def __init__(self, irreps_in, ham_irreps: Irreps):
+        super().__init__()
+        self.irreps_in, self.ham_irreps = Irreps(irreps_in), ham_irreps
+        self.residual_block = ResidualBlock(irreps_in, irreps_in)
+        self.linear_transform = E3Linear(irreps_in, ham_irreps)
+
+    def compile(self, device):
+        self.residual_block.compile(device)
+        prog, self.girr, self.slot_pos = P.build_ham_linear_program(self.linear_transform.weight.detach().cpu().double().numpy(),
+                                                                    self.irreps_in, self.ham_irreps)
+        self._dp = ops.DeviceProgram(prog, device)
+
+    def forward(self, x_planar):
+        y = self.residual_block(x_planar)
+        return ops.tp_fused(self._dp, [y], y.shape[0])                          # planar rows grouped by (L,p)

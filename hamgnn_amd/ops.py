@@ -1,0 +1,171 @@
+"""Thin torch-tensor wrappers over the C ABI (include/hamgnn_hip.h).  PyTorch is plumbing here: device memory, streams.
+Every function launches hand-written HIP kernels from libhamgnn_hip.so; nothing falls back to torch arithmetic."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import plan as P
+from ._lib import check, f32, i32, i64, lib, ptr
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(arr: np.ndarray, device, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device)
+
+
+def _require_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("hamgnn_amd: the MI355X hot path needs CUDA(ROCm) tensors; there is no CPU fallback")
+
+
+class DeviceProgram:
+    """A plan.Program uploaded to the GPU."""
+
+    def __init__(self, prog: P.Program, device):
+        self.prog = prog
+        self.weights = _dev(prog.weights, device)
+        self.segs = _dev(prog.seg_table, device)
+        self.items = _dev(prog.item_table, device)
+        self.nseg = int(prog.seg_table.shape[0])
+        self.hidden = int(prog.hidden)
+        self.out_dim = int(prog.out_layout.dim)
+        self.lds_bytes = int(prog.tile_floats) * 4
+
+
+def wig_offsets(lmax):
+    offs, tot = P.wigner_offsets(lmax)
+    arr = (C.c_int * 8)(*([int(o) for o in offs] + [0] * (8 - len(offs))))
+    return arr, tot
+
+
+class Geometry:
+    """rbf, packed per-edge Wigner matrices and the receiver CSR of one graph batch (computed once per forward)."""
+
+    def __init__(self, pos, edge_index, nbr_shift, cutoff, num_radial, lmax, jtab_dev):
+        _require_gpu(pos)
+        E = edge_index.shape[1]
+        dev = pos.device
+        self.E, self.lmax = E, lmax
+        self.wig_off, self.nW = wig_offsets(lmax)
+        self.rbf = torch.empty(E, num_radial, device=dev, dtype=torch.float32)
+        self.wig = torch.empty(E, self.nW, device=dev, dtype=torch.float32)
+        self.length = torch.empty(E, device=dev, dtype=torch.float32)
+        ang = torch.empty(E, 4, device=dev, dtype=torch.float32)
+        pos = pos.contiguous().float()
+        self.edge_index = edge_index.contiguous()
+        nbr_shift = nbr_shift.contiguous().float()
+        check(lib().hg_edge_geometry(ptr(pos), ptr(self.edge_index), ptr(nbr_shift), i64(E), f32(cutoff), i32(num_radial), i32(lmax),
+                                     ptr(jtab_dev), ptr(self.rbf), ptr(self.wig), ptr(self.length), ptr(ang), _stream()), "hg_edge_geometry")
+        self.src = self.edge_index[0].contiguous()
+        self.dst = self.edge_index[1].contiguous()
+        self._csr = None
+
+    def receiver_csr(self, N):
+        """index preparation for the deterministic segmented node scatter (receiver = edge_index[1])."""
+        if self._csr is None:
+            perm = torch.sort(self.dst, stable=True).indices.contiguous()
+            counts = torch.bincount(self.dst, minlength=N)
+            rowptr = torch.zeros(N + 1, dtype=torch.int64, device=self.dst.device)
+            rowptr[1:] = torch.cumsum(counts, 0)
+            self._csr = (rowptr.contiguous(), perm)
+        return self._csr
+
+
+def radial_hidden(rbf: torch.Tensor, layers: Sequence[torch.Tensor], act_cst: float) -> torch.Tensor:
+    E = rbf.shape[0]
+    dims = [int(layers[0].shape[0])] + [int(w.shape[1]) for w in layers]
+    W = torch.cat([w.reshape(-1) for w in layers]).contiguous()
+    out = torch.empty(E, dims[-1], device=rbf.device, dtype=torch.float32)
+    darr = (C.c_int * len(dims))(*dims)
+    check(lib().hg_radial_hidden(ptr(rbf), i64(E), ptr(W), darr, i32(len(layers)), f32(act_cst), ptr(out), _stream()), "hg_radial_hidden")
+    return out
+
+
+def rotate_gather(x: torch.Tensor, idx: Optional[torch.Tensor], geo: Geometry, elem_tab: torch.Tensor, transpose=False) -> torch.Tensor:
+    E = geo.E
+    Dp = int(elem_tab.shape[0])
+    out = torch.empty(E, Dp, device=x.device, dtype=torch.float32)
+    check(lib().hg_rotate_gather(ptr(x), i64(x.stride(0)), ptr(idx), ptr(geo.wig), i32(geo.nW), geo.wig_off, ptr(elem_tab), i32(Dp),
+                                 i64(E), i32(1 if transpose else 0), ptr(out), i64(Dp), _stream()), "hg_rotate_gather")
+    return out
+
+
+def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None) -> torch.Tensor:
+    _require_gpu(srcs[0])
+    out = torch.zeros(rows, dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # channel padding must stay finite (zero)
+    n = len(srcs)
+    sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
+    ss = (C.c_int64 * 4)(*([int(s.stride(0)) for s in srcs] + [0] * (4 - n)))
+    wig, nW, woff = (ptr(geo.wig), geo.nW, geo.wig_off) if geo is not None else (C.c_void_p(0), 0, (C.c_int * 8)())
+    check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
+                            i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), _stream()), "hg_tp_fused")
+    return out
+
+
+def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, N: int) -> torch.Tensor:
+    Dp = msg.shape[1]
+    out = torch.empty(N, Dp, device=msg.device, dtype=torch.float32)
+    check(lib().hg_segment_sum(ptr(msg), i64(msg.stride(0)), ptr(rowptr), ptr(perm), i64(N), i32(Dp), ptr(out), i64(Dp), _stream()), "hg_segment_sum")
+    return out
+
+
+def gate(x: torch.Tensor, tab: torch.Tensor, consts: torch.Tensor) -> torch.Tensor:
+    rows, Dout = x.shape[0], int(tab.shape[0])
+    out = torch.empty(rows, Dout, device=x.device, dtype=torch.float32)
+    check(lib().hg_gate(ptr(x), i64(x.stride(0)), ptr(tab), i32(Dout), ptr(consts), i64(rows), ptr(out), i64(Dout), _stream()), "hg_gate")
+    return out
+
+
+def add_rows(a, b, c=None):
+    rows, D = a.shape
+    out = torch.empty_like(a)
+    check(lib().hg_add_rows(ptr(a), i64(a.stride(0)), ptr(b), i64(b.stride(0)), ptr(c), i64(c.stride(0) if c is not None else 0), i64(rows),
+                            i32(D), ptr(out), i64(D), _stream()), "hg_add_rows")
+    return out
+
+
+def to_planar(x: torch.Tensor, imap: torch.Tensor, Dp: int) -> torch.Tensor:
+    x = x.contiguous().float()
+    out = torch.empty(x.shape[0], Dp, device=x.device, dtype=torch.float32)
+    check(lib().hg_to_planar(ptr(x), i64(x.shape[0]), i32(x.shape[1]), ptr(imap), ptr(out), i32(Dp), _stream()), "hg_to_planar")
+    return out
+
+
+def from_planar(xp: torch.Tensor, imap: torch.Tensor) -> torch.Tensor:
+    D = int(imap.shape[0])
+    out = torch.empty(xp.shape[0], D, device=xp.device, dtype=torch.float32)
+    check(lib().hg_from_planar(ptr(xp), i64(xp.shape[0]), i32(xp.shape[1]), ptr(imap), ptr(out), i32(D), _stream()), "hg_from_planar")
+    return out
+
+
+def embed_lookup(Ta, Tb, z, idx_a, idx_b, rows, T, Tp):
+    out = torch.empty(rows, Tp, device=Ta.device, dtype=torch.float32)
+    check(lib().hg_embed_lookup(ptr(Ta), ptr(Tb), ptr(z), ptr(idx_a), ptr(idx_b), i64(rows), i32(T), i32(Tp), ptr(out), _stream()), "hg_embed_lookup")
+    return out
+
+
+def ham_merge(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, nao2):
+    rows = coeff.shape[0]
+    out = torch.empty(rows, nao2, device=coeff.device, dtype=torch.float32)
+    wig, nW, woff = (ptr(geo.wig), geo.nW, geo.wig_off) if geo is not None else (C.c_void_p(0), 0, (C.c_int * 8)())
+    check(lib().hg_ham_merge(ptr(coeff), i64(coeff.stride(0)), wig, i32(nW), woff, ptr(slot_tab), i32(nao2), ptr(cg_ptr), ptr(cg_idx),
+                             ptr(cg_val), i32(nao2), i64(rows), ptr(out), _stream()), "hg_ham_merge")
+    return out
+
+
+def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetrize=True):
+    rows = Hraw.shape[0]
+    out = torch.empty_like(Hraw)
+    check(lib().hg_ham_finish(ptr(Hraw), ptr(inv), ptr(H0), ptr(orb_mask), ptr(z), ptr(idx_a), ptr(idx_b), i32(nao), f32(sign),
+                              i32(1 if symmetrize else 0), i64(rows), ptr(out), _stream()), "hg_ham_finish")
+    return out

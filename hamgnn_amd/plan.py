@@ -118,7 +118,7 @@ class Program:
     seg_items: List[List[List[int]]] = field(default_factory=list)    # per segment: item records (kept contiguous per segment)
     chunks: List[np.ndarray] = field(default_factory=list)
     _woff: int = 0
-    tile_floats: int = 0                              # max LDS tile floats per 64 edges (for launch config)
+    tile_floats: int = 0                              # dynamic LDS floats per workgroup (4 wave-private tiles)
     flops_per_row: float = 0.0                        # algorithmic (unpadded) flops per edge/row
     mfma_per_wave: int = 0                            # issued MFMAs per 16-row wave tile (padded)
 
@@ -160,7 +160,7 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     rto = ceil_div(mul_k, 16)
     prog.segs.append([lk, mul_k, rto, lay.off[out_index], lay.mulp[out_index], 0, 0, flags])
     prog.seg_items.append([])
-    prog.tile_floats = max(prog.tile_floats, rto * 16 * ((2 * lk + 1) * 64 + 4))
+    prog.tile_floats = max(prog.tile_floats, 4 * rto * 16 * ((2 * lk + 1) * 16 + 4))   # 4 wave-private tiles
     return len(prog.segs) - 1
 
 
@@ -384,3 +384,179 @@ def radial_hidden_weights(sd: Dict[str, np.ndarray], prefix: str, act_cst: float
         W = np.asarray(sd[k], dtype=np.float64)
         out.append((W / math.sqrt(W.shape[0])).astype(np.float32))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ small device tables
+
+# e3nn normalize2mom constants (E_{z~N(0,1)}[act(z)^2]^(-1/2), e3nn's 1e6-sample Monte-Carlo recipe with CPU seed 0; values
+# reproduced with torch 2.10).  Index = activation id of csrc/aux_kernels.hip:hg_act.
+ACT_NONE, ACT_SSP, ACT_TANH, ACT_SILU, ACT_ABS = 0, 1, 2, 3, 4
+ACT_CONSTS = np.array([1.0, 1.878204668541552, 1.5937334472592692, 1.6791767923989418, 1.0], dtype=np.float32)
+
+
+def wigner_jtab(lmax) -> np.ndarray:
+    Js, sg = [], []
+    for l in range(lmax + 1):
+        J, s = so3.wigner_tables(l)
+        Js.append(J.reshape(-1))
+        sg.append(s)
+    return np.concatenate(Js + sg).astype(np.float32)
+
+
+def rotate_table(layout: PlanarLayout) -> np.ndarray:
+    """int32[Dp][4] = {l (or -1 for channel padding), component a, planar index of (b=0, u), mulp}."""
+    tab = np.full((layout.dim, 4), -1, dtype=np.int32)
+    for (mul, l, p), off, mp in zip(layout.irreps, layout.off, layout.mulp):
+        for a in range(2 * l + 1):
+            for u in range(mul):
+                tab[off + a * mp + u] = (l, a, off + u, mp)
+    return tab
+
+
+def gate_tables(feature_irreps):
+    """Layouts + element table of the reference ResidualBlock's e3nn Gate (interaction_blocks.py:311-323; irreps2gate
+    utils/irreps_utils.py:33-65; e3nn Gate = _Sortcut(sorted+simplified input) -> Activation / ElementwiseTensorProduct).
+    Returns (irreps_gate_in, irreps_gate_out, table int32[Dout_planar][4])."""
+    feats = Irreps(feature_irreps)
+    scalars = Irreps([(m, l, p) for m, l, p in feats if l == 0]).simplify()
+    gated = Irreps([(m, l, p) for m, l, p in feats if l != 0]).simplify()
+    gates = Irreps([(m, 0, 1) for m, _, _ in gated]).simplify()
+    entries = [("s", i, it) for i, it in enumerate(scalars)] + [("g", i, it) for i, it in enumerate(gates)] + \
+              [("d", i, it) for i, it in enumerate(gated)]
+    order = sorted(range(len(entries)), key=lambda i: ((entries[i][2][1], entries[i][2][2]), i))
+    merged, where = [], {}                      # where[(grp, idx)] = (merged entry, channel offset)
+    for i in order:
+        grp, idx, (m, l, p) = entries[i]
+        if merged and merged[-1][1:] == (l, p):
+            where[(grp, idx)] = (len(merged) - 1, merged[-1][0])
+            merged[-1] = (merged[-1][0] + m, l, p)
+        else:
+            where[(grp, idx)] = (len(merged), 0)
+            merged.append((m, l, p))
+    irr_in = Irreps(merged)
+    lay_in = PlanarLayout(irr_in)
+    # scalar activations: even scalars -> ssp, odd -> tanh (odd act keeps parity); gates (0e) -> ssp
+    out_items = [(m, 0, p) for m, _, p in scalars] + list(gated.items)
+    irr_out = Irreps(out_items)
+    lay_out = PlanarLayout(irr_out)
+    tab = np.full((lay_out.dim, 4), -1, dtype=np.int32)
+    for i, (m, _, p) in enumerate(scalars):
+        me, u0 = where[("s", i)]
+        act = ACT_SSP if p == 1 else ACT_TANH
+        for u in range(m):
+            tab[lay_out.off[i] + u] = (lay_in.off[me] + u0 + u, act, -1, 0)
+    gate_pos = []                               # planar input index of every gate channel, in gate order
+    for i, (m, _, _) in enumerate(gates):
+        me, u0 = where[("g", i)]
+        gate_pos += [lay_in.off[me] + u0 + u for u in range(m)]
+    gc = 0
+    for i, (m, l, p) in enumerate(gated):
+        me, u0 = where[("d", i)]
+        oi = len(scalars) + i
+        for u in range(m):
+            for a in range(2 * l + 1):
+                tab[lay_out.off[oi] + a * lay_out.mulp[oi] + u] = (lay_in.off[me] + a * lay_in.mulp[me] + u0 + u, ACT_NONE, gate_pos[gc + u], ACT_SSP)
+        gc += m
+    return irr_in, irr_out, tab
+
+
+def ham_irreps(row: Irreps):
+    """hamiltonian_irreps of the reference head (hamgnn_output.py:258-272): per (row shell, col shell) all L, parity (-1)^(li+lj)."""
+    out = []
+    for _, li, _ in row:
+        for _, lj, _ in row:
+            for L in range(abs(li - lj), li + lj + 1):
+                out.append((1, L, (-1) ** (li + lj)))
+    return Irreps(out)
+
+
+def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps):
+    """o3.Linear(D -> hamiltonian_irreps) (HamLayer.linear_transform, hamgnn_output.py:49,56) regrouped by (L,p) so that the
+    89..312 multiplicity-1 outputs become a handful of GEMM segments.  Returns (program, grouped irreps, slot->(group, col))."""
+    irreps_in = Irreps(irreps_in)
+    groups, slot_pos = [], []
+    key_to_g = {}
+    for s, (_, L, p) in enumerate(hirr):
+        if (L, p) not in key_to_g:
+            key_to_g[(L, p)] = len(groups)
+            groups.append([0, L, p])
+        g = key_to_g[(L, p)]
+        slot_pos.append((g, groups[g][0]))
+        groups[g][0] += 1
+    girr = Irreps([tuple(g) for g in groups])
+    # e3nn flat weight order: for i_in, for i_out (matching ir): block (mul_in, 1)
+    mats = {}
+    fan = {}
+    off = 0
+    for i, (mi, li, pi) in enumerate(irreps_in):
+        for s, (_, L, p) in enumerate(hirr):
+            if (li, pi) == (L, p):
+                g, col = slot_pos[s]
+                M = mats.setdefault((i, g), np.zeros((mi, girr[g][0])))
+                M[:, col] = weight[off:off + mi]
+                off += mi
+                fan[s] = fan.get(s, 0) + mi
+    assert off == weight.size, (off, weight.size)
+    prog, seg_of_k = new_program(girr, 0)
+    in_layout = PlanarLayout(irreps_in)
+    for (i, g), M in mats.items():
+        mi, li, _ = irreps_in[i]
+        cols_fan = np.array([fan[s] for s in range(len(hirr)) if slot_pos[s][0] == g], dtype=np.float64)
+        Mn = M / np.sqrt(cols_fan)[None, :]
+        mk = girr[g][0]
+        nc = 2 * li + 1
+        chunk = rtm_max(nc) * 16
+        ksteps = in_layout.mulp[i] // 4
+        for r0 in range(0, mk, chunk):
+            r1 = min(mk, r0 + chunk)
+            rtm = ceil_div(r1 - r0, 16)
+            a1_off = prog.add_weights(_frag_A(Mn[:, r0:r1], ksteps, rtm)[None])
+            _add_item(prog, seg_of_k[g], IT_LIN, [0], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0, a1_off, 0, 0, 0, r1 - r0, row_off=r0)
+        prog.flops_per_row += 2.0 * mi * mk * nc
+    return prog.finalize(), girr, slot_pos
+
+
+def ham_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, slot_pos):
+    """slot table + CSR Clebsch-Gordan table of hg_ham_merge (merge_tensor_components hamgnn_output.py:851-891 followed by
+    reorder_matrix :1056-1096 folded in)."""
+    glay = PlanarLayout(girr)
+    hirr = ham_irreps(row)
+    slot_tab = np.zeros((nao * nao, 4), dtype=np.int32)
+    coef_off = []
+    q = 0
+    for s, (_, L, p) in enumerate(hirr):
+        g, col = slot_pos[s]
+        coef_off.append(q)
+        for a in range(2 * L + 1):
+            slot_tab[q] = (L, a, glay.off[g] + col, glay.mulp[g])
+            q += 1
+    assert q == nao * nao
+    entries = [[] for _ in range(nao * nao)]          # per merged (pre-reorder) element: list of (coef index, value)
+    s = 0
+    r0 = 0
+    for _, li, _ in row:
+        c0 = 0
+        for _, lj, _ in row:
+            for L in range(abs(li - lj), li + lj + 1):
+                cg = math.sqrt(2 * L + 1) * so3.wigner_3j(li, lj, L)
+                for a in range(2 * li + 1):
+                    for b in range(2 * lj + 1):
+                        for M in range(2 * L + 1):
+                            if abs(cg[a, b, M]) > 1e-14:
+                                entries[(r0 + a) * nao + (c0 + b)].append((coef_off[s] + M, cg[a, b, M]))
+                s += 1
+            c0 += 2 * lj + 1
+        r0 += 2 * li + 1
+    ic = list(range(nao)) if index_change is None else list(index_change)
+    sign = np.ones(nao)
+    if minus_index is not None:
+        sign[list(minus_index)] = -1
+    ptr, idx, val = [0], [], []
+    for r in range(nao):
+        for c in range(nao):
+            sg = sign[r] * sign[c]
+            for (ci, v) in entries[ic[r] * nao + ic[c]]:
+                idx.append(ci)
+                val.append(sg * v)
+            ptr.append(len(idx))
+    return slot_tab, np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(val, np.float32)

@@ -1,0 +1,102 @@
+/* hamgnn_hip.h -- C ABI of libhamgnn_hip.so: the MI355X (gfx950) drop-in for HamGNN's equivariant message-passing
+ * hot path.  The reference (QuantumLab-ZY/HamGNN) has NO native/FFI interface on this path: its boundary is the Python
+ * module API (hamgnn/models/hamgnn_conv.py:88,248 ; hamgnn/models/hamgnn_output.py:96,2916).  Each entry point below
+ * therefore names the reference *PyTorch-op cluster* it replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator in the Python host layer) EXCEPT the tiny
+ *    host arrays `src`, `src_stride`, `wig_off`, `dims` (<= 8 entries, copied into the kernel arguments); no hidden
+ *    allocation, no host synchronisation; `stream` is a hipStream_t passed as void*.
+ *  - features use the PLANAR layout of hamgnn_amd/plan.py: per irrep (mul,l,p) a block [2l+1][mulp], mulp = ceil4(mul).
+ *  - return value: 0 = ok, negative = error (hg_last_error() gives the text).  Plain C types only.
+ */
+#ifndef HAMGNN_HIP_H
+#define HAMGNN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* hg_last_error(void);
+int hg_version(void);
+
+/* (a1+a2) SphericalHarmonicEdgeAttrs.forward  hamgnn/toolbox/nequip/nn/embedding/_edge.py:59-67
+ *         RadialBasisEdgeEncoding.forward      hamgnn/nn/embeddings.py:73-100  (+ utils/basis_functions.py:193-208,
+ *         utils/cutoff_functions.py:50-61).
+ * Per edge e (j = edge_index[0][e] centre, i = edge_index[1][e] neighbour): v = pos[i] + nbr_shift[e] - pos[j];
+ * rbf[e][n] = sin((n+1) pi r / rc)/r * 0.5 (cos(pi r/rc)+1) [r<rc];  wig[e] = packed Wigner matrices D^l(R_e), l=0..lmax_wig,
+ * of the rotation that takes the edge direction onto the pole (edge-aligned frame; replaces the explicit SH tensor);
+ * sh (nullable) = component-normalised real SH of v[[1,2,0]] up to lmax_sh, for API parity / tests.
+ * jtab: DEVICE copy of the constants from hamgnn_amd/so3.py:wigner_tables, packed [sum (2l+1)^2] J matrices then
+ * [sum (l+1)] sine signs.  ang_scratch: caller-provided [E][4] floats (rotation angles; no hidden allocation).        */
+int hg_edge_geometry(const float* pos, const int64_t* edge_index, const float* nbr_shift, int64_t E, float cutoff,
+                     int num_radial, int lmax_wig, const float* jtab, float* rbf, float* wig, float* edge_len,
+                     float* ang_scratch, void* stream);
+
+/* e3nn FullyConnectedNet hidden layers (all but the last) of a radial weight generator:
+ * hamgnn/nn/message_passing.py:173-189, 218, 223 ; tensor_products.py:152-168, 183.
+ * h = act(... act(rbf @ W0) @ W1 ...), act(x) = act_cst * silu(x); W_k [dims[k], dims[k+1]] already scaled by 1/sqrt(h_in). */
+int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const int32_t* dims, int nlayers, float act_cst,
+                     float* h_out, void* stream);
+
+/* node_features[sender] / [receiver] gathers of ConvBlockE3.forward (hamgnn/nn/convolution.py:138-141) and
+ * PairInteractionBlock.forward (interaction_blocks.py:141-145), fused with the rotation into the edge-aligned frame:
+ * out[e][i][a][u] = sum_b D_e^{l_i}[a][b] x[idx[e]][i][b][u]   (idx == NULL: identity gather; transpose != 0: D^T).
+ * elem_tab: int32[Dp][4] = {l, a, base_in, mulp} per output element (hamgnn_amd/plan.py:rotate_table).              */
+int hg_rotate_gather(const float* x, int64_t x_stride, const int64_t* idx, const float* wig, int nW, const int32_t* wig_off,
+                     const int32_t* elem_tab, int Dp, int64_t E, int transpose, float* out, int64_t out_stride, void* stream);
+
+/* THE hot kernel.  Replaces, per launch, one whole MessagePackBlock.forward (hamgnn/nn/message_passing.py:191-231:
+ * AttentionHeadsToVector + 2 x o3.TensorProduct(uvw, ~255 paths each) + 2 x LinearScaleWithWeights (tensor_products.py:25-47)
+ * + last radial-MLP layer + 2 x o3.Linear) [+ PairInteractionBlock skip linear, interaction_blocks.py:151-152]; the
+ * embedding TP (tensor_products.py:170-189); or any o3.Linear (IT_LIN items).  Programs come from hamgnn_amd/plan.py.
+ * src[k]/src_stride[k]: planar source rows (slot 0: rotated src-node rows, 1: rotated dst-node rows, 2: edge rows).
+ * rows: number of edges (or nodes for node-level linears).  lds_bytes: prog.tile_floats*4 (dynamic LDS).             */
+int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
+                int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights,
+                const int32_t* seg_table, int nseg, const int32_t* item_table, float* out, int64_t out_stride,
+                int64_t rows, int lds_bytes, void* stream);
+
+/* torch_scatter.scatter(messages, receiver, dim_size=N) of ConvBlockE3.forward (hamgnn/nn/convolution.py:147-149) as a
+ * deterministic segmented reduction: out[n] = sum_{q in [rowptr[n], rowptr[n+1])} msg[perm[q]].                     */
+int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_t* rowptr, const int64_t* perm, int64_t N, int Dp,
+                   float* out, int64_t out_stride, void* stream);
+
+/* e3nn Gate of ResidualBlock (hamgnn/nn/interaction_blocks.py:311-323, 348) on planar rows, optionally fused with the
+ * residual/skip adds.  tab: int32[Dout][4] = {src index, act id (0 none,1 ssp,2 tanh,3 silu,4 abs), gate index or -1, gate act id}.
+ * consts[act id] = normalize2mom constant.                                                                          */
+int hg_gate(const float* x, int64_t x_stride, const int32_t* tab, int Dout, const float* consts, int64_t rows, float* out,
+            int64_t out_stride, void* stream);
+
+/* y = a + b (+ c) on [rows, D] planar rows: ResidualBlock "+x" (interaction_blocks.py:355-356), ConvBlockE3 "+= skip"
+ * (convolution.py:155-156).  c may be NULL.                                                                         */
+int hg_add_rows(const float* a, int64_t sa, const float* b, int64_t sb, const float* c, int64_t sc, int64_t rows, int D,
+                float* out, int64_t so, void* stream);
+
+/* layout conversion e3nn [u][a] <-> planar [a][mulp] via an index map (int32[D_e3nn] -> planar index).               */
+int hg_to_planar(const float* x, int64_t rows, int D, const int32_t* map, float* out, int Dp, void* stream);
+int hg_from_planar(const float* xp, int64_t rows, int Dp, const int32_t* map, float* out, int D, void* stream);
+
+/* embedding source rows: out[e][t] = Ts[z[src[e]]][t] + Td[z[dst[e]]][t]   (PairInteractionEmbeddingBlock.forward,
+ * hamgnn/nn/embeddings.py:325-326 with one-hot node attrs: the two o3.Linear are row look-ups);
+ * idx_b == NULL => single table (chemical embedding AtomwiseLinear, toolbox/nequip/nn/_atomwise.py:55-57).           */
+int hg_embed_lookup(const float* Ta, const float* Tb, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b,
+                    int64_t rows, int T, int Tp, float* out, void* stream);
+
+/* Read-out head, stage 1 (hamgnn/models/hamgnn_output.py:851-891 merge_tensor_components + :1056-1096 reorder_matrix):
+ * coeff: planar rows of the HamLayer output regrouped by (L,p) (rotated frame if wig != NULL -> un-rotated here);
+ * cg_tab: sparse list {out element (row*nao+col, after reorder and sign), coeff slot, value}; Hraw[e][nao*nao].       */
+int hg_ham_merge(const float* coeff, int64_t c_stride, const float* wig, int nW, const int32_t* wig_off,
+                 const int32_t* slot_tab, int nslots, const int32_t* cg_ptr, const int32_t* cg_idx, const float* cg_val,
+                 int nao2, int64_t rows, float* Hraw, void* stream);
+
+/* Read-out head, stage 2 (:1231-1285 symmetrize, :3782-3795 +H0, :2288-2365 orbital masks):
+ * H[e] = mask(z_a, z_b) * (0.5 (Hraw[e] + sign * Hraw[inv[e]]^T) + H0[e]);  inv == NULL => on-site (own transpose).   */
+int hg_ham_finish(const float* Hraw, const int64_t* inv, const float* H0, const float* orb_mask, const int64_t* z,
+                  const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int symmetrize, int64_t rows, float* H,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,184 @@
+"""GPU parity checks (HIP path through the C ABI vs the CPU oracle / committed golden fixtures).  Used by
+tests/test_gpu_parity.py (-m gpu) and by __graft_entry__.smoke().  Nothing here reads /root/reference."""
+import json
+import math
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+MINI, SH = "8x0e+4x0o+4x1o+2x1e+2x2o+3x2e+2x3o", "0e+1o+2e+3o"
+TOL = 1e-5          # north_star: within 1e-5 relative (fp32) of the reference path
+
+
+def load(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False)
+    out = {}
+    for k in z.files:
+        g, kk = k.split("/", 1)
+        out.setdefault(g, {})[kk] = z[k]
+    return out
+
+
+def rel(a, b):
+    a = a.detach().double().cpu() if torch.is_tensor(a) else torch.as_tensor(a, dtype=torch.float64)
+    b = b.detach().double().cpu() if torch.is_tensor(b) else torch.as_tensor(b, dtype=torch.float64)
+    return ((a - b).abs().max() / b.abs().max()).item()
+
+
+def load_weights(module, weights: dict):
+    """reference-named arrays -> module parameters; every parameter must be covered."""
+    sd = {k: torch.as_tensor(v) for k, v in weights.items()}
+    res = module.load_state_dict(sd, strict=False)
+    params = set(dict(module.named_parameters()))
+    assert not (set(res.missing_keys) & params), sorted(set(res.missing_keys) & params)[:5]
+    return module
+
+
+def to_graph(gd, device, dtype=torch.float32):
+    from hamgnn_amd.data import Graph
+    g = Graph()
+    for k, v in gd.items():
+        t = torch.as_tensor(v)
+        if t.is_floating_point():
+            t = t.to(dtype)
+        g[k] = t.to(device)
+    return g
+
+
+def check_geometry(device="cuda"):
+    """edge frames + radial basis vs host float64 reference implementations."""
+    from hamgnn_amd import ops, plan as P, so3
+    rng = np.random.default_rng(0)
+    E, lmax, R, rc = 257, 6, 64, 26.0
+    v = rng.normal(size=(E, 3)) * 5.0
+    v[0] = (0, 0, 3.0)          # pole
+    v[1] = (0, 0, -3.0)         # anti-pole
+    v[2] = (2.0, 0, 0)
+    pos = torch.zeros(2, 3)
+    ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.long)])
+    jtab = torch.from_numpy(P.wigner_jtab(lmax)).to(device)
+    geo = ops.Geometry(pos.to(device), ei.to(device), torch.from_numpy(v).float().to(device), rc, R, lmax, jtab)
+    torch.cuda.synchronize()
+    v32 = v.astype(np.float32).astype(np.float64)
+    r = np.linalg.norm(v32, axis=1)
+    n = np.stack([v32[:, 1], v32[:, 2], v32[:, 0]], 1) / r[:, None]
+    offs, _ = P.wigner_offsets(lmax)
+    werr = 0.0
+    wig = geo.wig.double().cpu().numpy()
+    for e in range(0, E, 7):
+        for l in range(lmax + 1):
+            D = so3.edge_wigner(l, n[e])
+            werr = max(werr, np.abs(wig[e, offs[l]:offs[l] + (2 * l + 1) ** 2].reshape(2 * l + 1, -1) - D).max())
+    freqs = np.arange(1, R + 1) * math.pi / rc
+    rbf = np.sin(r[:, None] * freqs[None]) / r[:, None] * (0.5 * (np.cos(r * math.pi / rc) + 1) * (r < rc))[:, None]
+    rerr = np.abs(geo.rbf.double().cpu().numpy() - rbf).max() / np.abs(rbf).max()
+    return {"wigner_abs_err": werr, "rbf_rel_err": rerr}
+
+
+def check_message_pack(device="cuda", unrotate=True):
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    f = load("message_pack_block")
+    i = f["inputs"]
+    m = load_weights(hnn.MessagePackBlock(MINI, MINI, SH, MINI, 8, [16, 16]), f["weights"])
+    m.compile(device, unrotate=unrotate)
+    lay = P.PlanarLayout(MINI)
+    E = i["src"].shape[0]
+    n = i["sh"][:, 1:4] / math.sqrt(3.0)
+    v = np.stack([n[:, 2], n[:, 0], n[:, 1]], 1) * 2.0                      # physical (x,y,z)
+    jtab = torch.from_numpy(P.wigner_jtab(3)).to(device)
+    ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.long)]).to(device)
+    geo = ops.Geometry(torch.zeros(2, 3, device=device), ei, torch.from_numpy(v).float().to(device), 8.0, 8, 3, jtab)
+    geo.rbf = torch.from_numpy(i["rbf"]).float().to(device).contiguous()
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    rot = torch.from_numpy(P.rotate_table(lay)).to(device)
+    pl = lambda k: ops.to_planar(torch.from_numpy(i[k]).float().to(device), imap, lay.dim)
+    xs, xd, fe = (ops.rotate_gather(pl(k), None, geo, rot) for k in ("src", "dst", "edge_feats"))
+    out = m.run(xs, xd, fe, geo)
+    if not unrotate:
+        out = ops.rotate_gather(out, None, geo, rot, transpose=True)
+    y = ops.from_planar(out, imap)
+    torch.cuda.synchronize()
+    return {"message_pack_rel_err": rel(y, f["outputs"]["out"])}
+
+
+def build_backbone_from_fixture(device="cuda"):
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    f = load("backbone")
+    cfg = json.loads(str(f["meta"]["cfg"]))
+    m = load_weights(HamGNNConvE3(cfg), f["weights"])
+    return m, f
+
+
+def check_backbone(device="cuda"):
+    m, f = build_backbone_from_fixture(device)
+    g = to_graph(f["graph"], device)
+    rep = m(g)
+    torch.cuda.synchronize()
+    return {"backbone_node_rel_err": rel(rep["node_attr"], f["outputs"]["node_attr"]),
+            "backbone_edge_rel_err": rel(rep["edge_attr"], f["outputs"]["edge_attr"])}
+
+
+def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, use_planar_path=False):
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load(name)
+    m = load_weights(HamGNNPlusPlusOut(MINI, MINI, nao_max=nao, ham_type=ham_type, ham_only=True, symmetrize=True, add_H0=True,
+                                       soc_switch=False, calculate_sparsity=True), f["weights"])
+    bb = load("backbone")["graph"]
+    gd = dict(f["graph"])
+    for k in ("pos", "nbr_shift", "cell"):
+        gd[k] = bb[k]
+    g = to_graph(gd, device)
+    rep = {"node_attr": torch.from_numpy(f["inputs"]["node_attr"]).float().to(device),
+           "edge_attr": torch.from_numpy(f["inputs"]["edge_attr"]).float().to(device)}
+    out = m(g, rep)
+    torch.cuda.synchronize()
+    return {name + "_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"]), "sparsity_ratio": float(out["sparsity_ratio"])}
+
+
+def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, nao=19, num_layers=2, radial=(16, 16), num_radial=8):
+    """Seeded random weights on a synthetic periodic cell: full backbone + head, HIP (fp32) vs oracle (fp64, CPU)."""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    cfg = dict(num_types=96, irreps_edge_sh=sh, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=num_radial, num_layers=num_layers, irreps_node_features=irreps, use_kan=False,
+               radial_MLP=list(radial), correlation=2, num_hidden_features=16, radius_type="openmx", use_corr_prod=False,
+               legacy_edge_update=False, lite_mode=False)
+    torch.manual_seed(666 + seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.HamGNNConvE3(cfg)
+        ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True)
+    finally:
+        torch.set_default_dtype(prev)
+    g = S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004)
+    S.add_random_targets(g, nao, seed=seed)
+    hip = load_weights(HamGNNConvE3(cfg), {k: v for k, v in ref.state_dict().items()})
+    hip_head = load_weights(HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                              soc_switch=False), {k: v for k, v in ref_head.state_dict().items()})
+    g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    with torch.no_grad():
+        rep_ref = ref(g64)
+        H_ref = ref_head(g64, rep_ref)["hamiltonian"]
+        gd = g.to(device)
+        rep = hip(gd)
+        H = hip_head(gd, rep)["hamiltonian"]
+    torch.cuda.synchronize()
+    return {"E": g.num_edges, "node_rel_err": rel(rep["node_attr"], rep_ref["node_attr"]), "edge_rel_err": rel(rep["edge_attr"], rep_ref["edge_attr"]),
+            "H_rel_err": rel(H, H_ref), "H_mae": (H.double().cpu() - H_ref).abs().mean().item()}
+
+
+def smoke_check():
+    r = {}
+    r.update(check_geometry())
+    r.update(check_message_pack())
+    r.update(check_backbone())
+    print("smoke:", json.dumps(r))
+    assert r["wigner_abs_err"] < 5e-6 and r["rbf_rel_err"] < 1e-6
+    assert r["message_pack_rel_err"] < TOL and r["backbone_node_rel_err"] < TOL and r["backbone_edge_rel_err"] < TOL
+    return r

@@ -1,0 +1,46 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle / golden fixtures.  Tolerance: 1e-5 relative (max-norm),
+the north_star's fp32 bar."""
+import pytest
+import torch
+
+from tests import gpu_checks as G
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def test_geometry():
+    r = G.check_geometry()
+    print(r)
+    assert r["wigner_abs_err"] < 5e-6 and r["rbf_rel_err"] < 1e-6
+
+
+@pytest.mark.parametrize("unrotate", [True, False])
+def test_message_pack_block_golden(unrotate):
+    r = G.check_message_pack(unrotate=unrotate)
+    print(r)
+    assert r["message_pack_rel_err"] < G.TOL
+
+
+def test_backbone_golden():
+    r = G.check_backbone()
+    print(r)
+    assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
+
+
+@pytest.mark.parametrize("name,ham_type,nao", [("head_openmx_19", "openmx", 19), ("head_abacus_13", "abacus", 13)])
+def test_head_golden(name, ham_type, nao):
+    r = G.check_head(name=name, ham_type=ham_type, nao=nao)
+    print(r)
+    assert r[name + "_rel_err"] < G.TOL
+
+
+def test_full_forward_vs_oracle_random_cell():
+    r = G.oracle_vs_hip_random()
+    print(r)
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
