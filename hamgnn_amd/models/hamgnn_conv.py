@@ -11,6 +11,7 @@ from torch import nn
 
 from .. import nn as hnn
 from .. import ops
+from .. import parallel
 from .. import plan as P
 from ..so3 import Irreps
 
@@ -111,13 +112,13 @@ class HamGNNConvE3(nn.Module):
             xd = ops.rotate_gather(node, geo.dst, geo, self._rot_tab)
             msg = conv.conv_tp.run(xs, xd, f, geo)                                   # global frame (un-rotated in the epilogue)
             agg = ops.segment_sum(msg, rowptr, perm, N)
+            parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
             node = conv.residual(agg, extra=skip)
             # ---- PairInteractionBlock.forward (interaction_blocks.py:130-164)
             xs = ops.rotate_gather(pair.linear_up_src(node), geo.src, geo, self._rot_tab)
             xd = ops.rotate_gather(pair.linear_up_tar(node), geo.dst, geo, self._rot_tab)
-            mix = pair.conv_tp.run(xs, xd, f, geo)                                   # stays in the edge frame (+ fused skip linear)
-            if pair.use_skip_connections or not pair.legacy_edge_update:
-                f = mix
+            if pair.use_skip_connections or not pair.legacy_edge_update:           # legacy layer-0: edge features kept (:154-156)
+                f = pair.conv_tp.run(xs, xd, f, geo)                                # stays in the edge frame (+ fused skip linear)
         rep = Representation()
         rep["node_attr"] = ops.from_planar(node, self._imap)
         rep["edge_attr"] = ops.from_planar(ops.rotate_gather(f, None, geo, self._rot_tab, transpose=True), self._imap)

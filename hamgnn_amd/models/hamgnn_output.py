@@ -100,7 +100,7 @@ class HamGNNPlusPlusOut(nn.Module):
     def _global_inverse(data):
         src = data.edge_index[0]
         batch = getattr(data, "batch", None)
-        if batch is None:
+        if batch is None or data.get("_hg_inv_is_local_global", False):
             return data.inv_edge_idx.contiguous(), None
         b = batch[src]
         counts = torch.bincount(b, minlength=int(data.node_counts.shape[0]) if hasattr(data, "node_counts") else 0)

@@ -128,7 +128,7 @@ class MessagePackBlock(nn.Module):
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
         hn = ops.radial_hidden(geo.rbf, self._hn, cst)
         he = ops.radial_hidden(geo.rbf, self._he, cst)
-        return ops.tp_fused(self._dp, [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo)
+        return ops.tp_fused(self._dp, [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo, tag="message_pack")
 
 
 class ResidualBlock(nn.Module):
@@ -220,7 +220,7 @@ class PairInteractionEmbeddingBlock(nn.Module):
     def run(self, z, geo: ops.Geometry):
         x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, self.num_types, self._Tp)
         h = ops.radial_hidden(geo.rbf, self._h, float(P.ACT_CONSTS[P.ACT_SILU]))
-        return ops.tp_fused(self._dp, [x], geo.E, h, None, geo)                # edge features, edge-aligned frame
+        return ops.tp_fused(self._dp, [x], geo.E, h, None, geo, tag="embedding")      # edge features, edge-aligned frame
 
 
 class HamLayer(nn.Module):

@@ -100,15 +100,25 @@ def rotate_gather(x: torch.Tensor, idx: Optional[torch.Tensor], geo: Geometry, e
     return out
 
 
-def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None) -> torch.Tensor:
+PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, rows, tag) HIP event pairs around hg_tp_fused launches
+
+
+def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None,
+             tag: str = "linear") -> torch.Tensor:
     _require_gpu(srcs[0])
     out = torch.zeros(rows, dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # channel padding must stay finite (zero)
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
     ss = (C.c_int64 * 4)(*([int(s.stride(0)) for s in srcs] + [0] * (4 - n)))
     wig, nW, woff = (ptr(geo.wig), geo.nW, geo.wig_off) if geo is not None else (C.c_void_p(0), 0, (C.c_int * 8)())
+    if PROFILE_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
                             i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), _stream()), "hg_tp_fused")
+    if PROFILE_EVENTS is not None:
+        ev1.record()
+        PROFILE_EVENTS.append((ev0, ev1, rows, tag))
     return out
 
 
