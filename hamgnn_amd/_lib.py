@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhamgnn_hip.so")
+LIB_PATH = os.environ.get("HG_LIB_PATH", os.path.join(_HERE, "lib", "libhamgnn_hip.so"))   # override: kernel-variant A/B runs
 _lib = None
 
 EXPORTS = ["hg_last_error", "hg_version", "hg_edge_geometry", "hg_radial_hidden", "hg_rotate_gather", "hg_tp_fused",

@@ -41,6 +41,9 @@ struct TpArgs {
 };
 
 #define SEG_UNROTATE 1
+#ifndef HG_TP_WAVES
+#define HG_TP_WAVES 2            // min waves per SIMD the register allocator leaves room for (measured: 2 beats 1, 3, 4 - r1 A/B)
+#endif
 
 __device__ __forceinline__ const float* pick_src(const TpArgs& A, int i) {
     return i == 0 ? A.src[0] : (i == 1 ? A.src[1] : (i == 2 ? A.src[2] : A.src[3]));
@@ -51,10 +54,11 @@ __device__ __forceinline__ int64_t pick_stride(const TpArgs& A, int i) {
 
 template <int MM, int RTM>
 __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict__ it, float* __restrict__ tile,
-                                          int rowstride, int lk, int rto, int64_t erow, int lane) {
+                                          int rowstride, int lk, int rto, int mul_k, int64_t erow, int lane) {
     constexpr int NC = 2 * MM + 1;
+    constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], s0 = it[1], s1 = it[2], in_off = it[3], in_mulp = it[4], li = it[5], neg = it[7];
-    const int ksteps = it[8], mlp = it[10];
+    const int ksteps = it[8], mlp = it[10], x4 = it[17];
     const int g = lane >> 4, el = lane & 15;
 
     f32x4 mid[RTM][NC];
@@ -63,42 +67,79 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 #pragma unroll
         for (int c = 0; c < NC; ++c) mid[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---------------------------------------------------------------- GEMM1: mid = A1^T-fragments x B(rotated features)
+    // ---------------------------------------------------------------- GEMM1: mid = A1 fragments x B(rotated features)
+    // A operand: one float4 per lane = 4 K-steps (pre-packed, coalesced 1 KiB per wave-load).
+    // B operand: x4 mode (mulp % 16 == 0): one float4 per (column, 4 K-steps) with the permuted K order u = 16G + 4g + q;
+    //            x1 mode: one dword per (column, K-step), u = 4s + g.
     const int step = neg ? -in_mulp : in_mulp;                 // column c <-> m = c - MM, input component a = li +/- m
     const int a0 = neg ? li + MM : li - MM;
-    const float* __restrict__ a1 = A.W + it[11] + lane;
+    const int ngrp = (ksteps + 3) >> 2;
+    const f32x4* __restrict__ a1 = reinterpret_cast<const f32x4*>(A.W + it[11]) + lane;
     const int nsrc = s1 >= 0 ? 2 : 1;
+#pragma unroll 1
     for (int si = 0; si < nsrc; ++si) {
         const int sidx = si ? s1 : s0;
-        const float* __restrict__ x0 = pick_src(A, sidx) + erow * pick_stride(A, sidx) + in_off + a0 * in_mulp + g;
-        const float* __restrict__ aw = a1 + (size_t)si * ksteps * RTM * 64;
-        for (int s = 0; s < ksteps; ++s) {
-            float b[NC];
+        const float* __restrict__ xb = pick_src(A, sidx) + erow * pick_stride(A, sidx) + in_off + a0 * in_mulp;
+        const f32x4* __restrict__ aw = a1 + (size_t)si * ngrp * RTM * 64;
+        if (NC <= 3 && x4) {                                   // planner sets x4 only for NC <= 3 (keeps bv[] at 12 VGPRs)
+            const float* __restrict__ x0 = xb + 4 * g;
+#pragma unroll 1
+            for (int G = 0; G < ngrp; ++G) {
+                f32x4 av[RTM], bv[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) b[c] = x0[c * step + 4 * s];
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[(G * RTM + rt) * 64];
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) {
-                const float a = aw[(s * RTM + rt) * 64];
+                for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(x0 + c * step + 16 * G);
 #pragma unroll
-                for (int c = 0; c < NC; ++c) mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], mid[rt][c], 0, 0, 0);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
+            }
+        } else {
+            const float* __restrict__ x0 = xb + g;
+#pragma unroll 1
+            for (int G = 0; G < ngrp; ++G) {
+                f32x4 av[RTM];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[(G * RTM + rt) * 64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (4 * G + q < ksteps) {
+                        float b[NC];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) b[c] = x0[c * step + 4 * (4 * G + q)];
+#pragma unroll
+                        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
+                    }
+                }
             }
         }
     }
 
     float* __restrict__ tp = tile + (4 * g) * rowstride + (lk - MM) * 16 + el;
     if (typ == 0) {
-        // ------------------------------------------------------------ radial scale s_e = W3^T h2  (MFMA, K = hidden)
+        // ------------------------------------------------------------ radial scale s_e = W3^T h2  (MFMA, K = hidden, permuted K)
         f32x4 S[RTM];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + g;
-        const float* __restrict__ w3 = A.W + it[12] + lane;
-        const int hsteps = A.hidden >> 2;
-        for (int s = 0; s < hsteps; ++s) {
-            const float hb = hrow[4 * s];
+        const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
+        const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(A.W + it[12]) + lane;
+        const int hgrp = A.hidden >> 4;
+#pragma unroll 1
+        for (int G = 0; G < hgrp; ++G) {
+            const f32x4 hb = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt)
-                S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[(s * RTM + rt) * 64], hb, S[rt], 0, 0, 0);
+            for (int rt = 0; rt < RTM; ++rt) {
+                const f32x4 wv = w3[(G * RTM + rt) * 64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q], hb[q], S[rt], 0, 0, 0);
+            }
         }
         const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(A.W + it[13]) + g;     // [rt][c][g] float4
 #pragma unroll
@@ -106,36 +147,48 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 #pragma unroll
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NC + c) * 4];
 
-        // ------------------------------------------------------------ GEMM2: tile[w'', m] += L'^T-fragments x mid
-        const float* __restrict__ a2 = A.W + it[14] + lane;
+        // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
+        const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(A.W + it[14]) + lane;
+#pragma unroll 1
         for (int rtp = 0; rtp < rto; ++rtp) {
-            f32x4 acc[NC];
+            f32x4 av[RTM];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a = a2[((rtp * RTM + rt) * 4 + r) * 64];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, mid[rt][c][r], acc[c], 0, 0, 0);
-                }
-            }
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = a2[(rtp * RTM + rt) * 64];
             float* __restrict__ t = tp + (16 * rtp) * rowstride;
+            const int rbase = 16 * rtp + 4 * g;
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int c0 = 0; c0 < NC; c0 += CW) {
+                f32x4 acc[CW];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t[r * rowstride + c * 16] += acc[c][r];
+                for (int c = 0; c < CW; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < CW; ++c)
+                            if (c0 + c < NC)
+                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c0 + c][r], acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c0 + c < NC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (rbase + r < mul_k) t[r * rowstride + (c0 + c) * 16] += acc[c][r];
+                    }
+            }
         }
     } else {
         // plain o3.Linear path: rows are output channels; add straight into the tile
-        float* __restrict__ t0 = tp + it[16] * rowstride;
+        const int row0 = it[16];
+        float* __restrict__ t0 = tp + row0 * rowstride;
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) t0[(16 * rt + r) * rowstride + c * 16] += mid[rt][c][r];
+                for (int r = 0; r < 4; ++r)
+                    if (row0 + 16 * rt + 4 * g + r < mul_k) t0[(16 * rt + r) * rowstride + c * 16] += mid[rt][c][r];
     }
 }
 
@@ -145,13 +198,14 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
     constexpr int NCO = 2 * LK + 1;
     const int g = lane >> 4, el = lane & 15;
     const float* __restrict__ D = A.wig ? A.wig + erow * A.nW + A.wig_off[LK] : nullptr;
+#pragma unroll 1
     for (int w = g; w < mul_k; w += 4) {
         float t[NCO];
 #pragma unroll
         for (int m = 0; m < NCO; ++m) t[m] = tile[w * rowstride + m * 16 + el];
         float* __restrict__ o = A.out + e * A.ostride + out_off + w;
         if (flags & SEG_UNROTATE) {
-#pragma unroll
+#pragma unroll 1
             for (int a = 0; a < NCO; ++a) {
                 float acc = 0.f;
 #pragma unroll
@@ -167,9 +221,9 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 }
 
 #define HG_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, it, tile, rowstride, lk, rto, erow, lane); break;
+    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, it, tile, rowstride, lk, rto, mul_k, erow, lane); break;
 
-__global__ __launch_bounds__(256) void tp_fused_kernel(const TpArgs A) {
+__global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t e = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
@@ -182,7 +236,7 @@ __global__ __launch_bounds__(256) void tp_fused_kernel(const TpArgs A) {
         const int lk = S[0], mul_k = S[1], rto = S[2], out_off = S[3], out_mulp = S[4], ib = S[5], ie = S[6], flags = S[7];
         const int nco = 2 * lk + 1;
         const int rowstride = nco * 16 + 4;
-        const int tfl = rto * 16 * rowstride;
+        const int tfl = mul_k * rowstride;
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
         __syncthreads();
         for (int ii = ib; ii < ie; ++ii) {
@@ -191,11 +245,11 @@ __global__ __launch_bounds__(256) void tp_fused_kernel(const TpArgs A) {
             switch (mm * 8 + rtm) {
                 HG_CASE(0, 1) HG_CASE(0, 2) HG_CASE(0, 3) HG_CASE(0, 4)
                 HG_CASE(1, 1) HG_CASE(1, 2) HG_CASE(1, 3) HG_CASE(1, 4)
-                HG_CASE(2, 1) HG_CASE(2, 2)
+                HG_CASE(2, 1) HG_CASE(2, 2) HG_CASE(2, 3)
                 HG_CASE(3, 1) HG_CASE(3, 2)
-                HG_CASE(4, 1) HG_CASE(4, 2)
-                HG_CASE(5, 1) HG_CASE(5, 2)
-                HG_CASE(6, 1) HG_CASE(6, 2)
+                HG_CASE(4, 1)
+                HG_CASE(5, 1)
+                HG_CASE(6, 1)
                 default: break;
             }
         }
@@ -220,7 +274,7 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
                            int64_t out_stride, int64_t rows, int lds_bytes, void* stream) {
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_fused: nsrc must be 1..4");
-    if (hidden & 3) return hg_fail(-2, "hg_tp_fused: hidden width must be a multiple of 4");
+    if (hidden & 15) return hg_fail(-2, "hg_tp_fused: (padded) hidden width must be a multiple of 16");
     if (lds_bytes <= 0 || lds_bytes > 160 * 1024) return hg_fail(-2, "hg_tp_fused: bad LDS size");
     TpArgs A;
     for (int i = 0; i < 4; ++i) {

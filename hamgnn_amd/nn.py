@@ -78,7 +78,10 @@ class FullyConnectedNet(nn.Module):
         out = []
         for i in range(n - 1):
             W = getattr(self, f"layer{i}").weight.detach().double()
-            out.append((W / math.sqrt(W.shape[0])).float().contiguous().to(device))
+            W = W / math.sqrt(W.shape[0])
+            if i == n - 2 and W.shape[1] % 16:                 # pad the last hidden width to the kernel's K granule (silu(0)=0)
+                W = torch.nn.functional.pad(W, (0, 16 - W.shape[1] % 16))
+            out.append(W.float().contiguous().to(device))
         return out
 
 

@@ -37,7 +37,7 @@ class DeviceProgram:
         self.segs = _dev(prog.seg_table, device)
         self.items = _dev(prog.item_table, device)
         self.nseg = int(prog.seg_table.shape[0])
-        self.hidden = int(prog.hidden)
+        self.hidden = int(prog.hidden_pad)
         self.out_dim = int(prog.out_layout.dim)
         self.lds_bytes = int(prog.tile_floats) * 4
 

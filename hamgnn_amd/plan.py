@@ -46,7 +46,8 @@ def ceil_div(a, b):
 
 
 def rtm_max(nc):
-    return 4 if nc <= 3 else 2
+    """row tiles per item: keeps the GEMM1 accumulators at <= 16 f32x4 fragments (64 VGPRs) so 3-4 waves/SIMD fit."""
+    return max(1, min(4, 16 // nc))
 
 
 class PlanarLayout:
@@ -113,7 +114,12 @@ def tp_instructions(irreps1: Irreps, irreps2: Irreps, target: Irreps):
 @dataclass
 class Program:
     out_layout: PlanarLayout
-    hidden: int = 0                                   # radial hidden width H (multiple of 4) or 0
+    hidden: int = 0                                   # radial hidden width H or 0
+
+    @property
+    def hidden_pad(self):                             # H padded to the permuted-K granule (16)
+        return ceil_div(self.hidden, 16) * 16
+
     segs: List[List[int]] = field(default_factory=list)
     seg_items: List[List[List[int]]] = field(default_factory=list)    # per segment: item records (kept contiguous per segment)
     chunks: List[np.ndarray] = field(default_factory=list)
@@ -146,13 +152,25 @@ class Program:
         return self
 
 
-def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int) -> np.ndarray:
-    """mat[k, row] -> fragments [ksteps][rtm][64], lane L holds mat[4s + (L>>4)][16 rt + (L&15)] (zero padded)."""
+def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:
+    """mat[k, row] -> A fragments [ngrp][rtm][64 lanes][4]: one float4 per lane covers 4 MFMA K-steps (q = 0..3).
+    lane L = (i = L&15, g = L>>4) holds mat[k(G, q, g)][16 rt + i] with
+        x4 (permuted K, B operand loaded as float4):  k = 16 G + 4 g + q
+        x1 (B operand loaded as dwords)            :  k = 4 (4 G + q) + g
+    zero padded to ngrp = ceil(ksteps / 4) groups."""
     K, Rr = mat_kxr.shape
-    P = np.zeros((ksteps * 4, rtm * 16), dtype=np.float64)
+    ngrp = ceil_div(ksteps, 4)
+    P = np.zeros((ngrp * 16, rtm * 16), dtype=np.float64)
     P[:K, :Rr] = mat_kxr
-    # [s, g, rt, r] -> [s, rt, g, r]
-    return P.reshape(ksteps, 4, rtm, 16).transpose(0, 2, 1, 3).reshape(ksteps, rtm, 64)
+    P = P.reshape(ngrp, 4, 4, rtm, 16)                      # x4: [G, g, q, rt, i] ; x1: [G, q, g, rt, i]
+    if x4:
+        return P.transpose(0, 3, 1, 4, 2).reshape(ngrp, rtm, 64, 4)
+    return P.transpose(0, 3, 2, 4, 1).reshape(ngrp, rtm, 64, 4)
+
+
+def use_x4(in_mulp, nc):
+    """permuted-K float4 B loads: channel block a multiple of 16 and few columns (register budget of the kernel)."""
+    return in_mulp % 16 == 0 and nc <= 3
 
 
 def _add_segment(prog: Program, lk, mul_k, out_index, flags):
@@ -160,21 +178,21 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     rto = ceil_div(mul_k, 16)
     prog.segs.append([lk, mul_k, rto, lay.off[out_index], lay.mulp[out_index], 0, 0, flags])
     prog.seg_items.append([])
-    prog.tile_floats = max(prog.tile_floats, 4 * rto * 16 * ((2 * lk + 1) * 16 + 4))   # 4 wave-private tiles
+    prog.tile_floats = max(prog.tile_floats, 4 * mul_k * ((2 * lk + 1) * 16 + 4))   # 4 wave-private tiles [mul_k rows]
     return len(prog.segs) - 1
 
 
 def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0):
     assert len(srcs) in (1, 2)
     rec = [typ, srcs[0], srcs[1] if len(srcs) == 2 else -1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp,
-           a1, w3, cf, a2, nrows, row_off, 0, 0, 0]
+           a1, w3, cf, a2, nrows, row_off, 1 if use_x4(in_mulp, 2 * mm + 1) else 0, 0, 0]
     assert len(rec) == ITEM_I32
     prog.seg_items[seg].append(rec)
     nc = 2 * mm + 1
     rto = prog.segs[seg][2]
     n = len(srcs) * ksteps * rtm * nc
     if typ == IT_TP:
-        n += (prog.hidden // 4) * rtm + rto * rtm * 4 * nc
+        n += (prog.hidden_pad // 4) * rtm + rto * rtm * 4 * nc
     prog.mfma_per_wave += n
 
 
@@ -269,19 +287,20 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
                 r1 = min(nrows, r0 + chunk)
                 rtm = ceil_div(r1 - r0, 16)
                 a1 = []
+                x4 = use_x4(in_layout.mulp[i], nc)
                 for s_ in range(nsrc):
                     Wk = rows_W[r0:r1, s_ * mi:(s_ + 1) * mi].T                      # [u, row]
-                    a1.append(_frag_A(Wk, ksteps, rtm))
+                    a1.append(_frag_A(Wk, ksteps, rtm, x4))
                 a1_off = prog.add_weights(np.stack(a1))
-                w3_off = prog.add_weights(_frag_A(w3[:, rows_ch[r0:r1]], H // 4, rtm))
+                w3_off = prog.add_weights(_frag_A(w3[:, rows_ch[r0:r1]], prog.hidden_pad // 4, rtm, True))
                 cfp = np.zeros((rtm * 16, nc))
                 cfp[:r1 - r0] = rows_cf[r0:r1]
                 cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))       # [rt][c][g][r]
                 rto = prog.segs[seg][2]
                 Lp = np.zeros((rtm * 16, rto * 16))
                 Lp[:r1 - r0, :mk] = rows_L[r0:r1]
-                # A2[rt'][rt][r][lane]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
-                a2 = Lp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 2, 1, 4).reshape(rto, rtm, 4, 64)
+                # A2[rt'][rt][lane][r]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
+                a2 = Lp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4)
                 a2_off = prog.add_weights(a2)
                 _add_item(prog, seg, IT_TP, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, par, ksteps, rtm, mlp,
                           a1_off, w3_off, cf_off, a2_off, r1 - r0)
@@ -310,7 +329,7 @@ def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarL
         for r0 in range(0, mk, chunk):
             r1 = min(mk, r0 + chunk)
             rtm = ceil_div(r1 - r0, 16)
-            a1_off = prog.add_weights(_frag_A(W[:, r0:r1], ksteps, rtm)[None])
+            a1_off = prog.add_weights(_frag_A(W[:, r0:r1], ksteps, rtm, use_x4(in_layout.mulp[i], nc))[None])
             _add_item(prog, seg, IT_LIN, [src], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0,
                       a1_off, 0, 0, 0, r1 - r0, row_off=r0)
         prog.flops_per_row += 2.0 * mi * mk * nc
@@ -510,7 +529,7 @@ def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps):
         for r0 in range(0, mk, chunk):
             r1 = min(mk, r0 + chunk)
             rtm = ceil_div(r1 - r0, 16)
-            a1_off = prog.add_weights(_frag_A(Mn[:, r0:r1], ksteps, rtm)[None])
+            a1_off = prog.add_weights(_frag_A(Mn[:, r0:r1], ksteps, rtm, use_x4(in_layout.mulp[i], nc))[None])
             _add_item(prog, seg_of_k[g], IT_LIN, [0], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0, a1_off, 0, 0, 0, r1 - r0, row_off=r0)
         prog.flops_per_row += 2.0 * mi * mk * nc
     return prog.finalize(), girr, slot_pos

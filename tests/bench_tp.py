@@ -1,0 +1,36 @@
+"""Micro-benchmark of ONE fused MessagePackBlock launch (set-A or set-B irreps) on synthetic rotated rows: quick A/B of
+kernel variants (HG_LIB_PATH selects the .so).  Prints ms per launch and issued-MFMA TFLOP/s."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from hamgnn_amd import nn as hnn, ops, plan as P
+IRR = {"A": "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e", "B": "64x0e+32x1o+16x1e+8x2o+20x2e+8x3o+4x3e+4x4e"}
+ap = argparse.ArgumentParser(); ap.add_argument("--irreps", default="A"); ap.add_argument("--edges", type=int, default=131072)
+ap.add_argument("--reps", type=int, default=5); ap.add_argument("--tag", default="")
+a = ap.parse_args()
+irr, sh = IRR[a.irreps], "0e+1o+2e+3o+4e+5o"
+torch.manual_seed(0)
+m = hnn.MessagePackBlock(irr, irr, sh, irr, 64, [64, 64])
+dev = torch.device("cuda")
+m.compile(dev, unrotate=True)
+E = a.edges
+lay = P.PlanarLayout(irr)
+g = torch.Generator(device="cpu").manual_seed(1)
+pos = torch.zeros(2, 3, device=dev)
+ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.long)]).to(dev)
+shift = (torch.randn(E, 3, generator=g) * 4).to(dev)
+geo = ops.Geometry(pos, ei, shift, 26.0, 64, 6, torch.from_numpy(P.wigner_jtab(6)).to(dev))
+xs, xd, fe = (torch.randn(E, lay.dim, generator=g).to(dev) for _ in range(3))
+hn = ops.radial_hidden(geo.rbf, m._hn, 1.679); he = ops.radial_hidden(geo.rbf, m._he, 1.679)
+for _ in range(2):
+    out = ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.reps):
+    out = ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.reps
+prog = m._dp.prog
+print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
+                  "issued_TF": prog.mfma_per_wave * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
+                  "Medges_s": E / dt / 1e6, "checksum": float(out.double().abs().mean())}))

@@ -61,37 +61,49 @@ def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64
                 (typ, s0, s1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off) = (int(v) for v in it[:17])
                 nc = 2 * mm + 1
                 nsrc = 2 if s1 >= 0 else 1
-                A1 = Wt[a1:a1 + nsrc * ksteps * rtm * 64].reshape(nsrc, ksteps, rtm, 4, 16)      # [src][s][rt][k][i]
+                x4 = int(it[17])
+                ngrp = -(-ksteps // 4)
+                A1 = Wt[a1:a1 + nsrc * ngrp * rtm * 256].reshape(nsrc, ngrp, rtm, 4, 16, 4)      # [src][G][rt][g][i][q]
                 mid = np.zeros((rtm, nc, 16, 16), dtype=dtype)
                 for si, sidx in enumerate([s0, s1][:nsrc]):
                     X = srcs[sidx]
                     for c in range(nc):
                         m = c - mm
                         a = li + (-m if neg else m)
-                        for s in range(ksteps):
-                            B = np.zeros((4, 16), dtype=dtype)
-                            B[:, :ne] = X[cols, in_off + a * in_mulp + 4 * s:in_off + a * in_mulp + 4 * s + 4].T
-                            for rt in range(rtm):
-                                mid[rt, c] += A1[si, s, rt].T @ B
+                        base = in_off + a * in_mulp
+                        for G in range(ngrp):
+                            for q in range(4):
+                                if not x4 and 4 * G + q >= ksteps:
+                                    continue
+                                B = np.zeros((4, 16), dtype=dtype)             # B[k = g][j = edge]
+                                for g in range(4):
+                                    u = 16 * G + 4 * g + q if x4 else 4 * (4 * G + q) + g
+                                    B[g, :ne] = X[cols, base + u]
+                                for rt in range(rtm):
+                                    mid[rt, c] += A1[si, G, rt, :, :, q].T @ B
                 if typ == P.IT_TP:
-                    W3 = Wt[w3:w3 + (H // 4) * rtm * 64].reshape(H // 4, rtm, 4, 16)
+                    Hp = prog.hidden_pad
+                    W3 = Wt[w3:w3 + (Hp // 16) * rtm * 256].reshape(Hp // 16, rtm, 4, 16, 4)        # [G][rt][g][i][q]
                     S = np.zeros((rtm, 16, 16), dtype=dtype)
-                    hh = h2[mlp]
-                    for s in range(H // 4):
-                        B = np.zeros((4, 16), dtype=dtype)
-                        B[:, :ne] = hh[cols, 4 * s:4 * s + 4].T
-                        for rt in range(rtm):
-                            S[rt] += W3[s, rt].T @ B
+                    hh = np.zeros((E, Hp), dtype=dtype)
+                    hh[:, :H] = h2[mlp]
+                    for G in range(Hp // 16):
+                        for q in range(4):
+                            B = np.zeros((4, 16), dtype=dtype)
+                            for g in range(4):
+                                B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
+                            for rt in range(rtm):
+                                S[rt] += W3[G, rt, :, :, q].T @ B
                     CF = Wt[cf:cf + rtm * nc * 16].reshape(rtm, nc, 16)                           # [rt][c][row = 4g + r]
                     mid = mid * S[:, None, :, :] * CF[:, :, :, None]
-                    A2 = Wt[a2:a2 + rto * rtm * 4 * 64].reshape(rto, rtm, 4, 4, 16)               # [rt'][rt][r][k][i]
+                    A2 = Wt[a2:a2 + rto * rtm * 4 * 64].reshape(rto, rtm, 4, 16, 4)               # [rt'][rt][k=g][i][r]
                     for rtp in range(rto):
                         for c in range(nc):
                             acc = np.zeros((16, 16), dtype=dtype)
                             for rt in range(rtm):
                                 for r in range(4):
                                     Bm = mid[rt, c][r::4, :]                                     # rows 4k + r, k = 0..3
-                                    acc += A2[rtp, rt, r].T @ Bm
+                                    acc += A2[rtp, rt, :, :, r].T @ Bm
                             tile[16 * rtp:16 * rtp + 16, lk - mm + c] += acc
                 else:
                     for rt in range(rtm):

@@ -71,3 +71,36 @@ def test_linear_program(golden_dir):
     lin = e3.Linear(MINI, gate_in)
     lin.weight.data = torch.from_numpy(f["weights"]["linear1.weight"])
     assert rel(y, lin(torch.from_numpy(x)).detach().numpy()) < 1e-6
+
+
+def test_message_pack_program_x4_path_vs_oracle():
+    """irreps with 16-/32-channel blocks exercise the permuted-K float4 (x4) operand packing; reference = the oracle."""
+    import torch
+    from oracle import hamgnn_ref as R
+    irr, sh = "16x0e+16x0o+32x1o+4x1e+3x2e", "0e+1o+2e"
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
+        E = 19
+        g = torch.Generator().manual_seed(1)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
+        vec = torch.randn(E, 3, generator=g)
+        n = torch.nn.functional.normalize(vec, dim=-1)
+        from oracle import e3
+        shv = e3.spherical_harmonics([0, 1, 2], n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        out = ref(src, dst, ef, shv, rbf).detach().numpy()
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay = P.PlanarLayout(irr)
+    D = emu.edge_wigner_all(n.numpy(), 2)
+    xs, xd, fe = (emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, 2) for t in (src, dst, ef))
+    hn = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
+    he = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
+    prog = P.build_message_pack_program(sd, irr, irr, sh, irr, unrotate=True)
+    assert any(int(it[17]) for it in prog.item_table) and any(not int(it[17]) for it in prog.item_table)
+    outp = emu.run_program(prog, [xs, xd, fe], (hn, he), D, 2)
+    assert rel(lay.from_planar(outp), out) < 1e-6
