@@ -69,56 +69,104 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 
     // ---------------------------------------------------------------- GEMM1: mid = A1 fragments x B(rotated features)
     // A operand: one float4 per lane = 4 K-steps (pre-packed, coalesced 1 KiB per wave-load).
-    // B operand: x4 mode (mulp % 16 == 0): one float4 per (column, 4 K-steps) with the permuted K order u = 16G + 4g + q;
+    // B operand: x4 mode (mulp % 16 == 0, NC <= 3): one float4 per (column, 4 K-steps), permuted K order u = 16G + 4g + q;
     //            x1 mode: one dword per (column, K-step), u = 4s + g.
+    // Register double buffering: the fragments of group t+1 are requested before the MFMAs of group t are issued, so the
+    // L2/HBM latency of the operand stream hides behind 4*RTM*NC MFMAs even at 2 waves per SIMD.
     const int step = neg ? -in_mulp : in_mulp;                 // column c <-> m = c - MM, input component a = li +/- m
     const int a0 = neg ? li + MM : li - MM;
     const int ngrp = (ksteps + 3) >> 2;
-    const f32x4* __restrict__ a1 = reinterpret_cast<const f32x4*>(A.W + it[11]) + lane;
     const int nsrc = s1 >= 0 ? 2 : 1;
+    const int ntot = nsrc * ngrp;
+    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(A.W + it[11]) + lane;      // [src][G][rt][lane]
+    const float* __restrict__ xsrc0 = pick_src(A, s0) + erow * pick_stride(A, s0) + in_off + a0 * in_mulp;
+    const float* __restrict__ xsrc1 = nsrc == 2 ? pick_src(A, s1) + erow * pick_stride(A, s1) + in_off + a0 * in_mulp : xsrc0;
+
+    // early requests for the later phases (their latency hides behind GEMM1)
+    const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
+    const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(A.W + it[12]) + lane;
+    f32x4 hb_n = (f32x4){0.f, 0.f, 0.f, 0.f}, w3_n[RTM];
+    if (typ == 0) {
+        hb_n = *reinterpret_cast<const f32x4*>(hrow);
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = w3[rt * 64];
+    }
+
+    if (NC <= 3 && x4) {                                       // planner sets x4 only for NC <= 3 (keeps bv[] at 12 VGPRs)
+        f32x4 av_n[RTM], bv_n[NC];
+        {
+            const float* __restrict__ x0 = xsrc0 + 4 * g;
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) bv_n[c] = *reinterpret_cast<const f32x4*>(x0 + c * step);
+        }
 #pragma unroll 1
-    for (int si = 0; si < nsrc; ++si) {
-        const int sidx = si ? s1 : s0;
-        const float* __restrict__ xb = pick_src(A, sidx) + erow * pick_stride(A, sidx) + in_off + a0 * in_mulp;
-        const f32x4* __restrict__ aw = a1 + (size_t)si * ngrp * RTM * 64;
-        if (NC <= 3 && x4) {                                   // planner sets x4 only for NC <= 3 (keeps bv[] at 12 VGPRs)
-            const float* __restrict__ x0 = xb + 4 * g;
-#pragma unroll 1
-            for (int G = 0; G < ngrp; ++G) {
-                f32x4 av[RTM], bv[NC];
+        for (int t = 0; t < ntot; ++t) {
+            f32x4 av[RTM], bv[NC];
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[(G * RTM + rt) * 64];
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(x0 + c * step + 16 * G);
+            for (int c = 0; c < NC; ++c) bv[c] = bv_n[c];
+            if (t + 1 < ntot) {
+                const int tn = t + 1;
+                const int G = tn >= ngrp ? tn - ngrp : tn;
+                const float* __restrict__ x0 = (tn >= ngrp ? xsrc1 : xsrc0) + 4 * g + 16 * G;
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[(tn * RTM + rt) * 64];
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                        for (int c = 0; c < NC; ++c)
-                            mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
+                for (int c = 0; c < NC; ++c) bv_n[c] = *reinterpret_cast<const f32x4*>(x0 + c * step);
             }
-        } else {
-            const float* __restrict__ x0 = xb + g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
+        }
+    } else {
+        // x1: K-steps s = 0 .. nsrc*ksteps-1 flattened; A float4 covers steps 4G..4G+3 of one source
+        const int nsteps = nsrc * ksteps;
+        float b_n[NC];
+        f32x4 av[RTM];
+        {
+            const float* __restrict__ x0 = xsrc0 + g;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) b_n[c] = x0[c * step];
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[rt * 64];
+        }
+        int sl = 0, srcsel = 0;                                // local step within the source, source index
 #pragma unroll 1
-            for (int G = 0; G < ngrp; ++G) {
-                f32x4 av[RTM];
+        for (int t = 0; t < nsteps; ++t) {
+            float b[NC];
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[(G * RTM + rt) * 64];
+            for (int c = 0; c < NC; ++c) b[c] = b_n[c];
+            const int q = sl & 3;
+            f32x4 avc[RTM];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (4 * G + q < ksteps) {
-                        float b[NC];
+            for (int rt = 0; rt < RTM; ++rt) avc[rt] = av[rt];
+            // advance
+            int sl_n = sl + 1, src_n = srcsel;
+            if (sl_n == ksteps) { sl_n = 0; src_n = srcsel + 1; }
+            if (t + 1 < nsteps) {
+                const float* __restrict__ x0 = (src_n ? xsrc1 : xsrc0) + g + 4 * sl_n;
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) b[c] = x0[c * step + 4 * (4 * G + q)];
+                for (int c = 0; c < NC; ++c) b_n[c] = x0[c * step];
+                if ((sl_n & 3) == 0) {
+                    const int Gn = src_n * ngrp + (sl_n >> 2);
 #pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                            for (int c = 0; c < NC; ++c)
-                                mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
-                    }
+                    for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[(Gn * RTM + rt) * 64];
                 }
             }
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) {
+                const float a = q == 0 ? avc[rt][0] : (q == 1 ? avc[rt][1] : (q == 2 ? avc[rt][2] : avc[rt][3]));
+#pragma unroll
+                for (int c = 0; c < NC; ++c) mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], mid[rt][c], 0, 0, 0);
+            }
+            sl = sl_n; srcsel = src_n;
         }
     }
 
@@ -128,18 +176,26 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
         f32x4 S[RTM];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
-        const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(A.W + it[12]) + lane;
         const int hgrp = A.hidden >> 4;
+        const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(A.W + it[14]) + lane;
+        f32x4 a2_n[RTM];
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];                               // GEMM2 operands of rtp = 0, early
 #pragma unroll 1
         for (int G = 0; G < hgrp; ++G) {
-            const f32x4 hb = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
+            const f32x4 hb = hb_n;
+            f32x4 wv[RTM];
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) {
-                const f32x4 wv = w3[(G * RTM + rt) * 64];
+            for (int rt = 0; rt < RTM; ++rt) wv[rt] = w3_n[rt];
+            if (G + 1 < hgrp) {
+                hb_n = *reinterpret_cast<const f32x4*>(hrow + 16 * (G + 1));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q], hb[q], S[rt], 0, 0, 0);
+                for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = w3[((G + 1) * RTM + rt) * 64];
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rt][q], hb[q], S[rt], 0, 0, 0);
         }
         const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(A.W + it[13]) + g;     // [rt][c][g] float4
 #pragma unroll
@@ -148,12 +204,15 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NC + c) * 4];
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
-        const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(A.W + it[14]) + lane;
 #pragma unroll 1
         for (int rtp = 0; rtp < rto; ++rtp) {
             f32x4 av[RTM];
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) av[rt] = a2[(rtp * RTM + rt) * 64];
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = a2_n[rt];
+            if (rtp + 1 < rto) {
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
+            }
             float* __restrict__ t = tp + (16 * rtp) * rowstride;
             const int rbase = 16 * rtp + 4 * g;
 #pragma unroll

@@ -77,7 +77,7 @@ def test_message_pack_program_x4_path_vs_oracle():
     """irreps with 16-/32-channel blocks exercise the permuted-K float4 (x4) operand packing; reference = the oracle."""
     import torch
     from oracle import hamgnn_ref as R
-    irr, sh = "16x0e+16x0o+32x1o+4x1e+3x2e", "0e+1o+2e"
+    irr, sh = "16x0e+12x0o+32x1o+4x1e+7x2e", "0e+1o+2e"
     torch.manual_seed(0)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
