@@ -433,18 +433,20 @@ class TensorProduct(torch.nn.Module):
                 off += n
             zw = "z" if batch_w else ""
             mode = ins.connection_mode
+            # contraction order of e3nn's generated code: outer product of the inputs, then the 3j tensor, then the weights
             if mode == "uvw":
-                r = torch.einsum(f"{zw}uvw,ijk,zui,zvj->zwk", w, C, x1, x2)
+                xx = torch.einsum("zui,zvj->zuvij", x1, x2)
+                r = torch.einsum("zuvij,ijk->zuvk", xx, C)
+                r = torch.einsum(f"zuvk,{zw}uvw->zwk", r, w)
             elif mode == "uvu":
-                if w is not None:
-                    r = torch.einsum(f"{zw}uv,ijk,zui,zvj->zuk", w, C, x1, x2)
-                else:
-                    r = torch.einsum("ijk,zui,zvj->zuk", C, x1, x2)
+                xx = torch.einsum("zui,zvj->zuvij", x1, x2)
+                r = torch.einsum("zuvij,ijk->zuvk", xx, C)
+                r = torch.einsum(f"zuvk,{zw}uv->zuk", r, w) if w is not None else r.sum(2)
             elif mode == "uuu":
+                xx = torch.einsum("zui,zuj->zuij", x1, x2)
+                r = torch.einsum("zuij,ijk->zuk", xx, C)
                 if w is not None:
-                    r = torch.einsum(f"{zw}u,ijk,zui,zuj->zuk", w, C, x1, x2)
-                else:
-                    r = torch.einsum("ijk,zui,zuj->zuk", C, x1, x2)
+                    r = r * (w[:, :, None] if batch_w else w[None, :, None])
             else:
                 raise NotImplementedError(mode)
             r = ins.path_weight * r.reshape(Z, -1)
