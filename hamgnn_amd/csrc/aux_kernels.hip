@@ -182,33 +182,73 @@ extern "C" int hg_radial_hidden(const float* rbf, int64_t E, const float* weight
 }
 
 // ------------------------------------------------------------------------------------------------ gather + rotate
-__global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restrict__ x, int64_t xs, const int64_t* __restrict__ idx,
-                                                            const float* __restrict__ wig, int nW, const HgWigOff wo,
-                                                            const int4* __restrict__ tab, int Dp, int64_t E, int transpose,
-                                                            float* __restrict__ out, int64_t os) {
-    const int64_t e = blockIdx.x;
-    const int64_t row = idx ? idx[e] : e;
-    const float* __restrict__ xr = x + row * xs;
-    const float* __restrict__ D = wig + e * nW;
-    for (int p = threadIdx.x; p < Dp; p += blockDim.x) {
-        const int4 t = tab[p];                       // {l, a, base_in, mulp}
+// One workgroup per edge.  The edge's packed Wigner matrices (<= 455 floats) are staged in LDS once (coalesced), then one
+// thread per CHANNEL (irrep block i, channel u) loads its 2l+1 components (coalesced across u), multiplies by D^l (LDS
+// broadcast reads) and stores 2l+1 components.  Up to two gathered sources (sender / receiver rows) share the staged D.
+// chan_tab: int32[nchan][4] = {l, planar offset of (component 0, channel u), mulp, 0}.
+template <int L>
+__device__ __forceinline__ void rotate_channel(const float* __restrict__ Dl, const float* __restrict__ xin, float* __restrict__ xout,
+                                               int base, int mulp, int transpose) {
+    constexpr int N = 2 * L + 1;
+    float v[N];
+#pragma unroll
+    for (int b = 0; b < N; ++b) v[b] = xin[base + b * mulp];
+#pragma unroll
+    for (int a = 0; a < N; ++a) {
         float acc = 0.f;
-        if (t.x >= 0) {
-            const int n = 2 * t.x + 1;
-            const float* __restrict__ Dl = D + wo.o[t.x];
-            if (!transpose) for (int b = 0; b < n; ++b) acc = fmaf(Dl[t.y * n + b], xr[t.z + b * t.w], acc);
-            else            for (int b = 0; b < n; ++b) acc = fmaf(Dl[b * n + t.y], xr[t.z + b * t.w], acc);
+        if (!transpose) {
+#pragma unroll
+            for (int b = 0; b < N; ++b) acc = fmaf(Dl[a * N + b], v[b], acc);
+        } else {
+#pragma unroll
+            for (int b = 0; b < N; ++b) acc = fmaf(Dl[b * N + a], v[b], acc);
         }
-        out[e * os + p] = acc;
+        xout[base + a * mulp] = acc;
     }
 }
 
-extern "C" int hg_rotate_gather(const float* x, int64_t x_stride, const int64_t* idx, const float* wig, int nW, const int32_t* wig_off,
-                                const int32_t* elem_tab, int Dp, int64_t E, int transpose, float* out, int64_t out_stride, void* stream) {
+__global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int64_t xs,
+                                                            const int64_t* __restrict__ idx0, const int64_t* __restrict__ idx1,
+                                                            const float* __restrict__ wig, int nW, const HgWigOff wo,
+                                                            const int4* __restrict__ tab, int nchan, int transpose,
+                                                            float* __restrict__ out0, float* __restrict__ out1, int64_t os) {
+    extern __shared__ float Dsm[];
+    const int64_t e = blockIdx.x;
+    for (int i = threadIdx.x; i < nW; i += blockDim.x) Dsm[i] = wig[e * nW + i];
+    __syncthreads();
+    const int nsrc = x1 ? 2 : 1;
+    for (int j = threadIdx.x; j < nchan * nsrc; j += blockDim.x) {
+        const int sidx = j >= nchan;
+        const int4 t = tab[sidx ? j - nchan : j];
+        const int64_t row = sidx ? (idx1 ? idx1[e] : e) : (idx0 ? idx0[e] : e);
+        const float* __restrict__ xin = (sidx ? x1 : x0) + row * xs;
+        float* __restrict__ xo = (sidx ? out1 : out0) + e * os;
+        const float* __restrict__ Dl = Dsm + wo.o[t.x];
+        if (t.w) {                                             // channel padding: keep it zero (it feeds zero-weight MFMA K-steps)
+            for (int a = 0; a < 2 * t.x + 1; ++a) xo[t.y + a * t.z] = 0.f;
+            continue;
+        }
+        switch (t.x) {
+            case 0: xo[t.y] = xin[t.y]; break;
+            case 1: rotate_channel<1>(Dl, xin, xo, t.y, t.z, transpose); break;
+            case 2: rotate_channel<2>(Dl, xin, xo, t.y, t.z, transpose); break;
+            case 3: rotate_channel<3>(Dl, xin, xo, t.y, t.z, transpose); break;
+            case 4: rotate_channel<4>(Dl, xin, xo, t.y, t.z, transpose); break;
+            case 5: rotate_channel<5>(Dl, xin, xo, t.y, t.z, transpose); break;
+            case 6: rotate_channel<6>(Dl, xin, xo, t.y, t.z, transpose); break;
+            default: break;
+        }
+    }
+}
+
+extern "C" int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stride, const int64_t* idx0, const int64_t* idx1,
+                                const float* wig, int nW, const int32_t* wig_off, const int32_t* chan_tab, int nchan, int64_t E,
+                                int transpose, float* out0, float* out1, int64_t out_stride, void* stream) {
     if (E <= 0) return 0;
     HgWigOff wo;
     for (int i = 0; i < 8; ++i) wo.o[i] = wig_off[i];
-    rotate_gather_kernel<<<dim3((unsigned)E), 256, 0, (hipStream_t)stream>>>(x, x_stride, idx, wig, nW, wo, (const int4*)elem_tab, Dp, E, transpose, out, out_stride);
+    rotate_gather_kernel<<<dim3((unsigned)E), 256, sizeof(float) * (size_t)nW, (hipStream_t)stream>>>(
+        x0, x1, x_stride, idx0, idx1, wig, nW, wo, (const int4*)chan_tab, nchan, transpose, out0, out1, out_stride);
     return hg_check_launch("hg_rotate_gather");
 }
 

@@ -76,3 +76,69 @@ extern "C" int hg_ham_finish(const float* Hraw, const int64_t* inv, const float*
     ham_finish_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign, symmetrize, H);
     return hg_check_launch("hg_ham_finish");
 }
+
+// ------------------------------------------------------------------------------------------------ SOC / so3 (a18)
+// symmetrize_orbital_coefficients (hamgnn_output.py:2367-2431): every element -> mean over its (row shell, col shell) block.
+// tab: int32[nao2][4] = {r0, r1, c0, c1} of the block the element belongs to.
+__global__ __launch_bounds__(256) void block_mean_kernel(const float* __restrict__ x, int64_t xs, const int4* __restrict__ tab, int nao,
+                                                         float* __restrict__ out) {
+    extern __shared__ float sm[];
+    const int64_t e = blockIdx.x;
+    const int nao2 = nao * nao;
+    for (int q = threadIdx.x; q < nao2; q += blockDim.x) sm[q] = x[e * xs + q];
+    __syncthreads();
+    for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+        const int4 t = tab[q];
+        float acc = 0.f;
+        for (int r = t.x; r < t.y; ++r)
+            for (int c = t.z; c < t.w; ++c) acc += sm[r * nao + c];
+        out[e * nao2 + q] = acc / (float)((t.y - t.x) * (t.w - t.z));
+    }
+}
+
+extern "C" int hg_block_mean(const float* x, int64_t x_stride, const int32_t* tab, int nao, int64_t rows, float* out, void* stream) {
+    if (rows <= 0) return 0;
+    block_mean_kernel<<<dim3((unsigned)rows), 256, sizeof(float) * (size_t)nao * nao, (hipStream_t)stream>>>(x, x_stride, (const int4*)tab, nao, out);
+    return hg_check_launch("hg_block_mean");
+}
+
+// spin-block assembly of the so3 SOC Hamiltonian (hamgnn_output.py:3076-3144, 3603-3609):
+//   A_k = antiherm(ksi * L[..., k]) = 0.5 (ksi L_k - (ksi L_k)[inv]^T)          (k: 0 = x, 1 = y, 2 = z)
+//   real = [[H, A_1], [A_1, H]] + H0r ;  imag = [[A_2, A_0], [-A_0, -A_2]] + H0i
+// zero_diag != 0 (add_H_nonsoc): the spin-diagonal blocks of H0r are not added (:3034-3049).
+__global__ __launch_bounds__(256) void soc_assemble_kernel(const float* __restrict__ H, const float* __restrict__ ksi, const float* __restrict__ L,
+                                                           const int64_t* __restrict__ inv, const float* __restrict__ H0r,
+                                                           const float* __restrict__ H0i, int nao, int symmetrize, int zero_diag,
+                                                           float* __restrict__ outr, float* __restrict__ outi) {
+    const int64_t e = blockIdx.x;
+    const int64_t eo = inv ? inv[e] : e;
+    const int nao2 = nao * nao, n2 = 2 * nao;
+    const int64_t big = (int64_t)n2 * n2;
+    for (int q = threadIdx.x; q < (int)big; q += blockDim.x) {
+        const int R = q / n2, Cc = q - R * n2;
+        const int sr = R >= nao, sc = Cc >= nao;
+        const int r = R - sr * nao, c = Cc - sc * nao;
+        const int el = r * nao + c, elT = c * nao + r;
+        const int k = (sr == sc) ? 2 : 0;                      // imag: diagonal blocks use L_z, off-diagonal L_x
+        const float kv = ksi[e * nao2 + el], kvT = ksi[eo * nao2 + elT];
+        float ai = kv * L[(e * nao2 + el) * 3 + k];
+        float ar = kv * L[(e * nao2 + el) * 3 + 1];
+        if (symmetrize) {
+            ai = 0.5f * (ai - kvT * L[(eo * nao2 + elT) * 3 + k]);
+            ar = 0.5f * (ar - kvT * L[(eo * nao2 + elT) * 3 + 1]);
+        }
+        float vr = (sr == sc) ? H[e * nao2 + el] : ar;
+        float vi = (sr == sc) ? (sr ? -ai : ai) : (sr ? -ai : ai);   // (0,0): +A2, (1,1): -A2, (0,1): +A0, (1,0): -A0
+        if (H0r && !(zero_diag && sr == sc)) vr += H0r[e * big + q];
+        if (H0i) vi += H0i[e * big + q];
+        outr[e * big + q] = vr;
+        outi[e * big + q] = vi;
+    }
+}
+
+extern "C" int hg_soc_assemble(const float* H, const float* ksi, const float* L, const int64_t* inv, const float* H0r, const float* H0i,
+                               int nao, int symmetrize, int zero_diag, int64_t rows, float* out_real, float* out_imag, void* stream) {
+    if (rows <= 0) return 0;
+    soc_assemble_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(H, ksi, L, inv, H0r, H0i, nao, symmetrize, zero_diag, out_real, out_imag);
+    return hg_check_launch("hg_soc_assemble");
+}

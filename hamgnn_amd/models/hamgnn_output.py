@@ -82,6 +82,7 @@ class HamGNNPlusPlusOut(nn.Module):
         self._rot_tab = torch.from_numpy(P.rotate_table(self.edge_layout)).to(dev)
         self._lmax = max(self.edge_layout.irreps.lmax, self.hamiltonian_irreps.lmax)
         self._jtab = torch.from_numpy(P.wigner_jtab(self._lmax)).to(dev)
+        self._blk = torch.from_numpy(P.shell_block_table(self.row, self.nao_max)).to(dev)
         self._compiled_for = dev
         return self
 
@@ -161,8 +162,24 @@ class HamGNNPlusPlusOut(nn.Module):
         if not self.ham_only:
             s_on, s_off = self._blocks(self.onsite_overlap_network, self.offsite_overlap_network, node_pl, edge_rot, geo, data, inv, None, None)
             result["overlap"] = self._cat_by_crystal(data, s_on, s_off, edge_counts)
-        if self.soc_switch:
-            raise NotImplementedError("SOC/so3 assembly kernel lands next (oracle + fixtures already cover it)")
+        if self.soc_switch:                                                  # ---- SOC / so3 (hamgnn_output.py:3026-3144)
+            n = self.nao_max
+            if self.add_H_nonsoc:
+                on, off = f32c(data.Hon_nonsoc), f32c(data.Hoff_nonsoc)
+            else:
+                on, off = self._blocks(self.onsite_hamiltonian_network, self.offsite_hamiltonian_network, node_pl, edge_rot, geo, data, inv, None, None)
+            ksi_on = ops.block_mean(self.onsite_ksi_network(node_pl), self._blk, n)
+            ksi_off = ops.block_mean(self.offsite_ksi_network(edge_rot), self._blk, n)
+            H0 = (f32c(data.Hon0), f32c(data.Hoff0), f32c(data.iHon0), f32c(data.iHoff0)) if self.add_H0 else (None,) * 4
+            on_r, on_i = ops.soc_assemble(on, ksi_on, f32c(data.Lon), None, H0[0], H0[2], n, self.symmetrize, self.add_H_nonsoc)
+            off_r, off_i = ops.soc_assemble(off, ksi_off, f32c(data.Loff), inv, H0[1], H0[3], n, self.symmetrize, self.add_H_nonsoc)
+            Hr = self._cat_by_crystal(data, on_r, off_r, edge_counts)
+            Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
+            result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
+                           "wavefunction": None})
+            if self.calculate_sparsity:
+                result["sparsity_ratio"] = self.calculate_sparsity_ratio(data)
+            return result
         H0_on = f32c(data.Hon0) if self.add_H0 else None
         H0_off = f32c(data.Hoff0) if self.add_H0 else None
         on, off = self._blocks(self.onsite_hamiltonian_network, self.offsite_hamiltonian_network, node_pl, edge_rot, geo, data, inv, H0_on, H0_off)

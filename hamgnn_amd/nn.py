@@ -235,8 +235,11 @@ class HamLayer(nn.Module):
 
     def compile(self, device):
         self.residual_block.compile(device)
-        prog, self.girr, self.slot_pos = P.build_ham_linear_program(self.linear_transform.weight.detach().cpu().double().numpy(),
-                                                                    self.irreps_in, self.ham_irreps)
+        W = self.linear_transform.weight.detach().cpu().double().numpy()
+        if all(m == 1 for m, _, _ in self.ham_irreps):         # hamiltonian irreps: regroup the multiplicity-1 outputs by (L,p)
+            prog, self.girr, self.slot_pos = P.build_ham_linear_program(W, self.irreps_in, self.ham_irreps)
+        else:                                                  # xi networks (nao^2 x 0e): a plain o3.Linear
+            prog, self.girr, self.slot_pos = P.build_linear_program(W, self.irreps_in, self.ham_irreps), self.ham_irreps, None
         self._dp = ops.DeviceProgram(prog, device)
 
     def forward(self, x_planar):

@@ -91,13 +91,19 @@ def radial_hidden(rbf: torch.Tensor, layers: Sequence[torch.Tensor], act_cst: fl
     return out
 
 
-def rotate_gather(x: torch.Tensor, idx: Optional[torch.Tensor], geo: Geometry, elem_tab: torch.Tensor, transpose=False) -> torch.Tensor:
+def rotate_gather(x: torch.Tensor, idx: Optional[torch.Tensor], geo: Geometry, chan_tab: torch.Tensor, transpose=False,
+                  x2: Optional[torch.Tensor] = None, idx2: Optional[torch.Tensor] = None):
+    """one or two gathered sources rotated with the same per-edge frames; returns out (or (out, out2))."""
     E = geo.E
-    Dp = int(elem_tab.shape[0])
-    out = torch.empty(E, Dp, device=x.device, dtype=torch.float32)
-    check(lib().hg_rotate_gather(ptr(x), i64(x.stride(0)), ptr(idx), ptr(geo.wig), i32(geo.nW), geo.wig_off, ptr(elem_tab), i32(Dp),
-                                 i64(E), i32(1 if transpose else 0), ptr(out), i64(Dp), _stream()), "hg_rotate_gather")
-    return out
+    Dp = int(x.shape[1])
+    out = torch.empty(E, Dp, device=x.device, dtype=torch.float32)              # the kernel writes every slot incl. zero padding
+    out2 = torch.empty(E, Dp, device=x.device, dtype=torch.float32) if x2 is not None else None
+    if x2 is not None:
+        assert x2.stride(0) == x.stride(0)
+    check(lib().hg_rotate_gather(ptr(x), ptr(x2), i64(x.stride(0)), ptr(idx), ptr(idx2), ptr(geo.wig), i32(geo.nW), geo.wig_off,
+                                 ptr(chan_tab), i32(chan_tab.shape[0]), i64(E), i32(1 if transpose else 0), ptr(out), ptr(out2), i64(Dp),
+                                 _stream()), "hg_rotate_gather")
+    return out if x2 is None else (out, out2)
 
 
 PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, rows, tag) HIP event pairs around hg_tp_fused launches
@@ -179,3 +185,19 @@ def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetri
     check(lib().hg_ham_finish(ptr(Hraw), ptr(inv), ptr(H0), ptr(orb_mask), ptr(z), ptr(idx_a), ptr(idx_b), i32(nao), f32(sign),
                               i32(1 if symmetrize else 0), i64(rows), ptr(out), _stream()), "hg_ham_finish")
     return out
+
+
+def block_mean(x, tab, nao):
+    rows = x.shape[0]
+    out = torch.empty(rows, nao * nao, device=x.device, dtype=torch.float32)
+    check(lib().hg_block_mean(ptr(x), i64(x.stride(0)), ptr(tab), i32(nao), i64(rows), ptr(out), _stream()), "hg_block_mean")
+    return out
+
+
+def soc_assemble(H, ksi, L, inv, H0r, H0i, nao, symmetrize=True, zero_diag=False):
+    rows = H.shape[0]
+    outr = torch.empty(rows, 4 * nao * nao, device=H.device, dtype=torch.float32)
+    outi = torch.empty_like(outr)
+    check(lib().hg_soc_assemble(ptr(H), ptr(ksi), ptr(L), ptr(inv), ptr(H0r), ptr(H0i), i32(nao), i32(1 if symmetrize else 0),
+                                i32(1 if zero_diag else 0), i64(rows), ptr(outr), ptr(outi), _stream()), "hg_soc_assemble")
+    return outr, outi

@@ -245,6 +245,7 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
     H = prog.hidden
     for k in order:
         mk, lk, pk = irreps_out[k]
+        assert mk <= MAX_SEG_ROWS, "tensor-product targets wider than 64 channels per irrep are not supported by the planner"
         seg = seg_of_k[k]
         off, fan = lin_off[k]
         L = lin_scale_w[off:off + fan * mk].reshape(fan, mk).astype(np.float64) / math.sqrt(fan)
@@ -318,30 +319,42 @@ def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarL
     for i, k in paths:
         mi, li, _ = irr_in[i]
         mk = irreps_out[k][0]
-        W = weight[off:off + mi * mk].reshape(mi, mk).astype(np.float64) * (extra_scale / math.sqrt(fan[k]))
+        Wfull = weight[off:off + mi * mk].reshape(mi, mk).astype(np.float64) * (extra_scale / math.sqrt(fan[k]))
         off += mi * mk
-        seg = seg_of_k[k]
-        rto = prog.segs[seg][2]
         ksteps = in_layout.mulp[i] // 4
         # rows chunked like TP items so that the per-wave register budget is the same
         nc = 2 * li + 1
         chunk = rtm_max(nc) * 16
-        for r0 in range(0, mk, chunk):
-            r1 = min(mk, r0 + chunk)
-            rtm = ceil_div(r1 - r0, 16)
-            a1_off = prog.add_weights(_frag_A(W[:, r0:r1], ksteps, rtm, use_x4(in_layout.mulp[i], nc))[None])
-            _add_item(prog, seg, IT_LIN, [src], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0,
-                      a1_off, 0, 0, 0, r1 - r0, row_off=r0)
+        for seg, c0, c1 in prog.seg_chunks[k]:
+            W = Wfull[:, c0:c1]
+            for r0 in range(0, c1 - c0, chunk):
+                r1 = min(c1 - c0, r0 + chunk)
+                rtm = ceil_div(r1 - r0, 16)
+                a1_off = prog.add_weights(_frag_A(W[:, r0:r1], ksteps, rtm, use_x4(in_layout.mulp[i], nc))[None])
+                _add_item(prog, seg, IT_LIN, [src], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0,
+                          a1_off, 0, 0, 0, r1 - r0, row_off=r0)
         prog.flops_per_row += 2.0 * mi * mk * nc
     assert off == weight.size, (off, weight.size)
 
 
+MAX_SEG_ROWS = 64        # output channels per segment (bounds the LDS tile); wider irreps are split column-wise
+
+
 def new_program(irreps_out, hidden=0, flags_of=lambda k, ir: 0) -> Tuple[Program, Dict[int, int]]:
+    """seg_of_k[k] = segment id of output irrep k (first chunk); prog.seg_chunks[k] = [(segment, c0, c1), ...]."""
     lay = PlanarLayout(irreps_out)
     prog = Program(out_layout=lay, hidden=hidden)
     seg_of_k = {}
+    prog.seg_chunks = {}
     for k, (mk, lk, pk) in enumerate(lay.irreps):
-        seg_of_k[k] = _add_segment(prog, lk, mk, k, flags_of(k, (mk, lk, pk)))
+        chunks = []
+        for c0 in range(0, mk, MAX_SEG_ROWS):
+            c1 = min(mk, c0 + MAX_SEG_ROWS)
+            sid = _add_segment(prog, lk, c1 - c0, k, flags_of(k, (mk, lk, pk)))
+            prog.segs[sid][3] += c0                            # channel offset inside the planar block
+            chunks.append((sid, c0, c1))
+        seg_of_k[k] = chunks[0][0]
+        prog.seg_chunks[k] = chunks
     return prog, seg_of_k
 
 
@@ -423,13 +436,12 @@ def wigner_jtab(lmax) -> np.ndarray:
 
 
 def rotate_table(layout: PlanarLayout) -> np.ndarray:
-    """int32[Dp][4] = {l (or -1 for channel padding), component a, planar index of (b=0, u), mulp}."""
-    tab = np.full((layout.dim, 4), -1, dtype=np.int32)
+    """int32[nchan][4] = {l, planar offset of (component 0, channel u), mulp, is_padding}: one entry per channel slot."""
+    rows = []
     for (mul, l, p), off, mp in zip(layout.irreps, layout.off, layout.mulp):
-        for a in range(2 * l + 1):
-            for u in range(mul):
-                tab[off + a * mp + u] = (l, a, off + u, mp)
-    return tab
+        for u in range(mp):
+            rows.append((l, off + u, mp, 0 if u < mul else 1))
+    return np.asarray(rows, dtype=np.int32).reshape(-1, 4)
 
 
 def gate_tables(feature_irreps):
@@ -526,11 +538,12 @@ def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps):
         nc = 2 * li + 1
         chunk = rtm_max(nc) * 16
         ksteps = in_layout.mulp[i] // 4
-        for r0 in range(0, mk, chunk):
-            r1 = min(mk, r0 + chunk)
-            rtm = ceil_div(r1 - r0, 16)
-            a1_off = prog.add_weights(_frag_A(Mn[:, r0:r1], ksteps, rtm, use_x4(in_layout.mulp[i], nc))[None])
-            _add_item(prog, seg_of_k[g], IT_LIN, [0], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0, a1_off, 0, 0, 0, r1 - r0, row_off=r0)
+        for seg, c0, c1 in prog.seg_chunks[g]:
+            for r0 in range(0, c1 - c0, chunk):
+                r1 = min(c1 - c0, r0 + chunk)
+                rtm = ceil_div(r1 - r0, 16)
+                a1_off = prog.add_weights(_frag_A(Mn[:, c0 + r0:c0 + r1], ksteps, rtm, use_x4(in_layout.mulp[i], nc))[None])
+                _add_item(prog, seg, IT_LIN, [0], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0, a1_off, 0, 0, 0, r1 - r0, row_off=r0)
         prog.flops_per_row += 2.0 * mi * mk * nc
     return prog.finalize(), girr, slot_pos
 
@@ -579,3 +592,20 @@ def ham_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, 
                 val.append(sg * v)
             ptr.append(len(idx))
     return slot_tab, np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(val, np.float32)
+
+
+def shell_block_table(row: Irreps, nao) -> np.ndarray:
+    """int32[nao^2][4] = {r0, r1, c0, c1}: the (row shell, col shell) block of every matrix element (ksi block means)."""
+    bounds, o = [], 0
+    for _, l, _ in row:
+        bounds.append((o, o + 2 * l + 1))
+        o += 2 * l + 1
+    assert o == nao
+    owner = np.zeros(nao, dtype=np.int64)
+    for b, (a0, a1) in enumerate(bounds):
+        owner[a0:a1] = b
+    tab = np.zeros((nao * nao, 4), dtype=np.int32)
+    for r in range(nao):
+        for c in range(nao):
+            tab[r * nao + c] = (*bounds[owner[r]], *bounds[owner[c]])
+    return tab

@@ -41,10 +41,13 @@ int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const in
 
 /* node_features[sender] / [receiver] gathers of ConvBlockE3.forward (hamgnn/nn/convolution.py:138-141) and
  * PairInteractionBlock.forward (interaction_blocks.py:141-145), fused with the rotation into the edge-aligned frame:
- * out[e][i][a][u] = sum_b D_e^{l_i}[a][b] x[idx[e]][i][b][u]   (idx == NULL: identity gather; transpose != 0: D^T).
- * elem_tab: int32[Dp][4] = {l, a, base_in, mulp} per output element (hamgnn_amd/plan.py:rotate_table).              */
-int hg_rotate_gather(const float* x, int64_t x_stride, const int64_t* idx, const float* wig, int nW, const int32_t* wig_off,
-                     const int32_t* elem_tab, int Dp, int64_t E, int transpose, float* out, int64_t out_stride, void* stream);
+ * out_s[e][i][a][u] = sum_b D_e^{l_i}[a][b] x_s[idx_s[e]][i][b][u]  for up to two sources s = 0,1 sharing the edge's D
+ * (x1 == NULL: one source; idx == NULL: identity gather; transpose != 0: D^T, i.e. back to the global frame).
+ * chan_tab: int32[nchan][4] = {l, planar offset of (component 0, channel u), mulp, is_padding} (plan.py:rotate_table);
+ * padding channel slots are written as zeros.                                                                           */
+int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stride, const int64_t* idx0, const int64_t* idx1,
+                     const float* wig, int nW, const int32_t* wig_off, const int32_t* chan_tab, int nchan, int64_t E,
+                     int transpose, float* out0, float* out1, int64_t out_stride, void* stream);
 
 /* THE hot kernel.  Replaces, per launch, one whole MessagePackBlock.forward (hamgnn/nn/message_passing.py:191-231:
  * AttentionHeadsToVector + 2 x o3.TensorProduct(uvw, ~255 paths each) + 2 x LinearScaleWithWeights (tensor_products.py:25-47)
@@ -95,6 +98,16 @@ int hg_ham_merge(const float* coeff, int64_t c_stride, const float* wig, int nW,
 int hg_ham_finish(const float* Hraw, const int64_t* inv, const float* H0, const float* orb_mask, const int64_t* z,
                   const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int symmetrize, int64_t rows, float* H,
                   void* stream);
+
+/* SOC / so3 branch (hamgnn_output.py:3026-3144).  hg_block_mean = symmetrize_orbital_coefficients (:2367-2431): each element
+ * of the nao x nao xi matrix -> mean over its (row shell, col shell) block; tab int32[nao^2][4] = {r0, r1, c0, c1}.          */
+int hg_block_mean(const float* x, int64_t x_stride, const int32_t* tab, int nao, int64_t rows, float* out, void* stream);
+
+/* spin-block assembly: A_k = antiherm(xi * L[...,k]) through inv (NULL => on-site);
+ * real = [[H, A_y],[A_y, H]] + H0r (spin-diagonal H0r skipped if zero_diag: add_H_nonsoc, :3034-3049);
+ * imag = [[A_z, A_x],[-A_x, -A_z]] + H0i.   H [rows,nao^2], xi [rows,nao^2], L [rows,nao^2,3], outputs [rows,(2 nao)^2].  */
+int hg_soc_assemble(const float* H, const float* ksi, const float* L, const int64_t* inv, const float* H0r, const float* H0i,
+                    int nao, int symmetrize, int zero_diag, int64_t rows, float* out_real, float* out_imag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,24 @@ def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, 
     return {name + "_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"]), "sparsity_ratio": float(out["sparsity_ratio"])}
 
 
+def check_head_soc(device="cuda"):
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load("head_soc_so3_openmx_19")
+    m = load_weights(HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                       soc_switch=True, soc_basis="so3", calculate_sparsity=False), f["weights"])
+    bb = load("backbone")["graph"]
+    gd = dict(f["graph"])
+    for k in ("pos", "nbr_shift", "cell"):
+        gd[k] = bb[k]
+    g = to_graph(gd, device)
+    rep = {"node_attr": torch.from_numpy(f["inputs"]["node_attr"]).float().to(device),
+           "edge_attr": torch.from_numpy(f["inputs"]["edge_attr"]).float().to(device)}
+    out = m(g, rep)
+    torch.cuda.synchronize()
+    return {"soc_real_rel_err": rel(out["hamiltonian_real"], f["outputs"]["hamiltonian_real"]),
+            "soc_imag_rel_err": rel(out["hamiltonian_imag"], f["outputs"]["hamiltonian_imag"])}
+
+
 def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, nao=19, num_layers=2, radial=(16, 16), num_radial=8):
     """Seeded random weights on a synthetic periodic cell: full backbone + head, HIP (fp32) vs oracle (fp64, CPU)."""
     from oracle import hamgnn_ref as R

@@ -44,3 +44,9 @@ def test_full_forward_vs_oracle_random_cell():
     r = G.oracle_vs_hip_random()
     print(r)
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
+
+
+def test_head_soc_so3_golden():
+    r = G.check_head_soc()
+    print(r)
+    assert r["soc_real_rel_err"] < G.TOL and r["soc_imag_rel_err"] < G.TOL
