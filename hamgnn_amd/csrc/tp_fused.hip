@@ -52,9 +52,32 @@ __device__ __forceinline__ int64_t pick_stride(const TpArgs& A, int i) {
     return i == 0 ? A.sstride[0] : (i == 1 ? A.sstride[1] : (i == 2 ? A.sstride[2] : A.sstride[3]));
 }
 
+#ifdef HG_ABL_NOA
+#define HG_LDA(p) ((f32x4){.1f, .2f, .3f, .4f})
+#else
+#define HG_LDA(p) (*(p))
+#endif
+#ifndef HG_EARLY
+#define HG_NO_EARLY 1            // early requests of scale/GEMM2 operands cost more in spills than they hide (r1 A/B: 12.65 -> 12.24 ms)
+#endif
+#ifndef HG_DMA_AUX
+#define HG_DMA_AUX 2              // cache policy of the B-operand DMA: nt (streamed once per CU; keeps the shared A lines in L1; r1 A/B: -3 %)
+#endif
+#define HG_STAGE_FLOATS 2816      // wave-private LDS-DMA ring for B operands: 11 KiB = 11 x 1-KiB (float4) or 44 x 256-B (dword) slots
+
+// LDS-DMA: per-lane global address -> LDS at (wave-uniform base + lane * size); no VGPR round trip, counted by vmcnt
+__device__ __forceinline__ void hg_dma16(const float* __restrict__ gsrc, float* lds_dst) {
+#ifndef HG_ABL_NOB
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, HG_DMA_AUX);
+#endif
+}
+__device__ __forceinline__ void hg_dma4(const float* __restrict__ gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
+}
+
 template <int MM, int RTM>
 __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict__ it, float* __restrict__ tile,
-                                          int rowstride, int lk, int rto, int mul_k, int64_t erow, int lane) {
+                                          float* __restrict__ stage, int rowstride, int lk, int rto, int mul_k, int64_t erow, int lane) {
     constexpr int NC = 2 * MM + 1;
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], s0 = it[1], s1 = it[2], in_off = it[3], in_mulp = it[4], li = it[5], neg = it[7];
@@ -68,105 +91,113 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
         for (int c = 0; c < NC; ++c) mid[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---------------------------------------------------------------- GEMM1: mid = A1 fragments x B(rotated features)
-    // A operand: one float4 per lane = 4 K-steps (pre-packed, coalesced 1 KiB per wave-load).
-    // B operand: x4 mode (mulp % 16 == 0, NC <= 3): one float4 per (column, 4 K-steps), permuted K order u = 16G + 4g + q;
-    //            x1 mode: one dword per (column, K-step), u = 4s + g.
-    // Register double buffering: the fragments of group t+1 are requested before the MFMAs of group t are issued, so the
-    // L2/HBM latency of the operand stream hides behind 4*RTM*NC MFMAs even at 2 waves per SIMD.
-    const int step = neg ? -in_mulp : in_mulp;                 // column c <-> m = c - MM, input component a = li +/- m
-    const int a0 = neg ? li + MM : li - MM;
-    const int ngrp = (ksteps + 3) >> 2;
+    // A operand: one float4 per lane = 4 K-steps (pre-packed, coalesced 1 KiB per wave-load), register double-buffered.
+    // B operand: rows of 16 different edges => every gather wave-load touches 16 distinct cache lines, and the per-CU
+    // miss-level parallelism (not bytes, not capacity: an L2-resident 2.7 MB working set is as slow as the full one; only an
+    // L1-resident one is fast -- r1 experiments) bounds the kernel: ~92 k of the 136 k line requests per 16-edge tile were
+    // 16-byte B pieces.  So B is staged per item and source as what it is in memory: ONE contiguous span of NC*mulp floats per
+    // edge row (components a_lo .. a_lo+NC-1 of irrep i).  LDS-DMA (global_load_lds, no landing VGPRs) fetches it in
+    // full-line requests -- one instruction = 8 rows x 128 B, lane (r8 = lane>>3) takes piece (lane&7)^r8 of its row so that
+    // the later fragment reads of 16 different rows spread over the LDS banks -- all requests of the item in flight at once,
+    // ONE vmcnt(0), then the MFMA loop reads fragments from LDS.   Slot (2j+h) holds pieces 8j..8j+7 of rows 8h..8h+7.
     const int nsrc = s1 >= 0 ? 2 : 1;
-    const int ntot = nsrc * ngrp;
+    const int ngrp = (ksteps + 3) >> 2;
+    const int P1 = in_mulp >> 2;                               // float4 pieces per column
+    const int P = NC * P1;                                     // pieces per row span (planner guarantees P <= 40)
+    const int nj = (P + 7) >> 3;
+    const int a_lo = li - MM;
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(A.W + it[11]) + lane;      // [src][G][rt][lane]
-    const float* __restrict__ xsrc0 = pick_src(A, s0) + erow * pick_stride(A, s0) + in_off + a0 * in_mulp;
-    const float* __restrict__ xsrc1 = nsrc == 2 ? pick_src(A, s1) + erow * pick_stride(A, s1) + in_off + a0 * in_mulp : xsrc0;
+    // staging role of this lane: rows r8 and 8 + r8 of the wave's 16 edges
+    const int r8s = lane >> 3, p8s = (lane & 7) ^ r8s;
+    const int64_t ebase = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16;
+    const int64_t eA = ebase + r8s < A.rows ? ebase + r8s : A.rows - 1;
+    const int64_t eB = ebase + 8 + r8s < A.rows ? ebase + 8 + r8s : A.rows - 1;
+    // fragment-read role: edge el = 8 h + r8e
+    const int lds_lane = (el >> 3) * 256 + (el & 7) * 32;      // float offset of (h, r8e) inside a slot pair
+    const int r8e = el & 7;
 
     // early requests for the later phases (their latency hides behind GEMM1)
     const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
     const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(A.W + it[12]) + lane;
     f32x4 hb_n = (f32x4){0.f, 0.f, 0.f, 0.f}, w3_n[RTM];
+#ifndef HG_NO_EARLY
     if (typ == 0) {
         hb_n = *reinterpret_cast<const f32x4*>(hrow);
 #pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = w3[rt * 64];
+        for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = HG_LDA(w3 + rt * 64);
     }
+#endif
 
-    if (NC <= 3 && x4) {                                       // planner sets x4 only for NC <= 3 (keeps bv[] at 12 VGPRs)
-        f32x4 av_n[RTM], bv_n[NC];
-        {
-            const float* __restrict__ x0 = xsrc0 + 4 * g;
+    f32x4 av_n[RTM];
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) bv_n[c] = *reinterpret_cast<const f32x4*>(x0 + c * step);
-        }
+    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + rt * 64);
 #pragma unroll 1
-        for (int t = 0; t < ntot; ++t) {
-            f32x4 av[RTM], bv[NC];
+    for (int si = 0; si < nsrc; ++si) {
+        const int sidx = si ? s1 : s0;
+        const float* __restrict__ sb = pick_src(A, sidx) + in_off + a_lo * in_mulp;
+        const int64_t sst = pick_stride(A, sidx);
+        const float* __restrict__ rowA = sb + eA * sst;
+        const float* __restrict__ rowB = sb + eB * sst;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // previous fragment reads retired
+#pragma unroll 1
+        for (int j = 0; j < nj; ++j) {
+            int p = 8 * j + p8s;
+            p = p < P ? p : P - 1;
+            hg_dma16(rowA + 4 * p, stage + (2 * j) * 256);
+            hg_dma16(rowB + 4 * p, stage + (2 * j + 1) * 256);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int abase = si * ngrp;
+        if (NC <= 3 && x4) {                                   // permuted K: fragment = piece (c', 4G + g)
+#pragma unroll 1
+            for (int G = 0; G < ngrp; ++G) {
+                f32x4 av[RTM], bv[NC];
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+                if (abase + G + 1 < nsrc * ngrp) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) bv[c] = bv_n[c];
-            if (t + 1 < ntot) {
-                const int tn = t + 1;
-                const int G = tn >= ngrp ? tn - ngrp : tn;
-                const float* __restrict__ x0 = (tn >= ngrp ? xsrc1 : xsrc0) + 4 * g + 16 * G;
+                    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + ((abase + G + 1) * RTM + rt) * 64);
+                }
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[(tn * RTM + rt) * 64];
+                for (int c = 0; c < NC; ++c) {
+                    const int piece = (neg ? NC - 1 - c : c) * P1 + 4 * G + g;
+                    bv[c] = *reinterpret_cast<const f32x4*>(stage + (piece >> 3) * 512 + lds_lane + (((piece & 7) ^ r8e) << 2));
+                }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) bv_n[c] = *reinterpret_cast<const f32x4*>(x0 + c * step);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                    for (int c = 0; c < NC; ++c)
-                        mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
-        }
-    } else {
-        // x1: K-steps s = 0 .. nsrc*ksteps-1 flattened; A float4 covers steps 4G..4G+3 of one source
-        const int nsteps = nsrc * ksteps;
-        float b_n[NC];
-        f32x4 av[RTM];
-        {
-            const float* __restrict__ x0 = xsrc0 + g;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) b_n[c] = x0[c * step];
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[rt * 64];
-        }
-        int sl = 0, srcsel = 0;                                // local step within the source, source index
+        } else {                                               // natural K: element (c', 4 sl + g) = piece c' P1 + sl, component g
+            f32x4 av[RTM];
 #pragma unroll 1
-        for (int t = 0; t < nsteps; ++t) {
-            float b[NC];
+            for (int sl = 0; sl < ksteps; ++sl) {
+                const int q = sl & 3;
+                if (q == 0) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) b[c] = b_n[c];
-            const int q = sl & 3;
-            f32x4 avc[RTM];
+                    for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+                    const int Gn = abase + (sl >> 2) + 1;
+                    if (Gn < nsrc * ngrp) {
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) avc[rt] = av[rt];
-            // advance
-            int sl_n = sl + 1, src_n = srcsel;
-            if (sl_n == ksteps) { sl_n = 0; src_n = srcsel + 1; }
-            if (t + 1 < nsteps) {
-                const float* __restrict__ x0 = (src_n ? xsrc1 : xsrc0) + g + 4 * sl_n;
+                        for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + (Gn * RTM + rt) * 64);
+                    }
+                }
+                float b[NC];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) b_n[c] = x0[c * step];
-                if ((sl_n & 3) == 0) {
-                    const int Gn = src_n * ngrp + (sl_n >> 2);
+                for (int c = 0; c < NC; ++c) {
+                    const int piece = (neg ? NC - 1 - c : c) * P1 + sl;
+                    b[c] = stage[(piece >> 3) * 512 + lds_lane + (((piece & 7) ^ r8e) << 2) + g];
+                }
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) av[rt] = aw[(Gn * RTM + rt) * 64];
+                for (int rt = 0; rt < RTM; ++rt) {
+                    const float a = q == 0 ? av[rt][0] : (q == 1 ? av[rt][1] : (q == 2 ? av[rt][2] : av[rt][3]));
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], mid[rt][c], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) {
-                const float a = q == 0 ? avc[rt][0] : (q == 1 ? avc[rt][1] : (q == 2 ? avc[rt][2] : avc[rt][3]));
-#pragma unroll
-                for (int c = 0; c < NC; ++c) mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], mid[rt][c], 0, 0, 0);
-            }
-            sl = sl_n; srcsel = src_n;
         }
     }
 
@@ -179,8 +210,14 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
         const int hgrp = A.hidden >> 4;
         const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(A.W + it[14]) + lane;
         f32x4 a2_n[RTM];
+#ifdef HG_NO_EARLY
+        hb_n = *reinterpret_cast<const f32x4*>(hrow);
 #pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];                               // GEMM2 operands of rtp = 0, early
+        for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = HG_LDA(w3 + rt * 64);
+#else
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);                      // GEMM2 operands of rtp = 0, early
+#endif
 #pragma unroll 1
         for (int G = 0; G < hgrp; ++G) {
             const f32x4 hb = hb_n;
@@ -197,6 +234,10 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rt][q], hb[q], S[rt], 0, 0, 0);
         }
+#ifdef HG_NO_EARLY
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);
+#endif
         const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(A.W + it[13]) + g;     // [rt][c][g] float4
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
@@ -280,7 +321,7 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 }
 
 #define HG_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, it, tile, rowstride, lk, rto, mul_k, erow, lane); break;
+    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, it, tile, stage, rowstride, lk, rto, mul_k, erow, lane); break;
 
 __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -289,6 +330,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
     const bool valid = e < A.rows;
     const int64_t erow = valid ? e : A.rows - 1;
     float* tile = lds + wave * A.tile_floats_wave;
+    float* stage = tile + (A.tile_floats_wave - HG_STAGE_FLOATS);          // B-operand DMA ring behind the segment tile
 
     for (int sg = 0; sg < A.nseg; ++sg) {
         const int* __restrict__ S = A.segs + sg * 8;

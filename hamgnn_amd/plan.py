@@ -22,6 +22,7 @@ GEMM1 -> scale -> GEMM2 without any cross-lane movement (C regs feed the next B 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -39,6 +40,7 @@ SEG_UNROTATE = 1     # epilogue applies D^l(R_e)^T (messages go back to the glob
 ITEM_I32 = 20        # int32 words per item record
 SEG_I32 = 8          # int32 words per segment record
 MAX_SRC = 4
+STAGE_FLOATS = 2816      # = HG_STAGE_FLOATS of csrc/tp_fused.hip (wave-private LDS-DMA ring for B operands)
 
 
 def ceil_div(a, b):
@@ -47,7 +49,8 @@ def ceil_div(a, b):
 
 def rtm_max(nc):
     """row tiles per item: keeps the GEMM1 accumulators at <= 16 f32x4 fragments (64 VGPRs) so 3-4 waves/SIMD fit."""
-    return max(1, min(4, 16 // nc))
+    tab = [int(v) for v in os.environ.get("HG_RTM", "4,4,3,2,1,1,1").split(",")]        # row tiles by MM = (nc-1)/2 (r1 A/B)
+    return tab[(nc - 1) // 2]
 
 
 class PlanarLayout:
@@ -178,12 +181,14 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     rto = ceil_div(mul_k, 16)
     prog.segs.append([lk, mul_k, rto, lay.off[out_index], lay.mulp[out_index], 0, 0, flags])
     prog.seg_items.append([])
-    prog.tile_floats = max(prog.tile_floats, 4 * mul_k * ((2 * lk + 1) * 16 + 4))   # 4 wave-private tiles [mul_k rows]
+    prog.tile_floats = max(prog.tile_floats, 4 * (mul_k * ((2 * lk + 1) * 16 + 4) + STAGE_FLOATS))   # 4 waves x (tile [mul_k rows] + DMA ring)
     return len(prog.segs) - 1
 
 
 def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0):
     assert len(srcs) in (1, 2)
+    if (2 * mm + 1) * in_mulp > 160:
+        raise NotImplementedError(f"input irrep block too wide for the kernel's B staging ring: (2*{mm}+1) x {in_mulp} channels > 160")
     rec = [typ, srcs[0], srcs[1] if len(srcs) == 2 else -1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp,
            a1, w3, cf, a2, nrows, row_off, 1 if use_x4(in_mulp, 2 * mm + 1) else 0, 0, 0]
     assert len(rec) == ITEM_I32

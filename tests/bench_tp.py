@@ -6,7 +6,7 @@ import torch
 from hamgnn_amd import nn as hnn, ops, plan as P
 IRR = {"A": "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e", "B": "64x0e+32x1o+16x1e+8x2o+20x2e+8x3o+4x3e+4x4e"}
 ap = argparse.ArgumentParser(); ap.add_argument("--irreps", default="A"); ap.add_argument("--edges", type=int, default=131072)
-ap.add_argument("--reps", type=int, default=5); ap.add_argument("--tag", default="")
+ap.add_argument("--reps", type=int, default=5); ap.add_argument("--tag", default=""); ap.add_argument("--same-rows", type=int, default=0, help="alias the B-operand rows onto this many distinct rows (cache-residency experiment)")
 a = ap.parse_args()
 irr, sh = IRR[a.irreps], "0e+1o+2e+3o+4e+5o"
 torch.manual_seed(0)
@@ -21,6 +21,13 @@ ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.lo
 shift = (torch.randn(E, 3, generator=g) * 4).to(dev)
 geo = ops.Geometry(pos, ei, shift, 26.0, 64, 6, torch.from_numpy(P.wigner_jtab(6)).to(dev))
 xs, xd, fe = (torch.randn(E, lay.dim, generator=g).to(dev) for _ in range(3))
+if a.same_rows:
+    k = a.same_rows
+    idx = (torch.arange(E, device=dev) % k)
+    if k == 1:
+        xs, xd, fe = (t[:1].expand(E, lay.dim) for t in (xs, xd, fe))
+    else:   # rows repeat with period k: footprint k * 3 * Dp * 4 bytes
+        xs, xd, fe = (t[:k].repeat((E + k - 1) // k, 1)[:E].contiguous() for t in (xs, xd, fe))
 hn = ops.radial_hidden(geo.rbf, m._hn, 1.679); he = ops.radial_hidden(geo.rbf, m._he, 1.679)
 for _ in range(2):
     out = ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)

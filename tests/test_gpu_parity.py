@@ -50,3 +50,12 @@ def test_head_soc_so3_golden():
     r = G.check_head_soc()
     print(r)
     assert r["soc_real_rel_err"] < G.TOL and r["soc_imag_rel_err"] < G.TOL
+
+
+def test_sharded_two_rank_forward_matches_single_rank():
+    """2 ranks (gloo) sharing cuda:0: pair-sharded edges + all-reduce of node aggregates == unsharded forward."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29541", os.path.join(root, "tests", "dist_gpu_check.py")], capture_output=True, text=True, timeout=300)
+    assert "DIST_CHECK" in cp.stdout, cp.stdout[-2000:] + cp.stderr[-2000:]
