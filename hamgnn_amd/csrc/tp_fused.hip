@@ -63,6 +63,13 @@ __device__ __forceinline__ int64_t pick_stride(const TpArgs& A, int i) {
 #ifndef HG_DMA_AUX
 #define HG_DMA_AUX 2              // cache policy of the B-operand DMA: nt (streamed once per CU; keeps the shared A lines in L1; r1 A/B: -3 %)
 #endif
+// tiles and DMA rings are wave-private: the four waves of a workgroup never exchange data, so a wave-local LDS fence
+// (LDS ops of one wave retire in order) replaces workgroup barriers and the waves free-run (their DMA waits interleave).
+#ifdef HG_USE_BARRIER
+#define HG_WAVE_FENCE() __syncthreads()
+#else
+#define HG_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
 #define HG_STAGE_FLOATS 2816      // wave-private LDS-DMA ring for B operands: 11 KiB = 11 x 1-KiB (float4) or 44 x 256-B (dword) slots
 
 // LDS-DMA: per-lane global address -> LDS at (wave-uniform base + lane * size); no VGPR round trip, counted by vmcnt
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         const int rowstride = nco * 16 + 4;
         const int tfl = mul_k * rowstride;
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
-        __syncthreads();
+        HG_WAVE_FENCE();
         for (int ii = ib; ii < ie; ++ii) {
             const int* __restrict__ it = A.items + ii * 20;
             const int mm = it[6], rtm = it[9];
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
                 default: break;
             }
         }
-        __syncthreads();
+        HG_WAVE_FENCE();
         switch (lk) {
             case 0: epilogue<0>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
             case 1: epilogue<1>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
             case 6: epilogue<6>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
             default: break;
         }
-        __syncthreads();
+        HG_WAVE_FENCE();
     }
 }
 
