@@ -1,0 +1,121 @@
+"""`graph_data.npz` reader / writer for the hot path (reference container: hamgnn/data/graph_data.py:96-185 NPZGraphDataset;
+produced by DFT_interfaces/*/graph_data_gen.py:357-374 as ``np.savez(path, graph={idx: Data(...)})``).
+
+The reference stores pickled torch_geometric ``Data`` objects.  This reader works without torch_geometric: a restricted
+unpickler maps ``torch_geometric.data.*`` classes onto the dependency-free ``Graph`` container (attribute + key access,
+same field names), so files written by the reference tool-chain and by ``save_graph_npz`` load the same way.  Dict-of-
+arrays graphs (the reference's second accepted form, graph_data.py:141-156) are converted as well.  LMDB
+(graph_data.py:23-93, keys ``num_graphs`` / ``graph_{i}``) needs the ``lmdb`` module, which this image lacks: a clear error."""
+from __future__ import annotations
+
+import io
+import pickle
+import zipfile
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from .graph import Graph, collate
+
+
+class _PyGStub:
+    """stand-in for torch_geometric.data.Data / storage classes while unpickling: keeps the attribute dict."""
+
+    def __init__(self, *a, **k):
+        self.__dict__.update(k)
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__["_state"] = state
+
+
+def _to_graph(obj) -> Graph:
+    if isinstance(obj, Graph):
+        return obj
+    if isinstance(obj, dict):
+        items = obj
+    else:
+        d = dict(getattr(obj, "__dict__", {}))
+        store = d.get("_store", None)                       # PyG >= 2: Data.__dict__['_store'] is a GlobalStorage with a _mapping
+        if store is not None:
+            sd = getattr(store, "__dict__", {})
+            items = dict(sd.get("_mapping", sd))
+        else:
+            items = {k: v for k, v in d.items() if not k.startswith("_")}
+    g = Graph()
+    for k, v in items.items():
+        if isinstance(v, np.ndarray):
+            v = torch.from_numpy(v)
+        g[k] = v
+    for req in ("z", "pos", "edge_index"):
+        if req not in g:
+            raise ValueError(f"graph record lacks the field {req!r}")
+    return g
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith("torch_geometric"):
+            return _PyGStub
+        if module.startswith("hamgnn_amd.data") and name == "Graph":
+            return Graph
+        return super().find_class(module, name)
+
+
+def load_graph_npz(path: str) -> List[Graph]:
+    """All graphs of a ``graph_data.npz`` as Graph objects (order of the stored dict)."""
+    with zipfile.ZipFile(path) as zf:
+        names = zf.namelist()
+        if "graph.npy" in names:
+            with zf.open("graph.npy") as f:
+                buf = io.BytesIO(f.read())
+            major, minor = np.lib.format.read_magic(buf)
+            (np.lib.format.read_array_header_1_0 if major == 1 else np.lib.format.read_array_header_2_0)(buf)
+            obj = _Unpickler(buf).load()                    # object array of shape () holding the dict
+            payload = obj.item() if isinstance(obj, np.ndarray) else obj
+            records = list(payload.values()) if isinstance(payload, dict) else list(payload)
+            return [_to_graph(r) for r in records]
+    with np.load(path, allow_pickle=False) as data:         # architecture 2: every key is one graph stored as arrays is not poolable
+        raise ValueError(f"{path}: no 'graph' entry (found {list(data.keys())[:5]})")
+
+
+def save_graph_npz(graphs: Sequence[Graph] | Dict[int, Graph], path: str):
+    """Write graphs in the reference container format: key 'graph' -> dict {index: graph object}."""
+    d = dict(graphs) if isinstance(graphs, dict) else {i: g for i, g in enumerate(graphs)}
+    np.savez(path, graph=np.array(d, dtype=object))
+
+
+class NPZGraphDataset:
+    """Minimal mirror of the reference dataset class (len / getitem / optional transform)."""
+
+    def __init__(self, npz_path: str, indices=None, transform=None, preload: int = 0):
+        self.data_list = load_graph_npz(npz_path)
+        self.indices = list(indices) if indices is not None else list(range(len(self.data_list)))
+        self.transform = transform
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, list):
+            return [self[i] for i in idx]
+        g = self.data_list[self.indices[idx]]
+        return self.transform(g) if self.transform is not None else g
+
+
+class LMDBGraphDataset:
+    def __init__(self, *a, **k):
+        try:
+            import lmdb  # noqa: F401
+        except ImportError as e:
+            raise ImportError("LMDB graph stores need the `lmdb` module, which is not available in this environment; "
+                              "convert with tools/npz_to_lmdb.py's inverse or use graph_data.npz") from e
+        raise NotImplementedError("LMDB reader: not built this round (SURVEY 8f-1)")
+
+
+def batches(graphs: Sequence[Graph], batch_size: int = 1):
+    for i in range(0, len(graphs), batch_size):
+        yield collate(list(graphs[i:i + batch_size]))

@@ -156,7 +156,8 @@ def check_head_soc(device="cuda"):
             "soc_imag_rel_err": rel(out["hamiltonian_imag"], f["outputs"]["hamiltonian_imag"])}
 
 
-def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, nao=19, num_layers=2, radial=(16, 16), num_radial=8):
+def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, nao=19, num_layers=2, radial=(16, 16), num_radial=8,
+                         n_graphs=1):
     """Seeded random weights on a synthetic periodic cell: full backbone + head, HIP (fp32) vs oracle (fp64, CPU)."""
     from oracle import hamgnn_ref as R
     from hamgnn_amd.data import synthetic as S
@@ -174,8 +175,13 @@ def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, n
         ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True)
     finally:
         torch.set_default_dtype(prev)
-    g = S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004)
-    S.add_random_targets(g, nao, seed=seed)
+    gs = [S.add_random_targets(S.random_cell(n_atoms + 2 * k, [14, 8, 6, 1], seed=seed + k, density=0.004), nao, seed=seed + k)
+          for k in range(n_graphs)]
+    if n_graphs == 1:
+        g = gs[0]
+    else:
+        from hamgnn_amd.data import collate
+        g = collate(gs)                                       # multi-crystal batch: per-graph inverse offsets + [on;off] interleave
     hip = load_weights(HamGNNConvE3(cfg), {k: v for k, v in ref.state_dict().items()})
     hip_head = load_weights(HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
                                               soc_switch=False), {k: v for k, v in ref_head.state_dict().items()})

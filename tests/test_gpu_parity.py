@@ -59,3 +59,9 @@ def test_sharded_two_rank_forward_matches_single_rank():
     cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                          "--master-port", "29541", os.path.join(root, "tests", "dist_gpu_check.py")], capture_output=True, text=True, timeout=300)
     assert "DIST_CHECK" in cp.stdout, cp.stdout[-2000:] + cp.stderr[-2000:]
+
+
+def test_multi_crystal_batch_vs_oracle():
+    r = G.oracle_vs_hip_random(n_graphs=3, seed=5)
+    print(r)
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL

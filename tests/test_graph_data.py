@@ -1,0 +1,52 @@
+"""graph_data.npz container round trip, the torch_geometric-free unpickling shim, batching."""
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+
+from hamgnn_amd.data import Graph, collate
+from hamgnn_amd.data import graph_data as GD
+from hamgnn_amd.data import synthetic as S
+
+
+def test_npz_roundtrip(tmp_path):
+    g1 = S.add_random_targets(S.si_diamond(primitive=True), 19)
+    g2 = S.add_random_targets(S.random_cell(5, [14, 8], seed=1, density=0.004), 19)
+    p = str(tmp_path / "graph_data.npz")
+    GD.save_graph_npz([g1, g2], p)
+    ds = GD.NPZGraphDataset(p)
+    assert len(ds) == 2
+    for a, b in zip(ds.data_list, (g1, g2)):
+        for k in ("z", "pos", "edge_index", "nbr_shift", "inv_edge_idx", "Hon0", "Hoff0"):
+            assert torch.equal(a[k], b[k])
+        assert a.z is a["z"]
+
+
+def test_reads_pyg_style_pickles_without_torch_geometric(tmp_path):
+    """records pickled as torch_geometric.data.data.Data (attribute dict / _store mapping) load as Graph."""
+    mod = types.ModuleType("torch_geometric"); sub = types.ModuleType("torch_geometric.data"); sub2 = types.ModuleType("torch_geometric.data.data")
+    Data = type("Data", (), {"__init__": lambda self, **k: self.__dict__.update(k)})   # what the producer side pickles
+    Data.__module__, Data.__qualname__ = "torch_geometric.data.data", "Data"
+    sub2.Data = Data
+    sys.modules.update({"torch_geometric": mod, "torch_geometric.data": sub, "torch_geometric.data.data": sub2})
+    try:
+        g = S.si_diamond(primitive=True)
+        rec = Data(**{k: v for k, v in g.items()})
+        p = str(tmp_path / "graph_data.npz")
+        np.savez(p, graph=np.array({0: rec}, dtype=object))
+    finally:
+        for k in ("torch_geometric", "torch_geometric.data", "torch_geometric.data.data"):
+            sys.modules.pop(k, None)
+    out = GD.load_graph_npz(p)
+    assert isinstance(out[0], Graph) and torch.equal(out[0].edge_index, g.edge_index) and torch.equal(out[0]["pos"], g.pos)
+
+
+def test_collate_offsets():
+    g1, g2 = S.si_diamond(primitive=True), S.random_cell(4, [14, 8], seed=2, density=0.004)
+    b = collate([g1, g2])
+    assert b.z.shape[0] == 6 and b.edge_index.shape[1] == g1.num_edges + g2.num_edges
+    assert torch.equal(b.edge_index[:, g1.num_edges:], g2.edge_index + 2)
+    assert torch.equal(b.inv_edge_idx[g1.num_edges:], g2.inv_edge_idx)          # graph-local, as the reference expects
+    assert b.node_counts.tolist() == [2, 4] and b.batch.tolist() == [0, 0, 1, 1, 1, 1]
