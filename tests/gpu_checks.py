@@ -197,6 +197,47 @@ def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, n
             "H_rel_err": rel(H, H_ref), "H_mae": (H.double().cpu() - H_ref).abs().mean().item()}
 
 
+def check_default_irreps_si2(device="cuda", which="A"):
+    """BASELINE config #1: Si diamond 2-atom cell (172 edges) with the shipped default irreps (set-A, D=877, l<=6, sh lmax 5,
+    64 radial, MLP [64,64], 3 layers, nao 19) -- full HIP forward vs the fp64 oracle.  Exercises every kernel instantiation."""
+    import bench
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    irreps = bench.IRREPS[which]
+    cfg = bench.make_cfg(irreps)
+    torch.manual_seed(666)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.HamGNNConvE3(cfg)
+        ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", symmetrize=True, add_H0=True)
+    finally:
+        torch.set_default_dtype(prev)
+    g = S.add_random_targets(S.si_diamond(primitive=True), 19, seed=0)
+    hip = load_weights(HamGNNConvE3(cfg), dict(ref.state_dict()))
+    hip_head = load_weights(HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                              soc_switch=False), dict(ref_head.state_dict()))
+    g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    with torch.no_grad():
+        rep_ref = ref(g64)
+        H_ref = ref_head(g64, rep_ref)["hamiltonian"]
+        gd = g.to(device)
+        rep = hip(gd)
+        H = hip_head(gd, rep)["hamiltonian"]
+        # network part alone (no H0): the parity figure that is not diluted by the added reference Hamiltonian
+        ref_head.add_H0 = False
+        hip_head.add_H0 = False
+        Hn_ref = ref_head(g64, rep_ref)["hamiltonian"]
+        Hn = hip_head(gd, rep)["hamiltonian"]
+    torch.cuda.synchronize()
+    return {"irreps": which, "E": g.num_edges, "Hnet_rel_err": rel(Hn, Hn_ref), "Hnet_absmax": Hn_ref.abs().max().item(), "node_rel_err": rel(rep["node_attr"], rep_ref["node_attr"]),
+            "edge_rel_err": rel(rep["edge_attr"], rep_ref["edge_attr"]), "H_rel_err": rel(H, H_ref),
+            "H_mae": (H.double().cpu() - H_ref).abs().mean().item(), "H_absmax": H_ref.abs().max().item()}
+
+
 def smoke_check():
     r = {}
     r.update(check_geometry())

@@ -65,3 +65,11 @@ def test_multi_crystal_batch_vs_oracle():
     r = G.oracle_vs_hip_random(n_graphs=3, seed=5)
     print(r)
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
+
+
+@pytest.mark.parametrize("which", ["A", "B"])
+def test_si2_default_irreps_vs_oracle(which):
+    """BASELINE config #1 with the shipped irreps (set-A: D=877, l<=6) and the lmax-4 set (set-B)."""
+    r = G.check_default_irreps_si2(which=which)
+    print(r)
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL and r["Hnet_rel_err"] < G.TOL
