@@ -99,41 +99,26 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 
     // ---------------------------------------------------------------- GEMM1: mid = A1 fragments x B(rotated features)
     // A operand: one float4 per lane = 4 K-steps (pre-packed, coalesced 1 KiB per wave-load), register double-buffered.
-    // B operand: rows of 16 different edges => every gather wave-load touches 16 distinct cache lines, and the per-CU
-    // miss-level parallelism (not bytes, not capacity: an L2-resident 2.7 MB working set is as slow as the full one; only an
-    // L1-resident one is fast -- r1 experiments) bounds the kernel: ~92 k of the 136 k line requests per 16-edge tile were
-    // 16-byte B pieces.  So B is staged per item and source as what it is in memory: ONE contiguous span of NC*mulp floats per
-    // edge row (components a_lo .. a_lo+NC-1 of irrep i).  LDS-DMA (global_load_lds, no landing VGPRs) fetches it in
-    // full-line requests -- one instruction = 8 rows x 128 B, lane (r8 = lane>>3) takes piece (lane&7)^r8 of its row so that
-    // the later fragment reads of 16 different rows spread over the LDS banks -- all requests of the item in flight at once,
-    // ONE vmcnt(0), then the MFMA loop reads fragments from LDS.   Slot (2j+h) holds pieces 8j..8j+7 of rows 8h..8h+7.
+    // B operand: per item and source ONE contiguous span of NC*mulp floats per edge row (components a_lo .. a_lo+NC-1 of the
+    // input irrep), staged by LDS-DMA (global_load_lds: no landing VGPRs, all requests of the item in flight at once, ONE
+    // vmcnt(0)).  One DMA instruction = 16 rows x 4 consecutive 16-B pieces (lane = row + 16*(piece&3)), which makes the LDS
+    // image linear:  float offset(piece p, row e) = 64 p + 4 e.  A fragment read is then `column base + 64*step`: one pointer
+    // per column bumped by a constant (the r1 ISA audit of the previous swizzled image showed 241 instructions per 14 MFMAs
+    // in this loop -- issue-bound on address arithmetic, not memory-bound).  ds_read_b128 of 16 rows is conflict-free, the
+    // dword reads of x1 mode are 2-way.
     const int nsrc = s1 >= 0 ? 2 : 1;
     const int ngrp = (ksteps + 3) >> 2;
     const int P1 = in_mulp >> 2;                               // float4 pieces per column
     const int P = NC * P1;                                     // pieces per row span (planner guarantees P <= 40)
-    const int nj = (P + 7) >> 3;
+    const int nj = (P + 3) >> 2;                               // DMA instructions per source
     const int a_lo = li - MM;
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(A.W + it[11]) + lane;      // [src][G][rt][lane]
-    // staging role of this lane: rows r8 and 8 + r8 of the wave's 16 edges
-    const int r8s = lane >> 3, p8s = (lane & 7) ^ r8s;
-    const int64_t ebase = (int64_t)blockIdx.x * 64 + (threadIdx.x >> 6) * 16;
-    const int64_t eA = ebase + r8s < A.rows ? ebase + r8s : A.rows - 1;
-    const int64_t eB = ebase + 8 + r8s < A.rows ? ebase + 8 + r8s : A.rows - 1;
-    // fragment-read role: edge el = 8 h + r8e
-    const int lds_lane = (el >> 3) * 256 + (el & 7) * 32;      // float offset of (h, r8e) inside a slot pair
-    const int r8e = el & 7;
+    const int cdir = neg ? -P1 : P1;                           // column c -> span piece base (neg ? NC-1-c : c) * P1
+    const int c0p = neg ? (NC - 1) * P1 : 0;
 
-    // early requests for the later phases (their latency hides behind GEMM1)
     const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
     const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(A.W + it[12]) + lane;
     f32x4 hb_n = (f32x4){0.f, 0.f, 0.f, 0.f}, w3_n[RTM];
-#ifndef HG_NO_EARLY
-    if (typ == 0) {
-        hb_n = *reinterpret_cast<const f32x4*>(hrow);
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = HG_LDA(w3 + rt * 64);
-    }
-#endif
 
     f32x4 av_n[RTM];
 #pragma unroll
@@ -141,21 +126,18 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 #pragma unroll 1
     for (int si = 0; si < nsrc; ++si) {
         const int sidx = si ? s1 : s0;
-        const float* __restrict__ sb = pick_src(A, sidx) + in_off + a_lo * in_mulp;
-        const int64_t sst = pick_stride(A, sidx);
-        const float* __restrict__ rowA = sb + eA * sst;
-        const float* __restrict__ rowB = sb + eB * sst;
+        const float* __restrict__ row = pick_src(A, sidx) + erow * pick_stride(A, sidx) + in_off + a_lo * in_mulp;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // previous fragment reads retired
 #pragma unroll 1
         for (int j = 0; j < nj; ++j) {
-            int p = 8 * j + p8s;
+            int p = 4 * j + g;
             p = p < P ? p : P - 1;
-            hg_dma16(rowA + 4 * p, stage + (2 * j) * 256);
-            hg_dma16(rowB + 4 * p, stage + (2 * j + 1) * 256);
+            hg_dma16(row + 4 * p, stage + j * 256);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int abase = si * ngrp;
-        if (NC <= 3 && x4) {                                   // permuted K: fragment = piece (c', 4G + g)
+        if (NC <= 3 && x4) {                                   // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
+            const float* __restrict__ fb = stage + (c0p + g) * 64 + el * 4;
 #pragma unroll 1
             for (int G = 0; G < ngrp; ++G) {
                 f32x4 av[RTM], bv[NC];
@@ -166,10 +148,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
                     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + ((abase + G + 1) * RTM + rt) * 64);
                 }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int piece = (neg ? NC - 1 - c : c) * P1 + 4 * G + g;
-                    bv[c] = *reinterpret_cast<const f32x4*>(stage + (piece >> 3) * 512 + lds_lane + (((piece & 7) ^ r8e) << 2));
-                }
+                for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (c * cdir + 4 * G) * 64);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -178,31 +157,30 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
                         for (int c = 0; c < NC; ++c)
                             mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
             }
-        } else {                                               // natural K: element (c', 4 sl + g) = piece c' P1 + sl, component g
-            f32x4 av[RTM];
+        } else {                                               // natural K: element (c, 4 sl + g) = piece cbase + sl, component g
+            const float* __restrict__ fb = stage + c0p * 64 + el * 4 + g;
 #pragma unroll 1
-            for (int sl = 0; sl < ksteps; ++sl) {
-                const int q = sl & 3;
-                if (q == 0) {
+            for (int G = 0; G < ngrp; ++G) {
+                f32x4 av[RTM];
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
-                    const int Gn = abase + (sl >> 2) + 1;
-                    if (Gn < nsrc * ngrp) {
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+                if (abase + G + 1 < nsrc * ngrp) {
 #pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + (Gn * RTM + rt) * 64);
+                    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + ((abase + G + 1) * RTM + rt) * 64);
+                }
+                const int nq = ksteps - 4 * G;                 // K-steps in this group (>= 4 except in the tail group)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < nq) {
+                        float b[NC];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) b[c] = fb[(c * cdir + 4 * G + q) * 64];
+#pragma unroll
+                        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
                     }
-                }
-                float b[NC];
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int piece = (neg ? NC - 1 - c : c) * P1 + sl;
-                    b[c] = stage[(piece >> 3) * 512 + lds_lane + (((piece & 7) ^ r8e) << 2) + g];
-                }
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) {
-                    const float a = q == 0 ? av[rt][0] : (q == 1 ? av[rt][1] : (q == 2 ? av[rt][2] : av[rt][3]));
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], mid[rt][c], 0, 0, 0);
                 }
             }
         }
@@ -261,8 +239,13 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
             }
-            float* __restrict__ t = tp + (16 * rtp) * rowstride;
-            const int rbase = 16 * rtp + 4 * g;
+            // rows beyond mul_k (fragment padding) are redirected to a trash row behind the tile: no divergent branches
+            float* __restrict__ trow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * rtp + 4 * g + r;
+                trow[r] = tile + (rr < mul_k ? rr : mul_k) * rowstride + (lk - MM) * 16 + el;
+            }
 #pragma unroll
             for (int c0 = 0; c0 < NC; c0 += CW) {
                 f32x4 acc[CW];
@@ -280,22 +263,22 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (rbase + r < mul_k) t[r * rowstride + (c0 + c) * 16] += acc[c][r];
+                        for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] += acc[c][r];
                     }
             }
         }
     } else {
         // plain o3.Linear path: rows are output channels; add straight into the tile
         const int row0 = it[16];
-        float* __restrict__ t0 = tp + row0 * rowstride;
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
+            for (int r = 0; r < 4; ++r) {
+                const int rr = row0 + 16 * rt + 4 * g + r;
+                float* __restrict__ t0 = tile + (rr < mul_k ? rr : mul_k) * rowstride + (lk - MM) * 16 + el;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (row0 + 16 * rt + 4 * g + r < mul_k) t0[(16 * rt + r) * rowstride + c * 16] += mid[rt][c][r];
+                for (int c = 0; c < NC; ++c) t0[c * 16] += mid[rt][c][r];
+            }
     }
 }
 
@@ -344,7 +327,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         const int lk = S[0], mul_k = S[1], rto = S[2], out_off = S[3], out_mulp = S[4], ib = S[5], ie = S[6], flags = S[7];
         const int nco = 2 * lk + 1;
         const int rowstride = nco * 16 + 4;
-        const int tfl = mul_k * rowstride;
+        const int tfl = (mul_k + 1) * rowstride;           // + trash row for padded fragment rows
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
         HG_WAVE_FENCE();
         for (int ii = ib; ii < ie; ++ii) {

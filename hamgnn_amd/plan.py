@@ -181,7 +181,7 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     rto = ceil_div(mul_k, 16)
     prog.segs.append([lk, mul_k, rto, lay.off[out_index], lay.mulp[out_index], 0, 0, flags])
     prog.seg_items.append([])
-    prog.tile_floats = max(prog.tile_floats, 4 * (mul_k * ((2 * lk + 1) * 16 + 4) + STAGE_FLOATS))   # 4 waves x (tile [mul_k rows] + DMA ring)
+    prog.tile_floats = max(prog.tile_floats, 4 * ((mul_k + 1) * ((2 * lk + 1) * 16 + 4) + STAGE_FLOATS))   # 4 waves x (tile [mul_k rows + trash row] + DMA ring)
     return len(prog.segs) - 1
 
 
