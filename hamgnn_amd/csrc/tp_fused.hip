@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
                 HG_CASE(1, 1) HG_CASE(1, 2) HG_CASE(1, 3) HG_CASE(1, 4)
                 HG_CASE(2, 1) HG_CASE(2, 2) HG_CASE(2, 3)
                 HG_CASE(3, 1) HG_CASE(3, 2)
+                HG_CASE(2, 4) HG_CASE(3, 3) HG_CASE(4, 2) HG_CASE(5, 2)
                 HG_CASE(4, 1)
                 HG_CASE(5, 1)
                 HG_CASE(6, 1)

@@ -49,7 +49,7 @@ def ceil_div(a, b):
 
 def rtm_max(nc):
     """row tiles per item: keeps the GEMM1 accumulators at <= 16 f32x4 fragments (64 VGPRs) so 3-4 waves/SIMD fit."""
-    tab = [int(v) for v in os.environ.get("HG_RTM", "4,4,3,2,1,1,1").split(",")]        # row tiles by MM = (nc-1)/2 (r1 A/B)
+    tab = [int(v) for v in os.environ.get("HG_RTM", "4,4,4,3,2,2,1").split(",")]        # row tiles by MM = (nc-1)/2 (r1 A/B)
     return tab[(nc - 1) // 2]
 
 
