@@ -83,7 +83,7 @@ __device__ __forceinline__ void hg_dma4(const float* __restrict__ gsrc, float* l
 }
 
 template <int MM, int RTM>
-__device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict__ it, float* __restrict__ tile,
+__device__ __forceinline__ void item_body(const TpArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ tile,
                                           float* __restrict__ stage, int rowstride, int lk, int rto, int mul_k, int64_t erow, int lane) {
     constexpr int NC = 2 * MM + 1;
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
@@ -112,12 +112,12 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
     const int P = NC * P1;                                     // pieces per row span (planner guarantees P <= 40)
     const int nj = (P + 3) >> 2;                               // DMA instructions per source
     const int a_lo = li - MM;
-    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(A.W + it[11]) + lane;      // [src][G][rt][lane]
+    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;      // [src][G][rt][lane]
     const int cdir = neg ? -P1 : P1;                           // column c -> span piece base (neg ? NC-1-c : c) * P1
     const int c0p = neg ? (NC - 1) * P1 : 0;
 
     const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
-    const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(A.W + it[12]) + lane;
+    const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
     f32x4 hb_n = (f32x4){0.f, 0.f, 0.f, 0.f}, w3_n[RTM];
 
     f32x4 av_n[RTM];
@@ -193,7 +193,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int hgrp = A.hidden >> 4;
-        const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(A.W + it[14]) + lane;
+        const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
         f32x4 a2_n[RTM];
 #ifdef HG_NO_EARLY
         hb_n = *reinterpret_cast<const f32x4*>(hrow);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const int* __restrict
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);
 #endif
-        const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(A.W + it[13]) + g;     // [rt][c][g] float4
+        const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(Wb + it[13]) + g;     // [rt][c][g] float4
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -311,9 +311,10 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 }
 
 #define HG_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, it, tile, stage, rowstride, lk, rto, mul_k, erow, lane); break;
+    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, tile, stage, rowstride, lk, rto, mul_k, erow, lane); break;
 
-__global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A) {
+__global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A, const int* __restrict__ g_segs, const int* __restrict__ g_items,
+                                                                   const float* __restrict__ g_W) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t e = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
     float* stage = tile + (A.tile_floats_wave - HG_STAGE_FLOATS);          // B-operand DMA ring behind the segment tile
 
     for (int sg = 0; sg < A.nseg; ++sg) {
-        const int* __restrict__ S = A.segs + sg * 8;
+        const int* __restrict__ S = g_segs + sg * 8;
         const int lk = S[0], mul_k = S[1], rto = S[2], out_off = S[3], out_mulp = S[4], ib = S[5], ie = S[6], flags = S[7];
         const int nco = 2 * lk + 1;
         const int rowstride = nco * 16 + 4;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
         HG_WAVE_FENCE();
         for (int ii = ib; ii < ie; ++ii) {
-            const int* __restrict__ it = A.items + ii * 20;
+            const int* __restrict__ it = g_items + ii * 20;
             const int mm = it[6], rtm = it[9];
             switch (mm * 8 + rtm) {
                 HG_CASE(0, 1) HG_CASE(0, 2) HG_CASE(0, 3) HG_CASE(0, 4)
@@ -392,6 +393,6 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
         if (e != hipSuccess) return hg_fail(-3, hipGetErrorString(e));
     }
     const unsigned grid = (unsigned)((rows + 63) / 64);
-    hipLaunchKernelGGL(tp_fused_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(tp_fused_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
     return hg_check_launch("hg_tp_fused");
 }
