@@ -134,39 +134,67 @@ extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, con
 }
 
 // ------------------------------------------------------------------------------------------------ radial hidden layers
-#define RH_TE 16
+// 64 edges per workgroup; activations and the current layer's weights in LDS; each thread owns a 4 (edges) x 4 (outputs)
+// register tile per pass.  act(x) = cst * silu(x) (e3nn normalize2mom(silu)); weights already carry 1/sqrt(h_in).
+#define RH_TE 64
 __global__ __launch_bounds__(256) void radial_hidden_kernel(const float* __restrict__ rbf, int64_t E, const float* __restrict__ W,
                                                             int d0, int d1, int d2, int d3, int nlayers, float cst,
                                                             float* __restrict__ out, int maxd) {
     extern __shared__ float sm[];
+    const int ld = maxd + 1;                                   // +1: conflict-free column access
     float* buf0 = sm;
-    float* buf1 = sm + RH_TE * (maxd + 1);
+    float* buf1 = sm + RH_TE * ld;
+    float* wsm = sm + 2 * RH_TE * ld;                          // [di][dn]
     const int64_t e0 = (int64_t)blockIdx.x * RH_TE;
     const int dims[4] = {d0, d1, d2, d3};
     for (int i = threadIdx.x; i < RH_TE * d0; i += blockDim.x) {
         const int e = i / d0, k = i - e * d0;
-        buf0[e * (maxd + 1) + k] = (e0 + e < E) ? rbf[(e0 + e) * d0 + k] : 0.f;
+        buf0[e * ld + k] = (e0 + e < E) ? rbf[(e0 + e) * d0 + k] : 0.f;
     }
-    __syncthreads();
     const float* w = W;
     float* in = buf0;
     float* ot = buf1;
     for (int l = 0; l < nlayers; ++l) {
         const int di = dims[l], dn = dims[l + 1];
-        for (int i = threadIdx.x; i < RH_TE * dn; i += blockDim.x) {
-            const int e = i / dn, j = i - e * dn;
-            float acc = 0.f;
-            for (int k = 0; k < di; ++k) acc = fmaf(in[e * (maxd + 1) + k], w[k * dn + j], acc);
-            ot[e * (maxd + 1) + j] = cst * acc / (1.f + __expf(-acc));
-        }
         __syncthreads();
+        for (int i = threadIdx.x; i < di * dn; i += blockDim.x) wsm[i] = w[i];
+        __syncthreads();
+        const int ng = (dn + 3) >> 2;                          // output groups of 4
+        for (int tile = threadIdx.x; tile < (RH_TE / 4) * ng; tile += blockDim.x) {
+            const int eg = tile / ng, og = tile - eg * ng;
+            float acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+            for (int k = 0; k < di; ++k) {
+                float xv[4], wv[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) xv[a] = in[(4 * eg + a) * ld + k];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) wv[b] = (4 * og + b < dn) ? wsm[k * dn + 4 * og + b] : 0.f;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(xv[a], wv[b], acc[a][b]);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (4 * og + b < dn) {
+                        const float v = acc[a][b];
+                        ot[(4 * eg + a) * ld + 4 * og + b] = cst * v / (1.f + __expf(-v));
+                    }
+        }
         w += di * dn;
         float* t = in; in = ot; ot = t;
     }
+    __syncthreads();
     const int dl = dims[nlayers];
     for (int i = threadIdx.x; i < RH_TE * dl; i += blockDim.x) {
         const int e = i / dl, j = i - e * dl;
-        if (e0 + e < E) out[(e0 + e) * dl + j] = in[e * (maxd + 1) + j];
+        if (e0 + e < E) out[(e0 + e) * dl + j] = in[e * ld + j];
     }
 }
 
@@ -174,9 +202,11 @@ extern "C" int hg_radial_hidden(const float* rbf, int64_t E, const float* weight
                                 float* h_out, void* stream) {
     if (E <= 0) return 0;
     if (nlayers < 1 || nlayers > 3) return hg_fail(-2, "hg_radial_hidden: 1..3 hidden layers supported");
-    int d[4] = {0, 0, 0, 0}, maxd = 0;
+    int d[4] = {0, 0, 0, 0}, maxd = 0, maxw = 0;
     for (int i = 0; i <= nlayers; ++i) { d[i] = dims[i]; if (d[i] > maxd) maxd = d[i]; }
-    const size_t lds = 2 * RH_TE * (size_t)(maxd + 1) * sizeof(float);
+    for (int i = 0; i < nlayers; ++i) if (d[i] * d[i + 1] > maxw) maxw = d[i] * d[i + 1];
+    const size_t lds = (2 * RH_TE * (size_t)(maxd + 1) + (size_t)maxw) * sizeof(float);
+    if (lds > 64 * 1024) return hg_fail(-2, "hg_radial_hidden: layer too wide for the LDS-resident kernel");
     radial_hidden_kernel<<<dim3((unsigned)((E + RH_TE - 1) / RH_TE)), 256, lds, (hipStream_t)stream>>>(rbf, E, weights, d[0], d[1], d[2], d[3], nlayers, act_cst, h_out, maxd);
     return hg_check_launch("hg_radial_hidden");
 }
@@ -207,23 +237,29 @@ __device__ __forceinline__ void rotate_channel(const float* __restrict__ Dl, con
     }
 }
 
+#define RG_EB 8          // edges per workgroup: amortises the frame staging + barrier over 8 x nsrc x nchan channel work-items
 __global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int64_t xs,
                                                             const int64_t* __restrict__ idx0, const int64_t* __restrict__ idx1,
                                                             const float* __restrict__ wig, int nW, const HgWigOff wo,
-                                                            const int4* __restrict__ tab, int nchan, int transpose,
+                                                            const int4* __restrict__ tab, int nchan, int64_t E, int transpose,
                                                             float* __restrict__ out0, float* __restrict__ out1, int64_t os) {
-    extern __shared__ float Dsm[];
-    const int64_t e = blockIdx.x;
-    for (int i = threadIdx.x; i < nW; i += blockDim.x) Dsm[i] = wig[e * nW + i];
+    extern __shared__ float Dsm[];                             // [RG_EB][nW]
+    const int64_t e0 = (int64_t)blockIdx.x * RG_EB;
+    const int ne = (int)((E - e0) < RG_EB ? (E - e0) : RG_EB);
+    for (int i = threadIdx.x; i < ne * nW; i += blockDim.x) Dsm[i] = wig[e0 * nW + i];
     __syncthreads();
     const int nsrc = x1 ? 2 : 1;
-    for (int j = threadIdx.x; j < nchan * nsrc; j += blockDim.x) {
-        const int sidx = j >= nchan;
-        const int4 t = tab[sidx ? j - nchan : j];
+    const int per_edge = nchan * nsrc;
+    for (int j = threadIdx.x; j < per_edge * ne; j += blockDim.x) {
+        const int le = j / per_edge;
+        const int r = j - le * per_edge;
+        const int sidx = r >= nchan;
+        const int4 t = tab[sidx ? r - nchan : r];
+        const int64_t e = e0 + le;
         const int64_t row = sidx ? (idx1 ? idx1[e] : e) : (idx0 ? idx0[e] : e);
         const float* __restrict__ xin = (sidx ? x1 : x0) + row * xs;
         float* __restrict__ xo = (sidx ? out1 : out0) + e * os;
-        const float* __restrict__ Dl = Dsm + wo.o[t.x];
+        const float* __restrict__ Dl = Dsm + le * nW + wo.o[t.x];
         if (t.w) {                                             // channel padding: keep it zero (it feeds zero-weight MFMA K-steps)
             for (int a = 0; a < 2 * t.x + 1; ++a) xo[t.y + a * t.z] = 0.f;
             continue;
@@ -247,8 +283,8 @@ extern "C" int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stri
     if (E <= 0) return 0;
     HgWigOff wo;
     for (int i = 0; i < 8; ++i) wo.o[i] = wig_off[i];
-    rotate_gather_kernel<<<dim3((unsigned)E), 256, sizeof(float) * (size_t)nW, (hipStream_t)stream>>>(
-        x0, x1, x_stride, idx0, idx1, wig, nW, wo, (const int4*)chan_tab, nchan, transpose, out0, out1, out_stride);
+    rotate_gather_kernel<<<dim3((unsigned)((E + RG_EB - 1) / RG_EB)), 256, sizeof(float) * (size_t)nW * RG_EB, (hipStream_t)stream>>>(
+        x0, x1, x_stride, idx0, idx1, wig, nW, wo, (const int4*)chan_tab, nchan, E, transpose, out0, out1, out_stride);
     return hg_check_launch("hg_rotate_gather");
 }
 
