@@ -126,12 +126,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if os.environ.get("HG_BENCH_SAME_DEVICE") == "1":      # test hook: validate the N>1 script path on a 1-GPU box (gloo, shared device)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("HG_BENCH_BACKEND", "nccl")          # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from hamgnn_amd import ops, parallel
     from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
