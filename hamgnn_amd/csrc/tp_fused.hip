@@ -269,7 +269,17 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
         }
     } else {
         // plain o3.Linear path: rows are output channels; add straight into the tile
+        // (typ 2, lite_mode paths: each column first takes its aligned-frame CG coefficient, message_passing.py:197-215)
         const int row0 = it[16];
+        if (typ == 2) {
+            const float* __restrict__ cfc = Wb + it[13];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float cv = cfc[c];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) mid[rt][c] = mid[rt][c] * cv;
+            }
+        }
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -279,6 +289,80 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 #pragma unroll
                 for (int c = 0; c < NC; ++c) t0[c * 16] += mid[rt][c][r];
             }
+    }
+}
+
+// lite_mode segment post-op (message_passing.py:209-215: combine_messages = LinearScaleWithWeights on the summed branches):
+//   tile[v, m] <- sum_w'' Lc[w'', v] * s_e[w''] * tile[w'', m],   s_e = W3^T h2 by MFMA, in place per column chunk.
+__device__ __forceinline__ void post_item(const TpArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
+                                          float* __restrict__ tile, int rowstride, int nco, int rto, int mul_k, int64_t erow, int lane) {
+    const int g = lane >> 4, el = lane & 15;
+    const float* __restrict__ hrow = A.h2[0] + erow * A.hidden + 4 * g;
+    const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;          // [G][rto][lane]
+    const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;          // [rtp][rt][lane]
+    f32x4 S[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int hgrp = A.hidden >> 4;
+#pragma unroll 1
+    for (int G = 0; G < hgrp; ++G) {
+        const f32x4 hb = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            if (rt < rto) {
+                const f32x4 wv = w3[(G * rto + rt) * 64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q], hb[q], S[rt], 0, 0, 0);
+            }
+        }
+    }
+    int rowoff[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * rt + 4 * g + r;
+            rowoff[rt][r] = (rr < mul_k ? rr : mul_k) * rowstride + el;
+        }
+#pragma unroll 1
+    for (int c0 = 0; c0 < nco; c0 += 4) {
+        f32x4 md[4][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                md[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (rt < rto && c0 + c < nco) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) md[rt][c][r] = (16 * rt + 4 * g + r < mul_k) ? tile[rowoff[rt][r] + (c0 + c) * 16] * S[rt][r] : 0.f;
+                }
+            }
+        HG_WAVE_FENCE();
+#pragma unroll 1
+        for (int rtp = 0; rtp < rto; ++rtp) {
+            f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                if (rt < rto) {
+                    const f32x4 av = a2[(rtp * rto + rt) * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], md[rt][c][r], acc[c], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c0 + c < nco) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 16 * rtp + 4 * g + r;
+                        tile[(rr < mul_k ? rr : mul_k) * rowstride + el + (c0 + c) * 16] = acc[c][r];
+                    }
+                }
+        }
     }
 }
 
@@ -313,6 +397,7 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 #define HG_CASE(MMv, RTMv) \
     case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, tile, stage, rowstride, lk, rto, mul_k, erow, lane); break;
 
+template <bool HAS_POST>
 __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A, const int* __restrict__ g_segs, const int* __restrict__ g_items,
                                                                    const float* __restrict__ g_W) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -334,6 +419,11 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         for (int ii = ib; ii < ie; ++ii) {
             const int* __restrict__ it = g_items + ii * 20;
             const int mm = it[6], rtm = it[9];
+            if (HAS_POST && it[0] == 3) {                      // segment post-op (lite_mode programs only: separate instantiation)
+                HG_WAVE_FENCE();
+                post_item(A, g_W, it, tile, rowstride, nco, rto, mul_k, erow, lane);
+                continue;
+            }
             switch (mm * 8 + rtm) {
                 HG_CASE(0, 1) HG_CASE(0, 2) HG_CASE(0, 3) HG_CASE(0, 4)
                 HG_CASE(1, 1) HG_CASE(1, 2) HG_CASE(1, 3) HG_CASE(1, 4)
@@ -364,7 +454,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
 extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node,
                            const float* h2_edge, int hidden, const float* wig, int nW, const int32_t* wig_off,
                            const float* weights, const int32_t* seg_table, int nseg, const int32_t* item_table, float* out,
-                           int64_t out_stride, int64_t rows, int lds_bytes, void* stream) {
+                           int64_t out_stride, int64_t rows, int lds_bytes, int program_flags, void* stream) {
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_fused: nsrc must be 1..4");
     if (hidden & 15) return hg_fail(-2, "hg_tp_fused: (padded) hidden width must be a multiple of 16");
@@ -389,10 +479,14 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
     A.rows = rows;
     A.tile_floats_wave = lds_bytes / 16;           // 4 waves x 4 bytes
     if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)tp_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipError_t e = hipFuncSetAttribute((program_flags & 1) ? (const void*)tp_fused_kernel<true> : (const void*)tp_fused_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return hg_fail(-3, hipGetErrorString(e));
     }
     const unsigned grid = (unsigned)((rows + 63) / 64);
-    hipLaunchKernelGGL(tp_fused_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
+    if (program_flags & 1)
+        hipLaunchKernelGGL(tp_fused_kernel<true>, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
+    else
+        hipLaunchKernelGGL(tp_fused_kernel<false>, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
     return hg_check_launch("hg_tp_fused");
 }

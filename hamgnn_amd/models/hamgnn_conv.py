@@ -47,7 +47,8 @@ class HamGNNConvE3(nn.Module):
         self.legacy_edge_update = bool(g("legacy_edge_update", False))
         if str(g("rbf_func", "bessel")).lower() != "bessel":
             raise ValueError(f"Unsupported radial basis function on the MI355X path: {g('rbf_func')}")
-        for k in ("use_kan", "use_corr_prod", "build_internal_graph", "lite_mode", "apply_charge_doping"):
+        self.lite_mode = bool(g("lite_mode", False))
+        for k in ("use_kan", "use_corr_prod", "build_internal_graph", "apply_charge_doping"):
             if g(k, False):
                 raise NotImplementedError(f"HamGNN_pre.{k}=True is outside the MI355X hot-path scope of this round (SURVEY 8f)")
         if g("edge_sh_normalization", "component") != "component" or not g("edge_sh_normalize", True):
@@ -56,15 +57,15 @@ class HamGNNConvE3(nn.Module):
             assert p == (-1) ** l
         D, sh, R, mlp = self.irreps_node_features, self.irreps_edge_sh, self.num_radial, self.radial_MLP
         self.lmax = max(D.lmax, sh.lmax)
-        self.pair_embedding = hnn.PairInteractionEmbeddingBlock(self.num_types, sh, D, R, mlp)
+        self.pair_embedding = hnn.PairInteractionEmbeddingBlock(self.num_types, sh, D, R, mlp, self.lite_mode)
         self.chemical_embedding = nn.Module()
         self.chemical_embedding.linear = hnn.E3Linear(Irreps([(self.num_types, 0, 1)]), D)
         self.convolutions = nn.ModuleList()
         self.pair_interactions = nn.ModuleList()
         for i in range(self.num_layers):
-            self.convolutions.append(hnn.ConvBlockE3(D, sh, R, mlp))
+            self.convolutions.append(hnn.ConvBlockE3(D, sh, R, mlp, self.lite_mode))
             skip = (i > 0) if self.legacy_edge_update else True
-            self.pair_interactions.append(hnn.PairInteractionBlock(D, sh, R, mlp, skip, self.legacy_edge_update))
+            self.pair_interactions.append(hnn.PairInteractionBlock(D, sh, R, mlp, skip, self.legacy_edge_update, self.lite_mode))
         self.layout = P.PlanarLayout(D)
         self._compiled_for = None
 
@@ -116,7 +117,10 @@ class HamGNNConvE3(nn.Module):
             # ---- PairInteractionBlock.forward (interaction_blocks.py:130-164)
             xs, xd = ops.rotate_gather(pair.linear_up_src(node), geo.src, geo, self._rot_tab, x2=pair.linear_up_tar(node), idx2=geo.dst)
             if pair.use_skip_connections or not pair.legacy_edge_update:           # legacy layer-0: edge features kept (:154-156)
-                f = pair.conv_tp.run(xs, xd, f, geo)                                # stays in the edge frame (+ fused skip linear)
+                mix = pair.conv_tp.run(xs, xd, f, geo)                              # stays in the edge frame (+ fused skip linear)
+                if self.lite_mode and pair.use_skip_connections:
+                    mix = ops.add_rows(mix, pair.skip_linear(f))
+                f = mix
         rep = Representation()
         rep["node_attr"] = ops.from_planar(node, self._imap)
         rep["edge_attr"] = ops.from_planar(ops.rotate_gather(f, None, geo, self._rot_tab, transpose=True), self._imap)

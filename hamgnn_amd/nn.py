@@ -99,38 +99,69 @@ class LinearScaleWithWeights(nn.Module):
         self.linear_out = _LinOutHolder(tp, irreps_out)
 
 
+class _MidLinear(nn.Module):
+    """o3.Linear(mid.simplify() -> irreps_out) of the lite-mode branches: weight holder (fan_k = sum of the path input muls)."""
+
+    def __init__(self, irreps_in1: Irreps, irreps_sh: Irreps, irreps_out: Irreps):
+        super().__init__()
+        ins = P.tp_instructions(irreps_in1, irreps_sh, irreps_out)
+        fan = {}
+        for i, _, k, _ in ins:
+            fan[k] = fan.get(k, 0) + irreps_in1[i][0]
+        self.weight = nn.Parameter(torch.randn(sum(f * irreps_out[k][0] for k, f in fan.items())))
+
+
+class _CombineMessages(nn.Module):
+    def __init__(self, irreps_out: Irreps):
+        super().__init__()
+        self.weight_numel = irreps_out.simplify().num_irreps
+        self.linear_out = E3Linear(irreps_out.simplify(), irreps_out)
+
+
 class MessagePackBlock(nn.Module):
     def __init__(self, irreps_node_feats, irreps_edge_feats, irreps_local_env_edge, irreps_out, num_radial, radial_MLP=(64, 64),
                  lite_mode=False):
         super().__init__()
-        if lite_mode:
-            raise NotImplementedError("lite_mode (uvu) is not built for the MI355X path yet (SURVEY 8f); the oracle covers it")
+        self.lite_mode = lite_mode
         self.irreps_node, self.irreps_edge = Irreps(irreps_node_feats), Irreps(irreps_edge_feats)
         self.irreps_sh, self.irreps_out = Irreps(irreps_local_env_edge), Irreps(irreps_out)
         comb = Irreps([(max(1, 2 * m), l, p) for m, l, p in self.irreps_node])
-        self.node_tensor_product = E3TensorProduct(comb, self.irreps_sh, self.irreps_out)
-        self.edge_tensor_product = E3TensorProduct(self.irreps_edge, self.irreps_sh, self.irreps_out)
-        self.node_linear_scaler = LinearScaleWithWeights(self.node_tensor_product, self.irreps_out)
-        self.edge_linear_scaler = LinearScaleWithWeights(self.edge_tensor_product, self.irreps_out)
-        self.node_weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.node_linear_scaler.weight_numel])
-        self.edge_weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.edge_linear_scaler.weight_numel])
-        self.node_linear_out = E3Linear(self.irreps_out, self.irreps_out)
-        self.edge_linear_out = E3Linear(self.irreps_out, self.irreps_out)
+        if lite_mode:                                          # message_passing.py:99-111, 123-125 (uvu products carry no weights)
+            self.node_linear_scaler = _MidLinear(comb, self.irreps_sh, self.irreps_out)
+            self.edge_linear_scaler = _MidLinear(self.irreps_edge, self.irreps_sh, self.irreps_out)
+            self.combine_messages = _CombineMessages(self.irreps_out)
+            self.weight_generator_combine = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.combine_messages.weight_numel])
+        else:
+            self.node_tensor_product = E3TensorProduct(comb, self.irreps_sh, self.irreps_out)
+            self.edge_tensor_product = E3TensorProduct(self.irreps_edge, self.irreps_sh, self.irreps_out)
+            self.node_linear_scaler = LinearScaleWithWeights(self.node_tensor_product, self.irreps_out)
+            self.edge_linear_scaler = LinearScaleWithWeights(self.edge_tensor_product, self.irreps_out)
+            self.node_weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.node_linear_scaler.weight_numel])
+            self.edge_weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.edge_linear_scaler.weight_numel])
+            self.node_linear_out = E3Linear(self.irreps_out, self.irreps_out)
+            self.edge_linear_out = E3Linear(self.irreps_out, self.irreps_out)
         self._dp = None
 
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
-        prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
+        if self.lite_mode:
+            prog = P.build_message_pack_program_lite(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
+            if skip_weight is not None:                        # PairInteractionBlock skip o3.Linear: must come AFTER the combine post-op
+                raise NotImplementedError
+            self._hn = self.weight_generator_combine.hidden_layers(device)
+            self._he = None
+        else:
+            prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
+            self._hn = self.node_weight_generator.hidden_layers(device)
+            self._he = self.edge_weight_generator.hidden_layers(device)
         self._dp = ops.DeviceProgram(prog, device)
-        self._hn = self.node_weight_generator.hidden_layers(device)
-        self._he = self.edge_weight_generator.hidden_layers(device)
         return self
 
     def run(self, xs_rot, xd_rot, f_rot, geo: ops.Geometry):
         """xs_rot/xd_rot/f_rot: planar rows in the edge-aligned frame.  Returns planar [E, Dp] (global frame if unrotate)."""
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
         hn = ops.radial_hidden(geo.rbf, self._hn, cst)
-        he = ops.radial_hidden(geo.rbf, self._he, cst)
+        he = ops.radial_hidden(geo.rbf, self._he, cst) if self._he is not None else None
         return ops.tp_fused(self._dp, [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo, tag="message_pack")
 
 
@@ -162,10 +193,10 @@ class ResidualBlock(nn.Module):
 
 
 class ConvBlockE3(nn.Module):
-    def __init__(self, irreps, irreps_sh, num_radial, radial_MLP):
+    def __init__(self, irreps, irreps_sh, num_radial, radial_MLP, lite_mode=False):
         super().__init__()
         self.residual = ResidualBlock(irreps, irreps)
-        self.conv_tp = MessagePackBlock(irreps, irreps, irreps_sh, irreps, num_radial, radial_MLP)
+        self.conv_tp = MessagePackBlock(irreps, irreps, irreps_sh, irreps, num_radial, radial_MLP, lite_mode)
         self.skip_linear = E3Linear(irreps, irreps)
 
     def compile(self, device):
@@ -175,12 +206,12 @@ class ConvBlockE3(nn.Module):
 
 
 class PairInteractionBlock(nn.Module):
-    def __init__(self, irreps, irreps_sh, num_radial, radial_MLP, use_skip_connections=True, legacy_edge_update=False):
+    def __init__(self, irreps, irreps_sh, num_radial, radial_MLP, use_skip_connections=True, legacy_edge_update=False, lite_mode=False):
         super().__init__()
-        self.use_skip_connections, self.legacy_edge_update = use_skip_connections, legacy_edge_update
+        self.use_skip_connections, self.legacy_edge_update, self.lite_mode = use_skip_connections, legacy_edge_update, lite_mode
         self.linear_up_src = E3Linear(irreps, irreps)
         self.linear_up_tar = E3Linear(irreps, irreps)
-        self.conv_tp = MessagePackBlock(irreps, irreps, irreps_sh, irreps, num_radial, radial_MLP)
+        self.conv_tp = MessagePackBlock(irreps, irreps, irreps_sh, irreps, num_radial, radial_MLP, lite_mode)
         if use_skip_connections:
             self.skip_linear = E3Linear(irreps, irreps)
 
@@ -188,35 +219,46 @@ class PairInteractionBlock(nn.Module):
         self.linear_up_src.compile(device)
         self.linear_up_tar.compile(device)
         skip = self.skip_linear.weight.detach().cpu().double().numpy() if self.use_skip_connections else None
-        self.conv_tp.compile(device, unrotate=False, skip_weight=skip)       # skip o3.Linear fused as extra items
+        if self.lite_mode:                                     # the combine post-op must not touch the skip term: separate launch + add
+            self.conv_tp.compile(device, unrotate=False)
+            if self.use_skip_connections:
+                self.skip_linear.compile(device)
+        else:
+            self.conv_tp.compile(device, unrotate=False, skip_weight=skip)   # skip o3.Linear fused as extra items
 
 
 class _EmbTP(nn.Module):
     """TensorProductWithMemoryOptimizationWithWeight parameter holder (tensor_products.py:51-189)."""
 
-    def __init__(self, irreps_in, irreps_sh, irreps_out, num_radial, radial_MLP):
+    def __init__(self, irreps_in, irreps_sh, irreps_out, num_radial, radial_MLP, lite_mode=False):
         super().__init__()
-        self.tensor_product = E3TensorProduct(irreps_in, irreps_sh, irreps_out)
-        self.linear_scaler = LinearScaleWithWeights(self.tensor_product, Irreps(irreps_out))
+        if lite_mode:                                          # uvu, no TP weights; mid multiplicity = input multiplicity
+            self.linear_scaler = nn.Module()
+            self.linear_scaler.linear_out = _MidLinear(Irreps(irreps_in), Irreps(irreps_sh), Irreps(irreps_out))
+            ins = P.tp_instructions(Irreps(irreps_in), Irreps(irreps_sh), Irreps(irreps_out))
+            self.linear_scaler.weight_numel = sum(Irreps(irreps_in)[i][0] for i, _, _, _ in ins)
+        else:
+            self.tensor_product = E3TensorProduct(irreps_in, irreps_sh, irreps_out)
+            self.linear_scaler = LinearScaleWithWeights(self.tensor_product, Irreps(irreps_out))
         self.weight_generator = FullyConnectedNet([num_radial] + list(radial_MLP) + [self.linear_scaler.weight_numel])
 
 
 class PairInteractionEmbeddingBlock(nn.Module):
-    def __init__(self, num_types, irreps_sh, irreps_out, num_radial, radial_MLP):
+    def __init__(self, num_types, irreps_sh, irreps_out, num_radial, radial_MLP, lite_mode=False):
         super().__init__()
-        self.num_types = num_types
+        self.num_types, self.lite_mode = num_types, lite_mode
         attrs = Irreps([(num_types, 0, 1)])
         self.irreps_sh, self.irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
         self.linear_up_src = E3Linear(attrs, attrs)
         self.linear_up_dst = E3Linear(attrs, attrs)
-        self.conv_tp = _EmbTP(attrs, self.irreps_sh, self.irreps_out, num_radial, radial_MLP)
+        self.conv_tp = _EmbTP(attrs, self.irreps_sh, self.irreps_out, num_radial, radial_MLP, lite_mode)
 
     def compile(self, device):
         T = self.num_types
         s = 1.0 / math.sqrt(T)
         self._Ts = (self.linear_up_src.weight.detach().double().reshape(T, T) * s).float().contiguous().to(device)
         self._Td = (self.linear_up_dst.weight.detach().double().reshape(T, T) * s).float().contiguous().to(device)
-        self._dp = ops.DeviceProgram(P.build_embedding_program(_np_sd(self.conv_tp), T, self.irreps_sh, self.irreps_out), device)
+        self._dp = ops.DeviceProgram(P.build_embedding_program(_np_sd(self.conv_tp), T, self.irreps_sh, self.irreps_out, self.lite_mode), device)
         self._h = self.conv_tp.weight_generator.hidden_layers(device)
         self._Tp = P.PlanarLayout([(T, 0, 1)]).dim
 

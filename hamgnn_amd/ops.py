@@ -40,6 +40,7 @@ class DeviceProgram:
         self.hidden = int(prog.hidden_pad)
         self.out_dim = int(prog.out_layout.dim)
         self.lds_bytes = int(prog.tile_floats) * 4
+        self.flags = 1 if (prog.item_table.shape[0] and (prog.item_table[:, 0] == P.IT_POST).any()) else 0
 
 
 def wig_offsets(lmax):
@@ -121,7 +122,7 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
-                            i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), _stream()), "hg_tp_fused")
+                            i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), i32(dp.flags), _stream()), "hg_tp_fused")
     if PROFILE_EVENTS is not None:
         ev1.record()
         PROFILE_EVENTS.append((ev0, ev1, rows, tag))

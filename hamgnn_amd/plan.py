@@ -34,6 +34,8 @@ from .so3 import Irreps
 # item types
 IT_TP = 0        # GEMM1 -> radial scale * CG coef -> GEMM2 -> add into segment tile
 IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, add into tile
+IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: aligned-frame CG coefficient per m)
+IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
 # segment flags
 SEG_UNROTATE = 1     # epilogue applies D^l(R_e)^T (messages go back to the global frame before the node scatter)
 
@@ -196,6 +198,8 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
     nc = 2 * mm + 1
     rto = prog.segs[seg][2]
     n = len(srcs) * ksteps * rtm * nc
+    if typ == IT_POST:
+        n = (prog.hidden_pad // 4) * rto + rto * rto * 4 * (2 * prog.segs[seg][0] + 1)
     if typ == IT_TP:
         n += (prog.hidden_pad // 4) * rtm + rto * rtm * 4 * nc
     prog.mfma_per_wave += n
@@ -206,13 +210,14 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
 
 def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
                  irreps_sh: Irreps, irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray,
-                 lin_out_w: Optional[np.ndarray], mlp: int):
+                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False):
     """Items of ONE reference tensor-product branch (node or edge) of a MessagePackBlock / embedding TP.
 
     in_layout : planar layout of ONE source row (irreps of the un-doubled features); nsrc = 2 for the node branch
                 (reference input = (2 mul) x ir with the first mul channels from src, the rest from dst: attention_utils.py:85-119).
     tp_weight : flat o3.TensorProduct.weight;  w3: last radial layer [H, n_chan] already divided by sqrt(H);
     lin_scale_w: flat LinearScaleWithWeights.linear_out.weight;  lin_out_w: flat trailing o3.Linear(out->out) or None.
+    uvu       : lite_mode product (tensor_products.py:81-84,127-130): no TP weights, mid multiplicity = input multiplicity.
     """
     irr_in = Irreps([(m * nsrc, l, p) for m, l, p in in_layout.irreps])
     ins = tp_instructions(irr_in, irreps_sh, irreps_out)
@@ -222,9 +227,9 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
     for (i, j, k, slot) in ins:
         woff.append(wo)
         choff.append(co)
-        wo += irr_in[i][0] * irreps_out[k][0]
-        co += irreps_out[k][0]
-    assert wo == tp_weight.size, (wo, tp_weight.size)
+        wo += 0 if uvu else irr_in[i][0] * irreps_out[k][0]
+        co += irr_in[i][0] if uvu else irreps_out[k][0]
+    assert wo == (0 if tp_weight is None else tp_weight.size), (wo, tp_weight.size)
     assert co == w3.shape[1], (co, w3.shape)
     # Linear(mid.simplify() -> irreps_out): simplified mid has one entry per distinct out irrep, in sorted order
     irs = [(l, p) for _, l, p in irreps_out]
@@ -236,7 +241,7 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
     order = sorted(by_k, key=lambda k: ((irreps_out[k][1], irreps_out[k][2]), k))
     lin_off, lo = {}, 0
     for k in order:
-        fan = sum(irreps_out[k][0] for _ in by_k[k])
+        fan = sum((irr_in[ins[n][0]][0] if uvu else irreps_out[k][0]) for n in by_k[k])
         lin_off[k] = (lo, fan)
         lo += fan * irreps_out[k][0]
     assert lo == lin_scale_w.size, (lo, lin_scale_w.size)
@@ -276,15 +281,20 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
                 this_par = (li + lj + lk) % 2
                 assert par is None or par == this_par
                 par = this_par
-                cpath = math.sqrt((2 * lk + 1) / (mi2 * irreps_sh[j][0]))
-                W = tp_weight[woff[n]:woff[n] + mi2 * mk].reshape(mi2, mk).astype(np.float64) * cpath
+                if uvu:                                        # unweighted uvu: coefficient sqrt(2 l_k + 1), channels pass through
+                    mmid = mi2
+                    W = np.eye(mi2) * math.sqrt(2 * lk + 1)
+                else:
+                    mmid = mk
+                    cpath = math.sqrt((2 * lk + 1) / (mi2 * irreps_sh[j][0]))
+                    W = tp_weight[woff[n]:woff[n] + mi2 * mk].reshape(mi2, mk).astype(np.float64) * cpath
                 cf = np.array([coef_c[lk + m] for m in range(-mm, mm + 1)])
-                for w in range(mk):
+                for w in range(mmid):
                     rows_W.append(W[:, w])
                     rows_ch.append(choff[n] + w)
                     rows_cf.append(cf)
                     rows_L.append(L[choff[n] - ch0 + w])
-                prog.flops_per_row += 2.0 * mi2 * mk * nc + 2.0 * H * mk + 2.0 * mk * mk * nc + 2.0 * mk * nc
+                prog.flops_per_row += (0.0 if uvu else 2.0 * mi2 * mk * nc) + 2.0 * H * mmid + 2.0 * mmid * mk * nc + 2.0 * mmid * nc
             rows_W, rows_cf, rows_L = np.array(rows_W), np.array(rows_cf), np.array(rows_L)
             nrows = len(rows_ch)
             chunk = rtm_max(nc) * 16
@@ -394,7 +404,7 @@ def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_ed
     return prog.finalize()
 
 
-def build_embedding_program(sd: Dict[str, np.ndarray], num_types, irreps_sh, irreps_out) -> Program:
+def build_embedding_program(sd: Dict[str, np.ndarray], num_types, irreps_sh, irreps_out, lite_mode=False) -> Program:
     """PairInteractionEmbeddingBlock.conv_tp (embeddings.py:328-334, tensor_products.py:170-189): source slot 0 holds
     x = Lin_src(onehot[src]) + Lin_dst(onehot[dst])  (num_types x 0e; identical in every frame)."""
     irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
@@ -402,7 +412,8 @@ def build_embedding_program(sd: Dict[str, np.ndarray], num_types, irreps_sh, irr
     H = w3.shape[0]
     prog, seg_of_k = new_program(irreps_out, H)
     add_tp_items(prog, seg_of_k, PlanarLayout([(num_types, 0, 1)]), 1, [SRC_XS], irreps_sh, irreps_out,
-                 np.asarray(sd["tensor_product.weight"]), w3 / math.sqrt(H), np.asarray(sd["linear_scaler.linear_out.weight"]), None, mlp=0)
+                 None if lite_mode else np.asarray(sd["tensor_product.weight"]), w3 / math.sqrt(H),
+                 np.asarray(sd["linear_scaler.linear_out.weight"]), None, mlp=0, uvu=lite_mode)
     return prog.finalize()
 
 
@@ -614,3 +625,80 @@ def shell_block_table(row: Irreps, nao) -> np.ndarray:
         for c in range(nao):
             tab[r * nao + c] = (*bounds[owner[r]], *bounds[owner[c]])
     return tab
+
+
+def add_lite_branch_items(prog: Program, seg_of_k, in_layout: PlanarLayout, nsrc, srcs, irreps_sh: Irreps, irreps_out: Irreps,
+                          lin_w: np.ndarray):
+    """lite_mode branch (message_passing.py:197-206): unweighted uvu tensor product followed by o3.Linear(mid.simplify()->out),
+    i.e. per path p = (i, l_sh, k):  tile_k[w'', m] += coef_p[m] * sum_u (sqrt(2 l_k+1)/sqrt(fan_k) L_k[(p,u), w'']) x'_i[u, src_p(m)]."""
+    irr_in = Irreps([(m * nsrc, l, p) for m, l, p in in_layout.irreps])
+    ins = tp_instructions(irr_in, irreps_sh, irreps_out)          # slot order = sorted by output irrep (stable), as the reference
+    by_k: Dict[int, List[int]] = {}
+    for n, (i, j, k, slot) in enumerate(ins):
+        by_k.setdefault(k, []).append(n)
+    order = sorted(by_k, key=lambda k: ((irreps_out[k][1], irreps_out[k][2]), k))
+    off = 0
+    for k in order:
+        mk, lk, pk = irreps_out[k]
+        fan = sum(irr_in[ins[n][0]][0] for n in by_k[k])
+        Lk = lin_w[off:off + fan * mk].reshape(fan, mk).astype(np.float64) * (math.sqrt(2 * lk + 1) / math.sqrt(fan))
+        off += fan * mk
+        r = 0
+        for n in by_k[k]:
+            i, j, _, _ = ins[n]
+            mi2, li, pi = irr_in[i]
+            mi = mi2 // nsrc
+            lj = irreps_sh[j][1]
+            mm = min(li, lk)
+            nc = 2 * mm + 1
+            _, coef_c = so3.aligned_path(li, lj, lk)
+            cf = np.array([coef_c[lk + m] for m in range(-mm, mm + 1)])
+            Wp = Lk[r:r + mi2]                                   # [u (src channels then dst channels), w'']
+            r += mi2
+            ksteps = in_layout.mulp[i] // 4
+            chunk = rtm_max(nc) * 16
+            for seg, c0, c1 in prog.seg_chunks[k]:
+                for r0 in range(c0, c1, chunk):
+                    r1 = min(c1, r0 + chunk)
+                    rtm = ceil_div(r1 - r0, 16)
+                    a1 = [_frag_A(Wp[s_ * mi:(s_ + 1) * mi, r0:r1], ksteps, rtm, use_x4(in_layout.mulp[i], nc)) for s_ in range(nsrc)]
+                    a1_off = prog.add_weights(np.stack(a1))
+                    cf_off = prog.add_weights(cf)
+                    _add_item(prog, seg, IT_LINC, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, (li + lj + lk) % 2, ksteps, rtm, 0,
+                              a1_off, 0, cf_off, 0, r1 - r0, row_off=r0 - c0)
+            prog.flops_per_row += 2.0 * mi2 * mk * nc
+    assert off == lin_w.size, (off, lin_w.size)
+
+
+def build_message_pack_program_lite(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool) -> Program:
+    """MessagePackBlock with lite_mode=True (message_passing.py:197-215) as one fused-kernel program."""
+    irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
+    _, w3 = _last_layer(sd, "weight_generator_combine")
+    H = w3.shape[0]
+    prog, seg_of_k = new_program(irreps_out, H, lambda k, ir: SEG_UNROTATE if unrotate else 0)
+    add_lite_branch_items(prog, seg_of_k, PlanarLayout(irreps_node), 2, [SRC_XS, SRC_XD], irreps_sh, irreps_out, np.asarray(sd["node_linear_scaler.weight"]))
+    add_lite_branch_items(prog, seg_of_k, PlanarLayout(irreps_edge), 1, [SRC_F], irreps_sh, irreps_out, np.asarray(sd["edge_linear_scaler.weight"]))
+    # post-op per segment: scale by the radial weights (one per channel of irreps_out.simplify()) and o3.Linear(out -> out)
+    w3n = w3 / math.sqrt(H)
+    lc = np.asarray(sd["combine_messages.linear_out.weight"])
+    irs = [(l, p) for _, l, p in irreps_out]
+    assert len(set(irs)) == len(irs)
+    ch_off, lo_off, co, lo = {}, {}, 0, 0
+    for k, (mk, lk, pk) in enumerate(irreps_out):
+        ch_off[k], lo_off[k] = co, lo
+        co += mk
+        lo += mk * mk
+    assert co == w3.shape[1] and lo == lc.size
+    for k, (mk, lk, pk) in enumerate(irreps_out):
+        assert len(prog.seg_chunks[k]) == 1, "lite_mode post-op needs <= 64 channels per output irrep"
+        seg = seg_of_k[k]
+        rto = prog.segs[seg][2]
+        Lk = lc[lo_off[k]:lo_off[k] + mk * mk].reshape(mk, mk).astype(np.float64) / math.sqrt(mk)
+        w3_off = prog.add_weights(_frag_A(w3n[:, ch_off[k]:ch_off[k] + mk], prog.hidden_pad // 4, rto, True))
+        Lp = np.zeros((rto * 16, rto * 16))
+        Lp[:mk, :mk] = Lk
+        a2 = Lp.reshape(rto, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rto, 64, 4)
+        a2_off = prog.add_weights(a2)
+        _add_item(prog, seg, IT_POST, [0], 0, 4, 0, 0, 0, 0, rto, 0, 0, w3_off, 0, a2_off, mk)
+        prog.flops_per_row += 2.0 * H * mk + 2.0 * mk * mk * (2 * lk + 1)
+    return prog.finalize()

@@ -54,11 +54,12 @@ int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stride, const i
  * + last radial-MLP layer + 2 x o3.Linear) [+ PairInteractionBlock skip linear, interaction_blocks.py:151-152]; the
  * embedding TP (tensor_products.py:170-189); or any o3.Linear (IT_LIN items).  Programs come from hamgnn_amd/plan.py.
  * src[k]/src_stride[k]: planar source rows (slot 0: rotated src-node rows, 1: rotated dst-node rows, 2: edge rows).
- * rows: number of edges (or nodes for node-level linears).  lds_bytes: prog.tile_floats*4 (dynamic LDS).             */
+ * rows: number of edges (or nodes for node-level linears).  lds_bytes: prog.tile_floats*4 (dynamic LDS).
+ * program_flags: bit 0 = the program contains lite_mode segment post-ops (plan.IT_POST; selects that kernel instantiation). */
 int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
                 int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights,
                 const int32_t* seg_table, int nseg, const int32_t* item_table, float* out, int64_t out_stride,
-                int64_t rows, int lds_bytes, void* stream);
+                int64_t rows, int lds_bytes, int program_flags, void* stream);
 
 /* torch_scatter.scatter(messages, receiver, dim_size=N) of ConvBlockE3.forward (hamgnn/nn/convolution.py:147-149) as a
  * deterministic segmented reduction: out[n] = sum_{q in [rowptr[n], rowptr[n+1])} msg[perm[q]].                     */

@@ -343,6 +343,21 @@ def main():
     r2 = ref2(Graph(G))
     _check(mine2(G)["edge_attr"], r2["edge_attr"], "backbone legacy_edge_update edge_attr")
 
+    # lite_mode variant (uvu products, plain Linears, one combined radial scale) incl. the lite embedding block
+    cfg3 = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, lite_mode=True).items() if k != 'radius_scale'}))
+    torch.manual_seed(12)
+    ref3, mine3 = ref_conv.HamGNNConvE3(cfg3), R.HamGNNConvE3(dict(cfg3))
+    res = mine3.load_state_dict(ref3.state_dict(), strict=False)
+    assert not (set(res.missing_keys) & set(dict(mine3.named_parameters()))), res.missing_keys
+    r3 = ref3(Graph(G))
+    o3_ = mine3(G)
+    _check(o3_["edge_attr"], r3["edge_attr"], "backbone lite_mode edge_attr")
+    _check(o3_["node_attr"], r3["node_attr"], "backbone lite_mode node_attr")
+    _save("backbone_lite", weights={k: v for k, v in ref3.state_dict().items() if k in dict(mine3.named_parameters())},
+          graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
+          outputs=dict(node_attr=r3["node_attr"], edge_attr=r3["edge_attr"]),
+          meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg3["HamGNN_pre"]).items()}))))
+
     # ---- 4. head, non-SOC (openmx nao 14/19/26, abacus 13 with minus_index) -----------------------------------------
     print("HamGNNPlusPlusOut")
     D = e3.Irreps(mini).dim

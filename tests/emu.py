@@ -59,6 +59,31 @@ def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64
             tile = np.zeros((rto * 16, nco, 16), dtype=dtype)
             for it in prog.item_table[ib:ie]:
                 (typ, s0, s1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off) = (int(v) for v in it[:17])
+                if typ == P.IT_POST:                                   # tile <- Lc^T (s_e * tile), fragment-exact
+                    Hp = prog.hidden_pad
+                    W3 = Wt[w3:w3 + (Hp // 16) * rto * 256].reshape(Hp // 16, rto, 4, 16, 4)
+                    hh = np.zeros((E, Hp), dtype=dtype)
+                    hh[:, :H] = h2[0]
+                    S = np.zeros((rto, 16, 16), dtype=dtype)
+                    for G in range(Hp // 16):
+                        for q in range(4):
+                            B = np.zeros((4, 16), dtype=dtype)
+                            for g in range(4):
+                                B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
+                            for rt in range(rto):
+                                S[rt] += W3[G, rt, :, :, q].T @ B
+                    A2 = Wt[a2:a2 + rto * rto * 256].reshape(rto, rto, 4, 16, 4)
+                    new = np.zeros_like(tile)
+                    for c in range(nco):
+                        md = tile[:, c, :].reshape(rto, 16, 16) * S
+                        for rtp in range(rto):
+                            acc = np.zeros((16, 16), dtype=dtype)
+                            for rt in range(rto):
+                                for r in range(4):
+                                    acc += A2[rtp, rt, :, :, r].T @ md[rt][r::4, :]
+                            new[16 * rtp:16 * rtp + 16, c] = acc
+                    tile = new
+                    continue
                 nc = 2 * mm + 1
                 nsrc = 2 if s1 >= 0 else 1
                 x4 = int(it[17])
@@ -106,6 +131,8 @@ def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64
                                     acc += A2[rtp, rt, :, :, r].T @ Bm
                             tile[16 * rtp:16 * rtp + 16, lk - mm + c] += acc
                 else:
+                    if typ == P.IT_LINC:
+                        mid = mid * Wt[cf:cf + nc][None, :, None, None]
                     for rt in range(rtm):
                         r0 = row_off + 16 * rt
                         tile[r0:r0 + 16, lk - mm:lk + mm + 1] += mid[rt].transpose(1, 0, 2)

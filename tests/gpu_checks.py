@@ -104,16 +104,16 @@ def check_message_pack(device="cuda", unrotate=True):
     return {"message_pack_rel_err": rel(y, f["outputs"]["out"])}
 
 
-def build_backbone_from_fixture(device="cuda"):
+def build_backbone_from_fixture(device="cuda", name="backbone"):
     from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
-    f = load("backbone")
+    f = load(name)
     cfg = json.loads(str(f["meta"]["cfg"]))
     m = load_weights(HamGNNConvE3(cfg), f["weights"])
     return m, f
 
 
-def check_backbone(device="cuda"):
-    m, f = build_backbone_from_fixture(device)
+def check_backbone(device="cuda", name="backbone"):
+    m, f = build_backbone_from_fixture(device, name)
     g = to_graph(f["graph"], device)
     rep = m(g)
     torch.cuda.synchronize()

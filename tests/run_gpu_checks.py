@@ -6,7 +6,7 @@ import torch
 from tests import gpu_checks as G
 
 checks = [("geometry", G.check_geometry, {}), ("message_pack_unrot", G.check_message_pack, {"unrotate": True}),
-          ("message_pack_rot", G.check_message_pack, {"unrotate": False}), ("backbone", G.check_backbone, {}),
+          ("message_pack_rot", G.check_message_pack, {"unrotate": False}), ("backbone", G.check_backbone, {}), ("backbone_lite", G.check_backbone, {"name": "backbone_lite"}),
           ("head19", G.check_head, {}), ("head_abacus13", G.check_head, {"name": "head_abacus_13", "ham_type": "abacus", "nao": 13}),
           ("head_soc_so3", G.check_head_soc, {}), ("random_cell", G.oracle_vs_hip_random, {}), ("batch_of_3", G.oracle_vs_hip_random, {"n_graphs": 3, "seed": 5}),
           ("si2_setA", G.check_default_irreps_si2, {"which": "A"}), ("si2_setB", G.check_default_irreps_si2, {"which": "B"})]

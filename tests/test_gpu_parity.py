@@ -73,3 +73,10 @@ def test_si2_default_irreps_vs_oracle(which):
     r = G.check_default_irreps_si2(which=which)
     print(r)
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL and r["Hnet_rel_err"] < G.TOL
+
+
+def test_backbone_lite_mode_golden():
+    """lite_mode (uvu products + plain Linears + one combined radial scale, message_passing.py:197-215) incl. the lite embedding."""
+    r = G.check_backbone(name="backbone_lite")
+    print(r)
+    assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL

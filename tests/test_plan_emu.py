@@ -104,3 +104,16 @@ def test_message_pack_program_x4_path_vs_oracle():
     assert any(int(it[17]) for it in prog.item_table) and any(not int(it[17]) for it in prog.item_table)
     outp = emu.run_program(prog, [xs, xd, fe], (hn, he), D, 2)
     assert rel(lay.from_planar(outp), out) < 1e-6
+
+
+def test_message_pack_lite_program_vs_golden(golden_dir):
+    f = load(golden_dir, "message_pack_block_lite")
+    sd, i = f["weights"], f["inputs"]
+    lay = P.PlanarLayout(MINI)
+    n = i["sh"][:, 1:4] / math.sqrt(3.0)
+    D = emu.edge_wigner_all(n, 3)
+    xs, xd, fe = (emu.rotate_rows(lay.to_planar(i[k]), lay, D, 3) for k in ("src", "dst", "edge_feats"))
+    h = emu.radial_hidden(i["rbf"], P.radial_hidden_weights(sd, "weight_generator_combine", emu.SILU_CST))
+    prog = P.build_message_pack_program_lite(sd, MINI, MINI, SH, MINI, unrotate=True)
+    outp = emu.run_program(prog, [xs, xd, fe], (h, None), D, 3)
+    assert rel(lay.from_planar(outp), f["outputs"]["out"]) < 1e-6
