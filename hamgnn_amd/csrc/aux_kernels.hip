@@ -103,7 +103,7 @@ extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, con
                                 int num_radial, int lmax_wig, const float* jtab, float* rbf, float* wig, float* edge_len,
                                 float* ang_scratch, void* stream) {
     if (E <= 0) return 0;
-    if (lmax_wig > 6) return hg_fail(-2, "hg_edge_geometry: lmax_wig > 6 not instantiated");
+    if (lmax_wig > 7) return hg_fail(-2, "hg_edge_geometry: lmax_wig > 7 not instantiated");
     hipStream_t st = (hipStream_t)stream;
     int nW = 0, nJ = 0;
     for (int l = 0; l <= lmax_wig; ++l) nW += (2 * l + 1) * (2 * l + 1);
@@ -125,6 +125,7 @@ extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, con
                 case 4: wigner_kernel<4><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
                 case 5: wigner_kernel<5><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
                 case 6: wigner_kernel<6><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
+                case 7: wigner_kernel<7><<<grid, 256, 0, st>>>(ang, E, J, sg, wig, nW, off); break;
             }
             off += N * N;
             soff += l + 1;

@@ -10,12 +10,13 @@
 __global__ __launch_bounds__(256) void ham_merge_kernel(const float* __restrict__ coeff, int64_t cs, const float* __restrict__ wig,
                                                         int nW, const HgWigOff wo, const int4* __restrict__ slot_tab,
                                                         const int* __restrict__ cg_ptr, const int* __restrict__ cg_idx,
-                                                        const float* __restrict__ cg_val, int nao2, float* __restrict__ Hraw) {
+                                                        const float* __restrict__ cg_val, int nslots, int nout,
+                                                        float* __restrict__ Hraw) {
     extern __shared__ float coef[];
     const int64_t e = blockIdx.x;
     const float* __restrict__ c = coeff + e * cs;
     const float* __restrict__ D = wig ? wig + e * nW : nullptr;
-    for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+    for (int q = threadIdx.x; q < nslots; q += blockDim.x) {
         const int4 t = slot_tab[q];                  // {L, a, base (planar index of component 0), component stride}
         float acc;
         if (D) {
@@ -29,51 +30,57 @@ __global__ __launch_bounds__(256) void ham_merge_kernel(const float* __restrict_
         coef[q] = acc;
     }
     __syncthreads();
-    for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+    for (int q = threadIdx.x; q < nout; q += blockDim.x) {
         float acc = 0.f;
         for (int k = cg_ptr[q]; k < cg_ptr[q + 1]; ++k) acc = fmaf(cg_val[k], coef[cg_idx[k]], acc);
-        Hraw[e * nao2 + q] = acc;
+        Hraw[e * nout + q] = acc;
     }
 }
 
 extern "C" int hg_ham_merge(const float* coeff, int64_t c_stride, const float* wig, int nW, const int32_t* wig_off,
                             const int32_t* slot_tab, int nslots, const int32_t* cg_ptr, const int32_t* cg_idx, const float* cg_val,
-                            int nao2, int64_t rows, float* Hraw, void* stream) {
+                            int nout, int64_t rows, float* Hraw, void* stream) {
     if (rows <= 0) return 0;
-    if (nslots != nao2) return hg_fail(-2, "hg_ham_merge: slot table must have nao^2 entries");
+    if (nslots <= 0 || nout <= 0 || nslots > 16384) return hg_fail(-2, "hg_ham_merge: bad slot / output count");
     HgWigOff wo;
     for (int i = 0; i < 8; ++i) wo.o[i] = wig_off ? wig_off[i] : 0;
-    ham_merge_kernel<<<dim3((unsigned)rows), 256, sizeof(float) * (size_t)nao2, (hipStream_t)stream>>>(
-        coeff, c_stride, wig, nW, wo, (const int4*)slot_tab, cg_ptr, cg_idx, cg_val, nao2, Hraw);
+    ham_merge_kernel<<<dim3((unsigned)rows), 256, sizeof(float) * (size_t)nslots, (hipStream_t)stream>>>(
+        coeff, c_stride, wig, nW, wo, (const int4*)slot_tab, cg_ptr, cg_idx, cg_val, nslots, nout, Hraw);
     return hg_check_launch("hg_ham_merge");
 }
 
-// stage 2: H = mask * (0.5 (Hraw[e] + sign Hraw[inv e]^T) + H0)   (hamgnn_output.py:1231-1285, 3782-3795, 2288-2365)
-__global__ __launch_bounds__(256) void ham_finish_kernel(const float* __restrict__ Hraw, const int64_t* __restrict__ inv,
+// stage 2: H = mask * (0.5 (Hraw[e] + sign Hraw[inv e]^T) + H0)   (hamgnn_output.py:1231-1285, 3782-3795, 2288-2365);
+// flags bit 1: H0 is added after the mask (SOC branches, :3603-3609).  The orbital-mask row index wraps at mask_w so that the
+// same kernel finishes the (2 nao)^2 spin-block matrices of the su2 branch (:3163-3168) with sign = +1 (real) / -1 (imag).
+__global__ __launch_bounds__(256) void ham_finish_kernel(const float* __restrict__ Hraw, int64_t hs, const int64_t* __restrict__ inv,
                                                          const float* __restrict__ H0, const float* __restrict__ orb_mask,
                                                          const int64_t* __restrict__ z, const int64_t* __restrict__ ia,
-                                                         const int64_t* __restrict__ ib, int nao, float sign, int symmetrize,
+                                                         const int64_t* __restrict__ ib, int nao, int mask_w, float sign, int flags,
                                                          float* __restrict__ H) {
     const int64_t e = blockIdx.x;
     const int nao2 = nao * nao;
     const int64_t eo = inv ? inv[e] : e;
-    const float* __restrict__ ma = orb_mask ? orb_mask + z[ia ? ia[e] : e] * nao : nullptr;
-    const float* __restrict__ mb = orb_mask ? orb_mask + z[ib ? ib[e] : e] * nao : nullptr;
+    const float* __restrict__ ma = orb_mask ? orb_mask + z[ia ? ia[e] : e] * mask_w : nullptr;
+    const float* __restrict__ mb = orb_mask ? orb_mask + z[ib ? ib[e] : e] * mask_w : nullptr;
+    const bool sym = flags & 1, h0_last = flags & 2;
     for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
         const int r = q / nao, c = q - r * nao;
-        float v = Hraw[e * nao2 + q];
-        if (symmetrize) v = 0.5f * (v + sign * Hraw[eo * nao2 + c * nao + r]);
-        if (H0) v += H0[e * nao2 + q];
-        if (ma) v *= ma[r] * mb[c];
+        float v = Hraw[e * hs + q];
+        if (sym) v = 0.5f * (v + sign * Hraw[eo * hs + c * nao + r]);
+        if (H0 && !h0_last) v += H0[e * nao2 + q];
+        if (ma) v *= ma[r % mask_w] * mb[c % mask_w];
+        if (H0 && h0_last) v += H0[e * nao2 + q];
         H[e * nao2 + q] = v;
     }
 }
 
-extern "C" int hg_ham_finish(const float* Hraw, const int64_t* inv, const float* H0, const float* orb_mask, const int64_t* z,
-                             const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int symmetrize, int64_t rows, float* H,
-                             void* stream) {
+extern "C" int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t* inv, const float* H0, const float* orb_mask,
+                             int mask_w, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int flags,
+                             int64_t rows, float* H, void* stream) {
     if (rows <= 0) return 0;
-    ham_finish_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign, symmetrize, H);
+    if (orb_mask && (mask_w <= 0 || nao % mask_w)) return hg_fail(-2, "hg_ham_finish: nao must be a multiple of the mask width");
+    ham_finish_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(Hraw, h_stride, inv, H0, orb_mask, z, idx_a, idx_b, nao,
+                                                                             mask_w > 0 ? mask_w : nao, sign, flags, H);
     return hg_check_launch("hg_ham_finish");
 }
 

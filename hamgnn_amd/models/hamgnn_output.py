@@ -1,9 +1,10 @@
 """HamGNNPlusPlusOut -- MI355X drop-in for the reference pair read-out head (hamgnn/models/hamgnn_output.py:96-123 ctor,
 :2916-4021 forward).  Same constructor keywords, parameter names ({onsite,offsite}_hamiltonian_network.{residual_block,
 linear_transform}, ..._ksi_network, ..._overlap_network) and result dict.  In scope this round: the non-SOC branch
-(:3772-3799) incl. overlap networks, SOC/so3 (:3026-3144), masks, symmetrisation, H0, per-crystal concatenation,
-sparsity ratio.  Out of scope (raise NotImplementedError): band/k-space code, spin-constrained / collinear branches,
-SOC/su2, forces."""
+(:3772-3799) incl. overlap networks, SOC/so3 (:3026-3144), SOC/su2 (:3146-3178; E3TensorDecomposition.get_H,
+hamgnn/nn/tensor_decomposition.py:553-603), masks, symmetrisation, H0, per-crystal concatenation, sparsity ratio.
+Out of scope (raise NotImplementedError): band/k-space code, spin-constrained / collinear branches, forces
+(SURVEY.md section 2 / 8f)."""
 from __future__ import annotations
 
 import numpy as np
@@ -39,12 +40,28 @@ class HamGNNPlusPlusOut(nn.Module):
                            (get_nonzero_mask_tensor, "get_nonzero_mask_tensor"), (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
             if flag:
                 raise NotImplementedError(f"HamGNNPlusPlusOut({name}) is outside the MI355X hot-path scope of this round")
-        if soc_switch and self.soc_basis != "so3":
-            raise NotImplementedError("SOC basis 'su2' (SIESTA/ABACUS SOC) is not built yet; 'so3' is")
+        if soc_switch and self.soc_basis not in ("so3", "su2"):
+            raise NotImplementedError("Unsupported SOC basis")                  # hamgnn_output.py:3180-3181
         t = B.basis_table(self.ham_type, nao_max)
         self.row = self.col = Irreps(t["row"])
         self.index_change, self.minus_index, self.basis_def = t["index_change"], t["minus_index"], t["basis_def"]
         self.hamiltonian_irreps = P.ham_irreps(self.row)
+        self.node_layout = P.PlanarLayout(irreps_in_node)
+        self.edge_layout = P.PlanarLayout(irreps_in_edge)
+        self._compiled_for = None
+        if soc_switch and self.soc_basis == "su2":
+            # hamgnn_output.py:281-293 + :189-198: irreps_out = 2 * (required + required); get_H reads copies 0 (re) and 2 (im)
+            half = P.su2_irreps(self.row)
+            if half.lmax > 7:
+                raise NotImplementedError("su2 SOC head: L x 1 couplings beyond l = 7 are not instantiated")
+            self.hamiltonian_irreps_su2 = Irreps(list(half) * 2)
+            keep = [c in (0, 2) for c in range(4) for _ in range(len(half))]
+            self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, Irreps(list(half) * 4), keep)
+            self.offsite_hamiltonian_network = hnn.HamLayer(irreps_in_edge, Irreps(list(half) * 4), keep)
+            if not ham_only:
+                self.onsite_overlap_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
+                self.offsite_overlap_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
+            return
         self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
         self.offsite_hamiltonian_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
         if soc_switch:
@@ -54,9 +71,6 @@ class HamGNNPlusPlusOut(nn.Module):
         if not ham_only:
             self.onsite_overlap_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
             self.offsite_overlap_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
-        self.node_layout = P.PlanarLayout(irreps_in_node)
-        self.edge_layout = P.PlanarLayout(irreps_in_edge)
-        self._compiled_for = None
 
     # ------------------------------------------------------------------------------------------------------------
     def compile(self, device):
@@ -64,10 +78,17 @@ class HamGNNPlusPlusOut(nn.Module):
         for m in self.children():
             if isinstance(m, hnn.HamLayer):
                 m.compile(dev)
-        net = self.onsite_hamiltonian_network
-        st, ptr, idx, val = P.ham_merge_tables(self.row, self.nao_max, self.index_change, self.minus_index, net.girr, net.slot_pos)
-        self._slot = torch.from_numpy(st).to(dev)
-        self._cg = tuple(torch.from_numpy(a).to(dev) for a in (ptr, idx, val))
+        su2 = self.soc_switch and self.soc_basis == "su2"
+        net = self.onsite_overlap_network if (su2 and not self.ham_only) else self.onsite_hamiltonian_network
+        if not su2 or not self.ham_only:
+            st, ptr, idx, val = P.ham_merge_tables(self.row, self.nao_max, self.index_change, self.minus_index, net.girr, net.slot_pos)
+            self._slot = torch.from_numpy(st).to(dev)
+            self._cg = tuple(torch.from_numpy(a).to(dev) for a in (ptr, idx, val))
+        if su2:
+            net = self.onsite_hamiltonian_network
+            st, ptr, idx, val = P.su2_merge_tables(self.row, self.nao_max, self.index_change, self.minus_index, net.girr, net.slot_pos)
+            self._slot_su2 = torch.from_numpy(st).to(dev)
+            self._cg_su2 = tuple(torch.from_numpy(a).to(dev) for a in (ptr, idx, val))
         mask = np.zeros((119, self.nao_max), dtype=np.float32)
         for Z, orb in self.basis_def.items():
             mask[Z, orb] = 1.0
@@ -80,7 +101,7 @@ class HamGNNPlusPlusOut(nn.Module):
         self._n_imap = torch.from_numpy(self.node_layout.index_map().astype(np.int32)).to(dev)
         self._e_imap = torch.from_numpy(self.edge_layout.index_map().astype(np.int32)).to(dev)
         self._rot_tab = torch.from_numpy(P.rotate_table(self.edge_layout)).to(dev)
-        self._lmax = max(self.edge_layout.irreps.lmax, self.hamiltonian_irreps.lmax)
+        self._lmax = max(self.edge_layout.irreps.lmax, self.hamiltonian_irreps.lmax, P.su2_irreps(self.row).lmax if su2 else 0)
         self._jtab = torch.from_numpy(P.wigner_jtab(self._lmax)).to(dev)
         self._blk = torch.from_numpy(P.shell_block_table(self.row, self.nao_max)).to(dev)
         self._compiled_for = dev
@@ -162,6 +183,23 @@ class HamGNNPlusPlusOut(nn.Module):
         if not self.ham_only:
             s_on, s_off = self._blocks(self.onsite_overlap_network, self.offsite_overlap_network, node_pl, edge_rot, geo, data, inv, None, None)
             result["overlap"] = self._cat_by_crystal(data, s_on, s_off, edge_counts)
+        if self.soc_switch and self.soc_basis == "su2":                      # ---- SOC / su2 (hamgnn_output.py:3146-3178)
+            n, big = self.nao_max, 4 * self.nao_max ** 2
+            z = data.z.contiguous()
+            H0 = (f32c(data.Hon0), f32c(data.Hoff0), f32c(data.iHon0), f32c(data.iHoff0)) if self.add_H0 else (None,) * 4
+            raw_on = ops.ham_merge(self.onsite_hamiltonian_network(node_pl), None, self._slot_su2, *self._cg_su2, 2 * big)
+            raw_off = ops.ham_merge(self.offsite_hamiltonian_network(edge_rot), geo, self._slot_su2, *self._cg_su2, 2 * big)
+            fin = lambda raw, plane, inv_, h0, ia, ib: ops.ham_finish(raw[:, plane * big:(plane + 1) * big], inv_, h0, self._mask, z, ia, ib,
+                                                                       2 * n, 1.0 if plane == 0 else -1.0, self.symmetrize, True)
+            on_r, on_i = fin(raw_on, 0, None, H0[0], None, None), fin(raw_on, 1, None, H0[2], None, None)
+            off_r, off_i = fin(raw_off, 0, inv, H0[1], geo.src, geo.dst), fin(raw_off, 1, inv, H0[3], geo.src, geo.dst)
+            Hr = self._cat_by_crystal(data, on_r, off_r, edge_counts)
+            Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
+            result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
+                           "wavefunction": None})
+            if self.calculate_sparsity:
+                result["sparsity_ratio"] = self.calculate_sparsity_ratio(data)
+            return result
         if self.soc_switch:                                                  # ---- SOC / so3 (hamgnn_output.py:3026-3144)
             n = self.nao_max
             if self.add_H_nonsoc:

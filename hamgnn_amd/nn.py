@@ -269,9 +269,11 @@ class PairInteractionEmbeddingBlock(nn.Module):
 
 
 class HamLayer(nn.Module):
-    def __init__(self, irreps_in, ham_irreps: Irreps):
+    def __init__(self, irreps_in, ham_irreps: Irreps, keep=None):
+        """keep: optional bool per output irrep -- outputs the caller never reads (they keep their weights, for checkpoint
+        compatibility, but no GEMM rows are spent on them; SOC/su2 head)."""
         super().__init__()
-        self.irreps_in, self.ham_irreps = Irreps(irreps_in), ham_irreps
+        self.irreps_in, self.ham_irreps, self.keep = Irreps(irreps_in), ham_irreps, keep
         self.residual_block = ResidualBlock(irreps_in, irreps_in)
         self.linear_transform = E3Linear(irreps_in, ham_irreps)
 
@@ -279,7 +281,7 @@ class HamLayer(nn.Module):
         self.residual_block.compile(device)
         W = self.linear_transform.weight.detach().cpu().double().numpy()
         if all(m == 1 for m, _, _ in self.ham_irreps):         # hamiltonian irreps: regroup the multiplicity-1 outputs by (L,p)
-            prog, self.girr, self.slot_pos = P.build_ham_linear_program(W, self.irreps_in, self.ham_irreps)
+            prog, self.girr, self.slot_pos = P.build_ham_linear_program(W, self.irreps_in, self.ham_irreps, self.keep)
         else:                                                  # xi networks (nao^2 x 0e): a plain o3.Linear
             prog, self.girr, self.slot_pos = P.build_linear_program(W, self.irreps_in, self.ham_irreps), self.ham_irreps, None
         self._dp = ops.DeviceProgram(prog, device)

@@ -171,20 +171,25 @@ def embed_lookup(Ta, Tb, z, idx_a, idx_b, rows, T, Tp):
     return out
 
 
-def ham_merge(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, nao2):
+def ham_merge(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, nout):
     rows = coeff.shape[0]
-    out = torch.empty(rows, nao2, device=coeff.device, dtype=torch.float32)
+    out = torch.empty(rows, nout, device=coeff.device, dtype=torch.float32)
     wig, nW, woff = (ptr(geo.wig), geo.nW, geo.wig_off) if geo is not None else (C.c_void_p(0), 0, (C.c_int * 8)())
-    check(lib().hg_ham_merge(ptr(coeff), i64(coeff.stride(0)), wig, i32(nW), woff, ptr(slot_tab), i32(nao2), ptr(cg_ptr), ptr(cg_idx),
-                             ptr(cg_val), i32(nao2), i64(rows), ptr(out), _stream()), "hg_ham_merge")
+    check(lib().hg_ham_merge(ptr(coeff), i64(coeff.stride(0)), wig, i32(nW), woff, ptr(slot_tab), i32(slot_tab.shape[0]), ptr(cg_ptr),
+                             ptr(cg_idx), ptr(cg_val), i32(nout), i64(rows), ptr(out), _stream()), "hg_ham_merge")
     return out
 
 
-def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetrize=True):
+def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetrize=True, h0_after_mask=False):
+    """Hraw: [rows, >= nao^2] (a column slice of a wider buffer is fine: the row stride is passed on)."""
     rows = Hraw.shape[0]
-    out = torch.empty_like(Hraw)
-    check(lib().hg_ham_finish(ptr(Hraw), ptr(inv), ptr(H0), ptr(orb_mask), ptr(z), ptr(idx_a), ptr(idx_b), i32(nao), f32(sign),
-                              i32(1 if symmetrize else 0), i64(rows), ptr(out), _stream()), "hg_ham_finish")
+    assert Hraw.stride(1) == 1
+    out = torch.empty(rows, nao * nao, device=Hraw.device, dtype=torch.float32)
+    mask_w = int(orb_mask.shape[1]) if orb_mask is not None else 0
+    _require_gpu(Hraw)
+    check(lib().hg_ham_finish(C.c_void_p(Hraw.data_ptr()), i64(Hraw.stride(0)), ptr(inv), ptr(H0), ptr(orb_mask), i32(mask_w), ptr(z), ptr(idx_a), ptr(idx_b),
+                              i32(nao), f32(sign), i32((1 if symmetrize else 0) | (2 if h0_after_mask else 0)), i64(rows), ptr(out),
+                              _stream()), "hg_ham_finish")
     return out
 
 

@@ -517,13 +517,19 @@ def ham_irreps(row: Irreps):
     return Irreps(out)
 
 
-def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps):
+def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps, keep=None):
     """o3.Linear(D -> hamiltonian_irreps) (HamLayer.linear_transform, hamgnn_output.py:49,56) regrouped by (L,p) so that the
-    89..312 multiplicity-1 outputs become a handful of GEMM segments.  Returns (program, grouped irreps, slot->(group, col))."""
+    89..312 multiplicity-1 outputs become a handful of GEMM segments.  Returns (program, grouped irreps, slot->(group, col)).
+    keep: optional bool per output slot; slots not kept own weights (checkpoint layout) but are never computed (the su2 head
+    reads only half of its 2 x 2 x required irreps, tensor_decomposition.py:545-551)."""
     irreps_in = Irreps(irreps_in)
+    keep = [True] * len(hirr) if keep is None else list(keep)
     groups, slot_pos = [], []
     key_to_g = {}
     for s, (_, L, p) in enumerate(hirr):
+        if not keep[s]:
+            slot_pos.append(None)
+            continue
         if (L, p) not in key_to_g:
             key_to_g[(L, p)] = len(groups)
             groups.append([0, L, p])
@@ -538,17 +544,18 @@ def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps):
     for i, (mi, li, pi) in enumerate(irreps_in):
         for s, (_, L, p) in enumerate(hirr):
             if (li, pi) == (L, p):
-                g, col = slot_pos[s]
-                M = mats.setdefault((i, g), np.zeros((mi, girr[g][0])))
-                M[:, col] = weight[off:off + mi]
+                if keep[s]:
+                    g, col = slot_pos[s]
+                    M = mats.setdefault((i, g), np.zeros((mi, girr[g][0])))
+                    M[:, col] = weight[off:off + mi]
+                    fan[s] = fan.get(s, 0) + mi
                 off += mi
-                fan[s] = fan.get(s, 0) + mi
     assert off == weight.size, (off, weight.size)
     prog, seg_of_k = new_program(girr, 0)
     in_layout = PlanarLayout(irreps_in)
     for (i, g), M in mats.items():
         mi, li, _ = irreps_in[i]
-        cols_fan = np.array([fan[s] for s in range(len(hirr)) if slot_pos[s][0] == g], dtype=np.float64)
+        cols_fan = np.array([fan[s] for s in range(len(hirr)) if keep[s] and slot_pos[s][0] == g], dtype=np.float64)
         Mn = M / np.sqrt(cols_fan)[None, :]
         mk = girr[g][0]
         nc = 2 * li + 1
@@ -562,6 +569,95 @@ def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps):
                 _add_item(prog, seg, IT_LIN, [0], in_layout.off[i], in_layout.mulp[i], li, li, 0, ksteps, rtm, 0, a1_off, 0, 0, 0, r1 - r0, row_off=r0)
         prog.flops_per_row += 2.0 * mi * mk * nc
     return prog.finalize(), girr, slot_pos
+
+
+def su2_irreps(row: Irreps) -> Irreps:
+    """One complex half of E3TensorDecomposition(spinful=True).required_irreps_out (hamgnn/nn/tensor_decomposition.py:40-88,
+    463-486): per (row shell, col shell) the L list of l_i x l_j, then for every L the coupling with the spin vector
+    L x 1 -> |L-1|..L+1; parity (-1)^(l_i+l_j) throughout."""
+    out = []
+    for _, li, _ in row:
+        for _, lj, _ in row:
+            p = (-1) ** (li + lj)
+            Ls = range(abs(li - lj), li + lj + 1)
+            out += [(1, L, p) for L in Ls]
+            out += [(1, l2, p) for L in Ls for l2 in range(abs(L - 1), L + 2)]
+    return Irreps(out)
+
+
+def su2_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, slot_pos):
+    """slot table + CSR table of hg_ham_merge for the SOC/su2 head: E3TensorDecomposition.get_H (tensor_decomposition.py:
+    553-603) + reorder_matrix (hamgnn_output.py:1056-1096) + the (2,2,nao,nao)->(2 nao, 2 nao) spin-block interleave
+    (:3151-3152) as ONE real-linear map from the used network outputs (re: copy 0, im: copy 2 of the 4 x required irreps)
+    to [real plane | imag plane], each (2 nao)^2.  slot_pos indexes the full 4-copy irreps list."""
+    glay = PlanarLayout(girr)
+    half = su2_irreps(row)
+    S = len(half)
+    R = sum(2 * L + 1 for _, L, _ in half)
+    assert R == 4 * nao * nao
+    slot_tab = np.zeros((2 * R, 4), dtype=np.int32)
+    q = 0
+    for copy in (0, 2):
+        for s, (_, L, p) in enumerate(half):
+            g, col = slot_pos[copy * S + s]
+            for a in range(2 * L + 1):
+                slot_tab[q] = (L, a, glay.off[g] + col, glay.mulp[g])
+                q += 1
+    s2 = math.sqrt(2.0)
+    spin = np.array([[1, 0, 1, 0], [0, -1j, 0, 1], [0, 1j, 0, 1], [1, 0, -1, 0]], dtype=np.complex128) / s2
+    entries = {}                                     # (j, A, B) pre-reorder -> (coef index array, complex values)
+    off, r0 = 0, 0
+    for _, li, _ in row:
+        c0 = 0
+        ni = 2 * li + 1
+        for _, lj, _ in row:
+            nj = 2 * lj + 1
+            Ls = list(range(abs(li - lj), li + lj + 1))
+            m = ni * nj
+            wm = np.concatenate([so3.wigner_3j(li, lj, L) for L in Ls], axis=-1)          # [ni, nj, m]
+            T = np.zeros((4, ni, nj, 4 * m), dtype=np.complex128)
+            T[:, :, :, :m] = np.einsum("j,abm->jabm", spin[:, 0], wm)
+            o2, mo = m, 0
+            for L in Ls:
+                Lp = list(range(abs(L - 1), L + 2))
+                wsp = np.concatenate([so3.wigner_3j(L, 1, l2) for l2 in Lp], axis=-1)       # [2L+1, 3, d]
+                d = wsp.shape[-1]
+                T[:, :, :, o2:o2 + d] = np.einsum("jn,abM,Mnl->jabl", spin[:, 1:], wm[:, :, mo:mo + 2 * L + 1], wsp)
+                o2 += d
+                mo += 2 * L + 1
+            assert o2 == 4 * m
+            for j in range(4):
+                for a in range(ni):
+                    for b in range(nj):
+                        v = T[j, a, b]
+                        nz = np.nonzero(np.abs(v) > 1e-14)[0]
+                        entries[(j, r0 + a, c0 + b)] = (off + nz, v[nz])
+            off += 4 * m
+            c0 += nj
+        r0 += ni
+    assert off == R
+    ic = list(range(nao)) if index_change is None else list(index_change)
+    sign = np.ones(nao)
+    if minus_index is not None:
+        sign[list(minus_index)] = -1
+    n2 = 2 * nao
+    ptr, idx, val = [0], [], []
+    for plane in (0, 1):
+        for Rr in range(n2):
+            for Cc in range(n2):
+                s1, r = divmod(Rr, nao)
+                s2_, c = divmod(Cc, nao)
+                k, v = entries[(2 * s1 + s2_, ic[r], ic[c])]
+                v = v * (sign[r] * sign[c])
+                re_c, im_c = (v.real, -v.imag) if plane == 0 else (v.imag, v.real)      # (A_r + i A_i)(x + i y)
+                for kk, w in zip(k, re_c):
+                    if abs(w) > 1e-14:
+                        idx.append(kk); val.append(w)
+                for kk, w in zip(k, im_c):
+                    if abs(w) > 1e-14:
+                        idx.append(R + kk); val.append(w)
+                ptr.append(len(idx))
+    return slot_tab, np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(val, np.float32)
 
 
 def ham_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, slot_pos):

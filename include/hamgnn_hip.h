@@ -87,18 +87,23 @@ int hg_from_planar(const float* xp, int64_t rows, int Dp, const int32_t* map, fl
 int hg_embed_lookup(const float* Ta, const float* Tb, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b,
                     int64_t rows, int T, int Tp, float* out, void* stream);
 
-/* Read-out head, stage 1 (hamgnn/models/hamgnn_output.py:851-891 merge_tensor_components + :1056-1096 reorder_matrix):
+/* Read-out head, stage 1 (hamgnn/models/hamgnn_output.py:851-891 merge_tensor_components + :1056-1096 reorder_matrix;
+ * SOC/su2: hamgnn/nn/tensor_decomposition.py:553-603 E3TensorDecomposition.get_H + hamgnn_output.py:3149-3152):
  * coeff: planar rows of the HamLayer output regrouped by (L,p) (rotated frame if wig != NULL -> un-rotated here);
- * cg_tab: sparse list {out element (row*nao+col, after reorder and sign), coeff slot, value}; Hraw[e][nao*nao].       */
+ * slot_tab int32[nslots][4] = {L, component, planar index of component 0, component stride} of every coefficient read;
+ * cg_ptr/idx/val: CSR rows = output elements (after reorder and sign), columns = slots; Hraw[e][nout]
+ * (nout = nao^2, or 2 (2 nao)^2 = [real plane | imag plane] for su2).                                                   */
 int hg_ham_merge(const float* coeff, int64_t c_stride, const float* wig, int nW, const int32_t* wig_off,
                  const int32_t* slot_tab, int nslots, const int32_t* cg_ptr, const int32_t* cg_idx, const float* cg_val,
-                 int nao2, int64_t rows, float* Hraw, void* stream);
+                 int nout, int64_t rows, float* Hraw, void* stream);
 
 /* Read-out head, stage 2 (:1231-1285 symmetrize, :3782-3795 +H0, :2288-2365 orbital masks):
- * H[e] = mask(z_a, z_b) * (0.5 (Hraw[e] + sign * Hraw[inv[e]]^T) + H0[e]);  inv == NULL => on-site (own transpose).   */
-int hg_ham_finish(const float* Hraw, const int64_t* inv, const float* H0, const float* orb_mask, const int64_t* z,
-                  const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int symmetrize, int64_t rows, float* H,
-                  void* stream);
+ * H[e] = mask(z_a, z_b) * (0.5 (Hraw[e] + sign * Hraw[inv[e]]^T) + H0[e]);  inv == NULL => on-site (own transpose).
+ * Hraw rows are h_stride floats apart; orb_mask is [Z][mask_w] and indexed modulo mask_w (nao = 2 mask_w for the su2
+ * spin-block matrices, :3163-3168); flags: bit 0 symmetrise, bit 1 add H0 after the mask (SOC, :3603-3609).            */
+int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t* inv, const float* H0, const float* orb_mask, int mask_w,
+                  const int64_t* z, const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int flags, int64_t rows,
+                  float* H, void* stream);
 
 /* SOC / so3 branch (hamgnn_output.py:3026-3144).  hg_block_mean = symmetrize_orbital_coefficients (:2367-2431): each element
  * of the nao x nao xi matrix -> mean over its (row shell, col shell) block; tab int32[nao^2][4] = {r0, r1, c0, c1}.          */

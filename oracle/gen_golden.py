@@ -414,6 +414,33 @@ def main():
             keys = ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0", "iHon0", "iHoff0", "Lon", "Loff")
             _save("head_soc_so3_openmx_19", weights=sd, graph={k: Gs[k] for k in keys}, inputs=dict(node_attr=node_attr, edge_attr=edge_attr),
                   outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"], hamiltonian_imag=out_ref["hamiltonian_imag"]))
+    # ---- 6. head, SOC su2 (E3TensorDecomposition.get_H; siesta/abacus nao 13, openmx 19) ---------------------------
+    for ham_type, nao, zs in (("abacus", 13, (6, 1, 8)), ("siesta", 13, (6, 1, 8)), ("openmx", 19, (14, 8, 42))):
+        Gu = Graph(G)
+        Gu.z = torch.tensor(zs)
+        m2 = 4 * nao * nao
+        for k, n in (("Hon0", N), ("Hoff0", E), ("iHon0", N), ("iHoff0", E), ("Hon", N), ("Hoff", E), ("iHon", N), ("iHoff", E)):
+            Gu[k] = 0.1 * torch.randn(n, m2, generator=gen)
+        Gu["Son"], Gu["Soff"] = torch.randn(N, nao * nao, generator=gen), torch.randn(E, nao * nao, generator=gen)
+        torch.manual_seed(13)
+        ref = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type=ham_type, ham_only=True,
+                                        symmetrize=True, add_H0=True, soc_switch=True, soc_basis="su2", calculate_band_energy=False,
+                                        calculate_sparsity=False)
+        mine = R.HamGNNPlusPlusOut(mini, mini, nao_max=nao, ham_type=ham_type, symmetrize=True, add_H0=True, soc_switch=True,
+                                   soc_basis="su2")
+        assert str(ref.onsite_hamiltonian_network.linear_transform.irreps_out) == str(mine.onsite_hamiltonian_network.linear_transform.irreps_out)
+        sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("cg_calculator")}
+        res = mine.load_state_dict(sd, strict=False)
+        assert not res.missing_keys, res.missing_keys
+        gin = Graph({k: (v.clone() if torch.is_tensor(v) else v) for k, v in Gu.items()})
+        out_ref = ref(gin, {"node_attr": node_attr, "edge_attr": edge_attr})
+        out_mine = mine(Gu, {"node_attr": node_attr, "edge_attr": edge_attr})
+        _check(out_mine["hamiltonian_real"], out_ref["hamiltonian_real"], f"head SOC su2 {ham_type} nao={nao} real")
+        _check(out_mine["hamiltonian_imag"], out_ref["hamiltonian_imag"], f"head SOC su2 {ham_type} nao={nao} imag")
+        if (ham_type, nao) == ("abacus", 13):
+            keys = ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0", "iHon0", "iHoff0")
+            _save("head_soc_su2_abacus_13", weights=sd, graph={k: Gu[k] for k in keys}, inputs=dict(node_attr=node_attr, edge_attr=edge_attr),
+                  outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"], hamiltonian_imag=out_ref["hamiltonian_imag"]))
     print("ALL WIRING CHECKS PASSED")
 
 

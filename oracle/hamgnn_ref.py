@@ -317,6 +317,23 @@ class HamLayer(nn.Module):
         return self.linear_transform(self.residual_block(x))
 
 
+def su2_required_irreps(row):
+    """irreps of one complex half of the spinful decomposition (tensor_decomposition.py:40-88, 463-486): per (row shell, col
+    shell) the L list of l_i x l_j, then for every L its coupling with the spin vector, L x 1 -> |L-1|..L+1; parity
+    (-1)^(l_i+l_j) throughout."""
+    out = Irreps([])
+    for _, li in row:
+        for _, lj in row:
+            p = (-1) ** (li.l + lj.l)
+            Ls = list(range(abs(li.l - lj.l), li.l + lj.l + 1))
+            for L in Ls:
+                out = out + Irrep(L, p)
+            for L in Ls:
+                for l2 in range(abs(L - 1), L + 2):
+                    out = out + Irrep(l2, p)
+    return out
+
+
 class HamGNNPlusPlusOut(nn.Module):
     """Non-SOC branch and SOC/so3 branch of the reference head; ham_only=True; band/k-space code out of scope."""
 
@@ -327,7 +344,7 @@ class HamGNNPlusPlusOut(nn.Module):
         self.symmetrize, self.add_H0, self.soc_switch, self.add_H_nonsoc = symmetrize, add_H0, soc_switch, add_H_nonsoc
         self.zero_point_shift = zero_point_shift
         self.soc_basis = soc_basis.lower() if self.ham_type == "openmx" or not soc_switch else "su2"
-        assert not soc_switch or self.soc_basis == "so3", "oracle covers so3 only"
+        assert self.soc_basis in ("so3", "su2")
         t = load_basis_tables()[f"{self.ham_type}_{nao_max}"]
         self.row = self.col = Irreps(t["row"])
         self.index_change = torch.tensor(t["index_change"]) if t["index_change"] is not None else None
@@ -339,6 +356,15 @@ class HamGNNPlusPlusOut(nn.Module):
                 for L in range(abs(li.l - lj.l), li.l + lj.l + 1):
                     irr = irr + Irrep(L, (-1) ** (li.l + lj.l))
         self.hamiltonian_irreps = irr
+        if soc_switch and self.soc_basis == "su2":
+            # E3TensorDecomposition(spinful=True).required_irreps_out (tensor_decomposition.py:463-527) is already the doubled
+            # (re, im) list; the head doubles it once more (hamgnn_output.py:193,197) -- only copies 0 and 2 are ever read
+            self.su2_required = su2_required_irreps(self.row)
+            net = self.su2_required + self.su2_required
+            net = net + net
+            self.onsite_hamiltonian_network = HamLayer(irreps_in_node, net)
+            self.offsite_hamiltonian_network = HamLayer(irreps_in_edge, net)
+            return
         self.onsite_hamiltonian_network = HamLayer(irreps_in_node, irr)
         self.offsite_hamiltonian_network = HamLayer(irreps_in_edge, irr)
         if soc_switch:
@@ -426,12 +452,67 @@ class HamGNNPlusPlusOut(nn.Module):
             out += [a, b]
         return torch.cat(out, 0)
 
+    def su2_get_H(self, net_out):
+        """E3TensorDecomposition.get_H, spinful (tensor_decomposition.py:553-603): complex [Z, 4, nao, nao]."""
+        half = net_out.shape[-1] // 2
+        c = torch.complex(net_out[:, :half], net_out[:, half:])
+        Z, n = c.shape[0], self.nao_max
+        s2 = math.sqrt(2.0)
+        spin = torch.tensor([[1, 0, 1, 0], [0, -1j, 0, 1], [0, 1j, 0, 1], [1, 0, -1, 0]], dtype=c.dtype) / s2
+        H = c.new_zeros(Z, 4, n, n)
+        off, r0 = 0, 0
+        for _, li in self.row:
+            c0 = 0
+            for _, lj in self.col:
+                Ls = list(range(abs(li.l - lj.l), li.l + lj.l + 1))
+                m = li.dim * lj.dim
+                cols = [c[:, off:off + m].unsqueeze(-1)]                                   # n = 0: the spin-scalar part
+                o2 = off + m
+                vec = []
+                for L in Ls:                                                               # n = 1..3: (L x 1) -> L
+                    Lp = list(range(abs(L - 1), L + 2))
+                    w = torch.cat([e3.wigner_3j(L, 1, l2, dtype=net_out.dtype) for l2 in Lp], dim=-1).to(c.dtype)
+                    d = sum(2 * l2 + 1 for l2 in Lp)
+                    vec.append(torch.einsum("jkl,il->ijk", w, c[:, o2:o2 + d]))
+                    o2 += d
+                Hb = torch.cat([cols[0], torch.cat(vec, dim=-2)], dim=-1)                     # [Z, m, 4]
+                wm = torch.cat([e3.wigner_3j(li.l, lj.l, L, dtype=net_out.dtype) for L in Ls], dim=-1).to(c.dtype)
+                H[:, :, r0:r0 + li.dim, c0:c0 + lj.dim] += torch.einsum("imn,klm,jn->ijkl", Hb, wm, spin)
+                off = o2
+                c0 += lj.dim
+            r0 += li.dim
+        return H
+
+    def forward_su2(self, data, rep, inv):
+        """SOC / su2 branch (hamgnn_output.py:3146-3178, 3603-3625)."""
+        n = self.nao_max
+
+        def block(net, x, inv_):
+            H = self.su2_get_H(net(x))                                                     # [Z, 4, n, n]
+            H = self.reorder_matrix(H.reshape(-1, n * n)).reshape(-1, 2, 2, n, n).swapaxes(2, 3).reshape(-1, 2 * n, 2 * n)
+            if self.symmetrize:
+                H = 0.5 * (H + (H if inv_ is None else H[inv_]).conj().transpose(1, 2))
+            return H.reshape(-1, 2, n, 2, n)
+
+        on, off = block(self.onsite_hamiltonian_network, rep["node_attr"], None), block(self.offsite_hamiltonian_network, rep["edge_attr"], inv)
+        m_on, m_off = self.orbital_mask(data.z, data.edge_index)
+        m_on, m_off = m_on.reshape(-1, 1, n, 1, n).to(on.real.dtype), m_off.reshape(-1, 1, n, 1, n).to(on.real.dtype)
+        on, off = (on * m_on).reshape(-1, 4 * n * n), (off * m_off).reshape(-1, 4 * n * n)
+        on_r, on_i, off_r, off_i = on.real, on.imag, off.real, off.imag
+        if self.add_H0:
+            on_r, off_r = on_r + data.Hon0, off_r + data.Hoff0
+            on_i, off_i = on_i + data.iHon0, off_i + data.iHoff0
+        Hr, Hi = self.cat_by_crystal(data, on_r, off_r), self.cat_by_crystal(data, on_i, off_i)
+        return {"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi}
+
     def forward(self, data, rep):
         node_attr, edge_attr = rep["node_attr"], rep["edge_attr"]
         for Z in data.z.unique().tolist():
             if Z not in self.basis_def:
                 raise ValueError(f"element Z={Z} missing from basis_def")
         inv = self.global_inverse_edges(data)
+        if self.soc_switch and self.soc_basis == "su2":
+            return self.forward_su2(data, rep, inv)
         on = self._sym(self.reorder_matrix(self.merge_tensor_components(self.onsite_hamiltonian_network(node_attr))))
         off = self._sym(self.reorder_matrix(self.merge_tensor_components(self.offsite_hamiltonian_network(edge_attr))), inv)
         m_on, m_off = self.orbital_mask(data.z, data.edge_index)

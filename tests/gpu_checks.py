@@ -52,7 +52,7 @@ def check_geometry(device="cuda"):
     """edge frames + radial basis vs host float64 reference implementations."""
     from hamgnn_amd import ops, plan as P, so3
     rng = np.random.default_rng(0)
-    E, lmax, R, rc = 257, 6, 64, 26.0
+    E, lmax, R, rc = 257, 7, 64, 26.0
     v = rng.normal(size=(E, 3)) * 5.0
     v[0] = (0, 0, 3.0)          # pole
     v[1] = (0, 0, -3.0)         # anti-pole
@@ -154,6 +154,49 @@ def check_head_soc(device="cuda"):
     torch.cuda.synchronize()
     return {"soc_real_rel_err": rel(out["hamiltonian_real"], f["outputs"]["hamiltonian_real"]),
             "soc_imag_rel_err": rel(out["hamiltonian_imag"], f["outputs"]["hamiltonian_imag"])}
+
+
+def check_head_su2(device="cuda"):
+    """SOC / su2 head (E3TensorDecomposition.get_H): reference fixture (abacus nao 13) + a random-weight run on irreps up to
+    l = 5 so that every L x 1 -> L' coefficient is populated and un-rotated (vs the fp64 oracle, no H0)."""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load("head_soc_su2_abacus_13")
+    m = load_weights(HamGNNPlusPlusOut(MINI, MINI, nao_max=13, ham_type="abacus", ham_only=True, symmetrize=True, add_H0=True,
+                                       soc_switch=True, calculate_sparsity=False), f["weights"])
+    assert m.soc_basis == "su2"
+    bb = load("backbone")["graph"]
+    gd = dict(f["graph"])
+    for k in ("pos", "nbr_shift", "cell"):
+        gd[k] = bb[k]
+    g = to_graph(gd, device)
+    rep = {"node_attr": torch.from_numpy(f["inputs"]["node_attr"]).float().to(device),
+           "edge_attr": torch.from_numpy(f["inputs"]["edge_attr"]).float().to(device)}
+    out = m(g, rep)
+    torch.cuda.synchronize()
+    res = {"su2_real_rel_err": rel(out["hamiltonian_real"], f["outputs"]["hamiltonian_real"]),
+           "su2_imag_rel_err": rel(out["hamiltonian_imag"], f["outputs"]["hamiltonian_imag"])}
+    rich = "8x0e+8x0o+4x1e+4x1o+4x2e+4x2o+2x3e+2x3o+2x4e+2x4o+2x5e+2x5o"
+    torch.manual_seed(5)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.HamGNNPlusPlusOut(rich, rich, nao_max=13, ham_type="siesta", symmetrize=True, add_H0=False, soc_switch=True)
+    finally:
+        torch.set_default_dtype(prev)
+    hip = load_weights(HamGNNPlusPlusOut(rich, rich, nao_max=13, ham_type="siesta", ham_only=True, symmetrize=True, add_H0=False,
+                                         soc_switch=True, calculate_sparsity=False), dict(ref.state_dict()))
+    D = R.Irreps(rich).dim
+    gen = torch.Generator().manual_seed(6)
+    na, ea = torch.randn(len(gd["z"]), D, generator=gen, dtype=torch.float64), torch.randn(gd["edge_index"].shape[1], D, generator=gen, dtype=torch.float64)
+    g64 = to_graph(gd, "cpu", torch.float64)
+    with torch.no_grad():
+        o_ref = ref(g64, {"node_attr": na, "edge_attr": ea})
+        o = hip(g, {"node_attr": na.float().to(device), "edge_attr": ea.float().to(device)})
+    torch.cuda.synchronize()
+    res.update({"su2_rich_real_rel_err": rel(o["hamiltonian_real"], o_ref["hamiltonian_real"]),
+                "su2_rich_imag_rel_err": rel(o["hamiltonian_imag"], o_ref["hamiltonian_imag"])})
+    return res
 
 
 def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, nao=19, num_layers=2, radial=(16, 16), num_radial=8,

@@ -52,6 +52,12 @@ def test_head_soc_so3_golden():
     assert r["soc_real_rel_err"] < G.TOL and r["soc_imag_rel_err"] < G.TOL
 
 
+def test_head_soc_su2():
+    r = G.check_head_su2()
+    print(r)
+    assert all(v < G.TOL for v in r.values()), r
+
+
 def test_sharded_two_rank_forward_matches_single_rank():
     """2 ranks (gloo) sharing cuda:0: pair-sharded edges + all-reduce of node aggregates == unsharded forward."""
     import os, subprocess, sys

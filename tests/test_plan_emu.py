@@ -117,3 +117,61 @@ def test_message_pack_lite_program_vs_golden(golden_dir):
     prog = P.build_message_pack_program_lite(sd, MINI, MINI, SH, MINI, unrotate=True)
     outp = emu.run_program(prog, [xs, xd, fe], (h, None), D, 3)
     assert rel(lay.from_planar(outp), f["outputs"]["out"]) < 1e-6
+
+
+def _merge_emu(yp, slot_tab, ptr, idx, val):
+    """numpy twin of ham_merge_kernel without rotation (hamgnn_amd/csrc/head.hip)."""
+    coef = np.stack([yp[:, b + a * st] for (_, a, b, st) in slot_tab], axis=1)
+    out = np.zeros((yp.shape[0], len(ptr) - 1))
+    for q in range(len(ptr) - 1):
+        sl = slice(ptr[q], ptr[q + 1])
+        out[:, q] = coef[:, idx[sl]] @ val[sl].astype(np.float64)
+    return out
+
+
+@pytest.mark.parametrize("ham_type,nao", [("openmx", 19), ("abacus", 13)])
+def test_head_linear_and_merge_tables(ham_type, nao):
+    """HamLayer.linear_transform regrouped by (L,p) + merge_tensor_components + reorder_matrix tables vs the oracle."""
+    import torch
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import basis as B
+    torch.manual_seed(0)
+    ref = R.HamGNNPlusPlusOut(MINI, MINI, nao_max=nao, ham_type=ham_type).double()
+    t = B.basis_table(ham_type, nao)
+    row = so3.Irreps(t["row"])
+    hirr = P.ham_irreps(row)
+    W = ref.onsite_hamiltonian_network.linear_transform.weight.detach().numpy()
+    prog, girr, slot_pos = P.build_ham_linear_program(W, MINI, hirr)
+    x = np.random.default_rng(0).standard_normal((5, so3.Irreps(MINI).dim))
+    yp = emu.run_program(prog, [P.PlanarLayout(MINI).to_planar(x)])
+    tabs = P.ham_merge_tables(row, nao, t["index_change"], t["minus_index"], girr, slot_pos)
+    got = _merge_emu(yp, *tabs)
+    want = ref.reorder_matrix(ref.merge_tensor_components(ref.onsite_hamiltonian_network.linear_transform(torch.from_numpy(x))))
+    assert rel(got, want.detach().numpy()) < 1e-6
+
+
+def test_head_su2_tables():
+    """su2: only copies 0/2 of the 4 x required irreps are computed; merge table == get_H + reorder + spin interleave."""
+    import torch
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import basis as B
+    nao, ham_type = 13, "abacus"
+    torch.manual_seed(1)
+    ref = R.HamGNNPlusPlusOut(MINI, MINI, nao_max=nao, ham_type=ham_type, soc_switch=True).double()
+    t = B.basis_table(ham_type, nao)
+    row = so3.Irreps(t["row"])
+    half = P.su2_irreps(row)
+    S = len(half)
+    full = so3.Irreps(list(half) * 4)
+    assert str(full) == str(so3.Irreps(str(ref.onsite_hamiltonian_network.linear_transform.irreps_out)))
+    W = ref.onsite_hamiltonian_network.linear_transform.weight.detach().numpy()
+    keep = [(s // S) in (0, 2) for s in range(4 * S)]
+    prog, girr, slot_pos = P.build_ham_linear_program(W, MINI, full, keep)
+    x = np.random.default_rng(1).standard_normal((4, so3.Irreps(MINI).dim))
+    yp = emu.run_program(prog, [P.PlanarLayout(MINI).to_planar(x)])
+    tabs = P.su2_merge_tables(row, nao, t["index_change"], t["minus_index"], girr, slot_pos)
+    got = _merge_emu(yp, *tabs)
+    H = ref.su2_get_H(ref.onsite_hamiltonian_network.linear_transform(torch.from_numpy(x)))
+    H = ref.reorder_matrix(H.reshape(-1, nao * nao)).reshape(-1, 2, 2, nao, nao).swapaxes(2, 3).reshape(-1, 4 * nao * nao)
+    want = torch.cat([H.real, H.imag], 1).detach().numpy()
+    assert rel(got, want) < 1e-6
