@@ -149,3 +149,72 @@ extern "C" int hg_soc_assemble(const float* H, const float* ksi, const float* L,
     soc_assemble_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(H, ksi, L, inv, H0r, H0i, nao, symmetrize, zero_diag, out_real, out_imag);
     return hg_check_launch("hg_soc_assemble");
 }
+
+// ------------------------------------------------------------------------------------------------ zero-point shift (a17)
+// hamgnn_output.py:3971-3981 (non-SOC) / :3892-3913 (SOC, spin-diagonal real blocks):
+//   dE = sum_{S > thr} (H - Href) / sum_{S > thr} S ;  H -= dE * S          (one dE per batch, fp64 accumulation)
+// SOC (soc != 0): H, Href are [(2 nao)^2] rows, S is [nao^2]; the difference is (uu + dd) - (uu_ref + dd_ref), the
+// denominator 2 sum S, and both spin-diagonal blocks are shifted.
+__device__ __forceinline__ int64_t zp_index(int64_t i, int nao, int soc, int blk) {
+    if (!soc) return i;
+    const int64_t n2 = (int64_t)nao * nao, row = i / n2;
+    const int q = (int)(i - row * n2), a = q / nao, b = q - a * nao;
+    return row * 4 * n2 + (int64_t)(blk * nao + a) * (2 * nao) + blk * nao + b;
+}
+
+__global__ __launch_bounds__(256) void zp_partial_kernel(const float* __restrict__ H, const float* __restrict__ Href,
+                                                         const float* __restrict__ S, int64_t count, int nao, int soc, float thr,
+                                                         double* __restrict__ partial) {
+    __shared__ double sn[256], sd[256];
+    double num = 0.0, den = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = S[i];
+        if (s > thr) {
+            const int64_t i0 = zp_index(i, nao, soc, 0);
+            double d = (double)H[i0] - (double)Href[i0];
+            if (soc) {
+                const int64_t i1 = zp_index(i, nao, soc, 1);
+                d += (double)H[i1] - (double)Href[i1];
+            }
+            num += d;
+            den += (double)s;
+        }
+    }
+    sn[threadIdx.x] = num; sd[threadIdx.x] = den;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { sn[threadIdx.x] += sn[threadIdx.x + w]; sd[threadIdx.x] += sd[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = sn[0]; partial[2 * blockIdx.x + 1] = sd[0]; }
+}
+
+__global__ __launch_bounds__(256) void zp_apply_kernel(float* __restrict__ H, const float* __restrict__ S, int64_t count, int nao, int soc,
+                                                       const double* __restrict__ partial, int nparts, float* __restrict__ shift_out) {
+    __shared__ double sh_shift;
+    if (threadIdx.x == 0) {                                     // fixed-order reduction of the block partials: deterministic
+        double num = 0.0, den = 0.0;
+        for (int p = 0; p < nparts; ++p) { num += partial[2 * p]; den += partial[2 * p + 1]; }
+        sh_shift = num / (soc ? 2.0 * den : den);
+        if (blockIdx.x == 0 && shift_out) *shift_out = (float)sh_shift;
+    }
+    __syncthreads();
+    const float dE = (float)sh_shift;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = S[i];
+        const int64_t i0 = zp_index(i, nao, soc, 0);
+        H[i0] -= dE * s;
+        if (soc) { const int64_t i1 = zp_index(i, nao, soc, 1); H[i1] -= dE * s; }
+    }
+}
+
+extern "C" int hg_zero_point_shift(float* H, const float* Href, const float* S, int64_t rows, int nao, int soc, float threshold,
+                                   double* partial_scratch, int nparts, float* shift_out, void* stream) {
+    if (rows <= 0) return 0;
+    if (nparts <= 0 || nparts > 1024) return hg_fail(-2, "hg_zero_point_shift: scratch must hold 1..1024 partial pairs");
+    const int64_t count = rows * nao * nao;
+    zp_partial_kernel<<<dim3((unsigned)nparts), 256, 0, (hipStream_t)stream>>>(H, Href, S, count, nao, soc, threshold, partial_scratch);
+    const unsigned grid = (unsigned)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    zp_apply_kernel<<<dim3(grid), 256, 0, (hipStream_t)stream>>>(H, S, count, nao, soc, partial_scratch, nparts, shift_out);
+    return hg_check_launch("hg_zero_point_shift");
+}

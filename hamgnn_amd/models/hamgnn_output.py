@@ -36,7 +36,7 @@ class HamGNNPlusPlusOut(nn.Module):
         self.calculate_sparsity = calculate_sparsity
         for flag, name in ((return_forces, "return_forces"), (calculate_band_energy, "calculate_band_energy"),
                            (spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
-                           (export_reciprocal_values, "export_reciprocal_values"), (zero_point_shift, "zero_point_shift"),
+                           (export_reciprocal_values, "export_reciprocal_values"),
                            (get_nonzero_mask_tensor, "get_nonzero_mask_tensor"), (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
             if flag:
                 raise NotImplementedError(f"HamGNNPlusPlusOut({name}) is outside the MI355X hot-path scope of this round")
@@ -140,6 +140,17 @@ class HamGNNPlusPlusOut(nn.Module):
             out += [a, b]
         return torch.cat(out, 0)
 
+    def _apply_zero_point_shift(self, data, H, edge_counts, soc):
+        """hamgnn_output.py:3971-3981 / :3892-3913; targets as the reference prepares them (:2975-2978, :3617-3618)."""
+        f32c = lambda t: t.contiguous().float()
+        S = data["overlap"] if "overlap" in data else self._cat_by_crystal(data, data.Son, data.Soff, edge_counts)
+        if not soc and "hamiltonian" in data:
+            Href = data["hamiltonian"]
+        else:
+            Href = self._cat_by_crystal(data, data.Hon, data.Hoff, edge_counts)
+        ops.zero_point_shift(H, f32c(Href), f32c(S), self.nao_max, soc)
+        return H
+
     def calculate_sparsity_ratio(self, data):
         z = data.z
         n2 = self.nao_max ** 2
@@ -195,6 +206,8 @@ class HamGNNPlusPlusOut(nn.Module):
             off_r, off_i = fin(raw_off, 0, inv, H0[1], geo.src, geo.dst), fin(raw_off, 1, inv, H0[3], geo.src, geo.dst)
             Hr = self._cat_by_crystal(data, on_r, off_r, edge_counts)
             Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
+            if self.zero_point_shift:
+                Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
             result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
                            "wavefunction": None})
             if self.calculate_sparsity:
@@ -213,6 +226,8 @@ class HamGNNPlusPlusOut(nn.Module):
             off_r, off_i = ops.soc_assemble(off, ksi_off, f32c(data.Loff), inv, H0[1], H0[3], n, self.symmetrize, self.add_H_nonsoc)
             Hr = self._cat_by_crystal(data, on_r, off_r, edge_counts)
             Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
+            if self.zero_point_shift:
+                Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
             result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
                            "wavefunction": None})
             if self.calculate_sparsity:
@@ -221,8 +236,10 @@ class HamGNNPlusPlusOut(nn.Module):
         H0_on = f32c(data.Hon0) if self.add_H0 else None
         H0_off = f32c(data.Hoff0) if self.add_H0 else None
         on, off = self._blocks(self.onsite_hamiltonian_network, self.offsite_hamiltonian_network, node_pl, edge_rot, geo, data, inv, H0_on, H0_off)
-        result.update({"hamiltonian": self._cat_by_crystal(data, on, off, edge_counts), "band_energy": None, "wavefunction": None,
-                       "band_gap": None, "H_sym": None})
+        H = self._cat_by_crystal(data, on, off, edge_counts)
+        if self.zero_point_shift:
+            H = self._apply_zero_point_shift(data, H, edge_counts, False)
+        result.update({"hamiltonian": H, "band_energy": None, "wavefunction": None, "band_gap": None, "H_sym": None})
         if self.calculate_sparsity:
             result["sparsity_ratio"] = self.calculate_sparsity_ratio(data)
         return result

@@ -207,3 +207,15 @@ def soc_assemble(H, ksi, L, inv, H0r, H0i, nao, symmetrize=True, zero_diag=False
     check(lib().hg_soc_assemble(ptr(H), ptr(ksi), ptr(L), ptr(inv), ptr(H0r), ptr(H0i), i32(nao), i32(1 if symmetrize else 0),
                                 i32(1 if zero_diag else 0), i64(rows), ptr(outr), ptr(outi), _stream()), "hg_soc_assemble")
     return outr, outi
+
+
+def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
+    """in place on H; returns the shift (device scalar)."""
+    _require_gpu(H)
+    rows = S.shape[0]
+    nparts = 256
+    scratch = torch.empty(2 * nparts, device=H.device, dtype=torch.float64)
+    shift = torch.empty(1, device=H.device, dtype=torch.float32)
+    check(lib().hg_zero_point_shift(ptr(H), ptr(Href), ptr(S), i64(rows), i32(nao), i32(1 if soc else 0), f32(threshold), ptr(scratch),
+                                    i32(nparts), ptr(shift), _stream()), "hg_zero_point_shift")
+    return shift

@@ -105,6 +105,13 @@ int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t* inv, const
                   const int64_t* z, const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int flags, int64_t rows,
                   float* H, void* stream);
 
+/* zero-point energy shift (hamgnn_output.py:3971-3981; SOC spin-diagonal real blocks :3892-3913), in place:
+ *   dE = sum_{S>thr}(H - Href) / sum_{S>thr} S ;  H -= dE * S    -- one dE per call (= per batch, as the reference).
+ * soc != 0: H/Href rows are (2 nao)^2, S rows nao^2; (uu+dd) differences, denominator 2 sum S, both diagonal blocks shifted.
+ * partial_scratch: 2*nparts doubles of caller scratch (fixed-order two-stage reduction => deterministic).              */
+int hg_zero_point_shift(float* H, const float* Href, const float* S, int64_t rows, int nao, int soc, float threshold,
+                        double* partial_scratch, int nparts, float* shift_out, void* stream);
+
 /* SOC / so3 branch (hamgnn_output.py:3026-3144).  hg_block_mean = symmetrize_orbital_coefficients (:2367-2431): each element
  * of the nao x nao xi matrix -> mean over its (row shell, col shell) block; tab int32[nao^2][4] = {r0, r1, c0, c1}.          */
 int hg_block_mean(const float* x, int64_t x_stride, const int32_t* tab, int nao, int64_t rows, float* out, void* stream);

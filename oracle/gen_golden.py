@@ -381,6 +381,9 @@ def main():
         out_mine = mine(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})
         _check(out_mine["hamiltonian"], out_ref["hamiltonian"], f"head {ham_type} nao={nao} hamiltonian")
         assert str(ref.hamiltonian_irreps) == str(mine.hamiltonian_irreps)
+        ref.zero_point_shift = mine.zero_point_shift = True                      # :3971-3981
+        _check(mine(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"],
+               ref(Graph(Gh), {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"], f"head {ham_type} nao={nao} zero_point_shift")
         if (ham_type, nao) in (("openmx", 19), ("abacus", 13)):
             _save(f"head_{ham_type}_{nao}", weights=sd, graph={k: Gh[k] for k in ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0")},
                   inputs=dict(node_attr=node_attr, edge_attr=edge_attr), outputs=dict(hamiltonian=out_ref["hamiltonian"]))
@@ -411,6 +414,10 @@ def main():
         _check(out_mine["hamiltonian_real"], out_ref["hamiltonian_real"], f"head SOC so3 add_H_nonsoc={nonsoc} real")
         _check(out_mine["hamiltonian_imag"], out_ref["hamiltonian_imag"], f"head SOC so3 add_H_nonsoc={nonsoc} imag")
         if not nonsoc:
+            ref.zero_point_shift = mine.zero_point_shift = True                  # :3892-3913
+            gin = Graph({k: (v.clone() if torch.is_tensor(v) else v) for k, v in Gs.items()})
+            _check(mine(Gs, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian_real"],
+                   ref(gin, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian_real"], "head SOC so3 zero_point_shift real")
             keys = ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0", "iHon0", "iHoff0", "Lon", "Loff")
             _save("head_soc_so3_openmx_19", weights=sd, graph={k: Gs[k] for k in keys}, inputs=dict(node_attr=node_attr, edge_attr=edge_attr),
                   outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"], hamiltonian_imag=out_ref["hamiltonian_imag"]))
@@ -437,6 +444,10 @@ def main():
         out_mine = mine(Gu, {"node_attr": node_attr, "edge_attr": edge_attr})
         _check(out_mine["hamiltonian_real"], out_ref["hamiltonian_real"], f"head SOC su2 {ham_type} nao={nao} real")
         _check(out_mine["hamiltonian_imag"], out_ref["hamiltonian_imag"], f"head SOC su2 {ham_type} nao={nao} imag")
+        ref.zero_point_shift = mine.zero_point_shift = True
+        gin = Graph({k: (v.clone() if torch.is_tensor(v) else v) for k, v in Gu.items()})
+        _check(mine(Gu, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian_real"],
+               ref(gin, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian_real"], f"head SOC su2 {ham_type} zero_point_shift real")
         if (ham_type, nao) == ("abacus", 13):
             keys = ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0", "iHon0", "iHoff0")
             _save("head_soc_su2_abacus_13", weights=sd, graph={k: Gu[k] for k in keys}, inputs=dict(node_attr=node_attr, edge_attr=edge_attr),

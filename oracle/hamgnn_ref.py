@@ -452,6 +452,19 @@ class HamGNNPlusPlusOut(nn.Module):
             out += [a, b]
         return torch.cat(out, 0)
 
+    def soc_zero_point(self, data, Hr):
+        """zero_point_shift of the non-collinear branches (hamgnn_output.py:3892-3913): spin-diagonal real blocks."""
+        n = self.nao_max
+        S = self.cat_by_crystal(data, data.Son, data.Soff).reshape(-1, n, n)
+        H5 = Hr.reshape(-1, 2, n, 2, n).clone()
+        R5 = self.cat_by_crystal(data, data.Hon, data.Hoff).reshape(-1, 2, n, 2, n)
+        diff = (H5[:, 0, :, 0, :] + H5[:, 1, :, 1, :]) - (R5[:, 0, :, 0, :] + R5[:, 1, :, 1, :])
+        sel = S > 1e-6
+        dE = diff[sel].sum() / (2.0 * S[sel].sum())
+        H5[:, 0, :, 0, :] -= dE * S
+        H5[:, 1, :, 1, :] -= dE * S
+        return H5.reshape(-1, 4 * n * n)
+
     def su2_get_H(self, net_out):
         """E3TensorDecomposition.get_H, spinful (tensor_decomposition.py:553-603): complex [Z, 4, nao, nao]."""
         half = net_out.shape[-1] // 2
@@ -503,6 +516,8 @@ class HamGNNPlusPlusOut(nn.Module):
             on_r, off_r = on_r + data.Hon0, off_r + data.Hoff0
             on_i, off_i = on_i + data.iHon0, off_i + data.iHoff0
         Hr, Hi = self.cat_by_crystal(data, on_r, off_r), self.cat_by_crystal(data, on_i, off_i)
+        if self.zero_point_shift:
+            Hr = self.soc_zero_point(data, Hr)
         return {"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi}
 
     def forward(self, data, rep):
@@ -566,4 +581,6 @@ class HamGNNPlusPlusOut(nn.Module):
             on_r, off_r = on_r + Hon0, off_r + Hoff0
             on_i, off_i = on_i + data.iHon0, off_i + data.iHoff0
         Hr, Hi = self.cat_by_crystal(data, on_r, off_r), self.cat_by_crystal(data, on_i, off_i)
+        if self.zero_point_shift:
+            Hr = self.soc_zero_point(data, Hr)
         return {"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi}

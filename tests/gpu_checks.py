@@ -156,6 +156,42 @@ def check_head_soc(device="cuda"):
             "soc_imag_rel_err": rel(out["hamiltonian_imag"], f["outputs"]["hamiltonian_imag"])}
 
 
+def check_zero_point_shift(device="cuda"):
+    """zero_point_shift (hamgnn_output.py:3971-3981, SOC :3892-3913; pinned oracle-vs-reference in oracle/gen_golden.py):
+    fixture weights + seeded random targets, HIP fp32 vs oracle fp64; non-SOC (openmx 19) and SOC su2 (abacus 13)."""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    res = {}
+    bb = load("backbone")["graph"]
+    for name, ham_type, nao, soc in (("head_openmx_19", "openmx", 19, False), ("head_soc_su2_abacus_13", "abacus", 13, True)):
+        f = load(name)
+        gd = dict(f["graph"])
+        for k in ("pos", "nbr_shift", "cell"):
+            gd[k] = bb[k]
+        N, E = len(gd["z"]), gd["edge_index"].shape[1]
+        gen = torch.Generator().manual_seed(11)
+        w = (4 if soc else 1) * nao * nao
+        for k, n, width in (("Hon", N, w), ("Hoff", E, w), ("Son", N, nao * nao), ("Soff", E, nao * nao)):
+            gd[k] = (0.3 * torch.randn(n, width, generator=gen, dtype=torch.float64)).numpy()
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            ref = R.HamGNNPlusPlusOut(MINI, MINI, nao_max=nao, ham_type=ham_type, symmetrize=True, add_H0=True, soc_switch=soc, zero_point_shift=True)
+        finally:
+            torch.set_default_dtype(prev)
+        ref.load_state_dict({k: torch.as_tensor(v) for k, v in f["weights"].items()}, strict=False)
+        m = load_weights(HamGNNPlusPlusOut(MINI, MINI, nao_max=nao, ham_type=ham_type, ham_only=True, symmetrize=True, add_H0=True,
+                                           soc_switch=soc, zero_point_shift=True, calculate_sparsity=False), f["weights"])
+        key = "hamiltonian_real" if soc else "hamiltonian"
+        with torch.no_grad():
+            o_ref = ref(to_graph(gd, "cpu", torch.float64), {k: torch.from_numpy(v) for k, v in f["inputs"].items()})[key]
+            o = m(to_graph(gd, device), {k: torch.from_numpy(v).float().to(device) for k, v in f["inputs"].items()})[key]
+        torch.cuda.synchronize()
+        res[("soc_" if soc else "") + "zero_point_rel_err"] = rel(o, o_ref)
+        res[("soc_" if soc else "") + "shift_effect"] = rel(torch.as_tensor(f["outputs"][key]), o_ref)     # must be far from 0
+    return res
+
+
 def check_head_su2(device="cuda"):
     """SOC / su2 head (E3TensorDecomposition.get_H): reference fixture (abacus nao 13) + a random-weight run on irreps up to
     l = 5 so that every L x 1 -> L' coefficient is populated and un-rotated (vs the fp64 oracle, no H0)."""

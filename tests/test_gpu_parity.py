@@ -52,6 +52,13 @@ def test_head_soc_so3_golden():
     assert r["soc_real_rel_err"] < G.TOL and r["soc_imag_rel_err"] < G.TOL
 
 
+def test_zero_point_shift():
+    r = G.check_zero_point_shift()
+    print(r)
+    assert r["zero_point_rel_err"] < G.TOL and r["soc_zero_point_rel_err"] < G.TOL
+    assert r["shift_effect"] > 1e-3 and r["soc_shift_effect"] > 1e-3
+
+
 def test_head_soc_su2():
     r = G.check_head_su2()
     print(r)
