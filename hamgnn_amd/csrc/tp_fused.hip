@@ -52,6 +52,8 @@ __device__ __forceinline__ int64_t pick_stride(const TpArgs& A, int i) {
     return i == 0 ? A.sstride[0] : (i == 1 ? A.sstride[1] : (i == 2 ? A.sstride[2] : A.sstride[3]));
 }
 
+// ablation hooks (timing experiments only, tests/build_variants.sh): HG_SINK keeps a value alive without using it
+#define HG_SINK(v) asm volatile("" ::"v"(v))
 #ifdef HG_ABL_NOA
 #define HG_LDA(p) ((f32x4){.1f, .2f, .3f, .4f})
 #else
@@ -88,7 +90,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
     constexpr int NC = 2 * MM + 1;
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], s0 = it[1], s1 = it[2], in_off = it[3], in_mulp = it[4], li = it[5], neg = it[7];
-    const int ksteps = it[8], mlp = it[10], x4 = it[17];
+    const int ksteps = it[8], mlp = it[10], x4 = it[17], nk2 = it[18];
     const int g = lane >> 4, el = lane & 15;
 
     f32x4 mid[RTM][NC];
@@ -106,7 +108,11 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
     // per column bumped by a constant (the r1 ISA audit of the previous swizzled image showed 241 instructions per 14 MFMAs
     // in this loop -- issue-bound on address arithmetic, not memory-bound).  ds_read_b128 of 16 rows is conflict-free, the
     // dword reads of x1 mode are 2-way.
+#ifdef HG_ABL_NOG1
+    const int nsrc = 0;
+#else
     const int nsrc = s1 >= 0 ? 2 : 1;
+#endif
     const int ngrp = (ksteps + 3) >> 2;
     const int P1 = in_mulp >> 2;                               // float4 pieces per column
     const int P = NC * P1;                                     // pieces per row span (planner guarantees P <= 40)
@@ -203,8 +209,13 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);                      // GEMM2 operands of rtp = 0, early
 #endif
+#ifdef HG_ABL_NOSCALE
+        const int hgrp_run = 1;
+#else
+        const int hgrp_run = hgrp;
+#endif
 #pragma unroll 1
-        for (int G = 0; G < hgrp; ++G) {
+        for (int G = 0; G < hgrp_run; ++G) {
             const f32x4 hb = hb_n;
             f32x4 wv[RTM];
 #pragma unroll
@@ -224,14 +235,28 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);
 #endif
         const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(Wb + it[13]) + g;     // [rt][c][g] float4
+#ifdef HG_ABL_NOSCALEMUL
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) HG_SINK(S[rt]);
+#else
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NC + c) * 4];
+#endif
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
+#ifdef HG_ABL_NOG2
+        const int rto_run = 0;
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) HG_SINK(mid[rt][c]);
+#else
+        const int rto_run = rto;
+#endif
 #pragma unroll 1
-        for (int rtp = 0; rtp < rto; ++rtp) {
+        for (int rtp = 0; rtp < rto_run; ++rtp) {
             f32x4 av[RTM];
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) av[rt] = a2_n[rt];
@@ -255,15 +280,21 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
+                        if (4 * rt + r < nk2) {                // trailing K-steps hold only padding rows (planner row order): not issued
 #pragma unroll
-                        for (int c = 0; c < CW; ++c)
-                            if (c0 + c < NC)
-                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c0 + c][r], acc[c], 0, 0, 0);
+                            for (int c = 0; c < CW; ++c)
+                                if (c0 + c < NC)
+                                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c0 + c][r], acc[c], 0, 0, 0);
+                        }
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
+#ifdef HG_ABL_NOWB
+                        HG_SINK(acc[c]);
+#else
 #pragma unroll
                         for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] += acc[c][r];
+#endif
                     }
             }
         }
@@ -367,29 +398,46 @@ __device__ __forceinline__ void post_item(const TpArgs& A, const float* __restri
 }
 
 template <int LK>
-__device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restrict__ tile, int rowstride, int mul_k,
+__device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restrict__ tile, float* __restrict__ stage, int rowstride, int mul_k,
                                          int out_off, int out_mulp, int flags, int64_t e, int64_t erow, bool valid, int lane) {
     constexpr int NCO = 2 * LK + 1;
     const int g = lane >> 4, el = lane & 15;
-    const float* __restrict__ D = A.wig ? A.wig + erow * A.nW + A.wig_off[LK] : nullptr;
+    const float* __restrict__ tl = tile + el;
+    float* __restrict__ ob = A.out + e * A.ostride + out_off;
+    if (flags & SEG_UNROTATE) {
+        // out[w, a] = sum_m D^l(R_e)[m, a] tile[w, m].  The 16 Wigner blocks of the wave are pulled into the (idle) B-operand
+        // ring by LDS-DMA, image [m * NCO + a][edge]: ONE exposed memory latency per segment (the r1 ablations showed per-column
+        // global loads costing 0.6-0.75 of 10 ms: ~50 exposed L2/HBM latencies per wave), conflict-free broadcast reads after.
+        const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[LK];
+        constexpr int NJ = (NCO * NCO + 3) / 4;
 #pragma unroll 1
-    for (int w = g; w < mul_k; w += 4) {
-        float t[NCO];
+        for (int j = 0; j < NJ; ++j) {
+            int idx = 4 * j + g;
+            idx = idx < NCO * NCO ? idx : NCO * NCO - 1;
+            hg_dma4(D + idx, stage + j * 64);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float* __restrict__ dl = stage + el;
+#pragma unroll 1
+        for (int a = 0; a < NCO; ++a) {
+            float dc[NCO];
 #pragma unroll
-        for (int m = 0; m < NCO; ++m) t[m] = tile[w * rowstride + m * 16 + el];
-        float* __restrict__ o = A.out + e * A.ostride + out_off + w;
-        if (flags & SEG_UNROTATE) {
+            for (int m = 0; m < NCO; ++m) dc[m] = dl[(m * NCO + a) * 16];
 #pragma unroll 1
-            for (int a = 0; a < NCO; ++a) {
+            for (int w = g; w < mul_k; w += 4) {
+                const float* __restrict__ tw = tl + w * rowstride;
                 float acc = 0.f;
 #pragma unroll
-                for (int m = 0; m < NCO; ++m) acc = fmaf(D[m * NCO + a], t[m], acc);
-                if (valid) o[a * out_mulp] = acc;
+                for (int m = 0; m < NCO; ++m) acc = fmaf(dc[m], tw[m * 16], acc);
+                if (valid) ob[a * out_mulp + w] = acc;
             }
-        } else {
+        }
+    } else {
+#pragma unroll 1
+        for (int w = g; w < mul_k; w += 4) {
 #pragma unroll
             for (int a = 0; a < NCO; ++a)
-                if (valid) o[a * out_mulp] = t[a];
+                if (valid) ob[a * out_mulp + w] = tl[w * rowstride + a * 16];
         }
     }
 }
@@ -414,7 +462,9 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         const int nco = 2 * lk + 1;
         const int rowstride = nco * 16 + 4;
         const int tfl = (mul_k + 1) * rowstride;           // + trash row for padded fragment rows
+#ifndef HG_ABL_NOZERO
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
+#endif
         HG_WAVE_FENCE();
         for (int ii = ib; ii < ie; ++ii) {
             const int* __restrict__ it = g_items + ii * 20;
@@ -437,16 +487,18 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
             }
         }
         HG_WAVE_FENCE();
+#ifndef HG_ABL_NOEPI
         switch (lk) {
-            case 0: epilogue<0>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
-            case 1: epilogue<1>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
-            case 2: epilogue<2>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
-            case 3: epilogue<3>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
-            case 4: epilogue<4>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
-            case 5: epilogue<5>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
-            case 6: epilogue<6>(A, tile, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
+            case 0: epilogue<0>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
+            case 1: epilogue<1>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
+            case 2: epilogue<2>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
+            case 3: epilogue<3>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
+            case 4: epilogue<4>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
+            case 5: epilogue<5>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
+            case 6: epilogue<6>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
             default: break;
         }
+#endif
         HG_WAVE_FENCE();
     }
 }

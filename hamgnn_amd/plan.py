@@ -187,12 +187,13 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     return len(prog.segs) - 1
 
 
-def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0):
+def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0, nk2=None):
     assert len(srcs) in (1, 2)
+    nk2 = 4 * rtm if nk2 is None else nk2                      # GEMM2 K-steps actually issued (item[18])
     if (2 * mm + 1) * in_mulp > 160:
         raise NotImplementedError(f"input irrep block too wide for the kernel's B staging ring: (2*{mm}+1) x {in_mulp} channels > 160")
     rec = [typ, srcs[0], srcs[1] if len(srcs) == 2 else -1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp,
-           a1, w3, cf, a2, nrows, row_off, 1 if use_x4(in_mulp, 2 * mm + 1) else 0, 0, 0]
+           a1, w3, cf, a2, nrows, row_off, 1 if use_x4(in_mulp, 2 * mm + 1) else 0, nk2, 0]
     assert len(rec) == ITEM_I32
     prog.seg_items[seg].append(rec)
     nc = 2 * mm + 1
@@ -201,7 +202,7 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
     if typ == IT_POST:
         n = (prog.hidden_pad // 4) * rto + rto * rto * 4 * (2 * prog.segs[seg][0] + 1)
     if typ == IT_TP:
-        n += (prog.hidden_pad // 4) * rtm + rto * rtm * 4 * nc
+        n += (prog.hidden_pad // 4) * rtm + rto * nk2 * nc
     prog.mfma_per_wave += n
 
 
@@ -301,25 +302,35 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
             ksteps = in_layout.mulp[i] // 4
             for r0 in range(0, nrows, chunk):
                 r1 = min(nrows, r0 + chunk)
-                rtm = ceil_div(r1 - r0, 16)
+                n = r1 - r0
+                rtm = ceil_div(n, 16)
+                # physical row of logical row rho: within each 16-row tile the (g, r) index of the C fragment is transposed so
+                # that GEMM2's K-step (rt, r) -- which reads rows {16 rt + 4 g + r : g} -- holds logical rows 16 rt + 4 r + g:
+                # padding rows fill whole trailing K-steps and only ceil(n / 4) of the 4 rtm K-steps are issued (item[18])
+                rho = np.arange(n)
+                phys = 16 * (rho // 16) + 4 * (rho % 4) + (rho % 16) // 4
+                R = rtm * 16
                 a1 = []
                 x4 = use_x4(in_layout.mulp[i], nc)
                 for s_ in range(nsrc):
-                    Wk = rows_W[r0:r1, s_ * mi:(s_ + 1) * mi].T                      # [u, row]
+                    Wk = np.zeros((mi, R))
+                    Wk[:, phys] = rows_W[r0:r1, s_ * mi:(s_ + 1) * mi].T             # [u, physical row]
                     a1.append(_frag_A(Wk, ksteps, rtm, x4))
                 a1_off = prog.add_weights(np.stack(a1))
-                w3_off = prog.add_weights(_frag_A(w3[:, rows_ch[r0:r1]], prog.hidden_pad // 4, rtm, True))
-                cfp = np.zeros((rtm * 16, nc))
-                cfp[:r1 - r0] = rows_cf[r0:r1]
+                w3p = np.zeros((w3.shape[0], R))
+                w3p[:, phys] = w3[:, rows_ch[r0:r1]]
+                w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
+                cfp = np.zeros((R, nc))
+                cfp[phys] = rows_cf[r0:r1]
                 cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))       # [rt][c][g][r]
                 rto = prog.segs[seg][2]
-                Lp = np.zeros((rtm * 16, rto * 16))
-                Lp[:r1 - r0, :mk] = rows_L[r0:r1]
+                Lp = np.zeros((R, rto * 16))
+                Lp[phys, :mk] = rows_L[r0:r1]
                 # A2[rt'][rt][lane][r]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
                 a2 = Lp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4)
                 a2_off = prog.add_weights(a2)
                 _add_item(prog, seg, IT_TP, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, par, ksteps, rtm, mlp,
-                          a1_off, w3_off, cf_off, a2_off, r1 - r0)
+                          a1_off, w3_off, cf_off, a2_off, n, nk2=ceil_div(n, 4))
 
 
 def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, src: int, irreps_out: Irreps,

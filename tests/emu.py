@@ -127,6 +127,8 @@ def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64
                             acc = np.zeros((16, 16), dtype=dtype)
                             for rt in range(rtm):
                                 for r in range(4):
+                                    if 4 * rt + r >= int(it[18]):                                # K-steps of pure padding are not issued
+                                        continue
                                     Bm = mid[rt, c][r::4, :]                                     # rows 4k + r, k = 0..3
                                     acc += A2[rtp, rt, :, :, r].T @ Bm
                             tile[16 * rtp:16 * rtp + 16, lk - mm + c] += acc
