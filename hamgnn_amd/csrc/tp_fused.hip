@@ -84,9 +84,48 @@ __device__ __forceinline__ void hg_dma4(const float* __restrict__ gsrc, float* l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
 }
 
+// Tile write-back.  With HG_PREFETCH: an LDS store the compiler does not see.  SIInsertWaitcnts must assume that any LDS access it knows of aliases a pending LDS-DMA and
+// drains vmcnt in front of it -- which would turn the next item's freshly issued B-span DMAs into a full stall at the write-back.
+// (LDS executes one wave's instructions in order, so later reads of the tile still observe these stores.  DS_ADD_F32 was tried
+//  for the read-modify-write and is far slower: 23.6 vs 9.7 ms per launch.)
+__device__ __forceinline__ void lds_store(float* p, float v) {
+#ifdef HG_PREFETCH
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)p;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+#else
+    *p = v;
+#endif
+}
+
+// B-operand span of one (item, source): NC * mulp contiguous floats per edge row -> linear LDS image (see item_body).
+// Sources of a two-source item share the ring when both spans fit (slot = source index), else they take turns at offset 0.
+#define HG_RING_PIECES 44
+struct Span {                      // wave-uniform (SGPR) description of an item's B operand; s0 < 0: none
+    int s0, s1, in_off, in_mulp, li, mm;
+};
+__device__ __forceinline__ Span span_of(const int* __restrict__ it) { return Span{it[1], it[2], it[3], it[4], it[5], it[6]}; }
+__device__ __forceinline__ int span_nj(const Span& sp) { return ((2 * sp.mm + 1) * (sp.in_mulp >> 2) + 3) >> 2; }
+__device__ __forceinline__ bool span_both_fit(const Span& sp) { return sp.s1 >= 0 && 2 * span_nj(sp) * 4 <= HG_RING_PIECES; }
+__device__ __forceinline__ int span_slot_floats(const Span& sp, int si) { return span_both_fit(sp) ? si * span_nj(sp) * 256 : 0; }
+__device__ __forceinline__ void issue_span(const TpArgs& A, const Span& sp, int si, float* __restrict__ stage, int64_t erow, int g) {
+    const int sidx = si ? sp.s1 : sp.s0;
+    const int P = (2 * sp.mm + 1) * (sp.in_mulp >> 2), nj = (P + 3) >> 2;
+    const float* __restrict__ row = pick_src(A, sidx) + erow * pick_stride(A, sidx) + sp.in_off + (sp.li - sp.mm) * sp.in_mulp;
+    float* __restrict__ dst = stage + span_slot_floats(sp, si);
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+        int p = 4 * j + g;
+        p = p < P ? p : P - 1;
+        hg_dma16(row + 4 * p, dst + j * 256);
+    }
+}
+// how many sources of the next item are staged ahead of time (during this item's last GEMM2 step): all that fit the ring
+__device__ __forceinline__ int prefetch_sources(const Span& sp) { return span_both_fit(sp) ? 2 : 1; }
+
 template <int MM, int RTM>
-__device__ __forceinline__ void item_body(const TpArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ tile,
-                                          float* __restrict__ stage, int rowstride, int lk, int rto, int mul_k, int64_t erow, int lane) {
+__device__ __forceinline__ void item_body(const TpArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, const Span nx,
+                                          int& pf, float* __restrict__ tile, float* __restrict__ stage, int rowstride, int lk, int rto, int mul_k,
+                                          int64_t erow, int lane) {
     constexpr int NC = 2 * MM + 1;
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], s0 = it[1], s1 = it[2], in_off = it[3], in_mulp = it[4], li = it[5], neg = it[7];
@@ -129,21 +168,20 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
     f32x4 av_n[RTM];
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + rt * 64);
+    const Span me = Span{s0, s1, in_off, in_mulp, li, MM};
+    const int npf = pf;                                         // sources the previous item already put into the ring
+    pf = 0;
 #pragma unroll 1
     for (int si = 0; si < nsrc; ++si) {
-        const int sidx = si ? s1 : s0;
-        const float* __restrict__ row = pick_src(A, sidx) + erow * pick_stride(A, sidx) + in_off + a_lo * in_mulp;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                         // previous fragment reads retired
-#pragma unroll 1
-        for (int j = 0; j < nj; ++j) {
-            int p = 4 * j + g;
-            p = p < P ? p : P - 1;
-            hg_dma16(row + 4 * p, stage + j * 256);
+        if (si >= npf) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // previous fragment reads retired
+            issue_span(A, me, si, stage, erow, g);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const float* __restrict__ sbase = stage + span_slot_floats(me, si);
         const int abase = si * ngrp;
         if (NC <= 3 && x4) {                                   // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
-            const float* __restrict__ fb = stage + (c0p + g) * 64 + el * 4;
+            const float* __restrict__ fb = sbase + (c0p + g) * 64 + el * 4;
 #pragma unroll 1
             for (int G = 0; G < ngrp; ++G) {
                 f32x4 av[RTM], bv[NC];
@@ -164,7 +202,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                             mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
             }
         } else {                                               // natural K: element (c, 4 sl + g) = piece cbase + sl, component g
-            const float* __restrict__ fb = stage + c0p * 64 + el * 4 + g;
+            const float* __restrict__ fb = sbase + c0p * 64 + el * 4 + g;
 #pragma unroll 1
             for (int G = 0; G < ngrp; ++G) {
                 f32x4 av[RTM];
@@ -202,7 +240,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
         const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
         f32x4 a2_n[RTM];
 #ifdef HG_NO_EARLY
-        hb_n = *reinterpret_cast<const f32x4*>(hrow);
+        hb_n = HG_LDA(reinterpret_cast<const f32x4*>(hrow));
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = HG_LDA(w3 + rt * 64);
 #else
@@ -221,9 +259,9 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) wv[rt] = w3_n[rt];
             if (G + 1 < hgrp) {
-                hb_n = *reinterpret_cast<const f32x4*>(hrow + 16 * (G + 1));
+                hb_n = HG_LDA(reinterpret_cast<const f32x4*>(hrow + 16 * (G + 1)));
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = w3[((G + 1) * RTM + rt) * 64];
+                for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = HG_LDA(w3 + ((G + 1) * RTM + rt) * 64);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -242,7 +280,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NC + c) * 4];
+            for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * HG_LDA(cf + (rt * NC + c) * 4);
 #endif
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
@@ -262,7 +300,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
             for (int rt = 0; rt < RTM; ++rt) av[rt] = a2_n[rt];
             if (rtp + 1 < rto) {
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
+                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + ((rtp + 1) * RTM + rt) * 64);
             }
             // rows beyond mul_k (fragment padding) are redirected to a trash row behind the tile: no divergent branches
             float* __restrict__ trow[4];
@@ -273,9 +311,33 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
             }
 #pragma unroll
             for (int c0 = 0; c0 < NC; c0 += CW) {
+                // the tile values are the accumulator init (C operand): no separate add, and every LDS read of this step is issued
+                // before the next item's spans go out
                 f32x4 acc[CW];
 #pragma unroll
-                for (int c = 0; c < CW; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < CW; ++c)
+                    if (c0 + c < NC) {
+#ifdef HG_ABL_NOWB
+                        acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[c][r] = trow[r][(c0 + c) * 16];
+#endif
+                    }
+                if (rtp + 1 == rto && c0 + CW >= NC && nx.s0 >= 0) {
+                    // last VMEM request of this item is out: stage the NEXT item's B spans now (the ring is idle since GEMM1), so their
+                    // L2/HBM latency runs under this GEMM2 step instead of stalling the next item's first MFMA.  The A fragments
+                    // and tile values are touched first: the compiler cannot count DMAs issued in a runtime loop and would drain
+                    // vmcnt to 0 (wait for these very spans) at their first use otherwise.
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) HG_SINK(av[rt]);
+#pragma unroll
+                    for (int c = 0; c < CW; ++c)
+                        if (c0 + c < NC) HG_SINK(acc[c]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    pf = prefetch_sources(nx);
+                    for (int si = 0; si < pf; ++si) issue_span(A, nx, si, stage, erow, g);
+                }
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -286,6 +348,10 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                                 if (c0 + c < NC)
                                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c0 + c][r], acc[c], 0, 0, 0);
                         }
+                // MFMA result -> LDS store data needs up to 19 wait states that the hazard recognizer cannot insert for inline asm
+#ifdef HG_PREFETCH
+                asm volatile("s_nop 7\n s_nop 7\n s_nop 3" ::: "memory");
+#endif
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
@@ -293,7 +359,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                         HG_SINK(acc[c]);
 #else
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] += acc[c][r];
+                        for (int r = 0; r < 4; ++r) lds_store(trow[r] + (c0 + c) * 16, acc[c][r]);
 #endif
                     }
             }
@@ -311,15 +377,31 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                 for (int rt = 0; rt < RTM; ++rt) mid[rt][c] = mid[rt][c] * cv;
             }
         }
+        float* __restrict__ t0[RTM][4];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = row0 + 16 * rt + 4 * g + r;
-                float* __restrict__ t0 = tile + (rr < mul_k ? rr : mul_k) * rowstride + (lk - MM) * 16 + el;
+                t0[rt][r] = tile + (rr < mul_k ? rr : mul_k) * rowstride + (lk - MM) * 16 + el;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) t0[c * 16] += mid[rt][c][r];
+                for (int c = 0; c < NC; ++c) mid[rt][c][r] += t0[rt][r][c * 16];
             }
+        if (nx.s0 >= 0) {                                      // all LDS reads of this item are done: stage the next item's spans
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) HG_SINK(mid[rt][c]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            pf = prefetch_sources(nx);
+            for (int si = 0; si < pf; ++si) issue_span(A, nx, si, stage, erow, g);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) lds_store(t0[rt][r] + c * 16, mid[rt][c][r]);
     }
 }
 
@@ -443,7 +525,7 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 }
 
 #define HG_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, tile, stage, rowstride, lk, rto, mul_k, erow, lane); break;
+    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, nx, pf, tile, stage, rowstride, lk, rto, mul_k, erow, lane); break;
 
 template <bool HAS_POST>
 __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A, const int* __restrict__ g_segs, const int* __restrict__ g_items,
@@ -466,10 +548,20 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
 #endif
         HG_WAVE_FENCE();
+        int pf = 0;                                            // sources of the current item staged ahead by its predecessor
         for (int ii = ib; ii < ie; ++ii) {
             const int* __restrict__ it = g_items + ii * 20;
             const int mm = it[6], rtm = it[9];
-            if (HAS_POST && it[0] == 3) {                      // segment post-op (lite_mode programs only: separate instantiation)
+            // the last item of a segment stages nothing ahead: the epilogue borrows the ring for the Wigner blocks
+            Span nx = Span{-1, -1, 0, 0, 0, 0};
+#ifdef HG_PREFETCH
+            // opt-in experiment: stage the next item's spans during this item's last GEMM2 step.  Measured neutral (9.46 vs
+            // 9.39 ms): the exposed part of the span latency is HBM-class (the per-edge rows are re-read ~10x with a reuse distance
+            // far beyond L2/MALL) and much longer than one GEMM2 step.
+            if (ii + 1 < ie && !(HAS_POST && it[20] == 3)) nx = span_of(it + 20);
+#endif
+            if (HAS_POST && it[0] == 3) {
+                pf = 0;                      // segment post-op (lite_mode programs only: separate instantiation)
                 HG_WAVE_FENCE();
                 post_item(A, g_W, it, tile, rowstride, nco, rto, mul_k, erow, lane);
                 continue;
