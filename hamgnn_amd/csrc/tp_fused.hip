@@ -52,15 +52,30 @@ __device__ __forceinline__ int64_t pick_stride(const TpArgs& A, int i) {
     return i == 0 ? A.sstride[0] : (i == 1 ? A.sstride[1] : (i == 2 ? A.sstride[2] : A.sstride[3]));
 }
 
+// phase profiler (HG_PROF builds only, tests/bench_tp.py --prof): per-wave shader-clock time between probes, summed over waves
+#ifdef HG_PROF
+__device__ unsigned long long hg_prof_acc[16];
+struct Prof { unsigned long long t[12]; unsigned long long last; };
+#define HG_PROF_ARG , Prof& prof
+#define HG_PROF_PASS , prof
+#define HG_T(k)                                                      \
+    do {                                                             \
+        const unsigned long long t_ = __builtin_readcyclecounter();  \
+        prof.t[k] += t_ - prof.last;                                 \
+        prof.last = t_;                                              \
+    } while (0)
+#else
+#define HG_PROF_ARG
+#define HG_PROF_PASS
+#define HG_T(k)
+#endif
+
 // ablation hooks (timing experiments only, tests/build_variants.sh): HG_SINK keeps a value alive without using it
 #define HG_SINK(v) asm volatile("" ::"v"(v))
 #ifdef HG_ABL_NOA
 #define HG_LDA(p) ((f32x4){.1f, .2f, .3f, .4f})
 #else
 #define HG_LDA(p) (*(p))
-#endif
-#ifndef HG_EARLY
-#define HG_NO_EARLY 1            // early requests of scale/GEMM2 operands cost more in spills than they hide (r1 A/B: 12.65 -> 12.24 ms)
 #endif
 #ifndef HG_DMA_AUX
 #define HG_DMA_AUX 2              // cache policy of the B-operand DMA: nt (streamed once per CU; keeps the shared A lines in L1; r1 A/B: -3 %)
@@ -84,19 +99,18 @@ __device__ __forceinline__ void hg_dma4(const float* __restrict__ gsrc, float* l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
 }
 
-// Tile write-back.  With HG_PREFETCH: an LDS store the compiler does not see.  SIInsertWaitcnts must assume that any LDS access it knows of aliases a pending LDS-DMA and
-// drains vmcnt in front of it -- which would turn the next item's freshly issued B-span DMAs into a full stall at the write-back.
-// (LDS executes one wave's instructions in order, so later reads of the tile still observe these stores.  DS_ADD_F32 was tried
-//  for the read-modify-write and is far slower: 23.6 vs 9.7 ms per launch.)
+// LDS accesses the compiler does not see (HG_PREFETCH builds).  SIInsertWaitcnts must assume that any LDS access it knows of aliases
+// a pending LDS-DMA and drains vmcnt in front of it -- which would turn the next item's freshly issued B-span DMAs into a full
+// stall at the first tile access of GEMM2.  (LDS executes one wave's instructions in order, so later reads of the tile still
+// observe these stores.  DS_ADD_F32 was tried for the read-modify-write and is far slower: 23.6 vs 9.7 ms per launch.)
+__device__ __forceinline__ uint32_t lds_addr(float* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)p; }
 __device__ __forceinline__ void lds_store(float* p, float v) {
 #ifdef HG_PREFETCH
-    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)p;
-    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
 #else
     *p = v;
 #endif
 }
-
 // B-operand span of one (item, source): NC * mulp contiguous floats per edge row -> linear LDS image (see item_body).
 // Sources of a two-source item share the ring when both spans fit (slot = source index), else they take turns at offset 0.
 #define HG_RING_PIECES 44
@@ -125,18 +139,12 @@ __device__ __forceinline__ int prefetch_sources(const Span& sp) { return span_bo
 template <int MM, int RTM>
 __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, const Span nx,
                                           int& pf, float* __restrict__ tile, float* __restrict__ stage, int rowstride, int lk, int rto, int mul_k,
-                                          int64_t erow, int lane) {
+                                          int64_t erow, int lane HG_PROF_ARG) {
     constexpr int NC = 2 * MM + 1;
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], s0 = it[1], s1 = it[2], in_off = it[3], in_mulp = it[4], li = it[5], neg = it[7];
     const int ksteps = it[8], mlp = it[10], x4 = it[17], nk2 = it[18];
     const int g = lane >> 4, el = lane & 15;
-
-    f32x4 mid[RTM][NC];
-#pragma unroll
-    for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) mid[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // ---------------------------------------------------------------- GEMM1: mid = A1 fragments x B(rotated features)
     // A operand: one float4 per lane = 4 K-steps (pre-packed, coalesced 1 KiB per wave-load), register double-buffered.
@@ -161,23 +169,71 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
     const int cdir = neg ? -P1 : P1;                           // column c -> span piece base (neg ? NC-1-c : c) * P1
     const int c0p = neg ? (NC - 1) * P1 : 0;
 
-    const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
-    const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
-    f32x4 hb_n = (f32x4){0.f, 0.f, 0.f, 0.f}, w3_n[RTM];
+    HG_T(0);                                                    // dispatch: record loads, switch, prologue
+    const Span me = Span{s0, s1, in_off, in_mulp, li, MM};
+    int nissued = pf;                                           // sources already in the ring (opt-in prefetch by the previous item)
+    pf = 0;
+    {   // this item's spans go out first: their (HBM-class) latency runs under the radial-scale phase below
+        const int nfirst = nsrc == 0 ? 0 : (span_both_fit(me) ? nsrc : 1);
+        if (nissued < nfirst) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous fragment reads retired
+        for (; nissued < nfirst; ++nissued) issue_span(A, me, nissued, stage, erow, g);
+    }
+
+    // ---------------------------------------------------------------- radial scale s_e = W3^T h2  (MFMA, K = hidden, permuted K)
+    // Runs BEFORE GEMM1 (it does not depend on it): `mid` is not live yet, so every W3 / h fragment of the item (up to 4 x RTM + 4
+    // float4) is requested at once -- ONE exposed L2 latency, overlapped with the span DMAs, instead of one per 16-wide K group
+    // (r1b ablation: weight-load latency cost 2.3 of 9.7 ms, most of it in this phase whose MFMA time per fragment is only 128 clk).
+    f32x4 S[RTM];
+    if (typ == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
+        const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
+#ifdef HG_ABL_NOSCALE
+        const int hgrp = 1;
+#else
+        const int hgrp = A.hidden >> 4;
+#endif
+#pragma unroll 1
+        for (int G0 = 0; G0 < hgrp; G0 += 4) {
+            f32x4 hb[4], wv[4][RTM];
+#pragma unroll
+            for (int G = 0; G < 4; ++G)
+                if (G0 + G < hgrp) {
+                    hb[G] = HG_LDA(reinterpret_cast<const f32x4*>(hrow + 16 * (G0 + G)));
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = HG_LDA(w3 + ((G0 + G) * RTM + rt) * 64);
+                }
+#pragma unroll
+            for (int G = 0; G < 4; ++G)
+                if (G0 + G < hgrp) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
+                }
+        }
+    }
+
+    HG_T(1);                                                    // span issue + radial-scale phase
+    f32x4 mid[RTM][NC];
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) mid[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 av_n[RTM];
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = HG_LDA(aw + rt * 64);
-    const Span me = Span{s0, s1, in_off, in_mulp, li, MM};
-    const int npf = pf;                                         // sources the previous item already put into the ring
-    pf = 0;
 #pragma unroll 1
     for (int si = 0; si < nsrc; ++si) {
-        if (si >= npf) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // previous fragment reads retired
+        if (si >= nissued) {                                    // second source of a span pair too wide to share the ring
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_span(A, me, si, stage, erow, g);
+            ++nissued;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HG_T(2);                                                // waiting for the spans (and the first A fragments)
         const float* __restrict__ sbase = stage + span_slot_floats(me, si);
         const int abase = si * ngrp;
         if (NC <= 3 && x4) {                                   // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
@@ -228,51 +284,16 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                 }
             }
         }
+        HG_T(3);                                                // GEMM1 of this source
     }
 
-    float* __restrict__ tp = tile + (4 * g) * rowstride + (lk - MM) * 16 + el;
     if (typ == 0) {
-        // ------------------------------------------------------------ radial scale s_e = W3^T h2  (MFMA, K = hidden, permuted K)
-        f32x4 S[RTM];
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int hgrp = A.hidden >> 4;
         const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
+        const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(Wb + it[13]) + g;     // [rt][c][g] float4
+        {
         f32x4 a2_n[RTM];
-#ifdef HG_NO_EARLY
-        hb_n = HG_LDA(reinterpret_cast<const f32x4*>(hrow));
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = HG_LDA(w3 + rt * 64);
-#else
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);                      // GEMM2 operands of rtp = 0, early
-#endif
-#ifdef HG_ABL_NOSCALE
-        const int hgrp_run = 1;
-#else
-        const int hgrp_run = hgrp;
-#endif
-#pragma unroll 1
-        for (int G = 0; G < hgrp_run; ++G) {
-            const f32x4 hb = hb_n;
-            f32x4 wv[RTM];
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) wv[rt] = w3_n[rt];
-            if (G + 1 < hgrp) {
-                hb_n = HG_LDA(reinterpret_cast<const f32x4*>(hrow + 16 * (G + 1)));
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) w3_n[rt] = HG_LDA(w3 + ((G + 1) * RTM + rt) * 64);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rt][q], hb[q], S[rt], 0, 0, 0);
-        }
-#ifdef HG_NO_EARLY
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);
-#endif
-        const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(Wb + it[13]) + g;     // [rt][c][g] float4
 #ifdef HG_ABL_NOSCALEMUL
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) HG_SINK(S[rt]);
@@ -283,6 +304,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * HG_LDA(cf + (rt * NC + c) * 4);
 #endif
 
+        HG_T(4);                                                // mid *= S * cf (+ a2 / cf loads)
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
 #ifdef HG_ABL_NOG2
         const int rto_run = 0;
@@ -311,8 +333,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
             }
 #pragma unroll
             for (int c0 = 0; c0 < NC; c0 += CW) {
-                // the tile values are the accumulator init (C operand): no separate add, and every LDS read of this step is issued
-                // before the next item's spans go out
+                // the tile values are the accumulator init (C operand): no separate add
                 f32x4 acc[CW];
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
@@ -324,11 +345,12 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                         for (int r = 0; r < 4; ++r) acc[c][r] = trow[r][(c0 + c) * 16];
 #endif
                     }
+#ifdef HG_PREFETCH
                 if (rtp + 1 == rto && c0 + CW >= NC && nx.s0 >= 0) {
-                    // last VMEM request of this item is out: stage the NEXT item's B spans now (the ring is idle since GEMM1), so their
-                    // L2/HBM latency runs under this GEMM2 step instead of stalling the next item's first MFMA.  The A fragments
-                    // and tile values are touched first: the compiler cannot count DMAs issued in a runtime loop and would drain
-                    // vmcnt to 0 (wait for these very spans) at their first use otherwise.
+                    // last VMEM request and last visible LDS read of this item are out: stage the NEXT item's B spans now (the ring
+                    // is idle since GEMM1); their latency runs under this GEMM2 step and the next item's radial-scale phase.  The A
+                    // fragments and tile values are touched first: the compiler cannot count DMAs issued in a runtime loop and
+                    // would drain vmcnt to 0 (wait for these very spans) at their first use otherwise.
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) HG_SINK(av[rt]);
 #pragma unroll
@@ -338,6 +360,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                     pf = prefetch_sources(nx);
                     for (int si = 0; si < pf; ++si) issue_span(A, nx, si, stage, erow, g);
                 }
+#endif
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -348,8 +371,8 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                                 if (c0 + c < NC)
                                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c0 + c][r], acc[c], 0, 0, 0);
                         }
-                // MFMA result -> LDS store data needs up to 19 wait states that the hazard recognizer cannot insert for inline asm
 #ifdef HG_PREFETCH
+                // MFMA result -> LDS store data needs up to 19 wait states that the hazard recognizer cannot insert for inline asm
                 asm volatile("s_nop 7\n s_nop 7\n s_nop 3" ::: "memory");
 #endif
 #pragma unroll
@@ -364,6 +387,8 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                     }
             }
         }
+        }
+        HG_T(5);                                                // GEMM2 + tile write-back
     } else {
         // plain o3.Linear path: rows are output channels; add straight into the tile
         // (typ 2, lite_mode paths: each column first takes its aligned-frame CG coefficient, message_passing.py:197-215)
@@ -402,6 +427,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) lds_store(t0[rt][r] + c * 16, mid[rt][c][r]);
+        HG_T(6);                                                // linear-item write-back
     }
 }
 
@@ -525,7 +551,7 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 }
 
 #define HG_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, nx, pf, tile, stage, rowstride, lk, rto, mul_k, erow, lane); break;
+    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, nx, pf, tile, stage, rowstride, lk, rto, mul_k, erow, lane HG_PROF_PASS); break;
 
 template <bool HAS_POST>
 __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A, const int* __restrict__ g_segs, const int* __restrict__ g_items,
@@ -537,6 +563,12 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
     const int64_t erow = valid ? e : A.rows - 1;
     float* tile = lds + wave * A.tile_floats_wave;
     float* stage = tile + (A.tile_floats_wave - HG_STAGE_FLOATS);          // B-operand DMA ring behind the segment tile
+#ifdef HG_PROF
+    Prof prof;
+    for (int k = 0; k < 12; ++k) prof.t[k] = 0;
+    prof.last = __builtin_readcyclecounter();
+    const unsigned long long t_begin = prof.last;
+#endif
 
     for (int sg = 0; sg < A.nseg; ++sg) {
         const int* __restrict__ S = g_segs + sg * 8;
@@ -548,6 +580,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
 #endif
         HG_WAVE_FENCE();
+        HG_T(7);                                               // segment set-up: tile zeroing
         int pf = 0;                                            // sources of the current item staged ahead by its predecessor
         for (int ii = ib; ii < ie; ++ii) {
             const int* __restrict__ it = g_items + ii * 20;
@@ -592,8 +625,27 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         }
 #endif
         HG_WAVE_FENCE();
+        HG_T(8);                                               // epilogue
     }
+#ifdef HG_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 9; ++k) atomicAdd(&hg_prof_acc[k], prof.t[k]);
+        atomicAdd(&hg_prof_acc[15], prof.last - t_begin);
+    }
+#endif
 }
+
+#ifdef HG_PROF
+extern "C" int hg_prof_read(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(hg_prof_acc), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(hg_prof_acc), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node,
                            const float* h2_edge, int hidden, const float* wig, int nW, const int32_t* wig_off,

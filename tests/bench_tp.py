@@ -41,3 +41,14 @@ prog = m._dp.prog
 print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
                   "issued_TF": prog.mfma_per_wave * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
                   "Medges_s": E / dt / 1e6, "checksum": float(out.double().abs().mean())}))
+if os.environ.get("HG_PROF"):
+    import ctypes as C
+    from hamgnn_amd import _lib
+    L = _lib.lib()
+    buf = (C.c_ulonglong * 16)()
+    L.hg_prof_read(buf, 1)
+    ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)
+    L.hg_prof_read(buf, 0)
+    names = ["dispatch", "span issue + scale", "span wait", "GEMM1", "scale-mul + a2/cf loads", "GEMM2 + write-back", "linear write-back", "tile zero", "epilogue"]
+    tot = float(buf[15])
+    print(json.dumps({"prof_total_wave_cycles": tot, **{n: round(buf[k] / tot, 4) for k, n in enumerate(names)}}))
