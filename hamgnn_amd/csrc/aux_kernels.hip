@@ -212,37 +212,42 @@ extern "C" int hg_radial_hidden(const float* rbf, int64_t E, const float* weight
     return hg_check_launch("hg_radial_hidden");
 }
 
-// ------------------------------------------------------------------------------------------------ gather + rotate
-// One workgroup per edge.  The edge's packed Wigner matrices (<= 455 floats) are staged in LDS once (coalesced), then one
-// thread per CHANNEL (irrep block i, channel u) loads its 2l+1 components (coalesced across u), multiplies by D^l (LDS
-// broadcast reads) and stores 2l+1 components.  Up to two gathered sources (sender / receiver rows) share the staged D.
-// chan_tab: int32[nchan][4] = {l, planar offset of (component 0, channel u), mulp, 0}.
+// ------------------------------------------------------------------------------------------------ gather + frame rotation
+// out_s[e][i][a][u] = sum_b D_e^{l_i}[a][b] x_s[idx_s[e]][i][b][u].  Work item = (edge, source, group of 4 channels of one irrep):
+// 2l+1 float4 loads (component stride mulp), (2l+1)^2 x 4 FMAs against the edge's Wigner block staged in LDS (broadcast
+// reads, amortised over the 4 channels), 2l+1 float4 stores.  The group table is sorted by l and a wave covers 4 consecutive
+// groups x 16 (edge, source) pairs, so a wavefront runs one -- at block seams two -- of the <L> paths.  (The r1 kernel used one
+// channel per lane in layout order: a wavefront then spanned every l of the row and executed all seven paths serially -- it
+// was VALU-issue bound at 1.3 TB/s instead of HBM bound.)
+// grp_tab: int32[ngroups][4] = {l, planar offset of (component 0, first channel), mulp, valid channels (1..4)}.
+typedef float rg_f4 __attribute__((ext_vector_type(4)));
 template <int L>
-__device__ __forceinline__ void rotate_channel(const float* __restrict__ Dl, const float* __restrict__ xin, float* __restrict__ xout,
-                                               int base, int mulp, int transpose) {
+__device__ __forceinline__ void rotate_group(const float* __restrict__ Dl, const float* __restrict__ xin, float* __restrict__ xout,
+                                             int base, int mulp, int transpose, int nvalid) {
     constexpr int N = 2 * L + 1;
-    float v[N];
+    rg_f4 v[N];
 #pragma unroll
-    for (int b = 0; b < N; ++b) v[b] = xin[base + b * mulp];
+    for (int b = 0; b < N; ++b) v[b] = *reinterpret_cast<const rg_f4*>(xin + base + b * mulp);
+    const rg_f4 keep = (rg_f4){1.f, nvalid > 1 ? 1.f : 0.f, nvalid > 2 ? 1.f : 0.f, nvalid > 3 ? 1.f : 0.f};
 #pragma unroll
     for (int a = 0; a < N; ++a) {
-        float acc = 0.f;
+        rg_f4 acc = (rg_f4){0.f, 0.f, 0.f, 0.f};
         if (!transpose) {
 #pragma unroll
-            for (int b = 0; b < N; ++b) acc = fmaf(Dl[a * N + b], v[b], acc);
+            for (int b = 0; b < N; ++b) acc += Dl[a * N + b] * v[b];
         } else {
 #pragma unroll
-            for (int b = 0; b < N; ++b) acc = fmaf(Dl[b * N + a], v[b], acc);
+            for (int b = 0; b < N; ++b) acc += Dl[b * N + a] * v[b];
         }
-        xout[base + a * mulp] = acc;
+        *reinterpret_cast<rg_f4*>(xout + base + a * mulp) = acc * keep;        // channel padding stays zero (zero-weight MFMA K-steps)
     }
 }
 
-#define RG_EB 8          // edges per workgroup: amortises the frame staging + barrier over 8 x nsrc x nchan channel work-items
+#define RG_EB 16         // edges per workgroup: one frame staging + barrier per 16 x nsrc x ngroups work items
 __global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int64_t xs,
                                                             const int64_t* __restrict__ idx0, const int64_t* __restrict__ idx1,
                                                             const float* __restrict__ wig, int nW, const HgWigOff wo,
-                                                            const int4* __restrict__ tab, int nchan, int64_t E, int transpose,
+                                                            const int4* __restrict__ tab, int ngroups, int64_t E, int transpose,
                                                             float* __restrict__ out0, float* __restrict__ out1, int64_t os) {
     extern __shared__ float Dsm[];                             // [RG_EB][nW]
     const int64_t e0 = (int64_t)blockIdx.x * RG_EB;
@@ -250,42 +255,50 @@ __global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restr
     for (int i = threadIdx.x; i < ne * nW; i += blockDim.x) Dsm[i] = wig[e0 * nW + i];
     __syncthreads();
     const int nsrc = x1 ? 2 : 1;
-    const int per_edge = nchan * nsrc;
-    for (int j = threadIdx.x; j < per_edge * ne; j += blockDim.x) {
-        const int le = j / per_edge;
-        const int r = j - le * per_edge;
-        const int sidx = r >= nchan;
-        const int4 t = tab[sidx ? r - nchan : r];
+    const int npairs = RG_EB * nsrc;
+    const int nsg = (ngroups + 3) >> 2;                        // super-groups of 4 consecutive groups
+    for (int j = threadIdx.x; j < nsg * npairs * 4; j += blockDim.x) {
+        const int sg = j / (npairs * 4);
+        const int rem = j - sg * npairs * 4;
+        const int pair = rem >> 2;
+        const int gid = sg * 4 + (rem & 3);
+        const int le = pair / nsrc;
+        const int sidx = pair - le * nsrc;
+        if (gid >= ngroups || le >= ne) continue;
+        const int4 t = tab[gid];
         const int64_t e = e0 + le;
         const int64_t row = sidx ? (idx1 ? idx1[e] : e) : (idx0 ? idx0[e] : e);
         const float* __restrict__ xin = (sidx ? x1 : x0) + row * xs;
         float* __restrict__ xo = (sidx ? out1 : out0) + e * os;
         const float* __restrict__ Dl = Dsm + le * nW + wo.o[t.x];
-        if (t.w) {                                             // channel padding: keep it zero (it feeds zero-weight MFMA K-steps)
-            for (int a = 0; a < 2 * t.x + 1; ++a) xo[t.y + a * t.z] = 0.f;
-            continue;
-        }
         switch (t.x) {
-            case 0: xo[t.y] = xin[t.y]; break;
-            case 1: rotate_channel<1>(Dl, xin, xo, t.y, t.z, transpose); break;
-            case 2: rotate_channel<2>(Dl, xin, xo, t.y, t.z, transpose); break;
-            case 3: rotate_channel<3>(Dl, xin, xo, t.y, t.z, transpose); break;
-            case 4: rotate_channel<4>(Dl, xin, xo, t.y, t.z, transpose); break;
-            case 5: rotate_channel<5>(Dl, xin, xo, t.y, t.z, transpose); break;
-            case 6: rotate_channel<6>(Dl, xin, xo, t.y, t.z, transpose); break;
+            case 0: {
+                const rg_f4 keep = (rg_f4){1.f, t.w > 1 ? 1.f : 0.f, t.w > 2 ? 1.f : 0.f, t.w > 3 ? 1.f : 0.f};
+                *reinterpret_cast<rg_f4*>(xo + t.y) = *reinterpret_cast<const rg_f4*>(xin + t.y) * keep;
+                break;
+            }
+            case 1: rotate_group<1>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
+            case 2: rotate_group<2>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
+            case 3: rotate_group<3>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
+            case 4: rotate_group<4>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
+            case 5: rotate_group<5>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
+            case 6: rotate_group<6>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
             default: break;
         }
     }
 }
 
 extern "C" int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stride, const int64_t* idx0, const int64_t* idx1,
-                                const float* wig, int nW, const int32_t* wig_off, const int32_t* chan_tab, int nchan, int64_t E,
+                                const float* wig, int nW, const int32_t* wig_off, const int32_t* grp_tab, int ngroups, int64_t E,
                                 int transpose, float* out0, float* out1, int64_t out_stride, void* stream) {
     if (E <= 0) return 0;
+    if ((x_stride & 3) || (out_stride & 3)) return hg_fail(-2, "hg_rotate_gather: row strides must be multiples of 4 floats (planar rows)");
     HgWigOff wo;
     for (int i = 0; i < 8; ++i) wo.o[i] = wig_off[i];
-    rotate_gather_kernel<<<dim3((unsigned)((E + RG_EB - 1) / RG_EB)), 256, sizeof(float) * (size_t)nW * RG_EB, (hipStream_t)stream>>>(
-        x0, x1, x_stride, idx0, idx1, wig, nW, wo, (const int4*)chan_tab, nchan, E, transpose, out0, out1, out_stride);
+    const size_t lds = sizeof(float) * (size_t)nW * RG_EB;
+    if (lds > 64 * 1024) return hg_fail(-2, "hg_rotate_gather: Wigner row too wide for the LDS staging");
+    rotate_gather_kernel<<<dim3((unsigned)((E + RG_EB - 1) / RG_EB)), 256, lds, (hipStream_t)stream>>>(
+        x0, x1, x_stride, idx0, idx1, wig, nW, wo, (const int4*)grp_tab, ngroups, E, transpose, out0, out1, out_stride);
     return hg_check_launch("hg_rotate_gather");
 }
 

@@ -512,6 +512,7 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
     const int g = lane >> 4, el = lane & 15;
     const float* __restrict__ tl = tile + el;
     float* __restrict__ ob = A.out + e * A.ostride + out_off;
+    const int wend = mul_k + (flags >> 8);                     // + channel-padding slots of the planar block (last chunk only)
     if (flags & SEG_UNROTATE) {
         // out[w, a] = sum_m D^l(R_e)[m, a] tile[w, m].  The 16 Wigner blocks of the wave are pulled into the (idle) B-operand
         // ring by LDS-DMA, image [m * NCO + a][edge]: ONE exposed memory latency per segment (the r1 ablations showed per-column
@@ -532,20 +533,20 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 #pragma unroll
             for (int m = 0; m < NCO; ++m) dc[m] = dl[(m * NCO + a) * 16];
 #pragma unroll 1
-            for (int w = g; w < mul_k; w += 4) {
-                const float* __restrict__ tw = tl + w * rowstride;
+            for (int w = g; w < wend; w += 4) {                // rows mul_k .. wend-1 are the block's channel padding: written as zeros
+                const float* __restrict__ tw = tl + (w < mul_k ? w : mul_k) * rowstride;
                 float acc = 0.f;
 #pragma unroll
                 for (int m = 0; m < NCO; ++m) acc = fmaf(dc[m], tw[m * 16], acc);
-                if (valid) ob[a * out_mulp + w] = acc;
+                if (valid) ob[a * out_mulp + w] = w < mul_k ? acc : 0.f;
             }
         }
     } else {
 #pragma unroll 1
-        for (int w = g; w < mul_k; w += 4) {
+        for (int w = g; w < wend; w += 4) {
 #pragma unroll
             for (int a = 0; a < NCO; ++a)
-                if (valid) ob[a * out_mulp + w] = tl[w * rowstride + a * 16];
+                if (valid) ob[a * out_mulp + w] = w < mul_k ? tl[w * rowstride + a * 16] : 0.f;
         }
     }
 }

@@ -113,7 +113,7 @@ PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, rows, 
 def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None,
              tag: str = "linear") -> torch.Tensor:
     _require_gpu(srcs[0])
-    out = torch.zeros(rows, dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # channel padding must stay finite (zero)
+    out = torch.empty(rows, dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
     ss = (C.c_int64 * 4)(*([int(s.stride(0)) for s in srcs] + [0] * (4 - n)))

@@ -376,7 +376,8 @@ def new_program(irreps_out, hidden=0, flags_of=lambda k, ir: 0) -> Tuple[Program
         chunks = []
         for c0 in range(0, mk, MAX_SEG_ROWS):
             c1 = min(mk, c0 + MAX_SEG_ROWS)
-            sid = _add_segment(prog, lk, c1 - c0, k, flags_of(k, (mk, lk, pk)))
+            npad = lay.mulp[k] - mk if c1 == mk else 0         # channel-padding slots the last chunk zero-fills (flags bits 8..)
+            sid = _add_segment(prog, lk, c1 - c0, k, flags_of(k, (mk, lk, pk)) | (npad << 8))
             prog.segs[sid][3] += c0                            # channel offset inside the planar block
             chunks.append((sid, c0, c1))
         seg_of_k[k] = chunks[0][0]
@@ -463,11 +464,13 @@ def wigner_jtab(lmax) -> np.ndarray:
 
 
 def rotate_table(layout: PlanarLayout) -> np.ndarray:
-    """int32[nchan][4] = {l, planar offset of (component 0, channel u), mulp, is_padding}: one entry per channel slot."""
+    """int32[ngroups][4] = {l, planar offset of (component 0, first channel of the group), mulp, valid channels (1..4)}: one entry per
+    group of 4 channel slots, sorted by l (stable) so that the wavefronts of hg_rotate_gather run a single <L> code path."""
     rows = []
     for (mul, l, p), off, mp in zip(layout.irreps, layout.off, layout.mulp):
-        for u in range(mp):
-            rows.append((l, off + u, mp, 0 if u < mul else 1))
+        for u in range(0, mp, 4):
+            rows.append((l, off + u, mp, max(0, min(4, mul - u))))
+    rows.sort(key=lambda r: r[0])
     return np.asarray(rows, dtype=np.int32).reshape(-1, 4)
 
 

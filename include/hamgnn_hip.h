@@ -43,10 +43,11 @@ int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const in
  * PairInteractionBlock.forward (interaction_blocks.py:141-145), fused with the rotation into the edge-aligned frame:
  * out_s[e][i][a][u] = sum_b D_e^{l_i}[a][b] x_s[idx_s[e]][i][b][u]  for up to two sources s = 0,1 sharing the edge's D
  * (x1 == NULL: one source; idx == NULL: identity gather; transpose != 0: D^T, i.e. back to the global frame).
- * chan_tab: int32[nchan][4] = {l, planar offset of (component 0, channel u), mulp, is_padding} (plan.py:rotate_table);
- * padding channel slots are written as zeros.                                                                           */
+ * grp_tab: int32[ngroups][4] = {l, planar offset of (component 0, first channel), mulp, valid channels 1..4}, one entry per
+ * group of 4 channel slots, sorted by l (plan.py:rotate_table); padding channel slots are written as zeros; row strides
+ * must be multiples of 4 floats.                                                                                         */
 int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stride, const int64_t* idx0, const int64_t* idx1,
-                     const float* wig, int nW, const int32_t* wig_off, const int32_t* chan_tab, int nchan, int64_t E,
+                     const float* wig, int nW, const int32_t* wig_off, const int32_t* grp_tab, int ngroups, int64_t E,
                      int transpose, float* out0, float* out1, int64_t out_stride, void* stream);
 
 /* THE hot kernel.  Replaces, per launch, one whole MessagePackBlock.forward (hamgnn/nn/message_passing.py:191-231:
