@@ -93,3 +93,16 @@ def test_backbone_lite_mode_golden():
     r = G.check_backbone(name="backbone_lite")
     print(r)
     assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
+
+
+@pytest.mark.parametrize("workload,which,soc", [("si512", "B", False), ("mos2_1200", "A", True)])
+def test_full_size_properties(workload, which, soc):
+    """BASELINE configs #2 (Si512, set-B) and #3 (MoS2 1200 atoms + SOC, set-A) at full size: symmetry / Hermiticity, rotation
+    invariants (eigenvalues, singular values), translation invariance."""
+    r = G.check_full_size_properties(workload=workload, which=which, soc=soc)
+    print(r)
+    assert r["onsite_sym_err"] < 1e-6 and r["offsite_sym_err"] < 1e-6
+    if not soc:
+        assert r["rot_onsite_eig_err"] < 5e-5 and r["rot_offsite_sv_err"] < 5e-5
+        assert r["rot_changes_H"] > 1e-2
+    assert r["translation_err"] < 5e-5
