@@ -1,0 +1,528 @@
+// tp_is.hip -- input-stationary variant of the fused equivariant edge kernel (gfx950, CDNA4).  Hand-written HIP.
+//
+// Same items and the same per-item arithmetic as tp_fused.hip (GEMM1 -> radial scale -> GEMM2 chained through MFMA C
+// fragments), but a different loop nest and work split, driven by the measured HBM traffic of the segment-stationary kernel
+// (profiles/r01c_tp_fused_hbm_pmc.md: 12x the algorithmic bytes, because every item re-stages its input-irrep span and the
+// reuse distance is far beyond L2 / Infinity Cache):
+//   * a workgroup = 4 waves = ONE tile of 16 edges; the tiles of ALL output segments live in LDS at once (<= 80 KB: 2 WG/CU);
+//   * outer loop over the input irrep blocks ("phases", hamgnn_amd/plan.py:is_schedule): the block of the 16 edges (both
+//     sources of the node branch) is staged ONCE by LDS-DMA, cooperatively, and every item that reads it runs in that phase,
+//     spread over the four waves (the planner keeps all items of one (phase, output segment) on one wave, so no two waves
+//     update the same tile between two barriers);
+//   * B operands are read by all waves from the shared staged block; each input row is fetched once per launch (10.8 KB/edge
+//     instead of ~170 KB/edge), and the exposed span latencies drop from one per item to one per phase.
+// Items, fragments and weights are exactly those of the segment-stationary program (same planner output, regrouped).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hg_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct IsArgs {
+    const float* src[4];
+    int64_t sstride[4];
+    const float* h2[2];
+    int hidden;
+    const float* wig;
+    int nW;
+    int wig_off[8];
+    float* out;
+    int64_t ostride;
+    int64_t rows;
+    int nseg;
+    int nphase;
+    int trash_off;               // float offsets inside the workgroup's LDS
+    int stage_off;
+    int ctr_off;                 // work-claim counter (one dword)
+    const int64_t* idx[4];       // per source slot: row gather (NULL: row = edge)
+    int rot_mask;                // bit i: source i holds GLOBAL-frame rows that are rotated into the edge frame while staged
+};
+
+#define SEG_UNROTATE 1
+
+// phase profiler (HG_PROF builds only, tests/bench_tp.py): per-wave shader-clock time between probes, summed over waves
+#ifdef HG_PROF
+__device__ unsigned long long hg_prof_is_acc[16];
+struct ProfIs { unsigned long long t[12]; unsigned long long last; };
+#define IS_PROF_ARG , ProfIs& prof
+#define IS_PROF_PASS , prof
+#define IS_T(k)                                                      \
+    do {                                                             \
+        const unsigned long long t_ = __builtin_readcyclecounter();  \
+        prof.t[k] += t_ - prof.last;                                 \
+        prof.last = t_;                                              \
+    } while (0)
+#else
+#define IS_PROF_ARG
+#define IS_PROF_PASS
+#define IS_T(k)
+#endif
+
+__device__ __forceinline__ const float* is_pick_src(const IsArgs& A, int i) {
+    return i == 0 ? A.src[0] : (i == 1 ? A.src[1] : (i == 2 ? A.src[2] : A.src[3]));
+}
+__device__ __forceinline__ int64_t is_pick_stride(const IsArgs& A, int i) {
+    return i == 0 ? A.sstride[0] : (i == 1 ? A.sstride[1] : (i == 2 ? A.sstride[2] : A.sstride[3]));
+}
+// LDS-DMA: per-lane global address -> LDS at (wave-uniform base + lane * size); counted by vmcnt
+__device__ __forceinline__ void is_dma16(const float* __restrict__ gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
+}
+__device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
+}
+
+// One item on the workgroup's 16 edges.  stage: the phase's staged input block(s), image offset(piece p, row e) = 64 p + 4 e per
+// source (pieces of the FULL irrep block: component a, channel piece s -> p = a * P1 + s).
+template <int MM, int RTM>
+__device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, const int* __restrict__ S8,
+                                        float* __restrict__ lds, int64_t erow, int lane IS_PROF_ARG) {
+    constexpr int NC = 2 * MM + 1;
+    constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
+    const int typ = it[0], so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], neg = it[7];     // [1], [2]: stage offsets of the sources
+    const int ksteps = it[8], mlp = it[10], x4 = it[17], nk2 = it[18];
+    const int lk = S8[0], mul_k = S8[1], rto = S8[2], tile_off = S8[5];
+    const int g = lane >> 4, el = lane & 15;
+    const int rowstride = (2 * lk + 1) * 16 + 4;
+    float* __restrict__ tile = lds + tile_off;
+    float* __restrict__ trash = lds + A.trash_off;
+    const float* __restrict__ stage = lds + A.stage_off;
+    IS_T(0);                                                    // dispatch
+
+    // ---------------------------------------------------------------- radial scale s_e = W3^T h2 first (see tp_fused.hip)
+    f32x4 S[RTM];
+    if (typ == 0) {
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
+        const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
+        const int hgrp = A.hidden >> 4;
+#pragma unroll 1
+        for (int G0 = 0; G0 < hgrp; G0 += 4) {
+            f32x4 hb[4], wv[4][RTM];
+#pragma unroll
+            for (int G = 0; G < 4; ++G)
+                if (G0 + G < hgrp) {
+                    hb[G] = *reinterpret_cast<const f32x4*>(hrow + 16 * (G0 + G));
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[((G0 + G) * RTM + rt) * 64];
+                }
+#pragma unroll
+            for (int G = 0; G < 4; ++G)
+                if (G0 + G < hgrp) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
+                }
+        }
+    }
+
+    IS_T(1);                                                    // radial scale
+    // ---------------------------------------------------------------- GEMM1: mid = A1 fragments x staged block
+    f32x4 mid[RTM][NC];
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) mid[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nsrc = so1 >= 0 ? 2 : 1;
+    const int ngrp = (ksteps + 3) >> 2;
+    const int P1 = in_mulp >> 2;                               // float4 pieces per component
+    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;      // [src][G][rt][lane]
+    const int cdir = neg ? -P1 : P1;                           // column c -> component (neg ? a_hi - c : a_lo + c)
+    const int c0p = (li - MM) * P1 + (neg ? (NC - 1) * P1 : 0);
+    f32x4 av_n[RTM];
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
+#pragma unroll 1
+    for (int si = 0; si < nsrc; ++si) {
+        const float* __restrict__ sbase = stage + (si ? so1 : so0);
+        const int abase = si * ngrp;
+        if (NC <= 3 && x4) {                                   // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
+            const float* __restrict__ fb = sbase + (c0p + g) * 64 + el * 4;
+#pragma unroll 1
+            for (int G = 0; G < ngrp; ++G) {
+                f32x4 av[RTM], bv[NC];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+                if (abase + G + 1 < nsrc * ngrp) {
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (c * cdir + 4 * G) * 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+                            mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
+            }
+        } else {                                               // natural K: element (c, 4 sl + g) = piece cbase + sl, component g
+            const float* __restrict__ fb = sbase + c0p * 64 + el * 4 + g;
+#pragma unroll 1
+            for (int G = 0; G < ngrp; ++G) {
+                f32x4 av[RTM];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+                if (abase + G + 1 < nsrc * ngrp) {
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
+                }
+                const int nq = ksteps - 4 * G;                 // K-steps in this group (>= 4 except in the tail group)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < nq) {
+                        float b[NC];
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) b[c] = fb[(c * cdir + 4 * G + q) * 64];
+#pragma unroll
+                        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    IS_T(2);                                                    // GEMM1
+    if (typ == 0) {
+        const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
+        const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(Wb + it[13]) + g;     // [rt][c][g] float4
+        f32x4 a2_n[RTM];
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NC + c) * 4];
+
+        // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
+#pragma unroll 1
+        for (int rtp = 0; rtp < rto; ++rtp) {
+            f32x4 av[RTM];
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = a2_n[rt];
+            if (rtp + 1 < rto) {
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
+            }
+            // rows beyond mul_k (fragment padding) go to the shared trash row: no divergent branches (their L' columns are zero)
+            float* __restrict__ trow[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * rtp + 4 * g + r;
+                trow[r] = (rr < mul_k ? tile + rr * rowstride : trash) + (lk - MM) * 16 + el;
+            }
+#pragma unroll
+            for (int c0 = 0; c0 < NC; c0 += CW) {
+                f32x4 acc[CW];                                 // tile values are the accumulator init (C operand)
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c0 + c < NC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[c][r] = trow[r][(c0 + c) * 16];
+                    }
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * rt + r < nk2) {                // trailing K-steps hold only padding rows: not issued
+#pragma unroll
+                            for (int c = 0; c < CW; ++c)
+                                if (c0 + c < NC)
+                                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c0 + c][r], acc[c], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c0 + c < NC) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] = acc[c][r];
+                    }
+            }
+        }
+    } else {
+        // plain o3.Linear item (PairInteractionBlock skip): rows are output channels; add straight into the tile
+        const int row0 = it[16];
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = row0 + 16 * rt + 4 * g + r;
+                float* __restrict__ t0 = (rr < mul_k ? tile + rr * rowstride : trash) + (lk - MM) * 16 + el;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) t0[c * 16] += mid[rt][c][r];
+            }
+    }
+    IS_T(3);                                                    // scale-mul + GEMM2 + write-back
+}
+
+// un-rotate (optional) + planar store of one segment, rows split over the four waves; D blocks staged in `dst` (see kernel)
+template <int LK>
+__device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __restrict__ tile, const float* __restrict__ dstage, int mul_k,
+                                            int out_off, int out_mulp, int flags, int64_t e, bool valid, int wave, int lane) {
+    constexpr int NCO = 2 * LK + 1;
+    const int g = lane >> 4, el = lane & 15;
+    const int rowstride = NCO * 16 + 4;
+    const float* __restrict__ tl = tile + el;
+    float* __restrict__ ob = A.out + e * A.ostride + out_off;
+    const int wend = mul_k + ((flags >> 8) & 0xff);            // + channel-padding slots of the planar block (last chunk only)
+    if (flags & SEG_UNROTATE) {
+        const float* __restrict__ dl = dstage + el;
+#pragma unroll 1
+        for (int a = 0; a < NCO; ++a) {
+            float dc[NCO];
+#pragma unroll
+            for (int m = 0; m < NCO; ++m) dc[m] = dl[(m * NCO + a) * 16];
+#pragma unroll 1
+            for (int w = 4 * wave + g; w < wend; w += 16) {
+                const float* __restrict__ tw = tl + (w < mul_k ? w : 0) * rowstride;
+                float acc = 0.f;
+#pragma unroll
+                for (int m = 0; m < NCO; ++m) acc = fmaf(dc[m], tw[m * 16], acc);
+                if (valid) ob[a * out_mulp + w] = w < mul_k ? acc : 0.f;
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int w = 4 * wave + g; w < wend; w += 16) {
+#pragma unroll
+            for (int a = 0; a < NCO; ++a)
+                if (valid) ob[a * out_mulp + w] = w < mul_k ? tl[w * rowstride + a * 16] : 0.f;
+        }
+    }
+}
+
+// Stage one input block (all its sources) of the workgroup's 16 edges: image offset(piece p = a * P1 + s, row e) = 64 p + 4 e per source.
+//   plain source  : rows are already in the edge frame -> LDS-DMA, the four waves share the DMA instructions;
+//   rotated source: rows are node features in the global frame, gathered by idx[] and multiplied by D^l(R_e) on the way in
+//                   (x'[a] = sum_b D[a][b] x[b], hamgnn_amd/so3.py) -- ONCE per edge, input block and launch, which replaces the
+//                   separate hg_rotate_gather pass and the materialised per-edge copies xs', xd' of the node rows.
+template <int L>
+__device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restrict__ P, float* __restrict__ stage, int64_t erow, int wave, int lane) {
+    constexpr int N = 2 * L + 1;
+    const int s0 = P[0], s1 = P[1], in_off = P[2], in_mulp = P[3], nsrc = P[5];
+    const int g = lane >> 4, el = lane & 15;
+    const int P1 = in_mulp >> 2;
+    const int Pfull = N * P1;
+    const int nj = (Pfull + 3) >> 2;
+    const bool rot0 = (A.rot_mask >> s0) & 1, rot1 = nsrc == 2 && ((A.rot_mask >> s1) & 1);
+    const float* __restrict__ rowp[2];
+    for (int si = 0; si < nsrc; ++si) {
+        const int sidx = si ? s1 : s0;
+        const int64_t* __restrict__ ix = sidx == 0 ? A.idx[0] : (sidx == 1 ? A.idx[1] : (sidx == 2 ? A.idx[2] : A.idx[3]));
+        const int64_t r = ix ? ix[erow] : erow;
+        rowp[si] = is_pick_src(A, sidx) + r * is_pick_stride(A, sidx) + in_off;
+    }
+    if (nsrc == 1) rowp[1] = rowp[0];
+    for (int si = 0; si < nsrc; ++si) {
+        const float* __restrict__ row = rowp[si];
+        float* __restrict__ dst = stage + (si ? P[7] : P[6]);
+        if (si ? rot1 : rot0) {
+            const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
+#pragma unroll 1
+            for (int t = 4 * wave + g; t < Pfull; t += 16) {
+                const int a = t / P1, p = t - a * P1;
+                f32x4 v[N];
+                float d[N];
+#pragma unroll
+                for (int b = 0; b < N; ++b) {
+                    v[b] = *reinterpret_cast<const f32x4*>(row + b * in_mulp + 4 * p);
+                    d[b] = D[a * N + b];
+                }
+                f32x4 acc = d[0] * v[0];
+#pragma unroll
+                for (int b = 1; b < N; ++b) acc += d[b] * v[b];
+                *reinterpret_cast<f32x4*>(dst + t * 64 + el * 4) = acc;
+            }
+        } else {
+#pragma unroll 1
+            for (int j = wave; j < nj; j += 4) {               // the four waves share the block's DMA instructions
+                int p = 4 * j + g;
+                p = p < Pfull ? p : Pfull - 1;
+                is_dma16(row + 4 * p, dst + j * 256);
+            }
+        }
+    }
+}
+
+#define IS_CASE(MMv, RTMv) \
+    case (MMv * 8 + RTMv): item_is<MMv, RTMv>(A, g_W, it, g_segs + it[19] * 8, lds, erow, lane IS_PROF_PASS); break;
+
+#define SEG_NEWBATCH (1 << 16)
+
+__global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
+                                                       const int* __restrict__ g_phases, const int* __restrict__ g_groups,
+                                                       const int* __restrict__ g_items, const float* __restrict__ g_W) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4;
+    const int64_t e = (int64_t)blockIdx.x * 16 + (lane & 15);
+    const bool valid = e < A.rows;
+    const int64_t erow = valid ? e : A.rows - 1;
+    float* __restrict__ stage = lds + A.stage_off;
+    int* __restrict__ ctr = reinterpret_cast<int*>(lds + A.ctr_off);
+#ifdef HG_PROF
+    ProfIs prof;
+    for (int k = 0; k < 12; ++k) prof.t[k] = 0;
+    prof.last = __builtin_readcyclecounter();
+    const unsigned long long t_begin = prof.last;
+#endif
+
+    for (int i = threadIdx.x; i < A.stage_off; i += 256) lds[i] = 0.f;             // all segment tiles + the trash row
+    IS_T(4);                                                   // zero fill
+
+    for (int ph = 0; ph < A.nphase; ++ph) {
+        const int* __restrict__ P = g_phases + ph * 4;
+        const int b0 = P[0], b1 = P[1], g0 = P[2], g1 = P[3];
+        __syncthreads();                                       // every wave is done with the previous blocks (and the zero fill)
+        IS_T(5);                                               // waiting for the slowest wave of the previous phase
+        if (threadIdx.x == 0) *ctr = g0;
+#pragma unroll 1
+        for (int b = b0; b < b1; ++b) {
+            const int* __restrict__ B = g_blocks + b * 8;
+            switch (B[4]) {
+                case 0: stage_block<0>(A, B, stage, erow, wave, lane); break;
+                case 1: stage_block<1>(A, B, stage, erow, wave, lane); break;
+                case 2: stage_block<2>(A, B, stage, erow, wave, lane); break;
+                case 3: stage_block<3>(A, B, stage, erow, wave, lane); break;
+                case 4: stage_block<4>(A, B, stage, erow, wave, lane); break;
+                case 5: stage_block<5>(A, B, stage, erow, wave, lane); break;
+                case 6: stage_block<6>(A, B, stage, erow, wave, lane); break;
+                default: break;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        IS_T(6);                                               // staging the phase's input blocks
+        // work groups = all items of one (phase, output segment), claimed largest-first: dynamic balance, and a tile is only ever
+        // updated by one wave between two barriers
+        while (true) {
+            int gi = 0;
+            if (lane == 0) gi = atomicAdd(ctr, 1);
+            gi = __builtin_amdgcn_readfirstlane(gi);
+            if (gi >= g1) break;
+            const int ib = g_groups[2 * gi], ie = g_groups[2 * gi + 1];
+            for (int ii = ib; ii < ie; ++ii) {
+                const int* __restrict__ it = g_items + ii * 20;
+                switch (it[6] * 8 + it[9]) {
+                    IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(0, 3) IS_CASE(0, 4)
+                    IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(1, 3) IS_CASE(1, 4)
+                    IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(2, 3) IS_CASE(2, 4)
+                    IS_CASE(3, 1) IS_CASE(3, 2) IS_CASE(3, 3)
+                    IS_CASE(4, 1) IS_CASE(4, 2)
+                    IS_CASE(5, 1) IS_CASE(5, 2)
+                    IS_CASE(6, 1)
+                    default: break;
+                }
+            }
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue: all four waves on one segment at a time; the Wigner
+    // blocks of a batch of segments (one block per l, as many l as fit the staging area) are staged together by LDS-DMA
+    for (int sg = 0; sg < A.nseg; ++sg) {
+        const int* __restrict__ S8 = g_segs + sg * 8;
+        const int lk = S8[0], mul_k = S8[1], out_off = S8[3], out_mulp = S8[4], tile_off = S8[5], woff = S8[6], flags = S8[7];
+        if (sg == 0 || (flags & SEG_NEWBATCH)) {
+            __syncthreads();                                   // tiles complete / previous batch no longer read
+            if (flags & SEG_NEWBATCH) {
+                int lprev = -1;
+                for (int s2 = sg; s2 < A.nseg; ++s2) {
+                    const int* __restrict__ T8 = g_segs + s2 * 8;
+                    if (s2 > sg && (T8[7] & SEG_NEWBATCH)) break;
+                    const int l2 = T8[0];
+                    if (!(T8[7] & SEG_UNROTATE) || l2 == lprev) continue;      // one block per l (segments are ordered by batch, l)
+                    lprev = l2;
+                    const int nn = (2 * l2 + 1) * (2 * l2 + 1);
+                    const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[l2];
+                    const int nj = (nn + 3) >> 2;
+#pragma unroll 1
+                    for (int j = wave; j < nj; j += 4) {       // image [m * NCO + a][edge]
+                        int idx = 4 * j + g;
+                        idx = idx < nn ? idx : nn - 1;
+                        is_dma4(D + idx, stage + T8[6] + j * 64);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+        const float* __restrict__ tile = lds + tile_off;
+        const float* __restrict__ dst = stage + woff;
+        switch (lk) {
+            case 0: epilogue_is<0>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            case 1: epilogue_is<1>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            case 2: epilogue_is<2>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            case 3: epilogue_is<3>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            case 4: epilogue_is<4>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            case 5: epilogue_is<5>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            case 6: epilogue_is<6>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            default: break;
+        }
+    }
+    IS_T(7);                                                   // epilogue
+#ifdef HG_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&hg_prof_is_acc[k], prof.t[k]);
+        atomicAdd(&hg_prof_is_acc[15], prof.last - t_begin);
+    }
+#endif
+}
+
+#ifdef HG_PROF
+extern "C" int hg_prof_is_read(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(hg_prof_is_acc), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(hg_prof_is_acc), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
+
+extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
+                        int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
+                        int nseg, const int32_t* block_table, const int32_t* phase_table, int nphase, const int32_t* group_table,
+                        const int32_t* item_table, int trash_off, int stage_off, int ctr_off, int lds_bytes,
+                        const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream) {
+    if (rows <= 0) return 0;
+    if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_is: nsrc must be 1..4");
+    if (hidden & 15) return hg_fail(-2, "hg_tp_is: (padded) hidden width must be a multiple of 16");
+    if (lds_bytes <= 0 || lds_bytes > 160 * 1024 || lds_bytes < 4 * (ctr_off + 1) || ctr_off < stage_off || stage_off < trash_off)
+        return hg_fail(-2, "hg_tp_is: bad LDS layout");
+    IsArgs A;
+    for (int i = 0; i < 4; ++i) {
+        A.src[i] = i < nsrc ? src[i] : src[0];
+        A.sstride[i] = i < nsrc ? src_stride[i] : src_stride[0];
+    }
+    A.h2[0] = h2_node;
+    A.h2[1] = h2_edge;
+    A.hidden = hidden;
+    A.wig = wig;
+    A.nW = nW;
+    for (int i = 0; i < 8; ++i) A.wig_off[i] = wig_off ? wig_off[i] : 0;
+    A.out = out;
+    A.ostride = out_stride;
+    A.rows = rows;
+    A.nseg = nseg;
+    A.nphase = nphase;
+    A.trash_off = trash_off;
+    A.stage_off = stage_off;
+    A.ctr_off = ctr_off;
+    for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
+    A.rot_mask = rot_mask;
+    if (rot_mask && !wig) return hg_fail(-2, "hg_tp_is: rotated sources need the Wigner rows");
+    if (lds_bytes > 64 * 1024) {
+        hipError_t err = hipFuncSetAttribute((const void*)tp_is_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (err != hipSuccess) return hg_fail(-3, hipGetErrorString(err));
+    }
+    const unsigned grid = (unsigned)((rows + 15) / 16);
+    hipLaunchKernelGGL(tp_is_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table, group_table,
+                       item_table, weights);
+    return hg_check_launch("hg_tp_is");
+}

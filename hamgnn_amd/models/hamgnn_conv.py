@@ -109,15 +109,13 @@ class HamGNNConvE3(nn.Module):
         for conv, pair in zip(self.convolutions, self.pair_interactions):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             skip = conv.skip_linear(node)
-            xs, xd = ops.rotate_gather(node, geo.src, geo, self._rot_tab, x2=node, idx2=geo.dst)
-            msg = conv.conv_tp.run(xs, xd, f, geo)                                   # global frame (un-rotated in the epilogue)
+            msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab)          # global frame (un-rotated in the epilogue)
             agg = ops.segment_sum(msg, rowptr, perm, N)
             parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
             node = conv.residual(agg, extra=skip)
             # ---- PairInteractionBlock.forward (interaction_blocks.py:130-164)
-            xs, xd = ops.rotate_gather(pair.linear_up_src(node), geo.src, geo, self._rot_tab, x2=pair.linear_up_tar(node), idx2=geo.dst)
             if pair.use_skip_connections or not pair.legacy_edge_update:           # legacy layer-0: edge features kept (:154-156)
-                mix = pair.conv_tp.run(xs, xd, f, geo)                              # stays in the edge frame (+ fused skip linear)
+                mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab)   # edge frame (+ fused skip linear)
                 if self.lite_mode and pair.use_skip_connections:
                     mix = ops.add_rows(mix, pair.skip_linear(f))
                 f = mix

@@ -9,6 +9,8 @@ MessagePackBlock (message_passing.py:26-231), ResidualBlock (interaction_blocks.
 (embeddings.py:215-337), HamLayer (models/hamgnn_output.py:38-58)."""
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Dict, List, Optional
 
@@ -118,6 +120,9 @@ class _CombineMessages(nn.Module):
         self.linear_out = E3Linear(irreps_out.simplify(), irreps_out)
 
 
+MP_KERNEL_DEFAULT = "seg"
+
+
 class MessagePackBlock(nn.Module):
     def __init__(self, irreps_node_feats, irreps_edge_feats, irreps_local_env_edge, irreps_out, num_radial, radial_MLP=(64, 64),
                  lite_mode=False):
@@ -154,7 +159,8 @@ class MessagePackBlock(nn.Module):
             prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
             self._hn = self.node_weight_generator.hidden_layers(device)
             self._he = self.edge_weight_generator.hidden_layers(device)
-        self._dp = ops.DeviceProgram(prog, device)
+        # HG_MP_KERNEL = seg | is | auto: which schedule of the fused MessagePackBlock program runs (default: see DESIGN.md section 5)
+        self._dp = ops.DeviceProgram(prog, device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
         return self
 
     def run(self, xs_rot, xd_rot, f_rot, geo: ops.Geometry):
@@ -163,6 +169,19 @@ class MessagePackBlock(nn.Module):
         hn = ops.radial_hidden(geo.rbf, self._hn, cst)
         he = ops.radial_hidden(geo.rbf, self._he, cst) if self._he is not None else None
         return ops.tp_fused(self._dp, [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo, tag="message_pack")
+
+    def run_nodes(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab):
+        """node_s / node_d: planar NODE rows (global frame) whose sender / receiver gathers feed the block
+        (convolution.py:138-141, interaction_blocks.py:141-145).  Input-stationary schedule: gathered and rotated inside the kernel;
+        otherwise through hg_rotate_gather."""
+        if self._dp.sched is None:
+            xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)
+            return self.run(xs, xd, f_rot, geo)
+        cst = float(P.ACT_CONSTS[P.ACT_SILU])
+        hn = ops.radial_hidden(geo.rbf, self._hn, cst)
+        he = ops.radial_hidden(geo.rbf, self._he, cst) if self._he is not None else None
+        return ops.tp_fused(self._dp, [node_s, node_d, f_rot], geo.E, hn, he, geo, tag="message_pack", gather=[geo.src, geo.dst, None],
+                            rot_mask=0b011)
 
 
 class ResidualBlock(nn.Module):

@@ -31,7 +31,9 @@ def _require_gpu(t: torch.Tensor):
 class DeviceProgram:
     """A plan.Program uploaded to the GPU."""
 
-    def __init__(self, prog: P.Program, device):
+    def __init__(self, prog: P.Program, device, schedule: str = "seg"):
+        """schedule: "seg" = segment-stationary kernel only (hg_tp_fused); "is" / "auto" = also build the input-stationary
+        schedule (hg_tp_is); "auto" silently keeps "seg" when it does not fit."""
         self.prog = prog
         self.weights = _dev(prog.weights, device)
         self.segs = _dev(prog.seg_table, device)
@@ -41,6 +43,17 @@ class DeviceProgram:
         self.out_dim = int(prog.out_layout.dim)
         self.lds_bytes = int(prog.tile_floats) * 4
         self.flags = 1 if (prog.item_table.shape[0] and (prog.item_table[:, 0] == P.IT_POST).any()) else 0
+        # input-stationary schedule of the same items (csrc/tp_is.hip) when the tiles of all output segments fit the LDS
+        self.sched = None
+        if schedule in ("is", "auto"):
+            try:
+                sc = P.is_schedule(prog)
+                self.sched = sc
+                self.is_segs, self.is_blocks, self.is_phases, self.is_groups, self.is_items = (
+                    _dev(t, device) for t in (sc.seg_table, sc.block_table, sc.phase_table, sc.group_table, sc.item_table))
+            except NotImplementedError:
+                if schedule == "is":
+                    raise
 
 
 def wig_offsets(lmax):
@@ -111,8 +124,11 @@ PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, rows, 
 
 
 def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None,
-             tag: str = "linear") -> torch.Tensor:
+             tag: str = "linear", gather: Optional[List[Optional[torch.Tensor]]] = None, rot_mask: int = 0) -> torch.Tensor:
+    """gather / rot_mask (input-stationary schedule only): srcs[i] holds global-frame node rows, gathered by gather[i] and rotated
+    into the edge frame inside the kernel (bit i of rot_mask) instead of a separate hg_rotate_gather pass."""
     _require_gpu(srcs[0])
+    assert (gather is None and rot_mask == 0) or dp.sched is not None
     out = torch.empty(rows, dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
@@ -121,8 +137,18 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     if PROFILE_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
-    check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
-                            i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), i32(dp.flags), _stream()), "hg_tp_fused")
+    if dp.sched is not None:
+        sc = dp.sched
+        gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
+        gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
+        check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.is_segs),
+                             i32(dp.nseg), ptr(dp.is_blocks), ptr(dp.is_phases), i32(sc.phase_table.shape[0]), ptr(dp.is_groups),
+                             ptr(dp.is_items), i32(sc.trash_off), i32(sc.stage_off), i32(sc.ctr_off), i32(sc.lds_floats * 4), gp,
+                             i32(rot_mask), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
+    else:
+        check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
+                                i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), i32(dp.flags), _stream()),
+              "hg_tp_fused")
     if PROFILE_EVENTS is not None:
         ev1.record()
         PROFILE_EVENTS.append((ev0, ev1, rows, tag))

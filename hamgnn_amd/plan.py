@@ -157,6 +157,142 @@ class Program:
         return self
 
 
+# ---- input-stationary schedule (csrc/tp_is.hip): the SAME items, regrouped by input irrep block ------------------------------
+IS_WAVES = 4                       # waves of a workgroup; all of them work on the same 16 edges
+IS_BLOCK_I32 = 8                   # {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
+IS_PHASE_I32 = 4                   # {block_begin, block_end, group_begin, group_end}
+IS_LDS_BYTES = 80 * 1024           # two workgroups per CU
+
+
+@dataclass
+class IsSchedule:
+    seg_table: np.ndarray          # int32[nseg][8] = {lk, mul_k, rto, out_off, out_mulp, tile_off, wigner stage_off, flags | batch bit}
+    block_table: np.ndarray        # int32[nblock][8]: input irrep blocks; stage offsets in floats relative to the staging area
+    phase_table: np.ndarray        # int32[nphase][4]: the blocks staged together and the work groups that read them
+    group_table: np.ndarray        # int32[ngroup][2] = {item_begin, item_end}: all items of one (phase, output segment); claimed
+    #                                dynamically by the waves (largest first), so no two waves update one tile between barriers
+    item_table: np.ndarray         # int32[nitems][20]: Program.item_table records with [1], [2] = stage offsets of source 0 / 1 (-1)
+    trash_off: int                 # float offset of the shared trash row (absorbs fragment-padding rows)
+    stage_off: int                 # float offset of the staging area
+    stage_floats: int
+    ctr_off: int                   # float offset of the work-claim counter
+    lds_floats: int
+    balance: float                 # LPT estimate: sum(cost) / (waves * sum over phases of max wave cost)
+
+
+SEG_NEWBATCH = 1 << 16             # IS epilogue: this segment starts a new Wigner staging batch
+
+
+def is_schedule(prog: "Program") -> IsSchedule:
+    """Regroup a finalized fused-kernel program for the input-stationary kernel.  Input irrep blocks (per source set) are packed
+    into phases whose staged rows fit the staging area; every item reading a staged block runs in that phase.  Raises
+    NotImplementedError when the tiles of all output segments + a useful staging area do not fit IS_LDS_BYTES."""
+    if (prog.item_table[:, 0] == IT_POST).any() or (prog.item_table[:, 0] == IT_LINC).any():
+        raise NotImplementedError("lite_mode programs run on the segment-stationary kernel")
+    segs = prog.seg_table.copy()
+    off, maxstride = 0, 0
+    for s in segs:
+        lk, mul_k = int(s[0]), int(s[1])
+        stride = (2 * lk + 1) * 16 + 4
+        s[5], s[6] = off, 0
+        off += mul_k * stride
+        maxstride = max(maxstride, stride)
+    trash_off = off
+    stage_off = trash_off + maxstride
+    stage_floats = IS_LDS_BYTES // 4 - stage_off - 4
+    ctr_off = stage_off + stage_floats
+    # ---- input blocks
+    blocks: Dict[Tuple[int, int, int], dict] = {}
+    for rec in prog.item_table:
+        key = (int(rec[1]), int(rec[2]), int(rec[3]))
+        b = blocks.setdefault(key, dict(key=key, in_mulp=int(rec[4]), li=int(rec[5]), items=[]))
+        assert b["in_mulp"] == int(rec[4]) and b["li"] == int(rec[5])
+        b["items"].append(rec)
+    for b in blocks.values():
+        b["nsrc"] = 2 if b["key"][1] >= 0 else 1
+        b["src_floats"] = ceil_div((2 * b["li"] + 1) * (b["in_mulp"] // 4), 4) * 256
+        b["floats"] = b["nsrc"] * b["src_floats"]
+        if b["floats"] > stage_floats:
+            raise NotImplementedError(f"input-stationary schedule: LDS staging area of {stage_floats * 4} B is smaller than an input block")
+    # ---- phases: first-fit decreasing packing of the blocks into the staging area
+    phases: List[List[dict]] = []
+    for b in sorted(blocks.values(), key=lambda b: -b["floats"]):
+        for ph in phases:
+            if sum(x["floats"] for x in ph) + b["floats"] <= stage_floats:
+                ph.append(b)
+                break
+        else:
+            phases.append([b])
+    hp4 = prog.hidden_pad // 4
+
+    def cost(rec):
+        typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
+        c = nsrc * int(rec[8]) * rtm * nc + 60                 # GEMM1 + a per-item latency allowance (in MFMA slots)
+        if typ == IT_TP:
+            c += hp4 * rtm + int(segs[int(rec[19])][2]) * int(rec[18]) * nc
+        return c
+    btab, ptab, gtab, items, tot, crit = [], [], [], [], 0, 0
+    for ph in phases:
+        ph.sort(key=lambda b: -b["key"][0])                    # edge-row blocks (plain LDS-DMA) first: their latency runs under the
+        b0, g0, o = len(btab), len(gtab), 0                    # rotation work of the node-row blocks
+        by_seg: Dict[int, List[np.ndarray]] = {}
+        for b in ph:
+            s0, s1, in_off = b["key"]
+            o0, o1 = o, (o + b["src_floats"] if b["nsrc"] == 2 else -1)
+            o += b["floats"]
+            btab.append([s0, s1, in_off, b["in_mulp"], b["li"], b["nsrc"], o0, o1])
+            for rec in b["items"]:
+                r = rec.copy()
+                r[1], r[2], r[3] = o0, o1, 0
+                by_seg.setdefault(int(rec[19]), []).append(r)
+        groups = sorted(((sum(cost(r) for r in recs), sg) for sg, recs in by_seg.items()), reverse=True)
+        loads = [0] * IS_WAVES
+        for c, sg in groups:                                   # claim order = LPT order
+            loads[loads.index(min(loads))] += c
+            gtab.append([len(items), len(items) + len(by_seg[sg])])
+            items += by_seg[sg]
+        tot += sum(loads)
+        crit += max(loads)
+        ptab.append([b0, len(btab), g0, len(gtab)])
+    # ---- epilogue: Wigner blocks of the un-rotated segments staged in as few batches as fit the staging area (one block per l)
+    need = {}
+    for sg in segs:
+        if int(sg[7]) & SEG_UNROTATE:
+            need[int(sg[0])] = ceil_div((2 * int(sg[0]) + 1) ** 2, 4) * 64
+    batches: List[List[int]] = []
+    for l in sorted(need, key=lambda l: -need[l]):
+        if need[l] > stage_floats:
+            raise NotImplementedError("input-stationary schedule: staging area smaller than a Wigner block")
+        for bt in batches:
+            if sum(need[x] for x in bt) + need[l] <= stage_floats:
+                bt.append(l)
+                break
+        else:
+            batches.append([l])
+    woff, batch_of = {}, {}
+    for bi, bt in enumerate(batches):
+        o = 0
+        for l in bt:
+            woff[l], batch_of[l] = o, bi
+            o += need[l]
+    order = sorted(range(len(segs)), key=lambda i: (batch_of.get(int(segs[i][0]), -1) if int(segs[i][7]) & SEG_UNROTATE else -1))
+    remap = {old: new for new, old in enumerate(order)}
+    segs2 = segs[order].copy()
+    prev = None
+    for sg in segs2:
+        if int(sg[7]) & SEG_UNROTATE:
+            l = int(sg[0])
+            sg[6] = woff[l]
+            if batch_of[l] != prev:
+                sg[7] |= SEG_NEWBATCH
+                prev = batch_of[l]
+    items = np.asarray(items, np.int32).reshape(-1, ITEM_I32)
+    items[:, 19] = [remap[int(x)] for x in items[:, 19]]
+    return IsSchedule(segs2.astype(np.int32), np.asarray(btab, np.int32).reshape(-1, IS_BLOCK_I32),
+                      np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
+                      trash_off, stage_off, stage_floats, ctr_off, ctr_off + 4, tot / (IS_WAVES * crit) if crit else 1.0)
+
+
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:
     """mat[k, row] -> A fragments [ngrp][rtm][64 lanes][4]: one float4 per lane covers 4 MFMA K-steps (q = 0..3).
     lane L = (i = L&15, g = L>>4) holds mat[k(G, q, g)][16 rt + i] with
@@ -193,7 +329,7 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
     if (2 * mm + 1) * in_mulp > 160:
         raise NotImplementedError(f"input irrep block too wide for the kernel's B staging ring: (2*{mm}+1) x {in_mulp} channels > 160")
     rec = [typ, srcs[0], srcs[1] if len(srcs) == 2 else -1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp,
-           a1, w3, cf, a2, nrows, row_off, 1 if use_x4(in_mulp, 2 * mm + 1) else 0, nk2, 0]
+           a1, w3, cf, a2, nrows, row_off, 1 if use_x4(in_mulp, 2 * mm + 1) else 0, nk2, seg]
     assert len(rec) == ITEM_I32
     prog.seg_items[seg].append(rec)
     nc = 2 * mm + 1

@@ -7,6 +7,7 @@ from hamgnn_amd import nn as hnn, ops, plan as P
 IRR = {"A": "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e", "B": "64x0e+32x1o+16x1e+8x2o+20x2e+8x3o+4x3e+4x4e"}
 ap = argparse.ArgumentParser(); ap.add_argument("--irreps", default="A"); ap.add_argument("--edges", type=int, default=131072)
 ap.add_argument("--reps", type=int, default=5); ap.add_argument("--tag", default=""); ap.add_argument("--same-rows", type=int, default=0, help="alias the B-operand rows onto this many distinct rows (cache-residency experiment)")
+ap.add_argument("--nodes", type=int, default=0, help="feed NODE rows + random sender/receiver indices (gather + rotation fused into the input-stationary kernel, or hg_rotate_gather + kernel otherwise) instead of pre-rotated edge rows")
 a = ap.parse_args()
 irr, sh = IRR[a.irreps], "0e+1o+2e+3o+4e+5o"
 torch.manual_seed(0)
@@ -29,19 +30,38 @@ if a.same_rows:
     else:   # rows repeat with period k: footprint k * 3 * Dp * 4 bytes
         xs, xd, fe = (t[:k].repeat((E + k - 1) // k, 1)[:E].contiguous() for t in (xs, xd, fe))
 hn = ops.radial_hidden(geo.rbf, m._hn, 1.679); he = ops.radial_hidden(geo.rbf, m._he, 1.679)
+if a.nodes:
+    node = torch.randn(a.nodes, lay.dim, generator=g).to(dev)
+    geo.src = torch.randint(0, a.nodes, (E,), generator=g).to(dev)
+    geo.dst = torch.randint(0, a.nodes, (E,), generator=g).to(dev)
+    rot = torch.from_numpy(P.rotate_table(lay)).to(dev)
+    launch = lambda: m.run_nodes(node, node, fe, geo, rot)
+else:
+    launch = lambda: ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)
 for _ in range(2):
-    out = ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)
+    out = launch()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.reps):
-    out = ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)
+    out = launch()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
 prog = m._dp.prog
 print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
                   "issued_TF": prog.mfma_per_wave * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
                   "Medges_s": E / dt / 1e6, "checksum": float(out.double().abs().mean())}))
-if os.environ.get("HG_PROF"):
+if os.environ.get("HG_PROF") and m._dp.sched is not None:
+    import ctypes as C
+    from hamgnn_amd import _lib
+    L = _lib.lib()
+    buf = (C.c_ulonglong * 16)()
+    L.hg_prof_is_read(buf, 1)
+    launch()
+    L.hg_prof_is_read(buf, 0)
+    names = ["dispatch", "radial scale", "GEMM1", "scale-mul + GEMM2 + write-back", "zero fill", "phase barrier (imbalance)", "staging", "epilogue"]
+    tot = float(buf[15])
+    print(json.dumps({"prof_total_wave_cycles": tot, "balance": m._dp.sched.balance, **{n: round(buf[k] / tot, 4) for k, n in enumerate(names)}}))
+elif os.environ.get("HG_PROF"):
     import ctypes as C
     from hamgnn_amd import _lib
     L = _lib.lib()

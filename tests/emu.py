@@ -43,106 +43,164 @@ def radial_hidden(rbf, layers):
     return h
 
 
+def _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype):
+    """one item record on one 16-edge column tile, fragment-exact (tile: [rto*16, nco, 16], updated in place / returned)."""
+    E = srcs[0].shape[0]
+    H = prog.hidden
+    (typ, s0, s1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off) = (int(v) for v in it[:17])
+    nco = 2 * lk + 1
+    if typ == P.IT_POST:                                   # tile <- Lc^T (s_e * tile), fragment-exact
+        Hp = prog.hidden_pad
+        W3 = Wt[w3:w3 + (Hp // 16) * rto * 256].reshape(Hp // 16, rto, 4, 16, 4)
+        hh = np.zeros((E, Hp), dtype=dtype)
+        hh[:, :H] = h2[0]
+        S = np.zeros((rto, 16, 16), dtype=dtype)
+        for G in range(Hp // 16):
+            for q in range(4):
+                B = np.zeros((4, 16), dtype=dtype)
+                for g in range(4):
+                    B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
+                for rt in range(rto):
+                    S[rt] += W3[G, rt, :, :, q].T @ B
+        A2 = Wt[a2:a2 + rto * rto * 256].reshape(rto, rto, 4, 16, 4)
+        new = np.zeros_like(tile)
+        for c in range(nco):
+            md = tile[:, c, :].reshape(rto, 16, 16) * S
+            for rtp in range(rto):
+                acc = np.zeros((16, 16), dtype=dtype)
+                for rt in range(rto):
+                    for r in range(4):
+                        acc += A2[rtp, rt, :, :, r].T @ md[rt][r::4, :]
+                new[16 * rtp:16 * rtp + 16, c] = acc
+        return new
+    nc = 2 * mm + 1
+    nsrc = 2 if s1 >= 0 else 1
+    x4 = int(it[17])
+    ngrp = -(-ksteps // 4)
+    A1 = Wt[a1:a1 + nsrc * ngrp * rtm * 256].reshape(nsrc, ngrp, rtm, 4, 16, 4)      # [src][G][rt][g][i][q]
+    mid = np.zeros((rtm, nc, 16, 16), dtype=dtype)
+    for si, sidx in enumerate([s0, s1][:nsrc]):
+        X = srcs[sidx]
+        for c in range(nc):
+            m = c - mm
+            a = li + (-m if neg else m)
+            base = in_off + a * in_mulp
+            for G in range(ngrp):
+                for q in range(4):
+                    if not x4 and 4 * G + q >= ksteps:
+                        continue
+                    B = np.zeros((4, 16), dtype=dtype)             # B[k = g][j = edge]
+                    for g in range(4):
+                        u = 16 * G + 4 * g + q if x4 else 4 * (4 * G + q) + g
+                        B[g, :ne] = X[cols, base + u]
+                    for rt in range(rtm):
+                        mid[rt, c] += A1[si, G, rt, :, :, q].T @ B
+    if typ == P.IT_TP:
+        Hp = prog.hidden_pad
+        W3 = Wt[w3:w3 + (Hp // 16) * rtm * 256].reshape(Hp // 16, rtm, 4, 16, 4)        # [G][rt][g][i][q]
+        S = np.zeros((rtm, 16, 16), dtype=dtype)
+        hh = np.zeros((E, Hp), dtype=dtype)
+        hh[:, :H] = h2[mlp]
+        for G in range(Hp // 16):
+            for q in range(4):
+                B = np.zeros((4, 16), dtype=dtype)
+                for g in range(4):
+                    B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
+                for rt in range(rtm):
+                    S[rt] += W3[G, rt, :, :, q].T @ B
+        CF = Wt[cf:cf + rtm * nc * 16].reshape(rtm, nc, 16)                           # [rt][c][row = 4g + r]
+        mid = mid * S[:, None, :, :] * CF[:, :, :, None]
+        A2 = Wt[a2:a2 + rto * rtm * 4 * 64].reshape(rto, rtm, 4, 16, 4)               # [rt'][rt][k=g][i][r]
+        for rtp in range(rto):
+            for c in range(nc):
+                acc = np.zeros((16, 16), dtype=dtype)
+                for rt in range(rtm):
+                    for r in range(4):
+                        if 4 * rt + r >= int(it[18]):                                # K-steps of pure padding are not issued
+                            continue
+                        Bm = mid[rt, c][r::4, :]                                     # rows 4k + r, k = 0..3
+                        acc += A2[rtp, rt, :, :, r].T @ Bm
+                tile[16 * rtp:16 * rtp + 16, lk - mm + c] += acc
+    else:
+        if typ == P.IT_LINC:
+            mid = mid * Wt[cf:cf + nc][None, :, None, None]
+        for rt in range(rtm):
+            r0 = row_off + 16 * rt
+            tile[r0:r0 + 16, lk - mm:lk + mm + 1] += mid[rt].transpose(1, 0, 2)
+    return tile
+
+
+def _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype):
+    lk, mul_k, rto, out_off, out_mulp = (int(v) for v in seg[:5])
+    flags = int(seg[7])
+    nco = 2 * lk + 1
+    t = tile[:mul_k, :, :ne]                                                              # [w, m, e]
+    if flags & P.SEG_UNROTATE:
+        Dl = D[cols, woffs[lk]:woffs[lk] + nco * nco].reshape(ne, nco, nco)
+        t = np.einsum("ema,wme->wae", Dl, t)                                              # out[a] = sum_m D[m][a] t[m]
+    blk = np.zeros((ne, nco, out_mulp), dtype=dtype)
+    blk[:, :, :mul_k] = t.transpose(2, 1, 0)
+    out[cols, out_off:out_off + nco * out_mulp] = blk.reshape(ne, -1)
+
+
 def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
     """srcs: list of planar [E, dim] arrays (slot order).  Returns planar out [E, out_layout.dim]."""
     E = srcs[0].shape[0]
     Wt = prog.weights.astype(dtype)
     out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
-    H = prog.hidden
     woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
     for e0 in range(0, E, 16):
         ne = min(16, E - e0)
         cols = np.arange(e0, e0 + ne)
         for seg in prog.seg_table:
             lk, mul_k, rto, out_off, out_mulp, ib, ie, flags = (int(v) for v in seg)
-            nco = 2 * lk + 1
-            tile = np.zeros((rto * 16, nco, 16), dtype=dtype)
+            tile = np.zeros((rto * 16, 2 * lk + 1, 16), dtype=dtype)
             for it in prog.item_table[ib:ie]:
-                (typ, s0, s1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off) = (int(v) for v in it[:17])
-                if typ == P.IT_POST:                                   # tile <- Lc^T (s_e * tile), fragment-exact
-                    Hp = prog.hidden_pad
-                    W3 = Wt[w3:w3 + (Hp // 16) * rto * 256].reshape(Hp // 16, rto, 4, 16, 4)
-                    hh = np.zeros((E, Hp), dtype=dtype)
-                    hh[:, :H] = h2[0]
-                    S = np.zeros((rto, 16, 16), dtype=dtype)
-                    for G in range(Hp // 16):
-                        for q in range(4):
-                            B = np.zeros((4, 16), dtype=dtype)
-                            for g in range(4):
-                                B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
-                            for rt in range(rto):
-                                S[rt] += W3[G, rt, :, :, q].T @ B
-                    A2 = Wt[a2:a2 + rto * rto * 256].reshape(rto, rto, 4, 16, 4)
-                    new = np.zeros_like(tile)
-                    for c in range(nco):
-                        md = tile[:, c, :].reshape(rto, 16, 16) * S
-                        for rtp in range(rto):
-                            acc = np.zeros((16, 16), dtype=dtype)
-                            for rt in range(rto):
-                                for r in range(4):
-                                    acc += A2[rtp, rt, :, :, r].T @ md[rt][r::4, :]
-                            new[16 * rtp:16 * rtp + 16, c] = acc
-                    tile = new
-                    continue
-                nc = 2 * mm + 1
-                nsrc = 2 if s1 >= 0 else 1
-                x4 = int(it[17])
-                ngrp = -(-ksteps // 4)
-                A1 = Wt[a1:a1 + nsrc * ngrp * rtm * 256].reshape(nsrc, ngrp, rtm, 4, 16, 4)      # [src][G][rt][g][i][q]
-                mid = np.zeros((rtm, nc, 16, 16), dtype=dtype)
-                for si, sidx in enumerate([s0, s1][:nsrc]):
-                    X = srcs[sidx]
-                    for c in range(nc):
-                        m = c - mm
-                        a = li + (-m if neg else m)
-                        base = in_off + a * in_mulp
-                        for G in range(ngrp):
-                            for q in range(4):
-                                if not x4 and 4 * G + q >= ksteps:
-                                    continue
-                                B = np.zeros((4, 16), dtype=dtype)             # B[k = g][j = edge]
-                                for g in range(4):
-                                    u = 16 * G + 4 * g + q if x4 else 4 * (4 * G + q) + g
-                                    B[g, :ne] = X[cols, base + u]
-                                for rt in range(rtm):
-                                    mid[rt, c] += A1[si, G, rt, :, :, q].T @ B
-                if typ == P.IT_TP:
-                    Hp = prog.hidden_pad
-                    W3 = Wt[w3:w3 + (Hp // 16) * rtm * 256].reshape(Hp // 16, rtm, 4, 16, 4)        # [G][rt][g][i][q]
-                    S = np.zeros((rtm, 16, 16), dtype=dtype)
-                    hh = np.zeros((E, Hp), dtype=dtype)
-                    hh[:, :H] = h2[mlp]
-                    for G in range(Hp // 16):
-                        for q in range(4):
-                            B = np.zeros((4, 16), dtype=dtype)
-                            for g in range(4):
-                                B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
-                            for rt in range(rtm):
-                                S[rt] += W3[G, rt, :, :, q].T @ B
-                    CF = Wt[cf:cf + rtm * nc * 16].reshape(rtm, nc, 16)                           # [rt][c][row = 4g + r]
-                    mid = mid * S[:, None, :, :] * CF[:, :, :, None]
-                    A2 = Wt[a2:a2 + rto * rtm * 4 * 64].reshape(rto, rtm, 4, 16, 4)               # [rt'][rt][k=g][i][r]
-                    for rtp in range(rto):
-                        for c in range(nc):
-                            acc = np.zeros((16, 16), dtype=dtype)
-                            for rt in range(rtm):
-                                for r in range(4):
-                                    if 4 * rt + r >= int(it[18]):                                # K-steps of pure padding are not issued
-                                        continue
-                                    Bm = mid[rt, c][r::4, :]                                     # rows 4k + r, k = 0..3
-                                    acc += A2[rtp, rt, :, :, r].T @ Bm
-                            tile[16 * rtp:16 * rtp + 16, lk - mm + c] += acc
-                else:
-                    if typ == P.IT_LINC:
-                        mid = mid * Wt[cf:cf + nc][None, :, None, None]
-                    for rt in range(rtm):
-                        r0 = row_off + 16 * rt
-                        tile[r0:r0 + 16, lk - mm:lk + mm + 1] += mid[rt].transpose(1, 0, 2)
-            t = tile[:mul_k, :, :ne]                                                              # [w, m, e]
-            if flags & P.SEG_UNROTATE:
-                Dl = D[cols, woffs[lk]:woffs[lk] + nco * nco].reshape(ne, nco, nco)
-                t = np.einsum("ema,wme->wae", Dl, t)                                              # out[a] = sum_m D[m][a] t[m]
-            blk = np.zeros((ne, nco, out_mulp), dtype=dtype)
-            blk[:, :, :mul_k] = t.transpose(2, 1, 0)
-            out[cols, out_off:out_off + nco * out_mulp] = blk.reshape(ne, -1)
+                tile = _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype)
+            _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)
+    return out
+
+
+def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
+    """the input-stationary schedule (plan.is_schedule, csrc/tp_is.hip): phases -> work groups -> items, all segment tiles live at
+    once; items address their sources through the phase's staged blocks."""
+    E = srcs[0].shape[0]
+    Wt = prog.weights.astype(dtype)
+    out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
+    woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
+    for e0 in range(0, E, 16):
+        ne = min(16, E - e0)
+        cols = np.arange(e0, e0 + ne)
+        tiles = [np.zeros((int(s[2]) * 16, 2 * int(s[0]) + 1, 16), dtype=dtype) for s in sched.seg_table]
+        seen = set()
+        for b0, b1, g0, g1 in sched.phase_table:
+            staged = {}
+            used = 0
+            for blk in sched.block_table[b0:b1]:
+                s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in blk)
+                size = -(-((2 * li + 1) * (in_mulp // 4)) // 4) * 256
+                assert o0 == used and (o1 == o0 + size if nsrc == 2 else o1 == -1)
+                used += nsrc * size
+                staged[o0] = (s0, s1, in_off, in_mulp, li)
+            assert used <= sched.stage_floats
+            owner = set()
+            for gi in range(g0, g1):
+                ib, ie = (int(v) for v in sched.group_table[gi])
+                sgs = set()
+                for ii in range(ib, ie):
+                    it = sched.item_table[ii].copy()
+                    s0, s1, in_off, in_mulp, li = staged[int(it[1])]
+                    assert (int(it[4]), int(it[5])) == (in_mulp, li) and ((int(it[2]) >= 0) == (s1 >= 0))
+                    it[1], it[2], it[3] = s0, s1, in_off
+                    assert ii not in seen
+                    seen.add(ii)
+                    sg = int(it[19])
+                    sgs.add(sg)
+                    seg = sched.seg_table[sg]
+                    tiles[sg] = _apply_item(prog, Wt, it, srcs, h2, cols, ne, tiles[sg], int(seg[0]), int(seg[2]), dtype)
+                assert len(sgs) == 1 and not (sgs & owner), "a tile must belong to exactly one work group per phase"
+                owner |= sgs
+        assert len(seen) == sched.item_table.shape[0]
+        for sg, seg in enumerate(sched.seg_table):
+            _write_segment(prog, seg, tiles[sg], out, cols, ne, D, woffs, dtype)
     return out

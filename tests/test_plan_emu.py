@@ -175,3 +175,29 @@ def test_head_su2_tables():
     H = ref.reorder_matrix(H.reshape(-1, nao * nao)).reshape(-1, 2, 2, nao, nao).swapaxes(2, 3).reshape(-1, 4 * nao * nao)
     want = torch.cat([H.real, H.imag], 1).detach().numpy()
     assert rel(got, want) < 1e-6
+
+
+def test_input_stationary_schedule_vs_golden(golden_dir):
+    """plan.is_schedule (csrc/tp_is.hip): same items regrouped by input block -> identical result; schedule invariants."""
+    f = load(golden_dir, "message_pack_block")
+    sd, i = f["weights"], f["inputs"]
+    lay = P.PlanarLayout(MINI)
+    lmax = 3
+    n = i["sh"][:, 1:4] / math.sqrt(3.0)
+    D = emu.edge_wigner_all(n, lmax)
+    xs, xd, fe = (emu.rotate_rows(lay.to_planar(i[k]), lay, D, lmax) for k in ("src", "dst", "edge_feats"))
+    hn = emu.radial_hidden(i["rbf"], P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
+    he = emu.radial_hidden(i["rbf"], P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
+    skip = np.random.default_rng(3).standard_normal(so3.Irreps(MINI).dim * 0 + sum(m * m for m, _, _ in so3.Irreps(MINI)))
+    prog = P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=True)
+    sched = P.is_schedule(prog)
+    assert sched.item_table.shape == prog.item_table.shape and sched.lds_floats * 4 <= P.IS_LDS_BYTES
+    assert sched.ctr_off == sched.stage_off + sched.stage_floats and sched.balance > 0.5
+    outp = emu.run_program_is(prog, sched, [xs, xd, fe], (hn, he), D, lmax)
+    assert rel(lay.from_planar(outp), f["outputs"]["out"]) < 1e-6
+    assert rel(outp, emu.run_program(prog, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
+    # with the PairInteractionBlock skip o3.Linear folded in (extra linear items in the edge-row phases)
+    prog2 = P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=False, skip_weight=skip)
+    s2 = P.is_schedule(prog2)
+    a = emu.run_program_is(prog2, s2, [xs, xd, fe], (hn, he), D, lmax)
+    assert rel(a, emu.run_program(prog2, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
