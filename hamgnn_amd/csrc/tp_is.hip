@@ -64,6 +64,12 @@ __device__ __forceinline__ const float* is_pick_src(const IsArgs& A, int i) {
 __device__ __forceinline__ int64_t is_pick_stride(const IsArgs& A, int i) {
     return i == 0 ? A.sstride[0] : (i == 1 ? A.sstride[1] : (i == 2 ? A.sstride[2] : A.sstride[3]));
 }
+// (kernel-argument arrays are only ever indexed through select chains: a dynamically indexed member makes the compiler copy the whole
+//  argument block into per-lane scratch -- 232 B x 2.1 M lanes = 0.5 GB of HBM writes per launch in the first build)
+__device__ __forceinline__ int is_pick_wig_off(const IsArgs& A, int l) {
+    return l == 0 ? A.wig_off[0] : (l == 1 ? A.wig_off[1] : (l == 2 ? A.wig_off[2] : (l == 3 ? A.wig_off[3] : (l == 4 ? A.wig_off[4] :
+           (l == 5 ? A.wig_off[5] : (l == 6 ? A.wig_off[6] : A.wig_off[7]))))));
+}
 // LDS-DMA: per-lane global address -> LDS at (wave-uniform base + lane * size); counted by vmcnt
 __device__ __forceinline__ void is_dma16(const float* __restrict__ gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
@@ -270,15 +276,22 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
     const float* __restrict__ tl = tile + el;
     float* __restrict__ ob = A.out + e * A.ostride + out_off;
     const int wend = mul_k + ((flags >> 8) & 0xff);            // + channel-padding slots of the planar block (last chunk only)
+    // work unit = (output component a, 16 consecutive channels): one wave writes 64 contiguous bytes per edge and component in four
+    // back-to-back stores, so the memory side sees whole sectors (interleaving the channels of one component over the waves
+    // tripled the HBM write traffic: WRITE_SIZE 1.39 GB vs 0.46 GB of output per 131 072 edges)
+    const int nw16 = (wend + 15) >> 4;
+    const int U = NCO * nw16, per = (U + 3) >> 2;              // each wave takes a contiguous range of units (adjacent bytes of the row)
+    const int u_begin = wave * per, u_end = (u_begin + per) < U ? (u_begin + per) : U;
     if (flags & SEG_UNROTATE) {
         const float* __restrict__ dl = dstage + el;
 #pragma unroll 1
-        for (int a = 0; a < NCO; ++a) {
+        for (int u = u_begin; u < u_end; ++u) {
+            const int a = u / nw16, w0 = (u - a * nw16) * 16;
             float dc[NCO];
 #pragma unroll
             for (int m = 0; m < NCO; ++m) dc[m] = dl[(m * NCO + a) * 16];
 #pragma unroll 1
-            for (int w = 4 * wave + g; w < wend; w += 16) {
+            for (int w = w0 + g; w < wend && w < w0 + 16; w += 4) {
                 const float* __restrict__ tw = tl + (w < mul_k ? w : 0) * rowstride;
                 float acc = 0.f;
 #pragma unroll
@@ -288,9 +301,10 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
         }
     } else {
 #pragma unroll 1
-        for (int w = 4 * wave + g; w < wend; w += 16) {
-#pragma unroll
-            for (int a = 0; a < NCO; ++a)
+        for (int u = u_begin; u < u_end; ++u) {
+            const int a = u / nw16, w0 = (u - a * nw16) * 16;
+#pragma unroll 1
+            for (int w = w0 + g; w < wend && w < w0 + 16; w += 4)
                 if (valid) ob[a * out_mulp + w] = w < mul_k ? tl[w * rowstride + a * 16] : 0.f;
         }
     }
@@ -310,16 +324,11 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
     const int Pfull = N * P1;
     const int nj = (Pfull + 3) >> 2;
     const bool rot0 = (A.rot_mask >> s0) & 1, rot1 = nsrc == 2 && ((A.rot_mask >> s1) & 1);
-    const float* __restrict__ rowp[2];
     for (int si = 0; si < nsrc; ++si) {
         const int sidx = si ? s1 : s0;
         const int64_t* __restrict__ ix = sidx == 0 ? A.idx[0] : (sidx == 1 ? A.idx[1] : (sidx == 2 ? A.idx[2] : A.idx[3]));
         const int64_t r = ix ? ix[erow] : erow;
-        rowp[si] = is_pick_src(A, sidx) + r * is_pick_stride(A, sidx) + in_off;
-    }
-    if (nsrc == 1) rowp[1] = rowp[0];
-    for (int si = 0; si < nsrc; ++si) {
-        const float* __restrict__ row = rowp[si];
+        const float* __restrict__ row = is_pick_src(A, sidx) + r * is_pick_stride(A, sidx) + in_off;
         float* __restrict__ dst = stage + (si ? P[7] : P[6]);
         if (si ? rot1 : rot0) {
             const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A, const int
                     if (!(T8[7] & SEG_UNROTATE) || l2 == lprev) continue;      // one block per l (segments are ordered by batch, l)
                     lprev = l2;
                     const int nn = (2 * l2 + 1) * (2 * l2 + 1);
-                    const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[l2];
+                    const float* __restrict__ D = A.wig + erow * A.nW + is_pick_wig_off(A, l2);
                     const int nj = (nn + 3) >> 2;
 #pragma unroll 1
                     for (int j = wave; j < nj; j += 4) {       // image [m * NCO + a][edge]

@@ -120,7 +120,8 @@ class _CombineMessages(nn.Module):
         self.linear_out = E3Linear(irreps_out.simplify(), irreps_out)
 
 
-MP_KERNEL_DEFAULT = "seg"
+# "auto": input-stationary schedule (csrc/tp_is.hip) when the tiles of all output segments fit the LDS, else segment-stationary
+MP_KERNEL_DEFAULT = "auto"
 
 
 class MessagePackBlock(nn.Module):

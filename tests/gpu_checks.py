@@ -78,12 +78,19 @@ def check_geometry(device="cuda"):
     return {"wigner_abs_err": werr, "rbf_rel_err": rerr}
 
 
-def check_message_pack(device="cuda", unrotate=True):
+def check_message_pack(device="cuda", unrotate=True, schedule=None):
+    """schedule: None = product default; "seg" / "is" force the segment- / input-stationary kernel."""
     from hamgnn_amd import nn as hnn, ops, plan as P
+    if schedule is not None:
+        os.environ["HG_MP_KERNEL"] = schedule
     f = load("message_pack_block")
     i = f["inputs"]
     m = load_weights(hnn.MessagePackBlock(MINI, MINI, SH, MINI, 8, [16, 16]), f["weights"])
-    m.compile(device, unrotate=unrotate)
+    try:
+        m.compile(device, unrotate=unrotate)
+    finally:
+        os.environ.pop("HG_MP_KERNEL", None) if schedule is not None else None
+    assert schedule is None or (m._dp.sched is not None) == (schedule == "is")
     lay = P.PlanarLayout(MINI)
     E = i["src"].shape[0]
     n = i["sh"][:, 1:4] / math.sqrt(3.0)

@@ -20,11 +20,22 @@ def test_geometry():
     assert r["wigner_abs_err"] < 5e-6 and r["rbf_rel_err"] < 1e-6
 
 
+@pytest.mark.parametrize("schedule", ["seg", "is"])
 @pytest.mark.parametrize("unrotate", [True, False])
-def test_message_pack_block_golden(unrotate):
-    r = G.check_message_pack(unrotate=unrotate)
+def test_message_pack_block_golden(unrotate, schedule):
+    """the fused MessagePackBlock on both kernels: segment-stationary (tp_fused.hip) and input-stationary (tp_is.hip)"""
+    r = G.check_message_pack(unrotate=unrotate, schedule=schedule)
     print(r)
     assert r["message_pack_rel_err"] < G.TOL
+
+
+@pytest.mark.parametrize("schedule", ["seg", "auto"])
+def test_backbone_golden_both_kernels(schedule, monkeypatch):
+    """whole backbone on the segment-stationary kernel + hg_rotate_gather vs the default (input-stationary, fused gather+rotation)"""
+    monkeypatch.setenv("HG_MP_KERNEL", schedule)
+    r = G.check_backbone()
+    print(r)
+    assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
 
 
 def test_backbone_golden():
