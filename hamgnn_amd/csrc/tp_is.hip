@@ -324,6 +324,40 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
     const int Pfull = N * P1;
     const int nj = (Pfull + 3) >> 2;
     const bool rot0 = (A.rot_mask >> s0) & 1, rot1 = nsrc == 2 && ((A.rot_mask >> s1) & 1);
+    if (rot0 && rot1) {
+        // sender and receiver rows of the node branch share the edge's Wigner row: one output piece t = a * P1 + p (component a,
+        // channels 4p..4p+3) of BOTH sources per (wave, g) slot and step -- 2 N float4 loads of the node rows + the N entries of
+        // row a in flight together, 2 N float4 FMAs, two ds_write_b128 straight into the operand images
+        const int64_t* __restrict__ ix0 = s0 == 0 ? A.idx[0] : (s0 == 1 ? A.idx[1] : (s0 == 2 ? A.idx[2] : A.idx[3]));
+        const int64_t* __restrict__ ix1 = s1 == 0 ? A.idx[0] : (s1 == 1 ? A.idx[1] : (s1 == 2 ? A.idx[2] : A.idx[3]));
+        const int64_t r0 = ix0 ? ix0[erow] : erow, r1 = ix1 ? ix1[erow] : erow;
+        const float* __restrict__ row0 = is_pick_src(A, s0) + r0 * is_pick_stride(A, s0) + in_off;
+        const float* __restrict__ row1 = is_pick_src(A, s1) + r1 * is_pick_stride(A, s1) + in_off;
+        const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
+        float* __restrict__ d0 = stage + P[6] + el * 4;
+        float* __restrict__ d1 = stage + P[7] + el * 4;
+#pragma unroll 1
+        for (int t = 4 * wave + g; t < Pfull; t += 16) {
+            const int a = t / P1, p = t - a * P1;
+            f32x4 v0[N], v1[N];
+            float d[N];
+#pragma unroll
+            for (int b = 0; b < N; ++b) {
+                v0[b] = *reinterpret_cast<const f32x4*>(row0 + b * in_mulp + 4 * p);
+                v1[b] = *reinterpret_cast<const f32x4*>(row1 + b * in_mulp + 4 * p);
+                d[b] = D[a * N + b];
+            }
+            f32x4 acc0 = d[0] * v0[0], acc1 = d[0] * v1[0];
+#pragma unroll
+            for (int b = 1; b < N; ++b) {
+                acc0 += d[b] * v0[b];
+                acc1 += d[b] * v1[b];
+            }
+            *reinterpret_cast<f32x4*>(d0 + t * 64) = acc0;
+            *reinterpret_cast<f32x4*>(d1 + t * 64) = acc1;
+        }
+        return;
+    }
     for (int si = 0; si < nsrc; ++si) {
         const int sidx = si ? s1 : s0;
         const int64_t* __restrict__ ix = sidx == 0 ? A.idx[0] : (sidx == 1 ? A.idx[1] : (sidx == 2 ? A.idx[2] : A.idx[3]));
