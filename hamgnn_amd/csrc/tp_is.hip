@@ -207,6 +207,61 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NC + c) * 4];
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
+        // rows beyond mul_k (fragment padding) go to the shared trash row: no divergent branches (their L' columns are zero)
+        const int coff = (lk - MM) * 16 + el;
+        if (CW == NC) {
+            // software-pipelined over the output row tiles: the tile values of step rtp+1 (the MFMA accumulator init) are read
+            // while the MFMAs of step rtp execute -- the LDS latency was exposed once per step (GEMM2 ran at half the MFMA
+            // density of GEMM1 in the phase profile)
+            float* __restrict__ tnext[4];
+            f32x4 acc_n[NC];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 4 * g + r;
+                tnext[r] = (rr < mul_k ? tile + rr * rowstride : trash) + coff;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][c * 16];
+#pragma unroll 1
+            for (int rtp = 0; rtp < rto; ++rtp) {
+                f32x4 av[RTM], acc[NC];
+                float* __restrict__ trow[4];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = a2_n[rt];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] = acc_n[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) trow[r] = tnext[r];
+                if (rtp + 1 < rto) {
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 16 * (rtp + 1) + 4 * g + r;
+                        tnext[r] = (rr < mul_k ? tile + rr * rowstride : trash) + coff;
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][c * 16];
+                }
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (4 * rt + r < nk2) {                // trailing K-steps hold only padding rows: not issued
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c][r], acc[c], 0, 0, 0);
+                        }
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) trow[r][c * 16] = acc[c][r];
+            }
+        } else {
 #pragma unroll 1
         for (int rtp = 0; rtp < rto; ++rtp) {
             f32x4 av[RTM];
@@ -216,12 +271,11 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
             }
-            // rows beyond mul_k (fragment padding) go to the shared trash row: no divergent branches (their L' columns are zero)
             float* __restrict__ trow[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = 16 * rtp + 4 * g + r;
-                trow[r] = (rr < mul_k ? tile + rr * rowstride : trash) + (lk - MM) * 16 + el;
+                trow[r] = (rr < mul_k ? tile + rr * rowstride : trash) + coff;
             }
 #pragma unroll
             for (int c0 = 0; c0 < NC; c0 += CW) {
@@ -249,6 +303,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                         for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] = acc[c][r];
                     }
             }
+        }
         }
     } else {
         // plain o3.Linear item (PairInteractionBlock skip): rows are output channels; add straight into the tile
