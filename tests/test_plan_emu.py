@@ -201,3 +201,55 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     s2 = P.is_schedule(prog2)
     a = emu.run_program_is(prog2, s2, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(a, emu.run_program(prog2, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
+
+
+@pytest.mark.parametrize("which", ["A", "B"])
+def test_input_stationary_schedule_shipped_irreps(which):
+    """schedule invariants for the shipped irreps sets (bench.IRREPS): every item exactly once, one owner group per (phase, segment),
+    staged blocks inside the staging area, LDS budget, Wigner batches inside the staging area."""
+    import torch
+    import bench
+    from hamgnn_amd import nn as hnn
+    irr = bench.IRREPS[which]
+    torch.manual_seed(0)
+    m = hnn.MessagePackBlock(irr, irr, bench.SH, irr, 64, [64, 64])
+    skip = np.zeros(sum(mm * mm for mm, _, _ in so3.Irreps(irr)))
+    prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, bench.SH, irr, True, skip)
+    sc = P.is_schedule(prog)
+    assert sc.lds_floats * 4 <= P.IS_LDS_BYTES and sc.item_table.shape == prog.item_table.shape
+    seen = np.zeros(sc.item_table.shape[0], dtype=int)
+    for b0, b1, g0, g1 in sc.phase_table:
+        used, offs = 0, set()
+        for blk in sc.block_table[b0:b1]:
+            size = -(-((2 * int(blk[4]) + 1) * (int(blk[3]) // 4)) // 4) * 256 * int(blk[5])
+            assert int(blk[6]) == used
+            used += size
+            offs.add(int(blk[6]))
+        assert used <= sc.stage_floats
+        owners = set()
+        for ib, ie in sc.group_table[g0:g1]:
+            segs = set(int(x) for x in sc.item_table[ib:ie, 19])
+            assert len(segs) == 1 and not (segs & owners)
+            owners |= segs
+            seen[ib:ie] += 1
+            assert all(int(o) in offs for o in sc.item_table[ib:ie, 1])
+    assert (seen == 1).all()
+    for sg in sc.seg_table:
+        if int(sg[7]) & P.SEG_UNROTATE:
+            assert int(sg[6]) + -(-((2 * int(sg[0]) + 1) ** 2) // 4) * 64 <= sc.stage_floats
+    assert int(sc.seg_table[0][7]) & P.SEG_NEWBATCH
+    # tile offsets are disjoint and end at the trash row
+    ends = sorted((int(s[5]), int(s[5]) + int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4)) for s in sc.seg_table)
+    assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] <= sc.trash_off
+
+
+def test_input_stationary_schedule_falls_back_when_too_wide():
+    """tiles of all output segments beyond the LDS budget -> NotImplementedError (ops.DeviceProgram 'auto' keeps the segment-stationary kernel)"""
+    import torch
+    from hamgnn_amd import nn as hnn
+    irr, sh = "64x0e+64x0o+48x1o+48x1e+32x2e+32x2o+20x3o+20x3e", "0e+1o+2e+3o"
+    torch.manual_seed(0)
+    m = hnn.MessagePackBlock(irr, irr, sh, irr, 8, [16, 16])
+    prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, sh, irr, True)
+    with pytest.raises(NotImplementedError):
+        P.is_schedule(prog)
