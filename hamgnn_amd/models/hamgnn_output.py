@@ -34,10 +34,11 @@ class HamGNNPlusPlusOut(nn.Module):
             self.soc_basis = "su2"                                           # hamgnn_output.py:151-153
         self.zero_point_shift, self.add_H_nonsoc = zero_point_shift, add_H_nonsoc
         self.calculate_sparsity = calculate_sparsity
+        self.get_nonzero_mask_tensor = get_nonzero_mask_tensor
         for flag, name in ((return_forces, "return_forces"), (calculate_band_energy, "calculate_band_energy"),
                            (spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
                            (export_reciprocal_values, "export_reciprocal_values"),
-                           (get_nonzero_mask_tensor, "get_nonzero_mask_tensor"), (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
+                           (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
             if flag:
                 raise NotImplementedError(f"HamGNNPlusPlusOut({name}) is outside the MI355X hot-path scope of this round")
         if soc_switch and self.soc_basis not in ("so3", "su2"):
@@ -151,6 +152,19 @@ class HamGNNPlusPlusOut(nn.Module):
         ops.zero_point_shift(H, f32c(Href), f32c(S), self.nao_max, soc)
         return H
 
+    def build_interaction_masks(self, data, edge_counts=None, soc=False):
+        """bool masks of the matrix elements that exist for the atoms' basis sets (index plumbing, no arithmetic):
+        non-SOC build_interaction_masks (hamgnn_output.py:2616-2665: [on-site rows; off-site rows], NOT per crystal),
+        SOC build_spin_orbit_interaction_masks (:2716-2783: every spin block carries the orbital mask; per-crystal order)."""
+        m = self._mask[data.z] > 0                                           # [N, nao]
+        src, dst = data.edge_index
+        on = m[:, :, None] & m[:, None, :]
+        off = m[src][:, :, None] & m[dst][:, None, :]
+        if not soc:
+            return torch.cat([on.reshape(on.shape[0], -1), off.reshape(off.shape[0], -1)], 0)
+        n2 = (2 * self.nao_max) ** 2
+        return self._cat_by_crystal(data, on.repeat(1, 2, 2).reshape(-1, n2), off.repeat(1, 2, 2).reshape(-1, n2), edge_counts)
+
     def calculate_sparsity_ratio(self, data):
         z = data.z
         n2 = self.nao_max ** 2
@@ -210,6 +224,8 @@ class HamGNNPlusPlusOut(nn.Module):
                 Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
             result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
                            "wavefunction": None})
+            if self.get_nonzero_mask_tensor:
+                result["mask_real_imag"] = self.build_interaction_masks(data, edge_counts, soc=True)
             if self.calculate_sparsity:
                 result["sparsity_ratio"] = self.calculate_sparsity_ratio(data)
             return result
@@ -230,6 +246,8 @@ class HamGNNPlusPlusOut(nn.Module):
                 Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
             result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
                            "wavefunction": None})
+            if self.get_nonzero_mask_tensor:
+                result["mask_real_imag"] = self.build_interaction_masks(data, edge_counts, soc=True)
             if self.calculate_sparsity:
                 result["sparsity_ratio"] = self.calculate_sparsity_ratio(data)
             return result
@@ -240,6 +258,8 @@ class HamGNNPlusPlusOut(nn.Module):
         if self.zero_point_shift:
             H = self._apply_zero_point_shift(data, H, edge_counts, False)
         result.update({"hamiltonian": H, "band_energy": None, "wavefunction": None, "band_gap": None, "H_sym": None})
+        if self.get_nonzero_mask_tensor:
+            result["mask"] = self.build_interaction_masks(data)
         if self.calculate_sparsity:
             result["sparsity_ratio"] = self.calculate_sparsity_ratio(data)
         return result

@@ -381,6 +381,7 @@ def main():
         out_mine = mine(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})
         _check(out_mine["hamiltonian"], out_ref["hamiltonian"], f"head {ham_type} nao={nao} hamiltonian")
         assert str(ref.hamiltonian_irreps) == str(mine.hamiltonian_irreps)
+        assert torch.equal(mine.interaction_masks(Gh), ref.build_interaction_masks(Graph(Gh))), "build_interaction_masks"
         ref.zero_point_shift = mine.zero_point_shift = True                      # :3971-3981
         _check(mine(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"],
                ref(Graph(Gh), {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"], f"head {ham_type} nao={nao} zero_point_shift")
@@ -413,6 +414,7 @@ def main():
         out_mine = mine(Gs, {"node_attr": node_attr, "edge_attr": edge_attr})
         _check(out_mine["hamiltonian_real"], out_ref["hamiltonian_real"], f"head SOC so3 add_H_nonsoc={nonsoc} real")
         _check(out_mine["hamiltonian_imag"], out_ref["hamiltonian_imag"], f"head SOC so3 add_H_nonsoc={nonsoc} imag")
+        assert torch.equal(mine.interaction_masks(Gs, soc=True), ref.build_spin_orbit_interaction_masks(Graph(Gs))[0]), "SOC masks"
         if not nonsoc:
             ref.zero_point_shift = mine.zero_point_shift = True                  # :3892-3913
             gin = Graph({k: (v.clone() if torch.is_tensor(v) else v) for k, v in Gs.items()})

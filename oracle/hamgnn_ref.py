@@ -416,6 +416,16 @@ class HamGNNPlusPlusOut(nn.Module):
         off = (m[src][:, :, None] * m[dst][:, None, :]).reshape(-1, self.nao_max ** 2)
         return on, off
 
+    def interaction_masks(self, data, soc=False):
+        """build_interaction_masks (hamgnn_output.py:2616-2665) / build_spin_orbit_interaction_masks (:2716-2783)."""
+        on, off = self.orbital_mask(data.z, data.edge_index)
+        on, off = on.bool(), off.bool()
+        if not soc:
+            return torch.cat([on, off], 0)
+        n = self.nao_max
+        big = lambda a: a.reshape(-1, n, n).repeat(1, 2, 2).reshape(-1, 4 * n * n)
+        return self.cat_by_crystal(data, big(on), big(off))
+
     def ksi_average(self, ksi):
         """symmetrize_orbital_coefficients (hamgnn_output.py:2367-2431): mean over each (row shell, col shell) block."""
         K = ksi.reshape(-1, self.nao_max, self.nao_max).clone()

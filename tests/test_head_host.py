@@ -1,0 +1,28 @@
+"""host-side (index / bool plumbing) parts of the MI355X head that need no GPU: interaction masks, sparsity ratio inputs."""
+import numpy as np
+import torch
+
+from oracle import hamgnn_ref as R
+from hamgnn_amd.data import Graph, collate
+from hamgnn_amd.data import synthetic as S
+from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+
+MINI = "8x0e+4x0o+4x1o+2x1e+2x2o+3x2e+2x3o"
+
+
+def _graphs():
+    return [S.add_random_targets(S.random_cell(4 + k, [14, 8, 6, 1], seed=k, density=0.006), 19, seed=k) for k in range(2)]
+
+
+def test_interaction_masks_match_oracle():
+    """get_nonzero_mask_tensor (hamgnn_output.py:2616-2665, 2716-2783; oracle pinned against the reference in oracle/gen_golden.py)"""
+    g = collate(_graphs())
+    head = HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, soc_switch=False, get_nonzero_mask_tensor=True)
+    head.compile("cpu")
+    ref = R.HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx")
+    m = head.build_interaction_masks(g)
+    assert m.dtype == torch.bool and torch.equal(m, ref.interaction_masks(g))
+    _, counts = head._global_inverse(g)
+    ms = head.build_interaction_masks(g, counts, soc=True)
+    assert torch.equal(ms, ref.interaction_masks(g, soc=True))
+    assert 0 < int(m.sum()) < m.numel()
