@@ -323,8 +323,15 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     return len(prog.segs) - 1
 
 
+# (MM, RTM) template instantiations of both fused kernels (csrc/tp_fused.hip HG_CASE / csrc/tp_is.hip IS_CASE): an item outside this
+# set would be skipped silently by the kernels' dispatch, so the planner refuses to emit one
+KERNEL_RTM_MAX = (4, 4, 4, 3, 2, 2, 1)
+
+
 def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0, nk2=None):
     assert len(srcs) in (1, 2)
+    if typ != IT_POST and not (0 <= mm < len(KERNEL_RTM_MAX) and 1 <= rtm <= KERNEL_RTM_MAX[mm]):
+        raise NotImplementedError(f"no kernel instantiation for an item with min(l_in, l_out) = {mm} and {rtm} row tiles")
     nk2 = 4 * rtm if nk2 is None else nk2                      # GEMM2 K-steps actually issued (item[18])
     if (2 * mm + 1) * in_mulp > 160:
         raise NotImplementedError(f"input irrep block too wide for the kernel's B staging ring: (2*{mm}+1) x {in_mulp} channels > 160")
