@@ -316,6 +316,8 @@ def use_x4(in_mulp, nc):
 
 def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     lay = prog.out_layout
+    if lk > 6:
+        raise NotImplementedError(f"output irreps with l = {lk} > 6 have no kernel epilogue instantiation")
     rto = ceil_div(mul_k, 16)
     prog.segs.append([lk, mul_k, rto, lay.off[out_index], lay.mulp[out_index], 0, 0, flags])
     prog.seg_items.append([])
