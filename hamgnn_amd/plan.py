@@ -205,6 +205,8 @@ def is_schedule(prog: "Program") -> IsSchedule:
     blocks: Dict[Tuple[int, int, int], dict] = {}
     for rec in prog.item_table:
         key = (int(rec[1]), int(rec[2]), int(rec[3]))
+        if int(rec[5]) > 6:
+            raise NotImplementedError("input irreps with l > 6 have no staging instantiation")
         b = blocks.setdefault(key, dict(key=key, in_mulp=int(rec[4]), li=int(rec[5]), items=[]))
         assert b["in_mulp"] == int(rec[4]) and b["li"] == int(rec[5])
         b["items"].append(rec)
@@ -613,6 +615,8 @@ def rotate_table(layout: PlanarLayout) -> np.ndarray:
     group of 4 channel slots, sorted by l (stable) so that the wavefronts of hg_rotate_gather run a single <L> code path."""
     rows = []
     for (mul, l, p), off, mp in zip(layout.irreps, layout.off, layout.mulp):
+        if l > 6:
+            raise NotImplementedError(f"feature irreps with l = {l} > 6 have no rotation kernel instantiation")
         for u in range(0, mp, 4):
             rows.append((l, off + u, mp, max(0, min(4, mul - u))))
     rows.sort(key=lambda r: r[0])
