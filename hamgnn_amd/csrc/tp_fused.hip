@@ -99,25 +99,12 @@ __device__ __forceinline__ void hg_dma4(const float* __restrict__ gsrc, float* l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
 }
 
-// LDS accesses the compiler does not see (HG_PREFETCH builds).  SIInsertWaitcnts must assume that any LDS access it knows of aliases
-// a pending LDS-DMA and drains vmcnt in front of it -- which would turn the next item's freshly issued B-span DMAs into a full
-// stall at the first tile access of GEMM2.  (LDS executes one wave's instructions in order, so later reads of the tile still
-// observe these stores.  DS_ADD_F32 was tried for the read-modify-write and is far slower: 23.6 vs 9.7 ms per launch.)
-__device__ __forceinline__ uint32_t lds_addr(float* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)p; }
-__device__ __forceinline__ void lds_store(float* p, float v) {
-#ifdef HG_PREFETCH
-    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
-#else
-    *p = v;
-#endif
-}
 // B-operand span of one (item, source): NC * mulp contiguous floats per edge row -> linear LDS image (see item_body).
 // Sources of a two-source item share the ring when both spans fit (slot = source index), else they take turns at offset 0.
 #define HG_RING_PIECES 44
 struct Span {                      // wave-uniform (SGPR) description of an item's B operand; s0 < 0: none
     int s0, s1, in_off, in_mulp, li, mm;
 };
-__device__ __forceinline__ Span span_of(const int* __restrict__ it) { return Span{it[1], it[2], it[3], it[4], it[5], it[6]}; }
 __device__ __forceinline__ int span_nj(const Span& sp) { return ((2 * sp.mm + 1) * (sp.in_mulp >> 2) + 3) >> 2; }
 __device__ __forceinline__ bool span_both_fit(const Span& sp) { return sp.s1 >= 0 && 2 * span_nj(sp) * 4 <= HG_RING_PIECES; }
 __device__ __forceinline__ int span_slot_floats(const Span& sp, int si) { return span_both_fit(sp) ? si * span_nj(sp) * 256 : 0; }
@@ -133,12 +120,10 @@ __device__ __forceinline__ void issue_span(const TpArgs& A, const Span& sp, int 
         hg_dma16(row + 4 * p, dst + j * 256);
     }
 }
-// how many sources of the next item are staged ahead of time (during this item's last GEMM2 step): all that fit the ring
-__device__ __forceinline__ int prefetch_sources(const Span& sp) { return span_both_fit(sp) ? 2 : 1; }
 
 template <int MM, int RTM>
-__device__ __forceinline__ void item_body(const TpArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, const Span nx,
-                                          int& pf, float* __restrict__ tile, float* __restrict__ stage, int rowstride, int lk, int rto, int mul_k,
+__device__ __forceinline__ void item_body(const TpArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
+                                          float* __restrict__ tile, float* __restrict__ stage, int rowstride, int lk, int rto, int mul_k,
                                           int64_t erow, int lane HG_PROF_ARG) {
     constexpr int NC = 2 * MM + 1;
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
@@ -171,8 +156,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 
     HG_T(0);                                                    // dispatch: record loads, switch, prologue
     const Span me = Span{s0, s1, in_off, in_mulp, li, MM};
-    int nissued = pf;                                           // sources already in the ring (opt-in prefetch by the previous item)
-    pf = 0;
+    int nissued = 0;                                            // sources of this item whose span DMAs are out
     {   // this item's spans go out first: their (HBM-class) latency runs under the radial-scale phase below
         const int nfirst = nsrc == 0 ? 0 : (span_both_fit(me) ? nsrc : 1);
         if (nissued < nfirst) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // previous fragment reads retired
@@ -345,22 +329,6 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                         for (int r = 0; r < 4; ++r) acc[c][r] = trow[r][(c0 + c) * 16];
 #endif
                     }
-#ifdef HG_PREFETCH
-                if (rtp + 1 == rto && c0 + CW >= NC && nx.s0 >= 0) {
-                    // last VMEM request and last visible LDS read of this item are out: stage the NEXT item's B spans now (the ring
-                    // is idle since GEMM1); their latency runs under this GEMM2 step and the next item's radial-scale phase.  The A
-                    // fragments and tile values are touched first: the compiler cannot count DMAs issued in a runtime loop and
-                    // would drain vmcnt to 0 (wait for these very spans) at their first use otherwise.
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) HG_SINK(av[rt]);
-#pragma unroll
-                    for (int c = 0; c < CW; ++c)
-                        if (c0 + c < NC) HG_SINK(acc[c]);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    pf = prefetch_sources(nx);
-                    for (int si = 0; si < pf; ++si) issue_span(A, nx, si, stage, erow, g);
-                }
-#endif
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -371,10 +339,6 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                                 if (c0 + c < NC)
                                     acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c0 + c][r], acc[c], 0, 0, 0);
                         }
-#ifdef HG_PREFETCH
-                // MFMA result -> LDS store data needs up to 19 wait states that the hazard recognizer cannot insert for inline asm
-                asm volatile("s_nop 7\n s_nop 7\n s_nop 3" ::: "memory");
-#endif
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
@@ -382,7 +346,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
                         HG_SINK(acc[c]);
 #else
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) lds_store(trow[r] + (c0 + c) * 16, acc[c][r]);
+                        for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] = acc[c][r];
 #endif
                     }
             }
@@ -412,21 +376,12 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 #pragma unroll
                 for (int c = 0; c < NC; ++c) mid[rt][c][r] += t0[rt][r][c * 16];
             }
-        if (nx.s0 >= 0) {                                      // all LDS reads of this item are done: stage the next item's spans
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) HG_SINK(mid[rt][c]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            pf = prefetch_sources(nx);
-            for (int si = 0; si < pf; ++si) issue_span(A, nx, si, stage, erow, g);
-        }
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) lds_store(t0[rt][r] + c * 16, mid[rt][c][r]);
+                for (int c = 0; c < NC; ++c) t0[rt][r][c * 16] = mid[rt][c][r];
         HG_T(6);                                                // linear-item write-back
     }
 }
@@ -552,7 +507,7 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
 }
 
 #define HG_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, nx, pf, tile, stage, rowstride, lk, rto, mul_k, erow, lane HG_PROF_PASS); break;
+    case (MMv * 8 + RTMv): item_body<MMv, RTMv>(A, g_W, it, tile, stage, rowstride, lk, rto, mul_k, erow, lane HG_PROF_PASS); break;
 
 template <bool HAS_POST>
 __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs A, const int* __restrict__ g_segs, const int* __restrict__ g_items,
@@ -582,20 +537,12 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
 #endif
         HG_WAVE_FENCE();
         HG_T(7);                                               // segment set-up: tile zeroing
-        int pf = 0;                                            // sources of the current item staged ahead by its predecessor
         for (int ii = ib; ii < ie; ++ii) {
             const int* __restrict__ it = g_items + ii * 20;
             const int mm = it[6], rtm = it[9];
             // the last item of a segment stages nothing ahead: the epilogue borrows the ring for the Wigner blocks
-            Span nx = Span{-1, -1, 0, 0, 0, 0};
-#ifdef HG_PREFETCH
-            // opt-in experiment: stage the next item's spans during this item's last GEMM2 step.  Measured neutral (9.46 vs
-            // 9.39 ms): the exposed part of the span latency is HBM-class (the per-edge rows are re-read ~10x with a reuse distance
-            // far beyond L2/MALL) and much longer than one GEMM2 step.
-            if (ii + 1 < ie && !(HAS_POST && it[20] == 3)) nx = span_of(it + 20);
-#endif
             if (HAS_POST && it[0] == 3) {
-                pf = 0;                      // segment post-op (lite_mode programs only: separate instantiation)
+                // segment post-op (lite_mode programs only: separate instantiation)
                 HG_WAVE_FENCE();
                 post_item(A, g_W, it, tile, rowstride, nco, rto, mul_k, erow, lane);
                 continue;
