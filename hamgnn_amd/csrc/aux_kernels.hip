@@ -199,10 +199,74 @@ __global__ __launch_bounds__(256) void radial_hidden_kernel(const float* __restr
     }
 }
 
+// MFMA version for the shipped shape (64 radial functions -> 64 -> 64): edges are the MFMA columns (16 per wave tile), both weight
+// matrices live in registers as A fragments (2 x 16 float4 per lane) for the whole persistent loop, and layer 1's C fragments
+// feed layer 2 as B operands directly (permuted-K packing, as in tp_fused.hip): 128 v_mfma_f32_16x16x4_f32 per 16 edges, one
+// coalesced read of the rbf row, one write of the hidden row.  (The LDS/VALU kernel above ran at 21 TFLOP/s, 0.64 ms per launch.)
+typedef float rh_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rh_f4 rh_silu(rh_f4 v, float cst) {
+    rh_f4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = cst * v[r] / (1.f + __expf(-v[r]));
+    return o;
+}
+__global__ __launch_bounds__(256) void radial_hidden_mfma_kernel(const float* __restrict__ rbf, int64_t E, const float* __restrict__ W, float cst,
+                                                                 float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    // A fragments: lane (i, g), tile (rt, T), register q  <-  W[in = 16 T + 4 g + q][out = 16 rt + i]   (W row-major [in][out])
+    rh_f4 a1[4][4], a2[4][4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int T = 0; T < 4; ++T)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                a1[rt][T][q] = W[(16 * T + 4 * g + q) * 64 + 16 * rt + i];
+                a2[rt][T][q] = W[4096 + (16 * T + 4 * g + q) * 64 + 16 * rt + i];
+            }
+    const int64_t ntile = (E + 15) >> 4;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntile; t += (int64_t)gridDim.x * 4) {
+        const int64_t e = t * 16 + i;
+        const int64_t er = e < E ? e : E - 1;
+        rh_f4 x[4];
+#pragma unroll
+        for (int T = 0; T < 4; ++T) x[T] = *reinterpret_cast<const rh_f4*>(rbf + er * 64 + 16 * T + 4 * g);
+        rh_f4 h1[4], h2[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            rh_f4 acc = (rh_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt][T][q], x[T][q], acc, 0, 0, 0);
+            h1[rt] = rh_silu(acc, cst);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            rh_f4 acc = (rh_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int T = 0; T < 4; ++T)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[rt][T][q], h1[T][q], acc, 0, 0, 0);
+            h2[rt] = rh_silu(acc, cst);
+        }
+        if (e < E) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<rh_f4*>(out + e * 64 + 16 * rt + 4 * g) = h2[rt];
+        }
+    }
+}
+
 extern "C" int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const int32_t* dims, int nlayers, float act_cst,
                                 float* h_out, void* stream) {
     if (E <= 0) return 0;
     if (nlayers < 1 || nlayers > 3) return hg_fail(-2, "hg_radial_hidden: 1..3 hidden layers supported");
+    if (nlayers == 2 && dims[0] == 64 && dims[1] == 64 && dims[2] == 64) {
+        const int64_t nwg = (E + 63) / 64;
+        const unsigned grid = (unsigned)(nwg < 2048 ? nwg : 2048);            // persistent: the weight fragments are loaded once per wave
+        radial_hidden_mfma_kernel<<<dim3(grid), 256, 0, (hipStream_t)stream>>>(rbf, E, weights, act_cst, h_out);
+        return hg_check_launch("hg_radial_hidden");
+    }
     int d[4] = {0, 0, 0, 0}, maxd = 0, maxw = 0;
     for (int i = 0; i <= nlayers; ++i) { d[i] = dims[i]; if (d[i] > maxd) maxd = d[i]; }
     for (int i = 0; i < nlayers; ++i) if (d[i] * d[i + 1] > maxw) maxw = d[i] * d[i + 1];
