@@ -9,8 +9,8 @@ backbone (embedding + num_layers x (ConvBlockE3 + PairInteractionBlock)) + pair 
 add_H0, no SOC), random-init weights (seed 666), fp32.  value = directed edges of the crystal * steps / time, whole job.
 For N > 1 the undirected pairs are sharded over the ranks (hamgnn_amd/parallel.py) with one RCCL all-reduce of the node
 aggregates per layer; the crystal (total work) is fixed => "scaling": "strong".
-Prints ONE JSON line (rank 0) incl. `roofline` for the dominant kernel (hg_tp_fused, timed live with HIP events on the
-launch stream inside the timed region) and `cpu_baseline` (the oracle = unfused pure-torch port of the reference path,
+Prints ONE JSON line (rank 0) incl. `roofline` for the dominant kernel (the fused MessagePackBlock launches: hg_tp_is, or
+hg_tp_fused on the fallback path; timed live with HIP events on the launch stream inside the timed region) and `cpu_baseline` (the oracle = unfused pure-torch port of the reference path,
 timed on the host cores over a bounded sample of the same workload; rank 0, N=1 only).
 """
 import argparse
