@@ -31,6 +31,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(the MI355X hot path has no CPU fallback)")
+        import torch  # noqa: F401  -- first: the library must bind to the HIP runtime PyTorch already loaded (its bundled
+        #                libamdhip64), not open a second copy of the runtime ("no ROCm-capable device" when loaded before torch)
         _lib = C.CDLL(LIB_PATH)
         _lib.hg_last_error.restype = C.c_char_p
         for name in EXPORTS:
