@@ -9,7 +9,11 @@ checks = [("geometry", G.check_geometry, {}), ("message_pack_unrot", G.check_mes
           ("message_pack_rot", G.check_message_pack, {"unrotate": False}), ("backbone", G.check_backbone, {}), ("backbone_lite", G.check_backbone, {"name": "backbone_lite"}),
           ("head19", G.check_head, {}), ("head_abacus13", G.check_head, {"name": "head_abacus_13", "ham_type": "abacus", "nao": 13}),
           ("head_soc_so3", G.check_head_soc, {}), ("random_cell", G.oracle_vs_hip_random, {}), ("batch_of_3", G.oracle_vs_hip_random, {"n_graphs": 3, "seed": 5}),
-          ("si2_setA", G.check_default_irreps_si2, {"which": "A"}), ("si2_setB", G.check_default_irreps_si2, {"which": "B"})]
+          ("si2_setA", G.check_default_irreps_si2, {"which": "A"}), ("si2_setB", G.check_default_irreps_si2, {"which": "B"}),
+          ("message_pack_seg", G.check_message_pack, {"unrotate": True, "schedule": "seg"}), ("message_pack_is", G.check_message_pack, {"unrotate": True, "schedule": "is"}),
+          ("head_soc_su2", G.check_head_su2, {}), ("zero_point_shift", G.check_zero_point_shift, {}),
+          ("si512_full_size", G.check_full_size_properties, {"workload": "si512", "which": "B"}),
+          ("mos2_1200_soc_full_size", G.check_full_size_properties, {"workload": "mos2_1200", "which": "A", "soc": True})]
 out = {}
 for name, fn, kw in checks:
     t = time.time()
