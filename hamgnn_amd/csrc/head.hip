@@ -218,3 +218,54 @@ extern "C" int hg_zero_point_shift(float* H, const float* Href, const float* S, 
     zp_apply_kernel<<<dim3(grid), 256, 0, (hipStream_t)stream>>>(H, S, count, nao, soc, partial_scratch, nparts, shift_out);
     return hg_check_launch("hg_zero_point_shift");
 }
+
+// ------------------------------------------------------------------------------------------------ correlation product (a21)
+// MACE symmetric contraction with correlation <= 2 on the nodes (hamgnn/nn/interaction_blocks.py:234-260 ->
+// toolbox/mace/modules/symmetric_contraction.py:212-230), sparse form of the reference's dense einsums:
+//   out[o, c] = sum_x ( sum_(e in row1(o)) U1 W1[z, kap, c]  +  sum_(e in row2(o)) U2 W2[z, kap, c] x[c, i] ) x[c, x]
+// One workgroup per node; the node's hidden features x[c][ell] sit in LDS; one thread per (output element o, channel c).
+// Node-level and off in the shipped configurations: written for correctness and coalesced weight reads, not tuned.
+__global__ __launch_bounds__(256) void sym_contraction_kernel(const float* __restrict__ h, int64_t hs, const int64_t* __restrict__ z, int C, int num_ell,
+                                                              const int* __restrict__ ell_off, int nout, const int* __restrict__ out_off,
+                                                              const int* __restrict__ ptr1, const int4* __restrict__ ent1,
+                                                              const int* __restrict__ ptr2, const int4* __restrict__ ent2,
+                                                              const float* __restrict__ W1, int K1, const float* __restrict__ W2, int K2,
+                                                              float* __restrict__ out, int64_t os) {
+    extern __shared__ float xs[];                              // [num_ell][C]
+    const int64_t b = blockIdx.x;
+    const float* __restrict__ hb = h + b * hs;
+    for (int i = threadIdx.x; i < num_ell * C; i += blockDim.x) {
+        const int ell = i / C, c = i - ell * C;
+        xs[i] = hb[ell_off[ell] + c];
+    }
+    __syncthreads();
+    const int64_t zb = z[b];
+    const float* __restrict__ w1 = W1 + zb * (int64_t)K1 * C;
+    const float* __restrict__ w2 = W2 + zb * (int64_t)K2 * C;
+    for (int idx = threadIdx.x; idx < nout * C; idx += blockDim.x) {
+        const int o = idx / C, c = idx - o * C;
+        float acc = 0.f;
+        for (int e = ptr1[o]; e < ptr1[o + 1]; ++e) {
+            const int4 t = ent1[e];                            // {x, kappa, -, value}
+            acc = fmaf(__int_as_float(t.w) * w1[t.y * C + c], xs[t.x * C + c], acc);
+        }
+        for (int e = ptr2[o]; e < ptr2[o + 1]; ++e) {
+            const int4 t = ent2[e];                            // {x, i, kappa, value}
+            acc = fmaf(__int_as_float(t.w) * w2[t.z * C + c] * xs[t.y * C + c], xs[t.x * C + c], acc);
+        }
+        out[b * os + out_off[o] + c] = acc;
+    }
+}
+
+extern "C" int hg_sym_contraction(const float* h, int64_t h_stride, const int64_t* z, int64_t N, int C, int num_ell, const int32_t* ell_off,
+                                  int nout, const int32_t* out_off, const int32_t* ptr1, const int32_t* ent1, const int32_t* ptr2,
+                                  const int32_t* ent2, const float* W1, int K1, const float* W2, int K2, float* out, int64_t out_stride,
+                                  void* stream) {
+    if (N <= 0) return 0;
+    const size_t lds = sizeof(float) * (size_t)num_ell * C;
+    if (lds > 64 * 1024) return hg_fail(-2, "hg_sym_contraction: hidden features too wide for the LDS-resident kernel");
+    sym_contraction_kernel<<<dim3((unsigned)N), 256, lds, (hipStream_t)stream>>>(h, h_stride, z, C, num_ell, ell_off, nout, out_off, ptr1,
+                                                                                 (const int4*)ent1, ptr2, (const int4*)ent2, W1, K1, W2, K2, out,
+                                                                                 out_stride);
+    return hg_check_launch("hg_sym_contraction");
+}

@@ -48,7 +48,8 @@ class HamGNNConvE3(nn.Module):
         if str(g("rbf_func", "bessel")).lower() != "bessel":
             raise ValueError(f"Unsupported radial basis function on the MI355X path: {g('rbf_func')}")
         self.lite_mode = bool(g("lite_mode", False))
-        for k in ("use_kan", "use_corr_prod", "build_internal_graph", "apply_charge_doping"):
+        self.use_corr_prod = bool(g("use_corr_prod", False))
+        for k in ("use_kan", "build_internal_graph", "apply_charge_doping"):
             if g(k, False):
                 raise NotImplementedError(f"HamGNN_pre.{k}=True is outside the MI355X hot-path scope of this round (SURVEY 8f)")
         if g("edge_sh_normalization", "component") != "component" or not g("edge_sh_normalize", True):
@@ -62,6 +63,9 @@ class HamGNNConvE3(nn.Module):
         self.chemical_embedding.linear = hnn.E3Linear(Irreps([(self.num_types, 0, 1)]), D)
         self.convolutions = nn.ModuleList()
         self.pair_interactions = nn.ModuleList()
+        if self.use_corr_prod:                                  # hamgnn_conv.py:193-218
+            self.corr_products = nn.ModuleList([hnn.CorrProductBlock(D, int(g("num_hidden_features")), int(g("correlation")), self.num_types, True)
+                                                for _ in range(self.num_layers)])
         for i in range(self.num_layers):
             self.convolutions.append(hnn.ConvBlockE3(D, sh, R, mlp, self.lite_mode))
             skip = (i > 0) if self.legacy_edge_update else True
@@ -77,6 +81,9 @@ class HamGNNConvE3(nn.Module):
         for c, p in zip(self.convolutions, self.pair_interactions):
             c.compile(dev)
             p.compile(dev)
+        if self.use_corr_prod:
+            for c in self.corr_products:
+                c.compile(dev)
         lay = self.layout
         self._imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(dev)
         self._rot_tab = torch.from_numpy(P.rotate_table(lay)).to(dev)
@@ -106,13 +113,15 @@ class HamGNNConvE3(nn.Module):
         f = self.pair_embedding.run(z, geo)                                          # [E, Dp] edge-aligned frame
         node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)          # [N, Dp]
         rowptr, perm = geo.receiver_csr(N)
-        for conv, pair in zip(self.convolutions, self.pair_interactions):
+        for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             skip = conv.skip_linear(node)
             msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab)          # global frame (un-rotated in the epilogue)
             agg = ops.segment_sum(msg, rowptr, perm, N)
             parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
             node = conv.residual(agg, extra=skip)
+            if self.use_corr_prod:                              # CorrProductBlock.forward (interaction_blocks.py:234-260; hamgnn_conv.py:274-275)
+                node = self.corr_products[li](node, z)
             # ---- PairInteractionBlock.forward (interaction_blocks.py:130-164)
             if pair.use_skip_connections or not pair.legacy_edge_update:           # legacy layer-0: edge features kept (:154-156)
                 mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab)   # edge frame (+ fused skip linear)

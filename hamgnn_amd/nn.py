@@ -309,3 +309,68 @@ class HamLayer(nn.Module):
     def forward(self, x_planar):
         y = self.residual_block(x_planar)
         return ops.tp_fused(self._dp, [y], y.shape[0])                          # planar rows grouped by (L,p)
+
+
+# ------------------------------------------------------------------------------------------------ correlation product (a21)
+class _Contraction(nn.Module):
+    """parameter holder of one MACE Contraction (toolbox/mace/modules/symmetric_contraction.py:101-233): weights_max for nu =
+    correlation, weights[0] for nu = 1; shapes [num_elements, num_paths, num_features]."""
+
+    def __init__(self, num_elements, k1, k2, num_features):
+        super().__init__()
+        self.weights_max = nn.Parameter(torch.randn(num_elements, k2, num_features) / max(1, k2))
+        self.weights = nn.ParameterList([nn.Parameter(torch.randn(num_elements, k1, num_features) / max(1, k1))])
+
+
+class _SymmetricContraction(nn.Module):
+    def __init__(self, num_elements, K1, K2, num_features):
+        super().__init__()
+        self.contractions = nn.ModuleList([_Contraction(num_elements, k1, k2, num_features) for k1, k2 in zip(K1, K2)])
+
+
+class _ProductBasis(nn.Module):
+    def __init__(self, irreps_hidden, num_elements, K1, K2, num_features):
+        super().__init__()
+        self.symmetric_contractions = _SymmetricContraction(num_elements, K1, K2, num_features)
+        self.linear = E3Linear(irreps_hidden, irreps_hidden)
+
+
+class CorrProductBlock(nn.Module):
+    """Drop-in for hamgnn/nn/interaction_blocks.py:168-260 (correlation 2): linear_pre -> symmetric contraction with element-
+    dependent weights -> prod.linear -> linear_out (+ linear_sc skip), all on planar node rows; same parameter names."""
+
+    def __init__(self, irreps_node_feats, num_hidden_features, correlation, num_elements, use_skip_connections=True):
+        super().__init__()
+        if correlation != 2:
+            raise NotImplementedError("CorrProductBlock: correlation 2 (the reference default) is built")
+        self.irreps = Irreps(irreps_node_feats)
+        if len({(l, p) for _, l, p in self.irreps}) != len(self.irreps):
+            raise NotImplementedError("CorrProductBlock expects simplified node irreps (one entry per (l, p))")
+        self.irreps_hidden = P.corr_hidden_irreps(self.irreps, num_hidden_features)
+        self.num_hidden, self.num_elements, self.use_skip_connections = num_hidden_features, num_elements, use_skip_connections
+        self._tab_np = P.sym_contraction_tables(self.irreps_hidden, correlation)
+        self.linear_pre = E3Linear(self.irreps, self.irreps_hidden)
+        self.linear_sc = E3Linear(self.irreps, self.irreps)
+        self.prod = _ProductBasis(self.irreps_hidden, num_elements, self._tab_np["K1"], self._tab_np["K2"], num_hidden_features)
+        self.linear_out = E3Linear(self.irreps_hidden, self.irreps)
+        self._tab = None
+
+    def compile(self, device):
+        for m in (self.linear_pre, self.linear_sc, self.prod.linear, self.linear_out):
+            m.compile(device)
+        t = self._tab_np
+        self._tab = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in t.items()}
+        cons = self.prod.symmetric_contractions.contractions
+        self._W2 = torch.cat([c.weights_max.detach() for c in cons], dim=1).float().contiguous().to(device)
+        self._W1 = torch.cat([c.weights[0].detach() for c in cons], dim=1).float().contiguous().to(device)
+        self._hdim = P.PlanarLayout(self.irreps_hidden).dim
+        return self
+
+    def forward(self, node_planar, z):
+        """returns the new planar node rows (the reference writes them back into the graph dict)"""
+        if self._tab is None:
+            self.compile(node_planar.device)
+        h = self.linear_pre(node_planar)
+        c = ops.sym_contraction(h, z, self.num_hidden, self._tab, self._W1, self._W2, self._hdim)
+        out = self.linear_out(self.prod.linear(c))
+        return ops.add_rows(out, self.linear_sc(node_planar)) if self.use_skip_connections else out

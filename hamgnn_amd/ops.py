@@ -245,3 +245,14 @@ def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
     check(lib().hg_zero_point_shift(ptr(H), ptr(Href), ptr(S), i64(rows), i32(nao), i32(1 if soc else 0), f32(threshold), ptr(scratch),
                                     i32(nparts), ptr(shift), _stream()), "hg_zero_point_shift")
     return shift
+
+
+def sym_contraction(h, z, C, tab, W1, W2, out_dim):
+    """tab: device tensors of plan.sym_contraction_tables; W1 [nel, K1, C], W2 [nel, K2, C]; returns planar hidden rows [N, out_dim]"""
+    _require_gpu(h)
+    N = h.shape[0]
+    out = torch.zeros(N, out_dim, device=h.device, dtype=torch.float32)           # channel padding stays zero
+    check(lib().hg_sym_contraction(ptr(h), i64(h.stride(0)), ptr(z), i64(N), i32(C), i32(tab["num_ell"]), ptr(tab["ell_off"]), i32(tab["nout"]),
+                                   ptr(tab["out_off"]), ptr(tab["ptr1"]), ptr(tab["ent1"]), ptr(tab["ptr2"]), ptr(tab["ent2"]), ptr(W1),
+                                   i32(W1.shape[1]), ptr(W2), i32(W2.shape[1]), ptr(out), i64(out_dim), _stream()), "hg_sym_contraction")
+    return out

@@ -961,3 +961,67 @@ def build_message_pack_program_lite(sd: Dict[str, np.ndarray], irreps_node, irre
         _add_item(prog, seg, IT_POST, [0], 0, 4, 0, 0, 0, 0, rto, 0, 0, w3_off, 0, a2_off, mk)
         prog.flops_per_row += 2.0 * H * mk + 2.0 * mk * mk * (2 * lk + 1)
     return prog.finalize()
+
+
+# ------------------------------------------------------------------------------------------------ correlation product (a21)
+
+def corr_hidden_irreps(irreps_node, num_hidden) -> Irreps:
+    """hidden irreps of CorrProductBlock (hamgnn/nn/interaction_blocks.py:196-199): num_hidden x every irrep of the node features"""
+    return Irreps([(num_hidden, l, p) for _, l, p in Irreps(irreps_node)])
+
+
+def sym_contraction_tables(irreps_hidden: Irreps, correlation: int = 2):
+    """Sparse coupling tables of the MACE symmetric contraction with correlation <= 2 on `num_hidden x irreps`
+    (hamgnn/toolbox/mace/tools/cg.py:16-131 U_matrix_real, modules/symmetric_contraction.py:101-233), for hg_sym_contraction:
+        out_k[c, w] = sum_x ( sum_kap U1_k[w, x, kap] W1_k[z, kap, c]  +  sum_{i, kap} U2_k[w, x, i, kap] W2_k[z, kap, c] x[c, i] ) x[c, x]
+    The coupling irreps are one copy of every hidden irrep, component index "ell" running over them in order.  U_nu stacks, for the
+    target irrep, every coupling path in enumeration order (left irrep, right irrep) -- cg.py sorts by output irrep only, stably --
+    with 'component' normalisation sqrt(2L+1) w3j(L, l_left, l_right).
+    Returns dict(ell_off, out_off, ptr1, ent1, ptr2, ent2, K1 (per target), K2 (per target), num_ell, nout) with
+      ell_off[i]  planar offset of ell component i (channel 0) in the hidden layout,   out_off[o] same for output element o = (k, w)
+      ent1 rows (x, kappa_global, value-bits), ent2 rows (x, i, kappa_global, value-bits); kappa_global indexes the concatenated
+      weights of all targets."""
+    assert correlation in (1, 2), "correlation > 2 is not built"
+    lay = PlanarLayout(irreps_hidden)
+    irs = [(l, p) for _, l, p in irreps_hidden]
+    sl, o = [], 0
+    for l, p in irs:
+        sl.append((o, o + 2 * l + 1))
+        o += 2 * l + 1
+    num_ell = o
+    ell_off = np.zeros(num_ell, np.int32)
+    for j, (l, p) in enumerate(irs):
+        for m in range(2 * l + 1):
+            ell_off[sl[j][0] + m] = lay.off[j] + m * lay.mulp[j]
+    out_off, ptr1, ent1, ptr2, ent2, K1, K2 = [], [0], [], [0], [], [], []
+    k1g = k2g = 0
+    for k, (L, pL) in enumerate(irs):
+        # nu = 1: identity block of the target irrep (one path)
+        paths1 = [j for j, ir in enumerate(irs) if ir == (L, pL)]
+        # nu = 2: (left a, right b) with (L, pL) in a x b
+        paths2 = [(a, b) for a, (la, pa) in enumerate(irs) for b, (lb, pb) in enumerate(irs)
+                  if pa * pb == pL and abs(la - lb) <= L <= la + lb] if correlation == 2 else []
+        cg = {ab: math.sqrt(2 * L + 1) * so3.wigner_3j(L, irs[ab[0]][0], irs[ab[1]][0]) for ab in paths2}
+        for w in range(2 * L + 1):
+            out_off.append(lay.off[k] + w * lay.mulp[k])
+            for kap, j in enumerate(paths1):
+                ent1.append((sl[j][0] + w, k1g + kap, 1.0))
+            ptr1.append(len(ent1))
+            for kap, (a, b) in enumerate(paths2):
+                C = cg[(a, b)][w]                                      # [2la+1, 2lb+1]
+                for ma, mb in zip(*np.nonzero(np.abs(C) > 1e-14)):
+                    ent2.append((sl[a][0] + ma, sl[b][0] + mb, k2g + kap, C[ma, mb]))
+            ptr2.append(len(ent2))
+        K1.append(len(paths1))
+        K2.append(len(paths2))
+        k1g += len(paths1)
+        k2g += len(paths2)
+
+    def pack(ents, ncols):
+        arr = np.zeros((max(1, len(ents)), 4), np.int32)
+        for r, e in enumerate(ents):
+            arr[r, :ncols] = e[:ncols]
+            arr[r, 3] = np.float32(e[-1]).view(np.int32)
+        return arr
+    return dict(ell_off=ell_off, out_off=np.asarray(out_off, np.int32), ptr1=np.asarray(ptr1, np.int32), ent1=pack(ent1, 2),
+                ptr2=np.asarray(ptr2, np.int32), ent2=pack(ent2, 3), K1=K1, K2=K2, num_ell=num_ell, nout=len(out_off))

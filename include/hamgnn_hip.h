@@ -125,6 +125,18 @@ int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t* inv, const
                   const int64_t* z, const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int flags, int64_t rows,
                   float* H, void* stream);
 
+/* CorrProductBlock's symmetric contraction (hamgnn/nn/interaction_blocks.py:234-260 -> toolbox/mace/modules/
+ * symmetric_contraction.py:212-230 with U_matrix_real of toolbox/mace/tools/cg.py:89-131), correlation <= 2, on planar
+ * hidden node rows h [N, .] (num_hidden x every node irrep):
+ *   out[o, c] = sum_x ( sum_kap U1[o, x, kap] W1[z, kap, c] + sum_{i, kap} U2[o, x, i, kap] W2[z, kap, c] x[c, i] ) x[c, x]
+ * with the U tensors given sparsely (plan.py:sym_contraction_tables): ell_off / out_off = planar offsets of the input
+ * components / output elements, ptr1/ent1 {x, kappa, -, value bits} and ptr2/ent2 {x, i, kappa, value bits} CSR rows per output
+ * element; W1 [num_elements][K1][C], W2 [num_elements][K2][C] = the contractions' weights concatenated over the targets.   */
+int hg_sym_contraction(const float* h, int64_t h_stride, const int64_t* z, int64_t N, int C, int num_ell, const int32_t* ell_off,
+                       int nout, const int32_t* out_off, const int32_t* ptr1, const int32_t* ent1, const int32_t* ptr2,
+                       const int32_t* ent2, const float* W1, int K1, const float* W2, int K2, float* out, int64_t out_stride,
+                       void* stream);
+
 /* zero-point energy shift (hamgnn_output.py:3971-3981; SOC spin-diagonal real blocks :3892-3913), in place:
  *   dE = sum_{S>thr}(H - Href) / sum_{S>thr} S ;  H -= dE * S    -- one dE per call (= per batch, as the reference).
  * soc != 0: H/Href rows are (2 nao)^2, S rows nao^2; (uu+dd) differences, denominator 2 sum S, both diagonal blocks shifted.

@@ -144,6 +144,25 @@ def install_stubs():
     emb.Embedding_block_q = _Dummy
 
 
+def _load_real_mace():
+    """execute the four MACE-derived files of the reference the CorrProductBlock needs (unmodified, from where they lie), with
+    opt_einsum_fx's optimiser and e3nn's CodeGenMixin replaced by no-ops; everything else of the toolbox stays a permissive stub."""
+    import importlib.util
+    importlib.import_module("opt_einsum_fx").optimize_einsums_full = lambda model, example_inputs: model
+    importlib.import_module("e3nn.util.codegen").CodeGenMixin = type("CodeGenMixin", (), {})
+    base = os.path.join(REF, "hamgnn", "toolbox", "mace")
+    out = {}
+    for name, rel in (("cg", "tools/cg.py"), ("irreps_tools", "modules/irreps_tools.py"),
+                      ("symmetric_contraction", "modules/symmetric_contraction.py"), ("blocks", "modules/blocks.py")):
+        full = "hamgnn.toolbox.mace." + rel[:-3].replace("/", ".")
+        spec = importlib.util.spec_from_file_location(full, os.path.join(base, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[full] = mod
+        spec.loader.exec_module(mod)
+        out[name] = mod
+    return out
+
+
 class _PrefixStub(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def __init__(self, prefix):
         self.prefix = prefix
@@ -454,6 +473,49 @@ def main():
             keys = ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0", "iHon0", "iHoff0")
             _save("head_soc_su2_abacus_13", weights=sd, graph={k: Gu[k] for k in keys}, inputs=dict(node_attr=node_attr, edge_attr=edge_attr),
                   outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"], hamiltonian_imag=out_ref["hamiltonian_imag"]))
+
+    # ---- 7. CorrProductBlock (optional MACE-style correlation product; interaction_blocks.py:168-260) ---------------
+    print("CorrProductBlock")
+    from oracle import mace_ref as M
+    real = _load_real_mace()
+    ref_ib.EquivariantProductBasisBlock, ref_ib.reshape_irreps = real["blocks"].EquivariantProductBasisBlock, real["irreps_tools"].reshape_irreps
+    for irr, nh in ((mini, 4), ("6x0e+3x1o+2x2e", 3)):
+        torch.manual_seed(14)
+        refc = ref_ib.CorrProductBlock(irreps_node_feats=e3.Irreps(irr), num_hidden_features=nh, correlation=2, num_elements=8,
+                                       use_skip_connections=True)
+        minec = M.CorrProductBlock(irr, nh, 2, 8, True)
+        sdc = {k: v for k, v in refc.state_dict().items()}
+        res = minec.load_state_dict(sdc, strict=False)
+        assert not (set(res.missing_keys) & set(dict(minec.named_parameters()))), res.missing_keys
+        for k, cm in enumerate(minec.prod.symmetric_contractions.contractions):      # the U tensors themselves
+            cr = refc.prod.symmetric_contractions.contractions[k]
+            for nu in (1, 2):
+                _check(cm.U(nu), cr.U_tensors(nu), f"U_matrix_{nu} of target {k}", tol=1e-12)
+        Dn = e3.Irreps(irr).dim
+        xn = torch.randn(5, Dn, generator=gen)
+        zc = torch.tensor([1, 6, 0, 7, 3])
+        onehot = torch.nn.functional.one_hot(zc, 8).to(xn.dtype)
+        gd = {"node_features": xn.clone(), "node_attrs": onehot}
+        refc(gd)
+        _check(minec(xn, onehot), gd["node_features"], f"CorrProductBlock {irr} hidden={nh}")
+        if irr == mini:
+            _save("corr_product_block", weights={k: v for k, v in sdc.items() if k in dict(minec.named_parameters())},
+                  inputs=dict(node_features=xn, z=zc), outputs=dict(node_features=gd["node_features"]),
+                  meta=dict(irreps=np.array(irr), num_hidden=np.array(nh), num_elements=np.array(8)))
+    # backbone with use_corr_prod=True (hamgnn_conv.py:193-218, 274-275)
+    cfg4 = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, use_corr_prod=True, num_hidden_features=4).items() if k != 'radius_scale'}))
+    torch.manual_seed(15)
+    ref4, mine4 = ref_conv.HamGNNConvE3(cfg4), R.HamGNNConvE3(dict(cfg4))
+    res = mine4.load_state_dict(ref4.state_dict(), strict=False)
+    assert not (set(res.missing_keys) & set(dict(mine4.named_parameters()))), res.missing_keys
+    r4 = ref4(Graph(G))
+    o4 = mine4(G)
+    _check(o4["node_attr"], r4["node_attr"], "backbone use_corr_prod node_attr")
+    _check(o4["edge_attr"], r4["edge_attr"], "backbone use_corr_prod edge_attr")
+    _save("backbone_corr", weights={k: v for k, v in ref4.state_dict().items() if k in dict(mine4.named_parameters())},
+          graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
+          outputs=dict(node_attr=r4["node_attr"], edge_attr=r4["edge_attr"]),
+          meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg4["HamGNN_pre"]).items()}))))
     print("ALL WIRING CHECKS PASSED")
 
 

@@ -267,7 +267,8 @@ class HamGNNConvE3(nn.Module):
         self.legacy_edge_update = c.get("legacy_edge_update", False)
         self.lite_mode = c.get("lite_mode", False)
         assert c.get("rbf_func", "bessel").lower() == "bessel" and not c.get("use_kan", False)
-        assert not c.get("use_corr_prod", False) and not c.get("build_internal_graph", False)
+        assert not c.get("build_internal_graph", False)
+        self.use_corr_prod = bool(c.get("use_corr_prod", False))
         mlp = list(c["radial_MLP"])
         attrs = Irreps([(self.num_types, (0, 1))])
         emb = Irreps([(self.num_radial, (0, 1))])
@@ -277,6 +278,10 @@ class HamGNNConvE3(nn.Module):
         self.chemical_embedding.linear = Linear(attrs, D)
         self.convolutions = nn.ModuleList()
         self.pair_interactions = nn.ModuleList()
+        if self.use_corr_prod:                                  # hamgnn_conv.py:193-218
+            from .mace_ref import CorrProductBlock
+            self.corr_products = nn.ModuleList([CorrProductBlock(D, int(c["num_hidden_features"]), int(c["correlation"]), self.num_types, True)
+                                                for _ in range(self.num_layers)])
         for i in range(self.num_layers):
             self.convolutions.append(ConvBlockE3(D, D, self.irreps_edge_sh, emb, mlp, self.lite_mode))
             skip = (i > 0) if self.legacy_edge_update else True
@@ -292,8 +297,10 @@ class HamGNNConvE3(nn.Module):
         g["edge_attrs"], g["edge_embedding"] = sh, rbf
         self.pair_embedding(g)
         g["node_features"] = self.chemical_embedding.linear(g["node_features"])
-        for conv, pair in zip(self.convolutions, self.pair_interactions):
+        for i, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             conv(g)
+            if self.use_corr_prod:                              # hamgnn_conv.py:274-275
+                g["node_features"] = self.corr_products[i](g["node_features"], g["node_attrs"])
             pair(g)
         return {"node_attr": g["node_features"], "edge_attr": g["edge_features"]}
 

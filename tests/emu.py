@@ -204,3 +204,23 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
         for sg, seg in enumerate(sched.seg_table):
             _write_segment(prog, seg, tiles[sg], out, cols, ne, D, woffs, dtype)
     return out
+
+
+def sym_contraction(tab, hp, z, W1, W2, C, out_dim):
+    """numpy twin of hg_sym_contraction (hamgnn_amd/csrc/head.hip): hp planar hidden rows [N, Dp]; W1 [nel, K1tot, C], W2 [nel, K2tot, C]"""
+    N = hp.shape[0]
+    out = np.zeros((N, out_dim), dtype=np.float64)
+    x = np.stack([hp[:, tab["ell_off"] + c] for c in range(C)], axis=1)          # [N, C, num_ell]
+    val1 = tab["ent1"][:, 3].view(np.float32).astype(np.float64)
+    val2 = tab["ent2"][:, 3].view(np.float32).astype(np.float64)
+    for o in range(tab["nout"]):
+        acc = np.zeros((N, C))
+        for e in range(tab["ptr1"][o], tab["ptr1"][o + 1]):
+            xi, kap = tab["ent1"][e, 0], tab["ent1"][e, 1]
+            acc += val1[e] * W1[z, kap, :] * x[:, :, xi]
+        for e in range(tab["ptr2"][o], tab["ptr2"][o + 1]):
+            xi, ii, kap = tab["ent2"][e, 0], tab["ent2"][e, 1], tab["ent2"][e, 2]
+            acc += val2[e] * W2[z, kap, :] * x[:, :, ii] * x[:, :, xi]
+        for c in range(C):
+            out[:, tab["out_off"][o] + c] = acc[:, c]
+    return out

@@ -128,6 +128,21 @@ def check_backbone(device="cuda", name="backbone"):
             "backbone_edge_rel_err": rel(rep["edge_attr"], f["outputs"]["edge_attr"])}
 
 
+def check_corr_product(device="cuda"):
+    """CorrProductBlock (a21) vs the reference fixture: linear_pre -> symmetric contraction -> prod.linear -> linear_out + skip."""
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    f = load("corr_product_block")
+    irr, nh, nel = str(f["meta"]["irreps"]), int(f["meta"]["num_hidden"]), int(f["meta"]["num_elements"])
+    m = load_weights(hnn.CorrProductBlock(irr, nh, 2, nel, True), f["weights"])
+    lay = P.PlanarLayout(irr)
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    x = ops.to_planar(torch.from_numpy(f["inputs"]["node_features"]).float().to(device), imap, lay.dim)
+    z = torch.from_numpy(f["inputs"]["z"]).to(device)
+    y = ops.from_planar(m.compile(device)(x, z), imap)
+    torch.cuda.synchronize()
+    return {"corr_product_rel_err": rel(y, f["outputs"]["node_features"])}
+
+
 def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, use_planar_path=False):
     from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
     f = load(name)

@@ -38,6 +38,18 @@ def test_backbone_golden_both_kernels(schedule, monkeypatch):
     assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
 
 
+def test_corr_product_block_golden():
+    r = G.check_corr_product()
+    print(r)
+    assert r["corr_product_rel_err"] < G.TOL
+
+
+def test_backbone_use_corr_prod_golden():
+    r = G.check_backbone(name="backbone_corr")
+    print(r)
+    assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
+
+
 def test_backbone_golden():
     r = G.check_backbone()
     print(r)

@@ -253,3 +253,33 @@ def test_input_stationary_schedule_falls_back_when_too_wide():
     prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, sh, irr, True)
     with pytest.raises(NotImplementedError):
         P.is_schedule(prog)
+
+
+def test_sym_contraction_tables_vs_oracle(golden_dir):
+    """CorrProductBlock's symmetric contraction (a21): sparse U tables + concatenated weights == the oracle's dense einsums"""
+    import torch
+    from oracle import mace_ref as M
+    f = load(golden_dir, "corr_product_block")
+    irr, nh, nel = str(f["meta"]["irreps"]), int(f["meta"]["num_hidden"]), int(f["meta"]["num_elements"])
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        blk = M.CorrProductBlock(irr, nh, 2, nel, True)
+    finally:
+        torch.set_default_dtype(prev)
+    blk.load_state_dict({k: torch.as_tensor(v) for k, v in f["weights"].items()}, strict=False)
+    hid = P.corr_hidden_irreps(irr, nh)
+    tab = P.sym_contraction_tables(hid, 2)
+    cons = blk.prod.symmetric_contractions.contractions
+    assert tab["K2"] == [c.U(2).shape[-1] for c in cons] and tab["K1"] == [c.U(1).shape[-1] for c in cons]
+    W2 = np.concatenate([c.weights_max.detach().numpy() for c in cons], axis=1)
+    W1 = np.concatenate([c.weights[0].detach().numpy() for c in cons], axis=1)
+    rng = np.random.default_rng(2)
+    lay = P.PlanarLayout(hid)
+    h = rng.standard_normal((6, so3.Irreps(str(hid)).dim)) if hasattr(so3.Irreps, "dim") else None
+    h = rng.standard_normal((6, sum(m * (2 * l + 1) for m, l, _ in hid)))
+    z = rng.integers(0, nel, size=6)
+    got = lay.from_planar(emu.sym_contraction(tab, lay.to_planar(h), z, W1, W2, nh, lay.dim))
+    ht = torch.from_numpy(h)
+    want = blk.prod.symmetric_contractions(M.reshape_irreps(blk.irreps_hidden, ht), torch.nn.functional.one_hot(torch.from_numpy(z), nel).double())
+    assert rel(got, want.detach().numpy()) < 1e-6
