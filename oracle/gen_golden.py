@@ -401,6 +401,19 @@ def main():
         _check(out_mine["hamiltonian"], out_ref["hamiltonian"], f"head {ham_type} nao={nao} hamiltonian")
         assert str(ref.hamiltonian_irreps) == str(mine.hamiltonian_irreps)
         assert torch.equal(mine.interaction_masks(Gh), ref.build_interaction_masks(Graph(Gh))), "build_interaction_masks"
+        if (ham_type, nao) == ("abacus", 13):                                     # overlap networks (ham_only=False, :2995-3019)
+            torch.manual_seed(16)
+            refo = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type=ham_type, ham_only=False,
+                                             symmetrize=True, add_H0=True, soc_switch=False, calculate_band_energy=False, calculate_sparsity=False)
+            mineo = R.HamGNNPlusPlusOut(mini, mini, nao_max=nao, ham_type=ham_type, symmetrize=True, add_H0=True, ham_only=False)
+            sdo = {k: v for k, v in refo.state_dict().items() if not k.startswith("cg_calculator")}
+            assert not mineo.load_state_dict(sdo, strict=False).missing_keys
+            oref = refo(Graph(Gh), {"node_attr": node_attr, "edge_attr": edge_attr})
+            omine = mineo(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})
+            _check(omine["overlap"], oref["overlap"], "head overlap networks (ham_only=False)")
+            _check(omine["hamiltonian"], oref["hamiltonian"], "head hamiltonian with overlap networks")
+            _save("head_overlap_abacus_13", weights=sdo, graph={k: Gh[k] for k in ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0")},
+                  inputs=dict(node_attr=node_attr, edge_attr=edge_attr), outputs=dict(hamiltonian=oref["hamiltonian"], overlap=oref["overlap"]))
         ref.zero_point_shift = mine.zero_point_shift = True                      # :3971-3981
         _check(mine(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"],
                ref(Graph(Gh), {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"], f"head {ham_type} nao={nao} zero_point_shift")

@@ -345,7 +345,7 @@ class HamGNNPlusPlusOut(nn.Module):
     """Non-SOC branch and SOC/so3 branch of the reference head; ham_only=True; band/k-space code out of scope."""
 
     def __init__(self, irreps_in_node, irreps_in_edge, nao_max=19, ham_type="openmx", symmetrize=True, add_H0=True,
-                 soc_switch=False, soc_basis="so3", add_H_nonsoc=False, zero_point_shift=False):
+                 soc_switch=False, soc_basis="so3", add_H_nonsoc=False, zero_point_shift=False, ham_only=True):
         super().__init__()
         self.nao_max, self.ham_type = nao_max, ham_type.lower()
         self.symmetrize, self.add_H0, self.soc_switch, self.add_H_nonsoc = symmetrize, add_H0, soc_switch, add_H_nonsoc
@@ -363,6 +363,10 @@ class HamGNNPlusPlusOut(nn.Module):
                 for L in range(abs(li.l - lj.l), li.l + lj.l + 1):
                     irr = irr + Irrep(L, (-1) ** (li.l + lj.l))
         self.hamiltonian_irreps = irr
+        self.ham_only = ham_only
+        if not ham_only:                                        # hamgnn_output.py:247-256
+            self.onsite_overlap_network = HamLayer(irreps_in_node, irr)
+            self.offsite_overlap_network = HamLayer(irreps_in_edge, irr)
         if soc_switch and self.soc_basis == "su2":
             # E3TensorDecomposition(spinful=True).required_irreps_out (tensor_decomposition.py:463-527) is already the doubled
             # (re, im) list; the head doubles it once more (hamgnn_output.py:193,197) -- only copies 0 and 2 are ever read
@@ -543,6 +547,17 @@ class HamGNNPlusPlusOut(nn.Module):
             if Z not in self.basis_def:
                 raise ValueError(f"element Z={Z} missing from basis_def")
         inv = self.global_inverse_edges(data)
+        if not self.ham_only:                                   # overlap matrices (hamgnn_output.py:2995-3019, 4009-4013)
+            res = self._forward_hamiltonian(data, rep, inv)
+            s_on = self._sym(self.reorder_matrix(self.merge_tensor_components(self.onsite_overlap_network(node_attr))))
+            s_off = self._sym(self.reorder_matrix(self.merge_tensor_components(self.offsite_overlap_network(edge_attr))), inv)
+            mo, mf = self.orbital_mask(data.z, data.edge_index)
+            res["overlap"] = self.cat_by_crystal(data, s_on * mo.to(s_on.dtype), s_off * mf.to(s_on.dtype))
+            return res
+        return self._forward_hamiltonian(data, rep, inv)
+
+    def _forward_hamiltonian(self, data, rep, inv):
+        node_attr, edge_attr = rep["node_attr"], rep["edge_attr"]
         if self.soc_switch and self.soc_basis == "su2":
             return self.forward_su2(data, rep, inv)
         on = self._sym(self.reorder_matrix(self.merge_tensor_components(self.onsite_hamiltonian_network(node_attr))))

@@ -160,6 +160,24 @@ def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, 
     return {name + "_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"]), "sparsity_ratio": float(out["sparsity_ratio"])}
 
 
+def check_head_overlap(device="cuda"):
+    """ham_only=False: the overlap networks next to the Hamiltonian networks (hamgnn_output.py:2995-3019, 4009-4013)"""
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load("head_overlap_abacus_13")
+    m = load_weights(HamGNNPlusPlusOut(MINI, MINI, nao_max=13, ham_type="abacus", ham_only=False, symmetrize=True, add_H0=True,
+                                       soc_switch=False, calculate_sparsity=False), f["weights"])
+    bb = load("backbone")["graph"]
+    gd = dict(f["graph"])
+    for k in ("pos", "nbr_shift", "cell"):
+        gd[k] = bb[k]
+    g = to_graph(gd, device)
+    rep = {"node_attr": torch.from_numpy(f["inputs"]["node_attr"]).float().to(device),
+           "edge_attr": torch.from_numpy(f["inputs"]["edge_attr"]).float().to(device)}
+    out = m(g, rep)
+    torch.cuda.synchronize()
+    return {"overlap_rel_err": rel(out["overlap"], f["outputs"]["overlap"]), "hamiltonian_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"])}
+
+
 def check_head_soc(device="cuda"):
     from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
     f = load("head_soc_so3_openmx_19")

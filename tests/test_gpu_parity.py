@@ -69,6 +69,12 @@ def test_full_forward_vs_oracle_random_cell():
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
 
 
+def test_head_overlap_networks_golden():
+    r = G.check_head_overlap()
+    print(r)
+    assert r["overlap_rel_err"] < G.TOL and r["hamiltonian_rel_err"] < G.TOL
+
+
 def test_head_soc_so3_golden():
     r = G.check_head_soc()
     print(r)
