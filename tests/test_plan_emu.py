@@ -283,3 +283,58 @@ def test_sym_contraction_tables_vs_oracle(golden_dir):
     ht = torch.from_numpy(h)
     want = blk.prod.symmetric_contractions(M.reshape_irreps(blk.irreps_hidden, ht), torch.nn.functional.one_hot(torch.from_numpy(z), nel).double())
     assert rel(got, want.detach().numpy()) < 1e-6
+
+
+def _random_irreps(rng, lmax):
+    """random simplified irreps (distinct (l, p), sorted like the reference's configs: by l, odd/even in random order)"""
+    out = []
+    for l in range(lmax + 1):
+        ps = [p for p in (1, -1) if rng.random() < (0.9 if l == 0 and p == 1 else 0.6)]
+        rng.shuffle(ps)
+        for p in ps:
+            out.append(f"{int(rng.integers(1, 20))}x{l}{'e' if p == 1 else 'o'}")
+    return "+".join(out) if out else "3x0e"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_irreps_both_schedules_vs_oracle(seed):
+    """planner generality: random irreps sets (odd multiplicities, missing parities, single-irrep rows), random weights ->
+    segment-stationary AND input-stationary schedules, emulated fragment-exactly, vs the oracle MessagePackBlock."""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    rng = np.random.default_rng(100 + seed)
+    lmax = int(rng.integers(1, 4))
+    irr = _random_irreps(rng, lmax)
+    if "0e" not in irr:
+        irr = "5x0e+" + irr
+    lsh = int(rng.integers(1, 4))
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
+        E = 17
+        g = torch.Generator().manual_seed(seed)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        out = ref(src, dst, ef, shv, rbf).detach().numpy()
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay = P.PlanarLayout(irr)
+    lm = max(lmax, lsh)
+    D = emu.edge_wigner_all(n.numpy(), lm)
+    xs, xd, fe = (emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, lm) for t in (src, dst, ef))
+    hn = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
+    he = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
+    prog = P.build_message_pack_program(sd, irr, irr, sh, irr, unrotate=True)
+    scale = np.abs(out).max()
+    if scale < 1e-12:                                          # no path reaches the output irreps (degenerate draw)
+        return
+    outp = emu.run_program(prog, [xs, xd, fe], (hn, he), D, lm)
+    assert rel(lay.from_planar(outp), out) < 1e-6, irr
+    outi = emu.run_program_is(prog, P.is_schedule(prog), [xs, xd, fe], (hn, he), D, lm)
+    assert rel(lay.from_planar(outi), out) < 1e-6, irr
