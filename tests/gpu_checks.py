@@ -119,6 +119,57 @@ def build_backbone_from_fixture(device="cuda", name="backbone"):
     return m, f
 
 
+def check_message_pack_random(device="cuda", seed=0, schedule="auto"):
+    """random irreps set (odd multiplicities, missing parities) + random weights: fused MessagePackBlock on the GPU vs the fp64 oracle"""
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    from tests.test_plan_emu import _random_irreps
+    rng = np.random.default_rng(100 + seed)
+    lmax = int(rng.integers(1, 4))
+    irr = _random_irreps(rng, lmax)
+    if "0e" not in irr:
+        irr = "5x0e+" + irr
+    lsh = int(rng.integers(1, 4))
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
+        E = 83
+        g = torch.Generator().manual_seed(seed)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
+        vec = torch.randn(E, 3, generator=g) * 3.0
+        n = torch.nn.functional.normalize(vec, dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        out = ref(src, dst, ef, shv, rbf).detach()
+    finally:
+        torch.set_default_dtype(prev)
+    m = load_weights(hnn.MessagePackBlock(irr, irr, sh, irr, 8, [16, 16]), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    os.environ["HG_MP_KERNEL"] = schedule
+    try:
+        m.compile(device, unrotate=True)
+    finally:
+        os.environ.pop("HG_MP_KERNEL", None)
+    lay = P.PlanarLayout(irr)
+    lm = max(lmax, lsh)
+    v = torch.stack([n[:, 2], n[:, 0], n[:, 1]], 1) * 2.0          # e3nn axis order (y, z, x) -> physical (x, y, z)
+    jtab = torch.from_numpy(P.wigner_jtab(lm)).to(device)
+    ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.long)]).to(device)
+    geo = ops.Geometry(torch.zeros(2, 3, device=device), ei, v.float().to(device), 8.0, 8, lm, jtab)
+    geo.rbf = rbf.float().to(device).contiguous()
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    rot = torch.from_numpy(P.rotate_table(lay)).to(device)
+    pl = lambda t: ops.to_planar(t.float().to(device), imap, lay.dim)
+    xs, xd, fe = (ops.rotate_gather(pl(t), None, geo, rot) for t in (src, dst, ef))
+    y = ops.from_planar(m.run(xs, xd, fe, geo), imap)
+    torch.cuda.synchronize()
+    scale = out.abs().max().item()
+    return {"irreps": irr, "sh": sh, "kernel": "is" if m._dp.sched is not None else "seg",
+            "rel_err": 0.0 if scale < 1e-12 else rel(y, out)}
+
+
 def check_backbone(device="cuda", name="backbone"):
     m, f = build_backbone_from_fixture(device, name)
     g = to_graph(f["graph"], device)

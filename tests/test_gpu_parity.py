@@ -38,6 +38,14 @@ def test_backbone_golden_both_kernels(schedule, monkeypatch):
     assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
 
 
+@pytest.mark.parametrize("schedule", ["seg", "auto"])
+@pytest.mark.parametrize("seed", range(5))
+def test_message_pack_random_irreps_vs_oracle(seed, schedule):
+    r = G.check_message_pack_random(seed=seed, schedule=schedule)
+    print(r)
+    assert r["rel_err"] < G.TOL
+
+
 def test_corr_product_block_golden():
     r = G.check_corr_product()
     print(r)
