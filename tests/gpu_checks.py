@@ -327,7 +327,7 @@ def check_head_su2(device="cuda"):
 
 
 def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, nao=19, num_layers=2, radial=(16, 16), num_radial=8,
-                         n_graphs=1):
+                         n_graphs=1, legacy_edge_update=False, zs=(14, 8, 6, 1), soc=False):
     """Seeded random weights on a synthetic periodic cell: full backbone + head, HIP (fp32) vs oracle (fp64, CPU)."""
     from oracle import hamgnn_ref as R
     from hamgnn_amd.data import synthetic as S
@@ -336,16 +336,16 @@ def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, n
     cfg = dict(num_types=96, irreps_edge_sh=sh, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
                cutoff=26.0, rbf_func="bessel", num_radial=num_radial, num_layers=num_layers, irreps_node_features=irreps, use_kan=False,
                radial_MLP=list(radial), correlation=2, num_hidden_features=16, radius_type="openmx", use_corr_prod=False,
-               legacy_edge_update=False, lite_mode=False)
+               legacy_edge_update=legacy_edge_update, lite_mode=False)
     torch.manual_seed(666 + seed)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
         ref = R.HamGNNConvE3(cfg)
-        ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True)
+        ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True, soc_switch=soc)
     finally:
         torch.set_default_dtype(prev)
-    gs = [S.add_random_targets(S.random_cell(n_atoms + 2 * k, [14, 8, 6, 1], seed=seed + k, density=0.004), nao, seed=seed + k)
+    gs = [S.add_random_targets(S.random_cell(n_atoms + 2 * k, list(zs), seed=seed + k, density=0.004), nao, seed=seed + k, soc=soc)
           for k in range(n_graphs)]
     if n_graphs == 1:
         g = gs[0]
@@ -354,7 +354,7 @@ def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, n
         g = collate(gs)                                       # multi-crystal batch: per-graph inverse offsets + [on;off] interleave
     hip = load_weights(HamGNNConvE3(cfg), {k: v for k, v in ref.state_dict().items()})
     hip_head = load_weights(HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
-                                              soc_switch=False), {k: v for k, v in ref_head.state_dict().items()})
+                                              soc_switch=soc), {k: v for k, v in ref_head.state_dict().items()})
     g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
     with torch.no_grad():
         rep_ref = ref(g64)

@@ -117,6 +117,14 @@ def test_multi_crystal_batch_vs_oracle():
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
 
 
+def test_uni_hamgnn_style_batch_vs_oracle():
+    """BASELINE config #5 in small: mixed-Z multi-crystal batch, nao_max 26 (f shells), legacy_edge_update (layer 0 keeps the
+    embedded edge features), SOC so3 head -- full HIP forward vs the fp64 oracle."""
+    r = G.oracle_vs_hip_random(n_graphs=3, seed=9, nao=26, legacy_edge_update=True, zs=(14, 8, 79, 42), soc=True)
+    print(r)
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
+
+
 @pytest.mark.parametrize("which", ["A", "B"])
 def test_si2_default_irreps_vs_oracle(which):
     """BASELINE config #1 with the shipped irreps (set-A: D=877, l<=6) and the lmax-4 set (set-B)."""
