@@ -622,10 +622,12 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
     A.ostride = out_stride;
     A.rows = rows;
     A.tile_floats_wave = lds_bytes / 16;           // 4 waves x 4 bytes
-    if (lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((program_flags & 1) ? (const void*)tp_fused_kernel<true> : (const void*)tp_fused_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    static bool lds_attr_set = false;                          // once per process (not a stream operation: illegal during graph capture)
+    if (!lds_attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)tp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return hg_fail(-3, hipGetErrorString(e));
+        lds_attr_set = true;
     }
     const unsigned grid = (unsigned)((rows + 63) / 64);
     if (program_flags & 1)

@@ -615,9 +615,11 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
     A.rot_mask = rot_mask;
     if (rot_mask && !wig) return hg_fail(-2, "hg_tp_is: rotated sources need the Wigner rows");
-    if (lds_bytes > 64 * 1024) {
-        hipError_t err = hipFuncSetAttribute((const void*)tp_is_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    static bool lds_attr_set = false;                          // once per process (not a stream operation: illegal during graph capture)
+    if (!lds_attr_set) {
+        hipError_t err = hipFuncSetAttribute((const void*)tp_is_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (err != hipSuccess) return hg_fail(-3, hipGetErrorString(err));
+        lds_attr_set = true;
     }
     const unsigned grid = (unsigned)((rows + 15) / 16);
     hipLaunchKernelGGL(tp_is_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table, group_table,

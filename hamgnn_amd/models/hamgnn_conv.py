@@ -112,7 +112,12 @@ class HamGNNConvE3(nn.Module):
         Dp = self.layout.dim
         f = self.pair_embedding.run(z, geo)                                          # [E, Dp] edge-aligned frame
         node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)          # [N, Dp]
-        rowptr, perm = geo.receiver_csr(N)
+        csr = data.get("_hg_receiver_csr") if isinstance(data, dict) else None
+        if csr is None or csr[1].shape[0] != geo.E or csr[1].device != geo.dst.device:
+            csr = geo.receiver_csr(N)                          # topology-only index plumbing: once per graph object (bincount host-syncs)
+            if isinstance(data, dict):
+                dict.__setitem__(data, "_hg_receiver_csr", csr)
+        rowptr, perm = csr
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             skip = conv.skip_linear(node)

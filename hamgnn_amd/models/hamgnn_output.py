@@ -125,10 +125,16 @@ class HamGNNPlusPlusOut(nn.Module):
         batch = getattr(data, "batch", None)
         if batch is None or data.get("_hg_inv_is_local_global", False):
             return data.inv_edge_idx.contiguous(), None
+        cached = data.get("_hg_global_inverse") if isinstance(data, dict) else None
+        if cached is not None and cached[0].shape[0] == src.shape[0] and cached[0].device == src.device:
+            return cached                                      # topology-only index plumbing: once per graph object (bincount host-syncs)
         b = batch[src]
         counts = torch.bincount(b, minlength=int(data.node_counts.shape[0]) if hasattr(data, "node_counts") else 0)
         offs = torch.cumsum(counts, 0) - counts
-        return (data.inv_edge_idx + offs[b]).contiguous(), counts
+        res = ((data.inv_edge_idx + offs[b]).contiguous(), counts)
+        if isinstance(data, dict):
+            dict.__setitem__(data, "_hg_global_inverse", res)
+        return res
 
     @staticmethod
     def _cat_by_crystal(data, on, off, edge_counts):
