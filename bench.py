@@ -160,7 +160,6 @@ def main():
     g = g.to(dev)
     model.compile(dev)
     head.compile(dev)
-    g["_hg_validated"] = True
 
     def step():
         with torch.no_grad():

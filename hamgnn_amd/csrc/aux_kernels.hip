@@ -20,8 +20,16 @@ int hg_check_launch(const char* what) {
     }
     return 0;
 }
+int hg_lds_attr_once(unsigned char* done, int dev, const void* kernel, int bytes) {
+    if (dev < 0 || dev >= HG_MAX_DEVICES) return hg_fail(-3, "device index out of range");
+    if (__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) return 0;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return hg_fail(-3, hipGetErrorString(e));
+    __atomic_store_n(&done[dev], (unsigned char)1, __ATOMIC_RELEASE);
+    return 0;
+}
 extern "C" const char* hg_last_error(void) { return g_err; }
-extern "C" int hg_version(void) { return 1; }
+extern "C" int hg_version(void) { return 2; }
 
 // ------------------------------------------------------------------------------------------------ edge geometry
 // angles of R_e = Rx(beta) Ry(alpha) taking the e3nn-order unit vector n = (v_y, v_z, v_x)/|v| onto the pole (0,1,0);
@@ -102,6 +110,7 @@ __global__ void wigner_kernel(const float4* __restrict__ ang, int64_t E, const f
 extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, const float* nbr_shift, int64_t E, float cutoff,
                                 int num_radial, int lmax_wig, const float* jtab, float* rbf, float* wig, float* edge_len,
                                 float* ang_scratch, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (E <= 0) return 0;
     if (lmax_wig > 7) return hg_fail(-2, "hg_edge_geometry: lmax_wig > 7 not instantiated");
     hipStream_t st = (hipStream_t)stream;
@@ -259,6 +268,7 @@ __global__ __launch_bounds__(256) void radial_hidden_mfma_kernel(const float* __
 
 extern "C" int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const int32_t* dims, int nlayers, float act_cst,
                                 float* h_out, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (E <= 0) return 0;
     if (nlayers < 1 || nlayers > 3) return hg_fail(-2, "hg_radial_hidden: 1..3 hidden layers supported");
     if (nlayers == 2 && dims[0] == 64 && dims[1] == 64 && dims[2] == 64) {
@@ -355,6 +365,7 @@ __global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restr
 extern "C" int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stride, const int64_t* idx0, const int64_t* idx1,
                                 const float* wig, int nW, const int32_t* wig_off, const int32_t* grp_tab, int ngroups, int64_t E,
                                 int transpose, float* out0, float* out1, int64_t out_stride, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (E <= 0) return 0;
     if ((x_stride & 3) || (out_stride & 3)) return hg_fail(-2, "hg_rotate_gather: row strides must be multiples of 4 floats (planar rows)");
     HgWigOff wo;
@@ -380,6 +391,7 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
 
 extern "C" int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_t* rowptr, const int64_t* perm, int64_t N, int Dp,
                               float* out, int64_t out_stride, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (N <= 0) return 0;
     segment_sum_kernel<<<dim3((unsigned)N), 256, 0, (hipStream_t)stream>>>(msg, msg_stride, rowptr, perm, Dp, out, out_stride);
     return hg_check_launch("hg_segment_sum");
@@ -413,6 +425,7 @@ __global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, 
 
 extern "C" int hg_gate(const float* x, int64_t x_stride, const int32_t* tab, int Dout, const float* consts, int64_t rows, float* out,
                        int64_t out_stride, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     gate_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(x, x_stride, (const int4*)tab, Dout, consts, rows, out, out_stride);
     return hg_check_launch("hg_gate");
@@ -431,6 +444,7 @@ __global__ void add_rows_kernel(const float* __restrict__ a, int64_t sa, const f
 
 extern "C" int hg_add_rows(const float* a, int64_t sa, const float* b, int64_t sb, const float* c, int64_t sc, int64_t rows, int D,
                            float* out, int64_t so, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     add_rows_kernel<<<dim3((unsigned)((rows * D + 255) / 256)), 256, 0, (hipStream_t)stream>>>(a, sa, b, sb, c, sc, rows, D, out, so);
     return hg_check_launch("hg_add_rows");
@@ -451,12 +465,14 @@ __global__ void from_planar_kernel(const float* __restrict__ xp, int64_t rows, i
     out[i] = xp[r * Dp + map[k]];
 }
 extern "C" int hg_to_planar(const float* x, int64_t rows, int D, const int32_t* map, float* out, int Dp, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)rows * Dp, (hipStream_t)stream);
     to_planar_kernel<<<dim3((unsigned)((rows * D + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, rows, D, map, out, Dp);
     return hg_check_launch("hg_to_planar");
 }
 extern "C" int hg_from_planar(const float* xp, int64_t rows, int Dp, const int32_t* map, float* out, int D, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     from_planar_kernel<<<dim3((unsigned)((rows * D + 255) / 256)), 256, 0, (hipStream_t)stream>>>(xp, rows, Dp, map, out, D);
     return hg_check_launch("hg_from_planar");
@@ -478,6 +494,7 @@ __global__ void embed_lookup_kernel(const float* __restrict__ Ta, const float* _
 }
 extern "C" int hg_embed_lookup(const float* Ta, const float* Tb, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b,
                                int64_t rows, int T, int Tp, float* out, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     embed_lookup_kernel<<<dim3((unsigned)((rows * Tp + 255) / 256)), 256, 0, (hipStream_t)stream>>>(Ta, Tb, z, idx_a, idx_b, rows, T, Tp, out);
     return hg_check_launch("hg_embed_lookup");

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void ham_merge_kernel(const float* __restrict_
 extern "C" int hg_ham_merge(const float* coeff, int64_t c_stride, const float* wig, int nW, const int32_t* wig_off,
                             const int32_t* slot_tab, int nslots, const int32_t* cg_ptr, const int32_t* cg_idx, const float* cg_val,
                             int nout, int64_t rows, float* Hraw, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nslots <= 0 || nout <= 0 || nslots > 16384) return hg_fail(-2, "hg_ham_merge: bad slot / output count");
     HgWigOff wo;
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void ham_finish_kernel(const float* __restrict
 extern "C" int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t* inv, const float* H0, const float* orb_mask,
                              int mask_w, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b, int nao, float sign, int flags,
                              int64_t rows, float* H, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (orb_mask && (mask_w <= 0 || nao % mask_w)) return hg_fail(-2, "hg_ham_finish: nao must be a multiple of the mask width");
     ham_finish_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(Hraw, h_stride, inv, H0, orb_mask, z, idx_a, idx_b, nao,
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(256) void block_mean_kernel(const float* __restrict
 }
 
 extern "C" int hg_block_mean(const float* x, int64_t x_stride, const int32_t* tab, int nao, int64_t rows, float* out, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     block_mean_kernel<<<dim3((unsigned)rows), 256, sizeof(float) * (size_t)nao * nao, (hipStream_t)stream>>>(x, x_stride, (const int4*)tab, nao, out);
     return hg_check_launch("hg_block_mean");
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256) void soc_assemble_kernel(const float* __restri
 
 extern "C" int hg_soc_assemble(const float* H, const float* ksi, const float* L, const int64_t* inv, const float* H0r, const float* H0i,
                                int nao, int symmetrize, int zero_diag, int64_t rows, float* out_real, float* out_imag, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     soc_assemble_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(H, ksi, L, inv, H0r, H0i, nao, symmetrize, zero_diag, out_real, out_imag);
     return hg_check_launch("hg_soc_assemble");
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(256) void zp_apply_kernel(float* __restrict__ H, co
 
 extern "C" int hg_zero_point_shift(float* H, const float* Href, const float* S, int64_t rows, int nao, int soc, float threshold,
                                    double* partial_scratch, int nparts, float* shift_out, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nparts <= 0 || nparts > 1024) return hg_fail(-2, "hg_zero_point_shift: scratch must hold 1..1024 partial pairs");
     const int64_t count = rows * nao * nao;
@@ -261,6 +266,7 @@ extern "C" int hg_sym_contraction(const float* h, int64_t h_stride, const int64_
                                   int nout, const int32_t* out_off, const int32_t* ptr1, const int32_t* ent1, const int32_t* ptr2,
                                   const int32_t* ent2, const float* W1, int K1, const float* W2, int K2, float* out, int64_t out_stride,
                                   void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (N <= 0) return 0;
     const size_t lds = sizeof(float) * (size_t)num_ell * C;
     if (lds > 64 * 1024) return hg_fail(-2, "hg_sym_contraction: hidden features too wide for the LDS-resident kernel");

@@ -599,6 +599,7 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
                            const float* h2_edge, int hidden, const float* wig, int nW, const int32_t* wig_off,
                            const float* weights, const int32_t* seg_table, int nseg, const int32_t* item_table, float* out,
                            int64_t out_stride, int64_t rows, int lds_bytes, int program_flags, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_fused: nsrc must be 1..4");
     if (hidden & 15) return hg_fail(-2, "hg_tp_fused: (padded) hidden width must be a multiple of 16");
@@ -622,13 +623,9 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
     A.ostride = out_stride;
     A.rows = rows;
     A.tile_floats_wave = lds_bytes / 16;           // 4 waves x 4 bytes
-    static bool lds_attr_set = false;                          // once per process (not a stream operation: illegal during graph capture)
-    if (!lds_attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)tp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)tp_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return hg_fail(-3, hipGetErrorString(e));
-        lds_attr_set = true;
-    }
+    static unsigned char lds_attr_done[2][HG_MAX_DEVICES];     // once per device (not a stream operation: illegal during graph capture)
+    if (int rc = hg_lds_attr_once(lds_attr_done[0], dev_guard.dev, (const void*)tp_fused_kernel<true>, 160 * 1024)) return rc;
+    if (int rc = hg_lds_attr_once(lds_attr_done[1], dev_guard.dev, (const void*)tp_fused_kernel<false>, 160 * 1024)) return rc;
     const unsigned grid = (unsigned)((rows + 63) / 64);
     if (program_flags & 1)
         hipLaunchKernelGGL(tp_fused_kernel<true>, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);

@@ -588,6 +588,7 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
                         int nseg, const int32_t* block_table, const int32_t* phase_table, int nphase, const int32_t* group_table,
                         const int32_t* item_table, int trash_off, int stage_off, int ctr_off, int lds_bytes,
                         const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_is: nsrc must be 1..4");
     if (hidden & 15) return hg_fail(-2, "hg_tp_is: (padded) hidden width must be a multiple of 16");
@@ -615,12 +616,8 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
     A.rot_mask = rot_mask;
     if (rot_mask && !wig) return hg_fail(-2, "hg_tp_is: rotated sources need the Wigner rows");
-    static bool lds_attr_set = false;                          // once per process (not a stream operation: illegal during graph capture)
-    if (!lds_attr_set) {
-        hipError_t err = hipFuncSetAttribute((const void*)tp_is_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err != hipSuccess) return hg_fail(-3, hipGetErrorString(err));
-        lds_attr_set = true;
-    }
+    static unsigned char lds_attr_done[HG_MAX_DEVICES];        // once per device (not a stream operation: illegal during graph capture)
+    if (int rc = hg_lds_attr_once(lds_attr_done, dev_guard.dev, (const void*)tp_is_kernel, 160 * 1024)) return rc;
     const unsigned grid = (unsigned)((rows + 15) / 16);
     hipLaunchKernelGGL(tp_is_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table, group_table,
                        item_table, weights);

@@ -16,7 +16,8 @@ class Graph(dict):
         self[k] = v
 
     def to(self, device, non_blocking=False):
-        return Graph({k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v) for k, v in self.items()})
+        # the topology cache (hamgnn_amd/topo.py) belongs to THIS object's tensors: never copied to a derived graph
+        return Graph({k: (v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v) for k, v in self.items() if k != "_hg_topology"})
 
     def to_dict(self):
         return dict(self)

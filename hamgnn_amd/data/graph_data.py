@@ -1,7 +1,7 @@
 """`graph_data.npz` reader / writer for the hot path (reference container: hamgnn/data/graph_data.py:96-185 NPZGraphDataset;
 produced by DFT_interfaces/*/graph_data_gen.py:357-374 as ``np.savez(path, graph={idx: Data(...)})``).
 
-The reference stores pickled torch_geometric ``Data`` objects.  This reader works without torch_geometric: a restricted
+The reference stores pickled torch_geometric ``Data`` objects.  This reader works without torch_geometric: an allow-list
 unpickler maps ``torch_geometric.data.*`` classes onto the dependency-free ``Graph`` container (attribute + key access,
 same field names), so files written by the reference tool-chain and by ``save_graph_npz`` load the same way.  Dict-of-
 arrays graphs (the reference's second accepted form, graph_data.py:141-156) are converted as well.  LMDB
@@ -56,13 +56,36 @@ def _to_graph(obj) -> Graph:
     return g
 
 
+# Everything a pickled graph record legitimately refers to: tensors / storages, numpy arrays and scalars, plain containers, and
+# the torch_geometric container classes (mapped onto _PyGStub).  Any other global is refused: np.load(allow_pickle=True), which the
+# reference uses (hamgnn/data/graph_data.py:110-119), would execute it.
+_ALLOWED = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"),
+    ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"),
+    ("builtins", "bytes"), ("builtins", "complex"), ("builtins", "slice"), ("builtins", "range"), ("builtins", "bytearray"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch.storage", "_load_from_bytes"),
+    ("torch.serialization", "_get_layout"), ("torch", "Tensor"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"), ("numpy.core.numeric", "_frombuffer"),
+    ("numpy._core.numeric", "_frombuffer"), ("_codecs", "encode"), ("copyreg", "_reconstructor"), ("builtins", "object"),
+}
+_ALLOWED_TORCH_NAMES = {n for n in dir(torch) if n.endswith("Storage")} | {str(d).split(".")[-1] for d in (
+    torch.float16, torch.float32, torch.float64, torch.bfloat16, torch.int8, torch.uint8, torch.int16, torch.int32, torch.int64, torch.bool,
+    torch.complex64, torch.complex128)}
+
+
 class _Unpickler(pickle.Unpickler):
+    """allow-list unpickler (see _ALLOWED); torch_geometric classes become _PyGStub"""
+
     def find_class(self, module, name):
         if module.startswith("torch_geometric"):
             return _PyGStub
         if module.startswith("hamgnn_amd.data") and name == "Graph":
             return Graph
-        return super().find_class(module, name)
+        if (module, name) in _ALLOWED or (module == "torch" and name in _ALLOWED_TORCH_NAMES):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"graph record refers to {module}.{name}, which is not on the loader's allow-list")
 
 
 def load_graph_npz(path: str) -> List[Graph]:

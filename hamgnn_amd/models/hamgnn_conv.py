@@ -14,6 +14,7 @@ from .. import ops
 from .. import parallel
 from .. import plan as P
 from ..so3 import Irreps
+from ..topo import get_topology, gget
 
 
 class Representation(dict):
@@ -108,16 +109,13 @@ class HamGNNConvE3(nn.Module):
             self.compile(dev)
         N = data.z.shape[0]
         z = data.z.contiguous()
+        topo = get_topology(data)                              # index plumbing + validation: once per graph object (host-syncs)
+        topo.check_num_types(self.num_types)                   # z >= num_types would index past the embedding tables on the device
         geo = ops.Geometry(data.pos, data.edge_index, data.nbr_shift, self.cutoff, self.num_radial, self.lmax, self._jtab)
         Dp = self.layout.dim
         f = self.pair_embedding.run(z, geo)                                          # [E, Dp] edge-aligned frame
         node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)          # [N, Dp]
-        csr = data.get("_hg_receiver_csr") if isinstance(data, dict) else None
-        if csr is None or csr[1].shape[0] != geo.E or csr[1].device != geo.dst.device:
-            csr = geo.receiver_csr(N)                          # topology-only index plumbing: once per graph object (bincount host-syncs)
-            if isinstance(data, dict):
-                dict.__setitem__(data, "_hg_receiver_csr", csr)
-        rowptr, perm = csr
+        rowptr, perm = topo.receiver_csr()
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             skip = conv.skip_linear(node)

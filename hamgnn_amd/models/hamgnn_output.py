@@ -16,6 +16,7 @@ from .. import nn as hnn
 from .. import ops
 from .. import plan as P
 from ..so3 import Irreps
+from ..topo import get_topology, gget, ghas
 
 
 class HamGNNPlusPlusOut(nn.Module):
@@ -110,31 +111,11 @@ class HamGNNPlusPlusOut(nn.Module):
 
     # -- index preparation (integer plumbing; hamgnn_output.py:2874-2914, 2985-2990, 1187-1229, 2784-2872)
     def _validate(self, data):
-        if data.get("_hg_validated", False) if isinstance(data, dict) else False:
-            return
-        ok = bool(self._defined[data.z].all().item())
-        if not ok:
-            missing = [int(z) for z in data.z.unique().cpu().tolist() if z not in self.basis_def]
-            raise ValueError("The following elements are missing from basis_def: " + ", ".join(f"Z={z}" for z in missing))
-        if isinstance(data, dict):
-            dict.__setitem__(data, "_hg_validated", True)
+        get_topology(data).check_basis(self._defined, self.basis_def)
 
     @staticmethod
     def _global_inverse(data):
-        src = data.edge_index[0]
-        batch = getattr(data, "batch", None)
-        if batch is None or data.get("_hg_inv_is_local_global", False):
-            return data.inv_edge_idx.contiguous(), None
-        cached = data.get("_hg_global_inverse") if isinstance(data, dict) else None
-        if cached is not None and cached[0].shape[0] == src.shape[0] and cached[0].device == src.device:
-            return cached                                      # topology-only index plumbing: once per graph object (bincount host-syncs)
-        b = batch[src]
-        counts = torch.bincount(b, minlength=int(data.node_counts.shape[0]) if hasattr(data, "node_counts") else 0)
-        offs = torch.cumsum(counts, 0) - counts
-        res = ((data.inv_edge_idx + offs[b]).contiguous(), counts)
-        if isinstance(data, dict):
-            dict.__setitem__(data, "_hg_global_inverse", res)
-        return res
+        return get_topology(data).global_inverse(data)
 
     @staticmethod
     def _cat_by_crystal(data, on, off, edge_counts):

@@ -1,0 +1,107 @@
+"""Model -- Lightning-free mirror of the reference's training wrapper as far as the hot path needs it
+(hamgnn/models/Model.py:63-82 ctor, :359-376 forward): ``forward(batch) = output_module(batch, representation(batch))`` with the
+sub-module names ``representation`` / ``output_module`` that Lightning checkpoints prefix their keys with (Model.py:81-82).
+``Model.load_from_checkpoint(checkpoint_path=..., representation=..., output=..., **ignored)`` has the call shape of
+hamgnn/main.py:374-377, :527-537 and Uni-HamGNN/Uni-HamiltonianPredictor.py:213-225.  Losses / optimiser / logging are the
+training harness (out of scope) and are accepted but unused."""
+from __future__ import annotations
+
+import pickle
+from typing import Dict, Iterable, Optional
+
+import torch
+from torch import nn
+
+# Non-learned buffers the reference / e3nn 0.5.0 keep in their state_dicts (constants a loader may drop): e3nn `output_mask` of
+# o3.Linear / o3.TensorProduct and the w3j constants of the code-generated sub-modules; BesselBasis.freqs (utils/basis_functions.py:190),
+# CosineCutoff.cutoff (utils/cutoff_functions.py:48), GaussianSmearing.offset (:216), ClebschGordanCoefficients.cg_* (physics/
+# Clebsch_Gordan_coefficients.py:27).  Anything else the model has no slot for is an error (a learned tensor would be lost silently).
+_IGNORABLE_LAST = ("output_mask", "freqs", "cutoff", "offset")
+_IGNORABLE_PREFIX_LAST = ("cg_", "_w3j", "w3j", "_big_w3j")
+
+
+def _is_ignorable(key: str) -> bool:
+    last = key.rsplit(".", 1)[-1]
+    return last in _IGNORABLE_LAST or last.startswith(_IGNORABLE_PREFIX_LAST) or "_compiled" in key or "_codegen" in key
+
+
+def load_reference_state_dict(module: nn.Module, state_dict: Dict[str, torch.Tensor], prefix: str = "", allow_unexpected: Iterable[str] = ()):
+    """Load reference-named tensors into a HIP module and VERIFY the result (load_state_dict(strict=False) alone would leave a renamed
+    or missing parameter at its random initial value, silently): every parameter of `module` must be covered with the right shape, and
+    keys the module does not know must be non-learned e3nn / reference buffers.  Returns the list of ignored keys."""
+    sd = {}
+    for k, v in state_dict.items():
+        if prefix and not k.startswith(prefix):
+            continue
+        sd[k[len(prefix):]] = v if torch.is_tensor(v) else torch.as_tensor(v)
+    params = dict(module.named_parameters())
+    missing = sorted(k for k in params if k not in sd)
+    if missing:
+        raise KeyError(f"checkpoint lacks {len(missing)} parameter(s) of {type(module).__name__}, e.g. {missing[:4]}")
+    bad = sorted(k for k in params if tuple(sd[k].shape) != tuple(params[k].shape) and sd[k].numel() != params[k].numel())
+    if bad:
+        k = bad[0]
+        raise ValueError(f"shape mismatch for {k}: checkpoint {tuple(sd[k].shape)} vs model {tuple(params[k].shape)} (+{len(bad) - 1} more)")
+    own = set(params) | set(dict(module.named_buffers()))
+    unexpected = sorted(k for k in sd if k not in own)
+    allow = tuple(allow_unexpected)
+    rogue = [k for k in unexpected if not _is_ignorable(k) and not k.startswith(allow)]
+    if rogue:
+        raise KeyError(f"checkpoint holds {len(rogue)} tensor(s) the model has no slot for, e.g. {rogue[:4]}")
+    with torch.no_grad():
+        for k, p in params.items():
+            p.copy_(sd[k].to(p.dtype).reshape(p.shape))
+    for m in module.modules():                                 # weights changed: packed MFMA fragments are stale
+        if hasattr(m, "_compiled_for"):
+            m._compiled_for = None
+    return unexpected
+
+
+def read_checkpoint_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """state_dict of a Lightning ``.ckpt`` (a torch.save'd dict with key 'state_dict') or of a bare torch.save'd state_dict.
+    Tensors only (weights_only=True): nothing else in the file is executed."""
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError:
+        # Lightning checkpoints also pickle hyper-parameter objects (EasyDict ...): read them with permissive STUB classes, never the real ones
+        from ..uni import stub_load
+        with open(path, "rb") as f:
+            obj = stub_load(f, torch_zip=True)
+    if isinstance(obj, dict) and "state_dict" in obj:
+        obj = obj["state_dict"]
+    if not isinstance(obj, dict) or not all(torch.is_tensor(v) for v in obj.values()):
+        raise ValueError(f"{path}: no state_dict found")
+    return dict(obj)
+
+
+class Model(nn.Module):
+    def __init__(self, representation: nn.Module, output: nn.Module, losses=None, validation_metrics=None, lr: Optional[float] = 1e-3,
+                 lr_decay: Optional[float] = 0.1, lr_patience: Optional[int] = 100, lr_monitor: str = "training/total_loss", epsilon: float = 1e-8,
+                 beta1: float = 0.99, beta2: float = 0.999, amsgrad: bool = True, max_points_to_scatter: int = 100000, post_processing=None):
+        super().__init__()
+        self.representation = representation
+        self.output_module = output
+        self.losses, self.metrics = losses, validation_metrics
+        self.lr, self.lr_decay, self.lr_patience, self.lr_monitor = lr, lr_decay, lr_patience, lr_monitor
+        self.post_processing = post_processing
+        self.requires_derivatives = getattr(self.output_module, "derivative", False)
+        if self.requires_derivatives:
+            raise NotImplementedError("forces (return_forces=True) need the backward pass: outside this round's scope")
+
+    def forward(self, batch):
+        representation = self.representation(batch)
+        return self.output_module(batch, representation)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path: str, map_location=None, strict: bool = True, **model_kwargs):
+        """Lightning's classmethod, for the checkpoint layouts the reference writes: keys ``representation.*`` / ``output_module.*``."""
+        model = cls(**model_kwargs)
+        sd = read_checkpoint_state_dict(checkpoint_path)
+        load_reference_state_dict(model.representation, sd, prefix="representation.")
+        load_reference_state_dict(model.output_module, sd, prefix="output_module.")
+        other = [k for k in sd if not k.startswith(("representation.", "output_module."))]
+        if strict and other:
+            raise KeyError(f"unexpected checkpoint keys outside representation./output_module.: {other[:4]}")
+        if map_location is not None:
+            model = model.to(map_location)
+        return model

@@ -16,6 +16,24 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _on_tensor_device(fn):
+    """Run the launch with the device of the first tensor argument current (its current stream is then the launch stream): a caller
+    that drives a second GPU without torch.cuda.set_device would otherwise enqueue on the wrong device's stream."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        for a in args:
+            t = a if torch.is_tensor(a) else (a[0] if isinstance(a, (list, tuple)) and a and torch.is_tensor(a[0]) else None)
+            if t is not None:
+                if t.is_cuda and t.device.index != torch.cuda.current_device():
+                    with torch.cuda.device(t.device):
+                        return fn(*args, **kwargs)
+                break
+        return fn(*args, **kwargs)
+    return wrapped
+
+
 def _dev(arr: np.ndarray, device, dtype=None):
     t = torch.from_numpy(np.ascontiguousarray(arr))
     if dtype is not None:
@@ -67,6 +85,8 @@ class Geometry:
 
     def __init__(self, pos, edge_index, nbr_shift, cutoff, num_radial, lmax, jtab_dev):
         _require_gpu(pos)
+        if pos.device.index != torch.cuda.current_device():
+            raise RuntimeError(f"hamgnn_amd: make {pos.device} the current device (torch.cuda.set_device) before the forward")
         E = edge_index.shape[1]
         dev = pos.device
         self.E, self.lmax = E, lmax
@@ -82,19 +102,9 @@ class Geometry:
                                      ptr(jtab_dev), ptr(self.rbf), ptr(self.wig), ptr(self.length), ptr(ang), _stream()), "hg_edge_geometry")
         self.src = self.edge_index[0].contiguous()
         self.dst = self.edge_index[1].contiguous()
-        self._csr = None
-
-    def receiver_csr(self, N):
-        """index preparation for the deterministic segmented node scatter (receiver = edge_index[1])."""
-        if self._csr is None:
-            perm = torch.sort(self.dst, stable=True).indices.contiguous()
-            counts = torch.bincount(self.dst, minlength=N)
-            rowptr = torch.zeros(N + 1, dtype=torch.int64, device=self.dst.device)
-            rowptr[1:] = torch.cumsum(counts, 0)
-            self._csr = (rowptr.contiguous(), perm)
-        return self._csr
 
 
+@_on_tensor_device
 def radial_hidden(rbf: torch.Tensor, layers: Sequence[torch.Tensor], act_cst: float) -> torch.Tensor:
     E = rbf.shape[0]
     dims = [int(layers[0].shape[0])] + [int(w.shape[1]) for w in layers]
@@ -105,6 +115,7 @@ def radial_hidden(rbf: torch.Tensor, layers: Sequence[torch.Tensor], act_cst: fl
     return out
 
 
+@_on_tensor_device
 def rotate_gather(x: torch.Tensor, idx: Optional[torch.Tensor], geo: Geometry, chan_tab: torch.Tensor, transpose=False,
                   x2: Optional[torch.Tensor] = None, idx2: Optional[torch.Tensor] = None):
     """one or two gathered sources rotated with the same per-edge frames; returns out (or (out, out2))."""
@@ -123,6 +134,7 @@ def rotate_gather(x: torch.Tensor, idx: Optional[torch.Tensor], geo: Geometry, c
 PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, rows, tag) HIP event pairs around hg_tp_fused launches
 
 
+@_on_tensor_device
 def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None,
              tag: str = "linear", gather: Optional[List[Optional[torch.Tensor]]] = None, rot_mask: int = 0) -> torch.Tensor:
     """gather / rot_mask (input-stationary schedule only): srcs[i] holds global-frame node rows, gathered by gather[i] and rotated
@@ -155,6 +167,7 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     return out
 
 
+@_on_tensor_device
 def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, N: int) -> torch.Tensor:
     Dp = msg.shape[1]
     out = torch.empty(N, Dp, device=msg.device, dtype=torch.float32)
@@ -162,6 +175,7 @@ def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, N: 
     return out
 
 
+@_on_tensor_device
 def gate(x: torch.Tensor, tab: torch.Tensor, consts: torch.Tensor) -> torch.Tensor:
     rows, Dout = x.shape[0], int(tab.shape[0])
     out = torch.empty(rows, Dout, device=x.device, dtype=torch.float32)
@@ -169,6 +183,7 @@ def gate(x: torch.Tensor, tab: torch.Tensor, consts: torch.Tensor) -> torch.Tens
     return out
 
 
+@_on_tensor_device
 def add_rows(a, b, c=None):
     rows, D = a.shape
     out = torch.empty_like(a)
@@ -177,6 +192,7 @@ def add_rows(a, b, c=None):
     return out
 
 
+@_on_tensor_device
 def to_planar(x: torch.Tensor, imap: torch.Tensor, Dp: int) -> torch.Tensor:
     x = x.contiguous().float()
     out = torch.empty(x.shape[0], Dp, device=x.device, dtype=torch.float32)
@@ -184,6 +200,7 @@ def to_planar(x: torch.Tensor, imap: torch.Tensor, Dp: int) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def from_planar(xp: torch.Tensor, imap: torch.Tensor) -> torch.Tensor:
     D = int(imap.shape[0])
     out = torch.empty(xp.shape[0], D, device=xp.device, dtype=torch.float32)
@@ -191,12 +208,14 @@ def from_planar(xp: torch.Tensor, imap: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_on_tensor_device
 def embed_lookup(Ta, Tb, z, idx_a, idx_b, rows, T, Tp):
     out = torch.empty(rows, Tp, device=Ta.device, dtype=torch.float32)
     check(lib().hg_embed_lookup(ptr(Ta), ptr(Tb), ptr(z), ptr(idx_a), ptr(idx_b), i64(rows), i32(T), i32(Tp), ptr(out), _stream()), "hg_embed_lookup")
     return out
 
 
+@_on_tensor_device
 def ham_merge(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, nout):
     rows = coeff.shape[0]
     out = torch.empty(rows, nout, device=coeff.device, dtype=torch.float32)
@@ -206,6 +225,7 @@ def ham_merge(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, 
     return out
 
 
+@_on_tensor_device
 def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetrize=True, h0_after_mask=False):
     """Hraw: [rows, >= nao^2] (a column slice of a wider buffer is fine: the row stride is passed on)."""
     rows = Hraw.shape[0]
@@ -219,6 +239,7 @@ def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetri
     return out
 
 
+@_on_tensor_device
 def block_mean(x, tab, nao):
     rows = x.shape[0]
     out = torch.empty(rows, nao * nao, device=x.device, dtype=torch.float32)
@@ -226,6 +247,7 @@ def block_mean(x, tab, nao):
     return out
 
 
+@_on_tensor_device
 def soc_assemble(H, ksi, L, inv, H0r, H0i, nao, symmetrize=True, zero_diag=False):
     rows = H.shape[0]
     outr = torch.empty(rows, 4 * nao * nao, device=H.device, dtype=torch.float32)
@@ -235,6 +257,7 @@ def soc_assemble(H, ksi, L, inv, H0r, H0i, nao, symmetrize=True, zero_diag=False
     return outr, outi
 
 
+@_on_tensor_device
 def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
     """in place on H; returns the shift (device scalar)."""
     _require_gpu(H)
@@ -247,6 +270,7 @@ def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
     return shift
 
 
+@_on_tensor_device
 def sym_contraction(h, z, C, tab, W1, W2, out_dim):
     """tab: device tensors of plan.sym_contraction_tables; W1 [nel, K1, C], W2 [nel, K2, C]; returns planar hidden rows [N, out_dim]"""
     _require_gpu(h)

@@ -1,0 +1,128 @@
+"""Topology-only index plumbing of one graph object, computed once and cached ON the object (integer work, no arithmetic):
+receiver CSR for the deterministic node scatter (replaces the atomics of torch_scatter.scatter, hamgnn/nn/convolution.py:147-149),
+the batch-global inverse edge map (hamgnn/models/hamgnn_output.py:2985-2990) and the one-time input validation the reference
+does implicitly (F.one_hot(z, num_types) raises for z >= num_types: toolbox/nequip/nn/embedding/_one_hot.py:35-43;
+validate_elements_in_basis_def, hamgnn_output.py:2874-2914).
+
+The cache is keyed on the identity AND the in-place version counter of `edge_index` / `z` / `inv_edge_idx` / `batch`, so replacing
+or mutating any of them invalidates it; it is never copied to derived graphs (Graph.to / shard_graph / collate drop it).
+Works for dict-like graphs (hamgnn_amd.data.Graph) and for attribute-style objects (torch_geometric Data/Batch)."""
+from __future__ import annotations
+
+import torch
+
+CACHE_ATTR = "_hg_topology"
+
+
+def gget(data, key, default=None):
+    """field of a dict-like or attribute-style graph object"""
+    if isinstance(data, dict):
+        return data.get(key, default)
+    try:
+        v = getattr(data, key)
+    except (AttributeError, KeyError):
+        return default
+    return default if v is None else v
+
+
+def ghas(data, key):
+    if isinstance(data, dict):
+        return key in data
+    try:
+        return key in data                                     # PyG Data supports `in`
+    except TypeError:
+        return getattr(data, key, None) is not None
+
+
+def _sig(t):
+    return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+
+class Topology:
+    def __init__(self, data):
+        self.edge_index = gget(data, "edge_index")
+        self.z = gget(data, "z")
+        self.key = self.make_key(data)
+        self.N = int(self.z.shape[0])
+        self.E = int(self.edge_index.shape[1])
+        self._csr = None
+        self._ginv = None
+        self._checked = {}
+
+    @staticmethod
+    def make_key(data):
+        return tuple(_sig(gget(data, k)) for k in ("edge_index", "z", "inv_edge_idx", "batch"))
+
+    # ---- receiver CSR: rowptr[N+1], perm[E] (stable: incoming edges of a node in edge order => fixed summation order)
+    def receiver_csr(self):
+        if self._csr is None:
+            dst = self.edge_index[1]
+            perm = torch.sort(dst, stable=True).indices.contiguous()
+            counts = torch.bincount(dst, minlength=self.N)
+            rowptr = torch.zeros(self.N + 1, dtype=torch.int64, device=dst.device)
+            rowptr[1:] = torch.cumsum(counts, 0)
+            self._csr = (rowptr.contiguous(), perm)
+        return self._csr
+
+    # ---- inverse edge with the per-graph edge offset (hamgnn_output.py:2985-2990) and edges per crystal
+    def global_inverse(self, data):
+        if self._ginv is None:
+            inv = gget(data, "inv_edge_idx")
+            batch = gget(data, "batch")
+            if batch is None or gget(data, "_hg_inv_is_local_global", False):
+                self._ginv = (inv.contiguous(), None)
+            else:
+                src = self.edge_index[0]
+                b = batch[src]
+                nc = gget(data, "node_counts")
+                counts = torch.bincount(b, minlength=int(nc.shape[0]) if nc is not None else 0)
+                offs = torch.cumsum(counts, 0) - counts
+                self._ginv = ((inv + offs[b]).contiguous(), counts)
+        return self._ginv
+
+    # ---- one-time validation (host sync once per graph object, like the reference's z.unique().cpu())
+    def check_num_types(self, num_types: int):
+        if self._checked.get(("types", num_types)):
+            return
+        if self.N:
+            lo, hi = int(self.z.min()), int(self.z.max())
+            if lo < 0 or hi >= num_types:
+                raise ValueError(f"atomic numbers must lie in [0, num_types={num_types}): found z in [{lo}, {hi}] "
+                                 "(the reference's one-hot encoding raises for these)")
+        if self.E:
+            lo, hi = int(self.edge_index.min()), int(self.edge_index.max())
+            if lo < 0 or hi >= self.N:
+                raise ValueError(f"edge_index refers to atoms outside [0, {self.N})")
+        self._checked[("types", num_types)] = True
+
+    def check_basis(self, defined_dev: torch.Tensor, basis_def: dict):
+        k = ("basis", id(basis_def))
+        if self._checked.get(k):
+            return
+        zmax = int(self.z.max()) if self.N else 0
+        ok = zmax < defined_dev.shape[0] and bool(defined_dev[self.z].all().item())
+        if not ok:
+            missing = [int(z) for z in self.z.unique().cpu().tolist() if z not in basis_def]
+            raise ValueError("The following elements are missing from basis_def: " + ", ".join(f"Z={z}" for z in missing))
+        self._checked[k] = True
+
+
+def get_topology(data) -> Topology:
+    """the cached Topology of `data`, rebuilt when edge_index / z / inv_edge_idx / batch were replaced or mutated in place"""
+    t = data.get(CACHE_ATTR) if isinstance(data, dict) else getattr(data, "__dict__", {}).get(CACHE_ATTR)
+    if t is not None and t.key == Topology.make_key(data):
+        return t
+    t = Topology(data)
+    try:
+        if isinstance(data, dict):
+            dict.__setitem__(data, CACHE_ATTR, t)
+        else:
+            object.__setattr__(data, CACHE_ATTR, t)            # bypasses PyG's __setattr__ (which would store it as a graph field)
+    except Exception:                                          # objects without a __dict__: recomputed per call
+        pass
+    return t
+
+
+def strip_cache(d: dict) -> dict:
+    d.pop(CACHE_ATTR, None)
+    return d

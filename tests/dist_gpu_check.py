@@ -18,12 +18,14 @@ from hamgnn_amd.data import synthetic as S
 from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
 from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
 
-irreps = bench.IRREPS["B"]
+irreps = bench.IRREPS[os.environ.get("HG_DIST_IRREPS", "B")]
+workload = os.environ.get("HG_DIST_WORKLOAD", "si64")
 torch.manual_seed(666)
 model = HamGNNConvE3(bench.make_cfg(irreps))
 head = HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=False,
                          calculate_sparsity=False)
-g = S.add_random_targets(S.si_diamond(2, 2, 2, jitter=0.05, seed=0), 19, seed=0)
+g = S.si_diamond(2, 2, 2, jitter=0.05, seed=0) if workload == "si64" else S.amorphous_sio2(int(workload.split("_")[1]), seed=1)
+g = S.add_random_targets(g, 19, seed=0)
 N, E = g.num_nodes, g.num_edges
 sg = parallel.shard_graph(g, rank, world).to(dev)
 with torch.no_grad():
@@ -41,6 +43,6 @@ if rank == 0:
         assert torch.allclose(on, gathered[0][1], atol=0, rtol=0) or (on - gathered[0][1]).abs().max() < 1e-5
     full = torch.cat([gathered[0][1], off], 0)
     err = ((full - ref).abs().max() / ref.abs().max()).item()
-    print("DIST_CHECK", json.dumps({"world": world, "N": N, "E": E, "edges_per_rank": [int(x[0].numel()) for x in gathered], "rel_err": err}))
-    assert err < 1e-5
+    assert err < 1e-5, err
+    print("DIST_CHECK", json.dumps({"world": world, "workload": workload, "N": N, "E": E, "edges_per_rank": [int(x[0].numel()) for x in gathered], "rel_err": err}))
 dist.destroy_process_group()

@@ -367,9 +367,10 @@ def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, n
             "H_rel_err": rel(H, H_ref), "H_mae": (H.double().cpu() - H_ref).abs().mean().item()}
 
 
-def check_default_irreps_si2(device="cuda", which="A"):
+def check_default_irreps_si2(device="cuda", which="A", graph="si2"):
     """BASELINE config #1: Si diamond 2-atom cell (172 edges) with the shipped default irreps (set-A, D=877, l<=6, sh lmax 5,
-    64 radial, MLP [64,64], 3 layers, nao 19) -- full HIP forward vs the fp64 oracle.  Exercises every kernel instantiation."""
+    64 radial, MLP [64,64], 3 layers, nao 19) -- full HIP forward vs the fp64 oracle.  Exercises every kernel instantiation.
+    graph="sio2_<n>": the generator of BASELINE config #4 (amorphous SiO2) at a size the fp64 oracle affords."""
     import bench
     from oracle import hamgnn_ref as R
     from hamgnn_amd.data import synthetic as S
@@ -386,7 +387,7 @@ def check_default_irreps_si2(device="cuda", which="A"):
         ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", symmetrize=True, add_H0=True)
     finally:
         torch.set_default_dtype(prev)
-    g = S.add_random_targets(S.si_diamond(primitive=True), 19, seed=0)
+    g = S.add_random_targets(S.si_diamond(primitive=True) if graph == "si2" else S.amorphous_sio2(int(graph.split("_")[1]), seed=1), 19, seed=0)
     hip = load_weights(HamGNNConvE3(cfg), dict(ref.state_dict()))
     hip_head = load_weights(HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
                                               soc_switch=False), dict(ref_head.state_dict()))
@@ -436,6 +437,11 @@ def check_full_size_properties(device="cuda", workload="si512", which="B", soc=F
     model = HamGNNConvE3(bench.make_cfg(irreps))
     head = HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
                              soc_switch=soc, soc_basis="so3", calculate_sparsity=False)
+    if workload == "sio2_10k":
+        torch.manual_seed(666)                                 # the seed bench.py uses: same weights as the benchmarked forward
+        model = HamGNNConvE3(bench.make_cfg(irreps))
+        head = HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
+                                 soc_switch=soc, soc_basis="so3", calculate_sparsity=False)
     g = bench.make_graph(workload, nao) if not soc else S.add_random_targets(
         S.mos2_monolayer(20, 20) if workload == "mos2_1200" else bench.make_graph(workload, nao), nao, seed=0, soc=True)
     N, E = g.num_nodes, g.num_edges
@@ -498,5 +504,131 @@ def check_full_size_properties(device="cuda", workload="si512", which="B", soc=F
     g3["pos"] = g.pos + torch.tensor([0.37, -1.21, 2.05])
     H3 = run(g3)
     res["translation_err"] = (H3 - H).abs().max().item() / scale
+    torch.cuda.synchronize()
+    return res
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config #5 (Uni-HamGNN)
+UNI_ZS = (1, 6, 8, 14, 22, 26, 31, 42, 47, 56, 74, 79, 83)      # light ... heavy, s / p / d / f shells of the 26-orbital table
+
+
+def _uni_config(irreps, soc, num_layers=3, radial=(64, 64), num_radial=64):
+    pre = dict(num_types=96, irreps_edge_sh=SH_FULL, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=num_radial, num_layers=num_layers, irreps_node_features=irreps, use_kan=False,
+               radial_MLP=list(radial), correlation=2, num_hidden_features=16)
+    out = dict(nao_max=26, ham_type="openmx", ham_only=True, symmetrize=True, calculate_band_energy=False, num_k=4, k_path=None,
+               band_num_control=None, soc_switch=soc, nonlinearity_type="gate", add_H0=True, spin_constrained=False, collinear_spin=False,
+               minMagneticMoment=0.5)
+    return dict(representation_nets=dict(HamGNN_pre=pre), output_nets=dict(HamGNN_out=out))
+
+
+SH_FULL = "0e+1o+2e+3o+4e+5o"
+
+
+def _uni_models(irreps):
+    """the two universal models (non-SOC and SOC/so3 with add_H_nonsoc) as HIP Models and as fp64 oracle modules, same weights"""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import uni
+    from hamgnn_amd.models.model import Model
+    hip, ref = {}, {}
+    for soc in (False, True):
+        cfg = _uni_config(irreps, soc)
+        rep, head = uni.build_hamgnn_components(cfg)
+        assert rep.legacy_edge_update and not rep.use_corr_prod and head.add_H_nonsoc == soc and head.zero_point_shift == (not soc)
+        torch.manual_seed(700 + int(soc))
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            r_rep = R.HamGNNConvE3(dict(cfg["representation_nets"]["HamGNN_pre"]))
+            r_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=26, ham_type="openmx", symmetrize=True, add_H0=True, soc_switch=soc,
+                                         add_H_nonsoc=soc, zero_point_shift=False)
+        finally:
+            torch.set_default_dtype(prev)
+        assert r_rep.legacy_edge_update
+        load_weights(rep, dict(r_rep.state_dict()))
+        load_weights(head, dict(r_head.state_dict()))
+        hip[soc] = Model(representation=rep, output=head)
+        ref[soc] = (r_rep, r_head)
+    return hip, ref
+
+
+def _uni_graph_pair(n_atoms, seed, density=0.004):
+    """one crystal as the (non-SOC, SOC) record pair the universal predictor reads: same geometry, nao^2 vs (2 nao)^2 targets"""
+    from hamgnn_amd.data import synthetic as S
+    base = S.random_cell(n_atoms, list(UNI_ZS), seed=seed, density=density)
+    g_ns = S.add_random_targets(type(base)(base), 26, seed=seed, soc=False)
+    g_soc = S.add_random_targets(type(base)(base), 26, seed=seed + 1000, soc=True)
+    return g_ns, g_soc
+
+
+def check_uni_chain_vs_oracle(device="cuda", irreps=None, n_graphs=8):
+    """BASELINE config #5 as the reference runs it (Uni-HamiltonianPredictor.py:290-319): mixed-Z crystals, one per batch, set-A
+    irreps, nao_max 26, non-SOC model -> Hon_nonsoc/Hoff_nonsoc -> SOC/so3 model with add_H_nonsoc -- HIP chain vs the same chain on
+    the fp64 oracle, 8 graphs (4..11 atoms so that the oracle finishes in seconds)."""
+    import bench
+    from hamgnn_amd import uni
+    irreps = irreps or bench.IRREPS["A"]
+    hip, ref = _uni_models(irreps)
+    pred = uni.HamiltonianPredictor(hip[False].to(device), hip[True].to(device), device)
+    res = {"real": 0.0, "imag": 0.0, "nonsoc": 0.0, "edges": 0, "mask_mismatch": 0}
+    to64 = lambda g: type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    for k in range(n_graphs):
+        g_ns, g_soc = _uni_graph_pair(4 + k, seed=40 + k)
+        with torch.no_grad():
+            r_ns = ref[False][1](to64(g_ns), ref[False][0](to64(g_ns)))["hamiltonian"]
+            gs64 = to64(g_soc)
+            n = g_soc.num_nodes
+            gs64["Hon_nonsoc"], gs64["Hoff_nonsoc"] = r_ns[:n], r_ns[n:]
+            r_soc = ref[True][1](gs64, ref[True][0](gs64))
+        b_ns, b_soc = g_ns.to(device), g_soc.to(device)
+        out = pred.predict(b_ns, b_soc)
+        torch.cuda.synchronize()
+        res["nonsoc"] = max(res["nonsoc"], rel(torch.cat([b_soc["Hon_nonsoc"], b_soc["Hoff_nonsoc"]]), r_ns))
+        res["real"] = max(res["real"], rel(out["hamiltonian_real"], r_soc["hamiltonian_real"]))
+        res["imag"] = max(res["imag"], rel(out["hamiltonian_imag"], r_soc["hamiltonian_imag"]))
+        assert torch.equal(out["hamiltonian"], torch.cat([out["hamiltonian_real"], out["hamiltonian_imag"]]))
+        # mask_real_imag (get_nonzero_mask_tensor=True): every predicted non-zero lies inside the mask
+        m = out["mask_real_imag"]
+        res["mask_mismatch"] += int(((out["hamiltonian_real"] != 0) & ~m).sum()) + int(((out["hamiltonian_imag"] != 0) & ~m).sum())
+        res["edges"] += g_ns.num_edges
+    return res
+
+
+def check_uni_chain_full_size(device="cuda", n_graphs=8):
+    """the same chain on config #5's sizes (8 crystals of 32..128 atoms, Z from the 26-orbital table), no oracle: structure the
+    reference's assembly guarantees -- real spin-diagonal blocks == the non-SOC prediction, Hermiticity of the spinor matrix,
+    mask zeros, finiteness."""
+    import bench
+    from hamgnn_amd import uni
+    irreps = bench.IRREPS["A"]
+    hip, _ = _uni_models(irreps)
+    pred = uni.HamiltonianPredictor(hip[False].to(device), hip[True].to(device), device)
+    rng = np.random.default_rng(2)
+    nao, res = 26, {"diag_vs_nonsoc": 0.0, "herm_err": 0.0, "masked_nonzero": 0, "edges": 0, "atoms": 0}
+    for k in range(n_graphs):
+        n_atoms = int(rng.integers(32, 129))
+        g_ns, g_soc = _uni_graph_pair(n_atoms, seed=60 + k, density=0.012)
+        for g in (g_ns, g_soc):                                # no H0 in this check: the network part alone must carry the structure
+            for key in ("Hon0", "Hoff0", "iHon0", "iHoff0"):
+                if key in g:
+                    g[key] = torch.zeros_like(g[key])
+        b_ns, b_soc = g_ns.to(device), g_soc.to(device)
+        out = pred.predict(b_ns, b_soc)
+        N, E = g_ns.num_nodes, g_ns.num_edges
+        Hr = out["hamiltonian_real"].reshape(N + E, 2 * nao, 2 * nao)
+        Hi = out["hamiltonian_imag"].reshape(N + E, 2 * nao, 2 * nao)
+        assert torch.isfinite(Hr).all() and torch.isfinite(Hi).all()
+        ns = torch.cat([b_soc["Hon_nonsoc"], b_soc["Hoff_nonsoc"]]).reshape(N + E, nao, nao)
+        scale = ns.abs().max().item()
+        res["diag_vs_nonsoc"] = max(res["diag_vs_nonsoc"], (Hr[:, :nao, :nao] - ns).abs().max().item() / scale,
+                                    (Hr[:, nao:, nao:] - ns).abs().max().item() / scale)
+        H = torch.complex(Hr, Hi)
+        inv = b_soc.inv_edge_idx
+        partner = torch.cat([torch.arange(N, device=device), N + inv])
+        res["herm_err"] = max(res["herm_err"], (H - H[partner].conj().transpose(1, 2)).abs().max().item() / max(scale, H.abs().max().item()))
+        m = out["mask_real_imag"]
+        res["masked_nonzero"] += int(((out["hamiltonian_real"] != 0) & ~m).sum())
+        res["edges"] += E
+        res["atoms"] += N
     torch.cuda.synchronize()
     return res
