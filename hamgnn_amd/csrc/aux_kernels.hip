@@ -408,26 +408,64 @@ __device__ __forceinline__ float hg_act(float x, int id, const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, int64_t xs, const int4* __restrict__ tab, int Dout,
-                                                   const float* __restrict__ cst, int64_t rows, float* __restrict__ out, int64_t os) {
-    const int64_t r = blockIdx.x;
-    const float* __restrict__ xr = x + r * xs;
-    for (int p = threadIdx.x; p < Dout; p += blockDim.x) {
-        const int4 t = tab[p];                       // {src, act, gate, gate_act}
-        float v = 0.f;
-        if (t.x >= 0) {
-            v = hg_act(xr[t.x], t.y, cst);
-            if (t.z >= 0) v *= hg_act(xr[t.z], t.w, cst);
+// One wave per row, no block barriers.  Phase A: the row's DISTINCT activated scalars (the 0e / 0o scalars and the gate channels: 263 of
+// the 1012 inputs for set-A) go through their activation once, into a wave-private LDS strip; phase B: every output element is a plain
+// input or an activated scalar, times its gate's activated value -- look-ups only.  (The r1 kernel evaluated softplus = log1pf(expf)
+// once per OUTPUT element, i.e. (2l+1) times per gate channel: the E-row gates of the head ran compute-bound at 1.8 TB/s.)
+// act_tab: int32[nact][2] = {input index, act id};  out_tab: int32[Dout][2] = {source code, gate code}: source code = input index, or
+// 0x40000000 | act slot; gate code = act slot or -1; source code -1 = structural zero.
+#define HG_GATE_WAVES 4
+__global__ __launch_bounds__(256) void gate_kernel(const float* __restrict__ x, int64_t xs, const int2* __restrict__ act_tab, int nact,
+                                                   const int2* __restrict__ out_tab, int Dout, const float* __restrict__ cst, int64_t rows,
+                                                   float* __restrict__ out, int64_t os) {
+    extern __shared__ __attribute__((aligned(16))) int sm_i[];
+    int2* __restrict__ s_out = reinterpret_cast<int2*>(sm_i);                           // [Dout]
+    int2* __restrict__ s_act = s_out + Dout;                                            // [nact]
+    float* __restrict__ s_val = reinterpret_cast<float*>(s_act + nact);                 // [HG_GATE_WAVES][nact]
+    for (int i = threadIdx.x; i < Dout; i += blockDim.x) s_out[i] = out_tab[i];
+    for (int i = threadIdx.x; i < nact; i += blockDim.x) s_act[i] = act_tab[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* __restrict__ av = s_val + wave * nact;
+    float c[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = cst[i];
+    for (int64_t r = (int64_t)blockIdx.x * HG_GATE_WAVES + wave; r < rows; r += (int64_t)gridDim.x * HG_GATE_WAVES) {
+        const float* __restrict__ xr = x + r * xs;
+        for (int i = lane; i < nact; i += 64) {
+            const int2 t = s_act[i];
+            av[i] = hg_act(xr[t.x], t.y, c);
         }
-        out[r * os + p] = v;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* __restrict__ orow = out + r * os;
+#pragma unroll 4
+        for (int p = lane; p < Dout; p += 64) {
+            const int2 t = s_out[p];
+            float v = 0.f;
+            if (t.x >= 0) {
+                v = (t.x & 0x40000000) ? av[t.x & 0x3fffffff] : xr[t.x];
+                if (t.y >= 0) v *= av[t.y];
+            }
+            orow[p] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // the strip is rewritten by the next row
     }
 }
 
-extern "C" int hg_gate(const float* x, int64_t x_stride, const int32_t* tab, int Dout, const float* consts, int64_t rows, float* out,
-                       int64_t out_stride, void* stream) {
+extern "C" int hg_gate(const float* x, int64_t x_stride, const int32_t* act_tab, int nact, const int32_t* out_tab, int Dout, const float* consts,
+                       int64_t rows, float* out, int64_t out_stride, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
-    gate_kernel<<<dim3((unsigned)rows), 256, 0, (hipStream_t)stream>>>(x, x_stride, (const int4*)tab, Dout, consts, rows, out, out_stride);
+    if (nact < 0 || Dout <= 0) return hg_fail(-2, "hg_gate: bad table sizes");
+    const size_t lds = sizeof(int) * (2 * (size_t)Dout + 2 * (size_t)nact + (size_t)HG_GATE_WAVES * (size_t)nact);
+    if (lds > 64 * 1024) return hg_fail(-2, "hg_gate: row too wide for the LDS tables");
+    const int64_t want = (rows + HG_GATE_WAVES - 1) / HG_GATE_WAVES;
+    const int64_t blocks = want < 256 * 8 ? want : 256 * 8;    // persistent: the tables are staged once per block
+    gate_kernel<<<dim3((unsigned)blocks), 256, lds, (hipStream_t)stream>>>(x, x_stride, (const int2*)act_tab, nact, (const int2*)out_tab, Dout,
+                                                                           consts, rows, out, out_stride);
     return hg_check_launch("hg_gate");
 }
 

@@ -86,6 +86,165 @@ extern "C" int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t*
     return hg_check_launch("hg_ham_finish");
 }
 
+// ------------------------------------------------------------------------------------------------ one-pass read-out (non-SOC head)
+// stage 1 + stage 2 in ONE pass over the rows.  A block walks groups of HR_PAIRS (edge, inverse edge) PAIRS: the rows' coefficient and
+// Wigner rows are pulled into the LDS with coalesced loads (all rows of the group in flight together), un-rotated and CG-expanded
+// LDS -> LDS, the two merged blocks of a pair are symmetrised against each other, + H0, masked, and written straight into the caller's
+// [rows, nao^2] result.  Against hg_ham_merge + hg_ham_finish this removes the Hraw round trip (1 write + 2 reads of nao^2 per row),
+// one launch, the dependent per-element gathers and the per-row re-reading of the CSR table (staged once per block).  On-site rows pair
+// with themselves.
+#define HR_PAIRS 2
+__global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restrict__ coeff, int64_t cs, int cw, const float* __restrict__ wig,
+                                                          int nW, int nWuse, const HgWigOff wo, const int4* __restrict__ slot_tab,
+                                                          const int* __restrict__ cg_ptr, const int* __restrict__ cg_idx,
+                                                          const float* __restrict__ cg_val, int nslots, int nao, int nnz,
+                                                          const int64_t* __restrict__ pair_a, const int64_t* __restrict__ pair_b,
+                                                          int64_t npairs, const float* __restrict__ H0, const float* __restrict__ orb_mask,
+                                                          int mask_w, const int64_t* __restrict__ z, const int64_t* __restrict__ ia,
+                                                          const int64_t* __restrict__ ib, float sign, int flags, float* __restrict__ H) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int R = 2 * HR_PAIRS;                            // rows per step
+    const int nao2 = nao * nao;
+    const int rawlen = cw + nWuse;                             // per row: coefficient row, then the Wigner blocks l <= lmax(ham irreps)
+    const int rlen = rawlen > nao2 ? rawlen : nao2;            // the merged block re-uses the raw buffer
+    int* __restrict__ s_ptr = reinterpret_cast<int*>(sm);
+    int* __restrict__ s_idx = s_ptr + nao2 + 1;
+    float* __restrict__ s_val = reinterpret_cast<float*>(s_idx + nnz);
+    int* __restrict__ s_rc = reinterpret_cast<int*>(s_val + nnz);      // [nao2] (row | col << 8 | transposed index << 16) of every element
+    float* __restrict__ s_raw = reinterpret_cast<float*>(s_rc + nao2); // [R][rlen]   raw rows, later the merged nao x nao blocks
+    float* __restrict__ s_coef = s_raw + R * rlen;             // [R][nslots] un-rotated coefficients
+    float* __restrict__ s_mask = s_coef + R * nslots;          // [R][2][nao] orbital masks of the row's two atoms
+    __shared__ int64_t s_row[R];
+    for (int i = threadIdx.x; i <= nao2; i += blockDim.x) s_ptr[i] = cg_ptr[i];
+    for (int i = threadIdx.x; i < nnz; i += blockDim.x) {
+        s_idx[i] = cg_idx[i];
+        s_val[i] = cg_val[i];
+    }
+    for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+        const int rr = q / nao, cc = q - rr * nao;
+        s_rc[q] = rr | (cc << 8) | ((cc * nao + rr) << 16);
+    }
+    const bool sym = flags & 1, h0_last = flags & 2;
+    const int64_t ngroups = (npairs + HR_PAIRS - 1) / HR_PAIRS;
+    for (int64_t gp = blockIdx.x; gp < ngroups; gp += gridDim.x) {
+        __syncthreads();                                       // tables staged / previous group's buffers free
+        if (threadIdx.x < R) {
+            const int64_t p = gp * HR_PAIRS + (threadIdx.x >> 1);
+            int64_t row = -1;
+            if (p < npairs) {
+                const int64_t ra = pair_a ? pair_a[p] : p;
+                const int64_t rb = pair_b ? pair_b[p] : ra;
+                row = (threadIdx.x & 1) ? (rb == ra ? -1 : rb) : ra;       // self-paired rows occupy slot 0 of their pair only
+            }
+            s_row[threadIdx.x] = row;
+        }
+        __syncthreads();
+        // ---- bulk staging: contiguous coefficient row + leading part of the Wigner row + the two mask rows; every row of the group in
+        //      flight at once
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t e = s_row[r];
+            float* __restrict__ dst = s_raw + r * rlen;
+            if (e < 0) continue;
+            const float* __restrict__ c = coeff + e * cs;
+            for (int k = threadIdx.x; k < cw; k += blockDim.x) dst[k] = c[k];
+            if (wig) {
+                const float* __restrict__ D = wig + e * nW;
+                for (int k = threadIdx.x; k < nWuse; k += blockDim.x) dst[cw + k] = D[k];
+            }
+            if (orb_mask && threadIdx.x < 2 * nao) {
+                const int side = threadIdx.x >= nao, o = threadIdx.x - side * nao;
+                const int64_t atom = side ? (ib ? ib[e] : e) : (ia ? ia[e] : e);
+                s_mask[(r * 2 + side) * nao + o] = orb_mask[z[atom] * mask_w + o % mask_w];
+            }
+        }
+        __syncthreads();
+        // ---- un-rotate: coef[q] = sum_m D^L[m][a] c[L slot][m]
+        for (int q = threadIdx.x; q < nslots; q += blockDim.x) {
+            const int4 t = slot_tab[q];                        // {L, a, base (planar index of component 0), component stride}
+            const int n = 2 * t.x + 1;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (s_row[r] < 0) continue;
+                const float* __restrict__ c = s_raw + r * rlen;
+                float acc;
+                if (wig) {
+                    const float* __restrict__ Dl = c + cw + wo.o[t.x];
+                    acc = 0.f;
+                    for (int m = 0; m < n; ++m) acc = fmaf(Dl[m * n + t.y], c[t.z + m * t.w], acc);
+                } else {
+                    acc = c[t.z + t.y * t.w];
+                }
+                s_coef[r * nslots + q] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- CG expansion (+ reorder, signs: folded into the CSR table) into the raw buffer: one table walk serves all rows
+        for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+            float acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = 0.f;
+            for (int k = s_ptr[q]; k < s_ptr[q + 1]; ++k) {
+                const float v = s_val[k];
+                const int j = s_idx[k];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[r] = fmaf(v, s_coef[r * nslots + j], acc[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) s_raw[r * rlen + q] = acc[r];
+        }
+        __syncthreads();
+        // ---- symmetrise against the partner row, + H0, mask, store
+        for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+            const int code = s_rc[q];
+            const int rr = code & 0xff, cc = (code >> 8) & 0xff, qt = code >> 16;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t e = s_row[r];
+                if (e < 0) continue;
+                const int rp = s_row[r ^ 1] >= 0 ? (r ^ 1) : r; // partner slot (itself for self-paired rows)
+                float v = s_raw[r * rlen + q];
+                if (sym) v = 0.5f * (v + sign * s_raw[rp * rlen + qt]);
+                const float h0 = H0 ? H0[e * nao2 + q] : 0.f;
+                if (!h0_last) v += h0;
+                if (orb_mask) v *= s_mask[(r * 2) * nao + rr] * s_mask[(r * 2 + 1) * nao + cc];
+                if (h0_last) v += h0;
+                H[e * nao2 + q] = v;
+            }
+        }
+    }
+}
+
+extern "C" int hg_ham_readout(const float* coeff, int64_t c_stride, int c_width, const float* wig, int nW, const int32_t* wig_off,
+                              int lmax_ham, const int32_t* slot_tab, int nslots, const int32_t* cg_ptr, const int32_t* cg_idx,
+                              const float* cg_val, int nnz, int nao, const int64_t* pair_a, const int64_t* pair_b, int64_t npairs,
+                              const float* H0, const float* orb_mask, int mask_w, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b,
+                              float sign, int flags, float* H, void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (npairs <= 0) return 0;
+    const int nao2 = nao * nao;
+    if (nslots <= 0 || nao <= 0 || nnz <= 0 || c_width <= 0) return hg_fail(-2, "hg_ham_readout: bad table sizes");
+    if (orb_mask && (mask_w <= 0 || nao % mask_w)) return hg_fail(-2, "hg_ham_readout: nao must be a multiple of the mask width");
+    if (lmax_ham < 0 || lmax_ham > 7) return hg_fail(-2, "hg_ham_readout: lmax of the hamiltonian irreps must be 0..7");
+    HgWigOff wo;
+    int nWuse = 0;
+    for (int i = 0; i < 8; ++i) wo.o[i] = wig_off ? wig_off[i] : 0;
+    if (wig) {
+        nWuse = wo.o[lmax_ham] + (2 * lmax_ham + 1) * (2 * lmax_ham + 1);
+        if (nWuse > nW) return hg_fail(-2, "hg_ham_readout: Wigner rows do not reach lmax of the hamiltonian irreps");
+    }
+    const int rawlen = c_width + nWuse, rlen = rawlen > nao2 ? rawlen : nao2;
+    if (nao > 181) return hg_fail(-2, "hg_ham_readout: nao too large for the packed index table");
+    const size_t lds = sizeof(float) * ((size_t)(2 * nao2 + 1) + 2 * (size_t)nnz + (size_t)(2 * HR_PAIRS) * ((size_t)rlen + (size_t)nslots + 2 * (size_t)nao));
+    if (lds > 64 * 1024) return hg_fail(-2, "hg_ham_readout: tables exceed 64 KB of LDS (use hg_ham_merge + hg_ham_finish)");
+    const int64_t ngroups = (npairs + HR_PAIRS - 1) / HR_PAIRS;
+    const int64_t blocks = ngroups < 256 * 5 ? ngroups : 256 * 5;    // persistent blocks (~5 per CU fit the LDS), each walks groups of pairs
+    ham_readout_kernel<<<dim3((unsigned)blocks), 256, lds, (hipStream_t)stream>>>(
+        coeff, c_stride, c_width, wig, nW, nWuse, wo, (const int4*)slot_tab, cg_ptr, cg_idx, cg_val, nslots, nao, nnz, pair_a, pair_b, npairs, H0,
+        orb_mask, mask_w > 0 ? mask_w : nao, z, idx_a, idx_b, sign, flags, H);
+    return hg_check_launch("hg_ham_readout");
+}
+
 // ------------------------------------------------------------------------------------------------ SOC / so3 (a18)
 // symmetrize_orbital_coefficients (hamgnn_output.py:2367-2431): every element -> mean over its (row shell, col shell) block.
 // tab: int32[nao2][4] = {r0, r1, c0, c1} of the block the element belongs to.

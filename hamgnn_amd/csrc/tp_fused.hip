@@ -38,6 +38,8 @@ struct TpArgs {
     int64_t ostride;
     int64_t rows;
     int tile_floats_wave;
+    const float* res[2];         // optional residual rows (same planar layout as `out`), added in the epilogue: out = program(x) + res0 + res1
+    int64_t rstride[2];
 };
 
 #define SEG_UNROTATE 1
@@ -496,6 +498,33 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
                 if (valid) ob[a * out_mulp + w] = w < mul_k ? acc : 0.f;
             }
         }
+    } else if (A.res[0]) {
+        // ResidualBlock tail x + Lin2(Gate(Lin1 x)) [+ skip] (hamgnn/nn/interaction_blocks.py:352-357, convolution.py:158): the adds ride on
+        // the producing launch instead of a separate pass over all rows.  WU channels per lane and step: WU x NCO residual loads in
+        // flight before the first add (one load per step left the epilogue waiting on L2/HBM once per channel)
+        const float* __restrict__ r0 = A.res[0] + erow * A.rstride[0] + out_off;
+        const float* __restrict__ r1 = A.res[1] ? A.res[1] + erow * A.rstride[1] + out_off : nullptr;
+        constexpr int WU = NCO <= 3 ? 4 : 2;
+#pragma unroll 1
+        for (int w0 = g; w0 < wend; w0 += 4 * WU) {
+            float v[WU][NCO];
+#pragma unroll
+            for (int j = 0; j < WU; ++j) {
+                const int w = w0 + 4 * j;
+                const int wr = w < mul_k ? w : 0;               // padding slots: any readable address, value dropped below
+#pragma unroll
+                for (int a = 0; a < NCO; ++a) v[j][a] = r0[a * out_mulp + wr] + (r1 ? r1[a * out_mulp + wr] : 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < WU; ++j) {
+                const int w = w0 + 4 * j;
+                if (w < wend) {
+#pragma unroll
+                    for (int a = 0; a < NCO; ++a)
+                        if (valid) ob[a * out_mulp + w] = w < mul_k ? v[j][a] + tl[w * rowstride + a * 16] : 0.f;
+                }
+            }
+        }
     } else {
 #pragma unroll 1
         for (int w = g; w < wend; w += 4) {
@@ -552,7 +581,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
                 HG_CASE(1, 1) HG_CASE(1, 2) HG_CASE(1, 3) HG_CASE(1, 4)
                 HG_CASE(2, 1) HG_CASE(2, 2) HG_CASE(2, 3)
                 HG_CASE(3, 1) HG_CASE(3, 2)
-                HG_CASE(2, 4) HG_CASE(3, 3) HG_CASE(4, 2) HG_CASE(5, 2)
+                HG_CASE(4, 2)                                              // row-tile table of plan.py:rtm_max (4,4,3,2,2,1,1)
                 HG_CASE(4, 1)
                 HG_CASE(5, 1)
                 HG_CASE(6, 1)
@@ -598,7 +627,8 @@ extern "C" int hg_prof_read(unsigned long long* out16, int reset) {
 extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node,
                            const float* h2_edge, int hidden, const float* wig, int nW, const int32_t* wig_off,
                            const float* weights, const int32_t* seg_table, int nseg, const int32_t* item_table, float* out,
-                           int64_t out_stride, int64_t rows, int lds_bytes, int program_flags, void* stream) {
+                           int64_t out_stride, int64_t rows, int lds_bytes, int program_flags, const float* res0, int64_t res0_stride,
+                           const float* res1, int64_t res1_stride, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_fused: nsrc must be 1..4");
@@ -623,6 +653,8 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
     A.ostride = out_stride;
     A.rows = rows;
     A.tile_floats_wave = lds_bytes / 16;           // 4 waves x 4 bytes
+    if (res1 && !res0) return hg_fail(-2, "hg_tp_fused: res1 without res0");
+    A.res[0] = res0, A.res[1] = res1, A.rstride[0] = res0_stride, A.rstride[1] = res1_stride;
     static unsigned char lds_attr_done[2][HG_MAX_DEVICES];     // once per device (not a stream operation: illegal during graph capture)
     if (int rc = hg_lds_attr_once(lds_attr_done[0], dev_guard.dev, (const void*)tp_fused_kernel<true>, 160 * 1024)) return rc;
     if (int rc = hg_lds_attr_once(lds_attr_done[1], dev_guard.dev, (const void*)tp_fused_kernel<false>, 160 * 1024)) return rc;

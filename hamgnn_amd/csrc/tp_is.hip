@@ -505,14 +505,14 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A, const int
             if (gi >= g1) break;
             const int ib = g_groups[2 * gi], ie = g_groups[2 * gi + 1];
             for (int ii = ib; ii < ie; ++ii) {
-                const int* __restrict__ it = g_items + ii * 20;
+                const int* __restrict__ it = g_items + ii * 24;
                 switch (it[6] * 8 + it[9]) {
                     IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(0, 3) IS_CASE(0, 4)
                     IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(1, 3) IS_CASE(1, 4)
-                    IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(2, 3) IS_CASE(2, 4)
-                    IS_CASE(3, 1) IS_CASE(3, 2) IS_CASE(3, 3)
+                    IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(2, 3)              // row-tile table of plan.py:rtm_max (4,4,3,2,2,1,1): the r1 shapes
+                    IS_CASE(3, 1) IS_CASE(3, 2)                            // <2,4>, <3,3>, <5,2> held 80-88 accumulator VGPRs and spilled
                     IS_CASE(4, 1) IS_CASE(4, 2)
-                    IS_CASE(5, 1) IS_CASE(5, 2)
+                    IS_CASE(5, 1)
                     IS_CASE(6, 1)
                     default: break;
                 }

@@ -18,7 +18,37 @@ from ..topo import get_topology, gget
 
 
 class Representation(dict):
-    """EasyDict-like result: key and attribute access (reference returns an EasyDict, hamgnn_conv.py:278-284)."""
+    """EasyDict-like result: key and attribute access (reference returns an EasyDict, hamgnn_conv.py:278-284).
+    `node_attr` / `edge_attr` (e3nn layout, global frame) are produced ON FIRST ACCESS: the MI355X head reads the planar / edge-frame
+    tensors directly (`_node_planar`, `_edge_planar_rot`), so a forward that never looks at them skips the layout conversion and the
+    un-rotation of all E edge rows (4.5 ms per forward at 0.82 M edges)."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        dict.__setitem__(self, "_lazy", {})
+
+    def set_lazy(self, key, thunk):
+        dict.__getitem__(self, "_lazy")[key] = thunk
+
+    def __missing__(self, key):
+        lazy = dict.__getitem__(self, "_lazy")
+        if key in lazy:
+            v = lazy.pop(key)()
+            dict.__setitem__(self, key, v)
+            return v
+        raise KeyError(key)
+
+    def get(self, key, default=None):
+        try:
+            return self[key]
+        except KeyError:
+            return default
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in dict.__getitem__(self, "_lazy")
+
+    def keys(self):
+        return [k for k in dict.keys(self) if k != "_lazy"] + list(dict.__getitem__(self, "_lazy"))
 
     def __getattr__(self, k):
         try:
@@ -129,11 +159,12 @@ class HamGNNConvE3(nn.Module):
             if pair.use_skip_connections or not pair.legacy_edge_update:           # legacy layer-0: edge features kept (:154-156)
                 mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab)   # edge frame (+ fused skip linear)
                 if self.lite_mode and pair.use_skip_connections:
-                    mix = ops.add_rows(mix, pair.skip_linear(f))
+                    mix = pair.skip_linear(f, res=[mix])
                 f = mix
         rep = Representation()
-        rep["node_attr"] = ops.from_planar(node, self._imap)
-        rep["edge_attr"] = ops.from_planar(ops.rotate_gather(f, None, geo, self._rot_tab, transpose=True), self._imap)
+        imap, rot_tab = self._imap, self._rot_tab
+        rep.set_lazy("node_attr", lambda: ops.from_planar(node, imap))
+        rep.set_lazy("edge_attr", lambda: ops.from_planar(ops.rotate_gather(f, None, geo, rot_tab, transpose=True), imap))
         # extras for the MI355X head: skip the layout/frame round trip
         rep["_node_planar"], rep["_edge_planar_rot"], rep["_geometry"] = node, f, geo
         return rep

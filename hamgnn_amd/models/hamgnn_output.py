@@ -163,14 +163,19 @@ class HamGNNPlusPlusOut(nn.Module):
         return (total / eff.to(torch.float64)).to(torch.float32)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _blocks(self, net_on, net_off, node_pl, edge_rot, geo, data, inv, H0_on, H0_off):
+    def _blocks(self, net_on, net_off, node_pl, edge_rot, geo, data, inv, H0_on, H0_off, into=None):
+        """into: optional [N+E, nao^2] buffer (single crystal: the result rows [on-site; off-site] are written in place)"""
         n, n2 = self.nao_max, self.nao_max ** 2
         src, dst = geo.src, geo.dst
         z = data.z.contiguous()
-        raw_on = ops.ham_merge(net_on(node_pl), None, self._slot, *self._cg, n2)
-        on = ops.ham_finish(raw_on, None, H0_on, self._mask, z, None, None, n, 1.0, self.symmetrize)
-        raw_off = ops.ham_merge(net_off(edge_rot), geo, self._slot, *self._cg, n2)
-        off = ops.ham_finish(raw_off, inv, H0_off, self._mask, z, src, dst, n, 1.0, self.symmetrize)
+        N = z.shape[0]
+        E = src.shape[0]
+        on = into[:N] if into is not None else torch.empty(N, n2, device=z.device, dtype=torch.float32)
+        off = into[N:] if into is not None else torch.empty(E, n2, device=z.device, dtype=torch.float32)
+        # one pass per row set: CG merge + reorder + symmetrise (against the inverse edge, same block) + H0 + mask, written in place
+        ops.ham_readout(net_on(node_pl), None, self._slot, *self._cg, n, None, H0_on, self._mask, z, None, None, on, self.hamiltonian_irreps.lmax, 1.0, self.symmetrize)
+        pairs = get_topology(data).inverse_pairs(data)
+        ops.ham_readout(net_off(edge_rot), geo, self._slot, *self._cg, n, pairs, H0_off, self._mask, z, src, dst, off, self.hamiltonian_irreps.lmax, 1.0, self.symmetrize)
         return on, off
 
     def forward(self, data, graph_representation=None):
@@ -240,8 +245,11 @@ class HamGNNPlusPlusOut(nn.Module):
             return result
         H0_on = f32c(data.Hon0) if self.add_H0 else None
         H0_off = f32c(data.Hoff0) if self.add_H0 else None
-        on, off = self._blocks(self.onsite_hamiltonian_network, self.offsite_hamiltonian_network, node_pl, edge_rot, geo, data, inv, H0_on, H0_off)
-        H = self._cat_by_crystal(data, on, off, edge_counts)
+        single = edge_counts is None or edge_counts.numel() <= 1
+        H = torch.empty(node_pl.shape[0] + edge_rot.shape[0], self.nao_max ** 2, device=dev, dtype=torch.float32) if single else None
+        on, off = self._blocks(self.onsite_hamiltonian_network, self.offsite_hamiltonian_network, node_pl, edge_rot, geo, data, inv, H0_on, H0_off, into=H)
+        if not single:
+            H = self._cat_by_crystal(data, on, off, edge_counts)
         if self.zero_point_shift:
             H = self._apply_zero_point_shift(data, H, edge_counts, False)
         result.update({"hamiltonian": H, "band_energy": None, "wavefunction": None, "band_gap": None, "H_sym": None})

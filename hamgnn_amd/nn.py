@@ -41,10 +41,11 @@ class E3Linear(nn.Module):
         self._dp = ops.DeviceProgram(P.build_linear_program(self.weight.detach().cpu().double().numpy(), self.irreps_in, self.irreps_out), device)
         return self
 
-    def forward(self, x_planar: torch.Tensor) -> torch.Tensor:
+    def forward(self, x_planar: torch.Tensor, res=()) -> torch.Tensor:
+        """res: residual rows (output layout) added in the kernel epilogue"""
         if self._dp is None:
             self.compile(x_planar.device)
-        return ops.tp_fused(self._dp, [x_planar], x_planar.shape[0])
+        return ops.tp_fused(self._dp, [x_planar], x_planar.shape[0], res=res)
 
 
 class E3TensorProduct(nn.Module):
@@ -198,7 +199,7 @@ class ResidualBlock(nn.Module):
     def compile(self, device):
         self.linear1.compile(device)
         self.linear2.compile(device)
-        self._tab = torch.from_numpy(self._tab_np).to(device)
+        self._tab = tuple(torch.from_numpy(t).contiguous().to(device) for t in P.gate_tables_compact(self._tab_np))
         self._cst = torch.from_numpy(P.ACT_CONSTS).to(device)
         return self
 
@@ -206,10 +207,8 @@ class ResidualBlock(nn.Module):
         """x + Lin2(Gate(Lin1(x))) [+ extra]  on planar rows."""
         if self._tab is None:
             self.compile(x_planar.device)
-        y = self.linear2(ops.gate(self.linear1(x_planar), self._tab, self._cst))
-        if self.resnet:
-            return ops.add_rows(x_planar, y, extra)
-        return y if extra is None else ops.add_rows(y, extra)
+        res = ([x_planar] if self.resnet else []) + ([extra] if extra is not None else [])
+        return self.linear2(ops.gate(self.linear1(x_planar), self._tab, self._cst), res=res)      # adds fused into linear2's epilogue
 
 
 class ConvBlockE3(nn.Module):
@@ -372,5 +371,5 @@ class CorrProductBlock(nn.Module):
             self.compile(node_planar.device)
         h = self.linear_pre(node_planar)
         c = ops.sym_contraction(h, z, self.num_hidden, self._tab, self._W1, self._W2, self._hdim)
-        out = self.linear_out(self.prod.linear(c))
-        return ops.add_rows(out, self.linear_sc(node_planar)) if self.use_skip_connections else out
+        skip = [self.linear_sc(node_planar)] if self.use_skip_connections else []
+        return self.linear_out(self.prod.linear(c), res=skip)

@@ -136,11 +136,17 @@ PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, rows, 
 
 @_on_tensor_device
 def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None,
-             tag: str = "linear", gather: Optional[List[Optional[torch.Tensor]]] = None, rot_mask: int = 0) -> torch.Tensor:
+             tag: str = "linear", gather: Optional[List[Optional[torch.Tensor]]] = None, rot_mask: int = 0,
+             res: Sequence[Optional[torch.Tensor]] = ()) -> torch.Tensor:
     """gather / rot_mask (input-stationary schedule only): srcs[i] holds global-frame node rows, gathered by gather[i] and rotated
-    into the edge frame inside the kernel (bit i of rot_mask) instead of a separate hg_rotate_gather pass."""
+    into the edge frame inside the kernel (bit i of rot_mask) instead of a separate hg_rotate_gather pass.
+    res: up to two residual row tensors in the output's planar layout, added in the epilogue (segment-stationary programs)."""
     _require_gpu(srcs[0])
     assert (gather is None and rot_mask == 0) or dp.sched is not None
+    res = [r for r in res if r is not None]
+    assert len(res) <= 2 and (not res or dp.sched is None)
+    for r in res:
+        assert r.shape == (rows, dp.out_dim) and r.stride(1) == 1
     out = torch.empty(rows, dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
@@ -159,7 +165,9 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
                              i32(rot_mask), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
     else:
         check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
-                                i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), i32(dp.flags), _stream()),
+                                i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), i32(dp.flags),
+                                C.c_void_p(res[0].data_ptr() if res else 0), i64(res[0].stride(0) if res else 0),
+                                C.c_void_p(res[1].data_ptr() if len(res) > 1 else 0), i64(res[1].stride(0) if len(res) > 1 else 0), _stream()),
               "hg_tp_fused")
     if PROFILE_EVENTS is not None:
         ev1.record()
@@ -176,10 +184,13 @@ def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, N: 
 
 
 @_on_tensor_device
-def gate(x: torch.Tensor, tab: torch.Tensor, consts: torch.Tensor) -> torch.Tensor:
-    rows, Dout = x.shape[0], int(tab.shape[0])
+def gate(x: torch.Tensor, tabs, consts: torch.Tensor) -> torch.Tensor:
+    """tabs = (act_tab [nact,2], out_tab [Dout,2]) device int32 tensors of plan.gate_tables_compact"""
+    act_tab, out_tab = tabs
+    rows, Dout = x.shape[0], int(out_tab.shape[0])
     out = torch.empty(rows, Dout, device=x.device, dtype=torch.float32)
-    check(lib().hg_gate(ptr(x), i64(x.stride(0)), ptr(tab), i32(Dout), ptr(consts), i64(rows), ptr(out), i64(Dout), _stream()), "hg_gate")
+    check(lib().hg_gate(ptr(x), i64(x.stride(0)), ptr(act_tab), i32(act_tab.shape[0]), ptr(out_tab), i32(Dout), ptr(consts), i64(rows), ptr(out),
+                        i64(Dout), _stream()), "hg_gate")
     return out
 
 
@@ -226,16 +237,38 @@ def ham_merge(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, 
 
 
 @_on_tensor_device
-def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetrize=True, h0_after_mask=False):
-    """Hraw: [rows, >= nao^2] (a column slice of a wider buffer is fine: the row stride is passed on)."""
+def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetrize=True, h0_after_mask=False, out=None):
+    """Hraw: [rows, >= nao^2] (a column slice of a wider buffer is fine: the row stride is passed on).
+    out: optional contiguous [rows, nao^2] destination (e.g. the row range of the [N+E, nao^2] result: no torch.cat afterwards)."""
     rows = Hraw.shape[0]
     assert Hraw.stride(1) == 1
-    out = torch.empty(rows, nao * nao, device=Hraw.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(rows, nao * nao, device=Hraw.device, dtype=torch.float32)
+    assert out.shape == (rows, nao * nao) and out.is_contiguous() and out.dtype == torch.float32
     mask_w = int(orb_mask.shape[1]) if orb_mask is not None else 0
     _require_gpu(Hraw)
     check(lib().hg_ham_finish(C.c_void_p(Hraw.data_ptr()), i64(Hraw.stride(0)), ptr(inv), ptr(H0), ptr(orb_mask), i32(mask_w), ptr(z), ptr(idx_a), ptr(idx_b),
                               i32(nao), f32(sign), i32((1 if symmetrize else 0) | (2 if h0_after_mask else 0)), i64(rows), ptr(out),
                               _stream()), "hg_ham_finish")
+    return out
+
+
+@_on_tensor_device
+def ham_readout(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, nao, pairs, H0, orb_mask, z, idx_a, idx_b, out,
+                lmax_ham, sign=1.0, symmetrize=True, h0_after_mask=False):
+    """one-pass non-SOC read-out of `coeff` rows into `out` [rows, nao^2]; pairs = (pair_a, pair_b) int64 row indices or None (rows pair
+    with themselves: on-site)."""
+    _require_gpu(coeff)
+    rows = coeff.shape[0]
+    assert out.shape == (rows, nao * nao) and out.is_contiguous() and out.dtype == torch.float32
+    wig, nW, woff = (ptr(geo.wig), geo.nW, geo.wig_off) if geo is not None else (C.c_void_p(0), 0, (C.c_int * 8)())
+    pa, pb = pairs if pairs is not None else (None, None)
+    npairs = rows if pa is None else pa.shape[0]
+    mask_w = int(orb_mask.shape[1]) if orb_mask is not None else 0
+    check(lib().hg_ham_readout(ptr(coeff), i64(coeff.stride(0)), i32(coeff.shape[1]), wig, i32(nW), woff, i32(lmax_ham), ptr(slot_tab), i32(slot_tab.shape[0]), ptr(cg_ptr),
+                               ptr(cg_idx), ptr(cg_val), i32(cg_idx.shape[0]), i32(nao), ptr(pa), ptr(pb), i64(npairs), ptr(H0), ptr(orb_mask),
+                               i32(mask_w), ptr(z), ptr(idx_a), ptr(idx_b), f32(sign), i32((1 if symmetrize else 0) | (2 if h0_after_mask else 0)),
+                               C.c_void_p(out.data_ptr()), _stream()), "hg_ham_readout")
     return out
 
 

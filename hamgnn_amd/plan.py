@@ -50,8 +50,10 @@ def ceil_div(a, b):
 
 
 def rtm_max(nc):
-    """row tiles per item: keeps the GEMM1 accumulators at <= 16 f32x4 fragments (64 VGPRs) so 3-4 waves/SIMD fit."""
-    tab = [int(v) for v in os.environ.get("HG_RTM", "4,4,4,3,2,2,1").split(",")]        # row tiles by MM = (nc-1)/2 (r1 A/B)
+    """row tiles per item by MM = (nc-1)/2: keeps the GEMM1 accumulators (rtm x nc f32x4 fragments) at <= 72 VGPRs, which is what
+    the input-stationary kernel can hold next to its resident radial rows and double-buffered weight fragments without spilling
+    (r1 table 4,4,4,3,2,2,1: 88 VGPRs, spilled; same MFMA count, 312 instead of 292 items for set-A)."""
+    tab = [int(v) for v in os.environ.get("HG_RTM", "4,4,3,2,2,1,1").split(",")]
     return tab[(nc - 1) // 2]
 
 
@@ -162,6 +164,7 @@ IS_WAVES = 4                       # waves of a workgroup; all of them work on t
 IS_BLOCK_I32 = 8                   # {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
 IS_PHASE_I32 = 4                   # {block_begin, block_end, group_begin, group_end}
 IS_LDS_BYTES = 80 * 1024           # two workgroups per CU
+IS_ITEM_I32 = 24                   # item record of the IS kernel = fused-kernel record + {lk, mul_k, rto, tile_off} of its segment
 
 
 @dataclass
@@ -171,7 +174,8 @@ class IsSchedule:
     phase_table: np.ndarray        # int32[nphase][4]: the blocks staged together and the work groups that read them
     group_table: np.ndarray        # int32[ngroup][2] = {item_begin, item_end}: all items of one (phase, output segment); claimed
     #                                dynamically by the waves (largest first), so no two waves update one tile between barriers
-    item_table: np.ndarray         # int32[nitems][20]: Program.item_table records with [1], [2] = stage offsets of source 0 / 1 (-1)
+    item_table: np.ndarray         # int32[nitems][24]: Program.item_table records with [1], [2] = stage offsets of source 0 / 1 (-1),
+    #                                [20..23] = {lk, mul_k, rto, tile_off} of the item's segment
     trash_off: int                 # float offset of the shared trash row (absorbs fragment-padding rows)
     stage_off: int                 # float offset of the staging area
     stage_floats: int
@@ -290,6 +294,11 @@ def is_schedule(prog: "Program") -> IsSchedule:
                 prev = batch_of[l]
     items = np.asarray(items, np.int32).reshape(-1, ITEM_I32)
     items[:, 19] = [remap[int(x)] for x in items[:, 19]]
+    wide = np.zeros((items.shape[0], IS_ITEM_I32), np.int32)   # + the segment fields an item needs (csrc/tp_is.hip:ItemRec)
+    wide[:, :ITEM_I32] = items
+    for n, sg in enumerate(items[:, 19]):
+        wide[n, 20], wide[n, 21], wide[n, 22], wide[n, 23] = segs2[sg][0], segs2[sg][1], segs2[sg][2], segs2[sg][5]
+    items = wide
     return IsSchedule(segs2.astype(np.int32), np.asarray(btab, np.int32).reshape(-1, IS_BLOCK_I32),
                       np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
                       trash_off, stage_off, stage_floats, ctr_off, ctr_off + 4, tot / (IS_WAVES * crit) if crit else 1.0)
@@ -329,7 +338,7 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
 
 # (MM, RTM) template instantiations of both fused kernels (csrc/tp_fused.hip HG_CASE / csrc/tp_is.hip IS_CASE): an item outside this
 # set would be skipped silently by the kernels' dispatch, so the planner refuses to emit one
-KERNEL_RTM_MAX = (4, 4, 4, 3, 2, 2, 1)
+KERNEL_RTM_MAX = (4, 4, 3, 2, 2, 1, 1)
 
 
 def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0, nk2=None):
@@ -668,6 +677,27 @@ def gate_tables(feature_irreps):
                 tab[lay_out.off[oi] + a * lay_out.mulp[oi] + u] = (lay_in.off[me] + a * lay_in.mulp[me] + u0 + u, ACT_NONE, gate_pos[gc + u], ACT_SSP)
         gc += m
     return irr_in, irr_out, tab
+
+
+def gate_tables_compact(tab: np.ndarray):
+    """tables of hg_gate from gate_tables' [Dout][4] = {src, act, gate, gate act}: the distinct (input, activation) pairs are listed once
+    (act_tab) and the outputs refer to them by slot, so a gate channel's activation is evaluated once per row instead of once per
+    component of the irrep it gates.  Returns (act_tab int32[nact][2], out_tab int32[Dout][2])."""
+    slots: Dict[Tuple[int, int], int] = {}
+
+    def slot(idx, act):
+        return slots.setdefault((int(idx), int(act)), len(slots))
+    out = np.full((tab.shape[0], 2), -1, dtype=np.int32)
+    for p, (src, act, gate, gact) in enumerate(tab):
+        if src < 0:
+            continue
+        out[p, 0] = src if act == ACT_NONE else (0x40000000 | slot(src, act))
+        if gate >= 0:
+            out[p, 1] = slot(gate, gact)
+    act_tab = np.zeros((max(1, len(slots)), 2), dtype=np.int32)
+    for (idx, act), k in slots.items():
+        act_tab[k] = (idx, act)
+    return act_tab[:len(slots)] if slots else act_tab[:0], out
 
 
 def ham_irreps(row: Irreps):

@@ -47,6 +47,7 @@ class Topology:
         self.E = int(self.edge_index.shape[1])
         self._csr = None
         self._ginv = None
+        self._pairs = None
         self._checked = {}
 
     @staticmethod
@@ -79,6 +80,17 @@ class Topology:
                 offs = torch.cumsum(counts, 0) - counts
                 self._ginv = ((inv + offs[b]).contiguous(), counts)
         return self._ginv
+
+    # ---- (edge, inverse edge) pairs, each once: the one-pass read-out symmetrises both rows of a pair in one block
+    def inverse_pairs(self, data):
+        if getattr(self, "_pairs", None) is None:
+            inv, _ = self.global_inverse(data)
+            e = torch.arange(self.E, device=inv.device)
+            if self.E and not bool((inv[inv] == e).all()):
+                raise ValueError("inv_edge_idx is not an involution: every edge needs its inverse (i -> j, -shift) in the list")
+            own = e <= inv                                     # e == inv(e) cannot happen for i != j or a non-zero shift; kept as self-pairs
+            self._pairs = (e[own].contiguous(), inv[own].contiguous())
+        return self._pairs
 
     # ---- one-time validation (host sync once per graph object, like the reference's z.unique().cpu())
     def check_num_types(self, num_types: int):

@@ -25,8 +25,8 @@ int hg_version(void);
  *         utils/cutoff_functions.py:50-61).
  * Per edge e (j = edge_index[0][e] centre, i = edge_index[1][e] neighbour): v = pos[i] + nbr_shift[e] - pos[j];
  * rbf[e][n] = sin((n+1) pi r / rc)/r * 0.5 (cos(pi r/rc)+1) [r<rc];  wig[e] = packed Wigner matrices D^l(R_e), l=0..lmax_wig,
- * of the rotation that takes the edge direction onto the pole (edge-aligned frame; replaces the explicit SH tensor);
- * sh (nullable) = component-normalised real SH of v[[1,2,0]] up to lmax_sh, for API parity / tests.
+ * of the rotation that takes the edge direction onto the pole (edge-aligned frame; REPLACES the explicit SH tensor: in that
+ * frame Y^l = sqrt(2l+1) e_0, so no `sh` output exists); edge_len[e] = |v|.
  * jtab: DEVICE copy of the constants from hamgnn_amd/so3.py:wigner_tables, packed [sum (2l+1)^2] J matrices then
  * [sum (l+1)] sine signs.  ang_scratch: caller-provided [E][4] floats (rotation angles; no hidden allocation).        */
 int hg_edge_geometry(const float* pos, const int64_t* edge_index, const float* nbr_shift, int64_t E, float cutoff,
@@ -56,11 +56,15 @@ int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stride, const i
  * embedding TP (tensor_products.py:170-189); or any o3.Linear (IT_LIN items).  Programs come from hamgnn_amd/plan.py.
  * src[k]/src_stride[k]: planar source rows (slot 0: rotated src-node rows, 1: rotated dst-node rows, 2: edge rows).
  * rows: number of edges (or nodes for node-level linears).  lds_bytes: prog.tile_floats*4 (dynamic LDS).
- * program_flags: bit 0 = the program contains lite_mode segment post-ops (plan.IT_POST; selects that kernel instantiation). */
+ * program_flags: bit 0 = the program contains lite_mode segment post-ops (plan.IT_POST; selects that kernel instantiation).
+ * res0 / res1 (nullable; res1 needs res0): residual rows in the OUTPUT's planar layout, added in the epilogue -- the
+ * `x + Lin2(Gate(Lin1 x))` and `+ skip` adds of ResidualBlock / ConvBlockE3 (hamgnn/nn/interaction_blocks.py:352-357,
+ * convolution.py:158) ride on the producing launch; not combined with un-rotating segments.                            */
 int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
                 int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights,
                 const int32_t* seg_table, int nseg, const int32_t* item_table, float* out, int64_t out_stride,
-                int64_t rows, int lds_bytes, int program_flags, void* stream);
+                int64_t rows, int lds_bytes, int program_flags, const float* res0, int64_t res0_stride, const float* res1,
+                int64_t res1_stride, void* stream);
 
 /* Input-stationary schedule of the same fused MessagePackBlock (same reference ops as hg_tp_fused: message_passing.py:191-231
  * [+ interaction_blocks.py:151-152]); csrc/tp_is.hip.  One workgroup = 16 edges with the tiles of ALL output segments in LDS;
@@ -86,11 +90,13 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
 int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_t* rowptr, const int64_t* perm, int64_t N, int Dp,
                    float* out, int64_t out_stride, void* stream);
 
-/* e3nn Gate of ResidualBlock (hamgnn/nn/interaction_blocks.py:311-323, 348) on planar rows, optionally fused with the
- * residual/skip adds.  tab: int32[Dout][4] = {src index, act id (0 none,1 ssp,2 tanh,3 silu,4 abs), gate index or -1, gate act id}.
- * consts[act id] = normalize2mom constant.                                                                          */
-int hg_gate(const float* x, int64_t x_stride, const int32_t* tab, int Dout, const float* consts, int64_t rows, float* out,
-            int64_t out_stride, void* stream);
+/* e3nn Gate of ResidualBlock (hamgnn/nn/interaction_blocks.py:311-323, 348) on planar rows.  Tables from
+ * hamgnn_amd/plan.py:gate_tables_compact: act_tab int32[nact][2] = {input index, act id (0 none,1 ssp,2 tanh,3 silu,4 abs)} -- the
+ * row's distinct activated scalars (scalars and gate channels), each evaluated ONCE per row; out_tab int32[Dout][2] =
+ * {source code, gate code}: source code = input index | (0x40000000 | act slot) | -1 (structural zero), gate code = act slot | -1.
+ * consts[act id] = normalize2mom constant.                                                                            */
+int hg_gate(const float* x, int64_t x_stride, const int32_t* act_tab, int nact, const int32_t* out_tab, int Dout, const float* consts,
+            int64_t rows, float* out, int64_t out_stride, void* stream);
 
 /* y = a + b (+ c) on [rows, D] planar rows: ResidualBlock "+x" (interaction_blocks.py:355-356), ConvBlockE3 "+= skip"
  * (convolution.py:155-156).  c may be NULL.                                                                         */
@@ -116,6 +122,19 @@ int hg_embed_lookup(const float* Ta, const float* Tb, const int64_t* z, const in
 int hg_ham_merge(const float* coeff, int64_t c_stride, const float* wig, int nW, const int32_t* wig_off,
                  const int32_t* slot_tab, int nslots, const int32_t* cg_ptr, const int32_t* cg_idx, const float* cg_val,
                  int nout, int64_t rows, float* Hraw, void* stream);
+
+/* Read-out head in ONE pass (non-SOC branch, hamgnn_output.py:3772-3799): stage 1 (merge_tensor_components + reorder_matrix,
+ * tables as for hg_ham_merge with nout = nao^2) and stage 2 (symmetrize :1231-1285, + H0, orbital masks :2288-2365) for PAIRS of
+ * rows (pair_a[p], pair_b[p]) = (edge, inverse edge) -- both merged blocks live in the LDS and are symmetrised against each
+ * other, so no intermediate Hraw exists.  pair_b == NULL: every row pairs with itself (on-site blocks; pair_a == NULL: row p).
+ * Each row must occur in exactly one pair.  H: [rows, nao^2] result rows (e.g. the row range of the [N+E, nao^2] output).
+ * c_width: floats per coefficient row; lmax_ham: largest L among the slots (the leading Wigner blocks l <= lmax_ham of each row are
+ * staged).  flags / sign / masks as hg_ham_finish.  Tables must fit 64 KB of LDS (else use the two-stage entry points).      */
+int hg_ham_readout(const float* coeff, int64_t c_stride, int c_width, const float* wig, int nW, const int32_t* wig_off,
+                   int lmax_ham, const int32_t* slot_tab, int nslots, const int32_t* cg_ptr, const int32_t* cg_idx,
+                   const float* cg_val, int nnz, int nao, const int64_t* pair_a, const int64_t* pair_b, int64_t npairs,
+                   const float* H0, const float* orb_mask, int mask_w, const int64_t* z, const int64_t* idx_a, const int64_t* idx_b,
+                   float sign, int flags, float* H, void* stream);
 
 /* Read-out head, stage 2 (:1231-1285 symmetrize, :3782-3795 +H0, :2288-2365 orbital masks):
  * H[e] = mask(z_a, z_b) * (0.5 (Hraw[e] + sign * Hraw[inv[e]]^T) + H0[e]);  inv == NULL => on-site (own transpose).

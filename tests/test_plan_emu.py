@@ -191,7 +191,10 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     skip = np.random.default_rng(3).standard_normal(so3.Irreps(MINI).dim * 0 + sum(m * m for m, _, _ in so3.Irreps(MINI)))
     prog = P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=True)
     sched = P.is_schedule(prog)
-    assert sched.item_table.shape == prog.item_table.shape and sched.lds_floats * 4 <= P.IS_LDS_BYTES
+    assert sched.item_table.shape == (prog.item_table.shape[0], P.IS_ITEM_I32) and sched.lds_floats * 4 <= P.IS_LDS_BYTES
+    for rec in sched.item_table:                              # the segment fields embedded in every item record (csrc/tp_is.hip:ItemRec)
+        sg = sched.seg_table[rec[19]]
+        assert (rec[20], rec[21], rec[22], rec[23]) == (sg[0], sg[1], sg[2], sg[5])
     assert sched.ctr_off == sched.stage_off + sched.stage_floats and sched.balance > 0.5
     outp = emu.run_program_is(prog, sched, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(lay.from_planar(outp), f["outputs"]["out"]) < 1e-6
@@ -216,7 +219,7 @@ def test_input_stationary_schedule_shipped_irreps(which):
     skip = np.zeros(sum(mm * mm for mm, _, _ in so3.Irreps(irr)))
     prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, bench.SH, irr, True, skip)
     sc = P.is_schedule(prog)
-    assert sc.lds_floats * 4 <= P.IS_LDS_BYTES and sc.item_table.shape == prog.item_table.shape
+    assert sc.lds_floats * 4 <= P.IS_LDS_BYTES and sc.item_table.shape == (prog.item_table.shape[0], P.IS_ITEM_I32)
     seen = np.zeros(sc.item_table.shape[0], dtype=int)
     for b0, b1, g0, g1 in sc.phase_table:
         used, offs = 0, set()
@@ -338,3 +341,42 @@ def test_random_irreps_both_schedules_vs_oracle(seed):
     assert rel(lay.from_planar(outp), out) < 1e-6, irr
     outi = emu.run_program_is(prog, P.is_schedule(prog), [xs, xd, fe], (hn, he), D, lm)
     assert rel(lay.from_planar(outi), out) < 1e-6, irr
+
+
+@pytest.mark.parametrize("irreps", [MINI, "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e", "3x0e+2x1o"])
+def test_gate_tables_compact_match_the_oracle_gate(irreps):
+    """hg_gate's tables (plan.gate_tables -> gate_tables_compact: distinct activated scalars once per row, outputs by look-up),
+    emulated in numpy on planar rows, against the oracle's e3nn-style Gate of the reference ResidualBlock."""
+    import torch
+    from oracle import hamgnn_ref as R
+    irr_in, irr_out, tab = P.gate_tables(irreps)
+    act_tab, out_tab = P.gate_tables_compact(tab)
+    assert len({(int(a), int(b)) for a, b in act_tab}) == len(act_tab)                  # every (input, activation) pair once
+    n_scal = sum(m for m, l, p in so3.Irreps(irreps) if l == 0)
+    n_gate = sum(m for m, l, p in so3.Irreps(irreps) if l > 0)
+    assert len(act_tab) == n_scal + n_gate
+    rb = R.ResidualBlock(irreps, irreps).double()
+    gate = rb.equivariant_nonlin
+    assert str(gate.irreps_in) == str(irr_in) and str(gate.irreps_out) == str(irr_out)
+    x = np.random.default_rng(2).standard_normal((7, so3.Irreps(str(irr_in)).dim))
+    want = gate(torch.from_numpy(x)).numpy()
+    lay_in, lay_out = P.PlanarLayout(irr_in), P.PlanarLayout(irr_out)
+    xp = lay_in.to_planar(x)
+
+    def act(v, k):
+        c = float(P.ACT_CONSTS[k])
+        if k == P.ACT_SSP:
+            return c * (np.log1p(np.exp(v)) - math.log(2.0))
+        if k == P.ACT_TANH:
+            return c * np.tanh(v)
+        if k == P.ACT_ABS:
+            return c * np.abs(v)
+        return v
+    av = np.stack([act(xp[:, i], k) for i, k in act_tab], 1)
+    out = np.zeros((x.shape[0], lay_out.dim))
+    for p, (sc, gc) in enumerate(out_tab):
+        if sc < 0:
+            continue
+        v = av[:, sc & 0x3fffffff] if sc & 0x40000000 else xp[:, sc]
+        out[:, p] = v * (av[:, gc] if gc >= 0 else 1.0)
+    assert rel(lay_out.from_planar(out), want) < 1e-6          # ACT_CONSTS are float32 roundings of the Monte-Carlo constants
