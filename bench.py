@@ -32,10 +32,10 @@ SH = "0e+1o+2e+3o+4e+5o"
 # algorithmic cost of ONE fused MessagePackBlock per edge in the REFERENCE formulation (non-zero CG entries)
 REF_FLOPS_PER_EDGE_BLOCK = {"A": 4.55e6, "B": 1.73e6}
 REF_BYTES_PER_EDGE_BLOCK = {"A": 14432.0, "B": 7888.0}
-# HBM bytes per edge of one MessagePackBlock launch from the rocprofv3 PMC passes in profiles/r01d_tp_is_hbm_pmc.md / r01c_tp_fused_hbm_pmc.md
+# HBM bytes per edge of one MessagePackBlock launch from the rocprofv3 PMC passes in profiles/r02_tp_is_hbm_pmc.md / r01c_tp_fused_hbm_pmc.md
 # (separate --pmc FETCH_SIZE / WRITE_SIZE runs on tests/bench_tp.py, 131072 edges; FETCH_SIZE x 2: gfx950 correction for
 # 16-B/lane reads, MI355X_MICROARCH.md "HBM"): measured offline for this kernel build, scaled to the launch's edge count.
-# kernel "is" = input-stationary tp_is_kernel (profiles/r01d_tp_is_hbm_pmc.md), "seg" = segment-stationary tp_fused_kernel
+# kernel "is" = input-stationary tp_is_kernel (profiles/r02_tp_is_hbm_pmc.md), "seg" = segment-stationary tp_fused_kernel
 PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 33.6e3, ("is", "B"): 13.1e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
@@ -152,7 +152,7 @@ def main():
     torch.manual_seed(666)
     model = HamGNNConvE3(make_cfg(irreps))
     head = HamGNNPlusPlusOut(irreps, irreps, nao_max=args.nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
-                             soc_switch=False, calculate_sparsity=False)
+                             soc_switch=False, calculate_sparsity=True)          # the reference's defaults
     g = make_graph(args.workload, args.nao)
     E_total, N_atoms = g.num_edges, g.num_nodes
     if world > 1:
@@ -175,11 +175,16 @@ def main():
         step()
     barrier()
     ops.PROFILE_EVENTS = []                                  # HIP event pairs around every hg_tp_fused launch (launch stream)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step boundaries on the launch stream (no host sync)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for k in range(args.steps):
         out = step()
+        marks[k + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     events, ops.PROFILE_EVENTS = ops.PROFILE_EVENTS, None
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -187,7 +192,7 @@ def main():
         dt = float(tmax.item())
     assert torch.isfinite(out["hamiltonian"]).all()
 
-    # ---- roofline of the dominant kernel: the MessagePackBlock launches of hg_tp_fused
+    # ---- roofline of the dominant kernel: the fused MessagePackBlock launches (hg_tp_is; hg_tp_fused on the fallback path)
     mp = [(s.elapsed_time(e) * 1e-3, rows, tag) for (s, e, rows, tag) in events if tag == "message_pack"]
     all_tp = sum(s.elapsed_time(e) * 1e-3 for (s, e, rows, tag) in events)
     n_launch = max(1, len(mp))
@@ -201,16 +206,17 @@ def main():
     pmc_bytes = PMC_HBM_BYTES_PER_EDGE_BLOCK[(kern, args.irreps)]
     roofline = {"kernel": ("tp_is_kernel (input-stationary" if kern == "is" else "tp_fused_kernel (segment-stationary") + " MessagePackBlock launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": pmc_bytes * rows_per_launch,
-                "traffic_unit": "bytes per launch (PMC, measured offline: profiles/r01d_tp_is_hbm_pmc.md, r01c_tp_fused_hbm_pmc.md)", "avg_launch_ms": avg_s * 1e3,
+                "traffic_unit": "bytes per launch (PMC, measured offline: profiles/r02_tp_is_hbm_pmc.md, r01c_tp_fused_hbm_pmc.md)", "avg_launch_ms": avg_s * 1e3,
                 "launches_timed": len(mp), "edges_per_launch": rows_per_launch,
                 "executed_useful_tflops": useful / avg_s / 1e12, "issued_mfma_tflops": issued / avg_s / 1e12,
                 "hbm_algorithmic_GBs": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9,
                 "hbm_frac": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9 / PEAK_HBM_GBS,
                 "hbm_measured_GBs": pmc_bytes * rows_per_launch / avg_s / 1e9,
-                "tp_fused_share_of_step": all_tp / dt}
+                "fused_program_launches_share_of_step": all_tp / dt}
 
     res = {"metric": "edges/sec (equivariant MP forward)", "value": E_total * args.steps / dt, "unit": "edges/s", "n_gpus": world,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": median_ms,
+           "edges_per_s_median_step": E_total / (median_ms * 1e-3), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {N_atoms} atoms, {E_total} directed edges, irreps set-{args.irreps} (D={model.irreps_node_features.dim}), "
                                   f"sh lmax 5, 3 layers, nao_max {args.nao}, no SOC, backbone+head forward",

@@ -29,11 +29,12 @@ struct IsArgs {
     float* out;
     int64_t ostride;
     int64_t rows;
-    int nseg;
+    int nseg;                    // single-part launches: the whole program (split launches read these per part, see IS_PART_I32)
     int nphase;
     int trash_off;               // float offsets inside the workgroup's LDS
     int stage_off;
     int ctr_off;                 // work-claim counter (one dword)
+    int tile_shift;              // split launches: this wave's private tile copy (floats added to every tile offset)
     const int64_t* idx[4];       // per source slot: row gather (NULL: row = edge)
     int rot_mask;                // bit i: source i holds GLOBAL-frame rows that are rotated into the edge frame while staged
 };
@@ -80,7 +81,7 @@ __device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* l
 
 // One item on the workgroup's 16 edges.  stage: the phase's staged input block(s), image offset(piece p, row e) = 64 p + 4 e per
 // source (pieces of the FULL irrep block: component a, channel piece s -> p = a * P1 + s).
-template <int MM, int RTM>
+template <int MM, int RTM, bool SPLIT>
 __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, const int* __restrict__ S8,
                                         float* __restrict__ lds, int64_t erow, int lane IS_PROF_ARG) {
     constexpr int NC = 2 * MM + 1;
@@ -90,7 +91,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const int lk = S8[0], mul_k = S8[1], rto = S8[2], tile_off = S8[5];
     const int g = lane >> 4, el = lane & 15;
     const int rowstride = (2 * lk + 1) * 16 + 4;
-    float* __restrict__ tile = lds + tile_off;
+    float* __restrict__ tile = lds + tile_off + (SPLIT ? A.tile_shift : 0);
     float* __restrict__ trash = lds + A.trash_off;
     const float* __restrict__ stage = lds + A.stage_off;
     IS_T(0);                                                    // dispatch
@@ -448,19 +449,43 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
 }
 
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_is<MMv, RTMv>(A, g_W, it, g_segs + it[19] * 8, lds, erow, lane IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT>(A, g_W, it, g_segs + it[19] * 8, lds, erow, lane IS_PROF_PASS); break;
 
 #define SEG_NEWBATCH (1 << 16)
 
-__global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
+// A launch runs `nparts` sub-schedules (blockIdx.y) of the same program: every part owns a disjoint set of output segments and the
+// phases / groups / items that feed them (plan.py:is_schedule(parts=...)).  One part = the whole program (large edge counts); several
+// parts spread ONE 16-edge tile's serial 34 k-MFMA pass over several workgroups when there are fewer tiles than CUs (small crystals).
+// part record, int32[8]: {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off (float offsets in the LDS),
+// copy_stride}.  copy_stride > 0: each of the four waves accumulates into its own copy of the part's tiles (copy w at + w * copy_stride),
+// so all waves can work on one output segment at once; the copies are summed before the epilogue.
+#define IS_PART_I32 8
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
                                                        const int* __restrict__ g_phases, const int* __restrict__ g_groups,
-                                                       const int* __restrict__ g_items, const float* __restrict__ g_W) {
+                                                       const int* __restrict__ g_items, const float* __restrict__ g_W,
+                                                       const int* __restrict__ g_parts) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4;
     const int64_t e = (int64_t)blockIdx.x * 16 + (lane & 15);
-    const bool valid = e < A.rows;
-    const int64_t erow = valid ? e : A.rows - 1;
+    const bool valid = e < A0.rows;
+    const int64_t erow = valid ? e : A0.rows - 1;
+    // SPLIT = false: one part = the whole program, every schedule scalar comes straight from the kernel arguments (the large-graph path,
+    // identical to the single-schedule kernel); SPLIT = true: blockIdx.y selects the part, its scalars replace the arguments'
+    const int* __restrict__ PT = g_parts + (SPLIT ? blockIdx.y : 0) * IS_PART_I32;
+    IsArgs Asplit;
+    if constexpr (SPLIT) {
+        Asplit = A0;
+        Asplit.trash_off = PT[4];
+        Asplit.stage_off = PT[5];
+        Asplit.ctr_off = PT[6];
+        Asplit.tile_shift = wave * PT[7];
+    }
+    const IsArgs& A = SPLIT ? Asplit : A0;
+    const int seg0 = SPLIT ? PT[0] : 0, seg1 = SPLIT ? PT[0] + PT[1] : A0.nseg, ph0 = SPLIT ? PT[2] : 0, ph1 = SPLIT ? PT[2] + PT[3] : A0.nphase;
+    const int copy_stride = SPLIT ? PT[7] : 0;
     float* __restrict__ stage = lds + A.stage_off;
     int* __restrict__ ctr = reinterpret_cast<int*>(lds + A.ctr_off);
 #ifdef HG_PROF
@@ -473,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A, const int
     for (int i = threadIdx.x; i < A.stage_off; i += 256) lds[i] = 0.f;             // all segment tiles + the trash row
     IS_T(4);                                                   // zero fill
 
-    for (int ph = 0; ph < A.nphase; ++ph) {
+    for (int ph = ph0; ph < ph1; ++ph) {
         const int* __restrict__ P = g_phases + ph * 4;
         const int b0 = P[0], b1 = P[1], g0 = P[2], g1 = P[3];
         __syncthreads();                                       // every wave is done with the previous blocks (and the zero fill)
@@ -520,16 +545,20 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A, const int
         }
     }
 
+    if (SPLIT && copy_stride) {                                // split launch: fold the waves' private tile copies into copy 0
+        __syncthreads();
+        for (int i = threadIdx.x; i < copy_stride; i += 256) lds[i] += lds[i + copy_stride] + lds[i + 2 * copy_stride] + lds[i + 3 * copy_stride];
+    }
     // ---------------------------------------------------------------- epilogue: all four waves on one segment at a time; the Wigner
     // blocks of a batch of segments (one block per l, as many l as fit the staging area) are staged together by LDS-DMA
-    for (int sg = 0; sg < A.nseg; ++sg) {
+    for (int sg = seg0; sg < seg1; ++sg) {
         const int* __restrict__ S8 = g_segs + sg * 8;
         const int lk = S8[0], mul_k = S8[1], out_off = S8[3], out_mulp = S8[4], tile_off = S8[5], woff = S8[6], flags = S8[7];
-        if (sg == 0 || (flags & SEG_NEWBATCH)) {
+        if (sg == seg0 || (flags & SEG_NEWBATCH)) {
             __syncthreads();                                   // tiles complete / previous batch no longer read
             if (flags & SEG_NEWBATCH) {
                 int lprev = -1;
-                for (int s2 = sg; s2 < A.nseg; ++s2) {
+                for (int s2 = sg; s2 < seg1; ++s2) {
                     const int* __restrict__ T8 = g_segs + s2 * 8;
                     if (s2 > sg && (T8[7] & SEG_NEWBATCH)) break;
                     const int l2 = T8[0];
@@ -585,15 +614,15 @@ extern "C" int hg_prof_is_read(unsigned long long* out16, int reset) {
 
 extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
                         int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
-                        int nseg, const int32_t* block_table, const int32_t* phase_table, int nphase, const int32_t* group_table,
-                        const int32_t* item_table, int trash_off, int stage_off, int ctr_off, int lds_bytes,
+                        const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table,
+                        const int32_t* item_table, const int32_t* part_table, const int32_t* part_table_host, int nparts, int lds_bytes,
                         const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_is: nsrc must be 1..4");
     if (hidden & 15) return hg_fail(-2, "hg_tp_is: (padded) hidden width must be a multiple of 16");
-    if (lds_bytes <= 0 || lds_bytes > 160 * 1024 || lds_bytes < 4 * (ctr_off + 1) || ctr_off < stage_off || stage_off < trash_off)
-        return hg_fail(-2, "hg_tp_is: bad LDS layout");
+    if (lds_bytes <= 0 || lds_bytes > 160 * 1024) return hg_fail(-2, "hg_tp_is: bad LDS size");
+    if (!part_table || !part_table_host || nparts < 1 || nparts > 64) return hg_fail(-2, "hg_tp_is: 1..64 parts");
     IsArgs A;
     for (int i = 0; i < 4; ++i) {
         A.src[i] = i < nsrc ? src[i] : src[0];
@@ -608,18 +637,25 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     A.out = out;
     A.ostride = out_stride;
     A.rows = rows;
-    A.nseg = nseg;
-    A.nphase = nphase;
-    A.trash_off = trash_off;
-    A.stage_off = stage_off;
-    A.ctr_off = ctr_off;
+    A.tile_shift = 0;
+    const int32_t* p0 = part_table_host;                       // single-part launches take the schedule scalars as kernel arguments
+    A.nseg = p0[1], A.nphase = p0[3], A.trash_off = p0[4], A.stage_off = p0[5], A.ctr_off = p0[6];
+    for (int p = 0; p < nparts; ++p) {
+        const int32_t* q = part_table_host + p * IS_PART_I32;
+        if (q[6] < q[5] || q[5] < q[4] || lds_bytes < 4 * (q[6] + 1) || (q[7] && 4 * q[7] > q[4])) return hg_fail(-2, "hg_tp_is: bad LDS layout");
+    }
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
     A.rot_mask = rot_mask;
     if (rot_mask && !wig) return hg_fail(-2, "hg_tp_is: rotated sources need the Wigner rows");
-    static unsigned char lds_attr_done[HG_MAX_DEVICES];        // once per device (not a stream operation: illegal during graph capture)
-    if (int rc = hg_lds_attr_once(lds_attr_done, dev_guard.dev, (const void*)tp_is_kernel, 160 * 1024)) return rc;
+    static unsigned char lds_attr_done[2][HG_MAX_DEVICES];     // once per device (not a stream operation: illegal during graph capture)
+    if (int rc = hg_lds_attr_once(lds_attr_done[0], dev_guard.dev, (const void*)tp_is_kernel<false>, 160 * 1024)) return rc;
+    if (int rc = hg_lds_attr_once(lds_attr_done[1], dev_guard.dev, (const void*)tp_is_kernel<true>, 160 * 1024)) return rc;
     const unsigned grid = (unsigned)((rows + 15) / 16);
-    hipLaunchKernelGGL(tp_is_kernel, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table, group_table,
-                       item_table, weights);
+    if (nparts == 1)
+        hipLaunchKernelGGL(tp_is_kernel<false>, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table,
+                           group_table, item_table, weights, part_table);
+    else
+        hipLaunchKernelGGL(tp_is_kernel<true>, dim3(grid, (unsigned)nparts), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table,
+                           phase_table, group_table, item_table, weights, part_table);
     return hg_check_launch("hg_tp_is");
 }

@@ -5,7 +5,7 @@ The reference stores pickled torch_geometric ``Data`` objects.  This reader work
 unpickler maps ``torch_geometric.data.*`` classes onto the dependency-free ``Graph`` container (attribute + key access,
 same field names), so files written by the reference tool-chain and by ``save_graph_npz`` load the same way.  Dict-of-
 arrays graphs (the reference's second accepted form, graph_data.py:141-156) are converted as well.  LMDB
-(graph_data.py:23-93, keys ``num_graphs`` / ``graph_{i}``) needs the ``lmdb`` module, which this image lacks: a clear error."""
+stores (graph_data.py:23-93, keys ``num_graphs`` / ``graph_{i}``) are read with the dependency-free parser in ``lmdb_lite``."""
 from __future__ import annotations
 
 import io
@@ -130,13 +130,52 @@ class NPZGraphDataset:
 
 
 class LMDBGraphDataset:
-    def __init__(self, *a, **k):
-        try:
-            import lmdb  # noqa: F401
-        except ImportError as e:
-            raise ImportError("LMDB graph stores need the `lmdb` module, which is not available in this environment; "
-                              "convert with tools/npz_to_lmdb.py's inverse or use graph_data.npz") from e
-        raise NotImplementedError("LMDB reader: not built this round (SURVEY 8f-1)")
+    """Mirror of the reference's LMDB dataset (hamgnn/data/graph_data.py:23-93): keys ``num_graphs`` and ``graph_{i}``, values =
+    pickled graph records; same constructor / len / getitem / transform / preload behaviour.  Reads the store with the dependency-free
+    parser in ``lmdb_lite`` (the ``lmdb`` module is not needed) and unpickles through the allow-list ``_Unpickler`` above, so records
+    written by the reference (torch_geometric ``Data``) come back as ``Graph`` objects."""
+
+    def __init__(self, lmdb_path: str, indices=None, transform=None, preload: int = 0):
+        from .lmdb_lite import LMDBReader
+        self.lmdb_path, self.transform, self.preload = lmdb_path, transform, preload
+        self._reader = LMDBReader(lmdb_path)
+        n = self._reader.get(b"num_graphs")
+        if n is None:
+            raise ValueError(f"{lmdb_path}: key 'num_graphs' is missing")
+        self.total_length = int(n.decode())
+        self.indices = list(indices) if indices is not None else list(range(self.total_length))
+        self.preloaded_data = {i: self._load(i) for i in self.indices[:max(0, preload)]}
+
+    def _load(self, real_idx: int) -> Graph:
+        raw = self._reader.get(f"graph_{real_idx}".encode())
+        if raw is None:
+            raise IndexError(f"Index {real_idx} out of bounds for LMDB dataset")
+        return _to_graph(_Unpickler(io.BytesIO(raw)).load())
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, list):
+            return [self[i] for i in idx]
+        real = self.indices[idx]
+        g = self.preloaded_data.get(real)
+        if g is None:
+            g = self._load(real)
+        return self.transform(g) if self.transform is not None else g
+
+    def close(self):
+        self._reader.close()
+
+
+def npz_to_lmdb(npz_path: str, lmdb_path: str) -> str:
+    """tools/npz_to_lmdb.py:27-109 without the lmdb module: ``num_graphs`` + ``graph_{i}`` (i = rank of the sorted npz key)."""
+    from .lmdb_lite import write_lmdb
+    graphs = load_graph_npz(npz_path)
+    items = {b"num_graphs": str(len(graphs)).encode()}
+    for i, g in enumerate(graphs):
+        items[f"graph_{i}".encode()] = pickle.dumps(g)
+    return write_lmdb(lmdb_path, items)
 
 
 def batches(graphs: Sequence[Graph], batch_size: int = 1):

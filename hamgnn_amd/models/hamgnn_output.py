@@ -54,8 +54,8 @@ class HamGNNPlusPlusOut(nn.Module):
         if soc_switch and self.soc_basis == "su2":
             # hamgnn_output.py:281-293 + :189-198: irreps_out = 2 * (required + required); get_H reads copies 0 (re) and 2 (im)
             half = P.su2_irreps(self.row)
-            if half.lmax > 6:
-                raise NotImplementedError("su2 SOC head: L x 1 couplings beyond l = 6 (f-orbital bases) are not instantiated")
+            if half.lmax > 7 or Irreps(irreps_in_node).lmax > 6 or Irreps(irreps_in_edge).lmax > 6:
+                raise NotImplementedError("su2 SOC head: features beyond l = 6 / couplings beyond l = 7 are not instantiated")
             self.hamiltonian_irreps_su2 = Irreps(list(half) * 2)
             keep = [c in (0, 2) for c in range(4) for _ in range(len(half))]
             self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, Irreps(list(half) * 4), keep)

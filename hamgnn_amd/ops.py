@@ -3,6 +3,7 @@ Every function launches hand-written HIP kernels from libhamgnn_hip.so; nothing 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -63,15 +64,37 @@ class DeviceProgram:
         self.flags = 1 if (prog.item_table.shape[0] and (prog.item_table[:, 0] == P.IT_POST).any()) else 0
         # input-stationary schedule of the same items (csrc/tp_is.hip) when the tiles of all output segments fit the LDS
         self.sched = None
+        self._device = device
+        self._is_tables = {}                                   # parts -> (IsSchedule, device tables)
         if schedule in ("is", "auto"):
             try:
-                sc = P.is_schedule(prog)
-                self.sched = sc
-                self.is_segs, self.is_blocks, self.is_phases, self.is_groups, self.is_items = (
-                    _dev(t, device) for t in (sc.seg_table, sc.block_table, sc.phase_table, sc.group_table, sc.item_table))
+                self.sched = self.is_tables(1)[0]
             except NotImplementedError:
                 if schedule == "is":
                     raise
+
+    def is_tables(self, parts: int):
+        """(schedule, device tables) of the input-stationary kernel split into `parts` sub-schedules (built on first use)"""
+        if parts not in self._is_tables:
+            sc = P.is_schedule(self.prog, parts)
+            self._is_tables[parts] = (sc, tuple(_dev(t, self._device) for t in (sc.seg_table, sc.block_table, sc.phase_table, sc.group_table,
+                                                                                  sc.item_table, sc.part_table)))
+        return self._is_tables[parts]
+
+    def is_parts_for(self, rows: int) -> int:
+        """How many workgroups share one 16-edge tile.  The chip holds 512 workgroups of this kernel (2 per CU); a launch with fewer
+        tiles than that is a latency problem -- every workgroup walks the whole program serially -- so the output segments are spread
+        over 8 (or one per segment) workgroups per tile while the extra staging work still fits the idle CUs."""
+        forced = os.environ.get("HG_IS_PARTS")
+        if forced:
+            return max(1, int(forced))
+        tiles = (rows + 15) // 16
+        nseg = int(self.prog.seg_table.shape[0])
+        if tiles * nseg <= 512:
+            return nseg
+        if tiles <= 300 and nseg >= 8:
+            return 8
+        return 1
 
 
 def wig_offsets(lmax):
@@ -156,13 +179,13 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     if dp.sched is not None:
-        sc = dp.sched
+        sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts) = dp.is_tables(dp.is_parts_for(rows))
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
-        check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.is_segs),
-                             i32(dp.nseg), ptr(dp.is_blocks), ptr(dp.is_phases), i32(sc.phase_table.shape[0]), ptr(dp.is_groups),
-                             ptr(dp.is_items), i32(sc.trash_off), i32(sc.stage_off), i32(sc.ctr_off), i32(sc.lds_floats * 4), gp,
-                             i32(rot_mask), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
+        check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(t_segs),
+                             ptr(t_blocks), ptr(t_phases), ptr(t_groups), ptr(t_items), ptr(t_parts),
+                             sc.part_table.ctypes.data_as(C.c_void_p), i32(sc.part_table.shape[0]),
+                             i32(sc.lds_floats * 4), gp, i32(rot_mask), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
     else:
         check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
                                 i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), i32(dp.flags),

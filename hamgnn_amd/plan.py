@@ -176,24 +176,92 @@ class IsSchedule:
     #                                dynamically by the waves (largest first), so no two waves update one tile between barriers
     item_table: np.ndarray         # int32[nitems][24]: Program.item_table records with [1], [2] = stage offsets of source 0 / 1 (-1),
     #                                [20..23] = {lk, mul_k, rto, tile_off} of the item's segment
-    trash_off: int                 # float offset of the shared trash row (absorbs fragment-padding rows)
-    stage_off: int                 # float offset of the staging area
-    stage_floats: int
-    ctr_off: int                   # float offset of the work-claim counter
-    lds_floats: int
-    balance: float                 # LPT estimate: sum(cost) / (waves * sum over phases of max wave cost)
+    part_table: np.ndarray         # int32[nparts][8] = {seg_begin, nseg, phase_begin, nphase, trash_off, stage_off, ctr_off, copy_stride}
+    #                                copy_stride > 0: every wave owns a private copy of the part's tiles (floats between copies)
+    lds_floats: int                # dynamic LDS of a workgroup (largest part)
+    balance: float                 # LPT estimate: sum(cost) / (waves * sum over phases of max wave cost), worst part
+    part_cost: List[int]           # estimated MFMA-slot cost of every part (critical path over its phases)
+
+    # single-part views (the common large-graph case; tests)
+    @property
+    def trash_off(self):
+        return int(self.part_table[0][4])
+
+    @property
+    def stage_off(self):
+        return int(self.part_table[0][5])
+
+    @property
+    def ctr_off(self):
+        return int(self.part_table[0][6])
+
+    @property
+    def stage_floats(self):
+        return self.ctr_off - self.stage_off
 
 
 SEG_NEWBATCH = 1 << 16             # IS epilogue: this segment starts a new Wigner staging batch
+IS_PART_I32 = 8
 
 
-def is_schedule(prog: "Program") -> IsSchedule:
+def _item_cost(rec, segs, hp4):
+    typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
+    c = nsrc * int(rec[8]) * rtm * nc + 60                     # GEMM1 + a per-item latency allowance (in MFMA slots)
+    if typ == IT_TP:
+        c += hp4 * rtm + int(segs[int(rec[19])][2]) * int(rec[18]) * nc
+    return c
+
+
+def is_schedule(prog: "Program", parts: int = 1) -> IsSchedule:
     """Regroup a finalized fused-kernel program for the input-stationary kernel.  Input irrep blocks (per source set) are packed
     into phases whose staged rows fit the staging area; every item reading a staged block runs in that phase.  Raises
-    NotImplementedError when the tiles of all output segments + a useful staging area do not fit IS_LDS_BYTES."""
+    NotImplementedError when the tiles of all output segments + a useful staging area do not fit IS_LDS_BYTES.
+    parts > 1: the output segments are split into `parts` sets of equal estimated cost (LPT); each set gets its own sub-schedule
+    (tiles, phases, groups) and runs in its own workgroup (grid.y) -- the per-tile latency drops at the price of staging the input
+    blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots."""
     if (prog.item_table[:, 0] == IT_POST).any() or (prog.item_table[:, 0] == IT_LINC).any():
         raise NotImplementedError("lite_mode programs run on the segment-stationary kernel")
-    segs = prog.seg_table.copy()
+    hp4 = prog.hidden_pad // 4
+    nseg = prog.seg_table.shape[0]
+    seg_cost = np.zeros(nseg)
+    for rec in prog.item_table:
+        seg_cost[int(rec[19])] += _item_cost(rec, prog.seg_table, hp4)
+    parts = max(1, min(int(parts), nseg))
+    owner = np.zeros(nseg, dtype=np.int64)
+    if parts > 1:
+        load = [0.0] * parts
+        for sg in np.argsort(-seg_cost, kind="stable"):
+            r = load.index(min(load))
+            owner[sg] = r
+            load[r] += seg_cost[sg]
+    segs_all, btab, ptab, gtab, items_all, parttab, part_cost = [], [], [], [], [], [], []
+    lds_floats, worst_balance = 0, 1.0
+    for part in range(parts):
+        members = [sg for sg in range(nseg) if owner[sg] == part]
+        sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
+                                split=parts > 1)
+        parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
+                        sub["copy_stride"]])
+        segs_all += list(sub["segs"])
+        btab += sub["btab"]
+        ptab += sub["ptab"]
+        gtab += sub["gtab"]
+        items_all += list(sub["items"])
+        lds_floats = max(lds_floats, sub["ctr_off"] + 4)
+        worst_balance = min(worst_balance, sub["balance"])
+        part_cost.append(sub["crit"])
+    items = np.asarray(items_all, np.int32).reshape(-1, IS_ITEM_I32)
+    return IsSchedule(np.asarray(segs_all, np.int32).reshape(-1, SEG_I32), np.asarray(btab, np.int32).reshape(-1, IS_BLOCK_I32),
+                      np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
+                      np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), lds_floats, worst_balance, part_cost)
+
+
+def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
+                      split: bool = False) -> dict:
+    """sub-schedule of the output segments `members` (indices into prog.seg_table); all table indices are emitted as ABSOLUTE indices
+    into the concatenated tables of the launch (bases given)."""
+    segs = prog.seg_table[members].copy()
+    local = {old: n for n, old in enumerate(members)}
     off, maxstride = 0, 0
     for s in segs:
         lk, mul_k = int(s[0]), int(s[1])
@@ -201,13 +269,24 @@ def is_schedule(prog: "Program") -> IsSchedule:
         s[5], s[6] = off, 0
         off += mul_k * stride
         maxstride = max(maxstride, stride)
+    # split launches (several parts): every wave accumulates into its OWN copy of the part's tiles (summed before the epilogue), so the
+    # items of one (phase, segment) can run on all four waves at once -- with one shared copy a part that owns one or two segments
+    # would keep a single wave busy.  Taken when the four copies leave room for the largest input block.
+    copy_stride = 0
+    if split:
+        need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256
+                   for r in prog.item_table if int(r[19]) in local)
+        if IS_WAVES * off + maxstride + need + 4 <= IS_LDS_BYTES // 4:
+            copy_stride = off
+            off *= IS_WAVES
     trash_off = off
     stage_off = trash_off + maxstride
     stage_floats = IS_LDS_BYTES // 4 - stage_off - 4
-    ctr_off = stage_off + stage_floats
-    # ---- input blocks
+    # ---- input blocks read by this part's items
     blocks: Dict[Tuple[int, int, int], dict] = {}
     for rec in prog.item_table:
+        if int(rec[19]) not in local:
+            continue
         key = (int(rec[1]), int(rec[2]), int(rec[3]))
         if int(rec[5]) > 6:
             raise NotImplementedError("input irreps with l > 6 have no staging instantiation")
@@ -220,6 +299,7 @@ def is_schedule(prog: "Program") -> IsSchedule:
         b["floats"] = b["nsrc"] * b["src_floats"]
         if b["floats"] > stage_floats:
             raise NotImplementedError(f"input-stationary schedule: LDS staging area of {stage_floats * 4} B is smaller than an input block")
+    # the staging area only needs to hold the largest phase: parts with small tiles keep the LDS small as well
     # ---- phases: first-fit decreasing packing of the blocks into the staging area
     phases: List[List[dict]] = []
     for b in sorted(blocks.values(), key=lambda b: -b["floats"]):
@@ -229,14 +309,6 @@ def is_schedule(prog: "Program") -> IsSchedule:
                 break
         else:
             phases.append([b])
-    hp4 = prog.hidden_pad // 4
-
-    def cost(rec):
-        typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
-        c = nsrc * int(rec[8]) * rtm * nc + 60                 # GEMM1 + a per-item latency allowance (in MFMA slots)
-        if typ == IT_TP:
-            c += hp4 * rtm + int(segs[int(rec[19])][2]) * int(rec[18]) * nc
-        return c
     btab, ptab, gtab, items, tot, crit = [], [], [], [], 0, 0
     for ph in phases:
         ph.sort(key=lambda b: -b["key"][0])                    # edge-row blocks (plain LDS-DMA) first: their latency runs under the
@@ -251,15 +323,19 @@ def is_schedule(prog: "Program") -> IsSchedule:
                 r = rec.copy()
                 r[1], r[2], r[3] = o0, o1, 0
                 by_seg.setdefault(int(rec[19]), []).append(r)
-        groups = sorted(((sum(cost(r) for r in recs), sg) for sg, recs in by_seg.items()), reverse=True)
+        if copy_stride:                                        # private tile copies: every item is its own work group
+            units = [[r] for recs in by_seg.values() for r in recs]
+        else:
+            units = list(by_seg.values())
+        groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
         loads = [0] * IS_WAVES
-        for c, sg in groups:                                   # claim order = LPT order
+        for c, n in groups:                                    # claim order = LPT order
             loads[loads.index(min(loads))] += c
-            gtab.append([len(items), len(items) + len(by_seg[sg])])
-            items += by_seg[sg]
+            gtab.append([item_base + len(items), item_base + len(items) + len(units[n])])
+            items += units[n]
         tot += sum(loads)
         crit += max(loads)
-        ptab.append([b0, len(btab), g0, len(gtab)])
+        ptab.append([block_base + b0, block_base + len(btab), group_base + g0, group_base + len(gtab)])
     # ---- epilogue: Wigner blocks of the un-rotated segments staged in as few batches as fit the staging area (one block per l)
     need = {}
     for sg in segs:
@@ -282,7 +358,7 @@ def is_schedule(prog: "Program") -> IsSchedule:
             woff[l], batch_of[l] = o, bi
             o += need[l]
     order = sorted(range(len(segs)), key=lambda i: (batch_of.get(int(segs[i][0]), -1) if int(segs[i][7]) & SEG_UNROTATE else -1))
-    remap = {old: new for new, old in enumerate(order)}
+    remap = {members[old]: seg_base + new for new, old in enumerate(order)}
     segs2 = segs[order].copy()
     prev = None
     for sg in segs2:
@@ -293,15 +369,16 @@ def is_schedule(prog: "Program") -> IsSchedule:
                 sg[7] |= SEG_NEWBATCH
                 prev = batch_of[l]
     items = np.asarray(items, np.int32).reshape(-1, ITEM_I32)
-    items[:, 19] = [remap[int(x)] for x in items[:, 19]]
-    wide = np.zeros((items.shape[0], IS_ITEM_I32), np.int32)   # + the segment fields an item needs (csrc/tp_is.hip:ItemRec)
+    wide = np.zeros((items.shape[0], IS_ITEM_I32), np.int32)   # + the segment fields an item needs (csrc/tp_is.hip)
     wide[:, :ITEM_I32] = items
-    for n, sg in enumerate(items[:, 19]):
-        wide[n, 20], wide[n, 21], wide[n, 22], wide[n, 23] = segs2[sg][0], segs2[sg][1], segs2[sg][2], segs2[sg][5]
-    items = wide
-    return IsSchedule(segs2.astype(np.int32), np.asarray(btab, np.int32).reshape(-1, IS_BLOCK_I32),
-                      np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
-                      trash_off, stage_off, stage_floats, ctr_off, ctr_off + 4, tot / (IS_WAVES * crit) if crit else 1.0)
+    for n in range(items.shape[0]):
+        g_abs = remap[int(items[n, 19])]
+        sg = segs2[g_abs - seg_base]
+        wide[n, 19] = g_abs
+        wide[n, 20], wide[n, 21], wide[n, 22], wide[n, 23] = sg[0], sg[1], sg[2], sg[5]
+    ctr_off = stage_off + stage_floats
+    return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off,
+                ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
 
 
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:
@@ -329,6 +406,7 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
     lay = prog.out_layout
     if lk > 6:
         raise NotImplementedError(f"output irreps with l = {lk} > 6 have no kernel epilogue instantiation")
+    assert mul_k <= seg_rows_cap(lk)
     rto = ceil_div(mul_k, 16)
     prog.segs.append([lk, mul_k, rto, lay.off[out_index], lay.mulp[out_index], 0, 0, flags])
     prog.seg_items.append([])
@@ -412,7 +490,8 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
     H = prog.hidden
     for k in order:
         mk, lk, pk = irreps_out[k]
-        assert mk <= MAX_SEG_ROWS, "tensor-product targets wider than 64 channels per irrep are not supported by the planner"
+        if mk > seg_rows_cap(lk):
+            raise NotImplementedError(f"tensor-product target {mk}x(l={lk}) is wider than the {seg_rows_cap(lk)} channels one LDS tile holds")
         seg = seg_of_k[k]
         off, fan = lin_off[k]
         L = lin_scale_w[off:off + fan * mk].reshape(fan, mk).astype(np.float64) / math.sqrt(fan)
@@ -522,6 +601,13 @@ def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarL
 MAX_SEG_ROWS = 64        # output channels per segment (bounds the LDS tile); wider irreps are split column-wise
 
 
+def seg_rows_cap(l: int) -> int:
+    """output channels of one segment of an l-irrep: the wave-private LDS tile [rows + 1][(2l+1) 16 + 4] of the segment-stationary kernel
+    has to stay below ~28 KB (4 waves x (tile + 11 KB operand ring) <= 160 KB): 64 rows up to l = 2, 48 / 32 / 32 / 32 / 16 for l = 3..7
+    (the su2 head of an f-shell basis groups > 64 multiplicity-1 outputs per high-l irrep)."""
+    return max(16, min(MAX_SEG_ROWS, ((7000 // ((2 * l + 1) * 16 + 4)) - 1) // 16 * 16))
+
+
 def new_program(irreps_out, hidden=0, flags_of=lambda k, ir: 0) -> Tuple[Program, Dict[int, int]]:
     """seg_of_k[k] = segment id of output irrep k (first chunk); prog.seg_chunks[k] = [(segment, c0, c1), ...]."""
     lay = PlanarLayout(irreps_out)
@@ -530,8 +616,9 @@ def new_program(irreps_out, hidden=0, flags_of=lambda k, ir: 0) -> Tuple[Program
     prog.seg_chunks = {}
     for k, (mk, lk, pk) in enumerate(lay.irreps):
         chunks = []
-        for c0 in range(0, mk, MAX_SEG_ROWS):
-            c1 = min(mk, c0 + MAX_SEG_ROWS)
+        cap = seg_rows_cap(lk)
+        for c0 in range(0, mk, cap):
+            c1 = min(mk, c0 + cap)
             npad = lay.mulp[k] - mk if c1 == mk else 0         # channel-padding slots the last chunk zero-fills (flags bits 8..)
             sid = _add_segment(prog, lk, c1 - c0, k, flags_of(k, (mk, lk, pk)) | (npad << 8))
             prog.segs[sid][3] += c0                            # channel offset inside the planar block
@@ -717,6 +804,10 @@ def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps, keep=N
     reads only half of its 2 x 2 x required irreps, tensor_decomposition.py:545-551)."""
     irreps_in = Irreps(irreps_in)
     keep = [True] * len(hirr) if keep is None else list(keep)
+    # an output irrep without a matching input irrep has no o3.Linear path: e3nn leaves it at zero.  Such slots (e.g. the l = 7 outputs
+    # of the su2 head of f-shell bases fed by l <= 6 features) are never computed; the merge tables treat them as zero coefficients.
+    have = {(l, p) for _, l, p in irreps_in}
+    keep = [k and ((L, p) in have) for k, (_, L, p) in zip(keep, hirr)]
     groups, slot_pos = [], []
     key_to_g = {}
     for s, (_, L, p) in enumerate(hirr):
@@ -790,11 +881,16 @@ def su2_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, 
     assert R == 4 * nao * nao
     slot_tab = np.zeros((2 * R, 4), dtype=np.int32)
     q = 0
+    dead = np.zeros(2 * R, dtype=bool)               # coefficients of outputs the Linear has no path to (identically zero)
     for copy in (0, 2):
         for s, (_, L, p) in enumerate(half):
-            g, col = slot_pos[copy * S + s]
+            pos = slot_pos[copy * S + s]
             for a in range(2 * L + 1):
-                slot_tab[q] = (L, a, glay.off[g] + col, glay.mulp[g])
+                if pos is None:
+                    slot_tab[q] = (0, 0, 0, 0)       # reads a finite value; every CSR entry pointing here is dropped below
+                    dead[q] = True
+                else:
+                    slot_tab[q] = (L, a, glay.off[pos[0]] + pos[1], glay.mulp[pos[0]])
                 q += 1
     s2 = math.sqrt(2.0)
     spin = np.array([[1, 0, 1, 0], [0, -1j, 0, 1], [0, 1j, 0, 1], [1, 0, -1, 0]], dtype=np.complex128) / s2
@@ -844,10 +940,10 @@ def su2_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, 
                 v = v * (sign[r] * sign[c])
                 re_c, im_c = (v.real, -v.imag) if plane == 0 else (v.imag, v.real)      # (A_r + i A_i)(x + i y)
                 for kk, w in zip(k, re_c):
-                    if abs(w) > 1e-14:
+                    if abs(w) > 1e-14 and not dead[kk]:
                         idx.append(kk); val.append(w)
                 for kk, w in zip(k, im_c):
-                    if abs(w) > 1e-14:
+                    if abs(w) > 1e-14 and not dead[R + kk]:
                         idx.append(R + kk); val.append(w)
                 ptr.append(len(idx))
     return slot_tab, np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(val, np.float32)
@@ -860,12 +956,16 @@ def ham_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, 
     hirr = ham_irreps(row)
     slot_tab = np.zeros((nao * nao, 4), dtype=np.int32)
     coef_off = []
+    dead = np.zeros(nao * nao, dtype=bool)           # coefficients of outputs the Linear has no path to (identically zero)
     q = 0
     for s, (_, L, p) in enumerate(hirr):
-        g, col = slot_pos[s]
+        pos = slot_pos[s]
         coef_off.append(q)
         for a in range(2 * L + 1):
-            slot_tab[q] = (L, a, glay.off[g] + col, glay.mulp[g])
+            if pos is None:
+                dead[q] = True                       # slot reads a finite value; its CSR entries are dropped below
+            else:
+                slot_tab[q] = (L, a, glay.off[pos[0]] + pos[1], glay.mulp[pos[0]])
             q += 1
     assert q == nao * nao
     entries = [[] for _ in range(nao * nao)]          # per merged (pre-reorder) element: list of (coef index, value)
@@ -879,7 +979,7 @@ def ham_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, 
                 for a in range(2 * li + 1):
                     for b in range(2 * lj + 1):
                         for M in range(2 * L + 1):
-                            if abs(cg[a, b, M]) > 1e-14:
+                            if abs(cg[a, b, M]) > 1e-14 and not dead[coef_off[s] + M]:
                                 entries[(r0 + a) * nao + (c0 + b)].append((coef_off[s] + M, cg[a, b, M]))
                 s += 1
             c0 += 2 * lj + 1

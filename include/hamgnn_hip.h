@@ -73,17 +73,26 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
  *   seg_table   int32[nseg][8]   = {lk, mul_k, rto, out_off, out_mulp, tile_off, Wigner stage_off, flags (| 1<<16: new batch)}
  *   block_table int32[nblock][8] = {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
  *   phase_table int32[nphase][4] = {block_begin, block_end, group_begin, group_end};  group_table int32[ngroup][2] = item range
- *   item_table  as for hg_tp_fused with [1], [2] = stage offsets of source 0 / 1 (-1) and [19] = segment
- * trash_off / stage_off / ctr_off: float offsets of the padding-row sink, the staging area and the claim counter inside the
- * workgroup's LDS (lds_bytes).  src_idx[i] (nullable): row gather of source i; rot_mask bit i: source i holds GLOBAL-frame
+ *   item_table  int32[nitems][24]: as for hg_tp_fused with [1], [2] = stage offsets of source 0 / 1 (-1), [19] = segment,
+ *               [20..23] = {lk, mul_k, rto, tile_off} of that segment
+ *   part_table  int32[nparts][8] = {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off, 0}: the launch runs
+ *               nparts sub-schedules (grid.y) that own disjoint sets of output segments; one part = the whole program, several
+ *               parts spread a 16-edge tile's serial pass over several workgroups when there are fewer tiles than CUs (small
+ *               crystals: BASELINE configs #1 and #5).  trash_off / stage_off / ctr_off: float offsets of the padding-row sink,
+ *               the staging area and the claim counter inside the workgroup's LDS (lds_bytes = the largest part's need);
+ *               [7] = copy_stride > 0: every wave accumulates into a private copy of the part's tiles.  part_table_host: the
+ *               same table in HOST memory (one of the tiny host arrays; validated, and a single part's scalars travel as
+ *               kernel arguments).
+ * src_idx[i] (nullable): row gather of source i; rot_mask bit i: source i holds GLOBAL-frame
  * node rows that are gathered and rotated by D^l(R_e) while staged -- the node_features[sender/receiver] gathers of
  * convolution.py:138-141 / interaction_blocks.py:141-145 fused into the operand staging (no hg_rotate_gather pass, no per-edge
  * copies of the node rows).                                                                                                */
 int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
              int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
-             int nseg, const int32_t* block_table, const int32_t* phase_table, int nphase, const int32_t* group_table,
-             const int32_t* item_table, int trash_off, int stage_off, int ctr_off, int lds_bytes,
-             const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream);
+             const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table, const int32_t* item_table,
+             const int32_t* part_table, const int32_t* part_table_host, int nparts, int lds_bytes, const int64_t* const* src_idx,
+             int rot_mask, float* out,
+             int64_t out_stride, int64_t rows, void* stream);
 
 /* torch_scatter.scatter(messages, receiver, dim_size=N) of ConvBlockE3.forward (hamgnn/nn/convolution.py:147-149) as a
  * deterministic segmented reduction: out[n] = sum_{q in [rowptr[n], rowptr[n+1])} msg[perm[q]].                     */

@@ -487,6 +487,39 @@ def main():
             _save("head_soc_su2_abacus_13", weights=sd, graph={k: Gu[k] for k in keys}, inputs=dict(node_attr=node_attr, edge_attr=edge_attr),
                   outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"], hamiltonian_imag=out_ref["hamiltonian_imag"]))
 
+    # ---- 6b. SOC su2 with an f-shell basis (abacus nao 27: L up to 6, L x 1 up to 7) on features up to l = 6 -------
+    gen27 = torch.Generator().manual_seed(27)                    # own stream: the later fixtures keep their bytes
+    rich = "4x0e+4x0o+2x1o+2x1e+2x2e+2x2o+2x3o+2x3e+1x4e+1x4o+1x5o+1x5e+1x6e+1x6o"
+    Dr = e3.Irreps(rich).dim
+    f32 = lambda t: t.float().to(t.dtype)                         # values exactly representable in fp32 (the fixture stores fp32)
+    na27, ea27 = f32(torch.randn(N, Dr, generator=gen27)), f32(torch.randn(E, Dr, generator=gen27))
+    nao = 27
+    Gu = Graph(G)
+    Gu.z = torch.tensor((26, 8, 41))
+    for k, n in (("Hon0", N), ("Hoff0", E), ("iHon0", N), ("iHoff0", E), ("Hon", N), ("Hoff", E), ("iHon", N), ("iHoff", E)):
+        Gu[k] = f32(0.1 * torch.randn(n, 4 * nao * nao, generator=gen27))
+    Gu["Son"], Gu["Soff"] = torch.randn(N, nao * nao, generator=gen27), torch.randn(E, nao * nao, generator=gen27)
+    torch.manual_seed(15)
+    ref = ref_out.HamGNNPlusPlusOut(irreps_in_node=rich, irreps_in_edge=rich, nao_max=nao, ham_type="abacus", ham_only=True, symmetrize=True,
+                                    add_H0=True, soc_switch=True, soc_basis="su2", calculate_band_energy=False, calculate_sparsity=False)
+    with torch.no_grad():
+        for prm in ref.parameters():
+            prm.copy_(f32(prm))
+    mine = R.HamGNNPlusPlusOut(rich, rich, nao_max=nao, ham_type="abacus", symmetrize=True, add_H0=True, soc_switch=True, soc_basis="su2")
+    sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("cg_calculator")}
+    res = mine.load_state_dict(sd, strict=False)
+    assert not res.missing_keys, res.missing_keys
+    gin = Graph({k: (v.clone() if torch.is_tensor(v) else v) for k, v in Gu.items()})
+    out_ref = ref(gin, {"node_attr": na27, "edge_attr": ea27})
+    out_mine = mine(Gu, {"node_attr": na27, "edge_attr": ea27})
+    _check(out_mine["hamiltonian_real"], out_ref["hamiltonian_real"], "head SOC su2 abacus nao=27 (f shells) real")
+    _check(out_mine["hamiltonian_imag"], out_ref["hamiltonian_imag"], "head SOC su2 abacus nao=27 (f shells) imag")
+    keys = ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0", "iHon0", "iHoff0")
+    sd32 = {k: v.float() for k, v in sd.items()}                 # fp32 storage keeps the fixture small; the comparison bar is 1e-5
+    _save("head_soc_su2_abacus_27", weights=sd32, graph={k: (Gu[k].float() if Gu[k].is_floating_point() else Gu[k]) for k in keys},
+          inputs=dict(node_attr=na27.float(), edge_attr=ea27.float()), meta=dict(irreps=rich),
+          outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"].float(), hamiltonian_imag=out_ref["hamiltonian_imag"].float()))
+
     # ---- 7. CorrProductBlock (optional MACE-style correlation product; interaction_blocks.py:168-260) ---------------
     print("CorrProductBlock")
     from oracle import mace_ref as M

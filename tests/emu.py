@@ -138,9 +138,11 @@ def _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype):
     if flags & P.SEG_UNROTATE:
         Dl = D[cols, woffs[lk]:woffs[lk] + nco * nco].reshape(ne, nco, nco)
         t = np.einsum("ema,wme->wae", Dl, t)                                              # out[a] = sum_m D[m][a] t[m]
-    blk = np.zeros((ne, nco, out_mulp), dtype=dtype)
-    blk[:, :, :mul_k] = t.transpose(2, 1, 0)
-    out[cols, out_off:out_off + nco * out_mulp] = blk.reshape(ne, -1)
+    npad = (flags >> 8) & 0xff                                 # channel-padding slots the (last) chunk of a planar block zero-fills
+    for a in range(nco):                                       # like the kernel epilogue: out[a * mulp + w], w < mul_k of THIS chunk
+        o = out_off + a * out_mulp
+        out[np.ix_(cols, np.arange(o, o + mul_k))] = t[:, a, :].T
+        out[np.ix_(cols, np.arange(o + mul_k, o + mul_k + npad))] = 0
 
 
 def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
@@ -162,8 +164,10 @@ def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64
 
 
 def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
-    """the input-stationary schedule (plan.is_schedule, csrc/tp_is.hip): phases -> work groups -> items, all segment tiles live at
-    once; items address their sources through the phase's staged blocks."""
+    """the input-stationary schedule (plan.is_schedule, csrc/tp_is.hip): parts -> phases -> work groups -> items; all segment tiles of a
+    part live at once; items address their sources through the phase's staged blocks.  Checks the schedule invariants on the way:
+    every item exactly once, staged blocks inside the part's staging area, and -- unless the part keeps a private tile copy per wave --
+    one owner group per (phase, segment)."""
     E = srcs[0].shape[0]
     Wt = prog.weights.astype(dtype)
     out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
@@ -172,35 +176,45 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
         ne = min(16, E - e0)
         cols = np.arange(e0, e0 + ne)
         tiles = [np.zeros((int(s[2]) * 16, 2 * int(s[0]) + 1, 16), dtype=dtype) for s in sched.seg_table]
-        seen = set()
-        for b0, b1, g0, g1 in sched.phase_table:
-            staged = {}
-            used = 0
-            for blk in sched.block_table[b0:b1]:
-                s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in blk)
-                size = -(-((2 * li + 1) * (in_mulp // 4)) // 4) * 256
-                assert o0 == used and (o1 == o0 + size if nsrc == 2 else o1 == -1)
-                used += nsrc * size
-                staged[o0] = (s0, s1, in_off, in_mulp, li)
-            assert used <= sched.stage_floats
-            owner = set()
-            for gi in range(g0, g1):
-                ib, ie = (int(v) for v in sched.group_table[gi])
-                sgs = set()
-                for ii in range(ib, ie):
-                    it = sched.item_table[ii].copy()
-                    s0, s1, in_off, in_mulp, li = staged[int(it[1])]
-                    assert (int(it[4]), int(it[5])) == (in_mulp, li) and ((int(it[2]) >= 0) == (s1 >= 0))
-                    it[1], it[2], it[3] = s0, s1, in_off
-                    assert ii not in seen
-                    seen.add(ii)
-                    sg = int(it[19])
-                    sgs.add(sg)
-                    seg = sched.seg_table[sg]
-                    tiles[sg] = _apply_item(prog, Wt, it, srcs, h2, cols, ne, tiles[sg], int(seg[0]), int(seg[2]), dtype)
-                assert len(sgs) == 1 and not (sgs & owner), "a tile must belong to exactly one work group per phase"
-                owner |= sgs
-        assert len(seen) == sched.item_table.shape[0]
+        seen, seg_seen = set(), set()
+        for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride in (tuple(int(v) for v in p) for p in sched.part_table):
+            stage_floats = ctr_off - stage_off
+            part_segs = set(range(sg0, sg0 + nsg))
+            assert not (part_segs & seg_seen)
+            seg_seen |= part_segs
+            tile_floats = sum(int(sched.seg_table[g][1]) * ((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4) for g in part_segs)
+            assert copy_stride in (0, tile_floats) and trash_off == (4 if copy_stride else 1) * tile_floats and (ctr_off + 4) * 4 <= P.IS_LDS_BYTES
+            for b0, b1, g0, g1 in sched.phase_table[ph0:ph0 + nph]:
+                staged = {}
+                used = 0
+                for blk in sched.block_table[b0:b1]:
+                    s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in blk)
+                    size = -(-((2 * li + 1) * (in_mulp // 4)) // 4) * 256
+                    assert o0 == used and (o1 == o0 + size if nsrc == 2 else o1 == -1)
+                    used += nsrc * size
+                    staged[o0] = (s0, s1, in_off, in_mulp, li)
+                assert used <= stage_floats
+                owner = set()
+                for gi in range(g0, g1):
+                    ib, ie = (int(v) for v in sched.group_table[gi])
+                    sgs = set()
+                    for ii in range(ib, ie):
+                        it = sched.item_table[ii].copy()
+                        s0, s1, in_off, in_mulp, li = staged[int(it[1])]
+                        assert (int(it[4]), int(it[5])) == (in_mulp, li) and ((int(it[2]) >= 0) == (s1 >= 0))
+                        it[1], it[2], it[3] = s0, s1, in_off
+                        assert ii not in seen
+                        seen.add(ii)
+                        sg = int(it[19])
+                        assert sg in part_segs
+                        sgs.add(sg)
+                        seg = sched.seg_table[sg]
+                        assert tuple(int(v) for v in it[20:24]) == (int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5]))
+                        tiles[sg] = _apply_item(prog, Wt, it[:P.ITEM_I32], srcs, h2, cols, ne, tiles[sg], int(seg[0]), int(seg[2]), dtype)
+                    if not copy_stride:
+                        assert len(sgs) == 1 and not (sgs & owner), "a shared tile must belong to exactly one work group per phase"
+                    owner |= sgs
+        assert len(seen) == sched.item_table.shape[0] and len(seg_seen) == sched.seg_table.shape[0]
         for sg, seg in enumerate(sched.seg_table):
             _write_segment(prog, seg, tiles[sg], out, cols, ne, D, woffs, dtype)
     return out

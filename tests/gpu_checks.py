@@ -303,6 +303,19 @@ def check_head_su2(device="cuda"):
     torch.cuda.synchronize()
     res = {"su2_real_rel_err": rel(out["hamiltonian_real"], f["outputs"]["hamiltonian_real"]),
            "su2_imag_rel_err": rel(out["hamiltonian_imag"], f["outputs"]["hamiltonian_imag"])}
+    # f-shell basis (abacus nao 27): L x 1 couplings up to l = 7 (structural zeros for l <= 6 features), reference fixture
+    f27 = load("head_soc_su2_abacus_27")
+    irr27 = str(f27["meta"]["irreps"])
+    m27 = load_weights(HamGNNPlusPlusOut(irr27, irr27, nao_max=27, ham_type="abacus", ham_only=True, symmetrize=True, add_H0=True,
+                                         soc_switch=True, calculate_sparsity=False), f27["weights"])
+    gd27 = dict(f27["graph"])
+    for k in ("pos", "nbr_shift", "cell"):
+        gd27[k] = bb[k]
+    o27 = m27(to_graph(gd27, device), {"node_attr": torch.from_numpy(f27["inputs"]["node_attr"]).float().to(device),
+                                       "edge_attr": torch.from_numpy(f27["inputs"]["edge_attr"]).float().to(device)})
+    torch.cuda.synchronize()
+    res.update({"su2_nao27_real_rel_err": rel(o27["hamiltonian_real"], f27["outputs"]["hamiltonian_real"]),
+                "su2_nao27_imag_rel_err": rel(o27["hamiltonian_imag"], f27["outputs"]["hamiltonian_imag"])})
     rich = "8x0e+8x0o+4x1e+4x1o+4x2e+4x2o+2x3e+2x3o+2x4e+2x4o+2x5e+2x5o"
     torch.manual_seed(5)
     prev = torch.get_default_dtype()

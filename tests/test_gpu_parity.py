@@ -121,6 +121,25 @@ def test_sharded_two_rank_forward_matches_single_rank(workload, irreps):
     assert r["rel_err"] < 1e-5, r
 
 
+def test_bench_script_two_rank_path_on_one_gpu():
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), on a 1-GPU box: both ranks
+    share cuda:0 and talk over gloo (HG_BENCH_SAME_DEVICE / HG_BENCH_BACKEND test hooks; RCCL refuses two ranks on one device).
+    Checks the sharded N > 1 code path of the benchmark itself: one JSON line from rank 0, whole-job edge count, n_gpus."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HG_BENCH_SAME_DEVICE="1", HG_BENCH_BACKEND="gloo")
+    cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                         "--workload", "si512", "--irreps", "B"], capture_output=True, text=True, timeout=600, env=env)
+    assert cp.returncode == 0, cp.stdout[-1500:] + cp.stderr[-1500:]
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, cp.stdout[-1500:]
+    r = json.loads(lines[0])
+    print({k: r[k] for k in ("value", "n_gpus", "ms_per_step", "scaling")})
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0 and r["scaling"] == "strong" and "cpu_baseline" not in r
+    assert "pair-sharded" in r["config"]["parallelism"]
+
+
 def test_multi_crystal_batch_vs_oracle():
     r = G.oracle_vs_hip_random(n_graphs=3, seed=5)
     print(r)

@@ -4,6 +4,7 @@ import sys
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from hamgnn_amd.data import Graph, collate
@@ -50,3 +51,34 @@ def test_collate_offsets():
     assert torch.equal(b.edge_index[:, g1.num_edges:], g2.edge_index + 2)
     assert torch.equal(b.inv_edge_idx[g1.num_edges:], g2.inv_edge_idx)          # graph-local, as the reference expects
     assert b.node_counts.tolist() == [2, 4] and b.batch.tolist() == [0, 0, 1, 1, 1, 1]
+
+
+def test_lmdb_store_roundtrip_without_the_lmdb_module(tmp_path):
+    """npz -> LMDB (bulk writer) -> LMDBGraphDataset (pure-python B+tree reader): inline values, overflow runs (graphs are far larger than
+    a page), several leaf pages and a branch level (200 extra keys), the reference's key scheme and dataset behaviour."""
+    from hamgnn_amd.data import lmdb_lite as L
+    gs = [S.add_random_targets(S.si_diamond(primitive=True), 19), S.add_random_targets(S.random_cell(5, [14, 8], seed=1, density=0.004), 19)]
+    npz = str(tmp_path / "graph_data.npz")
+    GD.save_graph_npz(gs, npz)
+    db = GD.npz_to_lmdb(npz, str(tmp_path / "store"))
+    ds = GD.LMDBGraphDataset(db, preload=1)
+    assert len(ds) == 2 and ds.total_length == 2
+    for a, b in zip([ds[0], ds[1]], gs):
+        for k in ("z", "pos", "edge_index", "nbr_shift", "inv_edge_idx", "Hon0", "Hoff0"):
+            assert torch.equal(a[k], b[k])
+    assert len(GD.LMDBGraphDataset(db, indices=[1])) == 1
+    with pytest.raises(IndexError):
+        ds._load(7)
+    ds.close()
+    # a deeper tree: many small keys + a few big values
+    rng = np.random.default_rng(0)
+    items = {f"k{i:05d}".encode(): bytes(rng.integers(0, 256, size=int(rng.integers(1, 300)), dtype=np.uint8)) for i in range(12000)}
+    items[b"big"] = bytes(rng.integers(0, 256, size=70000, dtype=np.uint8))
+    items[b""] = b"empty key"
+    L.write_lmdb(str(tmp_path / "deep"), items)
+    with L.LMDBReader(str(tmp_path / "deep")) as r:
+        assert len(r) == len(items) and r.depth >= 3
+        for k, v in items.items():
+            assert r.get(k) == v, k
+        assert r.get(b"k99999") is None and r.get(b"a") is None and r.get(b"zzz") is None
+        assert [k for k, _ in r.items()] == sorted(items)

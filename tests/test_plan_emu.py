@@ -150,12 +150,17 @@ def test_head_linear_and_merge_tables(ham_type, nao):
     assert rel(got, want.detach().numpy()) < 1e-6
 
 
-def test_head_su2_tables():
-    """su2: only copies 0/2 of the 4 x required irreps are computed; merge table == get_H + reorder + spin interleave."""
+RICH6 = "4x0e+4x0o+2x1o+2x1e+2x2e+2x2o+2x3o+2x3e+1x4e+1x4o+1x5o+1x5e+1x6e+1x6o"
+
+
+@pytest.mark.parametrize("nao,ham_type,MINI", [(13, "abacus", MINI), (27, "abacus", RICH6), (27, "abacus", MINI)])
+def test_head_su2_tables(nao, ham_type, MINI):
+    """su2: only copies 0/2 of the 4 x required irreps are computed; merge table == get_H + reorder + spin interleave.
+    nao 27 (s s s s p p d d f): the L x 1 couplings reach l = 7, for which l <= 6 features have no o3.Linear path -- those outputs
+    are structural zeros that the planner drops (also every l >= 4 output when the features stop at l = 3)."""
     import torch
     from oracle import hamgnn_ref as R
     from hamgnn_amd import basis as B
-    nao, ham_type = 13, "abacus"
     torch.manual_seed(1)
     ref = R.HamGNNPlusPlusOut(MINI, MINI, nao_max=nao, ham_type=ham_type, soc_switch=True).double()
     t = B.basis_table(ham_type, nao)
@@ -199,6 +204,10 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     outp = emu.run_program_is(prog, sched, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(lay.from_planar(outp), f["outputs"]["out"]) < 1e-6
     assert rel(outp, emu.run_program(prog, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
+    for parts in (2, 3, 7):                                   # split launches for small crystals: disjoint segment sets, private tile copies
+        sp = P.is_schedule(prog, parts)
+        assert sp.part_table.shape[0] == parts and all(int(p[7]) > 0 for p in sp.part_table)
+        assert rel(emu.run_program_is(prog, sp, [xs, xd, fe], (hn, he), D, lmax), outp) < 1e-12
     # with the PairInteractionBlock skip o3.Linear folded in (extra linear items in the edge-row phases)
     prog2 = P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=False, skip_weight=skip)
     s2 = P.is_schedule(prog2)
@@ -220,6 +229,10 @@ def test_input_stationary_schedule_shipped_irreps(which):
     prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, bench.SH, irr, True, skip)
     sc = P.is_schedule(prog)
     assert sc.lds_floats * 4 <= P.IS_LDS_BYTES and sc.item_table.shape == (prog.item_table.shape[0], P.IS_ITEM_I32)
+    for parts in (8, 13):                                     # split launches: every part fits, worst part well below the whole program
+        sp = P.is_schedule(prog, parts)
+        assert sp.lds_floats * 4 <= P.IS_LDS_BYTES and len(sp.part_cost) == min(parts, sc.seg_table.shape[0])
+        assert max(sp.part_cost) < 0.3 * sc.part_cost[0] and all(int(p[7]) > 0 for p in sp.part_table)
     seen = np.zeros(sc.item_table.shape[0], dtype=int)
     for b0, b1, g0, g1 in sc.phase_table:
         used, offs = 0, set()
