@@ -378,14 +378,26 @@ extern "C" int hg_rotate_gather(const float* x0, const float* x1, int64_t x_stri
 }
 
 // ------------------------------------------------------------------------------------------------ segmented node scatter
+// Wavefront segmented reduce over the receiver CSR: one block per node; a lane owns one 16-byte column of the row, so a wavefront reads
+// 1 KiB of each incoming message row with one coalesced float4 load; the edge list is walked four edges at a time (four independent
+// index loads, then four row loads in flight) and summed in list order -- fixed order, hence bit-reproducible, unlike the atomics of
+// torch_scatter.scatter (hamgnn/nn/convolution.py:147-149).
+typedef float ss_f4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restrict__ msg, int64_t ms, const int64_t* __restrict__ rowptr,
                                                           const int64_t* __restrict__ perm, int Dp, float* __restrict__ out, int64_t os) {
     const int64_t n = blockIdx.x;
     const int64_t q0 = rowptr[n], q1 = rowptr[n + 1];
-    for (int p = threadIdx.x; p < Dp; p += blockDim.x) {
-        float acc = 0.f;
-        for (int64_t q = q0; q < q1; ++q) acc += msg[perm[q] * ms + p];
-        out[n * os + p] = acc;
+    for (int p = 4 * threadIdx.x; p < Dp; p += 4 * blockDim.x) {
+        ss_f4 acc = (ss_f4){0.f, 0.f, 0.f, 0.f};
+        int64_t q = q0;
+        for (; q + 4 <= q1; q += 4) {
+            const int64_t e0 = perm[q], e1 = perm[q + 1], e2 = perm[q + 2], e3 = perm[q + 3];
+            const ss_f4 v0 = *reinterpret_cast<const ss_f4*>(msg + e0 * ms + p), v1 = *reinterpret_cast<const ss_f4*>(msg + e1 * ms + p);
+            const ss_f4 v2 = *reinterpret_cast<const ss_f4*>(msg + e2 * ms + p), v3 = *reinterpret_cast<const ss_f4*>(msg + e3 * ms + p);
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; q < q1; ++q) acc += *reinterpret_cast<const ss_f4*>(msg + perm[q] * ms + p);
+        *reinterpret_cast<ss_f4*>(out + n * os + p) = acc;
     }
 }
 
@@ -393,6 +405,8 @@ extern "C" int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_
                               float* out, int64_t out_stride, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (N <= 0) return 0;
+    if ((Dp & 3) || (msg_stride & 3) || (out_stride & 3) || ((reinterpret_cast<uintptr_t>(msg) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return hg_fail(-2, "hg_segment_sum: rows must be multiples of 4 floats and 16-byte aligned (planar rows are)");
     segment_sum_kernel<<<dim3((unsigned)N), 256, 0, (hipStream_t)stream>>>(msg, msg_stride, rowptr, perm, Dp, out, out_stride);
     return hg_check_launch("hg_segment_sum");
 }

@@ -555,7 +555,10 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
     const unsigned long long t_begin = prof.last;
 #endif
 
-    for (int sg = 0; sg < A.nseg; ++sg) {
+    // segments are independent (each owns its tile and items): launches with few row tiles put one segment per workgroup (grid.y) so
+    // that a 2-atom crystal's Linear is not one workgroup walking every segment serially
+    const int sg_begin = gridDim.y > 1 ? blockIdx.y : 0, sg_end = gridDim.y > 1 ? blockIdx.y + 1 : A.nseg;
+    for (int sg = sg_begin; sg < sg_end; ++sg) {
         const int* __restrict__ S = g_segs + sg * 8;
         const int lk = S[0], mul_k = S[1], rto = S[2], out_off = S[3], out_mulp = S[4], ib = S[5], ie = S[6], flags = S[7];
         const int nco = 2 * lk + 1;
@@ -659,9 +662,10 @@ extern "C" int hg_tp_fused(const float* const* src, const int64_t* src_stride, i
     if (int rc = hg_lds_attr_once(lds_attr_done[0], dev_guard.dev, (const void*)tp_fused_kernel<true>, 160 * 1024)) return rc;
     if (int rc = hg_lds_attr_once(lds_attr_done[1], dev_guard.dev, (const void*)tp_fused_kernel<false>, 160 * 1024)) return rc;
     const unsigned grid = (unsigned)((rows + 63) / 64);
+    const unsigned gy = ((int64_t)grid * nseg <= 1024 && nseg > 1) ? (unsigned)nseg : 1u;      // few row tiles: one segment per workgroup
     if (program_flags & 1)
-        hipLaunchKernelGGL(tp_fused_kernel<true>, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
+        hipLaunchKernelGGL(tp_fused_kernel<true>, dim3(grid, gy), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
     else
-        hipLaunchKernelGGL(tp_fused_kernel<false>, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
+        hipLaunchKernelGGL(tp_fused_kernel<false>, dim3(grid, gy), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, item_table, weights);
     return hg_check_launch("hg_tp_fused");
 }

@@ -648,3 +648,49 @@ def check_uni_chain_full_size(device="cuda", n_graphs=8):
         res["atoms"] += N
     torch.cuda.synchronize()
     return res
+
+
+def check_captured_forward_si2(device="cuda"):
+    """HIP-graph replay of the whole Si2 forward (set-A, split edge-kernel launches): same numbers as the eager forward, also after the
+    positions were rewritten in place; returns eager / replay milliseconds per forward"""
+    import time
+    import bench
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.graph_capture import CapturedForward
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    irreps = bench.IRREPS["A"]
+    torch.manual_seed(666)
+    model = HamGNNConvE3(bench.make_cfg(irreps))
+    head = HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=False,
+                             calculate_sparsity=False)
+    g = S.add_random_targets(S.si_diamond(primitive=True), 19, seed=0).to(device)
+    with torch.no_grad():
+        ref = head(g, model(g))["hamiltonian"].clone()
+    fwd = CapturedForward(lambda: head(g, model(g)))
+    out = fwd()["hamiltonian"]
+    torch.cuda.synchronize()
+    res = {"replay_vs_eager": rel(out, ref)}
+    # new coordinates of the same graph, written in place: replay == eager on the moved crystal
+    shift = torch.tensor([[0.0, 0.0, 0.0], [0.11, -0.07, 0.05]], device=device)
+    g.pos.add_(shift)
+    with torch.no_grad():
+        ref2 = head(g, model(g))["hamiltonian"].clone()
+    out2 = fwd()["hamiltonian"]
+    torch.cuda.synchronize()
+    res["replay_vs_eager_moved"] = rel(out2, ref2)
+    res["moved_changes_H"] = rel(ref2, ref)
+
+    def timeit(f, n=50):
+        for _ in range(5):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+    with torch.no_grad():
+        res["eager_ms"] = timeit(lambda: head(g, model(g)))
+    res["replay_ms"] = timeit(fwd)
+    return res

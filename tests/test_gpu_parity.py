@@ -162,6 +162,15 @@ def test_si2_default_irreps_vs_oracle(which):
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL and r["Hnet_rel_err"] < G.TOL
 
 
+def test_captured_forward_replay_si2():
+    """BASELINE config #1 as a HIP graph: replay == eager (also after an in-place position update), and faster than eager launches"""
+    r = G.check_captured_forward_si2()
+    print(r)
+    # (split launches accumulate a segment's items in claim order: run-to-run differences at fp32 rounding level)
+    assert r["replay_vs_eager"] < 5e-6 and r["replay_vs_eager_moved"] < 5e-6 and r["moved_changes_H"] > 1e-4
+    assert r["replay_ms"] < 1.1 * r["eager_ms"] and r["replay_ms"] < 2.0     # r1: 4.4-4.8 ms per forward, eager or replayed
+
+
 def test_backbone_lite_mode_golden():
     """lite_mode (uvu products + plain Linears + one combined radial scale, message_passing.py:197-215) incl. the lite embedding."""
     r = G.check_backbone(name="backbone_lite")
