@@ -498,39 +498,36 @@ __device__ __forceinline__ void epilogue(const TpArgs& A, const float* __restric
                 if (valid) ob[a * out_mulp + w] = w < mul_k ? acc : 0.f;
             }
         }
-    } else if (A.res[0]) {
-        // ResidualBlock tail x + Lin2(Gate(Lin1 x)) [+ skip] (hamgnn/nn/interaction_blocks.py:352-357, convolution.py:158): the adds ride on
-        // the producing launch instead of a separate pass over all rows.  WU channels per lane and step: WU x NCO residual loads in
-        // flight before the first add (one load per step left the epilogue waiting on L2/HBM once per channel)
-        const float* __restrict__ r0 = A.res[0] + erow * A.rstride[0] + out_off;
-        const float* __restrict__ r1 = A.res[1] ? A.res[1] + erow * A.rstride[1] + out_off : nullptr;
-        constexpr int WU = NCO <= 3 ? 4 : 2;
-#pragma unroll 1
-        for (int w0 = g; w0 < wend; w0 += 4 * WU) {
-            float v[WU][NCO];
-#pragma unroll
-            for (int j = 0; j < WU; ++j) {
-                const int w = w0 + 4 * j;
-                const int wr = w < mul_k ? w : 0;               // padding slots: any readable address, value dropped below
-#pragma unroll
-                for (int a = 0; a < NCO; ++a) v[j][a] = r0[a * out_mulp + wr] + (r1 ? r1[a * out_mulp + wr] : 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < WU; ++j) {
-                const int w = w0 + 4 * j;
-                if (w < wend) {
-#pragma unroll
-                    for (int a = 0; a < NCO; ++a)
-                        if (valid) ob[a * out_mulp + w] = w < mul_k ? v[j][a] + tl[w * rowstride + a * 16] : 0.f;
-                }
-            }
-        }
     } else {
+        // Planar store (+ optional residual rows: the x + Lin2(Gate(Lin1 x)) [+ skip] adds of ResidualBlock / ConvBlockE3,
+        // hamgnn/nn/interaction_blocks.py:352-357, convolution.py:158, ride on the producing launch).  A lane owns FOUR consecutive
+        // channels of one (row, component): the four lane groups of a row write 64 contiguous bytes per store instruction (whole
+        // sectors; the r1 epilogue wrote 4 scattered dwords per row and instruction and ran the E-row Linears at 1.3 TB/s), and the
+        // residual rows are read the same way.
+        const float* __restrict__ r0 = A.res[0] ? A.res[0] + erow * A.rstride[0] + out_off : nullptr;
+        const float* __restrict__ r1 = A.res[1] ? A.res[1] + erow * A.rstride[1] + out_off : nullptr;
 #pragma unroll 1
-        for (int w = g; w < wend; w += 4) {
+        for (int w0 = 4 * g; w0 < wend; w0 += 16) {            // wend and out_mulp are multiples of 4 except for the last chunk of a split irrep
+            if (w0 + 4 <= wend) {
 #pragma unroll
-            for (int a = 0; a < NCO; ++a)
-                if (valid) ob[a * out_mulp + w] = w < mul_k ? tl[w * rowstride + a * 16] : 0.f;
+                for (int a = 0; a < NCO; ++a) {
+                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (r0) v = *reinterpret_cast<const f32x4*>(r0 + a * out_mulp + w0);
+                    if (r1) v += *reinterpret_cast<const f32x4*>(r1 + a * out_mulp + w0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (w0 + j < mul_k) ? v[j] + tl[(w0 + j) * rowstride + a * 16] : 0.f;
+                    if (valid) *reinterpret_cast<f32x4*>(ob + a * out_mulp + w0) = v;
+                }
+            } else {                                           // ragged tail (segment chunks of a split irrep that are not multiples of 4)
+#pragma unroll 1
+                for (int w = w0; w < wend; ++w)
+#pragma unroll
+                    for (int a = 0; a < NCO; ++a) {
+                        float v = 0.f;
+                        if (w < mul_k) v = tl[w * rowstride + a * 16] + (r0 ? r0[a * out_mulp + w] : 0.f) + (r1 ? r1[a * out_mulp + w] : 0.f);
+                        if (valid) ob[a * out_mulp + w] = v;
+                    }
+            }
         }
     }
 }

@@ -366,6 +366,9 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
     }
 }
 
+#ifndef HG_STAGE_U
+#define HG_STAGE_U(L) 1          // measured (profiles/r02_tp_is_experiments.md): 2-4 pieces in flight per step are SLOWER (8.39 vs 8.13 ms)
+#endif
 // Stage one input block (all its sources) of the workgroup's 16 edges: image offset(piece p = a * P1 + s, row e) = 64 p + 4 e per source.
 //   plain source  : rows are already in the edge frame -> LDS-DMA, the four waves share the DMA instructions;
 //   rotated source: rows are node features in the global frame, gathered by idx[] and multiplied by D^l(R_e) on the way in
@@ -392,25 +395,40 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
         const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
         float* __restrict__ d0 = stage + P[6] + el * 4;
         float* __restrict__ d1 = stage + P[7] + el * 4;
+        // U output pieces per step (register budget by l): the node rows come from the Infinity Cache / HBM (35 MB of node rows do not
+        // fit an XCD's L2), so every step of this loop exposes ~1 us of latency -- with 2 N float4 + N scalar loads of U pieces in flight
+        // instead of one piece's
+        constexpr int U = HG_STAGE_U(L);
 #pragma unroll 1
-        for (int t = 4 * wave + g; t < Pfull; t += 16) {
-            const int a = t / P1, p = t - a * P1;
-            f32x4 v0[N], v1[N];
-            float d[N];
+        for (int t0 = 4 * wave + g; t0 < Pfull; t0 += 16 * U) {
+            f32x4 v0[U][N], v1[U][N];
+            float d[U][N];
 #pragma unroll
-            for (int b = 0; b < N; ++b) {
-                v0[b] = *reinterpret_cast<const f32x4*>(row0 + b * in_mulp + 4 * p);
-                v1[b] = *reinterpret_cast<const f32x4*>(row1 + b * in_mulp + 4 * p);
-                d[b] = D[a * N + b];
-            }
-            f32x4 acc0 = d[0] * v0[0], acc1 = d[0] * v1[0];
+            for (int u = 0; u < U; ++u) {
+                int t = t0 + 16 * u;
+                t = t < Pfull ? t : t0;                        // tail: re-read the first piece (result dropped below)
+                const int a = t / P1, p = t - a * P1;
 #pragma unroll
-            for (int b = 1; b < N; ++b) {
-                acc0 += d[b] * v0[b];
-                acc1 += d[b] * v1[b];
+                for (int b = 0; b < N; ++b) {
+                    v0[u][b] = *reinterpret_cast<const f32x4*>(row0 + b * in_mulp + 4 * p);
+                    v1[u][b] = *reinterpret_cast<const f32x4*>(row1 + b * in_mulp + 4 * p);
+                    d[u][b] = D[a * N + b];
+                }
             }
-            *reinterpret_cast<f32x4*>(d0 + t * 64) = acc0;
-            *reinterpret_cast<f32x4*>(d1 + t * 64) = acc1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + 16 * u;
+                if (t < Pfull) {
+                    f32x4 acc0 = d[u][0] * v0[u][0], acc1 = d[u][0] * v1[u][0];
+#pragma unroll
+                    for (int b = 1; b < N; ++b) {
+                        acc0 += d[u][b] * v0[u][b];
+                        acc1 += d[u][b] * v1[u][b];
+                    }
+                    *reinterpret_cast<f32x4*>(d0 + t * 64) = acc0;
+                    *reinterpret_cast<f32x4*>(d1 + t * 64) = acc1;
+                }
+            }
         }
         return;
     }
@@ -501,6 +519,9 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const in
     for (int ph = ph0; ph < ph1; ++ph) {
         const int* __restrict__ P = g_phases + ph * 4;
         const int b0 = P[0], b1 = P[1], g0 = P[2], g1 = P[3];
+#ifdef HG_IS_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();                                       // every wave is done with the previous blocks (and the zero fill)
         IS_T(5);                                               // waiting for the slowest wave of the previous phase
         if (threadIdx.x == 0) *ctr = g0;
@@ -521,6 +542,9 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const in
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         IS_T(6);                                               // staging the phase's input blocks
+#ifdef HG_IS_PRIO
+        __builtin_amdgcn_s_setprio(HG_IS_PRIO);                // MFMA phases of this workgroup win issue arbitration over the other's staging
+#endif
         // work groups = all items of one (phase, output segment), claimed largest-first: dynamic balance, and a tile is only ever
         // updated by one wave between two barriers
         while (true) {
