@@ -36,7 +36,7 @@ REF_BYTES_PER_EDGE_BLOCK = {"A": 14432.0, "B": 7888.0}
 # (separate --pmc FETCH_SIZE / WRITE_SIZE runs on tests/bench_tp.py, 131072 edges; FETCH_SIZE x 2: gfx950 correction for
 # 16-B/lane reads, MI355X_MICROARCH.md "HBM"): measured offline for this kernel build, scaled to the launch's edge count.
 # kernel "is" = input-stationary tp_is_kernel (profiles/r02_tp_is_hbm_pmc.md), "seg" = segment-stationary tp_fused_kernel
-PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 33.6e3, ("is", "B"): 13.1e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
+PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 34.8e3, ("is", "B"): 14.3e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
 

@@ -18,6 +18,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef IS_NW
+#define IS_NW 4                  // waves of a workgroup (all on the same 16 edges); plan.py:IS_WAVES.  6 = three waves per SIMD (experiment)
+#endif
+#define IS_NT (64 * IS_NW)
+
 struct IsArgs {
     const float* src[4];
     int64_t sstride[4];
@@ -336,7 +341,7 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
     // back-to-back stores, so the memory side sees whole sectors (interleaving the channels of one component over the waves
     // tripled the HBM write traffic: WRITE_SIZE 1.39 GB vs 0.46 GB of output per 131 072 edges)
     const int nw16 = (wend + 15) >> 4;
-    const int U = NCO * nw16, per = (U + 3) >> 2;              // each wave takes a contiguous range of units (adjacent bytes of the row)
+    const int U = NCO * nw16, per = (U + IS_NW - 1) / IS_NW;              // each wave takes a contiguous range of units (adjacent bytes of the row)
     const int u_begin = wave * per, u_end = (u_begin + per) < U ? (u_begin + per) : U;
     if (flags & SEG_UNROTATE) {
         const float* __restrict__ dl = dstage + el;
@@ -383,7 +388,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
     const int Pfull = N * P1;
     const int nj = (Pfull + 3) >> 2;
     const bool rot0 = (A.rot_mask >> s0) & 1, rot1 = nsrc == 2 && ((A.rot_mask >> s1) & 1);
-    if (rot0 && rot1) {
+    if (rot0 && rot1 && (IS_NW <= 4 || L <= 3)) {
         // sender and receiver rows of the node branch share the edge's Wigner row: one output piece t = a * P1 + p (component a,
         // channels 4p..4p+3) of BOTH sources per (wave, g) slot and step -- 2 N float4 loads of the node rows + the N entries of
         // row a in flight together, 2 N float4 FMAs, two ds_write_b128 straight into the operand images
@@ -400,12 +405,12 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
         // instead of one piece's
         constexpr int U = HG_STAGE_U(L);
 #pragma unroll 1
-        for (int t0 = 4 * wave + g; t0 < Pfull; t0 += 16 * U) {
+        for (int t0 = 4 * wave + g; t0 < Pfull; t0 += 4 * IS_NW * U) {
             f32x4 v0[U][N], v1[U][N];
             float d[U][N];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                int t = t0 + 16 * u;
+                int t = t0 + 4 * IS_NW * u;
                 t = t < Pfull ? t : t0;                        // tail: re-read the first piece (result dropped below)
                 const int a = t / P1, p = t - a * P1;
 #pragma unroll
@@ -417,7 +422,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = t0 + 16 * u;
+                const int t = t0 + 4 * IS_NW * u;
                 if (t < Pfull) {
                     f32x4 acc0 = d[u][0] * v0[u][0], acc1 = d[u][0] * v1[u][0];
 #pragma unroll
@@ -441,7 +446,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
         if (si ? rot1 : rot0) {
             const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
 #pragma unroll 1
-            for (int t = 4 * wave + g; t < Pfull; t += 16) {
+            for (int t = 4 * wave + g; t < Pfull; t += 4 * IS_NW) {
                 const int a = t / P1, p = t - a * P1;
                 f32x4 v[N];
                 float d[N];
@@ -457,7 +462,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
             }
         } else {
 #pragma unroll 1
-            for (int j = wave; j < nj; j += 4) {               // the four waves share the block's DMA instructions
+            for (int j = wave; j < nj; j += IS_NW) {           // the waves share the block's DMA instructions
                 int p = 4 * j + g;
                 p = p < Pfull ? p : Pfull - 1;
                 is_dma16(row + 4 * p, dst + j * 256);
@@ -466,8 +471,13 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
     }
 }
 
+#ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
+#define IS_CASE(MMv, RTMv) \
+    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT>(A, g_W, it, g_segs + it[19] * 8, lds, erow, lane IS_PROF_PASS); break;
+#else
 #define IS_CASE(MMv, RTMv) \
     case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT>(A, g_W, it, g_segs + it[19] * 8, lds, erow, lane IS_PROF_PASS); break;
+#endif
 
 #define SEG_NEWBATCH (1 << 16)
 
@@ -480,7 +490,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
 #define IS_PART_I32 8
 
 template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
+__global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
                                                        const int* __restrict__ g_phases, const int* __restrict__ g_groups,
                                                        const int* __restrict__ g_items, const float* __restrict__ g_W,
                                                        const int* __restrict__ g_parts) {
@@ -513,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const in
     const unsigned long long t_begin = prof.last;
 #endif
 
-    for (int i = threadIdx.x; i < A.stage_off; i += 256) lds[i] = 0.f;             // all segment tiles + the trash row
+    for (int i = threadIdx.x; i < A.stage_off; i += IS_NT) lds[i] = 0.f;             // all segment tiles + the trash row
     IS_T(4);                                                   // zero fill
 
     for (int ph = ph0; ph < ph1; ++ph) {
@@ -556,6 +566,10 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const in
             for (int ii = ib; ii < ie; ++ii) {
                 const int* __restrict__ it = g_items + ii * 24;
                 switch (it[6] * 8 + it[9]) {
+#if IS_NW > 4                      // three waves per SIMD: 168 VGPRs per wave, row-tile table 2,2,2,1,1,1,1 (HG_RTM)
+                    IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(3, 1) IS_CASE(4, 1) IS_CASE(5, 1)
+                    IS_CASE(6, 1)
+#else
                     IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(0, 3) IS_CASE(0, 4)
                     IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(1, 3) IS_CASE(1, 4)
                     IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(2, 3)              // row-tile table of plan.py:rtm_max (4,4,3,2,2,1,1): the r1 shapes
@@ -563,6 +577,7 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const in
                     IS_CASE(4, 1) IS_CASE(4, 2)
                     IS_CASE(5, 1)
                     IS_CASE(6, 1)
+#endif
                     default: break;
                 }
             }
@@ -571,7 +586,12 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const in
 
     if (SPLIT && copy_stride) {                                // split launch: fold the waves' private tile copies into copy 0
         __syncthreads();
-        for (int i = threadIdx.x; i < copy_stride; i += 256) lds[i] += lds[i + copy_stride] + lds[i + 2 * copy_stride] + lds[i + 3 * copy_stride];
+        for (int i = threadIdx.x; i < copy_stride; i += IS_NT) {
+            float acc = lds[i];
+#pragma unroll
+            for (int k = 1; k < IS_NW; ++k) acc += lds[i + k * copy_stride];
+            lds[i] = acc;
+        }
     }
     // ---------------------------------------------------------------- epilogue: all four waves on one segment at a time; the Wigner
     // blocks of a batch of segments (one block per l, as many l as fit the staging area) are staged together by LDS-DMA
@@ -592,7 +612,7 @@ __global__ __launch_bounds__(256, 2) void tp_is_kernel(const IsArgs A0, const in
                     const float* __restrict__ D = A.wig + erow * A.nW + is_pick_wig_off(A, l2);
                     const int nj = (nn + 3) >> 2;
 #pragma unroll 1
-                    for (int j = wave; j < nj; j += 4) {       // image [m * NCO + a][edge]
+                    for (int j = wave; j < nj; j += IS_NW) {   // image [m * NCO + a][edge]
                         int idx = 4 * j + g;
                         idx = idx < nn ? idx : nn - 1;
                         is_dma4(D + idx, stage + T8[6] + j * 64);
@@ -676,10 +696,10 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     if (int rc = hg_lds_attr_once(lds_attr_done[1], dev_guard.dev, (const void*)tp_is_kernel<true>, 160 * 1024)) return rc;
     const unsigned grid = (unsigned)((rows + 15) / 16);
     if (nparts == 1)
-        hipLaunchKernelGGL(tp_is_kernel<false>, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table,
+        hipLaunchKernelGGL(tp_is_kernel<false>, dim3(grid), dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table,
                            group_table, item_table, weights, part_table);
     else
-        hipLaunchKernelGGL(tp_is_kernel<true>, dim3(grid, (unsigned)nparts), dim3(256), lds_bytes, (hipStream_t)stream, A, seg_table, block_table,
+        hipLaunchKernelGGL(tp_is_kernel<true>, dim3(grid, (unsigned)nparts), dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table,
                            phase_table, group_table, item_table, weights, part_table);
     return hg_check_launch("hg_tp_is");
 }

@@ -160,7 +160,7 @@ class Program:
 
 
 # ---- input-stationary schedule (csrc/tp_is.hip): the SAME items, regrouped by input irrep block ------------------------------
-IS_WAVES = 4                       # waves of a workgroup; all of them work on the same 16 edges
+IS_WAVES = int(os.environ.get("HG_IS_WAVES", "4"))      # waves of a workgroup (= IS_NW of csrc/tp_is.hip); all on the same 16 edges
 IS_BLOCK_I32 = 8                   # {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
 IS_PHASE_I32 = 4                   # {block_begin, block_end, group_begin, group_end}
 IS_LDS_BYTES = 80 * 1024           # two workgroups per CU
