@@ -418,8 +418,10 @@ def main():
         _check(mine(Gh, {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"],
                ref(Graph(Gh), {"node_attr": node_attr, "edge_attr": edge_attr})["hamiltonian"], f"head {ham_type} nao={nao} zero_point_shift")
         if (ham_type, nao) in (("openmx", 19), ("abacus", 13)):
+            sr = ref.calculate_sparsity_ratio(Graph(Gh))                          # :2784-2872 (total / effective matrix elements)
             _save(f"head_{ham_type}_{nao}", weights=sd, graph={k: Gh[k] for k in ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0")},
-                  inputs=dict(node_attr=node_attr, edge_attr=edge_attr), outputs=dict(hamiltonian=out_ref["hamiltonian"]))
+                  inputs=dict(node_attr=node_attr, edge_attr=edge_attr),
+                  outputs=dict(hamiltonian=out_ref["hamiltonian"], sparsity_ratio=torch.as_tensor(sr, dtype=torch.float64).reshape(1)))
 
     # ---- 5. head, SOC so3 (openmx nao 19) --------------------------------------------------------------------------
     nao = 19

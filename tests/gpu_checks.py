@@ -208,7 +208,8 @@ def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, 
            "edge_attr": torch.from_numpy(f["inputs"]["edge_attr"]).float().to(device)}
     out = m(g, rep)
     torch.cuda.synchronize()
-    return {name + "_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"]), "sparsity_ratio": float(out["sparsity_ratio"])}
+    return {name + "_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"]), "sparsity_ratio": float(out["sparsity_ratio"]),
+            "sparsity_ratio_reference": float(f["outputs"]["sparsity_ratio"][0])}
 
 
 def check_head_overlap(device="cuda"):
@@ -693,4 +694,51 @@ def check_captured_forward_si2(device="cuda"):
     with torch.no_grad():
         res["eager_ms"] = timeit(lambda: head(g, model(g)))
     res["replay_ms"] = timeit(fwd)
+    return res
+
+
+class AttrGraph:
+    """attribute-style graph object without a dict base class -- what a torch_geometric Data looks like to the model code"""
+
+    def __init__(self, **k):
+        self.__dict__.update(k)
+
+    def __getitem__(self, k):
+        return self.__dict__[k]
+
+    def __setitem__(self, k, v):
+        self.__dict__[k] = v
+
+    def __contains__(self, k):
+        return k in self.__dict__
+
+
+def check_attribute_style_graph(device="cuda"):
+    """the backbone + head fixtures driven with an attribute-style (non-dict) graph: same numbers as with the dict-like Graph, and the
+    index-plumbing cache lives on the object (second forward does not rebuild it)"""
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.topo import CACHE_ATTR
+    m, f = build_backbone_from_fixture(device, "backbone")
+    g = to_graph(f["graph"], device)
+    a = AttrGraph(**{k: v for k, v in g.items()})
+    rep_d, rep_a = m(g), m(a)
+    res = {"node_attr": rel(rep_a["node_attr"], rep_d["node_attr"]), "edge_attr": rel(rep_a["edge_attr"], rep_d["edge_attr"]),
+           "node_vs_fixture": rel(rep_a.node_attr, f["outputs"]["node_attr"])}
+    fh = load("head_openmx_19")
+    head = load_weights(HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                          soc_switch=False, calculate_sparsity=True), fh["weights"])
+    gd = dict(fh["graph"])
+    for k in ("pos", "nbr_shift", "cell"):
+        gd[k] = f["graph"][k]
+    gh = to_graph(gd, device)
+    ah = AttrGraph(**{k: v for k, v in gh.items()})
+    rep = {"node_attr": torch.from_numpy(fh["inputs"]["node_attr"]).float().to(device), "edge_attr": torch.from_numpy(fh["inputs"]["edge_attr"]).float().to(device)}
+    out = head(ah, rep)
+    cache1 = ah.__dict__.get(CACHE_ATTR)
+    out2 = head(ah, rep)
+    torch.cuda.synchronize()
+    res["head_vs_fixture"] = rel(out["hamiltonian"], fh["outputs"]["hamiltonian"])
+    res["cache_reused"] = cache1 is not None and ah.__dict__.get(CACHE_ATTR) is cache1 and torch.equal(out["hamiltonian"], out2["hamiltonian"])
+    res["sparsity_ratio"] = float(out["sparsity_ratio"])
+    res["sparsity_ratio_fixture"] = float(fh["outputs"]["sparsity_ratio"][0])
     return res

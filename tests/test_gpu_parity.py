@@ -69,6 +69,7 @@ def test_head_golden(name, ham_type, nao):
     r = G.check_head(name=name, ham_type=ham_type, nao=nao)
     print(r)
     assert r[name + "_rel_err"] < G.TOL
+    assert abs(r["sparsity_ratio"] - r["sparsity_ratio_reference"]) < 1e-6 * r["sparsity_ratio_reference"]     # hamgnn_output.py:2784-2872
 
 
 def test_full_forward_vs_oracle_random_cell():
@@ -160,6 +161,15 @@ def test_si2_default_irreps_vs_oracle(which):
     r = G.check_default_irreps_si2(which=which)
     print(r)
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL and r["Hnet_rel_err"] < G.TOL
+
+
+def test_attribute_style_graph_object():
+    """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
+    r = G.check_attribute_style_graph()
+    print(r)
+    assert r["node_attr"] < 1e-6 and r["edge_attr"] < 1e-6 and r["node_vs_fixture"] < G.TOL and r["head_vs_fixture"] < G.TOL      # (split launches: claim-order rounding)
+    assert r["cache_reused"]
+    assert abs(r["sparsity_ratio"] - r["sparsity_ratio_fixture"]) < 1e-6 * r["sparsity_ratio_fixture"]
 
 
 def test_captured_forward_replay_si2():
