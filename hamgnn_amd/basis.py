@@ -14,7 +14,8 @@ def basis_table(ham_type: str, nao_max: int):
         raise NotImplementedError(f"ham_type={ham_type!r} nao_max={nao_max} not supported")      # hamgnn_output.py:343,526,594,810
     e = t[key]
     return {"row": e["row"], "index_change": e["index_change"], "minus_index": e.get("minus_index"),
-            "basis_def": {int(k): v for k, v in e["basis_def"].items()}}
+            "basis_def": {int(k): v for k, v in e["basis_def"].items()},
+            "num_valence": {int(k): v for k, v in e.get("num_valence", {}).items()}}
 
 
 def atomic_radii(kind="openmx"):

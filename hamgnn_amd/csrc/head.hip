@@ -434,3 +434,67 @@ extern "C" int hg_sym_contraction(const float* h, int64_t h_stride, const int64_
                                                                                  out_stride);
     return hg_check_launch("hg_sym_contraction");
 }
+
+// ------------------------------------------------------------------------------------------------ k-space assembly (f4: band energies)
+// H(k)[i a, j b] = delta_ij H_on[i][a][b] + sum_{e: i -> j} exp(2 pi i k . nbr_shift_e) H_off[e][a][b]  of ONE crystal, written straight in
+// the COMPACT orbital basis (orbitals an element does not have are skipped: the reference builds the nao_max-padded matrix and
+// masked_selects it, hamgnn_output.py:1776-1905).  The reference accumulates with index_put(accumulate=True) (atomics); here the edges
+// are grouped by atom pair on the host (index plumbing) and one block owns one (pair, k): fixed summation order, no atomics.
+//   pair_ptr[npairs+1], pair_edges[]: edges of every (i, j) pair (crystal-local edge ids);  pair_ij[npairs][2];
+//   orank[n][nao]: rank of orbital a inside atom i's valid set or -1;  ooff[n]: first compact index of atom i;  M: compact dimension;
+//   Hk: [nk][M][M] complex64 (float2), zero-initialised by the caller.
+__global__ __launch_bounds__(256) void hk_onsite_kernel(const float* __restrict__ on, int nao, const int* __restrict__ orank,
+                                                        const int* __restrict__ ooff, int M, int nk, float2* __restrict__ Hk) {
+    const int i = blockIdx.x, k = blockIdx.y;
+    const int nao2 = nao * nao;
+    for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+        const int a = q / nao, b = q - a * nao;
+        const int ra = orank[i * nao + a], rb = orank[i * nao + b];
+        if (ra < 0 || rb < 0) continue;
+        Hk[((int64_t)k * M + ooff[i] + ra) * M + ooff[i] + rb] = make_float2(on[(int64_t)i * nao2 + q], 0.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void hk_pairs_kernel(const float* __restrict__ off, const float* __restrict__ shift, const float* __restrict__ kvec,
+                                                       const int64_t* __restrict__ pair_ptr, const int64_t* __restrict__ pair_edges,
+                                                       const int64_t* __restrict__ pair_ij, int nao, const int* __restrict__ orank,
+                                                       const int* __restrict__ ooff, int M, float2* __restrict__ Hk) {
+    const int64_t p = blockIdx.x;
+    const int k = blockIdx.y;
+    const int nao2 = nao * nao;
+    const int64_t i = pair_ij[2 * p], j = pair_ij[2 * p + 1];
+    const int64_t q0 = pair_ptr[p], q1 = pair_ptr[p + 1];
+    const float kx = kvec[3 * k], ky = kvec[3 * k + 1], kz = kvec[3 * k + 2];
+    for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+        const int a = q / nao, b = q - a * nao;
+        const int ra = orank[i * nao + a], rb = orank[j * nao + b];
+        if (ra < 0 || rb < 0) continue;
+        float re = 0.f, im = 0.f;
+        for (int64_t t = q0; t < q1; ++t) {
+            const int64_t e = pair_edges[t];
+            // phase in double: |k . shift| reaches tens of turns for long bonds, and sincosf loses the fraction
+            const double ph = 6.283185307179586 * ((double)kx * shift[3 * e] + (double)ky * shift[3 * e + 1] + (double)kz * shift[3 * e + 2]);
+            double s, c;
+            sincos(ph, &s, &c);
+            const float h = off[e * nao2 + q];
+            re = fmaf((float)c, h, re);
+            im = fmaf((float)s, h, im);
+        }
+        float2* dst = Hk + ((int64_t)k * M + ooff[i] + ra) * M + ooff[j] + rb;
+        const float2 old = *dst;                               // (i, i) pairs (self images) add onto the on-site block; one owner per element
+        *dst = make_float2(old.x + re, old.y + im);
+    }
+}
+
+extern "C" int hg_hk_assemble(const float* on, const float* off, const float* nbr_shift, const float* kvec, int nk, const int64_t* pair_ptr,
+                              const int64_t* pair_edges, const int64_t* pair_ij, int64_t npairs, int n_atoms, int nao, const int32_t* orank,
+                              const int32_t* ooff, int M, float* Hk, void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (n_atoms <= 0 || nk <= 0 || M <= 0) return 0;
+    if (nao <= 0 || nk > 65535) return hg_fail(-2, "hg_hk_assemble: bad sizes");
+    hk_onsite_kernel<<<dim3((unsigned)n_atoms, (unsigned)nk), 256, 0, (hipStream_t)stream>>>(on, nao, orank, ooff, M, nk, (float2*)Hk);
+    if (npairs > 0)
+        hk_pairs_kernel<<<dim3((unsigned)npairs, (unsigned)nk), 256, 0, (hipStream_t)stream>>>(off, nbr_shift, kvec, pair_ptr, pair_edges, pair_ij, nao,
+                                                                                             orank, ooff, M, (float2*)Hk);
+    return hg_check_launch("hg_hk_assemble");
+}

@@ -1,0 +1,141 @@
+"""The k-space step after the read-out: `HamGNNPlusPlusOut(calculate_band_energy=True)` of the reference
+(hamgnn/models/hamgnn_output.py:1675-1996 calculate_band_energies; k-point generation :3802-3854; hamgnn/physics/kpoints.py:26-165).
+
+Per crystal: k-points (random, or a path through given nodes in reduced coordinates) -> H(k), S(k) in the compact orbital basis by the
+HIP kernel `hg_hk_assemble` (phase-factor sums over the edges of every atom pair, fixed order) -> generalized eigenproblem
+H(k) psi = E S(k) psi through the Cholesky factor of S(k) exactly as the reference does it, on hipSOLVER via `torch.linalg`
+(cholesky / inv / eigh on complex64: library calls, not kernels of this repository) -> band energies, wavefunctions, band gap,
+optional band window.  Non-SOC branch with the reference overlaps `Son / Soff` (ham_only=True); the SOC / overlap-network variants
+(:1368-1673, :1998-2286) are not built."""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .topo import gget
+
+
+# ------------------------------------------------------------------------------------------------ k-points (host geometry)
+def k_path_points(kpts, nk: int, lat: np.ndarray):
+    """kpoints_generator(dim_k=3, lat).k_path(kpts, nk) (hamgnn/physics/kpoints.py:26-165): `nk` nearly equidistant points (reduced
+    coordinates) along the straight segments through the nodes `kpts`; distances measured with the reciprocal metric of `lat`.
+    Returns (k_vec [nk,3] reduced, lat_per_inv = inv(lat).T)."""
+    k_list = np.asarray(kpts, dtype=float)
+    if k_list.ndim != 2 or k_list.shape[1] != 3:
+        raise Exception("\n\nk-space dimensions do not match")
+    if nk < k_list.shape[0]:
+        raise Exception("\n\nMust have more points in the path than number of nodes.")
+    lat = np.asarray(lat, dtype=float)
+    k_metric = np.linalg.inv(lat @ lat.T)
+    n_nodes = k_list.shape[0]
+    k_node = np.zeros(n_nodes)
+    for n in range(1, n_nodes):
+        dk = k_list[n] - k_list[n - 1]
+        k_node[n] = k_node[n - 1] + math.sqrt(dk @ k_metric @ dk)
+    node_index = [0] + [int(round(k_node[n] / k_node[-1] * (nk - 1))) for n in range(1, n_nodes - 1)] + [nk - 1]
+    k_vec = np.zeros((nk, 3))
+    k_vec[0] = k_list[0]
+    for n in range(1, n_nodes):
+        n_i, n_f = node_index[n - 1], node_index[n]
+        for j in range(n_i, n_f + 1):
+            frac = float(j - n_i) / float(n_f - n_i)
+            k_vec[j] = k_list[n - 1] + frac * (k_list[n] - k_list[n - 1])
+    return k_vec, np.linalg.inv(lat).T
+
+
+def make_k_vectors(k_path, num_k: int, cell: torch.Tensor, rng=np.random) -> torch.Tensor:
+    """data.k_vecs of the reference (:3802-3854): [n_crystals, num_k, 3] Cartesian-reciprocal k-vectors (no 2 pi: it sits in the phase).
+    k_path: list of nodes in reduced coordinates, or None -> uniformly random reduced k in [-1, 1)^3 (numpy's global RNG, as the reference).
+    ('auto' needs pymatgen's KPathSeek in the reference and is not available here.)"""
+    out = []
+    cells = cell.detach().cpu().double().numpy().reshape(-1, 3, 3)
+    for lat in cells:
+        if isinstance(k_path, (list, tuple)):
+            k_vec, lat_per_inv = k_path_points(k_path, num_k, lat)
+        elif k_path is None:
+            lat_per_inv = np.linalg.inv(lat).T
+            k_vec = 2.0 * rng.rand(num_k, 3) - 1.0
+        else:
+            raise NotImplementedError(f"k_path={k_path!r}: give a list of reduced k-points or None (random); 'auto' needs pymatgen")
+        out.append(torch.from_numpy(k_vec.dot(lat_per_inv[np.newaxis, :, :]).reshape(-1, 3)).float())
+    return torch.stack(out, 0)
+
+
+# ------------------------------------------------------------------------------------------------ per-crystal index plumbing
+def _crystal_slices(data):
+    node_counts = gget(data, "node_counts")
+    src = data.edge_index[0]
+    if node_counts is None:
+        return [(0, int(data.z.shape[0]), 0, int(src.shape[0]))]
+    ncs = [int(v) for v in node_counts.tolist()]
+    batch = gget(data, "batch")
+    ecs = torch.bincount(batch[src], minlength=len(ncs)).tolist() if batch is not None else [int(src.shape[0])]
+    out, n0, e0 = [], 0, 0
+    for n, e in zip(ncs, ecs):
+        out.append((n0, n, e0, int(e)))
+        n0, e0 = n0 + n, e0 + int(e)
+    return out
+
+
+def assemble_k(on, off, data, k_vecs_c, n0, n, e0, e, orank_all, nao):
+    """[nk, M, M] complex64 of one crystal (rows n0:n0+n, edges e0:e0+e) from planar [.., nao^2] blocks"""
+    dev = on.device
+    src = (data.edge_index[0][e0:e0 + e] - n0).contiguous()
+    dst = (data.edge_index[1][e0:e0 + e] - n0).contiguous()
+    key = src * n + dst
+    order = torch.sort(key, stable=True).indices
+    uniq, counts = torch.unique_consecutive(key[order], return_counts=True)
+    ptr = torch.zeros(uniq.numel() + 1, dtype=torch.int64, device=dev)
+    ptr[1:] = torch.cumsum(counts, 0)
+    pij = torch.stack([uniq // n, uniq % n], 1).contiguous()
+    orank = orank_all[n0:n0 + n].contiguous()
+    norb = (orank >= 0).sum(1)
+    ooff = (torch.cumsum(norb, 0) - norb).to(torch.int32).contiguous()
+    M = int(norb.sum())
+    return ops.hk_assemble(on[n0:n0 + n].contiguous(), off[e0:e0 + e].contiguous(), data.nbr_shift[e0:e0 + e].contiguous().float(),
+                           k_vecs_c.contiguous().float(), ptr, order.contiguous(), pij, n, nao, orank, ooff, M), M
+
+
+def band_energies(head, onsite_hamiltonian, offsite_hamiltonian, data, k_vecs: Optional[torch.Tensor] = None):
+    """calculate_band_energies(onsite, offsite, data) of the reference (:1675-1996, export_reciprocal_values=False): returns
+    (band_energy [sum_c bands_c, num_k], wavefunction (flattened), band_gap [n_crystals], H_sym (flattened))."""
+    nao = head.nao_max
+    dev = onsite_hamiltonian.device
+    k_vecs = gget(data, "k_vecs") if k_vecs is None else k_vecs
+    if k_vecs is None:
+        raise ValueError("band_energies: no k-vectors (data.k_vecs)")
+    k_vecs = k_vecs.to(dev)
+    z = data.z
+    orank_tab = head._orank.to(dev)                            # [119, nao] rank of an orbital in its element's valid set or -1
+    orank_all = orank_tab[z]
+    val = head._num_valence.to(dev)[z].to(torch.float64)
+    energies, waves, gaps, hsyms = [], [], [], []
+    Son, Soff = data.Son.contiguous().float(), data.Soff.contiguous().float()
+    for c, (n0, n, e0, e) in enumerate(_crystal_slices(data)):
+        Hk, M = assemble_k(onsite_hamiltonian, offsite_hamiltonian, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        Sk, _ = assemble_k(Son, Soff, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        # generalized eigenproblem through the Cholesky factor of S(k), as the reference (:1911-1928)
+        L = torch.linalg.cholesky(Sk)
+        Linv = torch.linalg.inv(L)
+        LHinv = torch.linalg.inv(L.conj().transpose(-1, -2))
+        Ht = torch.bmm(torch.bmm(Linv, Hk), LHinv)
+        evals, evecs = torch.linalg.eigh(Ht)
+        evecs = torch.einsum("ijk,ika->iaj", LHinv, evecs)
+        half = math.ceil(float(val[n0:n0 + n].sum()) / 2)
+        gaps.append((evals[:, half].min() - evals[:, half - 1].max()).reshape(1))
+        bnc = head.band_num_control
+        if bnc is not None:
+            if isinstance(bnc, dict):
+                nb = int(sum(int(bnc.get(int(zz), bnc.get(str(int(zz)), 0))) for zz in z[n0:n0 + n].tolist()))
+                evals, evecs = evals[:, :nb], evecs[:, :nb, :]
+            else:
+                win = max(1, int(bnc * half)) if isinstance(bnc, float) else min(int(bnc), half)
+                evals, evecs = evals[:, half - win:half + win], evecs[:, half - win:half + win, :]
+        energies.append(evals.transpose(-1, -2))
+        waves.append(evecs.reshape(-1))
+        hsyms.append(Ht.reshape(-1))
+    return torch.cat(energies, 0), torch.cat(waves, 0), torch.cat(gaps, 0), torch.cat(hsyms, 0)

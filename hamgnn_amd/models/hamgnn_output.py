@@ -3,7 +3,8 @@
 linear_transform}, ..._ksi_network, ..._overlap_network) and result dict.  In scope this round: the non-SOC branch
 (:3772-3799) incl. overlap networks, SOC/so3 (:3026-3144), SOC/su2 (:3146-3178; E3TensorDecomposition.get_H,
 hamgnn/nn/tensor_decomposition.py:553-603), masks, symmetrisation, H0, per-crystal concatenation, sparsity ratio.
-Out of scope (raise NotImplementedError): band/k-space code, spin-constrained / collinear branches, forces
+The k-space step `calculate_band_energy` is built for the non-SOC branch (hamgnn_amd/kspace.py).  Out of scope (raise NotImplementedError):
+SOC / overlap-network band variants, spin-constrained / collinear branches, forces
 (SURVEY.md section 2 / 8f)."""
 from __future__ import annotations
 
@@ -36,7 +37,10 @@ class HamGNNPlusPlusOut(nn.Module):
         self.zero_point_shift, self.add_H_nonsoc = zero_point_shift, add_H_nonsoc
         self.calculate_sparsity = calculate_sparsity
         self.get_nonzero_mask_tensor = get_nonzero_mask_tensor
-        for flag, name in ((return_forces, "return_forces"), (calculate_band_energy, "calculate_band_energy"),
+        self.calculate_band_energy, self.num_k, self.k_path, self.band_num_control = calculate_band_energy, num_k, k_path, band_num_control
+        if calculate_band_energy and (soc_switch or not ham_only):
+            raise NotImplementedError("calculate_band_energy is built for the non-SOC branch with reference overlaps (ham_only=True)")
+        for flag, name in ((return_forces, "return_forces"),
                            (spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
                            (export_reciprocal_values, "export_reciprocal_values"),
                            (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
@@ -45,6 +49,7 @@ class HamGNNPlusPlusOut(nn.Module):
         if soc_switch and self.soc_basis not in ("so3", "su2"):
             raise NotImplementedError("Unsupported SOC basis")                  # hamgnn_output.py:3180-3181
         t = B.basis_table(self.ham_type, nao_max)
+        self.num_valence = t["num_valence"]
         self.row = self.col = Irreps(t["row"])
         self.index_change, self.minus_index, self.basis_def = t["index_change"], t["minus_index"], t["basis_def"]
         self.hamiltonian_irreps = P.ham_irreps(self.row)
@@ -95,6 +100,13 @@ class HamGNNPlusPlusOut(nn.Module):
         for Z, orb in self.basis_def.items():
             mask[Z, orb] = 1.0
         self._mask = torch.from_numpy(mask).to(dev)
+        orank = np.full((119, self.nao_max), -1, dtype=np.int32)           # k-space step: rank of an orbital inside its element's valid set
+        for Z, orb in self.basis_def.items():
+            orank[Z, sorted(orb)] = np.arange(len(orb), dtype=np.int32)
+        nval = np.zeros(119, dtype=np.float32)
+        for Z, cnt in self.num_valence.items():
+            nval[int(Z)] = cnt
+        self._orank, self._num_valence = torch.from_numpy(orank).to(dev), torch.from_numpy(nval).to(dev)
         norb = np.full(256, self.nao_max, dtype=np.int64)
         defined = np.zeros(256, dtype=bool)
         for Z, orb in self.basis_def.items():
@@ -253,6 +265,14 @@ class HamGNNPlusPlusOut(nn.Module):
         if self.zero_point_shift:
             H = self._apply_zero_point_shift(data, H, edge_counts, False)
         result.update({"hamiltonian": H, "band_energy": None, "wavefunction": None, "band_gap": None, "H_sym": None})
+        if self.calculate_band_energy:                                        # hamgnn_output.py:3800-3880 (non-SOC, reference overlaps)
+            from .. import kspace
+            data["k_vecs"] = kspace.make_k_vectors(self.k_path, self.num_k, data.cell).to(dev)
+            be, wf, gap, hs = kspace.band_energies(self, on, off, data)
+            result.update({"band_energy": be, "wavefunction": wf, "band_gap": gap, "H_sym": hs})
+            with torch.no_grad():                                             # reference bands from the target blocks (:3876-3879)
+                tb, tw, tg, th = kspace.band_energies(self, f32c(data.Hon), f32c(data.Hoff), data)
+            data["band_energy"], data["wavefunction"], data["band_gap"], data["H_sym"] = tb, tw, tg, th
         if self.get_nonzero_mask_tensor:
             result["mask"] = self.build_interaction_masks(data)
         if self.calculate_sparsity:

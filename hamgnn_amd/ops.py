@@ -314,6 +314,18 @@ def soc_assemble(H, ksi, L, inv, H0r, H0i, nao, symmetrize=True, zero_diag=False
 
 
 @_on_tensor_device
+def hk_assemble(on, off, nbr_shift, kvec, pair_ptr, pair_edges, pair_ij, n_atoms, nao, orank, ooff, M):
+    """[nk, M, M] complex64 k-space matrix of one crystal in the compact orbital basis (see include/hamgnn_hip.h:hg_hk_assemble)"""
+    _require_gpu(on)
+    nk = int(kvec.shape[0])
+    out = torch.zeros(nk, M, M, 2, device=on.device, dtype=torch.float32)
+    check(lib().hg_hk_assemble(ptr(on), ptr(off), ptr(nbr_shift), ptr(kvec), i32(nk), ptr(pair_ptr), ptr(pair_edges), ptr(pair_ij),
+                               i64(pair_ij.shape[0]), i32(n_atoms), i32(nao), ptr(orank.to(torch.int32).contiguous()), ptr(ooff), i32(M), ptr(out),
+                               _stream()), "hg_hk_assemble")
+    return torch.view_as_complex(out)
+
+
+@_on_tensor_device
 def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
     """in place on H; returns the shift (device scalar)."""
     _require_gpu(H)

@@ -182,6 +182,17 @@ int hg_block_mean(const float* x, int64_t x_stride, const int32_t* tab, int nao,
 int hg_soc_assemble(const float* H, const float* ksi, const float* L, const int64_t* inv, const float* H0r, const float* H0i,
                     int nao, int symmetrize, int zero_diag, int64_t rows, float* out_real, float* out_imag, void* stream);
 
+/* k-space assembly of ONE crystal for the band-energy step (hamgnn/models/hamgnn_output.py:1776-1905 inside
+ * calculate_band_energies): X(k)[i a, j b] = delta_ij X_on[i][a][b] + sum_{e: i->j} exp(2 pi i k . nbr_shift_e) X_off[e][a][b], written in
+ * the COMPACT orbital basis (the reference builds the nao_max-padded matrix, then masked_selects the valid orbitals).  Edges are
+ * grouped by atom pair on the host (pair_ptr [npairs+1], pair_edges: crystal-local edge ids, pair_ij [npairs][2]); one block owns one
+ * (pair, k) -- fixed summation order instead of index_put(accumulate=True) atomics.  orank [n_atoms][nao]: rank of an orbital in its
+ * atom's valid set or -1; ooff [n_atoms]: first compact index of an atom; Hk: [nk][M][M] complex64 (re, im), ZERO-initialised by the
+ * caller.  The generalized eigenproblem that follows (Cholesky of S(k), eigh) is hipSOLVER's job, reached through torch.linalg.   */
+int hg_hk_assemble(const float* on, const float* off, const float* nbr_shift, const float* kvec, int nk, const int64_t* pair_ptr,
+                   const int64_t* pair_edges, const int64_t* pair_ij, int64_t npairs, int n_atoms, int nao, const int32_t* orank,
+                   const int32_t* ooff, int M, float* Hk, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -274,6 +274,7 @@ def main():
                 "index_change": ic.tolist() if ic is not None else None,
                 "minus_index": mi.tolist() if mi is not None else None,
                 "basis_def": {str(int(k)): [int(x) for x in v] for k, v in h.basis_def.items()},
+                "num_valence": {str(int(k)): int(v) for k, v in getattr(h, "num_valence", {}).items()},
             }
     os.makedirs(GOLD, exist_ok=True)
     with open(os.path.join(GOLD, "basis_tables.json"), "w") as f:
@@ -521,6 +522,49 @@ def main():
     _save("head_soc_su2_abacus_27", weights=sd32, graph={k: (Gu[k].float() if Gu[k].is_floating_point() else Gu[k]) for k in keys},
           inputs=dict(node_attr=na27.float(), edge_attr=ea27.float()), meta=dict(irreps=rich),
           outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"].float(), hamiltonian_imag=out_ref["hamiltonian_imag"].float()))
+
+    # ---- 6c. k-space step: calculate_band_energies (hamgnn_output.py:1675-1996) on a 2-crystal batch -----------------
+    genk = torch.Generator().manual_seed(31)
+    from hamgnn_amd.data import collate
+    from hamgnn_amd.data import synthetic as S
+    nao = 13
+    g1, g2 = S.random_cell(2, [6, 1], seed=21, density=0.003), S.random_cell(3, [6, 8, 1], seed=22, density=0.003)      # H: 5 of 13 orbitals
+    Gb = collate([g1, g2])
+    Nb, Eb = Gb.z.shape[0], Gb.edge_index.shape[1]
+    ginv, _ = R.global_inverse(Gb) if hasattr(R, "global_inverse") else (None, None)
+    inv_g = torch.cat([g1.inv_edge_idx, g2.inv_edge_idx + g1.edge_index.shape[1]])
+
+    f32 = lambda t: t.float().double()                          # the fixture stores fp32: keep every value exactly representable
+
+    def herm(n_on, scale, diag):
+        on = scale * torch.randn(n_on, nao, nao, generator=genk, dtype=torch.float64)
+        on = 0.5 * (on + on.transpose(1, 2)) + diag * torch.eye(nao, dtype=torch.float64)
+        off = scale * torch.randn(Eb, nao, nao, generator=genk, dtype=torch.float64)
+        off = 0.5 * (off + off[inv_g].transpose(1, 2))
+        return f32(on.reshape(n_on, -1)), f32(off.reshape(Eb, -1))
+    Gb = Graph({k: (f32(v) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in Gb.items()})
+    Gb["Son"], Gb["Soff"] = herm(Nb, 0.004, 1.0)                   # S(k) = 1 + small Hermitian part: positive definite
+    Hon, Hoff = herm(Nb, 0.3, 0.0)
+    Gb["k_vecs"] = f32(torch.randn(2, 5, 3, generator=genk, dtype=torch.float64) * 0.05)
+    refk = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True,
+                                     add_H0=True, soc_switch=False, calculate_band_energy=False, calculate_sparsity=False)
+    refk.num_k, refk.band_num_control = 5, None
+    minek = R.HamGNNPlusPlusOut(mini, mini, nao_max=nao, ham_type="openmx")
+    be_r, wf_r, gap_r, hs_r = refk.calculate_band_energies(Hon, Hoff, Graph(Gb))
+    be_m, wf_m, gap_m, hs_m = minek.calculate_band_energies(Hon, Hoff, Gb)
+    _check(be_m, be_r, "calculate_band_energies band_energy", tol=1e-9)
+    _check(gap_m, gap_r, "calculate_band_energies band_gap", tol=1e-9)
+    _check(hs_m.abs(), hs_r.abs(), "calculate_band_energies |H_sym|", tol=1e-9)
+    refk.band_num_control = minek.band_num_control = 3
+    _check(minek.calculate_band_energies(Hon, Hoff, Gb)[0], refk.calculate_band_energies(Hon, Hoff, Graph(Gb))[0], "band window (int)", tol=1e-9)
+    # k-path interpolation of the reference (hamgnn/physics/kpoints.py:26-165) on the first crystal's cell: data for the product's restatement
+    ref_kp = importlib.import_module("hamgnn.physics.kpoints")
+    nodes = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.5, 0.5, 0.0], [0.0, 0.0, 0.0], [0.5, 0.5, 0.5]]
+    lat0 = Gb["cell"][0].numpy()
+    kv_ref, _, _, lpi_ref = ref_kp.kpoints_generator(dim_k=3, lat=lat0).k_path(nodes, 23)
+    keys = ("z", "pos", "cell", "edge_index", "nbr_shift", "inv_edge_idx", "batch", "node_counts", "Son", "Soff", "k_vecs")
+    _save("band_energies_openmx_13", kpath=dict(nodes=np.asarray(nodes), nk=np.asarray(23), lat=lat0, k_vec=kv_ref, lat_per_inv=lpi_ref), graph={k: (Gb[k].float() if Gb[k].is_floating_point() else Gb[k]) for k in keys}, inputs=dict(Hon=Hon.float(), Hoff=Hoff.float()),
+          outputs=dict(band_energy=be_r, band_gap=gap_r, band_energy_window3=refk.calculate_band_energies(Hon, Hoff, Graph(Gb))[0]))
 
     # ---- 7. CorrProductBlock (optional MACE-style correlation product; interaction_blocks.py:168-260) ---------------
     print("CorrProductBlock")

@@ -25,6 +25,7 @@ tests/golden/*.npz generated from the reference's own modules (oracle/gen_golden
 from __future__ import annotations
 
 import json
+import numpy as np
 import math
 import os
 from typing import Dict, List, Optional
@@ -357,6 +358,8 @@ class HamGNNPlusPlusOut(nn.Module):
         self.index_change = torch.tensor(t["index_change"]) if t["index_change"] is not None else None
         self.minus_index = torch.tensor(t["minus_index"]) if t.get("minus_index") is not None else None
         self.basis_def = {int(k): v for k, v in t["basis_def"].items()}
+        self.num_valence = {int(k): v for k, v in t.get("num_valence", {}).items()}
+        self.band_num_control = None
         irr = Irreps([])
         for _, li in self.row:
             for _, lj in self.col:
@@ -616,3 +619,75 @@ class HamGNNPlusPlusOut(nn.Module):
         if self.zero_point_shift:
             Hr = self.soc_zero_point(data, Hr)
         return {"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi}
+
+
+# ---------------------------------------------------------------------------------------------- k-space step
+def calculate_band_energies(self, onsite_hamiltonian, offsite_hamiltonian, data):
+    """hamgnn/models/hamgnn_output.py:1675-1996 (export_reciprocal_values=False), same loop structure: per crystal, phase factors
+    exp(2 pi i k . nbr_shift) (:1779-1788), padded [num_k, n, n, nao, nao] H(k) / S(k) with on-site blocks on the diagonal (:1813-1821) and
+    off-site blocks accumulated at (source, target) (:1841-1862), orbital masked_select to the compact basis (:1897-1904), generalized
+    eigenproblem through the Cholesky factor of S(k) (:1911-1928), band gap at the half-filled band (:1930-1936), optional band window.
+    Returns (band_energy, wavefunction, band_gap, H_sym)."""
+    nao = self.nao_max
+    src, dst = data.edge_index
+    k_vecs = data.k_vecs
+    num_k = k_vecs.shape[1]
+    mask_tab = torch.zeros(99, nao)
+    for Z, idx in self.basis_def.items():
+        mask_tab[Z][idx] = 1
+    om = mask_tab[data.z]
+    nval = torch.zeros(99)
+    for Z, c in self.num_valence.items():
+        nval[Z] = c
+    node_counts = data.node_counts.tolist()
+    n_off = np.cumsum([0] + node_counts)
+    edge_counts = torch.bincount(data.batch[src], minlength=len(node_counts)).tolist()
+    e_off = np.cumsum([0] + edge_counts)
+    cdt = torch.complex128 if onsite_hamiltonian.dtype == torch.float64 else torch.complex64
+    bands, waves, gaps, hsyms = [], [], [], []
+    for c, n in enumerate(node_counts):
+        sl_n, sl_e = slice(n_off[c], n_off[c + 1]), slice(e_off[c], e_off[c + 1])
+        kp = k_vecs[c].to(onsite_hamiltonian.dtype)
+        phase = torch.exp(2j * math.pi * (data.nbr_shift[sl_e][:, None, :].to(kp.dtype) * kp[None, :, :]).sum(-1))     # [e, nk]
+        Hk = torch.zeros(num_k, n, n, nao, nao, dtype=cdt)
+        Sk = torch.zeros(num_k, n, n, nao, nao, dtype=cdt)
+        ar = torch.arange(n)
+        Hk[:, ar, ar] += onsite_hamiltonian[sl_n].reshape(-1, nao, nao)[None].to(cdt)
+        Sk[:, ar, ar] += data.Son[sl_n].reshape(-1, nao, nao)[None].to(cdt)
+        si, ti = src[sl_e] - n_off[c], dst[sl_e] - n_off[c]
+        Ho = offsite_hamiltonian[sl_e].reshape(-1, nao, nao).to(cdt)
+        So = data.Soff[sl_e].reshape(-1, nao, nao).to(cdt)
+        for k in range(num_k):
+            ph = phase[:, k].to(cdt)[:, None, None]
+            Hk[k] = torch.index_put(Hk[k], (si, ti), ph * Ho, accumulate=True)
+            Sk[k] = torch.index_put(Sk[k], (si, ti), ph * So, accumulate=True)
+        Hk = Hk.swapaxes(-2, -3).reshape(num_k, n * nao, n * nao)
+        Sk = Sk.swapaxes(-2, -3).reshape(num_k, n * nao, n * nao)
+        m = om[sl_n].reshape(-1)
+        keep = (m[:, None] * m[None, :] > 0)[None].expand(num_k, -1, -1)
+        norb = int(m.sum())
+        Hk = torch.masked_select(Hk, keep).reshape(num_k, norb, norb)
+        Sk = torch.masked_select(Sk, keep).reshape(num_k, norb, norb)
+        L = torch.linalg.cholesky(Sk)
+        LH = L.conj().transpose(-1, -2)
+        Linv, LHinv = torch.linalg.inv(L), torch.linalg.inv(LH)
+        Ht = torch.bmm(torch.bmm(Linv, Hk), LHinv)
+        ev, evec = torch.linalg.eigh(Ht)
+        evec = torch.einsum("ijk,ika->iaj", LHinv, evec)
+        half = math.ceil(float(nval[data.z[sl_n]].sum()) / 2)
+        gaps.append((ev[:, half].min() - ev[:, half - 1].max()).reshape(1))
+        bnc = self.band_num_control
+        if bnc is not None:
+            if isinstance(bnc, dict):
+                nb = int(sum(bnc[int(zz)] for zz in data.z[sl_n].tolist()))
+                ev, evec = ev[:, :nb], evec[:, :nb, :]
+            else:
+                win = max(1, int(bnc * half)) if isinstance(bnc, float) else min(bnc, half)
+                ev, evec = ev[:, half - win:half + win], evec[:, half - win:half + win, :]
+        bands.append(ev.transpose(-1, -2))
+        waves.append(evec.reshape(-1))
+        hsyms.append(Ht.reshape(-1))
+    return torch.cat(bands, 0), torch.cat(waves, 0), torch.cat(gaps, 0), torch.cat(hsyms, 0)
+
+
+HamGNNPlusPlusOut.calculate_band_energies = calculate_band_energies

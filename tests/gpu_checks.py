@@ -742,3 +742,42 @@ def check_attribute_style_graph(device="cuda"):
     res["sparsity_ratio"] = float(out["sparsity_ratio"])
     res["sparsity_ratio_fixture"] = float(fh["outputs"]["sparsity_ratio"][0])
     return res
+
+
+def check_band_energies(device="cuda"):
+    """k-space step (hg_hk_assemble + hipSOLVER through torch.linalg) vs the reference's calculate_band_energies output (fixture), fp32
+    complex64 on the GPU against the fp64 reference; and the head's forward with calculate_band_energy=True (random k: shapes, finiteness,
+    target bands == a direct call on the target blocks)."""
+    from hamgnn_amd import kspace
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load("band_energies_openmx_13")
+    head = HamGNNPlusPlusOut("4x0e", "4x0e", nao_max=13, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, soc_switch=False,
+                             calculate_band_energy=True, num_k=5, k_path=None, calculate_sparsity=False)
+    head.compile(device)
+    g = to_graph(f["graph"], device)
+    Hon, Hoff = (torch.from_numpy(f["inputs"][k]).float().to(device) for k in ("Hon", "Hoff"))
+    be, wf, gap, hs = kspace.band_energies(head, Hon, Hoff, g)
+    torch.cuda.synchronize()
+    scale = float(np.abs(f["outputs"]["band_energy"]).max())
+    res = {"band_energy_err": float((be.double().cpu() - torch.from_numpy(f["outputs"]["band_energy"])).abs().max()) / scale,
+           "band_gap_err": float((gap.double().cpu() - torch.from_numpy(f["outputs"]["band_gap"])).abs().max()) / scale,
+           "bands": tuple(be.shape)}
+    head.band_num_control = 3
+    be3 = kspace.band_energies(head, Hon, Hoff, g)[0]
+    res["window_err"] = float((be3.double().cpu() - torch.from_numpy(f["outputs"]["band_energy_window3"])).abs().max()) / scale
+    head.band_num_control = None
+    # through the forward: needs targets (Hon/Hoff) for the reference bands, like the reference
+    g["Hon"], g["Hoff"] = Hon, Hoff
+    rep = {"node_attr": torch.randn(g.z.shape[0], 4, device=device), "edge_attr": torch.randn(g.edge_index.shape[1], 4, device=device)}
+    np.random.seed(3)
+    out = head(g, rep)
+    torch.cuda.synchronize()
+    res["forward_ok"] = bool(out["band_energy"].shape == g["band_energy"].shape and torch.isfinite(out["band_energy"]).all()
+                             and out["band_gap"].shape[0] == 2 and tuple(g["k_vecs"].shape) == (2, 5, 3))
+    tb = kspace.band_energies(head, Hon, Hoff, g)[0]
+    res["targets_consistent"] = float((tb - g["band_energy"]).abs().max())
+    # a k-path through reduced nodes
+    head.k_path, head.num_k = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.5, 0.5, 0.0]], 7
+    out = head(g, rep)
+    res["kpath_ok"] = bool(out["band_energy"].shape[1] == 7 and torch.isfinite(out["band_energy"]).all())
+    return res

@@ -163,6 +163,15 @@ def test_si2_default_irreps_vs_oracle(which):
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL and r["Hnet_rel_err"] < G.TOL
 
 
+def test_band_energies_k_space_step():
+    """calculate_band_energy=True (non-SOC, reference overlaps) -- H(k) / S(k) assembly kernel + hipSOLVER eigensolver vs the
+    reference's output; fp32 complex arithmetic on the GPU against fp64: eigenvalues to 1e-4 of the spectrum's scale"""
+    r = G.check_band_energies()
+    print(r)
+    assert r["band_energy_err"] < 1e-4 and r["band_gap_err"] < 1e-4 and r["window_err"] < 1e-4
+    assert r["forward_ok"] and r["kpath_ok"] and r["targets_consistent"] < 1e-5
+
+
 def test_attribute_style_graph_object():
     """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
     r = G.check_attribute_style_graph()
