@@ -80,9 +80,14 @@ class HamGNNConvE3(nn.Module):
             raise ValueError(f"Unsupported radial basis function on the MI355X path: {g('rbf_func')}")
         self.lite_mode = bool(g("lite_mode", False))
         self.use_corr_prod = bool(g("use_corr_prod", False))
-        for k in ("use_kan", "build_internal_graph", "apply_charge_doping"):
+        for k in ("use_kan", "build_internal_graph"):
             if g(k, False):
                 raise NotImplementedError(f"HamGNN_pre.{k}=True is outside the MI355X hot-path scope of this round (SURVEY 8f)")
+        self.apply_charge_doping = bool(g("apply_charge_doping", False))                 # hamgnn_conv.py:147-153
+        if self.apply_charge_doping:
+            if self.use_corr_prod:
+                raise NotImplementedError("apply_charge_doping with use_corr_prod: the symmetric contraction gathers element weights by z")
+            self.atomic_embedding = hnn.ChargeEmbedding(self.num_types, int(g("num_charge_attr_feas", 8)))
         if g("edge_sh_normalization", "component") != "component" or not g("edge_sh_normalize", True):
             raise NotImplementedError("only component-normalised, normalised edge SH are supported")
         for _, l, p in self.irreps_edge_sh:
@@ -143,8 +148,17 @@ class HamGNNConvE3(nn.Module):
         topo.check_num_types(self.num_types)                   # z >= num_types would index past the embedding tables on the device
         geo = ops.Geometry(data.pos, data.edge_index, data.nbr_shift, self.cutoff, self.num_radial, self.lmax, self._jtab)
         Dp = self.layout.dim
-        f = self.pair_embedding.run(z, geo)                                          # [E, Dp] edge-aligned frame
-        node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)          # [N, Dp]
+        delta = None
+        if self.apply_charge_doping:                           # node_attrs = one_hot(z) + delta (toolbox/nequip/nn/embedding/_embedding_block.py:124-131)
+            q = gget(data, "doping_charge")
+            if q is None:
+                raise ValueError("apply_charge_doping=True needs data.doping_charge (scalar, one value per crystal, or one per atom)")
+            delta = self.atomic_embedding.to(dev).delta(q, gget(data, "batch"), N, dev)
+        f = self.pair_embedding.run(z, geo, delta)                                   # [E, Dp] edge-aligned frame
+        if delta is None:
+            node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)      # [N, Dp]
+        else:
+            node = (self._chem[z] + delta @ self._chem).contiguous()                # per-atom rows of the same table
         rowptr, perm = topo.receiver_csr()
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)

@@ -281,10 +281,56 @@ class PairInteractionEmbeddingBlock(nn.Module):
         self._h = self.conv_tp.weight_generator.hidden_layers(device)
         self._Tp = P.PlanarLayout([(T, 0, 1)]).dim
 
-    def run(self, z, geo: ops.Geometry):
-        x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, self.num_types, self._Tp)
+    def run(self, z, geo: ops.Geometry, delta=None):
+        """delta: optional [N, num_types] charge-doping correction of the node attributes -> per-atom source / target tables"""
+        if delta is not None:
+            Ts, Td = (self._Ts[z] + delta @ self._Ts).contiguous(), (self._Td[z] + delta @ self._Td).contiguous()
+            z = torch.arange(z.shape[0], device=z.device)
+            x = ops.embed_lookup(Ts, Td, z, geo.src, geo.dst, geo.E, self.num_types, self._Tp)
+        else:
+            x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, self.num_types, self._Tp)
         h = ops.radial_hidden(geo.rbf, self._h, float(P.ACT_CONSTS[P.ACT_SILU]))
         return ops.tp_fused(self._dp, [x], geo.E, h, None, geo, tag="embedding")      # edge features, edge-aligned frame
+
+
+class ChargeEmbedding(nn.Module):
+    """Embedding_block_q of the reference (hamgnn/toolbox/nequip/nn/embedding/_embedding_block.py:56-137), parameter names included
+    (`mlp_q.fcs.0.0.{weight,bias}`, `mlp_q.fc_out.{weight,bias}`): the charge-dependent CORRECTION of the one-hot node attributes,
+        delta[n] = mlp_q(gauss(q_n)) - mlp_q(gauss(0)),      node_attrs = one_hot(z) + delta.
+    delta is an [N, num_types] node-level quantity (usually one charge per crystal): F = 8 Gaussian features through an 8 -> 8 -> num_types
+    MLP.  It is evaluated with torch tensor ops on the device (a few kFLOP per atom, once per forward); everything that consumes it stays
+    on the HIP kernels: the embedding look-ups become per-ATOM tables `table[z] + delta @ table`."""
+
+    def __init__(self, num_types, num_charge_attr_feas=8):
+        super().__init__()
+        F = int(num_charge_attr_feas)
+        self.charge_min, self.charge_max = -8.0, 8.0
+        width = (self.charge_max - self.charge_min) / (F - 1) if F > 1 else 1.0
+        centers = torch.linspace(self.charge_min, self.charge_max, steps=F)
+        self.register_buffer("charge_centers", centers)
+        self.register_buffer("charge_gamma", torch.tensor(1.0 / width ** 2))
+        self.register_buffer("neutral_charge_attrs", torch.exp(-(1.0 / width ** 2) * centers * centers).view(1, -1))
+        self.mlp_q = nn.Module()
+        self.mlp_q.fcs = nn.ModuleList([nn.Sequential(nn.Linear(F, F, bias=True), nn.Softplus())])
+        self.mlp_q.fc_out = nn.Linear(F, num_types)
+
+    def _mlp(self, x):
+        for fc in self.mlp_q.fcs:
+            x = fc(x)
+        return self.mlp_q.fc_out(x)
+
+    def delta(self, doping_charge, batch, N, device):
+        q = torch.as_tensor(doping_charge, dtype=torch.float32, device=device)
+        q = q.view(1) if q.dim() == 0 else q
+        q = q.view(-1, 1) if q.dim() == 1 else q
+        if batch is not None and q.size(0) != N:
+            q = q[batch.view(-1)]
+        elif q.size(0) != N:
+            q = q[:1].expand(N, -1)
+        q = q.clamp(self.charge_min, self.charge_max)
+        diff = q - self.charge_centers.view(1, -1)
+        attrs = torch.exp(-self.charge_gamma * diff * diff)
+        return self._mlp(attrs) - self._mlp(self.neutral_charge_attrs.expand(attrs.size(0), -1))
 
 
 class HamLayer(nn.Module):

@@ -141,7 +141,7 @@ def install_stubs():
     emb = sys.modules["hamgnn.toolbox.nequip.nn.embedding"]
     emb.OneHotAtomEncoding = importlib.import_module("hamgnn.toolbox.nequip.nn.embedding._one_hot").OneHotAtomEncoding
     emb.SphericalHarmonicEdgeAttrs = importlib.import_module("hamgnn.toolbox.nequip.nn.embedding._edge").SphericalHarmonicEdgeAttrs
-    emb.Embedding_block_q = _Dummy
+    emb.Embedding_block_q = importlib.import_module("hamgnn.toolbox.nequip.nn.embedding._embedding_block").Embedding_block_q
 
 
 def _load_real_mace():
@@ -608,6 +608,32 @@ def main():
           graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
           outputs=dict(node_attr=r4["node_attr"], edge_attr=r4["edge_attr"]),
           meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg4["HamGNN_pre"]).items()}))))
+    # backbone with apply_charge_doping=True (hamgnn_conv.py:147-153; toolbox/nequip/nn/embedding/_embedding_block.py:56-137)
+    print("charge doping")
+    cfg5 = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, apply_charge_doping=True, num_charge_attr_feas=8).items()
+                                           if k != 'radius_scale'}))
+    torch.manual_seed(17)
+    ref5, mine5 = ref_conv.HamGNNConvE3(cfg5), R.HamGNNConvE3(dict(cfg5))
+    assert type(ref5.atomic_embedding).__name__ == "Embedding_block_q" and ref5.atomic_embedding.apply_charge_doping
+    with torch.no_grad():                                       # xavier / zero-bias init leaves mlp_q tiny: make the correction matter
+        for p_ in ref5.atomic_embedding.parameters():
+            p_.copy_(0.6 * torch.randn(p_.shape))
+    res = mine5.load_state_dict(ref5.state_dict(), strict=False)
+    assert not (set(res.missing_keys) & set(dict(mine5.named_parameters()))), res.missing_keys
+    outs5 = {}
+    for tag, q in (("scalar", torch.tensor(-1.75)), ("per_crystal", torch.tensor([0.6])), ("per_atom", torch.tensor([0.3, -2.0, 9.5]))):
+        G5 = Graph(G)
+        G5["doping_charge"] = q
+        r5, o5 = ref5(Graph(G5)), mine5(G5)
+        _check(o5["node_attr"], r5["node_attr"], f"backbone charge doping ({tag}) node_attr")
+        _check(o5["edge_attr"], r5["edge_attr"], f"backbone charge doping ({tag}) edge_attr")
+        outs5[f"q_{tag}"], outs5[f"node_attr_{tag}"], outs5[f"edge_attr_{tag}"] = q, r5["node_attr"], r5["edge_attr"]
+    G5["doping_charge"] = torch.tensor(0.0)                      # neutral: the correction vanishes identically
+    r5n = ref5(Graph(G5))
+    outs5["node_attr_neutral"], outs5["edge_attr_neutral"] = r5n["node_attr"], r5n["edge_attr"]
+    _save("backbone_charge_doping", weights={k: v for k, v in ref5.state_dict().items() if k in dict(mine5.named_parameters())},
+          graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
+          outputs=outs5, meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg5["HamGNN_pre"]).items()}))))
     print("ALL WIRING CHECKS PASSED")
 
 

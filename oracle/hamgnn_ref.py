@@ -252,6 +252,45 @@ def edge_geometry(pos, edge_index, nbr_shift, irreps_sh, cutoff, num_radial, sh_
     return sh, rbf * fc[:, None], r
 
 
+class Embedding_block_q(nn.Module):
+    """charge-doping node attributes (hamgnn/toolbox/nequip/nn/embedding/_embedding_block.py:56-137; mlp_q = denseRegression(n_h=2,
+    Softplus, no batch norm), hamgnn/utils/regression_layers.py:7-21, utils/mlp.py:11-35): one_hot(z) + mlp_q(gauss(q)) - mlp_q(gauss(0))"""
+
+    def __init__(self, num_types, num_charge_attr_feas):
+        super().__init__()
+        F = num_charge_attr_feas
+        self.charge_min, self.charge_max = -8.0, 8.0
+        width = (self.charge_max - self.charge_min) / (F - 1) if F > 1 else 1.0
+        centers = torch.linspace(self.charge_min, self.charge_max, steps=F)
+        self.register_buffer("charge_centers", centers)
+        self.register_buffer("charge_gamma", torch.tensor(1.0 / width ** 2))
+        self.register_buffer("neutral_charge_attrs", torch.exp(-(1.0 / width ** 2) * centers * centers).view(1, -1))
+        self.mlp_q = _Holder()
+        self.mlp_q.fcs = nn.ModuleList([nn.Sequential(nn.Linear(F, F, bias=True), nn.Softplus())])
+        self.mlp_q.fc_out = nn.Linear(F, num_types)
+
+    def _mlp(self, x):
+        for fc in self.mlp_q.fcs:
+            x = fc(x)
+        return self.mlp_q.fc_out(x)
+
+    def forward(self, data, one_hot):
+        q = data["doping_charge"] if "doping_charge" in data else data.doping_charge
+        q = torch.as_tensor(q).to(one_hot.dtype)
+        q = q.view(1) if q.dim() == 0 else q
+        q = q.view(-1, 1) if q.dim() == 1 else q
+        batch = data.get("batch") if hasattr(data, "get") else getattr(data, "batch", None)
+        if batch is not None and q.size(0) != one_hot.size(0):
+            q = q[batch.view(-1)]
+        elif q.size(0) != one_hot.size(0):
+            q = q[:1].expand(one_hot.size(0), -1)
+        q = q.clamp(self.charge_min, self.charge_max)
+        diff = q - self.charge_centers.view(1, -1).to(one_hot.dtype)
+        attrs = torch.exp(-self.charge_gamma.to(one_hot.dtype) * diff * diff)
+        neutral = self.neutral_charge_attrs.to(one_hot.dtype).expand(attrs.size(0), -1)
+        return one_hot + self._mlp(attrs) - self._mlp(neutral)
+
+
 class HamGNNConvE3(nn.Module):
     """cfg: mapping/namespace with the reference's HamGNN_pre keys (hamgnn/models/hamgnn_conv.py:89-147)."""
 
@@ -274,6 +313,9 @@ class HamGNNConvE3(nn.Module):
         attrs = Irreps([(self.num_types, (0, 1))])
         emb = Irreps([(self.num_radial, (0, 1))])
         D = self.irreps_node_features
+        self.apply_charge_doping = bool(c.get("apply_charge_doping", False))
+        if self.apply_charge_doping:                            # hamgnn_conv.py:147-153
+            self.atomic_embedding = Embedding_block_q(self.num_types, int(c.get("num_charge_attr_feas", 8)))
         self.pair_embedding = PairInteractionEmbeddingBlock(attrs, self.irreps_edge_sh, emb, D, mlp, self.lite_mode)
         self.chemical_embedding = _Holder()
         self.chemical_embedding.linear = Linear(attrs, D)
@@ -292,6 +334,8 @@ class HamGNNConvE3(nn.Module):
         dtype = self.chemical_embedding.linear.weight.dtype
         g = {"edge_index": data.edge_index}
         one_hot = torch.nn.functional.one_hot(data.z, self.num_types).to(dtype)
+        if self.apply_charge_doping:
+            one_hot = self.atomic_embedding(data, one_hot)
         g["node_attrs"] = g["node_features"] = one_hot
         sh, rbf, r = edge_geometry(data.pos.to(dtype), data.edge_index, data.nbr_shift.to(dtype), self.irreps_edge_sh, self.cutoff,
                                    self.num_radial, self.sh_normalize, self.sh_normalization)

@@ -179,6 +179,22 @@ def check_backbone(device="cuda", name="backbone"):
             "backbone_edge_rel_err": rel(rep["edge_attr"], f["outputs"]["edge_attr"])}
 
 
+def check_charge_doping(device="cuda"):
+    """apply_charge_doping=True (a ★ branch of HamGNNConvE3, hamgnn_conv.py:147-153) vs the reference fixture: scalar, per-crystal and
+    per-atom (one value past the clamp) charges; a neutral charge reproduces the undoped attributes."""
+    m, f = build_backbone_from_fixture(device, "backbone_charge_doping")
+    out = {}
+    for tag in ("scalar", "per_crystal", "per_atom", "neutral"):
+        g = to_graph(f["graph"], device)
+        g["doping_charge"] = torch.zeros((), device=device) if tag == "neutral" else torch.from_numpy(np.asarray(f["outputs"][f"q_{tag}"])).float().to(device)
+        rep = m(g)
+        torch.cuda.synchronize()
+        out[f"{tag}_node_rel_err"] = rel(rep["node_attr"], f["outputs"][f"node_attr_{tag}"])
+        out[f"{tag}_edge_rel_err"] = rel(rep["edge_attr"], f["outputs"][f"edge_attr_{tag}"])
+    out["effect_of_charge"] = rel(f["outputs"]["edge_attr_scalar"], f["outputs"]["edge_attr_neutral"])
+    return out
+
+
 def check_corr_product(device="cuda"):
     """CorrProductBlock (a21) vs the reference fixture: linear_pre -> symmetric contraction -> prod.linear -> linear_out + skip."""
     from hamgnn_amd import nn as hnn, ops, plan as P

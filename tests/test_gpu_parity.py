@@ -58,6 +58,13 @@ def test_backbone_use_corr_prod_golden():
     assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
 
 
+def test_backbone_charge_doping_golden():
+    r = G.check_charge_doping()
+    print(r)
+    assert r["effect_of_charge"] > 1e-3                                    # the fixture's charges do move the features
+    assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
+
+
 def test_backbone_golden():
     r = G.check_backbone()
     print(r)
