@@ -3,6 +3,7 @@ and `build_hamgnn_model(config)` (hamgnn/main.py:178-263: representation + outpu
 SystemExit(1) for unknown network / property names).  The CLI / trainer around them is the reference's training harness (out of scope)."""
 from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
 from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer
 from hamgnn_amd.models.model import Model  # noqa: F401
 
 
@@ -39,7 +40,9 @@ def build_hamgnn_model(config):
         if not _has(pre, "use_corr_prod"):
             _set(pre, "use_corr_prod", True)
         graph_representation = HamGNNConvE3(rep_cfg)
-    else:                                                      # incl. 'hamgnntransformer': alternate backbone, not on the MI355X path
+    elif net == "hamgnntransformer":
+        graph_representation = HamGNNTransformer(rep_cfg)
+    else:
         print(f"The network: {_get(setup, 'GNN_Net')} is not yet supported!")
         raise SystemExit(1)
     if str(_get(setup, "property")).lower() != "hamiltonian":

@@ -63,9 +63,11 @@ def _cfg_get(c, k, default=None):
     return getattr(c, k, default)
 
 
-class HamGNNConvE3(nn.Module):
-    def __init__(self, config):
-        super().__init__()
+class _BackboneBase(nn.Module):
+    """What HamGNNConvE3 and HamGNNTransformer share (hamgnn_conv.py:89-190 == hamgnn_transformer.py:37-112): config keys, atomic /
+    pair / chemical embedding, per-edge geometry, and the lazily converted result dict."""
+
+    def _init_common(self, config):
         c = _cfg_get(config, "HamGNN_pre", config)
         g = lambda k, d=None: _cfg_get(c, k, d)
         self.num_types = g("num_types")
@@ -79,7 +81,6 @@ class HamGNNConvE3(nn.Module):
         if str(g("rbf_func", "bessel")).lower() != "bessel":
             raise ValueError(f"Unsupported radial basis function on the MI355X path: {g('rbf_func')}")
         self.lite_mode = bool(g("lite_mode", False))
-        self.use_corr_prod = bool(g("use_corr_prod", False))
         for k in ("use_kan", "build_internal_graph"):
             if g(k, False):
                 raise NotImplementedError(f"HamGNN_pre.{k}=True is outside the MI355X hot-path scope of this round (SURVEY 8f)")
@@ -97,29 +98,12 @@ class HamGNNConvE3(nn.Module):
         self.pair_embedding = hnn.PairInteractionEmbeddingBlock(self.num_types, sh, D, R, mlp, self.lite_mode)
         self.chemical_embedding = nn.Module()
         self.chemical_embedding.linear = hnn.E3Linear(Irreps([(self.num_types, 0, 1)]), D)
-        self.convolutions = nn.ModuleList()
-        self.pair_interactions = nn.ModuleList()
-        if self.use_corr_prod:                                  # hamgnn_conv.py:193-218
-            self.corr_products = nn.ModuleList([hnn.CorrProductBlock(D, int(g("num_hidden_features")), int(g("correlation")), self.num_types, True)
-                                                for _ in range(self.num_layers)])
-        for i in range(self.num_layers):
-            self.convolutions.append(hnn.ConvBlockE3(D, sh, R, mlp, self.lite_mode))
-            skip = (i > 0) if self.legacy_edge_update else True
-            self.pair_interactions.append(hnn.PairInteractionBlock(D, sh, R, mlp, skip, self.legacy_edge_update, self.lite_mode))
         self.layout = P.PlanarLayout(D)
         self._compiled_for = None
+        return g
 
-    # ------------------------------------------------------------------------------------------------------------
-    def compile(self, device):
-        """(Re)pack all weights into MFMA fragment order and upload.  Call again after changing parameters."""
-        dev = torch.device(device)
+    def _compile_common(self, dev):
         self.pair_embedding.compile(dev)
-        for c, p in zip(self.convolutions, self.pair_interactions):
-            c.compile(dev)
-            p.compile(dev)
-        if self.use_corr_prod:
-            for c in self.corr_products:
-                c.compile(dev)
         lay = self.layout
         self._imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(dev)
         self._rot_tab = torch.from_numpy(P.rotate_table(lay)).to(dev)
@@ -136,9 +120,9 @@ class HamGNNConvE3(nn.Module):
         assert off == W.size
         self._chem = torch.from_numpy(table.astype(np.float32)).to(dev)
         self._compiled_for = dev
-        return self
 
-    def forward(self, data):
+    def _embed(self, data):
+        """-> (z, topology, geometry, node [N, Dp] planar, f [E, Dp] planar in the edge frame)"""
         dev = data.pos.device
         if self._compiled_for != dev:
             self.compile(dev)
@@ -159,6 +143,59 @@ class HamGNNConvE3(nn.Module):
             node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)      # [N, Dp]
         else:
             node = (self._chem[z] + delta @ self._chem).contiguous()                # per-atom rows of the same table
+        return z, topo, geo, node, f
+
+    def _representation(self, node, f, geo):
+        rep = Representation()
+        imap, rot_tab = self._imap, self._rot_tab
+        rep.set_lazy("node_attr", lambda: ops.from_planar(node, imap))
+        rep.set_lazy("edge_attr", lambda: ops.from_planar(ops.rotate_gather(f, None, geo, rot_tab, transpose=True), imap))
+        # extras for the MI355X head: skip the layout/frame round trip
+        rep["_node_planar"], rep["_edge_planar_rot"], rep["_geometry"] = node, f, geo
+        return rep
+
+    def _run_pair(self, pair, node, f, geo):
+        """PairInteractionBlock.forward (interaction_blocks.py:130-164)"""
+        if pair.use_skip_connections or not pair.legacy_edge_update:               # legacy layer-0: edge features kept (:154-156)
+            mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab)   # edge frame (+ fused skip linear)
+            if self.lite_mode and pair.use_skip_connections:
+                mix = pair.skip_linear(f, res=[mix])
+            f = mix
+        return f
+
+
+class HamGNNConvE3(_BackboneBase):
+    def __init__(self, config):
+        super().__init__()
+        self.use_corr_prod = bool(_cfg_get(_cfg_get(config, "HamGNN_pre", config), "use_corr_prod", False))
+        g = self._init_common(config)
+        D, sh, R, mlp = self.irreps_node_features, self.irreps_edge_sh, self.num_radial, self.radial_MLP
+        self.convolutions = nn.ModuleList()
+        self.pair_interactions = nn.ModuleList()
+        if self.use_corr_prod:                                  # hamgnn_conv.py:193-218
+            self.corr_products = nn.ModuleList([hnn.CorrProductBlock(D, int(g("num_hidden_features")), int(g("correlation")), self.num_types, True)
+                                                for _ in range(self.num_layers)])
+        for i in range(self.num_layers):
+            self.convolutions.append(hnn.ConvBlockE3(D, sh, R, mlp, self.lite_mode))
+            skip = (i > 0) if self.legacy_edge_update else True
+            self.pair_interactions.append(hnn.PairInteractionBlock(D, sh, R, mlp, skip, self.legacy_edge_update, self.lite_mode))
+
+    # ------------------------------------------------------------------------------------------------------------
+    def compile(self, device):
+        """(Re)pack all weights into MFMA fragment order and upload.  Call again after changing parameters."""
+        dev = torch.device(device)
+        for c, p in zip(self.convolutions, self.pair_interactions):
+            c.compile(dev)
+            p.compile(dev)
+        if self.use_corr_prod:
+            for c in self.corr_products:
+                c.compile(dev)
+        self._compile_common(dev)
+        return self
+
+    def forward(self, data):
+        z, topo, geo, node, f = self._embed(data)
+        N = z.shape[0]
         rowptr, perm = topo.receiver_csr()
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
@@ -169,16 +206,5 @@ class HamGNNConvE3(nn.Module):
             node = conv.residual(agg, extra=skip)
             if self.use_corr_prod:                              # CorrProductBlock.forward (interaction_blocks.py:234-260; hamgnn_conv.py:274-275)
                 node = self.corr_products[li](node, z)
-            # ---- PairInteractionBlock.forward (interaction_blocks.py:130-164)
-            if pair.use_skip_connections or not pair.legacy_edge_update:           # legacy layer-0: edge features kept (:154-156)
-                mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab)   # edge frame (+ fused skip linear)
-                if self.lite_mode and pair.use_skip_connections:
-                    mix = pair.skip_linear(f, res=[mix])
-                f = mix
-        rep = Representation()
-        imap, rot_tab = self._imap, self._rot_tab
-        rep.set_lazy("node_attr", lambda: ops.from_planar(node, imap))
-        rep.set_lazy("edge_attr", lambda: ops.from_planar(ops.rotate_gather(f, None, geo, rot_tab, transpose=True), imap))
-        # extras for the MI355X head: skip the layout/frame round trip
-        rep["_node_planar"], rep["_edge_planar_rot"], rep["_geometry"] = node, f, geo
-        return rep
+            f = self._run_pair(pair, node, f, geo)
+        return self._representation(node, f, geo)

@@ -15,9 +15,10 @@ from torch import nn
 # Non-learned buffers the reference / e3nn 0.5.0 keep in their state_dicts (constants a loader may drop): e3nn `output_mask` of
 # o3.Linear / o3.TensorProduct and the w3j constants of the code-generated sub-modules; BesselBasis.freqs (utils/basis_functions.py:190),
 # CosineCutoff.cutoff (utils/cutoff_functions.py:48), GaussianSmearing.offset (:216), ClebschGordanCoefficients.cg_* (physics/
-# Clebsch_Gordan_coefficients.py:27).  Anything else the model has no slot for is an error (a learned tensor would be lost silently).
+# Clebsch_Gordan_coefficients.py:27), the generalized-CG tensors U_matrix_{nu} of the MACE symmetric contraction (toolbox/mace/modules/
+# symmetric_contraction.py: register_buffer) and AttentionBlockE3.max_radius.  Anything else the model has no slot for is an error (a learned tensor would be lost silently).
 _IGNORABLE_LAST = ("output_mask", "freqs", "cutoff", "offset")
-_IGNORABLE_PREFIX_LAST = ("cg_", "_w3j", "w3j", "_big_w3j")
+_IGNORABLE_PREFIX_LAST = ("cg_", "_w3j", "w3j", "_big_w3j", "U_matrix_")
 
 
 def _is_ignorable(key: str) -> bool:
@@ -45,7 +46,8 @@ def load_reference_state_dict(module: nn.Module, state_dict: Dict[str, torch.Ten
     own = set(params) | set(dict(module.named_buffers()))
     unexpected = sorted(k for k in sd if k not in own)
     allow = tuple(allow_unexpected)
-    rogue = [k for k in unexpected if not _is_ignorable(k) and not k.startswith(allow)]
+    # (e3nn keeps an EMPTY `weight` buffer on tensor products whose weights are external or absent: nothing to lose there)
+    rogue = [k for k in unexpected if not _is_ignorable(k) and not k.startswith(allow) and sd[k].numel() > 0]
     if rogue:
         raise KeyError(f"checkpoint holds {len(rogue)} tensor(s) the model has no slot for, e.g. {rogue[:4]}")
     with torch.no_grad():

@@ -224,6 +224,40 @@ class ConvBlockE3(nn.Module):
         self.skip_linear.compile(device)
 
 
+class AttentionBlockE3(nn.Module):
+    """AttentionBlockE3 of the reference (hamgnn/nn/attention.py:167-360), parameter names included.  `linear_query` and `max_radius`
+    exist in the reference's state_dict but its forward never reads them (:339-340 use `linear_key` for key AND query): they are kept
+    as parameter slots so that checkpoints load verified."""
+
+    def __init__(self, irreps, irreps_sh, num_radial, num_heads, max_radius, radial_MLP):
+        super().__init__()
+        self.irreps, self.num_heads, self.cutoff = Irreps(irreps), int(num_heads), float(max_radius)
+        self._head_tab_np, self.head_dim = P.attention_head_table(self.irreps, self.num_heads)
+        self.register_buffer("max_radius", torch.tensor(float(max_radius)))
+        self.cutoff_func = nn.Module()
+        self.cutoff_func.cut_param = nn.Parameter(torch.tensor(10.0))                 # SoftUnitStepCutoff (utils/cutoff_functions.py:82)
+        self.linear_up_src, self.linear_up_tar, self.linear_up_edge = E3Linear(irreps, irreps), E3Linear(irreps, irreps), E3Linear(irreps, irreps)
+        self.residual = ResidualBlock(irreps, irreps)
+        self.conv_tp_value = MessagePackBlock(irreps, irreps, irreps_sh, irreps, num_radial, radial_MLP)
+        self.linear_key, self.linear_query = E3Linear(irreps, irreps), E3Linear(irreps, irreps)
+        self.skip_linear = E3Linear(irreps, irreps)
+
+    def compile(self, device):
+        for m in (self.linear_up_src, self.linear_up_tar, self.linear_up_edge, self.residual, self.linear_key, self.skip_linear):
+            m.compile(device)
+        self.conv_tp_value.compile(device, unrotate=True)      # values leave the kernel in the global frame, like ConvBlockE3's messages
+        self._head_tab = torch.from_numpy(self._head_tab_np).to(device)
+        self._cut = self.cutoff_func.cut_param.detach().float().reshape(1).contiguous().to(device)
+
+    def run(self, node, f, geo: ops.Geometry, rot_tab, rowptr, perm):
+        """node [N, Dp] planar (global frame), f [E, Dp] planar edge features (edge frame) -> new node rows (attention.py:315-360)"""
+        sc = self.skip_linear(node)
+        K = self.linear_key(node)
+        value = self.conv_tp_value.run_nodes(self.linear_up_src(node), self.linear_up_tar(node), self.linear_up_edge(f), geo, rot_tab)
+        agg = ops.attention_aggregate(K, value, geo, rowptr, perm, self._head_tab, self.num_heads, self.head_dim, self._cut, self.cutoff)
+        return self.residual(agg, extra=sc)
+
+
 class PairInteractionBlock(nn.Module):
     def __init__(self, irreps, irreps_sh, num_radial, radial_MLP, use_skip_connections=True, legacy_edge_update=False, lite_mode=False):
         super().__init__()

@@ -3,6 +3,7 @@ Every function launches hand-written HIP kernels from libhamgnn_hip.so; nothing 
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 from typing import List, Optional, Sequence
 
@@ -203,6 +204,22 @@ def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, N: 
     Dp = msg.shape[1]
     out = torch.empty(N, Dp, device=msg.device, dtype=torch.float32)
     check(lib().hg_segment_sum(ptr(msg), i64(msg.stride(0)), ptr(rowptr), ptr(perm), i64(N), i32(Dp), ptr(out), i64(Dp), _stream()), "hg_segment_sum")
+    return out
+
+
+@_on_tensor_device
+def attention_aggregate(K: torch.Tensor, V: torch.Tensor, geo: "Geometry", rowptr, perm, head_tab: torch.Tensor, H: int, head_dim: int,
+                        cut_param: torch.Tensor, cutoff: float) -> torch.Tensor:
+    """AttentionAggregation of the reference (hamgnn/nn/attention.py:126-164) with key = K[sender], query = K[receiver] and the soft
+    cutoff weight: [N, Dp] planar node rows from [E, Dp] planar value rows."""
+    N, Dp, E = int(K.shape[0]), int(K.shape[1]), geo.E
+    assert V.shape == (E, Dp) and V.stride(1) == 1 and K.stride(1) == 1
+    logits = torch.empty(E, H, device=K.device, dtype=torch.float32)
+    check(lib().hg_attn_logits(ptr(K), i64(K.stride(0)), ptr(geo.src), ptr(geo.dst), ptr(geo.length), ptr(head_tab), i32(Dp), i32(H),
+                               ptr(cut_param), f32(cutoff), f32(1.0 / math.sqrt(head_dim)), i64(E), ptr(logits), _stream()), "hg_attn_logits")
+    out = torch.empty(N, Dp, device=K.device, dtype=torch.float32)
+    check(lib().hg_attn_aggregate(ptr(logits), i32(H), ptr(V), i64(V.stride(0)), ptr(rowptr), ptr(perm), ptr(head_tab), i64(N), i32(Dp),
+                                  ptr(out), i64(Dp), _stream()), "hg_attn_aggregate")
     return out
 
 

@@ -787,6 +787,28 @@ def gate_tables_compact(tab: np.ndarray):
     return act_tab[:len(slots)] if slots else act_tab[:0], out
 
 
+def attention_head_table(irreps, num_heads: int):
+    """head of every planar column for AttentionAggregation (hamgnn/nn/attention.py:103-123, attention_utils.py:28-45): the reference
+    views each (mul x ir) block as [heads, mul / heads * dim], i.e. head h = channels [h mul/H, (h+1) mul/H) of the block, all m.
+    Returns (int32[Dp] head or -1 for padding columns, head dimension sum_k mul_k / H * (2 l_k + 1))."""
+    irreps = Irreps(irreps)
+    lay = PlanarLayout(irreps)
+    if not 1 <= num_heads <= 8:
+        raise NotImplementedError(f"num_heads = {num_heads}: the attention kernels hold 1..8 heads")
+    tab = np.full(lay.dim, -1, dtype=np.int32)
+    head_dim = 0
+    for k, (mul, l, p) in enumerate(irreps):
+        if mul % num_heads:
+            raise ValueError(f"irreps multiplicity {mul} (l={l}) is not divisible by num_heads={num_heads} "
+                             "(the reference's view(N, heads, -1) needs that, attention_utils.py:39-45)")
+        per = mul // num_heads
+        head_dim += per * (2 * l + 1)
+        for a in range(2 * l + 1):
+            o = lay.off[k] + a * lay.mulp[k]
+            tab[o:o + mul] = np.arange(mul) // per
+    return tab, head_dim
+
+
 def ham_irreps(row: Irreps):
     """hamiltonian_irreps of the reference head (hamgnn_output.py:258-272): per (row shell, col shell) all L, parity (-1)^(li+lj)."""
     out = []

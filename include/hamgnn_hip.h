@@ -193,6 +193,19 @@ int hg_hk_assemble(const float* on, const float* off, const float* nbr_shift, co
                    const int64_t* pair_edges, const int64_t* pair_ij, int64_t npairs, int n_atoms, int nao, const int32_t* orank,
                    const int32_t* ooff, int M, float* Hk, void* stream);
 
+/* AttentionBlockE3 / AttentionAggregation (hamgnn/nn/attention.py:91-164, 337-350; heads: hamgnn/nn/attention_utils.py:17-120).
+ * K [N, Dp]: planar rows of linear_key(node_feats) (key = K[sender], query = K[receiver], :339-340); head_tab int32[Dp]: head of a
+ * planar column (a head is a channel range of every irrep block) or -1 for padding columns; 1 <= H <= 8.
+ *   logits[e, h] = soft_unit_step(cut_param * (1 - length_e / cutoff)) * scale * <K[dst_e] | K[src_e]>_h ,  scale = 1 / sqrt(head dim);
+ *   cut_param: ONE device float (SoftUnitStepCutoff.cut_param, a learnable parameter, hamgnn/utils/cutoff_functions.py:65-100).      */
+int hg_attn_logits(const float* K, int64_t k_stride, const int64_t* src, const int64_t* dst, const float* length,
+                   const int32_t* head_tab, int Dp, int H, const float* cut_param, float cutoff, float scale, int64_t E,
+                   float* logits, void* stream);
+/* out[n, col] = sum_{q in [rowptr[n], rowptr[n+1])} softmax_q(logits[perm[q], head(col)]) * V[perm[q], col]  -- torch_geometric's
+ * softmax (max-shifted exp over a node's incoming edges, divided by (sum + 1e-16)) and torch_scatter.scatter, fixed order.           */
+int hg_attn_aggregate(const float* logits, int H, const float* V, int64_t v_stride, const int64_t* rowptr, const int64_t* perm,
+                      const int32_t* head_tab, int64_t N, int Dp, float* out, int64_t out_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

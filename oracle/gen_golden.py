@@ -634,6 +634,42 @@ def main():
     _save("backbone_charge_doping", weights={k: v for k, v in ref5.state_dict().items() if k in dict(mine5.named_parameters())},
           graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
           outputs=outs5, meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg5["HamGNN_pre"]).items()}))))
+    # ---- 8. attention backbone: HamGNNTransformer (hamgnn_transformer.py:36-250; nn/attention.py:91-360) -----------------
+    # third-party pieces absent here, restated from their published definitions (oracle/hamgnn_ref.py): torch_geometric.utils.softmax
+    # (PyG 2.x: max-shifted exp / (sum + 1e-16) per target node) and e3nn.math.soft_unit_step (exp(-1/x) for x > 0)
+    print("HamGNNTransformer")
+    importlib.import_module("torch_geometric.utils").softmax = lambda src, index: R.edge_softmax(src, index, int(index.max()) + 1)
+    importlib.import_module("hamgnn.utils.cutoff_functions").soft_unit_step = R.soft_unit_step
+    ref_tr = importlib.import_module("hamgnn.models.hamgnn_transformer")
+    att_irreps = "8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o"                      # multiplicities divisible by the two heads
+    cfg6 = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, irreps_node_features=att_irreps, num_heads=2,
+                                                                 num_hidden_features=4, correlation=2).items() if k != 'radius_scale'}))
+    torch.manual_seed(18)
+    ref6, mine6 = ref_tr.HamGNNTransformer(cfg6), R.HamGNNTransformer(dict(cfg6))
+    with torch.no_grad():
+        for blk in ref6.orb_transformers:
+            blk.cutoff_func.cut_param.fill_(3.5)                          # away from the init value: the parameter is exercised
+    res = mine6.load_state_dict(ref6.state_dict(), strict=False)
+    assert not (set(res.missing_keys) & set(dict(mine6.named_parameters()))), res.missing_keys
+    g6 = Graph(G)
+    r6, o6 = ref6(g6), mine6(G)
+    _check(o6["node_attr"], r6["node_attr"], "transformer node_attr")
+    _check(o6["edge_attr"], r6["edge_attr"], "transformer edge_attr")
+    # one attention block on its own (inputs = the embedding outputs of the same graph)
+    blk_r, blk_m = ref6.orb_transformers[0], mine6.orb_transformers[0]
+    sh6, rbf6, len6 = R.edge_geometry(G.pos, G.edge_index, G.nbr_shift, sh_irreps, 8.0, 8)
+    D6 = e3.Irreps(att_irreps).dim
+    xn6, xe6 = torch.randn(len(G.z), D6, generator=gen27), torch.randn(E, D6, generator=gen27)
+    gd = {"edge_index": G.edge_index, "node_features": xn6.clone(), "edge_features": xe6, "edge_attrs": sh6, "edge_embedding": rbf6, "edge_lengths": len6}
+    blk_r(gd)
+    gm = {"edge_index": G.edge_index, "node_features": xn6.clone(), "edge_features": xe6, "edge_attrs": sh6, "edge_embedding": rbf6, "edge_lengths": len6}
+    blk_m(gm)
+    _check(gm["node_features"], gd["node_features"], "AttentionBlockE3")
+    _save("backbone_transformer", weights={k: v for k, v in ref6.state_dict().items() if k in dict(mine6.named_parameters())},
+          graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
+          outputs=dict(node_attr=r6["node_attr"], edge_attr=r6["edge_attr"]),
+          block=dict(node_features=xn6, edge_features=xe6, out=gd["node_features"]),
+          meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg6["HamGNN_pre"]).items()}))))
     print("ALL WIRING CHECKS PASSED")
 
 

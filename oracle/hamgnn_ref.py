@@ -16,6 +16,8 @@ Each class cites the reference code it follows (paths relative to /root/referenc
   edge geometry                    hamgnn/toolbox/nequip/nn/embedding/_edge.py:59-67 ; hamgnn/nn/embeddings.py:73-100 ;
                                    hamgnn/utils/basis_functions.py:177-208 ; hamgnn/utils/cutoff_functions.py:35-61
   HamGNNConvE3                     hamgnn/models/hamgnn_conv.py:88-284
+  AttentionAggregation / AttentionBlockE3 / HamGNNTransformer
+                                   hamgnn/nn/attention.py:91-360 ; hamgnn/nn/attention_utils.py ; hamgnn/models/hamgnn_transformer.py:36-250
   HamLayer / HamGNNPlusPlusOut     hamgnn/models/hamgnn_output.py:38-58, 96-343, 851-891, 1056-1096, 1187-1285,
                                    2288-2365, 2916-3000, 3026-3144 (SOC so3), 3772-3799, 3966-4003
 
@@ -346,6 +348,140 @@ class HamGNNConvE3(nn.Module):
             conv(g)
             if self.use_corr_prod:                              # hamgnn_conv.py:274-275
                 g["node_features"] = self.corr_products[i](g["node_features"], g["node_attrs"])
+            pair(g)
+        return {"node_attr": g["node_features"], "edge_attr": g["edge_features"]}
+
+
+# ---------------------------------------------------------------------------------------------- attention backbone
+
+
+def soft_unit_step(x):
+    """e3nn.math.soft_unit_step (e3nn 0.5.0 math/_soft_unit_step.py): exp(-1/x) for x > 0, else 0"""
+    return torch.where(x > 0, torch.exp(-1.0 / torch.where(x > 0, x, torch.ones_like(x))), torch.zeros_like(x))
+
+
+def edge_softmax(src, index, num_nodes):
+    """torch_geometric.utils.softmax(src, index) (PyG 2.x utils/_softmax.py; third-party, absent here -- its published algorithm):
+    per group max subtracted, exp, divided by (group sum + 1e-16)"""
+    mx = src.new_full((num_nodes,) + src.shape[1:], -float("inf"))
+    mx = mx.scatter_reduce(0, index.view(-1, *([1] * (src.dim() - 1))).expand_as(src), src, reduce="amax", include_self=True)
+    out = (src - mx[index]).exp()
+    return out / (scatter_sum(out, index, num_nodes) + 1e-16)[index]
+
+
+def vector_to_heads(irreps_head, num_heads, x):
+    """VectorToAttentionHeads (hamgnn/nn/attention_utils.py:17-48): every (mul * heads) x ir block viewed as [heads, mul * dim]"""
+    out, i = [], 0
+    for mul, ir in irreps_head:
+        n = mul * num_heads * ir.dim
+        out.append(x[:, i:i + n].reshape(x.shape[0], num_heads, -1))
+        i += n
+    assert i == x.shape[1], "irreps multiplicities must be divisible by num_heads"
+    return torch.cat(out, 2)
+
+
+def heads_to_vector_att(irreps_head, x):
+    """AttentionHeadsToVector (hamgnn/nn/attention_utils.py:51-120)"""
+    sizes = [mul * ir.dim for mul, ir in irreps_head]
+    return torch.cat([t.reshape(x.shape[0], -1) for t in torch.split(x, sizes, dim=2)], 1)
+
+
+class AttentionAggregation(nn.Module):
+    """hamgnn/nn/attention.py:91-164; scale_irreps hamgnn/utils/irreps_utils.py:67-79"""
+
+    def __init__(self, num_heads, irreps):
+        super().__init__()
+        self.num_heads = num_heads
+        self.irreps_head = Irreps([(max(1, int(mul * (1 / num_heads))), ir) for mul, ir in Irreps(irreps)])
+
+    def forward(self, key, value, query, edge_weight_cutoff, edge_index, num_nodes):
+        key, value, query = (vector_to_heads(self.irreps_head, self.num_heads, t) for t in (key, value, query))
+        dst = edge_index[1]
+        w = (query * key).sum(-1)
+        if edge_weight_cutoff is not None:
+            w = edge_weight_cutoff[:, None] * w
+        w = edge_softmax(w / math.sqrt(self.irreps_head.dim), dst, num_nodes).unsqueeze(-1)
+        return heads_to_vector_att(self.irreps_head, scatter_sum(w * value, dst, num_nodes))
+
+
+class AttentionBlockE3(nn.Module):
+    """hamgnn/nn/attention.py:167-360.  As in the reference, BOTH key and query come from `linear_key` (`linear_query` is a parameter
+    that the forward never reads, :339-340) and the soft cutoff carries the learnable `cutoff_func.cut_param`
+    (hamgnn/utils/cutoff_functions.py:65-100)."""
+
+    def __init__(self, irreps, irreps_edge_attrs, irreps_edge_embed, num_heads, max_radius, radial_MLP):
+        super().__init__()
+        self.register_buffer("max_radius", torch.tensor(float(max_radius)))
+        self.cutoff_func = _Holder()
+        self.cutoff_func.cut_param = nn.Parameter(torch.tensor(10.0))
+        self.cutoff = float(max_radius)
+        self.linear_up_src, self.linear_up_tar, self.linear_up_edge = Linear(irreps, irreps), Linear(irreps, irreps), Linear(irreps, irreps)
+        self.residual = ResidualBlock(irreps, irreps)
+        self.conv_tp_value = MessagePackBlock(irreps, irreps, irreps_edge_attrs, irreps, irreps_edge_embed, radial_MLP)
+        self.linear_key, self.linear_query = Linear(irreps, irreps), Linear(irreps, irreps)
+        self.attention = AttentionAggregation(num_heads, irreps)
+        self.skip_linear = Linear(irreps, irreps)
+
+    def forward(self, g):
+        sender, receiver = g["edge_index"]
+        x = g["node_features"]
+        sc = self.skip_linear(x)
+        key, query = self.linear_key(x)[sender], self.linear_key(x)[receiver]
+        value = self.conv_tp_value(self.linear_up_src(x)[sender], self.linear_up_tar(x)[receiver], self.linear_up_edge(g["edge_features"]),
+                                   g["edge_attrs"], g["edge_embedding"])
+        cut = soft_unit_step(self.cutoff_func.cut_param * (1.0 - g["edge_lengths"] / self.cutoff))
+        x = self.attention(key, value, query, cut, g["edge_index"], x.shape[0])
+        g["node_features"] = self.residual(x) + sc
+        return g["node_features"]
+
+
+class HamGNNTransformer(nn.Module):
+    """hamgnn/models/hamgnn_transformer.py:36-250: the HamGNNConvE3 pipeline with AttentionBlockE3 in place of ConvBlockE3 and a
+    CorrProductBlock after every attention block (always on)."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        c = cfg if isinstance(cfg, dict) else vars(cfg)
+        c = c.get("HamGNN_pre", c)
+        self.num_types = c["num_types"]
+        self.irreps_edge_sh = Irreps(c["irreps_edge_sh"])
+        self.cutoff, self.num_radial, self.num_layers = float(c["cutoff"]), c["num_radial"], c["num_layers"]
+        self.sh_normalization = c.get("edge_sh_normalization", "component")
+        self.sh_normalize = c.get("edge_sh_normalize", True)
+        self.irreps_node_features = Irreps(c["irreps_node_features"])
+        assert c.get("rbf_func", "bessel").lower() == "bessel" and not c.get("use_kan", False) and not c.get("build_internal_graph", False)
+        mlp = list(c["radial_MLP"])
+        attrs = Irreps([(self.num_types, (0, 1))])
+        emb = Irreps([(self.num_radial, (0, 1))])
+        D = self.irreps_node_features
+        self.apply_charge_doping = bool(c.get("apply_charge_doping", False))
+        if self.apply_charge_doping:
+            self.atomic_embedding = Embedding_block_q(self.num_types, int(c.get("num_charge_attr_feas", 8)))
+        self.pair_embedding = PairInteractionEmbeddingBlock(attrs, self.irreps_edge_sh, emb, D, mlp)
+        self.chemical_embedding = _Holder()
+        self.chemical_embedding.linear = Linear(attrs, D)
+        from .mace_ref import CorrProductBlock
+        self.orb_transformers, self.corr_products, self.pair_interactions = nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for _ in range(self.num_layers):
+            self.orb_transformers.append(AttentionBlockE3(D, self.irreps_edge_sh, emb, int(c["num_heads"]), self.cutoff, mlp))
+            self.corr_products.append(CorrProductBlock(D, int(c["num_hidden_features"]), int(c["correlation"]), self.num_types, True))
+            self.pair_interactions.append(PairInteractionBlock(D, self.irreps_edge_sh, emb, D, mlp, True, bool(c.get("legacy_edge_update", False))))
+
+    def forward(self, data):
+        dtype = self.chemical_embedding.linear.weight.dtype
+        g = {"edge_index": data.edge_index}
+        one_hot = torch.nn.functional.one_hot(data.z, self.num_types).to(dtype)
+        if self.apply_charge_doping:
+            one_hot = self.atomic_embedding(data, one_hot)
+        g["node_attrs"] = g["node_features"] = one_hot
+        sh, rbf, r = edge_geometry(data.pos.to(dtype), data.edge_index, data.nbr_shift.to(dtype), self.irreps_edge_sh, self.cutoff,
+                                   self.num_radial, self.sh_normalize, self.sh_normalization)
+        g["edge_attrs"], g["edge_embedding"], g["edge_lengths"] = sh, rbf, r
+        self.pair_embedding(g)
+        g["node_features"] = self.chemical_embedding.linear(g["node_features"])
+        for att, corr, pair in zip(self.orb_transformers, self.corr_products, self.pair_interactions):
+            att(g)
+            g["node_features"] = corr(g["node_features"], g["node_attrs"])
             pair(g)
         return {"node_attr": g["node_features"], "edge_attr": g["edge_features"]}
 

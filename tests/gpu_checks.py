@@ -195,6 +195,69 @@ def check_charge_doping(device="cuda"):
     return out
 
 
+def check_transformer(device="cuda"):
+    """HamGNNTransformer (attention backbone) vs the reference fixture, and one AttentionBlockE3 on its own"""
+    from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer
+    from hamgnn_amd import ops, plan as P
+    from hamgnn_amd.topo import get_topology
+    f = load("backbone_transformer")
+    cfg = json.loads(str(f["meta"]["cfg"]))
+    m = load_weights(HamGNNTransformer(cfg), f["weights"])
+    g = to_graph(f["graph"], device)
+    rep = m(g)
+    torch.cuda.synchronize()
+    out = {"node_rel_err": rel(rep["node_attr"], f["outputs"]["node_attr"]), "edge_rel_err": rel(rep["edge_attr"], f["outputs"]["edge_attr"])}
+    lay = m.layout
+    geo = ops.Geometry(g.pos, g.edge_index, g.nbr_shift, m.cutoff, m.num_radial, m.lmax, m._jtab)
+    xn = ops.to_planar(torch.from_numpy(f["block"]["node_features"]).float().to(device), m._imap, lay.dim)
+    xe = torch.from_numpy(f["block"]["edge_features"]).float().to(device)
+    xe = ops.rotate_gather(ops.to_planar(xe, m._imap, lay.dim), None, geo, m._rot_tab)            # global -> edge frame
+    rowptr, perm = get_topology(g).receiver_csr()
+    y = ops.from_planar(m.orb_transformers[0].run(xn, xe, geo, m._rot_tab, rowptr, perm), m._imap)
+    torch.cuda.synchronize()
+    out["block_rel_err"] = rel(y, f["block"]["out"])
+    return out
+
+
+def check_transformer_vs_oracle(device="cuda", n_atoms=12, seed=3, heads=4, nao=19):
+    """attention backbone + head on a dense random crystal (up to ~190 incoming edges per atom, 4 heads, irreps up to l = 4, 2 layers) vs the
+    fp64 oracle; the soft cutoff parameter is moved off its initial value."""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    irr = "16x0e+8x0o+8x1o+4x1e+4x2o+8x2e+4x3o+4x3e+4x4e"
+    cfg = dict(num_types=20, irreps_edge_sh="0e+1o+2e+3o+4e", edge_sh_normalization="component", edge_sh_normalize=True,
+               build_internal_graph=False, cutoff=26.0, rbf_func="bessel", num_radial=16, num_layers=2, irreps_node_features=irr,
+               use_kan=False, radial_MLP=[32, 32], correlation=2, num_hidden_features=8, num_heads=heads, legacy_edge_update=False)
+    torch.manual_seed(700 + seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.HamGNNTransformer(dict(cfg))
+        ref_head = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True)
+        with torch.no_grad():
+            for b in ref.orb_transformers:
+                b.cutoff_func.cut_param.fill_(4.0)
+    finally:
+        torch.set_default_dtype(prev)
+    g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.02), nao, seed=seed)
+    hip = load_weights(HamGNNTransformer(cfg), dict(ref.state_dict()))
+    hip_head = load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                              soc_switch=False), dict(ref_head.state_dict()))
+    g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    with torch.no_grad():
+        rep_ref = ref(g64)
+        H_ref = ref_head(g64, rep_ref)["hamiltonian"]
+        gd = g.to(device)
+        rep = hip(gd)
+        H = hip_head(gd, rep)["hamiltonian"]
+    torch.cuda.synchronize()
+    deg = torch.bincount(g.edge_index[1])
+    return {"E": g.num_edges, "max_in_degree": int(deg.max()), "node_rel_err": rel(rep["node_attr"], rep_ref["node_attr"]),
+            "edge_rel_err": rel(rep["edge_attr"], rep_ref["edge_attr"]), "H_rel_err": rel(H, H_ref)}
+
+
 def check_corr_product(device="cuda"):
     """CorrProductBlock (a21) vs the reference fixture: linear_pre -> symmetric contraction -> prod.linear -> linear_out + skip."""
     from hamgnn_amd import nn as hnn, ops, plan as P

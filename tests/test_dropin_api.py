@@ -58,6 +58,48 @@ def test_missing_use_corr_prod_defaults_to_true_like_the_reference():
     assert rep.use_corr_prod and hasattr(rep, "corr_products")                  # main.py:216-217
 
 
+def test_transformer_backbone_through_build_hamgnn_model_and_verified_loading():
+    """GNN_Net: HamGNNTransformer (main.py:219-220): module tree / parameter names of the reference, weights load verified"""
+    from hamgnn.main import build_hamgnn_model
+    from hamgnn.models.hamgnn_transformer import HamGNNTransformer
+    from hamgnn_amd.models.model import load_reference_state_dict
+    from oracle import hamgnn_ref as R
+    cfg = _config()
+    cfg.setup.GNN_Net = "HamGNNTransformer"
+    cfg.representation_nets.HamGNN_pre.update(irreps_node_features="8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o", num_heads=2)
+    rep, out, _ = build_hamgnn_model(cfg)
+    assert isinstance(rep, HamGNNTransformer) and len(rep.orb_transformers) == 2 and len(rep.corr_products) == 2
+    ref = R.HamGNNTransformer(dict(cfg.representation_nets.HamGNN_pre))
+    theirs = {k for k, _ in ref.named_parameters()}
+    ours = {k for k, _ in rep.named_parameters()}
+    assert theirs == ours, sorted(theirs ^ ours)[:6]
+    assert "orb_transformers.0.cutoff_func.cut_param" in ours and "orb_transformers.1.linear_query.weight" in ours
+    sd = {k: torch.randn_like(v) for k, v in ref.state_dict().items()}
+    load_reference_state_dict(rep, sd)
+    assert torch.equal(rep.orb_transformers[1].linear_key.weight, sd["orb_transformers.1.linear_key.weight"].float())
+    bad = dict(sd)
+    bad["orb_transformers.0.linear_value.weight"] = bad.pop("orb_transformers.0.linear_key.weight")      # renamed parameter
+    with pytest.raises(KeyError):
+        load_reference_state_dict(rep, bad)
+    cfg.representation_nets.HamGNN_pre.num_heads = 3                             # 8x0e cannot be split over three heads
+    with pytest.raises(ValueError):
+        build_hamgnn_model(cfg)
+
+
+def test_attention_head_table():
+    from hamgnn_amd import plan as P
+    tab, hd = P.attention_head_table("8x0e+4x1o+2x2e", 2)
+    lay = P.PlanarLayout("8x0e+4x1o+2x2e")
+    assert hd == 4 + 2 * 3 + 1 * 5 and tab.shape == (lay.dim,)
+    assert tab[:8].tolist() == [0] * 4 + [1] * 4
+    o1 = lay.off[1]
+    for a in range(3):
+        assert tab[o1 + a * lay.mulp[1]:o1 + a * lay.mulp[1] + 4].tolist() == [0, 0, 1, 1]
+    o2 = lay.off[2]
+    assert tab[o2:o2 + lay.mulp[2]].tolist() == [0, 1] + [-1] * (lay.mulp[2] - 2)
+    assert (tab >= 0).sum() == 8 + 12 + 10
+
+
 def _fake_reference_checkpoint(model, extra=None):
     sd = {k: torch.randn_like(v) for k, v in model.state_dict().items()}
     sd["representation.radial_basis_functions.freqs"] = torch.arange(8.0)       # buffers the reference keeps in its state_dict

@@ -65,6 +65,19 @@ def test_backbone_charge_doping_golden():
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
 
+def test_transformer_backbone_golden():
+    r = G.check_transformer()
+    print(r)
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["block_rel_err"] < G.TOL
+
+
+def test_transformer_vs_oracle_random_crystal():
+    r = G.check_transformer_vs_oracle()
+    print(r)
+    assert r["max_in_degree"] > 130                                        # more than one LDS weight chunk of hg_attn_aggregate
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
+
+
 def test_backbone_golden():
     r = G.check_backbone()
     print(r)
