@@ -514,7 +514,7 @@ __global__ void from_planar_kernel(const float* __restrict__ xp, int64_t rows, i
     if (i >= rows * D) return;
     const int64_t r = i / D;
     const int k = (int)(i - r * D);
-    out[i] = xp[r * Dp + map[k]];
+    out[i] = map[k] >= 0 ? xp[r * Dp + map[k]] : 0.f;            // -1: structural zero (column gathers of the gradient layouts)
 }
 extern "C" int hg_to_planar(const float* x, int64_t rows, int D, const int32_t* map, float* out, int Dp, void* stream) {
     HgDeviceGuard dev_guard(stream);

@@ -165,6 +165,46 @@ class MessagePackBlock(nn.Module):
         self._dp = ops.DeviceProgram(prog, device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
         return self
 
+    # ---- backward, data gradient (the weight gradients are not built)
+    def compile_adjoint(self, device):
+        """upload the data-gradient program of this block (plan.build_message_pack_adjoint_program): same kernels, same weights"""
+        if self.lite_mode:
+            raise NotImplementedError("data gradient of a lite_mode MessagePackBlock")
+        prog = P.build_message_pack_adjoint_program(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
+        self._dp_adj = ops.DeviceProgram(prog, device, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
+        _, maps = P.message_pack_adjoint_layout(self.irreps_node, self.irreps_edge)
+        self._adj_maps = tuple(torch.from_numpy(m).to(device) for m in maps)
+        return self
+
+    def backward_data(self, grad_out, geo: ops.Geometry, out_is_global: bool, gather=None):
+        """grad_out [E, planar(irreps_out)]: gradient with respect to the rows this block's forward returned (global frame if the block
+        was compiled with unrotate=True, else edge frame); or, with `gather` = an [E] index tensor, NODE rows whose gather is that
+        per-edge gradient (the backward of the receiver scatter of a ConvBlockE3 is the gather grad_agg[receiver]; it is fused into the
+        kernel's staging like the forward's node gathers).  Returns per-edge gradients (g_src_rows, g_dst_rows, g_edge_rows), planar:
+        the first two in the GLOBAL frame, to be summed over the edges of each sender / receiver (ops.segment_sum over the sender /
+        receiver CSR) for the gradient of the gathered node rows; the third in the edge frame, where the forward read the edge rows."""
+        if getattr(self, "_dp_adj", None) is None:
+            self.compile_adjoint(grad_out.device)
+        cst = float(P.ACT_CONSTS[P.ACT_SILU])
+        hn = ops.radial_hidden(geo.rbf, self._hn, cst)
+        he = ops.radial_hidden(geo.rbf, self._he, cst)
+        dp = self._dp_adj
+        if dp.sched is not None:
+            g = ops.tp_fused(dp, [grad_out], geo.E, hn, he, geo, tag="message_pack_adjoint", gather=[gather], rot_mask=1 if out_is_global else 0)
+        else:
+            if out_is_global:
+                src = ops.rotate_gather(grad_out, gather, geo, self._rot_tab_out(grad_out.device))
+            else:
+                src = grad_out if gather is None else grad_out[gather].contiguous()
+            g = ops.tp_fused(dp, [src], geo.E, hn, he, geo, tag="message_pack_adjoint")
+        ims, imd, ime = self._adj_maps
+        return ops.from_planar(g, ims), ops.from_planar(g, imd), ops.from_planar(g, ime)      # column gathers (-1 = padding slot -> 0)
+
+    def _rot_tab_out(self, device):
+        if getattr(self, "_rt_out", None) is None:
+            self._rt_out = torch.from_numpy(P.rotate_table(P.PlanarLayout(self.irreps_out))).to(device)
+        return self._rt_out
+
     def run(self, xs_rot, xd_rot, f_rot, geo: ops.Geometry):
         """xs_rot/xd_rot/f_rot: planar rows in the edge-aligned frame.  Returns planar [E, Dp] (global frame if unrotate)."""
         cst = float(P.ACT_CONSTS[P.ACT_SILU])

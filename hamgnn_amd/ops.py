@@ -53,7 +53,8 @@ class DeviceProgram:
 
     def __init__(self, prog: P.Program, device, schedule: str = "seg"):
         """schedule: "seg" = segment-stationary kernel only (hg_tp_fused); "is" / "auto" = also build the input-stationary
-        schedule (hg_tp_is); "auto" silently keeps "seg" when it does not fit."""
+        schedule (hg_tp_is); "auto" silently keeps "seg" when it does not fit; "is_parts" = input-stationary with the output segments
+        spread over as many workgroups per 16-edge tile as their LDS tiles need (plan.lds_partition)."""
         self.prog = prog
         self.weights = _dev(prog.weights, device)
         self.segs = _dev(prog.seg_table, device)
@@ -67,14 +68,18 @@ class DeviceProgram:
         self.sched = None
         self._device = device
         self._is_tables = {}                                   # parts -> (IsSchedule, device tables)
-        if schedule in ("is", "auto"):
+        self.fixed_parts = None                                # "lds": the tiles of all output segments need several workgroups per 16 edges
+        if schedule in ("is", "auto", "is_parts"):             # "is_parts": input-stationary, over several workgroups per tile if need be
             try:
                 self.sched = self.is_tables(1)[0]
             except NotImplementedError:
                 if schedule == "is":
                     raise
+                if schedule == "is_parts":
+                    self.sched = self.is_tables("lds")[0]
+                    self.fixed_parts = "lds"
 
-    def is_tables(self, parts: int):
+    def is_tables(self, parts):
         """(schedule, device tables) of the input-stationary kernel split into `parts` sub-schedules (built on first use)"""
         if parts not in self._is_tables:
             sc = P.is_schedule(self.prog, parts)
@@ -86,6 +91,8 @@ class DeviceProgram:
         """How many workgroups share one 16-edge tile.  The chip holds 512 workgroups of this kernel (2 per CU); a launch with fewer
         tiles than that is a latency problem -- every workgroup walks the whole program serially -- so the output segments are spread
         over 8 (or one per segment) workgroups per tile while the extra staging work still fits the idle CUs."""
+        if self.fixed_parts is not None:
+            return self.fixed_parts
         forced = os.environ.get("HG_IS_PARTS")
         if forced:
             return max(1, int(forced))

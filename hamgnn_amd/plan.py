@@ -212,10 +212,36 @@ def _item_cost(rec, segs, hp4):
     return c
 
 
-def is_schedule(prog: "Program", parts: int = 1) -> IsSchedule:
+def lds_partition(prog: "Program") -> List[int]:
+    """owner part of every output segment when the tiles of ALL segments do not fit one workgroup's LDS (the data-gradient programs:
+    three feature rows of output per edge): first-fit decreasing on the tile sizes, capacity = the LDS minus the trash row, the largest
+    staged input block and the claim counter."""
+    nseg = prog.seg_table.shape[0]
+    size = [int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) for s in prog.seg_table]
+    maxstride = max((2 * int(s[0]) + 1) * 16 + 4 for s in prog.seg_table)
+    need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256 for r in prog.item_table)
+    cap = IS_LDS_BYTES // 4 - maxstride - need - 4
+    bins: List[int] = []
+    owner = [0] * nseg
+    for sg in sorted(range(nseg), key=lambda i: -size[i]):
+        if size[sg] > cap:
+            raise NotImplementedError("input-stationary schedule: one output segment's tile does not fit the LDS next to the staging area")
+        for b in range(len(bins)):
+            if bins[b] + size[sg] <= cap:
+                bins[b] += size[sg]
+                owner[sg] = b
+                break
+        else:
+            owner[sg] = len(bins)
+            bins.append(size[sg])
+    return owner
+
+
+def is_schedule(prog: "Program", parts=1) -> IsSchedule:
     """Regroup a finalized fused-kernel program for the input-stationary kernel.  Input irrep blocks (per source set) are packed
     into phases whose staged rows fit the staging area; every item reading a staged block runs in that phase.  Raises
     NotImplementedError when the tiles of all output segments + a useful staging area do not fit IS_LDS_BYTES.
+    parts = "lds": the fewest parts whose tiles fit the LDS (programs with more output than one workgroup can hold).
     parts > 1: the output segments are split into `parts` sets of equal estimated cost (LPT); each set gets its own sub-schedule
     (tiles, phases, groups) and runs in its own workgroup (grid.y) -- the per-tile latency drops at the price of staging the input
     blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots."""
@@ -226,9 +252,13 @@ def is_schedule(prog: "Program", parts: int = 1) -> IsSchedule:
     seg_cost = np.zeros(nseg)
     for rec in prog.item_table:
         seg_cost[int(rec[19])] += _item_cost(rec, prog.seg_table, hp4)
-    parts = max(1, min(int(parts), nseg))
     owner = np.zeros(nseg, dtype=np.int64)
-    if parts > 1:
+    if parts == "lds":                                         # as few parts as the LDS allows (see lds_partition)
+        owner = np.asarray(lds_partition(prog), dtype=np.int64)
+        parts = int(owner.max()) + 1
+    else:
+        parts = max(1, min(int(parts), nseg))
+    if parts > 1 and not owner.any():
         load = [0.0] * parts
         for sg in np.argsort(-seg_cost, kind="stable"):
             r = load.index(min(load))
@@ -443,17 +473,16 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
 # ------------------------------------------------------------------------------------------------ builders
 
 
-def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
-                 irreps_sh: Irreps, irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray,
-                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False):
-    """Items of ONE reference tensor-product branch (node or edge) of a MessagePackBlock / embedding TP.
-
-    in_layout : planar layout of ONE source row (irreps of the un-doubled features); nsrc = 2 for the node branch
-                (reference input = (2 mul) x ir with the first mul channels from src, the rest from dst: attention_utils.py:85-119).
-    tp_weight : flat o3.TensorProduct.weight;  w3: last radial layer [H, n_chan] already divided by sqrt(H);
-    lin_scale_w: flat LinearScaleWithWeights.linear_out.weight;  lin_out_w: flat trailing o3.Linear(out->out) or None.
-    uvu       : lite_mode product (tensor_products.py:81-84,127-130): no TP weights, mid multiplicity = input multiplicity.
-    """
+def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps_out: Irreps, tp_weight, w3: np.ndarray,
+                   lin_scale_w: np.ndarray, lin_out_w: Optional[np.ndarray], uvu: bool):
+    """The algebra of ONE reference tensor-product branch in the edge-aligned frame, as "super-paths" (input irrep i, output irrep k):
+    all e3nn paths (i, l_sh, k) stacked along `rows` (row = (path, mid channel w)).  Yields dicts with
+        W  [nrows, mul_i * nsrc]  TP weights x path normalisation        (mid[row] = sum_u W[row, u] x_i[u])
+        ch [nrows]                column of the last radial layer w3      (s[row]   = sum_h w3[h, ch[row]] h2[h])
+        cf [nrows, 2 mm + 1]      aligned-frame CG coefficient per column (mm = min(l_i, l_k))
+        L  [nrows, mul_k]         LinearScaleWithWeights.linear_out (x trailing o3.Linear) rows
+        par                       1: column c reads input component l_i + mm - c (reversed), 0: l_i - mm + c
+    and the flop count of the super-path per edge.  out[k][w'', c] += sum_rows L[row, w''] cf[row, c] s[row] mid[row, c]."""
     irr_in = Irreps([(m * nsrc, l, p) for m, l, p in in_layout.irreps])
     ins = tp_instructions(irr_in, irreps_sh, irreps_out)
     # flat TP weight offsets follow the instruction (slot) order; radial channels follow the sorted mid layout
@@ -486,13 +515,8 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
         o += mk * mk
     if lin_out_w is not None:
         assert o == lin_out_w.size
-
-    H = prog.hidden
     for k in order:
         mk, lk, pk = irreps_out[k]
-        if mk > seg_rows_cap(lk):
-            raise NotImplementedError(f"tensor-product target {mk}x(l={lk}) is wider than the {seg_rows_cap(lk)} channels one LDS tile holds")
-        seg = seg_of_k[k]
         off, fan = lin_off[k]
         L = lin_scale_w[off:off + fan * mk].reshape(fan, mk).astype(np.float64) / math.sqrt(fan)
         if lin_out_w is not None:
@@ -505,11 +529,11 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
             by_i.setdefault(ins[n][0], []).append(n)
         for i, plist in by_i.items():
             mi2, li, pi = irr_in[i]
-            mi = mi2 // nsrc
             mm = min(li, lk)
             nc = 2 * mm + 1
             par = None
             rows_W, rows_ch, rows_cf, rows_L = [], [], [], []
+            flops = 0.0
             for n in plist:
                 _, j, _, _ = ins[n]
                 lj = irreps_sh[j][1]
@@ -530,41 +554,113 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
                     rows_ch.append(choff[n] + w)
                     rows_cf.append(cf)
                     rows_L.append(L[choff[n] - ch0 + w])
-                prog.flops_per_row += (0.0 if uvu else 2.0 * mi2 * mk * nc) + 2.0 * H * mmid + 2.0 * mmid * mk * nc + 2.0 * mmid * nc
-            rows_W, rows_cf, rows_L = np.array(rows_W), np.array(rows_cf), np.array(rows_L)
-            nrows = len(rows_ch)
-            chunk = rtm_max(nc) * 16
-            ksteps = in_layout.mulp[i] // 4
+                flops += (0.0 if uvu else 2.0 * mi2 * mk * nc) + 2.0 * mmid * nc      # + 2 H mmid + 2 mmid mk nc, added by the caller (H)
+                flops += 2.0 * mmid * mk * nc
+            yield dict(i=i, k=k, mi=mi2 // nsrc, li=li, mk=mk, lk=lk, mm=mm, par=par, W=np.array(rows_W), ch=np.array(rows_ch),
+                       cf=np.array(rows_cf), L=np.array(rows_L), flops=flops, nmid=len(rows_ch))
+
+
+def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
+                 irreps_sh: Irreps, irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray,
+                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False):
+    """Items of ONE reference tensor-product branch (node or edge) of a MessagePackBlock / embedding TP.
+
+    in_layout : planar layout of ONE source row (irreps of the un-doubled features); nsrc = 2 for the node branch
+                (reference input = (2 mul) x ir with the first mul channels from src, the rest from dst: attention_utils.py:85-119).
+    tp_weight : flat o3.TensorProduct.weight;  w3: last radial layer [H, n_chan] already divided by sqrt(H);
+    lin_scale_w: flat LinearScaleWithWeights.linear_out.weight;  lin_out_w: flat trailing o3.Linear(out->out) or None.
+    uvu       : lite_mode product (tensor_products.py:81-84,127-130): no TP weights, mid multiplicity = input multiplicity.
+    """
+    H = prog.hidden
+    for sp in _tp_superpaths(nsrc, in_layout, irreps_sh, irreps_out, tp_weight, w3, lin_scale_w, lin_out_w, uvu):
+        i, k, mi, li, mk, lk, mm, par = sp["i"], sp["k"], sp["mi"], sp["li"], sp["mk"], sp["lk"], sp["mm"], sp["par"]
+        if mk > seg_rows_cap(lk):
+            raise NotImplementedError(f"tensor-product target {mk}x(l={lk}) is wider than the {seg_rows_cap(lk)} channels one LDS tile holds")
+        seg = seg_of_k[k]
+        nc = 2 * mm + 1
+        rows_W, rows_ch, rows_cf, rows_L = sp["W"], sp["ch"], sp["cf"], sp["L"]
+        prog.flops_per_row += sp["flops"] + 2.0 * H * sp["nmid"]
+        nrows = len(rows_ch)
+        chunk = rtm_max(nc) * 16
+        ksteps = in_layout.mulp[i] // 4
+        for r0 in range(0, nrows, chunk):
+            r1 = min(nrows, r0 + chunk)
+            n = r1 - r0
+            rtm = ceil_div(n, 16)
+            # physical row of logical row rho: within each 16-row tile the (g, r) index of the C fragment is transposed so
+            # that GEMM2's K-step (rt, r) -- which reads rows {16 rt + 4 g + r : g} -- holds logical rows 16 rt + 4 r + g:
+            # padding rows fill whole trailing K-steps and only ceil(n / 4) of the 4 rtm K-steps are issued (item[18])
+            rho = np.arange(n)
+            phys = 16 * (rho // 16) + 4 * (rho % 4) + (rho % 16) // 4
+            R = rtm * 16
+            a1 = []
+            x4 = use_x4(in_layout.mulp[i], nc)
+            for s_ in range(nsrc):
+                Wk = np.zeros((mi, R))
+                Wk[:, phys] = rows_W[r0:r1, s_ * mi:(s_ + 1) * mi].T             # [u, physical row]
+                a1.append(_frag_A(Wk, ksteps, rtm, x4))
+            a1_off = prog.add_weights(np.stack(a1))
+            w3p = np.zeros((w3.shape[0], R))
+            w3p[:, phys] = w3[:, rows_ch[r0:r1]]
+            w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
+            cfp = np.zeros((R, nc))
+            cfp[phys] = rows_cf[r0:r1]
+            cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))       # [rt][c][g][r]
+            rto = prog.segs[seg][2]
+            Lp = np.zeros((R, rto * 16))
+            Lp[phys, :mk] = rows_L[r0:r1]
+            # A2[rt'][rt][lane][r]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
+            a2 = Lp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4)
+            a2_off = prog.add_weights(a2)
+            _add_item(prog, seg, IT_TP, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, par, ksteps, rtm, mlp,
+                      a1_off, w3_off, cf_off, a2_off, n, nk2=ceil_div(n, 4))
+
+
+def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_g: int, gout_layout: PlanarLayout, irreps_sh: Irreps,
+                         irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray, lin_out_w: Optional[np.ndarray],
+                         mlp: int, target_base: int):
+    """DATA-GRADIENT items of one tensor-product branch: the adjoint of add_tp_items with respect to the branch's input rows, on the
+    SAME kernels.  With out[k] = sum_rows L^T (cf s (W x_i)) the gradient is  g_x[i] = sum_rows W^T (cf' s (L g_out[k]))  -- the same
+    item shape with the roles of the two weight matrices swapped: GEMM1 contracts the staged g_out block of irrep k (source slot
+    `src_g`, layout `gout_layout`) with L, the radial scale and the CG coefficient are those of the forward item, GEMM2 applies W^T
+    and accumulates into the tile of the program's output irrep `target_base + i` = the (nsrc * mul_i) x l_i block of the input
+    gradient (sender channels first, then receiver: the reference's doubled input).  Column bookkeeping: the forward reads input
+    component l_i - mm + c (par = 0) or l_i + mm - c (par = 1) for output column l_k - mm + c; the adjoint reads g_out component
+    l_k - mm + c' resp. l_k + mm - c' for its output column l_i - mm + c', i.e. the same `neg` flag with c' = c resp. 2 mm - c."""
+    H = prog.hidden
+    for sp in _tp_superpaths(nsrc, in_layout, irreps_sh, irreps_out, tp_weight, w3, lin_scale_w, lin_out_w, False):
+        i, k, mi, li, mk, lk, mm, par = sp["i"], sp["k"], sp["mi"], sp["li"], sp["mk"], sp["lk"], sp["mm"], sp["par"]
+        nc = 2 * mm + 1
+        rows_W, rows_ch, rows_L = sp["W"], sp["ch"], sp["L"]
+        rows_cf = sp["cf"][:, ::-1] if par else sp["cf"]
+        prog.flops_per_row += sp["flops"] + 2.0 * H * sp["nmid"]
+        nrows = len(rows_ch)
+        chunk = rtm_max(nc) * 16
+        ksteps = gout_layout.mulp[k] // 4
+        x4 = use_x4(gout_layout.mulp[k], nc)
+        for seg, c0, c1 in prog.seg_chunks[target_base + i]:  # column chunks of the (nsrc * mul_i) target channels
+            rto = prog.segs[seg][2]
             for r0 in range(0, nrows, chunk):
                 r1 = min(nrows, r0 + chunk)
                 n = r1 - r0
                 rtm = ceil_div(n, 16)
-                # physical row of logical row rho: within each 16-row tile the (g, r) index of the C fragment is transposed so
-                # that GEMM2's K-step (rt, r) -- which reads rows {16 rt + 4 g + r : g} -- holds logical rows 16 rt + 4 r + g:
-                # padding rows fill whole trailing K-steps and only ceil(n / 4) of the 4 rtm K-steps are issued (item[18])
                 rho = np.arange(n)
-                phys = 16 * (rho // 16) + 4 * (rho % 4) + (rho % 16) // 4
+                phys = 16 * (rho // 16) + 4 * (rho % 4) + (rho % 16) // 4        # see add_tp_items
                 R = rtm * 16
-                a1 = []
-                x4 = use_x4(in_layout.mulp[i], nc)
-                for s_ in range(nsrc):
-                    Wk = np.zeros((mi, R))
-                    Wk[:, phys] = rows_W[r0:r1, s_ * mi:(s_ + 1) * mi].T             # [u, physical row]
-                    a1.append(_frag_A(Wk, ksteps, rtm, x4))
-                a1_off = prog.add_weights(np.stack(a1))
+                Lk = np.zeros((mk, R))
+                Lk[:, phys] = rows_L[r0:r1].T                                     # [w'' (K of GEMM1), physical row]
+                a1_off = prog.add_weights(_frag_A(Lk, ksteps, rtm, x4)[None])
                 w3p = np.zeros((w3.shape[0], R))
                 w3p[:, phys] = w3[:, rows_ch[r0:r1]]
                 w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
                 cfp = np.zeros((R, nc))
                 cfp[phys] = rows_cf[r0:r1]
-                cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))       # [rt][c][g][r]
-                rto = prog.segs[seg][2]
-                Lp = np.zeros((R, rto * 16))
-                Lp[phys, :mk] = rows_L[r0:r1]
-                # A2[rt'][rt][lane][r]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
-                a2 = Lp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4)
+                cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))
+                Wp = np.zeros((R, rto * 16))
+                Wp[phys, :c1 - c0] = rows_W[r0:r1, c0:c1]                          # [physical row, target channel u]
+                a2 = Wp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4)
                 a2_off = prog.add_weights(a2)
-                _add_item(prog, seg, IT_TP, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, par, ksteps, rtm, mlp,
+                _add_item(prog, seg, IT_TP, [src_g], gout_layout.off[k], gout_layout.mulp[k], lk, mm, par, ksteps, rtm, mlp,
                           a1_off, w3_off, cf_off, a2_off, n, nk2=ceil_div(n, 4))
 
 
@@ -656,6 +752,51 @@ def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_ed
                  np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]), mlp=1)
     if skip_weight is not None:
         add_linear_items(prog, seg_of_k, PlanarLayout(irreps_edge), SRC_F, irreps_out, np.asarray(skip_weight))
+    return prog.finalize()
+
+
+def message_pack_adjoint_layout(irreps_node, irreps_edge):
+    """output irreps of the data-gradient program: the doubled node irreps (sender channels, then receiver channels, per irrep -- the
+    reference's concatenated node-branch input, message_passing.py:207-214) followed by the edge irreps; + for every planar column of a
+    node / edge feature row its column in that layout: (imap_src, imap_dst, imap_edge), each int32[Dp]."""
+    irreps_node, irreps_edge = Irreps(irreps_node), Irreps(irreps_edge)
+    adj = Irreps([(2 * m, l, p) for m, l, p in irreps_node] + [(m, l, p) for m, l, p in irreps_edge])
+    lay, ln, le = PlanarLayout(adj), PlanarLayout(irreps_node), PlanarLayout(irreps_edge)
+    imap_s, imap_d, imap_e = (np.full(ln.dim, -1, np.int32), np.full(ln.dim, -1, np.int32), np.full(le.dim, -1, np.int32))
+    for i, (m, l, p) in enumerate(irreps_node):
+        for a in range(2 * l + 1):
+            o, oc = ln.off[i] + a * ln.mulp[i], lay.off[i] + a * lay.mulp[i]
+            imap_s[o:o + m] = oc + np.arange(m)
+            imap_d[o:o + m] = oc + m + np.arange(m)
+    nb = len(irreps_node)
+    for i, (m, l, p) in enumerate(irreps_edge):
+        for a in range(2 * l + 1):
+            o, oc = le.off[i] + a * le.mulp[i], lay.off[nb + i] + a * lay.mulp[nb + i]
+            imap_e[o:o + m] = oc + np.arange(m)
+    return adj, (imap_s, imap_d, imap_e)
+
+
+def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out) -> Program:
+    """DATA GRADIENT of a (non-lite) MessagePackBlock forward (message_passing.py:191-231) as a program for the same fused kernels:
+    source slot 0 = the gradient with respect to the block's output rows [E, planar(irreps_out)] in the edge-aligned frame, output rows =
+    [gradient of the doubled node-branch input | gradient of the edge-feature input] (message_pack_adjoint_layout), the node part
+    un-rotated to the global frame in the epilogue (the adjoint of the rotation the forward applies while staging the gathered node
+    rows), the edge part left in the edge frame (where the forward read it).  The radial hidden activations are those of the forward.
+    Weight gradients are NOT part of this program."""
+    irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
+    _, w3n = _last_layer(sd, "node_weight_generator")
+    _, w3e = _last_layer(sd, "edge_weight_generator")
+    H = w3n.shape[0]
+    adj, _ = message_pack_adjoint_layout(irreps_node, irreps_edge)
+    nb = len(irreps_node)
+    prog, _ = new_program(adj, H, lambda k, ir: SEG_UNROTATE if k < nb else 0)
+    gl = PlanarLayout(irreps_out)
+    add_tp_adjoint_items(prog, PlanarLayout(irreps_node), 2, 0, gl, irreps_sh, irreps_out, np.asarray(sd["node_tensor_product.weight"]),
+                         w3n / math.sqrt(H), np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]),
+                         mlp=0, target_base=0)
+    add_tp_adjoint_items(prog, PlanarLayout(irreps_edge), 1, 0, gl, irreps_sh, irreps_out, np.asarray(sd["edge_tensor_product.weight"]),
+                         w3e / math.sqrt(H), np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]),
+                         mlp=1, target_base=nb)
     return prog.finalize()
 
 

@@ -65,6 +65,16 @@ class Topology:
             self._csr = (rowptr.contiguous(), perm)
         return self._csr
 
+    def sender_csr(self):
+        """edges grouped by their SENDER (edge_index[0]): the scatter of the backward pass (gradient of the gathered sender rows)"""
+        if getattr(self, "_csr_s", None) is None:
+            src = self.edge_index[0]
+            perm = torch.sort(src, stable=True).indices.contiguous()
+            rowptr = torch.zeros(self.N + 1, dtype=torch.int64, device=src.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(src, minlength=self.N), 0)
+            self._csr_s = (rowptr.contiguous(), perm)
+        return self._csr_s
+
     # ---- inverse edge with the per-graph edge offset (hamgnn_output.py:2985-2990) and edges per crystal
     def global_inverse(self, data):
         if self._ginv is None:

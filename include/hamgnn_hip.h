@@ -112,7 +112,8 @@ int hg_gate(const float* x, int64_t x_stride, const int32_t* act_tab, int nact, 
 int hg_add_rows(const float* a, int64_t sa, const float* b, int64_t sb, const float* c, int64_t sc, int64_t rows, int D,
                 float* out, int64_t so, void* stream);
 
-/* layout conversion e3nn [u][a] <-> planar [a][mulp] via an index map (int32[D_e3nn] -> planar index).               */
+/* layout conversion e3nn [u][a] <-> planar [a][mulp] via an index map (int32[D_e3nn] -> planar index).  hg_from_planar is a plain
+ * column gather out[r][k] = xp[r][map[k]] (map[k] = -1: 0) and also splits the rows of the data-gradient programs.             */
 int hg_to_planar(const float* x, int64_t rows, int D, const int32_t* map, float* out, int Dp, void* stream);
 int hg_from_planar(const float* xp, int64_t rows, int Dp, const int32_t* map, float* out, int D, void* stream);
 

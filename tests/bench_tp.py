@@ -8,6 +8,7 @@ IRR = {"A": "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+
 ap = argparse.ArgumentParser(); ap.add_argument("--irreps", default="A"); ap.add_argument("--edges", type=int, default=131072)
 ap.add_argument("--reps", type=int, default=5); ap.add_argument("--tag", default=""); ap.add_argument("--same-rows", type=int, default=0, help="alias the B-operand rows onto this many distinct rows (cache-residency experiment)")
 ap.add_argument("--nodes", type=int, default=0, help="feed NODE rows + random sender/receiver indices (gather + rotation fused into the input-stationary kernel, or hg_rotate_gather + kernel otherwise) instead of pre-rotated edge rows")
+ap.add_argument("--adjoint", action="store_true", help="time the data-gradient launch (adjoint program, hamgnn_amd.nn.MessagePackBlock.backward_data) instead of the forward")
 a = ap.parse_args()
 irr, sh = IRR[a.irreps], "0e+1o+2e+3o+4e+5o"
 torch.manual_seed(0)
@@ -38,6 +39,10 @@ if a.nodes:
     launch = lambda: m.run_nodes(node, node, fe, geo, rot)
 else:
     launch = lambda: ops.tp_fused(m._dp, [xs, xd, fe], E, hn, he, geo)
+if a.adjoint:
+    m.compile_adjoint(dev)
+    gout = torch.randn(a.nodes if a.nodes else E, lay.dim, generator=g).to(dev)
+    launch = (lambda: m.backward_data(gout, geo, True, gather=geo.dst)[0]) if a.nodes else (lambda: m.backward_data(gout, geo, True)[0])
 for _ in range(2):
     out = launch()
 torch.cuda.synchronize()
@@ -46,7 +51,7 @@ for _ in range(a.reps):
     out = launch()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
-prog = m._dp.prog
+prog = m._dp_adj.prog if a.adjoint else m._dp.prog
 print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
                   "issued_TF": prog.mfma_per_wave * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
                   "Medges_s": E / dt / 1e6, "checksum": float(out.double().abs().mean())}))

@@ -170,6 +170,106 @@ def check_message_pack_random(device="cuda", seed=0, schedule="auto"):
             "rel_err": 0.0 if scale < 1e-12 else rel(y, out)}
 
 
+def check_message_pack_backward(device="cuda", seed=0, irr=None, sh=None, schedule="auto", E=83, radial=(16, 16)):
+    """SURVEY 8f-3 (first step): data gradient of one MessagePackBlock forward on the GPU (adjoint program on the same HIP kernels) vs
+    torch.autograd through the fp64 oracle.  Random irreps set unless given."""
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    from tests.test_plan_emu import _random_irreps
+    rng = np.random.default_rng(100 + seed)
+    if irr is None:
+        lmax = int(rng.integers(1, 4))
+        irr = _random_irreps(rng, lmax)
+        if "0e" not in irr:
+            irr = "5x0e+" + irr
+        lsh = int(rng.integers(1, 4))
+        sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    lmax, lsh = P.Irreps(irr).lmax, P.Irreps(sh).lmax
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=list(radial))
+        g = torch.Generator().manual_seed(seed)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g).requires_grad_() for _ in range(3))
+        vec = torch.randn(E, 3, generator=g) * 3.0
+        n = torch.nn.functional.normalize(vec, dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        G = torch.randn(E, ref.irreps_node_feats.dim, generator=g)
+        (ref(src, dst, ef, shv, rbf) * G).sum().backward()
+    finally:
+        torch.set_default_dtype(prev)
+    m = load_weights(hnn.MessagePackBlock(irr, irr, sh, irr, 8, list(radial)), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    os.environ["HG_MP_KERNEL"] = schedule
+    try:
+        m.compile(device, unrotate=True)
+        m.compile_adjoint(device)
+    finally:
+        os.environ.pop("HG_MP_KERNEL", None)
+    lay = P.PlanarLayout(irr)
+    lm = max(lmax, lsh)
+    v = torch.stack([n[:, 2], n[:, 0], n[:, 1]], 1) * 2.0          # e3nn axis order (y, z, x) -> physical (x, y, z)
+    jtab = torch.from_numpy(P.wigner_jtab(lm)).to(device)
+    ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.long)]).to(device)
+    geo = ops.Geometry(torch.zeros(2, 3, device=device), ei, v.float().to(device), 8.0, 8, lm, jtab)
+    geo.rbf = rbf.float().to(device).contiguous()
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    rot = torch.from_numpy(P.rotate_table(lay)).to(device)
+    gs, gd, gf = m.backward_data(ops.to_planar(G.float().to(device), imap, lay.dim), geo, out_is_global=True)
+    gf = ops.rotate_gather(gf, None, geo, rot, transpose=True)                      # edge frame -> global frame
+    torch.cuda.synchronize()
+    scale = max(float(t.grad.abs().max()) for t in (src, dst, ef))
+    err = lambda a, t: 0.0 if scale < 1e-12 else float((ops.from_planar(a, imap).double().cpu() - t.grad).abs().max()) / scale
+    return {"irreps": irr, "sh": sh, "kernel": "is" if m._dp_adj.sched is not None else "seg",
+            "parts": int(m._dp_adj.sched.part_table.shape[0]) if m._dp_adj.sched is not None else 0,
+            "g_src_rel_err": err(gs, src), "g_dst_rel_err": err(gd, dst), "g_edge_rel_err": err(gf, ef)}
+
+
+def check_conv_message_backward(device="cuda", n_atoms=10, seed=2):
+    """the ConvBlockE3 message chain on a periodic cell:  agg = scatter_receiver(MessagePack(x[sender], x[receiver], f))  -- gradient of
+    sum(agg * G) with respect to the NODE rows x and the edge rows f: receiver gather fused into the adjoint launch, the two node
+    scatters by hg_segment_sum over the sender / receiver CSR; vs torch.autograd through the fp64 oracle."""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.topo import get_topology
+    irr, sh = "16x0e+8x0o+8x1o+4x1e+4x2o+8x2e+4x3o+4x3e+4x4e", "0e+1o+2e+3o+4e"
+    g = S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.006)
+    N, E = g.num_nodes, g.num_edges
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "16x0e", radial_MLP=[32, 32])
+        gen = torch.Generator().manual_seed(seed)
+        D = ref.irreps_node_feats.dim
+        x, f = torch.randn(N, D, generator=gen).requires_grad_(), torch.randn(E, D, generator=gen).requires_grad_()
+        G = torch.randn(N, D, generator=gen)
+        shv, rbf, _ = R.edge_geometry(g.pos.double(), g.edge_index, g.nbr_shift.double(), sh, 26.0, 16)
+        s_, r_ = g.edge_index
+        agg = R.scatter_sum(ref(x[s_], x[r_], f, shv, rbf), r_, N)
+        (agg * G).sum().backward()
+    finally:
+        torch.set_default_dtype(prev)
+    m = load_weights(hnn.MessagePackBlock(irr, irr, sh, irr, 16, [32, 32]), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    m.compile(device, unrotate=True)
+    lay = P.PlanarLayout(irr)
+    gd = g.to(device)
+    geo = ops.Geometry(gd.pos, gd.edge_index, gd.nbr_shift, 26.0, 16, 4, torch.from_numpy(P.wigner_jtab(4)).to(device))
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    rot = torch.from_numpy(P.rotate_table(lay)).to(device)
+    topo = get_topology(gd)
+    Gp = ops.to_planar(G.float().to(device), imap, lay.dim)
+    gs, gdst, gf = m.backward_data(Gp, geo, out_is_global=True, gather=geo.dst)     # backward of the receiver scatter = gather by receiver
+    gx = ops.segment_sum(gs, *topo.sender_csr(), N) + ops.segment_sum(gdst, *topo.receiver_csr(), N)
+    fp = ops.rotate_gather(ops.to_planar(f.detach().float().to(device), imap, lay.dim), None, geo, rot)   # (unused by the linear adjoint; layout check only)
+    gf = ops.rotate_gather(gf, None, geo, rot, transpose=True)
+    torch.cuda.synchronize()
+    return {"N": N, "E": E, "parts": int(m._dp_adj.sched.part_table.shape[0]) if m._dp_adj.sched is not None else 0,
+            "g_node_rel_err": rel(ops.from_planar(gx, imap), x.grad), "g_edge_rel_err": rel(ops.from_planar(gf, imap), f.grad)}
+
+
 def check_backbone(device="cuda", name="backbone"):
     m, f = build_backbone_from_fixture(device, name)
     g = to_graph(f["graph"], device)

@@ -5,6 +5,8 @@ import torch
 
 from tests import gpu_checks as G
 
+G_IRREPS_A = "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e"
+
 pytestmark = pytest.mark.gpu
 
 
@@ -76,6 +78,28 @@ def test_transformer_vs_oracle_random_crystal():
     print(r)
     assert r["max_in_degree"] > 130                                        # more than one LDS weight chunk of hg_attn_aggregate
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
+
+
+@pytest.mark.parametrize("seed,schedule", [(0, "auto"), (1, "auto"), (2, "seg"), (3, "auto"), (5, "auto")])
+def test_message_pack_data_gradient_vs_autograd(seed, schedule):
+    r = G.check_message_pack_backward(seed=seed, schedule=schedule)
+    print(r)
+    assert r["kernel"] == ("seg" if schedule == "seg" else "is")
+    assert max(r["g_src_rel_err"], r["g_dst_rel_err"], r["g_edge_rel_err"]) < G.TOL
+
+
+def test_message_pack_data_gradient_default_irreps():
+    """the shipped set-A irreps (l <= 6, sh lmax 5, hidden 64): three feature rows of output per edge -> several workgroups per tile"""
+    r = G.check_message_pack_backward(seed=7, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", E=45, radial=(64, 64))
+    print(r)
+    assert r["kernel"] == "is" and r["parts"] >= 3
+    assert max(r["g_src_rel_err"], r["g_dst_rel_err"], r["g_edge_rel_err"]) < G.TOL
+
+
+def test_conv_message_chain_data_gradient_vs_autograd():
+    r = G.check_conv_message_backward()
+    print(r)
+    assert r["g_node_rel_err"] < G.TOL and r["g_edge_rel_err"] < G.TOL
 
 
 def test_backbone_golden():

@@ -356,6 +356,77 @@ def test_random_irreps_both_schedules_vs_oracle(seed):
     assert rel(lay.from_planar(outi), out) < 1e-6, irr
 
 
+def _adjoint_case(irr, sh, lmax, lsh, seed, E=17, radial=(16, 16)):
+    """oracle MessagePackBlock + torch.autograd: gradients of sum(out * G) with respect to the three inputs; and the emulator inputs"""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=list(radial))
+        g = torch.Generator().manual_seed(seed)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g).requires_grad_() for _ in range(3))
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        G = torch.randn(E, ref.irreps_node_feats.dim, generator=g)
+        (ref(src, dst, ef, shv, rbf) * G).sum().backward()
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lm = max(lmax, lsh)
+    D = emu.edge_wigner_all(n.numpy(), lm)
+    hn = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
+    he = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
+    return sd, D, lm, (hn, he), G.numpy(), (src.grad.numpy(), dst.grad.numpy(), ef.grad.numpy())
+
+
+def _check_adjoint(prog, sched, irr, D, lm, h, G, want):
+    lay = P.PlanarLayout(irr)
+    _, maps = P.message_pack_adjoint_layout(irr, irr)
+    gout = emu.rotate_rows(lay.to_planar(G), lay, D, lm)                      # adjoint of the forward epilogue's un-rotation
+    o = emu.run_program(prog, [gout], h, D, lm) if sched is None else emu.run_program_is(prog, sched, [gout], h, D, lm)
+    take = lambda im: np.where(im[None, :] >= 0, o[:, np.maximum(im, 0)], 0.0)
+    got = (take(maps[0]), take(maps[1]), emu.rotate_rows(take(maps[2]), lay, D, lm, transpose=True))
+    for a, b in zip(got, want):
+        assert rel(lay.from_planar(a), b) < 1e-6, irr
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_data_gradient_program_vs_autograd(seed):
+    """SURVEY 8f-3, first step: the data gradient of a MessagePackBlock as an ADJOINT PROGRAM for the same kernels (roles of the two
+    weight matrices swapped, plan.add_tp_adjoint_items) vs torch.autograd through the fp64 oracle -- random irreps sets, both schedules."""
+    rng = np.random.default_rng(100 + seed)
+    lmax = int(rng.integers(1, 4))
+    irr = _random_irreps(rng, lmax)
+    if "0e" not in irr:
+        irr = "5x0e+" + irr
+    lsh = int(rng.integers(1, 4))
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    sd, D, lm, h, G, want = _adjoint_case(irr, sh, lmax, lsh, seed)
+    if max(np.abs(w).max() for w in want) < 1e-12:
+        return
+    prog = P.build_message_pack_adjoint_program(sd, irr, irr, sh, irr)
+    _check_adjoint(prog, None, irr, D, lm, h, G, want)
+    _check_adjoint(prog, P.is_schedule(prog, "lds"), irr, D, lm, h, G, want)
+
+
+def test_data_gradient_program_wide_rows_need_several_workgroups():
+    """three feature rows of output per edge: with wide irreps the tiles exceed one workgroup's LDS -> lds_partition spreads the output
+    segments over several parts (blockIdx.y); 2 x 64 channels of one irrep > 64 -> column chunks (sender / receiver halves)"""
+    irr, sh = "64x0e+32x0o+32x1o+16x1e+16x2e+8x2o+8x3o", "0e+1o+2e"
+    sd, D, lm, h, G, want = _adjoint_case(irr, sh, 3, 2, seed=3, E=5)
+    prog = P.build_message_pack_adjoint_program(sd, irr, irr, sh, irr)
+    assert len(prog.seg_chunks[0]) == 2
+    with pytest.raises(NotImplementedError):
+        P.is_schedule(prog, 1)
+    sc = P.is_schedule(prog, "lds")
+    assert sc.part_table.shape[0] >= 2
+    _check_adjoint(prog, sc, irr, D, lm, h, G, want)
+    _check_adjoint(prog, None, irr, D, lm, h, G, want)
+
+
 @pytest.mark.parametrize("irreps", [MINI, "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e", "3x0e+2x1o"])
 def test_gate_tables_compact_match_the_oracle_gate(irreps):
     """hg_gate's tables (plan.gate_tables -> gate_tables_compact: distinct activated scalars once per row, outputs by look-up),
