@@ -497,6 +497,8 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4;
+    // (an XCD-aware tile order -- contiguous tile ranges per XCD, workgroup b -> XCD b % 8 -- was measured on the 10 k-atom crystal:
+    //  49.6 ms per launch with and without it, profiles/r02_tp_is_experiments.md: the gathered node rows are not what the waves wait for)
     const int64_t e = (int64_t)blockIdx.x * 16 + (lane & 15);
     const bool valid = e < A0.rows;
     const int64_t erow = valid ? e : A0.rows - 1;
