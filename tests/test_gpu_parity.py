@@ -166,6 +166,14 @@ def test_sharded_two_rank_forward_matches_single_rank(workload, irreps):
     assert r["rel_err"] < 1e-5, r
 
 
+def test_rccl_backend_single_rank():
+    """the RCCL leg of the multi-GPU path (init with device_id, all_reduce, barrier) runs on this image / box -- one rank"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cp = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_smoke.py")], capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0 and "RCCL_OK" in cp.stdout, cp.stdout[-1500:] + cp.stderr[-1500:]
+
+
 def test_bench_script_two_rank_path_on_one_gpu():
     """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), on a 1-GPU box: both ranks
     share cuda:0 and talk over gloo (HG_BENCH_SAME_DEVICE / HG_BENCH_BACKEND test hooks; RCCL refuses two ranks on one device).
