@@ -38,13 +38,19 @@ class E3Linear(nn.Module):
         self._dp = None
 
     def compile(self, device):
-        self._dp = ops.DeviceProgram(P.build_linear_program(self.weight.detach().cpu().double().numpy(), self.irreps_in, self.irreps_out), device)
+        W = self.weight.detach().cpu().double().numpy()
+        if os.environ.get("HG_LINEAR_KERNEL", "stream") == "seg":                             # HG_LINEAR_KERNEL=seg: the Linear as a program of the segment-stationary kernel
+            self._dp = ops.DeviceProgram(P.build_linear_program(W, self.irreps_in, self.irreps_out), device)
+        else:                                                  # default: the streaming block-Linear kernel (csrc/linear.hip)
+            self._dp = ops.DeviceLinear(P.build_linear_tables(W, self.irreps_in, self.irreps_out), device)
         return self
 
     def forward(self, x_planar: torch.Tensor, res=()) -> torch.Tensor:
         """res: residual rows (output layout) added in the kernel epilogue"""
         if self._dp is None:
             self.compile(x_planar.device)
+        if isinstance(self._dp, ops.DeviceLinear):
+            return ops.linear_planar(self._dp, x_planar, res=res)
         return ops.tp_fused(self._dp, [x_planar], x_planar.shape[0], res=res)
 
 
@@ -419,15 +425,26 @@ class HamLayer(nn.Module):
     def compile(self, device):
         self.residual_block.compile(device)
         W = self.linear_transform.weight.detach().cpu().double().numpy()
+        stream = os.environ.get("HG_LINEAR_KERNEL", "stream") != "seg"
         if all(m == 1 for m, _, _ in self.ham_irreps):         # hamiltonian irreps: regroup the multiplicity-1 outputs by (L,p)
+            if stream:
+                mats, self.girr, self.slot_pos = P.ham_linear_mats(W, self.irreps_in, self.ham_irreps, self.keep)
+                self._dp = ops.DeviceLinear(P.linear_tables(mats, P.PlanarLayout(self.irreps_in), P.PlanarLayout(self.girr)), device)
+                return
             prog, self.girr, self.slot_pos = P.build_ham_linear_program(W, self.irreps_in, self.ham_irreps, self.keep)
         else:                                                  # xi networks (nao^2 x 0e): a plain o3.Linear
-            prog, self.girr, self.slot_pos = P.build_linear_program(W, self.irreps_in, self.ham_irreps), self.ham_irreps, None
+            self.girr, self.slot_pos = self.ham_irreps, None
+            if stream:
+                self._dp = ops.DeviceLinear(P.build_linear_tables(W, self.irreps_in, self.ham_irreps), device)
+                return
+            prog = P.build_linear_program(W, self.irreps_in, self.ham_irreps)
         self._dp = ops.DeviceProgram(prog, device)
 
     def forward(self, x_planar):
         y = self.residual_block(x_planar)
-        return ops.tp_fused(self._dp, [y], y.shape[0])                          # planar rows grouped by (L,p)
+        if isinstance(self._dp, ops.DeviceLinear):
+            return ops.linear_planar(self._dp, y)                              # planar rows grouped by (L,p)
+        return ops.tp_fused(self._dp, [y], y.shape[0])
 
 
 # ------------------------------------------------------------------------------------------------ correlation product (a21)

@@ -105,6 +105,41 @@ class DeviceProgram:
         return 1
 
 
+class DeviceLinear:
+    """plan.LinearTables uploaded to the GPU (hg_linear_planar)"""
+
+    def __init__(self, tabs: P.LinearTables, device):
+        self.tabs = tabs
+        self.nitems = int(tabs.items.shape[0])
+        self.items, self.units, self.paths = _dev(tabs.items, device), _dev(tabs.units, device), _dev(tabs.paths, device)
+        self.weights = _dev(tabs.weights, device)
+        self.in_dim, self.out_dim = int(tabs.in_dim), int(tabs.out_dim)
+
+
+@_on_tensor_device
+def linear_planar(dl: DeviceLinear, x: torch.Tensor, res: Sequence[Optional[torch.Tensor]] = (), tag: str = "linear") -> torch.Tensor:
+    """o3.Linear on planar rows, one streaming pass (csrc/linear.hip); res: up to two residual row tensors (output layout) added on the way"""
+    _require_gpu(x)
+    rows = int(x.shape[0])
+    assert x.shape[1] == dl.in_dim and x.stride(1) == 1
+    res = [r for r in res if r is not None]
+    assert len(res) <= 2
+    for r in res:
+        assert r.shape == (rows, dl.out_dim) and r.stride(1) == 1
+    out = torch.empty(rows, dl.out_dim, device=x.device, dtype=torch.float32)         # every column is written, padding included
+    if PROFILE_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().hg_linear_planar(ptr(x), i64(x.stride(0)), ptr(dl.items), i32(dl.nitems), ptr(dl.units), ptr(dl.paths), ptr(dl.weights),
+                                 C.c_void_p(res[0].data_ptr() if res else 0), i64(res[0].stride(0) if res else 0),
+                                 C.c_void_p(res[1].data_ptr() if len(res) > 1 else 0), i64(res[1].stride(0) if len(res) > 1 else 0),
+                                 i64(rows), ptr(out), i64(dl.out_dim), _stream()), "hg_linear_planar")
+    if PROFILE_EVENTS is not None:
+        ev1.record()
+        PROFILE_EVENTS.append((ev0, ev1, rows, tag))
+    return out
+
+
 def wig_offsets(lmax):
     offs, tot = P.wigner_offsets(lmax)
     arr = (C.c_int * 8)(*([int(o) for o in offs] + [0] * (8 - len(offs))))

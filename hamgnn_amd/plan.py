@@ -694,6 +694,86 @@ def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarL
     assert off == weight.size, (off, weight.size)
 
 
+# ---- streaming block-Linear (csrc/linear.hip): o3.Linear on planar rows as one HBM-bound pass --------------------------------
+LIN_CHUNK = 64           # output channels per unit (4 MFMA row tiles of accumulators per wave)
+LIN_UNIT_I32, LIN_PATH_I32, LIN_GROUP_I32 = 8, 4, 4
+
+
+@dataclass
+class LinearTables:
+    """tables of hg_linear_planar.  A "pair-row" is one (row, component a) of an irrep block: `mulp` contiguous floats.
+    groups int32[ngroup][4] = {unit_begin, nchunks, nco = 2 l + 1, 0}: one output irrep block = its channel chunks (units);
+    units  int32[nunit][8]  = {out_off, out_mulp, rtm, store_channels (multiple of 4), path_begin, path_end, 0, 0};
+    paths  int32[npath][4]  = {in_off, in_mulp, ngrp, w_off}: A fragments [ngrp][rtm][64][4] of the (normalised) weight block
+                              W^T[out channel][in channel], K permuted for float4 B loads (_frag_A(..., x4=True))."""
+    groups: np.ndarray
+    units: np.ndarray
+    paths: np.ndarray
+    weights: np.ndarray
+    items: np.ndarray            # int32[nitems][2] = {unit, component a}: the wave units of one block of rows, heaviest output block first
+    in_dim: int
+    out_dim: int
+    flops_per_row: float
+
+
+def linear_tables(mats: Dict[Tuple[int, int], np.ndarray], in_layout: PlanarLayout, out_layout: PlanarLayout) -> LinearTables:
+    """mats[(i, k)] = [mul_i, mul_k] weight block (normalisation folded in) from input irrep i to output irrep k of the two planar
+    layouts (same l, p).  Every output block is written in full (blocks without a path: zeros), padding channels included."""
+    groups, units, paths, chunks = [], [], [], []
+    woff, flops = 0, 0.0
+    order = sorted(range(len(out_layout.irreps)), key=lambda k: -sum(m.shape[0] for (i, kk), m in mats.items() if kk == k) * (2 * out_layout.irreps[k][1] + 1))
+    for k in order:
+        mk, lk, pk = out_layout.irreps[k]
+        mulp = out_layout.mulp[k]
+        ins = sorted(i for (i, kk) in mats if kk == k)
+        groups.append([len(units), ceil_div(mulp, LIN_CHUNK), 2 * lk + 1, 0])
+        for c0 in range(0, mulp, LIN_CHUNK):
+            c1 = min(mulp, c0 + LIN_CHUNK)
+            rtm = ceil_div(c1 - c0, 16)
+            pb = len(paths)
+            for i in ins:
+                M = np.asarray(mats[(i, k)], dtype=np.float64)
+                mi = in_layout.irreps[i][0]
+                assert M.shape == (mi, mk) and in_layout.irreps[i][1:] == (lk, pk)
+                blk = M[:, c0:min(c1, mk)]
+                if blk.shape[1] == 0 or not np.any(blk):
+                    continue
+                ngrp = ceil_div(in_layout.mulp[i], 16)
+                frag = _frag_A(blk, 4 * ngrp, rtm, True).astype(np.float32).reshape(-1)
+                paths.append([in_layout.off[i], in_layout.mulp[i], ngrp, woff])
+                chunks.append(frag)
+                woff += frag.size
+            units.append([out_layout.off[k] + c0, mulp, rtm, c1 - c0, pb, len(paths), 0, 0])
+        flops += sum(2.0 * mats[(i, k)].shape[0] * mk * (2 * lk + 1) for i in ins)
+    items = [[u0 + c, a] for u0, nch, nco, _ in groups for a in range(nco) for c in range(nch)]      # chunks of one (block, a) adjacent: shared input
+    return LinearTables(np.asarray(groups, np.int32).reshape(-1, LIN_GROUP_I32), np.asarray(units, np.int32).reshape(-1, LIN_UNIT_I32),
+                        np.asarray(paths, np.int32).reshape(-1, LIN_PATH_I32),
+                        np.concatenate(chunks) if chunks else np.zeros(4, np.float32), np.asarray(items, np.int32).reshape(-1, 2),
+                        in_layout.dim, out_layout.dim, flops)
+
+
+def o3_linear_mats(weight: np.ndarray, irreps_in, irreps_out) -> Dict[Tuple[int, int], np.ndarray]:
+    """weight blocks of e3nn's o3.Linear(irreps_in -> irreps_out): paths ordered (i_in, i_out), each (mul_in, mul_out) row-major,
+    normalised by 1 / sqrt(fan_in of the output irrep)."""
+    irreps_in, irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+    pth = [(i, k) for i, (_, li, pi) in enumerate(irreps_in) for k, (_, lk, pk) in enumerate(irreps_out) if (li, pi) == (lk, pk)]
+    fan: Dict[int, int] = {}
+    for i, k in pth:
+        fan[k] = fan.get(k, 0) + irreps_in[i][0]
+    mats, off = {}, 0
+    weight = np.asarray(weight, dtype=np.float64).reshape(-1)
+    for i, k in pth:
+        mi, mk = irreps_in[i][0], irreps_out[k][0]
+        mats[(i, k)] = weight[off:off + mi * mk].reshape(mi, mk) / math.sqrt(fan[k])
+        off += mi * mk
+    assert off == weight.size, (off, weight.size)
+    return mats
+
+
+def build_linear_tables(weight: np.ndarray, irreps_in, irreps_out) -> LinearTables:
+    return linear_tables(o3_linear_mats(weight, irreps_in, irreps_out), PlanarLayout(irreps_in), PlanarLayout(irreps_out))
+
+
 MAX_SEG_ROWS = 64        # output channels per segment (bounds the LDS tile); wider irreps are split column-wise
 
 
@@ -960,9 +1040,10 @@ def ham_irreps(row: Irreps):
     return Irreps(out)
 
 
-def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps, keep=None):
+def ham_linear_mats(weight: np.ndarray, irreps_in, hirr: Irreps, keep=None):
     """o3.Linear(D -> hamiltonian_irreps) (HamLayer.linear_transform, hamgnn_output.py:49,56) regrouped by (L,p) so that the
-    89..312 multiplicity-1 outputs become a handful of GEMM segments.  Returns (program, grouped irreps, slot->(group, col)).
+    89..312 multiplicity-1 outputs become a handful of GEMM blocks.  Returns (normalised weight blocks {(i_in, group): [mul_in, n_group]},
+    grouped irreps, slot -> (group, col)).
     keep: optional bool per output slot; slots not kept own weights (checkpoint layout) but are never computed (the su2 head
     reads only half of its 2 x 2 x required irreps, tensor_decomposition.py:545-551)."""
     irreps_in = Irreps(irreps_in)
@@ -998,12 +1079,20 @@ def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps, keep=N
                     fan[s] = fan.get(s, 0) + mi
                 off += mi
     assert off == weight.size, (off, weight.size)
+    for (i, g) in list(mats):
+        cols_fan = np.array([fan[s] for s in range(len(hirr)) if keep[s] and slot_pos[s][0] == g], dtype=np.float64)
+        mats[(i, g)] = mats[(i, g)] / np.sqrt(cols_fan)[None, :]
+    return mats, girr, slot_pos
+
+
+def build_ham_linear_program(weight: np.ndarray, irreps_in, hirr: Irreps, keep=None):
+    """ham_linear_mats as a program of the segment-stationary kernel (HG_LINEAR_KERNEL=seg).  Returns (program, grouped irreps, slot->(group, col))."""
+    irreps_in = Irreps(irreps_in)
+    mats, girr, slot_pos = ham_linear_mats(weight, irreps_in, hirr, keep)
     prog, seg_of_k = new_program(girr, 0)
     in_layout = PlanarLayout(irreps_in)
-    for (i, g), M in mats.items():
+    for (i, g), Mn in mats.items():
         mi, li, _ = irreps_in[i]
-        cols_fan = np.array([fan[s] for s in range(len(hirr)) if keep[s] and slot_pos[s][0] == g], dtype=np.float64)
-        Mn = M / np.sqrt(cols_fan)[None, :]
         mk = girr[g][0]
         nc = 2 * li + 1
         chunk = rtm_max(nc) * 16

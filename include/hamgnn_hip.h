@@ -194,6 +194,15 @@ int hg_hk_assemble(const float* on, const float* off, const float* nbr_shift, co
                    const int64_t* pair_edges, const int64_t* pair_ij, int64_t npairs, int n_atoms, int nao, const int32_t* orank,
                    const int32_t* ooff, int M, float* Hk, void* stream);
 
+/* e3nn o3.Linear on planar rows as one streaming pass (every o3.Linear of the hot path: hamgnn/nn/interaction_blocks.py:332-358,
+ * 141-152; nn/convolution.py:127; models/hamgnn_output.py:49-58).  Tables from hamgnn_amd/plan.py:linear_tables:
+ * items int32[nitems][2] = {unit, component a}: the wave units of one block of 32 rows (one workgroup per four of them),
+ * units int32[nunit][8] = {out_off, out_mulp, row tiles, channels to store, path_begin, path_end, 0, 0} (<= 64 output channels each),
+ * paths int32[npath][4] = {in_off, in_mulp, K groups of 16, weight offset}; weights: MFMA A fragments of the normalised blocks.
+ * y[row] = Linear(x[row]) (+ res0[row] + res1[row] if given: the residual / skip adds of ResidualBlock); every output column is written. */
+int hg_linear_planar(const float* x, int64_t x_stride, const int32_t* items, int nitems, const int32_t* units, const int32_t* paths, const float* weights, const float* res0, int64_t res0_stride,
+                     const float* res1, int64_t res1_stride, int64_t rows, float* y, int64_t y_stride, void* stream);
+
 /* AttentionBlockE3 / AttentionAggregation (hamgnn/nn/attention.py:91-164, 337-350; heads: hamgnn/nn/attention_utils.py:17-120).
  * K [N, Dp]: planar rows of linear_key(node_feats) (key = K[sender], query = K[receiver], :339-340); head_tab int32[Dp]: head of a
  * planar column (a head is a channel range of every irrep block) or -1 for padding columns; 1 <= H <= 8.

@@ -220,6 +220,34 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
     return out
 
 
+def run_linear_tables(tabs, x, res=(), dtype=np.float64):
+    """csrc/linear.hip on plan.LinearTables, fragment-exact: per unit (<= 64 output channels of one irrep block) and 16 pair-rows
+    (row, component), the A fragments [G][rt][lane = 16 g + i][q] hold W^T[16 rt + i][16 G + 4 g + q]; the B operand of lane (g, n) is the
+    float4 x[pair-row n][16 G + 4 g .. + 3] (zero beyond the block's padded width); C[16 rt + 4 g + r][n] is stored as channel 16 rt + 4 g + r."""
+    rows = x.shape[0]
+    out = np.full((rows, tabs.out_dim), np.nan, dtype=dtype)
+    W = tabs.weights.astype(dtype)
+    for unit0, nchunks, nco, _ in (tuple(int(v) for v in g) for g in tabs.groups):
+        for u in range(unit0, unit0 + nchunks):
+            out_off, out_mulp, rtm, nstore, pb, pe = (int(v) for v in tabs.units[u][:6])
+            assert nstore % 4 == 0 and nstore <= 16 * rtm <= 64
+            acc = np.zeros((rows, nco, 16 * rtm), dtype=dtype)
+            for p in range(pb, pe):
+                in_off, in_mulp, ngrp, woff = (int(v) for v in tabs.paths[p])
+                frag = W[woff:woff + ngrp * rtm * 256].reshape(ngrp, rtm, 4, 16, 4)          # [G][rt][g][i][q]
+                Wt = frag.transpose(1, 3, 0, 2, 4).reshape(rtm * 16, ngrp * 16)                # [out channel][k = 16 G + 4 g + q]
+                xin = np.zeros((rows, nco, ngrp * 16), dtype=dtype)
+                xin[:, :, :in_mulp] = x[:, in_off:in_off + nco * in_mulp].reshape(rows, nco, in_mulp)
+                acc += np.einsum("rak,ck->rac", xin, Wt)
+            for a in range(nco):
+                o = out_off + a * out_mulp
+                out[:, o:o + nstore] = acc[:, a, :nstore]
+    for r in res:
+        out = out + r
+    assert not np.isnan(out).any(), "an output column was not written"
+    return out
+
+
 def sym_contraction(tab, hp, z, W1, W2, C, out_dim):
     """numpy twin of hg_sym_contraction (hamgnn_amd/csrc/head.hip): hp planar hidden rows [N, Dp]; W1 [nel, K1tot, C], W2 [nel, K2tot, C]"""
     N = hp.shape[0]

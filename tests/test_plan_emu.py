@@ -148,6 +148,11 @@ def test_head_linear_and_merge_tables(ham_type, nao):
     got = _merge_emu(yp, *tabs)
     want = ref.reorder_matrix(ref.merge_tensor_components(ref.onsite_hamiltonian_network.linear_transform(torch.from_numpy(x))))
     assert rel(got, want.detach().numpy()) < 1e-6
+    # the same grouped Linear as tables of the streaming kernel (the default path, csrc/linear.hip)
+    mats, girr2, slot2 = P.ham_linear_mats(W, MINI, hirr)
+    assert str(girr2) == str(girr) and slot2 == slot_pos
+    ys = emu.run_linear_tables(P.linear_tables(mats, P.PlanarLayout(MINI), P.PlanarLayout(girr)), P.PlanarLayout(MINI).to_planar(x))
+    assert rel(ys, yp) < 1e-6
 
 
 RICH6 = "4x0e+4x0o+2x1o+2x1e+2x2e+2x2o+2x3o+2x3e+1x4e+1x4o+1x5o+1x5e+1x6e+1x6o"
@@ -354,6 +359,34 @@ def test_random_irreps_both_schedules_vs_oracle(seed):
     assert rel(lay.from_planar(outp), out) < 1e-6, irr
     outi = emu.run_program_is(prog, P.is_schedule(prog), [xs, xd, fe], (hn, he), D, lm)
     assert rel(lay.from_planar(outi), out) < 1e-6, irr
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_streaming_linear_tables_vs_oracle(seed):
+    """o3.Linear between random irreps sets (missing matches -> zero blocks, multiplicities > 64 -> channel chunks, several inputs per
+    output) as tables of the streaming kernel (plan.linear_tables / csrc/linear.hip), emulated fragment-exactly, vs the oracle Linear"""
+    import torch
+    from oracle import e3
+    rng = np.random.default_rng(300 + seed)
+    irr_in = _random_irreps(rng, int(rng.integers(1, 4)))
+    irr_out = _random_irreps(rng, int(rng.integers(1, 4)))
+    if seed == 0:
+        irr_in, irr_out = "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e", "199x0e+64x0o+32x1o+16x1e+12x2o+25x2e+3x3o"
+    if seed == 1:
+        irr_in, irr_out = "5x0e+7x0e+3x1o", "9x0e+2x1o+4x1o"                   # unsimplified: two inputs feed one output
+    torch.manual_seed(seed)
+    lin = e3.Linear(irr_in, irr_out).double()
+    x = torch.randn(21, e3.Irreps(irr_in).dim, dtype=torch.float64)
+    want = lin(x).detach().numpy()
+    tabs = P.build_linear_tables(lin.weight.detach().numpy(), irr_in, irr_out)
+    li, lo = P.PlanarLayout(irr_in), P.PlanarLayout(irr_out)
+    got = emu.run_linear_tables(tabs, li.to_planar(x.numpy()))
+    assert np.abs(lo.from_planar(got) - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (irr_in, irr_out)
+    pad = np.ones(lo.dim, bool)
+    pad[lo.index_map()] = False
+    assert not got[:, pad].any()                                               # channel-padding columns are written as zeros
+    r1, r2 = rng.normal(size=got.shape), rng.normal(size=got.shape)
+    assert np.allclose(emu.run_linear_tables(tabs, li.to_planar(x.numpy()), res=(r1, r2)), got + r1 + r2)
 
 
 def _adjoint_case(irr, sh, lmax, lsh, seed, E=17, radial=(16, 16)):
