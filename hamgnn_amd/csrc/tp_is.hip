@@ -39,6 +39,9 @@ struct IsArgs {
     int trash_off;               // float offsets inside the workgroup's LDS
     int stage_off;
     int ctr_off;                 // work-claim counter (one dword)
+    int rowtab_off;              // row table of GEMM2's output rows (ints): LDS float offset of every row's centre column, see plan.IsSchedule
+    int rowtab_begin;            // first entry / entries of this part in the global table
+    int rowtab_len;
     int tile_shift;              // split launches: this wave's private tile copy (floats added to every tile offset)
     const int64_t* idx[4];       // per source slot: row gather (NULL: row = edge)
     int rot_mask;                // bit i: source i holds GLOBAL-frame rows that are rotated into the edge frame while staged
@@ -93,11 +96,12 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], neg = it[7];     // [1], [2]: stage offsets of the sources
     const int ksteps = it[8], mlp = it[10], x4 = it[17], nk2 = it[18];
-    const int lk = S8[0], mul_k = S8[1], rto = S8[2], tile_off = S8[5];
+    const int rto = S8[2];
     const int g = lane >> 4, el = lane & 15;
-    const int rowstride = (2 * lk + 1) * 16 + 4;
-    float* __restrict__ tile = lds + tile_off + (SPLIT ? A.tile_shift : 0);
-    float* __restrict__ trash = lds + A.trash_off;
+    // GEMM2's output rows are addressed through the row table: entry = LDS offset of the row's centre column (m = 0) in its segment tile,
+    // rows beyond the segment's multiplicity (fragment padding) point at the trash row -- no compare / select / multiply per row
+    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23];
+    float* __restrict__ tbase = lds + (SPLIT ? A.tile_shift : 0) + (el - MM * 16);
     const float* __restrict__ stage = lds + A.stage_off;
     IS_T(0);                                                    // dispatch
 
@@ -214,7 +218,6 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
         // rows beyond mul_k (fragment padding) go to the shared trash row: no divergent branches (their L' columns are zero)
-        const int coff = (lk - MM) * 16 + el;
         if (CW == NC) {
             // software-pipelined over the output row tiles: the tile values of step rtp+1 (the MFMA accumulator init) are read
             // while the MFMAs of step rtp execute -- the LDS latency was exposed once per step (GEMM2 ran at half the MFMA
@@ -222,10 +225,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
             float* __restrict__ tnext[4];
             f32x4 acc_n[NC];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 4 * g + r;
-                tnext[r] = (rr < mul_k ? tile + rr * rowstride : trash) + coff;
-            }
+            for (int r = 0; r < 4; ++r) tnext[r] = tbase + rtab[4 * g + r];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -244,10 +244,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int rr = 16 * (rtp + 1) + 4 * g + r;
-                        tnext[r] = (rr < mul_k ? tile + rr * rowstride : trash) + coff;
-                    }
+                    for (int r = 0; r < 4; ++r) tnext[r] = tbase + rtab[16 * (rtp + 1) + 4 * g + r];
 #pragma unroll
                     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -279,10 +276,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
             }
             float* __restrict__ trow[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 16 * rtp + 4 * g + r;
-                trow[r] = (rr < mul_k ? tile + rr * rowstride : trash) + coff;
-            }
+            for (int r = 0; r < 4; ++r) trow[r] = tbase + rtab[16 * rtp + 4 * g + r];
 #pragma unroll
             for (int c0 = 0; c0 < NC; c0 += CW) {
                 f32x4 acc[CW];                                 // tile values are the accumulator init (C operand)
@@ -318,8 +312,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rr = row0 + 16 * rt + 4 * g + r;
-                float* __restrict__ t0 = (rr < mul_k ? tile + rr * rowstride : trash) + (lk - MM) * 16 + el;
+                float* __restrict__ t0 = tbase + rtab[row0 + 16 * rt + 4 * g + r];
 #pragma unroll
                 for (int c = 0; c < NC; ++c) t0[c * 16] += mid[rt][c][r];
             }
@@ -487,13 +480,13 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
 // part record, int32[8]: {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off (float offsets in the LDS),
 // copy_stride}.  copy_stride > 0: each of the four waves accumulates into its own copy of the part's tiles (copy w at + w * copy_stride),
 // so all waves can work on one output segment at once; the copies are summed before the epilogue.
-#define IS_PART_I32 8
+#define IS_PART_I32 12
 
 template <bool SPLIT>
 __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
                                                        const int* __restrict__ g_phases, const int* __restrict__ g_groups,
                                                        const int* __restrict__ g_items, const float* __restrict__ g_W,
-                                                       const int* __restrict__ g_parts) {
+                                                       const int* __restrict__ g_parts, const int* __restrict__ g_rowtab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4;
@@ -511,6 +504,9 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
         Asplit.trash_off = PT[4];
         Asplit.stage_off = PT[5];
         Asplit.ctr_off = PT[6];
+        Asplit.rowtab_off = PT[8];
+        Asplit.rowtab_begin = PT[9];
+        Asplit.rowtab_len = PT[10];
         Asplit.tile_shift = wave * PT[7];
     }
     const IsArgs& A = SPLIT ? Asplit : A0;
@@ -525,7 +521,12 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     const unsigned long long t_begin = prof.last;
 #endif
 
-    for (int i = threadIdx.x; i < A.stage_off; i += IS_NT) lds[i] = 0.f;             // all segment tiles + the trash row
+    for (int i = threadIdx.x; i < A.rowtab_off; i += IS_NT) lds[i] = 0.f;            // all segment tiles (all copies) + trash rows
+    {
+        int* __restrict__ rt_l = reinterpret_cast<int*>(lds + A.rowtab_off);
+        const int* __restrict__ rt_g = g_rowtab + A.rowtab_begin;
+        for (int i = threadIdx.x; i < A.rowtab_len; i += IS_NT) rt_l[i] = rt_g[i];
+    }
     IS_T(4);                                                   // zero fill
 
     for (int ph = ph0; ph < ph1; ++ph) {
@@ -661,7 +662,8 @@ extern "C" int hg_prof_is_read(unsigned long long* out16, int reset) {
 extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
                         int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
                         const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table,
-                        const int32_t* item_table, const int32_t* part_table, const int32_t* part_table_host, int nparts, int lds_bytes,
+                        const int32_t* item_table, const int32_t* part_table, const int32_t* part_table_host, int nparts,
+                        const int32_t* row_table, int lds_bytes,
                         const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
@@ -686,9 +688,12 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     A.tile_shift = 0;
     const int32_t* p0 = part_table_host;                       // single-part launches take the schedule scalars as kernel arguments
     A.nseg = p0[1], A.nphase = p0[3], A.trash_off = p0[4], A.stage_off = p0[5], A.ctr_off = p0[6];
+    A.rowtab_off = p0[8], A.rowtab_begin = p0[9], A.rowtab_len = p0[10];
+    if (!row_table) return hg_fail(-2, "hg_tp_is: no row table");
     for (int p = 0; p < nparts; ++p) {
         const int32_t* q = part_table_host + p * IS_PART_I32;
-        if (q[6] < q[5] || q[5] < q[4] || lds_bytes < 4 * (q[6] + 1) || (q[7] && 4 * q[7] > q[4])) return hg_fail(-2, "hg_tp_is: bad LDS layout");
+        if (q[6] < q[5] || q[5] < q[8] + q[10] || q[8] < q[4] || lds_bytes < 4 * (q[6] + 1) || (q[7] && IS_NW * q[7] > q[8]))
+            return hg_fail(-2, "hg_tp_is: bad LDS layout");
     }
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
     A.rot_mask = rot_mask;
@@ -699,9 +704,9 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     const unsigned grid = (unsigned)((rows + 15) / 16);
     if (nparts == 1)
         hipLaunchKernelGGL(tp_is_kernel<false>, dim3(grid), dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table,
-                           group_table, item_table, weights, part_table);
+                           group_table, item_table, weights, part_table, row_table);
     else
         hipLaunchKernelGGL(tp_is_kernel<true>, dim3(grid, (unsigned)nparts), dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table,
-                           phase_table, group_table, item_table, weights, part_table);
+                           phase_table, group_table, item_table, weights, part_table, row_table);
     return hg_check_launch("hg_tp_is");
 }

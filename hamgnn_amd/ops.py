@@ -84,7 +84,7 @@ class DeviceProgram:
         if parts not in self._is_tables:
             sc = P.is_schedule(self.prog, parts)
             self._is_tables[parts] = (sc, tuple(_dev(t, self._device) for t in (sc.seg_table, sc.block_table, sc.phase_table, sc.group_table,
-                                                                                  sc.item_table, sc.part_table)))
+                                                                                  sc.item_table, sc.part_table, sc.rowtab)))
         return self._is_tables[parts]
 
     def is_parts_for(self, rows: int) -> int:
@@ -222,12 +222,12 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     if dp.sched is not None:
-        sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts) = dp.is_tables(dp.is_parts_for(rows))
+        sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts, t_rowtab) = dp.is_tables(dp.is_parts_for(rows))
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
         check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(t_segs),
                              ptr(t_blocks), ptr(t_phases), ptr(t_groups), ptr(t_items), ptr(t_parts),
-                             sc.part_table.ctypes.data_as(C.c_void_p), i32(sc.part_table.shape[0]),
+                             sc.part_table.ctypes.data_as(C.c_void_p), i32(sc.part_table.shape[0]), ptr(t_rowtab),
                              i32(sc.lds_floats * 4), gp, i32(rot_mask), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
     else:
         check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),

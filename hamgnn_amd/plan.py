@@ -176,8 +176,12 @@ class IsSchedule:
     #                                dynamically by the waves (largest first), so no two waves update one tile between barriers
     item_table: np.ndarray         # int32[nitems][24]: Program.item_table records with [1], [2] = stage offsets of source 0 / 1 (-1),
     #                                [20..23] = {lk, mul_k, rto, tile_off} of the item's segment
-    part_table: np.ndarray         # int32[nparts][8] = {seg_begin, nseg, phase_begin, nphase, trash_off, stage_off, ctr_off, copy_stride}
+    part_table: np.ndarray         # int32[nparts][12] = {seg_begin, nseg, phase_begin, nphase, trash_off, stage_off, ctr_off, copy_stride,
+    #                                rowtab_off (LDS float offset of the part's row table), rowtab_begin, rowtab_len, 0}
     #                                copy_stride > 0: every wave owns a private copy of the part's tiles (floats between copies)
+    rowtab: np.ndarray             # int32: per part, for every (segment, row tile, row) of GEMM2's output the LDS float offset of that
+    #                                row's CENTRE column (m = 0) inside its segment tile; rows beyond mul_k -> the shared trash row.
+    #                                An item addresses its rows through item[23] = first table entry of its segment.
     lds_floats: int                # dynamic LDS of a workgroup (largest part)
     balance: float                 # LPT estimate: sum(cost) / (waves * sum over phases of max wave cost), worst part
     part_cost: List[int]           # estimated MFMA-slot cost of every part (critical path over its phases)
@@ -201,7 +205,7 @@ class IsSchedule:
 
 
 SEG_NEWBATCH = 1 << 16             # IS epilogue: this segment starts a new Wigner staging batch
-IS_PART_I32 = 8
+IS_PART_I32 = 12
 
 
 def _item_cost(rec, segs, hp4):
@@ -217,10 +221,10 @@ def lds_partition(prog: "Program") -> List[int]:
     three feature rows of output per edge): first-fit decreasing on the tile sizes, capacity = the LDS minus the trash row, the largest
     staged input block and the claim counter."""
     nseg = prog.seg_table.shape[0]
-    size = [int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) for s in prog.seg_table]
+    size = [int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) + int(s[2]) * 16 for s in prog.seg_table]      # tile + its row-table entries
     maxstride = max((2 * int(s[0]) + 1) * 16 + 4 for s in prog.seg_table)
     need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256 for r in prog.item_table)
-    cap = IS_LDS_BYTES // 4 - maxstride - need - 4
+    cap = IS_LDS_BYTES // 4 - maxstride - need - 8
     bins: List[int] = []
     owner = [0] * nseg
     for sg in sorted(range(nseg), key=lambda i: -size[i]):
@@ -264,14 +268,15 @@ def is_schedule(prog: "Program", parts=1) -> IsSchedule:
             r = load.index(min(load))
             owner[sg] = r
             load[r] += seg_cost[sg]
-    segs_all, btab, ptab, gtab, items_all, parttab, part_cost = [], [], [], [], [], [], []
+    segs_all, btab, ptab, gtab, items_all, parttab, part_cost, rowtab_all = [], [], [], [], [], [], [], []
     lds_floats, worst_balance = 0, 1.0
     for part in range(parts):
         members = [sg for sg in range(nseg) if owner[sg] == part]
         sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
                                 split=parts > 1)
         parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
-                        sub["copy_stride"]])
+                        sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), 0])
+        rowtab_all += sub["rowtab"]
         segs_all += list(sub["segs"])
         btab += sub["btab"]
         ptab += sub["ptab"]
@@ -283,7 +288,8 @@ def is_schedule(prog: "Program", parts=1) -> IsSchedule:
     items = np.asarray(items_all, np.int32).reshape(-1, IS_ITEM_I32)
     return IsSchedule(np.asarray(segs_all, np.int32).reshape(-1, SEG_I32), np.asarray(btab, np.int32).reshape(-1, IS_BLOCK_I32),
                       np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
-                      np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), lds_floats, worst_balance, part_cost)
+                      np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), np.asarray(rowtab_all, np.int32),
+                      lds_floats, worst_balance, part_cost)
 
 
 def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
@@ -303,14 +309,27 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     # items of one (phase, segment) can run on all four waves at once -- with one shared copy a part that owns one or two segments
     # would keep a single wave busy.  Taken when the four copies leave room for the largest input block.
     copy_stride = 0
+    tiles_end = off + maxstride                                # one copy: the tiles, then the trash row (as wide as the widest tile)
     if split:
         need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256
                    for r in prog.item_table if int(r[19]) in local)
-        if IS_WAVES * off + maxstride + need + 4 <= IS_LDS_BYTES // 4:
-            copy_stride = off
-            off *= IS_WAVES
+        ntab = sum(int(s[2]) * 16 for s in segs) + 4
+        if IS_WAVES * (off + maxstride) + ntab + need + 4 <= IS_LDS_BYTES // 4:
+            copy_stride = off + maxstride                      # every private copy carries its own trash row
+            tiles_end = IS_WAVES * copy_stride
     trash_off = off
-    stage_off = trash_off + maxstride
+    # row table (see IsSchedule.rowtab): offsets relative to the start of a tile copy
+    lmax_part = (maxstride - 4) // 32
+    rowtab: List[int] = []
+    rt_base = []
+    for s in segs:
+        lk, mul_k, rto = int(s[0]), int(s[1]), int(s[2])
+        stride = (2 * lk + 1) * 16 + 4
+        rt_base.append(len(rowtab))
+        rowtab += [(int(s[5]) + r * stride + lk * 16) if r < mul_k else (trash_off + lmax_part * 16) for r in range(rto * 16)]
+    rowtab += [0] * ((-len(rowtab)) % 4)
+    rowtab_off = tiles_end
+    stage_off = rowtab_off + len(rowtab)
     stage_floats = IS_LDS_BYTES // 4 - stage_off - 4
     # ---- input blocks read by this part's items
     blocks: Dict[Tuple[int, int, int], dict] = {}
@@ -405,10 +424,10 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         g_abs = remap[int(items[n, 19])]
         sg = segs2[g_abs - seg_base]
         wide[n, 19] = g_abs
-        wide[n, 20], wide[n, 21], wide[n, 22], wide[n, 23] = sg[0], sg[1], sg[2], sg[5]
+        wide[n, 20], wide[n, 21], wide[n, 22], wide[n, 23] = sg[0], sg[1], sg[2], rt_base[order[g_abs - seg_base]]
     ctr_off = stage_off + stage_floats
     return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off,
-                ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
+                rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
 
 
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:

@@ -74,8 +74,11 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
  *   block_table int32[nblock][8] = {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
  *   phase_table int32[nphase][4] = {block_begin, block_end, group_begin, group_end};  group_table int32[ngroup][2] = item range
  *   item_table  int32[nitems][24]: as for hg_tp_fused with [1], [2] = stage offsets of source 0 / 1 (-1), [19] = segment,
- *               [20..23] = {lk, mul_k, rto, tile_off} of that segment
- *   part_table  int32[nparts][8] = {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off, 0}: the launch runs
+ *               [20..22] = {lk, mul_k, rto} of that segment, [23] = first row-table entry of the rows its GEMM2 writes
+ *   row_table   int32: per part, for every output row (segment, 16-row tile, row) of GEMM2 the LDS float offset (relative to a tile
+ *               copy) of that row's centre column; rows beyond the segment's multiplicity point at the trash row
+ *   part_table  int32[nparts][12] = {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off, copy_stride,
+ *               rowtab_off (LDS float offset of the part's copy of the row table), rowtab_begin, rowtab_len, 0}: the launch runs
  *               nparts sub-schedules (grid.y) that own disjoint sets of output segments; one part = the whole program, several
  *               parts spread a 16-edge tile's serial pass over several workgroups when there are fewer tiles than CUs (small
  *               crystals: BASELINE configs #1 and #5).  trash_off / stage_off / ctr_off: float offsets of the padding-row sink,
@@ -90,9 +93,8 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
 int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
              int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
              const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table, const int32_t* item_table,
-             const int32_t* part_table, const int32_t* part_table_host, int nparts, int lds_bytes, const int64_t* const* src_idx,
-             int rot_mask, float* out,
-             int64_t out_stride, int64_t rows, void* stream);
+             const int32_t* part_table, const int32_t* part_table_host, int nparts, const int32_t* row_table, int lds_bytes,
+             const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream);
 
 /* torch_scatter.scatter(messages, receiver, dim_size=N) of ConvBlockE3.forward (hamgnn/nn/convolution.py:147-149) as a
  * deterministic segmented reduction: out[n] = sum_{q in [rowptr[n], rowptr[n+1])} msg[perm[q]].                     */

@@ -177,13 +177,18 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
         cols = np.arange(e0, e0 + ne)
         tiles = [np.zeros((int(s[2]) * 16, 2 * int(s[0]) + 1, 16), dtype=dtype) for s in sched.seg_table]
         seen, seg_seen = set(), set()
-        for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride in (tuple(int(v) for v in p) for p in sched.part_table):
+        for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _ in (tuple(int(v) for v in p) for p in sched.part_table):
             stage_floats = ctr_off - stage_off
             part_segs = set(range(sg0, sg0 + nsg))
             assert not (part_segs & seg_seen)
             seg_seen |= part_segs
             tile_floats = sum(int(sched.seg_table[g][1]) * ((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4) for g in part_segs)
-            assert copy_stride in (0, tile_floats) and trash_off == (4 if copy_stride else 1) * tile_floats and (ctr_off + 4) * 4 <= P.IS_LDS_BYTES
+            maxstride = max((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4 for g in part_segs)
+            # LDS layout of a part: [tile copies (each: tiles, trash row)] [row table] [staging area] [claim counter]
+            assert trash_off == tile_floats and copy_stride in (0, tile_floats + maxstride) and (ctr_off + 4) * 4 <= P.IS_LDS_BYTES
+            assert rowtab_off == (P.IS_WAVES * copy_stride if copy_stride else tile_floats + maxstride) and stage_off == rowtab_off + rtn
+            assert stage_off % 4 == 0
+            rowtab = sched.rowtab[rt0:rt0 + rtn]
             for b0, b1, g0, g1 in sched.phase_table[ph0:ph0 + nph]:
                 staged = {}
                 used = 0
@@ -209,7 +214,13 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                         assert sg in part_segs
                         sgs.add(sg)
                         seg = sched.seg_table[sg]
-                        assert tuple(int(v) for v in it[20:24]) == (int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5]))
+                        assert tuple(int(v) for v in it[20:23]) == (int(seg[0]), int(seg[1]), int(seg[2]))
+                        # the row table of the item's segment: real rows -> centre column of that row in the tile, padding rows -> trash row
+                        lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
+                        rt = rowtab[int(it[23]):int(it[23]) + 16 * rto_]
+                        strd = (2 * lk_ + 1) * 16 + 4
+                        assert all(int(rt[r]) == toff_ + r * strd + lk_ * 16 for r in range(mul_))
+                        assert all(trash_off + 16 * int(it[6]) <= int(rt[r]) <= trash_off + maxstride - 16 * (int(it[6]) + 1) for r in range(mul_, 16 * rto_))
                         tiles[sg] = _apply_item(prog, Wt, it[:P.ITEM_I32], srcs, h2, cols, ne, tiles[sg], int(seg[0]), int(seg[2]), dtype)
                     if not copy_stride:
                         assert len(sgs) == 1 and not (sgs & owner), "a shared tile must belong to exactly one work group per phase"

@@ -204,7 +204,8 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     assert sched.item_table.shape == (prog.item_table.shape[0], P.IS_ITEM_I32) and sched.lds_floats * 4 <= P.IS_LDS_BYTES
     for rec in sched.item_table:                              # the segment fields embedded in every item record (csrc/tp_is.hip:ItemRec)
         sg = sched.seg_table[rec[19]]
-        assert (rec[20], rec[21], rec[22], rec[23]) == (sg[0], sg[1], sg[2], sg[5])
+        assert (rec[20], rec[21], rec[22]) == (sg[0], sg[1], sg[2])
+        assert sched.rowtab[rec[23]] == sg[5] + sg[0] * 16                     # first row-table entry: centre column of row 0 of the tile
     assert sched.ctr_off == sched.stage_off + sched.stage_floats and sched.balance > 0.5
     outp = emu.run_program_is(prog, sched, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(lay.from_planar(outp), f["outputs"]["out"]) < 1e-6
