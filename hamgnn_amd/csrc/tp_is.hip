@@ -90,13 +90,13 @@ __device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* l
 // One item on the workgroup's 16 edges.  stage: the phase's staged input block(s), image offset(piece p, row e) = 64 p + 4 e per
 // source (pieces of the FULL irrep block: component a, channel piece s -> p = a * P1 + s).
 template <int MM, int RTM, bool SPLIT>
-__device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, const int* __restrict__ S8,
+__device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
                                         float* __restrict__ lds, int64_t erow, int lane IS_PROF_ARG) {
     constexpr int NC = 2 * MM + 1;
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], neg = it[7];     // [1], [2]: stage offsets of the sources
     const int ksteps = it[8], mlp = it[10], x4 = it[17], nk2 = it[18];
-    const int rto = S8[2];
+    const int rto = it[22];                                     // 16-row tiles of GEMM2's output: the item's segment, or all members of a merged item
     const int g = lane >> 4, el = lane & 15;
     // GEMM2's output rows are addressed through the row table: entry = LDS offset of the row's centre column (m = 0) in its segment tile,
     // rows beyond the segment's multiplicity (fragment padding) point at the trash row -- no compare / select / multiply per row
@@ -466,10 +466,10 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
 
 #ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT>(A, g_W, it, g_segs + it[19] * 8, lds, erow, lane IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
 #else
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT>(A, g_W, it, g_segs + it[19] * 8, lds, erow, lane IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
 #endif
 
 #define SEG_NEWBATCH (1 << 16)

@@ -164,9 +164,22 @@ class MessagePackBlock(nn.Module):
             self._hn = self.weight_generator_combine.hidden_layers(device)
             self._he = None
         else:
-            prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
             self._hn = self.node_weight_generator.hidden_layers(device)
             self._he = self.edge_weight_generator.hidden_layers(device)
+            sched = os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT)
+            if sched != "seg" and os.environ.get("HG_MP_MERGE", "1") != "0":
+                # input-stationary kernel with the small output irreps sharing MFMA row tiles (plan.choose_merge_groups): -5 % MFMAs, -17 %
+                # items for set-A.  Such a program has no segment-stationary form: if it does not fit, fall back to the plain program.
+                groups = P.choose_merge_groups(self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, self._hn[-1].shape[1])
+                if groups:
+                    try:
+                        prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate,
+                                                            skip_weight, merge_groups=groups)
+                        self._dp = ops.DeviceProgram(prog, device, schedule="is")
+                        return self
+                    except NotImplementedError:
+                        pass
+            prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
         # HG_MP_KERNEL = seg | is | auto: which schedule of the fused MessagePackBlock program runs (default: see DESIGN.md section 5)
         self._dp = ops.DeviceProgram(prog, device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
         return self

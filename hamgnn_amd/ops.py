@@ -68,6 +68,8 @@ class DeviceProgram:
         self.sched = None
         self._device = device
         self._is_tables = {}                                   # parts -> (IsSchedule, device tables)
+        if prog.vsegs and schedule not in ("is", "is_parts"):
+            raise ValueError("a program with merged items runs on the input-stationary kernel only")
         self.fixed_parts = None                                # "lds": the tiles of all output segments need several workgroups per 16 edges
         if schedule in ("is", "auto", "is_parts"):             # "is_parts": input-stationary, over several workgroups per tile if need be
             try:

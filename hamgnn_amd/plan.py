@@ -134,6 +134,11 @@ class Program:
     tile_floats: int = 0                              # dynamic LDS floats per workgroup (4 wave-private tiles)
     flops_per_row: float = 0.0                        # algorithmic (unpadded) flops per edge/row
     mfma_per_wave: int = 0                            # issued MFMAs per 16-row wave tile (padded)
+    # merged items (input-stationary kernel only): an item whose GEMM2 rows span SEVERAL output segments.  vsegs[v] = the member
+    # segments in row order; such an item is filed under its first member, carries v + 1 in its row_off field (item[16]) and its L'
+    # fragments address the concatenated channels of the members.  seg_key[s] = the segment whose work group owns segment s's tile.
+    vsegs: List[List[int]] = field(default_factory=list)
+    seg_key: Dict[int, int] = field(default_factory=dict)
 
     def add_weights(self, arr: np.ndarray) -> int:
         arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
@@ -208,36 +213,48 @@ SEG_NEWBATCH = 1 << 16             # IS epilogue: this segment starts a new Wign
 IS_PART_I32 = 12
 
 
-def _item_cost(rec, segs, hp4):
+def _item_rto(rec, segs, vsegs=()):
+    """16-row tiles of GEMM2's output of an item: its segment's, or -- merged item (item[16] = virtual segment + 1) -- of all members"""
+    if int(rec[0]) == IT_TP and int(rec[16]) > 0:
+        return ceil_div(sum(int(segs[m][1]) for m in vsegs[int(rec[16]) - 1]), 16)
+    return int(segs[int(rec[19])][2])
+
+
+def _item_cost(rec, segs, hp4, vsegs=()):
     typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
     c = nsrc * int(rec[8]) * rtm * nc + 60                     # GEMM1 + a per-item latency allowance (in MFMA slots)
     if typ == IT_TP:
-        c += hp4 * rtm + int(segs[int(rec[19])][2]) * int(rec[18]) * nc
+        c += hp4 * rtm + _item_rto(rec, segs, vsegs) * int(rec[18]) * nc
     return c
 
 
 def lds_partition(prog: "Program") -> List[int]:
     """owner part of every output segment when the tiles of ALL segments do not fit one workgroup's LDS (the data-gradient programs:
     three feature rows of output per edge): first-fit decreasing on the tile sizes, capacity = the LDS minus the trash row, the largest
-    staged input block and the claim counter."""
+    staged input block, the row table and the claim counter.  Segments that share a work-group key (merged items) stay together."""
     nseg = prog.seg_table.shape[0]
     size = [int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) + int(s[2]) * 16 for s in prog.seg_table]      # tile + its row-table entries
     maxstride = max((2 * int(s[0]) + 1) * 16 + 4 for s in prog.seg_table)
     need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256 for r in prog.item_table)
-    cap = IS_LDS_BYTES // 4 - maxstride - need - 8
+    cap = IS_LDS_BYTES // 4 - maxstride - need - 8 - 16 * sum(ceil_div(sum(int(prog.seg_table[m][1]) for m in v), 16) for v in prog.vsegs)
+    units: Dict[int, List[int]] = {}
+    for sg in range(nseg):
+        units.setdefault(prog.seg_key.get(sg, sg), []).append(sg)
     bins: List[int] = []
     owner = [0] * nseg
-    for sg in sorted(range(nseg), key=lambda i: -size[i]):
-        if size[sg] > cap:
+    for key in sorted(units, key=lambda k: -sum(size[m] for m in units[k])):
+        sz = sum(size[m] for m in units[key])
+        if sz > cap:
             raise NotImplementedError("input-stationary schedule: one output segment's tile does not fit the LDS next to the staging area")
         for b in range(len(bins)):
-            if bins[b] + size[sg] <= cap:
-                bins[b] += size[sg]
-                owner[sg] = b
+            if bins[b] + sz <= cap:
+                bins[b] += sz
                 break
         else:
-            owner[sg] = len(bins)
-            bins.append(size[sg])
+            b = len(bins)
+            bins.append(sz)
+        for m in units[key]:
+            owner[m] = b
     return owner
 
 
@@ -253,21 +270,27 @@ def is_schedule(prog: "Program", parts=1) -> IsSchedule:
         raise NotImplementedError("lite_mode programs run on the segment-stationary kernel")
     hp4 = prog.hidden_pad // 4
     nseg = prog.seg_table.shape[0]
+    key_of = [prog.seg_key.get(sg, sg) for sg in range(nseg)]   # segments written by merged items share one work-group key
     seg_cost = np.zeros(nseg)
     for rec in prog.item_table:
-        seg_cost[int(rec[19])] += _item_cost(rec, prog.seg_table, hp4)
+        seg_cost[key_of[int(rec[19])]] += _item_cost(rec, prog.seg_table, hp4, prog.vsegs)
     owner = np.zeros(nseg, dtype=np.int64)
+    nkeys = len(set(key_of))
     if parts == "lds":                                         # as few parts as the LDS allows (see lds_partition)
         owner = np.asarray(lds_partition(prog), dtype=np.int64)
         parts = int(owner.max()) + 1
     else:
-        parts = max(1, min(int(parts), nseg))
+        parts = max(1, min(int(parts), nkeys))
     if parts > 1 and not owner.any():
         load = [0.0] * parts
         for sg in np.argsort(-seg_cost, kind="stable"):
+            if key_of[sg] != sg:
+                continue
             r = load.index(min(load))
-            owner[sg] = r
             load[r] += seg_cost[sg]
+            for m in range(nseg):
+                if key_of[m] == sg:
+                    owner[m] = r
     segs_all, btab, ptab, gtab, items_all, parttab, part_cost, rowtab_all = [], [], [], [], [], [], [], []
     lds_floats, worst_balance = 0, 1.0
     for part in range(parts):
@@ -313,7 +336,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     if split:
         need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256
                    for r in prog.item_table if int(r[19]) in local)
-        ntab = sum(int(s[2]) * 16 for s in segs) + 4
+        ntab = sum(int(s[2]) * 16 for s in segs) + 4 + 16 * sum(ceil_div(sum(int(prog.seg_table[m][1]) for m in v), 16) for v in prog.vsegs)
         if IS_WAVES * (off + maxstride) + ntab + need + 4 <= IS_LDS_BYTES // 4:
             copy_stride = off + maxstride                      # every private copy carries its own trash row
             tiles_end = IS_WAVES * copy_stride
@@ -327,6 +350,21 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         stride = (2 * lk + 1) * 16 + 4
         rt_base.append(len(rowtab))
         rowtab += [(int(s[5]) + r * stride + lk * 16) if r < mul_k else (trash_off + lmax_part * 16) for r in range(rto * 16)]
+    vt_base: Dict[int, int] = {}                               # virtual segments (merged items): the members' rows one after the other
+    for rec in prog.item_table:
+        v = int(rec[16]) - 1 if int(rec[0]) == IT_TP else -1
+        if v < 0 or int(rec[19]) not in local or v in vt_base:
+            continue
+        vt_base[v] = len(rowtab)
+        nrow = 0
+        for m in prog.vsegs[v]:
+            assert m in local, "the members of a merged item must be in one part"
+            sm = segs[local[m]]
+            lk, mul_k = int(sm[0]), int(sm[1])
+            stride = (2 * lk + 1) * 16 + 4
+            rowtab += [int(sm[5]) + r * stride + lk * 16 for r in range(mul_k)]
+            nrow += mul_k
+        rowtab += [trash_off + lmax_part * 16] * (ceil_div(nrow, 16) * 16 - nrow)
     rowtab += [0] * ((-len(rowtab)) % 4)
     rowtab_off = tiles_end
     stage_off = rowtab_off + len(rowtab)
@@ -371,12 +409,12 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             for rec in b["items"]:
                 r = rec.copy()
                 r[1], r[2], r[3] = o0, o1, 0
-                by_seg.setdefault(int(rec[19]), []).append(r)
+                by_seg.setdefault(prog.seg_key.get(int(rec[19]), int(rec[19])), []).append(r)
         if copy_stride:                                        # private tile copies: every item is its own work group
             units = [[r] for recs in by_seg.values() for r in recs]
         else:
             units = list(by_seg.values())
-        groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
+        groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
         loads = [0] * IS_WAVES
         for c, n in groups:                                    # claim order = LPT order
             loads[loads.index(min(loads))] += c
@@ -425,6 +463,9 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         sg = segs2[g_abs - seg_base]
         wide[n, 19] = g_abs
         wide[n, 20], wide[n, 21], wide[n, 22], wide[n, 23] = sg[0], sg[1], sg[2], rt_base[order[g_abs - seg_base]]
+        v = int(items[n, 16]) - 1 if int(items[n, 0]) == IT_TP else -1
+        if v >= 0:                                             # merged item: rows of all members, through the virtual segment's table range
+            wide[n, 22], wide[n, 23] = _item_rto(items[n], prog.seg_table, prog.vsegs), vt_base[v]
     ctr_off = stage_off + stage_floats
     return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off,
                 rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
@@ -468,7 +509,7 @@ def _add_segment(prog: Program, lk, mul_k, out_index, flags):
 KERNEL_RTM_MAX = (4, 4, 3, 2, 2, 1, 1)
 
 
-def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0, nk2=None):
+def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp, a1, w3, cf, a2, nrows, row_off=0, nk2=None, rto=None):
     assert len(srcs) in (1, 2)
     if typ != IT_POST and not (0 <= mm < len(KERNEL_RTM_MAX) and 1 <= rtm <= KERNEL_RTM_MAX[mm]):
         raise NotImplementedError(f"no kernel instantiation for an item with min(l_in, l_out) = {mm} and {rtm} row tiles")
@@ -480,7 +521,7 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
     assert len(rec) == ITEM_I32
     prog.seg_items[seg].append(rec)
     nc = 2 * mm + 1
-    rto = prog.segs[seg][2]
+    rto = prog.segs[seg][2] if rto is None else rto
     n = len(srcs) * ksteps * rtm * nc
     if typ == IT_POST:
         n = (prog.hidden_pad // 4) * rto + rto * rto * 4 * (2 * prog.segs[seg][0] + 1)
@@ -581,8 +622,12 @@ def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps
 
 def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
                  irreps_sh: Irreps, irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray,
-                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False):
+                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False, merge_groups: Sequence[Sequence[int]] = ()):
     """Items of ONE reference tensor-product branch (node or edge) of a MessagePackBlock / embedding TP.
+    merge_groups: lists of output irreps k whose super-paths from one input irrep are stacked into ONE item (see Program.vsegs):
+    the rows of a 16-row MFMA tile are then filled by several small output irreps instead of one (4x5o alone uses 12 of 16 rows of
+    GEMM1 / the radial scale and 4 of 16 rows of GEMM2's output).  Only super-paths with l_i <= min l_k of the group are stacked (same
+    column count 2 l_i + 1); the members must share the parity class (l_k + [p_k odd]) mod 2 so that `par` agrees.
 
     in_layout : planar layout of ONE source row (irreps of the un-doubled features); nsrc = 2 for the node branch
                 (reference input = (2 mul) x ir with the first mul channels from src, the rest from dst: attention_utils.py:85-119).
@@ -591,17 +636,55 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
     uvu       : lite_mode product (tensor_products.py:81-84,127-130): no TP weights, mid multiplicity = input multiplicity.
     """
     H = prog.hidden
+    group_of = {k: gi for gi, G in enumerate(merge_groups) for k in G}
+    lmin = [min(irreps_out[k][1] for k in G) for G in merge_groups]
+    vid_of: Dict[int, int] = {}
+    for gi, G in enumerate(merge_groups):                      # one virtual segment per group (shared by the branches of a program)
+        members = [seg_of_k[k] for k in G]
+        assert all(len(prog.seg_chunks[k]) == 1 for k in G)
+        if members in prog.vsegs:
+            vid_of[gi] = prog.vsegs.index(members)
+        else:
+            vid_of[gi] = len(prog.vsegs)
+            prog.vsegs.append(members)
+        for sg in members:
+            prog.seg_key[sg] = members[0]
+    stacked: Dict[Tuple[int, int], List[dict]] = {}
+    plain: List[dict] = []
     for sp in _tp_superpaths(nsrc, in_layout, irreps_sh, irreps_out, tp_weight, w3, lin_scale_w, lin_out_w, uvu):
-        i, k, mi, li, mk, lk, mm, par = sp["i"], sp["k"], sp["mi"], sp["li"], sp["mk"], sp["lk"], sp["mm"], sp["par"]
-        if mk > seg_rows_cap(lk):
+        gi = group_of.get(sp["k"])
+        if gi is not None and sp["li"] <= lmin[gi]:
+            stacked.setdefault((sp["i"], gi), []).append(sp)
+        else:
+            plain.append(sp)
+    units = [(sp, seg_of_k[sp["k"]], None, sp["mk"], sp["L"]) for sp in plain]
+    for (i, gi), sps in stacked.items():
+        G = list(merge_groups[gi])
+        voff, o = {}, 0
+        for k in G:
+            voff[k] = o
+            o += irreps_out[k][0]
+        sps = sorted(sps, key=lambda sp: G.index(sp["k"]))
+        assert len({sp["par"] for sp in sps}) == 1 and len({sp["mm"] for sp in sps}) == 1, "merge group members must share the parity class"
+        Lv = np.zeros((sum(sp["nmid"] for sp in sps), o))
+        r = 0
+        for sp in sps:
+            Lv[r:r + sp["nmid"], voff[sp["k"]]:voff[sp["k"]] + sp["mk"]] = sp["L"]
+            r += sp["nmid"]
+        cat = dict(sps[0], W=np.concatenate([sp["W"] for sp in sps]), ch=np.concatenate([sp["ch"] for sp in sps]),
+                   cf=np.concatenate([sp["cf"] for sp in sps]), flops=sum(sp["flops"] for sp in sps), nmid=Lv.shape[0])
+        units.append((cat, seg_of_k[G[0]], vid_of[gi], o, Lv))
+    for sp, seg, vid, mk, rows_L in units:
+        i, mi, li, lk, mm, par = sp["i"], sp["mi"], sp["li"], sp["lk"], sp["mm"], sp["par"]
+        if vid is None and mk > seg_rows_cap(lk):
             raise NotImplementedError(f"tensor-product target {mk}x(l={lk}) is wider than the {seg_rows_cap(lk)} channels one LDS tile holds")
-        seg = seg_of_k[k]
         nc = 2 * mm + 1
-        rows_W, rows_ch, rows_cf, rows_L = sp["W"], sp["ch"], sp["cf"], sp["L"]
+        rows_W, rows_ch, rows_cf = sp["W"], sp["ch"], sp["cf"]
         prog.flops_per_row += sp["flops"] + 2.0 * H * sp["nmid"]
         nrows = len(rows_ch)
         chunk = rtm_max(nc) * 16
         ksteps = in_layout.mulp[i] // 4
+        rto = prog.segs[seg][2] if vid is None else ceil_div(mk, 16)
         for r0 in range(0, nrows, chunk):
             r1 = min(nrows, r0 + chunk)
             n = r1 - r0
@@ -625,14 +708,13 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
             cfp = np.zeros((R, nc))
             cfp[phys] = rows_cf[r0:r1]
             cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))       # [rt][c][g][r]
-            rto = prog.segs[seg][2]
             Lp = np.zeros((R, rto * 16))
             Lp[phys, :mk] = rows_L[r0:r1]
             # A2[rt'][rt][lane][r]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
             a2 = Lp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4)
             a2_off = prog.add_weights(a2)
             _add_item(prog, seg, IT_TP, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, par, ksteps, rtm, mlp,
-                      a1_off, w3_off, cf_off, a2_off, n, nk2=ceil_div(n, 4))
+                      a1_off, w3_off, cf_off, a2_off, n, row_off=0 if vid is None else vid + 1, nk2=ceil_div(n, 4), rto=rto)
 
 
 def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_g: int, gout_layout: PlanarLayout, irreps_sh: Irreps,
@@ -833,8 +915,61 @@ def _last_layer(sd, prefix):
     return ks, np.asarray(sd[ks[-1]], dtype=np.float64)
 
 
+def choose_merge_groups(irreps_node, irreps_edge, irreps_sh, irreps_out, hidden: int) -> List[List[int]]:
+    """Which small output irreps share their MFMA row tiles (add_tp_items merge_groups): per parity class (l + [p odd]) mod 2, the
+    partition of the irreps with <= 16 channels that minimises the issued MFMAs of the block (exhaustive over the handful of
+    candidates; cost = the planner's own count: radial scale + GEMM1 + GEMM2 per super-path, node and edge branch)."""
+    irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
+    H4 = ceil_div(hidden, 16) * 4
+    branches = []
+    for nsrc, irr in ((2, irreps_node), (1, irreps_edge)):
+        irr_in = Irreps([(m * nsrc, l, p) for m, l, p in irr])
+        ins = tp_instructions(irr_in, irreps_sh, irreps_out)
+        npath: Dict[Tuple[int, int], int] = {}
+        for (i, j, k, slot) in ins:
+            npath[(i, k)] = npath.get((i, k), 0) + 1
+        branches.append((nsrc, PlanarLayout(irr), irr_in, npath))
+
+    def cost(groups):
+        tot = 0
+        for G in groups:
+            lmin = min(irreps_out[k][1] for k in G)
+            rto = ceil_div(sum(irreps_out[k][0] for k in G), 16)
+            for nsrc, lay, irr_in, npath in branches:
+                for i, (mi2, li, pi) in enumerate(irr_in):
+                    if li <= lmin and len(G) > 1:
+                        stacks = [(sum(npath.get((i, k), 0) * irreps_out[k][0] for k in G), li, rto)]
+                    else:
+                        stacks = [(npath.get((i, k), 0) * irreps_out[k][0], min(li, irreps_out[k][1]), ceil_div(irreps_out[k][0], 16)) for k in G]
+                    for nrows, mm, rt_o in stacks:
+                        nc, ch = 2 * mm + 1, rtm_max(2 * mm + 1) * 16
+                        for r0 in range(0, nrows, ch):
+                            n = min(nrows, r0 + ch) - r0
+                            rtm = ceil_div(n, 16)
+                            tot += H4 * rtm + nsrc * (lay.mulp[i] // 4) * rtm * nc + rt_o * ceil_div(n, 4) * nc + 60
+        return tot
+
+    def partitions(xs):
+        if not xs:
+            yield []
+            return
+        for p in partitions(xs[1:]):
+            yield [[xs[0]]] + p
+            for n in range(len(p)):
+                yield p[:n] + [[xs[0]] + p[n]] + p[n + 1:]
+
+    out: List[List[int]] = []
+    for cls in (0, 1):
+        cand = [k for k, (m, l, p) in enumerate(irreps_out) if m <= 16 and (l + (p == -1)) % 2 == cls and m <= seg_rows_cap(l)]
+        if len(cand) < 2 or len(cand) > 7:
+            continue
+        best = min((p for p in partitions(cand) if all(sum(irreps_out[k][0] for k in G) <= 64 for G in p)), key=cost)
+        out += [sorted(G, key=lambda k: (irreps_out[k][1], k)) for G in best if len(G) > 1]
+    return out
+
+
 def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool,
-                               skip_weight: Optional[np.ndarray] = None) -> Program:
+                               skip_weight: Optional[np.ndarray] = None, merge_groups: Sequence[Sequence[int]] = ()) -> Program:
     """MessagePackBlock (non-lite, message_passing.py:216-229) [+ the PairInteractionBlock skip o3.Linear on the edge
     features, interaction_blocks.py:151-152] as ONE fused-kernel program.  `sd`: reference-named arrays of the block."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
@@ -845,10 +980,12 @@ def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_ed
     prog, seg_of_k = new_program(irreps_out, H, lambda k, ir: SEG_UNROTATE if unrotate else 0)
     add_tp_items(prog, seg_of_k, PlanarLayout(irreps_node), 2, [SRC_XS, SRC_XD], irreps_sh, irreps_out,
                  np.asarray(sd["node_tensor_product.weight"]), w3n / math.sqrt(H),
-                 np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]), mlp=0)
+                 np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]), mlp=0,
+                 merge_groups=merge_groups)
     add_tp_items(prog, seg_of_k, PlanarLayout(irreps_edge), 1, [SRC_F], irreps_sh, irreps_out,
                  np.asarray(sd["edge_tensor_product.weight"]), w3e / math.sqrt(H),
-                 np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]), mlp=1)
+                 np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]), mlp=1,
+                 merge_groups=merge_groups)
     if skip_weight is not None:
         add_linear_items(prog, seg_of_k, PlanarLayout(irreps_edge), SRC_F, irreps_out, np.asarray(skip_weight))
     return prog.finalize()

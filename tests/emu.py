@@ -151,6 +151,7 @@ def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64
     Wt = prog.weights.astype(dtype)
     out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
     woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
+    assert not prog.vsegs, "a program with merged items has no segment-stationary form"
     for e0 in range(0, E, 16):
         ne = min(16, E - e0)
         cols = np.arange(e0, e0 + ne)
@@ -165,17 +166,19 @@ def run_program(prog, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64
 
 def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
     """the input-stationary schedule (plan.is_schedule, csrc/tp_is.hip): parts -> phases -> work groups -> items; all segment tiles of a
-    part live at once; items address their sources through the phase's staged blocks.  Checks the schedule invariants on the way:
-    every item exactly once, staged blocks inside the part's staging area, and -- unless the part keeps a private tile copy per wave --
-    one owner group per (phase, segment)."""
+    part live at once in a flat LDS image [tiles | trash row | row table ...]; an item addresses its sources through the phase's staged
+    blocks and the rows of its GEMM2 output through the part's ROW TABLE (item[23], item[22] row tiles) exactly as the kernel does --
+    which is also how a merged item reaches the tiles of several segments.  Checks the schedule invariants on the way: every item exactly
+    once, staged blocks inside the part's staging area, the LDS layout, and -- unless the part keeps a private tile copy per wave -- one
+    owner work group per (phase, tile)."""
     E = srcs[0].shape[0]
     Wt = prog.weights.astype(dtype)
     out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
     woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
+    nprog_seg = prog.seg_table.shape[0]
     for e0 in range(0, E, 16):
         ne = min(16, E - e0)
         cols = np.arange(e0, e0 + ne)
-        tiles = [np.zeros((int(s[2]) * 16, 2 * int(s[0]) + 1, 16), dtype=dtype) for s in sched.seg_table]
         seen, seg_seen = set(), set()
         for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _ in (tuple(int(v) for v in p) for p in sched.part_table):
             stage_floats = ctr_off - stage_off
@@ -189,6 +192,12 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
             assert rowtab_off == (P.IS_WAVES * copy_stride if copy_stride else tile_floats + maxstride) and stage_off == rowtab_off + rtn
             assert stage_off % 4 == 0
             rowtab = sched.rowtab[rt0:rt0 + rtn]
+            lds = np.zeros(tile_floats + maxstride, dtype=dtype)               # one tile copy + its trash row
+            # which tile a row-table entry points into (for the ownership check)
+            tile_of = np.full(tile_floats + maxstride, -1)
+            for g in part_segs:
+                sgr = sched.seg_table[g]
+                tile_of[int(sgr[5]):int(sgr[5]) + int(sgr[1]) * ((2 * int(sgr[0]) + 1) * 16 + 4)] = g
             for b0, b1, g0, g1 in sched.phase_table[ph0:ph0 + nph]:
                 staged = {}
                 used = 0
@@ -202,7 +211,7 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                 owner = set()
                 for gi in range(g0, g1):
                     ib, ie = (int(v) for v in sched.group_table[gi])
-                    sgs = set()
+                    touched = set()
                     for ii in range(ib, ie):
                         it = sched.item_table[ii].copy()
                         s0, s1, in_off, in_mulp, li = staged[int(it[1])]
@@ -212,22 +221,42 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                         seen.add(ii)
                         sg = int(it[19])
                         assert sg in part_segs
-                        sgs.add(sg)
                         seg = sched.seg_table[sg]
-                        assert tuple(int(v) for v in it[20:23]) == (int(seg[0]), int(seg[1]), int(seg[2]))
-                        # the row table of the item's segment: real rows -> centre column of that row in the tile, padding rows -> trash row
-                        lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
-                        rt = rowtab[int(it[23]):int(it[23]) + 16 * rto_]
-                        strd = (2 * lk_ + 1) * 16 + 4
-                        assert all(int(rt[r]) == toff_ + r * strd + lk_ * 16 for r in range(mul_))
-                        assert all(trash_off + 16 * int(it[6]) <= int(rt[r]) <= trash_off + maxstride - 16 * (int(it[6]) + 1) for r in range(mul_, 16 * rto_))
-                        tiles[sg] = _apply_item(prog, Wt, it[:P.ITEM_I32], srcs, h2, cols, ne, tiles[sg], int(seg[0]), int(seg[2]), dtype)
+                        assert tuple(int(v) for v in it[20:23])[:2] == (int(seg[0]), int(seg[1]))
+                        mm, rto_i = int(it[6]), int(it[22])
+                        merged = int(it[0]) == P.IT_TP and int(it[16]) > 0
+                        rt = rowtab[int(it[23]):int(it[23]) + 16 * rto_i]
+                        if not merged:                         # plain item: its own segment's rows, then the trash row
+                            lk_, mul_, toff_ = int(seg[0]), int(seg[1]), int(seg[5])
+                            strd = (2 * lk_ + 1) * 16 + 4
+                            assert rto_i == int(seg[2]) and all(int(rt[r]) == toff_ + r * strd + lk_ * 16 for r in range(mul_))
+                            assert all(int(rt[r]) >= trash_off for r in range(mul_, 16 * rto_i))
+                        for r in range(16 * rto_i):            # every addressed row lies inside a tile (or the trash row), all 2 mm + 1 columns
+                            lo, hi = int(rt[r]) - 16 * mm, int(rt[r]) + 16 * mm + 16
+                            assert 0 <= lo and hi <= tile_floats + maxstride
+                            assert len(set(tile_of[lo:hi].tolist())) == 1
+                            touched.add(int(tile_of[lo]))
+                        tmp = np.zeros((16 * rto_i, 2 * mm + 1, 16), dtype=dtype)
+                        rec = it[:P.ITEM_I32].copy()
+                        if merged:
+                            rec[16] = 0
+                        tmp = _apply_item(prog, Wt, rec, srcs, h2, cols, ne, tmp, mm, rto_i, dtype)
+                        for r in range(16 * rto_i):
+                            base = int(rt[r])
+                            for c in range(2 * mm + 1):
+                                lds[base + (c - mm) * 16:base + (c - mm) * 16 + 16] += tmp[r, c]
+                    touched.discard(-1)
                     if not copy_stride:
-                        assert len(sgs) == 1 and not (sgs & owner), "a shared tile must belong to exactly one work group per phase"
-                    owner |= sgs
+                        assert not (touched & owner), "a shared tile must belong to exactly one work group per phase"
+                    owner |= touched
+            for sg in sorted(part_segs):
+                seg = sched.seg_table[sg]
+                lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
+                strd = (2 * lk_ + 1) * 16 + 4
+                tile = np.zeros((rto_ * 16, 2 * lk_ + 1, 16), dtype=dtype)
+                tile[:mul_] = lds[toff_:toff_ + mul_ * strd].reshape(mul_, strd)[:, :(2 * lk_ + 1) * 16].reshape(mul_, 2 * lk_ + 1, 16)
+                _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)
         assert len(seen) == sched.item_table.shape[0] and len(seg_seen) == sched.seg_table.shape[0]
-        for sg, seg in enumerate(sched.seg_table):
-            _write_segment(prog, seg, tiles[sg], out, cols, ne, D, woffs, dtype)
     return out
 
 

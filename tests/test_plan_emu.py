@@ -265,6 +265,58 @@ def test_input_stationary_schedule_shipped_irreps(which):
     assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] <= sc.trash_off
 
 
+@pytest.mark.parametrize("which", ["A", "B"])
+def test_merged_items_shipped_irreps(which):
+    """small output irreps of one parity class share MFMA row tiles (plan.choose_merge_groups / Program.vsegs): fewer issued MFMAs and
+    items, the same results (emulated through the row table on a few edges, single- and multi-part schedules), LDS budget kept"""
+    import torch
+    import bench
+    from oracle import hamgnn_ref as R, e3
+    irr, sh = bench.IRREPS[which], bench.SH
+    groups = P.choose_merge_groups(irr, irr, sh, irr, 16)
+    assert groups and all(len(G) > 1 for G in groups)
+    I = so3.Irreps(irr)
+    for G in groups:
+        assert len({(I[k][1] + (I[k][2] == -1)) % 2 for k in G}) == 1 and sum(I[k][0] for k in G) <= 64
+    torch.manual_seed(1)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
+        E = 5
+        g = torch.Generator().manual_seed(1)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
+        shv = e3.spherical_harmonics(list(range(6)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        want = ref(src, dst, ef, shv, rbf).detach().numpy()
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay = P.PlanarLayout(irr)
+    D = emu.edge_wigner_all(n.numpy(), 6)
+    xs, xd, fe = (emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, 6) for t in (src, dst, ef))
+    hn = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
+    he = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
+    skip = np.random.default_rng(0).normal(size=sum(mm * mm for mm, _, _ in I))
+    plain = P.build_message_pack_program(sd, irr, irr, sh, irr, True)
+    merged = P.build_message_pack_program(sd, irr, irr, sh, irr, True, merge_groups=groups)
+    assert merged.mfma_per_wave < 0.97 * plain.mfma_per_wave and merged.item_table.shape[0] < 0.9 * plain.item_table.shape[0]
+    sc = P.is_schedule(merged)
+    assert sc.lds_floats * 4 <= P.IS_LDS_BYTES and sc.balance > 0.85
+    got = emu.run_program_is(merged, sc, [xs, xd, fe], (hn, he), D, 6)
+    assert rel(lay.from_planar(got), want) < 1e-6
+    for parts in (3, 8):                                      # the members of a merged item stay in one part
+        sp = P.is_schedule(merged, parts)
+        assert rel(lay.from_planar(emu.run_program_is(merged, sp, [xs, xd, fe], (hn, he), D, 6)), want) < 1e-6
+    # with the PairInteractionBlock skip Linear (plain IT_LIN items into tiles that merged items write as well)
+    m2 = P.build_message_pack_program(sd, irr, irr, sh, irr, False, skip, merge_groups=groups)
+    p2 = P.build_message_pack_program(sd, irr, irr, sh, irr, False, skip)
+    a = emu.run_program_is(m2, P.is_schedule(m2), [xs, xd, fe], (hn, he), None, None)
+    b = emu.run_program_is(p2, P.is_schedule(p2), [xs, xd, fe], (hn, he), None, None)
+    assert rel(a, b) < 1e-9
+
+
 def test_input_stationary_schedule_falls_back_when_too_wide():
     """tiles of all output segments beyond the LDS budget -> NotImplementedError (ops.DeviceProgram 'auto' keeps the segment-stationary kernel)"""
     import torch
@@ -360,6 +412,12 @@ def test_random_irreps_both_schedules_vs_oracle(seed):
     assert rel(lay.from_planar(outp), out) < 1e-6, irr
     outi = emu.run_program_is(prog, P.is_schedule(prog), [xs, xd, fe], (hn, he), D, lm)
     assert rel(lay.from_planar(outi), out) < 1e-6, irr
+    groups = P.choose_merge_groups(irr, irr, sh, irr, 16)
+    if groups:                                                 # small output irreps stacked into shared MFMA row tiles
+        pm = P.build_message_pack_program(sd, irr, irr, sh, irr, unrotate=True, merge_groups=groups)
+        assert pm.item_table.shape[0] < prog.item_table.shape[0]              # (the chooser trades MFMAs against the per-item latency: 60 slots)
+        outm = emu.run_program_is(pm, P.is_schedule(pm), [xs, xd, fe], (hn, he), D, lm)
+        assert rel(lay.from_planar(outm), out) < 1e-6, (irr, groups)
 
 
 @pytest.mark.parametrize("seed", range(6))
