@@ -200,7 +200,8 @@ def main():
     rows_per_launch = sum(r for _, r, _ in mp) / n_launch
     flops_launch = REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_per_launch
     useful = model.convolutions[0].conv_tp._dp.prog.flops_per_row * rows_per_launch
-    issued = model.convolutions[0].conv_tp._dp.prog.mfma_per_wave * 2048.0 / 16.0 * rows_per_launch
+    dp0 = model.convolutions[0].conv_tp._dp
+    issued = (dp0.prog.mfma_per_wave - (dp0.prog.mfma_odd_skipped if dp0.sched is not None else 0)) * 2048.0 / 16.0 * rows_per_launch
     ach = flops_launch / avg_s / 1e12
     kern = "is" if model.convolutions[0].conv_tp._dp.sched is not None else "seg"
     pmc_bytes = PMC_HBM_BYTES_PER_EDGE_BLOCK[(kern, args.irreps)]

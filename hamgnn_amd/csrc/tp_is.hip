@@ -89,10 +89,15 @@ __device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* l
 
 // One item on the workgroup's 16 edges.  stage: the phase's staged input block(s), image offset(piece p, row e) = 64 p + 4 e per
 // source (pieces of the FULL irrep block: component a, channel piece s -> p = a * P1 + s).
-template <int MM, int RTM, bool SPLIT>
+// ODD: a super-path with l_i + l_sh + l_k odd (item[7], the reversed-column flag).  Its aligned-frame coupling is antisymmetric in m, so
+// the coefficient of the centre column (m = 0) vanishes for every path of the item (checked by the planner's emulator): the kernel
+// works on the 2 MM remaining columns only -- column slot c < MM is real column c, slot c >= MM is real column c + 1.
+template <int MM, int RTM, bool SPLIT, bool ODD>
 __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
                                         float* __restrict__ lds, int64_t erow, int lane IS_PROF_ARG) {
-    constexpr int NC = 2 * MM + 1;
+    constexpr int NCR = 2 * MM + 1;                            // real columns (fragment layouts of cf, tile columns)
+    constexpr int NC = ODD ? 2 * MM : NCR;                     // column slots this item computes
+#define IS_COL(c) ((ODD && (c) >= MM) ? (c) + 1 : (c))
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], neg = it[7];     // [1], [2]: stage offsets of the sources
     const int ksteps = it[8], mlp = it[10], x4 = it[17], nk2 = it[18];
@@ -146,7 +151,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const int P1 = in_mulp >> 2;                               // float4 pieces per component
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;      // [src][G][rt][lane]
     const int cdir = neg ? -P1 : P1;                           // column c -> component (neg ? a_hi - c : a_lo + c)
-    const int c0p = (li - MM) * P1 + (neg ? (NC - 1) * P1 : 0);
+    const int c0p = (li - MM) * P1 + (neg ? (NCR - 1) * P1 : 0);
     f32x4 av_n[RTM];
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
@@ -154,7 +159,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     for (int si = 0; si < nsrc; ++si) {
         const float* __restrict__ sbase = stage + (si ? so1 : so0);
         const int abase = si * ngrp;
-        if (NC <= 3 && x4) {                                   // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
+        if (NCR <= 3 && x4) {                                  // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
             const float* __restrict__ fb = sbase + (c0p + g) * 64 + el * 4;
 #pragma unroll 1
             for (int G = 0; G < ngrp; ++G) {
@@ -166,7 +171,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
                 }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (c * cdir + 4 * G) * 64);
+                for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (IS_COL(c) * cdir + 4 * G) * 64);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -192,7 +197,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                     if (q < nq) {
                         float b[NC];
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) b[c] = fb[(c * cdir + 4 * G + q) * 64];
+                        for (int c = 0; c < NC; ++c) b[c] = fb[(IS_COL(c) * cdir + 4 * G + q) * 64];
 #pragma unroll
                         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -214,7 +219,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NC + c) * 4];
+            for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NCR + IS_COL(c)) * 4];
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
         // rows beyond mul_k (fragment padding) go to the shared trash row: no divergent branches (their L' columns are zero)
@@ -229,7 +234,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][c * 16];
+                for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][IS_COL(c) * 16];
 #pragma unroll 1
             for (int rtp = 0; rtp < rto; ++rtp) {
                 f32x4 av[RTM], acc[NC];
@@ -248,7 +253,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int c = 0; c < NC; ++c)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][c * 16];
+                        for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][IS_COL(c) * 16];
                 }
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
@@ -262,7 +267,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) trow[r][c * 16] = acc[c][r];
+                    for (int r = 0; r < 4; ++r) trow[r][IS_COL(c) * 16] = acc[c][r];
             }
         } else {
 #pragma unroll 1
@@ -284,7 +289,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[c][r] = trow[r][(c0 + c) * 16];
+                        for (int r = 0; r < 4; ++r) acc[c][r] = trow[r][IS_COL(c0 + c) * 16];
                     }
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
@@ -300,7 +305,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] = acc[c][r];
+                        for (int r = 0; r < 4; ++r) trow[r][IS_COL(c0 + c) * 16] = acc[c][r];
                     }
             }
         }
@@ -314,10 +319,11 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
             for (int r = 0; r < 4; ++r) {
                 float* __restrict__ t0 = tbase + rtab[row0 + 16 * rt + 4 * g + r];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) t0[c * 16] += mid[rt][c][r];
+                for (int c = 0; c < NC; ++c) t0[IS_COL(c) * 16] += mid[rt][c][r];
             }
     }
     IS_T(3);                                                    // scale-mul + GEMM2 + write-back
+#undef IS_COL
 }
 
 // un-rotate (optional) + planar store of one segment, rows split over the four waves; D blocks staged in `dst` (see kernel)
@@ -466,10 +472,18 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
 
 #ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+#define IS_CASE_ODD(MMv, RTMv)
 #else
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+#ifdef HG_NO_ODD_SKIP                 // A/B hook: odd items through the full-column code
+#define IS_CASE_ODD(MMv, RTMv) \
+    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+#else
+#define IS_CASE_ODD(MMv, RTMv) \
+    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, true>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+#endif
 #endif
 
 #define SEG_NEWBATCH (1 << 16)
@@ -568,10 +582,12 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
             const int ib = g_groups[2 * gi], ie = g_groups[2 * gi + 1];
             for (int ii = ib; ii < ie; ++ii) {
                 const int* __restrict__ it = g_items + ii * 24;
-                switch (it[6] * 8 + it[9]) {
+                switch (it[6] * 8 + it[9] + ((it[0] == 0 && it[7]) ? 64 : 0)) {
 #if IS_NW > 4                      // three waves per SIMD: 168 VGPRs per wave, row-tile table 2,2,2,1,1,1,1 (HG_RTM)
                     IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(3, 1) IS_CASE(4, 1) IS_CASE(5, 1)
                     IS_CASE(6, 1)
+                    IS_CASE_ODD(1, 1) IS_CASE_ODD(1, 2) IS_CASE_ODD(2, 1) IS_CASE_ODD(2, 2) IS_CASE_ODD(3, 1) IS_CASE_ODD(4, 1) IS_CASE_ODD(5, 1)
+                    IS_CASE_ODD(6, 1)
 #else
                     IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(0, 3) IS_CASE(0, 4)
                     IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(1, 3) IS_CASE(1, 4)
@@ -580,6 +596,12 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
                     IS_CASE(4, 1) IS_CASE(4, 2)
                     IS_CASE(5, 1)
                     IS_CASE(6, 1)
+                    IS_CASE_ODD(1, 1) IS_CASE_ODD(1, 2) IS_CASE_ODD(1, 3) IS_CASE_ODD(1, 4)      // odd super-paths: centre column skipped
+                    IS_CASE_ODD(2, 1) IS_CASE_ODD(2, 2) IS_CASE_ODD(2, 3)
+                    IS_CASE_ODD(3, 1) IS_CASE_ODD(3, 2)
+                    IS_CASE_ODD(4, 1) IS_CASE_ODD(4, 2)
+                    IS_CASE_ODD(5, 1)
+                    IS_CASE_ODD(6, 1)
 #endif
                     default: break;
                 }

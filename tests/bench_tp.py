@@ -53,7 +53,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
 prog = m._dp_adj.prog if a.adjoint else m._dp.prog
 print(json.dumps({"tag": a.tag, "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
-                  "issued_TF": prog.mfma_per_wave * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
+                  "issued_TF": (prog.mfma_per_wave - (prog.mfma_odd_skipped if (m._dp_adj if a.adjoint else m._dp).sched is not None else 0)) * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
                   "Medges_s": E / dt / 1e6, "checksum": float(out.double().abs().mean())}))
 if os.environ.get("HG_PROF") and m._dp.sched is not None:
     import ctypes as C

@@ -241,6 +241,9 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                         if merged:
                             rec[16] = 0
                         tmp = _apply_item(prog, Wt, rec, srcs, h2, cols, ne, tmp, mm, rto_i, dtype)
+                        if int(it[0]) == P.IT_TP and int(it[7]) and mm > 0:
+                            # odd super-path: the kernel does not compute the centre column -- it has to vanish identically
+                            assert not tmp[:, mm, :].any(), "centre column of an odd item is not structurally zero"
                         for r in range(16 * rto_i):
                             base = int(rt[r])
                             for c in range(2 * mm + 1):
