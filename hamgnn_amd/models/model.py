@@ -94,6 +94,39 @@ class Model(nn.Module):
         representation = self.representation(batch)
         return self.output_module(batch, representation)
 
+    @torch.no_grad()
+    def test(self, batches, log_dir: Optional[str] = None, device=None):
+        """The test stage of the reference (Model.test_step / test_epoch_end / _save_predictions_and_targets, Model.py:268-357, 548-567)
+        without Lightning: forward every batch, collect `predictions[loss["prediction"].lower()]` and `batch[loss["target"].lower()]` for
+        every loss entry that names a target (default: hamiltonian vs hamiltonian), concatenate over the batches and -- if `log_dir` is
+        given -- write `prediction_{key}.npy` / `target_{key}.npy` there, as the reference's `stage: test` does.  Returns
+        ({prediction key: array}, {target key: array}).  `batches`: an iterable of graph batches (hamgnn_amd.data.collate output)."""
+        import os
+        import numpy as np
+        from ..topo import gget
+        pairs = [(d["prediction"], d["target"]) for d in (self.losses or [{"prediction": "hamiltonian", "target": "hamiltonian"}])
+                 if (d.get("target") if hasattr(d, "get") else "target" in d)]
+        preds = {p: [] for p, _ in pairs}
+        targets = {t: [] for _, t in pairs}
+        for batch in batches:
+            if device is not None:
+                batch = batch.to(device)
+            out = self(batch)
+            for pk, tk in pairs:
+                preds[pk].append(out[pk.lower()].detach().float().cpu().numpy())
+                tgt = gget(batch, tk.lower())
+                if tgt is not None:
+                    targets[tk].append(tgt.detach().float().cpu().numpy())
+        preds = {k: np.concatenate(v) for k, v in preds.items() if v}
+        targets = {k: np.concatenate(v) for k, v in targets.items() if v}
+        if log_dir is not None:
+            os.makedirs(log_dir, exist_ok=True)
+            for pk, tk in pairs:
+                if pk in preds and tk in targets:
+                    np.save(os.path.join(log_dir, f"prediction_{pk}.npy"), preds[pk])
+                    np.save(os.path.join(log_dir, f"target_{tk}.npy"), targets[tk])
+        return preds, targets
+
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path: str, map_location=None, strict: bool = True, **model_kwargs):
         """Lightning's classmethod, for the checkpoint layouts the reference writes: keys ``representation.*`` / ``output_module.*``."""

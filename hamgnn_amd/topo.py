@@ -34,6 +34,14 @@ def ghas(data, key):
         return getattr(data, key, None) is not None
 
 
+def gset(data, key, value):
+    """attach a derived field to the caller's graph object: item assignment on mappings, setattr otherwise"""
+    if isinstance(data, dict):
+        data[key] = value
+    else:
+        setattr(data, key, value)
+
+
 def _sig(t):
     return None if t is None else (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
 

@@ -270,6 +270,33 @@ def check_conv_message_backward(device="cuda", n_atoms=10, seed=2):
             "g_node_rel_err": rel(ops.from_planar(gx, imap), x.grad), "g_edge_rel_err": rel(ops.from_planar(gf, imap), f.grad)}
 
 
+def check_test_stage(device="cuda", tmpdir="/tmp/hg_test_stage"):
+    """Model.test: the reference's `stage: test` output files (prediction_hamiltonian.npy / target_hamiltonian.npy, per-crystal
+    [on-site; off-site] rows) over two batches of mixed-size crystals; targets = the combined Hon / Hoff the head attaches to the batch"""
+    import shutil
+    from hamgnn_amd.data import synthetic as S, collate
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    cfg = dict(num_types=96, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False)
+    torch.manual_seed(3)
+    model = Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                                       soc_switch=False, calculate_sparsity=False),
+                  losses=[{"metric": "mae", "prediction": "hamiltonian", "target": "hamiltonian", "loss_weight": 1.0}])
+    gs = [S.add_random_targets(S.random_cell(4 + k, [14, 8, 6, 1], seed=k, density=0.004), 19, seed=k) for k in range(4)]
+    batches = [collate(gs[:2]), collate(gs[2:])]
+    shutil.rmtree(tmpdir, ignore_errors=True)
+    preds, targets = model.test(batches, log_dir=tmpdir, device=device)
+    P_, T_ = np.load(os.path.join(tmpdir, "prediction_hamiltonian.npy")), np.load(os.path.join(tmpdir, "target_hamiltonian.npy"))
+    rows = sum(g.num_nodes + g.num_edges for g in gs)
+    # the target file holds, crystal by crystal, [Hon; Hoff] of the inputs
+    want = np.concatenate([np.concatenate([g.Hon.numpy(), g.Hoff.numpy()]) for g in gs])
+    return {"rows": int(P_.shape[0]), "rows_expected": rows, "target_max_abs_diff": float(np.abs(T_ - want).max()),
+            "finite": bool(np.isfinite(P_).all()), "same_as_returned": bool(np.array_equal(P_, preds["hamiltonian"]))}
+
+
 def check_backbone(device="cuda", name="backbone"):
     m, f = build_backbone_from_fixture(device, name)
     g = to_graph(f["graph"], device)

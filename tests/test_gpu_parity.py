@@ -102,6 +102,12 @@ def test_conv_message_chain_data_gradient_vs_autograd():
     assert r["g_node_rel_err"] < G.TOL and r["g_edge_rel_err"] < G.TOL
 
 
+def test_model_test_stage_writes_the_reference_files():
+    r = G.check_test_stage()
+    print(r)
+    assert r["rows"] == r["rows_expected"] and r["target_max_abs_diff"] == 0.0 and r["finite"] and r["same_as_returned"]
+
+
 def test_backbone_golden():
     r = G.check_backbone()
     print(r)
