@@ -483,6 +483,100 @@ extern "C" int hg_gate(const float* x, int64_t x_stride, const int32_t* act_tab,
     return hg_check_launch("hg_gate");
 }
 
+// Backward of the gate (data gradient): with out[p] = f(x[src]) (activated scalar), x[src] * act(x[gate]) (gated component),
+//   gx[src]  = gy[p] * f'(x[src])                       activated scalar
+//   gx[src]  = gy[p] * act(x[gate])                     gated component
+//   gx[gate] = act'(x[gate]) * sum_p gy[p] * x[src(p)]  over the components the gate channel multiplies
+// Same tables and the same wave-per-row structure as gate_kernel: activations and their derivatives once per row into wave-private LDS
+// strips, the per-gate sums accumulate there (ds_add_f32 inside one wave: no barrier), input columns no output reads get 0.
+__device__ __forceinline__ float hg_act_grad(float x, int id, const float* __restrict__ cst) {
+    switch (id) {
+        case 1: return cst[1] / (1.f + __expf(-x));                                             // d/dx softplus = sigmoid
+        case 2: { const float t = tanhf(x); return cst[2] * (1.f - t * t); }
+        case 3: { const float s = 1.f / (1.f + __expf(-x)); return cst[3] * s * (1.f + x * (1.f - s)); }
+        case 4: return cst[4] * (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f));
+        default: return 1.f;
+    }
+}
+__global__ __launch_bounds__(256) void gate_backward_kernel(const float* __restrict__ x, int64_t xs, const float* __restrict__ gy, int64_t gs,
+                                                            const int2* __restrict__ act_tab, int nact, const int2* __restrict__ out_tab, int Dout,
+                                                            const float* __restrict__ cst, int64_t rows, int Din, float* __restrict__ gx, int64_t gxs) {
+    extern __shared__ __attribute__((aligned(16))) int sm_i[];
+    int2* __restrict__ s_out = reinterpret_cast<int2*>(sm_i);                           // [Dout]
+    int2* __restrict__ s_act = s_out + Dout;                                            // [nact]
+    float* __restrict__ s_val = reinterpret_cast<float*>(s_act + nact);                 // [HG_GATE_WAVES][3 nact + Din]: act, act', gate sums, the gx row
+    for (int i = threadIdx.x; i < Dout; i += blockDim.x) s_out[i] = out_tab[i];
+    for (int i = threadIdx.x; i < nact; i += blockDim.x) s_act[i] = act_tab[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* __restrict__ av = s_val + wave * (3 * nact + Din);
+    float* __restrict__ dv = av + nact;
+    float* __restrict__ sv = dv + nact;
+    float* __restrict__ row = sv + nact;                       // the gradient row is assembled in LDS (every column written once, then
+    float c[5];                                                // gate columns accumulate), and leaves as one coalesced copy
+#pragma unroll
+    for (int i = 0; i < 5; ++i) c[i] = cst[i];
+    for (int64_t r = (int64_t)blockIdx.x * HG_GATE_WAVES + wave; r < rows; r += (int64_t)gridDim.x * HG_GATE_WAVES) {
+        const float* __restrict__ xr = x + r * xs;
+        const float* __restrict__ gr = gy + r * gs;
+        for (int i = lane; i < Din; i += 64) row[i] = 0.f;
+        for (int i = lane; i < nact; i += 64) {
+            const int2 t = s_act[i];
+            av[i] = hg_act(xr[t.x], t.y, c);
+            dv[i] = hg_act_grad(xr[t.x], t.y, c);
+            sv[i] = 0.f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int p = lane; p < Dout; p += 64) {
+            const int2 t = s_out[p];
+            if (t.x < 0) continue;
+            const float g = gr[p];
+            if (t.x & 0x40000000) {                            // activated scalar: slot -> its input column
+                const int slot = t.x & 0x3fffffff;
+                float v = g * dv[slot];
+                if (t.y >= 0) {                                // (an activated scalar that is gated as well: not produced by the planner)
+                    atomicAdd(&sv[t.y], g * av[slot]);
+                    v *= av[t.y];
+                }
+                row[s_act[slot].x] = v;
+            } else if (t.y >= 0) {                             // gated component
+                row[t.x] = g * av[t.y];
+                atomicAdd(&sv[t.y], g * xr[t.x]);
+            } else {
+                row[t.x] = g;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < nact; i += 64) row[s_act[i].x] += sv[i] * dv[i];          // gate channels: act'(x) * sum (plain scalars: + 0)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* __restrict__ orow = gx + r * gxs;
+        for (int i = lane; i < Din; i += 64) orow[i] = row[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                       // the strips are rewritten by the next row
+    }
+}
+
+extern "C" int hg_gate_backward(const float* x, int64_t x_stride, const float* gy, int64_t gy_stride, const int32_t* act_tab, int nact,
+                                const int32_t* out_tab, int Dout, const float* consts, int64_t rows, int Din, float* gx, int64_t gx_stride,
+                                void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (rows <= 0) return 0;
+    if (nact < 0 || Dout <= 0 || Din <= 0) return hg_fail(-2, "hg_gate_backward: bad table sizes");
+    const size_t lds = sizeof(int) * (2 * (size_t)Dout + 2 * (size_t)nact + (size_t)HG_GATE_WAVES * (3 * (size_t)nact + (size_t)Din));
+    if (lds > 64 * 1024) return hg_fail(-2, "hg_gate_backward: row too wide for the LDS tables");
+    const int64_t want = (rows + HG_GATE_WAVES - 1) / HG_GATE_WAVES;
+    const int64_t blocks = want < 256 * 8 ? want : 256 * 8;
+    gate_backward_kernel<<<dim3((unsigned)blocks), 256, lds, (hipStream_t)stream>>>(x, x_stride, gy, gy_stride, (const int2*)act_tab, nact,
+                                                                                    (const int2*)out_tab, Dout, consts, rows, Din, gx, gx_stride);
+    return hg_check_launch("hg_gate_backward");
+}
+
 __global__ void add_rows_kernel(const float* __restrict__ a, int64_t sa, const float* __restrict__ b, int64_t sb,
                                 const float* __restrict__ c, int64_t sc, int64_t rows, int D, float* __restrict__ out, int64_t so) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

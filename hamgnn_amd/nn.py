@@ -54,6 +54,34 @@ class E3Linear(nn.Module):
         return ops.tp_fused(self._dp, [x_planar], x_planar.shape[0], res=res)
 
 
+    # ---- backward: data gradient on the same streaming kernel with transposed blocks; the weight gradient of a Linear is
+    #      a plain reduction over the rows (one library GEMM per path)
+    def backward_data(self, gy_planar: torch.Tensor) -> torch.Tensor:
+        if getattr(self, "_dp_adj", None) is None:
+            W = self.weight.detach().cpu().double().numpy()
+            self._dp_adj = ops.DeviceLinear(P.build_linear_adjoint_tables(W, self.irreps_in, self.irreps_out), gy_planar.device)
+        return ops.linear_planar(self._dp_adj, gy_planar, tag="linear_adjoint")
+
+    def weight_grad(self, x_planar: torch.Tensor, gy_planar: torch.Tensor) -> torch.Tensor:
+        """d sum(y * gy) / d weight in e3nn's flat layout (paths (i_in, i_out), each [mul_in, mul_out], 1 / sqrt(fan_in) normalisation):
+        per path one GEMM over (rows x components) on the planar blocks (torch.einsum = rocBLAS / hipBLASLt: a library GEMM)."""
+        li, lo = P.PlanarLayout(self.irreps_in), P.PlanarLayout(self.irreps_out)
+        paths = [(i, k) for i, (_, l1, p1) in enumerate(self.irreps_in) for k, (_, l2, p2) in enumerate(self.irreps_out) if (l1, p1) == (l2, p2)]
+        fan = {}
+        for i, k in paths:
+            fan[k] = fan.get(k, 0) + self.irreps_in[i][0]
+        rows = x_planar.shape[0]
+        out = []
+        for i, k in paths:
+            mi, l, _ = self.irreps_in[i]
+            mk = self.irreps_out[k][0]
+            n = 2 * l + 1
+            X = x_planar[:, li.off[i]:li.off[i] + n * li.mulp[i]].reshape(rows * n, li.mulp[i])[:, :mi]
+            G = gy_planar[:, lo.off[k]:lo.off[k] + n * lo.mulp[k]].reshape(rows * n, lo.mulp[k])[:, :mk]
+            out.append(((X.t() @ G) / math.sqrt(fan[k])).reshape(-1))
+        return torch.cat(out) if out else x_planar.new_zeros(0)
+
+
 class E3TensorProduct(nn.Module):
     """o3.TensorProduct(uvw, internal shared weights) parameter holder; instructions by the reference rule."""
 
@@ -268,6 +296,24 @@ class ResidualBlock(nn.Module):
             self.compile(x_planar.device)
         res = ([x_planar] if self.resnet else []) + ([extra] if extra is not None else [])
         return self.linear2(ops.gate(self.linear1(x_planar), self._tab, self._cst), res=res)      # adds fused into linear2's epilogue
+
+
+    def backward(self, x_planar, gy_planar, extra_given: bool = False):
+        """gradient of forward(x, extra) = [x +] Lin2(Gate(Lin1(x))) [+ extra] for the output gradient gy (planar rows): returns
+        (g_x, {"linear1.weight": ..., "linear2.weight": ...}) -- and g_extra = gy.  Recomputes the two cheap intermediates; the data
+        gradients run on hg_linear_planar (transposed blocks) and hg_gate_backward, the weight gradients are one GEMM per path."""
+        if self._tab is None:
+            self.compile(x_planar.device)
+        y1 = self.linear1(x_planar)                            # gate input rows
+        y2 = ops.gate(y1, self._tab, self._cst)
+        g_w2 = self.linear2.weight_grad(y2, gy_planar)
+        g_y2 = self.linear2.backward_data(gy_planar)
+        g_y1 = ops.gate_backward(y1, g_y2, self._tab, self._cst)
+        g_w1 = self.linear1.weight_grad(x_planar, g_y1)
+        g_x = self.linear1.backward_data(g_y1)
+        if self.resnet:
+            g_x = g_x + gy_planar
+        return g_x, {"linear1.weight": g_w1, "linear2.weight": g_w2}
 
 
 class ConvBlockE3(nn.Module):

@@ -311,6 +311,18 @@ def embed_lookup(Ta, Tb, z, idx_a, idx_b, rows, T, Tp):
 
 
 @_on_tensor_device
+def gate_backward(x: torch.Tensor, gy: torch.Tensor, tabs, consts: torch.Tensor) -> torch.Tensor:
+    """data gradient of gate(x, tabs, consts): [rows, Din] from the gate input rows and the gradient of the gate output rows"""
+    act_tab, out_tab = tabs
+    rows, Din, Dout = x.shape[0], int(x.shape[1]), int(out_tab.shape[0])
+    assert gy.shape == (rows, Dout) and x.stride(1) == 1 and gy.stride(1) == 1
+    gx = torch.empty(rows, Din, device=x.device, dtype=torch.float32)
+    check(lib().hg_gate_backward(ptr(x), i64(x.stride(0)), ptr(gy), i64(gy.stride(0)), ptr(act_tab), i32(act_tab.shape[0]), ptr(out_tab), i32(Dout),
+                                 ptr(consts), i64(rows), i32(Din), ptr(gx), i64(Din), _stream()), "hg_gate_backward")
+    return gx
+
+
+@_on_tensor_device
 def ham_merge(coeff, geo: Optional[Geometry], slot_tab, cg_ptr, cg_idx, cg_val, nout):
     rows = coeff.shape[0]
     out = torch.empty(rows, nout, device=coeff.device, dtype=torch.float32)

@@ -878,6 +878,13 @@ def build_linear_tables(weight: np.ndarray, irreps_in, irreps_out) -> LinearTabl
     return linear_tables(o3_linear_mats(weight, irreps_in, irreps_out), PlanarLayout(irreps_in), PlanarLayout(irreps_out))
 
 
+def build_linear_adjoint_tables(weight: np.ndarray, irreps_in, irreps_out) -> LinearTables:
+    """data gradient of o3.Linear(irreps_in -> irreps_out) as tables of the same streaming kernel: g_x[i] = sum_k W_ik^T g_y[k] with the
+    forward's normalised blocks transposed."""
+    mats = {(k, i): M.T for (i, k), M in o3_linear_mats(weight, irreps_in, irreps_out).items()}
+    return linear_tables(mats, PlanarLayout(irreps_out), PlanarLayout(irreps_in))
+
+
 MAX_SEG_ROWS = 64        # output channels per segment (bounds the LDS tile); wider irreps are split column-wise
 
 

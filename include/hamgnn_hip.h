@@ -109,6 +109,11 @@ int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_t* rowptr, 
 int hg_gate(const float* x, int64_t x_stride, const int32_t* act_tab, int nact, const int32_t* out_tab, int Dout, const float* consts,
             int64_t rows, float* out, int64_t out_stride, void* stream);
 
+/* data gradient of hg_gate (same tables): gx [rows, Din] from the gate's input rows x and the gradient gy [rows, Dout] of its output:
+ * activated scalars gy * act'(x), gated components gy * act(gate), gate channels act'(gate) * sum gy * x over the components they gate.  */
+int hg_gate_backward(const float* x, int64_t x_stride, const float* gy, int64_t gy_stride, const int32_t* act_tab, int nact,
+                     const int32_t* out_tab, int Dout, const float* consts, int64_t rows, int Din, float* gx, int64_t gx_stride, void* stream);
+
 /* y = a + b (+ c) on [rows, D] planar rows: ResidualBlock "+x" (interaction_blocks.py:355-356), ConvBlockE3 "+= skip"
  * (convolution.py:155-156).  c may be NULL.                                                                         */
 int hg_add_rows(const float* a, int64_t sa, const float* b, int64_t sb, const float* c, int64_t sc, int64_t rows, int D,

@@ -297,6 +297,36 @@ def check_test_stage(device="cuda", tmpdir="/tmp/hg_test_stage"):
             "finite": bool(np.isfinite(P_).all()), "same_as_returned": bool(np.array_equal(P_, preds["hamiltonian"]))}
 
 
+def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):
+    """backward of ResidualBlock (x + Lin2(Gate(Lin1(x)))): data gradient (hg_linear_planar on transposed blocks,
+    hg_gate_backward) and the two Linear weight gradients (one GEMM per path) vs torch.autograd through the fp64 oracle"""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    irr = irr or "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e"
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.ResidualBlock(irr, irr)
+        g = torch.Generator().manual_seed(seed)
+        D = ref.linear1.irreps_in.dim
+        x = torch.randn(rows, D, generator=g).requires_grad_()
+        gy = torch.randn(rows, D, generator=g)
+        (ref(x) * gy).sum().backward()
+    finally:
+        torch.set_default_dtype(prev)
+    m = load_weights(hnn.ResidualBlock(irr, irr), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    m.compile(device)
+    lay = P.PlanarLayout(irr)
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    xp = ops.to_planar(x.detach().float().to(device), imap, lay.dim)
+    gp = ops.to_planar(gy.float().to(device), imap, lay.dim)
+    gx, gw = m.backward(xp, gp)
+    torch.cuda.synchronize()
+    return {"g_x_rel_err": rel(ops.from_planar(gx, imap), x.grad), "g_w1_rel_err": rel(gw["linear1.weight"], ref.linear1.weight.grad),
+            "g_w2_rel_err": rel(gw["linear2.weight"], ref.linear2.weight.grad)}
+
+
 def check_backbone(device="cuda", name="backbone"):
     m, f = build_backbone_from_fixture(device, name)
     g = to_graph(f["graph"], device)

@@ -108,6 +108,13 @@ def test_model_test_stage_writes_the_reference_files():
     assert r["rows"] == r["rows_expected"] and r["target_max_abs_diff"] == 0.0 and r["finite"] and r["same_as_returned"]
 
 
+@pytest.mark.parametrize("irr", [None, "8x0e+4x0o+4x1o+2x1e+2x2o+3x2e+2x3o"])
+def test_residual_block_backward_vs_autograd(irr):
+    r = G.check_residual_block_backward(irr=irr)
+    print(r)
+    assert max(r.values()) < G.TOL
+
+
 def test_backbone_golden():
     r = G.check_backbone()
     print(r)

@@ -448,6 +448,27 @@ def test_streaming_linear_tables_vs_oracle(seed):
     assert np.allclose(emu.run_linear_tables(tabs, li.to_planar(x.numpy()), res=(r1, r2)), got + r1 + r2)
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_linear_adjoint_tables_vs_autograd(seed):
+    """data gradient of o3.Linear = the streaming kernel on transposed blocks (plan.build_linear_adjoint_tables), emulated, vs autograd"""
+    import torch
+    from oracle import e3
+    rng = np.random.default_rng(400 + seed)
+    irr_in = _random_irreps(rng, int(rng.integers(1, 4)))
+    irr_out = _random_irreps(rng, int(rng.integers(1, 4)))
+    if seed == 0:
+        irr_in, irr_out = "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e", "199x0e+64x0o+32x1o+16x1e+12x2o+25x2e+3x3o"
+    torch.manual_seed(seed)
+    lin = e3.Linear(irr_in, irr_out).double()
+    x = torch.randn(9, e3.Irreps(irr_in).dim, dtype=torch.float64, requires_grad=True)
+    gy = torch.randn(9, e3.Irreps(irr_out).dim, dtype=torch.float64)
+    (lin(x) * gy).sum().backward()
+    li, lo = P.PlanarLayout(irr_in), P.PlanarLayout(irr_out)
+    tabs = P.build_linear_adjoint_tables(lin.weight.detach().numpy(), irr_in, irr_out)
+    got = emu.run_linear_tables(tabs, lo.to_planar(gy.numpy()))
+    assert np.abs(li.from_planar(got) - x.grad.numpy()).max() <= 1e-6 * max(1.0, np.abs(x.grad.numpy()).max()), (irr_in, irr_out)
+
+
 def _adjoint_case(irr, sh, lmax, lsh, seed, E=17, radial=(16, 16)):
     """oracle MessagePackBlock + torch.autograd: gradients of sum(out * G) with respect to the three inputs; and the emulator inputs"""
     import torch
