@@ -190,6 +190,46 @@ class HamGNNPlusPlusOut(nn.Module):
         ops.ham_readout(net_off(edge_rot), geo, self._slot, *self._cg, n, pairs, H0_off, self._mask, z, src, dst, off, self.hamiltonian_irreps.lmax, 1.0, self.symmetrize)
         return on, off
 
+    # ---- backward of the non-SOC read-out (K6 data gradient + the head's weight gradients)
+    def backward(self, data, graph_representation, grad_hamiltonian):
+        """grad_hamiltonian: gradient with respect to result["hamiltonian"] ([N + E, nao^2] rows in the forward's order).  Returns
+        (g_node_planar [N, Dp], g_edge_planar_rot [E, Dp] -- gradients of the representation's planar node rows and edge-frame edge rows --,
+        {parameter name: gradient}).  Chain: mask and symmetrisation are their own adjoint (hg_ham_finish on the gradient), the CG merge
+        + reorder is a CSR map applied transposed (hg_ham_merge with plan.ham_merge_adjoint_tables), the un-rotation's adjoint is the
+        rotation (hg_rotate_gather), then HamLayer.backward (Linear / Gate adjoints, weight gradients as GEMMs)."""
+        if self.soc_switch or not self.ham_only or self.zero_point_shift:
+            raise NotImplementedError("head backward: non-SOC, ham_only, without the zero-point shift")
+        rep = graph_representation
+        dev = data.z.device
+        if self._compiled_for != dev:
+            self.compile(dev)
+        if gget(data, "node_counts") is not None and int(gget(data, "node_counts").numel()) > 1:
+            raise NotImplementedError("head backward: single-crystal batches")
+        geo = rep["_geometry"]
+        node_pl, edge_rot = rep["_node_planar"], rep["_edge_planar_rot"]
+        inv, _ = self._global_inverse(data)
+        z = data.z.contiguous()
+        N, n = z.shape[0], self.nao_max
+        gH = grad_hamiltonian.contiguous().float()
+        if getattr(self, "_adj_tabs", None) is None:
+            net = self.onsite_hamiltonian_network
+            glay = P.PlanarLayout(net.girr)
+            st, ptr_, idx_, val_ = (t.cpu().numpy() for t in (self._slot,) + self._cg)
+            sid, pT, iT, vT, scat = P.ham_merge_adjoint_tables(st, ptr_, idx_, val_, glay.dim)
+            self._adj_tabs = tuple(torch.from_numpy(a).to(dev) for a in (sid, pT, iT, vT, scat)) + (
+                torch.from_numpy(P.rotate_table(glay)).to(dev), int(st.shape[0]))
+        sid, pT, iT, vT, scat, rot_g, ncoef = self._adj_tabs
+        # mask . symmetrise is self-adjoint (the orbital mask of an edge equals the transposed mask of its inverse edge)
+        g_on = ops.ham_finish(gH[:N], None, None, self._mask, z, None, None, n, 1.0, self.symmetrize)
+        g_off = ops.ham_finish(gH[N:], inv, None, self._mask, z, geo.src, geo.dst, n, 1.0, self.symmetrize)
+        gc_on = ops.from_planar(ops.ham_merge(g_on, None, sid, pT, iT, vT, ncoef), scat)
+        gc_off = ops.rotate_gather(ops.from_planar(ops.ham_merge(g_off, None, sid, pT, iT, vT, ncoef), scat), None, geo, rot_g)
+        g_node, gw_on = self.onsite_hamiltonian_network.backward(node_pl, gc_on)
+        g_edge, gw_off = self.offsite_hamiltonian_network.backward(edge_rot, gc_off)
+        grads = {"onsite_hamiltonian_network." + k: v for k, v in gw_on.items()}
+        grads.update({"offsite_hamiltonian_network." + k: v for k, v in gw_off.items()})
+        return g_node, g_edge, grads
+
     def forward(self, data, graph_representation=None):
         rep = graph_representation
         dev = data.z.device

@@ -499,6 +499,46 @@ class HamLayer(nn.Module):
             prog = P.build_linear_program(W, self.irreps_in, self.ham_irreps)
         self._dp = ops.DeviceProgram(prog, device)
 
+    # ---- backward
+    def backward(self, x_planar, g_out_planar):
+        """gradient of forward(x) = linear_transform(residual_block(x)) for the gradient of its (grouped planar) output rows: returns
+        (g_x, {parameter name: gradient in the reference's flat layout})"""
+        if not isinstance(self._dp, ops.DeviceLinear) or self.slot_pos is None and not all(m == 1 for m, _, _ in self.ham_irreps):
+            raise NotImplementedError("HamLayer.backward: streaming Linear path of the Hamiltonian networks only")
+        W = self.linear_transform.weight.detach().cpu().double().numpy()
+        mats, girr, slot_pos = P.ham_linear_mats(W, self.irreps_in, self.ham_irreps, self.keep)
+        dev = x_planar.device
+        if getattr(self, "_dp_adj", None) is None:
+            self._dp_adj = ops.DeviceLinear(P.linear_tables({(g, i): M.T for (i, g), M in mats.items()}, P.PlanarLayout(girr),
+                                                            P.PlanarLayout(self.irreps_in)), dev)
+        y = self.residual_block(x_planar)
+        # weight gradient of linear_transform in e3nn's flat layout: for i_in, for i_out (matching ir): block (mul_in, 1) / sqrt(fan_in)
+        li, lg = P.PlanarLayout(self.irreps_in), P.PlanarLayout(girr)
+        rows = x_planar.shape[0]
+        fan = {}
+        for i, (mi, l1, p1) in enumerate(self.irreps_in):
+            for s_, (_, L, p) in enumerate(self.ham_irreps):
+                if (l1, p1) == (L, p):
+                    fan[s_] = fan.get(s_, 0) + mi
+        blocks = {}
+        for (i, g) in mats:
+            mi, l, _ = self.irreps_in[i]
+            n = 2 * l + 1
+            X = y[:, li.off[i]:li.off[i] + n * li.mulp[i]].reshape(rows * n, li.mulp[i])[:, :mi]
+            G = g_out_planar[:, lg.off[g]:lg.off[g] + n * lg.mulp[g]].reshape(rows * n, lg.mulp[g])[:, :girr[g][0]]
+            blocks[(i, g)] = X.t() @ G                          # [mul_in, outputs of the group]
+        gw = []
+        for i, (mi, l1, p1) in enumerate(self.irreps_in):
+            for s_, (_, L, p) in enumerate(self.ham_irreps):
+                if (l1, p1) == (L, p):
+                    pos = slot_pos[s_]
+                    gw.append(blocks[(i, pos[0])][:, pos[1]] / math.sqrt(fan[s_]) if pos is not None else y.new_zeros(mi))
+        g_y = ops.linear_planar(self._dp_adj, g_out_planar, tag="linear_adjoint")
+        g_x, g_res = self.residual_block.backward(x_planar, g_y)
+        grads = {"linear_transform.weight": torch.cat(gw)}
+        grads.update({"residual_block." + k: v for k, v in g_res.items()})
+        return g_x, grads
+
     def forward(self, x_planar):
         y = self.residual_block(x_planar)
         if isinstance(self._dp, ops.DeviceLinear):

@@ -1417,6 +1417,34 @@ def ham_merge_tables(row: Irreps, nao, index_change, minus_index, girr: Irreps, 
     return slot_tab, np.asarray(ptr, np.int32), np.asarray(idx, np.int32), np.asarray(val, np.float32)
 
 
+def ham_merge_adjoint_tables(slot_tab: np.ndarray, ptr: np.ndarray, idx: np.ndarray, val: np.ndarray, planar_dim: int):
+    """Data gradient of hg_ham_merge from its own tables: with H = C (D^T y) (C = the CSR map, D^T = the per-irrep
+    un-rotation of the planar coefficient rows y) the gradient is g_y = D (C^T g_H).  Returns
+      slot_id int32[nout][4]  identity slots (the first launch reads g_H columns as they are, no rotation),
+      (ptrT, idxT, valT)      C^T as CSR over the coefficients,
+      scatter int32[planar_dim]  planar column -> coefficient index (or -1): hg_from_planar places C^T g_H into the planar rows,
+    after which hg_rotate_gather (not transposed) applies D."""
+    nout, ncoef = len(ptr) - 1, slot_tab.shape[0]
+    slot_id = np.zeros((nout, 4), dtype=np.int32)
+    slot_id[:, 2] = np.arange(nout)
+    rows = [[] for _ in range(ncoef)]
+    for p_ in range(nout):
+        for k in range(int(ptr[p_]), int(ptr[p_ + 1])):
+            rows[int(idx[k])].append((p_, float(val[k])))
+    ptrT, idxT, valT = [0], [], []
+    for q in range(ncoef):
+        for p_, v in rows[q]:
+            idxT.append(p_)
+            valT.append(v)
+        ptrT.append(len(idxT))
+    scatter = np.full(planar_dim, -1, dtype=np.int32)
+    for q in range(ncoef):
+        if rows[q]:
+            L, a, base, stride = (int(v) for v in slot_tab[q])
+            scatter[base + a * stride] = q
+    return slot_id, np.asarray(ptrT, np.int32), np.asarray(idxT, np.int32), np.asarray(valT, np.float32), scatter
+
+
 def shell_block_table(row: Irreps, nao) -> np.ndarray:
     """int32[nao^2][4] = {r0, r1, c0, c1}: the (row shell, col shell) block of every matrix element (ksi block means)."""
     bounds, o = [], 0

@@ -327,6 +327,52 @@ def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):
             "g_w2_rel_err": rel(gw["linear2.weight"], ref.linear2.weight.grad)}
 
 
+def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None):
+    """backward of the non-SOC read-out head (K6 + HamLayer): gradient of sum(H * G) with respect to the representation
+    (node_attr, edge_attr) and every head parameter vs torch.autograd through the fp64 oracle"""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import ops, plan as P
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    irr = irr or MINI
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True)
+    finally:
+        torch.set_default_dtype(prev)
+    g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004), nao, seed=seed)
+    N, E = g.num_nodes, g.num_edges
+    gen = torch.Generator().manual_seed(seed)
+    D = R.Irreps(irr).dim
+    node = torch.randn(N, D, generator=gen, dtype=torch.float64).requires_grad_()
+    edge = torch.randn(E, D, generator=gen, dtype=torch.float64).requires_grad_()
+    G_ = torch.randn(N + E, nao * nao, generator=gen, dtype=torch.float64)
+    g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    (ref(g64, {"node_attr": node, "edge_attr": edge})["hamiltonian"] * G_).sum().backward()
+    hip = load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                         soc_switch=False, calculate_sparsity=False, zero_point_shift=False), dict(ref.state_dict()))
+    hip.compile(device)
+    gd = g.to(device)
+    lay = P.PlanarLayout(irr)
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    geo = ops.Geometry(gd.pos, gd.edge_index, gd.nbr_shift, 1.0, 1, hip._lmax, hip._jtab)
+    node_pl = ops.to_planar(node.detach().float().to(device), imap, lay.dim)
+    edge_rot = ops.rotate_gather(ops.to_planar(edge.detach().float().to(device), imap, lay.dim), None, geo, hip._rot_tab)
+    rep = {"_node_planar": node_pl, "_edge_planar_rot": edge_rot, "_geometry": geo}
+    H = hip(gd, rep)["hamiltonian"]
+    g_node, g_edge, gw = hip.backward(gd, rep, G_.float().to(device))
+    g_edge = ops.rotate_gather(g_edge, None, geo, hip._rot_tab, transpose=True)
+    torch.cuda.synchronize()
+    out = {"forward_rel_err": rel(H, ref(g64, {"node_attr": node, "edge_attr": edge})["hamiltonian"]),
+           "g_node_rel_err": rel(ops.from_planar(g_node, imap), node.grad), "g_edge_rel_err": rel(ops.from_planar(g_edge, imap), edge.grad)}
+    refp = dict(ref.named_parameters())
+    assert set(gw) == set(refp), sorted(set(gw) ^ set(refp))[:4]
+    out["g_weights_max_rel_err"] = max(rel(gw[k], refp[k].grad) for k in gw)
+    return out
+
+
 def check_backbone(device="cuda", name="backbone"):
     m, f = build_backbone_from_fixture(device, name)
     g = to_graph(f["graph"], device)

@@ -115,6 +115,12 @@ def test_residual_block_backward_vs_autograd(irr):
     assert max(r.values()) < G.TOL
 
 
+def test_head_backward_vs_autograd():
+    r = G.check_head_backward()
+    print(r)
+    assert max(r.values()) < G.TOL
+
+
 def test_backbone_golden():
     r = G.check_backbone()
     print(r)

@@ -155,6 +155,25 @@ def test_head_linear_and_merge_tables(ham_type, nao):
     assert rel(ys, yp) < 1e-6
 
 
+def test_ham_merge_adjoint_tables():
+    """<C y, g> == <y, C^T g> for the CSR merge map and its transposed tables (plan.ham_merge_adjoint_tables), plus the scatter map"""
+    from hamgnn_amd import basis as B
+    t = B.basis_table("openmx", 19)
+    row = so3.Irreps(t["row"])
+    hirr = P.ham_irreps(row)
+    W = np.random.default_rng(0).normal(size=sum(m for m, l, p in so3.Irreps(MINI) for _, L, pp in hirr if (l, p) == (L, pp)))
+    mats, girr, slot_pos = P.ham_linear_mats(W, MINI, hirr)
+    st, ptr, idx, val = P.ham_merge_tables(row, 19, t["index_change"], t["minus_index"], girr, slot_pos)
+    glay = P.PlanarLayout(girr)
+    sid, pT, iT, vT, scat = P.ham_merge_adjoint_tables(st, ptr, idx, val, glay.dim)
+    rng = np.random.default_rng(1)
+    yp, g = rng.normal(size=(3, glay.dim)), rng.normal(size=(3, 361))
+    Cy = _merge_emu(yp, st, ptr, idx, val)
+    CTg_coef = _merge_emu(g, sid, pT, iT, vT)                       # [3, ncoef]
+    CTg = np.where(scat[None, :] >= 0, CTg_coef[:, np.maximum(scat, 0)], 0.0)
+    assert abs((Cy * g).sum() - (yp * CTg).sum()) < 1e-9 * abs((Cy * g).sum())
+
+
 RICH6 = "4x0e+4x0o+2x1o+2x1e+2x2e+2x2o+2x3o+2x3e+1x4e+1x4o+1x5o+1x5e+1x6e+1x6o"
 
 
