@@ -1,0 +1,58 @@
+"""Fine-tuning the read-out head on a frozen backbone (the part of the training path that is built): the forward and the
+backward of HamGNNPlusPlusOut (non-SOC) run on the HIP kernels, the gradients land in `parameter.grad` in the reference's flat layouts, so
+any torch optimiser steps them.  What the reference's Lightning `training_step` does around it (hamgnn/models/Model.py:150-196: loss from
+`losses: [{metric, prediction, target, loss_weight}]`) is restated for the Hamiltonian entry.
+
+Not built: gradients of the backbone's fused edge kernel weights -- the backbone stays frozen."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .topo import gget
+
+
+def _loss_and_grad(pred: torch.Tensor, target: torch.Tensor, metric: str):
+    diff = pred - target
+    n = diff.numel()
+    metric = metric.lower()
+    if metric == "mae":
+        return diff.abs().mean(), torch.sign(diff) / n
+    if metric == "mse":
+        return (diff * diff).mean(), 2.0 * diff / n
+    if metric == "rmse":
+        rm = torch.sqrt((diff * diff).mean())
+        return rm, diff / (n * rm.clamp_min(1e-30))
+    raise ValueError(f"unsupported loss metric {metric!r} (mae | mse | rmse)")
+
+
+@torch.no_grad()
+def head_training_step(model, batch, metric: str = "mae", target: Optional[torch.Tensor] = None,
+                       representation=None) -> Dict[str, torch.Tensor]:
+    """One loss / gradient evaluation for the head of `model` (hamgnn_amd.models.model.Model): forward, loss(hamiltonian, target),
+    backward through the head on the GPU kernels, `.grad` of every head parameter set (accumulated if already present).  The caller owns
+    the optimiser: `opt.step(); opt.zero_grad()` -- the head repacks its weights on the next forward.
+    representation: reuse a frozen backbone's output for this batch (it does not change while only the head is trained)."""
+    head = model.output_module
+    rep = representation if representation is not None else model.representation(batch)
+    out = head(batch, rep)
+    tgt = target if target is not None else gget(batch, "hamiltonian")
+    if tgt is None:
+        raise ValueError("head_training_step: the batch carries no target (Hon / Hoff or hamiltonian)")
+    H = out["hamiltonian"]
+    loss, gH = _loss_and_grad(H, tgt.to(H.dtype), metric)
+    g_node, g_edge, grads = head.backward(batch, rep, gH)
+    params = dict(head.named_parameters())
+    for k, g in grads.items():
+        p = params[k]
+        g = g.reshape(p.shape).to(p.dtype)
+        p.grad = g.clone() if p.grad is None else p.grad + g
+    for m in head.modules():                                   # the packed weight fragments are stale once the optimiser has stepped
+        if hasattr(m, "_dp"):
+            m._dp = None
+            if hasattr(m, "_dp_adj"):
+                m._dp_adj = None
+    head._compiled_for = None
+    head._adj_tabs = None
+    return {"loss": loss, "representation": rep, "g_node_planar": g_node, "g_edge_planar_rot": g_edge}

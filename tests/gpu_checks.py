@@ -373,6 +373,39 @@ def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None):
     return out
 
 
+def check_head_finetune(device="cuda", steps=40):
+    """fine-tuning the read-out head on a frozen backbone with the HIP forward + backward and torch's Adam: the loss on a small crystal
+    falls (hamgnn_amd.training.head_training_step)"""
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    from hamgnn_amd.training import head_training_step
+    cfg = dict(num_types=96, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False)
+    torch.manual_seed(5)
+    model = Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
+                                                       soc_switch=False, calculate_sparsity=False, zero_point_shift=False)).to(device)
+    g = S.add_random_targets(S.random_cell(6, [14, 8, 6, 1], seed=2, density=0.004), 19, seed=2).to(device)
+    # targets = a TEACHER head (same architecture, other weights) on the same frozen representation: the loss can go to zero
+    torch.manual_seed(6)
+    teacher = HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, soc_switch=False,
+                                calculate_sparsity=False, zero_point_shift=False).to(device)
+    with torch.no_grad():
+        target = teacher(g, model.representation(g))["hamiltonian"].clone()
+    opt = torch.optim.Adam(model.output_module.parameters(), lr=1e-2)
+    losses, rep = [], None
+    for _ in range(steps):
+        r = head_training_step(model, g, metric="mse", representation=rep, target=target)
+        rep = r["representation"]
+        losses.append(float(r["loss"]))
+        opt.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    return {"first_loss": losses[0], "last_loss": losses[-1], "monotone_fraction": sum(b < a for a, b in zip(losses, losses[1:])) / (steps - 1)}
+
+
 def check_backbone(device="cuda", name="backbone"):
     m, f = build_backbone_from_fixture(device, name)
     g = to_graph(f["graph"], device)

@@ -121,6 +121,12 @@ def test_head_backward_vs_autograd():
     assert max(r.values()) < G.TOL
 
 
+def test_head_finetune_loss_falls():
+    r = G.check_head_finetune()
+    print(r)
+    assert r["last_loss"] < 0.5 * r["first_loss"] and r["monotone_fraction"] > 0.7
+
+
 def test_backbone_golden():
     r = G.check_backbone()
     print(r)
