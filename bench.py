@@ -48,7 +48,7 @@ def make_cfg(irreps):
                 radius_type="openmx", use_corr_prod=False, legacy_edge_update=False, lite_mode=False)
 
 
-def make_graph(workload, nao):
+def make_graph(workload, nao, soc=False):
     from hamgnn_amd.data import synthetic as S
     if workload == "sio2_10k":
         g = S.amorphous_sio2(10002, seed=1)
@@ -62,7 +62,7 @@ def make_graph(workload, nao):
         g = S.amorphous_sio2(int(workload.split("_")[1]), seed=1)
     else:
         raise SystemExit(f"unknown workload {workload}")
-    return S.add_random_targets(g, nao, seed=0)
+    return S.add_random_targets(g, nao, seed=0, soc=soc)
 
 
 def cpu_baseline(workload, irreps_key, nao, budget_s=15.0):
@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--workload", default="sio2_10k")
     ap.add_argument("--irreps", default="A", choices=["A", "B"])
     ap.add_argument("--nao", type=int, default=19)
+    ap.add_argument("--soc", action="store_true", help="SOC / so3 read-out (BASELINE config #3: MoS2 with spin-orbit coupling); the CPU baseline leg stays non-SOC")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -152,8 +153,8 @@ def main():
     torch.manual_seed(666)
     model = HamGNNConvE3(make_cfg(irreps))
     head = HamGNNPlusPlusOut(irreps, irreps, nao_max=args.nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
-                             soc_switch=False, calculate_sparsity=True)          # the reference's defaults
-    g = make_graph(args.workload, args.nao)
+                             soc_switch=args.soc, soc_basis="so3", calculate_sparsity=True, zero_point_shift=False)   # the reference's defaults
+    g = make_graph(args.workload, args.nao, soc=args.soc)
     E_total, N_atoms = g.num_edges, g.num_nodes
     if world > 1:
         g = parallel.shard_graph(g, rank, world)
@@ -220,7 +221,7 @@ def main():
            "edges_per_s_median_step": E_total / (median_ms * 1e-3), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {N_atoms} atoms, {E_total} directed edges, irreps set-{args.irreps} (D={model.irreps_node_features.dim}), "
-                                  f"sh lmax 5, 3 layers, nao_max {args.nao}, no SOC, backbone+head forward",
+                                  f"sh lmax 5, 3 layers, nao_max {args.nao}, {'SOC (so3 head)' if args.soc else 'no SOC'}, backbone+head forward",
                       "parallelism": "single GPU" if world == 1 else f"pair-sharded edges x{world} + RCCL all-reduce of node aggregates"},
            "roofline": roofline}
     if rank == 0:
