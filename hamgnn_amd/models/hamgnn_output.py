@@ -82,6 +82,7 @@ class HamGNNPlusPlusOut(nn.Module):
     # ------------------------------------------------------------------------------------------------------------
     def compile(self, device):
         dev = torch.device(device)
+        self._adj_tabs = None
         for m in self.children():
             if isinstance(m, hnn.HamLayer):
                 m.compile(dev)

@@ -39,6 +39,7 @@ class E3Linear(nn.Module):
 
     def compile(self, device):
         W = self.weight.detach().cpu().double().numpy()
+        self._dp_adj = None                                    # adjoint tables are packed from the same weights: rebuilt on demand
         if os.environ.get("HG_LINEAR_KERNEL", "stream") == "seg":                             # HG_LINEAR_KERNEL=seg: the Linear as a program of the segment-stationary kernel
             self._dp = ops.DeviceProgram(P.build_linear_program(W, self.irreps_in, self.irreps_out), device)
         else:                                                  # default: the streaming block-Linear kernel (csrc/linear.hip)
@@ -185,6 +186,7 @@ class MessagePackBlock(nn.Module):
 
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
+        self._dp_adj = None                                    # the data-gradient program is packed from the same weights
         if self.lite_mode:
             prog = P.build_message_pack_program_lite(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
             if skip_weight is not None:                        # PairInteractionBlock skip o3.Linear: must come AFTER the combine post-op
@@ -483,6 +485,7 @@ class HamLayer(nn.Module):
 
     def compile(self, device):
         self.residual_block.compile(device)
+        self._dp_adj = None
         W = self.linear_transform.weight.detach().cpu().double().numpy()
         stream = os.environ.get("HG_LINEAR_KERNEL", "stream") != "seg"
         if all(m == 1 for m, _, _ in self.ham_irreps):         # hamiltonian irreps: regroup the multiplicity-1 outputs by (L,p)
