@@ -220,7 +220,10 @@ class MessagePackBlock(nn.Module):
         if self.lite_mode:
             raise NotImplementedError("data gradient of a lite_mode MessagePackBlock")
         prog = P.build_message_pack_adjoint_program(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
-        self._dp_adj = ops.DeviceProgram(prog, device, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
+        try:
+            self._dp_adj = ops.DeviceProgram(prog, device, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
+        except NotImplementedError:                            # tiles / staging do not fit even split over workgroups: segment-stationary kernel
+            self._dp_adj = ops.DeviceProgram(prog, device, schedule="seg")
         _, maps = P.message_pack_adjoint_layout(self.irreps_node, self.irreps_edge)
         self._adj_maps = tuple(torch.from_numpy(m).to(device) for m in maps)
         return self

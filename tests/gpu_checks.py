@@ -119,18 +119,20 @@ def build_backbone_from_fixture(device="cuda", name="backbone"):
     return m, f
 
 
-def check_message_pack_random(device="cuda", seed=0, schedule="auto"):
+def check_message_pack_random(device="cuda", seed=0, schedule="auto", irr=None, sh=None):
     """random irreps set (odd multiplicities, missing parities) + random weights: fused MessagePackBlock on the GPU vs the fp64 oracle"""
     from oracle import hamgnn_ref as R, e3
     from hamgnn_amd import nn as hnn, ops, plan as P
     from tests.test_plan_emu import _random_irreps
     rng = np.random.default_rng(100 + seed)
-    lmax = int(rng.integers(1, 4))
-    irr = _random_irreps(rng, lmax)
-    if "0e" not in irr:
-        irr = "5x0e+" + irr
-    lsh = int(rng.integers(1, 4))
-    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    if irr is None:
+        lmax = int(rng.integers(1, 4))
+        irr = _random_irreps(rng, lmax)
+        if "0e" not in irr:
+            irr = "5x0e+" + irr
+        lsh = int(rng.integers(1, 4))
+        sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    lmax, lsh = P.Irreps(irr).lmax, P.Irreps(sh).lmax
     torch.manual_seed(seed)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
