@@ -219,8 +219,12 @@ __device__ __forceinline__ rh_f4 rh_silu(rh_f4 v, float cst) {
     for (int r = 0; r < 4; ++r) o[r] = cst * v[r] / (1.f + __expf(-v[r]));
     return o;
 }
-__global__ __launch_bounds__(256) void radial_hidden_mfma_kernel(const float* __restrict__ rbf, int64_t E, const float* __restrict__ W, float cst,
-                                                                 float* __restrict__ out) {
+__global__ __launch_bounds__(256) void radial_hidden_mfma_kernel(const float* __restrict__ rbf, int64_t E, const float* __restrict__ W_all, float cst,
+                                                                 float* __restrict__ out_all) {
+    // blockIdx.y: which MLP of a batch of 64 -> 64 -> 64 weight generators that share the radial basis rows (hg_radial_hidden_multi: all
+    // 13 generators of a 3-layer backbone in ONE launch -- the basis rows come from HBM once, the other readers hit L2 / Infinity Cache)
+    const float* __restrict__ W = W_all + (int64_t)blockIdx.y * 8192;
+    float* __restrict__ out = out_all + (int64_t)blockIdx.y * E * 64;
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
     // A fragments: lane (i, g), tile (rt, T), register q  <-  W[in = 16 T + 4 g + q][out = 16 rt + i]   (W row-major [in][out])
     rh_f4 a1[4][4], a2[4][4];
@@ -284,6 +288,16 @@ extern "C" int hg_radial_hidden(const float* rbf, int64_t E, const float* weight
     if (lds > 64 * 1024) return hg_fail(-2, "hg_radial_hidden: layer too wide for the LDS-resident kernel");
     radial_hidden_kernel<<<dim3((unsigned)((E + RH_TE - 1) / RH_TE)), 256, lds, (hipStream_t)stream>>>(rbf, E, weights, d[0], d[1], d[2], d[3], nlayers, act_cst, h_out, maxd);
     return hg_check_launch("hg_radial_hidden");
+}
+
+extern "C" int hg_radial_hidden_multi(const float* rbf, int64_t E, const float* weights, int nmlp, float act_cst, float* h_out, void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (E <= 0 || nmlp <= 0) return 0;
+    if (nmlp > 1024) return hg_fail(-2, "hg_radial_hidden_multi: at most 1024 generators per launch");
+    const int64_t nwg = (E + 63) / 64;
+    const unsigned grid = (unsigned)(nwg < 2048 ? nwg : 2048);
+    radial_hidden_mfma_kernel<<<dim3(grid, (unsigned)nmlp), 256, 0, (hipStream_t)stream>>>(rbf, E, weights, act_cst, h_out);
+    return hg_check_launch("hg_radial_hidden_multi");
 }
 
 // ------------------------------------------------------------------------------------------------ gather + frame rotation

@@ -131,6 +131,8 @@ class _BackboneBase(nn.Module):
         topo = get_topology(data)                              # index plumbing + validation: once per graph object (host-syncs)
         topo.check_num_types(self.num_types)                   # z >= num_types would index past the embedding tables on the device
         geo = ops.Geometry(data.pos, data.edge_index, data.nbr_shift, self.cutoff, self.num_radial, self.lmax, self._jtab)
+        # hidden activations of ALL radial weight generators of this forward (embedding + two per message block) in one launch
+        ops.prefill_radial_hidden(geo, self._radial_generators(), float(P.ACT_CONSTS[P.ACT_SILU]))
         Dp = self.layout.dim
         delta = None
         if self.apply_charge_doping:                           # node_attrs = one_hot(z) + delta (toolbox/nequip/nn/embedding/_embedding_block.py:124-131)
@@ -144,6 +146,13 @@ class _BackboneBase(nn.Module):
         else:
             node = (self._chem[z] + delta @ self._chem).contiguous()                # per-atom rows of the same table
         return z, topo, geo, node, f
+
+    def _radial_generators(self):
+        gens = [self.pair_embedding._h]
+        for m in self.modules():
+            if isinstance(m, hnn.MessagePackBlock) and m._dp is not None:
+                gens += [g for g in (m._hn, m._he) if g is not None]
+        return gens
 
     def _representation(self, node, f, geo):
         rep = Representation()

@@ -238,8 +238,8 @@ class MessagePackBlock(nn.Module):
         if getattr(self, "_dp_adj", None) is None:
             self.compile_adjoint(grad_out.device)
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
-        hn = ops.radial_hidden(geo.rbf, self._hn, cst)
-        he = ops.radial_hidden(geo.rbf, self._he, cst)
+        hn = ops.radial_hidden_cached(geo, self._hn, cst)
+        he = ops.radial_hidden_cached(geo, self._he, cst)
         dp = self._dp_adj
         if dp.sched is not None:
             g = ops.tp_fused(dp, [grad_out], geo.E, hn, he, geo, tag="message_pack_adjoint", gather=[gather], rot_mask=1 if out_is_global else 0)
@@ -260,8 +260,8 @@ class MessagePackBlock(nn.Module):
     def run(self, xs_rot, xd_rot, f_rot, geo: ops.Geometry):
         """xs_rot/xd_rot/f_rot: planar rows in the edge-aligned frame.  Returns planar [E, Dp] (global frame if unrotate)."""
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
-        hn = ops.radial_hidden(geo.rbf, self._hn, cst)
-        he = ops.radial_hidden(geo.rbf, self._he, cst) if self._he is not None else None
+        hn = ops.radial_hidden_cached(geo, self._hn, cst)
+        he = ops.radial_hidden_cached(geo, self._he, cst) if self._he is not None else None
         return ops.tp_fused(self._dp, [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo, tag="message_pack")
 
     def run_nodes(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab):
@@ -272,8 +272,8 @@ class MessagePackBlock(nn.Module):
             xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)
             return self.run(xs, xd, f_rot, geo)
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
-        hn = ops.radial_hidden(geo.rbf, self._hn, cst)
-        he = ops.radial_hidden(geo.rbf, self._he, cst) if self._he is not None else None
+        hn = ops.radial_hidden_cached(geo, self._hn, cst)
+        he = ops.radial_hidden_cached(geo, self._he, cst) if self._he is not None else None
         return ops.tp_fused(self._dp, [node_s, node_d, f_rot], geo.E, hn, he, geo, tag="message_pack", gather=[geo.src, geo.dst, None],
                             rot_mask=0b011)
 
@@ -433,7 +433,7 @@ class PairInteractionEmbeddingBlock(nn.Module):
             x = ops.embed_lookup(Ts, Td, z, geo.src, geo.dst, geo.E, self.num_types, self._Tp)
         else:
             x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, self.num_types, self._Tp)
-        h = ops.radial_hidden(geo.rbf, self._h, float(P.ACT_CONSTS[P.ACT_SILU]))
+        h = ops.radial_hidden_cached(geo, self._h, float(P.ACT_CONSTS[P.ACT_SILU]))
         return ops.tp_fused(self._dp, [x], geo.E, h, None, geo, tag="embedding")      # edge features, edge-aligned frame
 
 

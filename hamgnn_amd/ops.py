@@ -183,6 +183,42 @@ def radial_hidden(rbf: torch.Tensor, layers: Sequence[torch.Tensor], act_cst: fl
     return out
 
 
+def radial_hidden_cached(geo: "Geometry", layers: Sequence[torch.Tensor], act_cst: float) -> torch.Tensor:
+    """radial_hidden(geo.rbf, layers) through the per-forward cache on the geometry object (filled for all weight generators of a
+    backbone at once by prefill_radial_hidden; computed singly otherwise)"""
+    cache = geo.__dict__.setdefault("_hcache", {})
+    key = id(layers[0])
+    if key not in cache:
+        cache[key] = radial_hidden(geo.rbf, layers, act_cst)
+    return cache[key]
+
+
+def prefill_radial_hidden(geo: "Geometry", generators: Sequence[Sequence[torch.Tensor]], act_cst: float) -> bool:
+    """all weight generators of a forward in ONE launch (hg_radial_hidden_multi); False if their shapes do not allow it"""
+    H = radial_hidden_multi(geo.rbf, generators, act_cst)
+    if H is None:
+        return False
+    cache = geo.__dict__.setdefault("_hcache", {})
+    for m, g in enumerate(generators):
+        cache[id(g[0])] = H[m]
+    return True
+
+
+@_on_tensor_device
+def radial_hidden_multi(rbf: torch.Tensor, generators: Sequence[Sequence[torch.Tensor]], act_cst: float) -> Optional[torch.Tensor]:
+    """hidden activations of SEVERAL radial weight generators that read the same basis rows, one launch: [n, E, 64]; None when a
+    generator is not of the shipped 64 -> 64 -> 64 shape (callers then use radial_hidden per generator)."""
+    if not generators or any(len(g) != 2 or tuple(g[0].shape) != (64, 64) or tuple(g[1].shape) != (64, 64) for g in generators):
+        return None
+    if rbf.shape[1] != 64:
+        return None
+    E = rbf.shape[0]
+    W = torch.cat([w.reshape(-1) for g in generators for w in g]).contiguous()
+    out = torch.empty(len(generators), E, 64, device=rbf.device, dtype=torch.float32)
+    check(lib().hg_radial_hidden_multi(ptr(rbf), i64(E), ptr(W), i32(len(generators)), f32(act_cst), ptr(out), _stream()), "hg_radial_hidden_multi")
+    return out
+
+
 @_on_tensor_device
 def rotate_gather(x: torch.Tensor, idx: Optional[torch.Tensor], geo: Geometry, chan_tab: torch.Tensor, transpose=False,
                   x2: Optional[torch.Tensor] = None, idx2: Optional[torch.Tensor] = None):

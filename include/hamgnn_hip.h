@@ -38,6 +38,9 @@ int hg_edge_geometry(const float* pos, const int64_t* edge_index, const float* n
  * h = act(... act(rbf @ W0) @ W1 ...), act(x) = act_cst * silu(x); W_k [dims[k], dims[k+1]] already scaled by 1/sqrt(h_in). */
 int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const int32_t* dims, int nlayers, float act_cst,
                      float* h_out, void* stream);
+/* the same for `nmlp` weight generators of the shipped shape 64 -> 64 -> 64 that read the same radial basis rows, in ONE launch
+ * (grid.y = generator): weights [nmlp][2][64][64] (layer 1 | layer 2, 1/sqrt(fan_in) folded in), h_out [nmlp][E][64].            */
+int hg_radial_hidden_multi(const float* rbf, int64_t E, const float* weights, int nmlp, float act_cst, float* h_out, void* stream);
 
 /* node_features[sender] / [receiver] gathers of ConvBlockE3.forward (hamgnn/nn/convolution.py:138-141) and
  * PairInteractionBlock.forward (interaction_blocks.py:141-145), fused with the rotation into the edge-aligned frame:
