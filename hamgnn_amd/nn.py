@@ -206,10 +206,16 @@ class MessagePackBlock(nn.Module):
                         prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate,
                                                             skip_weight, merge_groups=groups)
                         self._dp = ops.DeviceProgram(prog, device, schedule="is")
+                        # launches with fewer 16-edge tiles than workgroup slots run the PLAIN program split over one workgroup per output
+                        # segment: merging trades parts (9 instead of 13 for set-A) for MFMAs, the wrong trade when latency is all there is
+                        # (Si 2-atom cell: 0.113 -> 0.110 ms per launch); built on first use
+                        self._plain_args = (sd, unrotate, skip_weight, device)
+                        self._dp_plain = None
                         return self
                     except NotImplementedError:
                         pass
             prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
+        self._plain_args = None
         # HG_MP_KERNEL = seg | is | auto: which schedule of the fused MessagePackBlock program runs (default: see DESIGN.md section 5)
         self._dp = ops.DeviceProgram(prog, device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
         return self
@@ -252,6 +258,19 @@ class MessagePackBlock(nn.Module):
         ims, imd, ime = self._adj_maps
         return ops.from_planar(g, ims), ops.from_planar(g, imd), ops.from_planar(g, ime)      # column gathers (-1 = padding slot -> 0)
 
+    def _dp_for(self, rows: int):
+        """the program a launch of `rows` edges runs: the merged one, or -- split launches of small crystals -- the plain one"""
+        if getattr(self, "_plain_args", None) is None or self._dp.is_parts_for(rows) == 1:
+            return self._dp
+        if self._dp_plain is None:
+            sd, unrotate, skip_weight, device = self._plain_args
+            prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
+            try:
+                self._dp_plain = ops.DeviceProgram(prog, device, schedule="is")
+            except NotImplementedError:
+                self._dp_plain = self._dp
+        return self._dp_plain
+
     def _rot_tab_out(self, device):
         if getattr(self, "_rt_out", None) is None:
             self._rt_out = torch.from_numpy(P.rotate_table(P.PlanarLayout(self.irreps_out))).to(device)
@@ -262,7 +281,7 @@ class MessagePackBlock(nn.Module):
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
         hn = ops.radial_hidden_cached(geo, self._hn, cst)
         he = ops.radial_hidden_cached(geo, self._he, cst) if self._he is not None else None
-        return ops.tp_fused(self._dp, [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo, tag="message_pack")
+        return ops.tp_fused(self._dp_for(geo.E), [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo, tag="message_pack")
 
     def run_nodes(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab):
         """node_s / node_d: planar NODE rows (global frame) whose sender / receiver gathers feed the block
@@ -274,7 +293,7 @@ class MessagePackBlock(nn.Module):
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
         hn = ops.radial_hidden_cached(geo, self._hn, cst)
         he = ops.radial_hidden_cached(geo, self._he, cst) if self._he is not None else None
-        return ops.tp_fused(self._dp, [node_s, node_d, f_rot], geo.E, hn, he, geo, tag="message_pack", gather=[geo.src, geo.dst, None],
+        return ops.tp_fused(self._dp_for(geo.E), [node_s, node_d, f_rot], geo.E, hn, he, geo, tag="message_pack", gather=[geo.src, geo.dst, None],
                             rot_mask=0b011)
 
 
