@@ -67,8 +67,8 @@ __global__ void geometry_kernel(const float* __restrict__ pos, const int64_t* __
 
 // D^l(R_e) = J Z(beta) J^T Z(alpha): one thread per (edge, row a).  (hamgnn_amd/so3.py:edge_wigner is the host twin.)
 template <int L>
-__global__ void wigner_kernel(const float4* __restrict__ ang, int64_t E, const float* __restrict__ J, const float* __restrict__ sgn,
-                              float* __restrict__ wig, int nW, int off) {
+__device__ __forceinline__ void wigner_rows(const float4* __restrict__ ang, int64_t E, const float* __restrict__ J, const float* __restrict__ sgn,
+                                            float* __restrict__ wig, int nW, int off) {
     constexpr int N = 2 * L + 1;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * N) return;
@@ -106,6 +106,33 @@ __global__ void wigner_kernel(const float4* __restrict__ ang, int64_t E, const f
         o[L - m] = t2[L - m] * ca[m] + s * t2[L + m];
     }
 }
+template <int L>
+__global__ void wigner_kernel(const float4* __restrict__ ang, int64_t E, const float* __restrict__ J, const float* __restrict__ sgn,
+                              float* __restrict__ wig, int nW, int off) {
+    wigner_rows<L>(ang, E, J, sgn, wig, nW, off);
+}
+// all l in ONE launch (blockIdx.y = l): small crystals, where seven extra launches are 4 % of a forward; blocks past E (2 l + 1) exit
+__global__ void wigner_all_kernel(const float4* __restrict__ ang, int64_t E, const float* __restrict__ jtab, int nJ, float* __restrict__ wig, int nW) {
+    const int l = blockIdx.y;
+    int off = 0, soff = nJ;
+    for (int k = 0; k < l; ++k) {
+        off += (2 * k + 1) * (2 * k + 1);
+        soff += k + 1;
+    }
+    const float* __restrict__ J = jtab + off;
+    const float* __restrict__ sg = jtab + soff;
+    switch (l) {
+        case 0: wigner_rows<0>(ang, E, J, sg, wig, nW, off); break;
+        case 1: wigner_rows<1>(ang, E, J, sg, wig, nW, off); break;
+        case 2: wigner_rows<2>(ang, E, J, sg, wig, nW, off); break;
+        case 3: wigner_rows<3>(ang, E, J, sg, wig, nW, off); break;
+        case 4: wigner_rows<4>(ang, E, J, sg, wig, nW, off); break;
+        case 5: wigner_rows<5>(ang, E, J, sg, wig, nW, off); break;
+        case 6: wigner_rows<6>(ang, E, J, sg, wig, nW, off); break;
+        case 7: wigner_rows<7>(ang, E, J, sg, wig, nW, off); break;
+        default: break;
+    }
+}
 
 extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, const float* nbr_shift, int64_t E, float cutoff,
                                 int num_radial, int lmax_wig, const float* jtab, float* rbf, float* wig, float* edge_len,
@@ -119,7 +146,9 @@ extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, con
     nJ = nW;
     float4* ang = reinterpret_cast<float4*>(ang_scratch);
     geometry_kernel<<<dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st>>>(pos, edge_index, nbr_shift, E, cutoff, num_radial, ang, rbf, edge_len);
-    if (wig) {
+    if (wig && E * (2 * lmax_wig + 1) <= 256 * 2048) {        // small crystal: every l in one launch
+        wigner_all_kernel<<<dim3((unsigned)((E * (2 * lmax_wig + 1) + 255) / 256), (unsigned)(lmax_wig + 1)), 256, 0, st>>>(ang, E, jtab, nJ, wig, nW);
+    } else if (wig) {
         int off = 0, soff = nJ;
         for (int l = 0; l <= lmax_wig; ++l) {
             const int N = 2 * l + 1;
