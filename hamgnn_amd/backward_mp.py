@@ -1,0 +1,171 @@
+"""Weight gradients of a (non-lite) MessagePackBlock, first version (plan.build_message_pack_wgrad_programs).
+
+The two materialisation programs run on the fused HIP kernels (per edge: A = cf (W x) and B = L g for every row of every super-path, in the
+edge-aligned frame); everything below is reductions over the edges of products of those rows with the block's inputs -- plain GEMMs and
+element-wise products on torch tensors (rocBLAS / hipBLASLt), device-agnostic so that the CPU suite runs the same code on the emulator's
+output.  Gradients come back in the reference's parameter names and flat e3nn layouts:
+
+  {node,edge}_tensor_product.weight          g_W[u, w] (path n) = c_path * sum_{e, c} x[e, u, sigma(c)] * (s cf B)[e, row(n, w), c]
+  {node,edge}_linear_scaler.linear_out.weight, {node,edge}_linear_out.weight
+                                             from g_L[row, w''] = sum_{e, c} (s A)[e, row, c] g[e, w'', c]  with L = Ls / sqrt(fan) @ Lo / sqrt(mul)
+  {node,edge}_weight_generator.layer*.weight  last layer: h^T g_s / sqrt(H) with g_s[e, row] = sum_c A B;  hidden layers: torch.autograd on
+                                             the 64-wide MLP (two dense layers per edge; the radial basis rows are inputs, not parameters)
+
+Correct, not fast: 2 x ~70 KB of intermediates per edge and branch, processed in chunks of edges.  The fused weight-gradient kernel
+ replaces this."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+
+from . import plan as P
+
+
+def _block(x: torch.Tensor, off: int, mulp: int, comps: Sequence[int], nch: int) -> torch.Tensor:
+    """planar rows -> [E, len(comps), nch]: channels 0..nch of the given components of the irrep block at `off`"""
+    idx = torch.as_tensor([off + a * mulp for a in comps], device=x.device)
+    return torch.stack([x[:, int(o):int(o) + nch] for o in idx.tolist()], 1)
+
+
+def radial_mlp(rbf: torch.Tensor, layers: List[torch.Tensor], act_cst: float) -> torch.Tensor:
+    """FullyConnectedNet hidden layers as torch ops (e3nn: x @ W / sqrt(fan_in), normalised SiLU): the differentiable twin of
+    hg_radial_hidden; `layers` are the RAW parameters [h_in, h_out]"""
+    h = rbf
+    for W in layers:
+        h = torch.nn.functional.silu(h @ (W / math.sqrt(W.shape[0]))) * act_cst
+    return h
+
+
+def weight_grads_from_rows(chunks, Arows: torch.Tensor, Brows: torch.Tensor, srcs: Sequence[torch.Tensor], g: torch.Tensor,
+                           S: Dict[str, torch.Tensor], acc: Dict[str, torch.Tensor], gs_all: Dict[str, torch.Tensor], irreps_out):
+    """One chunk of edges.  chunks: plan.build_message_pack_wgrad_programs' bookkeeping; Arows / Brows: the two materialised row tensors
+    [E, out_dim]; srcs = (x_sender, x_receiver, f) planar edge-frame rows; g: gradient rows (edge frame, planar(irreps_out));
+    S[branch] = h @ W3 / sqrt(H) [E, n_channels]; acc: running sums of the per-path / per-k gradients (updated in place);
+    gs_all[branch]: [E, n_channels] (filled)."""
+    gl = P.PlanarLayout(irreps_out)
+    for c in chunks:
+        sp, r0, r1 = c["sp"], c["r0"], c["r1"]
+        n, mm, li, lk, mk, k, i = r1 - r0, sp["mm"], sp["li"], sp["lk"], sp["mk"], sp["k"], sp["i"]
+        nc = 2 * mm + 1
+        cols = [lk - mm + cc for cc in range(nc)]
+        A = _block(Arows, c["out_off"], c["out_mulp"], cols, n)                    # [E, nc, n]
+        B = _block(Brows, c["out_off"], c["out_mulp"], cols, n)
+        ch = torch.as_tensor(sp["ch"][r0:r1], device=A.device)
+        s = S[c["branch"]][:, ch]                                                  # [E, n]
+        gs_all[c["branch"]][:, ch] = (A * B).sum(1)
+        Gk = _block(g, gl.off[k], gl.mulp[k], cols, mk)                            # [E, nc, mk]
+        gL = torch.einsum("ecn,ecw->nw", A * s[:, None, :], Gk)                    # rows x mul_k
+        cf = torch.as_tensor(sp["cf"][r0:r1].T.copy(), device=A.device, dtype=A.dtype)   # [nc, n]
+        T1 = B * s[:, None, :] * cf[None]
+        lay = c["lay"]
+        comps = [(li + mm - cc) if sp["par"] else (li - mm + cc) for cc in range(nc)]
+        X = torch.cat([_block(srcs[sl], lay.off[i], lay.mulp[i], comps, sp["mi"]) for sl in c["srcs"]], 2)    # [E, nc, nsrc * mi]
+        gW = torch.einsum("ecn,ecu->nu", T1, X)                                    # rows x (nsrc mul_i)
+        name = c["branch"]
+        for r in range(n):
+            pn, w, cpath, lrow = sp["meta"][r0 + r]
+            acc[f"{name}_tp"][(pn, sp["woff"][pn], X.shape[2], mk)][:, w] += cpath * gW[r]
+            acc[f"{name}_L"][k][lrow] += gL[r]
+
+
+class MessagePackWeightGrad:
+    """holds the two materialisation programs of one MessagePackBlock and turns (inputs, output gradient) into parameter gradients"""
+
+    def __init__(self, sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
+        self.sd = {k: np.asarray(v, dtype=np.float64) for k, v in sd.items()}
+        self.irreps_out = P.Irreps(irreps_out)
+        self.progA, self.progB, self.chunks = P.build_message_pack_wgrad_programs(sd, irreps_node, irreps_edge, irreps_sh, irreps_out)
+
+    def new_acc(self, device, dtype):
+        acc = {}
+        for name in ("node", "edge"):
+            tp, Lk = {}, {}
+            for c in self.chunks:
+                if c["branch"] != name:
+                    continue
+                sp = c["sp"]
+                for (pn, w, cpath, lrow) in sp["meta"][c["r0"]:c["r1"]]:
+                    tp.setdefault((pn, sp["woff"][pn], c["nsrc"] * sp["mi"], sp["mk"]), None)
+                Lk.setdefault(sp["k"], None)
+            acc[f"{name}_tp"] = {key: torch.zeros(key[2], key[3], device=device, dtype=dtype) for key in tp}
+            acc[f"{name}_L"] = {}
+            for c in self.chunks:
+                if c["branch"] == name and c["sp"]["k"] not in acc[f"{name}_L"]:
+                    off, fan = c["sp"]["lin"]
+                    acc[f"{name}_L"][c["sp"]["k"]] = torch.zeros(fan, c["sp"]["mk"], device=device, dtype=dtype)
+        return acc
+
+    def finish(self, acc, gW3: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """per-path / per-k sums -> the reference's flat parameter gradients"""
+        out = {}
+        any_g = next(iter(next(iter(gW3.values())).values()))
+        dev, dt = any_g.device, any_g.dtype
+        for name in ("node", "edge"):
+            wsize = self.sd[f"{name}_tensor_product.weight"].size
+            gtp = torch.zeros(wsize, device=dev, dtype=dt)
+            for (pn, woff, mi2, mk), G in acc[f"{name}_tp"].items():
+                gtp[woff:woff + mi2 * mk] = G.reshape(-1)
+            out[f"{name}_tensor_product.weight"] = gtp
+            Ls_flat = torch.as_tensor(self.sd[f"{name}_linear_scaler.linear_out.weight"], device=dev, dtype=dt)
+            Lo_flat = torch.as_tensor(self.sd[f"{name}_linear_out.weight"], device=dev, dtype=dt)
+            gLs, gLo = torch.zeros_like(Ls_flat), torch.zeros_like(Lo_flat)
+            seen = set()
+            for c in self.chunks:
+                sp = c["sp"]
+                if c["branch"] != name or sp["k"] in seen:
+                    continue
+                seen.add(sp["k"])
+                (off, fan), lo_off, mk = sp["lin"], sp["lo_off"], sp["mk"]
+                Ls = Ls_flat[off:off + fan * mk].reshape(fan, mk) / math.sqrt(fan)
+                Lo = Lo_flat[lo_off:lo_off + mk * mk].reshape(mk, mk) / math.sqrt(mk)
+                gL = acc[f"{name}_L"][sp["k"]]                 # d / d (Ls @ Lo)
+                gLs[off:off + fan * mk] = ((gL @ Lo.t()) / math.sqrt(fan)).reshape(-1)
+                gLo[lo_off:lo_off + mk * mk] = ((Ls.t() @ gL) / math.sqrt(mk)).reshape(-1)
+            out[f"{name}_linear_scaler.linear_out.weight"] = gLs
+            out[f"{name}_linear_out.weight"] = gLo
+            out.update(gW3[name])
+        return out
+
+
+def block_weight_grads(wg: MessagePackWeightGrad, run_program, xs, xd, f, g, rbf, act_cst: float, chunk: int = 16384) -> Dict[str, torch.Tensor]:
+    """run_program(prog, sources, h_node, h_edge) -> rows [E_chunk, out_dim] (the HIP kernels on the GPU, the emulator in the CPU suite).
+    xs / xd / f: planar edge-frame input rows of the block; g: gradient of its output rows (edge frame); rbf: radial basis rows."""
+    dev, dt = xs.device, xs.dtype
+    E = xs.shape[0]
+    sd = wg.sd
+    acc = wg.new_acc(dev, dt)
+    gen = {}
+    for name in ("node", "edge"):
+        ks = sorted(k for k in sd if k.startswith(f"{name}_weight_generator.layer") and k.endswith(".weight"))
+        gen[name] = [torch.as_tensor(sd[k], device=dev, dtype=dt).requires_grad_() for k in ks]
+    H = gen["node"][-1].shape[0]
+    gW3 = {name: {} for name in gen}
+    gh_hidden = {name: torch.zeros(E, H, device=dev, dtype=dt) for name in gen}
+    gW3_last = {name: torch.zeros_like(gen[name][-1]) for name in gen}
+    for e0 in range(0, E, chunk):
+        sl = slice(e0, min(E, e0 + chunk))
+        n = sl.stop - sl.start
+        with torch.no_grad():
+            h = {name: radial_mlp(rbf[sl], [w.detach() for w in gen[name][:-1]], act_cst) for name in gen}
+            S = {name: h[name] @ (gen[name][-1].detach() / math.sqrt(H)) for name in gen}
+            ones = torch.zeros(n, wg.progA.hidden_pad, device=dev, dtype=dt)
+            ones[:, 0] = 1.0
+            Arows = run_program(wg.progA, [xs[sl], xd[sl], f[sl]], ones, ones)
+            Brows = run_program(wg.progB, [g[sl]], ones, ones)
+            gs_all = {name: torch.zeros(n, gen[name][-1].shape[1], device=dev, dtype=dt) for name in gen}
+            weight_grads_from_rows(wg.chunks, Arows, Brows, (xs[sl], xd[sl], f[sl]), g[sl], S, acc, gs_all, wg.irreps_out)
+            for name in gen:
+                gW3_last[name] += h[name].t() @ gs_all[name] / math.sqrt(H)
+                gh_hidden[name][sl] = gs_all[name] @ (gen[name][-1].detach().t() / math.sqrt(H))
+    for name in gen:                                           # hidden layers of the radial MLPs: two dense layers per edge, torch.autograd
+        hidden = gen[name][:-1]
+        hfull = radial_mlp(rbf, hidden, act_cst)
+        grads = torch.autograd.grad(hfull, hidden, grad_outputs=gh_hidden[name], allow_unused=True)
+        ks = sorted(k for k in sd if k.startswith(f"{name}_weight_generator.layer") and k.endswith(".weight"))
+        for k, gk in zip(ks[:-1], grads):
+            gW3[name][k] = gk if gk is not None else torch.zeros_like(gen[name][0])
+        gW3[name][ks[-1]] = gW3_last[name]
+    return wg.finish(acc, gW3)

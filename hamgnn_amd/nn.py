@@ -187,6 +187,7 @@ class MessagePackBlock(nn.Module):
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
         self._dp_adj = None                                    # the data-gradient program is packed from the same weights
+        self._wgrad = None
         if self.lite_mode:
             prog = P.build_message_pack_program_lite(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
             if skip_weight is not None:                        # PairInteractionBlock skip o3.Linear: must come AFTER the combine post-op
@@ -270,6 +271,25 @@ class MessagePackBlock(nn.Module):
             except NotImplementedError:
                 self._dp_plain = self._dp
         return self._dp_plain
+
+    def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 16384):
+        """gradients of every parameter of this block for the output gradient `grad_out` (see backward_data for its frame), first
+        version (hamgnn_amd/backward_mp.py): two materialisation programs on the fused kernels + library GEMMs over the edges.
+        node_s / node_d: planar NODE rows gathered by sender / receiver as in run_nodes; f_rot: planar edge rows (edge frame).
+        Returns {reference parameter name: gradient in the reference's flat layout}."""
+        from . import backward_mp as BM
+        if self.lite_mode:
+            raise NotImplementedError("weight gradients of a lite_mode MessagePackBlock")
+        dev = grad_out.device
+        if getattr(self, "_wgrad", None) is None:
+            wg = BM.MessagePackWeightGrad(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
+            self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
+        wg, dpA, dpB = self._wgrad
+        xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)
+        g = ops.rotate_gather(grad_out, None, geo, self._rot_tab_out(dev)) if out_is_global else grad_out
+        dps = {id(wg.progA): dpA, id(wg.progB): dpB}
+        run = lambda prog, srcs, hn, he: ops.tp_fused(dps[id(prog)], [t.contiguous() for t in srcs], srcs[0].shape[0], hn, he, None, tag="wgrad_rows")
+        return BM.block_weight_grads(wg, run, xs, xd, f_rot, g, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk)
 
     def _rot_tab_out(self, device):
         if getattr(self, "_rt_out", None) is None:

@@ -596,6 +596,7 @@ def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps
             nc = 2 * mm + 1
             par = None
             rows_W, rows_ch, rows_cf, rows_L = [], [], [], []
+            rows_meta = []                                     # per row: (instruction n, mid channel w, path normalisation, row of the k-block of L)
             flops = 0.0
             for n in plist:
                 _, j, _, _ = ins[n]
@@ -617,10 +618,12 @@ def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps
                     rows_ch.append(choff[n] + w)
                     rows_cf.append(cf)
                     rows_L.append(L[choff[n] - ch0 + w])
+                    rows_meta.append((n, w, 0.0 if uvu else cpath, choff[n] - ch0 + w))
                 flops += (0.0 if uvu else 2.0 * mi2 * mk * nc) + 2.0 * mmid * nc      # + 2 H mmid + 2 mmid mk nc, added by the caller (H)
                 flops += 2.0 * mmid * mk * nc
             yield dict(i=i, k=k, mi=mi2 // nsrc, li=li, mk=mk, lk=lk, mm=mm, par=par, W=np.array(rows_W), ch=np.array(rows_ch),
-                       cf=np.array(rows_cf), L=np.array(rows_L), flops=flops, nmid=len(rows_ch))
+                       cf=np.array(rows_cf), L=np.array(rows_L), flops=flops, nmid=len(rows_ch), meta=rows_meta,
+                       woff={n: woff[n] for n in plist}, lin=lin_off[k], lo_off=lo_off[k], pk=pk, pi=pi)
 
 
 def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
@@ -1044,6 +1047,81 @@ def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, i
                          w3e / math.sqrt(H), np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]),
                          mlp=1, target_base=nb)
     return prog.finalize()
+
+
+def build_message_pack_wgrad_programs(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
+    """WEIGHT gradients of a (non-lite) MessagePackBlock, first version: two programs for the existing fused kernels that
+    MATERIALISE, per edge, what the reference's unfused graph holds anyway --
+      program A (sources: sender rows, receiver rows, edge rows, edge frame):  A[row, c] = cf[row, c] (W x)[row, c]   (radial scale 1, L' = 1)
+      program B (source: the gradient of the block's output rows, edge frame): B[row, c] = (L g)[row, c]              (cf = 1, scale 1)
+    for every row (= (e3nn path, mid channel)) of every super-path, both in the SAME output layout (one output "irrep" (rows, l_k, p_k)
+    per row chunk, columns centred like the forward's tiles).  The gradients are then reductions over the edges of products of these
+    rows with the inputs (plain library GEMMs, hamgnn_amd/backward_mp.py):
+      g_s[row] = sum_c A B,   g_L = (s A)^T g,   g_W = x^T (s cf B),   g_W3 = h^T g_s,   g_h = g_s W3^T.
+    Correct, not fast (140 KB of intermediates per edge and branch): the fused weight-gradient kernel is the next step.
+    Returns (program A, program B, chunks) with chunks[j] = the bookkeeping of output irrep j."""
+    irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
+    _, w3n = _last_layer(sd, "node_weight_generator")
+    _, w3e = _last_layer(sd, "edge_weight_generator")
+    H = w3n.shape[0]
+    gl = PlanarLayout(irreps_out)
+    branches = (("node", 2, [SRC_XS, SRC_XD], PlanarLayout(irreps_node), 0, w3n), ("edge", 1, [SRC_F], PlanarLayout(irreps_edge), 1, w3e))
+    chunks = []
+    for name, nsrc, srcs, lay, mlp, w3 in branches:
+        for sp in _tp_superpaths(nsrc, lay, irreps_sh, irreps_out, np.asarray(sd[f"{name}_tensor_product.weight"]), w3 / math.sqrt(H),
+                                 np.asarray(sd[f"{name}_linear_scaler.linear_out.weight"]), np.asarray(sd[f"{name}_linear_out.weight"]), False):
+            nc = 2 * sp["mm"] + 1
+            step = min(rtm_max(nc) * 16, seg_rows_cap(sp["lk"]))
+            for r0 in range(0, sp["nmid"], step):
+                chunks.append(dict(sp=sp, branch=name, nsrc=nsrc, srcs=srcs, lay=lay, mlp=mlp, r0=r0, r1=min(sp["nmid"], r0 + step)))
+    out_irreps = Irreps([(c["r1"] - c["r0"], c["sp"]["lk"], c["sp"]["pk"]) for c in chunks])
+    progs = []
+    for which in ("A", "B"):
+        prog, seg_of = new_program(out_irreps, H)
+        for j, c in enumerate(chunks):
+            sp, r0, r1 = c["sp"], c["r0"], c["r1"]
+            n, mm, lk, mk = r1 - r0, sp["mm"], sp["lk"], sp["mk"]
+            nc = 2 * mm + 1
+            rtm = ceil_div(n, 16)
+            rho = np.arange(n)
+            phys = 16 * (rho // 16) + 4 * (rho % 4) + (rho % 16) // 4        # see add_tp_items
+            R = rtm * 16
+            seg = seg_of[j]
+            rto = prog.segs[seg][2]
+            w3p = np.zeros((H, R))
+            w3p[0, phys] = 1.0                                 # radial scale 1: the launch gets hidden rows with a 1 in column 0
+            w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
+            cfp = np.zeros((R, nc))
+            cfp[phys] = sp["cf"][r0:r1] if which == "A" else 1.0
+            cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))
+            Ip = np.zeros((R, rto * 16))
+            Ip[phys, rho] = 1.0                                # GEMM2 = identity: output channel = logical row
+            a2_off = prog.add_weights(Ip.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4))
+            if which == "A":
+                lay, mi, i = c["lay"], sp["mi"], sp["i"]
+                ksteps = lay.mulp[i] // 4
+                x4 = use_x4(lay.mulp[i], nc)
+                a1 = []
+                for s_ in range(c["nsrc"]):
+                    Wk = np.zeros((mi, R))
+                    Wk[:, phys] = sp["W"][r0:r1, s_ * mi:(s_ + 1) * mi].T
+                    a1.append(_frag_A(Wk, ksteps, rtm, x4))
+                a1_off = prog.add_weights(np.stack(a1))
+                _add_item(prog, seg, IT_TP, list(c["srcs"]), lay.off[i], lay.mulp[i], sp["li"], mm, sp["par"], ksteps, rtm, c["mlp"],
+                          a1_off, w3_off, cf_off, a2_off, n, nk2=ceil_div(n, 4))
+            else:
+                k = sp["k"]
+                ksteps = gl.mulp[k] // 4
+                Lk = np.zeros((mk, R))
+                Lk[:, phys] = sp["L"][r0:r1].T
+                a1_off = prog.add_weights(_frag_A(Lk, ksteps, rtm, use_x4(gl.mulp[k], nc))[None])
+                _add_item(prog, seg, IT_TP, [0], gl.off[k], gl.mulp[k], lk, mm, 0, ksteps, rtm, c["mlp"],
+                          a1_off, w3_off, cf_off, a2_off, n, nk2=ceil_div(n, 4))
+        progs.append(prog.finalize())
+    lay_out = PlanarLayout(out_irreps)
+    for j, c in enumerate(chunks):
+        c["out_off"], c["out_mulp"] = lay_out.off[j], lay_out.mulp[j]
+    return progs[0], progs[1], chunks
 
 
 def build_embedding_program(sd: Dict[str, np.ndarray], num_types, irreps_sh, irreps_out, lite_mode=False) -> Program:

@@ -228,6 +228,61 @@ def check_message_pack_backward(device="cuda", seed=0, irr=None, sh=None, schedu
             "g_src_rel_err": err(gs, src), "g_dst_rel_err": err(gd, dst), "g_edge_rel_err": err(gf, ef)}
 
 
+def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=53, radial=(16, 16), num_radial=8):
+    """gradients of EVERY parameter of a MessagePackBlock (TP weights, linear_scaler, linear_out, all radial MLP layers, both
+    branches) on the GPU (materialisation programs on the fused kernels + GEMMs over the edges) vs torch.autograd through the fp64 oracle"""
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    from tests.test_plan_emu import _random_irreps
+    rng = np.random.default_rng(100 + seed)
+    if irr is None:
+        lmax = int(rng.integers(1, 4))
+        irr = _random_irreps(rng, lmax)
+        if "0e" not in irr:
+            irr = "5x0e+" + irr
+        lsh = int(rng.integers(1, 4))
+        sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    lmax, lsh = P.Irreps(irr).lmax, P.Irreps(sh).lmax
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, f"{num_radial}x0e", radial_MLP=list(radial))
+        g = torch.Generator().manual_seed(seed)
+        N = 7
+        D = ref.irreps_node_feats.dim
+        x, ef = torch.randn(N, D, generator=g), torch.randn(E, D, generator=g)
+        s_, r_ = torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)
+        vec = torch.randn(E, 3, generator=g) * 3.0
+        n = torch.nn.functional.normalize(vec, dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, num_radial, generator=g)
+        G = torch.randn(E, D, generator=g)
+        (ref(x[s_], x[r_], ef, shv, rbf) * G).sum().backward()
+        want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    finally:
+        torch.set_default_dtype(prev)
+    m = load_weights(hnn.MessagePackBlock(irr, irr, sh, irr, num_radial, list(radial)), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    m.compile(device, unrotate=True)
+    lay = P.PlanarLayout(irr)
+    lm = max(lmax, lsh)
+    v = torch.stack([n[:, 2], n[:, 0], n[:, 1]], 1) * 2.0
+    jtab = torch.from_numpy(P.wigner_jtab(lm)).to(device)
+    pos = torch.zeros(N, 3, device=device)
+    ei = torch.stack([s_, r_]).to(device)
+    geo = ops.Geometry(pos, ei, v.float().to(device), 8.0, num_radial, lm, jtab)
+    geo.rbf = rbf.float().to(device).contiguous()
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    rot = torch.from_numpy(P.rotate_table(lay)).to(device)
+    pl = lambda t: ops.to_planar(t.float().to(device), imap, lay.dim)
+    f_rot = ops.rotate_gather(pl(ef), None, geo, rot)
+    got = m.backward_weights(pl(x), pl(x), f_rot, geo, rot, pl(G), out_is_global=True, chunk=32)
+    torch.cuda.synchronize()
+    assert set(got) == set(want), sorted(set(got) ^ set(want))[:4]
+    errs = {k: float((got[k].double().cpu().reshape(want[k].shape) - want[k]).abs().max()) / max(float(want[k].abs().max()), 1e-3) for k in want}
+    return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
+
+
 def check_conv_message_backward(device="cuda", n_atoms=10, seed=2):
     """the ConvBlockE3 message chain on a periodic cell:  agg = scatter_receiver(MessagePack(x[sender], x[receiver], f))  -- gradient of
     sum(agg * G) with respect to the NODE rows x and the edge rows f: receiver gather fused into the adjoint launch, the two node

@@ -115,6 +115,19 @@ def test_residual_block_backward_vs_autograd(irr):
     assert max(r.values()) < G.TOL
 
 
+@pytest.mark.parametrize("seed", [0, 1, 3])
+def test_message_pack_weight_gradients_vs_autograd(seed):
+    r = G.check_message_pack_weight_grads(seed=seed)
+    print(r)
+    assert r["max_rel_err"] < G.TOL
+
+
+def test_message_pack_weight_gradients_default_irreps():
+    r = G.check_message_pack_weight_grads(seed=7, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", E=37, radial=(64, 64), num_radial=64)
+    print(r)
+    assert r["max_rel_err"] < G.TOL
+
+
 def test_head_backward_vs_autograd():
     r = G.check_head_backward()
     print(r)

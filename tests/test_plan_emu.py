@@ -488,6 +488,52 @@ def test_linear_adjoint_tables_vs_autograd(seed):
     assert np.abs(li.from_planar(got) - x.grad.numpy()).max() <= 1e-6 * max(1.0, np.abs(x.grad.numpy()).max()), (irr_in, irr_out)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_message_pack_weight_gradients_vs_autograd(seed):
+    """weight gradients of a MessagePackBlock through the two materialisation programs (emulated) + the edge reductions of
+    hamgnn_amd/backward_mp.py, every parameter of the block vs torch.autograd through the fp64 oracle"""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import backward_mp as BM
+    rng = np.random.default_rng(500 + seed)
+    lmax = int(rng.integers(1, 3))
+    irr = _random_irreps(rng, lmax)
+    if "0e" not in irr:
+        irr = "5x0e+" + irr
+    lsh = int(rng.integers(1, 3))
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
+        E = 11
+        g_ = torch.Generator().manual_seed(seed)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g_) for _ in range(3))
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g_), dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g_)
+        G = torch.randn(E, ref.irreps_node_feats.dim, generator=g_)
+        (ref(src, dst, ef, shv, rbf) * G).sum().backward()
+        want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    finally:
+        torch.set_default_dtype(prev)
+    if max(float(v.abs().max()) for v in want.values()) < 1e-12:
+        return
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay = P.PlanarLayout(irr)
+    lm = max(lmax, lsh)
+    D = emu.edge_wigner_all(n.numpy(), lm)
+    rot = lambda t: torch.from_numpy(emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, lm))
+    wg = BM.MessagePackWeightGrad(sd, irr, irr, sh, irr)
+    run = lambda prog, srcs, hn, he: torch.from_numpy(emu.run_program(prog, [t.numpy() for t in srcs], (hn.numpy(), he.numpy())))
+    got = BM.block_weight_grads(wg, run, rot(src), rot(dst), rot(ef), rot(G), rbf, emu.SILU_CST, chunk=7)
+    assert set(got) == set(want), sorted(set(got) ^ set(want))
+    for k in want:
+        scale = max(float(want[k].abs().max()), 1e-30)
+        assert float((got[k].reshape(want[k].shape) - want[k]).abs().max()) < 2e-6 * max(scale, 1e-3), (k, irr, sh)
+
+
 def _adjoint_case(irr, sh, lmax, lsh, seed, E=17, radial=(16, 16)):
     """oracle MessagePackBlock + torch.autograd: gradients of sum(out * G) with respect to the three inputs; and the emulator inputs"""
     import torch
