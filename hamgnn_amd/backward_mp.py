@@ -40,11 +40,12 @@ def radial_mlp(rbf: torch.Tensor, layers: List[torch.Tensor], act_cst: float) ->
 
 
 def weight_grads_from_rows(chunks, Arows: torch.Tensor, Brows: torch.Tensor, srcs: Sequence[torch.Tensor], g: torch.Tensor,
-                           S: Dict[str, torch.Tensor], acc: Dict[str, torch.Tensor], gs_all: Dict[str, torch.Tensor], irreps_out):
-    """One chunk of edges.  chunks: plan.build_message_pack_wgrad_programs' bookkeeping; Arows / Brows: the two materialised row tensors
-    [E, out_dim]; srcs = (x_sender, x_receiver, f) planar edge-frame rows; g: gradient rows (edge frame, planar(irreps_out));
-    S[branch] = h @ W3 / sqrt(H) [E, n_channels]; acc: running sums of the per-path / per-k gradients (updated in place);
-    gs_all[branch]: [E, n_channels] (filled)."""
+                           S: Dict[str, torch.Tensor], acc: Dict[str, torch.Tensor], gs_all: Dict[str, torch.Tensor], irreps_out, gx=None):
+    """One chunk of edges.  chunks: plan.build_tp_wgrad_programs' bookkeeping; Arows / Brows: the two materialised row tensors
+    [E, out_dim]; srcs = the program's source rows by slot (message pack: x_sender, x_receiver, f), planar, edge frame; g: gradient rows
+    (edge frame, planar(irreps_out)); S[branch] = h @ W3 / sqrt(H) [E, n_channels]; acc: running sums of the per-path / per-k gradients
+    (updated in place); gs_all[branch]: [E, n_channels] (filled); gx: optional list of zero tensors like srcs -- the gradient with
+    respect to the source rows is accumulated there (W^T (s cf B); used for the 0e-only embedding input, where it is a few columns)."""
     gl = P.PlanarLayout(irreps_out)
     for c in chunks:
         sp, r0, r1 = c["sp"], c["r0"], c["r1"]
@@ -64,6 +65,13 @@ def weight_grads_from_rows(chunks, Arows: torch.Tensor, Brows: torch.Tensor, src
         comps = [(li + mm - cc) if sp["par"] else (li - mm + cc) for cc in range(nc)]
         X = torch.cat([_block(srcs[sl], lay.off[i], lay.mulp[i], comps, sp["mi"]) for sl in c["srcs"]], 2)    # [E, nc, nsrc * mi]
         gW = torch.einsum("ecn,ecu->nu", T1, X)                                    # rows x (nsrc mul_i)
+        if gx is not None:
+            Wr = torch.as_tensor(sp["W"][r0:r1], device=A.device, dtype=A.dtype)   # [n, nsrc * mi], path normalisation included
+            GX = torch.einsum("ecn,nu->ecu", T1, Wr)
+            for q, sl in enumerate(c["srcs"]):
+                for cc, a in enumerate(comps):
+                    o = lay.off[i] + a * lay.mulp[i]
+                    gx[sl][:, o:o + sp["mi"]] += GX[:, cc, q * sp["mi"]:(q + 1) * sp["mi"]]
         name = c["branch"]
         for r in range(n):
             pn, w, cpath, lrow = sp["meta"][r0 + r]
@@ -71,25 +79,28 @@ def weight_grads_from_rows(chunks, Arows: torch.Tensor, Brows: torch.Tensor, src
             acc[f"{name}_L"][k][lrow] += gL[r]
 
 
-class MessagePackWeightGrad:
-    """holds the two materialisation programs of one MessagePackBlock and turns (inputs, output gradient) into parameter gradients"""
+class TPWeightGrad:
+    """holds the two materialisation programs of the weighted tensor-product branches of one block and turns (inputs, output gradient)
+    into parameter gradients.  branches: plan.message_pack_wgrad_branches / plan.embedding_wgrad_branches."""
 
-    def __init__(self, sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
+    def __init__(self, sd: Dict[str, np.ndarray], branches, irreps_sh, irreps_out):
         self.sd = {k: np.asarray(v, dtype=np.float64) for k, v in sd.items()}
         self.irreps_out = P.Irreps(irreps_out)
-        self.progA, self.progB, self.chunks = P.build_message_pack_wgrad_programs(sd, irreps_node, irreps_edge, irreps_sh, irreps_out)
+        self.branches = branches
+        self.H = int(branches[0]["w3"].shape[0])
+        self.progA, self.progB, self.chunks = P.build_tp_wgrad_programs(branches, irreps_sh, irreps_out, self.H)
 
     def new_acc(self, device, dtype):
         acc = {}
-        for name in ("node", "edge"):
-            tp, Lk = {}, {}
+        for b in self.branches:
+            name = b["name"]
+            tp = {}
             for c in self.chunks:
                 if c["branch"] != name:
                     continue
                 sp = c["sp"]
                 for (pn, w, cpath, lrow) in sp["meta"][c["r0"]:c["r1"]]:
                     tp.setdefault((pn, sp["woff"][pn], c["nsrc"] * sp["mi"], sp["mk"]), None)
-                Lk.setdefault(sp["k"], None)
             acc[f"{name}_tp"] = {key: torch.zeros(key[2], key[3], device=device, dtype=dtype) for key in tp}
             acc[f"{name}_L"] = {}
             for c in self.chunks:
@@ -98,20 +109,20 @@ class MessagePackWeightGrad:
                     acc[f"{name}_L"][c["sp"]["k"]] = torch.zeros(fan, c["sp"]["mk"], device=device, dtype=dtype)
         return acc
 
-    def finish(self, acc, gW3: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def finish(self, acc, gW3: Dict[str, Dict[str, torch.Tensor]], dev, dt) -> Dict[str, torch.Tensor]:
         """per-path / per-k sums -> the reference's flat parameter gradients"""
         out = {}
-        any_g = next(iter(next(iter(gW3.values())).values()))
-        dev, dt = any_g.device, any_g.dtype
-        for name in ("node", "edge"):
-            wsize = self.sd[f"{name}_tensor_product.weight"].size
-            gtp = torch.zeros(wsize, device=dev, dtype=dt)
+        for b in self.branches:
+            name, keys = b["name"], b["keys"]
+            gtp = torch.zeros(self.sd[keys["tp"]].size, device=dev, dtype=dt)
             for (pn, woff, mi2, mk), G in acc[f"{name}_tp"].items():
                 gtp[woff:woff + mi2 * mk] = G.reshape(-1)
-            out[f"{name}_tensor_product.weight"] = gtp
-            Ls_flat = torch.as_tensor(self.sd[f"{name}_linear_scaler.linear_out.weight"], device=dev, dtype=dt)
-            Lo_flat = torch.as_tensor(self.sd[f"{name}_linear_out.weight"], device=dev, dtype=dt)
-            gLs, gLo = torch.zeros_like(Ls_flat), torch.zeros_like(Lo_flat)
+            out[keys["tp"]] = gtp
+            Ls_flat = torch.as_tensor(self.sd[keys["ls"]], device=dev, dtype=dt)
+            gLs = torch.zeros_like(Ls_flat)
+            if keys["lo"] is not None:
+                Lo_flat = torch.as_tensor(self.sd[keys["lo"]], device=dev, dtype=dt)
+                gLo = torch.zeros_like(Lo_flat)
             seen = set()
             for c in self.chunks:
                 sp = c["sp"]
@@ -119,32 +130,43 @@ class MessagePackWeightGrad:
                     continue
                 seen.add(sp["k"])
                 (off, fan), lo_off, mk = sp["lin"], sp["lo_off"], sp["mk"]
+                gL = acc[f"{name}_L"][sp["k"]]                 # d / d (Ls / sqrt(fan) [@ Lo / sqrt(mk)])
+                if keys["lo"] is None:
+                    gLs[off:off + fan * mk] = (gL / math.sqrt(fan)).reshape(-1)
+                    continue
                 Ls = Ls_flat[off:off + fan * mk].reshape(fan, mk) / math.sqrt(fan)
                 Lo = Lo_flat[lo_off:lo_off + mk * mk].reshape(mk, mk) / math.sqrt(mk)
-                gL = acc[f"{name}_L"][sp["k"]]                 # d / d (Ls @ Lo)
                 gLs[off:off + fan * mk] = ((gL @ Lo.t()) / math.sqrt(fan)).reshape(-1)
                 gLo[lo_off:lo_off + mk * mk] = ((Ls.t() @ gL) / math.sqrt(mk)).reshape(-1)
-            out[f"{name}_linear_scaler.linear_out.weight"] = gLs
-            out[f"{name}_linear_out.weight"] = gLo
+            out[keys["ls"]] = gLs
+            if keys["lo"] is not None:
+                out[keys["lo"]] = gLo
             out.update(gW3[name])
         return out
 
 
-def block_weight_grads(wg: MessagePackWeightGrad, run_program, xs, xd, f, g, rbf, act_cst: float, chunk: int = 16384) -> Dict[str, torch.Tensor]:
+class MessagePackWeightGrad(TPWeightGrad):
+    def __init__(self, sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
+        super().__init__(sd, P.message_pack_wgrad_branches(sd, irreps_node, irreps_edge), irreps_sh, irreps_out)
+
+
+def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor], g, rbf, act_cst: float, chunk: int = 16384, want_gx: bool = False):
     """run_program(prog, sources, h_node, h_edge) -> rows [E_chunk, out_dim] (the HIP kernels on the GPU, the emulator in the CPU suite).
-    xs / xd / f: planar edge-frame input rows of the block; g: gradient of its output rows (edge frame); rbf: radial basis rows."""
-    dev, dt = xs.device, xs.dtype
-    E = xs.shape[0]
-    sd = wg.sd
+    srcs: planar edge-frame input rows of the block by source slot; g: gradient of its output rows (edge frame); rbf: radial basis rows.
+    Returns the parameter gradients ({reference name: flat gradient}) -- and, with want_gx, the gradients of the source rows."""
+    dev, dt = g.device, g.dtype
+    E = g.shape[0]
+    sd, H = wg.sd, wg.H
     acc = wg.new_acc(dev, dt)
-    gen = {}
-    for name in ("node", "edge"):
-        ks = sorted(k for k in sd if k.startswith(f"{name}_weight_generator.layer") and k.endswith(".weight"))
-        gen[name] = [torch.as_tensor(sd[k], device=dev, dtype=dt).requires_grad_() for k in ks]
-    H = gen["node"][-1].shape[0]
+    gen, gkeys = {}, {}
+    for b in wg.branches:
+        pre = b["keys"]["gen"]
+        gkeys[b["name"]] = sorted(k for k in sd if k.startswith(pre + ".layer") and k.endswith(".weight"))
+        gen[b["name"]] = [torch.as_tensor(sd[k], device=dev, dtype=dt).requires_grad_() for k in gkeys[b["name"]]]
     gW3 = {name: {} for name in gen}
     gh_hidden = {name: torch.zeros(E, H, device=dev, dtype=dt) for name in gen}
     gW3_last = {name: torch.zeros_like(gen[name][-1]) for name in gen}
+    gx = [torch.zeros_like(t) for t in srcs] if want_gx else None
     for e0 in range(0, E, chunk):
         sl = slice(e0, min(E, e0 + chunk))
         n = sl.stop - sl.start
@@ -153,19 +175,29 @@ def block_weight_grads(wg: MessagePackWeightGrad, run_program, xs, xd, f, g, rbf
             S = {name: h[name] @ (gen[name][-1].detach() / math.sqrt(H)) for name in gen}
             ones = torch.zeros(n, wg.progA.hidden_pad, device=dev, dtype=dt)
             ones[:, 0] = 1.0
-            Arows = run_program(wg.progA, [xs[sl], xd[sl], f[sl]], ones, ones)
+            part = [t[sl] for t in srcs]
+            Arows = run_program(wg.progA, part, ones, ones)
             Brows = run_program(wg.progB, [g[sl]], ones, ones)
             gs_all = {name: torch.zeros(n, gen[name][-1].shape[1], device=dev, dtype=dt) for name in gen}
-            weight_grads_from_rows(wg.chunks, Arows, Brows, (xs[sl], xd[sl], f[sl]), g[sl], S, acc, gs_all, wg.irreps_out)
+            weight_grads_from_rows(wg.chunks, Arows, Brows, part, g[sl], S, acc, gs_all, wg.irreps_out,
+                                   gx=None if gx is None else [t[sl] for t in gx])
             for name in gen:
                 gW3_last[name] += h[name].t() @ gs_all[name] / math.sqrt(H)
                 gh_hidden[name][sl] = gs_all[name] @ (gen[name][-1].detach().t() / math.sqrt(H))
     for name in gen:                                           # hidden layers of the radial MLPs: two dense layers per edge, torch.autograd
         hidden = gen[name][:-1]
-        hfull = radial_mlp(rbf, hidden, act_cst)
-        grads = torch.autograd.grad(hfull, hidden, grad_outputs=gh_hidden[name], allow_unused=True)
-        ks = sorted(k for k in sd if k.startswith(f"{name}_weight_generator.layer") and k.endswith(".weight"))
-        for k, gk in zip(ks[:-1], grads):
-            gW3[name][k] = gk if gk is not None else torch.zeros_like(gen[name][0])
+        ks = gkeys[name]
+        if hidden:
+            with torch.enable_grad():                          # callers run under no_grad (training_step)
+                hfull = radial_mlp(rbf, hidden, act_cst)
+                grads = torch.autograd.grad(hfull, hidden, grad_outputs=gh_hidden[name], allow_unused=True)
+            for k, w, gk in zip(ks[:-1], hidden, grads):
+                gW3[name][k] = gk if gk is not None else torch.zeros_like(w)
         gW3[name][ks[-1]] = gW3_last[name]
-    return wg.finish(acc, gW3)
+    out = wg.finish(acc, gW3, dev, dt)
+    return (out, gx) if want_gx else out
+
+
+def block_weight_grads(wg: MessagePackWeightGrad, run_program, xs, xd, f, g, rbf, act_cst: float, chunk: int = 16384) -> Dict[str, torch.Tensor]:
+    """MessagePackBlock: sources = (sender rows, receiver rows, edge rows), all planar in the edge frame"""
+    return tp_weight_grads(wg, run_program, [xs, xd, f], g, rbf, act_cst, chunk)

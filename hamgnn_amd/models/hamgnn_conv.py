@@ -202,18 +202,90 @@ class HamGNNConvE3(_BackboneBase):
         self._compile_common(dev)
         return self
 
-    def forward(self, data):
+    def forward(self, data, save_for_backward: bool = False):
+        """save_for_backward: keep the layer inputs (node rows, edge rows, aggregated messages) on the result (`_tape`) for `backward`"""
         z, topo, geo, node, f = self._embed(data)
         N = z.shape[0]
         rowptr, perm = topo.receiver_csr()
+        tape = [] if save_for_backward else None
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             skip = conv.skip_linear(node)
             msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab)          # global frame (un-rotated in the epilogue)
             agg = ops.segment_sum(msg, rowptr, perm, N)
             parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
+            if tape is not None:
+                tape.append(dict(node_in=node, f_in=f, agg=agg))
             node = conv.residual(agg, extra=skip)
             if self.use_corr_prod:                              # CorrProductBlock.forward (interaction_blocks.py:234-260; hamgnn_conv.py:274-275)
                 node = self.corr_products[li](node, z)
+            if tape is not None:
+                tape[-1]["node_out"] = node
             f = self._run_pair(pair, node, f, geo)
-        return self._representation(node, f, geo)
+        rep = self._representation(node, f, geo)
+        if tape is not None:
+            rep["_tape"] = tape
+        return rep
+
+    # ------------------------------------------------------------------------------------------------------------ backward (SURVEY 8f-3)
+    def backward(self, data, rep, g_node, g_edge_rot, chunk: int = 16384):
+        """Gradients of EVERY backbone parameter for the gradients of the representation the forward returned: g_node [N, Dp] (planar node
+        rows) and g_edge_rot [E, Dp] (planar edge rows in the edge frame) -- what HamGNNPlusPlusOut.backward hands back.  `rep` must come
+        from forward(data, save_for_backward=True).  Chains the block-level backwards (all on the HIP kernels + library GEMMs):
+        per layer, last to first:  PairInteractionBlock (message block data + weight gradients, sender / receiver segment sums, the two
+        linear_up adjoints, the fused skip o3.Linear)  ->  ResidualBlock  ->  skip o3.Linear  ->  ConvBlockE3's message block with the
+        receiver scatter's adjoint (a gather) fused into its staging;  then the pair embedding and the chemical embedding table.
+        Returns {reference parameter name: gradient in the reference's layout}.  Non-lite, no CorrProduct, no charge doping, one rank."""
+        if self.lite_mode or self.use_corr_prod or self.apply_charge_doping:
+            raise NotImplementedError("backbone backward: non-lite HamGNNConvE3 without CorrProductBlock / charge doping")
+        if parallel.is_sharded(data):
+            raise NotImplementedError("backbone backward of an edge-sharded graph")
+        tape = rep["_tape"]
+        geo = rep["_geometry"]
+        z = data.z.contiguous()
+        topo = get_topology(data)
+        N = z.shape[0]
+        rp_r, pm_r = topo.receiver_csr()
+        rp_s, pm_s = topo.sender_csr()
+        rot = self._rot_tab
+        grads = {}
+        put = lambda prefix, d: grads.update({prefix + k: v for k, v in d.items()})
+        g_node, g_f = g_node.contiguous(), g_edge_rot.contiguous()
+        for li in reversed(range(self.num_layers)):
+            conv, pair, t = self.convolutions[li], self.pair_interactions[li], tape[li]
+            node_in, f_in, agg, node_out = t["node_in"], t["f_in"], t["agg"], t["node_out"]
+            # ---- PairInteractionBlock (interaction_blocks.py:130-164): f_out = MP(up_src(node_out)[src], up_tar(node_out)[dst], f_in) + skip(f_in)
+            pre = f"pair_interactions.{li}."
+            if pair.use_skip_connections or not pair.legacy_edge_update:
+                up_s, up_t = pair.linear_up_src(node_out), pair.linear_up_tar(node_out)
+                put(pre + "conv_tp.", pair.conv_tp.backward_weights(up_s, up_t, f_in, geo, rot, g_f, out_is_global=False, chunk=chunk))
+                gs, gd, ge = pair.conv_tp.backward_data(g_f, geo, out_is_global=False)
+                g_up_s = ops.segment_sum(gs, rp_s, pm_s, N)
+                g_up_t = ops.segment_sum(gd, rp_r, pm_r, N)
+                grads[pre + "linear_up_src.weight"] = pair.linear_up_src.weight_grad(node_out, g_up_s)
+                grads[pre + "linear_up_tar.weight"] = pair.linear_up_tar.weight_grad(node_out, g_up_t)
+                g_node = g_node + pair.linear_up_src.backward_data(g_up_s) + pair.linear_up_tar.backward_data(g_up_t)
+                if pair.use_skip_connections:
+                    grads[pre + "skip_linear.weight"] = pair.skip_linear.weight_grad(f_in, g_f)
+                    ge = ge + pair.skip_linear.backward_data(g_f)
+                g_f = ge
+            else:                                              # legacy layer 0: the block is not evaluated, its parameters get zeros
+                for k, p_ in pair.named_parameters():
+                    grads[pre + k] = torch.zeros_like(p_).reshape(-1)
+            # ---- ConvBlockE3 (convolution.py:116-160): node_out = residual(agg) + skip(node_in), agg = scatter_dst MP(node_in[src], node_in[dst], f_in)
+            pre = f"convolutions.{li}."
+            g_agg, g_res = conv.residual.backward(agg, g_node, extra_given=True)
+            put(pre + "residual.", g_res)
+            grads[pre + "skip_linear.weight"] = conv.skip_linear.weight_grad(node_in, g_node)
+            g_node_in = conv.skip_linear.backward_data(g_node)
+            put(pre + "conv_tp.", conv.conv_tp.backward_weights(node_in, node_in, f_in, geo, rot, g_agg, out_is_global=True, chunk=chunk, gather=geo.dst))
+            gs, gd, ge = conv.conv_tp.backward_data(g_agg, geo, out_is_global=True, gather=geo.dst)
+            g_node = g_node_in + ops.segment_sum(gs, rp_s, pm_s, N) + ops.segment_sum(gd, rp_r, pm_r, N)
+            g_f = g_f + ge
+        # ---- embeddings: edge rows from the pair embedding, node rows = rows of the chemical embedding table
+        put("pair_embedding.", self.pair_embedding.backward(z, geo, g_f, chunk=chunk))
+        T, lay = self.num_types, self.layout
+        gtab = torch.zeros(T, lay.dim, device=g_node.device, dtype=g_node.dtype).index_add_(0, z.long(), g_node)
+        gw = [gtab[:, lay.off[k]:lay.off[k] + mk].reshape(-1) / math.sqrt(T) for k, (mk, lk, pk) in enumerate(self.irreps_node_features) if (lk, pk) == (0, 1)]
+        grads["chemical_embedding.linear.weight"] = torch.cat(gw)
+        return grads

@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's hot-path modules (hamgnn/nn/*.py): same attribute / parameter names and flat
 e3nn weight layouts (so reference state_dicts load unchanged), but `forward` drives the hand-written HIP kernels through
-the C ABI.  Weights are (re)packed into MFMA fragment order by `compile()`; inference-only in this round.
+the C ABI.  Weights are (re)packed into MFMA fragment order by `compile()`.  The `backward*` methods are the block-level pieces of the
+training path (chained by HamGNNConvE3.backward / HamGNNPlusPlusOut.backward / hamgnn_amd.training).
 
 Reference classes mirrored here: o3.Linear / o3.TensorProduct / FullyConnectedNet parameter holders [e3nn 0.5.0];
 LinearScaleWithWeights (tensor_products.py:25-47), TensorProductWithMemoryOptimizationWithWeight (:51-189),
@@ -160,6 +161,12 @@ class _CombineMessages(nn.Module):
 MP_KERNEL_DEFAULT = "auto"
 
 
+def _wgrad_runner(wg, dpA, dpB):
+    """backward_mp's run_program on the device: the two materialisation programs on the segment-stationary fused kernel"""
+    dps = {id(wg.progA): dpA, id(wg.progB): dpB}
+    return lambda prog, srcs, hn, he: ops.tp_fused(dps[id(prog)], [t.contiguous() for t in srcs], srcs[0].shape[0], hn, he, None, tag="wgrad_rows")
+
+
 class MessagePackBlock(nn.Module):
     def __init__(self, irreps_node_feats, irreps_edge_feats, irreps_local_env_edge, irreps_out, num_radial, radial_MLP=(64, 64),
                  lite_mode=False):
@@ -221,7 +228,7 @@ class MessagePackBlock(nn.Module):
         self._dp = ops.DeviceProgram(prog, device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
         return self
 
-    # ---- backward, data gradient (the weight gradients are not built)
+    # ---- backward: data gradient as an adjoint program, weight gradients through backward_mp
     def compile_adjoint(self, device):
         """upload the data-gradient program of this block (plan.build_message_pack_adjoint_program): same kernels, same weights"""
         if self.lite_mode:
@@ -272,8 +279,8 @@ class MessagePackBlock(nn.Module):
                 self._dp_plain = self._dp
         return self._dp_plain
 
-    def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 16384):
-        """gradients of every parameter of this block for the output gradient `grad_out` (see backward_data for its frame), first
+    def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 16384, gather=None):
+        """gradients of every parameter of this block for the output gradient `grad_out` (frame and `gather` as in backward_data), first
         version (hamgnn_amd/backward_mp.py): two materialisation programs on the fused kernels + library GEMMs over the edges.
         node_s / node_d: planar NODE rows gathered by sender / receiver as in run_nodes; f_rot: planar edge rows (edge frame).
         Returns {reference parameter name: gradient in the reference's flat layout}."""
@@ -286,10 +293,11 @@ class MessagePackBlock(nn.Module):
             self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
         wg, dpA, dpB = self._wgrad
         xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)
-        g = ops.rotate_gather(grad_out, None, geo, self._rot_tab_out(dev)) if out_is_global else grad_out
-        dps = {id(wg.progA): dpA, id(wg.progB): dpB}
-        run = lambda prog, srcs, hn, he: ops.tp_fused(dps[id(prog)], [t.contiguous() for t in srcs], srcs[0].shape[0], hn, he, None, tag="wgrad_rows")
-        return BM.block_weight_grads(wg, run, xs, xd, f_rot, g, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk)
+        if out_is_global:
+            g = ops.rotate_gather(grad_out, gather, geo, self._rot_tab_out(dev))
+        else:
+            g = grad_out if gather is None else grad_out[gather].contiguous()
+        return BM.block_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), xs, xd, f_rot, g, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk)
 
     def _rot_tab_out(self, device):
         if getattr(self, "_rt_out", None) is None:
@@ -427,6 +435,8 @@ class PairInteractionBlock(nn.Module):
                 self.skip_linear.compile(device)
         else:
             self.conv_tp.compile(device, unrotate=False, skip_weight=skip)   # skip o3.Linear fused as extra items
+            if self.use_skip_connections:
+                self.skip_linear._dp_adj = None                # its forward is fused above; only the backward uses the module's own tables
 
 
 class _EmbTP(nn.Module):
@@ -463,6 +473,30 @@ class PairInteractionEmbeddingBlock(nn.Module):
         self._dp = ops.DeviceProgram(P.build_embedding_program(_np_sd(self.conv_tp), T, self.irreps_sh, self.irreps_out, self.lite_mode), device)
         self._h = self.conv_tp.weight_generator.hidden_layers(device)
         self._Tp = P.PlanarLayout([(T, 0, 1)]).dim
+        self._wgrad = None
+
+    def backward(self, z, geo: ops.Geometry, g_f, chunk: int = 16384):
+        """gradients of every parameter of the block for the gradient g_f of the edge rows it returned (planar, edge frame):
+        conv_tp.* through the materialisation programs (backward_mp), linear_up_src / linear_up_dst from the gradient of the
+        num_types scalar input channels (an index_add over the element of the sender / receiver)."""
+        from . import backward_mp as BM
+        if self.lite_mode:
+            raise NotImplementedError("backward of a lite_mode PairInteractionEmbeddingBlock")
+        dev, T = g_f.device, self.num_types
+        if self._wgrad is None:
+            sd = _np_sd(self.conv_tp)
+            wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T), self.irreps_sh, self.irreps_out)
+            self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
+        wg, dpA, dpB = self._wgrad
+        x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, T, self._Tp)
+        grads, gx = BM.tp_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), [x], g_f, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk, want_gx=True)
+        out = {"conv_tp." + k: v for k, v in grads.items()}
+        gx = gx[0][:, :T]
+        s = 1.0 / math.sqrt(T)
+        for name, idx in (("linear_up_src", geo.src), ("linear_up_dst", geo.dst)):
+            gT = torch.zeros(T, T, device=dev, dtype=gx.dtype).index_add_(0, z[idx.long()].long(), gx)
+            out[name + ".weight"] = (gT * s).reshape(-1)
+        return out
 
     def run(self, z, geo: ops.Geometry, delta=None):
         """delta: optional [N, num_types] charge-doping correction of the node attributes -> per-atom source / target tables"""

@@ -55,6 +55,11 @@ def shard_graph(g: Graph, rank: int, world: int) -> Graph:
     return out
 
 
+def is_sharded(data) -> bool:
+    shard = data.get("_hg_shard") if hasattr(data, "get") else None
+    return shard is not None and shard[1] > 1
+
+
 def allreduce_nodes(t: torch.Tensor, data) -> torch.Tensor:
     """Sum the per-rank partial node aggregates in place (RCCL over xGMI: torch.distributed backend 'nccl')."""
     shard = data.get("_hg_shard") if hasattr(data, "get") else None

@@ -1049,31 +1049,29 @@ def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, i
     return prog.finalize()
 
 
-def build_message_pack_wgrad_programs(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
-    """WEIGHT gradients of a (non-lite) MessagePackBlock, first version: two programs for the existing fused kernels that
-    MATERIALISE, per edge, what the reference's unfused graph holds anyway --
-      program A (sources: sender rows, receiver rows, edge rows, edge frame):  A[row, c] = cf[row, c] (W x)[row, c]   (radial scale 1, L' = 1)
+def build_tp_wgrad_programs(branches, irreps_sh, irreps_out, H: int):
+    """WEIGHT gradients of the weighted tensor-product branches of a (non-lite) MessagePackBlock / the embedding TP, first version
+    (SURVEY 8f-3): two programs for the existing fused kernels that MATERIALISE, per edge, what the reference's unfused graph holds anyway --
+      program A (sources: the branch inputs, edge frame):                      A[row, c] = cf[row, c] (W x)[row, c]   (radial scale 1, L' = 1)
       program B (source: the gradient of the block's output rows, edge frame): B[row, c] = (L g)[row, c]              (cf = 1, scale 1)
     for every row (= (e3nn path, mid channel)) of every super-path, both in the SAME output layout (one output "irrep" (rows, l_k, p_k)
     per row chunk, columns centred like the forward's tiles).  The gradients are then reductions over the edges of products of these
     rows with the inputs (plain library GEMMs, hamgnn_amd/backward_mp.py):
       g_s[row] = sum_c A B,   g_L = (s A)^T g,   g_W = x^T (s cf B),   g_W3 = h^T g_s,   g_h = g_s W3^T.
     Correct, not fast (140 KB of intermediates per edge and branch): the fused weight-gradient kernel is the next step.
+    branches: dicts {name, nsrc, srcs, lay, mlp, tp_w, w3 (raw last radial layer), ls_w, lo_w | None}.
     Returns (program A, program B, chunks) with chunks[j] = the bookkeeping of output irrep j."""
-    irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
-    _, w3n = _last_layer(sd, "node_weight_generator")
-    _, w3e = _last_layer(sd, "edge_weight_generator")
-    H = w3n.shape[0]
+    irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
     gl = PlanarLayout(irreps_out)
-    branches = (("node", 2, [SRC_XS, SRC_XD], PlanarLayout(irreps_node), 0, w3n), ("edge", 1, [SRC_F], PlanarLayout(irreps_edge), 1, w3e))
     chunks = []
-    for name, nsrc, srcs, lay, mlp, w3 in branches:
-        for sp in _tp_superpaths(nsrc, lay, irreps_sh, irreps_out, np.asarray(sd[f"{name}_tensor_product.weight"]), w3 / math.sqrt(H),
-                                 np.asarray(sd[f"{name}_linear_scaler.linear_out.weight"]), np.asarray(sd[f"{name}_linear_out.weight"]), False):
+    for b in branches:
+        for sp in _tp_superpaths(b["nsrc"], b["lay"], irreps_sh, irreps_out, np.asarray(b["tp_w"]), np.asarray(b["w3"]) / math.sqrt(H),
+                                 np.asarray(b["ls_w"]), None if b["lo_w"] is None else np.asarray(b["lo_w"]), False):
             nc = 2 * sp["mm"] + 1
             step = min(rtm_max(nc) * 16, seg_rows_cap(sp["lk"]))
             for r0 in range(0, sp["nmid"], step):
-                chunks.append(dict(sp=sp, branch=name, nsrc=nsrc, srcs=srcs, lay=lay, mlp=mlp, r0=r0, r1=min(sp["nmid"], r0 + step)))
+                chunks.append(dict(sp=sp, branch=b["name"], nsrc=b["nsrc"], srcs=b["srcs"], lay=b["lay"], mlp=b["mlp"], r0=r0,
+                                   r1=min(sp["nmid"], r0 + step)))
     out_irreps = Irreps([(c["r1"] - c["r0"], c["sp"]["lk"], c["sp"]["pk"]) for c in chunks])
     progs = []
     for which in ("A", "B"):
@@ -1122,6 +1120,31 @@ def build_message_pack_wgrad_programs(sd: Dict[str, np.ndarray], irreps_node, ir
     for j, c in enumerate(chunks):
         c["out_off"], c["out_mulp"] = lay_out.off[j], lay_out.mulp[j]
     return progs[0], progs[1], chunks
+
+
+def message_pack_wgrad_branches(sd: Dict[str, np.ndarray], irreps_node, irreps_edge):
+    """the two weighted branches of a non-lite MessagePackBlock, with the reference's parameter names (message_passing.py:112-160)"""
+    out = []
+    for name, nsrc, srcs, irr, mlp in (("node", 2, [SRC_XS, SRC_XD], irreps_node, 0), ("edge", 1, [SRC_F], irreps_edge, 1)):
+        keys = dict(tp=f"{name}_tensor_product.weight", ls=f"{name}_linear_scaler.linear_out.weight", lo=f"{name}_linear_out.weight",
+                    gen=f"{name}_weight_generator")
+        _, w3 = _last_layer(sd, keys["gen"])
+        out.append(dict(name=name, nsrc=nsrc, srcs=srcs, lay=PlanarLayout(Irreps(irr)), mlp=mlp, keys=keys, tp_w=sd[keys["tp"]], w3=w3,
+                        ls_w=sd[keys["ls"]], lo_w=sd[keys["lo"]]))
+    return out
+
+
+def embedding_wgrad_branches(sd: Dict[str, np.ndarray], num_types: int):
+    """the single branch of PairInteractionEmbeddingBlock.conv_tp (non-lite; embeddings.py:328-334): input num_types x 0e"""
+    keys = dict(tp="tensor_product.weight", ls="linear_scaler.linear_out.weight", lo=None, gen="weight_generator")
+    _, w3 = _last_layer(sd, keys["gen"])
+    return [dict(name="emb", nsrc=1, srcs=[SRC_XS], lay=PlanarLayout([(num_types, 0, 1)]), mlp=0, keys=keys, tp_w=sd[keys["tp"]], w3=w3,
+                 ls_w=sd[keys["ls"]], lo_w=None)]
+
+
+def build_message_pack_wgrad_programs(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
+    br = message_pack_wgrad_branches(sd, irreps_node, irreps_edge)
+    return build_tp_wgrad_programs(br, irreps_sh, irreps_out, br[0]["w3"].shape[0])
 
 
 def build_embedding_program(sd: Dict[str, np.ndarray], num_types, irreps_sh, irreps_out, lite_mode=False) -> Program:

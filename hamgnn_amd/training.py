@@ -3,7 +3,9 @@ backward of HamGNNPlusPlusOut (non-SOC) run on the HIP kernels, the gradients la
 any torch optimiser steps them.  What the reference's Lightning `training_step` does around it (hamgnn/models/Model.py:150-196: loss from
 `losses: [{metric, prediction, target, loss_weight}]`) is restated for the Hamiltonian entry.
 
-Not built: gradients of the backbone's fused edge kernel weights -- the backbone stays frozen."""
+`training_step` chains the backbone's backward behind it (HamGNNConvE3.backward: every block-level backward on the HIP kernels, the
+message blocks' weight gradients through the materialisation programs of hamgnn_amd/backward_mp.py): the gradient of the loss with
+respect to EVERY parameter of the model, i.e. what `trainer.fit` needs per batch (hamgnn/main.py:389-420).  No DDP, no Lightning loop."""
 from __future__ import annotations
 
 from typing import Dict, Optional
@@ -56,3 +58,43 @@ def head_training_step(model, batch, metric: str = "mae", target: Optional[torch
     head._compiled_for = None
     head._adj_tabs = None
     return {"loss": loss, "representation": rep, "g_node_planar": g_node, "g_edge_planar_rot": g_edge}
+
+
+def _invalidate(module):
+    """the packed weight fragments / adjoint tables are stale once the optimiser has stepped: repacked on the next forward"""
+    for m in module.modules():
+        for attr in ("_dp", "_dp_adj", "_wgrad", "_adj_tabs"):
+            if hasattr(m, attr):
+                setattr(m, attr, None)
+        if hasattr(m, "_compiled_for"):
+            m._compiled_for = None
+
+
+@torch.no_grad()
+def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """One loss / gradient evaluation of the WHOLE model (HamGNNConvE3 backbone + non-SOC HamGNNPlusPlusOut head): forward with the
+    layer inputs kept, loss(hamiltonian, target), backward through head and backbone on the GPU kernels, `.grad` of every parameter set
+    (accumulated if already present).  The caller owns the optimiser (`opt.step(); opt.zero_grad()`); all packed weights are dropped
+    here and repacked by the next forward (a host-side repack of every block: fine for fine-tuning runs, the thing to make
+    incremental for long trainings)."""
+    backbone, head = model.representation, model.output_module
+    rep = backbone(batch, save_for_backward=True)
+    out = head(batch, rep)
+    tgt = target if target is not None else gget(batch, "hamiltonian")
+    if tgt is None:
+        raise ValueError("training_step: the batch carries no target (Hon / Hoff or hamiltonian)")
+    H = out["hamiltonian"]
+    loss, gH = _loss_and_grad(H, tgt.to(H.dtype), metric)
+    g_node, g_edge, g_head = head.backward(batch, rep, gH)
+    g_back = backbone.backward(batch, rep, g_node, g_edge)
+    for mod, grads in ((head, g_head), (backbone, g_back)):
+        params = dict(mod.named_parameters())
+        missing = set(params) - set(grads)
+        if missing:
+            raise RuntimeError(f"training_step: no gradient for {sorted(missing)[:4]} ...")
+        for k, g in grads.items():
+            p = params[k]
+            g = g.reshape(p.shape).to(p.dtype)
+            p.grad = g.clone() if p.grad is None else p.grad + g
+    _invalidate(model)
+    return {"loss": loss, "hamiltonian": H}

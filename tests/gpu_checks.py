@@ -283,6 +283,83 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8):
+    """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
+    parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
+    fp64 oracle with the same weights"""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    from hamgnn_amd.training import training_step
+    irr, sh = irr or MINI, sh or SH
+    cfg = dict(num_types=20, irreps_edge_sh=sh, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=num_radial, num_layers=num_layers, irreps_node_features=irr, use_kan=False,
+               radial_MLP=list(radial), correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        rb = R.HamGNNConvE3(cfg)
+        rh = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=False)
+    finally:
+        torch.set_default_dtype(prev)
+    g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004), nao, seed=seed)
+    g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    Href = rh(g64, rb(g64))["hamiltonian"]
+    target = torch.cat([g64["Hon"], g64["Hoff"]], 0).reshape(Href.shape)
+    diff = Href - target
+    loss_ref = (diff * diff).mean() if metric == "mse" else diff.abs().mean()
+    loss_ref.backward()
+    model = Model(load_weights(HamGNNConvE3(cfg), dict(rb.state_dict())),
+                  load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
+                                                 soc_switch=False, calculate_sparsity=False, zero_point_shift=False), dict(rh.state_dict()))).to(device)
+    r = training_step(model, g.to(device), metric=metric, target=target.float().to(device))
+    torch.cuda.synchronize()
+    out = {"N": g.num_nodes, "E": g.num_edges, "loss_rel_err": abs(float(r["loss"]) - float(loss_ref.detach())) / abs(float(loss_ref.detach()))}
+    worst = {}
+    for mod, ref in ((model.representation, rb), (model.output_module, rh)):
+        refp = dict(ref.named_parameters())
+        for k, p in mod.named_parameters():
+            assert p.grad is not None, k
+            want = refp[k].grad if refp[k].grad is not None else torch.zeros_like(refp[k])
+            worst[k] = float((p.grad.double().cpu().reshape(want.shape) - want).abs().max()) / max(float(want.abs().max()), 1e-6)
+    k = max(worst, key=worst.get)
+    out.update(n_params=len(worst), max_rel_err=worst[k], worst=k)
+    return out
+
+
+def check_full_training(device="cuda", steps=12):
+    """training the WHOLE model with the HIP forward + backward and torch's Adam (hamgnn_amd.training.training_step): teacher-student
+    targets on a small crystal, the loss falls"""
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    from hamgnn_amd.training import training_step
+    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False)
+    head = lambda: HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, soc_switch=False,
+                                     calculate_sparsity=False, zero_point_shift=False)
+    torch.manual_seed(11)
+    teacher = Model(HamGNNConvE3(cfg), head()).to(device)
+    torch.manual_seed(12)
+    model = Model(HamGNNConvE3(cfg), head()).to(device)
+    g = S.add_random_targets(S.random_cell(6, [14, 8, 6, 1], seed=2, density=0.004), 19, seed=2).to(device)
+    with torch.no_grad():
+        target = teacher(g)["hamiltonian"].clone()
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    losses = []
+    for _ in range(steps):
+        losses.append(float(training_step(model, g, metric="mse", target=target)["loss"]))
+        opt.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    return {"first": losses[0], "last": losses[-1], "losses": losses}
+
+
 def check_conv_message_backward(device="cuda", n_atoms=10, seed=2):
     """the ConvBlockE3 message chain on a periodic cell:  agg = scatter_receiver(MessagePack(x[sender], x[receiver], f))  -- gradient of
     sum(agg * G) with respect to the NODE rows x and the edge rows f: receiver gather fused into the adjoint launch, the two node

@@ -128,6 +128,26 @@ def test_message_pack_weight_gradients_default_irreps():
     assert r["max_rel_err"] < G.TOL
 
 
+@pytest.mark.parametrize("legacy,metric", [(False, "mse"), (True, "mae")])
+def test_full_model_backward_vs_autograd(legacy, metric):
+    r = G.check_full_backward(legacy=legacy, metric=metric)
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
+
+
+def test_full_model_backward_default_irreps():
+    """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
+    r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
+
+
+def test_full_model_training_loss_falls():
+    r = G.check_full_training()
+    print(r)
+    assert r["last"] < 0.8 * r["first"] and all(b < a for a, b in zip(r["losses"], r["losses"][1:])), r
+
+
 def test_head_backward_vs_autograd():
     r = G.check_head_backward()
     print(r)

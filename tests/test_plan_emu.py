@@ -534,6 +534,49 @@ def test_message_pack_weight_gradients_vs_autograd(seed):
         assert float((got[k].reshape(want[k].shape) - want[k]).abs().max()) < 2e-6 * max(scale, 1e-3), (k, irr, sh)
 
 
+@pytest.mark.parametrize("seed", range(2))
+def test_embedding_tp_weight_and_input_gradients_vs_autograd(seed):
+    """the embedding tensor product (PairInteractionEmbeddingBlock.conv_tp, num_types x 0e input) through the same
+    materialisation programs: every parameter AND the input rows' gradient vs torch.autograd through the fp64 oracle"""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import backward_mp as BM
+    rng = np.random.default_rng(700 + seed)
+    T = int(rng.integers(3, 9))
+    lsh = 2 + seed
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    irr = "6x0e+5x1o+3x2e" + ("+2x3o" if lsh >= 3 else "")
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.RadialTensorProduct(f"{T}x0e", sh, irr, "8x0e", [16, 16])
+        E = 9
+        g_ = torch.Generator().manual_seed(seed)
+        x = torch.randn(E, T, generator=g_).requires_grad_()
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g_), dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g_)
+        G = torch.randn(E, P.Irreps(irr).dim, generator=g_)
+        (ref(x, shv, rbf) * G).sum().backward()
+        want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay, lin = P.PlanarLayout(irr), P.PlanarLayout([(T, 0, 1)])
+    D = emu.edge_wigner_all(n.numpy(), lsh)
+    grot = torch.from_numpy(emu.rotate_rows(lay.to_planar(G.numpy()), lay, D, lsh))
+    wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T), sh, irr)
+    run = lambda prog, srcs, hn, he: torch.from_numpy(emu.run_program(prog, [t.numpy() for t in srcs], (hn.numpy(), he.numpy())))
+    xp = torch.from_numpy(lin.to_planar(x.detach().numpy()))
+    got, gx = BM.tp_weight_grads(wg, run, [xp], grot, rbf, emu.SILU_CST, chunk=5, want_gx=True)
+    assert set(got) == set(want), sorted(set(got) ^ set(want))
+    for k in want:
+        scale = max(float(want[k].abs().max()), 1e-3)
+        assert float((got[k].reshape(want[k].shape) - want[k]).abs().max()) < 2e-6 * scale, k
+    assert float((gx[0][:, :T] - x.grad).abs().max()) < 2e-6 * max(float(x.grad.abs().max()), 1e-3)
+
+
 def _adjoint_case(irr, sh, lmax, lsh, seed, E=17, radial=(16, 16)):
     """oracle MessagePackBlock + torch.autograd: gradients of sum(out * G) with respect to the three inputs; and the emulator inputs"""
     import torch
