@@ -11,7 +11,7 @@ output.  Gradients come back in the reference's parameter names and flat e3nn la
   {node,edge}_weight_generator.layer*.weight  last layer: h^T g_s / sqrt(H) with g_s[e, row] = sum_c A B;  hidden layers: torch.autograd on
                                              the 64-wide MLP (two dense layers per edge; the radial basis rows are inputs, not parameters)
 
-Correct, not fast: 2 x ~70 KB of intermediates per edge and branch, processed in chunks of edges.  The fused weight-gradient kernel
+Correct, not fast: 2 x ~80 KB of intermediates per edge, processed in chunks of 65 536 edges (10 GB), ~20 small launches per row chunk.  The fused weight-gradient kernel
  replaces this."""
 from __future__ import annotations
 
@@ -25,9 +25,14 @@ from . import plan as P
 
 
 def _block(x: torch.Tensor, off: int, mulp: int, comps: Sequence[int], nch: int) -> torch.Tensor:
-    """planar rows -> [E, len(comps), nch]: channels 0..nch of the given components of the irrep block at `off`"""
-    idx = torch.as_tensor([off + a * mulp for a in comps], device=x.device)
-    return torch.stack([x[:, int(o):int(o) + nch] for o in idx.tolist()], 1)
+    """planar rows -> [E, len(comps), nch]: channels 0..nch of the given components of the irrep block at `off`.  The components of a
+    block are `mulp` floats apart: a contiguous ascending run of components is a VIEW (no launch), a descending one a flipped view."""
+    comps = list(comps)
+    lo, hi = min(comps), max(comps)
+    if comps == list(range(lo, hi + 1)) or comps == list(range(hi, lo - 1, -1)):
+        v = x[:, off + lo * mulp:off + (hi + 1) * mulp].unflatten(1, (hi - lo + 1, mulp))[:, :, :nch]
+        return v if comps[0] == lo else v.flip(1)
+    return torch.stack([x[:, off + a * mulp:off + a * mulp + nch] for a in comps], 1)
 
 
 def radial_mlp(rbf: torch.Tensor, layers: List[torch.Tensor], act_cst: float) -> torch.Tensor:
@@ -37,6 +42,28 @@ def radial_mlp(rbf: torch.Tensor, layers: List[torch.Tensor], act_cst: float) ->
     for W in layers:
         h = torch.nn.functional.silu(h @ (W / math.sqrt(W.shape[0]))) * act_cst
     return h
+
+
+def _chunk_consts(c, device, dtype):
+    """per row chunk, once per (TPWeightGrad, device): the index / coefficient tensors of its rows"""
+    key = (str(device), dtype)
+    d = c.get("_dev")
+    if d is not None and d[0] == key:
+        return d[1]
+    sp, r0, r1 = c["sp"], c["r0"], c["r1"]
+    meta = sp["meta"][r0:r1]
+    ch = sp["ch"][r0:r1]
+    mk, mi2 = sp["mk"], c["nsrc"] * sp["mi"]
+    # flat TP weight of row r (path pn, mid channel w), input channel u: woff[pn] + u mk + w;  row of the k-block of L: lrow
+    base = np.array([sp["woff"][m[0]] + m[1] for m in meta], dtype=np.int64)
+    tp_idx = base[:, None] + np.arange(mi2, dtype=np.int64)[None, :] * mk
+    out = dict(ch=torch.as_tensor(ch, device=device), cf=torch.as_tensor(sp["cf"][r0:r1].T.copy(), device=device, dtype=dtype),
+               ch_slice=slice(int(ch[0]), int(ch[-1]) + 1) if np.array_equal(ch, np.arange(ch[0], ch[0] + len(ch))) else None,
+               tp_idx=torch.as_tensor(tp_idx.reshape(-1), device=device),
+               cpath=torch.as_tensor([m[2] for m in meta], device=device, dtype=dtype)[:, None],
+               lrow=torch.as_tensor([m[3] for m in meta], device=device, dtype=torch.int64))
+    c["_dev"] = (key, out)
+    return out
 
 
 def weight_grads_from_rows(chunks, Arows: torch.Tensor, Brows: torch.Tensor, srcs: Sequence[torch.Tensor], g: torch.Tensor,
@@ -52,31 +79,29 @@ def weight_grads_from_rows(chunks, Arows: torch.Tensor, Brows: torch.Tensor, src
         n, mm, li, lk, mk, k, i = r1 - r0, sp["mm"], sp["li"], sp["lk"], sp["mk"], sp["k"], sp["i"]
         nc = 2 * mm + 1
         cols = [lk - mm + cc for cc in range(nc)]
+        K = _chunk_consts(c, Arows.device, Arows.dtype)
         A = _block(Arows, c["out_off"], c["out_mulp"], cols, n)                    # [E, nc, n]
         B = _block(Brows, c["out_off"], c["out_mulp"], cols, n)
-        ch = torch.as_tensor(sp["ch"][r0:r1], device=A.device)
-        s = S[c["branch"]][:, ch]                                                  # [E, n]
-        gs_all[c["branch"]][:, ch] = (A * B).sum(1)
+        chs = K["ch_slice"] if K["ch_slice"] is not None else K["ch"]
+        s = S[c["branch"]][:, chs]                                                 # [E, n]
+        gs_all[c["branch"]][:, chs] = (A * B).sum(1)
         Gk = _block(g, gl.off[k], gl.mulp[k], cols, mk)                            # [E, nc, mk]
         gL = torch.einsum("ecn,ecw->nw", A * s[:, None, :], Gk)                    # rows x mul_k
-        cf = torch.as_tensor(sp["cf"][r0:r1].T.copy(), device=A.device, dtype=A.dtype)   # [nc, n]
-        T1 = B * s[:, None, :] * cf[None]
+        T1 = B * s[:, None, :] * K["cf"][None]
         lay = c["lay"]
         comps = [(li + mm - cc) if sp["par"] else (li - mm + cc) for cc in range(nc)]
         X = torch.cat([_block(srcs[sl], lay.off[i], lay.mulp[i], comps, sp["mi"]) for sl in c["srcs"]], 2)    # [E, nc, nsrc * mi]
         gW = torch.einsum("ecn,ecu->nu", T1, X)                                    # rows x (nsrc mul_i)
         if gx is not None:
-            Wr = torch.as_tensor(sp["W"][r0:r1], device=A.device, dtype=A.dtype)   # [n, nsrc * mi], path normalisation included
+            Wr = torch.as_tensor(sp["W"][r0:r1], device=T1.device, dtype=T1.dtype)   # [n, nsrc * mi], path normalisation included
             GX = torch.einsum("ecn,nu->ecu", T1, Wr)
             for q, sl in enumerate(c["srcs"]):
                 for cc, a in enumerate(comps):
                     o = lay.off[i] + a * lay.mulp[i]
                     gx[sl][:, o:o + sp["mi"]] += GX[:, cc, q * sp["mi"]:(q + 1) * sp["mi"]]
         name = c["branch"]
-        for r in range(n):
-            pn, w, cpath, lrow = sp["meta"][r0 + r]
-            acc[f"{name}_tp"][(pn, sp["woff"][pn], X.shape[2], mk)][:, w] += cpath * gW[r]
-            acc[f"{name}_L"][k][lrow] += gL[r]
+        acc[f"{name}_tp"].index_add_(0, K["tp_idx"], (gW * K["cpath"]).reshape(-1))
+        acc[f"{name}_L"][k].index_add_(0, K["lrow"], gL)
 
 
 class TPWeightGrad:
@@ -88,20 +113,24 @@ class TPWeightGrad:
         self.irreps_out = P.Irreps(irreps_out)
         self.branches = branches
         self.H = int(branches[0]["w3"].shape[0])
+        self.irreps_sh = P.Irreps(irreps_sh)
         self.progA, self.progB, self.chunks = P.build_tp_wgrad_programs(branches, irreps_sh, irreps_out, self.H)
+
+    def adopt_constants(self, old: "TPWeightGrad"):
+        """after a weight update: the per-chunk index / coefficient tensors already on the device depend on the irreps only -- take them
+        over from the previous instance instead of re-uploading ~2 000 small arrays per block and step"""
+        if old is None or len(old.chunks) != len(self.chunks):
+            return self
+        for c, o in zip(self.chunks, old.chunks):
+            if "_dev" in o and (c["branch"], c["r0"], c["r1"], c["sp"]["i"], c["sp"]["k"]) == (o["branch"], o["r0"], o["r1"], o["sp"]["i"], o["sp"]["k"]):
+                c["_dev"] = o["_dev"]
+        return self
 
     def new_acc(self, device, dtype):
         acc = {}
         for b in self.branches:
             name = b["name"]
-            tp = {}
-            for c in self.chunks:
-                if c["branch"] != name:
-                    continue
-                sp = c["sp"]
-                for (pn, w, cpath, lrow) in sp["meta"][c["r0"]:c["r1"]]:
-                    tp.setdefault((pn, sp["woff"][pn], c["nsrc"] * sp["mi"], sp["mk"]), None)
-            acc[f"{name}_tp"] = {key: torch.zeros(key[2], key[3], device=device, dtype=dtype) for key in tp}
+            acc[f"{name}_tp"] = torch.zeros(self.sd[b["keys"]["tp"]].size, device=device, dtype=dtype)      # the reference's flat layout
             acc[f"{name}_L"] = {}
             for c in self.chunks:
                 if c["branch"] == name and c["sp"]["k"] not in acc[f"{name}_L"]:
@@ -114,10 +143,7 @@ class TPWeightGrad:
         out = {}
         for b in self.branches:
             name, keys = b["name"], b["keys"]
-            gtp = torch.zeros(self.sd[keys["tp"]].size, device=dev, dtype=dt)
-            for (pn, woff, mi2, mk), G in acc[f"{name}_tp"].items():
-                gtp[woff:woff + mi2 * mk] = G.reshape(-1)
-            out[keys["tp"]] = gtp
+            out[keys["tp"]] = acc[f"{name}_tp"]
             Ls_flat = torch.as_tensor(self.sd[keys["ls"]], device=dev, dtype=dt)
             gLs = torch.zeros_like(Ls_flat)
             if keys["lo"] is not None:
@@ -150,7 +176,7 @@ class MessagePackWeightGrad(TPWeightGrad):
         super().__init__(sd, P.message_pack_wgrad_branches(sd, irreps_node, irreps_edge), irreps_sh, irreps_out)
 
 
-def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor], g, rbf, act_cst: float, chunk: int = 16384, want_gx: bool = False):
+def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor], g, rbf, act_cst: float, chunk: int = 65536, want_gx: bool = False):
     """run_program(prog, sources, h_node, h_edge) -> rows [E_chunk, out_dim] (the HIP kernels on the GPU, the emulator in the CPU suite).
     srcs: planar edge-frame input rows of the block by source slot; g: gradient of its output rows (edge frame); rbf: radial basis rows.
     Returns the parameter gradients ({reference name: flat gradient}) -- and, with want_gx, the gradients of the source rows."""
@@ -198,6 +224,6 @@ def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor],
     return (out, gx) if want_gx else out
 
 
-def block_weight_grads(wg: MessagePackWeightGrad, run_program, xs, xd, f, g, rbf, act_cst: float, chunk: int = 16384) -> Dict[str, torch.Tensor]:
+def block_weight_grads(wg: MessagePackWeightGrad, run_program, xs, xd, f, g, rbf, act_cst: float, chunk: int = 65536) -> Dict[str, torch.Tensor]:
     """MessagePackBlock: sources = (sender rows, receiver rows, edge rows), all planar in the edge frame"""
     return tp_weight_grads(wg, run_program, [xs, xd, f], g, rbf, act_cst, chunk)

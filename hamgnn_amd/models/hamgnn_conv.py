@@ -228,7 +228,7 @@ class HamGNNConvE3(_BackboneBase):
         return rep
 
     # ------------------------------------------------------------------------------------------------------------ backward
-    def backward(self, data, rep, g_node, g_edge_rot, chunk: int = 16384):
+    def backward(self, data, rep, g_node, g_edge_rot, chunk: int = 65536):
         """Gradients of EVERY backbone parameter for the gradients of the representation the forward returned: g_node [N, Dp] (planar node
         rows) and g_edge_rot [E, Dp] (planar edge rows in the edge frame) -- what HamGNNPlusPlusOut.backward hands back.  `rep` must come
         from forward(data, save_for_backward=True).  Chains the block-level backwards (all on the HIP kernels + library GEMMs):

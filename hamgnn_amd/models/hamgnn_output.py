@@ -141,6 +141,16 @@ class HamGNNPlusPlusOut(nn.Module):
             out += [a, b]
         return torch.cat(out, 0)
 
+    @staticmethod
+    def _split_by_crystal(data, H, edge_counts):
+        """inverse of _cat_by_crystal: rows in the result's per-crystal [on-site; off-site] order -> (all on-site rows, all off-site rows)"""
+        if edge_counts is None or edge_counts.numel() <= 1:
+            N = data.z.shape[0]
+            return H[:N], H[N:]
+        sizes = [v for pair in zip(data.node_counts.tolist(), edge_counts.tolist()) for v in pair]
+        parts = torch.split(H, sizes)
+        return torch.cat(parts[0::2], 0), torch.cat(parts[1::2], 0)
+
     def _apply_zero_point_shift(self, data, H, edge_counts, soc):
         """hamgnn_output.py:3971-3981 / :3892-3913; targets as the reference prepares them (:2975-2978, :3617-3618)."""
         f32c = lambda t: t.contiguous().float()
@@ -204,14 +214,12 @@ class HamGNNPlusPlusOut(nn.Module):
         dev = data.z.device
         if self._compiled_for != dev:
             self.compile(dev)
-        if gget(data, "node_counts") is not None and int(gget(data, "node_counts").numel()) > 1:
-            raise NotImplementedError("head backward: single-crystal batches")
         geo = rep["_geometry"]
         node_pl, edge_rot = rep["_node_planar"], rep["_edge_planar_rot"]
-        inv, _ = self._global_inverse(data)
+        inv, edge_counts = self._global_inverse(data)
         z = data.z.contiguous()
         N, n = z.shape[0], self.nao_max
-        gH = grad_hamiltonian.contiguous().float()
+        gH_on, gH_off = (t.contiguous() for t in self._split_by_crystal(data, grad_hamiltonian.float(), edge_counts))
         if getattr(self, "_adj_tabs", None) is None:
             net = self.onsite_hamiltonian_network
             glay = P.PlanarLayout(net.girr)
@@ -221,8 +229,8 @@ class HamGNNPlusPlusOut(nn.Module):
                 torch.from_numpy(P.rotate_table(glay)).to(dev), int(st.shape[0]))
         sid, pT, iT, vT, scat, rot_g, ncoef = self._adj_tabs
         # mask . symmetrise is self-adjoint (the orbital mask of an edge equals the transposed mask of its inverse edge)
-        g_on = ops.ham_finish(gH[:N], None, None, self._mask, z, None, None, n, 1.0, self.symmetrize)
-        g_off = ops.ham_finish(gH[N:], inv, None, self._mask, z, geo.src, geo.dst, n, 1.0, self.symmetrize)
+        g_on = ops.ham_finish(gH_on, None, None, self._mask, z, None, None, n, 1.0, self.symmetrize)
+        g_off = ops.ham_finish(gH_off, inv, None, self._mask, z, geo.src, geo.dst, n, 1.0, self.symmetrize)
         gc_on = ops.from_planar(ops.ham_merge(g_on, None, sid, pT, iT, vT, ncoef), scat)
         gc_off = ops.rotate_gather(ops.from_planar(ops.ham_merge(g_off, None, sid, pT, iT, vT, ncoef), scat), None, geo, rot_g)
         g_node, gw_on = self.onsite_hamiltonian_network.backward(node_pl, gc_on)

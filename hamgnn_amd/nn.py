@@ -194,7 +194,7 @@ class MessagePackBlock(nn.Module):
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
         self._dp_adj = None                                    # the data-gradient program is packed from the same weights
-        self._wgrad = None
+        self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
         if self.lite_mode:
             prog = P.build_message_pack_program_lite(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
             if skip_weight is not None:                        # PairInteractionBlock skip o3.Linear: must come AFTER the combine post-op
@@ -279,7 +279,7 @@ class MessagePackBlock(nn.Module):
                 self._dp_plain = self._dp
         return self._dp_plain
 
-    def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 16384, gather=None):
+    def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 65536, gather=None):
         """gradients of every parameter of this block for the output gradient `grad_out` (frame and `gather` as in backward_data), first
         version (hamgnn_amd/backward_mp.py): two materialisation programs on the fused kernels + library GEMMs over the edges.
         node_s / node_d: planar NODE rows gathered by sender / receiver as in run_nodes; f_rot: planar edge rows (edge frame).
@@ -290,6 +290,7 @@ class MessagePackBlock(nn.Module):
         dev = grad_out.device
         if getattr(self, "_wgrad", None) is None:
             wg = BM.MessagePackWeightGrad(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
+            wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
             self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
         wg, dpA, dpB = self._wgrad
         xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)
@@ -473,9 +474,9 @@ class PairInteractionEmbeddingBlock(nn.Module):
         self._dp = ops.DeviceProgram(P.build_embedding_program(_np_sd(self.conv_tp), T, self.irreps_sh, self.irreps_out, self.lite_mode), device)
         self._h = self.conv_tp.weight_generator.hidden_layers(device)
         self._Tp = P.PlanarLayout([(T, 0, 1)]).dim
-        self._wgrad = None
+        self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
 
-    def backward(self, z, geo: ops.Geometry, g_f, chunk: int = 16384):
+    def backward(self, z, geo: ops.Geometry, g_f, chunk: int = 65536):
         """gradients of every parameter of the block for the gradient g_f of the edge rows it returned (planar, edge frame):
         conv_tp.* through the materialisation programs (backward_mp), linear_up_src / linear_up_dst from the gradient of the
         num_types scalar input channels (an index_add over the element of the sender / receiver)."""
@@ -486,6 +487,7 @@ class PairInteractionEmbeddingBlock(nn.Module):
         if self._wgrad is None:
             sd = _np_sd(self.conv_tp)
             wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T), self.irreps_sh, self.irreps_out)
+            wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
             self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
         wg, dpA, dpB = self._wgrad
         x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, T, self._Tp)

@@ -613,16 +613,17 @@ def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps
                     cpath = math.sqrt((2 * lk + 1) / (mi2 * irreps_sh[j][0]))
                     W = tp_weight[woff[n]:woff[n] + mi2 * mk].reshape(mi2, mk).astype(np.float64) * cpath
                 cf = np.array([coef_c[lk + m] for m in range(-mm, mm + 1)])
-                for w in range(mmid):
-                    rows_W.append(W[:, w])
-                    rows_ch.append(choff[n] + w)
-                    rows_cf.append(cf)
-                    rows_L.append(L[choff[n] - ch0 + w])
-                    rows_meta.append((n, w, 0.0 if uvu else cpath, choff[n] - ch0 + w))
+                l0 = choff[n] - ch0                            # the path's mmid rows, all at once (this runs on every weight repack)
+                rows_W.append(W.T)
+                rows_ch.append(choff[n] + np.arange(mmid))
+                rows_cf.append(np.broadcast_to(cf, (mmid, nc)))
+                rows_L.append(L[l0:l0 + mmid])
+                rows_meta += zip([n] * mmid, range(mmid), [0.0 if uvu else cpath] * mmid, range(l0, l0 + mmid))
                 flops += (0.0 if uvu else 2.0 * mi2 * mk * nc) + 2.0 * mmid * nc      # + 2 H mmid + 2 mmid mk nc, added by the caller (H)
                 flops += 2.0 * mmid * mk * nc
-            yield dict(i=i, k=k, mi=mi2 // nsrc, li=li, mk=mk, lk=lk, mm=mm, par=par, W=np.array(rows_W), ch=np.array(rows_ch),
-                       cf=np.array(rows_cf), L=np.array(rows_L), flops=flops, nmid=len(rows_ch), meta=rows_meta,
+            ch = np.concatenate(rows_ch)
+            yield dict(i=i, k=k, mi=mi2 // nsrc, li=li, mk=mk, lk=lk, mm=mm, par=par, W=np.concatenate(rows_W), ch=ch,
+                       cf=np.concatenate(rows_cf), L=np.concatenate(rows_L), flops=flops, nmid=len(ch), meta=rows_meta,
                        woff={n: woff[n] for n in plist}, lin=lin_off[k], lo_off=lo_off[k], pk=pk, pi=pi)
 
 
@@ -1702,3 +1703,34 @@ def sym_contraction_tables(irreps_hidden: Irreps, correlation: int = 2):
         return arr
     return dict(ell_off=ell_off, out_off=np.asarray(out_off, np.int32), ptr1=np.asarray(ptr1, np.int32), ent1=pack(ent1, 2),
                 ptr2=np.asarray(ptr2, np.int32), ent2=pack(ent2, 3), K1=K1, K2=K2, num_ell=num_ell, nout=len(out_off))
+
+
+# ------------------------------------------------------------------------------------------------ host-side cost of a (re)pack
+# The builders above run on every weight repack (each optimiser step of hamgnn_amd.training).  Their dense algebra is hundreds of TINY
+# matrix products (L @ Lo per output irrep, fragment packing); a multi-threaded BLAS spends ~30 ms of thread hand-off on each of them
+# (measured: 13 products of [832, 64] x [64, 64]: 424 ms on 8 OpenBLAS threads, 1.8 ms on one).  Run the builders single-threaded.
+try:
+    from threadpoolctl import ThreadpoolController as _TPC
+except ImportError:                                            # no threadpoolctl: correct, only slower
+    _TPC = None
+_tpc = None
+
+
+def _single_thread_blas(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        global _tpc
+        if _TPC is None:
+            return fn(*a, **k)
+        if _tpc is None:
+            _tpc = _TPC()
+        with _tpc.limit(limits=1, user_api="blas"):
+            return fn(*a, **k)
+    return wrapped
+
+
+for _name, _fn in list(globals().items()):
+    if callable(_fn) and _name.startswith(("build_", "choose_merge_groups", "ham_linear_mats", "linear_tables", "is_schedule")):
+        globals()[_name] = _single_thread_blas(_fn)

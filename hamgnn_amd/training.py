@@ -60,10 +60,30 @@ def head_training_step(model, batch, metric: str = "mae", target: Optional[torch
     return {"loss": loss, "representation": rep, "g_node_planar": g_node, "g_edge_planar_rot": g_edge}
 
 
+def allreduce_gradients(model, average: bool = True):
+    """Data-parallel training (the reference's DDP, hamgnn/main.py:318-321: every rank steps the same model on its own batches): average the
+    `.grad` of all parameters over the ranks of the default process group -- ONE flat bucket, i.e. one RCCL all-reduce per step (xGMI
+    rings are per-link bound: few large collectives; the whole set-A model is 30 MB of fp32 gradients).  A no-op without an initialised
+    process group or with one rank.  Parameters without a gradient on this rank contribute zeros."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    params = [p for p in model.parameters() if p.requires_grad]
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    o = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[o:o + n].reshape(p.shape).to(p.dtype)
+        o += n
+
+
 def _invalidate(module):
     """the packed weight fragments / adjoint tables are stale once the optimiser has stepped: repacked on the next forward"""
     for m in module.modules():
-        for attr in ("_dp", "_dp_adj", "_wgrad", "_adj_tabs"):
+        for attr in ("_dp", "_dp_adj", "_adj_tabs"):             # (`_wgrad` is handed over by the blocks' compile(): its device constants are reused)
             if hasattr(m, attr):
                 setattr(m, attr, None)
         if hasattr(m, "_compiled_for"):
@@ -96,5 +116,6 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
             p = params[k]
             g = g.reshape(p.shape).to(p.dtype)
             p.grad = g.clone() if p.grad is None else p.grad + g
+    allreduce_gradients(model)                                 # data-parallel runs: mean over ranks, one collective; else a no-op
     _invalidate(model)
     return {"loss": loss, "hamiltonian": H}

@@ -283,7 +283,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -305,10 +305,12 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
         rh = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=False)
     finally:
         torch.set_default_dtype(prev)
-    g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004), nao, seed=seed)
+    from hamgnn_amd.data import collate
+    gs = [S.add_random_targets(S.random_cell(n_atoms + c, [14, 8, 6, 1], seed=seed + c, density=0.004), nao, seed=seed + c) for c in range(crystals)]
+    g = gs[0] if crystals == 1 else collate(gs)
     g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
     Href = rh(g64, rb(g64))["hamiltonian"]
-    target = torch.cat([g64["Hon"], g64["Hoff"]], 0).reshape(Href.shape)
+    target = 0.1 * torch.randn(Href.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
     diff = Href - target
     loss_ref = (diff * diff).mean() if metric == "mse" else diff.abs().mean()
     loss_ref.backward()

@@ -135,6 +135,13 @@ def test_full_model_backward_vs_autograd(legacy, metric):
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
 
 
+def test_full_model_backward_batch_of_crystals():
+    """three crystals of different sizes in one batch (per-crystal [on-site; off-site] row order of the result, batch-global inverse edges)"""
+    r = G.check_full_backward(n_atoms=3, seed=8, crystals=3, metric="mae")
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
+
+
 def test_full_model_backward_default_irreps():
     """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
     r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)

@@ -129,3 +129,35 @@ def test_sharded_forward_matches_unsharded_gloo(tmp_path):
     tmp = str(tmp_path / "err.txt")
     mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
     assert float(open(tmp).read()) < 1e-10
+
+
+def _worker_grads(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from hamgnn_amd.training import allreduce_gradients
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    params = list(m.parameters())
+    for i, p in enumerate(params):
+        p.grad = None if (rank == 1 and i == 2) else torch.full_like(p, float(rank + 1) * (i + 1))
+    allreduce_gradients(m)
+    want = [(i + 1) * 1.5 for i in range(len(params))]
+    want[2] = 3 * 1.0 / 2                                       # rank 1 had no gradient for parameter 2: zeros
+    ok = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(params, want))
+    with open(os.path.join(tmp, f"g{rank}.json"), "w") as f:
+        json.dump({"ok": bool(ok)}, f)
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_gloo(tmp_path):
+    """data-parallel training: the mean of the ranks' gradients in one flat bucket (hamgnn_amd.training.allreduce_gradients)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tmp = str(tmp_path)
+    mp.spawn(_worker_grads, args=(2, port, tmp), nprocs=2, join=True)
+    for r in range(2):
+        assert json.load(open(os.path.join(tmp, f"g{r}.json")))["ok"]

@@ -525,8 +525,13 @@ def test_message_pack_weight_gradients_vs_autograd(seed):
     lm = max(lmax, lsh)
     D = emu.edge_wigner_all(n.numpy(), lm)
     rot = lambda t: torch.from_numpy(emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, lm))
-    wg = BM.MessagePackWeightGrad(sd, irr, irr, sh, irr)
     run = lambda prog, srcs, hn, he: torch.from_numpy(emu.run_program(prog, [t.numpy() for t in srcs], (hn.numpy(), he.numpy())))
+    # a previous instance with OTHER weights (the state after an optimiser step): its per-chunk constants are taken over
+    rs = np.random.default_rng(seed)
+    wg0 = BM.MessagePackWeightGrad({k: v + 0.1 * rs.normal(size=v.shape) for k, v in sd.items()}, irr, irr, sh, irr)
+    BM.block_weight_grads(wg0, run, rot(src), rot(dst), rot(ef), rot(G), rbf, emu.SILU_CST, chunk=7)
+    wg = BM.MessagePackWeightGrad(sd, irr, irr, sh, irr).adopt_constants(wg0)
+    assert all("_dev" in c for c in wg.chunks)
     got = BM.block_weight_grads(wg, run, rot(src), rot(dst), rot(ef), rot(G), rbf, emu.SILU_CST, chunk=7)
     assert set(got) == set(want), sorted(set(got) ^ set(want))
     for k in want:
