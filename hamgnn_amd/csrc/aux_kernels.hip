@@ -172,6 +172,34 @@ extern "C" int hg_edge_geometry(const float* pos, const int64_t* edge_index, con
     return hg_check_launch("hg_edge_geometry");
 }
 
+// ------------------------------------------------------------------------------------------------ other radial bases
+// rbf_func = "gaussian" (hamgnn/models/hamgnn_conv.py:123-125 -> GaussianSmearing, utils/basis_functions.py:211-224, start 0, stop =
+// cutoff, no inner cutoff) x the cosine cutoff of RadialBasisEdgeEncoding (nn/embeddings.py:93-97), from the edge lengths that
+// hg_edge_geometry wrote.  fp64 internally, rounded once.  `offsets` = the reference's fp32 centres (torch.linspace is not n * delta
+// to the last bit), `delta` = offsets[1] - offsets[0] in fp32 (the reference's width): both from the host, so both sides use the same numbers.
+__global__ void gaussian_basis_kernel(const float* __restrict__ len, int64_t E, float cutoff, const float* __restrict__ offsets, float delta, int R,
+                                      float* __restrict__ rbf) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * R) return;
+    const int64_t e = idx / R;
+    const int n = (int)(idx - e * R);
+    const double r = (double)len[e];
+    const double off = (double)offsets[n];
+    const double fc = (r < (double)cutoff) ? 0.5 * (cos(M_PI * r / (double)cutoff) + 1.0) : 0.0;
+    const double d = r - off;
+    rbf[idx] = (float)(exp(-0.5 * d * d / ((double)delta * (double)delta)) * fc);
+}
+
+extern "C" int hg_radial_basis(const float* edge_len, int64_t E, int kind, float cutoff, const float* offsets, float delta, int num_radial, float* rbf,
+                               void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (E <= 0) return 0;
+    if (kind != 1) return hg_fail(-2, "hg_radial_basis: kind 1 (gaussian) is built; bessel comes from hg_edge_geometry");
+    if (num_radial < 2) return hg_fail(-2, "hg_radial_basis: num_radial >= 2");
+    gaussian_basis_kernel<<<dim3((unsigned)((E * num_radial + 255) / 256)), 256, 0, (hipStream_t)stream>>>(edge_len, E, cutoff, offsets, delta, num_radial, rbf);
+    return hg_check_launch("hg_radial_basis");
+}
+
 // ------------------------------------------------------------------------------------------------ radial hidden layers
 // 64 edges per workgroup; activations and the current layer's weights in LDS; each thread owns a 4 (edges) x 4 (outputs)
 // register tile per pass.  act(x) = cst * silu(x) (e3nn normalize2mom(silu)); weights already carry 1/sqrt(h_in).

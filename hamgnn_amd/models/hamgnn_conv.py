@@ -78,8 +78,13 @@ class _BackboneBase(nn.Module):
         self.irreps_node_features = Irreps(g("irreps_node_features"))
         self.radial_MLP = list(g("radial_MLP"))
         self.legacy_edge_update = bool(g("legacy_edge_update", False))
-        if str(g("rbf_func", "bessel")).lower() != "bessel":
-            raise ValueError(f"Unsupported radial basis function on the MI355X path: {g('rbf_func')}")
+        self.rbf_func = str(g("rbf_func", "bessel")).lower()
+        if self.rbf_func in ("exp-gaussian", "exp-bernstein", "bernstein"):
+            # these reference bases hold float64 buffers and return a float64 edge embedding (utils/basis_functions.py:16-105): they only
+            # run under `precision: 64`, which is not built here
+            raise NotImplementedError(f"rbf_func={self.rbf_func!r} needs the reference's fp64 mode (precision: 64), which is not built")
+        if self.rbf_func not in ("bessel", "gaussian"):
+            raise ValueError(f"Unsupported radial basis function: {g('rbf_func')}")      # hamgnn_conv.py:139-141
         self.lite_mode = bool(g("lite_mode", False))
         for k in ("use_kan", "build_internal_graph"):
             if g(k, False):
@@ -130,7 +135,7 @@ class _BackboneBase(nn.Module):
         z = data.z.contiguous()
         topo = get_topology(data)                              # index plumbing + validation: once per graph object (host-syncs)
         topo.check_num_types(self.num_types)                   # z >= num_types would index past the embedding tables on the device
-        geo = ops.Geometry(data.pos, data.edge_index, data.nbr_shift, self.cutoff, self.num_radial, self.lmax, self._jtab)
+        geo = ops.Geometry(data.pos, data.edge_index, data.nbr_shift, self.cutoff, self.num_radial, self.lmax, self._jtab, self.rbf_func)
         # hidden activations of ALL radial weight generators of this forward (embedding + two per message block) in one launch
         ops.prefill_radial_hidden(geo, self._radial_generators(), float(P.ACT_CONSTS[P.ACT_SILU]))
         Dp = self.layout.dim

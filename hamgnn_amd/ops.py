@@ -151,7 +151,7 @@ def wig_offsets(lmax):
 class Geometry:
     """rbf, packed per-edge Wigner matrices and the receiver CSR of one graph batch (computed once per forward)."""
 
-    def __init__(self, pos, edge_index, nbr_shift, cutoff, num_radial, lmax, jtab_dev):
+    def __init__(self, pos, edge_index, nbr_shift, cutoff, num_radial, lmax, jtab_dev, rbf_func: str = "bessel"):
         _require_gpu(pos)
         if pos.device.index != torch.cuda.current_device():
             raise RuntimeError(f"hamgnn_amd: make {pos.device} the current device (torch.cuda.set_device) before the forward")
@@ -168,8 +168,26 @@ class Geometry:
         nbr_shift = nbr_shift.contiguous().float()
         check(lib().hg_edge_geometry(ptr(pos), ptr(self.edge_index), ptr(nbr_shift), i64(E), f32(cutoff), i32(num_radial), i32(lmax),
                                      ptr(jtab_dev), ptr(self.rbf), ptr(self.wig), ptr(self.length), ptr(ang), _stream()), "hg_edge_geometry")
+        if rbf_func == "gaussian":                             # GaussianSmearing(0, cutoff, num_radial) x cosine cutoff, from the lengths
+            offs = _gaussian_offsets(float(cutoff), int(num_radial), dev)
+            delta = float((offs[2][1] - offs[2][0]).item())    # the reference's width: spacing of its fp32 linspace (host copy, no sync)
+            check(lib().hg_radial_basis(ptr(self.length), i64(E), i32(1), f32(cutoff), ptr(offs[1]), f32(delta), i32(num_radial), ptr(self.rbf),
+                                        _stream()), "hg_radial_basis")
+        elif rbf_func != "bessel":
+            raise ValueError(f"Unsupported radial basis function on the MI355X path: {rbf_func}")
         self.src = self.edge_index[0].contiguous()
         self.dst = self.edge_index[1].contiguous()
+
+
+_GAUSS_OFFS = {}
+
+
+def _gaussian_offsets(cutoff, num_radial, dev):
+    key = (cutoff, num_radial, str(dev))
+    if key not in _GAUSS_OFFS:
+        host = torch.linspace(0.0, cutoff, num_radial, dtype=torch.float32)
+        _GAUSS_OFFS[key] = (key, host.to(dev), host)
+    return _GAUSS_OFFS[key]
 
 
 @_on_tensor_device

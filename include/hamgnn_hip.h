@@ -33,6 +33,14 @@ int hg_edge_geometry(const float* pos, const int64_t* edge_index, const float* n
                      int num_radial, int lmax_wig, const float* jtab, float* rbf, float* wig, float* edge_len,
                      float* ang_scratch, void* stream);
 
+/* rbf_func = "gaussian": GaussianSmearing(0, cutoff, num_radial)  hamgnn/utils/basis_functions.py:211-224 (hamgnn_conv.py:123-125)
+ * x CosineCutoff (nn/embeddings.py:93-97), from the edge lengths hg_edge_geometry wrote:
+ * rbf[e][n] = exp(-0.5 (r - offsets[n])^2 / delta^2) * 0.5 (cos(pi r / rc) + 1) [r < rc].  kind: 1 = gaussian (the only one; Bessel
+ * comes from hg_edge_geometry; the reference's exp-gaussian / exp-bernstein / bernstein bases return float64 and need `precision: 64`).
+ * offsets: DEVICE [num_radial] fp32 centres = torch.linspace(0, rc, num_radial); delta = offsets[1] - offsets[0] in fp32.          */
+int hg_radial_basis(const float* edge_len, int64_t E, int kind, float cutoff, const float* offsets, float delta, int num_radial,
+                    float* rbf, void* stream);
+
 /* e3nn FullyConnectedNet hidden layers (all but the last) of a radial weight generator:
  * hamgnn/nn/message_passing.py:173-189, 218, 223 ; tensor_products.py:152-168, 183.
  * h = act(... act(rbf @ W0) @ W1 ...), act(x) = act_cst * silu(x); W_k [dims[k], dims[k+1]] already scaled by 1/sqrt(h_in). */

@@ -634,6 +634,24 @@ def main():
     _save("backbone_charge_doping", weights={k: v for k, v in ref5.state_dict().items() if k in dict(mine5.named_parameters())},
           graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
           outputs=outs5, meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg5["HamGNN_pre"]).items()}))))
+    # backbone with rbf_func="gaussian" (hamgnn_conv.py:123-125 GaussianSmearing; utils/basis_functions.py:211-224).  The other bases
+    # (exp-gaussian, exp-bernstein, bernstein) carry float64 buffers and return a float64 edge embedding: usable with `precision: 64` only
+    print("gaussian radial basis")
+    cfg7 = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, rbf_func="gaussian").items() if k != 'radius_scale'}))
+    torch.manual_seed(19)
+    ref7, mine7 = ref_conv.HamGNNConvE3(cfg7), R.HamGNNConvE3(dict(cfg7))
+    assert type(ref7.radial_basis_functions).__name__ == "GaussianSmearing"
+    res = mine7.load_state_dict(ref7.state_dict(), strict=False)
+    assert not (set(res.missing_keys) & set(dict(mine7.named_parameters()))), res.missing_keys
+    g7 = Graph(G)
+    r7, o7 = ref7(g7), mine7(G)
+    _check(R.edge_geometry(G.pos, G.edge_index, G.nbr_shift, sh_irreps, 8.0, 8, rbf_func="gaussian")[1], g7["edge_embedding"], "gaussian edge rbf", tol=1e-6)
+    _check(o7["node_attr"], r7["node_attr"], "backbone gaussian rbf node_attr", tol=1e-6)
+    _check(o7["edge_attr"], r7["edge_attr"], "backbone gaussian rbf edge_attr", tol=1e-6)
+    _save("backbone_gaussian_rbf", weights={k: v for k, v in ref7.state_dict().items() if k in dict(mine7.named_parameters())},
+          graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
+          outputs=dict(node_attr=r7["node_attr"], edge_attr=r7["edge_attr"], edge_embedding=g7["edge_embedding"]),
+          meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg7["HamGNN_pre"]).items()}))))
     # ---- 8. attention backbone: HamGNNTransformer (hamgnn_transformer.py:36-250; nn/attention.py:91-360) -----------------
     # third-party pieces absent here, restated from their published definitions (oracle/hamgnn_ref.py): torch_geometric.utils.softmax
     # (PyG 2.x: max-shifted exp / (sum + 1e-16) per target node) and e3nn.math.soft_unit_step (exp(-1/x) for x > 0)

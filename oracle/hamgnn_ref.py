@@ -241,15 +241,24 @@ class _Holder(nn.Module):
     pass
 
 
-def edge_geometry(pos, edge_index, nbr_shift, irreps_sh, cutoff, num_radial, sh_normalize=True, sh_normalization="component"):
-    """edge_attrs (SH of v[[1,2,0]]), edge_embedding (Bessel * cosine cutoff), lengths.  j = row 0, i = row 1."""
+def edge_geometry(pos, edge_index, nbr_shift, irreps_sh, cutoff, num_radial, sh_normalize=True, sh_normalization="component", rbf_func="bessel"):
+    """edge_attrs (SH of v[[1,2,0]]), edge_embedding (radial basis * cosine cutoff: hamgnn/nn/embeddings.py:73-100), lengths.
+    j = row 0, i = row 1.  rbf_func: "bessel" (utils/basis_functions.py:177-208) or "gaussian" (GaussianSmearing, :211-224, start 0,
+    stop = cutoff; the width comes from the fp32 linspace, as the reference's `.item()` of a float32 tensor)."""
     j, i = edge_index
     vec = (pos[i] + nbr_shift) - pos[j]
     unit = torch.nn.functional.normalize(vec, dim=-1)
     sh = e3.spherical_harmonics(Irreps(irreps_sh).ls, unit[:, [1, 2, 0]], sh_normalize, sh_normalization)
     r = vec.norm(dim=-1)
-    freqs = torch.arange(1, num_radial + 1, dtype=pos.dtype) * math.pi / cutoff
-    rbf = torch.sin(r[:, None] * freqs[None, :]) / r[:, None]
+    if rbf_func == "bessel":
+        freqs = torch.arange(1, num_radial + 1, dtype=pos.dtype) * math.pi / cutoff
+        rbf = torch.sin(r[:, None] * freqs[None, :]) / r[:, None]
+    elif rbf_func == "gaussian":
+        offset32 = torch.linspace(0.0, cutoff, num_radial, dtype=torch.float32)
+        coeff = -0.5 / (offset32[1] - offset32[0]).item() ** 2
+        rbf = torch.exp(coeff * (r[:, None] - offset32.to(pos.dtype)[None, :]) ** 2)
+    else:
+        raise NotImplementedError(rbf_func)
     fc = 0.5 * (torch.cos(r * math.pi / cutoff) + 1.0) * (r < cutoff).to(pos.dtype)
     return sh, rbf * fc[:, None], r
 
@@ -308,7 +317,8 @@ class HamGNNConvE3(nn.Module):
         self.irreps_node_features = Irreps(c["irreps_node_features"])
         self.legacy_edge_update = c.get("legacy_edge_update", False)
         self.lite_mode = c.get("lite_mode", False)
-        assert c.get("rbf_func", "bessel").lower() == "bessel" and not c.get("use_kan", False)
+        self.rbf_func = c.get("rbf_func", "bessel").lower()
+        assert self.rbf_func in ("bessel", "gaussian") and not c.get("use_kan", False)
         assert not c.get("build_internal_graph", False)
         self.use_corr_prod = bool(c.get("use_corr_prod", False))
         mlp = list(c["radial_MLP"])
@@ -340,7 +350,7 @@ class HamGNNConvE3(nn.Module):
             one_hot = self.atomic_embedding(data, one_hot)
         g["node_attrs"] = g["node_features"] = one_hot
         sh, rbf, r = edge_geometry(data.pos.to(dtype), data.edge_index, data.nbr_shift.to(dtype), self.irreps_edge_sh, self.cutoff,
-                                   self.num_radial, self.sh_normalize, self.sh_normalization)
+                                   self.num_radial, self.sh_normalize, self.sh_normalization, self.rbf_func)
         g["edge_attrs"], g["edge_embedding"] = sh, rbf
         self.pair_embedding(g)
         g["node_features"] = self.chemical_embedding.linear(g["node_features"])
@@ -449,7 +459,8 @@ class HamGNNTransformer(nn.Module):
         self.sh_normalization = c.get("edge_sh_normalization", "component")
         self.sh_normalize = c.get("edge_sh_normalize", True)
         self.irreps_node_features = Irreps(c["irreps_node_features"])
-        assert c.get("rbf_func", "bessel").lower() == "bessel" and not c.get("use_kan", False) and not c.get("build_internal_graph", False)
+        self.rbf_func = c.get("rbf_func", "bessel").lower()
+        assert self.rbf_func in ("bessel", "gaussian") and not c.get("use_kan", False) and not c.get("build_internal_graph", False)
         mlp = list(c["radial_MLP"])
         attrs = Irreps([(self.num_types, (0, 1))])
         emb = Irreps([(self.num_radial, (0, 1))])
@@ -475,7 +486,7 @@ class HamGNNTransformer(nn.Module):
             one_hot = self.atomic_embedding(data, one_hot)
         g["node_attrs"] = g["node_features"] = one_hot
         sh, rbf, r = edge_geometry(data.pos.to(dtype), data.edge_index, data.nbr_shift.to(dtype), self.irreps_edge_sh, self.cutoff,
-                                   self.num_radial, self.sh_normalize, self.sh_normalization)
+                                   self.num_radial, self.sh_normalize, self.sh_normalization, self.rbf_func)
         g["edge_attrs"], g["edge_embedding"], g["edge_lengths"] = sh, rbf, r
         self.pair_embedding(g)
         g["node_features"] = self.chemical_embedding.linear(g["node_features"])

@@ -60,6 +60,13 @@ def test_backbone_use_corr_prod_golden():
     assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
 
 
+def test_backbone_gaussian_rbf_golden():
+    """rbf_func="gaussian": hg_radial_basis (GaussianSmearing x cosine cutoff) vs the reference fixture"""
+    r = G.check_backbone(name="backbone_gaussian_rbf")
+    print(r)
+    assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
+
+
 def test_backbone_charge_doping_golden():
     r = G.check_charge_doping()
     print(r)
