@@ -129,6 +129,9 @@ class _BackboneBase(nn.Module):
     def _embed(self, data):
         """-> (z, topology, geometry, node [N, Dp] planar, f [E, Dp] planar in the edge frame)"""
         dev = data.pos.device
+        if getattr(self, "_pending_refresh", False):           # an optimiser stepped since the last forward (training.weights_changed)
+            self._pending_refresh = False
+            self.refresh_weights()
         if self._compiled_for != dev:
             self.compile(dev)
         N = data.z.shape[0]
@@ -206,6 +209,23 @@ class HamGNNConvE3(_BackboneBase):
                 c.compile(dev)
         self._compile_common(dev)
         return self
+
+    def refresh_weights(self):
+        """after an optimiser step (hamgnn_amd.training): bring the uploaded programs up to date WITHOUT the host planner for the
+        message blocks (device-side repack, hamgnn_amd/repack.py); the small Linear / embedding tables are rebuilt on the host (< 1 ms each)"""
+        dev = self._compiled_for
+        if dev is None:
+            return
+        if self.lite_mode or self.use_corr_prod:
+            self._compiled_for = None                          # full recompile on the next forward
+            return
+        for conv, pair in zip(self.convolutions, self.pair_interactions):
+            conv.residual.compile(dev)
+            conv.skip_linear.compile(dev)
+            if not conv.conv_tp.refresh():
+                conv.conv_tp.compile(dev, unrotate=True)
+            pair.refresh(dev)
+        self._compile_common(dev)
 
     def forward(self, data, save_for_backward: bool = False):
         """save_for_backward: keep the layer inputs (node rows, edge rows, aggregated messages) on the result (`_tape`) for `backward`"""

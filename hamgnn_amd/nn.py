@@ -193,6 +193,8 @@ class MessagePackBlock(nn.Module):
 
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
+        self._compile_args = (bool(unrotate), skip_weight is not None, None)      # (unrotate, fused skip Linear, merge groups)
+        self._packers = getattr(self, "_packers", None) or {}                     # structural: survive recompiles of the same block
         self._dp_adj = None                                    # the data-gradient program is packed from the same weights
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
         if self.lite_mode:
@@ -214,6 +216,7 @@ class MessagePackBlock(nn.Module):
                         prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate,
                                                             skip_weight, merge_groups=groups)
                         self._dp = ops.DeviceProgram(prog, device, schedule="is")
+                        self._compile_args = (bool(unrotate), skip_weight is not None, groups)
                         # launches with fewer 16-edge tiles than workgroup slots run the PLAIN program split over one workgroup per output
                         # segment: merging trades parts (9 instead of 13 for set-A) for MFMAs, the wrong trade when latency is all there is
                         # (Si 2-atom cell: 0.113 -> 0.110 ms per launch); built on first use
@@ -227,6 +230,51 @@ class MessagePackBlock(nn.Module):
         # HG_MP_KERNEL = seg | is | auto: which schedule of the fused MessagePackBlock program runs (default: see DESIGN.md section 5)
         self._dp = ops.DeviceProgram(prog, device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
         return self
+
+    # ---- training: repack the weights of the uploaded programs on the device after an optimiser step (hamgnn_amd/repack.py)
+    def refresh(self, skip=None) -> bool:
+        """skip: the flat weight of the fused skip o3.Linear (device tensor) if the block was compiled with one.  Returns False when
+        there is nothing to refresh in place (never compiled, lite_mode): the caller compiles instead."""
+        from . import repack as RP
+        if self.lite_mode or self._dp is None or getattr(self, "_compile_args", None) is None:
+            return False
+        unrotate, has_skip, groups = self._compile_args
+        if has_skip != (skip is not None):
+            return False
+        params = {k: v.detach() for k, v in self.state_dict().items()}
+        shapes = {k: tuple(v.shape) for k, v in params.items()}
+        last = {n: sorted(k for k in params if k.startswith(f"{n}_weight_generator.layer") and k.endswith(".weight"))[-1] for n in ("node", "edge")}
+        lays = RP.mp_branch_layouts(self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
+        args = (self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
+        nskip = int(skip.numel()) if skip is not None else 0
+        src = RP.mp_sources(lambda k: params[k].double().reshape(-1), last, lays, None if skip is None else skip.detach().double().reshape(-1), lib=torch)
+
+        def packer(tag, fn, ns):
+            if tag not in self._packers:
+                sizes = RP.mp_source_sizes(shapes, last, ns)
+                self._packers[tag] = RP.AffinePack(lambda d: fn(RP.mp_probe_state_dict(d, shapes, last, lays, self.irreps_out), d.get("skip")), sizes)
+            return self._packers[tag]
+
+        def update(dp, tag, fn, ns):
+            blob = packer(tag, fn, ns).apply({k: v for k, v in src.items() if ns or k != "skip"})
+            assert blob.numel() == dp.weights.numel(), (tag, blob.numel(), dp.weights.numel())
+            dp.weights.copy_(blob)
+
+        fwd = lambda g_: (lambda d, sk: P.build_message_pack_program(d, *args, unrotate, sk, **({"merge_groups": g_} if g_ else {})).weights)
+        update(self._dp, ("fwd", unrotate, has_skip, bool(groups)), fwd(groups), nskip)
+        if getattr(self, "_dp_plain", None) is not None and self._dp_plain is not self._dp:
+            update(self._dp_plain, ("fwd", unrotate, has_skip, False), fwd(None), nskip)
+        if getattr(self, "_dp_adj", None) is not None:
+            update(self._dp_adj, ("adj",), lambda d, sk: P.build_message_pack_adjoint_program(d, *args).weights, 0)
+        if getattr(self, "_wgrad", None) is not None:
+            wg, dpA, dpB = self._wgrad
+            update(dpA, ("wgA",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[0].weights, 0)
+            update(dpB, ("wgB",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[1].weights, 0)
+            wg.sd = {k: v.cpu().double().numpy() for k, v in params.items()}     # the radial MLP / Ls / Lo values that finish() reads
+        dev = self._dp.weights.device
+        self._hn = self.node_weight_generator.hidden_layers(dev)
+        self._he = self.edge_weight_generator.hidden_layers(dev)
+        return True
 
     # ---- backward (SURVEY 8f-3): data gradient as an adjoint program, weight gradients through backward_mp
     def compile_adjoint(self, device):
@@ -438,6 +486,17 @@ class PairInteractionBlock(nn.Module):
             self.conv_tp.compile(device, unrotate=False, skip_weight=skip)   # skip o3.Linear fused as extra items
             if self.use_skip_connections:
                 self.skip_linear._dp_adj = None                # its forward is fused above; only the backward uses the module's own tables
+
+
+    def refresh(self, device):
+        """after an optimiser step: the two linear_up tables (host, < 1 ms) and the message block's programs (device repack)"""
+        self.linear_up_src.compile(device)
+        self.linear_up_tar.compile(device)
+        skip = self.skip_linear.weight if (self.use_skip_connections and not self.lite_mode) else None
+        if not self.conv_tp.refresh(skip=skip):
+            self.compile(device)
+        elif self.use_skip_connections:
+            self.skip_linear._dp_adj = None
 
 
 class _EmbTP(nn.Module):

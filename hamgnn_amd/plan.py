@@ -118,6 +118,20 @@ def tp_instructions(irreps1: Irreps, irreps2: Irreps, target: Irreps):
 # ------------------------------------------------------------------------------------------------ program container
 
 
+# dtype of the packed weight blob: float32 for the device; hamgnn_amd/repack.py probes the builders in float64 (probe_dtype)
+_WEIGHT_DTYPE = [np.float32]
+
+
+class probe_dtype:
+    """with probe_dtype(): the builders keep their weight blobs in float64 (used to discover blob = const + coef * source[idx])"""
+
+    def __enter__(self):
+        _WEIGHT_DTYPE[0] = np.float64
+
+    def __exit__(self, *a):
+        _WEIGHT_DTYPE[0] = np.float32
+
+
 @dataclass
 class Program:
     out_layout: PlanarLayout
@@ -142,13 +156,13 @@ class Program:
     seg_key: Dict[int, int] = field(default_factory=dict)
 
     def add_weights(self, arr: np.ndarray) -> int:
-        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        arr = np.ascontiguousarray(arr, dtype=_WEIGHT_DTYPE[0]).reshape(-1)
         off = self._woff
         self.chunks.append(arr)
         self._woff += arr.size
         pad = (-self._woff) % 4                       # keep 16-byte alignment of every operand block
         if pad:
-            self.chunks.append(np.zeros(pad, np.float32))
+            self.chunks.append(np.zeros(pad, _WEIGHT_DTYPE[0]))
             self._woff += pad
         return off
 
@@ -534,6 +548,27 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
 
 
 # ------------------------------------------------------------------------------------------------ builders
+
+
+def linear_scaler_layout(nsrc: int, in_layout: PlanarLayout, irreps_sh, irreps_out):
+    """[(k, offset into LinearScaleWithWeights.linear_out.weight, fan_in, offset into the trailing o3.Linear(out -> out) weight, mul_k)]
+    of a weighted ("uvw") tensor-product branch, in the order the flat linear_scaler weight stores its blocks"""
+    irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
+    irr_in = Irreps([(m * nsrc, l, p) for m, l, p in in_layout.irreps])
+    by_k: Dict[int, List[int]] = {}
+    for n, (i, j, k, slot) in enumerate(tp_instructions(irr_in, irreps_sh, irreps_out)):
+        by_k.setdefault(k, []).append(n)
+    lo_off, o = {}, 0
+    for k, (mk, lk, pk) in enumerate(irreps_out):
+        lo_off[k] = o
+        o += mk * mk
+    out, lo = [], 0
+    for k in sorted(by_k, key=lambda k: ((irreps_out[k][1], irreps_out[k][2]), k)):
+        mk = irreps_out[k][0]
+        fan = mk * len(by_k[k])
+        out.append((k, lo, fan, lo_off[k], mk))
+        lo += fan * mk
+    return out
 
 
 def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps_out: Irreps, tp_weight, w3: np.ndarray,

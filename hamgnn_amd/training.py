@@ -60,6 +60,17 @@ def head_training_step(model, batch, metric: str = "mae", target: Optional[torch
     return {"loss": loss, "representation": rep, "g_node_planar": g_node, "g_edge_planar_rot": g_edge}
 
 
+def weights_changed(model):
+    """call after the optimiser stepped (training_step does it for the step that follows): the backbone's message blocks repack their
+    weights on the device, everything else is dropped and repacked by the next forward"""
+    rep = getattr(model, "representation", None)
+    if rep is not None and hasattr(rep, "refresh_weights"):
+        _invalidate(model.output_module)
+        rep._pending_refresh = True                            # the optimiser steps AFTER training_step returns: refresh at the next forward
+    else:
+        _invalidate(model)
+
+
 def allreduce_gradients(model, average: bool = True):
     """Data-parallel training (the reference's DDP, hamgnn/main.py:318-321: every rank steps the same model on its own batches): average the
     `.grad` of all parameters over the ranks of the default process group -- ONE flat bucket, i.e. one RCCL all-reduce per step (xGMI
@@ -117,5 +128,5 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
             g = g.reshape(p.shape).to(p.dtype)
             p.grad = g.clone() if p.grad is None else p.grad + g
     allreduce_gradients(model)                                 # data-parallel runs: mean over ranks, one collective; else a no-op
-    _invalidate(model)
+    weights_changed(model)
     return {"loss": loss, "hamiltonian": H}

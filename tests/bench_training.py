@@ -51,7 +51,7 @@ def main():
             for k, v in grads.items():
                 params[k].grad = v.reshape(params[k].shape)
         opt.step(); opt.zero_grad()
-        T._invalidate(model)
+        T.weights_changed(model)
         sync(); t4 = time.time()
         print(f"step {step}: N {g.num_nodes} E {g.num_edges} loss {float(loss):.5f} | forward (incl. repack) {1e3 * (t1 - t0):.0f} ms, head backward "
               f"{1e3 * (t2 - t1):.0f} ms, backbone backward {1e3 * (t3 - t2):.0f} ms, optimiser {1e3 * (t4 - t3):.0f} ms", flush=True)

@@ -362,6 +362,42 @@ def check_full_training(device="cuda", steps=12):
     return {"first": losses[0], "last": losses[-1], "losses": losses}
 
 
+def check_refresh_equals_recompile(device="cuda", legacy=False):
+    """training: after an optimiser step the message blocks repack their weights on the device (hamgnn_amd/repack.py).  A model that
+    took a step, had ALL parameters perturbed and was refreshed must give the loss and every gradient of a freshly compiled model with
+    the same parameters."""
+    import copy
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    from hamgnn_amd.training import training_step
+    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
+    mk = lambda: Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
+                                                          soc_switch=False, calculate_sparsity=False, zero_point_shift=False))
+    torch.manual_seed(21)
+    a = mk().to(device)
+    g = S.add_random_targets(S.random_cell(6, [14, 8, 6, 1], seed=2, density=0.004), 19, seed=2).to(device)
+    target = 0.1 * torch.randn(g.num_nodes + g.num_edges, 19 * 19, generator=torch.Generator().manual_seed(3)).to(device)
+    training_step(a, g, metric="mse", target=target)            # builds every program (forward, adjoint, weight-gradient), marks them stale
+    gen = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for p in a.parameters():                                # "the optimiser step"
+            p.add_(0.05 * torch.randn(p.shape, generator=gen).to(device))
+            p.grad = None
+    b = mk().to(device)
+    b.load_state_dict(copy.deepcopy(a.state_dict()))
+    ra = training_step(a, g, metric="mse", target=target)
+    refreshed = sum(len(m._packers) for m in a.modules() if hasattr(m, "_packers"))
+    rb = training_step(b, g, metric="mse", target=target)
+    torch.cuda.synchronize()
+    pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
+    worst = max(float((pa[k].grad - pb[k].grad).abs().max()) / max(float(pb[k].grad.abs().max()), 1e-6) for k in pb)
+    return {"packers": refreshed, "loss_rel_diff": abs(float(ra["loss"]) - float(rb["loss"])) / abs(float(rb["loss"])), "grad_max_rel_diff": worst}
+
+
 def check_conv_message_backward(device="cuda", n_atoms=10, seed=2):
     """the ConvBlockE3 message chain on a periodic cell:  agg = scatter_receiver(MessagePack(x[sender], x[receiver], f))  -- gradient of
     sum(agg * G) with respect to the NODE rows x and the edge rows f: receiver gather fused into the adjoint launch, the two node

@@ -156,6 +156,13 @@ def test_full_model_backward_default_irreps():
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_device_repack_equals_recompile(legacy):
+    r = G.check_refresh_equals_recompile(legacy=legacy)
+    print(r)
+    assert r["packers"] >= 8 and r["loss_rel_diff"] < 1e-6 and r["grad_max_rel_diff"] < 1e-5, r
+
+
 def test_full_model_training_loss_falls():
     r = G.check_full_training()
     print(r)

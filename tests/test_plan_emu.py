@@ -690,3 +690,45 @@ def test_gate_tables_compact_match_the_oracle_gate(irreps):
         v = av[:, sc & 0x3fffffff] if sc & 0x40000000 else xp[:, sc]
         out[:, p] = v * (av[:, gc] if gc >= 0 else 1.0)
     assert rel(lay_out.from_planar(out), want) < 1e-6          # ACT_CONSTS are float32 roundings of the Monte-Carlo constants
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_device_repack_map_equals_host_builder(seed):
+    """hamgnn_amd/repack.py: the affine map (const, coef, idx) discovered by probing the host builders reproduces the packed weight blob
+    of every program of a MessagePackBlock (forward plain / merged with a fused skip Linear, data-gradient adjoint, the two weight-
+    gradient materialisation programs) for fresh random weights"""
+    import torch
+    from hamgnn_amd import nn as hnn, repack as RP
+    rng = np.random.default_rng(900 + seed)
+    irr = _random_irreps(rng, int(rng.integers(1, 4)))
+    if "0e" not in irr:
+        irr = "5x0e+" + irr
+    lsh = int(rng.integers(1, 4))
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    torch.manual_seed(seed)
+    blk = hnn.MessagePackBlock(irr, irr, sh, irr, 8, [16, 16])
+    sd = hnn._np_sd(blk)
+    shapes = {k: v.shape for k, v in sd.items()}
+    last = {n: P._last_layer(sd, f"{n}_weight_generator")[0][-1] for n in ("node", "edge")}
+    lays = RP.mp_branch_layouts(irr, irr, sh, irr)
+    nskip = hnn.E3Linear(irr, irr).weight.numel()
+    groups = P.choose_merge_groups(blk.irreps_node, blk.irreps_edge, blk.irreps_sh, blk.irreps_out, 16)
+    args = (blk.irreps_node, blk.irreps_edge, blk.irreps_sh, blk.irreps_out)
+    builders = {
+        "plain": (lambda d, skip: P.build_message_pack_program(d, *args, True, None).weights, 0),
+        "merged+skip": (lambda d, skip: P.build_message_pack_program(d, *args, False, skip, merge_groups=groups).weights, nskip),
+        "adjoint": (lambda d, skip: P.build_message_pack_adjoint_program(d, *args).weights, 0),
+        "wgradA": (lambda d, skip: P.build_message_pack_wgrad_programs(d, *args)[0].weights, 0),
+        "wgradB": (lambda d, skip: P.build_message_pack_wgrad_programs(d, *args)[1].weights, 0),
+    }
+    sd2 = {k: rng.normal(size=v.shape) for k, v in sd.items()}             # "after the optimiser step"
+    skip2 = rng.normal(size=nskip)
+    for name, (fn, ns) in builders.items():
+        sizes = RP.mp_source_sizes(shapes, last, ns)
+        pk = RP.AffinePack(lambda src, fn=fn: fn(RP.mp_probe_state_dict(src, shapes, last, lays, irr), src.get("skip")), sizes)
+        want = np.asarray(fn(sd2, skip2 if ns else None), dtype=np.float32)
+        got = pk.apply_np(RP.mp_sources(lambda k: sd2[k].reshape(-1), last, lays, skip2 if ns else None)).astype(np.float32)
+        assert want.shape == got.shape, name
+        assert np.abs(want - got).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
+        t = pk.apply({k: torch.from_numpy(np.asarray(v)) for k, v in RP.mp_sources(lambda k: sd2[k].reshape(-1), last, lays, skip2 if ns else None).items()})
+        assert np.abs(t.numpy() - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
