@@ -44,64 +44,111 @@ def radial_mlp(rbf: torch.Tensor, layers: List[torch.Tensor], act_cst: float) ->
     return h
 
 
-def _chunk_consts(c, device, dtype):
-    """per row chunk, once per (TPWeightGrad, device): the index / coefficient tensors of its rows"""
-    key = (str(device), dtype)
-    d = c.get("_dev")
-    if d is not None and d[0] == key:
-        return d[1]
-    sp, r0, r1 = c["sp"], c["r0"], c["r1"]
-    meta = sp["meta"][r0:r1]
-    ch = sp["ch"][r0:r1]
-    mk, mi2 = sp["mk"], c["nsrc"] * sp["mi"]
-    # flat TP weight of row r (path pn, mid channel w), input channel u: woff[pn] + u mk + w;  row of the k-block of L: lrow
-    base = np.array([sp["woff"][m[0]] + m[1] for m in meta], dtype=np.int64)
-    tp_idx = base[:, None] + np.arange(mi2, dtype=np.int64)[None, :] * mk
-    out = dict(ch=torch.as_tensor(ch, device=device), cf=torch.as_tensor(sp["cf"][r0:r1].T.copy(), device=device, dtype=dtype),
-               ch_slice=slice(int(ch[0]), int(ch[-1]) + 1) if np.array_equal(ch, np.arange(ch[0], ch[0] + len(ch))) else None,
-               tp_idx=torch.as_tensor(tp_idx.reshape(-1), device=device),
-               cpath=torch.as_tensor([m[2] for m in meta], device=device, dtype=dtype)[:, None],
-               lrow=torch.as_tensor([m[3] for m in meta], device=device, dtype=torch.int64))
-    c["_dev"] = (key, out)
+def _build_groups(wg, device, dtype):
+    """Row chunks of like shape are processed TOGETHER (one gather / product / einsum / index_add per group instead of per chunk: the
+    per-chunk version was launch-bound, ~20 small launches x 340 chunks per block).  Group key = (branch, columns, parity);
+    inside a group the rows n, the output multiplicity mk and the input channels U are padded to the group maximum.
+    Padding costs no masks: padded rows read the spare ZERO column of S (scale 0), padded outputs land in the spare slot of the
+    accumulators.  Everything here depends on the irreps only, not on the weights."""
+    gl = P.PlanarLayout(wg.irreps_out)
+    slot_base = {}                                             # column offset of each source slot in the concatenated source rows
+    groups = {}
+    for j, c in enumerate(wg.chunks):
+        sp = c["sp"]
+        n, U = c["r1"] - c["r0"], c["nsrc"] * sp["mi"]
+        groups.setdefault((c["branch"], 2 * sp["mm"] + 1, sp["par"]), []).append(j)
+    out = []
+    for (branch, nc, par), js in groups.items():
+        b = next(b for b in wg.branches if b["name"] == branch)
+        lay = b["lay"]
+        nch = int(np.asarray(b["w3"]).shape[1])
+        tp_size = int(wg.sd[b["keys"]["tp"]].size)
+        ls_size = int(wg.sd[b["keys"]["ls"]].size)
+        # bound the gathered tensors to ~48 KB per edge
+        cs = [wg.chunks[j] for j in js]
+        idx_of = {id(c): j for j, c in zip(js, cs)}
+        per = max(nc * max(max(c["r1"] - c["r0"] for c in cs), max(c["nsrc"] * c["sp"]["mi"] for c in cs)), 1)
+        gmax = max(1, 12288 // per)
+        for g0 in range(0, len(cs), gmax):
+            part = cs[g0:g0 + gmax]
+            G = len(part)
+            N = max(c["r1"] - c["r0"] for c in part)
+            MK = max(c["sp"]["mk"] for c in part)
+            U = max(c["nsrc"] * c["sp"]["mi"] for c in part)
+            a_idx = np.zeros((G, nc, N), np.int64)
+            g_idx = np.zeros((G, nc, MK), np.int64)
+            x_idx = np.zeros((G, nc, U), np.int64)
+            ch_idx = np.full((G, N), nch, np.int64)            # spare column of S / gs_all
+            cf = np.zeros((G, nc, N))
+            cpath = np.zeros((G, N, 1))
+            tp_idx = np.full((G, N, U), tp_size, np.int64)     # spare slot of the flat TP-weight accumulator
+            l_idx = np.full((G, N, MK), ls_size, np.int64)     # spare slot of the flat L' accumulator
+            for q, c in enumerate(part):
+                sp, r0, r1 = c["sp"], c["r0"], c["r1"]
+                n, mm, li, lk, mk, k, i, mi = r1 - r0, sp["mm"], sp["li"], sp["lk"], sp["mk"], sp["k"], sp["i"], sp["mi"]
+                u = c["nsrc"] * mi
+                cols = np.array([lk - mm + cc for cc in range(nc)])
+                comps = np.array([(li + mm - cc) if par else (li - mm + cc) for cc in range(nc)])
+                a_idx[q, :, :n] = c["out_off"] + cols[:, None] * c["out_mulp"] + np.arange(n)[None, :]
+                g_idx[q, :, :mk] = gl.off[k] + cols[:, None] * gl.mulp[k] + np.arange(mk)[None, :]
+                for t, sl in enumerate(c["srcs"]):
+                    base = slot_base.setdefault((branch, sl), len([1 for key in slot_base if key[0] == branch]) * lay.dim)
+                    x_idx[q, :, t * mi:(t + 1) * mi] = base + lay.off[i] + comps[:, None] * lay.mulp[i] + np.arange(mi)[None, :]
+                ch_idx[q, :n] = sp["ch"][r0:r1]
+                cf[q, :, :n] = sp["cf"][r0:r1].T
+                meta = sp["meta"][r0:r1]
+                cpath[q, :n, 0] = [m[2] for m in meta]
+                base_tp = np.array([sp["woff"][m[0]] + m[1] for m in meta], dtype=np.int64)
+                tp_idx[q, :n, :u] = base_tp[:, None] + np.arange(u, dtype=np.int64)[None, :] * mk
+                off, fan = sp["lin"]
+                lrow = np.array([m[3] for m in meta], dtype=np.int64)
+                l_idx[q, :n, :mk] = off + lrow[:, None] * mk + np.arange(mk, dtype=np.int64)[None, :]
+            t_ = lambda arr, dt=None: torch.as_tensor(arr, device=device, dtype=dt)
+            out.append(dict(branch=branch, srcs=sorted({sl for c in part for sl in c["srcs"]}, key=lambda sl: slot_base[(branch, sl)]),
+                            a_idx=t_(a_idx), g_idx=t_(g_idx), x_idx=t_(x_idx), ch_idx=t_(ch_idx), cf=t_(cf, dtype), cpath=t_(cpath, dtype),
+                            tp_idx=t_(tp_idx.reshape(-1)), l_idx=t_(l_idx.reshape(-1)), cidx=[idx_of[id(c)] for c in part], shape=(G, N, U)))
     return out
 
 
-def weight_grads_from_rows(chunks, Arows: torch.Tensor, Brows: torch.Tensor, srcs: Sequence[torch.Tensor], g: torch.Tensor,
-                           S: Dict[str, torch.Tensor], acc: Dict[str, torch.Tensor], gs_all: Dict[str, torch.Tensor], irreps_out, gx=None):
-    """One chunk of edges.  chunks: plan.build_tp_wgrad_programs' bookkeeping; Arows / Brows: the two materialised row tensors
-    [E, out_dim]; srcs = the program's source rows by slot (message pack: x_sender, x_receiver, f), planar, edge frame; g: gradient rows
-    (edge frame, planar(irreps_out)); S[branch] = h @ W3 / sqrt(H) [E, n_channels]; acc: running sums of the per-path / per-k gradients
-    (updated in place); gs_all[branch]: [E, n_channels] (filled); gx: optional list of zero tensors like srcs -- the gradient with
-    respect to the source rows is accumulated there (W^T (s cf B); used for the 0e-only embedding input, where it is a few columns)."""
-    gl = P.PlanarLayout(irreps_out)
-    for c in chunks:
-        sp, r0, r1 = c["sp"], c["r0"], c["r1"]
-        n, mm, li, lk, mk, k, i = r1 - r0, sp["mm"], sp["li"], sp["lk"], sp["mk"], sp["k"], sp["i"]
-        nc = 2 * mm + 1
-        cols = [lk - mm + cc for cc in range(nc)]
-        K = _chunk_consts(c, Arows.device, Arows.dtype)
-        A = _block(Arows, c["out_off"], c["out_mulp"], cols, n)                    # [E, nc, n]
-        B = _block(Brows, c["out_off"], c["out_mulp"], cols, n)
-        chs = K["ch_slice"] if K["ch_slice"] is not None else K["ch"]
-        s = S[c["branch"]][:, chs]                                                 # [E, n]
-        gs_all[c["branch"]][:, chs] = (A * B).sum(1)
-        Gk = _block(g, gl.off[k], gl.mulp[k], cols, mk)                            # [E, nc, mk]
-        gL = torch.einsum("ecn,ecw->nw", A * s[:, None, :], Gk)                    # rows x mul_k
-        T1 = B * s[:, None, :] * K["cf"][None]
-        lay = c["lay"]
-        comps = [(li + mm - cc) if sp["par"] else (li - mm + cc) for cc in range(nc)]
-        X = torch.cat([_block(srcs[sl], lay.off[i], lay.mulp[i], comps, sp["mi"]) for sl in c["srcs"]], 2)    # [E, nc, nsrc * mi]
-        gW = torch.einsum("ecn,ecu->nu", T1, X)                                    # rows x (nsrc mul_i)
+def weight_grads_from_rows(wg, Arows: torch.Tensor, Brows: torch.Tensor, srcs: Sequence[torch.Tensor], g: torch.Tensor,
+                           S: Dict[str, torch.Tensor], acc: Dict[str, torch.Tensor], gs_all: Dict[str, torch.Tensor], gx=None):
+    """One chunk of edges.  Arows / Brows: the two materialised row tensors [E, out_dim]; srcs = the program's source rows by slot
+    (message pack: x_sender, x_receiver, f), planar, edge frame; g: gradient rows (edge frame, planar(irreps_out)); S[branch] =
+    [h @ W3 / sqrt(H), 0] [E, n_channels + 1]; acc: flat running sums of the TP-weight and L' gradients (+ one spare slot each, updated
+    in place); gs_all[branch]: [E, n_channels + 1] (filled); gx: optional list of zero tensors like srcs -- the gradient with respect to
+    the source rows is accumulated there (W^T (s cf B); used for the 0e-only embedding input, where it is a few columns)."""
+    if getattr(wg, "_groups", None) is None or wg._groups[0] != (str(Arows.device), Arows.dtype):
+        wg._groups = ((str(Arows.device), Arows.dtype), _build_groups(wg, Arows.device, Arows.dtype))
+    xcat = {}
+    for grp in wg._groups[1]:
+        name = grp["branch"]
+        if name not in xcat:
+            slots = sorted({sl for g_ in wg._groups[1] if g_["branch"] == name for sl in g_["srcs"]})
+            assert all(grp2["srcs"] == grp["srcs"] or grp2["branch"] != name for grp2 in wg._groups[1])
+            xcat[name] = (srcs[slots[0]] if len(slots) == 1 else torch.cat([srcs[sl] for sl in slots], 1), slots)
+        X = xcat[name][0][:, grp["x_idx"]]                                         # [E, G, nc, U]
+        A, B = Arows[:, grp["a_idx"]], Brows[:, grp["a_idx"]]                      # [E, G, nc, N]
+        s = S[name][:, grp["ch_idx"]]                                              # [E, G, N]  (0 on padded rows)
+        gs_all[name][:, grp["ch_idx"].reshape(-1)] = (A * B).sum(2).flatten(1)
+        Gk = g[:, grp["g_idx"]]                                                    # [E, G, nc, MK]
+        gL = torch.einsum("egcn,egcw->gnw", A * s[:, :, None, :], Gk)
+        T1 = B * s[:, :, None, :] * grp["cf"][None]
+        gW = torch.einsum("egcn,egcu->gnu", T1, X)
+        acc[f"{name}_tp"].index_add_(0, grp["tp_idx"], (gW * grp["cpath"]).reshape(-1))
+        acc[f"{name}_L"].index_add_(0, grp["l_idx"], gL.reshape(-1))
         if gx is not None:
-            Wr = torch.as_tensor(sp["W"][r0:r1], device=T1.device, dtype=T1.dtype)   # [n, nsrc * mi], path normalisation included
-            GX = torch.einsum("ecn,nu->ecu", T1, Wr)
-            for q, sl in enumerate(c["srcs"]):
-                for cc, a in enumerate(comps):
-                    o = lay.off[i] + a * lay.mulp[i]
-                    gx[sl][:, o:o + sp["mi"]] += GX[:, cc, q * sp["mi"]:(q + 1) * sp["mi"]]
-        name = c["branch"]
-        acc[f"{name}_tp"].index_add_(0, K["tp_idx"], (gW * K["cpath"]).reshape(-1))
-        acc[f"{name}_L"][k].index_add_(0, K["lrow"], gL)
+            Wg_np = np.zeros(grp["shape"])                                         # [G, N, U] from the CURRENT weights, path normalisation included
+            for q, j in enumerate(grp["cidx"]):
+                c = wg.chunks[j]
+                Wr = c["sp"]["W"][c["r0"]:c["r1"]]
+                Wg_np[q, :Wr.shape[0], :Wr.shape[1]] = Wr
+            Wg = torch.as_tensor(Wg_np, device=T1.device, dtype=T1.dtype)
+            GX = torch.einsum("egcn,gnu->egcu", T1, Wg).flatten(1)
+            lay_dim = xcat[name][0].shape[1] // len(xcat[name][1])
+            cols = grp["x_idx"].reshape(-1)
+            for t, sl in enumerate(xcat[name][1]):                                 # columns of slot t of the concatenated sources
+                sel = (cols >= t * lay_dim) & (cols < (t + 1) * lay_dim)
+                gx[sl].index_add_(1, cols[sel] - t * lay_dim, GX[:, sel])
 
 
 class TPWeightGrad:
@@ -116,26 +163,28 @@ class TPWeightGrad:
         self.irreps_sh = P.Irreps(irreps_sh)
         self.progA, self.progB, self.chunks = P.build_tp_wgrad_programs(branches, irreps_sh, irreps_out, self.H)
 
+    params_dev = None                                          # optional {name: device tensor}: the CURRENT parameters (training: no host round trip)
+
+    def param(self, key, device, dtype):
+        if self.params_dev is not None and key in self.params_dev:
+            return self.params_dev[key].detach().to(device=device, dtype=dtype)
+        return torch.as_tensor(self.sd[key], device=device, dtype=dtype)
+
     def adopt_constants(self, old: "TPWeightGrad"):
-        """after a weight update: the per-chunk index / coefficient tensors already on the device depend on the irreps only -- take them
-        over from the previous instance instead of re-uploading ~2 000 small arrays per block and step"""
-        if old is None or len(old.chunks) != len(self.chunks):
-            return self
-        for c, o in zip(self.chunks, old.chunks):
-            if "_dev" in o and (c["branch"], c["r0"], c["r1"], c["sp"]["i"], c["sp"]["k"]) == (o["branch"], o["r0"], o["r1"], o["sp"]["i"], o["sp"]["k"]):
-                c["_dev"] = o["_dev"]
+        """after a weight update: the grouped index / coefficient tensors already on the device depend on the irreps only -- take them
+        over from the previous instance instead of rebuilding and re-uploading them per block and step"""
+        sig = lambda w: [(c["branch"], c["r0"], c["r1"], c["sp"]["i"], c["sp"]["k"]) for c in w.chunks]
+        if old is not None and getattr(old, "_groups", None) is not None and sig(old) == sig(self):
+            self._groups = old._groups
+            self._groups_adopted = True
         return self
 
     def new_acc(self, device, dtype):
+        """flat accumulators in the reference's layouts (+ one spare slot that padded group entries write to)"""
         acc = {}
         for b in self.branches:
-            name = b["name"]
-            acc[f"{name}_tp"] = torch.zeros(self.sd[b["keys"]["tp"]].size, device=device, dtype=dtype)      # the reference's flat layout
-            acc[f"{name}_L"] = {}
-            for c in self.chunks:
-                if c["branch"] == name and c["sp"]["k"] not in acc[f"{name}_L"]:
-                    off, fan = c["sp"]["lin"]
-                    acc[f"{name}_L"][c["sp"]["k"]] = torch.zeros(fan, c["sp"]["mk"], device=device, dtype=dtype)
+            acc[f"{b['name']}_tp"] = torch.zeros(self.sd[b["keys"]["tp"]].size + 1, device=device, dtype=dtype)
+            acc[f"{b['name']}_L"] = torch.zeros(self.sd[b["keys"]["ls"]].size + 1, device=device, dtype=dtype)     # d / d L', linear_scaler's layout
         return acc
 
     def finish(self, acc, gW3: Dict[str, Dict[str, torch.Tensor]], dev, dt) -> Dict[str, torch.Tensor]:
@@ -143,11 +192,11 @@ class TPWeightGrad:
         out = {}
         for b in self.branches:
             name, keys = b["name"], b["keys"]
-            out[keys["tp"]] = acc[f"{name}_tp"]
-            Ls_flat = torch.as_tensor(self.sd[keys["ls"]], device=dev, dtype=dt)
+            out[keys["tp"]] = acc[f"{name}_tp"][:-1]
+            Ls_flat = self.param(keys["ls"], dev, dt).reshape(-1)
             gLs = torch.zeros_like(Ls_flat)
             if keys["lo"] is not None:
-                Lo_flat = torch.as_tensor(self.sd[keys["lo"]], device=dev, dtype=dt)
+                Lo_flat = self.param(keys["lo"], dev, dt).reshape(-1)
                 gLo = torch.zeros_like(Lo_flat)
             seen = set()
             for c in self.chunks:
@@ -156,7 +205,7 @@ class TPWeightGrad:
                     continue
                 seen.add(sp["k"])
                 (off, fan), lo_off, mk = sp["lin"], sp["lo_off"], sp["mk"]
-                gL = acc[f"{name}_L"][sp["k"]]                 # d / d (Ls / sqrt(fan) [@ Lo / sqrt(mk)])
+                gL = acc[f"{name}_L"][off:off + fan * mk].reshape(fan, mk)      # d / d (Ls / sqrt(fan) [@ Lo / sqrt(mk)])
                 if keys["lo"] is None:
                     gLs[off:off + fan * mk] = (gL / math.sqrt(fan)).reshape(-1)
                     continue
@@ -188,7 +237,7 @@ def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor],
     for b in wg.branches:
         pre = b["keys"]["gen"]
         gkeys[b["name"]] = sorted(k for k in sd if k.startswith(pre + ".layer") and k.endswith(".weight"))
-        gen[b["name"]] = [torch.as_tensor(sd[k], device=dev, dtype=dt).requires_grad_() for k in gkeys[b["name"]]]
+        gen[b["name"]] = [wg.param(k, dev, dt).clone().requires_grad_() for k in gkeys[b["name"]]]
     gW3 = {name: {} for name in gen}
     gh_hidden = {name: torch.zeros(E, H, device=dev, dtype=dt) for name in gen}
     gW3_last = {name: torch.zeros_like(gen[name][-1]) for name in gen}
@@ -198,15 +247,15 @@ def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor],
         n = sl.stop - sl.start
         with torch.no_grad():
             h = {name: radial_mlp(rbf[sl], [w.detach() for w in gen[name][:-1]], act_cst) for name in gen}
-            S = {name: h[name] @ (gen[name][-1].detach() / math.sqrt(H)) for name in gen}
+            S = {name: torch.nn.functional.pad(h[name] @ (gen[name][-1].detach() / math.sqrt(H)), (0, 1)) for name in gen}   # + the zero column
             ones = torch.zeros(n, wg.progA.hidden_pad, device=dev, dtype=dt)
             ones[:, 0] = 1.0
             part = [t[sl] for t in srcs]
             Arows = run_program(wg.progA, part, ones, ones)
             Brows = run_program(wg.progB, [g[sl]], ones, ones)
-            gs_all = {name: torch.zeros(n, gen[name][-1].shape[1], device=dev, dtype=dt) for name in gen}
-            weight_grads_from_rows(wg.chunks, Arows, Brows, part, g[sl], S, acc, gs_all, wg.irreps_out,
-                                   gx=None if gx is None else [t[sl] for t in gx])
+            gs_all = {name: torch.zeros(n, gen[name][-1].shape[1] + 1, device=dev, dtype=dt) for name in gen}
+            weight_grads_from_rows(wg, Arows, Brows, part, g[sl], S, acc, gs_all, gx=None if gx is None else [t[sl] for t in gx])
+            gs_all = {name: v[:, :-1] for name, v in gs_all.items()}
             for name in gen:
                 gW3_last[name] += h[name].t() @ gs_all[name] / math.sqrt(H)
                 gh_hidden[name][sl] = gs_all[name] @ (gen[name][-1].detach().t() / math.sqrt(H))

@@ -220,7 +220,8 @@ class HamGNNConvE3(_BackboneBase):
             self._compiled_for = None                          # full recompile on the next forward
             return
         for conv, pair in zip(self.convolutions, self.pair_interactions):
-            conv.residual.compile(dev)
+            conv.residual.linear1.compile(dev)                 # (not residual.compile: its gate tables are structural)
+            conv.residual.linear2.compile(dev)
             conv.skip_linear.compile(dev)
             if not conv.conv_tp.refresh():
                 conv.conv_tp.compile(dev, unrotate=True)

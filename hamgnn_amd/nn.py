@@ -270,7 +270,7 @@ class MessagePackBlock(nn.Module):
             wg, dpA, dpB = self._wgrad
             update(dpA, ("wgA",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[0].weights, 0)
             update(dpB, ("wgB",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[1].weights, 0)
-            wg.sd = {k: v.cpu().double().numpy() for k, v in params.items()}     # the radial MLP / Ls / Lo values that finish() reads
+            wg.params_dev = params                             # the radial MLP / Ls / Lo values that the reductions read: straight from the device
         dev = self._dp.weights.device
         self._hn = self.node_weight_generator.hidden_layers(dev)
         self._he = self.edge_weight_generator.hidden_layers(dev)
@@ -339,6 +339,7 @@ class MessagePackBlock(nn.Module):
         if getattr(self, "_wgrad", None) is None:
             wg = BM.MessagePackWeightGrad(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
             wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
+            wg.params_dev = {k: v.detach() for k, v in self.state_dict().items()}
             self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
         wg, dpA, dpB = self._wgrad
         xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--workload", default="si64")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--irreps", default="A")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the last step (host time: the step is host-bound at small sizes)")
     a = ap.parse_args()
     from hamgnn_amd.data import synthetic as S
     from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
@@ -36,6 +37,11 @@ def main():
     sync = torch.cuda.synchronize
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     for step in range(a.steps):
+        if a.profile and step == a.steps - 1:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
         sync(); t0 = time.time()
         with torch.no_grad():
             rep = model.representation(g, save_for_backward=True)
@@ -55,6 +61,9 @@ def main():
         sync(); t4 = time.time()
         print(f"step {step}: N {g.num_nodes} E {g.num_edges} loss {float(loss):.5f} | forward (incl. repack) {1e3 * (t1 - t0):.0f} ms, head backward "
               f"{1e3 * (t2 - t1):.0f} ms, backbone backward {1e3 * (t3 - t2):.0f} ms, optimiser {1e3 * (t4 - t3):.0f} ms", flush=True)
+        if a.profile and step == a.steps - 1:
+            pr.disable()
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
 
 
 if __name__ == "__main__":
