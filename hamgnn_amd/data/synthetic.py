@@ -69,7 +69,7 @@ def add_random_targets(g: Graph, nao, seed=0, soc=False, basis_def=None):
     def herm(rows, inv_):
         A = rng.normal(0, 0.1, size=(rows, dim, dim)).astype(np.float32)
         B = A if inv_ is None else A[inv_]
-        return (0.5 * (A + B.transpose(0, 2, 1))).reshape(rows, -1)
+        return (0.5 * (A + B.transpose(0, 2, 1))).reshape(rows, dim * dim)          # (explicit width: rows may be 0)
     g["Hon0"], g["Hoff0"] = torch.from_numpy(herm(N, None)), torch.from_numpy(herm(E, inv))
     g["Hon"], g["Hoff"] = g["Hon0"].clone(), g["Hoff0"].clone()
     g["Son"], g["Soff"] = torch.zeros(N, nao * nao), torch.zeros(E, nao * nao)

@@ -449,7 +449,7 @@ class TensorProduct(torch.nn.Module):
                     r = r * (w[:, :, None] if batch_w else w[None, :, None])
             else:
                 raise NotImplementedError(mode)
-            r = ins.path_weight * r.reshape(Z, -1)
+            r = ins.path_weight * r.flatten(1)                  # (flatten, not reshape(Z, -1): Z may be 0)
             outs[ins.i_out] = r if outs[ins.i_out] is None else outs[ins.i_out] + r
         res = []
         for i, (mul, ir) in enumerate(self.irreps_out):
@@ -509,7 +509,7 @@ class Linear(torch.nn.Module):
             W = w[off:off + mi * mo].reshape(mi, mo)
             off += mi * mo
             xi = x[:, self._si[i]].reshape(Z, mi, ir.dim)
-            r = torch.einsum("uw,zui->zwi", W, xi).reshape(Z, -1) / math.sqrt(self.fan_in[o])
+            r = torch.einsum("uw,zui->zwi", W, xi).flatten(1) / math.sqrt(self.fan_in[o])
             outs[o] = r if outs[o] is None else outs[o] + r
         res = [outs[o] if outs[o] is not None else x.new_zeros(Z, mul * ir.dim) for o, (mul, ir) in enumerate(self.irreps_out)]
         return torch.cat(res, dim=-1)

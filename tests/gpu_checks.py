@@ -828,7 +828,7 @@ def check_head_su2(device="cuda"):
 
 
 def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, nao=19, num_layers=2, radial=(16, 16), num_radial=8,
-                         n_graphs=1, legacy_edge_update=False, zs=(14, 8, 6, 1), soc=False):
+                         n_graphs=1, legacy_edge_update=False, zs=(14, 8, 6, 1), soc=False, isolated=False):
     """Seeded random weights on a synthetic periodic cell: full backbone + head, HIP (fp32) vs oracle (fp64, CPU)."""
     from oracle import hamgnn_ref as R
     from hamgnn_amd.data import synthetic as S
@@ -848,7 +848,10 @@ def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, n
         torch.set_default_dtype(prev)
     gs = [S.add_random_targets(S.random_cell(n_atoms + 2 * k, list(zs), seed=seed + k, density=0.004), nao, seed=seed + k, soc=soc)
           for k in range(n_graphs)]
-    if n_graphs == 1:
+    if isolated:                                              # a crystal WITHOUT edges in the middle of the batch (one atom, no neighbour in range)
+        gs.insert(1, S.add_random_targets(S.random_cell(1, [int(zs[0])], seed=seed, density=1e-6), nao, seed=seed, soc=soc))
+        assert gs[1].num_edges == 0
+    if len(gs) == 1:
         g = gs[0]
     else:
         from hamgnn_amd.data import collate

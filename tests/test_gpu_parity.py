@@ -278,6 +278,15 @@ def test_multi_crystal_batch_vs_oracle():
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
 
 
+def test_ragged_batch_with_an_edgeless_crystal_vs_oracle():
+    """ragged batch: crystals of 6 / 1 / 8 atoms, the middle one without a single edge (its on-site block comes from the embeddings alone;
+    empty segments in the receiver CSR, an empty slice in the per-crystal [on-site; off-site] order).  (A batch with NO edges at all is
+    not a case: the reference's AttentionHeadsToVector `.view(0, -1)` raises on it, nn/attention_utils.py:116.)"""
+    r = G.oracle_vs_hip_random(n_graphs=2, seed=9, isolated=True)
+    print(r)
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
+
+
 def test_uni_hamgnn_style_batch_vs_oracle():
     """BASELINE config #5 in small: mixed-Z multi-crystal batch, nao_max 26 (f shells), legacy_edge_update (layer 0 keeps the
     embedded edge features), SOC so3 head -- full HIP forward vs the fp64 oracle."""
