@@ -201,15 +201,20 @@ class HamGNNPlusPlusOut(nn.Module):
         ops.ham_readout(net_off(edge_rot), geo, self._slot, *self._cg, n, pairs, H0_off, self._mask, z, src, dst, off, self.hamiltonian_irreps.lmax, 1.0, self.symmetrize)
         return on, off
 
-    # ---- backward of the non-SOC read-out (K6 data gradient + the head's weight gradients)
+    # ---- backward of the read-out (K6 data gradient + the head's weight gradients): non-SOC and SOC / so3
     def backward(self, data, graph_representation, grad_hamiltonian):
-        """grad_hamiltonian: gradient with respect to result["hamiltonian"] ([N + E, nao^2] rows in the forward's order).  Returns
-        (g_node_planar [N, Dp], g_edge_planar_rot [E, Dp] -- gradients of the representation's planar node rows and edge-frame edge rows --,
-        {parameter name: gradient}).  Chain: mask and symmetrisation are their own adjoint (hg_ham_finish on the gradient), the CG merge
-        + reorder is a CSR map applied transposed (hg_ham_merge with plan.ham_merge_adjoint_tables), the un-rotation's adjoint is the
-        rotation (hg_rotate_gather), then HamLayer.backward (Linear / Gate adjoints, weight gradients as GEMMs)."""
-        if self.soc_switch or not self.ham_only or self.zero_point_shift:
-            raise NotImplementedError("head backward: non-SOC, ham_only, without the zero-point shift")
+        """grad_hamiltonian: gradient with respect to result["hamiltonian"] in the forward's row order -- non-SOC: [N + E, nao^2];
+        SOC / so3: [2 (N + E), (2 nao)^2] = [real rows; imaginary rows].  Returns (g_node_planar [N, Dp], g_edge_planar_rot [E, Dp] --
+        gradients of the representation's planar node rows and edge-frame edge rows --, {parameter name: gradient}).
+        Chain of the spin-free blocks: mask and symmetrisation are their own adjoint (hg_ham_finish on the gradient), the CG merge +
+        reorder is a CSR map applied transposed (hg_ham_merge with plan.ham_merge_adjoint_tables), the un-rotation's adjoint is the
+        rotation (hg_rotate_gather), then HamLayer.backward (Linear / Gate adjoints, weight gradients as GEMMs).
+        SOC / so3 (hamgnn_output.py:3026-3144; csrc/head.hip soc_assemble_kernel): the (2 nao)^2 gradient rows are folded back onto the
+        spin-free block (uu + dd of the real part) and onto ksi (the three L components x the antihermitised blocks), the shell-block
+        mean is its own adjoint (hg_block_mean), then the ksi networks' HamLayer.backward.  With add_H_nonsoc the spin-free block is an
+        input (the non-SOC model's prediction) and only the ksi path carries gradients -- the Uni-HamGNN SOC training mode."""
+        if not self.ham_only or self.zero_point_shift or (self.soc_switch and self.soc_basis != "so3"):
+            raise NotImplementedError("head backward: ham_only, without the zero-point shift; non-SOC or SOC / so3")
         rep = graph_representation
         dev = data.z.device
         if self._compiled_for != dev:
@@ -217,9 +222,54 @@ class HamGNNPlusPlusOut(nn.Module):
         geo = rep["_geometry"]
         node_pl, edge_rot = rep["_node_planar"], rep["_edge_planar_rot"]
         inv, edge_counts = self._global_inverse(data)
+        n = self.nao_max
+        gH = grad_hamiltonian.float()
+        g_node = g_edge = None
+        grads = {}
+        if self.soc_switch:
+            half = gH.shape[0] // 2
+            gr_on, gr_off = self._split_by_crystal(data, gH[:half], edge_counts)
+            gi_on, gi_off = self._split_by_crystal(data, gH[half:], edge_counts)
+            f32c = lambda t: t.contiguous().float()
+            gk_on, gh_on = self._soc_fold(gr_on, gi_on, f32c(data.Lon), None)
+            gk_off, gh_off = self._soc_fold(gr_off, gi_off, f32c(data.Loff), inv)
+            ksi_lay = P.PlanarLayout(self.onsite_ksi_network.ham_irreps)
+            pad = lambda t: torch.nn.functional.pad(t, (0, ksi_lay.dim - t.shape[1])).contiguous()
+            g_node, gw = self.onsite_ksi_network.backward(node_pl, pad(ops.block_mean(gk_on.contiguous(), self._blk, n)))
+            grads.update({"onsite_ksi_network." + k: v for k, v in gw.items()})
+            g_edge, gw = self.offsite_ksi_network.backward(edge_rot, pad(ops.block_mean(gk_off.contiguous(), self._blk, n)))
+            grads.update({"offsite_ksi_network." + k: v for k, v in gw.items()})
+            if self.add_H_nonsoc:                              # the spin-free networks are not evaluated (their parameters get zeros)
+                for name in ("onsite_hamiltonian_network", "offsite_hamiltonian_network"):
+                    grads.update({f"{name}.{k}": torch.zeros_like(p).reshape(-1) for k, p in getattr(self, name).named_parameters()})
+                return g_node, g_edge, grads
+            gH_on, gH_off = gh_on.contiguous(), gh_off.contiguous()
+        else:
+            gH_on, gH_off = (t.contiguous() for t in self._split_by_crystal(data, gH, edge_counts))
+        gn, ge, gw = self._backward_spin_free(data, geo, node_pl, edge_rot, inv, gH_on, gH_off)
+        grads.update(gw)
+        return (gn if g_node is None else g_node + gn), (ge if g_edge is None else g_edge + ge), grads
+
+    def _soc_fold(self, gr, gi, L, inv):
+        """adjoint of hg_soc_assemble for one row set: gradient rows of the real / imaginary (2 nao)^2 matrices -> (g_ksi [rows, nao^2],
+        g_H [rows, nao^2]).  real = [[H, A_y], [A_y, H]], imag = [[A_z, A_x], [-A_x, -A_z]],  A_k = antiherm(ksi L_k) (element-wise
+        torch ops on [rows, nao, nao] views: HBM-bound bookkeeping, a few MB per thousand rows)."""
+        n = self.nao_max
+        R = gr.reshape(-1, 2, n, 2, n)
+        I = gi.reshape(-1, 2, n, 2, n)
+        g_h = (R[:, 0, :, 0, :] + R[:, 1, :, 1, :]).reshape(-1, n * n)
+        g_a = torch.stack([I[:, 0, :, 1, :] - I[:, 1, :, 0, :],          # k = 0 (x): imaginary off-diagonal blocks
+                           R[:, 0, :, 1, :] + R[:, 1, :, 0, :],          # k = 1 (y): real off-diagonal blocks
+                           I[:, 0, :, 0, :] - I[:, 1, :, 1, :]], -1)     # k = 2 (z): imaginary diagonal blocks      -> [rows, n, n, 3]
+        if self.symmetrize:                                    # A_k[e] = (ksi L_k)[e] / 2 - (ksi L_k)[inv e]^T / 2
+            other = g_a if inv is None else g_a[inv]
+            g_a = 0.5 * (g_a - other.transpose(1, 2))
+        return (g_a * L.reshape(-1, n, n, 3)).sum(-1).reshape(-1, n * n), g_h
+
+    def _backward_spin_free(self, data, geo, node_pl, edge_rot, inv, gH_on, gH_off):
+        dev = data.z.device
         z = data.z.contiguous()
-        N, n = z.shape[0], self.nao_max
-        gH_on, gH_off = (t.contiguous() for t in self._split_by_crystal(data, grad_hamiltonian.float(), edge_counts))
+        n = self.nao_max
         if getattr(self, "_adj_tabs", None) is None:
             net = self.onsite_hamiltonian_network
             glay = P.PlanarLayout(net.girr)
@@ -268,6 +318,13 @@ class HamGNNPlusPlusOut(nn.Module):
         if not self.ham_only:
             s_on, s_off = self._blocks(self.onsite_overlap_network, self.offsite_overlap_network, node_pl, edge_rot, geo, data, inv, None, None)
             result["overlap"] = self._cat_by_crystal(data, s_on, s_off, edge_counts)
+        if self.soc_switch and not ghas(data, "hamiltonian") and all(ghas(data, k) for k in ("Hon", "Hoff", "iHon", "iHoff")):
+            # SOC targets as the reference attaches them (hamgnn_output.py:3621-3626): [real rows; imaginary rows], per crystal each
+            tr = self._cat_by_crystal(data, gget(data, "Hon"), gget(data, "Hoff"), edge_counts)
+            ti = self._cat_by_crystal(data, gget(data, "iHon"), gget(data, "iHoff"), edge_counts)
+            gset(data, "hamiltonian_real", tr)
+            gset(data, "hamiltonian_imag", ti)
+            gset(data, "hamiltonian", torch.cat([tr, ti], 0))
         if self.soc_switch and self.soc_basis == "su2":                      # ---- SOC / su2 (hamgnn_output.py:3146-3178)
             n, big = self.nao_max, 4 * self.nao_max ** 2
             z = data.z.contiguous()

@@ -28,6 +28,27 @@ def _np_sd(module: nn.Module) -> Dict[str, np.ndarray]:
     return {k: v.detach().cpu().double().numpy() for k, v in module.state_dict().items()}
 
 
+def o3_linear_weight_grad(irreps_in, irreps_out, x_planar: torch.Tensor, gy_planar: torch.Tensor) -> torch.Tensor:
+    """d sum(y * gy) / d weight of an o3.Linear in e3nn's flat layout (paths (i_in, i_out), each [mul_in, mul_out], 1 / sqrt(fan_in)
+    normalisation): per path one GEMM over (rows x components) on the planar blocks (rocBLAS / hipBLASLt: a library GEMM)."""
+    irreps_in, irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+    li, lo = P.PlanarLayout(irreps_in), P.PlanarLayout(irreps_out)
+    paths = [(i, k) for i, (_, l1, p1) in enumerate(irreps_in) for k, (_, l2, p2) in enumerate(irreps_out) if (l1, p1) == (l2, p2)]
+    fan = {}
+    for i, k in paths:
+        fan[k] = fan.get(k, 0) + irreps_in[i][0]
+    rows = x_planar.shape[0]
+    out = []
+    for i, k in paths:
+        mi, l, _ = irreps_in[i]
+        mk = irreps_out[k][0]
+        n = 2 * l + 1
+        X = x_planar[:, li.off[i]:li.off[i] + n * li.mulp[i]].reshape(rows * n, li.mulp[i])[:, :mi]
+        G = gy_planar[:, lo.off[k]:lo.off[k] + n * lo.mulp[k]].reshape(rows * n, lo.mulp[k])[:, :mk]
+        out.append(((X.t() @ G) / math.sqrt(fan[k])).reshape(-1))
+    return torch.cat(out) if out else x_planar.new_zeros(0)
+
+
 class E3Linear(nn.Module):
     """o3.Linear parameter holder: flat weight, paths ordered (i_in, i_out), each (mul_in, mul_out) row-major."""
 
@@ -65,23 +86,7 @@ class E3Linear(nn.Module):
         return ops.linear_planar(self._dp_adj, gy_planar, tag="linear_adjoint")
 
     def weight_grad(self, x_planar: torch.Tensor, gy_planar: torch.Tensor) -> torch.Tensor:
-        """d sum(y * gy) / d weight in e3nn's flat layout (paths (i_in, i_out), each [mul_in, mul_out], 1 / sqrt(fan_in) normalisation):
-        per path one GEMM over (rows x components) on the planar blocks (torch.einsum = rocBLAS / hipBLASLt: a library GEMM)."""
-        li, lo = P.PlanarLayout(self.irreps_in), P.PlanarLayout(self.irreps_out)
-        paths = [(i, k) for i, (_, l1, p1) in enumerate(self.irreps_in) for k, (_, l2, p2) in enumerate(self.irreps_out) if (l1, p1) == (l2, p2)]
-        fan = {}
-        for i, k in paths:
-            fan[k] = fan.get(k, 0) + self.irreps_in[i][0]
-        rows = x_planar.shape[0]
-        out = []
-        for i, k in paths:
-            mi, l, _ = self.irreps_in[i]
-            mk = self.irreps_out[k][0]
-            n = 2 * l + 1
-            X = x_planar[:, li.off[i]:li.off[i] + n * li.mulp[i]].reshape(rows * n, li.mulp[i])[:, :mi]
-            G = gy_planar[:, lo.off[k]:lo.off[k] + n * lo.mulp[k]].reshape(rows * n, lo.mulp[k])[:, :mk]
-            out.append(((X.t() @ G) / math.sqrt(fan[k])).reshape(-1))
-        return torch.cat(out) if out else x_planar.new_zeros(0)
+        return o3_linear_weight_grad(self.irreps_in, self.irreps_out, x_planar, gy_planar)
 
 
 class E3TensorProduct(nn.Module):
@@ -644,8 +649,18 @@ class HamLayer(nn.Module):
     def backward(self, x_planar, g_out_planar):
         """gradient of forward(x) = linear_transform(residual_block(x)) for the gradient of its (grouped planar) output rows: returns
         (g_x, {parameter name: gradient in the reference's flat layout})"""
-        if not isinstance(self._dp, ops.DeviceLinear) or self.slot_pos is None and not all(m == 1 for m, _, _ in self.ham_irreps):
-            raise NotImplementedError("HamLayer.backward: streaming Linear path of the Hamiltonian networks only")
+        if not isinstance(self._dp, ops.DeviceLinear):
+            raise NotImplementedError("HamLayer.backward: streaming Linear path only (HG_LINEAR_KERNEL=seg has no adjoint tables)")
+        if self.slot_pos is None:                               # xi networks: a plain o3.Linear (e.g. irreps_in -> nao^2 x 0e)
+            W = self.linear_transform.weight.detach().cpu().double().numpy()
+            if getattr(self, "_dp_adj", None) is None:
+                self._dp_adj = ops.DeviceLinear(P.build_linear_adjoint_tables(W, self.irreps_in, self.ham_irreps), x_planar.device)
+            y = self.residual_block(x_planar)
+            g_y = ops.linear_planar(self._dp_adj, g_out_planar, tag="linear_adjoint")
+            g_x, g_res = self.residual_block.backward(x_planar, g_y)
+            grads = {"linear_transform.weight": o3_linear_weight_grad(self.irreps_in, self.ham_irreps, y, g_out_planar)}
+            grads.update({"residual_block." + k: v for k, v in g_res.items()})
+            return g_x, grads
         W = self.linear_transform.weight.detach().cpu().double().numpy()
         mats, girr, slot_pos = P.ham_linear_mats(W, self.irreps_in, self.ham_irreps, self.keep)
         dev = x_planar.device

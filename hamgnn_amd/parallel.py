@@ -43,7 +43,7 @@ def shard_graph(g: Graph, rank: int, world: int) -> Graph:
     inv_local = newid[g["inv_edge_idx"][sel]]
     assert (inv_local >= 0).all(), "pair split across ranks"
     # derived per-batch tensors (topology cache, the combined targets the head attaches on its first forward) are not carried over
-    out = Graph({k: v for k, v in g.items() if k not in _EDGE_KEYS and k not in ("edge_index", "inv_edge_idx", "_hg_topology", "hamiltonian", "overlap")})
+    out = Graph({k: v for k, v in g.items() if k not in _EDGE_KEYS and k not in ("edge_index", "inv_edge_idx", "_hg_topology", "hamiltonian", "overlap", "hamiltonian_real", "hamiltonian_imag")})
     out["edge_index"] = g["edge_index"][:, sel].contiguous()
     out["inv_edge_idx"] = inv_local
     for k in _EDGE_KEYS:

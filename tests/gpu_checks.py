@@ -283,7 +283,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -302,12 +302,17 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     torch.set_default_dtype(torch.float64)
     try:
         rb = R.HamGNNConvE3(cfg)
-        rh = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=False)
+        skw = dict(soc_switch=True, soc_basis="so3", add_H_nonsoc=(soc == "so3_nonsoc")) if soc else {}
+        rh = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=False, **skw)
     finally:
         torch.set_default_dtype(prev)
     from hamgnn_amd.data import collate
-    gs = [S.add_random_targets(S.random_cell(n_atoms + c, [14, 8, 6, 1], seed=seed + c, density=0.004), nao, seed=seed + c) for c in range(crystals)]
+    gs = [S.add_random_targets(S.random_cell(n_atoms + c, [14, 8, 6, 1], seed=seed + c, density=0.004), nao, seed=seed + c, soc=bool(soc))
+          for c in range(crystals)]
     g = gs[0] if crystals == 1 else collate(gs)
+    if soc == "so3_nonsoc":                                    # the frozen non-SOC model's prediction (Uni-HamGNN chain): an input here
+        gen_ = torch.Generator().manual_seed(seed + 50)
+        g["Hon_nonsoc"], g["Hoff_nonsoc"] = 0.1 * torch.randn(g.num_nodes, nao * nao, generator=gen_), 0.1 * torch.randn(g.num_edges, nao * nao, generator=gen_)
     g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
     Href = rh(g64, rb(g64))["hamiltonian"]
     target = 0.1 * torch.randn(Href.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
@@ -316,7 +321,8 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     loss_ref.backward()
     model = Model(load_weights(HamGNNConvE3(cfg), dict(rb.state_dict())),
                   load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
-                                                 soc_switch=False, calculate_sparsity=False, zero_point_shift=False), dict(rh.state_dict()))).to(device)
+                                                 calculate_sparsity=False, zero_point_shift=False, **(skw if soc else dict(soc_switch=False))),
+                               dict(rh.state_dict()))).to(device)
     r = training_step(model, g.to(device), metric=metric, target=target.float().to(device))
     torch.cuda.synchronize()
     out = {"N": g.num_nodes, "E": g.num_edges, "loss_rel_err": abs(float(r["loss"]) - float(loss_ref.detach())) / abs(float(loss_ref.detach()))}
@@ -542,6 +548,62 @@ def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None):
     refp = dict(ref.named_parameters())
     assert set(gw) == set(refp), sorted(set(gw) ^ set(refp))[:4]
     out["g_weights_max_rel_err"] = max(rel(gw[k], refp[k].grad) for k in gw)
+    return out
+
+
+def check_soc_head_backward(device="cuda", n_atoms=5, seed=3, nao=19, add_H_nonsoc=False, crystals=1):
+    """backward of the SOC / so3 read-out head (ksi networks, shell-block mean, the (2 nao)^2 assembly with the three L
+    components; with add_H_nonsoc the Uni-HamGNN SOC training mode): gradient of sum(H * G) over [real; imag] rows with respect to the
+    representation and every head parameter vs torch.autograd through the fp64 oracle"""
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import ops, plan as P
+    from hamgnn_amd.data import synthetic as S, collate
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    irr = MINI
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True, soc_switch=True, soc_basis="so3",
+                                  add_H_nonsoc=add_H_nonsoc)
+    finally:
+        torch.set_default_dtype(prev)
+    gs = [S.add_random_targets(S.random_cell(n_atoms + c, [14, 8, 6, 1], seed=seed + c, density=0.004), nao, seed=seed + c, soc=True) for c in range(crystals)]
+    g = gs[0] if crystals == 1 else collate(gs)
+    N, E = g.num_nodes, g.num_edges
+    gen = torch.Generator().manual_seed(seed)
+    if add_H_nonsoc:
+        g["Hon_nonsoc"], g["Hoff_nonsoc"] = 0.1 * torch.randn(N, nao * nao, generator=gen), 0.1 * torch.randn(E, nao * nao, generator=gen)
+    D = R.Irreps(irr).dim
+    node = torch.randn(N, D, generator=gen, dtype=torch.float64).requires_grad_()
+    edge = torch.randn(E, D, generator=gen, dtype=torch.float64).requires_grad_()
+    G_ = torch.randn(2 * (N + E), 4 * nao * nao, generator=gen, dtype=torch.float64)
+    g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    Href = ref(g64, {"node_attr": node, "edge_attr": edge})["hamiltonian"]
+    (Href * G_).sum().backward()
+    hip = load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=True,
+                                         soc_basis="so3", add_H_nonsoc=add_H_nonsoc, calculate_sparsity=False, zero_point_shift=False),
+                       dict(ref.state_dict()))
+    hip.compile(device)
+    gd = g.to(device)
+    lay = P.PlanarLayout(irr)
+    imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+    geo = ops.Geometry(gd.pos, gd.edge_index, gd.nbr_shift, 1.0, 1, hip._lmax, hip._jtab)
+    node_pl = ops.to_planar(node.detach().float().to(device), imap, lay.dim)
+    edge_rot = ops.rotate_gather(ops.to_planar(edge.detach().float().to(device), imap, lay.dim), None, geo, hip._rot_tab)
+    rep = {"_node_planar": node_pl, "_edge_planar_rot": edge_rot, "_geometry": geo}
+    H = hip(gd, rep)["hamiltonian"]
+    g_node, g_edge, gw = hip.backward(gd, rep, G_.float().to(device))
+    g_edge = ops.rotate_gather(g_edge, None, geo, hip._rot_tab, transpose=True)
+    torch.cuda.synchronize()
+    out = {"forward_rel_err": rel(H, Href.detach()), "g_node_rel_err": rel(ops.from_planar(g_node, imap), node.grad),
+           "g_edge_rel_err": rel(ops.from_planar(g_edge, imap), edge.grad)}
+    refp = dict(ref.named_parameters())
+    assert set(gw) == set(refp), sorted(set(gw) ^ set(refp))[:4]
+    zero = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)
+    errs = {k: float((gw[k].double().cpu().reshape(refp[k].shape) - zero(refp[k])).abs().max()) / max(float(zero(refp[k]).abs().max()), 1e-6) for k in gw}
+    out["g_weights_max_rel_err"] = max(errs.values())
+    out["trained"] = sum(1 for k in refp if refp[k].grad is not None and float(refp[k].grad.abs().max()) > 0)
     return out
 
 

@@ -149,6 +149,14 @@ def test_full_model_backward_batch_of_crystals():
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
 
 
+@pytest.mark.parametrize("soc", ["so3", "so3_nonsoc"])
+def test_full_model_backward_soc(soc):
+    """SOC / so3 model (ksi networks + spin assembly); "so3_nonsoc": the Uni-HamGNN SOC training mode (spin-free block given, add_H_nonsoc)"""
+    r = G.check_full_backward(n_atoms=4, seed=6, soc=soc, crystals=2 if soc == "so3_nonsoc" else 1)
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
+
+
 def test_full_model_backward_default_irreps():
     """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
     r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)
@@ -167,6 +175,14 @@ def test_full_model_training_loss_falls():
     r = G.check_full_training()
     print(r)
     assert r["last"] < 0.8 * r["first"] and all(b < a for a, b in zip(r["losses"], r["losses"][1:])), r
+
+
+@pytest.mark.parametrize("nonsoc,crystals", [(False, 1), (True, 2)])
+def test_soc_head_backward_vs_autograd(nonsoc, crystals):
+    r = G.check_soc_head_backward(add_H_nonsoc=nonsoc, crystals=crystals)
+    print(r)
+    assert r["trained"] >= 6
+    assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
 
 def test_head_backward_vs_autograd():
