@@ -75,11 +75,11 @@ def _build_groups(wg, device, dtype):
             N = max(c["r1"] - c["r0"] for c in part)
             MK = max(c["sp"]["mk"] for c in part)
             U = max(c["nsrc"] * c["sp"]["mi"] for c in part)
-            a_idx = np.zeros((G, nc, N), np.int64)
-            g_idx = np.zeros((G, nc, MK), np.int64)
-            x_idx = np.zeros((G, nc, U), np.int64)
-            ch_idx = np.full((G, N), nch, np.int64)            # spare column of S / gs_all
-            cf = np.zeros((G, nc, N))
+            a_idx = np.zeros((G, N, nc), np.int64)             # FEATURE-major: the reductions run on transposed rows ([feature, edge]),
+            g_idx = np.zeros((G, MK, nc), np.int64)            # so a gather lands directly in the [G, rows, (column, edge)] operand layout
+            x_idx = np.zeros((G, U, nc), np.int64)             # of the batched GEMMs (no permute / contiguous copies)
+            ch_idx = np.full((G, N), nch, np.int64)            # spare row of S^T / gs_all^T
+            cf = np.zeros((G, N, nc))
             cpath = np.zeros((G, N, 1))
             tp_idx = np.full((G, N, U), tp_size, np.int64)     # spare slot of the flat TP-weight accumulator
             l_idx = np.full((G, N, MK), ls_size, np.int64)     # spare slot of the flat L' accumulator
@@ -89,13 +89,13 @@ def _build_groups(wg, device, dtype):
                 u = c["nsrc"] * mi
                 cols = np.array([lk - mm + cc for cc in range(nc)])
                 comps = np.array([(li + mm - cc) if par else (li - mm + cc) for cc in range(nc)])
-                a_idx[q, :, :n] = c["out_off"] + cols[:, None] * c["out_mulp"] + np.arange(n)[None, :]
-                g_idx[q, :, :mk] = gl.off[k] + cols[:, None] * gl.mulp[k] + np.arange(mk)[None, :]
+                a_idx[q, :n, :] = c["out_off"] + cols[None, :] * c["out_mulp"] + np.arange(n)[:, None]
+                g_idx[q, :mk, :] = gl.off[k] + cols[None, :] * gl.mulp[k] + np.arange(mk)[:, None]
                 for t, sl in enumerate(c["srcs"]):
                     base = slot_base.setdefault((branch, sl), len([1 for key in slot_base if key[0] == branch]) * lay.dim)
-                    x_idx[q, :, t * mi:(t + 1) * mi] = base + lay.off[i] + comps[:, None] * lay.mulp[i] + np.arange(mi)[None, :]
+                    x_idx[q, t * mi:(t + 1) * mi, :] = base + lay.off[i] + comps[None, :] * lay.mulp[i] + np.arange(mi)[:, None]
                 ch_idx[q, :n] = sp["ch"][r0:r1]
-                cf[q, :, :n] = sp["cf"][r0:r1].T
+                cf[q, :n, :] = sp["cf"][r0:r1]
                 meta = sp["meta"][r0:r1]
                 cpath[q, :n, 0] = [m[2] for m in meta]
                 base_tp = np.array([sp["woff"][m[0]] + m[1] for m in meta], dtype=np.int64)
@@ -105,50 +105,52 @@ def _build_groups(wg, device, dtype):
                 l_idx[q, :n, :mk] = off + lrow[:, None] * mk + np.arange(mk, dtype=np.int64)[None, :]
             t_ = lambda arr, dt=None: torch.as_tensor(arr, device=device, dtype=dt)
             out.append(dict(branch=branch, srcs=sorted({sl for c in part for sl in c["srcs"]}, key=lambda sl: slot_base[(branch, sl)]),
-                            a_idx=t_(a_idx), g_idx=t_(g_idx), x_idx=t_(x_idx), ch_idx=t_(ch_idx), cf=t_(cf, dtype), cpath=t_(cpath, dtype),
+                            a_idx=t_(a_idx), g_idx=t_(g_idx), x_idx=t_(x_idx), ch_idx=t_(ch_idx), cf=t_(cf[..., None], dtype), cpath=t_(cpath, dtype),
                             tp_idx=t_(tp_idx.reshape(-1)), l_idx=t_(l_idx.reshape(-1)), cidx=[idx_of[id(c)] for c in part], shape=(G, N, U)))
     return out
 
 
-def weight_grads_from_rows(wg, Arows: torch.Tensor, Brows: torch.Tensor, srcs: Sequence[torch.Tensor], g: torch.Tensor,
-                           S: Dict[str, torch.Tensor], acc: Dict[str, torch.Tensor], gs_all: Dict[str, torch.Tensor], gx=None):
-    """One chunk of edges.  Arows / Brows: the two materialised row tensors [E, out_dim]; srcs = the program's source rows by slot
-    (message pack: x_sender, x_receiver, f), planar, edge frame; g: gradient rows (edge frame, planar(irreps_out)); S[branch] =
-    [h @ W3 / sqrt(H), 0] [E, n_channels + 1]; acc: flat running sums of the TP-weight and L' gradients (+ one spare slot each, updated
-    in place); gs_all[branch]: [E, n_channels + 1] (filled); gx: optional list of zero tensors like srcs -- the gradient with respect to
-    the source rows is accumulated there (W^T (s cf B); used for the 0e-only embedding input, where it is a few columns)."""
-    if getattr(wg, "_groups", None) is None or wg._groups[0] != (str(Arows.device), Arows.dtype):
-        wg._groups = ((str(Arows.device), Arows.dtype), _build_groups(wg, Arows.device, Arows.dtype))
+def weight_grads_from_rows(wg, ArowsT: torch.Tensor, BrowsT: torch.Tensor, srcsT: Sequence[torch.Tensor], gT: torch.Tensor,
+                           ST: Dict[str, torch.Tensor], acc: Dict[str, torch.Tensor], gs_allT: Dict[str, torch.Tensor], gxT=None):
+    """One chunk of edges, everything FEATURE-major ([feature, edge]: the transposes are made once per chunk by the caller).
+    ArowsT / BrowsT: the two materialised row tensors [out_dim, E]; srcsT = the program's source rows by slot (message pack: x_sender,
+    x_receiver, f), planar, edge frame; gT: gradient rows (edge frame, planar(irreps_out)); ST[branch] = [h @ W3 / sqrt(H); 0]
+    [n_channels + 1, E]; acc: flat running sums of the TP-weight and L' gradients (+ one spare slot each, updated in place);
+    gs_allT[branch]: [n_channels + 1, E] (filled); gxT: optional list of zero tensors like srcsT -- the gradient with respect to the
+    source rows is accumulated there (W^T (s cf B); used for the 0e-only embedding input, where it is a few rows)."""
+    if getattr(wg, "_groups", None) is None or wg._groups[0] != (str(ArowsT.device), ArowsT.dtype):
+        wg._groups = ((str(ArowsT.device), ArowsT.dtype), _build_groups(wg, ArowsT.device, ArowsT.dtype))
+    E = ArowsT.shape[1]
     xcat = {}
     for grp in wg._groups[1]:
         name = grp["branch"]
         if name not in xcat:
             slots = sorted({sl for g_ in wg._groups[1] if g_["branch"] == name for sl in g_["srcs"]})
-            assert all(grp2["srcs"] == grp["srcs"] or grp2["branch"] != name for grp2 in wg._groups[1])
-            xcat[name] = (srcs[slots[0]] if len(slots) == 1 else torch.cat([srcs[sl] for sl in slots], 1), slots)
-        X = xcat[name][0][:, grp["x_idx"]]                                         # [E, G, nc, U]
-        A, B = Arows[:, grp["a_idx"]], Brows[:, grp["a_idx"]]                      # [E, G, nc, N]
-        s = S[name][:, grp["ch_idx"]]                                              # [E, G, N]  (0 on padded rows)
-        gs_all[name][:, grp["ch_idx"].reshape(-1)] = (A * B).sum(2).flatten(1)
-        Gk = g[:, grp["g_idx"]]                                                    # [E, G, nc, MK]
-        gL = torch.einsum("egcn,egcw->gnw", A * s[:, :, None, :], Gk)
-        T1 = B * s[:, :, None, :] * grp["cf"][None]
-        gW = torch.einsum("egcn,egcu->gnu", T1, X)
+            xcat[name] = (srcsT[slots[0]] if len(slots) == 1 else torch.cat([srcsT[sl] for sl in slots], 0), slots)
+        G, N, nc = grp["a_idx"].shape
+        X = xcat[name][0][grp["x_idx"]]                                            # [G, U, nc, E]
+        A, B = ArowsT[grp["a_idx"]], BrowsT[grp["a_idx"]]                          # [G, N, nc, E]
+        s = ST[name][grp["ch_idx"]][:, :, None, :]                                 # [G, N, 1, E]  (0 on padded rows)
+        gs_allT[name][grp["ch_idx"].reshape(-1)] = (A * B).sum(2).reshape(G * N, E)
+        Gk = gT[grp["g_idx"]]                                                      # [G, MK, nc, E]
+        gL = torch.bmm((A * s).reshape(G, N, nc * E), Gk.reshape(G, -1, nc * E).transpose(1, 2))          # [G, N, MK]
+        T1 = (B * s * grp["cf"]).reshape(G, N, nc * E)
+        gW = torch.bmm(T1, X.reshape(G, -1, nc * E).transpose(1, 2))                                        # [G, N, U]
         acc[f"{name}_tp"].index_add_(0, grp["tp_idx"], (gW * grp["cpath"]).reshape(-1))
         acc[f"{name}_L"].index_add_(0, grp["l_idx"], gL.reshape(-1))
-        if gx is not None:
+        if gxT is not None:
             Wg_np = np.zeros(grp["shape"])                                         # [G, N, U] from the CURRENT weights, path normalisation included
             for q, j in enumerate(grp["cidx"]):
                 c = wg.chunks[j]
                 Wr = c["sp"]["W"][c["r0"]:c["r1"]]
                 Wg_np[q, :Wr.shape[0], :Wr.shape[1]] = Wr
             Wg = torch.as_tensor(Wg_np, device=T1.device, dtype=T1.dtype)
-            GX = torch.einsum("egcn,gnu->egcu", T1, Wg).flatten(1)
-            lay_dim = xcat[name][0].shape[1] // len(xcat[name][1])
-            cols = grp["x_idx"].reshape(-1)
-            for t, sl in enumerate(xcat[name][1]):                                 # columns of slot t of the concatenated sources
-                sel = (cols >= t * lay_dim) & (cols < (t + 1) * lay_dim)
-                gx[sl].index_add_(1, cols[sel] - t * lay_dim, GX[:, sel])
+            GX = torch.bmm(Wg.transpose(1, 2), T1).reshape(-1, E)                  # [G U nc, E]
+            rows = grp["x_idx"].reshape(-1)
+            lay_dim = xcat[name][0].shape[0] // len(xcat[name][1])
+            for t, sl in enumerate(xcat[name][1]):                                 # rows of slot t of the concatenated sources
+                sel = (rows >= t * lay_dim) & (rows < (t + 1) * lay_dim)
+                gxT[sl].index_add_(0, rows[sel] - t * lay_dim, GX[sel])
 
 
 class TPWeightGrad:
@@ -248,14 +250,21 @@ def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor],
         with torch.no_grad():
             h = {name: radial_mlp(rbf[sl], [w.detach() for w in gen[name][:-1]], act_cst) for name in gen}
             S = {name: torch.nn.functional.pad(h[name] @ (gen[name][-1].detach() / math.sqrt(H)), (0, 1)) for name in gen}   # + the zero column
+            ST = {name: v.t().contiguous() for name, v in S.items()}
             ones = torch.zeros(n, wg.progA.hidden_pad, device=dev, dtype=dt)
             ones[:, 0] = 1.0
             part = [t[sl] for t in srcs]
             Arows = run_program(wg.progA, part, ones, ones)
             Brows = run_program(wg.progB, [g[sl]], ones, ones)
-            gs_all = {name: torch.zeros(n, gen[name][-1].shape[1] + 1, device=dev, dtype=dt) for name in gen}
-            weight_grads_from_rows(wg, Arows, Brows, part, g[sl], S, acc, gs_all, gx=None if gx is None else [t[sl] for t in gx])
-            gs_all = {name: v[:, :-1] for name, v in gs_all.items()}
+            gs_allT = {name: torch.zeros(gen[name][-1].shape[1] + 1, n, device=dev, dtype=dt) for name in gen}
+            gxT = None if gx is None else [torch.zeros(t.shape[1], n, device=dev, dtype=dt) for t in gx]
+            tr = lambda t: t.t().contiguous()                  # feature-major copies, once per chunk of edges
+            weight_grads_from_rows(wg, tr(Arows), tr(Brows), [tr(t) for t in part], tr(g[sl]), ST, acc, gs_allT, gxT=gxT)
+            del Arows, Brows
+            gs_all = {name: v[:-1].t() for name, v in gs_allT.items()}
+            if gx is not None:
+                for t, tT in zip(gx, gxT):
+                    t[sl] += tT.t()
             for name in gen:
                 gW3_last[name] += h[name].t() @ gs_all[name] / math.sqrt(H)
                 gh_hidden[name][sl] = gs_all[name] @ (gen[name][-1].detach().t() / math.sqrt(H))
