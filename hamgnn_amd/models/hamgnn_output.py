@@ -213,8 +213,8 @@ class HamGNNPlusPlusOut(nn.Module):
         spin-free block (uu + dd of the real part) and onto ksi (the three L components x the antihermitised blocks), the shell-block
         mean is its own adjoint (hg_block_mean), then the ksi networks' HamLayer.backward.  With add_H_nonsoc the spin-free block is an
         input (the non-SOC model's prediction) and only the ksi path carries gradients -- the Uni-HamGNN SOC training mode."""
-        if not self.ham_only or self.zero_point_shift or (self.soc_switch and self.soc_basis != "so3"):
-            raise NotImplementedError("head backward: ham_only, without the zero-point shift; non-SOC or SOC / so3")
+        if not self.ham_only or self.zero_point_shift:
+            raise NotImplementedError("head backward: ham_only, without the zero-point shift")
         rep = graph_representation
         dev = data.z.device
         if self._compiled_for != dev:
@@ -226,6 +226,17 @@ class HamGNNPlusPlusOut(nn.Module):
         gH = grad_hamiltonian.float()
         g_node = g_edge = None
         grads = {}
+        if self.soc_switch and self.soc_basis == "su2":
+            # SOC / su2 (hamgnn_output.py:3146-3178): the two (2 nao)^2 planes are finished separately (sign +1 real / -1 imaginary; mask and
+            # (anti)symmetrisation are again their own adjoint), side by side they are the gradient of the su2 CG merge's [real | imag] rows
+            half = gH.shape[0] // 2
+            z = data.z.contiguous()
+            gr_on, gr_off = self._split_by_crystal(data, gH[:half], edge_counts)
+            gi_on, gi_off = self._split_by_crystal(data, gH[half:], edge_counts)
+            fin = lambda g_, inv_, ia, ib, sign: ops.ham_finish(g_.contiguous(), inv_, None, self._mask, z, ia, ib, 2 * n, sign, self.symmetrize, True)
+            g_on = torch.cat([fin(gr_on, None, None, None, 1.0), fin(gi_on, None, None, None, -1.0)], 1)
+            g_off = torch.cat([fin(gr_off, inv, geo.src, geo.dst, 1.0), fin(gi_off, inv, geo.src, geo.dst, -1.0)], 1)
+            return self._backward_merge("su2", (self._slot_su2,) + self._cg_su2, geo, node_pl, edge_rot, g_on, g_off)
         if self.soc_switch:
             half = gH.shape[0] // 2
             gr_on, gr_off = self._split_by_crystal(data, gH[:half], edge_counts)
@@ -267,20 +278,28 @@ class HamGNNPlusPlusOut(nn.Module):
         return (g_a * L.reshape(-1, n, n, 3)).sum(-1).reshape(-1, n * n), g_h
 
     def _backward_spin_free(self, data, geo, node_pl, edge_rot, inv, gH_on, gH_off):
-        dev = data.z.device
         z = data.z.contiguous()
         n = self.nao_max
-        if getattr(self, "_adj_tabs", None) is None:
-            net = self.onsite_hamiltonian_network
-            glay = P.PlanarLayout(net.girr)
-            st, ptr_, idx_, val_ = (t.cpu().numpy() for t in (self._slot,) + self._cg)
-            sid, pT, iT, vT, scat = P.ham_merge_adjoint_tables(st, ptr_, idx_, val_, glay.dim)
-            self._adj_tabs = tuple(torch.from_numpy(a).to(dev) for a in (sid, pT, iT, vT, scat)) + (
-                torch.from_numpy(P.rotate_table(glay)).to(dev), int(st.shape[0]))
-        sid, pT, iT, vT, scat, rot_g, ncoef = self._adj_tabs
         # mask . symmetrise is self-adjoint (the orbital mask of an edge equals the transposed mask of its inverse edge)
         g_on = ops.ham_finish(gH_on, None, None, self._mask, z, None, None, n, 1.0, self.symmetrize)
         g_off = ops.ham_finish(gH_off, inv, None, self._mask, z, geo.src, geo.dst, n, 1.0, self.symmetrize)
+        return self._backward_merge("so3", (self._slot,) + self._cg, geo, node_pl, edge_rot, g_on, g_off)
+
+    def _backward_merge(self, key, tables, geo, node_pl, edge_rot, g_on, g_off):
+        """adjoint of the CG merge + reorder (a CSR map applied transposed: hg_ham_merge with plan.ham_merge_adjoint_tables), of the
+        off-site un-rotation (hg_rotate_gather) and of the two Hamiltonian HamLayers"""
+        dev = g_on.device
+        cache = self.__dict__.setdefault("_adj_tabs_by", {})
+        if getattr(self, "_adj_tabs", None) is None:           # compile() resets _adj_tabs: drop the derived tables with it
+            cache.clear()
+            self._adj_tabs = True
+        if key not in cache:
+            glay = P.PlanarLayout(self.onsite_hamiltonian_network.girr)
+            st, ptr_, idx_, val_ = (t.cpu().numpy() for t in tables)
+            sid, pT, iT, vT, scat = P.ham_merge_adjoint_tables(st, ptr_, idx_, val_, glay.dim)
+            cache[key] = tuple(torch.from_numpy(a).to(dev) for a in (sid, pT, iT, vT, scat)) + (
+                torch.from_numpy(P.rotate_table(glay)).to(dev), int(st.shape[0]))
+        sid, pT, iT, vT, scat, rot_g, ncoef = cache[key]
         gc_on = ops.from_planar(ops.ham_merge(g_on, None, sid, pT, iT, vT, ncoef), scat)
         gc_off = ops.rotate_gather(ops.from_planar(ops.ham_merge(g_off, None, sid, pT, iT, vT, ncoef), scat), None, geo, rot_g)
         g_node, gw_on = self.onsite_hamiltonian_network.backward(node_pl, gc_on)

@@ -551,7 +551,7 @@ def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None):
     return out
 
 
-def check_soc_head_backward(device="cuda", n_atoms=5, seed=3, nao=19, add_H_nonsoc=False, crystals=1):
+def check_soc_head_backward(device="cuda", n_atoms=5, seed=3, nao=19, add_H_nonsoc=False, crystals=1, basis="so3"):
     """backward of the SOC / so3 read-out head (ksi networks, shell-block mean, the (2 nao)^2 assembly with the three L
     components; with add_H_nonsoc the Uni-HamGNN SOC training mode): gradient of sum(H * G) over [real; imag] rows with respect to the
     representation and every head parameter vs torch.autograd through the fp64 oracle"""
@@ -559,16 +559,19 @@ def check_soc_head_backward(device="cuda", n_atoms=5, seed=3, nao=19, add_H_nons
     from hamgnn_amd import ops, plan as P
     from hamgnn_amd.data import synthetic as S, collate
     from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
-    irr = MINI
+    su2 = basis == "su2"                                       # siesta-13 (spinor CG merge), features up to l = 5 so that every coupling is fed
+    irr = "8x0e+8x0o+4x1e+4x1o+4x2e+4x2o+2x3e+2x3o+2x4e+2x4o+2x5e+2x5o" if su2 else MINI
+    ham_type, nao = ("siesta", 13) if su2 else ("openmx", nao)
+    zs = [14, 8, 6] if su2 else [14, 8, 6, 1]
     torch.manual_seed(seed)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
-        ref = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True, soc_switch=True, soc_basis="so3",
+        ref = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type=ham_type, symmetrize=True, add_H0=True, soc_switch=True, soc_basis=basis,
                                   add_H_nonsoc=add_H_nonsoc)
     finally:
         torch.set_default_dtype(prev)
-    gs = [S.add_random_targets(S.random_cell(n_atoms + c, [14, 8, 6, 1], seed=seed + c, density=0.004), nao, seed=seed + c, soc=True) for c in range(crystals)]
+    gs = [S.add_random_targets(S.random_cell(n_atoms + c, zs, seed=seed + c, density=0.004), nao, seed=seed + c, soc=True) for c in range(crystals)]
     g = gs[0] if crystals == 1 else collate(gs)
     N, E = g.num_nodes, g.num_edges
     gen = torch.Generator().manual_seed(seed)
@@ -581,8 +584,8 @@ def check_soc_head_backward(device="cuda", n_atoms=5, seed=3, nao=19, add_H_nons
     g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
     Href = ref(g64, {"node_attr": node, "edge_attr": edge})["hamiltonian"]
     (Href * G_).sum().backward()
-    hip = load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=True,
-                                         soc_basis="so3", add_H_nonsoc=add_H_nonsoc, calculate_sparsity=False, zero_point_shift=False),
+    hip = load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type=ham_type, ham_only=True, symmetrize=True, add_H0=True, soc_switch=True,
+                                         soc_basis=basis, add_H_nonsoc=add_H_nonsoc, calculate_sparsity=False, zero_point_shift=False),
                        dict(ref.state_dict()))
     hip.compile(device)
     gd = g.to(device)

@@ -185,6 +185,13 @@ def test_soc_head_backward_vs_autograd(nonsoc, crystals):
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
 
+def test_soc_su2_head_backward_vs_autograd():
+    """SOC / su2 head (siesta-13: spinor CG merge, [real | imaginary] planes finished with sign +1 / -1)"""
+    r = G.check_soc_head_backward(basis="su2", n_atoms=4)
+    print(r)
+    assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
+
+
 def test_head_backward_vs_autograd():
     r = G.check_head_backward()
     print(r)
