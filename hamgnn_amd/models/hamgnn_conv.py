@@ -148,6 +148,7 @@ class _BackboneBase(nn.Module):
             if q is None:
                 raise ValueError("apply_charge_doping=True needs data.doping_charge (scalar, one value per crystal, or one per atom)")
             delta = self.atomic_embedding.to(dev).delta(q, gget(data, "batch"), N, dev)
+        self._last_delta = delta
         f = self.pair_embedding.run(z, geo, delta)                                   # [E, Dp] edge-aligned frame
         if delta is None:
             node = ops.embed_lookup(self._chem, None, z, None, None, N, Dp, Dp)      # [N, Dp]
@@ -251,6 +252,8 @@ class HamGNNConvE3(_BackboneBase):
         rep = self._representation(node, f, geo)
         if tape is not None:
             rep["_tape"] = tape
+            if self._last_delta is not None:
+                rep["_charge_delta"] = self._last_delta
         return rep
 
     # ------------------------------------------------------------------------------------------------------------ backward
@@ -262,8 +265,8 @@ class HamGNNConvE3(_BackboneBase):
         linear_up adjoints, the fused skip o3.Linear)  ->  ResidualBlock  ->  skip o3.Linear  ->  ConvBlockE3's message block with the
         receiver scatter's adjoint (a gather) fused into its staging;  then the pair embedding and the chemical embedding table.
         Returns {reference parameter name: gradient in the reference's layout}.  Non-lite, no CorrProduct, no charge doping, one rank."""
-        if self.lite_mode or self.use_corr_prod or self.apply_charge_doping:
-            raise NotImplementedError("backbone backward: non-lite HamGNNConvE3 without CorrProductBlock / charge doping")
+        if self.lite_mode or self.use_corr_prod:
+            raise NotImplementedError("backbone backward: non-lite HamGNNConvE3 without CorrProductBlock")
         if parallel.is_sharded(data):
             raise NotImplementedError("backbone backward of an edge-sharded graph")
         tape = rep["_tape"]
@@ -309,9 +312,21 @@ class HamGNNConvE3(_BackboneBase):
             g_node = g_node_in + ops.segment_sum(gs, rp_s, pm_s, N) + ops.segment_sum(gd, rp_r, pm_r, N)
             g_f = g_f + ge
         # ---- embeddings: edge rows from the pair embedding, node rows = rows of the chemical embedding table
-        put("pair_embedding.", self.pair_embedding.backward(z, geo, g_f, chunk=chunk))
+        delta = rep.get("_charge_delta")                        # apply_charge_doping: node_attrs = one_hot(z) + delta
+        g_emb = self.pair_embedding.backward(z, geo, g_f, chunk=chunk, delta=delta)
+        g_delta = g_emb.pop("_g_delta", None)
+        put("pair_embedding.", g_emb)
         T, lay = self.num_types, self.layout
         gtab = torch.zeros(T, lay.dim, device=g_node.device, dtype=g_node.dtype).index_add_(0, z.long(), g_node)
+        if delta is not None:                                   # node rows = (one_hot(z) + delta) @ table
+            gtab = gtab + delta.t() @ g_node
+            g_delta = g_delta + g_node @ self._chem.t()
+            # the charge MLP (8 -> 8 -> num_types, torch tensor ops in the forward too): its parameters through autograd on those few ops
+            with torch.enable_grad():
+                d = self.atomic_embedding.delta(gget(data, "doping_charge"), gget(data, "batch"), z.shape[0], z.device)
+                names, params = zip(*self.atomic_embedding.named_parameters())
+                for k, gp in zip(names, torch.autograd.grad(d, params, grad_outputs=g_delta.to(d.dtype), allow_unused=True)):
+                    grads["atomic_embedding." + k] = gp if gp is not None else torch.zeros_like(dict(self.atomic_embedding.named_parameters())[k])
         gw = [gtab[:, lay.off[k]:lay.off[k] + mk].reshape(-1) / math.sqrt(T) for k, (mk, lk, pk) in enumerate(self.irreps_node_features) if (lk, pk) == (0, 1)]
         grads["chemical_embedding.linear.weight"] = torch.cat(gw)
         return grads

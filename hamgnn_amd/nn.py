@@ -541,10 +541,12 @@ class PairInteractionEmbeddingBlock(nn.Module):
         self._Tp = P.PlanarLayout([(T, 0, 1)]).dim
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
 
-    def backward(self, z, geo: ops.Geometry, g_f, chunk: int = 65536):
+    def backward(self, z, geo: ops.Geometry, g_f, chunk: int = 65536, delta=None):
         """gradients of every parameter of the block for the gradient g_f of the edge rows it returned (planar, edge frame):
         conv_tp.* through the materialisation programs (backward_mp), linear_up_src / linear_up_dst from the gradient of the
-        num_types scalar input channels (an index_add over the element of the sender / receiver)."""
+        num_types scalar input channels (an index_add over the element of the sender / receiver).
+        delta: the charge-doping correction the forward ran with ([N, num_types]; attrs = one_hot(z) + delta): its gradient is returned
+        under the key "_g_delta" (the caller backpropagates it through the charge MLP)."""
         from . import backward_mp as BM
         if self.lite_mode:
             raise NotImplementedError("backward of a lite_mode PairInteractionEmbeddingBlock")
@@ -555,14 +557,26 @@ class PairInteractionEmbeddingBlock(nn.Module):
             wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
             self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
         wg, dpA, dpB = self._wgrad
-        x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, T, self._Tp)
+        if delta is not None:
+            Ts, Td = (self._Ts[z] + delta @ self._Ts).contiguous(), (self._Td[z] + delta @ self._Td).contiguous()
+            x = ops.embed_lookup(Ts, Td, torch.arange(z.shape[0], device=dev), geo.src, geo.dst, geo.E, T, self._Tp)
+        else:
+            x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, T, self._Tp)
         grads, gx = BM.tp_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), [x], g_f, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk, want_gx=True)
         out = {"conv_tp." + k: v for k, v in grads.items()}
         gx = gx[0][:, :T]
         s = 1.0 / math.sqrt(T)
-        for name, idx in (("linear_up_src", geo.src), ("linear_up_dst", geo.dst)):
-            gT = torch.zeros(T, T, device=dev, dtype=gx.dtype).index_add_(0, z[idx.long()].long(), gx)
+        N = z.shape[0]
+        g_delta = torch.zeros(N, T, device=dev, dtype=gx.dtype) if delta is not None else None
+        for name, idx, tab in (("linear_up_src", geo.src, self._Ts), ("linear_up_dst", geo.dst, self._Td)):
+            g_atom = torch.zeros(N, T, device=dev, dtype=gx.dtype).index_add_(0, idx.long(), gx)      # gradient of the per-atom table rows
+            gT = torch.zeros(T, T, device=dev, dtype=gx.dtype).index_add_(0, z.long(), g_atom)        # rows one_hot(z) @ table
+            if delta is not None:                              # rows (one_hot(z) + delta) @ table
+                gT = gT + delta.t() @ g_atom
+                g_delta += g_atom @ tab.t()
             out[name + ".weight"] = (gT * s).reshape(-1)
+        if g_delta is not None:
+            out["_g_delta"] = g_delta
         return out
 
     def run(self, z, geo: ops.Geometry, delta=None):

@@ -283,7 +283,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -297,11 +297,17 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     cfg = dict(num_types=20, irreps_edge_sh=sh, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
                cutoff=26.0, rbf_func="bessel", num_radial=num_radial, num_layers=num_layers, irreps_node_features=irr, use_kan=False,
                radial_MLP=list(radial), correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
+    if charge:
+        cfg.update(apply_charge_doping=True, num_charge_attr_feas=8)
     torch.manual_seed(seed)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
         rb = R.HamGNNConvE3(cfg)
+        if charge:                                             # xavier / zero-bias init leaves the charge MLP tiny: make the correction matter
+            with torch.no_grad():
+                for p_ in rb.atomic_embedding.parameters():
+                    p_.copy_(0.6 * torch.randn(p_.shape))
         skw = dict(soc_switch=True, soc_basis="so3", add_H_nonsoc=(soc == "so3_nonsoc")) if soc else {}
         rh = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=False, **skw)
     finally:
@@ -313,6 +319,8 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     if soc == "so3_nonsoc":                                    # the frozen non-SOC model's prediction (Uni-HamGNN chain): an input here
         gen_ = torch.Generator().manual_seed(seed + 50)
         g["Hon_nonsoc"], g["Hoff_nonsoc"] = 0.1 * torch.randn(g.num_nodes, nao * nao, generator=gen_), 0.1 * torch.randn(g.num_edges, nao * nao, generator=gen_)
+    if charge:
+        g["doping_charge"] = torch.tensor([0.7, -1.3, 2.1][:crystals])          # one charge per crystal
     g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
     Href = rh(g64, rb(g64))["hamiltonian"]
     target = 0.1 * torch.randn(Href.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)

@@ -157,6 +157,14 @@ def test_full_model_backward_soc(soc):
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
 
 
+def test_full_model_backward_charge_doping():
+    """apply_charge_doping: node attributes one_hot(z) + mlp_q(gauss(q)) - mlp_q(gauss(0)); two crystals with different charges -- the
+    charge MLP's four parameters, the embedding tables and everything downstream"""
+    r = G.check_full_backward(n_atoms=4, seed=7, crystals=2, charge=True)
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] >= 78, r
+
+
 def test_full_model_backward_default_irreps():
     """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
     r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)
