@@ -217,9 +217,12 @@ class HamGNNConvE3(_BackboneBase):
         dev = self._compiled_for
         if dev is None:
             return
-        if self.lite_mode or self.use_corr_prod:
+        if self.lite_mode:
             self._compiled_for = None                          # full recompile on the next forward
             return
+        if self.use_corr_prod:
+            for c in self.corr_products:
+                c.compile(dev)                                 # four Linear tables + the concatenated element weights (host, ~ms)
         for conv, pair in zip(self.convolutions, self.pair_interactions):
             conv.residual.linear1.compile(dev)                 # (not residual.compile: its gate tables are structural)
             conv.residual.linear2.compile(dev)
@@ -245,6 +248,8 @@ class HamGNNConvE3(_BackboneBase):
                 tape.append(dict(node_in=node, f_in=f, agg=agg))
             node = conv.residual(agg, extra=skip)
             if self.use_corr_prod:                              # CorrProductBlock.forward (interaction_blocks.py:234-260; hamgnn_conv.py:274-275)
+                if tape is not None:
+                    tape[-1]["node_res"] = node                 # the ResidualBlock's output = the CorrProductBlock's input
                 node = self.corr_products[li](node, z)
             if tape is not None:
                 tape[-1]["node_out"] = node
@@ -265,8 +270,8 @@ class HamGNNConvE3(_BackboneBase):
         linear_up adjoints, the fused skip o3.Linear)  ->  ResidualBlock  ->  skip o3.Linear  ->  ConvBlockE3's message block with the
         receiver scatter's adjoint (a gather) fused into its staging;  then the pair embedding and the chemical embedding table.
         Returns {reference parameter name: gradient in the reference's layout}.  Non-lite, no CorrProduct, no charge doping, one rank."""
-        if self.lite_mode or self.use_corr_prod:
-            raise NotImplementedError("backbone backward: non-lite HamGNNConvE3 without CorrProductBlock")
+        if self.lite_mode:
+            raise NotImplementedError("backbone backward: non-lite HamGNNConvE3")
         if parallel.is_sharded(data):
             raise NotImplementedError("backbone backward of an edge-sharded graph")
         tape = rep["_tape"]
@@ -302,6 +307,9 @@ class HamGNNConvE3(_BackboneBase):
                 for k, p_ in pair.named_parameters():
                     grads[pre + k] = torch.zeros_like(p_).reshape(-1)
             # ---- ConvBlockE3 (convolution.py:116-160): node_out = residual(agg) + skip(node_in), agg = scatter_dst MP(node_in[src], node_in[dst], f_in)
+            if self.use_corr_prod:                              # CorrProductBlock between the ConvBlock's residual and the pair block
+                g_node, g_cp = self.corr_products[li].backward(t["node_res"], z, g_node)
+                put(f"corr_products.{li}.", g_cp)
             pre = f"convolutions.{li}."
             g_agg, g_res = conv.residual.backward(agg, g_node, extra_given=True)
             put(pre + "residual.", g_res)

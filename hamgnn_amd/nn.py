@@ -771,6 +771,35 @@ class CorrProductBlock(nn.Module):
         self._hdim = P.PlanarLayout(self.irreps_hidden).dim
         return self
 
+    def backward(self, node_planar, z, g_out):
+        """gradient of forward(node, z) for the gradient g_out of the rows it returned: (g_node, {parameter name: gradient}).
+        Linears: streaming-kernel adjoints + GEMM weight gradients; the symmetric contraction: hamgnn_amd/backward_corr.py."""
+        from .backward_corr import sym_contraction_backward
+        if self._tab is None:
+            self.compile(node_planar.device)
+        h = self.linear_pre(node_planar)
+        c = ops.sym_contraction(h, z, self.num_hidden, self._tab, self._W1, self._W2, self._hdim)
+        p = self.prod.linear(c)
+        grads = {"linear_out.weight": self.linear_out.weight_grad(p, g_out), }
+        g_p = self.linear_out.backward_data(g_out)
+        grads["prod.linear.weight"] = self.prod.linear.weight_grad(c, g_p)
+        g_c = self.prod.linear.backward_data(g_p)
+        g_h, gW1, gW2 = sym_contraction_backward(self._tab, h, z, self._W1, self._W2, self.num_hidden, g_c)
+        k1 = k2 = 0
+        for i, con in enumerate(self.prod.symmetric_contractions.contractions):   # the concatenated weights back to one block per target irrep
+            n1, n2 = con.weights[0].shape[1], con.weights_max.shape[1]
+            grads[f"prod.symmetric_contractions.contractions.{i}.weights.0"] = gW1[:, k1:k1 + n1]
+            grads[f"prod.symmetric_contractions.contractions.{i}.weights_max"] = gW2[:, k2:k2 + n2]
+            k1, k2 = k1 + n1, k2 + n2
+        grads["linear_pre.weight"] = self.linear_pre.weight_grad(node_planar, g_h)
+        g_node = self.linear_pre.backward_data(g_h)
+        if self.use_skip_connections:
+            grads["linear_sc.weight"] = self.linear_sc.weight_grad(node_planar, g_out)
+            g_node = g_node + self.linear_sc.backward_data(g_out)
+        else:
+            grads["linear_sc.weight"] = torch.zeros_like(self.linear_sc.weight).reshape(-1)
+        return g_node, grads
+
     def forward(self, node_planar, z):
         """returns the new planar node rows (the reference writes them back into the graph dict)"""
         if self._tab is None:

@@ -165,6 +165,13 @@ def test_full_model_backward_charge_doping():
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] >= 78, r
 
 
+def test_full_model_backward_corr_product():
+    """use_corr_prod: a CorrProductBlock (MACE symmetric contraction with element-dependent weights) after every ConvBlock"""
+    r = G.check_full_backward(n_atoms=5, seed=8, corr=True)
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] > 90, r
+
+
 def test_full_model_backward_default_irreps():
     """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
     r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)

@@ -378,6 +378,43 @@ def test_sym_contraction_tables_vs_oracle(golden_dir):
     assert rel(got, want.detach().numpy()) < 1e-6
 
 
+def test_sym_contraction_backward_vs_autograd(golden_dir):
+    """SURVEY 8f-3 x a21: gradients of the symmetric contraction (hamgnn_amd/backward_corr.py, sparse tables) with respect to the hidden
+    rows and the element-dependent weights vs torch.autograd through the oracle's dense einsums"""
+    import torch
+    from oracle import mace_ref as M
+    from hamgnn_amd.backward_corr import sym_contraction_backward
+    f = load(golden_dir, "corr_product_block")
+    irr, nh, nel = str(f["meta"]["irreps"]), int(f["meta"]["num_hidden"]), int(f["meta"]["num_elements"])
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        blk = M.CorrProductBlock(irr, nh, 2, nel, True)
+    finally:
+        torch.set_default_dtype(prev)
+    blk.load_state_dict({k: torch.as_tensor(v) for k, v in f["weights"].items()}, strict=False)
+    hid = P.corr_hidden_irreps(irr, nh)
+    tab = P.sym_contraction_tables(hid, 2)
+    cons = blk.prod.symmetric_contractions.contractions
+    lay = P.PlanarLayout(hid)
+    rng = np.random.default_rng(3)
+    N = 7
+    h = torch.from_numpy(rng.standard_normal((N, sum(m * (2 * l + 1) for m, l, _ in hid)))).requires_grad_()
+    z = torch.from_numpy(rng.integers(0, nel, size=N))
+    out = blk.prod.symmetric_contractions(M.reshape_irreps(blk.irreps_hidden, h), torch.nn.functional.one_hot(z, nel).double())
+    Gm = torch.from_numpy(rng.standard_normal(tuple(out.shape)))
+    (out * Gm).sum().backward()
+    W2 = torch.cat([c.weights_max.detach() for c in cons], 1)
+    W1 = torch.cat([c.weights[0].detach() for c in cons], 1)
+    hp = torch.from_numpy(lay.to_planar(h.detach().numpy()))
+    gp = torch.from_numpy(lay.to_planar(Gm.numpy()))
+    g_h, gW1, gW2 = sym_contraction_backward(tab, hp, z, W1, W2, nh, gp, chunk=3)
+    assert rel(lay.from_planar(g_h.numpy()), h.grad.numpy()) < 1e-6           # (the tables hold their coefficients in fp32)
+    want2 = torch.cat([c.weights_max.grad for c in cons], 1)
+    want1 = torch.cat([c.weights[0].grad for c in cons], 1)
+    assert rel(gW2.numpy(), want2.numpy()) < 1e-6 and rel(gW1.numpy(), want1.numpy()) < 1e-6
+
+
 def _random_irreps(rng, lmax):
     """random simplified irreps (distinct (l, p), sorted like the reference's configs: by l, odd/even in random order)"""
     out = []
