@@ -324,7 +324,10 @@ class MessagePackBlock(nn.Module):
         if getattr(self, "_plain_args", None) is None or self._dp.is_parts_for(rows) == 1:
             return self._dp
         if self._dp_plain is None:
-            sd, unrotate, skip_weight, device = self._plain_args
+            _, unrotate, skip_weight, device = self._plain_args
+            sd = _np_sd(self)                                  # the CURRENT weights (the merged program may have been refreshed since compile())
+            if skip_weight is not None and getattr(self, "_skip_source", None) is not None:
+                skip_weight = self._skip_source[0].weight.detach().cpu().double().numpy()
             prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
             try:
                 self._dp_plain = ops.DeviceProgram(prog, device, schedule="is")
@@ -489,6 +492,7 @@ class PairInteractionBlock(nn.Module):
             if self.use_skip_connections:
                 self.skip_linear.compile(device)
         else:
+            self.conv_tp._skip_source = (self.skip_linear,) if self.use_skip_connections else None   # (a tuple: not registered as a sub-module)
             self.conv_tp.compile(device, unrotate=False, skip_weight=skip)   # skip o3.Linear fused as extra items
             if self.use_skip_connections:
                 self.skip_linear._dp_adj = None                # its forward is fused above; only the backward uses the module's own tables
