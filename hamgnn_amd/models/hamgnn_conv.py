@@ -182,6 +182,56 @@ class _BackboneBase(nn.Module):
         return f
 
 
+    # ---- backward pieces shared by the two backbones
+    def _backward_pair(self, li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk):
+        """PairInteractionBlock (interaction_blocks.py:130-164): f_out = MP(up_src(node_out)[src], up_tar(node_out)[dst], f_in) + skip(f_in).
+        g_node: gradient of node_out so far, g_f: gradient of f_out (edge frame).  Returns (g_node, gradient of f_in); parameter
+        gradients go into `grads`."""
+        N = node_out.shape[0]
+        rp_r, pm_r = topo.receiver_csr()
+        rp_s, pm_s = topo.sender_csr()
+        pre = f"pair_interactions.{li}."
+        if pair.use_skip_connections or not pair.legacy_edge_update:
+            up_s, up_t = pair.linear_up_src(node_out), pair.linear_up_tar(node_out)
+            grads.update({pre + "conv_tp." + k: v for k, v in
+                          pair.conv_tp.backward_weights(up_s, up_t, f_in, geo, self._rot_tab, g_f, out_is_global=False, chunk=chunk).items()})
+            gs, gd, ge = pair.conv_tp.backward_data(g_f, geo, out_is_global=False)
+            g_up_s = ops.segment_sum(gs, rp_s, pm_s, N)
+            g_up_t = ops.segment_sum(gd, rp_r, pm_r, N)
+            grads[pre + "linear_up_src.weight"] = pair.linear_up_src.weight_grad(node_out, g_up_s)
+            grads[pre + "linear_up_tar.weight"] = pair.linear_up_tar.weight_grad(node_out, g_up_t)
+            g_node = g_node + pair.linear_up_src.backward_data(g_up_s) + pair.linear_up_tar.backward_data(g_up_t)
+            if pair.use_skip_connections:
+                grads[pre + "skip_linear.weight"] = pair.skip_linear.weight_grad(f_in, g_f)
+                ge = ge + pair.skip_linear.backward_data(g_f)
+            g_f = ge
+        else:                                                  # legacy layer 0: the block is not evaluated, its parameters get zeros
+            for k, p_ in pair.named_parameters():
+                grads[pre + k] = torch.zeros_like(p_).reshape(-1)
+        return g_node, g_f
+
+    def _backward_embeddings(self, data, rep, geo, g_node, g_f, grads, chunk):
+        """edge rows from the pair embedding, node rows = rows of the chemical embedding table (+ the charge-doping correction)"""
+        z = data.z.contiguous()
+        delta = rep.get("_charge_delta")                        # apply_charge_doping: node_attrs = one_hot(z) + delta
+        g_emb = self.pair_embedding.backward(z, geo, g_f, chunk=chunk, delta=delta)
+        g_delta = g_emb.pop("_g_delta", None)
+        grads.update({"pair_embedding." + k: v for k, v in g_emb.items()})
+        T, lay = self.num_types, self.layout
+        gtab = torch.zeros(T, lay.dim, device=g_node.device, dtype=g_node.dtype).index_add_(0, z.long(), g_node)
+        if delta is not None:                                   # node rows = (one_hot(z) + delta) @ table
+            gtab = gtab + delta.t() @ g_node
+            g_delta = g_delta + g_node @ self._chem.t()
+            # the charge MLP (8 -> 8 -> num_types, torch tensor ops in the forward too): its parameters through autograd on those few ops
+            with torch.enable_grad():
+                d = self.atomic_embedding.delta(gget(data, "doping_charge"), gget(data, "batch"), z.shape[0], z.device)
+                names, params = zip(*self.atomic_embedding.named_parameters())
+                for k, gp in zip(names, torch.autograd.grad(d, params, grad_outputs=g_delta.to(d.dtype), allow_unused=True)):
+                    grads["atomic_embedding." + k] = gp if gp is not None else torch.zeros_like(dict(self.atomic_embedding.named_parameters())[k])
+        gw = [gtab[:, lay.off[k]:lay.off[k] + mk].reshape(-1) / math.sqrt(T) for k, (mk, lk, pk) in enumerate(self.irreps_node_features) if (lk, pk) == (0, 1)]
+        grads["chemical_embedding.linear.weight"] = torch.cat(gw)
+
+
 class HamGNNConvE3(_BackboneBase):
     def __init__(self, config):
         super().__init__()
@@ -288,24 +338,7 @@ class HamGNNConvE3(_BackboneBase):
         for li in reversed(range(self.num_layers)):
             conv, pair, t = self.convolutions[li], self.pair_interactions[li], tape[li]
             node_in, f_in, agg, node_out = t["node_in"], t["f_in"], t["agg"], t["node_out"]
-            # ---- PairInteractionBlock (interaction_blocks.py:130-164): f_out = MP(up_src(node_out)[src], up_tar(node_out)[dst], f_in) + skip(f_in)
-            pre = f"pair_interactions.{li}."
-            if pair.use_skip_connections or not pair.legacy_edge_update:
-                up_s, up_t = pair.linear_up_src(node_out), pair.linear_up_tar(node_out)
-                put(pre + "conv_tp.", pair.conv_tp.backward_weights(up_s, up_t, f_in, geo, rot, g_f, out_is_global=False, chunk=chunk))
-                gs, gd, ge = pair.conv_tp.backward_data(g_f, geo, out_is_global=False)
-                g_up_s = ops.segment_sum(gs, rp_s, pm_s, N)
-                g_up_t = ops.segment_sum(gd, rp_r, pm_r, N)
-                grads[pre + "linear_up_src.weight"] = pair.linear_up_src.weight_grad(node_out, g_up_s)
-                grads[pre + "linear_up_tar.weight"] = pair.linear_up_tar.weight_grad(node_out, g_up_t)
-                g_node = g_node + pair.linear_up_src.backward_data(g_up_s) + pair.linear_up_tar.backward_data(g_up_t)
-                if pair.use_skip_connections:
-                    grads[pre + "skip_linear.weight"] = pair.skip_linear.weight_grad(f_in, g_f)
-                    ge = ge + pair.skip_linear.backward_data(g_f)
-                g_f = ge
-            else:                                              # legacy layer 0: the block is not evaluated, its parameters get zeros
-                for k, p_ in pair.named_parameters():
-                    grads[pre + k] = torch.zeros_like(p_).reshape(-1)
+            g_node, g_f = self._backward_pair(li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk)
             # ---- ConvBlockE3 (convolution.py:116-160): node_out = residual(agg) + skip(node_in), agg = scatter_dst MP(node_in[src], node_in[dst], f_in)
             if self.use_corr_prod:                              # CorrProductBlock between the ConvBlock's residual and the pair block
                 g_node, g_cp = self.corr_products[li].backward(t["node_res"], z, g_node)
@@ -319,22 +352,5 @@ class HamGNNConvE3(_BackboneBase):
             gs, gd, ge = conv.conv_tp.backward_data(g_agg, geo, out_is_global=True, gather=geo.dst)
             g_node = g_node_in + ops.segment_sum(gs, rp_s, pm_s, N) + ops.segment_sum(gd, rp_r, pm_r, N)
             g_f = g_f + ge
-        # ---- embeddings: edge rows from the pair embedding, node rows = rows of the chemical embedding table
-        delta = rep.get("_charge_delta")                        # apply_charge_doping: node_attrs = one_hot(z) + delta
-        g_emb = self.pair_embedding.backward(z, geo, g_f, chunk=chunk, delta=delta)
-        g_delta = g_emb.pop("_g_delta", None)
-        put("pair_embedding.", g_emb)
-        T, lay = self.num_types, self.layout
-        gtab = torch.zeros(T, lay.dim, device=g_node.device, dtype=g_node.dtype).index_add_(0, z.long(), g_node)
-        if delta is not None:                                   # node rows = (one_hot(z) + delta) @ table
-            gtab = gtab + delta.t() @ g_node
-            g_delta = g_delta + g_node @ self._chem.t()
-            # the charge MLP (8 -> 8 -> num_types, torch tensor ops in the forward too): its parameters through autograd on those few ops
-            with torch.enable_grad():
-                d = self.atomic_embedding.delta(gget(data, "doping_charge"), gget(data, "batch"), z.shape[0], z.device)
-                names, params = zip(*self.atomic_embedding.named_parameters())
-                for k, gp in zip(names, torch.autograd.grad(d, params, grad_outputs=g_delta.to(d.dtype), allow_unused=True)):
-                    grads["atomic_embedding." + k] = gp if gp is not None else torch.zeros_like(dict(self.atomic_embedding.named_parameters())[k])
-        gw = [gtab[:, lay.off[k]:lay.off[k] + mk].reshape(-1) / math.sqrt(T) for k, (mk, lk, pk) in enumerate(self.irreps_node_features) if (lk, pk) == (0, 1)]
-        grads["chemical_embedding.linear.weight"] = torch.cat(gw)
+        self._backward_embeddings(data, rep, geo, g_node, g_f, grads, chunk)
         return grads

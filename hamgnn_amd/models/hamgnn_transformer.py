@@ -40,15 +40,49 @@ class HamGNNTransformer(_BackboneBase):
         self._compile_common(dev)
         return self
 
-    def forward(self, data):
+    def forward(self, data, save_for_backward: bool = False):
+        """save_for_backward: keep the layer inputs on the result (`_tape`) for `backward`"""
         z, topo, geo, node, f = self._embed(data)
         shard = data.get("_hg_shard") if hasattr(data, "get") else None
         if shard is not None and shard[1] != 1:
             raise NotImplementedError("HamGNNTransformer on an edge-sharded graph: the per-node soft-max needs a max / sum exchange "
                                       "between the ranks that is not built (single-GPU only)")
         rowptr, perm = topo.receiver_csr()
+        tape = [] if save_for_backward else None
         for att, corr, pair in zip(self.orb_transformers, self.corr_products, self.pair_interactions):
+            if tape is not None:
+                tape.append(dict(node_in=node, f_in=f))
             node = att.run(node, f, geo, self._rot_tab, rowptr, perm)              # AttentionBlockE3.forward (attention.py:315-360)
+            if tape is not None:
+                tape[-1]["node_att"] = node
             node = corr(node, z)                                                    # CorrProductBlock.forward (interaction_blocks.py:234-260)
+            if tape is not None:
+                tape[-1]["node_out"] = node
             f = self._run_pair(pair, node, f, geo)
-        return self._representation(node, f, geo)
+        rep = self._representation(node, f, geo)
+        if tape is not None:
+            rep["_tape"] = tape
+            if self._last_delta is not None:
+                rep["_charge_delta"] = self._last_delta
+        return rep
+
+    # ------------------------------------------------------------------------------------------------------------ backward (SURVEY 8f-3 x 8f-4)
+    def backward(self, data, rep, g_node, g_edge_rot, chunk: int = 65536):
+        """as HamGNNConvE3.backward: gradients of every backbone parameter for the gradients of the representation (planar node rows,
+        edge-frame edge rows); per layer, last to first: PairInteractionBlock -> CorrProductBlock -> AttentionBlockE3; then the embeddings."""
+        from ..topo import get_topology
+        tape, geo = rep["_tape"], rep["_geometry"]
+        z = data.z.contiguous()
+        topo = get_topology(data)
+        grads = {}
+        g_node, g_f = g_node.contiguous(), g_edge_rot.contiguous()
+        for li in reversed(range(self.num_layers)):
+            att, corr, pair, t = self.orb_transformers[li], self.corr_products[li], self.pair_interactions[li], tape[li]
+            g_node, g_f = self._backward_pair(li, pair, t["node_out"], t["f_in"], geo, topo, g_node, g_f, grads, chunk)
+            g_node, g_cp = corr.backward(t["node_att"], z, g_node)
+            grads.update({f"corr_products.{li}." + k: v for k, v in g_cp.items()})
+            g_node, g_f_att, g_at = att.backward(t["node_in"], t["f_in"], geo, self._rot_tab, topo, g_node, chunk=chunk)
+            grads.update({f"orb_transformers.{li}." + k: v for k, v in g_at.items()})
+            g_f = g_f + g_f_att
+        self._backward_embeddings(data, rep, geo, g_node, g_f, grads, chunk)
+        return grads

@@ -473,6 +473,42 @@ class AttentionBlockE3(nn.Module):
         return self.residual(agg, extra=sc)
 
 
+    def backward(self, node, f, geo: ops.Geometry, rot_tab, topo, g_out, chunk: int = 65536):
+        """gradient of run(node, f, ...) for the gradient g_out of the node rows it returned: (g_node, g_f (edge frame), {parameter name:
+        gradient}).  ResidualBlock / Linears: the streaming-kernel adjoints; the attention aggregation (soft-max over incoming edges, the
+        learnable soft cutoff): hamgnn_amd/backward_attn.py; the value MessagePackBlock: its adjoint / materialisation programs, with the
+        sender / receiver segment sums for the two gathered node inputs."""
+        from .backward_attn import attention_backward
+        N = node.shape[0]
+        K = self.linear_key(node)
+        us, ut, ue = self.linear_up_src(node), self.linear_up_tar(node), self.linear_up_edge(f)
+        value = self.conv_tp_value.run_nodes(us, ut, ue, geo, rot_tab)                 # [E, Dp], global frame
+        rowptr, perm = topo.receiver_csr()
+        agg = ops.attention_aggregate(K, value, geo, rowptr, perm, self._head_tab, self.num_heads, self.head_dim, self._cut, self.cutoff)
+        grads = {}
+        g_agg, g_res = self.residual.backward(agg, g_out, extra_given=True)
+        grads.update({"residual." + k: v for k, v in g_res.items()})
+        grads["skip_linear.weight"] = self.skip_linear.weight_grad(node, g_out)
+        g_node = self.skip_linear.backward_data(g_out)
+        g_K, g_V, g_p = attention_backward(K, value, g_agg, geo.src, geo.dst, geo.length, self._head_tab, self.num_heads, self.head_dim,
+                                           self._cut, self.cutoff)
+        grads["cutoff_func.cut_param"] = g_p.reshape(())
+        grads["linear_key.weight"] = self.linear_key.weight_grad(node, g_K)
+        grads["linear_query.weight"] = torch.zeros_like(self.linear_query.weight)     # a parameter the reference's forward never reads
+        g_node = g_node + self.linear_key.backward_data(g_K.contiguous())
+        g_V = g_V.contiguous()
+        grads.update({"conv_tp_value." + k: v for k, v in
+                      self.conv_tp_value.backward_weights(us, ut, ue, geo, rot_tab, g_V, out_is_global=True, chunk=chunk).items()})
+        gs, gd, ge = self.conv_tp_value.backward_data(g_V, geo, out_is_global=True)
+        g_us = ops.segment_sum(gs, *topo.sender_csr(), N)
+        g_ut = ops.segment_sum(gd, rowptr, perm, N)
+        grads["linear_up_src.weight"] = self.linear_up_src.weight_grad(node, g_us)
+        grads["linear_up_tar.weight"] = self.linear_up_tar.weight_grad(node, g_ut)
+        grads["linear_up_edge.weight"] = self.linear_up_edge.weight_grad(f, ge)
+        g_node = g_node + self.linear_up_src.backward_data(g_us) + self.linear_up_tar.backward_data(g_ut)
+        return g_node, self.linear_up_edge.backward_data(ge), grads
+
+
 class PairInteractionBlock(nn.Module):
     def __init__(self, irreps, irreps_sh, num_radial, radial_MLP, use_skip_connections=True, legacy_edge_update=False, lite_mode=False):
         super().__init__()

@@ -283,7 +283,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -301,11 +301,13 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
         cfg.update(apply_charge_doping=True, num_charge_attr_feas=8)
     if corr:
         cfg.update(use_corr_prod=True)
+    if transformer:                                            # HamGNNTransformer: attention blocks, CorrProductBlock always on
+        cfg.update(num_heads=2)
     torch.manual_seed(seed)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
-        rb = R.HamGNNConvE3(cfg)
+        rb = R.HamGNNTransformer(cfg) if transformer else R.HamGNNConvE3(cfg)
         if charge:                                             # xavier / zero-bias init leaves the charge MLP tiny: make the correction matter
             with torch.no_grad():
                 for p_ in rb.atomic_embedding.parameters():
@@ -329,7 +331,11 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     diff = Href - target
     loss_ref = (diff * diff).mean() if metric == "mse" else diff.abs().mean()
     loss_ref.backward()
-    model = Model(load_weights(HamGNNConvE3(cfg), dict(rb.state_dict())),
+    if transformer:
+        from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer as Backbone
+    else:
+        Backbone = HamGNNConvE3
+    model = Model(load_weights(Backbone(cfg), dict(rb.state_dict())),
                   load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
                                                  calculate_sparsity=False, zero_point_shift=False, **(skw if soc else dict(soc_switch=False))),
                                dict(rh.state_dict()))).to(device)

@@ -172,6 +172,13 @@ def test_full_model_backward_corr_product():
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] > 90, r
 
 
+def test_full_model_backward_transformer():
+    """HamGNNTransformer: attention blocks (soft-max over incoming edges, learnable soft cutoff, value MessagePackBlock) + CorrProductBlocks"""
+    r = G.check_full_backward(n_atoms=5, seed=9, transformer=True, irr="8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o")
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] > 120, r
+
+
 def test_full_model_backward_default_irreps():
     """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
     r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)

@@ -32,3 +32,35 @@ def test_soc_fold_is_the_adjoint_of_the_spin_assembly(sym):
     ((real * Gr).sum() + (imag * Gi).sum()).backward()
     gk, gh = HamGNNPlusPlusOut._soc_fold(Head, Gr, Gi, L, inv)
     assert float((gk - ksi.grad).abs().max()) < 1e-12 and float((gh - H.grad).abs().max()) < 1e-12
+
+
+def test_attention_backward_vs_autograd_through_the_oracle():
+    """hamgnn_amd/backward_attn.py (planar rows, column -> head table) vs autograd through the oracle's AttentionAggregation
+    (hamgnn/nn/attention.py:91-164) incl. the learnable soft cutoff"""
+    import numpy as np
+    from oracle import hamgnn_ref as R
+    from hamgnn_amd import plan as P
+    from hamgnn_amd.backward_attn import attention_backward
+    torch.manual_seed(1)
+    irr, H = "8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o", 2
+    lay = P.PlanarLayout(irr)
+    D = P.Irreps(irr).dim
+    N, E, rc = 5, 23, 6.0
+    gen = torch.Generator().manual_seed(2)
+    src, dst = torch.randint(0, N, (E,), generator=gen), torch.randint(0, N, (E,), generator=gen)
+    K = torch.randn(N, D, generator=gen, dtype=torch.float64).requires_grad_()
+    V = torch.randn(E, D, generator=gen, dtype=torch.float64).requires_grad_()
+    length = 0.5 + 6.5 * torch.rand(E, generator=gen, dtype=torch.float64)        # some edges beyond the cutoff (cut = 0)
+    p = torch.tensor(3.0, dtype=torch.float64, requires_grad=True)
+    att = R.AttentionAggregation(H, irr)
+    cut = R.soft_unit_step(p * (1.0 - length / rc))
+    out = att(K[src], V, K[dst], cut, torch.stack([src, dst]), N)
+    G = torch.randn(N, D, generator=gen, dtype=torch.float64)
+    (out * G).sum().backward()
+    tab, hd = P.attention_head_table(irr, H)
+    pl = lambda t: torch.from_numpy(lay.to_planar(t.detach().numpy()))
+    gK, gV, gp = attention_backward(pl(K), pl(V), pl(G), src, dst, length, torch.from_numpy(tab), H, hd, p.detach(), rc)
+    rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert rel(lay.from_planar(gK.numpy()), K.grad.numpy()) < 1e-10
+    assert rel(lay.from_planar(gV.numpy()), V.grad.numpy()) < 1e-10
+    assert abs(float(gp) - float(p.grad)) < 1e-10 * max(1.0, abs(float(p.grad)))
