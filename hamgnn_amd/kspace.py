@@ -100,6 +100,60 @@ def assemble_k(on, off, data, k_vecs_c, n0, n, e0, e, orank_all, nao):
                            k_vecs_c.contiguous().float(), ptr, order.contiguous(), pij, n, nao, orank, ooff, M), M
 
 
+def _compact_index(orank_all, n0, n):
+    """[n, nao] compact orbital index of (atom, orbital) inside one crystal, or -1"""
+    orank = orank_all[n0:n0 + n]
+    norb = (orank >= 0).sum(1)
+    ooff = torch.cumsum(norb, 0) - norb
+    return torch.where(orank >= 0, ooff[:, None] + orank, torch.full_like(orank, -1)).long()
+
+
+def assemble_k_adjoint(G, data, k_vecs_c, n0, n, e0, e, orank_all, nao):
+    """Adjoint of assemble_k (hg_hk_assemble) for one crystal: G [nk, M, M] complex = the gradient of a real loss with respect to H(k) in
+    torch's convention (d/dRe + i d/dIm) -> (g_on [n, nao^2], g_off [e, nao^2]) real.  With H(k)[(i a), (j b)] = on_i[a, b] delta_ij +
+    sum_{e: i -> j} exp(2 pi i k . shift_e) off_e[a, b]:  g_off_e[a, b] = sum_k Re(conj(phase_k(e)) G_k[(i a), (j b)]).  Gathers and
+    one complex multiply-reduce per chunk of k (torch tensor ops; device-agnostic, checked on CPU against autograd)."""
+    comp = _compact_index(orank_all, n0, n)                    # [n, nao]
+    src = (data.edge_index[0][e0:e0 + e] - n0).long()
+    dst = (data.edge_index[1][e0:e0 + e] - n0).long()
+    nk = G.shape[0]
+    rdt = G.real.dtype
+    ok_on = ((comp[:, :, None] >= 0) & (comp[:, None, :] >= 0)).to(rdt)
+    Gon = G[:, comp.clamp(min=0)[:, :, None], comp.clamp(min=0)[:, None, :]]                # [nk, n, nao, nao]
+    g_on = (Gon.real.sum(0) * ok_on).reshape(n, nao * nao)
+    R, Cc = comp[src], comp[dst]
+    ok = ((R[:, :, None] >= 0) & (Cc[:, None, :] >= 0)).to(rdt)
+    shift = data.nbr_shift[e0:e0 + e].to(torch.float64)
+    ph = 2.0 * math.pi * (k_vecs_c.to(torch.float64)[:, None, :] * shift[None, :, :]).sum(-1)      # [nk, e] in double (see the kernel)
+    cph = torch.complex(torch.cos(ph), -torch.sin(ph)).to(G.dtype)                               # conj(phase)
+    g_off = torch.zeros(e, nao, nao, device=G.device, dtype=rdt)
+    for k0 in range(0, nk, 8):
+        Ge = G[k0:k0 + 8][:, R.clamp(min=0)[:, :, None], Cc.clamp(min=0)[:, None, :]]          # [<=8, e, nao, nao]
+        g_off += (cph[k0:k0 + 8][:, :, None, None] * Ge).real.sum(0)
+    return g_on, (g_off * ok).reshape(e, nao * nao)
+
+
+def _eig_chain(head, Hk, Sk, val_c, z_c):
+    """generalized eigenproblem through the Cholesky factor of S(k), as the reference (:1911-1928) -> (evals, evecs, Ht, gap)"""
+    L = torch.linalg.cholesky(Sk)
+    Linv = torch.linalg.inv(L)
+    LHinv = torch.linalg.inv(L.conj().transpose(-1, -2))
+    Ht = torch.bmm(torch.bmm(Linv, Hk), LHinv)
+    evals, evecs = torch.linalg.eigh(Ht)
+    evecs = torch.einsum("ijk,ika->iaj", LHinv, evecs)
+    half = math.ceil(float(val_c.sum()) / 2)
+    gap = (evals[:, half].min() - evals[:, half - 1].max()).reshape(1)
+    bnc = head.band_num_control
+    if bnc is not None:
+        if isinstance(bnc, dict):
+            nb = int(sum(int(bnc.get(int(zz), bnc.get(str(int(zz)), 0))) for zz in z_c.tolist()))
+            evals, evecs = evals[:, :nb], evecs[:, :nb, :]
+        else:
+            win = max(1, int(bnc * half)) if isinstance(bnc, float) else min(int(bnc), half)
+            evals, evecs = evals[:, half - win:half + win], evecs[:, half - win:half + win, :]
+    return evals, evecs, Ht, gap
+
+
 def band_energies(head, onsite_hamiltonian, offsite_hamiltonian, data, k_vecs: Optional[torch.Tensor] = None):
     """calculate_band_energies(onsite, offsite, data) of the reference (:1675-1996, export_reciprocal_values=False): returns
     (band_energy [sum_c bands_c, num_k], wavefunction (flattened), band_gap [n_crystals], H_sym (flattened))."""
@@ -110,32 +164,45 @@ def band_energies(head, onsite_hamiltonian, offsite_hamiltonian, data, k_vecs: O
         raise ValueError("band_energies: no k-vectors (data.k_vecs)")
     k_vecs = k_vecs.to(dev)
     z = data.z
-    orank_tab = head._orank.to(dev)                            # [119, nao] rank of an orbital in its element's valid set or -1
-    orank_all = orank_tab[z]
+    orank_all = head._orank.to(dev)[z]                         # [N, nao] rank of an orbital in its element's valid set or -1
     val = head._num_valence.to(dev)[z].to(torch.float64)
     energies, waves, gaps, hsyms = [], [], [], []
     Son, Soff = data.Son.contiguous().float(), data.Soff.contiguous().float()
     for c, (n0, n, e0, e) in enumerate(_crystal_slices(data)):
         Hk, M = assemble_k(onsite_hamiltonian, offsite_hamiltonian, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
         Sk, _ = assemble_k(Son, Soff, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
-        # generalized eigenproblem through the Cholesky factor of S(k), as the reference (:1911-1928)
-        L = torch.linalg.cholesky(Sk)
-        Linv = torch.linalg.inv(L)
-        LHinv = torch.linalg.inv(L.conj().transpose(-1, -2))
-        Ht = torch.bmm(torch.bmm(Linv, Hk), LHinv)
-        evals, evecs = torch.linalg.eigh(Ht)
-        evecs = torch.einsum("ijk,ika->iaj", LHinv, evecs)
-        half = math.ceil(float(val[n0:n0 + n].sum()) / 2)
-        gaps.append((evals[:, half].min() - evals[:, half - 1].max()).reshape(1))
-        bnc = head.band_num_control
-        if bnc is not None:
-            if isinstance(bnc, dict):
-                nb = int(sum(int(bnc.get(int(zz), bnc.get(str(int(zz)), 0))) for zz in z[n0:n0 + n].tolist()))
-                evals, evecs = evals[:, :nb], evecs[:, :nb, :]
-            else:
-                win = max(1, int(bnc * half)) if isinstance(bnc, float) else min(int(bnc), half)
-                evals, evecs = evals[:, half - win:half + win], evecs[:, half - win:half + win, :]
+        evals, evecs, Ht, gap = _eig_chain(head, Hk, Sk, val[n0:n0 + n], z[n0:n0 + n])
+        gaps.append(gap)
         energies.append(evals.transpose(-1, -2))
         waves.append(evecs.reshape(-1))
         hsyms.append(Ht.reshape(-1))
     return torch.cat(energies, 0), torch.cat(waves, 0), torch.cat(gaps, 0), torch.cat(hsyms, 0)
+
+
+def band_energy_backward(head, onsite_hamiltonian, offsite_hamiltonian, data, cotangent, k_vecs: Optional[torch.Tensor] = None):
+    """gradient of sum(band_energy * cotangent) with respect to the real-space blocks (the band-energy loss of the reference's second
+    training stage, Model.py:150-196 with prediction: band_energy): H(k) from the assembly kernel, the Cholesky / eigh chain
+    differentiated by torch.autograd (library solvers, as in the forward), then the assembly's adjoint.  Returns (g_on, g_off)."""
+    nao = head.nao_max
+    dev = onsite_hamiltonian.device
+    k_vecs = (gget(data, "k_vecs") if k_vecs is None else k_vecs).to(dev)
+    z = data.z
+    orank_all = head._orank.to(dev)[z]
+    val = head._num_valence.to(dev)[z].to(torch.float64)
+    Son, Soff = data.Son.contiguous().float(), data.Soff.contiguous().float()
+    g_on = torch.zeros_like(onsite_hamiltonian)
+    g_off = torch.zeros_like(offsite_hamiltonian)
+    row = 0
+    for c, (n0, n, e0, e) in enumerate(_crystal_slices(data)):
+        Hk, M = assemble_k(onsite_hamiltonian, offsite_hamiltonian, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        Sk, _ = assemble_k(Son, Soff, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        with torch.enable_grad():
+            Hk = Hk.detach().requires_grad_()
+            evals = _eig_chain(head, Hk, Sk, val[n0:n0 + n], z[n0:n0 + n])[0].transpose(-1, -2)     # [bands, nk]
+            nb = evals.shape[0]
+            (G,) = torch.autograd.grad((evals * cotangent[row:row + nb].to(evals.dtype)).sum(), Hk)
+        row += nb
+        a, b = assemble_k_adjoint(G, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        g_on[n0:n0 + n] = a
+        g_off[e0:e0 + e] = b
+    return g_on, g_off

@@ -102,7 +102,7 @@ def _invalidate(module):
 
 
 @torch.no_grad()
-def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tensor] = None, losses=None) -> Dict[str, torch.Tensor]:
     """One loss / gradient evaluation of the WHOLE model (HamGNNConvE3 backbone + non-SOC HamGNNPlusPlusOut head): forward with the
     layer inputs kept, loss(hamiltonian, target), backward through head and backbone on the GPU kernels, `.grad` of every parameter set
     (accumulated if already present).  The caller owns the optimiser (`opt.step(); opt.zero_grad()`); all packed weights are dropped
@@ -115,7 +115,30 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
     if tgt is None:
         raise ValueError("training_step: the batch carries no target (Hon / Hoff or hamiltonian)")
     H = out["hamiltonian"]
-    loss, gH = _loss_and_grad(H, tgt.to(H.dtype), metric)
+    if losses is None:
+        loss, gH = _loss_and_grad(H, tgt.to(H.dtype), metric)
+    else:
+        # the reference's `losses` list (Model.py:150-196): [{metric, prediction, target, loss_weight}] over `hamiltonian` and / or
+        # `band_energy` (the second training stage: bands of H(k) against the bands of the target Hamiltonian)
+        loss, gH = H.new_zeros(()), torch.zeros_like(H)
+        for spec in losses:
+            w, pred = float(spec.get("loss_weight", 1.0)), spec["prediction"]
+            if pred == "hamiltonian":
+                li, gi = _loss_and_grad(H, tgt.to(H.dtype), spec["metric"])
+                gH += w * gi
+            elif pred == "band_energy":
+                from . import kspace
+                if out.get("band_energy") is None:
+                    raise ValueError("a band_energy loss needs HamGNNPlusPlusOut(calculate_band_energy=True)")
+                be = out["band_energy"]
+                li, gbe = _loss_and_grad(be, gget(batch, spec.get("target", "band_energy")).to(be.dtype), spec["metric"])
+                edge_counts = head._global_inverse(batch)[1]
+                on, off = head._split_by_crystal(batch, H, edge_counts)
+                g_on, g_off = kspace.band_energy_backward(head, on.contiguous(), off.contiguous(), batch, w * gbe)
+                gH += head._cat_by_crystal(batch, g_on, g_off, edge_counts)
+            else:
+                raise ValueError(f"training_step: losses on {pred!r} are not built (hamiltonian | band_energy)")
+            loss = loss + w * li
     g_node, g_edge, g_head = head.backward(batch, rep, gH)
     g_back = backbone.backward(batch, rep, g_node, g_edge)
     for mod, grads in ((head, g_head), (backbone, g_back)):

@@ -563,8 +563,20 @@ def main():
     lat0 = Gb["cell"][0].numpy()
     kv_ref, _, _, lpi_ref = ref_kp.kpoints_generator(dim_k=3, lat=lat0).k_path(nodes, 23)
     keys = ("z", "pos", "cell", "edge_index", "nbr_shift", "inv_edge_idx", "batch", "node_counts", "Son", "Soff", "k_vecs")
+    be_w3 = refk.calculate_band_energies(Hon, Hoff, Graph(Gb))[0]
+    # gradient of the band energies with respect to the real-space blocks (the band-energy loss of the reference's second training stage,
+    # Model.py:150-196 with prediction: band_energy): autograd through the REFERENCE's calculate_band_energies for a random cotangent
+    refk.band_num_control = minek.band_num_control = None
+    cot = f32(torch.randn(be_r.shape, generator=genk, dtype=torch.float64))
+    grads_k = []
+    for mod, gr in ((refk, Graph(Gb)), (minek, Gb)):
+        a, b = Hon.clone().requires_grad_(), Hoff.clone().requires_grad_()
+        (mod.calculate_band_energies(a, b, gr)[0] * cot).sum().backward()
+        grads_k.append((a.grad, b.grad))
+    _check(grads_k[1][0], grads_k[0][0], "d band_energy / d Hon (autograd, oracle vs reference)", tol=1e-8)
+    _check(grads_k[1][1], grads_k[0][1], "d band_energy / d Hoff (autograd, oracle vs reference)", tol=1e-8)
     _save("band_energies_openmx_13", kpath=dict(nodes=np.asarray(nodes), nk=np.asarray(23), lat=lat0, k_vec=kv_ref, lat_per_inv=lpi_ref), graph={k: (Gb[k].float() if Gb[k].is_floating_point() else Gb[k]) for k in keys}, inputs=dict(Hon=Hon.float(), Hoff=Hoff.float()),
-          outputs=dict(band_energy=be_r, band_gap=gap_r, band_energy_window3=refk.calculate_band_energies(Hon, Hoff, Graph(Gb))[0]))
+          outputs=dict(band_energy=be_r, band_gap=gap_r, band_energy_window3=be_w3, band_cotangent=cot, g_Hon=grads_k[0][0], g_Hoff=grads_k[0][1]))
 
     # ---- 7. CorrProductBlock (optional MACE-style correlation product; interaction_blocks.py:168-260) ---------------
     print("CorrProductBlock")

@@ -1315,6 +1315,54 @@ def check_attribute_style_graph(device="cuda"):
     return res
 
 
+def check_band_energy_backward(device="cuda"):
+    """band-energy loss (training stage 2 of the reference, Model.py:150-196 with prediction: band_energy): (1) kspace.band_energy_backward
+    -- assembly kernel, complex64 Cholesky / eigh chain under autograd, assembly adjoint -- vs the REFERENCE's autograd gradient (fixture,
+    fp64); (2) training_step with losses = [hamiltonian, band_energy] on a whole model: finite gradients for every parameter and a loss that
+    falls under Adam."""
+    from hamgnn_amd import kspace
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    from hamgnn_amd.training import training_step
+    f = load("band_energies_openmx_13")
+    head = HamGNNPlusPlusOut("4x0e", "4x0e", nao_max=13, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, soc_switch=False,
+                             calculate_band_energy=True, num_k=5, k_path=None, calculate_sparsity=False)
+    head.compile(device)
+    g = to_graph(f["graph"], device)
+    Hon, Hoff = (torch.from_numpy(f["inputs"][k]).float().to(device) for k in ("Hon", "Hoff"))
+    cot = torch.from_numpy(f["outputs"]["band_cotangent"]).float().to(device)
+    g_on, g_off = kspace.band_energy_backward(head, Hon, Hoff, g, cot)
+    torch.cuda.synchronize()
+    res = {"g_on_rel_err": rel(g_on, f["outputs"]["g_Hon"]), "g_off_rel_err": rel(g_off, f["outputs"]["g_Hoff"])}
+    # whole model with both losses
+    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False)
+    torch.manual_seed(31)
+    model = Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(MINI, MINI, nao_max=13, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                                       soc_switch=False, calculate_sparsity=False, zero_point_shift=False,
+                                                       calculate_band_energy=True, num_k=4, k_path=None)).to(device)
+    gt = S.add_random_targets(S.random_cell(4, [6, 8, 1], seed=3, density=0.004), 13, seed=3)
+    gt["Son"] = torch.eye(13).reshape(1, -1).repeat(gt.num_nodes, 1)                   # S(k) = 1 (Soff = 0): positive definite
+    gt = gt.to(device)
+    losses = [{"metric": "mae", "prediction": "hamiltonian", "target": "hamiltonian", "loss_weight": 1.0},
+              {"metric": "mae", "prediction": "band_energy", "target": "band_energy", "loss_weight": 0.1}]
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    hist = []
+    for _ in range(6):
+        np.random.seed(0)                                       # the same random k-points every step
+        r = training_step(model, gt, losses=losses)
+        hist.append(float(r["loss"]))
+        finite = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+        opt.step()
+        opt.zero_grad()
+    torch.cuda.synchronize()
+    res.update(losses=hist, grads_finite=finite)
+    return res
+
+
 def check_band_energies(device="cuda"):
     """k-space step (hg_hk_assemble + hipSOLVER through torch.linalg) vs the reference's calculate_band_energies output (fixture), fp32
     complex64 on the GPU against the fp64 reference; and the head's forward with calculate_band_energy=True (random k: shapes, finiteness,

@@ -348,6 +348,13 @@ def test_si2_default_irreps_vs_oracle(which):
     assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL and r["Hnet_rel_err"] < G.TOL
 
 
+def test_band_energy_loss_backward():
+    r = G.check_band_energy_backward()
+    print(r)
+    assert r["g_on_rel_err"] < 1e-4 and r["g_off_rel_err"] < 1e-4          # complex64 Cholesky / inverse / eigh chain vs the fp64 reference (measured 4e-6)
+    assert r["grads_finite"] and r["losses"][-1] < r["losses"][0], r
+
+
 def test_band_energies_k_space_step():
     """calculate_band_energy=True (non-SOC, reference overlaps) -- H(k) / S(k) assembly kernel + hipSOLVER eigensolver vs the
     reference's output; fp32 complex arithmetic on the GPU against fp64: eigenvalues to 1e-4 of the spectrum's scale"""

@@ -64,3 +64,38 @@ def test_attention_backward_vs_autograd_through_the_oracle():
     assert rel(lay.from_planar(gK.numpy()), K.grad.numpy()) < 1e-10
     assert rel(lay.from_planar(gV.numpy()), V.grad.numpy()) < 1e-10
     assert abs(float(gp) - float(p.grad)) < 1e-10 * max(1.0, abs(float(p.grad)))
+
+
+def test_k_space_assembly_adjoint_vs_autograd():
+    """kspace.assemble_k_adjoint vs autograd through a dense restatement of the H(k) assembly (padded [nk, n, n, nao, nao] blocks with
+    index_put(accumulate) and masked_select to the compact basis -- the reference's formulation, hamgnn_output.py:1779-1905)"""
+    import math
+    import numpy as np
+    from hamgnn_amd import kspace
+    from hamgnn_amd.data import synthetic as S
+    g = S.random_cell(4, [6, 1, 8], seed=5, density=0.004)
+    n, e, nao, nk = g.num_nodes, g.num_edges, 5, 3
+    gen = torch.Generator().manual_seed(0)
+    valid = {6: [0, 1, 2, 3, 4], 1: [0, 2], 8: [0, 1, 3, 4]}                       # element -> orbitals it has
+    orank_all = torch.full((n, nao), -1, dtype=torch.int64)
+    for i, zz in enumerate(g.z.tolist()):
+        orank_all[i, valid[zz]] = torch.arange(len(valid[zz]))
+    on = torch.randn(n, nao * nao, generator=gen, dtype=torch.float64, requires_grad=True)
+    off = torch.randn(e, nao * nao, generator=gen, dtype=torch.float64, requires_grad=True)
+    kv = 0.1 * torch.randn(nk, 3, generator=gen, dtype=torch.float64)
+    src, dst = g.edge_index
+    phase = torch.exp(2j * math.pi * (g.nbr_shift.double()[:, None, :] * kv[None, :, :]).sum(-1))                # [e, nk]
+    Hk = torch.zeros(nk, n, n, nao, nao, dtype=torch.complex128)
+    ar = torch.arange(n)
+    Hk[:, ar, ar] += on.reshape(-1, nao, nao)[None].to(torch.complex128)
+    Ho = off.reshape(-1, nao, nao).to(torch.complex128)
+    Hk = torch.stack([torch.index_put(Hk[k], (src, dst), phase[:, k][:, None, None] * Ho, accumulate=True) for k in range(nk)])
+    Hk = Hk.swapaxes(-2, -3).reshape(nk, n * nao, n * nao)
+    m = (orank_all >= 0).reshape(-1)
+    M = int(m.sum())
+    Hc = torch.masked_select(Hk, (m[:, None] & m[None, :])[None].expand(nk, -1, -1)).reshape(nk, M, M)
+    G = torch.complex(torch.randn(nk, M, M, generator=gen, dtype=torch.float64), torch.randn(nk, M, M, generator=gen, dtype=torch.float64))
+    (Hc.real * G.real + Hc.imag * G.imag).sum().backward()
+    g_on, g_off = kspace.assemble_k_adjoint(G, g, kv, 0, n, 0, e, orank_all, nao)
+    assert float((g_on - on.grad).abs().max()) < 1e-12 and float((g_off - off.grad).abs().max()) < 1e-12
+    assert float(off.grad.abs().max()) > 0.1 and float((g_off.reshape(e, nao, nao)[:, 1, :].abs().sum(1) == 0).float().mean()) > 0   # masked orbitals
