@@ -193,3 +193,17 @@ def test_w3j_reproduces_real_gaunt_integrals(w3j_table):
         assert nz.any() and (np.abs(G[~nz]) < 1e-12).all(), (l1, l2, l3)
         ratio = G[nz] / W[nz]
         assert np.abs(ratio - ratio[0]).max() < 1e-10 * abs(ratio[0]), (l1, l2, l3)
+
+
+def test_normalize2mom_constants_are_second_moment_normalisers():
+    """e3nn's normalize2mom(act) = E_{z ~ N(0,1)}[act(z)^2]^(-1/2), estimated by e3nn with 1e6 Monte-Carlo samples (CPU seed 0).  The
+    shipped constants (hamgnn_amd.plan.ACT_CONSTS; reproduced with e3nn's recipe in tests/test_oracle_e3.py) must agree with the EXACT
+    integral to the Monte-Carlo error (~1e-3): an independent check that they are what their definition says, not a mis-remembered number."""
+    import numpy as np
+    from scipy import integrate
+    from hamgnn_amd import plan as P
+    pdf = lambda z: np.exp(-z * z / 2) / np.sqrt(2 * np.pi)
+    acts = {P.ACT_SILU: lambda z: z / (1 + np.exp(-z)), P.ACT_TANH: np.tanh, P.ACT_SSP: lambda z: np.log1p(np.exp(z)) - np.log(2.0), P.ACT_ABS: np.abs}
+    for aid, f in acts.items():
+        exact = integrate.quad(lambda z: f(z) ** 2 * pdf(z), -12, 12)[0] ** -0.5
+        assert abs(exact / float(P.ACT_CONSTS[aid]) - 1) < 3e-3, (aid, exact, P.ACT_CONSTS[aid])
