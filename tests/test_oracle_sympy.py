@@ -207,3 +207,57 @@ def test_normalize2mom_constants_are_second_moment_normalisers():
     for aid, f in acts.items():
         exact = integrate.quad(lambda z: f(z) ** 2 * pdf(z), -12, 12)[0] ** -0.5
         assert abs(exact / float(P.ACT_CONSTS[aid]) - 1) < 3e-3, (aid, exact, P.ACT_CONSTS[aid])
+
+
+def test_tensor_product_and_linear_preserve_unit_second_moments():
+    """e3nn's documented normalisation contract (irrep_normalization='component', path_normalization='element'): with inputs whose
+    components have unit second moment and weights ~ N(0, 1), every output component of a weighted 'uvw' TensorProduct path and of an
+    o3.Linear has unit second moment.  The oracle's restatement (oracle/e3.py) is checked against that PROPERTY with the reference's own
+    instruction rule -- a wrong sqrt(2l+1) / fan-in / path-count factor recalled from memory would show as a moment of 2l+1, 1/fan, ..."""
+    import torch
+    from oracle import e3, hamgnn_ref as R
+    torch.manual_seed(0)
+    irr_in, sh, irr_out = "16x0e+8x1o+8x1e+4x2e+4x2o", "0e+1o+2e", "16x0e+8x1o+4x2e"
+    irreps_mid, ins = R.tp_instructions(irr_in, sh, irr_out, "uvw", True)
+    D = e3.Irreps(irr_in).dim
+    acc_tp, acc_lin, T = 0, 0, 160
+    for _ in range(T):
+        tp = e3.TensorProduct(irr_in, sh, irreps_mid, ins, internal_weights=True, shared_weights=True)
+        x = torch.randn(128, D)
+        n = torch.nn.functional.normalize(torch.randn(128, 3), dim=-1)
+        acc_tp = acc_tp + tp(x, e3.spherical_harmonics([0, 1, 2], n, True, "component")).pow(2).mean(0)
+        acc_lin = acc_lin + e3.Linear(irr_in, irr_out)(x).pow(2).mean(0)
+    o = 0
+    for mul, ir in e3.Irreps(irreps_mid):                       # one mid irrep per path (the reference's instruction rule)
+        d = mul * ir.dim
+        assert abs(float((acc_tp / T)[o:o + d].mean()) - 1.0) < 0.08, (str(ir), float((acc_tp / T)[o:o + d].mean()))
+        o += d
+    o = 0
+    for mul, ir in e3.Irreps(irr_out):
+        d = mul * ir.dim
+        assert abs(float((acc_lin / T)[o:o + d].mean()) - 1.0) < 0.08, str(ir)
+        o += d
+
+
+def test_gate_and_radial_mlp_preserve_unit_second_moments():
+    """same contract for the two non-linear pieces: e3nn's Gate (normalize2mom activations on scalars and gates, gated irreps multiplied by
+    their gate) and FullyConnectedNet (x @ W / sqrt(h_in), normalised activation): unit-second-moment inputs give unit-second-moment
+    outputs, through the ResidualBlock's gate exactly as the reference builds it (interaction_blocks.py:264-358)"""
+    import torch
+    from oracle import e3, hamgnn_ref as R
+    torch.manual_seed(1)
+    rb = R.ResidualBlock("8x0e+4x0o+4x1o+2x1e+2x2o+3x2e", "8x0e+4x0o+4x1o+2x1e+2x2o+3x2e")
+    gate = rb.equivariant_nonlin
+    x = torch.randn(200000, gate.irreps_in.dim)
+    y = gate(x)
+    o = 0
+    for mul, ir in gate.irreps_out:
+        d = mul * ir.dim
+        assert abs(float(y[:, o:o + d].pow(2).mean()) - 1.0) < 0.03, (str(ir), float(y[:, o:o + d].pow(2).mean()))
+        o += d
+    acc, T = 0, 200
+    for _ in range(T):
+        net = e3.FullyConnectedNet([64, 64, 64, 12], torch.nn.functional.silu)          # the reference's radial_MLP width
+        acc = acc + net(torch.randn(256, 64)).pow(2).mean()
+    # (exact only for infinitely wide layers: a column of W has |w|^2 / h_in = 1 +- sqrt(2 / h_in), and act^2 is convex in that scale)
+    assert abs(float(acc / T) - 1.0) < 0.05, float(acc / T)
