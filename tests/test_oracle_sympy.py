@@ -225,8 +225,9 @@ def test_tensor_product_and_linear_preserve_unit_second_moments():
         tp = e3.TensorProduct(irr_in, sh, irreps_mid, ins, internal_weights=True, shared_weights=True)
         x = torch.randn(128, D)
         n = torch.nn.functional.normalize(torch.randn(128, 3), dim=-1)
-        acc_tp = acc_tp + tp(x, e3.spherical_harmonics([0, 1, 2], n, True, "component")).pow(2).mean(0)
-        acc_lin = acc_lin + e3.Linear(irr_in, irr_out)(x).pow(2).mean(0)
+        with torch.no_grad():
+            acc_tp = acc_tp + tp(x, e3.spherical_harmonics([0, 1, 2], n, True, "component")).pow(2).mean(0)
+            acc_lin = acc_lin + e3.Linear(irr_in, irr_out)(x).pow(2).mean(0)
     o = 0
     for mul, ir in e3.Irreps(irreps_mid):                       # one mid irrep per path (the reference's instruction rule)
         d = mul * ir.dim
@@ -249,7 +250,8 @@ def test_gate_and_radial_mlp_preserve_unit_second_moments():
     rb = R.ResidualBlock("8x0e+4x0o+4x1o+2x1e+2x2o+3x2e", "8x0e+4x0o+4x1o+2x1e+2x2o+3x2e")
     gate = rb.equivariant_nonlin
     x = torch.randn(200000, gate.irreps_in.dim)
-    y = gate(x)
+    with torch.no_grad():
+        y = gate(x)
     o = 0
     for mul, ir in gate.irreps_out:
         d = mul * ir.dim
@@ -258,6 +260,7 @@ def test_gate_and_radial_mlp_preserve_unit_second_moments():
     acc, T = 0, 200
     for _ in range(T):
         net = e3.FullyConnectedNet([64, 64, 64, 12], torch.nn.functional.silu)          # the reference's radial_MLP width
-        acc = acc + net(torch.randn(256, 64)).pow(2).mean()
+        with torch.no_grad():
+            acc = acc + net(torch.randn(256, 64)).pow(2).mean()
     # (exact only for infinitely wide layers: a column of W has |w|^2 / h_in = 1 +- sqrt(2 / h_in), and act^2 is convex in that scale)
     assert abs(float(acc / T) - 1.0) < 0.05, float(acc / T)
