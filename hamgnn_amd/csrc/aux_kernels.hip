@@ -31,6 +31,17 @@ int hg_lds_attr_once(unsigned char* done, int dev, const void* kernel, int bytes
 extern "C" const char* hg_last_error(void) { return g_err; }
 extern "C" int hg_version(void) { return 2; }
 
+// Workspace query ("no hidden allocation on the hot path -- workspace size is queried").  No entry point of this library
+// allocates: outputs and scratch are caller-provided.  The two that need scratch beyond their documented outputs report its size here;
+// every other entry point returns 0.  Host-only: callable without a GPU.
+extern "C" int64_t hg_scratch_bytes(const char* entry_point, int64_t rows, int arg) {
+    if (!entry_point || rows < 0) return -1;
+    auto is = [&](const char* n) { const char* a = entry_point; while (*a && *a == *n) { ++a; ++n; } return *a == 0 && *n == 0; };
+    if (is("hg_edge_geometry")) return rows * 4 * (int64_t)sizeof(float);              // ang_scratch [E][4]
+    if (is("hg_zero_point_shift")) return 2 * (int64_t)(arg > 0 ? arg : 256) * (int64_t)sizeof(double);   // partial_scratch [2 nparts]
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ edge geometry
 // angles of R_e = Rx(beta) Ry(alpha) taking the e3nn-order unit vector n = (v_y, v_z, v_x)/|v| onto the pole (0,1,0);
 // Bessel * cosine-cutoff radial basis evaluated in fp64 (phase n*pi*r/rc by Chebyshev recurrence) and rounded once.

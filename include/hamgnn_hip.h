@@ -20,6 +20,14 @@ extern "C" {
 const char* hg_last_error(void);
 int hg_version(void);
 
+/* Workspace query.  No entry point of this library allocates or synchronises: every output and every scratch buffer is provided by
+ * the caller (PyTorch's allocator in the shipped host code).  Scratch that is not an output: hg_edge_geometry (ang_scratch, rows = E)
+ * and hg_zero_point_shift (partial_scratch, arg = nparts); all other entry points report 0.  Host-only, needs no GPU.
+ * (SURVEY 8b sketched a plan-object ABI: plan create / workspace-bytes / forward-with-plan calls.  The built boundary keeps the
+ * planner on the host side of the ABI instead: the C functions take the planner's tables as plain device arrays, so the library
+ * holds no state, and this query stands in for the plan's workspace-bytes call.)                                                */
+int64_t hg_scratch_bytes(const char* entry_point, int64_t rows, int arg);
+
 /* (a1+a2) SphericalHarmonicEdgeAttrs.forward  hamgnn/toolbox/nequip/nn/embedding/_edge.py:59-67
  *         RadialBasisEdgeEncoding.forward      hamgnn/nn/embeddings.py:73-100  (+ utils/basis_functions.py:193-208,
  *         utils/cutoff_functions.py:50-61).

@@ -36,3 +36,15 @@ def test_missing_gpu_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         ops._require_gpu(torch.zeros(1))
+
+
+def test_scratch_query_is_host_only_and_matches_the_documented_sizes():
+    """hg_scratch_bytes: the workspace query of the boundary (no entry point allocates); callable without a GPU"""
+    import ctypes as C
+    L = _lib.lib()
+    L.hg_scratch_bytes.restype = C.c_int64
+    L.hg_scratch_bytes.argtypes = [C.c_char_p, C.c_int64, C.c_int]
+    assert L.hg_scratch_bytes(b"hg_edge_geometry", 822350, 0) == 822350 * 16          # ang_scratch [E][4] floats
+    assert L.hg_scratch_bytes(b"hg_zero_point_shift", 1, 256) == 2 * 256 * 8            # partial_scratch [2 nparts] doubles
+    assert all(L.hg_scratch_bytes(n.encode(), 1000, 0) == 0 for n in _lib.EXPORTS if n not in ("hg_edge_geometry", "hg_zero_point_shift"))
+    assert L.hg_scratch_bytes(None, 1, 0) == -1 and L.hg_scratch_bytes(b"hg_tp_is", -1, 0) == -1
