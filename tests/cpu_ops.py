@@ -1,0 +1,323 @@
+"""CPU stand-ins for the entry points of hamgnn_amd.ops -- TEST INFRASTRUCTURE, never shipped, never imported by the product.
+
+`install(monkeypatch)` replaces the ctypes bindings of `hamgnn_amd.ops` by numpy / torch twins that consume EXACTLY the tables the
+product hands to the HIP kernels (tests/emu.py: MFMA-fragment-order programs of both schedules, streaming Linear tables; here: gate
+tables, rotation channel tables, CG merge CSR, index maps), so that the CPU suite can drive the product's HOST logic end to end --
+`HamGNNConvE3.forward / backward`, `HamGNNPlusPlusOut.forward / backward`, `training_step` -- against the oracle without a GPU: the
+planner's tables, the orchestration of the block backwards, the parameter-gradient bookkeeping.  What it cannot check is the kernels
+themselves (the `-m gpu` tests do that through the C ABI).  The product keeps failing loudly on CPU tensors; only a test that asks for
+this module gets the stand-ins."""
+import math
+
+import numpy as np
+import torch
+
+from hamgnn_amd import ops
+from hamgnn_amd import plan as P
+from tests import emu
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().double().numpy()
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+class Geometry:
+    """twin of ops.Geometry (hg_edge_geometry [+ hg_radial_basis]): rbf, per-edge Wigner matrices (packed, float64), lengths"""
+
+    def __init__(self, pos, edge_index, nbr_shift, cutoff, num_radial, lmax, jtab_dev, rbf_func="bessel"):
+        j, i = edge_index
+        v = (pos[i].double() + nbr_shift.double()) - pos[j].double()
+        r = v.norm(dim=-1)
+        self.E, self.lmax = int(edge_index.shape[1]), lmax
+        self.wig_off, self.nW = ops.wig_offsets(lmax)
+        n = torch.stack([v[:, 1], v[:, 2], v[:, 0]], 1) / r[:, None]              # e3nn axis order = physical (y, z, x)
+        self.D = emu.edge_wigner_all(n.numpy(), lmax)
+        self.wig = _t(self.D)
+        fc = 0.5 * (torch.cos(math.pi * r / cutoff) + 1.0) * (r < cutoff).double()
+        if rbf_func == "bessel":
+            k = torch.arange(1, num_radial + 1, dtype=torch.float64)
+            rbf = torch.sin(k[None, :] * math.pi * r[:, None] / cutoff) / r[:, None]
+        else:
+            offs = torch.linspace(0.0, cutoff, num_radial, dtype=torch.float32)
+            delta = float((offs[1] - offs[0]).item())
+            rbf = torch.exp(-0.5 * (r[:, None] - offs.double()[None, :]) ** 2 / delta ** 2)
+        self.rbf = (rbf * fc[:, None]).float().contiguous()
+        self.length = r.float().contiguous()
+        self.edge_index = edge_index.contiguous()
+        self.src, self.dst = self.edge_index[0].contiguous(), self.edge_index[1].contiguous()
+
+
+def radial_hidden(rbf, layers, act_cst):
+    h = rbf.double()
+    for W in layers:
+        h = torch.nn.functional.silu(h @ W.double()) * act_cst
+    return h.float()
+
+
+def embed_lookup(Ta, Tb, z, idx_a, idx_b, rows, T, Tp):
+    za = z if idx_a is None else z[idx_a.long()]
+    out = torch.zeros(rows, Tp)
+    out[:, :T] = Ta[za.long()][:, :T]
+    if Tb is not None:
+        zb = z if idx_b is None else z[idx_b.long()]
+        out[:, :T] += Tb[zb.long()][:, :T]
+    return out
+
+
+def _rotate_by_table(x, D, lmax, chan_tab, transpose):
+    """hg_rotate_gather's channel table: rows {l, planar offset of (component 0, first channel of the group), mulp, valid channels}"""
+    offs, _ = P.wigner_offsets(lmax)
+    out = np.zeros_like(x)
+    for l, off, mulp, valid in (tuple(int(v) for v in r) for r in chan_tab):
+        n = 2 * l + 1
+        Dl = D[:, offs[l]:offs[l] + n * n].reshape(-1, n, n)
+        if transpose:
+            Dl = Dl.transpose(0, 2, 1)
+        cols = off + np.arange(n)[:, None] * mulp + np.arange(valid)[None, :]
+        out[:, cols] = np.einsum("eab,ebu->eau", Dl, x[:, cols])
+    return out
+
+
+def rotate_gather(x, idx, geo, chan_tab, transpose=False, x2=None, idx2=None):
+    tab = chan_tab.cpu().numpy()
+    f = lambda t, i: _t(_rotate_by_table(_np(t if i is None else t[i.long()]), geo.D, geo.lmax, tab, transpose))
+    return f(x, idx) if x2 is None else (f(x, idx), f(x2, idx2))
+
+
+def _rotate_blocks(x, D, lmax, blocks, slot):
+    """the staging rotation of the input-stationary kernel: every input irrep block of source `slot` (block table rows
+    {s0, s1, in_off, in_mulp, li, nsrc, ...}) into the edge frame"""
+    offs, _ = P.wigner_offsets(lmax)
+    out = x.copy()
+    for s0, s1, in_off, in_mulp, li, nsrc in (tuple(int(v) for v in b[:6]) for b in blocks):
+        if slot not in ((s0, s1)[:nsrc]):
+            continue
+        n = 2 * li + 1
+        Dl = D[:, offs[li]:offs[li] + n * n].reshape(-1, n, n)
+        blk = x[:, in_off:in_off + n * in_mulp].reshape(-1, n, in_mulp)
+        out[:, in_off:in_off + n * in_mulp] = np.einsum("eab,ebu->eau", Dl, blk).reshape(-1, n * in_mulp)
+    return out
+
+
+def tp_fused(dp, srcs, rows, h2n=None, h2e=None, geo=None, tag="linear", gather=None, rot_mask=0, res=()):
+    D = geo.D if geo is not None else None
+    lmax = geo.lmax if geo is not None else None
+    if dp.sched is not None:
+        sc = dp.is_tables(dp.is_parts_for(rows))[0]
+        xs = []
+        for i, s in enumerate(srcs):
+            a = _np(s if gather is None or gather[i] is None else s[gather[i].long()])
+            if rot_mask >> i & 1:
+                a = _rotate_blocks(a, D, lmax, sc.block_table, i)
+            xs.append(a)
+        out = emu.run_program_is(dp.prog, sc, xs, (_np(h2n), _np(h2e)), D, lmax)
+    else:
+        assert gather is None and rot_mask == 0
+        out = emu.run_program(dp.prog, [_np(s) for s in srcs], (_np(h2n), _np(h2e)), D, lmax)
+    for r in res:
+        if r is not None:
+            out = out + _np(r)
+    return _t(out)
+
+
+def linear_planar(dl, x, res=(), tag="linear"):
+    return _t(emu.run_linear_tables(dl.tabs, _np(x), [_np(r) for r in res if r is not None]))
+
+
+def segment_sum(msg, rowptr, perm, N):
+    out = torch.zeros(N, msg.shape[1])
+    seg = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1])
+    return out.index_add_(0, seg, msg[perm.long()].float())
+
+
+def to_planar(x, imap, Dp):
+    out = torch.zeros(x.shape[0], Dp)
+    out[:, imap.long()] = x.float()
+    return out
+
+
+def from_planar(xp, imap):
+    m = imap.long()
+    out = xp[:, m.clamp(min=0)].float().clone()
+    out[:, m < 0] = 0
+    return out
+
+
+def _act(x, aid, cst):
+    c = float(cst[aid])
+    if aid == P.ACT_SSP:
+        return c * (torch.nn.functional.softplus(x) - math.log(2.0))
+    if aid == P.ACT_TANH:
+        return c * torch.tanh(x)
+    if aid == P.ACT_SILU:
+        return c * torch.nn.functional.silu(x)
+    if aid == P.ACT_ABS:
+        return c * x.abs()
+    return x
+
+
+def gate(x, tabs, consts):
+    """hg_gate on plan.gate_tables_compact: act_tab[k] = (input column, activation), out_tab[p] = (plain source column | 0x40000000 + slot |
+    -1, gate slot | -1)"""
+    act_tab, out_tab = (t.cpu().numpy() for t in tabs)
+    av = [_act(x[:, int(c)], int(a), consts) for c, a in act_tab]
+    cols = []
+    for a, b in out_tab:
+        a, b = int(a), int(b)
+        if a < 0:
+            cols.append(torch.zeros_like(x[:, 0]))
+            continue
+        v = av[a & 0x3FFFFFFF] if a & 0x40000000 else x[:, a]
+        cols.append(v * av[b] if b >= 0 else v)
+    return torch.stack(cols, 1)
+
+
+def gate_backward(x, gy, tabs, consts):
+    with torch.enable_grad():
+        xr = x.detach().double().requires_grad_()
+        (g,) = torch.autograd.grad(gate(xr, tabs, consts), xr, grad_outputs=gy.double())
+    return g.float()
+
+
+def ham_merge(coeff, geo, slot_tab, cg_ptr, cg_idx, cg_val, nout):
+    """hg_ham_merge: slots {L, a, base, stride} (un-rotated with D^L(e)^T when a geometry is given), then the CSR expansion"""
+    c = _np(coeff)
+    st, ptr, idx, val = slot_tab.cpu().numpy(), cg_ptr.cpu().numpy(), cg_idx.cpu().numpy(), _np(cg_val)
+    coef = np.zeros((c.shape[0], st.shape[0]))
+    offs = P.wigner_offsets(geo.lmax)[0] if geo is not None else None
+    for q, (L, a, base, stride) in enumerate(st):
+        if geo is None:
+            coef[:, q] = c[:, base + a * stride]
+        else:
+            n = 2 * L + 1
+            Dl = geo.D[:, offs[L]:offs[L] + n * n].reshape(-1, n, n)
+            coef[:, q] = np.einsum("em,em->e", Dl[:, :, a], c[:, base + np.arange(n) * stride])
+    out = np.zeros((c.shape[0], nout))
+    for p in range(nout):
+        k = slice(int(ptr[p]), int(ptr[p + 1]))
+        out[:, p] = coef[:, idx[k]] @ val[k]
+    return _t(out)
+
+
+def ham_finish(Hraw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign=1.0, symmetrize=True, h0_after_mask=False, out=None):
+    rows = Hraw.shape[0]
+    H = Hraw[:, :nao * nao].double().reshape(rows, nao, nao)
+    if symmetrize:
+        other = H if inv is None else H[inv.long()]
+        H = 0.5 * (H + sign * other.transpose(1, 2))
+    h0 = None if H0 is None else H0.double().reshape(rows, nao, nao)
+    if h0 is not None and not h0_after_mask:
+        H = H + h0
+    if orb_mask is not None:
+        w = orb_mask.shape[1]
+        za = z if idx_a is None else z[idx_a.long()]
+        zb = z if idx_b is None else z[idx_b.long()]
+        ma, mb = orb_mask[za.long()].double().repeat(1, nao // w), orb_mask[zb.long()].double().repeat(1, nao // w)
+        H = H * ma[:, :, None] * mb[:, None, :]
+    if h0 is not None and h0_after_mask:
+        H = H + h0
+    res = H.reshape(rows, nao * nao).float()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def ham_readout(coeff, geo, slot_tab, cg_ptr, cg_idx, cg_val, nao, pairs, H0, orb_mask, z, idx_a, idx_b, out, lmax_ham, sign=1.0,
+                symmetrize=True, h0_after_mask=False):
+    raw = ham_merge(coeff, geo, slot_tab, cg_ptr, cg_idx, cg_val, nao * nao)
+    inv = None
+    if pairs is not None:
+        pa, pb = pairs
+        inv = torch.empty(coeff.shape[0], dtype=torch.long)
+        inv[pa.long()], inv[pb.long()] = pb.long(), pa.long()
+    return ham_finish(raw, inv, H0, orb_mask, z, idx_a, idx_b, nao, sign, symmetrize, h0_after_mask, out=out)
+
+
+def sym_contraction(h, z, C, tab, W1, W2, out_dim):
+    t = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in tab.items() if not str(k).startswith("_bw_")}
+    return _t(emu.sym_contraction(t, _np(h), z.cpu().numpy(), _np(W1), _np(W2), C, out_dim))
+
+
+def block_mean(x, tab, nao):
+    """hg_block_mean: every element -> the mean over its (row shell, col shell) block; tab[q] = {r0, r1, c0, c1}"""
+    X = x[:, :nao * nao].double().reshape(-1, nao, nao)
+    out = torch.zeros_like(X)
+    for q, (r0, r1, c0, c1) in enumerate(tab.cpu().numpy()):
+        out[:, q // nao, q % nao] = X[:, r0:r1, c0:c1].mean(dim=(1, 2))
+    return out.reshape(-1, nao * nao).float()
+
+
+def soc_assemble(H, ksi, L, inv, H0r, H0i, nao, symmetrize, zero_diag):
+    """hg_soc_assemble: real = [[H, A_y], [A_y, H]] + H0r (spin-diagonal blocks of H0r skipped with zero_diag), imag = [[A_z, A_x],
+    [-A_x, -A_z]] + H0i, A_k = antiherm(ksi L_k)"""
+    E = H.shape[0]
+    Hm, K, Lm = H.double().reshape(E, nao, nao), ksi.double().reshape(E, nao, nao), L.double().reshape(E, nao, nao, 3)
+
+    def A(k):
+        M = K * Lm[..., k]
+        return 0.5 * (M - (M if inv is None else M[inv.long()]).transpose(1, 2)) if symmetrize else M
+    Ax, Ay, Az = A(0), A(1), A(2)
+    real = torch.cat([torch.cat([Hm, Ay], 2), torch.cat([Ay, Hm], 2)], 1)
+    imag = torch.cat([torch.cat([Az, Ax], 2), torch.cat([-Ax, -Az], 2)], 1)
+    if H0r is not None:
+        h0 = H0r.double().reshape(E, 2 * nao, 2 * nao).clone()
+        if zero_diag:
+            h0[:, :nao, :nao] = 0
+            h0[:, nao:, nao:] = 0
+        real = real + h0
+    if H0i is not None:
+        imag = imag + H0i.double().reshape(E, 2 * nao, 2 * nao)
+    return real.reshape(E, -1).float(), imag.reshape(E, -1).float()
+
+
+def attention_aggregate(K, V, geo, rowptr, perm, head_tab, H, head_dim, cut_param, cutoff):
+    """hg_attn_logits + hg_attn_aggregate (hamgnn/nn/attention.py:126-164): per-head soft-max over a node's incoming edges"""
+    N, Dp = K.shape
+    M = torch.zeros(Dp, H, dtype=torch.float64)
+    cols = torch.nonzero(head_tab >= 0).reshape(-1)
+    M[cols, head_tab[cols].long()] = 1.0
+    src, dst = geo.src.long(), geo.dst.long()
+    x = cut_param.reshape(()).double() * (1.0 - geo.length.double() / cutoff)
+    cut = torch.where(x > 0, torch.exp(-1.0 / torch.where(x > 0, x, torch.ones_like(x))), torch.zeros_like(x))
+    logit = cut[:, None] / math.sqrt(head_dim) * ((K[src].double() * K[dst].double()) @ M)
+    mx = torch.full((N, H), -float("inf"), dtype=torch.float64).scatter_reduce(0, dst[:, None].expand(-1, H), logit, "amax")
+    ex = torch.exp(logit - mx[dst])
+    alpha = ex / (torch.zeros(N, H, dtype=torch.float64).index_add_(0, dst, ex) + 1e-16)[dst]
+    return torch.zeros(N, Dp, dtype=torch.float64).index_add_(0, dst, (alpha @ M.t()) * V.double()).float()
+
+
+def hk_assemble(on, off, nbr_shift, kvec, pair_ptr, pair_edges, pair_ij, n_atoms, nao, orank, ooff, M):
+    """hg_hk_assemble: H(k) of one crystal in the compact orbital basis"""
+    nk = kvec.shape[0]
+    out = torch.zeros(nk, M, M, dtype=torch.complex128)
+    comp = torch.where(orank >= 0, ooff[:, None].long() + orank.long(), torch.full_like(orank.long(), -1))
+    onm = on.double().reshape(n_atoms, nao, nao)
+    for i in range(n_atoms):
+        v = torch.nonzero(comp[i] >= 0).reshape(-1)
+        out[:, comp[i][v][:, None], comp[i][v][None, :]] += onm[i][v][:, v].to(torch.complex128)[None]
+    offm = off.double().reshape(-1, nao, nao)
+    ph = 2.0 * math.pi * (kvec.double()[:, None, :] * nbr_shift.double()[None, :, :]).sum(-1)            # [nk, e]
+    phase = torch.complex(torch.cos(ph), torch.sin(ph))
+    for p in range(pair_ij.shape[0]):
+        i, j = int(pair_ij[p, 0]), int(pair_ij[p, 1])
+        vi, vj = torch.nonzero(comp[i] >= 0).reshape(-1), torch.nonzero(comp[j] >= 0).reshape(-1)
+        for t in range(int(pair_ptr[p]), int(pair_ptr[p + 1])):
+            e = int(pair_edges[t])
+            out[:, comp[i][vi][:, None], comp[j][vj][None, :]] += phase[:, e][:, None, None] * offm[e][vi][:, vj].to(torch.complex128)[None]
+    return out.to(torch.complex64)
+
+
+def install(mp):
+    """monkeypatch hamgnn_amd.ops with the stand-ins above (pytest's `monkeypatch` fixture: undone after the test)"""
+    mp.setattr(ops, "_require_gpu", lambda t: None)
+    mp.setattr(ops, "Geometry", Geometry)
+    mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
+    for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
+                 "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "block_mean", "soc_assemble", "attention_aggregate",
+                 "hk_assemble"):
+        mp.setattr(ops, name, globals()[name])
