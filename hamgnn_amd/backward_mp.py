@@ -62,7 +62,7 @@ def _build_groups(wg, device, dtype):
         b = next(b for b in wg.branches if b["name"] == branch)
         lay = b["lay"]
         nch = int(np.asarray(b["w3"]).shape[1])
-        tp_size = int(wg.sd[b["keys"]["tp"]].size)
+        tp_size = int(wg.sd[b["keys"]["tp"]].size) if b["keys"]["tp"] is not None else 0     # uvu branches carry no tensor-product weights
         ls_size = int(wg.sd[b["keys"]["ls"]].size)
         # bound the gathered tensors to ~48 KB per edge
         cs = [wg.chunks[j] for j in js]
@@ -98,8 +98,9 @@ def _build_groups(wg, device, dtype):
                 cf[q, :n, :] = sp["cf"][r0:r1]
                 meta = sp["meta"][r0:r1]
                 cpath[q, :n, 0] = [m[2] for m in meta]
-                base_tp = np.array([sp["woff"][m[0]] + m[1] for m in meta], dtype=np.int64)
-                tp_idx[q, :n, :u] = base_tp[:, None] + np.arange(u, dtype=np.int64)[None, :] * mk
+                if b["keys"]["tp"] is not None:
+                    base_tp = np.array([sp["woff"][m[0]] + m[1] for m in meta], dtype=np.int64)
+                    tp_idx[q, :n, :u] = base_tp[:, None] + np.arange(u, dtype=np.int64)[None, :] * mk
                 off, fan = sp["lin"]
                 lrow = np.array([m[3] for m in meta], dtype=np.int64)
                 l_idx[q, :n, :mk] = off + lrow[:, None] * mk + np.arange(mk, dtype=np.int64)[None, :]
@@ -185,7 +186,7 @@ class TPWeightGrad:
         """flat accumulators in the reference's layouts (+ one spare slot that padded group entries write to)"""
         acc = {}
         for b in self.branches:
-            acc[f"{b['name']}_tp"] = torch.zeros(self.sd[b["keys"]["tp"]].size + 1, device=device, dtype=dtype)
+            acc[f"{b['name']}_tp"] = torch.zeros((self.sd[b["keys"]["tp"]].size if b["keys"]["tp"] is not None else 0) + 1, device=device, dtype=dtype)
             acc[f"{b['name']}_L"] = torch.zeros(self.sd[b["keys"]["ls"]].size + 1, device=device, dtype=dtype)     # d / d L', linear_scaler's layout
         return acc
 
@@ -194,7 +195,8 @@ class TPWeightGrad:
         out = {}
         for b in self.branches:
             name, keys = b["name"], b["keys"]
-            out[keys["tp"]] = acc[f"{name}_tp"][:-1]
+            if keys["tp"] is not None:
+                out[keys["tp"]] = acc[f"{name}_tp"][:-1]
             Ls_flat = self.param(keys["ls"], dev, dt).reshape(-1)
             gLs = torch.zeros_like(Ls_flat)
             if keys["lo"] is not None:

@@ -193,9 +193,8 @@ class _BackboneBase(nn.Module):
         pre = f"pair_interactions.{li}."
         if pair.use_skip_connections or not pair.legacy_edge_update:
             up_s, up_t = pair.linear_up_src(node_out), pair.linear_up_tar(node_out)
-            grads.update({pre + "conv_tp." + k: v for k, v in
-                          pair.conv_tp.backward_weights(up_s, up_t, f_in, geo, self._rot_tab, g_f, out_is_global=False, chunk=chunk).items()})
-            gs, gd, ge = pair.conv_tp.backward_data(g_f, geo, out_is_global=False)
+            gs, gd, ge, g_tp = pair.conv_tp.backward(up_s, up_t, f_in, geo, self._rot_tab, g_f, out_is_global=False, chunk=chunk)
+            grads.update({pre + "conv_tp." + k: v for k, v in g_tp.items()})
             g_up_s = ops.segment_sum(gs, rp_s, pm_s, N)
             g_up_t = ops.segment_sum(gd, rp_r, pm_r, N)
             grads[pre + "linear_up_src.weight"] = pair.linear_up_src.weight_grad(node_out, g_up_s)
@@ -320,8 +319,6 @@ class HamGNNConvE3(_BackboneBase):
         linear_up adjoints, the fused skip o3.Linear)  ->  ResidualBlock  ->  skip o3.Linear  ->  ConvBlockE3's message block with the
         receiver scatter's adjoint (a gather) fused into its staging;  then the pair embedding and the chemical embedding table.
         Returns {reference parameter name: gradient in the reference's layout}.  Non-lite, no CorrProduct, no charge doping, one rank."""
-        if self.lite_mode:
-            raise NotImplementedError("backbone backward: non-lite HamGNNConvE3")
         if parallel.is_sharded(data):
             raise NotImplementedError("backbone backward of an edge-sharded graph")
         tape = rep["_tape"]
@@ -348,8 +345,8 @@ class HamGNNConvE3(_BackboneBase):
             put(pre + "residual.", g_res)
             grads[pre + "skip_linear.weight"] = conv.skip_linear.weight_grad(node_in, g_node)
             g_node_in = conv.skip_linear.backward_data(g_node)
-            put(pre + "conv_tp.", conv.conv_tp.backward_weights(node_in, node_in, f_in, geo, rot, g_agg, out_is_global=True, chunk=chunk, gather=geo.dst))
-            gs, gd, ge = conv.conv_tp.backward_data(g_agg, geo, out_is_global=True, gather=geo.dst)
+            gs, gd, ge, g_tp = conv.conv_tp.backward(node_in, node_in, f_in, geo, rot, g_agg, out_is_global=True, gather=geo.dst, chunk=chunk)
+            put(pre + "conv_tp.", g_tp)
             g_node = g_node_in + ops.segment_sum(gs, rp_s, pm_s, N) + ops.segment_sum(gd, rp_r, pm_r, N)
             g_f = g_f + ge
         self._backward_embeddings(data, rep, geo, g_node, g_f, grads, chunk)

@@ -199,6 +199,7 @@ class MessagePackBlock(nn.Module):
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
         self._compile_args = (bool(unrotate), skip_weight is not None, None)      # (unrotate, fused skip Linear, merge groups)
+        self._lite_bw = None
         self._packers = getattr(self, "_packers", None) or {}                     # structural: survive recompiles of the same block
         self._dp_adj = None                                    # the data-gradient program is packed from the same weights
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
@@ -357,6 +358,37 @@ class MessagePackBlock(nn.Module):
             g = grad_out if gather is None else grad_out[gather].contiguous()
         return BM.block_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), xs, xd, f_rot, g, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk)
 
+    def backward(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, gather=None, chunk: int = 65536):
+        """data AND weight gradients of the block in one call: (g_src_rows, g_dst_rows, g_edge_rows, {parameter name: gradient}); arguments
+        as backward_data / backward_weights.  lite_mode blocks go through hamgnn_amd/backward_lite.py (nothing large to materialise)."""
+        if not self.lite_mode:
+            grads = self.backward_weights(node_s, node_d, f_rot, geo, rot_tab, grad_out, out_is_global, chunk=chunk, gather=gather)
+            return self.backward_data(grad_out, geo, out_is_global, gather=gather) + (grads,)
+        from . import backward_lite as BL
+        dev = grad_out.device
+        if getattr(self, "_lite_bw", None) is None:
+            lb = BL.LiteBackward(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
+            dp_t = ops.DeviceProgram(lb.prog_t, dev, schedule="seg")
+            try:
+                dp_a = ops.DeviceProgram(lb.prog_adj, dev, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
+            except NotImplementedError:
+                dp_a = ops.DeviceProgram(lb.prog_adj, dev, schedule="seg")
+            _, maps = P.message_pack_adjoint_layout(self.irreps_node, self.irreps_edge)
+            self._lite_bw = (lb, {id(lb.prog_t): dp_t, id(lb.prog_adj): dp_a}, ops.DeviceLinear(lb.lc_adj, dev),
+                             tuple(torch.from_numpy(m).to(dev) for m in maps))
+        lb, dps, dl, maps = self._lite_bw
+        xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)
+        if out_is_global:
+            g = ops.rotate_gather(grad_out, gather, geo, self._rot_tab_out(dev))
+        else:
+            g = grad_out if gather is None else grad_out[gather].contiguous()
+        hn = ops.radial_hidden_cached(geo, self._hn, float(P.ACT_CONSTS[P.ACT_SILU]))   # (no item of the two programs reads it; never hand the kernel a NULL row pointer)
+        run_program = lambda prog, srcs: ops.tp_fused(dps[id(prog)], [t.contiguous() for t in srcs], geo.E, hn, None, geo, tag="lite_backward")
+        run_linear = lambda tabs, x: ops.linear_planar(dl, x.contiguous(), tag="linear_adjoint")
+        rows, grads = lb.run(run_program, run_linear, o3_linear_weight_grad, xs, xd, f_rot, g, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]),
+                             params={k: v.detach() for k, v in self.state_dict().items()})
+        return ops.from_planar(rows, maps[0]), ops.from_planar(rows, maps[1]), ops.from_planar(rows, maps[2]), grads
+
     def _rot_tab_out(self, device):
         if getattr(self, "_rt_out", None) is None:
             self._rt_out = torch.from_numpy(P.rotate_table(P.PlanarLayout(self.irreps_out))).to(device)
@@ -497,9 +529,8 @@ class AttentionBlockE3(nn.Module):
         grads["linear_query.weight"] = torch.zeros_like(self.linear_query.weight)     # a parameter the reference's forward never reads
         g_node = g_node + self.linear_key.backward_data(g_K.contiguous())
         g_V = g_V.contiguous()
-        grads.update({"conv_tp_value." + k: v for k, v in
-                      self.conv_tp_value.backward_weights(us, ut, ue, geo, rot_tab, g_V, out_is_global=True, chunk=chunk).items()})
-        gs, gd, ge = self.conv_tp_value.backward_data(g_V, geo, out_is_global=True)
+        gs, gd, ge, g_cv = self.conv_tp_value.backward(us, ut, ue, geo, rot_tab, g_V, out_is_global=True, chunk=chunk)
+        grads.update({"conv_tp_value." + k: v for k, v in g_cv.items()})
         g_us = ops.segment_sum(gs, *topo.sender_csr(), N)
         g_ut = ops.segment_sum(gd, rowptr, perm, N)
         grads["linear_up_src.weight"] = self.linear_up_src.weight_grad(node, g_us)
@@ -588,12 +619,10 @@ class PairInteractionEmbeddingBlock(nn.Module):
         delta: the charge-doping correction the forward ran with ([N, num_types]; attrs = one_hot(z) + delta): its gradient is returned
         under the key "_g_delta" (the caller backpropagates it through the charge MLP)."""
         from . import backward_mp as BM
-        if self.lite_mode:
-            raise NotImplementedError("backward of a lite_mode PairInteractionEmbeddingBlock")
         dev, T = g_f.device, self.num_types
         if self._wgrad is None:
             sd = _np_sd(self.conv_tp)
-            wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T), self.irreps_sh, self.irreps_out)
+            wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T, self.lite_mode), self.irreps_sh, self.irreps_out)
             wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
             self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
         wg, dpA, dpB = self._wgrad

@@ -1101,8 +1101,9 @@ def build_tp_wgrad_programs(branches, irreps_sh, irreps_out, H: int):
     gl = PlanarLayout(irreps_out)
     chunks = []
     for b in branches:
-        for sp in _tp_superpaths(b["nsrc"], b["lay"], irreps_sh, irreps_out, np.asarray(b["tp_w"]), np.asarray(b["w3"]) / math.sqrt(H),
-                                 np.asarray(b["ls_w"]), None if b["lo_w"] is None else np.asarray(b["lo_w"]), False):
+        for sp in _tp_superpaths(b["nsrc"], b["lay"], irreps_sh, irreps_out, None if b["tp_w"] is None else np.asarray(b["tp_w"]),
+                                 np.asarray(b["w3"]) / math.sqrt(H), np.asarray(b["ls_w"]), None if b["lo_w"] is None else np.asarray(b["lo_w"]),
+                                 bool(b.get("uvu", False))):
             nc = 2 * sp["mm"] + 1
             step = min(rtm_max(nc) * 16, seg_rows_cap(sp["lk"]))
             for r0 in range(0, sp["nmid"], step):
@@ -1170,12 +1171,13 @@ def message_pack_wgrad_branches(sd: Dict[str, np.ndarray], irreps_node, irreps_e
     return out
 
 
-def embedding_wgrad_branches(sd: Dict[str, np.ndarray], num_types: int):
-    """the single branch of PairInteractionEmbeddingBlock.conv_tp (non-lite; embeddings.py:328-334): input num_types x 0e"""
-    keys = dict(tp="tensor_product.weight", ls="linear_scaler.linear_out.weight", lo=None, gen="weight_generator")
+def embedding_wgrad_branches(sd: Dict[str, np.ndarray], num_types: int, lite_mode: bool = False):
+    """the single branch of PairInteractionEmbeddingBlock.conv_tp (embeddings.py:328-334): input num_types x 0e; lite_mode: the
+    unweighted uvu product (no tensor_product.weight, one radial weight per INPUT channel and path)"""
+    keys = dict(tp=None if lite_mode else "tensor_product.weight", ls="linear_scaler.linear_out.weight", lo=None, gen="weight_generator")
     _, w3 = _last_layer(sd, keys["gen"])
-    return [dict(name="emb", nsrc=1, srcs=[SRC_XS], lay=PlanarLayout([(num_types, 0, 1)]), mlp=0, keys=keys, tp_w=sd[keys["tp"]], w3=w3,
-                 ls_w=sd[keys["ls"]], lo_w=None)]
+    return [dict(name="emb", nsrc=1, srcs=[SRC_XS], lay=PlanarLayout([(num_types, 0, 1)]), mlp=0, keys=keys, tp_w=None if lite_mode else sd[keys["tp"]],
+                 w3=w3, ls_w=sd[keys["ls"]], lo_w=None, uvu=lite_mode)]
 
 
 def build_message_pack_wgrad_programs(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
@@ -1642,8 +1644,69 @@ def add_lite_branch_items(prog: Program, seg_of_k, in_layout: PlanarLayout, nsrc
     assert off == lin_w.size, (off, lin_w.size)
 
 
-def build_message_pack_program_lite(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool) -> Program:
-    """MessagePackBlock with lite_mode=True (message_passing.py:197-215) as one fused-kernel program."""
+def lite_paths(in_layout: PlanarLayout, nsrc, irreps_sh, irreps_out, lin_w: np.ndarray):
+    """the paths of one lite_mode branch with their folded Linear blocks: yields (i, k, l_sh, Wp [nsrc mul_i, mul_k] (incl. sqrt(2 l_k + 1) /
+    sqrt(fan)), offset of the block's first row in the flat _MidLinear weight, fan, cf [2 mm + 1], parity) -- see add_lite_branch_items"""
+    irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
+    irr_in = Irreps([(m * nsrc, l, p) for m, l, p in in_layout.irreps])
+    ins = tp_instructions(irr_in, irreps_sh, irreps_out)
+    by_k: Dict[int, List[int]] = {}
+    for n, (i, j, k, slot) in enumerate(ins):
+        by_k.setdefault(k, []).append(n)
+    off = 0
+    for k in sorted(by_k, key=lambda k: ((irreps_out[k][1], irreps_out[k][2]), k)):
+        mk, lk, pk = irreps_out[k]
+        fan = sum(irr_in[ins[n][0]][0] for n in by_k[k])
+        scale = math.sqrt(2 * lk + 1) / math.sqrt(fan)
+        Lk = lin_w[off:off + fan * mk].reshape(fan, mk).astype(np.float64) * scale
+        r = 0
+        for n in by_k[k]:
+            i, j, _, _ = ins[n]
+            mi2, li, pi = irr_in[i]
+            lj = irreps_sh[j][1]
+            mm = min(li, lk)
+            _, coef_c = so3.aligned_path(li, lj, lk)
+            cf = np.array([coef_c[lk + m] for m in range(-mm, mm + 1)])
+            yield dict(i=i, k=k, lj=lj, Wp=Lk[r:r + mi2], w_off=off + r * mk, fan=fan, scale=scale, cf=cf, par=(li + lj + lk) % 2, mm=mm, li=li, lk=lk,
+                       mi=mi2 // nsrc, mk=mk)
+            r += mi2
+        off += fan * mk
+    assert off == lin_w.size, (off, lin_w.size)
+
+
+def build_message_pack_lite_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out) -> Program:
+    """DATA GRADIENT of the item part of a lite_mode MessagePackBlock (the uvu products folded with the _MidLinears; the combine
+    post-op's adjoint -- g_t = s * (Lc g_out) -- is applied to the gradient rows before, outside this program).  Source slot 0 = g_t
+    [E, planar(irreps_out)] in the edge frame; output rows as message_pack_adjoint_layout; IT_LINC items with the roles of the two
+    irreps exchanged: tile_i[u, l_i + s m] += cf[m] sum_w Wp[u, w] g_t[w, l_k + m]  (s = -1 for odd paths: the same `neg` flag, the
+    coefficient vector reversed)."""
+    irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
+    adj, _ = message_pack_adjoint_layout(irreps_node, irreps_edge)
+    nb = len(irreps_node)
+    prog, _ = new_program(adj, 0, lambda k, ir: SEG_UNROTATE if k < nb else 0)
+    gl = PlanarLayout(irreps_out)
+    for lay, nsrc, key, base in ((PlanarLayout(irreps_node), 2, "node_linear_scaler.weight", 0), (PlanarLayout(irreps_edge), 1, "edge_linear_scaler.weight", nb)):
+        for pth in lite_paths(lay, nsrc, irreps_sh, irreps_out, np.asarray(sd[key])):
+            i, k, mm, lk, mk = pth["i"], pth["k"], pth["mm"], pth["lk"], pth["mk"]
+            nc = 2 * mm + 1
+            cf = pth["cf"][::-1] if pth["par"] else pth["cf"]
+            ksteps = gl.mulp[k] // 4
+            chunk = rtm_max(nc) * 16
+            for seg, c0, c1 in prog.seg_chunks[base + i]:     # column chunks of the (nsrc * mul_i) target channels
+                for r0 in range(c0, c1, chunk):
+                    r1 = min(c1, r0 + chunk)
+                    rtm = ceil_div(r1 - r0, 16)
+                    a1_off = prog.add_weights(_frag_A(pth["Wp"][r0:r1].T, ksteps, rtm, use_x4(gl.mulp[k], nc))[None])
+                    cf_off = prog.add_weights(cf)
+                    _add_item(prog, seg, IT_LINC, [0], gl.off[k], gl.mulp[k], lk, mm, pth["par"], ksteps, rtm, 0, a1_off, 0, cf_off, 0, r1 - r0,
+                              row_off=r0 - c0)
+            prog.flops_per_row += 2.0 * pth["Wp"].shape[0] * mk * nc
+    return prog.finalize()
+
+
+def build_message_pack_program_lite(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool, post: bool = True) -> Program:
+    """MessagePackBlock with lite_mode=True (message_passing.py:197-215) as one fused-kernel program.  post=False: without the combine
+    post-op (the pre-combine rows t that the backward's reductions read)."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
     _, w3 = _last_layer(sd, "weight_generator_combine")
     H = w3.shape[0]
@@ -1662,6 +1725,8 @@ def build_message_pack_program_lite(sd: Dict[str, np.ndarray], irreps_node, irre
         lo += mk * mk
     assert co == w3.shape[1] and lo == lc.size
     for k, (mk, lk, pk) in enumerate(irreps_out):
+        if not post:
+            break
         assert len(prog.seg_chunks[k]) == 1, "lite_mode post-op needs <= 64 channels per output irrep"
         seg = seg_of_k[k]
         rto = prog.segs[seg][2]

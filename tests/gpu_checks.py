@@ -283,7 +283,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False, lite=False):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -301,6 +301,8 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
         cfg.update(apply_charge_doping=True, num_charge_attr_feas=8)
     if corr:
         cfg.update(use_corr_prod=True)
+    if lite:
+        cfg.update(lite_mode=True)
     if transformer:                                            # HamGNNTransformer: attention blocks, CorrProductBlock always on
         cfg.update(num_heads=2)
     torch.manual_seed(seed)

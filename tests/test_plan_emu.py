@@ -576,13 +576,14 @@ def test_message_pack_weight_gradients_vs_autograd(seed):
         assert float((got[k].reshape(want[k].shape) - want[k]).abs().max()) < 2e-6 * max(scale, 1e-3), (k, irr, sh)
 
 
-@pytest.mark.parametrize("seed", range(2))
+@pytest.mark.parametrize("seed", [(0, False), (1, False), (0, True), (1, True)], ids=["0", "1", "0-lite", "1-lite"])
 def test_embedding_tp_weight_and_input_gradients_vs_autograd(seed):
     """the embedding tensor product (PairInteractionEmbeddingBlock.conv_tp, num_types x 0e input) through the same
     materialisation programs: every parameter AND the input rows' gradient vs torch.autograd through the fp64 oracle"""
     import torch
     from oracle import hamgnn_ref as R, e3
     from hamgnn_amd import backward_mp as BM
+    seed, lite = seed
     rng = np.random.default_rng(700 + seed)
     T = int(rng.integers(3, 9))
     lsh = 2 + seed
@@ -592,7 +593,7 @@ def test_embedding_tp_weight_and_input_gradients_vs_autograd(seed):
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
-        ref = R.RadialTensorProduct(f"{T}x0e", sh, irr, "8x0e", [16, 16])
+        ref = R.RadialTensorProduct(f"{T}x0e", sh, irr, "8x0e", [16, 16], lite_mode=lite)
         E = 9
         g_ = torch.Generator().manual_seed(seed)
         x = torch.randn(E, T, generator=g_).requires_grad_()
@@ -608,7 +609,10 @@ def test_embedding_tp_weight_and_input_gradients_vs_autograd(seed):
     lay, lin = P.PlanarLayout(irr), P.PlanarLayout([(T, 0, 1)])
     D = emu.edge_wigner_all(n.numpy(), lsh)
     grot = torch.from_numpy(emu.rotate_rows(lay.to_planar(G.numpy()), lay, D, lsh))
-    wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T), sh, irr)
+    if lite:
+        sd = {k: v for k, v in sd.items() if "tensor_product" not in k}
+        want = {k: v for k, v in want.items() if "tensor_product" not in k}
+    wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T, lite), sh, irr)
     run = lambda prog, srcs, hn, he: torch.from_numpy(emu.run_program(prog, [t.numpy() for t in srcs], (hn.numpy(), he.numpy())))
     xp = torch.from_numpy(lin.to_planar(x.detach().numpy()))
     got, gx = BM.tp_weight_grads(wg, run, [xp], grot, rbf, emu.SILU_CST, chunk=5, want_gx=True)
@@ -769,3 +773,63 @@ def test_device_repack_map_equals_host_builder(seed):
         assert np.abs(want - got).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
         t = pk.apply({k: torch.from_numpy(np.asarray(v)) for k, v in RP.mp_sources(lambda k: sd2[k].reshape(-1), last, lays, skip2 if ns else None).items()})
         assert np.abs(t.numpy() - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), name
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lite_mode_message_pack_backward_vs_autograd(seed):
+    """SURVEY 8f-3, lite_mode MessagePackBlock (message_passing.py:197-215): data gradient (adjoint IT_LINC program, emulated on both
+    schedules) and EVERY parameter gradient (hamgnn_amd/backward_lite.py) vs torch.autograd through the fp64 oracle; random irreps sets"""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import backward_lite as BL
+    from hamgnn_amd.nn import o3_linear_weight_grad
+    rng = np.random.default_rng(300 + seed)
+    lmax = int(rng.integers(1, 4))
+    irr = _random_irreps(rng, lmax)
+    if "0e" not in irr:
+        irr = "5x0e+" + irr
+    lsh = int(rng.integers(1, 4))
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    E = 13
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16], lite_mode=True)
+        g = torch.Generator().manual_seed(seed)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g).requires_grad_() for _ in range(3))
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        G = torch.randn(E, ref.irreps_node_feats.dim, generator=g)
+        (ref(src, dst, ef, shv, rbf) * G).sum().backward()
+    finally:
+        torch.set_default_dtype(prev)
+    want_w = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items() if "tensor_product" not in k}
+    lay = P.PlanarLayout(irr)
+    lm = max(lmax, lsh)
+    D = emu.edge_wigner_all(n.numpy(), lm)
+    rot = lambda t: torch.from_numpy(emu.rotate_rows(lay.to_planar(t.detach().numpy()), lay, D, lm))
+    lb = BL.LiteBackward(sd, irr, irr, sh, irr)
+    for sched in ("seg", "is"):
+        def run_program(prog, srcs):
+            xs = [t.numpy() for t in srcs]
+            if sched == "is":
+                try:
+                    return torch.from_numpy(emu.run_program_is(prog, P.is_schedule(prog, "lds"), xs, (None, None), D, lm))
+                except NotImplementedError:
+                    pass
+            return torch.from_numpy(emu.run_program(prog, xs, (None, None), D, lm))
+        run_linear = lambda tabs, x: torch.from_numpy(emu.run_linear_tables(tabs, x.numpy()))
+        rows, grads = lb.run(run_program, run_linear, o3_linear_weight_grad, rot(src), rot(dst), rot(ef), rot(G), rbf, emu.SILU_CST)
+        _, maps = P.message_pack_adjoint_layout(irr, irr)
+        o = rows.numpy()
+        take = lambda im: np.where(im[None, :] >= 0, o[:, np.maximum(im, 0)], 0.0)
+        got = (take(maps[0]), take(maps[1]), emu.rotate_rows(take(maps[2]), lay, D, lm, transpose=True))
+        for a, b in zip(got, (src.grad, dst.grad, ef.grad)):
+            assert rel(lay.from_planar(a), b.numpy()) < 1e-6, (irr, sh)
+        assert set(grads) == set(want_w), sorted(set(grads) ^ set(want_w))
+        for k in want_w:
+            scale = max(float(want_w[k].abs().max()), 1e-3)
+            assert float((grads[k].reshape(want_w[k].shape) - want_w[k]).abs().max()) < 2e-6 * scale, (k, irr, sh)
