@@ -55,3 +55,39 @@ def test_device_repack_equals_recompile_on_cpu(cpu_backend):
 def test_band_energy_loss_backward_on_cpu(cpu_backend):
     r = G.check_band_energy_backward(device="cpu")
     assert r["g_on_rel_err"] < 1e-4 and r["g_off_rel_err"] < 1e-4 and r["grads_finite"] and r["losses"][-1] < r["losses"][0], r
+
+
+_REL = lambda r: all(v < G.TOL for k, v in r.items() if k.endswith("rel_err"))
+_FORWARD_CASES = {
+    "backbone": lambda: G.check_backbone("cpu", "backbone"),
+    "backbone_lite": lambda: G.check_backbone("cpu", "backbone_lite"),
+    "backbone_corr": lambda: G.check_backbone("cpu", "backbone_corr"),
+    "backbone_gaussian_rbf": lambda: G.check_backbone("cpu", "backbone_gaussian_rbf"),
+    "charge_doping": lambda: G.check_charge_doping("cpu"),
+    "transformer": lambda: G.check_transformer("cpu"),
+    "corr_product": lambda: G.check_corr_product("cpu"),
+    "head_openmx_19": lambda: G.check_head("cpu"),
+    "head_abacus_13": lambda: G.check_head("cpu", "head_abacus_13", "abacus", 13),
+    "head_from_planar_rows": lambda: G.check_head("cpu", use_planar_path=True),
+    "head_soc_so3": lambda: G.check_head_soc("cpu"),
+    "head_soc_su2": lambda: G.check_head_su2("cpu"),
+    "residual_block_backward": lambda: G.check_residual_block_backward("cpu"),
+    "head_backward": lambda: G.check_head_backward("cpu"),
+    "message_pack_backward": lambda: G.check_message_pack_backward("cpu", seed=1, E=21),
+    "message_pack_weight_grads": lambda: G.check_message_pack_weight_grads("cpu", seed=1, E=21),
+    "attribute_style_graph": lambda: G.check_attribute_style_graph("cpu"),
+}
+
+
+@pytest.mark.parametrize("name", list(_FORWARD_CASES))
+def test_gpu_check_functions_on_the_cpu_stand_ins(cpu_backend, name):
+    """the reference FIXTURES (backbones, heads, SOC, CorrProduct, transformer) and the block-level backward checks of the `-m gpu` suite,
+    unchanged, on the CPU stand-ins: the planner tables and the host code of every forward variant against the reference's own outputs"""
+    r = _FORWARD_CASES[name]()
+    if name == "attribute_style_graph":
+        assert r["node_attr"] < 1e-6 and r["edge_attr"] < 1e-6 and r["node_vs_fixture"] < G.TOL and r["head_vs_fixture"] < G.TOL and r["cache_reused"], r
+        assert abs(r["sparsity_ratio"] - r["sparsity_ratio_fixture"]) < 1e-6 * r["sparsity_ratio_fixture"]
+        return
+    assert _REL(r) and any(k.endswith("rel_err") for k in r), r
+    if "sparsity_ratio_reference" in r:
+        assert abs(r["sparsity_ratio"] - r["sparsity_ratio_reference"]) < 1e-6 * r["sparsity_ratio_reference"]
