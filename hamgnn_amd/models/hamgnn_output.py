@@ -162,6 +162,25 @@ class HamGNNPlusPlusOut(nn.Module):
         ops.zero_point_shift(H, f32c(Href), f32c(S), self.nao_max, soc)
         return H
 
+    def _zero_point_shift_adjoint(self, data, gH, edge_counts, threshold: float = 1e-6):
+        """adjoint of hg_zero_point_shift (hamgnn_output.py:3971-3981, SOC :3892-3913): H' = H - dE S with ONE dE per batch,
+        dE = sum_{S > thr} (H - Href) / sum_{S > thr} S  (SOC: the two spin-diagonal real blocks, denominator doubled)  =>
+        g_H = g - [S > thr] (sum g S) / den.  Element-wise tensor algebra + two global sums on the gradient rows."""
+        n = self.nao_max
+        S = (gget(data, "overlap") if ghas(data, "overlap") else self._cat_by_crystal(data, data.Son, data.Soff, edge_counts)).float()
+        sel = (S > threshold).to(gH.dtype)
+        den = (S * sel).double().sum()
+        if not self.soc_switch:
+            c = ((gH * S).double().sum() / den).to(gH.dtype)
+            return gH - sel * c
+        half = gH.shape[0] // 2                                # [real rows; imaginary rows]: only the real spin-diagonal blocks are shifted
+        R = gH[:half].reshape(-1, 2, n, 2, n).clone()
+        S3, sel3 = S.reshape(-1, n, n), sel.reshape(-1, n, n)
+        c = ((((R[:, 0, :, 0, :] + R[:, 1, :, 1, :]) * S3).double().sum()) / (2.0 * den)).to(gH.dtype)
+        R[:, 0, :, 0, :] -= sel3 * c
+        R[:, 1, :, 1, :] -= sel3 * c
+        return torch.cat([R.reshape(half, -1), gH[half:]], 0)
+
     def build_interaction_masks(self, data, edge_counts=None, soc=False):
         """bool masks of the matrix elements that exist for the atoms' basis sets (index plumbing, no arithmetic):
         non-SOC build_interaction_masks (hamgnn_output.py:2616-2665: [on-site rows; off-site rows], NOT per crystal),
@@ -213,8 +232,8 @@ class HamGNNPlusPlusOut(nn.Module):
         spin-free block (uu + dd of the real part) and onto ksi (the three L components x the antihermitised blocks), the shell-block
         mean is its own adjoint (hg_block_mean), then the ksi networks' HamLayer.backward.  With add_H_nonsoc the spin-free block is an
         input (the non-SOC model's prediction) and only the ksi path carries gradients -- the Uni-HamGNN SOC training mode."""
-        if not self.ham_only or self.zero_point_shift:
-            raise NotImplementedError("head backward: ham_only, without the zero-point shift")
+        if not self.ham_only:
+            raise NotImplementedError("head backward: ham_only=True (reference overlaps)")
         rep = graph_representation
         dev = data.z.device
         if self._compiled_for != dev:
@@ -224,6 +243,8 @@ class HamGNNPlusPlusOut(nn.Module):
         inv, edge_counts = self._global_inverse(data)
         n = self.nao_max
         gH = grad_hamiltonian.float()
+        if self.zero_point_shift:                              # the shift is the last step of the forward: its adjoint comes first
+            gH = self._zero_point_shift_adjoint(data, gH, edge_counts)
         g_node = g_edge = None
         grads = {}
         if self.soc_switch and self.soc_basis == "su2":

@@ -312,6 +312,23 @@ def hk_assemble(on, off, nbr_shift, kvec, pair_ptr, pair_edges, pair_ij, n_atoms
     return out.to(torch.complex64)
 
 
+def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
+    """hg_zero_point_shift, in place on H: one dE per batch over the elements with S > threshold (SOC: spin-diagonal real blocks)"""
+    Sd, sel = S.double(), S > threshold
+    if not soc:
+        dE = ((H.double() - Href.double())[sel]).sum() / Sd[sel].sum()
+        H -= (dE * Sd).float()
+        return dE.float().reshape(1)
+    n = nao
+    H5, R5, S3 = H.reshape(-1, 2, n, 2, n), Href.double().reshape(-1, 2, n, 2, n), Sd.reshape(-1, n, n)
+    diff = (H5[:, 0, :, 0, :].double() + H5[:, 1, :, 1, :].double()) - (R5[:, 0, :, 0, :] + R5[:, 1, :, 1, :])
+    s3 = sel.reshape(-1, n, n)
+    dE = diff[s3].sum() / (2.0 * S3[s3].sum())
+    H5[:, 0, :, 0, :] -= (dE * S3).float()
+    H5[:, 1, :, 1, :] -= (dE * S3).float()
+    return dE.float().reshape(1)
+
+
 def install(mp):
     """monkeypatch hamgnn_amd.ops with the stand-ins above (pytest's `monkeypatch` fixture: undone after the test)"""
     mp.setattr(ops, "_require_gpu", lambda t: None)
@@ -319,5 +336,5 @@ def install(mp):
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
     for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
                  "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "block_mean", "soc_assemble", "attention_aggregate",
-                 "hk_assemble"):
+                 "hk_assemble", "zero_point_shift"):
         mp.setattr(ops, name, globals()[name])

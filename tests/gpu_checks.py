@@ -283,7 +283,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False, lite=False):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False, lite=False, zps=False):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -315,13 +315,17 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
                 for p_ in rb.atomic_embedding.parameters():
                     p_.copy_(0.6 * torch.randn(p_.shape))
         skw = dict(soc_switch=True, soc_basis="so3", add_H_nonsoc=(soc == "so3_nonsoc")) if soc else {}
-        rh = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=False, **skw)
+        rh = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=False, zero_point_shift=zps, **skw)
     finally:
         torch.set_default_dtype(prev)
     from hamgnn_amd.data import collate
     gs = [S.add_random_targets(S.random_cell(n_atoms + c, [14, 8, 6, 1], seed=seed + c, density=0.004), nao, seed=seed + c, soc=bool(soc))
           for c in range(crystals)]
     g = gs[0] if crystals == 1 else collate(gs)
+    if zps:                                                    # the zero-point shift divides by the sum of the overlaps: give the targets real ones
+        gen_s = torch.Generator().manual_seed(seed + 70)
+        g["Son"] = torch.eye(nao).reshape(1, -1).repeat(g.num_nodes, 1) + 0.01 * torch.randn(g.num_nodes, nao * nao, generator=gen_s)
+        g["Soff"] = 0.05 * torch.randn(g.num_edges, nao * nao, generator=gen_s)
     if soc == "so3_nonsoc":                                    # the frozen non-SOC model's prediction (Uni-HamGNN chain): an input here
         gen_ = torch.Generator().manual_seed(seed + 50)
         g["Hon_nonsoc"], g["Hoff_nonsoc"] = 0.1 * torch.randn(g.num_nodes, nao * nao, generator=gen_), 0.1 * torch.randn(g.num_edges, nao * nao, generator=gen_)
@@ -339,7 +343,7 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
         Backbone = HamGNNConvE3
     model = Model(load_weights(Backbone(cfg), dict(rb.state_dict())),
                   load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
-                                                 calculate_sparsity=False, zero_point_shift=False, **(skw if soc else dict(soc_switch=False))),
+                                                 calculate_sparsity=False, zero_point_shift=zps, **(skw if soc else dict(soc_switch=False))),
                                dict(rh.state_dict()))).to(device)
     r = training_step(model, g.to(device), metric=metric, target=target.float().to(device))
     torch.cuda.synchronize()
