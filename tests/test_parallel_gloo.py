@@ -161,3 +161,60 @@ def test_gradient_allreduce_two_ranks_gloo(tmp_path):
     mp.spawn(_worker_grads, args=(2, port, tmp), nprocs=2, join=True)
     for r in range(2):
         assert json.load(open(os.path.join(tmp, f"g{r}.json")))["ok"]
+
+
+def _worker_product(rank, world, port, tmp):
+    """the PRODUCT's own sharded forward (parallel.shard_graph + the all-reduce hook inside HamGNNConvE3.forward + the head on the local
+    edges) on the CPU stand-ins of the kernels, vs the unsharded run"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from tests import cpu_ops
+    from tests.gpu_checks import MINI, SH
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+
+    class _MP:
+        @staticmethod
+        def setattr(o, n, v):
+            setattr(o, n, v)
+    cpu_ops.install(_MP)
+    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False)
+    torch.manual_seed(666)
+    model = HamGNNConvE3(cfg)
+    head = HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=False,
+                             calculate_sparsity=False)
+    g = S.add_random_targets(S.random_cell(5, [14, 8, 6, 1], seed=7, density=0.004), 19, seed=7)
+    N, E = g.num_nodes, g.num_edges
+    sg = parallel.shard_graph(g, rank, world)
+    with torch.no_grad():
+        out = head(sg, model(sg))["hamiltonian"]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (sg["_hg_edge_ids"], out[:N], out[N:]))
+    if rank == 0:
+        with torch.no_grad():
+            ref = head(g, model(g))["hamiltonian"]
+        off = torch.zeros(E, out.shape[1])
+        for ids, on, of in gathered:
+            off[ids] = of
+        on_err = max(float((on - gathered[0][1]).abs().max()) for _, on, _ in gathered)
+        err = float((torch.cat([gathered[0][1], off], 0) - ref).abs().max() / ref.abs().max())
+        with open(tmp, "w") as f:
+            json.dump({"err": err, "on_err": on_err, "edges_per_rank": [int(x[0].numel()) for x in gathered]}, f)
+    dist.destroy_process_group()
+
+
+def test_product_sharded_forward_on_cpu_stand_ins_gloo(tmp_path):
+    """world_size 2: what bench.py --gpus N runs per rank (pair-sharded edges, one all-reduce of the node aggregates per ConvBlock, the
+    head on the rank's edges), with the product's host code and the CPU stand-ins of the kernels (tests/cpu_ops.py)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tmp = str(tmp_path / "prod.json")
+    mp.spawn(_worker_product, args=(2, port, tmp), nprocs=2, join=True)
+    r = json.loads(open(tmp).read())
+    assert r["err"] < 1e-5 and r["on_err"] < 1e-5 and len(r["edges_per_rank"]) == 2 and min(r["edges_per_rank"]) > 0, r
