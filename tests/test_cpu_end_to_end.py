@@ -92,3 +92,10 @@ def test_gpu_check_functions_on_the_cpu_stand_ins(cpu_backend, name):
     assert _REL(r) and any(k.endswith("rel_err") for k in r), r
     if "sparsity_ratio_reference" in r:
         assert abs(r["sparsity_ratio"] - r["sparsity_ratio_reference"]) < 1e-6 * r["sparsity_ratio_reference"]
+
+
+def test_training_loop_on_cpu(cpu_backend):
+    """a few optimiser steps of the whole model (training_step -> Adam -> device-side refresh of the packed weights at the next forward):
+    the teacher-student loss falls monotonically"""
+    r = G.check_full_training(device="cpu", steps=5)
+    assert all(b < a for a, b in zip(r["losses"], r["losses"][1:])), r

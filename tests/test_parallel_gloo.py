@@ -218,3 +218,59 @@ def test_product_sharded_forward_on_cpu_stand_ins_gloo(tmp_path):
     mp.spawn(_worker_product, args=(2, port, tmp), nprocs=2, join=True)
     r = json.loads(open(tmp).read())
     assert r["err"] < 1e-5 and r["on_err"] < 1e-5 and len(r["edges_per_rank"]) == 2 and min(r["edges_per_rank"]) > 0, r
+
+
+def _worker_ddp(rank, world, port, tmp):
+    """data-parallel training step: every rank its own crystal; training_step's gradient all-reduce == the mean of the ranks' local gradients"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from tests import cpu_ops
+    from tests.gpu_checks import MINI, SH
+    from hamgnn_amd import training as T
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+
+    class _MP:
+        @staticmethod
+        def setattr(o, n, v):
+            setattr(o, n, v)
+    cpu_ops.install(_MP)
+    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=1, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False)
+    torch.manual_seed(5)                                        # the same model on every rank
+    model = Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                                       soc_switch=False, calculate_sparsity=False, zero_point_shift=False))
+    g = S.add_random_targets(S.random_cell(3 + rank, [14, 8, 6, 1], seed=20 + rank, density=0.004), 19, seed=rank)      # a different crystal per rank
+    keep = T.allreduce_gradients
+    T.allreduce_gradients = lambda m, average=True: None         # local gradients first
+    T.training_step(model, g, metric="mse")
+    local = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    for p in model.parameters():
+        p.grad = None
+    T.allreduce_gradients = keep
+    T.training_step(model, g, metric="mse")
+    reduced = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    both = [None] * world
+    dist.all_gather_object(both, (local, reduced))
+    if rank == 0:
+        mean = sum(b[0] for b in both) / world
+        err = float((both[0][1] - mean).abs().max() / mean.abs().max())
+        same = float((both[0][1] - both[1][1]).abs().max())
+        with open(tmp, "w") as f:
+            json.dump({"err": err, "same": same, "differs_from_local": float((both[0][0] - mean).abs().max() / mean.abs().max())}, f)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_step_gloo(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tmp = str(tmp_path / "ddp.json")
+    mp.spawn(_worker_ddp, args=(2, port, tmp), nprocs=2, join=True)
+    r = json.loads(open(tmp).read())
+    assert r["err"] < 1e-6 and r["same"] == 0.0 and r["differs_from_local"] > 1e-3, r
