@@ -183,7 +183,7 @@ class _BackboneBase(nn.Module):
 
 
     # ---- backward pieces shared by the two backbones
-    def _backward_pair(self, li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk):
+    def _backward_pair(self, li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk, data=None):
         """PairInteractionBlock (interaction_blocks.py:130-164): f_out = MP(up_src(node_out)[src], up_tar(node_out)[dst], f_in) + skip(f_in).
         g_node: gradient of node_out so far, g_f: gradient of f_out (edge frame).  Returns (g_node, gradient of f_in); parameter
         gradients go into `grads`."""
@@ -197,6 +197,9 @@ class _BackboneBase(nn.Module):
             grads.update({pre + "conv_tp." + k: v for k, v in g_tp.items()})
             g_up_s = ops.segment_sum(gs, rp_s, pm_s, N)
             g_up_t = ops.segment_sum(gd, rp_r, pm_r, N)
+            if data is not None:                               # edge-sharded: sums over THIS rank's edges -> sums over all edges (RCCL)
+                parallel.allreduce_nodes(g_up_s, data)
+                parallel.allreduce_nodes(g_up_t, data)
             grads[pre + "linear_up_src.weight"] = pair.linear_up_src.weight_grad(node_out, g_up_s)
             grads[pre + "linear_up_tar.weight"] = pair.linear_up_tar.weight_grad(node_out, g_up_t)
             g_node = g_node + pair.linear_up_src.backward_data(g_up_s) + pair.linear_up_tar.backward_data(g_up_t)
@@ -319,8 +322,8 @@ class HamGNNConvE3(_BackboneBase):
         linear_up adjoints, the fused skip o3.Linear)  ->  ResidualBlock  ->  skip o3.Linear  ->  ConvBlockE3's message block with the
         receiver scatter's adjoint (a gather) fused into its staging;  then the pair embedding and the chemical embedding table.
         Returns {reference parameter name: gradient in the reference's layout}.  Non-lite, no CorrProduct, no charge doping, one rank."""
-        if parallel.is_sharded(data):
-            raise NotImplementedError("backbone backward of an edge-sharded graph")
+        if parallel.is_sharded(data) and self.apply_charge_doping:
+            raise NotImplementedError("backbone backward of an edge-sharded graph with charge doping")
         tape = rep["_tape"]
         geo = rep["_geometry"]
         z = data.z.contiguous()
@@ -335,7 +338,7 @@ class HamGNNConvE3(_BackboneBase):
         for li in reversed(range(self.num_layers)):
             conv, pair, t = self.convolutions[li], self.pair_interactions[li], tape[li]
             node_in, f_in, agg, node_out = t["node_in"], t["f_in"], t["agg"], t["node_out"]
-            g_node, g_f = self._backward_pair(li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk)
+            g_node, g_f = self._backward_pair(li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk, data)
             # ---- ConvBlockE3 (convolution.py:116-160): node_out = residual(agg) + skip(node_in), agg = scatter_dst MP(node_in[src], node_in[dst], f_in)
             if self.use_corr_prod:                              # CorrProductBlock between the ConvBlock's residual and the pair block
                 g_node, g_cp = self.corr_products[li].backward(t["node_res"], z, g_node)
@@ -347,7 +350,9 @@ class HamGNNConvE3(_BackboneBase):
             g_node_in = conv.skip_linear.backward_data(g_node)
             gs, gd, ge, g_tp = conv.conv_tp.backward(node_in, node_in, f_in, geo, rot, g_agg, out_is_global=True, gather=geo.dst, chunk=chunk)
             put(pre + "conv_tp.", g_tp)
-            g_node = g_node_in + ops.segment_sum(gs, rp_s, pm_s, N) + ops.segment_sum(gd, rp_r, pm_r, N)
+            part = ops.segment_sum(gs, rp_s, pm_s, N) + ops.segment_sum(gd, rp_r, pm_r, N)
+            parallel.allreduce_nodes(part, data)               # edge-sharded: this rank's edges only -> all edges
+            g_node = g_node_in + part
             g_f = g_f + ge
         self._backward_embeddings(data, rep, geo, g_node, g_f, grads, chunk)
         return grads

@@ -70,3 +70,30 @@ def allreduce_nodes(t: torch.Tensor, data) -> torch.Tensor:
         raise RuntimeError("graph is sharded but torch.distributed is not initialised")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+# ---- training on an edge-sharded crystal (model-parallel; hamgnn_amd.training): which parameter gradients are sums over the edges
+def is_edge_summed(name: str) -> bool:
+    """In the sharded backward every node-level tensor is replicated (each partial sum over a rank's edges is all-reduced before it is
+    used), so the gradients of node-level parameters come out identical on all ranks; the gradients of parameters applied PER EDGE are
+    sums over the rank's own edges and still have to be added up across the ranks: the tensor-product blocks (message blocks, pair
+    embedding), the edge-row skip Linear of a PairInteractionBlock, the pair embedding's element tables, the off-site read-out networks."""
+    return (".conv_tp." in name or name.startswith("conv_tp.") or (name.startswith("pair_interactions.") and ".skip_linear." in name)
+            or name.startswith("pair_embedding.") or name.startswith("offsite_"))
+
+
+def allreduce_edge_summed_gradients(named_grads, data):
+    """SUM (not mean) over the ranks of the per-edge parameter gradients of a sharded training step, one flat bucket"""
+    if not is_sharded(data):
+        return
+    import torch.distributed as dist
+    keys = [k for k in named_grads if is_edge_summed(k)]
+    if not keys:
+        return
+    flat = torch.cat([named_grads[k].reshape(-1).float() for k in keys])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    o = 0
+    for k in keys:
+        n = named_grads[k].numel()
+        named_grads[k] = flat[o:o + n].reshape(named_grads[k].shape).to(named_grads[k].dtype)
+        o += n

@@ -12,6 +12,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import parallel
 from .topo import gget
 
 
@@ -27,6 +28,27 @@ def _loss_and_grad(pred: torch.Tensor, target: torch.Tensor, metric: str):
         rm = torch.sqrt((diff * diff).mean())
         return rm, diff / (n * rm.clamp_min(1e-30))
     raise ValueError(f"unsupported loss metric {metric!r} (mae | mse | rmse)")
+
+
+def _loss_and_grad_sharded(pred, target, metric: str, n_on: int):
+    """loss over [replicated on-site rows; this rank's off-site rows] of an edge-sharded crystal == the loss of the whole crystal:
+    the off-site sums are added up over the ranks, the on-site rows counted once"""
+    import torch.distributed as dist
+    diff = pred - target
+    metric = metric.lower()
+    f = {"mae": torch.abs, "mse": torch.square, "rmse": torch.square}.get(metric)
+    if f is None:
+        raise ValueError(f"unsupported loss metric {metric!r} (mae | mse | rmse)")
+    stats = torch.stack([f(diff[n_on:]).sum().double(), torch.tensor(float(diff[n_on:].numel()), dtype=torch.float64, device=diff.device)])
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    n = float(stats[1]) + diff[:n_on].numel()
+    total = (stats[0] + f(diff[:n_on]).sum().double()) / n
+    if metric == "mae":
+        return total.to(pred.dtype), torch.sign(diff) / n
+    if metric == "mse":
+        return total.to(pred.dtype), 2.0 * diff / n
+    rm = torch.sqrt(total)
+    return rm.to(pred.dtype), diff / (n * rm.clamp_min(1e-30).to(pred.dtype))
 
 
 @torch.no_grad()
@@ -115,7 +137,13 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
     if tgt is None:
         raise ValueError("training_step: the batch carries no target (Hon / Hoff or hamiltonian)")
     H = out["hamiltonian"]
-    if losses is None:
+    sharded = parallel.is_sharded(batch)
+    if sharded:
+        # model-parallel step on an edge-sharded crystal: the on-site rows are replicated, every rank holds its own off-site rows
+        if losses is not None:
+            raise NotImplementedError("training_step on an edge-sharded graph: the plain hamiltonian loss")
+        loss, gH = _loss_and_grad_sharded(H, tgt.to(H.dtype), metric, int(batch.z.shape[0]))
+    elif losses is None:
         loss, gH = _loss_and_grad(H, tgt.to(H.dtype), metric)
     else:
         # the reference's `losses` list (Model.py:150-196): [{metric, prediction, target, loss_weight}] over `hamiltonian` and / or
@@ -141,6 +169,9 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
             loss = loss + w * li
     g_node, g_edge, g_head = head.backward(batch, rep, gH)
     g_back = backbone.backward(batch, rep, g_node, g_edge)
+    if sharded:                                                # per-edge parameters: sum the ranks' partial gradients (one flat bucket each)
+        parallel.allreduce_edge_summed_gradients(g_head, batch)
+        parallel.allreduce_edge_summed_gradients(g_back, batch)
     for mod, grads in ((head, g_head), (backbone, g_back)):
         params = dict(mod.named_parameters())
         missing = set(params) - set(grads)
@@ -150,6 +181,7 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
             p = params[k]
             g = g.reshape(p.shape).to(p.dtype)
             p.grad = g.clone() if p.grad is None else p.grad + g
-    allreduce_gradients(model)                                 # data-parallel runs: mean over ranks, one collective; else a no-op
+    if not sharded:                                            # (a sharded step uses the process group for the model-parallel sums)
+        allreduce_gradients(model)                             # data-parallel runs: mean over ranks, one collective; else a no-op
     weights_changed(model)
     return {"loss": loss, "hamiltonian": H}
