@@ -43,16 +43,15 @@ class HamGNNTransformer(_BackboneBase):
     def forward(self, data, save_for_backward: bool = False):
         """save_for_backward: keep the layer inputs on the result (`_tape`) for `backward`"""
         z, topo, geo, node, f = self._embed(data)
-        shard = data.get("_hg_shard") if hasattr(data, "get") else None
-        if shard is not None and shard[1] != 1:
-            raise NotImplementedError("HamGNNTransformer on an edge-sharded graph: the per-node soft-max needs a max / sum exchange "
-                                      "between the ranks that is not built (single-GPU only)")
+        from .. import parallel
+        if parallel.is_sharded(data) and save_for_backward:
+            raise NotImplementedError("HamGNNTransformer: the backward of the edge-sharded attention is not built")
         rowptr, perm = topo.receiver_csr()
         tape = [] if save_for_backward else None
         for att, corr, pair in zip(self.orb_transformers, self.corr_products, self.pair_interactions):
             if tape is not None:
                 tape.append(dict(node_in=node, f_in=f))
-            node = att.run(node, f, geo, self._rot_tab, rowptr, perm)              # AttentionBlockE3.forward (attention.py:315-360)
+            node = att.run(node, f, geo, self._rot_tab, rowptr, perm, data)        # AttentionBlockE3.forward (attention.py:315-360)
             if tape is not None:
                 tape[-1]["node_att"] = node
             node = corr(node, z)                                                    # CorrProductBlock.forward (interaction_blocks.py:234-260)

@@ -496,13 +496,40 @@ class AttentionBlockE3(nn.Module):
         self._head_tab = torch.from_numpy(self._head_tab_np).to(device)
         self._cut = self.cutoff_func.cut_param.detach().float().reshape(1).contiguous().to(device)
 
-    def run(self, node, f, geo: ops.Geometry, rot_tab, rowptr, perm):
-        """node [N, Dp] planar (global frame), f [E, Dp] planar edge features (edge frame) -> new node rows (attention.py:315-360)"""
+    def run(self, node, f, geo: ops.Geometry, rot_tab, rowptr, perm, data=None):
+        """node [N, Dp] planar (global frame), f [E, Dp] planar edge features (edge frame) -> new node rows (attention.py:315-360).
+        data: the graph, for edge-sharded runs (the soft-max of a node then spans the edges of several ranks)"""
+        from . import parallel
         sc = self.skip_linear(node)
         K = self.linear_key(node)
         value = self.conv_tp_value.run_nodes(self.linear_up_src(node), self.linear_up_tar(node), self.linear_up_edge(f), geo, rot_tab)
         agg = ops.attention_aggregate(K, value, geo, rowptr, perm, self._head_tab, self.num_heads, self.head_dim, self._cut, self.cutoff)
+        if data is not None and parallel.is_sharded(data):
+            agg = self._merge_sharded_softmax(agg, K, geo)
         return self.residual(agg, extra=sc)
+
+    def _merge_sharded_softmax(self, agg_local, K, geo):
+        """edge-sharded attention: `agg_local` is normalised over THIS rank's incoming edges.  With the rank's soft-max statistics per
+        (node, head) -- m_r = max logit, Z_r = sum exp(logit - m_r) -- the rank's un-normalised sum is agg_local (Z_r + 1e-16); the global
+        result is  sum_r exp(m_r - m) (un-normalised sum)_r / (sum_r exp(m_r - m) Z_r + 1e-16),  m = max_r m_r:  one MAX all-reduce of
+        [N, H], one SUM all-reduce of [N, H] and one of [N, Dp] per block (RCCL)."""
+        import torch.distributed as dist
+        N, H = K.shape[0], self.num_heads
+        logits = ops.attention_logits(K, geo, self._head_tab, H, self.head_dim, self._cut, self.cutoff)
+        dst = geo.dst.long()
+        m_r = torch.full((N, H), -float("inf"), device=K.device, dtype=logits.dtype).scatter_reduce(0, dst[:, None].expand(-1, H), logits, "amax")
+        Z_r = torch.zeros(N, H, device=K.device, dtype=logits.dtype).index_add_(0, dst, torch.exp(logits - m_r[dst]))
+        m = m_r.clone()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        scale = torch.where(torch.isinf(m_r), torch.zeros_like(m_r), torch.exp(m_r - m))
+        Zs = Z_r * scale
+        dist.all_reduce(Zs, op=dist.ReduceOp.SUM)
+        M = torch.zeros(K.shape[1], H, device=K.device, dtype=agg_local.dtype)   # column -> head indicator (padding columns: zero)
+        cols = torch.nonzero(self._head_tab >= 0).reshape(-1)
+        M[cols, self._head_tab[cols].long()] = 1.0
+        num = agg_local * (((Z_r + 1e-16) * scale) @ M.t())
+        dist.all_reduce(num, op=dist.ReduceOp.SUM)
+        return (num / ((Zs + 1e-16) @ M.t()).clamp_min(1e-30)).contiguous()
 
 
     def backward(self, node, f, geo: ops.Geometry, rot_tab, topo, g_out, chunk: int = 65536):

@@ -322,6 +322,17 @@ def attention_aggregate(K: torch.Tensor, V: torch.Tensor, geo: "Geometry", rowpt
 
 
 @_on_tensor_device
+def attention_logits(K: torch.Tensor, geo: "Geometry", head_tab: torch.Tensor, H: int, head_dim: int, cut_param: torch.Tensor, cutoff: float) -> torch.Tensor:
+    """[E, H] soft-cutoff-weighted per-head dot products of the two gathered key rows (the first half of attention_aggregate; used on its
+    own by the edge-sharded attention, which needs the per-node soft-max statistics of the rank's edges)"""
+    Dp, E = int(K.shape[1]), geo.E
+    logits = torch.empty(E, H, device=K.device, dtype=torch.float32)
+    check(lib().hg_attn_logits(ptr(K), i64(K.stride(0)), ptr(geo.src), ptr(geo.dst), ptr(geo.length), ptr(head_tab), i32(Dp), i32(H),
+                               ptr(cut_param), f32(cutoff), f32(1.0 / math.sqrt(head_dim)), i64(E), ptr(logits), _stream()), "hg_attn_logits")
+    return logits
+
+
+@_on_tensor_device
 def gate(x: torch.Tensor, tabs, consts: torch.Tensor) -> torch.Tensor:
     """tabs = (act_tab [nact,2], out_tab [Dout,2]) device int32 tensors of plan.gate_tables_compact"""
     act_tab, out_tab = tabs

@@ -291,6 +291,16 @@ def attention_aggregate(K, V, geo, rowptr, perm, head_tab, H, head_dim, cut_para
     return torch.zeros(N, Dp, dtype=torch.float64).index_add_(0, dst, (alpha @ M.t()) * V.double()).float()
 
 
+def attention_logits(K, geo, head_tab, H, head_dim, cut_param, cutoff):
+    Dp = K.shape[1]
+    M = torch.zeros(Dp, H, dtype=torch.float64)
+    cols = torch.nonzero(head_tab >= 0).reshape(-1)
+    M[cols, head_tab[cols].long()] = 1.0
+    x = cut_param.reshape(()).double() * (1.0 - geo.length.double() / cutoff)
+    cut = torch.where(x > 0, torch.exp(-1.0 / torch.where(x > 0, x, torch.ones_like(x))), torch.zeros_like(x))
+    return (cut[:, None] / math.sqrt(head_dim) * ((K[geo.src.long()].double() * K[geo.dst.long()].double()) @ M)).float()
+
+
 def hk_assemble(on, off, nbr_shift, kvec, pair_ptr, pair_edges, pair_ij, n_atoms, nao, orank, ooff, M):
     """hg_hk_assemble: H(k) of one crystal in the compact orbital basis"""
     nk = kvec.shape[0]
@@ -336,5 +346,5 @@ def install(mp):
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
     for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
                  "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "block_mean", "soc_assemble", "attention_aggregate",
-                 "hk_assemble", "zero_point_shift"):
+                 "attention_logits", "hk_assemble", "zero_point_shift"):
         mp.setattr(ops, name, globals()[name])

@@ -163,7 +163,7 @@ def test_gradient_allreduce_two_ranks_gloo(tmp_path):
         assert json.load(open(os.path.join(tmp, f"g{r}.json")))["ok"]
 
 
-def _worker_product(rank, world, port, tmp):
+def _worker_product(rank, world, port, tmp, transformer=False):
     """the PRODUCT's own sharded forward (parallel.shard_graph + the all-reduce hook inside HamGNNConvE3.forward + the head on the local
     edges) on the CPU stand-ins of the kernels, vs the unsharded run"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -183,8 +183,14 @@ def _worker_product(rank, world, port, tmp):
                cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
                correlation=2, num_hidden_features=4, use_corr_prod=False)
     torch.manual_seed(666)
-    model = HamGNNConvE3(cfg)
-    head = HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=False,
+    irr = MINI
+    if transformer:                                             # attention backbone: the soft-max of a node spans the edges of both ranks
+        from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer
+        irr = "8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o"
+        model = HamGNNTransformer(dict(cfg, irreps_node_features=irr, num_heads=2))
+    else:
+        model = HamGNNConvE3(cfg)
+    head = HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=False,
                              calculate_sparsity=False)
     g = S.add_random_targets(S.random_cell(5, [14, 8, 6, 1], seed=7, density=0.004), 19, seed=7)
     N, E = g.num_nodes, g.num_edges
@@ -204,6 +210,19 @@ def _worker_product(rank, world, port, tmp):
         with open(tmp, "w") as f:
             json.dump({"err": err, "on_err": on_err, "edges_per_rank": [int(x[0].numel()) for x in gathered]}, f)
     dist.destroy_process_group()
+
+
+def test_sharded_attention_backbone_gloo(tmp_path):
+    """HamGNNTransformer on an edge-sharded crystal: per-node soft-max statistics merged across the ranks (max / sum all-reduces)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tmp = str(tmp_path / "att.json")
+    mp.spawn(_worker_product, args=(2, port, tmp, True), nprocs=2, join=True)
+    r = json.loads(open(tmp).read())
+    assert r["err"] < 1e-5 and r["on_err"] < 1e-5 and min(r["edges_per_rank"]) > 0, r
 
 
 def test_product_sharded_forward_on_cpu_stand_ins_gloo(tmp_path):
