@@ -77,6 +77,9 @@ _FORWARD_CASES = {
     "message_pack_backward": lambda: G.check_message_pack_backward("cpu", seed=1, E=21),
     "message_pack_weight_grads": lambda: G.check_message_pack_weight_grads("cpu", seed=1, E=21),
     "attribute_style_graph": lambda: G.check_attribute_style_graph("cpu"),
+    "zero_point_shift": lambda: G.check_zero_point_shift("cpu"),
+    "head_overlap_networks": lambda: G.check_head_overlap("cpu"),
+    "conv_message_chain_backward": lambda: G.check_conv_message_backward("cpu", n_atoms=4),
 }
 
 
