@@ -127,6 +127,18 @@ class Model(nn.Module):
                     np.save(os.path.join(log_dir, f"target_{tk}.npy"), targets[tk])
         return preds, targets
 
+    def save_checkpoint(self, path: str, **extra):
+        """write the model in the checkpoint layout the reference reads back (`Model.load_from_checkpoint`, hamgnn/main.py:374-377,
+        527-537): ``{"state_dict": {"representation.*", "output_module.*"}, ...}`` with the reference's parameter names and flat e3nn
+        layouts (tensors only, on the CPU).  The non-learned e3nn / reference buffers the product does not carry (w3j constants,
+        `output_mask`, `freqs`, ...) are rebuilt by the reference's constructors and need `strict=False` there -- they are exactly the
+        keys `load_reference_state_dict` ignores on the way in."""
+        sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items() if k.startswith(("representation.", "output_module."))}
+        ckpt = {"state_dict": sd, "hamgnn_amd": True}
+        ckpt.update(extra)
+        torch.save(ckpt, path)
+        return path
+
     @classmethod
     def load_from_checkpoint(cls, checkpoint_path: str, map_location=None, strict: bool = True, **model_kwargs):
         """Lightning's classmethod, for the checkpoint layouts the reference writes: keys ``representation.*`` / ``output_module.*``."""

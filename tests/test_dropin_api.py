@@ -262,3 +262,25 @@ def test_topology_cache_on_attribute_style_graphs_and_invalidation():
     g2["z"] = torch.tensor([14, 120])
     with pytest.raises(ValueError, match="num_types"):
         get_topology(g2).check_num_types(96)
+
+
+def test_checkpoint_round_trip(tmp_path):
+    """Model.save_checkpoint writes the reference's Lightning key layout; Model.load_from_checkpoint (verified loading) reads it back"""
+    import torch
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model, read_checkpoint_state_dict
+    mini = "8x0e+4x0o+4x1o+2x1e+2x2o+3x2e+2x3o"
+    cfg = dict(num_types=20, irreps_edge_sh="0e+1o+2e+3o", edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=mini, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=True)
+    mk = lambda: dict(representation=HamGNNConvE3(cfg), output=HamGNNPlusPlusOut(mini, mini, nao_max=19, ham_type="openmx", ham_only=True, soc_switch=False))
+    torch.manual_seed(0)
+    a = Model(**mk())
+    path = a.save_checkpoint(str(tmp_path / "last.ckpt"), epoch=3)
+    sd = read_checkpoint_state_dict(path)
+    assert all(k.startswith(("representation.", "output_module.")) for k in sd) and len(sd) == len(a.state_dict())
+    torch.manual_seed(1)
+    b = Model.load_from_checkpoint(path, **mk())
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb), ka
