@@ -17,9 +17,11 @@ import torch
 
 
 def attention_backward(K: torch.Tensor, V: torch.Tensor, g_agg: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, length: torch.Tensor,
-                       head_tab: torch.Tensor, num_heads: int, head_dim: int, cut_param: torch.Tensor, cutoff: float):
+                       head_tab: torch.Tensor, num_heads: int, head_dim: int, cut_param: torch.Tensor, cutoff: float, allreduce=None):
     """K, g_agg: [N, Dp] planar node rows; V: [E, Dp] planar value rows (the frame the forward aggregated them in); head_tab: int [Dp]
-    (head of a column, -1 = padding).  Returns (g_K [N, Dp], g_V [E, Dp], g_cut_param [scalar tensor])."""
+    (head of a column, -1 = padding).  Returns (g_K [N, Dp], g_V [E, Dp], g_cut_param [scalar tensor]).
+    allreduce: for an EDGE-SHARDED graph, `allreduce(tensor, op)` with op in {"max", "sum"} (in place, over the ranks): the soft-max
+    statistics, the per-node dot products, the key gradient and the cutoff gradient are then those of all edges (V, g_V stay local)."""
     N, Dp = K.shape
     dt = K.dtype
     src, dst = src.long(), dst.long()
@@ -37,15 +39,24 @@ def attention_backward(K: torch.Tensor, V: torch.Tensor, g_agg: torch.Tensor, sr
     Dh = (Ks * Kd) @ M                                                          # [E, H]
     logit = cut[:, None] * scale * Dh
     mx = torch.full((N, num_heads), -float("inf"), device=K.device, dtype=dt).scatter_reduce(0, dst[:, None].expand(-1, num_heads), logit, "amax")
+    if allreduce is not None:
+        allreduce(mx, "max")
     ex = torch.exp(logit - mx[dst])
-    den = torch.zeros(N, num_heads, device=K.device, dtype=dt).index_add_(0, dst, ex) + 1e-16
-    alpha = ex / den[dst]                                                       # [E, H]
+    zsum = torch.zeros(N, num_heads, device=K.device, dtype=dt).index_add_(0, dst, ex)
+    if allreduce is not None:
+        allreduce(zsum, "sum")
+    alpha = ex / (zsum + 1e-16)[dst]                                            # [E, H]
     g_V = (alpha @ M.t()) * Gd
     g_alpha = (V * Gd) @ M                                                      # [E, H]
     dot = torch.zeros(N, num_heads, device=K.device, dtype=dt).index_add_(0, dst, alpha * g_alpha)
+    if allreduce is not None:
+        allreduce(dot, "sum")
     g_logit = alpha * (g_alpha - dot[dst])
     g_D = (g_logit * cut[:, None] * scale) @ M.t()                              # [E, Dp], per column of its head
     g_K = torch.zeros_like(K).index_add_(0, src, g_D * Kd).index_add_(0, dst, g_D * Ks)
     g_cut = (g_logit * Dh).sum(1) * scale                                       # [E]
-    g_p = (g_cut * torch.where(pos, cut / (xs * xs), torch.zeros_like(x)) * u).sum()
-    return g_K, g_V, g_p
+    g_p = (g_cut * torch.where(pos, cut / (xs * xs), torch.zeros_like(x)) * u).sum().reshape(1)
+    if allreduce is not None:
+        allreduce(g_K, "sum")
+        allreduce(g_p, "sum")
+    return g_K, g_V, g_p.reshape(())

@@ -44,8 +44,6 @@ class HamGNNTransformer(_BackboneBase):
         """save_for_backward: keep the layer inputs on the result (`_tape`) for `backward`"""
         z, topo, geo, node, f = self._embed(data)
         from .. import parallel
-        if parallel.is_sharded(data) and save_for_backward:
-            raise NotImplementedError("HamGNNTransformer: the backward of the edge-sharded attention is not built")
         rowptr, perm = topo.receiver_csr()
         tape = [] if save_for_backward else None
         for att, corr, pair in zip(self.orb_transformers, self.corr_products, self.pair_interactions):
@@ -77,10 +75,10 @@ class HamGNNTransformer(_BackboneBase):
         g_node, g_f = g_node.contiguous(), g_edge_rot.contiguous()
         for li in reversed(range(self.num_layers)):
             att, corr, pair, t = self.orb_transformers[li], self.corr_products[li], self.pair_interactions[li], tape[li]
-            g_node, g_f = self._backward_pair(li, pair, t["node_out"], t["f_in"], geo, topo, g_node, g_f, grads, chunk)
+            g_node, g_f = self._backward_pair(li, pair, t["node_out"], t["f_in"], geo, topo, g_node, g_f, grads, chunk, data)
             g_node, g_cp = corr.backward(t["node_att"], z, g_node)
             grads.update({f"corr_products.{li}." + k: v for k, v in g_cp.items()})
-            g_node, g_f_att, g_at = att.backward(t["node_in"], t["f_in"], geo, self._rot_tab, topo, g_node, chunk=chunk)
+            g_node, g_f_att, g_at = att.backward(t["node_in"], t["f_in"], geo, self._rot_tab, topo, g_node, chunk=chunk, data=data)
             grads.update({f"orb_transformers.{li}." + k: v for k, v in g_at.items()})
             g_f = g_f + g_f_att
         self._backward_embeddings(data, rep, geo, g_node, g_f, grads, chunk)

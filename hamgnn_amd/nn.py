@@ -532,9 +532,9 @@ class AttentionBlockE3(nn.Module):
         return (num / ((Zs + 1e-16) @ M.t()).clamp_min(1e-30)).contiguous()
 
 
-    def backward(self, node, f, geo: ops.Geometry, rot_tab, topo, g_out, chunk: int = 65536):
+    def backward(self, node, f, geo: ops.Geometry, rot_tab, topo, g_out, chunk: int = 65536, data=None):
         """gradient of run(node, f, ...) for the gradient g_out of the node rows it returned: (g_node, g_f (edge frame), {parameter name:
-        gradient}).  ResidualBlock / Linears: the streaming-kernel adjoints; the attention aggregation (soft-max over incoming edges, the
+        gradient}).  data: the graph, for edge-sharded runs (soft-max statistics and node-level sums then span the ranks).  ResidualBlock / Linears: the streaming-kernel adjoints; the attention aggregation (soft-max over incoming edges, the
         learnable soft cutoff): hamgnn_amd/backward_attn.py; the value MessagePackBlock: its adjoint / materialisation programs, with the
         sender / receiver segment sums for the two gathered node inputs."""
         from .backward_attn import attention_backward
@@ -544,13 +544,19 @@ class AttentionBlockE3(nn.Module):
         value = self.conv_tp_value.run_nodes(us, ut, ue, geo, rot_tab)                 # [E, Dp], global frame
         rowptr, perm = topo.receiver_csr()
         agg = ops.attention_aggregate(K, value, geo, rowptr, perm, self._head_tab, self.num_heads, self.head_dim, self._cut, self.cutoff)
+        from . import parallel
+        allreduce = None
+        if data is not None and parallel.is_sharded(data):
+            import torch.distributed as dist
+            agg = self._merge_sharded_softmax(agg, K, geo)
+            allreduce = lambda t, op: dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
         grads = {}
         g_agg, g_res = self.residual.backward(agg, g_out, extra_given=True)
         grads.update({"residual." + k: v for k, v in g_res.items()})
         grads["skip_linear.weight"] = self.skip_linear.weight_grad(node, g_out)
         g_node = self.skip_linear.backward_data(g_out)
         g_K, g_V, g_p = attention_backward(K, value, g_agg, geo.src, geo.dst, geo.length, self._head_tab, self.num_heads, self.head_dim,
-                                           self._cut, self.cutoff)
+                                           self._cut, self.cutoff, allreduce=allreduce)
         grads["cutoff_func.cut_param"] = g_p.reshape(())
         grads["linear_key.weight"] = self.linear_key.weight_grad(node, g_K)
         grads["linear_query.weight"] = torch.zeros_like(self.linear_query.weight)     # a parameter the reference's forward never reads
@@ -560,6 +566,9 @@ class AttentionBlockE3(nn.Module):
         grads.update({"conv_tp_value." + k: v for k, v in g_cv.items()})
         g_us = ops.segment_sum(gs, *topo.sender_csr(), N)
         g_ut = ops.segment_sum(gd, rowptr, perm, N)
+        if allreduce is not None:                              # this rank's edges -> all edges
+            allreduce(g_us, "sum")
+            allreduce(g_ut, "sum")
         grads["linear_up_src.weight"] = self.linear_up_src.weight_grad(node, g_us)
         grads["linear_up_tar.weight"] = self.linear_up_tar.weight_grad(node, g_ut)
         grads["linear_up_edge.weight"] = self.linear_up_edge.weight_grad(f, ge)

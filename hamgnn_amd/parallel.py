@@ -78,8 +78,8 @@ def is_edge_summed(name: str) -> bool:
     used), so the gradients of node-level parameters come out identical on all ranks; the gradients of parameters applied PER EDGE are
     sums over the rank's own edges and still have to be added up across the ranks: the tensor-product blocks (message blocks, pair
     embedding), the edge-row skip Linear of a PairInteractionBlock, the pair embedding's element tables, the off-site read-out networks."""
-    return (".conv_tp." in name or name.startswith("conv_tp.") or (name.startswith("pair_interactions.") and ".skip_linear." in name)
-            or name.startswith("pair_embedding.") or name.startswith("offsite_"))
+    return (".conv_tp." in name or name.startswith("conv_tp.") or ".conv_tp_value." in name or name.endswith(".linear_up_edge.weight")
+            or (name.startswith("pair_interactions.") and ".skip_linear." in name) or name.startswith("pair_embedding.") or name.startswith("offsite_"))
 
 
 def allreduce_edge_summed_gradients(named_grads, data):

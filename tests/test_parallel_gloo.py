@@ -295,7 +295,7 @@ def test_data_parallel_training_step_gloo(tmp_path):
     assert r["err"] < 1e-6 and r["same"] == 0.0 and r["differs_from_local"] > 1e-3, r
 
 
-def _worker_sharded_training(rank, world, port, tmp):
+def _worker_sharded_training(rank, world, port, tmp, transformer=False):
     """model-parallel training step on an edge-sharded crystal == the single-process step on the whole crystal (loss and every gradient)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -316,10 +316,17 @@ def _worker_sharded_training(rank, world, port, tmp):
                cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
                correlation=2, num_hidden_features=4, use_corr_prod=True)
 
+    irr = "8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o" if transformer else MINI
+
     def make():
         torch.manual_seed(9)
-        return Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
-                                                          soc_switch=False, calculate_sparsity=False, zero_point_shift=False))
+        if transformer:
+            from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer
+            back = HamGNNTransformer(dict(cfg, irreps_node_features=irr, num_heads=2))
+        else:
+            back = HamGNNConvE3(cfg)
+        return Model(back, HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                             soc_switch=False, calculate_sparsity=False, zero_point_shift=False))
     g = S.add_random_targets(S.random_cell(5, [14, 8, 6, 1], seed=11, density=0.004), 19, seed=11)
     model = make()
     r = T.training_step(model, parallel.shard_graph(g, rank, world), metric="mae")
@@ -335,6 +342,20 @@ def _worker_sharded_training(rank, world, port, tmp):
             json.dump({"loss_err": abs(float(r["loss"]) - float(r0["loss"])) / abs(float(r0["loss"])), "grad_err": worst, "n": len(grads)}, f)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_model_parallel_training_step_attention_backbone_gloo(tmp_path):
+    """the same for HamGNNTransformer: the soft-max statistics, the per-node dot products of the soft-max backward, the key gradient and the
+    learnable cutoff's gradient span the edges of both ranks"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tmp = str(tmp_path / "mpt.json")
+    mp.spawn(_worker_sharded_training, args=(2, port, tmp, True), nprocs=2, join=True)
+    r = json.loads(open(tmp).read())
+    assert r["loss_err"] < 1e-6 and r["grad_err"] < 2e-5 and r["n"] > 120, r
 
 
 def test_model_parallel_training_step_gloo(tmp_path):
