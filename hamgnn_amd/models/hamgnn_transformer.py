@@ -40,6 +40,18 @@ class HamGNNTransformer(_BackboneBase):
         self._compile_common(dev)
         return self
 
+    def refresh_weights(self):
+        """after an optimiser step (hamgnn_amd.training): as HamGNNConvE3.refresh_weights -- message blocks repacked on the device, the
+        small tables on the host"""
+        dev = self._compiled_for
+        if dev is None:
+            return
+        for att, corr, pair in zip(self.orb_transformers, self.corr_products, self.pair_interactions):
+            att.refresh(dev)
+            corr.compile(dev)
+            pair.refresh(dev)
+        self._compile_common(dev)
+
     def forward(self, data, save_for_backward: bool = False):
         """save_for_backward: keep the layer inputs on the result (`_tape`) for `backward`"""
         z, topo, geo, node, f = self._embed(data)

@@ -496,6 +496,16 @@ class AttentionBlockE3(nn.Module):
         self._head_tab = torch.from_numpy(self._head_tab_np).to(device)
         self._cut = self.cutoff_func.cut_param.detach().float().reshape(1).contiguous().to(device)
 
+    def refresh(self, device):
+        """after an optimiser step: the Linear tables and the cutoff parameter on the host (< 1 ms each), the value block's programs on
+        the device (hamgnn_amd/repack.py)"""
+        for m in (self.linear_up_src, self.linear_up_tar, self.linear_up_edge, self.residual.linear1, self.residual.linear2, self.linear_key,
+                  self.skip_linear):
+            m.compile(device)
+        if not self.conv_tp_value.refresh():
+            self.conv_tp_value.compile(device, unrotate=True)
+        self._cut = self.cutoff_func.cut_param.detach().float().reshape(1).contiguous().to(device)
+
     def run(self, node, f, geo: ops.Geometry, rot_tab, rowptr, perm, data=None):
         """node [N, Dp] planar (global frame), f [E, Dp] planar edge features (edge frame) -> new node rows (attention.py:315-360).
         data: the graph, for edge-sharded runs (the soft-max of a node then spans the edges of several ranks)"""

@@ -390,7 +390,7 @@ def check_full_training(device="cuda", steps=12):
     return {"first": losses[0], "last": losses[-1], "losses": losses}
 
 
-def check_refresh_equals_recompile(device="cuda", legacy=False):
+def check_refresh_equals_recompile(device="cuda", legacy=False, transformer=False):
     """training: after an optimiser step the message blocks repack their weights on the device (hamgnn_amd/repack.py).  A model that
     took a step, had ALL parameters perturbed and was refreshed must give the loss and every gradient of a freshly compiled model with
     the same parameters."""
@@ -403,8 +403,14 @@ def check_refresh_equals_recompile(device="cuda", legacy=False):
     cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
                cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
                correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
-    mk = lambda: Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
-                                                          soc_switch=False, calculate_sparsity=False, zero_point_shift=False))
+    irr = "8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o" if transformer else MINI
+    if transformer:
+        from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer
+        back = lambda: HamGNNTransformer(dict(cfg, irreps_node_features=irr, num_heads=2))
+    else:
+        back = lambda: HamGNNConvE3(cfg)
+    mk = lambda: Model(back(), HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
+                                                 soc_switch=False, calculate_sparsity=False, zero_point_shift=False))
     torch.manual_seed(21)
     a = mk().to(device)
     g = S.add_random_targets(S.random_cell(6, [14, 8, 6, 1], seed=2, density=0.004), 19, seed=2).to(device)

@@ -53,6 +53,11 @@ def test_device_repack_equals_recompile_on_cpu(cpu_backend):
     assert r["packers"] >= 8 and r["loss_rel_diff"] < 1e-6 and r["grad_max_rel_diff"] < 1e-5, r
 
 
+def test_device_repack_equals_recompile_attention_backbone(cpu_backend):
+    r = G.check_refresh_equals_recompile(device="cpu", transformer=True)
+    assert r["packers"] >= 8 and r["loss_rel_diff"] < 1e-6 and r["grad_max_rel_diff"] < 1e-5, r
+
+
 def test_band_energy_loss_backward_on_cpu(cpu_backend):
     r = G.check_band_energy_backward(device="cpu")
     assert r["g_on_rel_err"] < 1e-4 and r["g_off_rel_err"] < 1e-4 and r["grads_finite"] and r["losses"][-1] < r["losses"][0], r
