@@ -107,3 +107,10 @@ def test_training_loop_on_cpu(cpu_backend):
     the teacher-student loss falls monotonically"""
     r = G.check_full_training(device="cpu", steps=5)
     assert all(b < a for a, b in zip(r["losses"], r["losses"][1:])), r
+
+
+def test_uni_hamgnn_two_model_chain_on_cpu(cpu_backend):
+    """BASELINE config #5 in small: non-SOC universal model (zero-point shift) -> Hon_nonsoc / Hoff_nonsoc -> SOC / so3 model with add_H_nonsoc
+    (hamgnn_amd/uni.py) vs the same chain on the oracle; mixed-Z crystals, nao 26"""
+    r = G.check_uni_chain_vs_oracle("cpu", irreps=G.MINI, n_graphs=2)
+    assert r["real"] < G.TOL and r["imag"] < G.TOL and r["nonsoc"] < G.TOL, r
