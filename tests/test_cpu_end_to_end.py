@@ -114,3 +114,11 @@ def test_uni_hamgnn_two_model_chain_on_cpu(cpu_backend):
     (hamgnn_amd/uni.py) vs the same chain on the oracle; mixed-Z crystals, nao 26"""
     r = G.check_uni_chain_vs_oracle("cpu", irreps=G.MINI, n_graphs=2)
     assert r["real"] < G.TOL and r["imag"] < G.TOL and r["nonsoc"] < G.TOL, r
+
+
+def test_default_irreps_si2_forward_on_cpu(cpu_backend):
+    """BASELINE config #1 (Si diamond 2-atom cell, 172 edges) at the SHIPPED irreps (set A: D = 877, l <= 6, SH to l = 5, 64 radial, three
+    layers, nao 19): the production planner output -- merged items, odd-path templates, split launches for a small crystal, the one-pass
+    read-out tables -- through the product's host code on the CPU stand-ins vs the fp64 oracle"""
+    r = G.check_default_irreps_si2("cpu", "A", "si2")
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL and r["Hnet_rel_err"] < G.TOL, r
