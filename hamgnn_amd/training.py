@@ -1,11 +1,18 @@
-"""Fine-tuning the read-out head on a frozen backbone (the part of the training path that is built): the forward and the
-backward of HamGNNPlusPlusOut (non-SOC) run on the HIP kernels, the gradients land in `parameter.grad` in the reference's flat layouts, so
-any torch optimiser steps them.  What the reference's Lightning `training_step` does around it (hamgnn/models/Model.py:150-196: loss from
-`losses: [{metric, prediction, target, loss_weight}]`) is restated for the Hamiltonian entry.
+"""The training step: what the reference's Lightning `training_step` + `loss.backward()` do per batch (hamgnn/main.py:389-420,
+hamgnn/models/Model.py:150-196), on the HIP kernels and without an autograd graph.
 
-`training_step` chains the backbone's backward behind it (HamGNNConvE3.backward: every block-level backward on the HIP kernels, the
-message blocks' weight gradients through the materialisation programs of hamgnn_amd/backward_mp.py): the gradient of the loss with
-respect to EVERY parameter of the model, i.e. what `trainer.fit` needs per batch (hamgnn/main.py:389-420).  No DDP, no Lightning loop."""
+  training_step(model, batch, ...)   forward with the layer inputs kept -> loss(es) -> head backward -> backbone backward -> `.grad` of EVERY
+                                     parameter in the reference's names / flat layouts (any torch optimiser steps them); both backbones
+                                     (HamGNNConvE3, HamGNNTransformer), the non-SOC / SOC so3 / SOC su2 heads, `losses=[{metric, prediction:
+                                     hamiltonian | band_energy, target, loss_weight}]` as in the reference's config
+  head_training_step(...)            the cheap variant for a frozen backbone (its representation can be reused across steps)
+  allreduce_gradients(model)         data-parallel training (the reference's DDP): mean of the ranks' gradients, one flat bucket
+  parallel.shard_graph(g, r, w)      model-parallel training of ONE large crystal: pass the rank's shard to training_step -- node-level partial
+                                     sums are all-reduced inside the backward, per-edge parameter gradients summed over the ranks
+  weights_changed(model)             after `optimizer.step()`: message blocks repack their weights on the device at the next forward
+                                     (hamgnn_amd/repack.py); training_step calls it for the step that follows
+
+No Lightning loop, no scheduler / logging / checkpoint policy: the caller owns those (`Model.save_checkpoint` writes the reference's layout)."""
 from __future__ import annotations
 
 from typing import Dict, Optional
