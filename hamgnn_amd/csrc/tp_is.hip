@@ -12,42 +12,7 @@
 //   * B operands are read by all waves from the shared staged block; each input row is fetched once per launch (10.8 KB/edge
 //     instead of ~170 KB/edge), and the exposed span latencies drop from one per item to one per phase.
 // Items, fragments and weights are exactly those of the segment-stationary program (same planner output, regrouped).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "hg_common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#ifndef IS_NW
-#define IS_NW 4                  // waves of a workgroup (all on the same 16 edges); plan.py:IS_WAVES.  6 = three waves per SIMD (experiment)
-#endif
-#define IS_NT (64 * IS_NW)
-
-struct IsArgs {
-    const float* src[4];
-    int64_t sstride[4];
-    const float* h2[2];
-    int hidden;
-    const float* wig;
-    int nW;
-    int wig_off[8];
-    float* out;
-    int64_t ostride;
-    int64_t rows;
-    int nseg;                    // single-part launches: the whole program (split launches read these per part, see IS_PART_I32)
-    int nphase;
-    int trash_off;               // float offsets inside the workgroup's LDS
-    int stage_off;
-    int ctr_off;                 // work-claim counter (one dword)
-    int rowtab_off;              // row table of GEMM2's output rows (ints): LDS float offset of every row's centre column, see plan.IsSchedule
-    int rowtab_begin;            // first entry / entries of this part in the global table
-    int rowtab_len;
-    int tile_shift;              // split launches: this wave's private tile copy (floats added to every tile offset)
-    const int64_t* idx[4];       // per source slot: row gather (NULL: row = edge)
-    int rot_mask;                // bit i: source i holds GLOBAL-frame rows that are rotated into the edge frame while staged
-};
-
-#define SEG_UNROTATE 1
+#include "tp_stage.h"
 
 // phase profiler (HG_PROF builds only, tests/bench_tp.py): per-wave shader-clock time between probes, summed over waves
 #ifdef HG_PROF
@@ -66,26 +31,6 @@ struct ProfIs { unsigned long long t[12]; unsigned long long last; };
 #define IS_PROF_PASS
 #define IS_T(k)
 #endif
-
-__device__ __forceinline__ const float* is_pick_src(const IsArgs& A, int i) {
-    return i == 0 ? A.src[0] : (i == 1 ? A.src[1] : (i == 2 ? A.src[2] : A.src[3]));
-}
-__device__ __forceinline__ int64_t is_pick_stride(const IsArgs& A, int i) {
-    return i == 0 ? A.sstride[0] : (i == 1 ? A.sstride[1] : (i == 2 ? A.sstride[2] : A.sstride[3]));
-}
-// (kernel-argument arrays are only ever indexed through select chains: a dynamically indexed member makes the compiler copy the whole
-//  argument block into per-lane scratch -- 232 B x 2.1 M lanes = 0.5 GB of HBM writes per launch in the first build)
-__device__ __forceinline__ int is_pick_wig_off(const IsArgs& A, int l) {
-    return l == 0 ? A.wig_off[0] : (l == 1 ? A.wig_off[1] : (l == 2 ? A.wig_off[2] : (l == 3 ? A.wig_off[3] : (l == 4 ? A.wig_off[4] :
-           (l == 5 ? A.wig_off[5] : (l == 6 ? A.wig_off[6] : A.wig_off[7]))))));
-}
-// LDS-DMA: per-lane global address -> LDS at (wave-uniform base + lane * size); counted by vmcnt
-__device__ __forceinline__ void is_dma16(const float* __restrict__ gsrc, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 2);
-}
-__device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
-}
 
 // One item on the workgroup's 16 edges.  stage: the phase's staged input block(s), image offset(piece p, row e) = 64 p + 4 e per
 // source (pieces of the FULL irrep block: component a, channel piece s -> p = a * P1 + s).
@@ -326,150 +271,6 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #undef IS_COL
 }
 
-// un-rotate (optional) + planar store of one segment, rows split over the four waves; D blocks staged in `dst` (see kernel)
-template <int LK>
-__device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __restrict__ tile, const float* __restrict__ dstage, int mul_k,
-                                            int out_off, int out_mulp, int flags, int64_t e, bool valid, int wave, int lane) {
-    constexpr int NCO = 2 * LK + 1;
-    const int g = lane >> 4, el = lane & 15;
-    const int rowstride = NCO * 16 + 4;
-    const float* __restrict__ tl = tile + el;
-    float* __restrict__ ob = A.out + e * A.ostride + out_off;
-    const int wend = mul_k + ((flags >> 8) & 0xff);            // + channel-padding slots of the planar block (last chunk only)
-    // work unit = (output component a, 16 consecutive channels): one wave writes 64 contiguous bytes per edge and component in four
-    // back-to-back stores, so the memory side sees whole sectors (interleaving the channels of one component over the waves
-    // tripled the HBM write traffic: WRITE_SIZE 1.39 GB vs 0.46 GB of output per 131 072 edges)
-    const int nw16 = (wend + 15) >> 4;
-    const int U = NCO * nw16, per = (U + IS_NW - 1) / IS_NW;              // each wave takes a contiguous range of units (adjacent bytes of the row)
-    const int u_begin = wave * per, u_end = (u_begin + per) < U ? (u_begin + per) : U;
-    if (flags & SEG_UNROTATE) {
-        const float* __restrict__ dl = dstage + el;
-#pragma unroll 1
-        for (int u = u_begin; u < u_end; ++u) {
-            const int a = u / nw16, w0 = (u - a * nw16) * 16;
-            float dc[NCO];
-#pragma unroll
-            for (int m = 0; m < NCO; ++m) dc[m] = dl[(m * NCO + a) * 16];
-#pragma unroll 1
-            for (int w = w0 + g; w < wend && w < w0 + 16; w += 4) {
-                const float* __restrict__ tw = tl + (w < mul_k ? w : 0) * rowstride;
-                float acc = 0.f;
-#pragma unroll
-                for (int m = 0; m < NCO; ++m) acc = fmaf(dc[m], tw[m * 16], acc);
-                if (valid) ob[a * out_mulp + w] = w < mul_k ? acc : 0.f;
-            }
-        }
-    } else {
-#pragma unroll 1
-        for (int u = u_begin; u < u_end; ++u) {
-            const int a = u / nw16, w0 = (u - a * nw16) * 16;
-#pragma unroll 1
-            for (int w = w0 + g; w < wend && w < w0 + 16; w += 4)
-                if (valid) ob[a * out_mulp + w] = w < mul_k ? tl[w * rowstride + a * 16] : 0.f;
-        }
-    }
-}
-
-#ifndef HG_STAGE_U
-#define HG_STAGE_U(L) 1          // measured (profiles/r02_tp_is_experiments.md): 2-4 pieces in flight per step are SLOWER (8.39 vs 8.13 ms)
-#endif
-// Stage one input block (all its sources) of the workgroup's 16 edges: image offset(piece p = a * P1 + s, row e) = 64 p + 4 e per source.
-//   plain source  : rows are already in the edge frame -> LDS-DMA, the four waves share the DMA instructions;
-//   rotated source: rows are node features in the global frame, gathered by idx[] and multiplied by D^l(R_e) on the way in
-//                   (x'[a] = sum_b D[a][b] x[b], hamgnn_amd/so3.py) -- ONCE per edge, input block and launch, which replaces the
-//                   separate hg_rotate_gather pass and the materialised per-edge copies xs', xd' of the node rows.
-template <int L>
-__device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restrict__ P, float* __restrict__ stage, int64_t erow, int wave, int lane) {
-    constexpr int N = 2 * L + 1;
-    const int s0 = P[0], s1 = P[1], in_off = P[2], in_mulp = P[3], nsrc = P[5];
-    const int g = lane >> 4, el = lane & 15;
-    const int P1 = in_mulp >> 2;
-    const int Pfull = N * P1;
-    const int nj = (Pfull + 3) >> 2;
-    const bool rot0 = (A.rot_mask >> s0) & 1, rot1 = nsrc == 2 && ((A.rot_mask >> s1) & 1);
-    if (rot0 && rot1 && (IS_NW <= 4 || L <= 3)) {
-        // sender and receiver rows of the node branch share the edge's Wigner row: one output piece t = a * P1 + p (component a,
-        // channels 4p..4p+3) of BOTH sources per (wave, g) slot and step -- 2 N float4 loads of the node rows + the N entries of
-        // row a in flight together, 2 N float4 FMAs, two ds_write_b128 straight into the operand images
-        const int64_t* __restrict__ ix0 = s0 == 0 ? A.idx[0] : (s0 == 1 ? A.idx[1] : (s0 == 2 ? A.idx[2] : A.idx[3]));
-        const int64_t* __restrict__ ix1 = s1 == 0 ? A.idx[0] : (s1 == 1 ? A.idx[1] : (s1 == 2 ? A.idx[2] : A.idx[3]));
-        const int64_t r0 = ix0 ? ix0[erow] : erow, r1 = ix1 ? ix1[erow] : erow;
-        const float* __restrict__ row0 = is_pick_src(A, s0) + r0 * is_pick_stride(A, s0) + in_off;
-        const float* __restrict__ row1 = is_pick_src(A, s1) + r1 * is_pick_stride(A, s1) + in_off;
-        const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
-        float* __restrict__ d0 = stage + P[6] + el * 4;
-        float* __restrict__ d1 = stage + P[7] + el * 4;
-        // U output pieces per step (register budget by l): the node rows come from the Infinity Cache / HBM (35 MB of node rows do not
-        // fit an XCD's L2), so every step of this loop exposes ~1 us of latency -- with 2 N float4 + N scalar loads of U pieces in flight
-        // instead of one piece's
-        constexpr int U = HG_STAGE_U(L);
-#pragma unroll 1
-        for (int t0 = 4 * wave + g; t0 < Pfull; t0 += 4 * IS_NW * U) {
-            f32x4 v0[U][N], v1[U][N];
-            float d[U][N];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int t = t0 + 4 * IS_NW * u;
-                t = t < Pfull ? t : t0;                        // tail: re-read the first piece (result dropped below)
-                const int a = t / P1, p = t - a * P1;
-#pragma unroll
-                for (int b = 0; b < N; ++b) {
-                    v0[u][b] = *reinterpret_cast<const f32x4*>(row0 + b * in_mulp + 4 * p);
-                    v1[u][b] = *reinterpret_cast<const f32x4*>(row1 + b * in_mulp + 4 * p);
-                    d[u][b] = D[a * N + b];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = t0 + 4 * IS_NW * u;
-                if (t < Pfull) {
-                    f32x4 acc0 = d[u][0] * v0[u][0], acc1 = d[u][0] * v1[u][0];
-#pragma unroll
-                    for (int b = 1; b < N; ++b) {
-                        acc0 += d[u][b] * v0[u][b];
-                        acc1 += d[u][b] * v1[u][b];
-                    }
-                    *reinterpret_cast<f32x4*>(d0 + t * 64) = acc0;
-                    *reinterpret_cast<f32x4*>(d1 + t * 64) = acc1;
-                }
-            }
-        }
-        return;
-    }
-    for (int si = 0; si < nsrc; ++si) {
-        const int sidx = si ? s1 : s0;
-        const int64_t* __restrict__ ix = sidx == 0 ? A.idx[0] : (sidx == 1 ? A.idx[1] : (sidx == 2 ? A.idx[2] : A.idx[3]));
-        const int64_t r = ix ? ix[erow] : erow;
-        const float* __restrict__ row = is_pick_src(A, sidx) + r * is_pick_stride(A, sidx) + in_off;
-        float* __restrict__ dst = stage + (si ? P[7] : P[6]);
-        if (si ? rot1 : rot0) {
-            const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
-#pragma unroll 1
-            for (int t = 4 * wave + g; t < Pfull; t += 4 * IS_NW) {
-                const int a = t / P1, p = t - a * P1;
-                f32x4 v[N];
-                float d[N];
-#pragma unroll
-                for (int b = 0; b < N; ++b) {
-                    v[b] = *reinterpret_cast<const f32x4*>(row + b * in_mulp + 4 * p);
-                    d[b] = D[a * N + b];
-                }
-                f32x4 acc = d[0] * v[0];
-#pragma unroll
-                for (int b = 1; b < N; ++b) acc += d[b] * v[b];
-                *reinterpret_cast<f32x4*>(dst + t * 64 + el * 4) = acc;
-            }
-        } else {
-#pragma unroll 1
-            for (int j = wave; j < nj; j += IS_NW) {           // the waves share the block's DMA instructions
-                int p = 4 * j + g;
-                p = p < Pfull ? p : Pfull - 1;
-                is_dma16(row + 4 * p, dst + j * 256);
-            }
-        }
-    }
-}
-
 #ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
 #define IS_CASE(MMv, RTMv) \
     case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
@@ -485,8 +286,6 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
     case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, true>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
 #endif
 #endif
-
-#define SEG_NEWBATCH (1 << 16)
 
 // A launch runs `nparts` sub-schedules (blockIdx.y) of the same program: every part owns a disjoint set of output segments and the
 // phases / groups / items that feed them (plan.py:is_schedule(parts=...)).  One part = the whole program (large edge counts); several

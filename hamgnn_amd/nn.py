@@ -265,6 +265,7 @@ class MessagePackBlock(nn.Module):
             blob = packer(tag, fn, ns).apply({k: v for k, v in src.items() if ns or k != "skip"})
             assert blob.numel() == dp.weights.numel(), (tag, blob.numel(), dp.weights.numel())
             dp.weights.copy_(blob)
+            dp.weights_changed()
 
         fwd = lambda g_: (lambda d, sk: P.build_message_pack_program(d, *args, unrotate, sk, **({"merge_groups": g_} if g_ else {})).weights)
         update(self._dp, ("fwd", unrotate, has_skip, bool(groups)), fwd(groups), nskip)

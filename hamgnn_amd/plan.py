@@ -205,6 +205,7 @@ class IsSchedule:
     lds_floats: int                # dynamic LDS of a workgroup (largest part)
     balance: float                 # LPT estimate: sum(cost) / (waves * sum over phases of max wave cost), worst part
     part_cost: List[int]           # estimated MFMA-slot cost of every part (critical path over its phases)
+    phase_cls: List[int] = field(default_factory=list)   # per phase: the radial weight generator of its tensor-product items
 
     # single-part views (the common large-graph case; tests)
     @property
@@ -273,14 +274,16 @@ def lds_partition(prog: "Program") -> List[int]:
     return owner
 
 
-def is_schedule(prog: "Program", parts=1) -> IsSchedule:
+def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSchedule:
     """Regroup a finalized fused-kernel program for the input-stationary kernel.  Input irrep blocks (per source set) are packed
     into phases whose staged rows fit the staging area; every item reading a staged block runs in that phase.  Raises
     NotImplementedError when the tiles of all output segments + a useful staging area do not fit IS_LDS_BYTES.
     parts = "lds": the fewest parts whose tiles fit the LDS (programs with more output than one workgroup can hold).
     parts > 1: the output segments are split into `parts` sets of equal estimated cost (LPT); each set gets its own sub-schedule
     (tiles, phases, groups) and runs in its own workgroup (grid.y) -- the per-tile latency drops at the price of staging the input
-    blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots."""
+    blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots.
+    separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (st_schedule: the wave keeps the
+    hidden rows of the phase's generator in registers); phase_table[:, 2] then holds that generator instead of the group range."""
     if (prog.item_table[:, 0] == IT_POST).any() or (prog.item_table[:, 0] == IT_LINC).any():
         raise NotImplementedError("lite_mode programs run on the segment-stationary kernel")
     hp4 = prog.hidden_pad // 4
@@ -307,14 +310,16 @@ def is_schedule(prog: "Program", parts=1) -> IsSchedule:
                 if key_of[m] == sg:
                     owner[m] = r
     segs_all, btab, ptab, gtab, items_all, parttab, part_cost, rowtab_all = [], [], [], [], [], [], [], []
+    phase_cls_all: List[int] = []
     lds_floats, worst_balance = 0, 1.0
     for part in range(parts):
         members = [sg for sg in range(nseg) if owner[sg] == part]
         sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
-                                split=parts > 1)
+                                split=parts > 1, separate_mlp=separate_mlp)
         parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
                         sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), 0])
         rowtab_all += sub["rowtab"]
+        phase_cls_all += sub["phase_cls"]
         segs_all += list(sub["segs"])
         btab += sub["btab"]
         ptab += sub["ptab"]
@@ -327,11 +332,11 @@ def is_schedule(prog: "Program", parts=1) -> IsSchedule:
     return IsSchedule(np.asarray(segs_all, np.int32).reshape(-1, SEG_I32), np.asarray(btab, np.int32).reshape(-1, IS_BLOCK_I32),
                       np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
                       np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), np.asarray(rowtab_all, np.int32),
-                      lds_floats, worst_balance, part_cost)
+                      lds_floats, worst_balance, part_cost, phase_cls_all)
 
 
 def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
-                      split: bool = False) -> dict:
+                      split: bool = False, separate_mlp: bool = False) -> dict:
     """sub-schedule of the output segments `members` (indices into prog.seg_table); all table indices are emitted as ABSOLUTE indices
     into the concatenated tables of the launch (bases given)."""
     segs = prog.seg_table[members].copy()
@@ -397,6 +402,10 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         b["items"].append(rec)
     for b in blocks.values():
         b["nsrc"] = 2 if b["key"][1] >= 0 else 1
+        cls = {int(r[10]) for r in b["items"] if int(r[0]) == IT_TP}
+        if separate_mlp and len(cls) > 1:                      # (data-gradient programs: one staged gradient block feeds both branches)
+            raise NotImplementedError("static-stream schedule: an input block whose items use both radial weight generators")
+        b["cls"] = cls.pop() if len(cls) == 1 else None        # None: plain Linear items only (no radial scale) / not separated
         b["src_floats"] = ceil_div((2 * b["li"] + 1) * (b["in_mulp"] // 4), 4) * 256
         b["floats"] = b["nsrc"] * b["src_floats"]
         if b["floats"] > stage_floats:
@@ -404,14 +413,19 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     # the staging area only needs to hold the largest phase: parts with small tiles keep the LDS small as well
     # ---- phases: first-fit decreasing packing of the blocks into the staging area
     phases: List[List[dict]] = []
+    def _cls(ph):
+        return next((x["cls"] for x in ph if x["cls"] is not None), None)
+
     for b in sorted(blocks.values(), key=lambda b: -b["floats"]):
         for ph in phases:
-            if sum(x["floats"] for x in ph) + b["floats"] <= stage_floats:
+            if sum(x["floats"] for x in ph) + b["floats"] <= stage_floats and (
+                    not separate_mlp or b["cls"] is None or _cls(ph) is None or _cls(ph) == b["cls"]):
                 ph.append(b)
                 break
         else:
             phases.append([b])
     btab, ptab, gtab, items, tot, crit = [], [], [], [], 0, 0
+    phase_cls: List[int] = []
     for ph in phases:
         ph.sort(key=lambda b: -b["key"][0])                    # edge-row blocks (plain LDS-DMA) first: their latency runs under the
         b0, g0, o = len(btab), len(gtab), 0                    # rotation work of the node-row blocks
@@ -438,6 +452,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         tot += sum(loads)
         crit += max(loads)
         ptab.append([block_base + b0, block_base + len(btab), group_base + g0, group_base + len(gtab)])
+        phase_cls.append(_cls(ph) or 0)
     # ---- epilogue: Wigner blocks of the un-rotated segments staged in as few batches as fit the staging area (one block per l)
     need = {}
     for sg in segs:
@@ -483,7 +498,127 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             wide[n, 22], wide[n, 23] = _item_rto(items[n], prog.seg_table, prog.vsegs), vt_base[v]
     ctr_off = stage_off + stage_floats
     return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off,
-                rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
+                phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
+
+
+# ---- static-stream schedule (csrc/tp_st.hip): the input-stationary phases with the work of every phase assigned to the waves at plan time
+ST_OP_I32 = 16
+ST_PAD_FRAGS = 8                   # the kernel requests up to 4 fragments beyond a wave's last one (step / GEMM2 look-ahead)
+# template instantiations of csrc/tp_st.hip (ST_CASE): MM -> largest RTO class; wider items fall back to the input-stationary kernel
+ST_RTO_MAX = (4, 4, 2, 2, 1, 1, 1)
+
+
+@dataclass
+class StSchedule:
+    base: IsSchedule               # segments, input blocks, phases (one radial generator each), row table, LDS layout: one part
+    phase_table: np.ndarray        # int32[nphase][4] = {block_begin, block_end, radial generator (0 node / 1 edge branch), 0}
+    op_table: np.ndarray           # int32[nops][16], see csrc/tp_st.hip; a wave's ops are contiguous in execution order
+    wave_phase: np.ndarray         # int32[nphase][IS_WAVES][2] = op range of (phase, wave)
+    wave_base: np.ndarray          # int32[IS_WAVES][4] = float offsets of the wave's A / R / C stream in `stream`
+    gather: np.ndarray             # int64: stream = concat(weights, [0])[gather] (device-side rebuild after a weight refresh)
+    balance: float                 # sum(cost) / (waves x sum over phases of the slowest wave)
+
+    def stream(self, weights: np.ndarray) -> np.ndarray:
+        return np.concatenate([np.asarray(weights, np.float32).reshape(-1), np.zeros(1, np.float32)])[self.gather]
+
+
+def st_schedule(prog: "Program") -> StSchedule:
+    """Static-stream form of a finalized program (csrc/tp_st.hip).  The phases are those of the input-stationary schedule (one radial
+    weight generator per phase); inside a phase the work groups -- all items of one (phase, output segment key), so that a tile is only
+    ever updated by one wave between two barriers -- go to the four waves in LPT order AT PLAN TIME.  Every wave therefore consumes a
+    fixed sequence of weight fragments over the whole 16-edge pass; it is emitted as three contiguous per-wave streams, row tile by row
+    tile in consumption order:  A = [GEMM1 fragments (source, K group)] [GEMM2 fragments (output row tile)],  R = the four fragments of
+    the last radial layer,  C = the coefficient block [column][row].  Raises NotImplementedError for programs the kernel has no
+    instantiation for (callers keep the input-stationary kernel)."""
+    if prog.hidden_pad != 64:
+        raise NotImplementedError("static-stream kernel: the radial hidden width must pad to 64")
+    base = is_schedule(prog, 1, separate_mlp=True)
+    hp4 = prog.hidden_pad // 4
+    nph = base.phase_table.shape[0]
+    ops_w: List[List[List[int]]] = [[] for _ in range(IS_WAVES)]       # per wave: op records in execution order
+    cnt_w = [[0] * nph for _ in range(IS_WAVES)]
+    gA: List[List[np.ndarray]] = [[] for _ in range(IS_WAVES)]
+    gR: List[List[np.ndarray]] = [[] for _ in range(IS_WAVES)]
+    gC: List[List[np.ndarray]] = [[] for _ in range(IS_WAVES)]
+    frag = np.arange(256, dtype=np.int64)
+    tot, crit = 0, 0
+    for ph in range(nph):
+        g0, g1 = int(base.phase_table[ph][2]), int(base.phase_table[ph][3])
+        loads = [0] * IS_WAVES
+        for gi in range(g0, g1):                               # group_table is in LPT (largest first) order
+            ib, ie = (int(v) for v in base.group_table[gi])
+            w = loads.index(min(loads))
+            for ii in range(ib, ie):
+                it = base.item_table[ii]
+                typ, so0, so1, in_mulp, li, mm, neg, ksteps, rtm = (int(it[k]) for k in (0, 1, 2, 4, 5, 6, 7, 8, 9))
+                ncx = 2 * mm + (0 if (neg and mm > 0 and typ == IT_TP) else 1)                 # odd items skip the centre column
+                loads[w] += (2 if so1 >= 0 else 1) * ksteps * rtm * ncx + 60 + ((hp4 * rtm + int(it[22]) * int(it[18]) * ncx) if typ == IT_TP else 0)
+                if typ == IT_TP and neg and mm == 0:
+                    continue                                   # odd super-path with one column: its only column vanishes identically
+                nsrc = 2 if so1 >= 0 else 1
+                ncr = 2 * mm + 1
+                x4 = 1 if (int(it[17]) and ncr <= 3) else 0
+                ngrp = ceil_div(ksteps, 4)
+                P1 = in_mulp // 4
+                fb0 = ((li - mm) * P1 + ((ncr - 1) * P1 if neg else 0)) * 64
+                cdir64 = (-P1 if neg else P1) * 64
+                rto = int(it[22])
+                if typ == IT_TP:
+                    if not (0 <= mm < len(ST_RTO_MAX) and 1 <= rto <= ST_RTO_MAX[mm]):
+                        raise NotImplementedError(f"static-stream kernel: no instantiation for min(l_in, l_out) = {mm} with {rto} output row tiles")
+                    rc = 0 if rto == 1 else (1 if rto == 2 else 2)
+                    code = (64 if neg else 0) + 32 * x4 + 4 * mm + rc
+                    flags = int(it[10]) | (4 if x4 else 0)
+                    a1, w3, cf, a2 = (int(it[k]) for k in (11, 12, 13, 14))
+                    for rt in range(rtm):
+                        for G in range(hp4 // 4):
+                            gR[w].append(w3 + (G * rtm + rt) * 256 + frag)
+                        for si in range(nsrc):
+                            for G in range(ngrp):
+                                gA[w].append(a1 + ((si * ngrp + G) * rtm + rt) * 256 + frag)
+                        for rtp in range(rto):
+                            gA[w].append(a2 + (rtp * rtm + rt) * 256 + frag)
+                        gC[w].append(cf + rt * ncr * 16 + np.arange(ncr * 16, dtype=np.int64))
+                    rec = [code, so0, so1, fb0, cdir64, ngrp, ksteps, nsrc, rtm, rto, int(it[18]), flags, int(it[23]), 0, ii, 0]
+                elif typ == IT_LIN:
+                    if mm > 6 or (x4 and mm > 1):
+                        raise NotImplementedError("static-stream kernel: no Linear instantiation")
+                    a1 = int(it[11])
+                    for rt in range(rtm):
+                        for G in range(ngrp):
+                            gA[w].append(a1 + (G * rtm + rt) * 256 + frag)
+                    rec = [128 + 8 * x4 + mm, so0, -1, fb0, cdir64, ngrp, ksteps, 1, rtm, 0, 0, 2 | (4 if x4 else 0), int(it[23]), int(it[16]), ii, 0]
+                else:
+                    raise NotImplementedError("static-stream kernel: tensor-product and Linear items only")
+                ops_w[w].append(rec)
+                cnt_w[w][ph] += 1
+        tot += sum(loads)
+        crit += max(loads)
+    nW = prog.weights.size                                     # index of the appended zero
+    pad = np.full(256, nW, dtype=np.int64)
+    wave_base = np.zeros((IS_WAVES, 4), np.int32)
+    parts: List[np.ndarray] = []
+    off = 0
+    for w in range(IS_WAVES):
+        for k, (lst, npad) in enumerate(((gA[w], ST_PAD_FRAGS), (gR[w], 4), (gC[w], 1))):
+            arr = np.concatenate(lst + [pad] * npad) if lst else np.concatenate([pad] * npad)
+            arr = np.concatenate([arr, np.full((-arr.size) % 256, nW, dtype=np.int64)])
+            wave_base[w][k] = off
+            parts.append(arr)
+            off += arr.size
+    op_table, wave_phase, o = [], np.zeros((nph, IS_WAVES, 2), np.int32), 0
+    for w in range(IS_WAVES):
+        k = 0
+        for ph in range(nph):
+            wave_phase[ph][w] = (o + k, o + k + cnt_w[w][ph])
+            k += cnt_w[w][ph]
+        op_table += ops_w[w]
+        o += len(ops_w[w])
+    ptab = np.zeros((nph, 4), np.int32)
+    ptab[:, 0:2] = base.phase_table[:, 0:2]
+    ptab[:, 2] = np.asarray(base.phase_cls, np.int32)
+    return StSchedule(base, ptab, np.asarray(op_table, np.int32).reshape(-1, ST_OP_I32), wave_phase, wave_base, np.concatenate(parts),
+                      tot / (IS_WAVES * crit) if crit else 1.0)
 
 
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:

@@ -119,7 +119,7 @@ def build_backbone_from_fixture(device="cuda", name="backbone"):
     return m, f
 
 
-def check_message_pack_random(device="cuda", seed=0, schedule="auto", irr=None, sh=None):
+def check_message_pack_random(device="cuda", seed=0, schedule="auto", irr=None, sh=None, radial=(16, 16), parts=None, E=83):
     """random irreps set (odd multiplicities, missing parities) + random weights: fused MessagePackBlock on the GPU vs the fp64 oracle"""
     from oracle import hamgnn_ref as R, e3
     from hamgnn_amd import nn as hnn, ops, plan as P
@@ -137,8 +137,7 @@ def check_message_pack_random(device="cuda", seed=0, schedule="auto", irr=None, 
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
-        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
-        E = 83
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=list(radial))
         g = torch.Generator().manual_seed(seed)
         src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
         vec = torch.randn(E, 3, generator=g) * 3.0
@@ -148,12 +147,20 @@ def check_message_pack_random(device="cuda", seed=0, schedule="auto", irr=None, 
         out = ref(src, dst, ef, shv, rbf).detach()
     finally:
         torch.set_default_dtype(prev)
-    m = load_weights(hnn.MessagePackBlock(irr, irr, sh, irr, 8, [16, 16]), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
+    m = load_weights(hnn.MessagePackBlock(irr, irr, sh, irr, 8, list(radial)), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
     os.environ["HG_MP_KERNEL"] = schedule
+    if parts is not None:                                      # workgroups per 16-edge tile (1: the large-graph path, static-stream kernel)
+        os.environ["HG_IS_PARTS"] = str(parts)
     try:
-        m.compile(device, unrotate=True)
+        return _message_pack_random_run(m, device, irr, sh, lmax, lsh, n, rbf, src, dst, ef, out, E)
     finally:
         os.environ.pop("HG_MP_KERNEL", None)
+        os.environ.pop("HG_IS_PARTS", None)
+
+
+def _message_pack_random_run(m, device, irr, sh, lmax, lsh, n, rbf, src, dst, ef, out, E):
+    from hamgnn_amd import ops, plan as P
+    m.compile(device, unrotate=True)
     lay = P.PlanarLayout(irr)
     lm = max(lmax, lsh)
     v = torch.stack([n[:, 2], n[:, 0], n[:, 1]], 1) * 2.0          # e3nn axis order (y, z, x) -> physical (x, y, z)
@@ -168,8 +175,9 @@ def check_message_pack_random(device="cuda", seed=0, schedule="auto", irr=None, 
     y = ops.from_planar(m.run(xs, xd, fe, geo), imap)
     torch.cuda.synchronize()
     scale = out.abs().max().item()
-    return {"irreps": irr, "sh": sh, "kernel": "is" if m._dp.sched is not None else "seg",
-            "rel_err": 0.0 if scale < 1e-12 else rel(y, out)}
+    dp = m._dp_for(E)
+    kern = "seg" if dp.sched is None else ("st" if (dp.st is not None and dp.is_parts_for(E) == 1) else "is")
+    return {"irreps": irr, "sh": sh, "kernel": kern, "rel_err": 0.0 if scale < 1e-12 else rel(y, out)}
 
 
 def check_message_pack_backward(device="cuda", seed=0, irr=None, sh=None, schedule="auto", E=83, radial=(16, 16)):

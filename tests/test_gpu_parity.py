@@ -48,6 +48,17 @@ def test_message_pack_random_irreps_vs_oracle(seed, schedule):
     assert r["rel_err"] < G.TOL
 
 
+@pytest.mark.parametrize("case", list(range(6)) + ["A", "B"])
+def test_message_pack_static_stream_vs_oracle(case):
+    """csrc/tp_st.hip (per-wave weight streams, the default kernel of launches with one workgroup per 16-edge tile): random irreps sets
+    and the two shipped sets, 64-wide radial MLP, forced onto the single-part path, vs the fp64 oracle"""
+    import bench
+    kw = dict(irr=bench.IRREPS[case], sh=bench.SH, seed=7, E=37) if isinstance(case, str) else dict(seed=case)
+    r = G.check_message_pack_random(radial=(64, 64), parts=1, **kw)
+    print(r)
+    assert r["kernel"] == "st" and r["rel_err"] < G.TOL
+
+
 def test_corr_product_block_golden():
     r = G.check_corr_product()
     print(r)
