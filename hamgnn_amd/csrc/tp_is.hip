@@ -353,6 +353,9 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
         if (threadIdx.x == 0) *ctr = g0;
 #pragma unroll 1
         for (int b = b0; b < b1; ++b) {
+#ifdef HG_ABL_NOSTAGE
+            if (A.rows > 0) continue;
+#endif
             const int* __restrict__ B = g_blocks + b * 8;
             switch (B[4]) {
                 case 0: stage_block<0>(A, B, stage, erow, wave, lane); break;
@@ -379,6 +382,9 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
             gi = __builtin_amdgcn_readfirstlane(gi);
             if (gi >= g1) break;
             const int ib = g_groups[2 * gi], ie = g_groups[2 * gi + 1];
+#ifdef HG_ABL_NOITEMS             // ablation: the launch without its items (wrong results; what the skeleton around them costs)
+            if (A.rows > 0) continue;
+#endif
             for (int ii = ib; ii < ie; ++ii) {
                 const int* __restrict__ it = g_items + ii * 24;
                 switch (it[6] * 8 + it[9] + ((it[0] == 0 && it[7]) ? 64 : 0)) {
@@ -420,6 +426,9 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     // ---------------------------------------------------------------- epilogue: all four waves on one segment at a time; the Wigner
     // blocks of a batch of segments (one block per l, as many l as fit the staging area) are staged together by LDS-DMA
     for (int sg = seg0; sg < seg1; ++sg) {
+#ifdef HG_ABL_NOEPI
+        if (A.rows > 0) continue;
+#endif
         const int* __restrict__ S8 = g_segs + sg * 8;
         const int lk = S8[0], mul_k = S8[1], out_off = S8[3], out_mulp = S8[4], tile_off = S8[5], woff = S8[6], flags = S8[7];
         if (sg == seg0 || (flags & SEG_NEWBATCH)) {

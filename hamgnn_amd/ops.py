@@ -80,14 +80,14 @@ class DeviceProgram:
                 if schedule == "is_parts":
                     self.sched = self.is_tables("lds")[0]
                     self.fixed_parts = "lds"
-        # static-stream form of the single-part schedule (csrc/tp_st.hip): per-wave weight streams, the default for launches that run
-        # one workgroup per 16-edge tile (HG_ST=0: keep the dynamically claimed input-stationary kernel)
+        # streamed form of the single-part schedule (csrc/tp_st.hip: per-group weight streams requested one step ahead, one 16-row tile per
+        # step).  Opt-in (HG_ST=1): measured 8 % slower than the input-stationary kernel on MI355X (profiles/r03_tp_st_experiments.md)
         self.st = None
-        if self.sched is not None and self.fixed_parts is None and os.environ.get("HG_ST", "1") != "0":
+        if self.sched is not None and self.fixed_parts is None and os.environ.get("HG_ST", "0") == "1":
             try:
                 st = P.st_schedule(prog)
-                self.st = (st, tuple(_dev(t, device) for t in (st.base.seg_table, st.base.block_table, st.phase_table, st.op_table,
-                                                                  st.wave_phase, st.wave_base, st.base.rowtab)),
+                self.st = (st, tuple(_dev(t, device) for t in (st.base.seg_table, st.base.block_table, st.phase_table, st.group_table,
+                                                                  st.op_table, st.base.rowtab)),
                            _dev(st.gather, device), _dev(st.stream(prog.weights), device))
             except NotImplementedError:
                 pass
@@ -295,11 +295,11 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     if dp.sched is not None and dp.st is not None and h2n is not None and h2e is not None and dp.is_parts_for(rows) == 1:
-        st, (t_segs, t_blocks, t_phases, t_ops, t_wph, t_wbase, t_rowtab), _, t_stream = dp.st
+        st, (t_segs, t_blocks, t_phases, t_groups, t_ops, t_rowtab), _, t_stream = dp.st
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
         check(lib().hg_tp_st(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(t_stream), ptr(t_segs),
-                             ptr(t_blocks), ptr(t_phases), ptr(t_ops), ptr(t_wph), ptr(t_wbase),
+                             ptr(t_blocks), ptr(t_phases), ptr(t_groups), ptr(t_ops),
                              st.base.part_table.ctypes.data_as(C.c_void_p), ptr(t_rowtab), i32(st.base.lds_floats * 4), gp, i32(rot_mask),
                              ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_st")
     elif dp.sched is not None:

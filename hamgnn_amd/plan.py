@@ -501,9 +501,11 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
                 phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
 
 
-# ---- static-stream schedule (csrc/tp_st.hip): the input-stationary phases with the work of every phase assigned to the waves at plan time
+# ---- streamed schedule (csrc/tp_st.hip): the input-stationary phases and work groups, every group with its own contiguous weight streams
 ST_OP_I32 = 16
-ST_PAD_FRAGS = 8                   # the kernel requests up to 4 fragments beyond a wave's last one (step / GEMM2 look-ahead)
+ST_GROUP_I32 = 8
+ST_PHASE_I32 = 8
+ST_PAD_FRAGS = 8                   # the kernel requests up to 4 fragments beyond a group's last one (step / GEMM2 look-ahead)
 # template instantiations of csrc/tp_st.hip (ST_CASE): MM -> largest RTO class; wider items fall back to the input-stationary kernel
 ST_RTO_MAX = (4, 4, 2, 2, 1, 1, 1)
 
@@ -511,48 +513,54 @@ ST_RTO_MAX = (4, 4, 2, 2, 1, 1, 1)
 @dataclass
 class StSchedule:
     base: IsSchedule               # segments, input blocks, phases (one radial generator each), row table, LDS layout: one part
-    phase_table: np.ndarray        # int32[nphase][4] = {block_begin, block_end, radial generator (0 node / 1 edge branch), 0}
-    op_table: np.ndarray           # int32[nops][16], see csrc/tp_st.hip; a wave's ops are contiguous in execution order
-    wave_phase: np.ndarray         # int32[nphase][IS_WAVES][2] = op range of (phase, wave)
-    wave_base: np.ndarray          # int32[IS_WAVES][4] = float offsets of the wave's A / R / C stream in `stream`
+    phase_table: np.ndarray        # int32[nphase][8] = {block_begin, block_end, group_begin, group_end, radial generator (0 node / 1 edge), 0..}
+    group_table: np.ndarray        # int32[ngroup][8] = {op_begin, op_end, A / R / C stream offsets (floats into `stream`), 0..}: all items of
+    #                                one (phase, output segment key), claimed by the waves largest first (a tile has one writer per phase)
+    op_table: np.ndarray           # int32[nops][16], see csrc/tp_st.hip; a group's ops are contiguous in execution order
     gather: np.ndarray             # int64: stream = concat(weights, [0])[gather] (device-side rebuild after a weight refresh)
-    balance: float                 # sum(cost) / (waves x sum over phases of the slowest wave)
+    balance: float                 # LPT estimate of the dynamic claim: sum(cost) / (waves x sum over phases of the slowest wave)
 
     def stream(self, weights: np.ndarray) -> np.ndarray:
         return np.concatenate([np.asarray(weights, np.float32).reshape(-1), np.zeros(1, np.float32)])[self.gather]
 
 
 def st_schedule(prog: "Program") -> StSchedule:
-    """Static-stream form of a finalized program (csrc/tp_st.hip).  The phases are those of the input-stationary schedule (one radial
-    weight generator per phase); inside a phase the work groups -- all items of one (phase, output segment key), so that a tile is only
-    ever updated by one wave between two barriers -- go to the four waves in LPT order AT PLAN TIME.  Every wave therefore consumes a
-    fixed sequence of weight fragments over the whole 16-edge pass; it is emitted as three contiguous per-wave streams, row tile by row
-    tile in consumption order:  A = [GEMM1 fragments (source, K group)] [GEMM2 fragments (output row tile)],  R = the four fragments of
-    the last radial layer,  C = the coefficient block [column][row].  Raises NotImplementedError for programs the kernel has no
-    instantiation for (callers keep the input-stationary kernel)."""
+    """Streamed form of a finalized program (csrc/tp_st.hip).  Phases and work groups are those of the input-stationary schedule (one radial
+    weight generator per phase; a group = all items of one (phase, output segment key), claimed dynamically, largest first).  What changes
+    is how a wave gets its weights: the fragments a group consumes are laid out as three contiguous streams, row tile by row tile in
+    consumption order --  A = [GEMM1 fragments (source, K group)] [GEMM2 fragments (output row tile)],  R = the four fragments of the last
+    radial layer,  C = the coefficient block [column][row] -- so the kernel requests every fragment one step before the MFMAs that use it
+    without knowing what it belongs to.  Raises NotImplementedError for programs the kernel has no instantiation for (callers keep the
+    input-stationary kernel)."""
     if prog.hidden_pad != 64:
-        raise NotImplementedError("static-stream kernel: the radial hidden width must pad to 64")
+        raise NotImplementedError("streamed kernel: the radial hidden width must pad to 64")
     base = is_schedule(prog, 1, separate_mlp=True)
     hp4 = prog.hidden_pad // 4
     nph = base.phase_table.shape[0]
-    ops_w: List[List[List[int]]] = [[] for _ in range(IS_WAVES)]       # per wave: op records in execution order
-    cnt_w = [[0] * nph for _ in range(IS_WAVES)]
-    gA: List[List[np.ndarray]] = [[] for _ in range(IS_WAVES)]
-    gR: List[List[np.ndarray]] = [[] for _ in range(IS_WAVES)]
-    gC: List[List[np.ndarray]] = [[] for _ in range(IS_WAVES)]
     frag = np.arange(256, dtype=np.int64)
+    nW = prog.weights.size                                     # index of the appended zero
+    pad = np.full(256, nW, dtype=np.int64)
+    ops: List[List[int]] = []
+    groups: List[List[int]] = []
+    gA: List[np.ndarray] = []
+    gR: List[np.ndarray] = []
+    gC: List[np.ndarray] = []
+    nA = nR = nC = 0
+    ptab = np.zeros((nph, ST_PHASE_I32), np.int32)
     tot, crit = 0, 0
     for ph in range(nph):
         g0, g1 = int(base.phase_table[ph][2]), int(base.phase_table[ph][3])
         loads = [0] * IS_WAVES
+        ptab[ph][:5] = (base.phase_table[ph][0], base.phase_table[ph][1], len(groups), len(groups) + g1 - g0, base.phase_cls[ph])
         for gi in range(g0, g1):                               # group_table is in LPT (largest first) order
             ib, ie = (int(v) for v in base.group_table[gi])
-            w = loads.index(min(loads))
+            grp = [len(ops), 0, nA, nR, nC, 0, 0, 0]
+            cost = 0
             for ii in range(ib, ie):
                 it = base.item_table[ii]
                 typ, so0, so1, in_mulp, li, mm, neg, ksteps, rtm = (int(it[k]) for k in (0, 1, 2, 4, 5, 6, 7, 8, 9))
                 ncx = 2 * mm + (0 if (neg and mm > 0 and typ == IT_TP) else 1)                 # odd items skip the centre column
-                loads[w] += (2 if so1 >= 0 else 1) * ksteps * rtm * ncx + 60 + ((hp4 * rtm + int(it[22]) * int(it[18]) * ncx) if typ == IT_TP else 0)
+                cost += (2 if so1 >= 0 else 1) * ksteps * rtm * ncx + 60 + ((hp4 * rtm + int(it[22]) * int(it[18]) * ncx) if typ == IT_TP else 0)
                 if typ == IT_TP and neg and mm == 0:
                     continue                                   # odd super-path with one column: its only column vanishes identically
                 nsrc = 2 if so1 >= 0 else 1
@@ -565,59 +573,54 @@ def st_schedule(prog: "Program") -> StSchedule:
                 rto = int(it[22])
                 if typ == IT_TP:
                     if not (0 <= mm < len(ST_RTO_MAX) and 1 <= rto <= ST_RTO_MAX[mm]):
-                        raise NotImplementedError(f"static-stream kernel: no instantiation for min(l_in, l_out) = {mm} with {rto} output row tiles")
+                        raise NotImplementedError(f"streamed kernel: no instantiation for min(l_in, l_out) = {mm} with {rto} output row tiles")
                     rc = 0 if rto == 1 else (1 if rto == 2 else 2)
                     code = (64 if neg else 0) + 32 * x4 + 4 * mm + rc
                     flags = int(it[10]) | (4 if x4 else 0)
                     a1, w3, cf, a2 = (int(it[k]) for k in (11, 12, 13, 14))
                     for rt in range(rtm):
                         for G in range(hp4 // 4):
-                            gR[w].append(w3 + (G * rtm + rt) * 256 + frag)
+                            gR.append(w3 + (G * rtm + rt) * 256 + frag)
                         for si in range(nsrc):
                             for G in range(ngrp):
-                                gA[w].append(a1 + ((si * ngrp + G) * rtm + rt) * 256 + frag)
+                                gA.append(a1 + ((si * ngrp + G) * rtm + rt) * 256 + frag)
                         for rtp in range(rto):
-                            gA[w].append(a2 + (rtp * rtm + rt) * 256 + frag)
-                        gC[w].append(cf + rt * ncr * 16 + np.arange(ncr * 16, dtype=np.int64))
+                            gA.append(a2 + (rtp * rtm + rt) * 256 + frag)
+                        gC.append(cf + rt * ncr * 16 + np.arange(ncr * 16, dtype=np.int64))
+                    nR += rtm * (hp4 // 4) * 256
+                    nA += rtm * (nsrc * ngrp + rto) * 256
+                    nC += rtm * ncr * 16
                     rec = [code, so0, so1, fb0, cdir64, ngrp, ksteps, nsrc, rtm, rto, int(it[18]), flags, int(it[23]), 0, ii, 0]
                 elif typ == IT_LIN:
                     if mm > 6 or (x4 and mm > 1):
-                        raise NotImplementedError("static-stream kernel: no Linear instantiation")
+                        raise NotImplementedError("streamed kernel: no Linear instantiation")
                     a1 = int(it[11])
                     for rt in range(rtm):
                         for G in range(ngrp):
-                            gA[w].append(a1 + (G * rtm + rt) * 256 + frag)
+                            gA.append(a1 + (G * rtm + rt) * 256 + frag)
+                    nA += rtm * ngrp * 256
                     rec = [128 + 8 * x4 + mm, so0, -1, fb0, cdir64, ngrp, ksteps, 1, rtm, 0, 0, 2 | (4 if x4 else 0), int(it[23]), int(it[16]), ii, 0]
                 else:
-                    raise NotImplementedError("static-stream kernel: tensor-product and Linear items only")
-                ops_w[w].append(rec)
-                cnt_w[w][ph] += 1
+                    raise NotImplementedError("streamed kernel: tensor-product and Linear items only")
+                ops.append(rec)
+            grp[1] = len(ops)
+            groups.append(grp)
+            w = loads.index(min(loads))
+            loads[w] += cost
         tot += sum(loads)
         crit += max(loads)
-    nW = prog.weights.size                                     # index of the appended zero
-    pad = np.full(256, nW, dtype=np.int64)
-    wave_base = np.zeros((IS_WAVES, 4), np.int32)
-    parts: List[np.ndarray] = []
-    off = 0
-    for w in range(IS_WAVES):
-        for k, (lst, npad) in enumerate(((gA[w], ST_PAD_FRAGS), (gR[w], 4), (gC[w], 1))):
-            arr = np.concatenate(lst + [pad] * npad) if lst else np.concatenate([pad] * npad)
-            arr = np.concatenate([arr, np.full((-arr.size) % 256, nW, dtype=np.int64)])
-            wave_base[w][k] = off
-            parts.append(arr)
-            off += arr.size
-    op_table, wave_phase, o = [], np.zeros((nph, IS_WAVES, 2), np.int32), 0
-    for w in range(IS_WAVES):
-        k = 0
-        for ph in range(nph):
-            wave_phase[ph][w] = (o + k, o + k + cnt_w[w][ph])
-            k += cnt_w[w][ph]
-        op_table += ops_w[w]
-        o += len(ops_w[w])
-    ptab = np.zeros((nph, 4), np.int32)
-    ptab[:, 0:2] = base.phase_table[:, 0:2]
-    ptab[:, 2] = np.asarray(base.phase_cls, np.int32)
-    return StSchedule(base, ptab, np.asarray(op_table, np.int32).reshape(-1, ST_OP_I32), wave_phase, wave_base, np.concatenate(parts),
+    # one array: [A | R | C], each padded (the kernel's look-ahead reads past the last group) and 1 KiB aligned
+    parts, off, base_off = [], 0, []
+    for lst, npad in ((gA, ST_PAD_FRAGS), (gR, 4), (gC, 1)):
+        arr = np.concatenate(lst + [pad] * npad) if lst else np.concatenate([pad] * npad)
+        arr = np.concatenate([arr, np.full((-arr.size) % 256, nW, dtype=np.int64)])
+        base_off.append(off)
+        parts.append(arr)
+        off += arr.size
+    gt = np.asarray(groups, np.int32).reshape(-1, ST_GROUP_I32)
+    for k in range(3):
+        gt[:, 2 + k] += base_off[k]
+    return StSchedule(base, ptab, gt, np.asarray(ops, np.int32).reshape(-1, ST_OP_I32), np.concatenate(parts),
                       tot / (IS_WAVES * crit) if crit else 1.0)
 
 

@@ -264,10 +264,10 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
 
 
 def run_program_st(prog, st, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
-    """the static-stream schedule (plan.st_schedule, csrc/tp_st.hip), fragment-exact: every wave walks its op list phase by phase and
+    """the streamed schedule (plan.st_schedule, csrc/tp_st.hip), fragment-exact: phase by phase every work group walks its op list and
     consumes its A / R / C streams strictly in order (row tile: 4 radial fragments, the GEMM1 fragments (source, K group), the coefficient
     block, the GEMM2 fragments (output row tile)); rows are addressed through the row table.  Checks on the way: every item of the
-    program exactly once, one radial generator per phase, a tile written by one wave per phase, the streams consumed to their end."""
+    program exactly once, one radial generator per phase, a tile written by one group per phase, a group's streams consumed exactly."""
     E = srcs[0].shape[0]
     base = st.base
     stream = st.stream(prog.weights).astype(dtype)
@@ -292,11 +292,10 @@ def run_program_st(prog, st, srcs, h2=(None, None), D=None, lmax=None, dtype=np.
         ne = min(16, E - e0)
         cols = np.arange(e0, e0 + ne)
         lds = np.zeros(tile_floats + maxstride, dtype=dtype)
-        pos = [[int(st.wave_base[w][k]) for k in range(3)] for w in range(P.IS_WAVES)]      # A, R, C cursors per wave
         seen = np.zeros(nops, dtype=int)
         items_seen = set()
         for ph in range(st.phase_table.shape[0]):
-            b0, b1, cls = (int(v) for v in st.phase_table[ph][:3])
+            b0, b1, g0, g1, cls = (int(v) for v in st.phase_table[ph][:5])
             staged, used = {}, 0
             for blk in base.block_table[b0:b1]:
                 s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in blk)
@@ -306,8 +305,10 @@ def run_program_st(prog, st, srcs, h2=(None, None), D=None, lmax=None, dtype=np.
                 staged[o0] = (s0, s1, in_off, in_mulp, li)
             assert used <= ctr_off - stage_off
             owner = {}
-            for w in range(P.IS_WAVES):
-                o_b, o_e = (int(v) for v in st.wave_phase[ph][w])
+            for w in range(g0, g1):                            # w: the work group (claimed by whichever wave is free)
+                o_b, o_e, *pos = (int(v) for v in st.group_table[w][:5])
+                if w + 1 < st.group_table.shape[0]:            # a group's streams end where the next group's begin
+                    ends = [int(v) for v in st.group_table[w + 1][2:5]]
                 for oi in range(o_b, o_e):
                     op = [int(v) for v in st.op_table[oi]]
                     seen[oi] += 1
@@ -331,8 +332,8 @@ def run_program_st(prog, st, srcs, h2=(None, None), D=None, lmax=None, dtype=np.
                     colsel = [c for c in range(ncr) if not (odd and c == mm)]
 
                     def pop(k, n):
-                        v = stream[pos[w][k]:pos[w][k] + n]
-                        pos[w][k] += n
+                        v = stream[pos[k]:pos[k] + n]
+                        pos[k] += n
                         return v
 
                     def bop(si, c, G, q):                      # B[k = g][edge] of K-step (G, q), column c, source si
@@ -398,15 +399,14 @@ def run_program_st(prog, st, srcs, h2=(None, None), D=None, lmax=None, dtype=np.
                                     touched.add(int(tile_of[lo]))
                     touched.discard(-1)
                     for tl in touched:
-                        assert owner.setdefault(tl, w) == w, "a tile must belong to one wave per phase"
+                        assert owner.setdefault(tl, w) == w, "a tile must belong to one work group per phase"
+                if w + 1 < st.group_table.shape[0]:
+                    assert pos == ends, "a group consumes exactly its streams"
         assert (seen == 1).all()
         missing = set(range(base.item_table.shape[0])) - items_seen
         for ii in missing:                                     # dropped items: one-column odd super-paths (structural zeros)
             it = base.item_table[ii]
             assert int(it[0]) == P.IT_TP and int(it[7]) and int(it[6]) == 0
-        for w in range(P.IS_WAVES):                            # streams consumed exactly up to their padding
-            ends = [int(st.wave_base[w][1]), int(st.wave_base[w][2]), int(st.wave_base[w + 1][0]) if w + 1 < P.IS_WAVES else st.gather.size]
-            assert 0 <= ends[0] - pos[w][0] - 256 * P.ST_PAD_FRAGS < 256 and 0 <= ends[1] - pos[w][1] - 1024 < 256 and 0 <= ends[2] - pos[w][2] - 256 < 256
         for sg, seg in enumerate(base.seg_table):
             lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
             strd = (2 * lk_ + 1) * 16 + 4

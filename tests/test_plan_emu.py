@@ -882,7 +882,7 @@ def test_static_stream_schedule_mini_and_shipped_irreps():
     streams consumed exactly; a tile written by one wave per phase (asserted inside the emulator)"""
     import bench
     st = _st_case(MINI, SH, 3, 19, 1, skip=True)
-    assert st is not None and st.balance > 0.6
+    assert st is not None and st.balance > 0.6 and st.group_table.shape[1] == P.ST_GROUP_I32
     for which, E in (("B", 5), ("A", 3)):
         st = _st_case(bench.IRREPS[which], bench.SH, 5 if which == "B" else 6, E, 2, skip=(which == "B"))
         assert st is not None and st.balance > 0.8
