@@ -83,6 +83,9 @@ class _Unpickler(pickle.Unpickler):
             return _PyGStub
         if module.startswith("hamgnn_amd.data") and name == "Graph":
             return Graph
+        if (module, name) == ("torch.storage", "_load_from_bytes"):
+            # the stock helper is torch.load(BytesIO(b), weights_only=False): a nested payload would run an arbitrary __reduce__
+            return lambda b: torch.load(io.BytesIO(b), weights_only=True)
         if (module, name) in _ALLOWED or (module == "torch" and name in _ALLOWED_TORCH_NAMES):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"graph record refers to {module}.{name}, which is not on the loader's allow-list")
@@ -136,15 +139,26 @@ class LMDBGraphDataset:
     written by the reference (torch_geometric ``Data``) come back as ``Graph`` objects."""
 
     def __init__(self, lmdb_path: str, indices=None, transform=None, preload: int = 0):
-        from .lmdb_lite import LMDBReader
         self.lmdb_path, self.transform, self.preload = lmdb_path, transform, preload
-        self._reader = LMDBReader(lmdb_path)
+        self._reader_obj = None                                # opened lazily (and again in every DataLoader worker: the mmap does not pickle)
         n = self._reader.get(b"num_graphs")
         if n is None:
             raise ValueError(f"{lmdb_path}: key 'num_graphs' is missing")
         self.total_length = int(n.decode())
         self.indices = list(indices) if indices is not None else list(range(self.total_length))
         self.preloaded_data = {i: self._load(i) for i in self.indices[:max(0, preload)]}
+
+    @property
+    def _reader(self):
+        if self._reader_obj is None:
+            from .lmdb_lite import LMDBReader
+            self._reader_obj = LMDBReader(self.lmdb_path)
+        return self._reader_obj
+
+    def __getstate__(self):                                    # spawn-mode DataLoader workers: reopen the store on first use, as the reference does
+        d = dict(self.__dict__)
+        d["_reader_obj"] = None
+        return d
 
     def _load(self, real_idx: int) -> Graph:
         raw = self._reader.get(f"graph_{real_idx}".encode())
@@ -165,7 +179,9 @@ class LMDBGraphDataset:
         return self.transform(g) if self.transform is not None else g
 
     def close(self):
-        self._reader.close()
+        if self._reader_obj is not None:
+            self._reader_obj.close()
+            self._reader_obj = None
 
 
 def npz_to_lmdb(npz_path: str, lmdb_path: str) -> str:

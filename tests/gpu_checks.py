@@ -293,7 +293,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False, lite=False, zps=False):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False, lite=False, zps=False, sparsity=False, split_losses=False, bands=False):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -329,13 +329,29 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     finally:
         torch.set_default_dtype(prev)
     from hamgnn_amd.data import collate
-    gs = [S.add_random_targets(S.random_cell(n_atoms + c, [14, 8, 6, 1], seed=seed + c, density=0.004), nao, seed=seed + c, soc=bool(soc))
+    species = [6, 8, 1] if nao == 13 else [14, 8, 6, 1]         # (the 13-orbital openmx table has no Si)
+    gs = [S.add_random_targets(S.random_cell(n_atoms + c, species, seed=seed + c, density=0.004), nao, seed=seed + c, soc=bool(soc))
           for c in range(crystals)]
     g = gs[0] if crystals == 1 else collate(gs)
     if zps:                                                    # the zero-point shift divides by the sum of the overlaps: give the targets real ones
         gen_s = torch.Generator().manual_seed(seed + 70)
         g["Son"] = torch.eye(nao).reshape(1, -1).repeat(g.num_nodes, 1) + 0.01 * torch.randn(g.num_nodes, nao * nao, generator=gen_s)
         g["Soff"] = 0.05 * torch.randn(g.num_edges, nao * nao, generator=gen_s)
+    kpath, nk = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.5, 0.5, 0.0]], 5
+    if bands:                                                  # band-energy loss: Hermitian overlaps with S(k) positive definite, fixed k-path
+        from hamgnn_amd import kspace
+        assert crystals == 1 and not soc
+        gen_s = torch.Generator().manual_seed(seed + 71)
+        inv_ = g.inv_edge_idx
+        so = 0.004 * torch.randn(g.num_edges, nao, nao, generator=gen_s)
+        g["Soff"] = (0.5 * (so + so[inv_].transpose(1, 2))).reshape(g.num_edges, -1)
+        sn = 0.004 * torch.randn(g.num_nodes, nao, nao, generator=gen_s)
+        g["Son"] = (torch.eye(nao) + 0.5 * (sn + sn.transpose(1, 2))).reshape(g.num_nodes, -1)
+        ho = g["Hoff"].reshape(-1, nao, nao)
+        g["Hoff"] = (0.5 * (ho + ho[inv_].transpose(1, 2))).reshape(g.num_edges, -1)         # Hermitian targets: real target bands
+        hn = g["Hon"].reshape(-1, nao, nao)
+        g["Hon"] = (0.5 * (hn + hn.transpose(1, 2))).reshape(g.num_nodes, -1)
+        g["k_vecs"] = kspace.make_k_vectors(kpath, nk, g.cell)
     if soc == "so3_nonsoc":                                    # the frozen non-SOC model's prediction (Uni-HamGNN chain): an input here
         gen_ = torch.Generator().manual_seed(seed + 50)
         g["Hon_nonsoc"], g["Hoff_nonsoc"] = 0.1 * torch.randn(g.num_nodes, nao * nao, generator=gen_), 0.1 * torch.randn(g.num_edges, nao * nao, generator=gen_)
@@ -345,18 +361,57 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     Href = rh(g64, rb(g64))["hamiltonian"]
     target = 0.1 * torch.randn(Href.shape, generator=torch.Generator().manual_seed(seed), dtype=torch.float64)
     diff = Href - target
-    loss_ref = (diff * diff).mean() if metric == "mse" else diff.abs().mean()
-    loss_ref.backward()
+    lf = (lambda d: (d * d).mean()) if metric == "mse" else (lambda d: d.abs().mean())
+    losses = None
+    if split_losses:                                           # SOC: the reference's two-loss config (hamiltonian_real / hamiltonian_imag, Model.py:150-166)
+        half = Href.shape[0] // 2
+        loss_ref = 1.0 * lf(diff[:half]) + 0.5 * lf(diff[half:])
+        losses = [dict(metric=metric, prediction="hamiltonian_real", target="hamiltonian_real", loss_weight=1.0),
+                  dict(metric=metric, prediction="hamiltonian_imag", target="hamiltonian_imag", loss_weight=0.5)]
+    elif bands:
+        # the reference's second training stage (Model.py:150-196): hamiltonian + band_energy losses.  The bands come from the blocks BEFORE the
+        # zero-point shift and are aligned by their mean (hamgnn_output.py:3802-3880, 3983-3985); target = the bands of the target blocks
+        rh.zero_point_shift = False
+        Hu = rh(g64, rb(g64))["hamiltonian"]
+        rh.zero_point_shift = zps
+        N_ = g.num_nodes
+        be = rh.calculate_band_energies(Hu[:N_], Hu[N_:], g64)[0]
+        with torch.no_grad():
+            tb = rh.calculate_band_energies(g64["Hon"], g64["Hoff"], g64)[0]
+        if zps:
+            be = be - torch.mean(be - tb)
+        target = g64["hamiltonian"] if "hamiltonian" in g64 else torch.cat([g64["Hon"], g64["Hoff"]], 0)
+        diff = Href - target
+        loss_ref = lf(diff) + 0.3 * lf(be - tb)
+        losses = [dict(metric=metric, prediction="hamiltonian", target="hamiltonian", loss_weight=1.0),
+                  dict(metric=metric, prediction="band_energy", target="band_energy", loss_weight=0.3)]
+    else:
+        loss_ref = lf(diff)
     if transformer:
         from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer as Backbone
     else:
         Backbone = HamGNNConvE3
     model = Model(load_weights(Backbone(cfg), dict(rb.state_dict())),
                   load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
-                                                 calculate_sparsity=False, zero_point_shift=zps, **(skw if soc else dict(soc_switch=False))),
+                                                 calculate_sparsity=sparsity, zero_point_shift=zps,
+                                                 **(dict(calculate_band_energy=True, num_k=nk, k_path=kpath) if bands else {}),
+                                                 **(skw if soc else dict(soc_switch=False))),
                                dict(rh.state_dict()))).to(device)
-    r = training_step(model, g.to(device), metric=metric, target=target.float().to(device))
-    torch.cuda.synchronize()
+    gd = g.to(device)
+    if split_losses:
+        half = target.shape[0] // 2
+        gd["hamiltonian_real"], gd["hamiltonian_imag"] = target[:half].float().to(device), target[half:].float().to(device)
+        gd["hamiltonian"] = target.float().to(device)
+        r = training_step(model, gd, losses=losses)
+    elif bands:
+        r = training_step(model, gd, losses=losses)
+    else:
+        r = training_step(model, gd, metric=metric, target=target.float().to(device))
+    if device != "cpu":
+        torch.cuda.synchronize()
+    if sparsity:                                               # Model.py:158-162: hamiltonian-type losses x predictions['sparsity_ratio'] (the head's
+        loss_ref = loss_ref * float(model.output_module.calculate_sparsity_ratio(gd))               # value is pinned by the head fixtures)
+    loss_ref.backward()
     out = {"N": g.num_nodes, "E": g.num_edges, "loss_rel_err": abs(float(r["loss"]) - float(loss_ref.detach())) / abs(float(loss_ref.detach()))}
     worst = {}
     for mod, ref in ((model.representation, rb), (model.output_module, rh)):
@@ -1421,4 +1476,36 @@ def check_band_energies(device="cuda"):
     head.k_path, head.num_k = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.5, 0.5, 0.0]], 7
     out = head(g, rep)
     res["kpath_ok"] = bool(out["band_energy"].shape[1] == 7 and torch.isfinite(out["band_energy"]).all())
+    return res
+
+
+def check_head_bands_zero_point(device="cuda", tag="batch"):
+    """the head's forward with calculate_band_energy AND zero_point_shift (the default of build_hamgnn_model) against the REFERENCE's own
+    forward (fixture head_bands_zero_point_*: hamgnn_output.py:3802-3880 precede :3971-3985): the bands come from the UNSHIFTED blocks and are
+    then aligned by their mean; the Hamiltonian rows carry the shift.  tag: 'batch' (two crystals) | 'single' (rows written in place)."""
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load(f"head_bands_zero_point_{tag}")
+    head = HamGNNPlusPlusOut(MINI, MINI, nao_max=13, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=False,
+                             calculate_band_energy=True, num_k=int(f["kpath"]["nk"]), k_path=f["kpath"]["nodes"].tolist(),
+                             zero_point_shift=True, calculate_sparsity=False)
+    load_weights(head, f["weights"])
+    head.compile(device)
+    g = to_graph(f["graph"], device)
+    rep = {k: torch.from_numpy(f["inputs"][k]).float().to(device) for k in ("node_attr", "edge_attr")}
+    out = head(g, rep)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    o = f["outputs"]
+    scale = float(np.abs(o["band_energy"]).max())
+    err = lambda a, b: float((a.double().cpu() - torch.from_numpy(np.asarray(b)).double()).abs().max())
+    res = {"H_rel_err": rel(out["hamiltonian"], o["hamiltonian"]),
+           "band_energy_err": err(out["band_energy"], o["band_energy"]) / scale,
+           "target_band_energy_err": err(g["band_energy"], o["target_band_energy"]) / scale,
+           # how far the two WRONG orders would be off (bands of the shifted rows / no mean alignment): the test must be able to tell
+           "shift_matters": err(torch.from_numpy(o["band_energy_unshifted"]), o["band_energy"]) / scale,
+           "H_shift_matters": rel(torch.from_numpy(o["hamiltonian_unshifted"]), o["hamiltonian"])}
+    head.zero_point_shift = False
+    out0 = head(to_graph(f["graph"], device), rep)
+    res["unshifted_band_energy_err"] = err(out0["band_energy"], o["band_energy_unshifted"]) / scale
+    res["unshifted_H_rel_err"] = rel(out0["hamiltonian"], o["hamiltonian_unshifted"])
     return res

@@ -102,6 +102,34 @@ def test_gpu_check_functions_on_the_cpu_stand_ins(cpu_backend, name):
         assert abs(r["sparsity_ratio"] - r["sparsity_ratio_reference"]) < 1e-6 * r["sparsity_ratio_reference"]
 
 
+def test_reference_loss_semantics_on_cpu(cpu_backend):
+    """the reference's calculate_loss (hamgnn/models/Model.py:150-166): hamiltonian-type losses are multiplied by the head's sparsity_ratio
+    (calculate_sparsity=True is the head's default), SOC models train on hamiltonian_real + hamiltonian_imag with their own weights --
+    loss value and every parameter gradient vs autograd through the oracle with that formula"""
+    r = G.check_full_backward(device="cpu", n_atoms=4, num_layers=1, nao=14, sparsity=True)
+    assert r["loss_rel_err"] < 1e-5 and r["max_rel_err"] < 2e-5, r
+    r = G.check_full_backward(device="cpu", n_atoms=4, num_layers=1, nao=14, soc="so3", sparsity=True, split_losses=True, metric="mae")
+    assert r["loss_rel_err"] < 1e-5 and r["max_rel_err"] < 2e-5, r
+
+
+@pytest.mark.parametrize("zps", [False, True])
+def test_band_energy_loss_with_zero_point_shift_on_cpu(cpu_backend, zps):
+    """hamiltonian + band_energy losses on a whole model vs autograd through the oracle: with zero_point_shift the band gradient enters at
+    the blocks BEFORE the shift (not through the shift's adjoint) and carries the adjoint of the mean alignment"""
+    r = G.check_full_backward(device="cpu", n_atoms=3, num_layers=1, nao=13, metric="mae", zps=zps, bands=True)
+    assert r["loss_rel_err"] < 1e-4 and r["max_rel_err"] < 5e-4, r
+
+
+@pytest.mark.parametrize("tag", ["batch", "single"])
+def test_head_bands_with_zero_point_shift_on_cpu(cpu_backend, tag):
+    """calculate_band_energy + zero_point_shift (the default of build_hamgnn_model) vs the reference's forward: bands from the unshifted
+    blocks, aligned by their mean (hamgnn_output.py:3802-3880, 3971-3985), for a two-crystal batch and for a single crystal (rows in place)"""
+    r = G.check_head_bands_zero_point("cpu", tag)
+    assert r["H_rel_err"] < G.TOL and r["unshifted_H_rel_err"] < G.TOL, r
+    assert r["band_energy_err"] < 1e-4 and r["unshifted_band_energy_err"] < 1e-4 and r["target_band_energy_err"] < 1e-4, r
+    assert r["shift_matters"] > 1e-3 and r["H_shift_matters"] > 1e-3, r       # the fixture separates the right order from the wrong ones
+
+
 def test_training_loop_on_cpu(cpu_backend):
     """a few optimiser steps of the whole model (training_step -> Adam -> device-side refresh of the packed weights at the next forward):
     the teacher-student loss falls monotonically"""

@@ -375,6 +375,16 @@ def test_band_energies_k_space_step():
     assert r["forward_ok"] and r["kpath_ok"] and r["targets_consistent"] < 1e-5
 
 
+@pytest.mark.parametrize("tag", ["batch", "single"])
+def test_head_bands_with_zero_point_shift(tag):
+    """calculate_band_energy + zero_point_shift vs the reference's forward (bands from the UNSHIFTED blocks, then aligned by their mean)"""
+    r = G.check_head_bands_zero_point(tag=tag)
+    print(r)
+    assert r["H_rel_err"] < G.TOL and r["unshifted_H_rel_err"] < G.TOL
+    assert r["band_energy_err"] < 1e-4 and r["unshifted_band_energy_err"] < 1e-4 and r["target_band_energy_err"] < 1e-4
+    assert r["shift_matters"] > 1e-3 and r["H_shift_matters"] > 1e-3
+
+
 def test_attribute_style_graph_object():
     """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
     r = G.check_attribute_style_graph()

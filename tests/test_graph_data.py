@@ -82,3 +82,44 @@ def test_lmdb_store_roundtrip_without_the_lmdb_module(tmp_path):
             assert r.get(k) == v, k
         assert r.get(b"k99999") is None and r.get(b"a") is None and r.get(b"zzz") is None
         assert [k for k, _ in r.items()] == sorted(items)
+
+
+class _Boom:
+    """a record whose unpickling would run an arbitrary callable"""
+    def __reduce__(self):
+        return (eval, ("__import__('os').environ.__setitem__('HG_PWNED', '1')",))
+
+
+def test_nested_torch_payload_cannot_run_code(tmp_path):
+    """`torch.storage._load_from_bytes` is on the allow-list (tensors pickled by old torch versions go through it), but the stock helper is
+    torch.load(weights_only=False): a record that reduces to _load_from_bytes(<torch.save of an object with __reduce__>) must be refused,
+    while a genuine tensor payload still loads"""
+    import io
+    import os
+    buf = io.BytesIO()
+    torch.save(_Boom(), buf)
+    evil = type("Evil", (), {"__reduce__": lambda self: (torch.storage._load_from_bytes, (buf.getvalue(),))})()
+    raw = pickle.dumps({"z": torch.tensor([1]), "pos": torch.zeros(1, 3), "edge_index": torch.zeros(2, 0, dtype=torch.long), "x": evil})
+    os.environ.pop("HG_PWNED", None)
+    with pytest.raises(Exception):
+        GD._Unpickler(io.BytesIO(raw)).load()
+    assert "HG_PWNED" not in os.environ
+    good = io.BytesIO()
+    torch.save(torch.arange(4.0), good)
+    ok = type("Ok", (), {"__reduce__": lambda self: (torch.storage._load_from_bytes, (good.getvalue(),))})()
+    out = GD._Unpickler(io.BytesIO(pickle.dumps({"t": ok}))).load()
+    assert torch.equal(out["t"], torch.arange(4.0))
+
+
+def test_lmdb_dataset_pickles_for_dataloader_workers(tmp_path):
+    """spawn-mode DataLoader workers receive a pickled dataset: the store is reopened lazily in the worker (the reference opens its env
+    lazily too, hamgnn/data/graph_data.py:38-52)"""
+    gs = [S.add_random_targets(S.si_diamond(primitive=True), 19)]
+    npz = str(tmp_path / "graph_data.npz")
+    GD.save_graph_npz(gs, npz)
+    db = GD.npz_to_lmdb(npz, str(tmp_path / "store"))
+    ds = GD.LMDBGraphDataset(db)
+    _ = ds[0]
+    clone = pickle.loads(pickle.dumps(ds))
+    assert clone._reader_obj is None and torch.equal(clone[0]["pos"], gs[0].pos)
+    ds.close()

@@ -295,7 +295,7 @@ def test_data_parallel_training_step_gloo(tmp_path):
     assert r["err"] < 1e-6 and r["same"] == 0.0 and r["differs_from_local"] > 1e-3, r
 
 
-def _worker_sharded_training(rank, world, port, tmp, transformer=False):
+def _worker_sharded_training(rank, world, port, tmp, transformer=False, defaults=False):
     """model-parallel training step on an edge-sharded crystal == the single-process step on the whole crystal (loss and every gradient)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -325,9 +325,14 @@ def _worker_sharded_training(rank, world, port, tmp, transformer=False):
             back = HamGNNTransformer(dict(cfg, irreps_node_features=irr, num_heads=2))
         else:
             back = HamGNNConvE3(cfg)
+        # defaults: what hamgnn.main.build_hamgnn_model builds -- zero_point_shift and calculate_sparsity on: ONE dE and ONE ratio per crystal
         return Model(back, HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
-                                             soc_switch=False, calculate_sparsity=False, zero_point_shift=False))
+                                             soc_switch=False, calculate_sparsity=defaults, zero_point_shift=defaults))
     g = S.add_random_targets(S.random_cell(5, [14, 8, 6, 1], seed=11, density=0.004), 19, seed=11)
+    if defaults:
+        gen_s = torch.Generator().manual_seed(81)
+        g["Son"] = torch.eye(19).reshape(1, -1).repeat(g.num_nodes, 1) + 0.01 * torch.randn(g.num_nodes, 361, generator=gen_s)
+        g["Soff"] = 0.05 * torch.randn(g.num_edges, 361, generator=gen_s)
     model = make()
     r = T.training_step(model, parallel.shard_graph(g, rank, world), metric="mae")
     grads = {k: p.grad.clone() for k, p in model.named_parameters()}
@@ -356,6 +361,20 @@ def test_model_parallel_training_step_attention_backbone_gloo(tmp_path):
     mp.spawn(_worker_sharded_training, args=(2, port, tmp, True), nprocs=2, join=True)
     r = json.loads(open(tmp).read())
     assert r["loss_err"] < 1e-6 and r["grad_err"] < 2e-5 and r["n"] > 120, r
+
+
+def test_model_parallel_training_step_default_head_options_gloo(tmp_path):
+    """zero_point_shift and calculate_sparsity as build_hamgnn_model switches them on: the shift's dE (numerator, denominator) and the
+    adjoint's sum(g S) are summed over the ranks with the replicated on-site rows counted once, the sparsity ratio is the whole crystal's"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tmp = str(tmp_path / "mpd.json")
+    mp.spawn(_worker_sharded_training, args=(2, port, tmp, False, True), nprocs=2, join=True)
+    r = json.loads(open(tmp).read())
+    assert r["loss_err"] < 1e-6 and r["grad_err"] < 1e-5 and r["n"] > 100, r
 
 
 def test_model_parallel_training_step_gloo(tmp_path):
