@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void rotate_gather_kernel(const float* __restr
             case 4: rotate_group<4>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
             case 5: rotate_group<5>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
             case 6: rotate_group<6>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;
+            case 7: rotate_group<7>(Dl, xin, xo, t.y, t.z, transpose, t.w); break;      // su2 couplings of f-shell bases (gradient rows of the read-out)
             default: break;
         }
     }

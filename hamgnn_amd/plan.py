@@ -1375,8 +1375,8 @@ def rotate_table(layout: PlanarLayout) -> np.ndarray:
     group of 4 channel slots, sorted by l (stable) so that the wavefronts of hg_rotate_gather run a single <L> code path."""
     rows = []
     for (mul, l, p), off, mp in zip(layout.irreps, layout.off, layout.mulp):
-        if l > 6:
-            raise NotImplementedError(f"feature irreps with l = {l} > 6 have no rotation kernel instantiation")
+        if l > 7:
+            raise NotImplementedError(f"feature irreps with l = {l} > 7 have no rotation kernel instantiation")
         for u in range(0, mp, 4):
             rows.append((l, off + u, mp, max(0, min(4, mul - u))))
     rows.sort(key=lambda r: r[0])

@@ -523,6 +523,35 @@ def main():
           inputs=dict(node_attr=na27.float(), edge_attr=ea27.float()), meta=dict(irreps=rich),
           outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"].float(), hamiltonian_imag=out_ref["hamiltonian_imag"].float()))
 
+    # ---- 6b'. the largest abacus basis (nao 40: four s, four p, two d, two f shells; its own generator stream) ----------------
+    gen40 = torch.Generator().manual_seed(40)
+    na40, ea40 = f32(torch.randn(N, Dr, generator=gen40)), f32(torch.randn(E, Dr, generator=gen40))
+    nao = 40
+    Gu = Graph(G)
+    Gu.z = torch.tensor((47, 6, 26))                               # Ag (s4 p2 d2 f1), C (s2 p2 d1), Fe (s4 p2 d2 f1)
+    for k, n in (("Hon0", N), ("Hoff0", E), ("iHon0", N), ("iHoff0", E), ("Hon", N), ("Hoff", E), ("iHon", N), ("iHoff", E)):
+        Gu[k] = f32(0.1 * torch.randn(n, 4 * nao * nao, generator=gen40))
+    Gu["Son"], Gu["Soff"] = torch.randn(N, nao * nao, generator=gen40), torch.randn(E, nao * nao, generator=gen40)
+    torch.manual_seed(17)
+    ref = ref_out.HamGNNPlusPlusOut(irreps_in_node=rich, irreps_in_edge=rich, nao_max=nao, ham_type="abacus", ham_only=True, symmetrize=True,
+                                    add_H0=True, soc_switch=True, soc_basis="su2", calculate_band_energy=False, calculate_sparsity=False)
+    with torch.no_grad():
+        for prm in ref.parameters():
+            prm.copy_(f32(prm))
+    mine = R.HamGNNPlusPlusOut(rich, rich, nao_max=nao, ham_type="abacus", symmetrize=True, add_H0=True, soc_switch=True, soc_basis="su2")
+    sd = {k: v for k, v in ref.state_dict().items() if not k.startswith("cg_calculator")}
+    res = mine.load_state_dict(sd, strict=False)
+    assert not res.missing_keys, res.missing_keys
+    gin = Graph({k: (v.clone() if torch.is_tensor(v) else v) for k, v in Gu.items()})
+    out_ref = ref(gin, {"node_attr": na40, "edge_attr": ea40})
+    out_mine = mine(Gu, {"node_attr": na40, "edge_attr": ea40})
+    _check(out_mine["hamiltonian_real"], out_ref["hamiltonian_real"], "head SOC su2 abacus nao=40 real")
+    _check(out_mine["hamiltonian_imag"], out_ref["hamiltonian_imag"], "head SOC su2 abacus nao=40 imag")
+    _save("head_soc_su2_abacus_40", weights={k: v.float() for k, v in sd.items()},
+          graph={k: (Gu[k].float() if Gu[k].is_floating_point() else Gu[k]) for k in keys},
+          inputs=dict(node_attr=na40.float(), edge_attr=ea40.float()), meta=dict(irreps=rich),
+          outputs=dict(hamiltonian_real=out_ref["hamiltonian_real"].float(), hamiltonian_imag=out_ref["hamiltonian_imag"].float()))
+
     # ---- 6c. k-space step: calculate_band_energies (hamgnn_output.py:1675-1996) on a 2-crystal batch -----------------
     genk = torch.Generator().manual_seed(31)
     from hamgnn_amd.data import collate

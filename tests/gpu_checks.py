@@ -652,10 +652,12 @@ def check_soc_head_backward(device="cuda", n_atoms=5, seed=3, nao=19, add_H_nons
     from hamgnn_amd import ops, plan as P
     from hamgnn_amd.data import synthetic as S, collate
     from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
-    su2 = basis == "su2"                                       # siesta-13 (spinor CG merge), features up to l = 5 so that every coupling is fed
+    su2 = basis in ("su2", "su2_f")                            # siesta-13 (spinor CG merge), features up to l = 5 so that every coupling is fed
     irr = "8x0e+8x0o+4x1e+4x1o+4x2e+4x2o+2x3e+2x3o+2x4e+2x4o+2x5e+2x5o" if su2 else MINI
     ham_type, nao = ("siesta", 13) if su2 else ("openmx", nao)
     zs = [14, 8, 6] if su2 else [14, 8, 6, 1]
+    if basis == "su2_f":                                       # f-shell basis (abacus 27: L x 1 couplings reach l = 7), features to l = 6
+        irr, ham_type, nao, zs, basis = "4x0e+4x0o+2x1o+2x1e+2x2e+2x2o+2x3o+2x3e+1x4e+1x4o+1x5o+1x5e+1x6e+1x6o", "abacus", 27, [14, 8, 6], "su2"
     torch.manual_seed(seed)
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
@@ -950,18 +952,20 @@ def check_head_su2(device="cuda"):
     res = {"su2_real_rel_err": rel(out["hamiltonian_real"], f["outputs"]["hamiltonian_real"]),
            "su2_imag_rel_err": rel(out["hamiltonian_imag"], f["outputs"]["hamiltonian_imag"])}
     # f-shell basis (abacus nao 27): L x 1 couplings up to l = 7 (structural zeros for l <= 6 features), reference fixture
-    f27 = load("head_soc_su2_abacus_27")
-    irr27 = str(f27["meta"]["irreps"])
-    m27 = load_weights(HamGNNPlusPlusOut(irr27, irr27, nao_max=27, ham_type="abacus", ham_only=True, symmetrize=True, add_H0=True,
-                                         soc_switch=True, calculate_sparsity=False), f27["weights"])
-    gd27 = dict(f27["graph"])
-    for k in ("pos", "nbr_shift", "cell"):
-        gd27[k] = bb[k]
-    o27 = m27(to_graph(gd27, device), {"node_attr": torch.from_numpy(f27["inputs"]["node_attr"]).float().to(device),
-                                       "edge_attr": torch.from_numpy(f27["inputs"]["edge_attr"]).float().to(device)})
-    torch.cuda.synchronize()
-    res.update({"su2_nao27_real_rel_err": rel(o27["hamiltonian_real"], f27["outputs"]["hamiltonian_real"]),
-                "su2_nao27_imag_rel_err": rel(o27["hamiltonian_imag"], f27["outputs"]["hamiltonian_imag"])})
+    for nao_f in (27, 40):                                     # f-shell bases: L x 1 couplings up to l = 7; 40 = the largest abacus table
+        f27 = load(f"head_soc_su2_abacus_{nao_f}")
+        irr27 = str(f27["meta"]["irreps"])
+        m27 = load_weights(HamGNNPlusPlusOut(irr27, irr27, nao_max=nao_f, ham_type="abacus", ham_only=True, symmetrize=True, add_H0=True,
+                                             soc_switch=True, calculate_sparsity=False), f27["weights"])
+        gd27 = dict(f27["graph"])
+        for k in ("pos", "nbr_shift", "cell"):
+            gd27[k] = bb[k]
+        o27 = m27(to_graph(gd27, device), {"node_attr": torch.from_numpy(f27["inputs"]["node_attr"]).float().to(device),
+                                           "edge_attr": torch.from_numpy(f27["inputs"]["edge_attr"]).float().to(device)})
+        if device != "cpu":
+            torch.cuda.synchronize()
+        res.update({f"su2_nao{nao_f}_real_rel_err": rel(o27["hamiltonian_real"], f27["outputs"]["hamiltonian_real"]),
+                    f"su2_nao{nao_f}_imag_rel_err": rel(o27["hamiltonian_imag"], f27["outputs"]["hamiltonian_imag"])})
     rich = "8x0e+8x0o+4x1e+4x1o+4x2e+4x2o+2x3e+2x3o+2x4e+2x4o+2x5e+2x5o"
     torch.manual_seed(5)
     prev = torch.get_default_dtype()

@@ -41,7 +41,8 @@ def test_full_backward_variants_vs_autograd(cpu_backend, kw):
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(add_H_nonsoc=True, crystals=2), dict(basis="su2", n_atoms=3)], ids=["so3", "so3_nonsoc", "su2"])
+@pytest.mark.parametrize("kw", [dict(), dict(add_H_nonsoc=True, crystals=2), dict(basis="su2", n_atoms=3), dict(basis="su2_f", n_atoms=2)],
+                         ids=["so3", "so3_nonsoc", "su2", "su2_f_shell_l7"])
 def test_soc_head_backward_vs_autograd(cpu_backend, kw):
     r = G.check_soc_head_backward(device="cpu", **kw)
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r

@@ -190,6 +190,36 @@ def test_full_model_backward_transformer():
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] > 120, r
 
 
+@pytest.mark.parametrize("kw", [dict(lite=True), dict(lite=True, legacy=True, crystals=2, n_atoms=2),
+                                dict(zps=True, crystals=2, n_atoms=2), dict(zps=True, soc="so3")],
+                         ids=["lite", "lite_legacy_batch", "zero_point_shift", "zero_point_shift_soc"])
+def test_full_model_backward_lite_mode_and_zero_point_shift(kw):
+    """lite_mode backward (hamgnn_amd/backward_lite.py: adjoint IT_LINC program, streaming-Linear adjoints) and the zero-point shift's adjoint
+    on the HIP kernels vs autograd through the fp64 oracle (round 2 had run these on the CPU stand-ins only)"""
+    r = G.check_full_backward(**dict(dict(n_atoms=3, seed=5), **kw))
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL
+
+
+def test_reference_loss_semantics():
+    """Model.py:150-166: hamiltonian-type losses x sparsity_ratio; SOC training on hamiltonian_real + hamiltonian_imag with their weights"""
+    r = G.check_full_backward(n_atoms=4, num_layers=1, nao=14, sparsity=True)
+    print(r)
+    assert r["loss_rel_err"] < 1e-5 and r["max_rel_err"] < 2e-5
+    r = G.check_full_backward(n_atoms=4, num_layers=1, nao=14, soc="so3", sparsity=True, split_losses=True, metric="mae")
+    print(r)
+    assert r["loss_rel_err"] < 1e-5 and r["max_rel_err"] < 2e-5
+
+
+@pytest.mark.parametrize("zps", [False, True])
+def test_band_energy_loss_with_zero_point_shift(zps):
+    """hamiltonian + band_energy losses vs autograd through the oracle; with zero_point_shift the band gradient enters BEFORE the shift and
+    carries the adjoint of the mean alignment (complex64 eigensolver on the GPU against fp64: looser bar)"""
+    r = G.check_full_backward(n_atoms=3, num_layers=1, nao=13, metric="mae", zps=zps, bands=True)
+    print(r)
+    assert r["loss_rel_err"] < 1e-4 and r["max_rel_err"] < 2e-3
+
+
 def test_full_model_backward_default_irreps():
     """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
     r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)
@@ -218,9 +248,11 @@ def test_soc_head_backward_vs_autograd(nonsoc, crystals):
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
 
-def test_soc_su2_head_backward_vs_autograd():
-    """SOC / su2 head (siesta-13: spinor CG merge, [real | imaginary] planes finished with sign +1 / -1)"""
-    r = G.check_soc_head_backward(basis="su2", n_atoms=4)
+@pytest.mark.parametrize("basis,n_atoms", [("su2", 4), ("su2_f", 2)], ids=["siesta_13", "abacus_27_f_shells_l7"])
+def test_soc_su2_head_backward_vs_autograd(basis, n_atoms):
+    """SOC / su2 head (siesta-13: spinor CG merge, [real | imaginary] planes finished with sign +1 / -1; abacus-27: f shells, couplings
+    up to l = 7 -- the gradient rows are rotated by the l = 7 instantiation of hg_rotate_gather)"""
+    r = G.check_soc_head_backward(basis=basis, n_atoms=n_atoms)
     print(r)
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
@@ -299,6 +331,27 @@ def test_sharded_two_rank_forward_matches_single_rank(workload, irreps):
     print(r)
     assert r["world"] == 2 and min(r["edges_per_rank"]) > 0 and sum(r["edges_per_rank"]) == r["E"]
     assert r["rel_err"] < 1e-5, r
+
+
+@pytest.mark.parametrize("mode", ["train_conv", "train_attn", "dp"])
+def test_two_rank_training_paths_on_one_gpu(mode):
+    """the multi-rank training paths ON THE HIP KERNELS (2 ranks over gloo sharing cuda:0): model-parallel training step of both backbones on
+    an edge-sharded crystal (sharded attention forward + backward, zero-point shift and sparsity ratio of the whole crystal) == the
+    single-process step; data-parallel allreduce_gradients == the mean of the single-process gradients"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29551", os.path.join(root, "tests", "dist_gpu_train_check.py")], capture_output=True, text=True,
+                        timeout=900, env=dict(os.environ, HG_DIST_MODE=mode))
+    tail = cp.stdout[-2000:] + cp.stderr[-2000:]
+    assert cp.returncode == 0, tail
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("DIST_TRAIN ")]
+    assert lines, tail
+    r = json.loads(lines[-1][len("DIST_TRAIN "):])
+    print(r)
+    assert r["loss_err"] < 1e-5 and r["grad_err"] < 5e-5 and r["n"] > 100, r
+    if mode == "dp":
+        assert r["differs_from_rank0_alone"] > 1e-3, r          # the mean is not rank 0's own gradient
 
 
 def test_rccl_backend_single_rank():
