@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- edges/sec of the equivariant message-passing forward (HamGNNConvE3 + HamGNNPlusPlusOut) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload sio2_10k|si512|mos2_1200|si2] [--irreps A|B]
+    python bench.py --gpus N --steps K --warmup W [--workload sio2_10k|si512|mos2_1200|si2|uni8] [--irreps A|B]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
 A "step" is ONE inference forward of the whole hot path over one synthetic periodic crystal already resident in HBM:
@@ -9,7 +9,9 @@ backbone (embedding + num_layers x (ConvBlockE3 + PairInteractionBlock)) + pair 
 add_H0, no SOC), random-init weights (seed 666), fp32.  value = directed edges of the crystal * steps / time, whole job.
 For N > 1 the undirected pairs are sharded over the ranks (hamgnn_amd/parallel.py) with one RCCL all-reduce of the node
 aggregates per layer; the crystal (total work) is fixed => "scaling": "strong".
-Prints ONE JSON line (rank 0) incl. `roofline` for the dominant kernel (the fused MessagePackBlock launches: hg_tp_is, or
+Prints ONE JSON line (rank 0) incl. `accuracy` (max|H - H_oracle| / max|H_oracle| and MAE of this model on a bounded sub-crystal, fp64 oracle
+in a child process), `compile_s` (host planner + upload), for N > 1 `per_rank` (edges, edge-kernel / all-reduce / other ms per step of every
+rank) and `ranks_seen`, `roofline` for the dominant kernel (the fused MessagePackBlock launches: hg_tp_is, or
 hg_tp_fused on the fallback path; timed live with HIP events on the launch stream inside the timed region) and `cpu_baseline` (the oracle = unfused pure-torch port of the reference path,
 timed on the host cores over a bounded sample of the same workload; rank 0, N=1 only).
 """
@@ -58,6 +60,10 @@ def make_graph(workload, nao, soc=False):
         g = S.mos2_monolayer(20, 20)
     elif workload == "si2":
         g = S.si_diamond(primitive=True)
+    elif workload == "si64":
+        g = S.si_diamond(2, 2, 2, jitter=0.05, seed=0)
+    elif workload == "mos2_48":
+        g = S.mos2_monolayer(4, 4)
     elif workload.startswith("sio2_"):
         g = S.amorphous_sio2(int(workload.split("_")[1]), seed=1)
     else:
@@ -110,6 +116,119 @@ def cpu_baseline(workload, irreps_key, nao, budget_s=15.0):
             "sample": f"{workload}-like crystal, {n2} atoms / {e2} directed edges, 1 forward in {t2:.1f}s, fp32, torch {torch.get_num_threads()} threads"}
 
 
+# BASELINE config #5 (Uni-HamGNN universal model, mixed-Z periodic-table batch): Z drawn from the 26-orbital OpenMX table -- light ... heavy,
+# s / p / d / f shells -- 8 crystals of 32-128 atoms (seed 2)
+UNI_ZS = (1, 6, 8, 14, 22, 26, 31, 42, 47, 56, 74, 79, 83)
+
+
+def uni_config(irreps, soc):
+    pre = dict(make_cfg(irreps), num_types=96)
+    out = dict(nao_max=26, ham_type="openmx", ham_only=True, symmetrize=True, calculate_band_energy=False, num_k=4, k_path=None,
+               band_num_control=None, soc_switch=soc, nonlinearity_type="gate", add_H0=True, spin_constrained=False, collinear_spin=False,
+               minMagneticMoment=0.5)
+    return dict(representation_nets=dict(HamGNN_pre=pre), output_nets=dict(HamGNN_out=out))
+
+
+def run_uni8(args, dev):
+    """--workload uni8: the two-model chain of Uni-HamiltonianPredictor.py:290-319 (non-SOC universal model -> Hon_nonsoc / Hoff_nonsoc ->
+    SOC / so3 model with add_H_nonsoc) over 8 mixed-Z crystals of 32-128 atoms, nao 26, set-A.  A step = all 8 crystals through both
+    models.  Three ways to issue the same work: one crystal per forward as the reference's DataLoader(batch_size=1) does (eager, and as
+    HIP-graph replays), and all 8 crystals collated into ONE batch per model (the per-launch choices -- split edge-kernel launches for
+    few tiles, one workgroup per tile otherwise -- are then made per batch instead of per crystal)."""
+    import numpy as np
+    from hamgnn_amd import ops, uni
+    from hamgnn_amd.data import collate, synthetic as S
+    from hamgnn_amd.graph_capture import CapturedForward
+    from hamgnn_amd.models.model import Model
+    irreps = IRREPS[args.irreps]
+    models = {}
+    for soc in (False, True):
+        torch.manual_seed(666 + int(soc))
+        rep, head = uni.build_hamgnn_components(uni_config(irreps, soc))
+        models[soc] = Model(representation=rep, output=head).to(dev)
+    pred = uni.HamiltonianPredictor(models[False], models[True], dev)
+    rng = np.random.default_rng(2)
+    pairs = []
+    for k in range(8):
+        base = S.random_cell(int(rng.integers(32, 129)), list(UNI_ZS), seed=60 + k, density=0.012)
+        pairs.append((S.add_random_targets(type(base)(base), 26, seed=60 + k, soc=False), S.add_random_targets(type(base)(base), 26, seed=1060 + k, soc=True)))
+    atoms, edges = [p[0].num_nodes for p in pairs], [p[0].num_edges for p in pairs]
+    E_total = sum(edges)
+    singles = [(a.to(dev), b.to(dev)) for a, b in pairs]
+    batch_ns, batch_soc = collate([p[0] for p in pairs]).to(dev), collate([p[1] for p in pairs]).to(dev)
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    per_crystal = lambda: [pred.predict(a, b) for a, b in singles]
+    batched = lambda: pred.predict(batch_ns, batch_soc)
+    ops.PROFILE_EVENTS = None
+    t_pc = timed(per_crystal, args.steps, args.warmup)
+    t_b = timed(batched, args.steps, args.warmup)
+    # consistency of the two issue orders (per-crystal rows == the batch's rows, crystal by crystal)
+    with torch.no_grad():
+        ob = batched()
+        oc = per_crystal()
+    hr = torch.cat([o["hamiltonian_real"] for o in oc], 0)
+    batch_vs_single = float((ob["hamiltonian_real"] - hr).abs().max() / hr.abs().max())
+    replays = [CapturedForward((lambda a=a, b=b: pred.predict(a, b))) for a, b in singles]
+    t_gr = timed(lambda: [r() for r in replays], args.steps, args.warmup)
+    lat = []
+    for r in replays:                                          # per-crystal latency of one replayed chain
+        lat.append(timed(r, max(3, args.steps), 1) * 1e3)
+    replay_b = CapturedForward(batched)
+    t_gb = timed(replay_b, args.steps, args.warmup)
+    modes = {"per_crystal_eager": {"ms_per_step": t_pc * 1e3, "edges_per_s": E_total / t_pc},
+             "per_crystal_graph_replay": {"ms_per_step": t_gr * 1e3, "edges_per_s": E_total / t_gr, "latency_ms_per_crystal": lat},
+             "batched_eager": {"ms_per_step": t_b * 1e3, "edges_per_s": E_total / t_b},
+             "batched_graph_replay": {"ms_per_step": t_gb * 1e3, "edges_per_s": E_total / t_gb}}
+    best = max(modes, key=lambda m: modes[m]["edges_per_s"])
+    res = {"metric": "edges/sec (equivariant MP forward)", "value": modes[best]["edges_per_s"], "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": modes[best]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"uni8: Uni-HamGNN two-model chain (non-SOC -> SOC/so3, add_H_nonsoc), 8 mixed-Z crystals of {min(atoms)}-{max(atoms)} atoms "
+                                  f"({sum(atoms)} atoms, {E_total} directed edges), irreps set-{args.irreps}, nao_max 26, 3 layers per model",
+                      "parallelism": f"single GPU, issue mode = {best}"},
+           "modes": modes, "batch_rows_vs_per_crystal_rows": batch_vs_single, "atoms": atoms, "edges": edges}
+    print(json.dumps(res), flush=True)
+
+
+def accuracy_vs_oracle(path):
+    """Accuracy leg (child process, host cores): the fp64 oracle on the bounded sub-crystal the GPU run left in `path` (graph, both
+    state_dicts, the GPU's Hamiltonian rows) -> max|H - H_oracle| / max|H_oracle| and the mean absolute error."""
+    from oracle import hamgnn_ref as R
+    blob = torch.load(path, weights_only=False)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        model = R.HamGNNConvE3(make_cfg(blob["irreps"]))
+        head = R.HamGNNPlusPlusOut(blob["irreps"], blob["irreps"], nao_max=blob["nao"], ham_type="openmx", symmetrize=True, add_H0=True)
+    finally:
+        torch.set_default_dtype(prev)
+    for mod, sd in ((model, blob["backbone"]), (head, blob["head"])):
+        res = mod.load_state_dict({k: v.double() for k, v in sd.items()}, strict=False)
+        missing = set(res.missing_keys) & set(dict(mod.named_parameters()))
+        assert not missing, sorted(missing)[:4]
+    g = blob["graph"]
+    g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        Href = head(g64, model(g64))["hamiltonian"]
+    H = blob["H"].double()
+    return {"rel_max": float((H - Href).abs().max() / Href.abs().max()), "mae": float((H - Href).abs().mean()),
+            "oracle_mean_abs": float(Href.abs().mean()), "tolerance": 1e-5,
+            "sample": f"{blob['what']}: {g64.num_nodes} atoms / {g64.num_edges} directed edges, same weights as the timed model, "
+                      f"fp32 HIP vs fp64 oracle ({time.perf_counter() - t0:.1f} s on the host)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,8 +240,13 @@ def main():
     ap.add_argument("--soc", action="store_true", help="SOC / so3 read-out (BASELINE config #3: MoS2 with spin-orbit coupling); the CPU baseline leg stays non-SOC")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--accuracy-from", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy leg (fp64 oracle on a bounded sub-crystal, host cores)")
     args = ap.parse_args()
     if args.cpu_baseline_only:                       # child process of the N=1 run (hard wall-clock bound in the parent)
+        if args.accuracy_from:
+            print("ACCURACY " + json.dumps(accuracy_vs_oracle(args.accuracy_from)), flush=True)
+            return
         print("CPU_BASELINE " + json.dumps(cpu_baseline(args.workload, args.irreps, args.nao)), flush=True)
         return
 
@@ -132,10 +256,14 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    if os.environ.get("HG_BENCH_SAME_DEVICE") == "1":      # test hook: validate the N>1 script path on a 1-GPU box (gloo, shared device)
+    same_device = os.environ.get("HG_BENCH_SAME_DEVICE") == "1"
+    if same_device:                                        # test hook: validate the N>1 script path on a 1-GPU box (gloo, shared device)
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} visible GPU(s)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,7 +272,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # every rank on its own GPU: gather (host, device index, PCI bus id) and refuse duplicates -- two ranks on one device would
+        # silently halve the job's throughput (and RCCL refuses them much later, inside the first collective)
+        props = torch.cuda.get_device_properties(dev)
+        ident = (os.uname().nodename, local_rank, str(getattr(props, "pci_bus_id", "")) + ":" + str(getattr(props, "uuid", "")))
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if not same_device and len({(h, d) for h, d, _ in idents}) != world:
+            raise SystemExit(f"rank {rank}: {world} ranks on {len({(h, d) for h, d, _ in idents})} distinct devices: {idents}")
 
+    if args.workload == "uni8":
+        if world > 1:
+            raise SystemExit("uni8 runs as replicas (one batch of crystals per GPU, no collective): launch it per GPU")
+        run_uni8(args, dev)
+        return
     from hamgnn_amd import ops, parallel
     from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
     from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
@@ -159,8 +300,18 @@ def main():
     if world > 1:
         g = parallel.shard_graph(g, rank, world)
     g = g.to(dev)
-    model.compile(dev)
+    E_local = g.num_edges
+    t_c = time.perf_counter()
+    model.compile(dev)                                     # host planner (numpy) + upload of the packed weights and tables: once per model
     head.compile(dev)
+    torch.cuda.synchronize()
+    compile_s = time.perf_counter() - t_c
+    if world > 1:                                          # first collective of the job (communicator set-up, buffer registration): untimed
+        warm = torch.zeros(N_atoms, model.node_layout.dim if hasattr(model, "node_layout") else 880, device=dev)
+        for _ in range(2):
+            torch.distributed.all_reduce(warm)
+        torch.cuda.synchronize()
+        del warm
 
     def step():
         with torch.no_grad():
@@ -176,6 +327,7 @@ def main():
         step()
     barrier()
     ops.PROFILE_EVENTS = []                                  # HIP event pairs around every hg_tp_fused launch (launch stream)
+    parallel.PROFILE_EVENTS = [] if world > 1 else None      # ... and around every node all-reduce
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step boundaries on the launch stream (no host sync)
     t0 = time.perf_counter()
     marks[0].record()
@@ -187,10 +339,23 @@ def main():
     step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     events, ops.PROFILE_EVENTS = ops.PROFILE_EVENTS, None
+    ar_events, parallel.PROFILE_EVENTS = parallel.PROFILE_EVENTS, None
+    per_rank = None
     if world > 1:
+        dt_local = dt
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
+        # what every rank spent per step (HIP events on its launch stream): the edge kernel, the node all-reduces (incl. the wait for the
+        # slowest rank), everything else (node-level Linears / gates, the read-out of its own edges, launch gaps)
+        tp_ms = sum(s.elapsed_time(e) for (s, e, rows, tag) in events if tag == "message_pack") / args.steps
+        ar_ms = sum(s.elapsed_time(e) for (s, e, nbytes) in ar_events) / args.steps
+        mine = {"rank": rank, "device": local_rank, "edges": int(E_local), "step_ms": dt_local / args.steps * 1e3, "tp_is_ms": tp_ms,
+                "allreduce_ms": ar_ms, "allreduce_calls_per_step": len(ar_events) / args.steps,
+                "allreduce_mbytes": (ar_events[0][2] / 1e6 if ar_events else 0.0), "other_ms": dt_local / args.steps * 1e3 - tp_ms - ar_ms,
+                "compile_s": compile_s}
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
     assert torch.isfinite(out["hamiltonian"]).all()
 
     # ---- roofline of the dominant kernel: the fused MessagePackBlock launches (hg_tp_is; hg_tp_fused on the fallback path)
@@ -223,8 +388,35 @@ def main():
            "config": {"workload": f"{args.workload}: {N_atoms} atoms, {E_total} directed edges, irreps set-{args.irreps} (D={model.irreps_node_features.dim}), "
                                   f"sh lmax 5, 3 layers, nao_max {args.nao}, {'SOC (so3 head)' if args.soc else 'no SOC'}, backbone+head forward",
                       "parallelism": "single GPU" if world == 1 else f"pair-sharded edges x{world} + RCCL all-reduce of node aggregates"},
-           "roofline": roofline}
+           "roofline": roofline, "compile_s": compile_s}
+    if per_rank is not None:
+        res["per_rank"] = per_rank
+        res["ranks_seen"] = {"backend": "RCCL (torch.distributed 'nccl')" if backend == "nccl" else backend, "world_size": torch.distributed.get_world_size(),
+                             "distinct_devices": len({(h, d) for h, d, _ in idents}), "max_over_mean_edges": max(r["edges"] for r in per_rank) * world / E_total}
     if rank == 0:
+        if world == 1 and not args.no_accuracy:
+            # accuracy of THIS model (same weights) on a bounded sub-crystal of the same generator: the HIP forward here, the fp64 oracle in a
+            # child process on the host cores -- reported next to the throughput, never inside the timed region
+            import subprocess
+            import tempfile
+            try:
+                small = make_graph({"sio2_10k": "sio2_60", "si512": "si64", "mos2_1200": "mos2_48", "si2": "si2"}.get(args.workload, "sio2_60"), args.nao) \
+                    if not args.soc else None
+                if small is not None:
+                    with torch.no_grad():
+                        sd = small.to(dev)
+                        Hs = head(sd, model(sd))["hamiltonian"].float().cpu()
+                    with tempfile.TemporaryDirectory() as td:
+                        pth = os.path.join(td, "acc.pt")
+                        torch.save({"graph": small, "backbone": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                                    "head": {k: v.detach().cpu() for k, v in head.state_dict().items()}, "H": Hs, "irreps": irreps, "nao": args.nao,
+                                    "what": f"sub-crystal of the {args.workload} generator"}, pth)
+                        cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--accuracy-from", pth],
+                                            capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+                    line = [l for l in cp.stdout.splitlines() if l.startswith("ACCURACY ")][-1]
+                    res["accuracy"] = json.loads(line[len("ACCURACY "):])
+            except Exception as exc:
+                res["accuracy"] = {"rel_max": None, "mae": None, "sample": f"failed: {exc!r}"[:200]}
         if world == 1 and not args.no_cpu_baseline:
             import subprocess
             try:

@@ -68,8 +68,17 @@ def allreduce_nodes(t: torch.Tensor, data) -> torch.Tensor:
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("graph is sharded but torch.distributed is not initialised")
+    if PROFILE_EVENTS is not None:                             # bench.py: HIP event pairs around the collective (launch stream)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if PROFILE_EVENTS is not None:
+        ev1.record()
+        PROFILE_EVENTS.append((ev0, ev1, int(t.numel()) * t.element_size()))
     return t
+
+
+PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, bytes) around every node all-reduce
 
 
 # ---- training on an edge-sharded crystal (model-parallel; hamgnn_amd.training): which parameter gradients are sums over the edges

@@ -68,18 +68,22 @@ def _ensure_hamiltonian_key(model, batch, keys):
 
 
 def uni_forward(non_soc_model, soc_model, non_soc_batch, soc_batch=None) -> dict:
-    """one crystal through the universal model(s); mutates the batches exactly where the reference does"""
+    """one crystal -- or a batch of crystals -- through the universal model(s); mutates the batches exactly where the reference does"""
     _ensure_hamiltonian_key(non_soc_model, non_soc_batch, ("Hon", "Hoff"))
     if soc_model is None:
         return non_soc_model(non_soc_batch)
     _ensure_hamiltonian_key(soc_model, soc_batch, ("Hon", "Hoff", "iHon", "iHoff"))
-    nb = gget(soc_batch, "node_counts")
-    if nb is not None and int(nb.shape[0]) > 1:
-        raise ValueError("the non-SOC -> SOC hand-over splits [on-site; off-site] of ONE crystal (the reference runs batch_size=1)")
     pred = non_soc_model(non_soc_batch)
-    n = len(soc_batch.z)
-    soc_batch["Hon_nonsoc"] = pred["hamiltonian"][:n]
-    soc_batch["Hoff_nonsoc"] = pred["hamiltonian"][n:]
+    # the reference runs DataLoader(batch_size=1) and splits [on-site; off-site] of that ONE crystal (:306-311); a batch of several crystals
+    # (the same crystals in the same order in both batches) carries the rows per crystal, so they are split back with the head's own inverse
+    # of concatenate_hamiltonians_by_crystal -- one launch sequence for the whole batch instead of one per crystal
+    head = non_soc_model.output_module
+    edge_counts = head._global_inverse(non_soc_batch)[1]
+    on, off = head._split_by_crystal(non_soc_batch, pred["hamiltonian"], edge_counts)
+    if on.shape[0] != len(soc_batch.z) or off.shape[0] != soc_batch.edge_index.shape[1]:
+        raise ValueError("uni_forward: the non-SOC and the SOC batch must hold the same crystals in the same order")
+    soc_batch["Hon_nonsoc"] = on
+    soc_batch["Hoff_nonsoc"] = off
     return soc_model(soc_batch)
 
 

@@ -1513,3 +1513,29 @@ def check_head_bands_zero_point(device="cuda", tag="batch"):
     res["unshifted_band_energy_err"] = err(out0["band_energy"], o["band_energy_unshifted"]) / scale
     res["unshifted_H_rel_err"] = rel(out0["hamiltonian"], o["hamiltonian_unshifted"])
     return res
+
+
+def check_uni_chain_batched(device="cuda", irreps=None, n_graphs=3):
+    """the two-model chain on a BATCH of crystals (uni.uni_forward splits the non-SOC prediction back per crystal with the head's own inverse
+    of concatenate_hamiltonians_by_crystal) == the chain one crystal at a time, as the reference's DataLoader(batch_size=1) issues it"""
+    import bench
+    from hamgnn_amd import uni
+    from hamgnn_amd.data import collate
+    from hamgnn_amd.models.model import Model
+    irreps = irreps or bench.IRREPS["A"]
+    models = {}
+    for soc in (False, True):
+        torch.manual_seed(700 + int(soc))
+        rep, head = uni.build_hamgnn_components(_uni_config(irreps, soc, num_layers=2, radial=(16, 16), num_radial=8))
+        models[soc] = Model(representation=rep, output=head).to(device)
+    pred = uni.HamiltonianPredictor(models[False], models[True], device)
+    pairs = [_uni_graph_pair(4 + 2 * k, seed=90 + k) for k in range(n_graphs)]
+    singles = [pred.predict(a.to(device), b.to(device)) for a, b in pairs]
+    out = pred.predict(collate([p[0] for p in pairs]).to(device), collate([p[1] for p in pairs]).to(device))
+    if device != "cpu":
+        torch.cuda.synchronize()
+    res = {}
+    for key in ("hamiltonian_real", "hamiltonian_imag"):
+        res[key + "_rel_err"] = rel(out[key], torch.cat([o[key] for o in singles], 0))
+    res["rows"] = int(out["hamiltonian_real"].shape[0])
+    return res

@@ -145,6 +145,12 @@ def test_uni_hamgnn_two_model_chain_on_cpu(cpu_backend):
     assert r["real"] < G.TOL and r["imag"] < G.TOL and r["nonsoc"] < G.TOL, r
 
 
+def test_uni_hamgnn_chain_on_a_batch_of_crystals_on_cpu(cpu_backend):
+    """the non-SOC -> SOC hand-over for a batch of crystals == the chain crystal by crystal (the reference's batch_size=1 order)"""
+    r = G.check_uni_chain_batched("cpu", irreps=G.MINI, n_graphs=3)
+    assert r["hamiltonian_real_rel_err"] < 1e-6 and r["hamiltonian_imag_rel_err"] < 1e-6 and r["rows"] > 0, r
+
+
 def test_default_irreps_si2_forward_on_cpu(cpu_backend):
     """BASELINE config #1 (Si diamond 2-atom cell, 172 edges) at the SHIPPED irreps (set A: D = 877, l <= 6, SH to l = 5, 64 radial, three
     layers, nao 19): the production planner output -- merged items, odd-path templates, split launches for a small crystal, the one-pass

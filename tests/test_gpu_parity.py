@@ -479,6 +479,13 @@ def test_uni_hamgnn_chain_vs_oracle():
     assert r["nonsoc"] < G.TOL and r["real"] < G.TOL and r["imag"] < G.TOL
 
 
+def test_uni_hamgnn_chain_on_a_batch_of_crystals():
+    """config #5 issued as ONE batch per model instead of one crystal per forward: same rows (set-A irreps, mixed-Z crystals)"""
+    r = G.check_uni_chain_batched(n_graphs=4)
+    print(r)
+    assert r["hamiltonian_real_rel_err"] < 1e-5 and r["hamiltonian_imag_rel_err"] < 1e-5
+
+
 def test_uni_hamgnn_chain_full_size_properties():
     r = G.check_uni_chain_full_size()
     print(r)
