@@ -590,6 +590,12 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         }
         HG_WAVE_FENCE();
 #ifndef HG_ABL_NOEPI
+        // opaque per segment: the row-derived pointers of the epilogue (output, residual rows, Wigner blocks) are rebuilt here instead of
+        // being hoisted out of the segment loop and carried -- spilled, in the lite_mode instantiation -- through all items
+        int64_t e_o = e, erow_o = erow;
+        asm volatile("" : "+v"(e_o), "+v"(erow_o));
+#define e e_o
+#define erow erow_o
         switch (lk) {
             case 0: epilogue<0>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
             case 1: epilogue<1>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
@@ -600,6 +606,8 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
             case 6: epilogue<6>(A, tile, stage, rowstride, mul_k, out_off, out_mulp, flags, e, erow, valid, lane); break;
             default: break;
         }
+#undef e
+#undef erow
 #endif
         HG_WAVE_FENCE();
         HG_T(8);                                               // epilogue

@@ -40,6 +40,9 @@ struct ProfIs { unsigned long long t[12]; unsigned long long last; };
 template <int MM, int RTM, bool SPLIT, bool ODD>
 __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
                                         float* __restrict__ lds, int64_t erow, int lane IS_PROF_ARG) {
+#ifdef HG_IS_OPAQUE_LANE               // A/B hook: lane-derived address terms recomputed per item instead of hoisted (235 -> 217 VGPRs, but 7.58 vs
+    asm volatile("" : "+v"(lane));     // 7.37 ms per 131 072-edge launch: the hoisted terms are worth their registers; profiles/r03_tp_is_experiments.md)
+#endif
     constexpr int NCR = 2 * MM + 1;                            // real columns (fragment layouts of cf, tile columns)
     constexpr int NC = ODD ? 2 * MM : NCR;                     // column slots this item computes
 #define IS_COL(c) ((ODD && (c) >= MM) ? (c) + 1 : (c))
@@ -55,6 +58,14 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const float* __restrict__ stage = lds + A.stage_off;
     IS_T(0);                                                    // dispatch
 
+    const int nsrc = so1 >= 0 ? 2 : 1;
+    const int ngrp = (ksteps + 3) >> 2;
+    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;      // [src][G][rt][lane]
+    f32x4 av_n[RTM];
+#ifdef HG_IS_EARLY_A1                  // first GEMM1 fragment group requested together with the radial operands: one exposed L2 latency fewer per item
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
+#endif
     // ---------------------------------------------------------------- radial scale s_e = W3^T h2 first (see tp_fused.hip)
     f32x4 S[RTM];
     if (typ == 0) {
@@ -91,15 +102,20 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
         for (int c = 0; c < NC; ++c) mid[rt][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nsrc = so1 >= 0 ? 2 : 1;
-    const int ngrp = (ksteps + 3) >> 2;
     const int P1 = in_mulp >> 2;                               // float4 pieces per component
-    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;      // [src][G][rt][lane]
     const int cdir = neg ? -P1 : P1;                           // column c -> component (neg ? a_hi - c : a_lo + c)
     const int c0p = (li - MM) * P1 + (neg ? (NCR - 1) * P1 : 0);
-    f32x4 av_n[RTM];
+#ifndef HG_IS_EARLY_A1
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
+#endif
+#ifdef HG_IS_EARLY_A2                  // GEMM2's first fragment tile requested under the last GEMM1 group instead of after it
+    const f32x4* __restrict__ a2e = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
+    f32x4 a2_e[RTM];
+#define IS_A2_EARLY() else if (typ == 0) { _Pragma("unroll") for (int rt = 0; rt < RTM; ++rt) a2_e[rt] = a2e[rt * 64]; }
+#else
+#define IS_A2_EARLY()
+#endif
 #pragma unroll 1
     for (int si = 0; si < nsrc; ++si) {
         const float* __restrict__ sbase = stage + (si ? so1 : so0);
@@ -115,6 +131,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
                 }
+                IS_A2_EARLY()
 #pragma unroll
                 for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (IS_COL(c) * cdir + 4 * G) * 64);
 #pragma unroll
@@ -136,6 +153,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
                 }
+                IS_A2_EARLY()
                 const int nq = ksteps - 4 * G;                 // K-steps in this group (>= 4 except in the tail group)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -159,8 +177,13 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
         const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
         const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(Wb + it[13]) + g;     // [rt][c][g] float4
         f32x4 a2_n[RTM];
+#ifdef HG_IS_EARLY_A2
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2_e[rt];
+#else
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];
+#endif
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -269,6 +292,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     }
     IS_T(3);                                                    // scale-mul + GEMM2 + write-back
 #undef IS_COL
+#undef IS_A2_EARLY
 }
 
 #ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)

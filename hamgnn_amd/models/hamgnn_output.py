@@ -134,8 +134,7 @@ class HamGNNPlusPlusOut(nn.Module):
     def _cat_by_crystal(data, on, off, edge_counts):
         if edge_counts is None or edge_counts.numel() <= 1:
             return torch.cat([on, off], 0)
-        nn_ = data.node_counts.tolist()
-        ne = edge_counts.tolist()
+        nn_, ne = get_topology(data).crystal_sizes(data)
         out = []
         for a, b in zip(torch.split(on, nn_), torch.split(off, ne)):
             out += [a, b]
@@ -147,7 +146,7 @@ class HamGNNPlusPlusOut(nn.Module):
         if edge_counts is None or edge_counts.numel() <= 1:
             N = data.z.shape[0]
             return H[:N], H[N:]
-        sizes = [v for pair in zip(data.node_counts.tolist(), edge_counts.tolist()) for v in pair]
+        sizes = [v for pair in zip(*get_topology(data).crystal_sizes(data)) for v in pair]
         parts = torch.split(H, sizes)
         return torch.cat(parts[0::2], 0), torch.cat(parts[1::2], 0)
 

@@ -99,6 +99,14 @@ class Topology:
                 self._ginv = ((inv + offs[b]).contiguous(), counts)
         return self._ginv
 
+    def crystal_sizes(self, data):
+        """(atoms per crystal, edges per crystal) as HOST lists, read back once per graph object: the per-crystal [on-site; off-site] row
+        order of the results is assembled with these (no device -> host sync in later forwards: a batched forward is then capture-safe)"""
+        if getattr(self, "_sizes", None) is None:
+            _, counts = self.global_inverse(data)
+            self._sizes = (gget(data, "node_counts").tolist(), counts.tolist())
+        return self._sizes
+
     # ---- (edge, inverse edge) pairs, each once: the one-pass read-out symmetrises both rows of a pair in one block
     def inverse_pairs(self, data):
         if getattr(self, "_pairs", None) is None:
