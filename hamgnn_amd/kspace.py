@@ -21,30 +21,27 @@ from .topo import gget
 
 # ------------------------------------------------------------------------------------------------ k-points (host geometry)
 def k_path_points(kpts, nk: int, lat: np.ndarray):
-    """kpoints_generator(dim_k=3, lat).k_path(kpts, nk) (hamgnn/physics/kpoints.py:26-165): `nk` nearly equidistant points (reduced
-    coordinates) along the straight segments through the nodes `kpts`; distances measured with the reciprocal metric of `lat`.
-    Returns (k_vec [nk,3] reduced, lat_per_inv = inv(lat).T)."""
-    k_list = np.asarray(kpts, dtype=float)
-    if k_list.ndim != 2 or k_list.shape[1] != 3:
-        raise Exception("\n\nk-space dimensions do not match")
-    if nk < k_list.shape[0]:
-        raise Exception("\n\nMust have more points in the path than number of nodes.")
-    lat = np.asarray(lat, dtype=float)
-    k_metric = np.linalg.inv(lat @ lat.T)
-    n_nodes = k_list.shape[0]
-    k_node = np.zeros(n_nodes)
-    for n in range(1, n_nodes):
-        dk = k_list[n] - k_list[n - 1]
-        k_node[n] = k_node[n - 1] + math.sqrt(dk @ k_metric @ dk)
-    node_index = [0] + [int(round(k_node[n] / k_node[-1] * (nk - 1))) for n in range(1, n_nodes - 1)] + [nk - 1]
-    k_vec = np.zeros((nk, 3))
-    k_vec[0] = k_list[0]
-    for n in range(1, n_nodes):
-        n_i, n_f = node_index[n - 1], node_index[n]
-        for j in range(n_i, n_f + 1):
-            frac = float(j - n_i) / float(n_f - n_i)
-            k_vec[j] = k_list[n - 1] + frac * (k_list[n] - k_list[n - 1])
-    return k_vec, np.linalg.inv(lat).T
+    """The k-path of the reference (kpoints_generator(dim_k=3, lat).k_path(kpts, nk), hamgnn/physics/kpoints.py:26-165) as one piecewise
+    linear interpolation: the path is a polyline through the reduced-coordinate nodes `kpts`, parametrised by its arc length in the
+    reciprocal metric of `lat`; every node is pinned to the sample index nearest to its share of the total length, and between two pinned
+    indices the samples are equally spaced.  That is `np.interp` of the three coordinates over the sample index with the pinned indices as
+    abscissae.  Returns (k_vec [nk, 3] reduced, inv(lat).T)."""
+    nodes = np.asarray(kpts, dtype=np.float64)
+    if nodes.ndim != 2 or nodes.shape[1] != 3:
+        raise ValueError("k_path: the nodes must be an [n, 3] list of reduced coordinates")
+    if nk < nodes.shape[0]:
+        raise ValueError("k_path: fewer sample points than nodes")
+    cellm = np.asarray(lat, dtype=np.float64)
+    metric = np.linalg.inv(cellm @ cellm.T)                                    # |dk|^2 = dk^T (A A^T)^-1 dk for reduced dk
+    steps = np.diff(nodes, axis=0)
+    arc = np.concatenate([[0.0], np.cumsum(np.sqrt(np.einsum("ni,ij,nj->n", steps, metric, steps)))])
+    pins = np.rint(arc / arc[-1] * (nk - 1)).astype(np.int64)                  # sample index of every node (ends: 0 and nk - 1 exactly)
+    pins[0], pins[-1] = 0, nk - 1
+    if np.any(np.diff(pins) <= 0):
+        raise ValueError("k_path: two nodes fall onto the same sample point (coincident nodes or too few points)")
+    idx = np.arange(nk, dtype=np.float64)
+    k_vec = np.stack([np.interp(idx, pins.astype(np.float64), nodes[:, d]) for d in range(3)], axis=1)
+    return k_vec, np.linalg.inv(cellm).T
 
 
 def make_k_vectors(k_path, num_k: int, cell: torch.Tensor, rng=np.random) -> torch.Tensor:

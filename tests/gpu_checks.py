@@ -1539,3 +1539,64 @@ def check_uni_chain_batched(device="cuda", irreps=None, n_graphs=3):
         res[key + "_rel_err"] = rel(out[key], torch.cat([o[key] for o in singles], 0))
     res["rows"] = int(out["hamiltonian_real"].shape[0])
     return res
+
+
+def check_band_cal(device="cuda"):
+    """hamgnn_amd.band_cal.band_structure (the non-SOC branch of DFT_interfaces/openmx/band_cal.py) on the k-space fixture: bands along the
+    path == a dense numpy restatement of the script's own loop (phase-factor sums per edge, orbital mask, scipy-style generalised eigenproblem)"""
+    import scipy.linalg
+    from hamgnn_amd import band_cal
+    from hamgnn_amd.data import Graph
+    f = load("band_energies_openmx_13")
+    g = to_graph(f["graph"], "cpu")
+    Hon, Hoff = (torch.from_numpy(f["inputs"][k]).float() for k in ("Hon", "Hoff"))
+    nao, nk = 13, 9
+    nodes = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.5, 0.5, 0.0]]
+    # the fixture is a 2-crystal batch: split it into its crystals (band_cal works crystal by crystal on the dataset's graphs)
+    ncs = g.node_counts.tolist()
+    ecs = torch.bincount(g.batch[g.edge_index[0]], minlength=len(ncs)).tolist()
+    graphs, rows, n0, e0 = [], [], 0, 0
+    for c, (n, e) in enumerate(zip(ncs, ecs)):
+        gc = Graph({"z": g.z[n0:n0 + n], "pos": g.pos[n0:n0 + n], "cell": g.cell[c:c + 1], "edge_index": g.edge_index[:, e0:e0 + e] - n0,
+                    "nbr_shift": g.nbr_shift[e0:e0 + e], "inv_edge_idx": g.inv_edge_idx[e0:e0 + e], "Son": g.Son[n0:n0 + n], "Soff": g.Soff[e0:e0 + e],
+                    "Hon": Hon[n0:n0 + n], "Hoff": Hoff[e0:e0 + e]})
+        graphs.append(gc)
+        rows += [Hon[n0:n0 + n], Hoff[e0:e0 + e]]
+        n0, e0 = n0 + n, e0 + e
+    res = band_cal.band_structure(graphs, torch.cat(rows).numpy(), nao_max=nao, ham_type="openmx", k_path=nodes, nk=nk, device=device)
+    res_t = band_cal.band_structure(graphs, None, nao_max=nao, ham_type="openmx", k_path=nodes, nk=nk, device=device)        # targets stored in the graphs
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    head = HamGNNPlusPlusOut("1x0e", "1x0e", nao_max=nao, ham_type="openmx", ham_only=True, soc_switch=False, calculate_sparsity=False)
+    worst, gaps = 0.0, []
+    for gc, r, rt in zip(graphs, res, res_t):
+        lat = gc.cell.double().numpy().reshape(3, 3)
+        k_cart = r["k_vec"] @ np.linalg.inv(lat).T
+        n = int(gc.z.shape[0])
+        mask = np.zeros((99, nao))
+        for Z, idx in head.basis_def.items():
+            mask[Z][list(idx)] = 1
+        om = mask[gc.z.numpy()].reshape(-1)
+        keep = np.outer(om, om) > 0
+        eig = []
+        for k in k_cart:
+            HK = np.zeros((n, n, nao, nao), complex)
+            SK = np.zeros((n, n, nao, nao), complex)
+            HK[np.arange(n), np.arange(n)] = gc.Hon.double().numpy().reshape(n, nao, nao)
+            SK[np.arange(n), np.arange(n)] = gc.Son.double().numpy().reshape(n, nao, nao)
+            coe = np.exp(2j * np.pi * (gc.nbr_shift.double().numpy() @ k))
+            for ie in range(gc.edge_index.shape[1]):
+                i, j = int(gc.edge_index[0, ie]), int(gc.edge_index[1, ie])
+                HK[i, j] += coe[ie] * gc.Hoff[ie].double().numpy().reshape(nao, nao)
+                SK[i, j] += coe[ie] * gc.Soff[ie].double().numpy().reshape(nao, nao)
+            HK = HK.swapaxes(1, 2).reshape(n * nao, n * nao)[keep]
+            SK = SK.swapaxes(1, 2).reshape(n * nao, n * nao)[keep]
+            m = int(round(np.sqrt(HK.size)))
+            eig.append(scipy.linalg.eigh(HK.reshape(m, m), SK.reshape(m, m), eigvals_only=True))
+        eig = np.array(eig).T * band_cal.AU2EV
+        nel = sum(head.num_valence[int(Z)] for Z in gc.z.tolist())
+        half = int(np.ceil(nel / 2))
+        vbm = eig[half - 1].max()
+        worst = max(worst, float(np.abs((eig - vbm) - r["bands_eV"]).max() / np.abs(eig).max()), float(np.abs(r["bands_eV"] - rt["bands_eV"]).max()))
+        gaps.append(abs((eig[half].min() - vbm) - r["band_gap_eV"]))
+        assert r["k_dist"].shape == (nk,) and abs(r["k_dist"][-1] - r["k_node"][-1]) < 1e-12 and r["bands_eV"][half - 1].max() == 0.0
+    return {"bands_rel_err": worst, "gap_abs_err_eV": max(gaps), "crystals": len(res)}

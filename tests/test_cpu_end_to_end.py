@@ -131,6 +131,12 @@ def test_head_bands_with_zero_point_shift_on_cpu(cpu_backend, tag):
     assert r["shift_matters"] > 1e-3 and r["H_shift_matters"] > 1e-3, r       # the fixture separates the right order from the wrong ones
 
 
+def test_band_cal_on_cpu(cpu_backend):
+    """band structure along a k-path from saved Hamiltonian rows (DFT_interfaces/openmx/band_cal.py, non-SOC branch) vs the script's own dense loop"""
+    r = G.check_band_cal("cpu")
+    assert r["bands_rel_err"] < 1e-4 and r["gap_abs_err_eV"] < 1e-2 and r["crystals"] == 2, r
+
+
 def test_training_loop_on_cpu(cpu_backend):
     """a few optimiser steps of the whole model (training_step -> Adam -> device-side refresh of the packed weights at the next forward):
     the teacher-student loss falls monotonically"""

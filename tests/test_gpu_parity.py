@@ -438,6 +438,14 @@ def test_head_bands_with_zero_point_shift(tag):
     assert r["shift_matters"] > 1e-3 and r["H_shift_matters"] > 1e-3
 
 
+def test_band_cal_along_a_k_path():
+    """hamgnn_amd.band_cal.band_structure (DFT_interfaces/openmx/band_cal.py:64-108, 296-392: saved prediction rows -> bands along a k-path, eV
+    relative to the valence-band maximum) on hg_hk_assemble + hipSOLVER vs the script's dense numpy / scipy loop in fp64"""
+    r = G.check_band_cal()
+    print(r)
+    assert r["bands_rel_err"] < 1e-4 and r["gap_abs_err_eV"] < 1e-2 and r["crystals"] == 2
+
+
 def test_attribute_style_graph_object():
     """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
     r = G.check_attribute_style_graph()

@@ -8,7 +8,7 @@ What is independent here:
     in SURVEY.md 8c-A, with sympy exact numbers (I, sqrt(2)) rather than torch complex tensors;
   * the real spherical harmonics to l = 6 incl. every sign, from sympy's Znm (exact expressions in theta, phi);
   * the explicit l = 2, 3, 4 polynomials that e3nn's generated `_spherical_harmonics` code uses, typed in as literals (23 of the 24
-    l <= 4 components; one l = 4 line is left out, see below).
+    l <= 4 components were recalled in round 2; the ninth l = 4 line is derived from the 3j slice, see below).
 What is still recall (no e3nn source or wheel exists in this container): that the Q_l / (-i)^l convention, the (y, z, x) axis order
 and the literal polynomials are e3nn's.  The three statements are mutually consistent (checked below: the literals equal the
 CG-recursion harmonics, which equal sympy's Znm up to ONE closed-form sign rule), which a wrong recollection of any single one
@@ -152,7 +152,9 @@ def _e3nn_literal_polynomials(x, y, z):
               + (3 / 56) * s(14) * sh_3_6 * x)
     sh_4_3 = -3 / 56 * s(42) * sh_3_1 * z + (3 / 28) * s(105) * sh_3_2 * y + (3 / 28) * s(70) * sh_3_3 * x + (3 / 56) * s(42) * sh_3_5 * x
     sh_4_4 = -3 / 28 * s(42) * sh_3_2 * x + (3 / 7) * s(7) * sh_3_3 * y - 3 / 28 * s(42) * sh_3_4 * z
-    sh_4_5 = None      # not pinned: the builder's recollection of this one line failed the consistency check (one sign), so it is left out
+    # (round 3) the line that round 2 left out: its four coefficients are DERIVED below (test_l4_literals_follow_from_the_3j_slice) from the
+    # sympy-pinned w3j(4, 1, 3) slice with the same positive constant as the other eight components, not recalled
+    sh_4_5 = -3 / 56 * s(42) * sh_3_1 * x + (3 / 28) * s(70) * sh_3_3 * z + (3 / 28) * s(105) * sh_3_4 * y - 3 / 56 * s(42) * sh_3_5 * z
     sh_4_6 = (-3 / 56 * s(14) * sh_3_0 * x - 3 / 56 * s(210) * sh_3_2 * x + (3 / 56) * s(210) * sh_3_4 * z + (3 / 14) * s(21) * sh_3_5 * y
               - 3 / 56 * s(14) * sh_3_6 * z)
     sh_4_7 = -3 / 8 * s(6) * sh_3_1 * x + (3 / 8) * s(6) * sh_3_5 * z + (3 / 4) * sh_3_6 * y
@@ -173,6 +175,23 @@ def test_e3nn_published_closed_forms_l2_l3_l4():
             if lit[l][c] is not None:
                 assert np.abs(Y[:, i] - lit[l][c]).max() < 1e-12, (l, c)
             i += 1
+
+
+def test_l4_literals_follow_from_the_3j_slice(w3j_table):
+    """e3nn generates its l = 4 lines as  Y^4_i = c sum_{jk} w3j(4, 1, 3)[i, j, k] Y^1_j Y^3_k  with ONE positive constant c: the
+    coefficient of (axis j) x sh_3_k in the literal of component i must therefore be c sqrt(3) w3j(4, 1, 3)[i, j, k] -- for all nine
+    components, the one round 2 could not recall included -- with the 3j slice taken from the sympy-pinned table"""
+    W = w3j_table[(4, 1, 3)]                                               # [9, 3, 7], exact (sympy) values
+    rng = np.random.default_rng(7)
+    v = rng.normal(size=(40, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    lit = _e3nn_literal_polynomials(v[:, 0], v[:, 1], v[:, 2])
+    Y1, Y3 = np.stack(lit[1], 1), np.stack(lit[3], 1)
+    T = np.einsum("ijk,nj,nk->ni", W, Y1, Y3)
+    Y4 = np.stack(lit[4], 1)
+    c = Y4 / T
+    assert np.all(c > 0) and np.abs(c - c.mean()).max() < 1e-9 * c.mean(), c.mean(0)
+    assert abs(c.mean() - 1.5 * math.sqrt(3)) < 1e-9                       # = sqrt(27) / 2: what makes |Y^4|^2 = 9 on the unit sphere
 
 
 # ------------------------------------------------------------------------------------------------ the Gaunt link between the two
