@@ -5,8 +5,9 @@ Per crystal: k-points (random, or a path through given nodes in reduced coordina
 HIP kernel `hg_hk_assemble` (phase-factor sums over the edges of every atom pair, fixed order) -> generalized eigenproblem
 H(k) psi = E S(k) psi through the Cholesky factor of S(k) exactly as the reference does it, on hipSOLVER via `torch.linalg`
 (cholesky / inv / eigh on complex64: library calls, not kernels of this repository) -> band energies, wavefunctions, band gap,
-optional band window.  Non-SOC branch with the reference overlaps `Son / Soff` (ham_only=True); the SOC / overlap-network variants
-(:1368-1673, :1998-2286) are not built."""
+optional band window.  The spin-free branch with the reference overlaps `Son / Soff` (also what the reference runs with ham_only=False: its
+overlap-network variant :1368-1673 factorises the REFERENCE overlap too and is only reached with export_reciprocal_values) and the spinor
+branch `band_energies_soc` (:1998-2286)."""
 from __future__ import annotations
 
 import math
@@ -174,6 +175,58 @@ def band_energies(head, onsite_hamiltonian, offsite_hamiltonian, data, k_vecs: O
         waves.append(evecs.reshape(-1))
         hsyms.append(Ht.reshape(-1))
     return torch.cat(energies, 0), torch.cat(waves, 0), torch.cat(gaps, 0), torch.cat(hsyms, 0)
+
+
+def band_energies_soc(head, real_onsite, imag_onsite, real_offsite, imag_offsite, data, k_vecs: Optional[torch.Tensor] = None):
+    """calculate_band_energies_with_spin_orbit_coupling of the reference (hamgnn_output.py:1998-2286): spinor Hamiltonian rows
+    [., (2 nao)^2] (real and imaginary part, on-site and off-site) -> (band_energy [sum_c bands_c, num_k], wavefunction (flattened)).
+    Per crystal the four spin blocks (uu, ud, du, dd) of H(k) are phase-factor sums like the spin-free case -- each block = assembly of its
+    real part + i x assembly of its imaginary part (the assembly is linear), eight launches of hg_hk_assemble -- stacked to [2 M, 2 M];
+    S(k) is the spin-free overlap on both spin diagonals (kron(1_2, S(k)), :2165-2167); generalised eigenproblem through the Cholesky
+    factor of S(k) (:2236-2252, hipSOLVER through torch.linalg); band window :2254-2263 (dict: leading bands; int: +- that many bands
+    around the number of valence electrons)."""
+    nao = head.nao_max
+    dev = real_onsite.device
+    k_vecs = (gget(data, "k_vecs") if k_vecs is None else k_vecs)
+    if k_vecs is None:
+        raise ValueError("band_energies_soc: no k-vectors (data.k_vecs)")
+    k_vecs = k_vecs.to(dev)
+    z = data.z
+    orank_all = head._orank.to(dev)[z]
+    val = head._num_valence.to(dev)[z].to(torch.float64)
+    Son, Soff = data.Son.contiguous().float(), data.Soff.contiguous().float()
+    blk = lambda t, a, b: t.reshape(-1, 2, nao, 2, nao)[:, a, :, b, :].reshape(-1, nao * nao).contiguous().float()
+    energies, waves = [], []
+    for c, (n0, n, e0, e) in enumerate(_crystal_slices(data)):
+        Sk, M = assemble_k(Son, Soff, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        rows = []
+        for a in (0, 1):
+            cols = []
+            for b in (0, 1):
+                Hr, _ = assemble_k(blk(real_onsite, a, b), blk(real_offsite, a, b), data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+                Hi, _ = assemble_k(blk(imag_onsite, a, b), blk(imag_offsite, a, b), data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+                cols.append(Hr + 1j * Hi)
+            rows.append(torch.cat(cols, -1))
+        Hk = torch.cat(rows, -2)                               # [nk, 2 M, 2 M]
+        Ssoc = torch.zeros_like(Hk)
+        Ssoc[:, :M, :M] = Sk
+        Ssoc[:, M:, M:] = Sk
+        L = torch.linalg.cholesky(Ssoc)
+        Linv = torch.linalg.inv(L)
+        LHinv = torch.linalg.inv(L.conj().transpose(-1, -2))
+        evals, evecs = torch.linalg.eigh(torch.bmm(torch.bmm(Linv, Hk), LHinv))
+        evecs = torch.bmm(LHinv, evecs)
+        bnc = head.band_num_control
+        if bnc is not None:
+            if isinstance(bnc, dict):
+                nb = int(sum(int(bnc.get(int(zz), bnc.get(str(int(zz)), 0))) for zz in z[n0:n0 + n].tolist()))
+                evals, evecs = evals[:, :nb], evecs[:, :nb, :]
+            else:
+                nval = int(val[n0:n0 + n].sum())
+                evals, evecs = evals[:, nval - int(bnc):nval + int(bnc)], evecs[:, nval - int(bnc):nval + int(bnc), :]
+        energies.append(evals.transpose(-1, -2))
+        waves.append(evecs.reshape(-1))
+    return torch.cat(energies, 0), torch.cat(waves, 0)
 
 
 def band_energy_backward(head, onsite_hamiltonian, offsite_hamiltonian, data, cotangent, k_vecs: Optional[torch.Tensor] = None):

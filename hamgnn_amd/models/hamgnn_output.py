@@ -3,9 +3,8 @@
 linear_transform}, ..._ksi_network, ..._overlap_network) and result dict.  In scope this round: the non-SOC branch
 (:3772-3799) incl. overlap networks, SOC/so3 (:3026-3144), SOC/su2 (:3146-3178; E3TensorDecomposition.get_H,
 hamgnn/nn/tensor_decomposition.py:553-603), masks, symmetrisation, H0, per-crystal concatenation, sparsity ratio.
-The k-space step `calculate_band_energy` is built for the non-SOC branch (hamgnn_amd/kspace.py).  Out of scope (raise NotImplementedError):
-SOC / overlap-network band variants, spin-constrained / collinear branches, forces
-(SURVEY.md section 2 / 8f)."""
+The k-space step `calculate_band_energy` is built for the spin-free and the spin-orbit branches (hamgnn_amd/kspace.py).
+Out of scope (raise NotImplementedError): spin-constrained / collinear branches, export_reciprocal_values, forces."""
 from __future__ import annotations
 
 import numpy as np
@@ -38,8 +37,6 @@ class HamGNNPlusPlusOut(nn.Module):
         self.calculate_sparsity = calculate_sparsity
         self.get_nonzero_mask_tensor = get_nonzero_mask_tensor
         self.calculate_band_energy, self.num_k, self.k_path, self.band_num_control = calculate_band_energy, num_k, k_path, band_num_control
-        if calculate_band_energy and (soc_switch or not ham_only):
-            raise NotImplementedError("calculate_band_energy is built for the non-SOC branch with reference overlaps (ham_only=True)")
         for flag, name in ((return_forces, "return_forces"),
                            (spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
                            (export_reciprocal_values, "export_reciprocal_values"),
@@ -149,6 +146,23 @@ class HamGNNPlusPlusOut(nn.Module):
         sizes = [v for pair in zip(*get_topology(data).crystal_sizes(data)) for v in pair]
         parts = torch.split(H, sizes)
         return torch.cat(parts[0::2], 0), torch.cat(parts[1::2], 0)
+
+    def _soc_bands(self, data, on_r, on_i, off_r, off_i, dev):
+        """calculate_band_energy of the spin-orbit branches (hamgnn_output.py:3629-3662): k-vectors (a path when k_path is given, else
+        random), bands of the prediction and -- attached to the batch -- of the target blocks; with zero_point_shift the predicted bands
+        are aligned by their mean (:3920-3922)"""
+        if not self.calculate_band_energy:
+            return None, None
+        from .. import kspace
+        f32c = lambda t: t.contiguous().float()
+        data["k_vecs"] = kspace.make_k_vectors(self.k_path if self.k_path is not None else None, self.num_k, data.cell).to(dev)
+        be, wf = kspace.band_energies_soc(self, on_r, on_i, off_r, off_i, data)
+        with torch.no_grad():
+            tb, tw = kspace.band_energies_soc(self, f32c(data.Hon), f32c(data.iHon), f32c(data.Hoff), f32c(data.iHoff), data)
+        data["band_energy"], data["wavefunction"] = tb, tw
+        if self.zero_point_shift:
+            be = be - torch.mean(be - tb)
+        return be, wf
 
     def _apply_zero_point_shift(self, data, H, edge_counts, soc):
         """hamgnn_output.py:3971-3981 / :3892-3913; targets as the reference prepares them (:2975-2978, :3617-3618)."""
@@ -416,10 +430,11 @@ class HamGNNPlusPlusOut(nn.Module):
             off_r, off_i = fin(raw_off, 0, inv, H0[1], geo.src, geo.dst), fin(raw_off, 1, inv, H0[3], geo.src, geo.dst)
             Hr = self._cat_by_crystal(data, on_r, off_r, edge_counts)
             Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
+            be, wf = self._soc_bands(data, on_r, on_i, off_r, off_i, dev)    # from the blocks BEFORE the shift (hamgnn_output.py:3642-3662)
             if self.zero_point_shift:
                 Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
-            result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
-                           "wavefunction": None})
+            result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": be,
+                           "wavefunction": wf})
             if self.get_nonzero_mask_tensor:
                 result["mask_real_imag"] = self.build_interaction_masks(data, edge_counts, soc=True)
             if self.calculate_sparsity:
@@ -438,10 +453,11 @@ class HamGNNPlusPlusOut(nn.Module):
             off_r, off_i = ops.soc_assemble(off, ksi_off, f32c(data.Loff), inv, H0[1], H0[3], n, self.symmetrize, self.add_H_nonsoc)
             Hr = self._cat_by_crystal(data, on_r, off_r, edge_counts)
             Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
+            be, wf = self._soc_bands(data, on_r, on_i, off_r, off_i, dev)    # from the blocks BEFORE the shift (hamgnn_output.py:3642-3662)
             if self.zero_point_shift:
                 Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
-            result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": None,
-                           "wavefunction": None})
+            result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": be,
+                           "wavefunction": wf})
             if self.get_nonzero_mask_tensor:
                 result["mask_real_imag"] = self.build_interaction_masks(data, edge_counts, soc=True)
             if self.calculate_sparsity:

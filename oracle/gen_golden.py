@@ -607,6 +607,43 @@ def main():
     _save("band_energies_openmx_13", kpath=dict(nodes=np.asarray(nodes), nk=np.asarray(23), lat=lat0, k_vec=kv_ref, lat_per_inv=lpi_ref), graph={k: (Gb[k].float() if Gb[k].is_floating_point() else Gb[k]) for k in keys}, inputs=dict(Hon=Hon.float(), Hoff=Hoff.float()),
           outputs=dict(band_energy=be_r, band_gap=gap_r, band_energy_window3=be_w3, band_cotangent=cot, g_Hon=grads_k[0][0], g_Hoff=grads_k[0][1]))
 
+    # ---- 6c'. the spin-orbit k-space step: calculate_band_energies_with_spin_orbit_coupling (hamgnn_output.py:1998-2286) on the same batch ----
+    gens = torch.Generator().manual_seed(7731)                 # own stream: the sections after this one keep theirs
+    def herm_soc(n_on):
+        A = 0.3 * (torch.randn(n_on, 2 * nao, 2 * nao, generator=gens, dtype=torch.float64) + 1j * torch.randn(n_on, 2 * nao, 2 * nao, generator=gens, dtype=torch.float64))
+        on = 0.5 * (A + A.conj().transpose(1, 2))
+        Bc = 0.3 * (torch.randn(Eb, 2 * nao, 2 * nao, generator=gens, dtype=torch.float64) + 1j * torch.randn(Eb, 2 * nao, 2 * nao, generator=gens, dtype=torch.float64))
+        off = 0.5 * (Bc + Bc[inv_g].conj().transpose(1, 2))
+        return (f32(on.real.reshape(n_on, -1)), f32(on.imag.reshape(n_on, -1)), f32(off.real.reshape(Eb, -1)), f32(off.imag.reshape(Eb, -1)))
+    ron, ion, roff, ioff = herm_soc(Nb)
+    refs = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True,
+                                     add_H0=True, soc_switch=True, soc_basis="so3", calculate_band_energy=False, calculate_sparsity=False)
+    refs.num_k = 5
+    mines = R.HamGNNPlusPlusOut(mini, mini, nao_max=nao, ham_type="openmx", soc_switch=True)
+    # the reference's last line (torch.cat of the [nk, bands, 2 norb] eigenvectors over the crystals, :2282) needs equal orbital counts, so a
+    # heterogeneous batch is run through it crystal by crystal; the restatement (which flattens per crystal first) takes the batch
+    n_cr = Gb["node_counts"].tolist()
+    e_cr = torch.bincount(Gb["batch"][Gb["edge_index"][0]], minlength=2).tolist()
+    def crystal(c):
+        n0, e0 = sum(n_cr[:c]), sum(e_cr[:c])
+        sn, se = slice(n0, n0 + n_cr[c]), slice(e0, e0 + e_cr[c])
+        sub = Graph({k: Gb[k][sn] for k in ("z", "pos", "Son")})
+        sub.update({k: Gb[k][se] for k in ("nbr_shift", "cell_shift", "Soff")})
+        sub.update(edge_index=Gb["edge_index"][:, se] - n0, batch=torch.zeros(n_cr[c], dtype=torch.long), node_counts=torch.tensor([n_cr[c]]),
+                   k_vecs=Gb["k_vecs"][c:c + 1], cell=Gb["cell"][c:c + 1], Hon=ron[sn])   # Hon: read for its dtype only (:2165)
+        return sub, (ron[sn], ion[sn], roff[se], ioff[se])
+    outs = {}
+    for bnc, tag in ((None, "all"), (3, "window3")):
+        refs.band_num_control = mines.band_num_control = bnc
+        be_s = torch.cat([refs.calculate_band_energies_with_spin_orbit_coupling(*crystal(c)[1], crystal(c)[0])[0] for c in range(2)], 0)
+        be_ms, wf_ms = mines.calculate_band_energies_with_spin_orbit_coupling(ron, ion, roff, ioff, Gb)
+        _check(be_ms, be_s, f"calculate_band_energies_with_spin_orbit_coupling band_energy ({tag})", tol=1e-9)
+        outs[tag] = be_s
+    _save("band_energies_soc_openmx_13", graph={k: (Gb[k].float() if Gb[k].is_floating_point() else Gb[k]) for k in
+                                                 ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts", "Son", "Soff", "k_vecs")},
+          inputs=dict(Hon=ron.float(), iHon=ion.float(), Hoff=roff.float(), iHoff=ioff.float()),
+          outputs=dict(band_energy=outs["all"], band_energy_window3=outs["window3"]))
+
     # ---- 6d. the head's forward with calculate_band_energy AND zero_point_shift (hamgnn_output.py:3802-3880 precede :3971-3985): the bands come
     # from the UNSHIFTED blocks and are then aligned by their mean; one fixture for a 2-crystal batch, one for a single crystal
     for tag, graphs in (("batch", [g1, g2]), ("single", [g2])):

@@ -882,3 +882,71 @@ def calculate_band_energies(self, onsite_hamiltonian, offsite_hamiltonian, data)
 
 
 HamGNNPlusPlusOut.calculate_band_energies = calculate_band_energies
+
+
+def calculate_band_energies_with_spin_orbit_coupling(self, real_onsite, imag_onsite, real_offsite, imag_offsite, data):
+    """hamgnn/models/hamgnn_output.py:1998-2286: spinor blocks [., (2 nao)^2] -> (band_energy, wavefunction).  Same steps: per crystal the
+    overlap S(k) = on-site + sum over edges of exp(2 pi i k . nbr_shift) S_off (the reference sums per unique cell shift first, :2131-2150:
+    the same sum), masked to the atoms' orbitals, kron(1_2, S(k)) (:2165-2167); the four spin blocks of H(k) likewise from
+    real + i imag (:2170-2233); Cholesky / eigh (:2236-2252); band window (:2254-2263: dict -> leading bands, int -> +- around the number
+    of valence electrons)."""
+    nao = self.nao_max
+    src, dst = data.edge_index
+    k_vecs = data.k_vecs
+    num_k = k_vecs.shape[1]
+    mask_tab = torch.zeros(99, nao)
+    for Z, idx in self.basis_def.items():
+        mask_tab[Z][idx] = 1
+    om = mask_tab[data.z]
+    nval = torch.zeros(99)
+    for Z, c in self.num_valence.items():
+        nval[Z] = c
+    node_counts = data.node_counts.tolist()
+    n_off = np.cumsum([0] + node_counts)
+    edge_counts = torch.bincount(data.batch[src], minlength=len(node_counts)).tolist()
+    e_off = np.cumsum([0] + edge_counts)
+    rdt = real_onsite.dtype
+    cdt = torch.complex128 if rdt == torch.float64 else torch.complex64
+    spin = lambda t: t.reshape(-1, 2, nao, 2, nao)
+    bands, waves = [], []
+    for c, n in enumerate(node_counts):
+        sl_n, sl_e = slice(n_off[c], n_off[c + 1]), slice(e_off[c], e_off[c + 1])
+        kp = k_vecs[c].to(rdt)
+        phase = torch.exp(2j * math.pi * (data.nbr_shift[sl_e][:, None, :].to(rdt) * kp[None, :, :]).sum(-1)).to(cdt)        # [e, nk]
+        si, ti = src[sl_e] - n_off[c], dst[sl_e] - n_off[c]
+        m = om[sl_n].reshape(-1)
+        keep = m[:, None] * m[None, :] > 0
+        norb = int(m.sum())
+        ar = torch.arange(n)
+
+        def to_k(on_blk, off_blk):                             # [n, nao, nao], [e, nao, nao] (complex) -> [nk, norb, norb]
+            out = torch.zeros(num_k, n, n, nao, nao, dtype=cdt)
+            out[:, ar, ar] += on_blk[None].to(cdt)
+            for k in range(num_k):
+                out[k] = torch.index_put(out[k], (si, ti), phase[:, k][:, None, None] * off_blk.to(cdt), accumulate=True)
+            out = out.swapaxes(2, 3).reshape(num_k, n * nao, n * nao)
+            return out[:, keep].reshape(num_k, norb, norb)
+        Sk = to_k(data.Son[sl_n].reshape(-1, nao, nao), data.Soff[sl_e].reshape(-1, nao, nao))
+        Ssoc = torch.kron(torch.eye(2, dtype=cdt), Sk)
+        ron, ion, roff, ioff = spin(real_onsite[sl_n]), spin(imag_onsite[sl_n]), spin(real_offsite[sl_e]), spin(imag_offsite[sl_e])
+        blocks = [[to_k(ron[:, a, :, b, :] + 1j * ion[:, a, :, b, :], roff[:, a, :, b, :] + 1j * ioff[:, a, :, b, :]) for b in (0, 1)] for a in (0, 1)]
+        Hk = torch.cat([torch.cat(blocks[0], -1), torch.cat(blocks[1], -1)], -2)
+        L = torch.linalg.cholesky(Ssoc)
+        LH = L.conj().transpose(-1, -2)
+        Linv, LHinv = torch.linalg.inv(L), torch.linalg.inv(LH)
+        ev, evec = torch.linalg.eigh(torch.bmm(torch.bmm(Linv, Hk), LHinv))
+        evec = torch.bmm(LHinv, evec)
+        bnc = self.band_num_control
+        if bnc is not None:
+            if isinstance(bnc, dict):
+                nb = int(sum(bnc[int(zz)] for zz in data.z[sl_n].tolist()))
+                ev, evec = ev[:, :nb], evec[:, :nb, :]
+            else:
+                nv = int(nval[data.z[sl_n]].sum())
+                ev, evec = ev[:, nv - bnc:nv + bnc], evec[:, nv - bnc:nv + bnc, :]
+        bands.append(ev.transpose(-1, -2))
+        waves.append(evec.reshape(-1))
+    return torch.cat(bands, 0), torch.cat(waves, 0)
+
+
+HamGNNPlusPlusOut.calculate_band_energies_with_spin_orbit_coupling = calculate_band_energies_with_spin_orbit_coupling

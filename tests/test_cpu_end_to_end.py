@@ -131,6 +131,20 @@ def test_head_bands_with_zero_point_shift_on_cpu(cpu_backend, tag):
     assert r["shift_matters"] > 1e-3 and r["H_shift_matters"] > 1e-3, r       # the fixture separates the right order from the wrong ones
 
 
+def test_band_energies_on_cpu(cpu_backend):
+    """k-space step + the head's forward with calculate_band_energy (ham_only True and False) through the host code"""
+    r = G.check_band_energies("cpu")
+    assert r["band_energy_err"] < 1e-4 and r["band_gap_err"] < 1e-4 and r["window_err"] < 1e-4
+    assert r["forward_ok"] and r["kpath_ok"] and r["with_overlap_ok"] and r["targets_consistent"] < 1e-5
+
+
+def test_band_energies_spin_orbit_on_cpu(cpu_backend):
+    """the spin-orbit k-space step and the SOC head's forward with calculate_band_energy=True through the host code (stand-in assembly)"""
+    r = G.check_band_energies_soc("cpu")
+    assert r["bands"] == r["ref_bands"] and r["band_energy_err"] < 1e-4 and r["window_err"] < 1e-4
+    assert r["forward_ok"] and r["targets_consistent"] < 1e-5
+
+
 def test_band_cal_on_cpu(cpu_backend):
     """band structure along a k-path from saved Hamiltonian rows (DFT_interfaces/openmx/band_cal.py, non-SOC branch) vs the script's own dense loop"""
     r = G.check_band_cal("cpu")

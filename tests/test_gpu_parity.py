@@ -425,7 +425,16 @@ def test_band_energies_k_space_step():
     r = G.check_band_energies()
     print(r)
     assert r["band_energy_err"] < 1e-4 and r["band_gap_err"] < 1e-4 and r["window_err"] < 1e-4
-    assert r["forward_ok"] and r["kpath_ok"] and r["targets_consistent"] < 1e-5
+    assert r["forward_ok"] and r["kpath_ok"] and r["with_overlap_ok"] and r["targets_consistent"] < 1e-5
+
+
+def test_band_energies_spin_orbit_k_space_step():
+    """calculate_band_energy=True of the spin-orbit branches (hamgnn_output.py:1998-2286): four spin blocks of H(k) from the
+    real / imaginary rows, kron(1_2, S(k)), eigensolver; vs the reference's output"""
+    r = G.check_band_energies_soc()
+    print(r)
+    assert r["bands"] == r["ref_bands"] and r["band_energy_err"] < 1e-4 and r["window_err"] < 1e-4
+    assert r["forward_ok"] and r["targets_consistent"] < 1e-5
 
 
 @pytest.mark.parametrize("tag", ["batch", "single"])
