@@ -284,6 +284,53 @@ def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor],
     return (out, gx) if want_gx else out
 
 
+def tp_weight_grads_fused(wg: TPWeightGrad, wf, run_wgrad, srcs: Sequence[torch.Tensor], g, rbf, act_cst: float, chunk: int = 1 << 20, hidden=None):
+    """the same gradients as tp_weight_grads through the FUSED kernel (csrc/tp_wgrad.hip, plan.WgFused `wf`): nothing per edge is
+    materialised except gs (the gradient with respect to the last radial layer's output).  run_wgrad(srcs_by_slot, g, h_node, h_edge) ->
+    (acc [splits, acc_floats], [gs per branch]) -- ops.tp_wgrad on the GPU, the numpy twin (tests/emu.py:run_wgrad_fused) in the CPU suite.
+    srcs: planar edge-frame source rows by slot; hidden: optional {branch: hidden rows [E, H]} (else recomputed from rbf)."""
+    dev, dt = g.device, g.dtype
+    E = g.shape[0]
+    sd, H = wg.sd, wg.H
+    gen, gkeys = {}, {}
+    for b in wg.branches:
+        pre = b["keys"]["gen"]
+        gkeys[b["name"]] = sorted(k for k in sd if k.startswith(pre + ".layer") and k.endswith(".weight"))
+        gen[b["name"]] = [wg.param(k, dev, dt).clone().requires_grad_() for k in gkeys[b["name"]]]
+    names = [b["name"] for b in wg.branches]
+    gW3 = {name: {} for name in gen}
+    gh_hidden = {name: torch.zeros(E, H, device=dev, dtype=dt) for name in gen}
+    gW3_last = {name: torch.zeros_like(gen[name][-1]) for name in gen}
+    flat = None
+    for e0 in range(0, E, chunk):
+        sl = slice(e0, min(E, e0 + chunk))
+        with torch.no_grad():
+            h = {name: (hidden[name][sl, :H] if hidden is not None else radial_mlp(rbf[sl], [w.detach() for w in gen[name][:-1]], act_cst)) for name in gen}
+            by_mlp = {b["mlp"]: h[b["name"]] for b in wg.branches}
+            acc, gs = run_wgrad([t[sl] if t is not None else None for t in srcs], g[sl], by_mlp[0], by_mlp.get(1))
+            part = acc.sum(0)
+            flat = part if flat is None else flat + part
+            for bi, name in enumerate(names):
+                gW3_last[name] += h[name].t() @ gs[bi] / math.sqrt(H)
+                gh_hidden[name][sl] = gs[bi] @ (gen[name][-1].detach().t() / math.sqrt(H))
+    for name in gen:                                           # hidden layers of the radial MLPs: two dense layers per edge, torch.autograd
+        hid, ks = gen[name][:-1], gkeys[name]
+        if hid:
+            with torch.enable_grad():
+                hfull = radial_mlp(rbf, hid, act_cst)
+                grads = torch.autograd.grad(hfull, hid, grad_outputs=gh_hidden[name], allow_unused=True)
+            for k, w, gk in zip(ks[:-1], hid, grads):
+                gW3[name][k] = gk if gk is not None else torch.zeros_like(w)
+        gW3[name][ks[-1]] = gW3_last[name]
+    acc_out = {}
+    as_t = lambda a, d: a if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), device=dev, dtype=d)
+    for bi, name in enumerate(names):                          # fixed-order gather of the (<= 4) edge-tile copies of every parameter's slot
+        tp = flat[as_t(wf.tp_pos[bi], torch.long)].sum(1) * as_t(wf.tp_scale[bi], dt)
+        acc_out[f"{name}_tp"] = torch.cat([tp, tp.new_zeros(1)])
+        acc_out[f"{name}_L"] = torch.cat([flat[as_t(wf.l_pos[bi], torch.long)].sum(1), flat.new_zeros(1)])
+    return wg.finish(acc_out, gW3, dev, dt)
+
+
 def block_weight_grads(wg: MessagePackWeightGrad, run_program, xs, xd, f, g, rbf, act_cst: float, chunk: int = 65536) -> Dict[str, torch.Tensor]:
     """MessagePackBlock: sources = (sender rows, receiver rows, edge rows), all planar in the edge frame"""
     return tp_weight_grads(wg, run_program, [xs, xd, f], g, rbf, act_cst, chunk)

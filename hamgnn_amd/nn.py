@@ -203,6 +203,7 @@ class MessagePackBlock(nn.Module):
         self._packers = getattr(self, "_packers", None) or {}                     # structural: survive recompiles of the same block
         self._dp_adj = None                                    # the data-gradient program is packed from the same weights
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
+        self._wgrad_fused = None                               # (tables hold the weights: rebuilt on first use)
         if self.lite_mode:
             prog = P.build_message_pack_program_lite(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
             if skip_weight is not None:                        # PairInteractionBlock skip o3.Linear: must come AFTER the combine post-op
@@ -275,9 +276,15 @@ class MessagePackBlock(nn.Module):
             update(self._dp_adj, ("adj",), lambda d, sk: P.build_message_pack_adjoint_program(d, *args).weights, 0)
         if getattr(self, "_wgrad", None) is not None:
             wg, dpA, dpB = self._wgrad
-            update(dpA, ("wgA",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[0].weights, 0)
-            update(dpB, ("wgB",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[1].weights, 0)
+            if dpA is not None:
+                update(dpA, ("wgA",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[0].weights, 0)
+                update(dpB, ("wgB",), lambda d, sk: P.build_message_pack_wgrad_programs(d, *args)[1].weights, 0)
             wg.params_dev = params                             # the radial MLP / Ls / Lo values that the reductions read: straight from the device
+            dwf = getattr(self, "_wgrad_fused", None)
+            if dwf:
+                irr = (self.irreps_node, self.irreps_edge)
+                fused = lambda d, sk: P.build_tp_wgrad_fused(P.message_pack_wgrad_branches(d, *irr), self.irreps_sh, self.irreps_out, dwf.wf.hidden).weights
+                dwf.weights.copy_(packer(("wgF",), fused, 0).apply({k: v for k, v in src.items() if k != "skip"}))
         dev = self._dp.weights.device
         self._hn = self.node_weight_generator.hidden_layers(dev)
         self._he = self.edge_weight_generator.hidden_layers(dev)
@@ -350,14 +357,38 @@ class MessagePackBlock(nn.Module):
             wg = BM.MessagePackWeightGrad(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
             wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
             wg.params_dev = {k: v.detach() for k, v in self.state_dict().items()}
-            self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
+            self._wgrad = [wg, None, None]
         wg, dpA, dpB = self._wgrad
         xs, xd = ops.rotate_gather(node_s, geo.src, geo, rot_tab, x2=node_d, idx2=geo.dst)
         if out_is_global:
             g = ops.rotate_gather(grad_out, gather, geo, self._rot_tab_out(dev))
         else:
             g = grad_out if gather is None else grad_out[gather].contiguous()
-        return BM.block_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), xs, xd, f_rot, g, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk)
+        cst = float(P.ACT_CONSTS[P.ACT_SILU])
+        dwf = self._wgrad_fused_for(wg, dev)
+        if dwf is not None:                                    # fused kernel (csrc/tp_wgrad.hip): nothing per edge is materialised but gs
+            hidden = {"node": ops.radial_hidden_cached(geo, self._hn, cst), "edge": ops.radial_hidden_cached(geo, self._he, cst)}
+            run = lambda srcs, g_, hn, he: ops.tp_wgrad(dwf, srcs, g_, hn, he)
+            return BM.tp_weight_grads_fused(wg, dwf.wf, run, [xs, xd, f_rot], g, geo.rbf, cst, hidden=hidden)
+        if dpA is None:                                        # materialisation route: the two row programs on the segment-stationary kernel
+            dpA, dpB = ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg")
+            self._wgrad[1:] = [dpA, dpB]
+        return BM.block_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), xs, xd, f_rot, g, geo.rbf, cst, chunk=chunk)
+
+    def _wgrad_fused_for(self, wg, dev):
+        """the fused weight-gradient tables of this block on the device, or None (HG_WGRAD=rows, or no kernel instantiation for these irreps:
+        the materialisation route then)"""
+        if os.environ.get("HG_WGRAD", "fused") != "fused":
+            return None
+        cur = getattr(self, "_wgrad_fused", None)
+        if cur is None:
+            try:
+                wf = P.build_tp_wgrad_fused(wg.branches, self.irreps_sh, self.irreps_out, wg.H)
+                cur = ops.DeviceWgFused(wf, dev)
+            except NotImplementedError:
+                cur = False
+            self._wgrad_fused = cur
+        return cur or None
 
     def backward(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, gather=None, chunk: int = 65536):
         """data AND weight gradients of the block in one call: (g_src_rows, g_dst_rows, g_edge_rows, {parameter name: gradient}); arguments

@@ -322,6 +322,51 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     return out
 
 
+class DeviceWgFused:
+    """plan.WgFused uploaded to the GPU (fused weight-gradient kernel, csrc/tp_wgrad.hip)"""
+
+    def __init__(self, wf: "P.WgFused", device):
+        self.wf = wf
+        self.units = _dev(wf.units, device)
+        self.weights = _dev(wf.weights, device, torch.float32)
+        self.chtab = _dev(wf.chtab, device)
+        self.tp_pos = [None if t is None else torch.from_numpy(t).to(device) for t in wf.tp_pos]
+        self.tp_scale = [None if t is None else torch.from_numpy(np.asarray(t, dtype=np.float32)).to(device) for t in wf.tp_scale]
+        self.l_pos = [torch.from_numpy(t).to(device) for t in wf.l_pos]
+
+    def nsplit_for(self, rows: int) -> int:
+        """edge splits of a launch: enough workgroups to fill the chip several times over, at least a few iterations each"""
+        tiles = (rows + 15) // 16
+        return int(max(1, min(32, -(-1536 // int(self.units.shape[0])), tiles // 4)))
+
+
+def tp_wgrad(dwf: DeviceWgFused, srcs: Sequence[Optional[torch.Tensor]], g: torch.Tensor, h_node: torch.Tensor, h_edge: Optional[torch.Tensor],
+             nsplit: Optional[int] = None):
+    """one launch of the fused weight-gradient kernel over all rows of `g`: (acc [nsplit, acc_floats], [gs per branch [rows, n_channels]]).
+    srcs: edge-frame planar source rows by slot (None for slots the block does not use)."""
+    _require_gpu(g)
+    wf = dwf.wf
+    rows = int(g.shape[0])
+    S = int(nsplit or dwf.nsplit_for(rows))
+    acc = torch.zeros(S, wf.acc_floats, device=g.device, dtype=torch.float32)
+    gs = [torch.zeros(rows, n, device=g.device, dtype=torch.float32) for n in wf.nch]
+    n = len(srcs)
+    keep = [t.contiguous() if t is not None else None for t in srcs]
+    sp = (C.c_void_p * 4)(*([(t.data_ptr() if t is not None else 0) for t in keep] + [0] * (4 - n)))
+    ss = (C.c_int64 * 4)(*([(t.stride(0) if t is not None else 0) for t in keep] + [0] * (4 - n)))
+    g = g.contiguous()
+    h_node = h_node.contiguous()
+    h_edge = h_edge.contiguous() if h_edge is not None else None
+    assert h_node.shape[1] >= wf.hidden and (h_edge is None or h_edge.stride(0) == h_node.stride(0))
+    with torch.cuda.device(g.device):
+        check(lib().hg_tp_wgrad(sp, ss, i32(n), ptr(g), i64(g.stride(0)), ptr(h_node), C.c_void_p(h_edge.data_ptr() if h_edge is not None else 0),
+                                i64(h_node.stride(0)), i32(wf.hidden), ptr(gs[0]), i64(gs[0].stride(0)),
+                                C.c_void_p(gs[1].data_ptr() if len(gs) > 1 else 0), i64(gs[1].stride(0) if len(gs) > 1 else 0),
+                                ptr(acc), i64(wf.acc_floats), i32(S), ptr(dwf.units), i32(int(dwf.units.shape[0])), ptr(dwf.weights), ptr(dwf.chtab),
+                                i32(wf.lds_bytes), i64(rows), _stream()), "hg_tp_wgrad")
+    return acc, gs
+
+
 @_on_tensor_device
 def segment_sum(msg: torch.Tensor, rowptr: torch.Tensor, perm: torch.Tensor, N: int) -> torch.Tensor:
     Dp = msg.shape[1]

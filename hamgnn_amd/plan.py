@@ -1297,6 +1297,166 @@ def build_tp_wgrad_programs(branches, irreps_sh, irreps_out, H: int):
     return progs[0], progs[1], chunks
 
 
+# ------------------------------------------------------------------------------------------------ fused weight-gradient kernel (csrc/tp_wgrad.hip)
+WG_UNIT_I32 = 32            # ints per unit record, see build_tp_wgrad_fused
+WG_WAVES = 4
+WG_LDS_ROW_MAX = 640        # floats: 2 buffers x 16 rows x 640 x 4 B = 80 KB (two workgroups per CU)
+def WG_MAXT_OF_NC(nc):      # accumulator fragments of the kernel per source (tiles of 16 channels), by column count: csrc/tp_wgrad.hip WG_MAXT_OF
+    return 4 if nc <= 7 else (2 if nc == 9 else 1)
+
+
+def WG_PIECES_OF_NC(nc):    # float4 pieces a thread holds in flight while the next edge tile is staged: csrc/tp_wgrad.hip WG_PIECES_OF
+    return 10 if nc <= 9 else (6 if nc == 11 else 5)
+
+
+@dataclass
+class WgFused:
+    """Launch tables of the fused weight-gradient kernel for the weighted tensor-product branches of one block.
+    A UNIT = (super-path (i, k) of a branch, up to four 16-row tiles of its rows); a workgroup owns one unit and a range of edge tiles:
+    wave w works on row tile w % nrtp of edge tile w / nrtp of every iteration, the unit's accumulators stay in its registers:
+        g_W[u, row] += sum_{c, e} x[e, u, comp(c)] * (s cf (L g))[e, row, c]        (K = the 16 edges: the C fragment of the first-stage MFMAs IS the B operand)
+        g_L[w, row] += sum_{c, e} g[e, w, col(c)] * (s cf (W x))[e, row, c]
+        gs[e, ch(row)] = sum_c cf (W x) (L g)                                         (written per edge: last radial layer / hidden-layer gradients)
+    units [n, WG_UNIT_I32] int32:
+         0 nsrc   1 slot0   2 slot1   3 x_off (floats into a source row: first component of the span)   4 in_mulp   5 nc   6 par (1: column c reads
+         span component nc-1-c)   7 g_off   8 g_mulp   9 mlp (which hidden rows / which gs buffer)   10 nrt   11 nrtp (1|2|4)   12 ET (edge tiles per
+        iteration)   13 RS (LDS row stride, floats, == 4 mod 64)   14 LDS offset of source 1   15 of the gradient span   16 of the hidden row
+        17 weight offset (floats)   18 weight stride per row tile   19 accumulator offset (floats, per split)   20 accumulator stride per row tile
+        21 chtab offset (ints; 16 per row tile, -1 = padding row)   22 ntu (tiles of 16 input channels)   23 ntk (tiles of 16 output channels)
+        24 pieces per LDS row (RS / 4)   25 x pieces per source   26 g pieces   27 h pieces   28 cost (MFMAs per iteration)
+    weights per (unit, row tile): [W: nsrc x ceil(in_mulp/16) x 64 x 4][L: ceil(g_mulp/16) x 64 x 4][W3: H/16 x 64 x 4][cf: nc x 16], B-operand
+    fragments in natural-K order (lane (row, kk) holds M[row][4 (4 G + q) + kk], q = float4 component).
+    accumulators per (split, unit, edge-tile copy, row tile): [nsrc*ntu + ntk fragments][16 rows][16 channels]."""
+    units: np.ndarray
+    weights: np.ndarray
+    chtab: np.ndarray
+    acc_floats: int
+    hidden: int
+    branch_names: List[str]
+    nch: List[int]
+    tp_pos: List[Optional[np.ndarray]]      # per branch: [tp_size, 4] positions in the accumulator block (acc_floats = a zero slot), or None (uvu)
+    tp_scale: List[Optional[np.ndarray]]
+    l_pos: List[np.ndarray]                 # per branch: [ls_size, 4]
+    lds_bytes: int
+    mfma_per_tile: float = 0.0
+
+
+def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
+    """see WgFused; branches as build_tp_wgrad_programs (weighted branches only)"""
+    irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
+    gl = PlanarLayout(irreps_out)
+    if H % 16:
+        raise NotImplementedError("fused weight gradients: hidden width of the radial MLP must be a multiple of 16")
+    units, wparts, chparts = [], [], []
+    woff = accoff = choff_t = 0
+    tp_pos, tp_scale, l_pos, nchs = [], [], [], []
+    lds_max = 0
+    total_cost = 0.0
+    for bi, b in enumerate(branches):
+        if b["tp_w"] is None:
+            raise NotImplementedError("fused weight gradients: unweighted (uvu) branches carry no tensor-product weights")
+        lay, nsrc = b["lay"], b["nsrc"]
+        w3 = np.asarray(b["w3"], dtype=np.float64) / math.sqrt(H)
+        tp_size, ls_size = int(np.asarray(b["tp_w"]).size), int(np.asarray(b["ls_w"]).size)
+        tpp = [[] for _ in range(tp_size)]
+        tps = np.zeros(tp_size)
+        lpp = [[] for _ in range(ls_size)]
+        nchs.append(int(w3.shape[1]))
+        for sp in _tp_superpaths(nsrc, lay, irreps_sh, irreps_out, np.asarray(b["tp_w"]), w3, np.asarray(b["ls_w"]),
+                                 None if b["lo_w"] is None else np.asarray(b["lo_w"]), False):
+            i, k, mi, mk, mm, li, lk = sp["i"], sp["k"], sp["mi"], sp["mk"], sp["mm"], sp["li"], sp["lk"]
+            nc = 2 * mm + 1
+            in_mulp, g_mulp = lay.mulp[i], gl.mulp[k]
+            ntu, ntk = ceil_div(in_mulp, 16), ceil_div(g_mulp, 16)
+            if nc > 13 or max(ntu, ntk) > WG_MAXT_OF_NC(nc):
+                raise NotImplementedError("fused weight gradients: no kernel instantiation for this many channels / columns of a super-path")
+            max_pieces = WG_PIECES_OF_NC(nc)
+            xp, gp, hp = nc * in_mulp // 4, nc * g_mulp // 4, H // 4
+            used = 4 * (nsrc * xp + gp + hp)
+            RS = used + ((4 - used) % 64)                       # == 4 mod 64: conflict-free dword reads of 16 rows x 4 K-slots AND of 4 rows x 16 channels
+            if RS > WG_LDS_ROW_MAX or ceil_div(16 * RS // 4, 64 * WG_WAVES) > max_pieces:
+                raise NotImplementedError("fused weight gradients: a 16-edge operand tile does not fit the LDS budget")
+            T = ceil_div(sp["nmid"], 16)
+            nun = ceil_div(T, WG_WAVES)
+            t0 = 0
+            for q in range(nun):
+                nrt = T // nun + (1 if q < T % nun else 0)
+                nrtp = 1 if nrt == 1 else (2 if nrt == 2 else 4)
+                ET = max(1, min(WG_WAVES // nrtp, WG_LDS_ROW_MAX // RS, (max_pieces * 64 * WG_WAVES) // (16 * RS // 4)))
+                ET = 4 if ET >= 4 else (2 if ET >= 2 else 1)
+                r0, r1 = 16 * t0, min(sp["nmid"], 16 * (t0 + nrt))
+                n = r1 - r0
+                R = nrt * 16
+                Wp = np.zeros((nsrc, in_mulp, R))
+                for s_ in range(nsrc):
+                    Wp[s_, :mi, :n] = sp["W"][r0:r1, s_ * mi:(s_ + 1) * mi].T
+                Lp = np.zeros((g_mulp, R))
+                Lp[:mk, :n] = sp["L"][r0:r1].T
+                W3p = np.zeros((H, R))
+                W3p[:, :n] = w3[:, sp["ch"][r0:r1]]
+                cfp = np.zeros((nc, R))
+                cfp[:, :n] = sp["cf"][r0:r1].T
+                fW = np.stack([_frag_A(Wp[s_], in_mulp // 4, nrt, False) for s_ in range(nsrc)])      # [nsrc, G, nrt, 64, 4]
+                fL = _frag_A(Lp, g_mulp // 4, nrt, False)
+                f3 = _frag_A(W3p, H // 4, nrt, False)
+                per_tile = []
+                for t in range(nrt):
+                    per_tile.append(np.concatenate([fW[:, :, t].reshape(-1), fL[:, t].reshape(-1), f3[:, t].reshape(-1), cfp[:, 16 * t:16 * t + 16].reshape(-1)]))
+                wstride = per_tile[0].size
+                nfr = nsrc * ntu + ntk
+                astride = nfr * 256
+                ch = np.full(R, -1, np.int64)
+                ch[:n] = sp["ch"][r0:r1]
+                cost = nrt * (nc * (nsrc * (in_mulp // 4) + g_mulp // 4) + H // 4 + 4 * nc * (nsrc * ntu + ntk))     # MFMAs per 16 edges
+                units.append([nsrc, b["srcs"][0], b["srcs"][-1], lay.off[i] + (li - mm) * in_mulp, in_mulp, nc, sp["par"], gl.off[k] + (lk - mm) * g_mulp, g_mulp,
+                              b["mlp"], nrt, nrtp, ET, RS, 4 * xp, 4 * nsrc * xp, 4 * (nsrc * xp + gp), woff, wstride, accoff, astride, choff_t, ntu, ntk,
+                              RS // 4, xp, gp, hp, int(cost), bi, 0, 0])
+                # where the gradient of every flat parameter lands: copy e (edge-tile lane of the workgroup), row tile t, fragment f, row, channel
+                meta = sp["meta"][r0:r1]
+                for e in range(ET):
+                    base_e = accoff + e * nrt * astride
+                    for rho in range(n):
+                        t, rr = divmod(rho, 16)
+                        nidx, wch, cpath, lrow = meta[rho]
+                        bt = base_e + t * astride
+                        for s_ in range(nsrc):
+                            u = np.arange(mi)
+                            pos = bt + (s_ * ntu + u // 16) * 256 + rr * 16 + u % 16
+                            tgt = sp["woff"][nidx] + wch + (s_ * mi + u) * mk
+                            for a, p_ in zip(tgt, pos):
+                                tpp[a].append(int(p_))
+                            tps[tgt] = cpath
+                        w_ = np.arange(mk)
+                        pos = bt + (nsrc * ntu + w_ // 16) * 256 + rr * 16 + w_ % 16
+                        off, fan = sp["lin"]
+                        tgt = off + lrow * mk + w_
+                        for a, p_ in zip(tgt, pos):
+                            lpp[a].append(int(p_))
+                wparts += per_tile
+                chparts.append(ch)
+                woff += wstride * nrt
+                accoff += ET * nrt * astride
+                choff_t += R
+                lds_max = max(lds_max, 2 * ET * 16 * RS * 4)
+                total_cost += cost
+                t0 += nrt
+        tp_pos.append(tpp)
+        tp_scale.append(tps)
+        l_pos.append(lpp)
+    zero = accoff                                              # one spare slot that stays zero
+    def table(lists):
+        out = np.full((len(lists), 4), zero, np.int64)
+        for a, l_ in enumerate(lists):
+            assert len(l_) <= 4
+            out[a, :len(l_)] = l_
+        return out
+    U = np.asarray(units, dtype=np.int64)
+    order = np.argsort(-U[:, 28] * U[:, 12], kind="stable")    # dearest units first (the hardware hands workgroups out in order)
+    return WgFused(units=U[order].astype(np.int32), weights=np.concatenate(wparts), chtab=np.concatenate(chparts).astype(np.int32), acc_floats=accoff + 1,
+                   hidden=H, branch_names=[b["name"] for b in branches], nch=nchs, tp_pos=[table(t) for t in tp_pos], tp_scale=tp_scale,
+                   l_pos=[table(t) for t in l_pos], lds_bytes=lds_max, mfma_per_tile=total_cost)
+
+
 def message_pack_wgrad_branches(sd: Dict[str, np.ndarray], irreps_node, irreps_edge):
     """the two weighted branches of a non-lite MessagePackBlock, with the reference's parameter names (message_passing.py:112-160)"""
     out = []

@@ -128,6 +128,22 @@ int hg_tp_st(const float* const* src, const int64_t* src_stride, int nsrc, const
              const int32_t* part_host, const int32_t* row_table, int lds_bytes,
              const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream_h);
 
+/* Fused WEIGHT gradients of the weighted tensor-product branches of a MessagePackBlock (csrc/tp_wgrad.hip): what torch.autograd computes
+ * for o3.TensorProduct.weight, LinearScaleWithWeights.linear_out.weight and the trailing o3.Linear of
+ * hamgnn/nn/message_passing.py:112-160, 191-231 (the reference has no hand-written backward).  Tables from hamgnn_amd/plan.py:
+ * build_tp_wgrad_fused (WgFused): units int32[nunits][32], weights (B-operand fragments per unit and 16-row tile), chtab (radial channel
+ * of every row).  src[slot]: planar per-edge source rows in the edge frame (sender rows, receiver rows, edge rows), g: gradient of the
+ * block's output rows (edge frame), h_node / h_edge: hidden rows [rows, hidden] of the two radial generators (h_edge may be NULL for
+ * one-generator blocks).  Outputs: gs_node / gs_edge [rows, n_channels] = gradient with respect to the last radial layer's OUTPUT
+ * (per edge; every channel of every row written once), acc [nsplit][acc_floats] partial sums of the weight gradients in the kernel's
+ * fragment layout (the host adds the splits and gathers them into the reference's flat layouts: WgFused.tp_pos / l_pos).
+ * grid = (nunits, nsplit).  Returns 0, or a negative code for arguments the kernel cannot run.                                        */
+int hg_tp_wgrad(const float* const* src, const int64_t* src_stride, int nsrc_slots, const float* g, int64_t g_stride,
+                const float* h_node, const float* h_edge, int64_t h_stride, int hidden,
+                float* gs_node, int64_t gs_node_stride, float* gs_edge, int64_t gs_edge_stride,
+                float* acc, int64_t acc_floats, int nsplit, const int32_t* units, int nunits, const float* weights, const int32_t* chtab,
+                int lds_bytes, int64_t rows, void* stream);
+
 /* torch_scatter.scatter(messages, receiver, dim_size=N) of ConvBlockE3.forward (hamgnn/nn/convolution.py:147-149) as a
  * deterministic segmented reduction: out[n] = sum_{q in [rowptr[n], rowptr[n+1])} msg[perm[q]].                     */
 int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_t* rowptr, const int64_t* perm, int64_t N, int Dp,

@@ -130,6 +130,18 @@ def tp_fused(dp, srcs, rows, h2n=None, h2e=None, geo=None, tag="linear", gather=
     return _t(out)
 
 
+def tp_wgrad(dwf, srcs, g, h_node, h_edge, nsplit=None):
+    """stand-in of ops.tp_wgrad: the kernel's numpy twin on the tables AND the weight blob the device object holds (so a refreshed blob is
+    what gets emulated), splits as the product chooses them"""
+    import copy
+    wf = copy.copy(dwf.wf)
+    wf.weights = _np(dwf.weights).astype(np.float64)
+    rows = int(g.shape[0])
+    S = int(nsplit or dwf.nsplit_for(rows))
+    acc, gs = emu.run_wgrad_fused(wf, [None if t is None else _np(t) for t in srcs], _np(g), (_np(h_node), _np(h_edge) if h_edge is not None else _np(h_node)), nsplit=S)
+    return _t(acc), [_t(a) for a in gs]
+
+
 def linear_planar(dl, x, res=(), tag="linear"):
     return _t(emu.run_linear_tables(dl.tabs, _np(x), [_np(r) for r in res if r is not None]))
 
@@ -350,7 +362,7 @@ def install(mp):
     mp.setattr(ops, "_require_gpu", lambda t: None)
     mp.setattr(ops, "Geometry", Geometry)
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
-    for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
+    for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
                  "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "block_mean", "soc_assemble", "attention_aggregate",
                  "attention_logits", "hk_assemble", "zero_point_shift"):
         mp.setattr(ops, name, globals()[name])

@@ -576,6 +576,60 @@ def test_message_pack_weight_gradients_vs_autograd(seed):
         assert float((got[k].reshape(want[k].shape) - want[k]).abs().max()) < 2e-6 * max(scale, 1e-3), (k, irr, sh)
 
 
+@pytest.mark.parametrize("seed", range(5))
+def test_message_pack_weight_gradients_fused_vs_autograd(seed):
+    """the FUSED weight-gradient kernel's tables (plan.build_tp_wgrad_fused: units, B-operand fragments, accumulator blocks of the
+    splits / edge-tile copies, the gather maps into the reference's flat parameters) through the kernel's numpy twin, every parameter of the
+    block vs torch.autograd through the fp64 oracle.  seeds 3, 4: wide irreps (several 16-row tiles per super-path, two channel tiles)."""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import backward_mp as BM
+    rng = np.random.default_rng(500 + seed)
+    lmax = int(rng.integers(1, 3))
+    irr = _random_irreps(rng, lmax)
+    if "0e" not in irr:
+        irr = "5x0e+" + irr
+    lsh = int(rng.integers(1, 3))
+    if seed >= 3:
+        irr, lsh = ("20x0e+17x1o+6x2e", 2) if seed == 3 else ("33x0e+5x0o+9x1o+4x1e+3x2e+2x3o", 3)
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    lmax = max(l for _, l, _ in P.Irreps(irr))
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
+        E = 37 if seed >= 3 else 21
+        g_ = torch.Generator().manual_seed(seed)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g_) for _ in range(3))
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g_), dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g_)
+        G = torch.randn(E, ref.irreps_node_feats.dim, generator=g_)
+        (ref(src, dst, ef, shv, rbf) * G).sum().backward()
+        want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay = P.PlanarLayout(irr)
+    lm = max(lmax, lsh)
+    D = emu.edge_wigner_all(n.numpy(), lm)
+    rot = lambda t: torch.from_numpy(emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, lm))
+    wg = BM.MessagePackWeightGrad(sd, irr, irr, sh, irr)
+    wf = P.build_tp_wgrad_fused(wg.branches, sh, irr, wg.H)
+    assert wf.units.shape[1] == P.WG_UNIT_I32 and wf.lds_bytes <= 80 * 1024
+    nsplit = 1 + seed % 3
+
+    def run(srcs, g, hn, he):
+        acc, gs = emu.run_wgrad_fused(wf, [t.numpy() for t in srcs], g.numpy(), (hn.numpy(), he.numpy()), nsplit=nsplit)
+        return torch.from_numpy(acc), [torch.from_numpy(a) for a in gs]
+    got = BM.tp_weight_grads_fused(wg, wf, run, [rot(src), rot(dst), rot(ef)], rot(G), rbf, emu.SILU_CST, chunk=16 if seed % 2 else 1 << 20)
+    assert set(got) == set(want), sorted(set(got) ^ set(want))
+    for k in want:
+        scale = max(float(want[k].abs().max()), 1e-30)
+        assert float((got[k].reshape(want[k].shape) - want[k]).abs().max()) < 2e-6 * max(scale, 1e-3), (k, irr, sh)
+
+
 @pytest.mark.parametrize("seed", [(0, False), (1, False), (0, True), (1, True)], ids=["0", "1", "0-lite", "1-lite"])
 def test_embedding_tp_weight_and_input_gradients_vs_autograd(seed):
     """the embedding tensor product (PairInteractionEmbeddingBlock.conv_tp, num_types x 0e input) through the same
