@@ -288,6 +288,7 @@ def tp_weight_grads_fused(wg: TPWeightGrad, wf, run_wgrad, srcs: Sequence[torch.
     """the same gradients as tp_weight_grads through the FUSED kernel (csrc/tp_wgrad.hip, plan.WgFused `wf`): nothing per edge is
     materialised except gs (the gradient with respect to the last radial layer's output).  run_wgrad(srcs_by_slot, g, h_node, h_edge) ->
     (acc [splits, acc_floats], [gs per branch]) -- ops.tp_wgrad on the GPU, the numpy twin (tests/emu.py:run_wgrad_fused) in the CPU suite.
+    wf: the plan object or ops.DeviceWgFused (same attribute names; its gather maps are device tensors: no upload per step).
     srcs: planar edge-frame source rows by slot; hidden: optional {branch: hidden rows [E, H]} (else recomputed from rbf)."""
     dev, dt = g.device, g.dtype
     E = g.shape[0]

@@ -369,7 +369,7 @@ class MessagePackBlock(nn.Module):
         if dwf is not None:                                    # fused kernel (csrc/tp_wgrad.hip): nothing per edge is materialised but gs
             hidden = {"node": ops.radial_hidden_cached(geo, self._hn, cst), "edge": ops.radial_hidden_cached(geo, self._he, cst)}
             run = lambda srcs, g_, hn, he: ops.tp_wgrad(dwf, srcs, g_, hn, he)
-            return BM.tp_weight_grads_fused(wg, dwf.wf, run, [xs, xd, f_rot], g, geo.rbf, cst, hidden=hidden)
+            return BM.tp_weight_grads_fused(wg, dwf, run, [xs, xd, f_rot], g, geo.rbf, cst, hidden=hidden)     # dwf: the gather maps as device tensors
         if dpA is None:                                        # materialisation route: the two row programs on the segment-stationary kernel
             dpA, dpB = ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg")
             self._wgrad[1:] = [dpA, dpB]

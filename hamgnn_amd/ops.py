@@ -337,7 +337,7 @@ class DeviceWgFused:
     def nsplit_for(self, rows: int) -> int:
         """edge splits of a launch: enough workgroups to fill the chip several times over, at least a few iterations each"""
         tiles = (rows + 15) // 16
-        return int(max(1, min(32, -(-1536 // int(self.units.shape[0])), tiles // 4)))
+        return int(max(1, min(64, -(-8192 // int(self.units.shape[0])), tiles // 8)))      # measured (profiles/r03_wgrad.md): 8 -> 64 splits 11.5 -> 9.3 ms at 44 k edges
 
 
 def tp_wgrad(dwf: DeviceWgFused, srcs: Sequence[Optional[torch.Tensor]], g: torch.Tensor, h_node: torch.Tensor, h_edge: Optional[torch.Tensor],

@@ -1298,35 +1298,45 @@ def build_tp_wgrad_programs(branches, irreps_sh, irreps_out, H: int):
 
 
 # ------------------------------------------------------------------------------------------------ fused weight-gradient kernel (csrc/tp_wgrad.hip)
-WG_UNIT_I32 = 32            # ints per unit record, see build_tp_wgrad_fused
+WG_UNIT_I32 = 64            # ints per unit record, see WgFused
+WG_WREC, WG_WREC_I32 = 24, 10
 WG_WAVES = 4
 WG_LDS_ROW_MAX = 640        # floats: 2 buffers x 16 rows x 640 x 4 B = 80 KB (two workgroups per CU)
-def WG_MAXT_OF_NC(nc):      # accumulator fragments of the kernel per source (tiles of 16 channels), by column count: csrc/tp_wgrad.hip WG_MAXT_OF
-    return 4 if nc <= 7 else (2 if nc == 9 else 1)
+WG_MAX_PIECES = 10          # float4 pieces a thread holds in flight while the next edge tile is staged (csrc/tp_wgrad.hip WG_NP) ...
 
 
-def WG_PIECES_OF_NC(nc):    # float4 pieces a thread holds in flight while the next edge tile is staged: csrc/tp_wgrad.hip WG_PIECES_OF
-    return 10 if nc <= 9 else (6 if nc == 11 else 5)
+def wg_pieces_of_nc(nc: int) -> int:
+    """... by the column count of a wave's row tile (csrc/tp_wgrad.hip WG_NP_OF); a unit's operand tile must fit its most demanding wave"""
+    return WG_MAX_PIECES if nc <= 9 else 5
+
+
+def wg_shape_ok(nc: int, g1: int, g2: int) -> bool:
+    """template instantiations of csrc/tp_wgrad.hip (WG_CASES_*): columns x tiles of 16 input / output channels"""
+    if nc == 1:
+        return 1 <= g1 <= 4 and 1 <= g2 <= 4
+    if nc in (3, 5, 7):
+        return 1 <= g1 <= 2 and 1 <= g2 <= 2
+    return nc in (9, 11, 13) and g1 == 1 and g2 == 1
 
 
 @dataclass
 class WgFused:
     """Launch tables of the fused weight-gradient kernel for the weighted tensor-product branches of one block.
-    A UNIT = (super-path (i, k) of a branch, up to four 16-row tiles of its rows); a workgroup owns one unit and a range of edge tiles:
-    wave w works on row tile w % nrtp of edge tile w / nrtp of every iteration, the unit's accumulators stay in its registers:
+    A UNIT = up to four 16-row tiles of super-paths (i, k) that read the SAME input irrep i of one branch (any k); a workgroup owns one unit
+    and a range of edge tiles; wave w works on its row tile for the edge tile `et` of every iteration (ET edge tiles per iteration: units with
+    fewer than four row tiles put several edge tiles side by side), weights and accumulators stay in its registers:
         g_W[u, row] += sum_{c, e} x[e, u, comp(c)] * (s cf (L g))[e, row, c]        (K = the 16 edges: the C fragment of the first-stage MFMAs IS the B operand)
         g_L[w, row] += sum_{c, e} g[e, w, col(c)] * (s cf (W x))[e, row, c]
         gs[e, ch(row)] = sum_c cf (W x) (L g)                                         (written per edge: last radial layer / hidden-layer gradients)
     units [n, WG_UNIT_I32] int32:
-         0 nsrc   1 slot0   2 slot1   3 x_off (floats into a source row: first component of the span)   4 in_mulp   5 nc   6 par (1: column c reads
-         span component nc-1-c)   7 g_off   8 g_mulp   9 mlp (which hidden rows / which gs buffer)   10 nrt   11 nrtp (1|2|4)   12 ET (edge tiles per
-        iteration)   13 RS (LDS row stride, floats, == 4 mod 64)   14 LDS offset of source 1   15 of the gradient span   16 of the hidden row
-        17 weight offset (floats)   18 weight stride per row tile   19 accumulator offset (floats, per split)   20 accumulator stride per row tile
-        21 chtab offset (ints; 16 per row tile, -1 = padding row)   22 ntu (tiles of 16 input channels)   23 ntk (tiles of 16 output channels)
-        24 pieces per LDS row (RS / 4)   25 x pieces per source   26 g pieces   27 h pieces   28 cost (MFMAs per iteration)
-    weights per (unit, row tile): [W: nsrc x ceil(in_mulp/16) x 64 x 4][L: ceil(g_mulp/16) x 64 x 4][W3: H/16 x 64 x 4][cf: nc x 16], B-operand
-    fragments in natural-K order (lane (row, kk) holds M[row][4 (4 G + q) + kk], q = float4 component).
-    accumulators per (split, unit, edge-tile copy, row tile): [nsrc*ntu + ntk fragments][16 rows][16 channels]."""
+         0 nsrc   1 slot0   2 slot1   3 x_off (floats into a source row: first staged component of irrep i)   4 in_mulp   5 x pieces per source
+         6 number of gradient spans   7 mlp (which hidden rows / which gs buffer)   8 ET   9 RS (LDS row stride, floats, == 4 mod 64)   10 RS / 4
+        11 h pieces   12 G1 = ceil(in_mulp / 16)   13 cost (MFMAs of the dearest wave per iteration)   14 busy waves   15 branch
+        16 + 2 s, 17 + 2 s: gradient span s (s < 4): float offset into a gradient row, pieces
+        24 + 10 w ...: wave w: busy, et, nc, par (1: column c reads component nc-1-c of its span), x column offset (floats, from the staged span),
+                       LDS offset of its gradient span (floats), g_mulp, weight offset (floats), accumulator offset (floats, per split), chtab offset
+    weights per row tile: [W: nsrc x G1 x 64 x 4][L: G2 x 64 x 4][W3: H/16 x 64 x 4][cf: nc x 16], B-operand fragments in natural-K order
+    (lane (row, kk) holds M[row][4 (4 G + q) + kk], q = float4 component).  accumulators per (split, wave): [nsrc*G1 + G2 fragments][16 rows][16 channels]."""
     units: np.ndarray
     weights: np.ndarray
     chtab: np.ndarray
@@ -1334,24 +1344,25 @@ class WgFused:
     hidden: int
     branch_names: List[str]
     nch: List[int]
-    tp_pos: List[Optional[np.ndarray]]      # per branch: [tp_size, 4] positions in the accumulator block (acc_floats = a zero slot), or None (uvu)
+    tp_pos: List[Optional[np.ndarray]]      # per branch: [tp_size, 4] positions in the accumulator block (acc_floats - 1 = a zero slot)
     tp_scale: List[Optional[np.ndarray]]
     l_pos: List[np.ndarray]                 # per branch: [ls_size, 4]
     lds_bytes: int
-    mfma_per_tile: float = 0.0
+    mfma_per_tile: float = 0.0              # issued MFMAs per 16 edges, all units
+    bytes_per_edge: float = 0.0             # staged bytes per edge, all units
 
 
 def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
     """see WgFused; branches as build_tp_wgrad_programs (weighted branches only)"""
     irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
     gl = PlanarLayout(irreps_out)
-    if H % 16:
-        raise NotImplementedError("fused weight gradients: hidden width of the radial MLP must be a multiple of 16")
+    if H != 64:
+        raise NotImplementedError("fused weight gradients: hidden width of the radial MLP must be 64")
     units, wparts, chparts = [], [], []
     woff = accoff = choff_t = 0
     tp_pos, tp_scale, l_pos, nchs = [], [], [], []
     lds_max = 0
-    total_cost = 0.0
+    total_cost = total_bytes = 0.0
     for bi, b in enumerate(branches):
         if b["tp_w"] is None:
             raise NotImplementedError("fused weight gradients: unweighted (uvu) branches carry no tensor-product weights")
@@ -1362,84 +1373,107 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
         tps = np.zeros(tp_size)
         lpp = [[] for _ in range(ls_size)]
         nchs.append(int(w3.shape[1]))
+        by_i: Dict[int, list] = {}
         for sp in _tp_superpaths(nsrc, lay, irreps_sh, irreps_out, np.asarray(b["tp_w"]), w3, np.asarray(b["ls_w"]),
                                  None if b["lo_w"] is None else np.asarray(b["lo_w"]), False):
-            i, k, mi, mk, mm, li, lk = sp["i"], sp["k"], sp["mi"], sp["mk"], sp["mm"], sp["li"], sp["lk"]
-            nc = 2 * mm + 1
-            in_mulp, g_mulp = lay.mulp[i], gl.mulp[k]
-            ntu, ntk = ceil_div(in_mulp, 16), ceil_div(g_mulp, 16)
-            if nc > 13 or max(ntu, ntk) > WG_MAXT_OF_NC(nc):
-                raise NotImplementedError("fused weight gradients: no kernel instantiation for this many channels / columns of a super-path")
-            max_pieces = WG_PIECES_OF_NC(nc)
-            xp, gp, hp = nc * in_mulp // 4, nc * g_mulp // 4, H // 4
-            used = 4 * (nsrc * xp + gp + hp)
-            RS = used + ((4 - used) % 64)                       # == 4 mod 64: conflict-free dword reads of 16 rows x 4 K-slots AND of 4 rows x 16 channels
-            if RS > WG_LDS_ROW_MAX or ceil_div(16 * RS // 4, 64 * WG_WAVES) > max_pieces:
-                raise NotImplementedError("fused weight gradients: a 16-edge operand tile does not fit the LDS budget")
-            T = ceil_div(sp["nmid"], 16)
-            nun = ceil_div(T, WG_WAVES)
-            t0 = 0
-            for q in range(nun):
-                nrt = T // nun + (1 if q < T % nun else 0)
-                nrtp = 1 if nrt == 1 else (2 if nrt == 2 else 4)
-                ET = max(1, min(WG_WAVES // nrtp, WG_LDS_ROW_MAX // RS, (max_pieces * 64 * WG_WAVES) // (16 * RS // 4)))
-                ET = 4 if ET >= 4 else (2 if ET >= 2 else 1)
-                r0, r1 = 16 * t0, min(sp["nmid"], 16 * (t0 + nrt))
-                n = r1 - r0
-                R = nrt * 16
-                Wp = np.zeros((nsrc, in_mulp, R))
-                for s_ in range(nsrc):
-                    Wp[s_, :mi, :n] = sp["W"][r0:r1, s_ * mi:(s_ + 1) * mi].T
-                Lp = np.zeros((g_mulp, R))
-                Lp[:mk, :n] = sp["L"][r0:r1].T
-                W3p = np.zeros((H, R))
-                W3p[:, :n] = w3[:, sp["ch"][r0:r1]]
-                cfp = np.zeros((nc, R))
-                cfp[:, :n] = sp["cf"][r0:r1].T
-                fW = np.stack([_frag_A(Wp[s_], in_mulp // 4, nrt, False) for s_ in range(nsrc)])      # [nsrc, G, nrt, 64, 4]
-                fL = _frag_A(Lp, g_mulp // 4, nrt, False)
-                f3 = _frag_A(W3p, H // 4, nrt, False)
-                per_tile = []
-                for t in range(nrt):
-                    per_tile.append(np.concatenate([fW[:, :, t].reshape(-1), fL[:, t].reshape(-1), f3[:, t].reshape(-1), cfp[:, 16 * t:16 * t + 16].reshape(-1)]))
-                wstride = per_tile[0].size
-                nfr = nsrc * ntu + ntk
-                astride = nfr * 256
-                ch = np.full(R, -1, np.int64)
-                ch[:n] = sp["ch"][r0:r1]
-                cost = nrt * (nc * (nsrc * (in_mulp // 4) + g_mulp // 4) + H // 4 + 4 * nc * (nsrc * ntu + ntk))     # MFMAs per 16 edges
-                units.append([nsrc, b["srcs"][0], b["srcs"][-1], lay.off[i] + (li - mm) * in_mulp, in_mulp, nc, sp["par"], gl.off[k] + (lk - mm) * g_mulp, g_mulp,
-                              b["mlp"], nrt, nrtp, ET, RS, 4 * xp, 4 * nsrc * xp, 4 * (nsrc * xp + gp), woff, wstride, accoff, astride, choff_t, ntu, ntk,
-                              RS // 4, xp, gp, hp, int(cost), bi, 0, 0])
-                # where the gradient of every flat parameter lands: copy e (edge-tile lane of the workgroup), row tile t, fragment f, row, channel
-                meta = sp["meta"][r0:r1]
-                for e in range(ET):
-                    base_e = accoff + e * nrt * astride
+            nc = 2 * sp["mm"] + 1
+            g1, g2 = ceil_div(lay.mulp[sp["i"]], 16), ceil_div(gl.mulp[sp["k"]], 16)
+            if not wg_shape_ok(nc, g1, g2):
+                raise NotImplementedError(f"fused weight gradients: no kernel instantiation for {nc} columns x {g1} / {g2} channel tiles")
+            cost = nc * (nsrc * (lay.mulp[sp["i"]] // 4) + gl.mulp[sp["k"]] // 4) + H // 4 + 4 * nc * (nsrc * g1 + g2)      # MFMAs per 16 edges and row tile
+            for t in range(ceil_div(sp["nmid"], 16)):
+                by_i.setdefault(sp["i"], []).append((sp, t, cost))
+        for i, tiles in by_i.items():
+            tiles.sort(key=lambda x: -x[2])                    # like-priced row tiles share a workgroup (its waves meet at a barrier every iteration)
+            in_mulp, li = lay.mulp[i], lay.irreps[i][1]
+            q0 = 0
+            while q0 < len(tiles):
+                # greedily take up to four row tiles whose operand row fits the LDS budget
+                take, segs = [], []
+                while q0 + len(take) < len(tiles) and len(take) < WG_WAVES:
+                    sp = tiles[q0 + len(take)][0]
+                    segs2 = segs if sp["k"] in segs else segs + [sp["k"]]
+                    mmax = max([sp["mm"]] + [t_[0]["mm"] for t_ in take])
+                    used = nsrc * (2 * mmax + 1) * in_mulp + sum((2 * min(li, irreps_out[k][1]) + 1) * gl.mulp[k] for k in segs2) + H
+                    RS = used + ((4 - used) % 64)
+                    if RS > WG_LDS_ROW_MAX or ceil_div(used // 4, 16) > wg_pieces_of_nc(2 * mmax + 1):      # 16 threads stage one row
+                        break
+                    take.append(tiles[q0 + len(take)])
+                    segs = segs2
+                if not take:
+                    raise NotImplementedError("fused weight gradients: a 16-edge operand tile does not fit the LDS budget")
+                q0 += len(take)
+                mmax = max(t_[0]["mm"] for t_ in take)
+                xp = (2 * mmax + 1) * in_mulp // 4
+                seg_p = [(2 * min(li, irreps_out[k][1]) + 1) * gl.mulp[k] // 4 for k in segs]
+                used = 4 * (nsrc * xp + sum(seg_p)) + H
+                RS = used + ((4 - used) % 64)                   # == 4 mod 64: conflict-free dword reads of 16 rows x 4 K-slots AND of 4 rows x 16 channels
+                nt = len(take)
+                ET = max(et_ for et_ in (1, 2, 4) if et_ == 1 or (et_ * nt <= WG_WAVES and et_ * RS <= WG_LDS_ROW_MAX
+                                                                  and ceil_div(used // 4 * et_, 16) <= wg_pieces_of_nc(2 * mmax + 1)))      # 16 / ET threads per row
+                rec = [0] * WG_UNIT_I32
+                rec[0:16] = [nsrc, b["srcs"][0], b["srcs"][-1], lay.off[i] + (li - mmax) * in_mulp, in_mulp, xp, len(segs), b["mlp"], ET, RS, RS // 4, H // 4,
+                             ceil_div(in_mulp, 16), int(max(t_[2] for t_ in take)), nt * ET, bi]
+                seg_lds, o = {}, 4 * nsrc * xp
+                for s_, k in enumerate(segs):
+                    lk = irreps_out[k][1]
+                    rec[16 + 2 * s_] = gl.off[k] + (lk - min(li, lk)) * gl.mulp[k]
+                    rec[17 + 2 * s_] = seg_p[s_]
+                    seg_lds[k] = o
+                    o += 4 * seg_p[s_]
+                for w_ in range(nt * ET):
+                    sp, t, cost = take[w_ % nt][:3]
+                    e = w_ // nt
+                    k, mi, mk, mm, lk = sp["k"], sp["mi"], sp["mk"], sp["mm"], sp["lk"]
+                    nc, g_mulp = 2 * mm + 1, gl.mulp[k]
+                    G1, G2 = ceil_div(in_mulp, 16), ceil_div(g_mulp, 16)
+                    r0, r1 = 16 * t, min(sp["nmid"], 16 * t + 16)
+                    n = r1 - r0
+                    nfr = nsrc * G1 + G2
+                    if e == 0:                                 # the row tile's weights and channel table (shared by its edge-tile copies)
+                        Wp = np.zeros((nsrc, in_mulp, 16))
+                        for s_ in range(nsrc):
+                            Wp[s_, :mi, :n] = sp["W"][r0:r1, s_ * mi:(s_ + 1) * mi].T
+                        Lp = np.zeros((g_mulp, 16))
+                        Lp[:mk, :n] = sp["L"][r0:r1].T
+                        W3p = np.zeros((H, 16))
+                        W3p[:, :n] = w3[:, sp["ch"][r0:r1]]
+                        cfp = np.zeros((nc, 16))
+                        cfp[:, :n] = sp["cf"][r0:r1].T
+                        blob = np.concatenate([np.stack([_frag_A(Wp[s_], in_mulp // 4, 1, False) for s_ in range(nsrc)]).reshape(-1),
+                                               _frag_A(Lp, g_mulp // 4, 1, False).reshape(-1), _frag_A(W3p, H // 4, 1, False).reshape(-1), cfp.reshape(-1)])
+                        ch = np.full(16, -1, np.int64)
+                        ch[:n] = sp["ch"][r0:r1]
+                        wparts.append(blob)
+                        chparts.append(ch)
+                        take[w_ % nt] = (sp, t, cost, woff, choff_t)
+                        woff += blob.size
+                        choff_t += 16
+                    my_w, my_ch = take[w_ % nt][3:]
+                    rec[WG_WREC + WG_WREC_I32 * w_:WG_WREC + WG_WREC_I32 * (w_ + 1)] = [1, e, nc, sp["par"], (mmax - mm) * in_mulp, seg_lds[k], g_mulp, my_w, accoff, my_ch]
+                    # where the gradient of every flat parameter lands: this wave's block, fragment f, row, channel
+                    meta = sp["meta"][r0:r1]
                     for rho in range(n):
-                        t, rr = divmod(rho, 16)
                         nidx, wch, cpath, lrow = meta[rho]
-                        bt = base_e + t * astride
                         for s_ in range(nsrc):
                             u = np.arange(mi)
-                            pos = bt + (s_ * ntu + u // 16) * 256 + rr * 16 + u % 16
+                            pos = accoff + (s_ * G1 + u // 16) * 256 + rho * 16 + u % 16
                             tgt = sp["woff"][nidx] + wch + (s_ * mi + u) * mk
-                            for a, p_ in zip(tgt, pos):
-                                tpp[a].append(int(p_))
+                            for a_, p_ in zip(tgt, pos):
+                                tpp[a_].append(int(p_))
                             tps[tgt] = cpath
-                        w_ = np.arange(mk)
-                        pos = bt + (nsrc * ntu + w_ // 16) * 256 + rr * 16 + w_ % 16
+                        w2 = np.arange(mk)
+                        pos = accoff + (nsrc * G1 + w2 // 16) * 256 + rho * 16 + w2 % 16
                         off, fan = sp["lin"]
-                        tgt = off + lrow * mk + w_
-                        for a, p_ in zip(tgt, pos):
-                            lpp[a].append(int(p_))
-                wparts += per_tile
-                chparts.append(ch)
-                woff += wstride * nrt
-                accoff += ET * nrt * astride
-                choff_t += R
+                        tgt = off + lrow * mk + w2
+                        for a_, p_ in zip(tgt, pos):
+                            lpp[a_].append(int(p_))
+                    accoff += nfr * 256
+                    if e == 0:
+                        total_cost += cost
+                units.append(rec)
                 lds_max = max(lds_max, 2 * ET * 16 * RS * 4)
-                total_cost += cost
-                t0 += nrt
+                total_bytes += used * 4.0
         tp_pos.append(tpp)
         tp_scale.append(tps)
         l_pos.append(lpp)
@@ -1451,10 +1485,10 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
             out[a, :len(l_)] = l_
         return out
     U = np.asarray(units, dtype=np.int64)
-    order = np.argsort(-U[:, 28] * U[:, 12], kind="stable")    # dearest units first (the hardware hands workgroups out in order)
+    order = np.argsort(-U[:, 13], kind="stable")               # dearest units first (the hardware hands workgroups out in order)
     return WgFused(units=U[order].astype(np.int32), weights=np.concatenate(wparts), chtab=np.concatenate(chparts).astype(np.int32), acc_floats=accoff + 1,
                    hidden=H, branch_names=[b["name"] for b in branches], nch=nchs, tp_pos=[table(t) for t in tp_pos], tp_scale=tp_scale,
-                   l_pos=[table(t) for t in l_pos], lds_bytes=lds_max, mfma_per_tile=total_cost)
+                   l_pos=[table(t) for t in l_pos], lds_bytes=lds_max, mfma_per_tile=total_cost, bytes_per_edge=total_bytes)
 
 
 def message_pack_wgrad_branches(sd: Dict[str, np.ndarray], irreps_node, irreps_edge):

@@ -474,8 +474,9 @@ def _unfrag_natural(frag, K, rows):
 def run_wgrad_fused(wf, srcs, g, h2, nsplit=1, dtype=np.float64):
     """numpy twin of csrc/tp_wgrad.hip driven by the same tables (plan.WgFused): srcs = edge-frame planar source rows by slot, g = gradient rows
     of the block's output (edge frame), h2 = hidden rows of the two radial generators.  Returns (acc [nsplit, acc_floats], [gs per branch])
-    in the kernel's layouts: edge tiles are dealt to the splits and to the edge-tile copies of a workgroup exactly as the kernel does, so the
-    accumulator positions of every copy are exercised."""
+    in the kernel's layouts: every busy wave of every unit is followed through its own record (row tile, edge-tile lane `et`, operand
+    offsets inside the staged LDS row, weight fragments, accumulator block), edge tiles are dealt to the splits as the kernel deals them."""
+    from hamgnn_amd import plan as P
     E = g.shape[0]
     H = wf.hidden
     acc = np.zeros((nsplit, wf.acc_floats), dtype=dtype)
@@ -483,54 +484,57 @@ def run_wgrad_fused(wf, srcs, g, h2, nsplit=1, dtype=np.float64):
     W = wf.weights.astype(dtype)
     T = -(-E // 16)
     for U in wf.units.astype(np.int64):
-        (nsrc, s0, s1, x_off, in_mulp, nc, par, g_off, g_mulp, mlp, nrt, nrtp, ET, RS, _, _, _, woff, wstride, accoff, astride, choff, ntu, ntk) = U[:24]
-        bi = int(U[29])
+        nsrc, s0, s1, x_off, in_mulp, xp, nseg, mlp, ET, RS, PR, hp, G1 = U[:13]
+        bi = int(U[15])
         slots = [s0, s1][:nsrc]
         NI = -(-T // ET)
         per = -(-NI // nsplit)
-        # operands of the whole launch for this unit: x [E, nsrc, nc, in_mulp] (column order), gk [E, nc, g_mulp]
-        comp = [(nc - 1 - c) if par else c for c in range(nc)]
-        x = np.stack([np.stack([srcs[s][:, x_off + a * in_mulp:x_off + (a + 1) * in_mulp] for a in comp], 1) for s in slots], 1).astype(dtype)
-        gk = np.stack([g[:, g_off + c * g_mulp:g_off + (c + 1) * g_mulp] for c in range(nc)], 1).astype(dtype)
-        hh = h2[mlp][:, :H].astype(dtype)
-        for t in range(nrt):
-            wt = W[woff + t * wstride:woff + (t + 1) * wstride]
-            o = 0
-            G1, G2, G3 = -(-(in_mulp // 4) // 4), -(-(g_mulp // 4) // 4), H // 16
-            Wm = [_unfrag_natural(wt[o + s * G1 * 256:o + (s + 1) * G1 * 256].reshape(G1, 64, 4), in_mulp, 16) for s in range(nsrc)]   # [in_mulp, 16 rows]
+        # the staged LDS row of every edge: [x source 0 | x source 1 | gradient spans | h], exactly as wg_load / wg_store lay it out
+        parts = [srcs[s][:, x_off:x_off + 4 * xp] for s in slots] + [g[:, U[16 + 2 * s]:U[16 + 2 * s] + 4 * U[17 + 2 * s]] for s in range(nseg)] + [h2[mlp][:, :H]]
+        row = np.concatenate(parts, 1).astype(dtype)
+        assert row.shape[1] <= RS and RS % 64 == 4 and PR * 4 == RS
+        hoff = row.shape[1] - H
+        hh = row[:, hoff:]
+        for w in range(4):
+            busy, et, nc, par, xc0, goff, g_mulp, woff, accoff, choff = U[P.WG_WREC + P.WG_WREC_I32 * w:P.WG_WREC + P.WG_WREC_I32 * (w + 1)]
+            if not busy:
+                continue
+            G2 = -(-g_mulp // 16)
+            assert P.wg_shape_ok(int(nc), int(G1), int(G2))
+            comp = [(nc - 1 - c) if par else c for c in range(nc)]
+            x = np.stack([np.stack([row[:, s * 4 * xp + xc0 + a * in_mulp:s * 4 * xp + xc0 + (a + 1) * in_mulp] for a in comp], 1) for s in range(nsrc)], 1)   # [E, nsrc, nc, in_mulp]
+            gk = np.stack([row[:, goff + c * g_mulp:goff + (c + 1) * g_mulp] for c in range(nc)], 1)                                                              # [E, nc, g_mulp]
+            o = woff
+            Wm = [_unfrag_natural(W[o + s * G1 * 256:o + (s + 1) * G1 * 256].reshape(G1, 64, 4), in_mulp, 16) for s in range(nsrc)]   # [in_mulp, 16 rows]
             o += nsrc * G1 * 256
-            Lm = _unfrag_natural(wt[o:o + G2 * 256].reshape(G2, 64, 4), g_mulp, 16)
+            Lm = _unfrag_natural(W[o:o + G2 * 256].reshape(G2, 64, 4), g_mulp, 16)
             o += G2 * 256
-            W3m = _unfrag_natural(wt[o:o + G3 * 256].reshape(G3, 64, 4), H, 16)
-            o += G3 * 256
-            cf = wt[o:o + nc * 16].reshape(nc, 16)
-            ch = wf.chtab[choff + 16 * t:choff + 16 * t + 16]
+            W3m = _unfrag_natural(W[o:o + (H // 16) * 256].reshape(H // 16, 64, 4), H, 16)
+            o += (H // 16) * 256
+            cf = W[o:o + nc * 16].reshape(nc, 16)
+            ch = wf.chtab[choff:choff + 16]
             mid = sum(np.einsum("ecu,ur->ecr", x[:, s], Wm[s]) for s in range(nsrc))          # [E, nc, 16]
             Bm = np.einsum("ecw,wr->ecr", gk, Lm)
             sv = hh @ W3m                                                                      # [E, 16]
             A_ = mid * cf[None]
-            gsr = (A_ * Bm).sum(1)                                                             # [E, 16]
-            gs[bi][:, ch[ch >= 0]] = gsr[:, ch >= 0]
             T1 = sv[:, None, :] * cf[None] * Bm
             T2 = sv[:, None, :] * A_
             for split in range(nsplit):
-                for et in range(ET):
-                    its = np.arange(split * per, min(NI, (split + 1) * per))
-                    tiles = its * ET + et
-                    tiles = tiles[tiles < T]
-                    if tiles.size == 0:
-                        continue
-                    rows = (tiles[:, None] * 16 + np.arange(16)[None]).reshape(-1)
-                    rows = rows[rows < E]
-                    base = accoff + (et * nrt + t) * astride
-                    for s in range(nsrc):
-                        gW = np.einsum("ecu,ecr->ru", x[rows, s], T1[rows])                    # [16 rows, in_mulp]
-                        full = np.zeros((16, ntu * 16), dtype=dtype)
-                        full[:, :in_mulp] = gW
-                        blk = full.reshape(16, ntu, 16).transpose(1, 0, 2)                     # [fragment, row, channel]
-                        acc[split, base + s * ntu * 256:base + (s + 1) * ntu * 256] += blk.reshape(-1)
-                    gL = np.einsum("ecw,ecr->rw", gk[rows], T2[rows])
-                    full = np.zeros((16, ntk * 16), dtype=dtype)
-                    full[:, :g_mulp] = gL
-                    acc[split, base + nsrc * ntu * 256:base + (nsrc * ntu + ntk) * 256] += full.reshape(16, ntk, 16).transpose(1, 0, 2).reshape(-1)
+                its = np.arange(split * per, min(NI, (split + 1) * per))
+                tiles = its * ET + et
+                tiles = tiles[tiles < T]
+                if tiles.size == 0:
+                    continue
+                rows = (tiles[:, None] * 16 + np.arange(16)[None]).reshape(-1)
+                rows = rows[rows < E]
+                gs[bi][np.ix_(rows, ch[ch >= 0])] = (A_[rows] * Bm[rows]).sum(1)[:, ch >= 0]   # written by the wave that owns (row tile, edge tile)
+                for s in range(nsrc):
+                    gW = np.einsum("ecu,ecr->ru", x[rows, s], T1[rows])                        # [16 rows, in_mulp]
+                    full = np.zeros((16, G1 * 16), dtype=dtype)
+                    full[:, :in_mulp] = gW
+                    acc[split, accoff + s * G1 * 256:accoff + (s + 1) * G1 * 256] += full.reshape(16, G1, 16).transpose(1, 0, 2).reshape(-1)
+                gL = np.einsum("ecw,ecr->rw", gk[rows], T2[rows])
+                full = np.zeros((16, G2 * 16), dtype=dtype)
+                full[:, :g_mulp] = gL
+                acc[split, accoff + nsrc * G1 * 256:accoff + (nsrc * G1 + G2) * 256] += full.reshape(16, G2, 16).transpose(1, 0, 2).reshape(-1)
     return acc, gs
