@@ -43,11 +43,11 @@ PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector == fp32-in
 PEAK_HBM_GBS = 8000.0
 
 
-def make_cfg(irreps):
+def make_cfg(irreps, lite=False):
     return dict(num_types=96, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True,
                 build_internal_graph=False, cutoff=26.0, rbf_func="bessel", num_radial=64, num_layers=3,
                 irreps_node_features=irreps, use_kan=False, radial_MLP=[64, 64], correlation=2, num_hidden_features=16,
-                radius_type="openmx", use_corr_prod=False, legacy_edge_update=False, lite_mode=False)
+                radius_type="openmx", use_corr_prod=False, legacy_edge_update=False, lite_mode=bool(lite))
 
 
 def make_graph(workload, nao, soc=False):
@@ -71,7 +71,7 @@ def make_graph(workload, nao, soc=False):
     return S.add_random_targets(g, nao, seed=0, soc=soc)
 
 
-def cpu_baseline(workload, irreps_key, nao, budget_s=15.0):
+def cpu_baseline(workload, irreps_key, nao, budget_s=15.0, lite=False):
     """Oracle (unfused torch port of the reference op graph) on the host cores, bounded sample of the same workload."""
     from oracle import hamgnn_ref as R
     from hamgnn_amd.data import synthetic as S
@@ -81,7 +81,7 @@ def cpu_baseline(workload, irreps_key, nao, budget_s=15.0):
     torch.set_num_threads(cores)
     irreps = IRREPS[irreps_key]
     torch.manual_seed(666)
-    model = R.HamGNNConvE3(make_cfg(irreps)).float()
+    model = R.HamGNNConvE3(make_cfg(irreps, lite)).float()
     head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True).float()
 
     def run(n_atoms):
@@ -209,7 +209,7 @@ def accuracy_vs_oracle(path):
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
-        model = R.HamGNNConvE3(make_cfg(blob["irreps"]))
+        model = R.HamGNNConvE3(make_cfg(blob["irreps"], blob.get("lite", False)))
         head = R.HamGNNPlusPlusOut(blob["irreps"], blob["irreps"], nao_max=blob["nao"], ham_type="openmx", symmetrize=True, add_H0=True)
     finally:
         torch.set_default_dtype(prev)
@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--irreps", default="A", choices=["A", "B"])
     ap.add_argument("--nao", type=int, default=19)
     ap.add_argument("--soc", action="store_true", help="SOC / so3 read-out (BASELINE config #3: MoS2 with spin-orbit coupling); the CPU baseline leg stays non-SOC")
+    ap.add_argument("--lite", action="store_true", help="lite_mode MessagePackBlocks (message_passing.py:197-215: unweighted uvu products + o3.Linear + one combined radial scale); "
+                    "runs on the segment-stationary kernel, the roofline then counts the planner's executed flops (SURVEY 8d's figures are for the default block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--accuracy-from", default=None, help=argparse.SUPPRESS)
@@ -247,7 +249,7 @@ def main():
         if args.accuracy_from:
             print("ACCURACY " + json.dumps(accuracy_vs_oracle(args.accuracy_from)), flush=True)
             return
-        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.workload, args.irreps, args.nao)), flush=True)
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.workload, args.irreps, args.nao, lite=args.lite)), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -292,7 +294,7 @@ def main():
 
     irreps = IRREPS[args.irreps]
     torch.manual_seed(666)
-    model = HamGNNConvE3(make_cfg(irreps))
+    model = HamGNNConvE3(make_cfg(irreps, args.lite))
     head = HamGNNPlusPlusOut(irreps, irreps, nao_max=args.nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
                              soc_switch=args.soc, soc_basis="so3", calculate_sparsity=True, zero_point_shift=False)   # the reference's defaults
     g = make_graph(args.workload, args.nao, soc=args.soc)
@@ -364,8 +366,8 @@ def main():
     n_launch = max(1, len(mp))
     avg_s = sum(t for t, _, _ in mp) / n_launch
     rows_per_launch = sum(r for _, r, _ in mp) / n_launch
-    flops_launch = REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_per_launch
     useful = model.convolutions[0].conv_tp._dp.prog.flops_per_row * rows_per_launch
+    flops_launch = useful if args.lite else REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_per_launch
     dp0 = model.convolutions[0].conv_tp._dp
     issued = (dp0.prog.mfma_per_wave - (dp0.prog.mfma_odd_skipped if dp0.sched is not None else 0)) * 2048.0 / 16.0 * rows_per_launch
     ach = flops_launch / avg_s / 1e12
@@ -386,7 +388,7 @@ def main():
            "edges_per_s_median_step": E_total / (median_ms * 1e-3), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {N_atoms} atoms, {E_total} directed edges, irreps set-{args.irreps} (D={model.irreps_node_features.dim}), "
-                                  f"sh lmax 5, 3 layers, nao_max {args.nao}, {'SOC (so3 head)' if args.soc else 'no SOC'}, backbone+head forward",
+                                  f"sh lmax 5, 3 layers, nao_max {args.nao}, {'SOC (so3 head)' if args.soc else 'no SOC'}{', lite_mode' if args.lite else ''}, backbone+head forward",
                       "parallelism": "single GPU" if world == 1 else f"pair-sharded edges x{world} + RCCL all-reduce of node aggregates"},
            "roofline": roofline, "compile_s": compile_s}
     if per_rank is not None:
@@ -409,7 +411,7 @@ def main():
                     with tempfile.TemporaryDirectory() as td:
                         pth = os.path.join(td, "acc.pt")
                         torch.save({"graph": small, "backbone": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                                    "head": {k: v.detach().cpu() for k, v in head.state_dict().items()}, "H": Hs, "irreps": irreps, "nao": args.nao,
+                                    "head": {k: v.detach().cpu() for k, v in head.state_dict().items()}, "H": Hs, "irreps": irreps, "nao": args.nao, "lite": args.lite,
                                     "what": f"sub-crystal of the {args.workload} generator"}, pth)
                         cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--accuracy-from", pth],
                                             capture_output=True, text=True, timeout=240, env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
@@ -421,7 +423,7 @@ def main():
             import subprocess
             try:
                 cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload,
-                                     "--irreps", args.irreps, "--nao", str(args.nao)], capture_output=True, text=True, timeout=150,
+                                     "--irreps", args.irreps, "--nao", str(args.nao)] + (["--lite"] if args.lite else []), capture_output=True, text=True, timeout=150,
                                     env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
                 line = [l for l in cp.stdout.splitlines() if l.startswith("CPU_BASELINE ")][-1]
                 res["cpu_baseline"] = json.loads(line[len("CPU_BASELINE "):])

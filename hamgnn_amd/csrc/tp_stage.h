@@ -106,6 +106,13 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
 #ifndef HG_STAGE_FUSE_LMAX
 #define HG_STAGE_FUSE_LMAX 6     // both node sources rotated in one pass up to this l (csrc/tp_st.hip carries its stream state through the staging: 3)
 #endif
+// piece index t -> (component a, channel piece p): t / P1 through the reciprocal (t < 2^9, P1 <= 16: (t + 0.5) / P1 is never within 0.03 of an
+// integer, so the float product rounds to the right side); an integer division per piece cost as much as the piece's own loads + FMAs at l = 0
+#ifndef HG_STAGE_IDIV
+#define HG_DIV_P1(t) ((int)(((float)(t) + 0.5f) * inv_P1))
+#else
+#define HG_DIV_P1(t) ((t) / P1)
+#endif
 #ifndef HG_STAGE_U
 #define HG_STAGE_U(L) 1          // measured (profiles/r02_tp_is_experiments.md): 2-4 pieces in flight per step are SLOWER (8.39 vs 8.13 ms)
 #endif
@@ -120,6 +127,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
     const int s0 = P[0], s1 = P[1], in_off = P[2], in_mulp = P[3], nsrc = P[5];
     const int g = lane >> 4, el = lane & 15;
     const int P1 = in_mulp >> 2;
+    const float inv_P1 = 1.0f / (float)P1;
     const int Pfull = N * P1;
     const int nj = (Pfull + 3) >> 2;
     const bool rot0 = (A.rot_mask >> s0) & 1, rot1 = nsrc == 2 && ((A.rot_mask >> s1) & 1);
@@ -147,7 +155,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
             for (int u = 0; u < U; ++u) {
                 int t = t0 + 4 * IS_NW * u;
                 t = t < Pfull ? t : t0;                        // tail: re-read the first piece (result dropped below)
-                const int a = t / P1, p = t - a * P1;
+                const int a = HG_DIV_P1(t), p = t - a * P1;
 #pragma unroll
                 for (int b = 0; b < N; ++b) {
                     v0[u][b] = *reinterpret_cast<const f32x4*>(row0 + b * in_mulp + 4 * p);
@@ -182,7 +190,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
             const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
 #pragma unroll 1
             for (int t = 4 * wave + g; t < Pfull; t += 4 * IS_NW) {
-                const int a = t / P1, p = t - a * P1;
+                const int a = HG_DIV_P1(t), p = t - a * P1;
                 f32x4 v[N];
                 float d[N];
 #pragma unroll

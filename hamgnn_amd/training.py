@@ -154,6 +154,9 @@ def _invalidate(module):
         for attr in ("_dp", "_dp_adj", "_adj_tabs"):             # (`_wgrad` is handed over by the blocks' compile(): its device constants are reused)
             if hasattr(m, attr):
                 setattr(m, attr, None)
+        if hasattr(m, "_rowprog"):                             # HamLayer's fused inference chain: its 0.1 s host build per step is not worth it while
+            m._rowprog = None                                  # the weights move (the backward re-evaluates the stages one by one anyway)
+            m._rowprog_off = True
         if hasattr(m, "_compiled_for"):
             m._compiled_for = None
 

@@ -144,6 +144,19 @@ int hg_tp_wgrad(const float* const* src, const int64_t* src_stride, int nsrc_slo
                 float* acc, int64_t acc_floats, int nsplit, const int32_t* units, int nunits, const float* weights, const int32_t* chtab,
                 int lds_bytes, int64_t rows, void* stream);
 
+/* A chain of row-local stages on planar feature rows (csrc/rowprog.hip; tables: hamgnn_amd/plan.py:build_row_program): HamLayer.forward
+ * (hamgnn/models/hamgnn_output.py:51-58) = linear_transform(x + Linear2(Gate(Linear1(x)))) -- ResidualBlock.forward
+ * (hamgnn/nn/interaction_blocks.py:332-358) followed by an o3.Linear -- as ONE pass: 16 rows staged in LDS, every stage LDS -> LDS.
+ * x [rows, din] (optionally gathered by row_idx), y [rows, dout] (+ up to two residual row tensors added on the way out).
+ * stages int32[nstages][24], units int32[.][12], weights (A-operand fragments), act_tab / out_tab int32[.][2] (the gates' tables as
+ * hg_gate's, concatenated: nact / nout entries in all; staged in LDS when they fit), consts_host float[5] (normalize2mom constants by activation id, HOST memory), in_buf / out_buf (which of
+ * the two LDS buffers holds the input / the result), rs_a / rs_b (LDS row strides in floats), strip (floats per wave for activations). */
+int hg_row_program(const float* x, int64_t x_stride, const int64_t* row_idx, int din, float* y, int64_t y_stride, int dout,
+                   const float* res0, int64_t res0_stride, const float* res1, int64_t res1_stride,
+                   const int32_t* stages, int nstages, const int32_t* units, const float* weights, const int32_t* act_tab,
+                   const int32_t* out_tab, int nact, int nout, const float* consts_host, int in_buf, int out_buf, int rs_a, int rs_b, int strip,
+                   int64_t rows, void* stream);
+
 /* torch_scatter.scatter(messages, receiver, dim_size=N) of ConvBlockE3.forward (hamgnn/nn/convolution.py:147-149) as a
  * deterministic segmented reduction: out[n] = sum_{q in [rowptr[n], rowptr[n+1])} msg[perm[q]].                     */
 int hg_segment_sum(const float* msg, int64_t msg_stride, const int64_t* rowptr, const int64_t* perm, int64_t N, int Dp,

@@ -8,7 +8,7 @@ mkdir -p ../lib/variants
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   ( for f in tp_is tp_st tp_wgrad; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include $flags -c $f.hip -o ../lib/variants/${f}_$name.o; done
-    hipcc --offload-arch=gfx950 -shared -fPIC ../lib/tp_fused.o ../lib/variants/tp_is_$name.o ../lib/variants/tp_st_$name.o ../lib/variants/tp_wgrad_$name.o ../lib/aux_kernels.o ../lib/head.o ../lib/attention.o ../lib/linear.o -o ../lib/variants/lib_$name.so
+    hipcc --offload-arch=gfx950 -shared -fPIC ../lib/tp_fused.o ../lib/variants/tp_is_$name.o ../lib/variants/tp_st_$name.o ../lib/variants/tp_wgrad_$name.o ../lib/aux_kernels.o ../lib/head.o ../lib/attention.o ../lib/linear.o ../lib/rowprog.o -o ../lib/variants/lib_$name.so
     rm -f ../lib/variants/tp_is_$name.o ../lib/variants/tp_st_$name.o ../lib/variants/tp_wgrad_$name.o ) &
 done
 wait

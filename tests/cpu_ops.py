@@ -142,6 +142,15 @@ def tp_wgrad(dwf, srcs, g, h_node, h_edge, nsplit=None):
     return _t(acc), [_t(a) for a in gs]
 
 
+def row_program(drp, x, res=(), row_idx=None, tag="row_program"):
+    """stand-in of ops.row_program: the kernel's numpy twin on the tables and the weight blob the device object holds"""
+    import copy
+    rp = copy.copy(drp.rp)
+    rp.weights = _np(drp.weights)
+    xin = _np(x if row_idx is None else x[row_idx.long()])
+    return _t(emu.run_row_program(rp, xin, [_np(r) for r in res]))
+
+
 def linear_planar(dl, x, res=(), tag="linear"):
     return _t(emu.run_linear_tables(dl.tabs, _np(x), [_np(r) for r in res if r is not None]))
 
@@ -362,7 +371,7 @@ def install(mp):
     mp.setattr(ops, "_require_gpu", lambda t: None)
     mp.setattr(ops, "Geometry", Geometry)
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
-    for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
+    for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "row_program", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
                  "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "block_mean", "soc_assemble", "attention_aggregate",
                  "attention_logits", "hk_assemble", "zero_point_shift"):
         mp.setattr(ops, name, globals()[name])

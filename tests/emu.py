@@ -538,3 +538,55 @@ def run_wgrad_fused(wf, srcs, g, h2, nsplit=1, dtype=np.float64):
                 full[:, :g_mulp] = gL
                 acc[split, accoff + nsrc * G1 * 256:accoff + (nsrc * G1 + G2) * 256] += full.reshape(16, G2, 16).transpose(1, 0, 2).reshape(-1)
     return acc, gs
+
+
+def _rp_act(x, aid):
+    from hamgnn_amd import plan as P
+    c = float(P.ACT_CONSTS[aid])
+    if aid == P.ACT_SSP:
+        return c * (np.logaddexp(0.0, x) - math.log(2.0))
+    if aid == P.ACT_TANH:
+        return c * np.tanh(x)
+    if aid == P.ACT_SILU:
+        return c * x / (1.0 + np.exp(-x))
+    if aid == P.ACT_ABS:
+        return c * np.abs(x)
+    return x
+
+
+def run_row_program(rp, x, res=(), dtype=np.float64):
+    """numpy twin of csrc/rowprog.hip on plan.RowProgram tables: x [rows, din] planar rows -> [rows, dout]; res: rows added to the result.
+    The units are decoded from the packed A-operand fragments (validates the packing), the LDS buffers are arrays of the planned strides."""
+    from hamgnn_amd import plan as P
+    rows = x.shape[0]
+    buf = [np.full((rows, rp.rs[0]), np.nan, dtype=dtype), np.full((rows, rp.rs[1]), np.nan, dtype=dtype)]      # NaN: a read of something never written shows up
+    buf[rp.in_buf][:, :rp.din] = x
+    W = rp.weights.astype(dtype)
+    for st in rp.stages.astype(np.int64):
+        if st[0] == P.RP_GATE:
+            b = buf[st[1]]
+            act = rp.act_tab[st[3]:st[3] + st[4]]
+            out = rp.out_tab[st[5]:st[5] + st[6]]
+            for i, a_ in act:                                  # in place
+                b[:, int(i)] = _rp_act(b[:, int(i)], int(a_))
+            res_ = np.zeros((rows, int(st[6])), dtype=dtype)
+            for p_, (src, gate) in enumerate(out):
+                if src >= 0:
+                    res_[:, p_] = b[:, src] * (b[:, gate] if gate >= 0 else 1.0)
+            b[:, :int(st[6])] = res_
+            continue
+        src, dst = buf[st[1]], buf[st[2]]
+        for w_ in range(P.RP_NW):
+            for u in rp.units[st[3 + w_]:st[4 + w_]].astype(np.int64):
+                in_off, in_mulp, nsteps, out_off, out_mulp, ncomp, nv4, woff, acc = u[:9]
+                G = -(-nsteps // 4)
+                Wm = _unfrag_natural(W[woff:woff + G * 256].reshape(G, 64, 4), 4 * nsteps, 16) if nsteps else np.zeros((0, 16))      # [K, 16 channels]
+                for m in range(ncomp):
+                    val = src[:, in_off + m * in_mulp:in_off + m * in_mulp + 4 * nsteps] @ Wm if nsteps else np.zeros((rows, 16))
+                    sl = slice(out_off + m * out_mulp, out_off + m * out_mulp + 4 * nv4)
+                    dst[:, sl] = (dst[:, sl] if acc else 0.0) + val[:, :4 * nv4]
+    out = buf[rp.out_buf][:, :rp.dout].copy()
+    for r in res:
+        out += r
+    assert np.isfinite(out).all()
+    return out
