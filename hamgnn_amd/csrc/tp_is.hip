@@ -295,6 +295,239 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #undef IS_A2_EARLY
 }
 
+// lite_mode items (message_passing.py:197-206: unweighted uvu product folded with its o3.Linear block), rows = output channels:
+//   typ 2 (IT_LINC): tile[w, m] += cf[m] * sum_u A[u, w] x[u, src(m)]        one path (i, l_sh, k): one weight matrix, a coefficient per column
+//   typ 4 (IT_LINM): tile[w, m] += sum_u A_m[u, w] x[u, src(m)]              ALL paths of (i, k) folded: A_m = sum_paths cf_path[m] A_path
+// one column at a time (the accumulators of one column only), natural-K operands, the next fragment group requested under the MFMAs
+template <int RTM>
+__device__ __forceinline__ void item_lite(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
+    const int typ = it[0], so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], mm = it[6], neg = it[7], ksteps = it[8], x4 = it[17];
+    const int g = lane >> 4, el = lane & 15;
+    const int nc = 2 * mm + 1;
+    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23] + it[16];
+    float* __restrict__ tbase = lds + A.tile_shift + (el - mm * 16);      // (split launches without a post-op: this wave's private tile copy)
+    const float* __restrict__ stage = lds + A.stage_off;
+    const int nsrc = so1 >= 0 ? 2 : 1;
+    const int ngrp = (ksteps + 3) >> 2;
+    const int P1 = in_mulp >> 2;
+    const int cdir = neg ? -P1 : P1;
+    const int c0p = (li - mm) * P1 + (neg ? (nc - 1) * P1 : 0);
+    const int colstride = typ == 4 ? it[13] : 0;               // floats between the fragment sets of two columns
+    int roff[RTM][4];
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) roff[rt][r] = rtab[16 * rt + 4 * g + r];
+    const int nfr = nsrc * ngrp;
+#pragma unroll 1
+    for (int c = 0; c < nc; ++c) {
+        const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11] + c * colstride) + lane;      // [src][G][rt][lane]
+        const float cfc = typ == 2 ? Wb[it[13] + c] : 1.f;
+        f32x4 acc[RTM], av_n[RTM];
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) {
+            acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            av_n[rt] = aw[rt * 64];
+        }
+#pragma unroll 1
+        for (int f = 0; f < nfr; ++f) {
+            const int si = f >= ngrp, G = f - si * ngrp;
+            const float* __restrict__ fb = stage + (si ? so1 : so0) + (c0p + c * cdir + 4 * G) * 64 + el * 4 + g;
+            f32x4 av[RTM];
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+            if (f + 1 < nfr) {
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((f + 1) * RTM + rt) * 64];
+            }
+            const int nq = ksteps - 4 * G;
+            float b[4];
+            if (x4) {                                          // permuted K (unfolded items whose channel block is a multiple of 16): one float4
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(stage + (si ? so1 : so0) + (c0p + c * cdir + 4 * G + g) * 64 + el * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = bv[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = q < nq ? fb[q * 64] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + c * 16] += cfc * acc[rt][r];
+    }
+}
+
+// IT_LINM with a deep weight ring: the item's fragments are ONE linear stream [column][source][K group][row tile]; a step (column c, fragment f)
+// issues 4 RTM MFMAs -- far fewer than an L2 round trip lasts -- so the fragments of step t + LM_RING are requested when step t starts
+// (ring slots are fixed registers: no shifting).  Measured: one-step look-ahead 48.8 ms per 822 k-edge launch, this ring see profiles/r03_lite.md
+#ifndef LM_RING
+#define LM_RING 4
+#endif
+template <int RTM>
+__device__ __forceinline__ void item_lite_m(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
+    const int so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], mm = it[6], neg = it[7], ksteps = it[8];
+    const int g = lane >> 4, el = lane & 15;
+    const int nc = 2 * mm + 1;
+    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23] + it[16];
+    float* __restrict__ tbase = lds + A.tile_shift + (el - mm * 16);      // (split launches without a post-op: this wave's private tile copy)
+    const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
+    const int nsrc = so1 >= 0 ? 2 : 1;
+    const int ngrp = (ksteps + 3) >> 2;
+    const int P1 = in_mulp >> 2;
+    const int cdir = neg ? -P1 : P1;
+    const int c0p = (li - mm) * P1 + (neg ? (nc - 1) * P1 : 0);
+    const int nfr = nsrc * ngrp, nsteps = nc * nfr;
+    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t, row tile rt: aw[(t * RTM + rt) * 64]
+    int roff[RTM][4];
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) roff[rt][r] = rtab[16 * rt + 4 * g + r];
+    f32x4 ring[LM_RING][RTM], acc[RTM];
+#pragma unroll
+    for (int j = 0; j < LM_RING; ++j)
+        if (j < nsteps) {
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
+        }
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int c = 0, f = 0;
+#pragma unroll 1
+    for (int t0 = 0; t0 < nsteps; t0 += LM_RING) {
+#pragma unroll
+        for (int j = 0; j < LM_RING; ++j) {
+            const int t = t0 + j;
+            if (t < nsteps) {                                  // uniform
+                f32x4 av[RTM];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
+                if (t + LM_RING < nsteps) {
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + LM_RING) * RTM + rt) * 64];
+                }
+                const int si = f >= ngrp, G = f - si * ngrp;
+                const float* __restrict__ fb = stage + (si ? so1 : so0) + (c0p + c * cdir + 4 * G) * 64;
+                const int nq = ksteps - 4 * G;
+                float b[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[q] = q < nq ? fb[q * 64] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
+                if (++f == nfr) {                              // column complete: add into the tile
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) {
+#pragma unroll
+#ifndef HG_ABL_LINM_NOWB
+                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + c * 16] += acc[rt][r];
+#else
+                        if (acc[rt][0] == 1.2345f) tbase[roff[rt][0]] = 0.f;
+#endif
+                        acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                    f = 0;
+                    ++c;
+                }
+            }
+        }
+    }
+}
+
+// lite_mode segment post-op (message_passing.py:209-215: combine_messages = LinearScaleWithWeights on the summed branches), the last phase of a
+// lite program's part: tile[v, m] <- sum_w Lc[w, v] * s_e[w] * tile[w, m] with s_e = W3^T h2 by MFMA, in place per chunk of four columns
+// (every row of a column is read before one is written; the segment belongs to this wave alone in its phase).
+template <int RTO>
+__device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds,
+                                        int64_t erow, int lane) {
+    const int g = lane >> 4, el = lane & 15;
+    const int lk = it[20], mul_k = it[21];
+    const int nco = 2 * lk + 1;
+    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23];
+    float* __restrict__ tb = lds + (el - lk * 16);
+    const float* __restrict__ hrow = A.h2[0] + erow * A.hidden + 4 * g;
+    const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;          // [G][rto][lane]
+    const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;          // [rtp][rt][lane]
+    // all loop bounds are compile-time (RTO row tiles, hidden = 64): the loads of a stage are issued together (the run-time-bounded version
+    // exposed one L2 round trip per fragment: ~35 us per 64-channel segment and 16 edges)
+    f32x4 S[RTO];
+#pragma unroll
+    for (int rt = 0; rt < RTO; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int hgrp = A.hidden >> 4;
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        if (G < hgrp) {
+            const f32x4 hb = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
+            f32x4 wv[RTO];
+#pragma unroll
+            for (int rt = 0; rt < RTO; ++rt) wv[rt] = w3[(G * RTO + rt) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RTO; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rt][q], hb[q], S[rt], 0, 0, 0);
+        }
+    }
+    for (int G = 4; G < hgrp; ++G) {                           // (hidden > 64)
+        const f32x4 hb = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
+#pragma unroll
+        for (int rt = 0; rt < RTO; ++rt) {
+            const f32x4 wv = w3[(G * RTO + rt) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[q], hb[q], S[rt], 0, 0, 0);
+        }
+    }
+    int rowoff[RTO][4];                                         // rows beyond mul_k (fragment padding): the trash row
+#pragma unroll
+    for (int rt = 0; rt < RTO; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowoff[rt][r] = rtab[16 * rt + 4 * g + r];
+    f32x4 av[RTO][RTO];                                         // the segment's Lc fragments, resident for all its columns
+#pragma unroll
+    for (int rtp = 0; rtp < RTO; ++rtp)
+#pragma unroll
+        for (int rt = 0; rt < RTO; ++rt) av[rtp][rt] = a2[(rtp * RTO + rt) * 64];
+    constexpr int CH = RTO >= 3 ? 2 : 4;                        // columns per chunk (register budget)
+#pragma unroll 1
+    for (int c0 = 0; c0 < nco; c0 += CH) {
+        f32x4 md[RTO][CH];
+#pragma unroll
+        for (int rt = 0; rt < RTO; ++rt)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int cc = c0 + c < nco ? c0 + c : c0;      // tail: recompute column c0 (dropped below)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) md[rt][c][r] = (16 * rt + 4 * g + r < mul_k) ? tb[rowoff[rt][r] + cc * 16] * S[rt][r] : 0.f;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int rtp = 0; rtp < RTO; ++rtp) {
+            f32x4 acc[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rt = 0; rt < RTO; ++rt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rtp][rt][r], md[rt][c][r], acc[c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if (c0 + c < nco) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tb[rowoff[rtp][r] + (c0 + c) * 16] = acc[c][r];
+                }
+        }
+    }
+}
+
 #ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
 #define IS_CASE(MMv, RTMv) \
     case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
@@ -319,7 +552,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 // so all waves can work on one output segment at once; the copies are summed before the epilogue.
 #define IS_PART_I32 12
 
-template <bool SPLIT>
+template <bool SPLIT, bool LITE>
 __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
                                                        const int* __restrict__ g_phases, const int* __restrict__ g_groups,
                                                        const int* __restrict__ g_items, const float* __restrict__ g_W,
@@ -411,6 +644,31 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
 #endif
             for (int ii = ib; ii < ie; ++ii) {
                 const int* __restrict__ it = g_items + ii * 24;
+                if (LITE) {                                    // lite_mode programs: their own (small) items, their own kernel instantiation
+#ifdef HG_ABL_NOPOST
+                    if (it[0] == 3) continue;
+#endif
+#ifdef HG_ABL_NOLINM
+                    if (it[0] != 3) continue;
+#endif
+#ifdef HG_ABL_LINM_NOWB
+#endif
+                    if (it[0] == 3) {                          // post-op of one segment (the part's last phase)
+                        if (it[22] == 1) post_is<1>(A, g_W, it, lds, erow, lane);
+                        else if (it[22] == 2) post_is<2>(A, g_W, it, lds, erow, lane);
+                        else if (it[22] == 3) post_is<3>(A, g_W, it, lds, erow, lane);
+                        else post_is<4>(A, g_W, it, lds, erow, lane);
+                    }
+                    else if (it[0] == 4 && it[9] == 1) item_lite_m<1>(A, g_W, it, lds, lane);
+                    else if (it[0] == 4 && it[9] == 2) item_lite_m<2>(A, g_W, it, lds, lane);
+                    else if (it[0] == 4 && it[9] == 3) item_lite_m<3>(A, g_W, it, lds, lane);
+                    else if (it[0] == 4) item_lite_m<4>(A, g_W, it, lds, lane);
+                    else if (it[9] == 1) item_lite<1>(A, g_W, it, lds, lane);
+                    else if (it[9] == 2) item_lite<2>(A, g_W, it, lds, lane);
+                    else if (it[9] == 3) item_lite<3>(A, g_W, it, lds, lane);
+                    else item_lite<4>(A, g_W, it, lds, lane);
+                    continue;
+                }
                 switch (it[6] * 8 + it[9] + ((it[0] == 0 && it[7]) ? 64 : 0)) {
 #if IS_NW > 4                      // three waves per SIMD: 168 VGPRs per wave, row-tile table 2,2,2,1,1,1,1 (HG_RTM)
                     IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(3, 1) IS_CASE(4, 1) IS_CASE(5, 1)
@@ -552,15 +810,23 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
     A.rot_mask = rot_mask;
     if (rot_mask && !wig) return hg_fail(-2, "hg_tp_is: rotated sources need the Wigner rows");
-    static unsigned char lds_attr_done[2][HG_MAX_DEVICES];     // once per device (not a stream operation: illegal during graph capture)
-    if (int rc = hg_lds_attr_once(lds_attr_done[0], dev_guard.dev, (const void*)tp_is_kernel<false>, 160 * 1024)) return rc;
-    if (int rc = hg_lds_attr_once(lds_attr_done[1], dev_guard.dev, (const void*)tp_is_kernel<true>, 160 * 1024)) return rc;
+    static unsigned char lds_attr_done[4][HG_MAX_DEVICES];     // once per device (not a stream operation: illegal during graph capture)
+    if (int rc = hg_lds_attr_once(lds_attr_done[0], dev_guard.dev, (const void*)tp_is_kernel<false, false>, 160 * 1024)) return rc;
+    if (int rc = hg_lds_attr_once(lds_attr_done[1], dev_guard.dev, (const void*)tp_is_kernel<true, false>, 160 * 1024)) return rc;
+    if (int rc = hg_lds_attr_once(lds_attr_done[2], dev_guard.dev, (const void*)tp_is_kernel<false, true>, 160 * 1024)) return rc;
+    if (int rc = hg_lds_attr_once(lds_attr_done[3], dev_guard.dev, (const void*)tp_is_kernel<true, true>, 160 * 1024)) return rc;
     const unsigned grid = (unsigned)((rows + 15) / 16);
-    if (nparts == 1)
-        hipLaunchKernelGGL(tp_is_kernel<false>, dim3(grid), dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table,
-                           group_table, item_table, weights, part_table, row_table);
-    else
-        hipLaunchKernelGGL(tp_is_kernel<true>, dim3(grid, (unsigned)nparts), dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table,
-                           phase_table, group_table, item_table, weights, part_table, row_table);
+    const bool lite = p0[11] != 0;                             // part record [11]: the program holds lite_mode items (plan.is_schedule)
+#define IS_LAUNCH(SPLITv, LITEv, GRID) \
+    hipLaunchKernelGGL((tp_is_kernel<SPLITv, LITEv>), GRID, dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table, \
+                       group_table, item_table, weights, part_table, row_table)
+    if (nparts == 1) {
+        if (lite) IS_LAUNCH(false, true, dim3(grid));
+        else IS_LAUNCH(false, false, dim3(grid));
+    } else {
+        if (lite) IS_LAUNCH(true, true, dim3(grid, (unsigned)nparts));
+        else IS_LAUNCH(true, false, dim3(grid, (unsigned)nparts));
+    }
+#undef IS_LAUNCH
     return hg_check_launch("hg_tp_is");
 }

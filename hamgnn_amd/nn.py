@@ -205,11 +205,23 @@ class MessagePackBlock(nn.Module):
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
         self._wgrad_fused = None                               # (tables hold the weights: rebuilt on first use)
         if self.lite_mode:
-            prog = P.build_message_pack_program_lite(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
             if skip_weight is not None:                        # PairInteractionBlock skip o3.Linear: must come AFTER the combine post-op
                 raise NotImplementedError
             self._hn = self.weight_generator_combine.hidden_layers(device)
             self._he = None
+            self._plain_args = None
+            if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg":
+                # input-stationary kernel (r3): the paths of every (input irrep, output irrep) pair folded into one item (IT_LINM), the
+                # combine post-op as the last phase; such a program has no segment-stationary form
+                try:
+                    args = (sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
+                    self._dp = ops.DeviceProgram(P.build_message_pack_program_lite(*args, fold=os.environ.get("HG_LITE_FOLD", "1") != "0"), device, schedule="is")
+                    return self
+                except NotImplementedError:
+                    pass
+            prog = P.build_message_pack_program_lite(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate)
+            self._dp = ops.DeviceProgram(prog, device, schedule="seg")
+            return self
         else:
             self._hn = self.node_weight_generator.hidden_layers(device)
             self._he = self.edge_weight_generator.hidden_layers(device)

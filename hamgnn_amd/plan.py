@@ -36,6 +36,7 @@ IT_TP = 0        # GEMM1 -> radial scale * CG coef -> GEMM2 -> add into segment 
 IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, add into tile
 IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: aligned-frame CG coefficient per m)
 IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
+IT_LINM = 4      # lite_mode, ALL paths (i, l_sh, k) of one (i, k) folded: one weight matrix per column, A_m = sum_paths cf_path[m] A_path (input-stationary kernel only)
 # segment flags
 SEG_UNROTATE = 1     # epilogue applies D^l(R_e)^T (messages go back to the global frame before the node scatter)
 
@@ -284,10 +285,13 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSched
     blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots.
     separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (st_schedule: the wave keeps the
     hidden rows of the phase's generator in registers); phase_table[:, 2] then holds that generator instead of the group range."""
-    if (prog.item_table[:, 0] == IT_POST).any() or (prog.item_table[:, 0] == IT_LINC).any():
-        raise NotImplementedError("lite_mode programs run on the segment-stationary kernel")
+    if separate_mlp and np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any():
+        raise NotImplementedError("lite_mode programs have no streamed schedule")
     hp4 = prog.hidden_pad // 4
     nseg = prog.seg_table.shape[0]
+    lite_flag = int(np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any())      # lite_mode items run in their own kernel instantiation
+    if lite_flag and np.isin(prog.item_table[:, 0], (IT_TP, IT_LIN)).any():
+        raise NotImplementedError("input-stationary schedule: a program mixes lite_mode items with tensor-product / Linear items")
     key_of = [prog.seg_key.get(sg, sg) for sg in range(nseg)]   # segments written by merged items share one work-group key
     seg_cost = np.zeros(nseg)
     for rec in prog.item_table:
@@ -317,7 +321,7 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSched
         sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
                                 split=parts > 1, separate_mlp=separate_mlp)
         parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
-                        sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), 0])
+                        sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag])
         rowtab_all += sub["rowtab"]
         phase_cls_all += sub["phase_cls"]
         segs_all += list(sub["segs"])
@@ -353,7 +357,10 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     # would keep a single wave busy.  Taken when the four copies leave room for the largest input block.
     copy_stride = 0
     tiles_end = off + maxstride                                # one copy: the tiles, then the trash row (as wide as the widest tile)
-    if split:
+    # lite_mode programs end with a post-op per segment (IT_POST: tile <- Lc^T (s * tile)) that runs as the part's LAST phase, on the one
+    # shared copy of the tiles: no private copies then
+    post_items = [rec for rec in prog.item_table if int(rec[19]) in local and int(rec[0]) == IT_POST]
+    if split and not post_items:
         need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256
                    for r in prog.item_table if int(r[19]) in local)
         ntab = sum(int(s[2]) * 16 for s in segs) + 4 + 16 * sum(ceil_div(sum(int(prog.seg_table[m][1]) for m in v), 16) for v in prog.vsegs)
@@ -392,7 +399,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     # ---- input blocks read by this part's items
     blocks: Dict[Tuple[int, int, int], dict] = {}
     for rec in prog.item_table:
-        if int(rec[19]) not in local:
+        if int(rec[19]) not in local or int(rec[0]) == IT_POST:
             continue
         key = (int(rec[1]), int(rec[2]), int(rec[3]))
         if int(rec[5]) > 6:
@@ -453,6 +460,20 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         crit += max(loads)
         ptab.append([block_base + b0, block_base + len(btab), group_base + g0, group_base + len(gtab)])
         phase_cls.append(_cls(ph) or 0)
+    if post_items:                                             # the last phase: nothing staged, one work group per segment's post-op, dearest first
+        g0 = len(gtab)
+        pc = lambda r: int(prog.seg_table[int(r[19])][2]) * (hp4 + int(prog.seg_table[int(r[19])][2]) * 4 * (2 * int(prog.seg_table[int(r[19])][0]) + 1)) + 60
+        loads = [0] * IS_WAVES
+        for rec in sorted(post_items, key=lambda r: -pc(r)):
+            r = rec.copy()
+            r[1], r[2], r[3] = 0, -1, 0
+            loads[loads.index(min(loads))] += pc(rec)
+            gtab.append([item_base + len(items), item_base + len(items) + 1])
+            items.append(r)
+        tot += sum(loads)
+        crit += max(loads)
+        ptab.append([block_base + len(btab), block_base + len(btab), group_base + g0, group_base + len(gtab)])
+        phase_cls.append(0)
     # ---- epilogue: Wigner blocks of the un-rotated segments staged in as few batches as fit the staging area (one block per l)
     need = {}
     for sg in segs:
@@ -2058,9 +2079,14 @@ def shell_block_table(row: Irreps, nao) -> np.ndarray:
 
 
 def add_lite_branch_items(prog: Program, seg_of_k, in_layout: PlanarLayout, nsrc, srcs, irreps_sh: Irreps, irreps_out: Irreps,
-                          lin_w: np.ndarray):
+                          lin_w: np.ndarray, fold: bool = False):
     """lite_mode branch (message_passing.py:197-206): unweighted uvu tensor product followed by o3.Linear(mid.simplify()->out),
-    i.e. per path p = (i, l_sh, k):  tile_k[w'', m] += coef_p[m] * sum_u (sqrt(2 l_k+1)/sqrt(fan_k) L_k[(p,u), w'']) x'_i[u, src_p(m)]."""
+    i.e. per path p = (i, l_sh, k):  tile_k[w'', m] += coef_p[m] * sum_u (sqrt(2 l_k+1)/sqrt(fan_k) L_k[(p,u), w'']) x'_i[u, src_p(m)].
+    fold (input-stationary kernel only): all paths of one (i, k) share the input block, the column map and its direction (the parity of
+    l_i + l_sh + l_k is fixed by the parities of i and k), so they fold into ONE item with a weight matrix per column,
+    A_m = sum_p coef_p[m] A_p (IT_LINM): 1 / (number of l_sh per pair) of the MFMAs and of the items."""
+    if fold:
+        return _add_lite_branch_items_folded(prog, seg_of_k, in_layout, nsrc, srcs, irreps_sh, irreps_out, lin_w)
     irr_in = Irreps([(m * nsrc, l, p) for m, l, p in in_layout.irreps])
     ins = tp_instructions(irr_in, irreps_sh, irreps_out)          # slot order = sorted by output irrep (stable), as the reference
     by_k: Dict[int, List[int]] = {}
@@ -2098,6 +2124,29 @@ def add_lite_branch_items(prog: Program, seg_of_k, in_layout: PlanarLayout, nsrc
                               a1_off, 0, cf_off, 0, r1 - r0, row_off=r0 - c0)
             prog.flops_per_row += 2.0 * mi2 * mk * nc
     assert off == lin_w.size, (off, lin_w.size)
+
+
+def _add_lite_branch_items_folded(prog: Program, seg_of_k, in_layout: PlanarLayout, nsrc, srcs, irreps_sh, irreps_out, lin_w):
+    pairs: Dict[Tuple[int, int], dict] = {}
+    for pth in lite_paths(in_layout, nsrc, irreps_sh, irreps_out, lin_w):
+        q = pairs.setdefault((pth["i"], pth["k"]), dict(pth, Wc=np.zeros((2 * pth["mm"] + 1,) + pth["Wp"].shape)))
+        assert (q["par"], q["mm"]) == (pth["par"], pth["mm"])
+        q["Wc"] += pth["cf"][:, None, None] * pth["Wp"][None]
+        prog.flops_per_row += 2.0 * pth["Wp"].shape[0] * pth["mk"] * (2 * pth["mm"] + 1)
+    for (i, k), q in pairs.items():
+        mi, mm, li = q["mi"], q["mm"], q["li"]
+        nc = 2 * mm + 1
+        ksteps = in_layout.mulp[i] // 4
+        chunk = rtm_max(nc) * 16
+        for seg, c0, c1 in prog.seg_chunks[k]:
+            for r0 in range(c0, c1, chunk):
+                r1 = min(c1, r0 + chunk)
+                rtm = ceil_div(r1 - r0, 16)
+                frags = np.stack([np.stack([_frag_A(q["Wc"][c, s_ * mi:(s_ + 1) * mi, r0:r1], ksteps, rtm, False) for s_ in range(nsrc)]) for c in range(nc)])
+                a1_off = prog.add_weights(frags)                # [column][source][G][rt][64][4]
+                _add_item(prog, seg, IT_LINM, list(srcs), in_layout.off[i], in_layout.mulp[i], li, mm, q["par"], ksteps, rtm, 0,
+                          a1_off, 0, int(frags[0].size), 0, r1 - r0, row_off=r0 - c0)
+                prog.seg_items[seg][-1][17] = 0                 # natural-K operands
 
 
 def lite_paths(in_layout: PlanarLayout, nsrc, irreps_sh, irreps_out, lin_w: np.ndarray):
@@ -2160,15 +2209,17 @@ def build_message_pack_lite_adjoint_program(sd: Dict[str, np.ndarray], irreps_no
     return prog.finalize()
 
 
-def build_message_pack_program_lite(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool, post: bool = True) -> Program:
+def build_message_pack_program_lite(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool, post: bool = True,
+                                    fold: bool = False) -> Program:
     """MessagePackBlock with lite_mode=True (message_passing.py:197-215) as one fused-kernel program.  post=False: without the combine
-    post-op (the pre-combine rows t that the backward's reductions read)."""
+    post-op (the pre-combine rows t that the backward's reductions read).  fold: the paths of every (input irrep, output irrep) pair as one
+    IT_LINM item (input-stationary kernel; the segment-stationary kernel runs the unfolded IT_LINC items)."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
     _, w3 = _last_layer(sd, "weight_generator_combine")
     H = w3.shape[0]
     prog, seg_of_k = new_program(irreps_out, H, lambda k, ir: SEG_UNROTATE if unrotate else 0)
-    add_lite_branch_items(prog, seg_of_k, PlanarLayout(irreps_node), 2, [SRC_XS, SRC_XD], irreps_sh, irreps_out, np.asarray(sd["node_linear_scaler.weight"]))
-    add_lite_branch_items(prog, seg_of_k, PlanarLayout(irreps_edge), 1, [SRC_F], irreps_sh, irreps_out, np.asarray(sd["edge_linear_scaler.weight"]))
+    add_lite_branch_items(prog, seg_of_k, PlanarLayout(irreps_node), 2, [SRC_XS, SRC_XD], irreps_sh, irreps_out, np.asarray(sd["node_linear_scaler.weight"]), fold)
+    add_lite_branch_items(prog, seg_of_k, PlanarLayout(irreps_edge), 1, [SRC_F], irreps_sh, irreps_out, np.asarray(sd["edge_linear_scaler.weight"]), fold)
     # post-op per segment: scale by the radial weights (one per channel of irreps_out.simplify()) and o3.Linear(out -> out)
     w3n = w3 / math.sqrt(H)
     lc = np.asarray(sd["combine_messages.linear_out.weight"])

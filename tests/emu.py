@@ -77,6 +77,25 @@ def _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype):
     nsrc = 2 if s1 >= 0 else 1
     x4 = int(it[17])
     ngrp = -(-ksteps // 4)
+    if typ == P.IT_LINM:                                   # one weight matrix per column (lite_mode paths of one (i, k) folded), natural K
+        assert not x4 and cf == nsrc * ngrp * rtm * 256
+        for c in range(nc):
+            A1 = Wt[a1 + c * cf:a1 + (c + 1) * cf].reshape(nsrc, ngrp, rtm, 4, 16, 4)
+            m = c - mm
+            base = in_off + (li + (-m if neg else m)) * in_mulp
+            for si, sidx in enumerate([s0, s1][:nsrc]):
+                X = srcs[sidx]
+                for G in range(ngrp):
+                    for q in range(4):
+                        if 4 * G + q >= ksteps:
+                            continue
+                        B = np.zeros((4, 16), dtype=dtype)
+                        for g in range(4):
+                            B[g, :ne] = X[cols, base + 4 * (4 * G + q) + g]
+                        for rt in range(rtm):
+                            r0 = row_off + 16 * rt
+                            tile[r0:r0 + 16, lk - mm + c] += A1[si, G, rt, :, :, q].T @ B
+        return tile
     A1 = Wt[a1:a1 + nsrc * ngrp * rtm * 256].reshape(nsrc, ngrp, rtm, 4, 16, 4)      # [src][G][rt][g][i][q]
     mid = np.zeros((rtm, nc, 16, 16), dtype=dtype)
     for si, sidx in enumerate([s0, s1][:nsrc]):
@@ -214,6 +233,23 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                     touched = set()
                     for ii in range(ib, ie):
                         it = sched.item_table[ii].copy()
+                        if int(it[0]) == P.IT_POST:            # lite_mode post-op of one segment (the part's last phase, nothing staged): in place on its tile
+                            assert b0 == b1 and ii not in seen
+                            seen.add(ii)
+                            sg = int(it[19])
+                            seg = sched.seg_table[sg]
+                            lk_, mul_, rto_ = int(seg[0]), int(seg[1]), int(seg[2])
+                            rt = rowtab[int(it[23]):int(it[23]) + 16 * rto_]
+                            tile = np.zeros((16 * rto_, 2 * lk_ + 1, 16), dtype=dtype)
+                            for r in range(mul_):
+                                for c in range(2 * lk_ + 1):
+                                    tile[r, c] = lds[int(rt[r]) + (c - lk_) * 16:int(rt[r]) + (c - lk_) * 16 + 16]
+                            new = _apply_item(prog, Wt, it[:P.ITEM_I32].copy(), srcs, h2, cols, ne, tile, lk_, rto_, dtype)
+                            for r in range(mul_):
+                                for c in range(2 * lk_ + 1):
+                                    lds[int(rt[r]) + (c - lk_) * 16:int(rt[r]) + (c - lk_) * 16 + 16] = new[r, c]
+                            touched.add(sg)
+                            continue
                         s0, s1, in_off, in_mulp, li = staged[int(it[1])]
                         assert (int(it[4]), int(it[5])) == (in_mulp, li) and ((int(it[2]) >= 0) == (s1 >= 0))
                         it[1], it[2], it[3] = s0, s1, in_off

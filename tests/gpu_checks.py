@@ -1653,3 +1653,81 @@ def check_band_cal(device="cuda"):
         gaps.append(abs((eig[half].min() - vbm) - r["band_gap_eV"]))
         assert r["k_dist"].shape == (nk,) and abs(r["k_dist"][-1] - r["k_node"][-1]) < 1e-12 and r["bands_eV"][half - 1].max() == 0.0
     return {"bands_rel_err": worst, "gap_abs_err_eV": max(gaps), "crystals": len(res)}
+
+
+def check_tp_wgrad_kernel(device="cuda", seed=0, irr=None, sh=None, E=150, nsplit=3):
+    """hg_tp_wgrad through the C ABI vs its numpy twin (tests/emu.py:run_wgrad_fused) on the SAME tables and the same random edge-frame rows:
+    accumulator blocks (every split / edge-tile copy) and the per-edge gs rows.  The twin itself is checked against autograd through the fp64
+    oracle in the CPU suite (test_message_pack_weight_gradients_fused_vs_autograd)."""
+    from hamgnn_amd import backward_mp as BM, nn as hnn, ops, plan as P
+    from tests import emu
+    from tests.test_plan_emu import _random_irreps
+    rng = np.random.default_rng(900 + seed)
+    if irr is None:
+        irr = _random_irreps(rng, int(rng.integers(1, 4)))
+        if "0e" not in irr:
+            irr = "5x0e+" + irr
+        lsh = int(rng.integers(1, 4))
+        sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    torch.manual_seed(seed)
+    m = hnn.MessagePackBlock(irr, irr, sh, irr, 8, [16, 64])
+    sd = {k: v.detach().double().numpy() for k, v in m.state_dict().items()}
+    wg = BM.MessagePackWeightGrad(sd, irr, irr, sh, irr)
+    wf = P.build_tp_wgrad_fused(wg.branches, sh, irr, wg.H)
+    lay = P.PlanarLayout(irr)
+    g_ = torch.Generator().manual_seed(seed)
+    xs, xd, fe, g = (torch.from_numpy(lay.to_planar(torch.randn(E, P.Irreps(irr).dim, generator=g_).numpy())).float() for _ in range(4))
+    hn, he = (torch.randn(E, 64, generator=g_) for _ in range(2))
+    dwf = ops.DeviceWgFused(wf, device)
+    acc, gs = ops.tp_wgrad(dwf, [t.to(device) for t in (xs, xd, fe)], g.to(device), hn.to(device), he.to(device), nsplit=nsplit)
+    torch.cuda.synchronize()
+    import copy
+    wf32 = copy.copy(wf)
+    wf32.weights = wf.weights.astype(np.float32).astype(np.float64)       # what the device holds
+    acc_ref, gs_ref = emu.run_wgrad_fused(wf32, [t.double().numpy() for t in (xs, xd, fe)], g.double().numpy(), (hn.double().numpy(), he.double().numpy()), nsplit=nsplit)
+    # only the accumulator slots the gather maps read are defined (padding channels of partial tiles hold products with stale LDS content)
+    used = np.unique(np.concatenate([t.reshape(-1) for t in wf.tp_pos + wf.l_pos]))
+    used = used[used < wf.acc_floats - 1]
+    a, b = acc.double().cpu().numpy().sum(0)[used], acc_ref.sum(0)[used]
+    res = {"acc_rel_err": float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)),
+           "gs_rel_err": max(float(np.abs(x.double().cpu().numpy() - y).max() / max(np.abs(y).max(), 1e-30)) for x, y in zip(gs, gs_ref)),
+           "units": int(wf.units.shape[0]), "irreps": irr, "sh": sh}
+    return res
+
+
+def check_row_program_kernel(device="cuda", seed=0, irr=None, rows=77, nao=13, ham_type="openmx"):
+    """hg_row_program (the fused HamLayer chain) through the C ABI vs the separate kernels (streaming Linear x 3 + gate) AND vs the numpy twin on
+    the same tables, random irreps"""
+    from hamgnn_amd import ops, plan as P
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from tests import emu
+    from tests.test_plan_emu import _random_irreps
+    rng = np.random.default_rng(950 + seed)
+    if irr is None:
+        irr = _random_irreps(rng, int(rng.integers(2, 5)))
+        if "0e" not in irr:
+            irr = "7x0e+" + irr
+    torch.manual_seed(seed)
+    head = HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type=ham_type, ham_only=True, symmetrize=True, add_H0=False, soc_switch=False, calculate_sparsity=False)
+    head.compile(device)
+    hl = head.offsite_hamiltonian_network
+    lay = P.PlanarLayout(irr)
+    x = torch.from_numpy(lay.to_planar(torch.randn(rows, P.Irreps(irr).dim, generator=torch.Generator().manual_seed(seed)).numpy())).float().to(device)
+    os.environ["HG_ROWPROG"] = "1"
+    hl._rowprog = None
+    try:
+        y = hl(x)
+        used = bool(hl._rowprog)
+        os.environ["HG_ROWPROG"] = "0"
+        hl._rowprog = None
+        y0 = hl(x)
+    finally:
+        os.environ.pop("HG_ROWPROG", None)
+        hl._rowprog = None
+    torch.cuda.synchronize()
+    res = {"used": used, "vs_separate_rel_err": rel(y, y0), "irreps": irr}
+    if used:
+        rp = hl._row_program(device).rp
+        res["vs_twin_rel_err"] = rel(y, torch.from_numpy(emu.run_row_program(rp, x.double().cpu().numpy())))
+        res["lds_bytes"] = rp.lds_bytes
+    return res

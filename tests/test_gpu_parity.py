@@ -521,3 +521,21 @@ def test_full_size_properties(workload, which, soc):
         assert r["rot_onsite_eig_err"] < 5e-5 and r["rot_offsite_sv_err"] < 5e-5
         assert r["rot_changes_H"] > 1e-2
     assert r["translation_err"] < 5e-5
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_tp_wgrad_kernel_vs_twin(seed):
+    """hg_tp_wgrad vs its numpy twin on the same tables (random irreps sets; seed 3: set-B with l up to 4, two sources, 64-channel blocks)"""
+    import bench
+    r = G.check_tp_wgrad_kernel(seed=seed, **({"irr": bench.IRREPS["B"], "sh": "0e+1o+2e+3o+4e", "E": 70} if seed == 3 else {}))
+    print(r)
+    assert r["acc_rel_err"] < 2e-5 and r["gs_rel_err"] < 2e-5, r              # fp32 sums over up to 150 edges x 13 columns against float64
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_row_program_kernel_vs_separate_kernels_and_twin(seed):
+    """hg_row_program (HamLayer as one LDS-resident pass) == Linear1 / gate / Linear2 + x / linear_transform as separate launches == the twin"""
+    import bench
+    r = G.check_row_program_kernel(seed=seed, **({"irr": bench.IRREPS["A"], "nao": 19, "rows": 45} if seed == 3 else {}))
+    print(r)
+    assert r["used"] and r["vs_separate_rel_err"] < 5e-6 and r["vs_twin_rel_err"] < 5e-6, r

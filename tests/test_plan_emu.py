@@ -117,6 +117,18 @@ def test_message_pack_lite_program_vs_golden(golden_dir):
     prog = P.build_message_pack_program_lite(sd, MINI, MINI, SH, MINI, unrotate=True)
     outp = emu.run_program(prog, [xs, xd, fe], (h, None), D, 3)
     assert rel(lay.from_planar(outp), f["outputs"]["out"]) < 1e-6
+    # the same program on the input-stationary schedule (r3: IT_LINC items in the phases of their input blocks, the segments' IT_POST items as
+    # the last phase), one and several workgroups per 16-edge tile
+    # ... and with the paths of every (input irrep, output irrep) pair folded into one item with a weight matrix per column (IT_LINM)
+    progf = P.build_message_pack_program_lite(sd, MINI, MINI, SH, MINI, unrotate=True, fold=True)
+    assert progf.item_table.shape[0] < prog.item_table.shape[0] and progf.mfma_per_wave < prog.mfma_per_wave
+    for pr in (prog, progf):
+        for parts in (1, 3):
+            sc = P.is_schedule(pr, parts)
+            assert (sc.item_table[:, 0] == P.IT_POST).sum() == pr.seg_table.shape[0] and sc.part_table[:, 11].all()
+            assert not sc.part_table[:, 7].any()               # no private tile copies: the post-op runs on the shared tiles
+            outi = emu.run_program_is(pr, sc, [xs, xd, fe], (h, None), D, 3)
+            assert rel(lay.from_planar(outi), f["outputs"]["out"]) < 1e-6
 
 
 def _merge_emu(yp, slot_tab, ptr, idx, val):
