@@ -153,6 +153,15 @@ def test_full_model_backward_vs_autograd(legacy, metric):
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
 
 
+def test_full_model_backward_materialisation_route(monkeypatch):
+    """HG_WGRAD=rows: the K2 weight gradients through the two materialisation programs + library reductions (the route irreps without a fused
+    kernel instantiation fall back to; the default since r3 is the fused kernel hg_tp_wgrad)"""
+    monkeypatch.setenv("HG_WGRAD", "rows")
+    r = G.check_full_backward(legacy=False, metric="mse")
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
+
+
 def test_full_model_backward_batch_of_crystals():
     """three crystals of different sizes in one batch (per-crystal [on-site; off-site] row order of the result, batch-global inverse edges)"""
     r = G.check_full_backward(n_atoms=3, seed=8, crystals=3, metric="mae")
