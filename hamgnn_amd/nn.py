@@ -49,6 +49,9 @@ def o3_linear_weight_grad(irreps_in, irreps_out, x_planar: torch.Tensor, gy_plan
     return torch.cat(out) if out else x_planar.new_zeros(0)
 
 
+_LINEAR_PACKERS: Dict[tuple, object] = {}
+
+
 class E3Linear(nn.Module):
     """o3.Linear parameter holder: flat weight, paths ordered (i_in, i_out), each (mul_in, mul_out) row-major."""
 
@@ -59,18 +62,44 @@ class E3Linear(nn.Module):
         self.weight = nn.Parameter(torch.randn(n))
         self._dp = None
 
+    _stale = False                                             # the weights moved since the tables were packed (training._invalidate): refresh on next use
+
+    def _packer(self, adjoint: bool):
+        """blob = const + coef * weight[idx] of the (adjoint) streaming-Linear tables, discovered once per (irreps pair, direction) by probing the
+        host builder (hamgnn_amd/repack.py) and shared by all Linears of that shape: after an optimiser step the tables are refreshed by one
+        gather on the device -- no host planner, no device -> host copy of the weights (a synchronisation point per Linear and step before r3)"""
+        from collections import OrderedDict
+        from . import repack as RP
+        key = (str(self.irreps_in), str(self.irreps_out), bool(adjoint))
+        if key not in _LINEAR_PACKERS:
+            build = P.build_linear_adjoint_tables if adjoint else P.build_linear_tables
+            _LINEAR_PACKERS[key] = RP.AffinePack(lambda d: build(d["w"], self.irreps_in, self.irreps_out, keep_zero_blocks=True).weights,
+                                                 OrderedDict(w=int(self.weight.numel())))
+        return _LINEAR_PACKERS[key]
+
     def compile(self, device):
+        self._stale = False
+        stream = os.environ.get("HG_LINEAR_KERNEL", "stream") != "seg"
+        if stream and isinstance(self._dp, ops.DeviceLinear) and self._dp.weights.device == torch.device(device) and getattr(self._dp, "refreshable", False):
+            w = {"w": self.weight.detach()}                    # already uploaded: refresh the weight blobs in place, on the device
+            self._dp.weights.copy_(self._packer(False).apply(w))
+            if getattr(self, "_dp_adj", None) is not None and getattr(self._dp_adj, "refreshable", False):
+                self._dp_adj.weights.copy_(self._packer(True).apply(w))
+            else:
+                self._dp_adj = None
+            return self
         W = self.weight.detach().cpu().double().numpy()
         self._dp_adj = None                                    # adjoint tables are packed from the same weights: rebuilt on demand
-        if os.environ.get("HG_LINEAR_KERNEL", "stream") == "seg":                             # HG_LINEAR_KERNEL=seg: the Linear as a program of the segment-stationary kernel
+        if not stream:                                         # HG_LINEAR_KERNEL=seg: the Linear as a program of the segment-stationary kernel
             self._dp = ops.DeviceProgram(P.build_linear_program(W, self.irreps_in, self.irreps_out), device)
         else:                                                  # default: the streaming block-Linear kernel (csrc/linear.hip)
-            self._dp = ops.DeviceLinear(P.build_linear_tables(W, self.irreps_in, self.irreps_out), device)
+            self._dp = ops.DeviceLinear(P.build_linear_tables(W, self.irreps_in, self.irreps_out, keep_zero_blocks=True), device)
+            self._dp.refreshable = True
         return self
 
     def forward(self, x_planar: torch.Tensor, res=()) -> torch.Tensor:
         """res: residual rows (output layout) added in the kernel epilogue"""
-        if self._dp is None:
+        if self._dp is None or self._stale:
             self.compile(x_planar.device)
         if isinstance(self._dp, ops.DeviceLinear):
             return ops.linear_planar(self._dp, x_planar, res=res)
@@ -80,10 +109,19 @@ class E3Linear(nn.Module):
     # ---- backward: data gradient on the same streaming kernel with transposed blocks; the weight gradient of a Linear is
     #      a plain reduction over the rows (one library GEMM per path)
     def backward_data(self, gy_planar: torch.Tensor) -> torch.Tensor:
-        if getattr(self, "_dp_adj", None) is None:
+        dev = gy_planar.device
+        adj = getattr(self, "_dp_adj", None)
+        if adj is not None and self._stale and getattr(adj, "refreshable", False) and self._dp is None:
+            adj.weights.copy_(self._packer(True).apply({"w": self.weight.detach()}))    # (a Linear whose forward is fused elsewhere: only these tables exist)
+            self._stale = False
+        elif self._stale:
+            self.compile(dev)
+            adj = getattr(self, "_dp_adj", None)
+        if adj is None:
             W = self.weight.detach().cpu().double().numpy()
-            self._dp_adj = ops.DeviceLinear(P.build_linear_adjoint_tables(W, self.irreps_in, self.irreps_out), gy_planar.device)
-        return ops.linear_planar(self._dp_adj, gy_planar, tag="linear_adjoint")
+            adj = self._dp_adj = ops.DeviceLinear(P.build_linear_adjoint_tables(W, self.irreps_in, self.irreps_out, keep_zero_blocks=True), dev)
+            adj.refreshable = True
+        return ops.linear_planar(adj, gy_planar, tag="linear_adjoint")
 
     def weight_grad(self, x_planar: torch.Tensor, gy_planar: torch.Tensor) -> torch.Tensor:
         return o3_linear_weight_grad(self.irreps_in, self.irreps_out, x_planar, gy_planar)
@@ -652,7 +690,7 @@ class PairInteractionBlock(nn.Module):
             self.conv_tp._skip_source = (self.skip_linear,) if self.use_skip_connections else None   # (a tuple: not registered as a sub-module)
             self.conv_tp.compile(device, unrotate=False, skip_weight=skip)   # skip o3.Linear fused as extra items
             if self.use_skip_connections:
-                self.skip_linear._dp_adj = None                # its forward is fused above; only the backward uses the module's own tables
+                self.skip_linear._stale = True                 # its forward is fused above; only the backward uses the module's own (adjoint) tables
 
 
     def refresh(self, device):
@@ -663,7 +701,7 @@ class PairInteractionBlock(nn.Module):
         if not self.conv_tp.refresh(skip=skip):
             self.compile(device)
         elif self.use_skip_connections:
-            self.skip_linear._dp_adj = None
+            self.skip_linear._stale = True
 
 
 class _EmbTP(nn.Module):

@@ -1018,9 +1018,10 @@ class LinearTables:
     flops_per_row: float
 
 
-def linear_tables(mats: Dict[Tuple[int, int], np.ndarray], in_layout: PlanarLayout, out_layout: PlanarLayout) -> LinearTables:
+def linear_tables(mats: Dict[Tuple[int, int], np.ndarray], in_layout: PlanarLayout, out_layout: PlanarLayout, keep_zero_blocks: bool = False) -> LinearTables:
     """mats[(i, k)] = [mul_i, mul_k] weight block (normalisation folded in) from input irrep i to output irrep k of the two planar
-    layouts (same l, p).  Every output block is written in full (blocks without a path: zeros), padding channels included."""
+    layouts (same l, p).  Every output block is written in full (blocks without a path: zeros), padding channels included.
+    keep_zero_blocks: the table structure does not depend on the weight VALUES (device-side refresh after an optimiser step, nn.E3Linear)."""
     groups, units, paths, chunks = [], [], [], []
     woff, flops = 0, 0.0
     order = sorted(range(len(out_layout.irreps)), key=lambda k: -sum(m.shape[0] for (i, kk), m in mats.items() if kk == k) * (2 * out_layout.irreps[k][1] + 1))
@@ -1038,10 +1039,10 @@ def linear_tables(mats: Dict[Tuple[int, int], np.ndarray], in_layout: PlanarLayo
                 mi = in_layout.irreps[i][0]
                 assert M.shape == (mi, mk) and in_layout.irreps[i][1:] == (lk, pk)
                 blk = M[:, c0:min(c1, mk)]
-                if blk.shape[1] == 0 or not np.any(blk):
+                if blk.shape[1] == 0 or not (keep_zero_blocks or np.any(blk)):
                     continue
                 ngrp = ceil_div(in_layout.mulp[i], 16)
-                frag = _frag_A(blk, 4 * ngrp, rtm, True).astype(np.float32).reshape(-1)
+                frag = _frag_A(blk, 4 * ngrp, rtm, True).astype(_WEIGHT_DTYPE[0]).reshape(-1)
                 paths.append([in_layout.off[i], in_layout.mulp[i], ngrp, woff])
                 chunks.append(frag)
                 woff += frag.size
@@ -1050,7 +1051,7 @@ def linear_tables(mats: Dict[Tuple[int, int], np.ndarray], in_layout: PlanarLayo
     items = [[u0 + c, a] for u0, nch, nco, _ in groups for a in range(nco) for c in range(nch)]      # chunks of one (block, a) adjacent: shared input
     return LinearTables(np.asarray(groups, np.int32).reshape(-1, LIN_GROUP_I32), np.asarray(units, np.int32).reshape(-1, LIN_UNIT_I32),
                         np.asarray(paths, np.int32).reshape(-1, LIN_PATH_I32),
-                        np.concatenate(chunks) if chunks else np.zeros(4, np.float32), np.asarray(items, np.int32).reshape(-1, 2),
+                        np.concatenate(chunks) if chunks else np.zeros(4, _WEIGHT_DTYPE[0]), np.asarray(items, np.int32).reshape(-1, 2),
                         in_layout.dim, out_layout.dim, flops)
 
 
@@ -1072,15 +1073,15 @@ def o3_linear_mats(weight: np.ndarray, irreps_in, irreps_out) -> Dict[Tuple[int,
     return mats
 
 
-def build_linear_tables(weight: np.ndarray, irreps_in, irreps_out) -> LinearTables:
-    return linear_tables(o3_linear_mats(weight, irreps_in, irreps_out), PlanarLayout(irreps_in), PlanarLayout(irreps_out))
+def build_linear_tables(weight: np.ndarray, irreps_in, irreps_out, keep_zero_blocks: bool = False) -> LinearTables:
+    return linear_tables(o3_linear_mats(weight, irreps_in, irreps_out), PlanarLayout(irreps_in), PlanarLayout(irreps_out), keep_zero_blocks)
 
 
-def build_linear_adjoint_tables(weight: np.ndarray, irreps_in, irreps_out) -> LinearTables:
+def build_linear_adjoint_tables(weight: np.ndarray, irreps_in, irreps_out, keep_zero_blocks: bool = False) -> LinearTables:
     """data gradient of o3.Linear(irreps_in -> irreps_out) as tables of the same streaming kernel: g_x[i] = sum_k W_ik^T g_y[k] with the
     forward's normalised blocks transposed."""
     mats = {(k, i): M.T for (i, k), M in o3_linear_mats(weight, irreps_in, irreps_out).items()}
-    return linear_tables(mats, PlanarLayout(irreps_out), PlanarLayout(irreps_in))
+    return linear_tables(mats, PlanarLayout(irreps_out), PlanarLayout(irreps_in), keep_zero_blocks)
 
 
 MAX_SEG_ROWS = 64        # output channels per segment (bounds the LDS tile); wider irreps are split column-wise

@@ -150,7 +150,11 @@ def allreduce_gradients(model, average: bool = True):
 
 def _invalidate(module):
     """the packed weight fragments / adjoint tables are stale once the optimiser has stepped: repacked on the next forward"""
+    from .nn import E3Linear
     for m in module.modules():
+        if isinstance(m, E3Linear) and m._dp is not None and getattr(m._dp, "refreshable", False):
+            m._stale = True                                    # its tables are refreshed on the device at the next use (nn.E3Linear.compile)
+            continue
         for attr in ("_dp", "_dp_adj", "_adj_tabs"):             # (`_wgrad` is handed over by the blocks' compile(): its device constants are reused)
             if hasattr(m, attr):
                 setattr(m, attr, None)

@@ -152,7 +152,10 @@ def row_program(drp, x, res=(), row_idx=None, tag="row_program"):
 
 
 def linear_planar(dl, x, res=(), tag="linear"):
-    return _t(emu.run_linear_tables(dl.tabs, _np(x), [_np(r) for r in res if r is not None]))
+    import copy
+    tabs = copy.copy(dl.tabs)
+    tabs.weights = _np(dl.weights)                             # the blob the device object holds (it is refreshed in place after an optimiser step)
+    return _t(emu.run_linear_tables(tabs, _np(x), [_np(r) for r in res if r is not None]))
 
 
 def segment_sum(msg, rowptr, perm, N):
