@@ -93,7 +93,9 @@ extern "C" int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t*
 // [rows, nao^2] result.  Against hg_ham_merge + hg_ham_finish this removes the Hraw round trip (1 write + 2 reads of nao^2 per row),
 // one launch, the dependent per-element gathers and the per-row re-reading of the CSR table (staged once per block).  On-site rows pair
 // with themselves.
-#define HR_PAIRS 2
+#ifndef HR_PAIRS
+#define HR_PAIRS 2                // measured r3: 4 pairs per step (LDS per block doubles, fewer resident blocks) 3.4 -> 6.1 ms per 822 k rows
+#endif
 __global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restrict__ coeff, int64_t cs, int cw, const float* __restrict__ wig,
                                                           int nW, int nWuse, const HgWigOff wo, const int4* __restrict__ slot_tab,
                                                           const int* __restrict__ cg_ptr, const int* __restrict__ cg_idx,
