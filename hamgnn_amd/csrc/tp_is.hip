@@ -440,6 +440,88 @@ __device__ __forceinline__ void item_lite_m(const IsArgs& A, const float* __rest
     }
 }
 
+// lite_mode RUN (plan._lite_runs): all folded items of one (phase, output segment, row chunk) as ONE stream of steps ordered by tile column.
+// step t: RTM weight fragments at stream + t * RTM * 256 and a descriptor {B operand base / 64 | K-steps - 1 << 10 | first << 12 | last << 13 |
+// tile column << 16}; fragments AND descriptors of step t + RL_RING are requested at step t -- across what used to be item boundaries -- and
+// a column's accumulators persist across the items that feed it (one tile read-modify-write per column and run).
+#ifndef RL_RING
+#define RL_RING 6
+#endif
+template <int RTM>
+__device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
+    const int g = lane >> 4, el = lane & 15;
+    const int nsteps = it[8], lk = it[20];
+    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23] + it[16];
+    float* __restrict__ tbase = lds + A.tile_shift + (el - lk * 16);
+    const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
+    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t, row tile rt: aw[(t * RTM + rt) * 64]
+    const int* __restrict__ dsc = reinterpret_cast<const int*>(Wb + it[12]);
+    int roff[RTM][4];
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) roff[rt][r] = rtab[16 * rt + 4 * g + r];
+    f32x4 ring[RL_RING][RTM], acc[RTM];
+    int dring[RL_RING];
+#pragma unroll
+    for (int j = 0; j < RL_RING; ++j)
+        if (j < nsteps) {
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
+            dring[j] = dsc[j];
+        }
+#pragma unroll
+    for (int rt = 0; rt < RTM; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int t0 = 0; t0 < nsteps; t0 += RL_RING) {
+#pragma unroll
+        for (int j = 0; j < RL_RING; ++j) {
+            const int t = t0 + j;
+            if (t < nsteps) {                                  // uniform
+                f32x4 av[RTM];
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
+                const int d = __builtin_amdgcn_readfirstlane(dring[j]);
+                if (t + RL_RING < nsteps) {
+#ifndef HG_ABL_RL_NOW
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RL_RING) * RTM + rt) * 64];
+#endif
+                    dring[j] = dsc[t + RL_RING];
+                }
+                const float* __restrict__ fb = stage + (d & 1023) * 64;
+                const int nq = ((d >> 10) & 3) + 1;
+                float b[4];
+#pragma unroll
+#ifdef HG_ABL_RL_NOLDS
+                for (int q = 0; q < 4; ++q) b[q] = (float)(q + el);
+#else
+                for (int q = 0; q < 4; ++q) b[q] = q < nq ? fb[q * 64] : 0.f;
+#endif
+                if (d & (1 << 12)) {
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+#ifdef HG_ABL_RL_NOMFMA
+                    for (int rt = 0; rt < RTM; ++rt) acc[rt][q] += av[rt][q] * b[q];
+#else
+                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
+#endif
+                if (d & (1 << 13)) {                           // column complete: add into the tile
+                    const int tc = (d >> 16) & 31;
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] += acc[rt][r];
+                }
+            }
+        }
+    }
+}
+
 // lite_mode segment post-op (message_passing.py:209-215: combine_messages = LinearScaleWithWeights on the summed branches), the last phase of a
 // lite program's part: tile[v, m] <- sum_w Lc[w, v] * s_e[w] * tile[w, m] with s_e = W3^T h2 by MFMA, in place per chunk of four columns
 // (every row of a column is read before one is written; the segment belongs to this wave alone in its phase).
@@ -659,6 +741,10 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
                         else if (it[22] == 3) post_is<3>(A, g_W, it, lds, erow, lane);
                         else post_is<4>(A, g_W, it, lds, erow, lane);
                     }
+                    else if (it[0] == 5 && it[9] == 1) run_lite<1>(A, g_W, it, lds, lane);
+                    else if (it[0] == 5 && it[9] == 2) run_lite<2>(A, g_W, it, lds, lane);
+                    else if (it[0] == 5 && it[9] == 3) run_lite<3>(A, g_W, it, lds, lane);
+                    else if (it[0] == 5) run_lite<4>(A, g_W, it, lds, lane);
                     else if (it[0] == 4 && it[9] == 1) item_lite_m<1>(A, g_W, it, lds, lane);
                     else if (it[0] == 4 && it[9] == 2) item_lite_m<2>(A, g_W, it, lds, lane);
                     else if (it[0] == 4 && it[9] == 3) item_lite_m<3>(A, g_W, it, lds, lane);

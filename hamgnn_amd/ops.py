@@ -68,6 +68,7 @@ class DeviceProgram:
         self.sched = None
         self._device = device
         self._is_tables = {}                                   # parts -> (IsSchedule, device tables)
+        self._is_weights = {}                                  # parts -> weight blob with the schedule's own streams appended (lite_mode runs)
         if prog.vsegs and schedule not in ("is", "is_parts"):
             raise ValueError("a program with merged items runs on the input-stationary kernel only")
         self.fixed_parts = None                                # "lds": the tiles of all output segments need several workgroups per 16 edges
@@ -94,6 +95,8 @@ class DeviceProgram:
 
     def weights_changed(self):
         """after the packed weight blob was rewritten in place (nn.MessagePackBlock.refresh): rebuild what is derived from it"""
+        self._is_weights.clear()                               # (lite programs are recompiled, not refreshed; kept consistent anyway)
+        self._is_tables = {k: v for k, v in self._is_tables.items() if v[0].extra_weights is None}
         if self.st is not None:
             st, tabs, gather, stream = self.st
             stream.copy_(torch.cat([self.weights, self.weights.new_zeros(1)])[gather])
@@ -104,7 +107,13 @@ class DeviceProgram:
             sc = P.is_schedule(self.prog, parts)
             self._is_tables[parts] = (sc, tuple(_dev(t, self._device) for t in (sc.seg_table, sc.block_table, sc.phase_table, sc.group_table,
                                                                                   sc.item_table, sc.part_table, sc.rowtab)))
+            if sc.extra_weights is not None:                   # lite_mode runs: their step streams ride behind the program's weights
+                self._is_weights[parts] = torch.cat([self.weights, _dev(sc.extra_weights, self._device, torch.float32)])
         return self._is_tables[parts]
+
+    def is_weights(self, parts) -> torch.Tensor:
+        """the weight blob a launch with `parts` sub-schedules reads"""
+        return self._is_weights.get(parts, self.weights)
 
     def is_parts_for(self, rows: int) -> int:
         """How many workgroups share one 16-edge tile.  The chip holds 512 workgroups of this kernel (2 per CU); a launch with fewer
@@ -306,7 +315,7 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts, t_rowtab) = dp.is_tables(dp.is_parts_for(rows))
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
-        check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(t_segs),
+        check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.is_weights(dp.is_parts_for(rows))), ptr(t_segs),
                              ptr(t_blocks), ptr(t_phases), ptr(t_groups), ptr(t_items), ptr(t_parts),
                              sc.part_table.ctypes.data_as(C.c_void_p), i32(sc.part_table.shape[0]), ptr(t_rowtab),
                              i32(sc.lds_floats * 4), gp, i32(rot_mask), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")

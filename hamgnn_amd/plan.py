@@ -36,6 +36,7 @@ IT_TP = 0        # GEMM1 -> radial scale * CG coef -> GEMM2 -> add into segment 
 IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, add into tile
 IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: aligned-frame CG coefficient per m)
 IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
+IT_RUN = 5       # lite_mode, input-stationary schedule: ALL IT_LINM items of one (phase, segment, row chunk) as one stream of steps (plan._lite_runs)
 IT_LINM = 4      # lite_mode, ALL paths (i, l_sh, k) of one (i, k) folded: one weight matrix per column, A_m = sum_paths cf_path[m] A_path (input-stationary kernel only)
 # segment flags
 SEG_UNROTATE = 1     # epilogue applies D^l(R_e)^T (messages go back to the global frame before the node scatter)
@@ -207,6 +208,7 @@ class IsSchedule:
     balance: float                 # LPT estimate: sum(cost) / (waves * sum over phases of max wave cost), worst part
     part_cost: List[int]           # estimated MFMA-slot cost of every part (critical path over its phases)
     phase_cls: List[int] = field(default_factory=list)   # per phase: the radial weight generator of its tensor-product items
+    extra_weights: Optional[np.ndarray] = None          # lite_mode runs (IT_RUN): their weight / descriptor streams, appended to Program.weights on the device
 
     # single-part views (the common large-graph case; tests)
     @property
@@ -238,6 +240,8 @@ def _item_rto(rec, segs, vsegs=()):
 
 
 def _item_cost(rec, segs, hp4, vsegs=()):
+    if int(rec[0]) == IT_RUN:
+        return 4 * int(rec[8]) * int(rec[9]) + 60
     typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
     c = nsrc * int(rec[8]) * rtm * nc + 60                     # GEMM1 + a per-item latency allowance (in MFMA slots)
     if typ == IT_TP:
@@ -313,13 +317,15 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSched
             for m in range(nseg):
                 if key_of[m] == sg:
                     owner[m] = r
+    # lite_mode programs with folded items: runs (see _lite_runs) unless HG_LITE_RUNS=0
+    runs = dict(base=int(prog.weights.size), w=[]) if ((prog.item_table[:, 0] == IT_LINM).any() and os.environ.get("HG_LITE_RUNS", "1") != "0") else None
     segs_all, btab, ptab, gtab, items_all, parttab, part_cost, rowtab_all = [], [], [], [], [], [], [], []
     phase_cls_all: List[int] = []
     lds_floats, worst_balance = 0, 1.0
     for part in range(parts):
         members = [sg for sg in range(nseg) if owner[sg] == part]
         sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
-                                split=parts > 1, separate_mlp=separate_mlp)
+                                split=parts > 1, separate_mlp=separate_mlp, runs=runs)
         parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
                         sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag])
         rowtab_all += sub["rowtab"]
@@ -336,11 +342,61 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSched
     return IsSchedule(np.asarray(segs_all, np.int32).reshape(-1, SEG_I32), np.asarray(btab, np.int32).reshape(-1, IS_BLOCK_I32),
                       np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
                       np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), np.asarray(rowtab_all, np.int32),
-                      lds_floats, worst_balance, part_cost, phase_cls_all)
+                      lds_floats, worst_balance, part_cost, phase_cls_all,
+                      extra_weights=(np.concatenate(runs["w"]) if runs is not None and runs["w"] else None))
+
+
+def _lite_runs(prog: "Program", recs, runs: dict):
+    """lite_mode, input-stationary schedule: the IT_LINM items of one (phase, output segment) -- `recs`, stage offsets already in [1], [2] --
+    regrouped into RUNS (one per row chunk of the segment): a run is a linear stream of STEPS ordered by tile column, every step = one
+    fragment group (rtm x 64 x 4 weights) + a descriptor {B operand base / 64 floats into the staging area | K-steps - 1 << 10 | first step
+    of the column << 12 | last << 13 | tile column << 16}; the accumulators of a column persist across the items that feed it (one tile
+    read-modify-write per column and run instead of one per item and column), the fragments and descriptors of step t + ring are requested at
+    step t -- across what used to be item boundaries (csrc/tp_is.hip:run_lite).  Streams are appended to runs["w"] (floats; the descriptors
+    as int32 bit patterns); returns the runs as item records of type IT_RUN."""
+    Wt = prog.weights
+    by_chunk: Dict[Tuple[int, int], list] = {}
+    for r in recs:
+        by_chunk.setdefault((int(r[16]), int(r[9])), []).append(r)
+    out = []
+    for (row_off, rtm), items in by_chunk.items():
+        seg = int(items[0][19])
+        lk = int(prog.seg_table[seg][0])
+        frags, desc = [], []
+        for tc in range(2 * lk + 1):
+            m = tc - lk
+            steps = []
+            for r in items:
+                so0, so1, in_mulp, li, mm, neg, ksteps, a1, colstride = int(r[1]), int(r[2]), int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[11]), int(r[13])
+                if abs(m) > mm:
+                    continue
+                c = m + mm
+                nsrc, ngrp, P1 = (2 if so1 >= 0 else 1), ceil_div(ksteps, 4), in_mulp // 4
+                cdir = -P1 if neg else P1
+                c0p = (li - mm) * P1 + ((2 * mm) * P1 if neg else 0)
+                for si in range(nsrc):
+                    for G in range(ngrp):
+                        base = (so1 if si else so0) + (c0p + c * cdir + 4 * G) * 64
+                        assert base % 64 == 0 and 0 <= base // 64 < 1024
+                        woff = a1 + c * colstride + (si * ngrp + G) * rtm * 256
+                        steps.append((Wt[woff:woff + rtm * 256], base // 64, min(4, ksteps - 4 * G)))
+            for n_, (w, b64, nq) in enumerate(steps):
+                frags.append(w)
+                desc.append(b64 | ((nq - 1) << 10) | ((1 if n_ == 0 else 0) << 12) | ((1 if n_ == len(steps) - 1 else 0) << 13) | (tc << 16))
+        w_off = runs["base"] + sum(x.size for x in runs["w"])
+        wblob = np.concatenate(frags).astype(np.float64)
+        dblob = np.asarray(desc, dtype=np.int32).view(np.float32).astype(np.float64)       # bit patterns ride in the float blob (exact: float32 -> float64 -> float32)
+        pad = (-len(desc)) % 4
+        runs["w"] += [wblob, dblob, np.zeros(pad)]
+        rec = np.zeros(ITEM_I32, dtype=np.int64)
+        rec[0], rec[8], rec[9], rec[11], rec[12], rec[16], rec[19] = IT_RUN, len(desc), rtm, w_off, w_off + wblob.size, row_off, seg
+        rec[2] = -1
+        out.append(rec)
+    return out
 
 
 def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
-                      split: bool = False, separate_mlp: bool = False) -> dict:
+                      split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None) -> dict:
     """sub-schedule of the output segments `members` (indices into prog.seg_table); all table indices are emitted as ABSOLUTE indices
     into the concatenated tables of the launch (bases given)."""
     segs = prog.seg_table[members].copy()
@@ -450,6 +506,8 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             units = [[r] for recs in by_seg.values() for r in recs]
         else:
             units = list(by_seg.values())
+        if runs is not None and all(int(r[0]) == IT_LINM for recs in units for r in recs):
+            units = [[run] for recs in units for run in _lite_runs(prog, recs, runs)]      # one run = one work group (disjoint rows of a tile)
         groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
         loads = [0] * IS_WAVES
         for c, n in groups:                                    # claim order = LPT order
