@@ -450,7 +450,7 @@ __device__ __forceinline__ void item_lite_m(const IsArgs& A, const float* __rest
 template <int RTM>
 __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
     const int g = lane >> 4, el = lane & 15;
-    const int nsteps = it[8], lk = it[20];
+    const int nsteps = it[8], lk = it[20];                     // nsteps: a multiple of RL_RING (no-op steps at the end), RL_RING more slots behind
     const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23] + it[16];
     float* __restrict__ tbase = lds + A.tile_shift + (el - lk * 16);
     const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
@@ -464,12 +464,11 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
     f32x4 ring[RL_RING][RTM], acc[RTM];
     int dring[RL_RING];
 #pragma unroll
-    for (int j = 0; j < RL_RING; ++j)
-        if (j < nsteps) {
+    for (int j = 0; j < RL_RING; ++j) {
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
-            dring[j] = dsc[j];
-        }
+        for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
+        dring[j] = dsc[j];
+    }
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -477,45 +476,41 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
 #pragma unroll
         for (int j = 0; j < RL_RING; ++j) {
             const int t = t0 + j;
-            if (t < nsteps) {                                  // uniform
-                f32x4 av[RTM];
+            f32x4 av[RTM];
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
-                const int d = __builtin_amdgcn_readfirstlane(dring[j]);
-                if (t + RL_RING < nsteps) {
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
+            const int d = __builtin_amdgcn_readfirstlane(dring[j]);
+            // the requests of step t + RL_RING: NO branch around them (the compiler waits for every outstanding load at the join of a
+            // conditional one: one L2 round trip per step, 860 cycles, in the first version of this loop)
 #ifndef HG_ABL_RL_NOW
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RL_RING) * RTM + rt) * 64];
+            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RL_RING) * RTM + rt) * 64];
 #endif
-                    dring[j] = dsc[t + RL_RING];
-                }
-                const float* __restrict__ fb = stage + (d & 1023) * 64;
-                const int nq = ((d >> 10) & 3) + 1;
-                float b[4];
+            dring[j] = dsc[t + RL_RING];
+            const float* __restrict__ fb = stage + (d & 1023) * 64;
+            const int nq = ((d >> 10) & 3) + 1;
+            float b[4];
 #pragma unroll
 #ifdef HG_ABL_RL_NOLDS
-                for (int q = 0; q < 4; ++q) b[q] = (float)(q + el);
+            for (int q = 0; q < 4; ++q) b[q] = (float)(q + el);
 #else
-                for (int q = 0; q < 4; ++q) b[q] = q < nq ? fb[q * 64] : 0.f;
-#endif
-                if (d & (1 << 12)) {
+            for (int q = 0; q < 4; ++q) b[q] = fb[(q < nq ? q : nq - 1) * 64];      // no branch: K-steps beyond the block's channels re-read its last
+#endif                                                          // piece and multiply zero weights
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
 #ifdef HG_ABL_RL_NOMFMA
-                    for (int rt = 0; rt < RTM; ++rt) acc[rt][q] += av[rt][q] * b[q];
+                for (int rt = 0; rt < RTM; ++rt) acc[rt][q] += av[rt][q] * b[q];
 #else
-                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
+                for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
 #endif
-                if (d & (1 << 13)) {                           // column complete: add into the tile
-                    const int tc = (d >> 16) & 31;
+            if (d & (1 << 13)) {                               // column complete: add into the tile
+                const int tc = (d >> 16) & 31;
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt)
+                for (int rt = 0; rt < RTM; ++rt) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] += acc[rt][r];
+                    for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] += acc[rt][r];
+                    acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // the next step starts a column
                 }
             }
         }
@@ -727,6 +722,7 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
             for (int ii = ib; ii < ie; ++ii) {
                 const int* __restrict__ it = g_items + ii * 24;
                 if (LITE) {                                    // lite_mode programs: their own (small) items, their own kernel instantiation
+                    IS_T(0);                                   // dispatch / claim
 #ifdef HG_ABL_NOPOST
                     if (it[0] == 3) continue;
 #endif
@@ -753,6 +749,7 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
                     else if (it[9] == 2) item_lite<2>(A, g_W, it, lds, lane);
                     else if (it[9] == 3) item_lite<3>(A, g_W, it, lds, lane);
                     else item_lite<4>(A, g_W, it, lds, lane);
+                    if (it[0] == 3) { IS_T(3); } else { IS_T(2); }       // (profile slots: 2 = lite items / runs, 3 = post-ops)
                     continue;
                 }
                 switch (it[6] * 8 + it[9] + ((it[0] == 0 && it[7]) ? 64 : 0)) {

@@ -36,6 +36,7 @@ IT_TP = 0        # GEMM1 -> radial scale * CG coef -> GEMM2 -> add into segment 
 IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, add into tile
 IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: aligned-frame CG coefficient per m)
 IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
+LITE_RING = 6    # request ring of csrc/tp_is.hip:run_lite (RL_RING)
 IT_RUN = 5       # lite_mode, input-stationary schedule: ALL IT_LINM items of one (phase, segment, row chunk) as one stream of steps (plan._lite_runs)
 IT_LINM = 4      # lite_mode, ALL paths (i, l_sh, k) of one (i, k) folded: one weight matrix per column, A_m = sum_paths cf_path[m] A_path (input-stationary kernel only)
 # segment flags
@@ -240,8 +241,8 @@ def _item_rto(rec, segs, vsegs=()):
 
 
 def _item_cost(rec, segs, hp4, vsegs=()):
-    if int(rec[0]) == IT_RUN:
-        return 4 * int(rec[8]) * int(rec[9]) + 60
+    if int(rec[0]) == IT_RUN:                                   # measured: a step costs ~860 cycles almost independently of its 4 rtm MFMAs (profiles/r03_lite.md)
+        return int(rec[8]) * (6 + int(rec[9])) + 60
     typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
     c = nsrc * int(rec[8]) * rtm * nc + 60                     # GEMM1 + a per-item latency allowance (in MFMA slots)
     if typ == IT_TP:
@@ -383,13 +384,20 @@ def _lite_runs(prog: "Program", recs, runs: dict):
             for n_, (w, b64, nq) in enumerate(steps):
                 frags.append(w)
                 desc.append(b64 | ((nq - 1) << 10) | ((1 if n_ == 0 else 0) << 12) | ((1 if n_ == len(steps) - 1 else 0) << 13) | (tc << 16))
+        # the kernel's request ring runs LITE_RING steps ahead WITHOUT a branch around the loads (a conditional load makes the compiler wait for
+        # every outstanding one at the join: vmcnt(0) per step): steps padded to a multiple of the ring with no-ops (zero weights, no column
+        # boundary), LITE_RING more slots behind the last step for the requests that run past it
+        npad = (-len(desc)) % LITE_RING
+        nreal = len(desc) + npad
+        frags += [np.zeros(rtm * 256)] * (npad + LITE_RING)
+        desc += [0] * (npad + LITE_RING)
         w_off = runs["base"] + sum(x.size for x in runs["w"])
         wblob = np.concatenate(frags).astype(np.float64)
         dblob = np.asarray(desc, dtype=np.int32).view(np.float32).astype(np.float64)       # bit patterns ride in the float blob (exact: float32 -> float64 -> float32)
         pad = (-len(desc)) % 4
         runs["w"] += [wblob, dblob, np.zeros(pad)]
         rec = np.zeros(ITEM_I32, dtype=np.int64)
-        rec[0], rec[8], rec[9], rec[11], rec[12], rec[16], rec[19] = IT_RUN, len(desc), rtm, w_off, w_off + wblob.size, row_off, seg
+        rec[0], rec[8], rec[9], rec[11], rec[12], rec[16], rec[19] = IT_RUN, nreal, rtm, w_off, w_off + wblob.size, row_off, seg
         rec[2] = -1
         out.append(rec)
     return out

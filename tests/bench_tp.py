@@ -8,11 +8,12 @@ IRR = {"A": "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+
 ap = argparse.ArgumentParser(); ap.add_argument("--irreps", default="A"); ap.add_argument("--edges", type=int, default=131072)
 ap.add_argument("--reps", type=int, default=5); ap.add_argument("--tag", default=""); ap.add_argument("--same-rows", type=int, default=0, help="alias the B-operand rows onto this many distinct rows (cache-residency experiment)")
 ap.add_argument("--nodes", type=int, default=0, help="feed NODE rows + random sender/receiver indices (gather + rotation fused into the input-stationary kernel, or hg_rotate_gather + kernel otherwise) instead of pre-rotated edge rows")
+ap.add_argument("--lite", action="store_true", help="lite_mode block (its own instantiation of the input-stationary kernel)")
 ap.add_argument("--adjoint", action="store_true", help="time the data-gradient launch (adjoint program, hamgnn_amd.nn.MessagePackBlock.backward_data) instead of the forward")
 a = ap.parse_args()
 irr, sh = IRR[a.irreps], "0e+1o+2e+3o+4e+5o"
 torch.manual_seed(0)
-m = hnn.MessagePackBlock(irr, irr, sh, irr, 64, [64, 64])
+m = hnn.MessagePackBlock(irr, irr, sh, irr, 64, [64, 64], lite_mode=a.lite)
 dev = torch.device("cuda")
 m.compile(dev, unrotate=True)
 E = a.edges
@@ -30,7 +31,7 @@ if a.same_rows:
         xs, xd, fe = (t[:1].expand(E, lay.dim) for t in (xs, xd, fe))
     else:   # rows repeat with period k: footprint k * 3 * Dp * 4 bytes
         xs, xd, fe = (t[:k].repeat((E + k - 1) // k, 1)[:E].contiguous() for t in (xs, xd, fe))
-hn = ops.radial_hidden(geo.rbf, m._hn, 1.679); he = ops.radial_hidden(geo.rbf, m._he, 1.679)
+hn = ops.radial_hidden(geo.rbf, m._hn, 1.679); he = ops.radial_hidden(geo.rbf, m._he, 1.679) if m._he is not None else None
 if a.nodes:
     node = torch.randn(a.nodes, lay.dim, generator=g).to(dev)
     geo.src = torch.randint(0, a.nodes, (E,), generator=g).to(dev)

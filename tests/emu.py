@@ -241,7 +241,9 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                             lk_, rtm_ = int(seg[0]), int(it[9])
                             Wall = np.concatenate([prog.weights.astype(dtype), sched.extra_weights.astype(dtype)])
                             nst, w0, d0 = int(it[8]), int(it[11]), int(it[12])
-                            desc = Wall[d0:d0 + nst].astype(np.float32).view(np.int32)
+                            assert nst % P.LITE_RING == 0                                     # padded with no-op steps; LITE_RING more slots follow
+                            desc = Wall[d0:d0 + nst + P.LITE_RING].astype(np.float32).view(np.int32)
+                            assert not desc[nst:].any() and not Wall[w0 + nst * rtm_ * 256:w0 + (nst + P.LITE_RING) * rtm_ * 256].any()
                             rt = rowtab[int(it[23]) + int(it[16]):int(it[23]) + int(it[16]) + 16 * rtm_]
                             acc = None
                             for t in range(nst):
