@@ -74,6 +74,23 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
         const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
         const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
         const int hgrp = A.hidden >> 4;
+#ifdef HG_IS_H64                       // A/B hook (r3): the shipped hidden width (64 = 4 groups) as straight-line code, no branch between the loads and
+        if (hgrp == 4) {               // the 16 RTM MFMAs
+            f32x4 hb[4], wv[4][RTM];
+#pragma unroll
+            for (int G = 0; G < 4; ++G) {
+                hb[G] = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[(G * RTM + rt) * 64];
+            }
+#pragma unroll
+            for (int G = 0; G < 4; ++G)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
+        } else
+#endif
 #pragma unroll 1
         for (int G0 = 0; G0 < hgrp; G0 += 4) {
             f32x4 hb[4], wv[4][RTM];
@@ -155,6 +172,22 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                 }
                 IS_A2_EARLY()
                 const int nq = ksteps - 4 * G;                 // K-steps in this group (>= 4 except in the tail group)
+#ifdef HG_IS_FULLG                     // A/B hook (r3): a full group as ONE basic block (no branch per K-step); only the tail group is guarded
+                if (nq >= 4) {
+                    float b[4][NC];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) b[q][c] = fb[(IS_COL(c) * cdir + 4 * G + q) * 64];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q][c], mid[rt][c], 0, 0, 0);
+                } else
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (q < nq) {
