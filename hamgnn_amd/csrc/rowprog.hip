@@ -307,14 +307,8 @@ extern "C" int hg_row_program(const float* x, int64_t x_stride, const int64_t* r
     A.rsA = rs_a; A.rsB = rs_b; A.strip = strip; A.nstages = nstages;
     A.nact = nact; A.nout = nout; A.lds_tabs = lds_tabs;
     for (int i = 0; i < 5; ++i) A.cst[i] = consts_host[i];
-    static bool attr_set[16] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return hg_fail(-3, "hg_row_program: hipGetDevice");
-    if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_program_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return hg_fail(-3, "hg_row_program: cannot raise the dynamic LDS limit");
-        attr_set[dev] = true;
-    }
+    static unsigned char lds_attr_done[HG_MAX_DEVICES];       // once per device (not a stream operation: illegal during graph capture)
+    if (int rc = hg_lds_attr_once(lds_attr_done, dev_guard.dev, (const void*)row_program_kernel, 160 * 1024)) return rc;
     const int64_t tiles = (rows + RP_ROWS - 1) / RP_ROWS;
     const int64_t blocks = tiles < 256 ? tiles : 256;          // persistent: one workgroup per CU (the two row buffers fill its LDS), tiles strided
     row_program_kernel<<<dim3((unsigned)blocks), RP_NT, lds, (hipStream_t)stream>>>(A, stages, units, weights, (const int2*)act_tab, (const int2*)out_tab);

@@ -393,8 +393,10 @@ extern "C" int hg_tp_wgrad(const float* const* src, const int64_t* src_stride, i
                            float* gs_node, int64_t gs_node_stride, float* gs_edge, int64_t gs_edge_stride,
                            float* acc, int64_t acc_floats, int nsplit, const int32_t* units, int nunits, const float* weights, const int32_t* chtab,
                            int lds_bytes, int64_t rows, void* stream) {
+    HgDeviceGuard dev_guard(stream);
     if (rows <= 0 || nunits <= 0) return 0;
-    if (nsplit < 1 || nsrc_slots > 4 || hidden != 64 || lds_bytes > 160 * 1024) return -1;
+    if (nsplit < 1 || nsrc_slots > 4 || lds_bytes > 160 * 1024) return hg_fail(-2, "hg_tp_wgrad: bad split / source count / LDS size");
+    if (hidden != 64) return hg_fail(-2, "hg_tp_wgrad: the kernel is built for a 64-wide last hidden layer of the radial MLP");
     WgArgs A;
     for (int i = 0; i < 4; ++i) {
         A.src[i] = i < nsrc_slots ? src[i] : nullptr;
@@ -413,11 +415,8 @@ extern "C" int hg_tp_wgrad(const float* const* src, const int64_t* src_stride, i
     A.acc_split = acc_floats;
     A.rows = rows;
     A.hidden = hidden;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(tp_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
-        attr_set = true;
-    }
+    static unsigned char lds_attr_done[HG_MAX_DEVICES];       // once per device (not a stream operation: illegal during graph capture)
+    if (int rc = hg_lds_attr_once(lds_attr_done, dev_guard.dev, (const void*)tp_wgrad_kernel, 160 * 1024)) return rc;
     hipLaunchKernelGGL(tp_wgrad_kernel, dim3(nunits, nsplit), dim3(WG_NT), lds_bytes, static_cast<hipStream_t>(stream), A, units, weights, chtab);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
+    return hg_check_launch("hg_tp_wgrad");
 }

@@ -396,7 +396,8 @@ def tp_wgrad(dwf: DeviceWgFused, srcs: Sequence[Optional[torch.Tensor]], g: torc
     rows = int(g.shape[0])
     S = int(nsplit or dwf.nsplit_for(rows))
     acc = torch.zeros(S, wf.acc_floats, device=g.device, dtype=torch.float32)
-    gs = [torch.zeros(rows, n, device=g.device, dtype=torch.float32) for n in wf.nch]
+    alloc = torch.empty if wf.gs_complete else torch.zeros      # (every channel of every row is written by exactly one wave when the row tiles cover all channels)
+    gs = [alloc(rows, n, device=g.device, dtype=torch.float32) for n in wf.nch]
     n = len(srcs)
     keep = [t.contiguous() if t is not None else None for t in srcs]
     sp = (C.c_void_p * 4)(*([(t.data_ptr() if t is not None else 0) for t in keep] + [0] * (4 - n)))

@@ -1436,6 +1436,7 @@ class WgFused:
     tp_scale: List[Optional[np.ndarray]]
     l_pos: List[np.ndarray]                 # per branch: [ls_size, 4]
     lds_bytes: int
+    gs_complete: bool = False               # every radial channel of every branch is written by some row tile (gs needs no zero fill)
     mfma_per_tile: float = 0.0              # issued MFMAs per 16 edges, all units
     bytes_per_edge: float = 0.0             # staged bytes per edge, all units
 
@@ -1449,6 +1450,7 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
     units, wparts, chparts = [], [], []
     woff = accoff = choff_t = 0
     tp_pos, tp_scale, l_pos, nchs = [], [], [], []
+    seen_ch: List[set] = []
     lds_max = 0
     total_cost = total_bytes = 0.0
     for bi, b in enumerate(branches):
@@ -1565,6 +1567,7 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
         tp_pos.append(tpp)
         tp_scale.append(tps)
         l_pos.append(lpp)
+        seen_ch.append(set(int(c) for sp_ in by_i.values() for (sp__, t_, *_) in sp_ for c in sp__["ch"][16 * t_:16 * t_ + 16]))
     zero = accoff                                              # one spare slot that stays zero
     def table(lists):
         out = np.full((len(lists), 4), zero, np.int64)
@@ -1576,7 +1579,8 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
     order = np.argsort(-U[:, 13], kind="stable")               # dearest units first (the hardware hands workgroups out in order)
     return WgFused(units=U[order].astype(np.int32), weights=np.concatenate(wparts), chtab=np.concatenate(chparts).astype(np.int32), acc_floats=accoff + 1,
                    hidden=H, branch_names=[b["name"] for b in branches], nch=nchs, tp_pos=[table(t) for t in tp_pos], tp_scale=tp_scale,
-                   l_pos=[table(t) for t in l_pos], lds_bytes=lds_max, mfma_per_tile=total_cost, bytes_per_edge=total_bytes)
+                   l_pos=[table(t) for t in l_pos], lds_bytes=lds_max, gs_complete=all(s_ == set(range(n_)) for s_, n_ in zip(seen_ch, nchs)),
+                   mfma_per_tile=total_cost, bytes_per_edge=total_bytes)
 
 
 def message_pack_wgrad_branches(sd: Dict[str, np.ndarray], irreps_node, irreps_edge):
