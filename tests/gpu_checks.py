@@ -1731,3 +1731,55 @@ def check_row_program_kernel(device="cuda", seed=0, irr=None, rows=77, nao=13, h
         res["vs_twin_rel_err"] = rel(y, torch.from_numpy(emu.run_row_program(rp, x.double().cpu().numpy())))
         res["lds_bytes"] = rp.lds_bytes
     return res
+
+
+def check_new_kernels_full_size(device="cuda", rows=822350, edges=131072):
+    """size-independent properties of the round-3 kernels at the benchmark's sizes (no oracle can run there):
+    * hg_row_program on 822 350 set-A rows == the separate kernels (streaming Linear x 3 + gate), and a block of rows taken out of the middle
+      == the same rows run alone (tile boundaries / the persistent loop do not leak between rows);
+    * hg_tp_wgrad on 131 072 edges: linear in the output-gradient rows (acc(g1 + g2) == acc(g1) + acc(g2), gs likewise), independent of
+      the number of splits, and equal to the sum over two halves of the edges."""
+    import bench
+    from hamgnn_amd import backward_mp as BM, nn as hnn, ops, plan as P
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    irr, sh = bench.IRREPS["A"], bench.SH
+    torch.manual_seed(0)
+    res = {}
+    head = HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, soc_switch=False, calculate_sparsity=False)
+    head.compile(device)
+    hl = head.offsite_hamiltonian_network
+    lay = P.PlanarLayout(irr)
+    valid = torch.from_numpy(lay.to_planar(np.ones((1, P.Irreps(irr).dim)))[0] != 0).to(device)      # channel padding of the planar layout stays zero
+    x = torch.randn(rows, lay.dim, device=device) * valid
+    y = hl(x)
+    os.environ["HG_ROWPROG"] = "0"
+    hl._rowprog = None
+    try:
+        y0 = hl(x)
+    finally:
+        os.environ.pop("HG_ROWPROG", None)
+        hl._rowprog = None
+    res["rowprog_vs_separate"] = rel(y, y0)
+    a, b = rows // 2 - 1003, rows // 2 + 2001
+    res["rowprog_subrange"] = rel(hl(x[a:b].contiguous()), y[a:b])
+    del y0
+    m = hnn.MessagePackBlock(irr, irr, sh, irr, 64, [64, 64])
+    sd = {k: v.detach().double().numpy() for k, v in m.state_dict().items()}
+    wg = BM.MessagePackWeightGrad(sd, irr, irr, sh, irr)
+    dwf = ops.DeviceWgFused(P.build_tp_wgrad_fused(wg.branches, sh, irr, wg.H), device)
+    E = edges
+    xs, xd, fe, g1, g2 = (torch.randn(E, lay.dim, device=device) * valid for _ in range(5))
+    hn, he = (torch.randn(E, 64, device=device) for _ in range(2))
+    run = lambda g_, S=None, sl=slice(None): ops.tp_wgrad(dwf, [xs[sl], xd[sl], fe[sl]], g_[sl], hn[sl], he[sl], nsplit=S)
+    def f(acc):                                                # the parameter gradients: splits added, the (<= 4) edge-tile copies of every slot gathered
+        flat = acc.double().sum(0)                             # (which copy an edge tile lands in depends on the launch; only their sum is an invariant)
+        return torch.cat([flat[t].sum(1) for t in dwf.tp_pos + dwf.l_pos])
+    a1, s1 = run(g1)
+    a2, s2 = run(g2)
+    a12, s12 = run(g1 + g2)
+    res["wgrad_linearity_acc"] = rel(f(a12), f(a1) + f(a2))
+    res["wgrad_linearity_gs"] = max(rel(u, v + w) for u, v, w in zip(s12, s1, s2))
+    res["wgrad_splits"] = rel(f(run(g1, 7)[0]), f(a1))
+    h = (E // 2 // 16) * 16 + 5                                # a ragged cut: the second half starts inside a 16-edge tile of the whole
+    res["wgrad_halves"] = rel(f(run(g1, None, slice(0, h))[0]) + f(run(g1, None, slice(h, E))[0]), f(a1))
+    return res

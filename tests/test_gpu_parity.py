@@ -548,3 +548,11 @@ def test_row_program_kernel_vs_separate_kernels_and_twin(seed):
     r = G.check_row_program_kernel(seed=seed, **({"irr": bench.IRREPS["A"], "nao": 19, "rows": 45} if seed == 3 else {}))
     print(r)
     assert r["used"] and r["vs_separate_rel_err"] < 5e-6 and r["vs_twin_rel_err"] < 5e-6, r
+
+
+def test_round3_kernels_full_size_properties():
+    """hg_row_program at 822 350 rows and hg_tp_wgrad at 131 072 edges (set-A): size-independent properties, see the check"""
+    r = G.check_new_kernels_full_size()
+    print(r)
+    assert r["rowprog_vs_separate"] < 5e-6 and r["rowprog_subrange"] < 1e-6
+    assert r["wgrad_linearity_acc"] < 2e-5 and r["wgrad_linearity_gs"] < 2e-5 and r["wgrad_splits"] < 2e-5 and r["wgrad_halves"] < 2e-5
