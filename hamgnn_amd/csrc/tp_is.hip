@@ -494,7 +494,7 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
     for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) roff[rt][r] = rtab[16 * rt + 4 * g + r];
-    f32x4 ring[RL_RING][RTM], acc[RTM];
+    f32x4 ring[RL_RING][RTM], acc[RTM], acc2[RTM];
     int dring[RL_RING];
 #pragma unroll
     for (int j = 0; j < RL_RING; ++j) {
@@ -503,7 +503,17 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
         dring[j] = dsc[j];
     }
 #pragma unroll
-    for (int rt = 0; rt < RTM; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rt = 0; rt < RTM; ++rt) acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // the B operands of step t + 1 are requested from LDS BEFORE the MFMAs of step t are issued (a wave issues in order: a read placed after
+    // a dependent MFMA chain waits for it); K-steps alternate between two accumulators (no back-to-back dependent MFMAs for RTM = 1)
+    float bn[4];
+    {
+        const int d0 = __builtin_amdgcn_readfirstlane(dring[0]);
+        const float* __restrict__ fb = stage + (d0 & 1023) * 64;
+        const int nq = ((d0 >> 10) & 3) + 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bn[q] = fb[(q < nq ? q : nq - 1) * 64];
+    }
 #pragma unroll 1
     for (int t0 = 0; t0 < nsteps; t0 += RL_RING) {
 #pragma unroll
@@ -513,37 +523,37 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
             const int d = __builtin_amdgcn_readfirstlane(dring[j]);
-            // the requests of step t + RL_RING: NO branch around them (the compiler waits for every outstanding load at the join of a
-            // conditional one: one L2 round trip per step, 860 cycles, in the first version of this loop)
+            // the requests of step t + RL_RING: NO branch around them (streams are padded: plan._lite_runs)
 #ifndef HG_ABL_RL_NOW
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RL_RING) * RTM + rt) * 64];
 #endif
             dring[j] = dsc[t + RL_RING];
-            const float* __restrict__ fb = stage + (d & 1023) * 64;
-            const int nq = ((d >> 10) & 3) + 1;
             float b[4];
 #pragma unroll
-#ifdef HG_ABL_RL_NOLDS
-            for (int q = 0; q < 4; ++q) b[q] = (float)(q + el);
-#else
-            for (int q = 0; q < 4; ++q) b[q] = fb[(q < nq ? q : nq - 1) * 64];      // no branch: K-steps beyond the block's channels re-read its last
-#endif                                                          // piece and multiply zero weights
+            for (int q = 0; q < 4; ++q) b[q] = bn[q];
+            {                                                  // operands of the next step (slot j + 1 holds step t + 1; after the wrap: the slot refilled above)
+                const int dn = __builtin_amdgcn_readfirstlane(dring[(j + 1) % RL_RING]);
+                const float* __restrict__ fb = stage + (dn & 1023) * 64;
+                const int nq = ((dn >> 10) & 3) + 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) bn[q] = fb[(q < nq ? q : nq - 1) * 64];
+            }
 #pragma unroll
-#ifdef HG_ABL_RL_NOMFMA
-                for (int rt = 0; rt < RTM; ++rt) acc[rt][q] += av[rt][q] * b[q];
-#else
-                for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
-#endif
+            for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) {
+                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q + 1], b[q + 1], acc2[rt], 0, 0, 0);
+                }
             if (d & (1 << 13)) {                               // column complete: add into the tile
                 const int tc = (d >> 16) & 31;
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) {
+                    const f32x4 sum = acc[rt] + acc2[rt];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] += acc[rt][r];
-                    acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // the next step starts a column
+                    for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] += sum[r];
+                    acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // the next step starts a column
                 }
             }
         }
