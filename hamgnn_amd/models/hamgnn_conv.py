@@ -89,6 +89,10 @@ class _BackboneBase(nn.Module):
         for k in ("use_kan", "build_internal_graph"):
             if g(k, False):
                 raise NotImplementedError(f"HamGNN_pre.{k}=True is outside the MI355X hot-path scope of this round (SURVEY 8f)")
+        # use_gradient_checkpointing (hamgnn_conv.py:40-85, 236-246: torch.utils.checkpoint around every layer) is accepted and has nothing to
+        # switch: the backward here keeps ONLY the layer inputs (forward(save_for_backward=True): node rows, edge rows, aggregates) and
+        # re-evaluates every intermediate inside the block backwards -- the memory profile the reference's flag buys
+        self.use_gradient_checkpointing = bool(g("use_gradient_checkpointing", False))
         self.apply_charge_doping = bool(g("apply_charge_doping", False))                 # hamgnn_conv.py:147-153
         if self.apply_charge_doping:
             if self.use_corr_prod:
