@@ -1459,9 +1459,8 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
         lay, nsrc = b["lay"], b["nsrc"]
         w3 = np.asarray(b["w3"], dtype=np.float64) / math.sqrt(H)
         tp_size, ls_size = int(np.asarray(b["tp_w"]).size), int(np.asarray(b["ls_w"]).size)
-        tpp = [[] for _ in range(tp_size)]
+        tpp_t, tpp_p, lpp_t, lpp_p = [], [], [], []            # (flat parameter index, accumulator position) pairs, one per wave that feeds it
         tps = np.zeros(tp_size)
-        lpp = [[] for _ in range(ls_size)]
         nchs.append(int(w3.shape[1]))
         by_i: Dict[int, list] = {}
         for sp in _tp_superpaths(nsrc, lay, irreps_sh, irreps_out, np.asarray(b["tp_w"]), w3, np.asarray(b["ls_w"]),
@@ -1543,37 +1542,42 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
                     rec[WG_WREC + WG_WREC_I32 * w_:WG_WREC + WG_WREC_I32 * (w_ + 1)] = [1, e, nc, sp["par"], (mmax - mm) * in_mulp, seg_lds[k], g_mulp, my_w, accoff, my_ch]
                     # where the gradient of every flat parameter lands: this wave's block, fragment f, row, channel
                     meta = sp["meta"][r0:r1]
-                    for rho in range(n):
-                        nidx, wch, cpath, lrow = meta[rho]
-                        for s_ in range(nsrc):
-                            u = np.arange(mi)
-                            pos = accoff + (s_ * G1 + u // 16) * 256 + rho * 16 + u % 16
-                            tgt = sp["woff"][nidx] + wch + (s_ * mi + u) * mk
-                            for a_, p_ in zip(tgt, pos):
-                                tpp[a_].append(int(p_))
-                            tps[tgt] = cpath
-                        w2 = np.arange(mk)
-                        pos = accoff + (nsrc * G1 + w2 // 16) * 256 + rho * 16 + w2 % 16
-                        off, fan = sp["lin"]
-                        tgt = off + lrow * mk + w2
-                        for a_, p_ in zip(tgt, pos):
-                            lpp[a_].append(int(p_))
+                    rho = np.arange(n)
+                    base_w = np.array([sp["woff"][m_[0]] + m_[1] for m_ in meta], dtype=np.int64)
+                    cps = np.array([m_[2] for m_ in meta])
+                    lrows = np.array([m_[3] for m_ in meta], dtype=np.int64)
+                    u = np.arange(mi)
+                    for s_ in range(nsrc):
+                        pos = accoff + ((s_ * G1 + u // 16) * 256 + u % 16)[None, :] + rho[:, None] * 16
+                        tgt = base_w[:, None] + ((s_ * mi + u) * mk)[None, :]
+                        tpp_t.append(tgt.reshape(-1))
+                        tpp_p.append(pos.reshape(-1))
+                        tps[tgt] = cps[:, None]
+                    w2 = np.arange(mk)
+                    pos = accoff + ((nsrc * G1 + w2 // 16) * 256 + w2 % 16)[None, :] + rho[:, None] * 16
+                    tgt = sp["lin"][0] + lrows[:, None] * mk + w2[None, :]
+                    lpp_t.append(tgt.reshape(-1))
+                    lpp_p.append(pos.reshape(-1))
                     accoff += nfr * 256
                     if e == 0:
                         total_cost += cost
                 units.append(rec)
                 lds_max = max(lds_max, 2 * ET * 16 * RS * 4)
                 total_bytes += used * 4.0
-        tp_pos.append(tpp)
+        tp_pos.append((np.concatenate(tpp_t), np.concatenate(tpp_p), tp_size))
         tp_scale.append(tps)
-        l_pos.append(lpp)
+        l_pos.append((np.concatenate(lpp_t), np.concatenate(lpp_p), ls_size))
         seen_ch.append(set(int(c) for sp_ in by_i.values() for (sp__, t_, *_) in sp_ for c in sp__["ch"][16 * t_:16 * t_ + 16]))
     zero = accoff                                              # one spare slot that stays zero
-    def table(lists):
-        out = np.full((len(lists), 4), zero, np.int64)
-        for a, l_ in enumerate(lists):
-            assert len(l_) <= 4
-            out[a, :len(l_)] = l_
+    def table(pairs):                                          # [n parameters, 4]: the (<= 4) edge-tile copies of every parameter's slot, padded with the zero slot
+        tgt, pos, n_ = pairs
+        order_ = np.argsort(tgt, kind="stable")
+        tgt, pos = tgt[order_], pos[order_]
+        first = np.searchsorted(tgt, tgt, side="left")
+        col = np.arange(tgt.size) - first
+        assert col.max(initial=0) < 4
+        out = np.full((n_, 4), zero, np.int64)
+        out[tgt, col] = pos
         return out
     U = np.asarray(units, dtype=np.int64)
     order = np.argsort(-U[:, 13], kind="stable")               # dearest units first (the hardware hands workgroups out in order)
