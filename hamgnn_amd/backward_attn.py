@@ -6,7 +6,7 @@ forward kernels: csrc/attention.hip hg_attn_logits / hg_attn_aggregate):
     agg[n, col] = sum_{e: dst_e = n} alpha[e, head(col)] V[e, col]
 
 Gradients with respect to the key rows K [N, Dp], the value rows V [E, Dp] and the learnable cutoff parameter p, as gathers, two small
-GEMMs against the column -> head indicator and `index_add_`s (torch tensor ops on the device; edge-level, HBM-bound: the HIP form is the
+GEMMs against the column -> head indicator and fixed-order row scatters (`ops.scatter_rows`: stable sort + segmented sum, no float atomics; torch tensor ops on the device; edge-level, HBM-bound: the HIP form is the
 two forward kernels with the roles of `agg` and `V` exchanged -- first version).  Device-agnostic: the CPU suite checks it against
 autograd through the oracle."""
 from __future__ import annotations
@@ -14,6 +14,8 @@ from __future__ import annotations
 import math
 
 import torch
+
+from . import ops
 
 
 def attention_backward(K: torch.Tensor, V: torch.Tensor, g_agg: torch.Tensor, src: torch.Tensor, dst: torch.Tensor, length: torch.Tensor,
@@ -42,18 +44,18 @@ def attention_backward(K: torch.Tensor, V: torch.Tensor, g_agg: torch.Tensor, sr
     if allreduce is not None:
         allreduce(mx, "max")
     ex = torch.exp(logit - mx[dst])
-    zsum = torch.zeros(N, num_heads, device=K.device, dtype=dt).index_add_(0, dst, ex)
+    zsum = ops.scatter_rows(dst, ex, N)
     if allreduce is not None:
         allreduce(zsum, "sum")
     alpha = ex / (zsum + 1e-16)[dst]                                            # [E, H]
     g_V = (alpha @ M.t()) * Gd
     g_alpha = (V * Gd) @ M                                                      # [E, H]
-    dot = torch.zeros(N, num_heads, device=K.device, dtype=dt).index_add_(0, dst, alpha * g_alpha)
+    dot = ops.scatter_rows(dst, alpha * g_alpha, N)
     if allreduce is not None:
         allreduce(dot, "sum")
     g_logit = alpha * (g_alpha - dot[dst])
     g_D = (g_logit * cut[:, None] * scale) @ M.t()                              # [E, Dp], per column of its head
-    g_K = torch.zeros_like(K).index_add_(0, src, g_D * Kd).index_add_(0, dst, g_D * Ks)
+    g_K = ops.scatter_rows(src, g_D * Kd, N) + ops.scatter_rows(dst, g_D * Ks, N)      # fixed summation order (no float atomics)
     g_cut = (g_logit * Dh).sum(1) * scale                                       # [E]
     g_p = (g_cut * torch.where(pos, cut / (xs * xs), torch.zeros_like(x)) * u).sum().reshape(1)
     if allreduce is not None:

@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import plan as P
+from .ops import scatter_rows as _scatter_rows
 
 
 def _block(x: torch.Tensor, off: int, mulp: int, comps: Sequence[int], nch: int) -> torch.Tensor:
@@ -151,7 +152,7 @@ def weight_grads_from_rows(wg, ArowsT: torch.Tensor, BrowsT: torch.Tensor, srcsT
             lay_dim = xcat[name][0].shape[0] // len(xcat[name][1])
             for t, sl in enumerate(xcat[name][1]):                                 # rows of slot t of the concatenated sources
                 sel = (rows >= t * lay_dim) & (rows < (t + 1) * lay_dim)
-                gxT[sl].index_add_(0, rows[sel] - t * lay_dim, GX[sel])
+                gxT[sl] += _scatter_rows(rows[sel] - t * lay_dim, GX[sel], gxT[sl].shape[0])      # fixed summation order (no float atomics)
 
 
 class TPWeightGrad:

@@ -224,7 +224,7 @@ class _BackboneBase(nn.Module):
         g_delta = g_emb.pop("_g_delta", None)
         grads.update({"pair_embedding." + k: v for k, v in g_emb.items()})
         T, lay = self.num_types, self.layout
-        gtab = torch.zeros(T, lay.dim, device=g_node.device, dtype=g_node.dtype).index_add_(0, z.long(), g_node)
+        gtab = ops.scatter_rows(z, g_node, T)                   # fixed summation order (no float atomics)
         if delta is not None:                                   # node rows = (one_hot(z) + delta) @ table
             gtab = gtab + delta.t() @ g_node
             g_delta = g_delta + g_node @ self._chem.t()

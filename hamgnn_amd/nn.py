@@ -610,7 +610,7 @@ class AttentionBlockE3(nn.Module):
         logits = ops.attention_logits(K, geo, self._head_tab, H, self.head_dim, self._cut, self.cutoff)
         dst = geo.dst.long()
         m_r = torch.full((N, H), -float("inf"), device=K.device, dtype=logits.dtype).scatter_reduce(0, dst[:, None].expand(-1, H), logits, "amax")
-        Z_r = torch.zeros(N, H, device=K.device, dtype=logits.dtype).index_add_(0, dst, torch.exp(logits - m_r[dst]))
+        Z_r = ops.scatter_rows(dst, torch.exp(logits - m_r[dst]), N)
         m = m_r.clone()
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
         scale = torch.where(torch.isinf(m_r), torch.zeros_like(m_r), torch.exp(m_r - m))
@@ -766,8 +766,8 @@ class PairInteractionEmbeddingBlock(nn.Module):
         N = z.shape[0]
         g_delta = torch.zeros(N, T, device=dev, dtype=gx.dtype) if delta is not None else None
         for name, idx, tab in (("linear_up_src", geo.src, self._Ts), ("linear_up_dst", geo.dst, self._Td)):
-            g_atom = torch.zeros(N, T, device=dev, dtype=gx.dtype).index_add_(0, idx.long(), gx)      # gradient of the per-atom table rows
-            gT = torch.zeros(T, T, device=dev, dtype=gx.dtype).index_add_(0, z.long(), g_atom)        # rows one_hot(z) @ table
+            g_atom = ops.scatter_rows(idx, gx, N)              # gradient of the per-atom table rows (fixed summation order: no float atomics)
+            gT = ops.scatter_rows(z, g_atom, T)                # rows one_hot(z) @ table
             if delta is not None:                              # rows (one_hot(z) + delta) @ table
                 gT = gT + delta.t() @ g_atom
                 g_delta += g_atom @ tab.t()

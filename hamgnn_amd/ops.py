@@ -331,6 +331,18 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     return out
 
 
+def scatter_rows(index: torch.Tensor, src: torch.Tensor, n: int) -> torch.Tensor:
+    """out[i] = sum of the rows src[q] with index[q] == i, in a FIXED order (stable sort by index, then a segmented sum): the
+    deterministic form of torch.zeros(n, ...).index_add_(0, index, src), whose float atomics make a training step differ from run to run.
+    torch tensor ops (sort / segment_reduce), any device; edge-level glue of the backward passes, not a hot kernel."""
+    index = index.long()
+    if src.shape[0] == 0:
+        return src.new_zeros((n,) + tuple(src.shape[1:]))
+    order = torch.sort(index, stable=True).indices
+    counts = torch.bincount(index, minlength=n)
+    return torch.segment_reduce(src[order].contiguous(), "sum", lengths=counts, axis=0, unsafe=True)
+
+
 class DeviceRowProgram:
     """plan.RowProgram uploaded to the GPU (csrc/rowprog.hip)"""
 

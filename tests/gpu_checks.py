@@ -1783,3 +1783,41 @@ def check_new_kernels_full_size(device="cuda", rows=822350, edges=131072):
     h = (E // 2 // 16) * 16 + 5                                # a ragged cut: the second half starts inside a 16-edge tile of the whole
     res["wgrad_halves"] = rel(f(run(g1, None, slice(0, h))[0]) + f(run(g1, None, slice(h, E))[0]), f(a1))
     return res
+
+
+def check_training_step_reproducible(device="cuda", transformer=False, n_atoms=260):
+    """two evaluations of hamgnn_amd.training.training_step on the same model and batch give BIT-identical losses and gradients: the node
+    scatter (hg_segment_sum), the fused weight-gradient kernel (split / copy blocks added in a fixed order) and the row scatters of the
+    backward glue (ops.scatter_rows instead of index_add_ atomics) have a fixed summation order"""
+    import bench
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    from hamgnn_amd.training import training_step
+    irr = MINI
+    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=irr, use_kan=False,
+               radial_MLP=[16, 64], correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=False)
+    if transformer:
+        from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer as Backbone
+        cfg.update(num_heads=2)
+    else:
+        Backbone = HamGNNConvE3
+    torch.manual_seed(3)
+    model = Model(Backbone(cfg), HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
+                                                   soc_switch=False, calculate_sparsity=True, zero_point_shift=False)).to(device)
+    # (> 300 edge tiles: single-part launches.  The split launches of small crystals claim their work dynamically into private tile copies;
+    #  their accumulation order -- and only theirs -- varies between runs, at fp32 rounding level: DESIGN.md section 5)
+    g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=11, density=0.004), 19, seed=11).to(device)
+    runs = []
+    for _ in range(2):
+        for p_ in model.parameters():
+            p_.grad = None
+        out = training_step(model, g, metric="mae")
+        torch.cuda.synchronize()
+        runs.append((out["loss"].clone(), {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}))
+    diffs = {k: float((runs[0][1][k] - runs[1][1][k]).abs().max()) for k in runs[0][1]}
+    worst = max(diffs, key=diffs.get)
+    return {"loss_diff": float((runs[0][0] - runs[1][0]).abs()), "max_grad_diff": diffs[worst], "worst": worst, "differing": sorted(k for k, v in diffs.items() if v > 0)[:8],
+            "n_params": len(runs[0][1]), "E": int(g.num_edges)}

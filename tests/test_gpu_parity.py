@@ -556,3 +556,10 @@ def test_round3_kernels_full_size_properties():
     print(r)
     assert r["rowprog_vs_separate"] < 5e-6 and r["rowprog_subrange"] < 1e-6
     assert r["wgrad_linearity_acc"] < 2e-5 and r["wgrad_linearity_gs"] < 2e-5 and r["wgrad_splits"] < 2e-5 and r["wgrad_halves"] < 2e-5
+
+
+def test_training_step_is_bit_reproducible():
+    """the default model's training step has a fixed summation order everywhere: loss and every gradient bit-identical between two runs"""
+    r = G.check_training_step_reproducible()
+    print(r)
+    assert r["loss_diff"] == 0.0 and r["max_grad_diff"] == 0.0 and r["n_params"] > 60, r
