@@ -130,6 +130,12 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const f32x4* __restrict__ a2e = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
     f32x4 a2_e[RTM];
 #define IS_A2_EARLY() else if (typ == 0) { _Pragma("unroll") for (int rt = 0; rt < RTM; ++rt) a2_e[rt] = a2e[rt * 64]; }
+#elif defined(HG_IS_TOUCH)             // A/B hook (r3): under the LAST GEMM1 group, one dword per 64-byte line of the coefficient block and of GEMM2's
+                                       // first fragment tiles -- so that the loads GEMM2 starts with (and waits for at once) hit the L1
+    float touch0 = 0.f, touch1 = 0.f;
+    const float* __restrict__ tch_cf = Wb + it[13] + (lane < RTM * NCR ? lane : RTM * NCR - 1) * 16;
+    const float* __restrict__ tch_a2 = Wb + it[14] + (lane < 16 * RTM ? lane : 16 * RTM - 1) * 16;
+#define IS_A2_EARLY() else if (typ == 0) { touch0 = *tch_cf; touch1 = *tch_a2; }
 #else
 #define IS_A2_EARLY()
 #endif
@@ -199,6 +205,14 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
+#ifdef HG_IS_SGB                       // A/B hook (r3; measured neutral: 7.36-7.39 vs 7.35-7.37 ms, off)
+                        // one row tile: every operand has ONE consumer and the scheduler emits read -> wait -> MFMA per column (an LDS
+                        // latency per MFMA; ISA audit, profiles/r03_tp_is_experiments.md): all NC reads first, then the NC MFMAs
+                        if (RTM == 1 && NC > 1) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, NC, 0);
+                        }
+#endif
                     }
                 }
             }
@@ -221,6 +235,9 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NCR + IS_COL(c)) * 4];
+#ifdef HG_IS_TOUCH
+        asm volatile("" :: "v"(touch0), "v"(touch1));
+#endif
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
         // rows beyond mul_k (fragment padding) go to the shared trash row: no divergent branches (their L' columns are zero)
@@ -388,10 +405,18 @@ __device__ __forceinline__ void item_lite(const IsArgs& A, const float* __restri
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
         }
+        // all tile reads, then all writes: written as "+=" the compiler keeps every read behind the previous write (the rows may alias
+        // for all it knows) -- one LDS round trip per ELEMENT (ISA audit, profiles/r03_lite.md).  Rows are distinct except the shared
+        // trash row of padding rows, whose value nobody reads.
+        float told[RTM][4];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + c * 16] += cfc * acc[rt][r];
+            for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + c * 16];
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + c * 16] = told[rt][r] + cfc * acc[rt][r];
     }
 }
 
@@ -455,11 +480,18 @@ __device__ __forceinline__ void item_lite_m(const IsArgs& A, const float* __rest
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
                 if (++f == nfr) {                              // column complete: add into the tile
+#ifndef HG_ABL_LINM_NOWB
+                    float told[RTM][4];                        // all reads, then all writes (see item_lite)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + c * 16];
+#endif
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) {
 #pragma unroll
 #ifndef HG_ABL_LINM_NOWB
-                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + c * 16] += acc[rt][r];
+                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + c * 16] = told[rt][r] + acc[rt][r];
 #else
                         if (acc[rt][0] == 1.2345f) tbase[roff[rt][0]] = 0.f;
 #endif
@@ -488,7 +520,16 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
     float* __restrict__ tbase = lds + A.tile_shift + (el - lk * 16);
     const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t, row tile rt: aw[(t * RTM + rt) * 64]
-    const int* __restrict__ dsc = reinterpret_cast<const int*>(Wb + it[12]);
+#ifndef HG_RL_VDESC
+    const int* __restrict__ dsc = reinterpret_cast<const int*>(Wb + it[12]);       // uniform address: the compiler makes these scalar loads
+#else
+    // A/B hook (r3): descriptors through the VECTOR memory path, RL_RING steps ahead like the fragments (an opaque zero makes the address
+    // formally divergent) instead of scalar loads issued at the end of an iteration and waited for at its head; measured SLOWER
+    // (5.41 vs 5.15 ms per 131 072 edges: one more vector-memory instruction per step), off
+    int lane0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
+    const int* __restrict__ dsc = reinterpret_cast<const int*>(Wb + it[12]) + lane0;
+#endif
     int roff[RTM][4];
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt)
@@ -501,6 +542,9 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
         dring[j] = dsc[j];
+        // slot order = request order: the scheduler issued these back to front, and the wait at the loop head -- one static instruction
+        // for both the first and the later iterations -- became vmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -523,11 +567,6 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
             const int d = __builtin_amdgcn_readfirstlane(dring[j]);
-            // the requests of step t + RL_RING: NO branch around them (streams are padded: plan._lite_runs)
-#ifndef HG_ABL_RL_NOW
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RL_RING) * RTM + rt) * 64];
-#endif
             dring[j] = dsc[t + RL_RING];
             float b[4];
 #pragma unroll
@@ -548,14 +587,27 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
                 }
             if (d & (1 << 13)) {                               // column complete: add into the tile
                 const int tc = (d >> 16) & 31;
+                float told[RTM][4];                            // all reads, then all writes (see item_lite)
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + tc * 16];
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) {
                     const f32x4 sum = acc[rt] + acc2[rt];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] += sum[r];
+                    for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] = told[rt][r] + sum[r];
                     acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // the next step starts a column
                 }
             }
+            // the fragment requests of step t + RL_RING: NO branch around them (streams are padded: plan._lite_runs), and issued AFTER the
+            // step's MFMAs have read slot j -- requested before them, the new value cannot share the slot's registers, the compiler rotates
+            // the whole ring with v_mov at the loop's back-edge and has to wait for EVERY outstanding load there (vmcnt(0) once per RL_RING
+            // steps; ISA audit, profiles/r03_lite.md)
+#ifndef HG_ABL_RL_NOW
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RL_RING) * RTM + rt) * 64];
+#endif
         }
     }
 }
