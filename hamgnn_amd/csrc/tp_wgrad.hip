@@ -141,6 +141,14 @@ __device__ __forceinline__ void wg_idle(const WgArgs& A, const int* __restrict__
     }
 }
 
+// Every LDS operand of the MFMA phases has ONE consumer, and the scheduler emits read -> s_waitcnt lgkmcnt(0) -> v_mfma per operand: an LDS
+// round trip per MFMA, in all four waves of a workgroup at once (they run the phases in lock step).  WG_SGB(cond, n): "n LDS reads, then
+// n MFMAs" for the instructions just written (ISA audit, profiles/r03_wgrad.md); -DWG_NO_SGB restores the compiler's order.
+#ifndef WG_NO_SGB
+#define WG_SGB(cond, n) if (cond) { __builtin_amdgcn_sched_group_barrier(0x100, (n), 0); __builtin_amdgcn_sched_group_barrier(0x008, (n), 0); }
+#else
+#define WG_SGB(cond, n)
+#endif
 template <int NC, int NSRC, int G1, int G2>
 __device__ __forceinline__ void wg_wave(const WgArgs& A, const int* __restrict__ U, const int* __restrict__ Wr, const float* __restrict__ Wg,
                                         const int* __restrict__ chtab, float* __restrict__ lds, int split, int nsplit) {
@@ -233,8 +241,10 @@ __device__ __forceinline__ void wg_wave(const WgArgs& A, const int* __restrict__
                                 if (NC == 1 && (q & 1)) mid2 = wg_mfma(a, fW[s][G][q], mid2);
                                 else mid[c] = wg_mfma(a, fW[s][G][q], mid[c]);
                             }
+                            WG_SGB(NC > 1, NC)
                         }
                     }
+                    WG_SGB(NC == 1 && G + 1 < G1, 4)
                 }
             }
             {
@@ -251,8 +261,10 @@ __device__ __forceinline__ void wg_wave(const WgArgs& A, const int* __restrict__
                                 if (NC == 1 && (q & 1)) bm2 = wg_mfma(a, fL[G][q], bm2);
                                 else bm[c] = wg_mfma(a, fL[G][q], bm[c]);
                             }
+                            WG_SGB(NC > 1, NC)
                         }
                     }
+                    WG_SGB(NC == 1 && G + 1 < G2, 4)
                 }
             }
             {
@@ -265,6 +277,7 @@ __device__ __forceinline__ void wg_wave(const WgArgs& A, const int* __restrict__
                         if (q & 1) sv2 = wg_mfma(ha[4 * (4 * G + q)], f3[G][q], sv2);
                         else sv = wg_mfma(ha[4 * (4 * G + q)], f3[G][q], sv);
                     }
+                    WG_SGB(true, 4)
                 }
                 sv += sv2;
             }
@@ -319,6 +332,7 @@ __device__ __forceinline__ void wg_wave(const WgArgs& A, const int* __restrict__
                     const float* __restrict__ gb = xb + goff + c * g_mulp + r * RS;
 #pragma unroll
                     for (int t = 0; t < G2; ++t) accL[t] = wg_mfma(gb[16 * t], mid[c][r], accL[t]);
+                    WG_SGB(true, NSRC * G1 + G2)
                 }
             }
         }
