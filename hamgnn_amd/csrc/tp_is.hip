@@ -333,12 +333,20 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
         const int row0 = it[16];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
+        {                                                      // a row tile's reads, then its writes (as "+=" per element the compiler chains
+            float* __restrict__ t0[4];                         // read -> wait -> write through all rows: they may alias for all it knows)
+            float told[4][NC];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float* __restrict__ t0 = tbase + rtab[row0 + 16 * rt + 4 * g + r];
+                t0[r] = tbase + rtab[row0 + 16 * rt + 4 * g + r];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) t0[IS_COL(c) * 16] += mid[rt][c][r];
+                for (int c = 0; c < NC; ++c) told[r][c] = t0[r][IS_COL(c) * 16];
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) t0[r][IS_COL(c) * 16] = told[r][c] + mid[rt][c][r];
+        }
     }
     IS_T(3);                                                    // scale-mul + GEMM2 + write-back
 #undef IS_COL
@@ -631,6 +639,11 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
     f32x4 S[RTO];
 #pragma unroll
     for (int rt = 0; rt < RTO; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 av[RTO][RTO];                                         // the segment's Lc fragments, resident for all its columns; requested ahead of
+#pragma unroll                                                  // the radial phase (they were waited for right after their request)
+    for (int rtp = 0; rtp < RTO; ++rtp)
+#pragma unroll
+        for (int rt = 0; rt < RTO; ++rt) av[rtp][rt] = a2[(rtp * RTO + rt) * 64];
     const int hgrp = A.hidden >> 4;
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
@@ -659,11 +672,6 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
     for (int rt = 0; rt < RTO; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rowoff[rt][r] = rtab[16 * rt + 4 * g + r];
-    f32x4 av[RTO][RTO];                                         // the segment's Lc fragments, resident for all its columns
-#pragma unroll
-    for (int rtp = 0; rtp < RTO; ++rtp)
-#pragma unroll
-        for (int rt = 0; rt < RTO; ++rt) av[rtp][rt] = a2[(rtp * RTO + rt) * 64];
     constexpr int CH = RTO >= 3 ? 2 : 4;                        // columns per chunk (register budget)
 #pragma unroll 1
     for (int c0 = 0; c0 < nco; c0 += CH) {
