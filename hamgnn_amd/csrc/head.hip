@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restric
     float* __restrict__ s_raw = reinterpret_cast<float*>(s_rc + nao2); // [R][rlen]   raw rows, later the merged nao x nao blocks
     float* __restrict__ s_coef = s_raw + R * rlen;             // [R][nslots] un-rotated coefficients
     float* __restrict__ s_mask = s_coef + R * nslots;          // [R][2][nao] orbital masks of the row's two atoms
-    __shared__ int64_t s_row[R];
     for (int i = threadIdx.x; i <= nao2; i += blockDim.x) s_ptr[i] = cg_ptr[i];
     for (int i = threadIdx.x; i < nnz; i += blockDim.x) {
         s_idx[i] = cg_idx[i];
@@ -128,38 +127,106 @@ __global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restric
     }
     const bool sym = flags & 1, h0_last = flags & 2;
     const int64_t ngroups = (npairs + HR_PAIRS - 1) / HR_PAIRS;
-    for (int64_t gp = blockIdx.x; gp < ngroups; gp += gridDim.x) {
-        __syncthreads();                                       // tables staged / previous group's buffers free
-        if (threadIdx.x < R) {
-            const int64_t p = gp * HR_PAIRS + (threadIdx.x >> 1);
-            int64_t row = -1;
-            if (p < npairs) {
-                const int64_t ra = pair_a ? pair_a[p] : p;
-                const int64_t rb = pair_b ? pair_b[p] : ra;
-                row = (threadIdx.x & 1) ? (rb == ra ? -1 : rb) : ra;       // self-paired rows occupy slot 0 of their pair only
-            }
-            s_row[threadIdx.x] = row;
-        }
-        __syncthreads();
-        // ---- bulk staging: contiguous coefficient row + leading part of the Wigner row + the two mask rows; every row of the group in
-        //      flight at once
+    // Software pipeline over the block's groups (r3, late): the rows of group i + 1 -- coefficient row, Wigner row, masks -- and the H0
+    // values of group i are requested into registers at the top of group i and land under its three LDS -> LDS stages; before, every
+    // group exposed its row-index load, its row loads and its H0 loads one after the other (3.4 ms per 822 k rows for 4 GB of traffic).
+    // Register slots: HR_CJ x 256 coefficient floats, HR_WJ x 256 Wigner floats, HR_HJ x 256 H0 values per row (wider rows: direct loads).
+    constexpr int HR_CJ = 2, HR_WJ = 1, HR_HJ = 2;
+    float pc[R][HR_CJ], pw[R][HR_WJ], pm[R];
+    int64_t rown[R];                                           // the next group's rows (uniform)
+    int zn[R][2];                                              // ... and the species of their two atoms (uniform: scalar loads -- as a
+                                                               // per-thread chain atom -> species -> mask it put a vmcnt(0) into the requests)
+    auto rows_of = [&](int64_t gq, int64_t (&rw)[R]) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int64_t e = s_row[r];
-            float* __restrict__ dst = s_raw + r * rlen;
+            const int64_t p = gq * HR_PAIRS + (r >> 1);
+            int64_t row = -1;
+            if (gq < ngroups && p < npairs) {
+                const int64_t ra = pair_a ? pair_a[p] : p;
+                const int64_t rb = pair_b ? pair_b[p] : ra;
+                row = (r & 1) ? (rb == ra ? -1 : rb) : ra;     // self-paired rows occupy slot 0 of their pair only
+            }
+            rw[r] = row;
+            if (orb_mask && row >= 0) {
+                zn[r][0] = (int)z[ia ? ia[row] : row];
+                zn[r][1] = (int)z[ib ? ib[row] : row];
+            }
+        }
+    };
+    auto request = [&](const int64_t (&rw)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t e = rw[r];
             if (e < 0) continue;
             const float* __restrict__ c = coeff + e * cs;
-            for (int k = threadIdx.x; k < cw; k += blockDim.x) dst[k] = c[k];
+#pragma unroll
+            for (int j = 0; j < HR_CJ; ++j) {
+                const int k = threadIdx.x + j * 256;
+                if (k < cw) pc[r][j] = c[k];
+            }
             if (wig) {
                 const float* __restrict__ D = wig + e * nW;
-                for (int k = threadIdx.x; k < nWuse; k += blockDim.x) dst[cw + k] = D[k];
+#pragma unroll
+                for (int j = 0; j < HR_WJ; ++j) {
+                    const int k = threadIdx.x + j * 256;
+                    if (k < nWuse) pw[r][j] = D[k];
+                }
             }
             if (orb_mask && threadIdx.x < 2 * nao) {
                 const int side = threadIdx.x >= nao, o = threadIdx.x - side * nao;
-                const int64_t atom = side ? (ib ? ib[e] : e) : (ia ? ia[e] : e);
-                s_mask[(r * 2 + side) * nao + o] = orb_mask[z[atom] * mask_w + o % mask_w];
+                pm[r] = orb_mask[(side ? zn[r][1] : zn[r][0]) * mask_w + o % mask_w];
             }
         }
+    };
+    rows_of(blockIdx.x, rown);
+    request(rown);
+    for (int64_t gp = blockIdx.x; gp < ngroups; gp += gridDim.x) {
+        int64_t rowc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rowc[r] = rown[r];
+        __syncthreads();                                       // tables staged / previous group's buffers free
+        // ---- the group's rows: registers -> LDS (wider rows than the register slots: the rest straight from memory)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t e = rowc[r];
+            float* __restrict__ dst = s_raw + r * rlen;
+            if (e < 0) continue;
+#pragma unroll
+            for (int j = 0; j < HR_CJ; ++j) {
+                const int k = threadIdx.x + j * 256;
+                if (k < cw) dst[k] = pc[r][j];
+            }
+            const float* __restrict__ c = coeff + e * cs;
+            for (int k = threadIdx.x + HR_CJ * 256; k < cw; k += blockDim.x) dst[k] = c[k];
+            if (wig) {
+#pragma unroll
+                for (int j = 0; j < HR_WJ; ++j) {
+                    const int k = threadIdx.x + j * 256;
+                    if (k < nWuse) dst[cw + k] = pw[r][j];
+                }
+                const float* __restrict__ D = wig + e * nW;
+                for (int k = threadIdx.x + HR_WJ * 256; k < nWuse; k += blockDim.x) dst[cw + k] = D[k];
+            }
+            if (orb_mask && threadIdx.x < 2 * nao) {
+                const int side = threadIdx.x >= nao, o = threadIdx.x - side * nao;
+                s_mask[(r * 2 + side) * nao + o] = pm[r];
+            }
+        }
+        // ---- requests that travel under this group's stages: its H0 values, the next group's rows
+        float ph[R][HR_HJ];
+        if (H0) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (rowc[r] < 0) continue;
+#pragma unroll
+                for (int j = 0; j < HR_HJ; ++j) {
+                    const int q = threadIdx.x + j * 256;
+                    if (q < nao2) ph[r][j] = H0[rowc[r] * nao2 + q];
+                }
+            }
+        }
+        rows_of(gp + gridDim.x, rown);
+        request(rown);
         __syncthreads();
         // ---- un-rotate: coef[q] = sum_m D^L[m][a] c[L slot][m]
         for (int q = threadIdx.x; q < nslots; q += blockDim.x) {
@@ -167,7 +234,7 @@ __global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restric
             const int n = 2 * t.x + 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                if (s_row[r] < 0) continue;
+                if (rowc[r] < 0) continue;
                 const float* __restrict__ c = s_raw + r * rlen;
                 float acc;
                 if (wig) {
@@ -197,22 +264,31 @@ __global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restric
         }
         __syncthreads();
         // ---- symmetrise against the partner row, + H0, mask, store
-        for (int q = threadIdx.x; q < nao2; q += blockDim.x) {
+        auto finish = [&](int q, int r, float h0) {
+            const int64_t e = rowc[r];
             const int code = s_rc[q];
             const int rr = code & 0xff, cc = (code >> 8) & 0xff, qt = code >> 16;
+            const int rp = rowc[r ^ 1] >= 0 ? (r ^ 1) : r;     // partner slot (itself for self-paired rows)
+            float v = s_raw[r * rlen + q];
+            if (sym) v = 0.5f * (v + sign * s_raw[rp * rlen + qt]);
+            if (!h0_last) v += h0;
+            if (orb_mask) v *= s_mask[(r * 2) * nao + rr] * s_mask[(r * 2 + 1) * nao + cc];
+            if (h0_last) v += h0;
+            H[e * nao2 + q] = v;
+        };
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int64_t e = s_row[r];
-                if (e < 0) continue;
-                const int rp = s_row[r ^ 1] >= 0 ? (r ^ 1) : r; // partner slot (itself for self-paired rows)
-                float v = s_raw[r * rlen + q];
-                if (sym) v = 0.5f * (v + sign * s_raw[rp * rlen + qt]);
-                const float h0 = H0 ? H0[e * nao2 + q] : 0.f;
-                if (!h0_last) v += h0;
-                if (orb_mask) v *= s_mask[(r * 2) * nao + rr] * s_mask[(r * 2 + 1) * nao + cc];
-                if (h0_last) v += h0;
-                H[e * nao2 + q] = v;
+        for (int j = 0; j < HR_HJ; ++j) {
+            const int q = threadIdx.x + j * 256;
+            if (q < nao2) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (rowc[r] >= 0) finish(q, r, H0 ? ph[r][j] : 0.f);
             }
+        }
+        for (int q = threadIdx.x + HR_HJ * 256; q < nao2; q += blockDim.x) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (rowc[r] >= 0) finish(q, r, H0 ? H0[rowc[r] * nao2 + q] : 0.f);
         }
     }
 }
