@@ -136,20 +136,30 @@ __global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restric
     int64_t rown[R];                                           // the next group's rows (uniform)
     int zn[R][2];                                              // ... and the species of their two atoms (uniform: scalar loads -- as a
                                                                // per-thread chain atom -> species -> mask it put a vmcnt(0) into the requests)
-    auto rows_of = [&](int64_t gq, int64_t (&rw)[R]) {
+    auto rows_of = [&](int64_t gq, int64_t (&rw)[R]) {       // three rounds of independent scalar loads (pairs -> atoms -> species), no branch
+        int64_t ra[HR_PAIRS], rb[HR_PAIRS];                    // between them: invalid slots read row 0 and are dropped afterwards
+        bool ok[HR_PAIRS];
+#pragma unroll
+        for (int pr = 0; pr < HR_PAIRS; ++pr) {
+            const int64_t p = gq * HR_PAIRS + pr;
+            ok[pr] = gq < ngroups && p < npairs;
+            const int64_t pcl = ok[pr] ? p : 0;
+            ra[pr] = pair_a ? pair_a[pcl] : pcl;
+            rb[pr] = pair_b ? pair_b[pcl] : ra[pr];
+        }
+        int64_t aa[R], bb[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int64_t p = gq * HR_PAIRS + (r >> 1);
-            int64_t row = -1;
-            if (gq < ngroups && p < npairs) {
-                const int64_t ra = pair_a ? pair_a[p] : p;
-                const int64_t rb = pair_b ? pair_b[p] : ra;
-                row = (r & 1) ? (rb == ra ? -1 : rb) : ra;     // self-paired rows occupy slot 0 of their pair only
-            }
-            rw[r] = row;
-            if (orb_mask && row >= 0) {
-                zn[r][0] = (int)z[ia ? ia[row] : row];
-                zn[r][1] = (int)z[ib ? ib[row] : row];
+            const int64_t row = (r & 1) ? rb[r >> 1] : ra[r >> 1];
+            rw[r] = !ok[r >> 1] ? -1 : ((r & 1) && rb[r >> 1] == ra[r >> 1]) ? -1 : row;      // self-paired rows occupy slot 0 of their pair only
+            aa[r] = ia ? ia[row] : row;
+            bb[r] = ib ? ib[row] : row;
+        }
+        if (orb_mask) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                zn[r][0] = (int)z[aa[r]];
+                zn[r][1] = (int)z[bb[r]];
             }
         }
     };
@@ -239,8 +249,8 @@ __global__ __launch_bounds__(256) void ham_readout_kernel(const float* __restric
                 float acc;
                 if (wig) {
                     const float* __restrict__ Dl = c + cw + wo.o[t.x];
-                    acc = 0.f;
-                    for (int m = 0; m < n; ++m) acc = fmaf(Dl[m * n + t.y], c[t.z + m * t.w], acc);
+                    acc = 0.f;                                 // (compile-time trip counts per L through a switch: the slots of a wave span several
+                    for (int m = 0; m < n; ++m) acc = fmaf(Dl[m * n + t.y], c[t.z + m * t.w], acc);       //  L, the divergent switch ran 4.3 vs 2.45 ms)
                 } else {
                     acc = c[t.z + t.y * t.w];
                 }
