@@ -238,6 +238,7 @@ def main():
     ap.add_argument("--irreps", default="A", choices=["A", "B"])
     ap.add_argument("--nao", type=int, default=19)
     ap.add_argument("--soc", action="store_true", help="SOC / so3 read-out (BASELINE config #3: MoS2 with spin-orbit coupling); the CPU baseline leg stays non-SOC")
+    ap.add_argument("--no-mfma-probe", action="store_true", help="skip the 20 ms fp32-MFMA ceiling probe that follows the timed region (roofline.mfma_probe_tflops)")
     ap.add_argument("--lite", action="store_true", help="lite_mode MessagePackBlocks (message_passing.py:197-215: unweighted uvu products + o3.Linear + one combined radial scale); "
                     "runs on the segment-stationary kernel, the roofline then counts the planner's executed flops (SURVEY 8d's figures are for the default block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -382,6 +383,13 @@ def main():
                 "hbm_frac": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9 / PEAK_HBM_GBS,
                 "hbm_measured_GBs": pmc_bytes * rows_per_launch / avg_s / 1e9,
                 "fused_program_launches_share_of_step": all_tp / dt}
+    if not args.no_mfma_probe:
+        # what the fp32 matrix pipe sustains on this device right now (random operands, two waves per SIMD, nothing but MFMAs; after the
+        # timed region): the chip clocks to its power budget, so the nominal peak above is not attainable on non-trivial data.  Reported
+        # beside `peak`; `frac` stays achieved / nominal peak.
+        probe = ops.mfma_probe(dev)
+        roofline["mfma_probe_tflops"] = probe
+        roofline["issued_over_probe"] = issued / avg_s / 1e12 / probe
 
     res = {"metric": "edges/sec (equivariant MP forward)", "value": E_total * args.steps / dt, "unit": "edges/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": median_ms,

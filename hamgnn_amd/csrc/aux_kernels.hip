@@ -728,3 +728,36 @@ extern "C" int hg_embed_lookup(const float* Ta, const float* Tb, const int64_t* 
     embed_lookup_kernel<<<dim3((unsigned)((rows * Tp + 255) / 256)), 256, 0, (hipStream_t)stream>>>(Ta, Tb, z, idx_a, idx_b, rows, T, Tp, out);
     return hg_check_launch("hg_embed_lookup");
 }
+
+
+// ------------------------------------------------------------------------------------------------ measurement aid (bench.py roofline)
+// What the fp32 matrix pipe sustains on THIS device at THIS moment: every wave issues `iters` x 8 v_mfma_f32_16x16x4_f32 on eight independent
+// accumulators, operands from the caller's (random) buffer, two waves per SIMD on every CU -- nothing else in the loop.  The chip clocks to its
+// power budget on non-trivial data (MI355X_MICROARCH.md, DVFS), so the nominal 157.3 TFLOP/s is quoted beside this number, not replaced by it.
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(const float* __restrict__ in, float* __restrict__ out, int iters) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    float a[8], b[8];
+    rh_f4 acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        a[k] = in[(tid * 16 + k) & 0xffff];
+        b[k] = in[(tid * 16 + 8 + k) & 0xffff];
+        acc[k] = (rh_f4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[(k + 3) & 7], acc[k], 0, 0, 0);
+    }
+    rh_f4 s = acc[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += acc[k];
+    out[tid] = s[0] + s[1] + s[2] + s[3];
+}
+
+extern "C" int hg_mfma_probe(const float* in65536, float* out, int nblocks, int iters, void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (nblocks <= 0 || iters <= 0) return hg_fail(-2, "hg_mfma_probe: nblocks and iters must be positive");
+    mfma_probe_kernel<<<dim3((unsigned)nblocks), 256, 0, (hipStream_t)stream>>>(in65536, out, iters);
+    return hg_check_launch("hg_mfma_probe");
+}

@@ -248,6 +248,27 @@ def prefill_radial_hidden(geo: "Geometry", generators: Sequence[Sequence[torch.T
     return True
 
 
+def mfma_probe(device, iters: int = 4000, reps: int = 3) -> float:
+    """fp32 MFMA TFLOP/s the device sustains right now on random operands (hg_mfma_probe: two waves per SIMD on every CU, nothing but
+    v_mfma_f32_16x16x4_f32 in the loop) -- the attainable ceiling bench.py quotes beside the nominal peak."""
+    dev = torch.device(device)
+    with torch.cuda.device(dev):
+        src = torch.randn(65536, device=dev)
+        nblocks = 2 * torch.cuda.get_device_properties(dev).multi_processor_count
+        out = torch.empty(nblocks * 256, device=dev)
+        run = lambda: check(lib().hg_mfma_probe(ptr(src), ptr(out), i32(nblocks), i32(iters), _stream()), "hg_mfma_probe")
+        run()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(reps):
+            run()
+        ev1.record()
+        torch.cuda.synchronize(dev)
+        ms = ev0.elapsed_time(ev1) / reps
+    return nblocks * 4 * iters * 8 * 2048 / (ms * 1e-3) / 1e12
+
+
 @_on_tensor_device
 def radial_hidden_multi(rbf: torch.Tensor, generators: Sequence[Sequence[torch.Tensor]], act_cst: float) -> Optional[torch.Tensor]:
     """hidden activations of SEVERAL radial weight generators that read the same basis rows, one launch: [n, E, 64]; None when a

@@ -58,6 +58,11 @@ int hg_radial_hidden(const float* rbf, int64_t E, const float* weights, const in
  * (grid.y = generator): weights [nmlp][2][64][64] (layer 1 | layer 2, 1/sqrt(fan_in) folded in), h_out [nmlp][E][64].            */
 int hg_radial_hidden_multi(const float* rbf, int64_t E, const float* weights, int nmlp, float act_cst, float* h_out, void* stream);
 
+/* Measurement aid for bench.py's roofline block (no reference counterpart): nblocks workgroups of 4 waves issue iters x 8
+ * v_mfma_f32_16x16x4_f32 each on independent accumulators, operands from in65536 (65 536 floats, caller-filled, e.g. random);
+ * out: nblocks * 256 floats (checksum sink).  FLOPs issued = nblocks * 4 * iters * 8 * 2048. */
+int hg_mfma_probe(const float* in65536, float* out, int nblocks, int iters, void* stream);
+
 /* node_features[sender] / [receiver] gathers of ConvBlockE3.forward (hamgnn/nn/convolution.py:138-141) and
  * PairInteractionBlock.forward (interaction_blocks.py:141-145), fused with the rotation into the edge-aligned frame:
  * out_s[e][i][a][u] = sum_b D_e^{l_i}[a][b] x_s[idx_s[e]][i][b][u]  for up to two sources s = 0,1 sharing the edge's D
