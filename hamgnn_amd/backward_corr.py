@@ -5,7 +5,7 @@ Forward (hg_sym_contraction, plan.sym_contraction_tables), per node n, channel c
     out[n, o, c] = sum_{(x, kap, v) in ent1[o]} v W1[z_n, kap, c] h[n, x, c]
                  + sum_{(x, i, kap, v) in ent2[o]} v W2[z_n, kap, c] h[n, i, c] h[n, x, c]
 A node-level operation (N rows of a few hundred floats): the gradients with respect to h, W1 and W2 are gathers, products and
-`index_add_`s over the sparse entry lists -- torch tensor ops on the device, in chunks of nodes (first version; the forward kernel's
+fixed-order segmented sums (ops.scatter_cols) over the sparse entry lists -- torch tensor ops on the device, in chunks of nodes (first version; the forward kernel's
 loop nest with the roles of `out` and `h` exchanged is the HIP form).  Device-agnostic, so the CPU suite checks it against autograd
 through the oracle's dense einsums."""
 from __future__ import annotations
@@ -14,6 +14,8 @@ from typing import Dict
 
 import numpy as np
 import torch
+
+from . import ops
 
 
 def _entries(tab: Dict, device):
@@ -51,19 +53,21 @@ def sym_contraction_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W1: to
         H = h[sl][:, hcol]                                        # [n, num_ell, C]
         G = g_out[sl][:, ocol]                                    # [n, nout, C]
         zc = zl[sl]
-        gH = torch.zeros_like(H)
+        nell = H.shape[1]
+        # every reduction in a fixed order (ops.scatter_cols / scatter_rows: sort + segmented sum) -- index_add_'s float atomics would make
+        # a training step with the CorrProductBlock differ from run to run
         # nu = 1
         t1 = G[:, E["o1"]] * E["v1"][None, :, None].to(dt)        # [n, E1, C]
-        gH.index_add_(1, E["x1"], t1 * W1[zc][:, E["k1"]])
-        p1 = torch.zeros(n, W1.shape[1], C, device=h.device, dtype=dt).index_add_(1, E["k1"], t1 * H[:, E["x1"]])
-        gW1.index_add_(0, zc, p1)
+        gH = ops.scatter_cols(E["x1"], t1 * W1[zc][:, E["k1"]], nell)
+        p1 = ops.scatter_cols(E["k1"], t1 * H[:, E["x1"]], W1.shape[1])
+        gW1 += ops.scatter_rows(zc, p1, W1.shape[0])
         # nu = 2
         t2 = G[:, E["o2"]] * E["v2"][None, :, None].to(dt)        # [n, E2, C]
         hx, hi = H[:, E["x2"]], H[:, E["i2"]]
         tw = t2 * W2[zc][:, E["k2"]]
-        gH.index_add_(1, E["x2"], tw * hi)
-        gH.index_add_(1, E["i2"], tw * hx)
-        p2 = torch.zeros(n, W2.shape[1], C, device=h.device, dtype=dt).index_add_(1, E["k2"], t2 * hx * hi)
-        gW2.index_add_(0, zc, p2)
-        g_h[sl].index_add_(1, hcol.reshape(-1), gH.reshape(n, -1))
+        gH = gH + ops.scatter_cols(E["x2"], tw * hi, nell)
+        gH = gH + ops.scatter_cols(E["i2"], tw * hx, nell)
+        p2 = ops.scatter_cols(E["k2"], t2 * hx * hi, W2.shape[1])
+        gW2 += ops.scatter_rows(zc, p2, W2.shape[0])
+        g_h[sl].index_add_(1, hcol.reshape(-1), gH.reshape(n, -1))     # (distinct columns: nothing is summed here)
     return g_h, gW1, gW2

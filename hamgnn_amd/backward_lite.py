@@ -18,7 +18,7 @@ from typing import Dict
 import numpy as np
 import torch
 
-from . import plan as P
+from . import ops, plan as P
 from .backward_mp import _block, radial_mlp
 
 
@@ -62,7 +62,7 @@ class LiteBackward:
             t = run_program(self.prog_t, [xs, xd, f])
             g_u = run_linear(self.lc_adj, g_out)
             g_t = (s_cols * g_u).contiguous()
-            g_s = torch.zeros(g_out.shape[0], self.nch, device=dev, dtype=dt).index_add_(1, chan[valid], (t * g_u)[:, valid])
+            g_s = ops.scatter_cols(chan[valid], (t * g_u)[:, valid], self.nch)       # fixed summation order (index_add_ sums with float atomics)
             grads = {"combine_messages.linear_out.weight": linear_weight_grad(self.irreps_out, self.irreps_out, s_cols * t, g_out),
                      self.gen_keys[-1]: h.t() @ g_s / math.sqrt(H)}
             g_h = g_s @ (gen[-1].detach().t() / math.sqrt(H))

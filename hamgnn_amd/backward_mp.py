@@ -138,8 +138,8 @@ def weight_grads_from_rows(wg, ArowsT: torch.Tensor, BrowsT: torch.Tensor, srcsT
         gL = torch.bmm((A * s).reshape(G, N, nc * E), Gk.reshape(G, -1, nc * E).transpose(1, 2))          # [G, N, MK]
         T1 = (B * s * grp["cf"]).reshape(G, N, nc * E)
         gW = torch.bmm(T1, X.reshape(G, -1, nc * E).transpose(1, 2))                                        # [G, N, U]
-        acc[f"{name}_tp"].index_add_(0, grp["tp_idx"], (gW * grp["cpath"]).reshape(-1))
-        acc[f"{name}_L"].index_add_(0, grp["l_idx"], gL.reshape(-1))
+        acc[f"{name}_tp"] += _scatter_rows(grp["tp_idx"], (gW * grp["cpath"]).reshape(-1), acc[f"{name}_tp"].shape[0])      # fixed order
+        acc[f"{name}_L"] += _scatter_rows(grp["l_idx"], gL.reshape(-1), acc[f"{name}_L"].shape[0])
         if gxT is not None:
             Wg_np = np.zeros(grp["shape"])                                         # [G, N, U] from the CURRENT weights, path normalisation included
             for q, j in enumerate(grp["cidx"]):

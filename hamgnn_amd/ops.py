@@ -364,6 +364,12 @@ def scatter_rows(index: torch.Tensor, src: torch.Tensor, n: int) -> torch.Tensor
     return torch.segment_reduce(src[order].contiguous(), "sum", lengths=counts, axis=0, unsafe=True)
 
 
+def scatter_cols(index: torch.Tensor, src: torch.Tensor, n: int) -> torch.Tensor:
+    """out[:, i] = sum of src[:, q] with index[q] == i (src [rows, Q, ...] -> [rows, n, ...]) in a fixed order: scatter_rows along dim 1,
+    the deterministic form of torch.zeros(rows, n, ...).index_add_(1, index, src)."""
+    return scatter_rows(index, src.transpose(0, 1).contiguous(), n).transpose(0, 1)
+
+
 class DeviceRowProgram:
     """plan.RowProgram uploaded to the GPU (csrc/rowprog.hip)"""
 
