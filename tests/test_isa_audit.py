@@ -1,0 +1,56 @@
+"""Compile-time guards on the hot kernels' code objects (no GPU: hipcc cross-compiles gfx950).  What they pin was measured on MI355X this
+round (profiles/r03_lite.md, r03_tp_is_experiments.md, r03_wgrad.md): register budgets that keep two waves per SIMD without scratch, and
+the wait structure of the lite run loop (its ring look-ahead silently collapses to vmcnt(0) when the refill is requested before the slot's
+last read or the priming loads are reordered -- 8 % of the launch)."""
+import os, re, shutil, sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import isa_audit as A
+
+CSRC = os.path.join(A.ROOT, "hamgnn_amd", "csrc")
+pytestmark = pytest.mark.skipif(not os.path.exists(A.HIPCC) and shutil.which("hipcc") is None, reason="hipcc not found")
+
+
+@pytest.fixture(scope="module")
+def tp_is():
+    return A.audit(os.path.join(CSRC, "tp_is.hip"))
+
+
+def test_tp_is_register_budget_and_no_scratch(tp_is):
+    ks = [k for k in tp_is if "tp_is_kernel" in k["name"]]
+    assert len(ks) == 4                                         # <SPLIT, LITE> in {false, true}^2
+    for k in ks:
+        m = k["meta"]
+        assert m["vgpr_spills"] == 0 and m["scratch"] == 0, (k["name"], m)
+        assert m["vgprs"] <= 240, (k["name"], m)                # 2 waves per SIMD need <= 256; 235 / 230 / 231 / 233 at the time of writing
+
+
+def test_lite_run_loop_keeps_its_ring_lookahead(tp_is):
+    lite = [k for k in tp_is if "tp_is_kernel" in k["name"] and "ELb1EEv" in k["name"] and "ILb0ELb1" in k["name"]]
+    assert len(lite) == 1
+    steps = [(lab, s) for lab, _, s, _ in lite[0]["blocks"]     # a step of run_lite<RTM>: 4 RTM MFMAs, RTM fragment requests, 4 + write-back LDS reads
+             if s.count("M") in (4, 8, 12, 16) and 1 <= s.count("G") <= 4 and s.count("r") >= 8 and "S" not in s.replace("[", "")[:0]]
+    steps = [(lab, s) for lab, s in steps if s.count("G") * 4 == s.count("M")]
+    assert len(steps) >= 20, len(steps)                         # 6 unrolled steps x 4 row-tile counts
+    for lab, s in steps:
+        assert not re.search(r"\[v\(0\)", s), (lab, s)          # every fragment wait leaves younger requests in flight
+    # the tile read-modify-write of a finished column: all reads, then all writes (was read -> wait -> write per element)
+    for lab, _, s, f in lite[0]["blocks"]:
+        assert "SERIAL-RMW" not in f, (lab, s)
+
+
+def test_default_kernel_has_no_serial_lds_read_modify_write(tp_is):
+    base = [k for k in tp_is if "ILb0ELb0" in k["name"]]
+    assert len(base) == 1
+    assert not [lab for lab, _, s, f in base[0]["blocks"] if "SERIAL-RMW" in f]
+
+
+def test_row_program_and_readout_register_budgets():
+    # row_program_kernel: 16 waves per workgroup = 128 VGPRs per wave at most; one VGPR (8 bytes of scratch) is spilled at the time of writing
+    for src, kern, max_spill in (("rowprog.hip", "row_program_kernel", 1), ("head.hip", "ham_readout_kernel", 0)):
+        ks = [k for k in A.audit(os.path.join(CSRC, src)) if kern in k["name"]]
+        assert ks, (src, kern)
+        for k in ks:
+            assert k["meta"]["vgpr_spills"] <= max_spill and k["meta"]["scratch"] <= 8 * max_spill, (k["name"], k["meta"])
