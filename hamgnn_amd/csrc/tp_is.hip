@@ -31,6 +31,24 @@ struct ProfIs { unsigned long long t[12]; unsigned long long last; };
 #define IS_PROF_PASS
 #define IS_T(k)
 #endif
+#ifdef HG_HB                           // the 16 edges' hidden rows of both radial MLPs (B operands of the radial-scale MFMAs) resident in registers
+#define IS_HB_ARG , const f32x4 (&hbn)[4], const f32x4 (&hbe)[4]
+#define IS_HB_PASS , hbn, hbe
+#else
+#define IS_HB_ARG
+#define IS_HB_PASS
+#endif
+
+// broadcast lane q of every row of 16 lanes to that row (DPP row_newbcast, gfx90a+): lanes (g, *) <- lane (g, q)
+#define IS_BC_CASE(Q) case Q: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + Q, 0xf, 0xf, false));
+__device__ __forceinline__ float is_row_bcast(float v, int q) {      // q is a compile-time constant at every call site (unrolled loops)
+    switch (q) {
+        IS_BC_CASE(0) IS_BC_CASE(1) IS_BC_CASE(2) IS_BC_CASE(3) IS_BC_CASE(4) IS_BC_CASE(5) IS_BC_CASE(6) IS_BC_CASE(7)
+        IS_BC_CASE(8) IS_BC_CASE(9) IS_BC_CASE(10) IS_BC_CASE(11) IS_BC_CASE(12) IS_BC_CASE(13) IS_BC_CASE(14)
+        default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x15f, 0xf, 0xf, false));
+    }
+}
+#undef IS_BC_CASE
 
 // One item on the workgroup's 16 edges.  stage: the phase's staged input block(s), image offset(piece p, row e) = 64 p + 4 e per
 // source (pieces of the FULL irrep block: component a, channel piece s -> p = a * P1 + s).
@@ -39,7 +57,7 @@ struct ProfIs { unsigned long long t[12]; unsigned long long last; };
 // works on the 2 MM remaining columns only -- column slot c < MM is real column c, slot c >= MM is real column c + 1.
 template <int MM, int RTM, bool SPLIT, bool ODD>
 __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
-                                        float* __restrict__ lds, int64_t erow, int lane IS_PROF_ARG) {
+                                        float* __restrict__ lds, int64_t erow, int lane IS_HB_ARG IS_PROF_ARG) {
 #ifdef HG_IS_OPAQUE_LANE               // A/B hook: lane-derived address terms recomputed per item instead of hoisted (235 -> 217 VGPRs, but 7.58 vs
     asm volatile("" : "+v"(lane));     // 7.37 ms per 131 072-edge launch: the hoisted terms are worth their registers; profiles/r03_tp_is_experiments.md)
 #endif
@@ -62,18 +80,76 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const int ngrp = (ksteps + 3) >> 2;
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;      // [src][G][rt][lane]
     f32x4 av_n[RTM];
+#ifdef HG_CFP                          // packed CG coefficients (plan._cf_block): one float4 per lane covers 16 (row tile, column) pairs, requested with the
+    constexpr int NPAIR = RTM * NCR, NJ = (NPAIR + 15) / 16;            // radial operands -- nothing left to wait for at the scale step
+    f32x4 cfv[NJ];
+    if (typ == 0) {
+        const f32x4* __restrict__ cfp = reinterpret_cast<const f32x4*>(Wb + it[13] + NPAIR * 16) + lane;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cfv[j] = cfp[j * 64];
+    }
+#endif
 #ifdef HG_IS_EARLY_A1                  // first GEMM1 fragment group requested together with the radial operands: one exposed L2 latency fewer per item
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
 #endif
     // ---------------------------------------------------------------- radial scale s_e = W3^T h2 first (see tp_fused.hip)
     f32x4 S[RTM];
+#ifdef HG_DUAL
+    f32x4 S2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
     if (typ == 0) {
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
         const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
         const int hgrp = A.hidden >> 4;
+#ifdef HG_HB
+        if (hgrp == 4) {               // rows resident; the guards stay run-time (small blocks: the MFMAs of a group start when ITS fragments arrive)
+            const int hg = __builtin_amdgcn_readfirstlane(A.hidden) >> 4;
+            f32x4 wv[4][RTM];
+#pragma unroll
+            for (int G = 0; G < 4; ++G)
+                if (G < hg) {
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[(G * RTM + rt) * 64];
+                }
+            if (mlp) {
+#pragma unroll
+                for (int G = 0; G < 4; ++G)
+                    if (G < hg) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int rt = 0; rt < RTM; ++rt) {
+#ifdef HG_DUAL
+                                if (RTM == 1 && (G & 1)) S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbe[G][q], S2, 0, 0, 0);
+                                else
+#endif
+                                S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbe[G][q], S[rt], 0, 0, 0);
+                            }
+                    }
+            } else {
+#pragma unroll
+                for (int G = 0; G < 4; ++G)
+                    if (G < hg) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int rt = 0; rt < RTM; ++rt) {
+#ifdef HG_DUAL
+                                if (RTM == 1 && (G & 1)) S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbn[G][q], S2, 0, 0, 0);
+                                else
+#endif
+                                S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbn[G][q], S[rt], 0, 0, 0);
+                            }
+                    }
+            }
+#ifdef HG_DUAL
+            if (RTM == 1) S[0] += S2;
+#endif
+        } else
+#endif
 #ifdef HG_IS_H64                       // A/B hook (r3): the shipped hidden width (64 = 4 groups) as straight-line code, no branch between the loads and
         if (hgrp == 4) {               // the 16 RTM MFMAs
             f32x4 hb[4], wv[4][RTM];
@@ -107,9 +183,19 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
+                        for (int rt = 0; rt < RTM; ++rt) {
+#ifdef HG_DUAL                         // one row tile: two accumulator chains (a dependent fp32 MFMA issues every 40 cycles, an independent one every 32,
+                            if (RTM == 1 && (G & 1))      // and a branch between two dependent MFMAs costs ~43 more: MI355X_MICROARCH.md)
+                                S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S2, 0, 0, 0);
+                            else
+#endif
+                            S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
+                        }
                 }
         }
+#ifdef HG_DUAL
+        if (RTM == 1) S[0] += S2;
+#endif
     }
 
     IS_T(1);                                                    // radial scale
@@ -231,10 +317,23 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];
 #endif
+#ifdef HG_CFP
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const int p = rt * NCR + IS_COL(c);
+                f32x4 cb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cb[r] = is_row_bcast(cfv[p >> 4][r], p & 15);
+                mid[rt][c] = mid[rt][c] * S[rt] * cb;
+            }
+#else
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NCR + IS_COL(c)) * 4];
+#endif
 #ifdef HG_IS_TOUCH
         asm volatile("" :: "v"(touch0), "v"(touch1));
 #endif
@@ -273,15 +372,25 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][IS_COL(c) * 16];
                 }
+#ifdef HG_DUAL
+                f32x4 accb = (f32x4){0.f, 0.f, 0.f, 0.f};      // NC == 1: the K-steps alternate between two accumulator chains
+#endif
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (4 * rt + r < nk2) {                // trailing K-steps hold only padding rows: not issued
+#ifdef HG_DUAL
+                            if (NC == 1 && (r & 1)) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][0][r], accb, 0, 0, 0);
+                            else
+#endif
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c][r], acc[c], 0, 0, 0);
                         }
+#ifdef HG_DUAL
+                if (NC == 1) acc[0] += accb;
+#endif
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -710,17 +819,17 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
 
 #ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
 #define IS_CASE_ODD(MMv, RTMv)
 #else
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
 #ifdef HG_NO_ODD_SKIP                 // A/B hook: odd items through the full-column code
 #define IS_CASE_ODD(MMv, RTMv) \
-    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
 #else
 #define IS_CASE_ODD(MMv, RTMv) \
-    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, true>(A, g_W, it, lds, erow, lane IS_PROF_PASS); break;
+    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, true>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
 #endif
 #endif
 
@@ -771,6 +880,14 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     const unsigned long long t_begin = prof.last;
 #endif
 
+#ifdef HG_HB
+    f32x4 hbn[4], hbe[4];
+#pragma unroll
+    for (int G = 0; G < 4; ++G) {
+        hbn[G] = (A.h2[0] && A.hidden >= 64) ? *reinterpret_cast<const f32x4*>(A.h2[0] + erow * A.hidden + 4 * g + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        hbe[G] = (A.h2[1] && A.hidden >= 64) ? *reinterpret_cast<const f32x4*>(A.h2[1] + erow * A.hidden + 4 * g + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#endif
     for (int i = threadIdx.x; i < A.rowtab_off; i += IS_NT) lds[i] = 0.f;            // all segment tiles (all copies) + trash rows
     {
         int* __restrict__ rt_l = reinterpret_cast<int*>(lds + A.rowtab_off);

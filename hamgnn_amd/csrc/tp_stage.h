@@ -1,6 +1,6 @@
 // tp_stage.h -- operand staging (gather + frame rotation / LDS-DMA), epilogue (un-rotation + planar store) and the launch-argument block
-// shared by the two input-stationary edge kernels: csrc/tp_is.hip (dynamic work claiming, register-chained row-tile chunks) and
-// csrc/tp_st.hip (static per-wave weight streams).  Hand-written HIP for gfx950 (CDNA4).
+// of the input-stationary edge kernel csrc/tp_is.hip (dynamic work claiming, register-chained row-tile chunks).
+// Hand-written HIP for gfx950 (CDNA4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -121,7 +121,7 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
 }
 
 #ifndef HG_STAGE_FUSE_LMAX
-#define HG_STAGE_FUSE_LMAX 6     // both node sources rotated in one pass up to this l (csrc/tp_st.hip carries its stream state through the staging: 3)
+#define HG_STAGE_FUSE_LMAX 6     // both node sources rotated in one pass up to this l 
 #endif
 // piece index t -> (component a, channel piece p): t / P1 through the reciprocal (t < 2^9, P1 <= 16: (t + 0.5) / P1 is never within 0.03 of an
 // integer, so the float product rounds to the right side); an integer division per piece cost as much as the piece's own loads + FMAs at l = 0

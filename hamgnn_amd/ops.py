@@ -81,25 +81,11 @@ class DeviceProgram:
                 if schedule == "is_parts":
                     self.sched = self.is_tables("lds")[0]
                     self.fixed_parts = "lds"
-        # streamed form of the single-part schedule (csrc/tp_st.hip: per-group weight streams requested one step ahead, one 16-row tile per
-        # step).  Opt-in (HG_ST=1): measured 8 % slower than the input-stationary kernel on MI355X (profiles/r03_tp_st_experiments.md)
-        self.st = None
-        if self.sched is not None and self.fixed_parts is None and os.environ.get("HG_ST", "0") == "1":
-            try:
-                st = P.st_schedule(prog)
-                self.st = (st, tuple(_dev(t, device) for t in (st.base.seg_table, st.base.block_table, st.phase_table, st.group_table,
-                                                                  st.op_table, st.base.rowtab)),
-                           _dev(st.gather, device), _dev(st.stream(prog.weights), device))
-            except NotImplementedError:
-                pass
 
     def weights_changed(self):
         """after the packed weight blob was rewritten in place (nn.MessagePackBlock.refresh): rebuild what is derived from it"""
         self._is_weights.clear()                               # (lite programs are recompiled, not refreshed; kept consistent anyway)
         self._is_tables = {k: v for k, v in self._is_tables.items() if v[0].extra_weights is None}
-        if self.st is not None:
-            st, tabs, gather, stream = self.st
-            stream.copy_(torch.cat([self.weights, self.weights.new_zeros(1)])[gather])
 
     def is_tables(self, parts):
         """(schedule, device tables) of the input-stationary kernel split into `parts` sub-schedules (built on first use)"""
@@ -324,15 +310,7 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     if PROFILE_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
-    if dp.sched is not None and dp.st is not None and h2n is not None and h2e is not None and dp.is_parts_for(rows) == 1:
-        st, (t_segs, t_blocks, t_phases, t_groups, t_ops, t_rowtab), _, t_stream = dp.st
-        gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
-        gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
-        check(lib().hg_tp_st(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(t_stream), ptr(t_segs),
-                             ptr(t_blocks), ptr(t_phases), ptr(t_groups), ptr(t_ops),
-                             st.base.part_table.ctypes.data_as(C.c_void_p), ptr(t_rowtab), i32(st.base.lds_floats * 4), gp, i32(rot_mask),
-                             ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_st")
-    elif dp.sched is not None:
+    if dp.sched is not None:
         sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts, t_rowtab) = dp.is_tables(dp.is_parts_for(rows))
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])

@@ -288,10 +288,9 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSched
     parts > 1: the output segments are split into `parts` sets of equal estimated cost (LPT); each set gets its own sub-schedule
     (tiles, phases, groups) and runs in its own workgroup (grid.y) -- the per-tile latency drops at the price of staging the input
     blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots.
-    separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (st_schedule: the wave keeps the
-    hidden rows of the phase's generator in registers); phase_table[:, 2] then holds that generator instead of the group range."""
+    separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (IsSchedule.phase_cls)."""
     if separate_mlp and np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any():
-        raise NotImplementedError("lite_mode programs have no streamed schedule")
+        raise NotImplementedError("lite_mode programs have no per-generator phases")
     hp4 = prog.hidden_pad // 4
     nseg = prog.seg_table.shape[0]
     lite_flag = int(np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any())      # lite_mode items run in their own kernel instantiation
@@ -588,129 +587,6 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
                 phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
 
 
-# ---- streamed schedule (csrc/tp_st.hip): the input-stationary phases and work groups, every group with its own contiguous weight streams
-ST_OP_I32 = 16
-ST_GROUP_I32 = 8
-ST_PHASE_I32 = 8
-ST_PAD_FRAGS = 8                   # the kernel requests up to 4 fragments beyond a group's last one (step / GEMM2 look-ahead)
-# template instantiations of csrc/tp_st.hip (ST_CASE): MM -> largest RTO class; wider items fall back to the input-stationary kernel
-ST_RTO_MAX = (4, 4, 2, 2, 1, 1, 1)
-
-
-@dataclass
-class StSchedule:
-    base: IsSchedule               # segments, input blocks, phases (one radial generator each), row table, LDS layout: one part
-    phase_table: np.ndarray        # int32[nphase][8] = {block_begin, block_end, group_begin, group_end, radial generator (0 node / 1 edge), 0..}
-    group_table: np.ndarray        # int32[ngroup][8] = {op_begin, op_end, A / R / C stream offsets (floats into `stream`), 0..}: all items of
-    #                                one (phase, output segment key), claimed by the waves largest first (a tile has one writer per phase)
-    op_table: np.ndarray           # int32[nops][16], see csrc/tp_st.hip; a group's ops are contiguous in execution order
-    gather: np.ndarray             # int64: stream = concat(weights, [0])[gather] (device-side rebuild after a weight refresh)
-    balance: float                 # LPT estimate of the dynamic claim: sum(cost) / (waves x sum over phases of the slowest wave)
-
-    def stream(self, weights: np.ndarray) -> np.ndarray:
-        return np.concatenate([np.asarray(weights, np.float32).reshape(-1), np.zeros(1, np.float32)])[self.gather]
-
-
-def st_schedule(prog: "Program") -> StSchedule:
-    """Streamed form of a finalized program (csrc/tp_st.hip).  Phases and work groups are those of the input-stationary schedule (one radial
-    weight generator per phase; a group = all items of one (phase, output segment key), claimed dynamically, largest first).  What changes
-    is how a wave gets its weights: the fragments a group consumes are laid out as three contiguous streams, row tile by row tile in
-    consumption order --  A = [GEMM1 fragments (source, K group)] [GEMM2 fragments (output row tile)],  R = the four fragments of the last
-    radial layer,  C = the coefficient block [column][row] -- so the kernel requests every fragment one step before the MFMAs that use it
-    without knowing what it belongs to.  Raises NotImplementedError for programs the kernel has no instantiation for (callers keep the
-    input-stationary kernel)."""
-    if prog.hidden_pad != 64:
-        raise NotImplementedError("streamed kernel: the radial hidden width must pad to 64")
-    base = is_schedule(prog, 1, separate_mlp=True)
-    hp4 = prog.hidden_pad // 4
-    nph = base.phase_table.shape[0]
-    frag = np.arange(256, dtype=np.int64)
-    nW = prog.weights.size                                     # index of the appended zero
-    pad = np.full(256, nW, dtype=np.int64)
-    ops: List[List[int]] = []
-    groups: List[List[int]] = []
-    gA: List[np.ndarray] = []
-    gR: List[np.ndarray] = []
-    gC: List[np.ndarray] = []
-    nA = nR = nC = 0
-    ptab = np.zeros((nph, ST_PHASE_I32), np.int32)
-    tot, crit = 0, 0
-    for ph in range(nph):
-        g0, g1 = int(base.phase_table[ph][2]), int(base.phase_table[ph][3])
-        loads = [0] * IS_WAVES
-        ptab[ph][:5] = (base.phase_table[ph][0], base.phase_table[ph][1], len(groups), len(groups) + g1 - g0, base.phase_cls[ph])
-        for gi in range(g0, g1):                               # group_table is in LPT (largest first) order
-            ib, ie = (int(v) for v in base.group_table[gi])
-            grp = [len(ops), 0, nA, nR, nC, 0, 0, 0]
-            cost = 0
-            for ii in range(ib, ie):
-                it = base.item_table[ii]
-                typ, so0, so1, in_mulp, li, mm, neg, ksteps, rtm = (int(it[k]) for k in (0, 1, 2, 4, 5, 6, 7, 8, 9))
-                ncx = 2 * mm + (0 if (neg and mm > 0 and typ == IT_TP) else 1)                 # odd items skip the centre column
-                cost += (2 if so1 >= 0 else 1) * ksteps * rtm * ncx + 60 + ((hp4 * rtm + int(it[22]) * int(it[18]) * ncx) if typ == IT_TP else 0)
-                if typ == IT_TP and neg and mm == 0:
-                    continue                                   # odd super-path with one column: its only column vanishes identically
-                nsrc = 2 if so1 >= 0 else 1
-                ncr = 2 * mm + 1
-                x4 = 1 if (int(it[17]) and ncr <= 3) else 0
-                ngrp = ceil_div(ksteps, 4)
-                P1 = in_mulp // 4
-                fb0 = ((li - mm) * P1 + ((ncr - 1) * P1 if neg else 0)) * 64
-                cdir64 = (-P1 if neg else P1) * 64
-                rto = int(it[22])
-                if typ == IT_TP:
-                    if not (0 <= mm < len(ST_RTO_MAX) and 1 <= rto <= ST_RTO_MAX[mm]):
-                        raise NotImplementedError(f"streamed kernel: no instantiation for min(l_in, l_out) = {mm} with {rto} output row tiles")
-                    rc = 0 if rto == 1 else (1 if rto == 2 else 2)
-                    code = (64 if neg else 0) + 32 * x4 + 4 * mm + rc
-                    flags = int(it[10]) | (4 if x4 else 0)
-                    a1, w3, cf, a2 = (int(it[k]) for k in (11, 12, 13, 14))
-                    for rt in range(rtm):
-                        for G in range(hp4 // 4):
-                            gR.append(w3 + (G * rtm + rt) * 256 + frag)
-                        for si in range(nsrc):
-                            for G in range(ngrp):
-                                gA.append(a1 + ((si * ngrp + G) * rtm + rt) * 256 + frag)
-                        for rtp in range(rto):
-                            gA.append(a2 + (rtp * rtm + rt) * 256 + frag)
-                        gC.append(cf + rt * ncr * 16 + np.arange(ncr * 16, dtype=np.int64))
-                    nR += rtm * (hp4 // 4) * 256
-                    nA += rtm * (nsrc * ngrp + rto) * 256
-                    nC += rtm * ncr * 16
-                    rec = [code, so0, so1, fb0, cdir64, ngrp, ksteps, nsrc, rtm, rto, int(it[18]), flags, int(it[23]), 0, ii, 0]
-                elif typ == IT_LIN:
-                    if mm > 6 or (x4 and mm > 1):
-                        raise NotImplementedError("streamed kernel: no Linear instantiation")
-                    a1 = int(it[11])
-                    for rt in range(rtm):
-                        for G in range(ngrp):
-                            gA.append(a1 + (G * rtm + rt) * 256 + frag)
-                    nA += rtm * ngrp * 256
-                    rec = [128 + 8 * x4 + mm, so0, -1, fb0, cdir64, ngrp, ksteps, 1, rtm, 0, 0, 2 | (4 if x4 else 0), int(it[23]), int(it[16]), ii, 0]
-                else:
-                    raise NotImplementedError("streamed kernel: tensor-product and Linear items only")
-                ops.append(rec)
-            grp[1] = len(ops)
-            groups.append(grp)
-            w = loads.index(min(loads))
-            loads[w] += cost
-        tot += sum(loads)
-        crit += max(loads)
-    # one array: [A | R | C], each padded (the kernel's look-ahead reads past the last group) and 1 KiB aligned
-    parts, off, base_off = [], 0, []
-    for lst, npad in ((gA, ST_PAD_FRAGS), (gR, 4), (gC, 1)):
-        arr = np.concatenate(lst + [pad] * npad) if lst else np.concatenate([pad] * npad)
-        arr = np.concatenate([arr, np.full((-arr.size) % 256, nW, dtype=np.int64)])
-        base_off.append(off)
-        parts.append(arr)
-        off += arr.size
-    gt = np.asarray(groups, np.int32).reshape(-1, ST_GROUP_I32)
-    for k in range(3):
-        gt[:, 2 + k] += base_off[k]
-    return StSchedule(base, ptab, gt, np.asarray(ops, np.int32).reshape(-1, ST_OP_I32), np.concatenate(parts),
-                      tot / (IS_WAVES * crit) if crit else 1.0)
-
-
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:
     """mat[k, row] -> A fragments [ngrp][rtm][64 lanes][4]: one float4 per lane covers 4 MFMA K-steps (q = 0..3).
     lane L = (i = L&15, g = L>>4) holds mat[k(G, q, g)][16 rt + i] with
@@ -725,6 +601,19 @@ def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:
     if x4:
         return P.transpose(0, 3, 1, 4, 2).reshape(ngrp, rtm, 64, 4)
     return P.transpose(0, 3, 2, 4, 1).reshape(ngrp, rtm, 64, 4)
+
+
+def _cf_block(cfp: np.ndarray, rtm: int, nc: int) -> np.ndarray:
+    """CF operand of a tensor-product item, two forms back to back: [rt][c][g][r] (segment-stationary kernel, emulators) and the PACKED
+    form the input-stationary kernel reads (csrc/tp_is.hip): the pairs p = rt * nc + c in groups of 16 as [J][g][p % 16][r] -- lane
+    (g, p) of a wave holds the float4 of pair p after ONE load per 16 pairs (instead of one load and four registers per pair); the scale
+    step broadcasts it along the 16 lanes of row g by DPP (row_newbcast).  The packed block starts rtm * nc * 16 floats behind item[13]."""
+    old = cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2)             # [rt][c][g][r]
+    npair = rtm * nc
+    pk = np.zeros((ceil_div(npair, 16) * 16, 4, 4), dtype=old.dtype)
+    pk[:npair] = old.reshape(npair, 4, 4)
+    pk = pk.reshape(-1, 16, 4, 4).transpose(0, 2, 1, 3)                # [J][g][p][r]
+    return np.concatenate([old.reshape(-1), pk.reshape(-1)])
 
 
 def use_x4(in_mulp, nc):
@@ -974,7 +863,7 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
             w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
             cfp = np.zeros((R, nc))
             cfp[phys] = rows_cf[r0:r1]
-            cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))       # [rt][c][g][r]
+            cf_off = prog.add_weights(_cf_block(cfp, rtm, nc))       # [rt][c][g][r]
             Lp = np.zeros((R, rto * 16))
             Lp[phys, :mk] = rows_L[r0:r1]
             # A2[rt'][rt][lane][r]: L'[row = 16 rt + 4 (lane>>4) + r][w'' = 16 rt' + (lane&15)]
@@ -1023,7 +912,7 @@ def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_
                 w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
                 cfp = np.zeros((R, nc))
                 cfp[phys] = rows_cf[r0:r1]
-                cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))
+                cf_off = prog.add_weights(_cf_block(cfp, rtm, nc))
                 Wp = np.zeros((R, rto * 16))
                 Wp[phys, :c1 - c0] = rows_W[r0:r1, c0:c1]                          # [physical row, target channel u]
                 a2 = Wp.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4)
@@ -1354,7 +1243,7 @@ def build_tp_wgrad_programs(branches, irreps_sh, irreps_out, H: int):
             w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
             cfp = np.zeros((R, nc))
             cfp[phys] = sp["cf"][r0:r1] if which == "A" else 1.0
-            cf_off = prog.add_weights(cfp.reshape(rtm, 4, 4, nc).transpose(0, 3, 1, 2))
+            cf_off = prog.add_weights(_cf_block(cfp, rtm, nc))
             Ip = np.zeros((R, rto * 16))
             Ip[phys, rho] = 1.0                                # GEMM2 = identity: output channel = logical row
             a2_off = prog.add_weights(Ip.reshape(rtm, 4, 4, rto, 16).transpose(3, 0, 1, 4, 2).reshape(rto, rtm, 64, 4))

@@ -120,19 +120,6 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
              const int32_t* part_table, const int32_t* part_table_host, int nparts, const int32_t* row_table, int lds_bytes,
              const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream);
 
-/* The same launch as hg_tp_is for schedules with ONE part, in its streamed form (hamgnn_amd/plan.py:st_schedule, csrc/tp_st.hip): same
- * phases and dynamically claimed work groups, but a group's weight fragments are three contiguous streams inside `stream` (GEMM1/GEMM2
- * fragments, last radial layer, CG coefficients; offsets in its group record) that a wave requests one step ahead of the MFMAs using
- * them.  Replaces the same reference code as hg_tp_is (MessagePackBlock.forward, hamgnn/nn/message_passing.py:191-231, with the node
- * gathers of convolution.py:138-141 / interaction_blocks.py:141-145).  phase_table int32[nphase][8] = {block_begin, block_end,
- * group_begin, group_end, radial generator, 0..}; group_table int32[ngroup][8] = {op_begin, op_end, A, R, C stream offsets, 0..};
- * op_table int32[nops][16]; part_host = the single record of plan.IsSchedule.part_table (host memory).  hidden must be 64.      */
-int hg_tp_st(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
-             int hidden, const float* wig, int nW, const int32_t* wig_off, const float* stream, const int32_t* seg_table,
-             const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table, const int32_t* op_table,
-             const int32_t* part_host, const int32_t* row_table, int lds_bytes,
-             const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream_h);
-
 /* Fused WEIGHT gradients of the weighted tensor-product branches of a MessagePackBlock (csrc/tp_wgrad.hip): what torch.autograd computes
  * for o3.TensorProduct.weight, LinearScaleWithWeights.linear_out.weight and the trailing o3.Linear of
  * hamgnn/nn/message_passing.py:112-160, 191-231 (the reference has no hand-written backward).  Tables from hamgnn_amd/plan.py:

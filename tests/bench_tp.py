@@ -44,6 +44,8 @@ if a.adjoint:
     m.compile_adjoint(dev)
     gout = torch.randn(a.nodes if a.nodes else E, lay.dim, generator=g).to(dev)
     launch = (lambda: m.backward_data(gout, geo, True, gather=geo.dst)[0]) if a.nodes else (lambda: m.backward_data(gout, geo, True)[0])
+if os.environ.get("HG_BENCH_LDS"):        # diagnostic: request this much LDS per workgroup (163840: ONE workgroup per CU instead of two)
+    m._dp.sched.lds_floats = int(os.environ["HG_BENCH_LDS"]) // 4
 for _ in range(2):
     out = launch()
 torch.cuda.synchronize()
@@ -53,21 +55,10 @@ for _ in range(a.reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
 prog = m._dp_adj.prog if a.adjoint else m._dp.prog
-print(json.dumps({"tag": a.tag, "kernel": ("st" if (m._dp.st is not None and not a.adjoint) else "is") if m._dp.sched is not None else "seg", "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
+print(json.dumps({"tag": a.tag, "kernel": "is" if m._dp.sched is not None else "seg", "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
                   "issued_TF": (prog.mfma_per_wave - (prog.mfma_odd_skipped if (m._dp_adj if a.adjoint else m._dp).sched is not None else 0)) * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
                   "Medges_s": E / dt / 1e6, "checksum": float(out.double().abs().mean())}))
-if os.environ.get("HG_PROF") and m._dp.sched is not None and m._dp.st is not None and os.environ.get("HG_ST", "0") == "1":
-    import ctypes as C
-    from hamgnn_amd import _lib
-    L = _lib.lib()
-    buf = (C.c_ulonglong * 16)()
-    L.hg_prof_st_read(buf, 1)
-    launch()
-    L.hg_prof_st_read(buf, 0)
-    names = ["dispatch", "acc init + radial", "GEMM1", "scale", "GEMM2", "write-back", "zero fill / bookkeeping", "phase barrier (imbalance)", "staging", "epilogue", "linear items"]
-    tot = float(buf[15])
-    print(json.dumps({"prof_total_wave_cycles": tot, "balance": m._dp.st[0].balance, **{n: round(buf[k] / tot, 4) for k, n in enumerate(names)}}))
-elif os.environ.get("HG_PROF") and m._dp.sched is not None:
+if os.environ.get("HG_PROF") and m._dp.sched is not None:
     import ctypes as C
     from hamgnn_amd import _lib
     L = _lib.lib()

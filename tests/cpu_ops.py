@@ -114,13 +114,7 @@ def tp_fused(dp, srcs, rows, h2n=None, h2e=None, geo=None, tag="linear", gather=
             if rot_mask >> i & 1:
                 a = _rotate_blocks(a, D, lmax, sc.block_table, i)
             xs.append(a)
-        if getattr(dp, "st", None) is not None and h2n is not None and h2e is not None and dp.is_parts_for(rows) == 1:
-            # the product takes the static-stream kernel here (ops.tp_fused): emulate ITS tables, from the stream the device holds
-            st = dp.st[0]
-            assert np.array_equal(_np(dp.st[3]), st.stream(_np(dp.weights)))
-            out = emu.run_program_st(dp.prog, st, xs, (_np(h2n), _np(h2e)), D, lmax)
-        else:
-            out = emu.run_program_is(dp.prog, sc, xs, (_np(h2n), _np(h2e)), D, lmax)
+        out = emu.run_program_is(dp.prog, sc, xs, (_np(h2n), _np(h2e)), D, lmax)
     else:
         assert gather is None and rot_mask == 0
         out = emu.run_program(dp.prog, [_np(s) for s in srcs], (_np(h2n), _np(h2e)), D, lmax)

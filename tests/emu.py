@@ -338,159 +338,6 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
     return out
 
 
-def run_program_st(prog, st, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64):
-    """the streamed schedule (plan.st_schedule, csrc/tp_st.hip), fragment-exact: phase by phase every work group walks its op list and
-    consumes its A / R / C streams strictly in order (row tile: 4 radial fragments, the GEMM1 fragments (source, K group), the coefficient
-    block, the GEMM2 fragments (output row tile)); rows are addressed through the row table.  Checks on the way: every item of the
-    program exactly once, one radial generator per phase, a tile written by one group per phase, a group's streams consumed exactly."""
-    E = srcs[0].shape[0]
-    base = st.base
-    stream = st.stream(prog.weights).astype(dtype)
-    out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
-    woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
-    H = prog.hidden
-    assert prog.hidden_pad == 64 and base.part_table.shape[0] == 1
-    sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _ = (int(v) for v in base.part_table[0])
-    tile_floats = sum(int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) for s in base.seg_table)
-    maxstride = max((2 * int(s[0]) + 1) * 16 + 4 for s in base.seg_table)
-    rowtab = base.rowtab[rt0:rt0 + rtn]
-    tile_of = np.full(tile_floats + maxstride, -1)
-    for g, sgr in enumerate(base.seg_table):
-        tile_of[int(sgr[5]):int(sgr[5]) + int(sgr[1]) * ((2 * int(sgr[0]) + 1) * 16 + 4)] = g
-    hh = [None, None]
-    for m in (0, 1):
-        if h2[m] is not None:
-            hh[m] = np.zeros((E, 64), dtype=dtype)
-            hh[m][:, :H] = h2[m]
-    nops = st.op_table.shape[0]
-    for e0 in range(0, E, 16):
-        ne = min(16, E - e0)
-        cols = np.arange(e0, e0 + ne)
-        lds = np.zeros(tile_floats + maxstride, dtype=dtype)
-        seen = np.zeros(nops, dtype=int)
-        items_seen = set()
-        for ph in range(st.phase_table.shape[0]):
-            b0, b1, g0, g1, cls = (int(v) for v in st.phase_table[ph][:5])
-            staged, used = {}, 0
-            for blk in base.block_table[b0:b1]:
-                s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in blk)
-                size = -(-((2 * li + 1) * (in_mulp // 4)) // 4) * 256
-                assert o0 == used and (o1 == o0 + size if nsrc == 2 else o1 == -1)
-                used += nsrc * size
-                staged[o0] = (s0, s1, in_off, in_mulp, li)
-            assert used <= ctr_off - stage_off
-            owner = {}
-            for w in range(g0, g1):                            # w: the work group (claimed by whichever wave is free)
-                o_b, o_e, *pos = (int(v) for v in st.group_table[w][:5])
-                if w + 1 < st.group_table.shape[0]:            # a group's streams end where the next group's begin
-                    ends = [int(v) for v in st.group_table[w + 1][2:5]]
-                for oi in range(o_b, o_e):
-                    op = [int(v) for v in st.op_table[oi]]
-                    seen[oi] += 1
-                    code, so0, so1, fb0, cdir64, ngrp, ksteps, nsrc, rtm, rto, nk2, flags, rti, row0, item, _ = op
-                    assert item not in items_seen
-                    items_seen.add(item)
-                    s0, s1, in_off, in_mulp, li = staged[so0]
-                    lin = bool(flags & 2)
-                    x4 = bool(flags & 4)
-                    if lin:
-                        mm, odd = code & 7, False
-                        assert code == 128 + 8 * x4 + mm
-                    else:
-                        odd, mm = bool(code & 64), (code & 31) >> 2
-                        assert bool(code & 32) == x4 and (flags & 1) == cls, "a phase's tensor-product items use the phase's radial generator"
-                    ncr = 2 * mm + 1
-                    P1 = in_mulp // 4
-                    neg = cdir64 < 0
-                    assert abs(cdir64) == P1 * 64 and fb0 == ((li - mm) * P1 + ((ncr - 1) * P1 if neg else 0)) * 64
-                    assert ngrp == -(-ksteps // 4) and (so1 >= 0) == (nsrc == 2) and (not x4 or (ncr <= 3 and in_mulp % 16 == 0))
-                    colsel = [c for c in range(ncr) if not (odd and c == mm)]
-
-                    def pop(k, n):
-                        v = stream[pos[k]:pos[k] + n]
-                        pos[k] += n
-                        return v
-
-                    def bop(si, c, G, q):                      # B[k = g][edge] of K-step (G, q), column c, source si
-                        m = c - mm
-                        a = li + (-m if neg else m)
-                        X = srcs[s1 if si else s0]
-                        B = np.zeros((4, 16), dtype=dtype)
-                        for g in range(4):
-                            u = 16 * G + 4 * g + q if x4 else 4 * (4 * G + q) + g
-                            B[g, :ne] = X[cols, in_off + a * in_mulp + u]
-                        return B
-
-                    rt_rows = rowtab[rti:]
-                    touched = set()
-                    acc = np.zeros((max(rto, 1), 16, ncr, 16), dtype=dtype)
-                    for rt in range(rtm):
-                        mid = np.zeros((ncr, 16, 16), dtype=dtype)
-                        if not lin:
-                            S = np.zeros((16, 16), dtype=dtype)
-                            for G in range(4):
-                                fr = pop(1, 256).reshape(4, 16, 4)
-                                for q in range(4):
-                                    B = np.zeros((4, 16), dtype=dtype)
-                                    for g in range(4):
-                                        B[g, :ne] = hh[cls][cols, 16 * G + 4 * g + q]
-                                    S += fr[:, :, q].T @ B
-                        for si in range(nsrc):
-                            for G in range(ngrp):
-                                fr = pop(0, 256).reshape(4, 16, 4)
-                                for q in range(4):
-                                    if not x4 and 4 * G + q >= ksteps:
-                                        continue
-                                    for c in colsel:
-                                        mid[c] += fr[:, :, q].T @ bop(si, c, G, q)
-                        if lin:
-                            for r in range(16):
-                                base_r = int(rt_rows[row0 + 16 * rt + r])
-                                for c in range(ncr):
-                                    lo = base_r + (c - mm) * 16
-                                    lds[lo:lo + 16] += mid[c][r]
-                                    touched.add(int(tile_of[lo]))
-                            continue
-                        CF = pop(2, ncr * 16).reshape(ncr, 16)
-                        mid = mid * S[None] * CF[:, :, None]
-                        kv = nk2 - 4 * rt
-                        for rtp in range(rto):
-                            fr = pop(0, 256).reshape(4, 16, 4)
-                            for r in range(4):
-                                if r >= kv:
-                                    continue
-                                for c in colsel:
-                                    acc[rtp, :, c] += fr[:, :, r].T @ mid[c][r::4, :]
-                    if not lin:
-                        if odd:
-                            assert not acc[:, :, mm].any()
-                        for rtp in range(rto):
-                            for r in range(16):
-                                base_r = int(rt_rows[16 * rtp + r])
-                                for c in colsel:
-                                    lo = base_r + (c - mm) * 16
-                                    assert 0 <= lo and lo + 16 <= tile_floats + maxstride and len(set(tile_of[lo:lo + 16].tolist())) == 1
-                                    lds[lo:lo + 16] += acc[rtp, r, c]
-                                    touched.add(int(tile_of[lo]))
-                    touched.discard(-1)
-                    for tl in touched:
-                        assert owner.setdefault(tl, w) == w, "a tile must belong to one work group per phase"
-                if w + 1 < st.group_table.shape[0]:
-                    assert pos == ends, "a group consumes exactly its streams"
-        assert (seen == 1).all()
-        missing = set(range(base.item_table.shape[0])) - items_seen
-        for ii in missing:                                     # dropped items: one-column odd super-paths (structural zeros)
-            it = base.item_table[ii]
-            assert int(it[0]) == P.IT_TP and int(it[7]) and int(it[6]) == 0
-        for sg, seg in enumerate(base.seg_table):
-            lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
-            strd = (2 * lk_ + 1) * 16 + 4
-            tile = np.zeros((rto_ * 16, 2 * lk_ + 1, 16), dtype=dtype)
-            tile[:mul_] = lds[toff_:toff_ + mul_ * strd].reshape(mul_, strd)[:, :(2 * lk_ + 1) * 16].reshape(mul_, 2 * lk_ + 1, 16)
-            _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)
-    return out
-
-
 def run_linear_tables(tabs, x, res=(), dtype=np.float64):
     """csrc/linear.hip on plan.LinearTables, fragment-exact: per unit (<= 64 output channels of one irrep block) and 16 pair-rows
     (row, component), the A fragments [G][rt][lane = 16 g + i][q] hold W^T[16 rt + i][16 G + 4 g + q]; the B operand of lane (g, n) is the

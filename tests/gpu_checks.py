@@ -149,15 +149,13 @@ def check_message_pack_random(device="cuda", seed=0, schedule="auto", irr=None, 
         torch.set_default_dtype(prev)
     m = load_weights(hnn.MessagePackBlock(irr, irr, sh, irr, 8, list(radial)), {k: v.detach().numpy() for k, v in ref.state_dict().items()})
     os.environ["HG_MP_KERNEL"] = schedule
-    if parts is not None:                                      # workgroups per 16-edge tile (1: the large-graph path); + the streamed kernel
+    if parts is not None:                                      # workgroups per 16-edge tile (1: the large-graph path)
         os.environ["HG_IS_PARTS"] = str(parts)
-        os.environ["HG_ST"] = "1"
     try:
         return _message_pack_random_run(m, device, irr, sh, lmax, lsh, n, rbf, src, dst, ef, out, E)
     finally:
         os.environ.pop("HG_MP_KERNEL", None)
         os.environ.pop("HG_IS_PARTS", None)
-        os.environ.pop("HG_ST", None)
 
 
 def _message_pack_random_run(m, device, irr, sh, lmax, lsh, n, rbf, src, dst, ef, out, E):
@@ -178,7 +176,7 @@ def _message_pack_random_run(m, device, irr, sh, lmax, lsh, n, rbf, src, dst, ef
     torch.cuda.synchronize()
     scale = out.abs().max().item()
     dp = m._dp_for(E)
-    kern = "seg" if dp.sched is None else ("st" if (dp.st is not None and dp.is_parts_for(E) == 1) else "is")
+    kern = "seg" if dp.sched is None else "is"
     return {"irreps": irr, "sh": sh, "kernel": kern, "rel_err": 0.0 if scale < 1e-12 else rel(y, out)}
 
 

@@ -49,14 +49,14 @@ def test_message_pack_random_irreps_vs_oracle(seed, schedule):
 
 
 @pytest.mark.parametrize("case", list(range(6)) + ["A", "B"])
-def test_message_pack_static_stream_vs_oracle(case):
-    """csrc/tp_st.hip (per-wave weight streams, the default kernel of launches with one workgroup per 16-edge tile): random irreps sets
-    and the two shipped sets, 64-wide radial MLP, forced onto the single-part path, vs the fp64 oracle"""
+def test_message_pack_single_part_vs_oracle(case):
+    """the LARGE-graph path of csrc/tp_is.hip (one workgroup per 16-edge tile, `tp_is_kernel<false, false>`: what the benchmark runs) forced
+    on small inputs: random irreps sets and the two shipped sets, 64-wide radial MLP (hidden rows resident in registers), vs the fp64 oracle"""
     import bench
     kw = dict(irr=bench.IRREPS[case], sh=bench.SH, seed=7, E=37) if isinstance(case, str) else dict(seed=case)
     r = G.check_message_pack_random(radial=(64, 64), parts=1, **kw)
     print(r)
-    assert r["kernel"] == "st" and r["rel_err"] < G.TOL
+    assert r["kernel"] == "is" and r["rel_err"] < G.TOL
 
 
 def test_corr_product_block_golden():

@@ -902,90 +902,3 @@ def test_lite_mode_message_pack_backward_vs_autograd(seed):
             assert float((grads[k].reshape(want_w[k].shape) - want_w[k]).abs().max()) < 2e-6 * scale, (k, irr, sh)
 
 
-def _st_case(irr, sh, lm, E, seed, skip=False):
-    """oracle MessagePackBlock (64-wide radial MLP) vs plan.st_schedule emulated fragment-exactly (tests/emu.py:run_program_st)"""
-    import torch
-    from oracle import hamgnn_ref as R, e3
-    torch.manual_seed(seed)
-    prev = torch.get_default_dtype()
-    torch.set_default_dtype(torch.float64)
-    try:
-        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[64, 64])
-        g = torch.Generator().manual_seed(seed)
-        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
-        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
-        shv = e3.spherical_harmonics(list(range(len(sh.split("+")))), n, True, "component")
-        rbf = torch.randn(E, 8, generator=g)
-        want = ref(src, dst, ef, shv, rbf).detach().numpy()
-    finally:
-        torch.set_default_dtype(prev)
-    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
-    lay = P.PlanarLayout(irr)
-    D = emu.edge_wigner_all(n.numpy(), lm)
-    xs, xd, fe = (emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, lm) for t in (src, dst, ef))
-    hn = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
-    he = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
-    groups = P.choose_merge_groups(irr, irr, sh, irr, 64)
-    prog = P.build_message_pack_program(sd, irr, irr, sh, irr, True, merge_groups=groups)
-    try:
-        st = P.st_schedule(prog)
-    except NotImplementedError:
-        return None
-    if np.abs(want).max() < 1e-12:
-        return st
-    got = emu.run_program_st(prog, st, [xs, xd, fe], (hn, he), D, lm)
-    assert rel(lay.from_planar(got), want) < 1e-6, irr
-    if skip:                                                   # + the PairInteractionBlock skip o3.Linear (plain Linear ops), edge frame
-        sk = np.random.default_rng(0).normal(size=sum(mm * mm for mm, _, _ in so3.Irreps(irr)))
-        p2 = P.build_message_pack_program(sd, irr, irr, sh, irr, False, sk, merge_groups=groups)
-        a = emu.run_program_st(p2, P.st_schedule(p2), [xs, xd, fe], (hn, he), None, None)
-        b = emu.run_program_is(p2, P.is_schedule(p2), [xs, xd, fe], (hn, he), None, None)
-        assert rel(a, b) < 1e-9
-    return st
-
-
-def test_static_stream_schedule_mini_and_shipped_irreps():
-    """plan.st_schedule (csrc/tp_st.hip): static per-wave op lists + weight streams reproduce the oracle; one radial generator per phase;
-    streams consumed exactly; a tile written by one wave per phase (asserted inside the emulator)"""
-    import bench
-    st = _st_case(MINI, SH, 3, 19, 1, skip=True)
-    assert st is not None and st.balance > 0.6 and st.group_table.shape[1] == P.ST_GROUP_I32
-    for which, E in (("B", 5), ("A", 3)):
-        st = _st_case(bench.IRREPS[which], bench.SH, 5 if which == "B" else 6, E, 2, skip=(which == "B"))
-        assert st is not None and st.balance > 0.8
-        assert st.base.lds_floats * 4 <= P.IS_LDS_BYTES
-        # every phase holds the blocks of ONE radial generator; the op codes are instantiated by the kernel
-        for code in st.op_table[:, 0]:
-            code = int(code)
-            if code >= 128:
-                assert (code & 7) <= 6 and (not (code & 8) or (code & 7) <= 1)
-            else:
-                mm, rc = (code & 31) >> 2, code & 3
-                assert (1, 2, 4)[rc] <= P.ST_RTO_MAX[mm] and (not (code & 32) or mm <= 1) and (not (code & 64) or mm >= 1)
-
-
-@pytest.mark.parametrize("seed", range(8))
-def test_static_stream_schedule_random_irreps(seed):
-    rng = np.random.default_rng(300 + seed)
-    lmax = int(rng.integers(1, 4))
-    irr = _random_irreps(rng, lmax)
-    if "0e" not in irr:
-        irr = "5x0e+" + irr
-    lsh = int(rng.integers(1, 4))
-    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
-    _st_case(irr, sh, max(lmax, lsh), 17, seed)
-
-
-def test_static_stream_refuses_what_the_kernel_cannot_run():
-    """hidden width != 64 and data-gradient programs (a staged block feeding both radial generators) keep the input-stationary kernel"""
-    import torch
-    from hamgnn_amd import nn as hnn
-    torch.manual_seed(0)
-    m = hnn.MessagePackBlock(MINI, MINI, SH, MINI, 8, [16, 16])
-    prog = P.build_message_pack_program(hnn._np_sd(m), MINI, MINI, SH, MINI, True)
-    with pytest.raises(NotImplementedError):
-        P.st_schedule(prog)
-    m = hnn.MessagePackBlock(MINI, MINI, SH, MINI, 8, [64, 64])
-    adj = P.build_message_pack_adjoint_program(hnn._np_sd(m), MINI, MINI, SH, MINI)
-    with pytest.raises(NotImplementedError):
-        P.st_schedule(adj)
