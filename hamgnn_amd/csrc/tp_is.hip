@@ -31,14 +31,6 @@ struct ProfIs { unsigned long long t[12]; unsigned long long last; };
 #define IS_PROF_PASS
 #define IS_T(k)
 #endif
-#ifdef HG_HB                           // the 16 edges' hidden rows of both radial MLPs (B operands of the radial-scale MFMAs) resident in registers
-#define IS_HB_ARG , const f32x4 (&hbn)[4], const f32x4 (&hbe)[4]
-#define IS_HB_PASS , hbn, hbe
-#else
-#define IS_HB_ARG
-#define IS_HB_PASS
-#endif
-
 // broadcast lane q of every row of 16 lanes to that row (DPP row_newbcast, gfx90a+): lanes (g, *) <- lane (g, q)
 #define IS_BC_CASE(Q) case Q: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + Q, 0xf, 0xf, false));
 __device__ __forceinline__ float is_row_bcast(float v, int q) {      // q is a compile-time constant at every call site (unrolled loops)
@@ -57,10 +49,7 @@ __device__ __forceinline__ float is_row_bcast(float v, int q) {      // q is a c
 // works on the 2 MM remaining columns only -- column slot c < MM is real column c, slot c >= MM is real column c + 1.
 template <int MM, int RTM, bool SPLIT, bool ODD>
 __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
-                                        float* __restrict__ lds, int64_t erow, int lane IS_HB_ARG IS_PROF_ARG) {
-#ifdef HG_IS_OPAQUE_LANE               // A/B hook: lane-derived address terms recomputed per item instead of hoisted (235 -> 217 VGPRs, but 7.58 vs
-    asm volatile("" : "+v"(lane));     // 7.37 ms per 131 072-edge launch: the hoisted terms are worth their registers; profiles/r03_tp_is_experiments.md)
-#endif
+                                        float* __restrict__ lds, int64_t erow, int lane, const f32x4 (&hbr)[4], int hbr_cls IS_PROF_ARG) {
     constexpr int NCR = 2 * MM + 1;                            // real columns (fragment layouts of cf, tile columns)
     constexpr int NC = ODD ? 2 * MM : NCR;                     // column slots this item computes
 #define IS_COL(c) ((ODD && (c) >= MM) ? (c) + 1 : (c))
@@ -80,32 +69,29 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const int ngrp = (ksteps + 3) >> 2;
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;      // [src][G][rt][lane]
     f32x4 av_n[RTM];
-#ifdef HG_CFP                          // packed CG coefficients (plan._cf_block): one float4 per lane covers 16 (row tile, column) pairs, requested with the
-    constexpr int NPAIR = RTM * NCR, NJ = (NPAIR + 15) / 16;            // radial operands -- nothing left to wait for at the scale step
+    // CG coefficients cf[row, column] in PACKED form (plan._cf_block): one float4 per lane covers 16 (row tile, column) pairs -- lane (g, p) holds
+    // the four rows 4 g + r of pair p -- requested with the radial operands, so nothing is left to wait for at the scale step, which broadcasts
+    // pair p along the 16 lanes of row g by DPP (r3: one float4 load and four registers per PAIR, requested after GEMM1 and waited for at once)
+    constexpr int NPAIR = RTM * NCR, NJ = (NPAIR + 15) / 16;
     f32x4 cfv[NJ];
     if (typ == 0) {
         const f32x4* __restrict__ cfp = reinterpret_cast<const f32x4*>(Wb + it[13] + NPAIR * 16) + lane;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) cfv[j] = cfp[j * 64];
     }
-#endif
-#ifdef HG_IS_EARLY_A1                  // first GEMM1 fragment group requested together with the radial operands: one exposed L2 latency fewer per item
-#pragma unroll
-    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
-#endif
     // ---------------------------------------------------------------- radial scale s_e = W3^T h2 first (see tp_fused.hip)
     f32x4 S[RTM];
-#ifdef HG_DUAL
-    f32x4 S2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#endif
     if (typ == 0) {
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
         const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
         const int hgrp = A.hidden >> 4;
-#ifdef HG_HB
-        if (hgrp == 4) {               // rows resident; the guards stay run-time (small blocks: the MFMAs of a group start when ITS fragments arrive)
+        if (mlp == hbr_cls) {
+            // the 16 edges' hidden rows of the phase's radial MLP (the B operands of these MFMAs, the same for every item of a branch) are
+            // resident in registers: read once per phase by the kernel, under the staging -- the planner keeps a phase on one generator where
+            // that is free (plan.is_schedule(separate_mlp)); r3 loaded them per item: 4 of an item's ~35 vector loads, and a second round
+            // trip when they missed the L1.  The group guards stay run-time: small blocks, a group's MFMAs start when ITS fragments arrive
             const int hg = __builtin_amdgcn_readfirstlane(A.hidden) >> 4;
             f32x4 wv[4][RTM];
 #pragma unroll
@@ -114,59 +100,15 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[(G * RTM + rt) * 64];
                 }
-            if (mlp) {
-#pragma unroll
-                for (int G = 0; G < 4; ++G)
-                    if (G < hg) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int rt = 0; rt < RTM; ++rt) {
-#ifdef HG_DUAL
-                                if (RTM == 1 && (G & 1)) S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbe[G][q], S2, 0, 0, 0);
-                                else
-#endif
-                                S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbe[G][q], S[rt], 0, 0, 0);
-                            }
-                    }
-            } else {
-#pragma unroll
-                for (int G = 0; G < 4; ++G)
-                    if (G < hg) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int rt = 0; rt < RTM; ++rt) {
-#ifdef HG_DUAL
-                                if (RTM == 1 && (G & 1)) S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbn[G][q], S2, 0, 0, 0);
-                                else
-#endif
-                                S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbn[G][q], S[rt], 0, 0, 0);
-                            }
-                    }
-            }
-#ifdef HG_DUAL
-            if (RTM == 1) S[0] += S2;
-#endif
-        } else
-#endif
-#ifdef HG_IS_H64                       // A/B hook (r3): the shipped hidden width (64 = 4 groups) as straight-line code, no branch between the loads and
-        if (hgrp == 4) {               // the 16 RTM MFMAs
-            f32x4 hb[4], wv[4][RTM];
-#pragma unroll
-            for (int G = 0; G < 4; ++G) {
-                hb[G] = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[(G * RTM + rt) * 64];
-            }
 #pragma unroll
             for (int G = 0; G < 4; ++G)
+                if (G < hg) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
+                        for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbr[G][q], S[rt], 0, 0, 0);
+                }
         } else
-#endif
 #pragma unroll 1
         for (int G0 = 0; G0 < hgrp; G0 += 4) {
             f32x4 hb[4], wv[4][RTM];
@@ -183,19 +125,9 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt) {
-#ifdef HG_DUAL                         // one row tile: two accumulator chains (a dependent fp32 MFMA issues every 40 cycles, an independent one every 32,
-                            if (RTM == 1 && (G & 1))      // and a branch between two dependent MFMAs costs ~43 more: MI355X_MICROARCH.md)
-                                S2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S2, 0, 0, 0);
-                            else
-#endif
-                            S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
-                        }
+                        for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
                 }
         }
-#ifdef HG_DUAL
-        if (RTM == 1) S[0] += S2;
-#endif
     }
 
     IS_T(1);                                                    // radial scale
@@ -208,23 +140,8 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const int P1 = in_mulp >> 2;                               // float4 pieces per component
     const int cdir = neg ? -P1 : P1;                           // column c -> component (neg ? a_hi - c : a_lo + c)
     const int c0p = (li - MM) * P1 + (neg ? (NCR - 1) * P1 : 0);
-#ifndef HG_IS_EARLY_A1
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
-#endif
-#ifdef HG_IS_EARLY_A2                  // GEMM2's first fragment tile requested under the last GEMM1 group instead of after it
-    const f32x4* __restrict__ a2e = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
-    f32x4 a2_e[RTM];
-#define IS_A2_EARLY() else if (typ == 0) { _Pragma("unroll") for (int rt = 0; rt < RTM; ++rt) a2_e[rt] = a2e[rt * 64]; }
-#elif defined(HG_IS_TOUCH)             // A/B hook (r3): under the LAST GEMM1 group, one dword per 64-byte line of the coefficient block and of GEMM2's
-                                       // first fragment tiles -- so that the loads GEMM2 starts with (and waits for at once) hit the L1
-    float touch0 = 0.f, touch1 = 0.f;
-    const float* __restrict__ tch_cf = Wb + it[13] + (lane < RTM * NCR ? lane : RTM * NCR - 1) * 16;
-    const float* __restrict__ tch_a2 = Wb + it[14] + (lane < 16 * RTM ? lane : 16 * RTM - 1) * 16;
-#define IS_A2_EARLY() else if (typ == 0) { touch0 = *tch_cf; touch1 = *tch_a2; }
-#else
-#define IS_A2_EARLY()
-#endif
 #pragma unroll 1
     for (int si = 0; si < nsrc; ++si) {
         const float* __restrict__ sbase = stage + (si ? so1 : so0);
@@ -240,7 +157,6 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
                 }
-                IS_A2_EARLY()
 #pragma unroll
                 for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (IS_COL(c) * cdir + 4 * G) * 64);
 #pragma unroll
@@ -262,24 +178,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
                 }
-                IS_A2_EARLY()
                 const int nq = ksteps - 4 * G;                 // K-steps in this group (>= 4 except in the tail group)
-#ifdef HG_IS_FULLG                     // A/B hook (r3): a full group as ONE basic block (no branch per K-step); only the tail group is guarded
-                if (nq >= 4) {
-                    float b[4][NC];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) b[q][c] = fb[(IS_COL(c) * cdir + 4 * G + q) * 64];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                            for (int c = 0; c < NC; ++c)
-                                mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q][c], mid[rt][c], 0, 0, 0);
-                } else
-#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (q < nq) {
@@ -291,14 +190,6 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
-#ifdef HG_IS_SGB                       // A/B hook (r3; measured neutral: 7.36-7.39 vs 7.35-7.37 ms, off)
-                        // one row tile: every operand has ONE consumer and the scheduler emits read -> wait -> MFMA per column (an LDS
-                        // latency per MFMA; ISA audit, profiles/r03_tp_is_experiments.md): all NC reads first, then the NC MFMAs
-                        if (RTM == 1 && NC > 1) {
-                            __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, NC, 0);
-                        }
-#endif
                     }
                 }
             }
@@ -310,14 +201,8 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
         const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + it[14]) + lane;
         const f32x4* __restrict__ cf = reinterpret_cast<const f32x4*>(Wb + it[13]) + g;     // [rt][c][g] float4
         f32x4 a2_n[RTM];
-#ifdef HG_IS_EARLY_A2
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2_e[rt];
-#else
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];
-#endif
-#ifdef HG_CFP
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
@@ -328,15 +213,6 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                 for (int r = 0; r < 4; ++r) cb[r] = is_row_bcast(cfv[p >> 4][r], p & 15);
                 mid[rt][c] = mid[rt][c] * S[rt] * cb;
             }
-#else
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * cf[(rt * NCR + IS_COL(c)) * 4];
-#endif
-#ifdef HG_IS_TOUCH
-        asm volatile("" :: "v"(touch0), "v"(touch1));
-#endif
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
         // rows beyond mul_k (fragment padding) go to the shared trash row: no divergent branches (their L' columns are zero)
@@ -372,25 +248,15 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][IS_COL(c) * 16];
                 }
-#ifdef HG_DUAL
-                f32x4 accb = (f32x4){0.f, 0.f, 0.f, 0.f};      // NC == 1: the K-steps alternate between two accumulator chains
-#endif
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (4 * rt + r < nk2) {                // trailing K-steps hold only padding rows: not issued
-#ifdef HG_DUAL
-                            if (NC == 1 && (r & 1)) accb = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][0][r], accb, 0, 0, 0);
-                            else
-#endif
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c][r], acc[c], 0, 0, 0);
                         }
-#ifdef HG_DUAL
-                if (NC == 1) acc[0] += accb;
-#endif
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -459,7 +325,6 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     }
     IS_T(3);                                                    // scale-mul + GEMM2 + write-back
 #undef IS_COL
-#undef IS_A2_EARLY
 }
 
 // lite_mode items (message_passing.py:197-206: unweighted uvu product folded with its o3.Linear block), rows = output channels:
@@ -819,17 +684,17 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
 
 #ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
 #define IS_CASE_ODD(MMv, RTMv)
 #else
 #define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
+    case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
 #ifdef HG_NO_ODD_SKIP                 // A/B hook: odd items through the full-column code
 #define IS_CASE_ODD(MMv, RTMv) \
-    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
+    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
 #else
 #define IS_CASE_ODD(MMv, RTMv) \
-    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, true>(A, g_W, it, lds, erow, lane IS_HB_PASS IS_PROF_PASS); break;
+    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, true>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
 #endif
 #endif
 
@@ -880,14 +745,6 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     const unsigned long long t_begin = prof.last;
 #endif
 
-#ifdef HG_HB
-    f32x4 hbn[4], hbe[4];
-#pragma unroll
-    for (int G = 0; G < 4; ++G) {
-        hbn[G] = (A.h2[0] && A.hidden >= 64) ? *reinterpret_cast<const f32x4*>(A.h2[0] + erow * A.hidden + 4 * g + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        hbe[G] = (A.h2[1] && A.hidden >= 64) ? *reinterpret_cast<const f32x4*>(A.h2[1] + erow * A.hidden + 4 * g + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-#endif
     for (int i = threadIdx.x; i < A.rowtab_off; i += IS_NT) lds[i] = 0.f;            // all segment tiles (all copies) + trash rows
     {
         int* __restrict__ rt_l = reinterpret_cast<int*>(lds + A.rowtab_off);
@@ -897,8 +754,17 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     IS_T(4);                                                   // zero fill
 
     for (int ph = ph0; ph < ph1; ++ph) {
-        const int* __restrict__ P = g_phases + ph * 4;
+        const int* __restrict__ P = g_phases + ph * 8;
         const int b0 = P[0], b1 = P[1], g0 = P[2], g1 = P[3];
+        // the hidden rows of the phase's radial MLP (P[4]; -1: none / hidden width != 64), resident for its items (item_is): requested here,
+        // first used after the staging
+        const int hbr_cls = (A.hidden == 64 && (P[4] == 0 || (P[4] == 1 && A.h2[1]))) ? P[4] : -1;
+        f32x4 hbr[4];
+        {
+            const float* __restrict__ hrow = (hbr_cls == 1 ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
+#pragma unroll
+            for (int G = 0; G < 4; ++G) hbr[G] = hbr_cls >= 0 ? *reinterpret_cast<const f32x4*>(hrow + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #ifdef HG_IS_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -921,6 +787,9 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
                 case 6: stage_block<6>(A, B, stage, erow, wave, lane); break;
                 default: break;
             }
+#ifdef HG_PROF                     // staging by kind: 8 = plain rows (LDS-DMA issue), 9 = gathered l = 0 rows, 10 = rotated l = 1..3, 11 = rotated l >= 4
+            if (!((A.rot_mask >> B[0]) & 1)) { IS_T(8); } else if (B[4] == 0) { IS_T(9); } else if (B[4] <= 3) { IS_T(10); } else { IS_T(11); }
+#endif
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -1056,7 +925,7 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     IS_T(7);                                                   // epilogue
 #ifdef HG_PROF
     if (lane == 0) {
-        for (int k = 0; k < 8; ++k) atomicAdd(&hg_prof_is_acc[k], prof.t[k]);
+        for (int k = 0; k < 12; ++k) atomicAdd(&hg_prof_is_acc[k], prof.t[k]);
         atomicAdd(&hg_prof_is_acc[15], prof.last - t_begin);
     }
 #endif

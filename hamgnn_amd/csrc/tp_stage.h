@@ -83,22 +83,6 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
             float dc[NCO];
 #pragma unroll
             for (int m = 0; m < NCO; ++m) dc[m] = dl[(m * NCO + a) * 16];
-#ifdef HG_EPI_UNROLL                   // A/B hook (r3): the four channel groups of a unit at once (4 NCO tile reads in flight instead of NCO, then one wait)
-            float acc[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int w = w0 + g + 4 * k;
-                const float* __restrict__ tw = tl + (w < mul_k ? w : 0) * rowstride;
-                acc[k] = 0.f;
-#pragma unroll
-                for (int m = 0; m < NCO; ++m) acc[k] = fmaf(dc[m], tw[m * 16], acc[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int w = w0 + g + 4 * k;
-                if (valid && w < wend) ob[a * out_mulp + w] = w < mul_k ? acc[k] : 0.f;
-            }
-#else
 #pragma unroll 1
             for (int w = w0 + g; w < wend && w < w0 + 16; w += 4) {
                 const float* __restrict__ tw = tl + (w < mul_k ? w : 0) * rowstride;
@@ -107,7 +91,6 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
                 for (int m = 0; m < NCO; ++m) acc = fmaf(dc[m], tw[m * 16], acc);
                 if (valid) ob[a * out_mulp + w] = w < mul_k ? acc : 0.f;
             }
-#endif
         }
     } else {
 #pragma unroll 1

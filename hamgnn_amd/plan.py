@@ -185,7 +185,7 @@ class Program:
 # ---- input-stationary schedule (csrc/tp_is.hip): the SAME items, regrouped by input irrep block ------------------------------
 IS_WAVES = int(os.environ.get("HG_IS_WAVES", "4"))      # waves of a workgroup (= IS_NW of csrc/tp_is.hip); all on the same 16 edges
 IS_BLOCK_I32 = 8                   # {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
-IS_PHASE_I32 = 4                   # {block_begin, block_end, group_begin, group_end}
+IS_PHASE_I32 = 8                   # {block_begin, block_end, group_begin, group_end, radial generator whose hidden rows the kernel keeps resident (-1: none), 0..}
 IS_LDS_BYTES = 80 * 1024           # two workgroups per CU
 IS_ITEM_I32 = 24                   # item record of the IS kernel = fused-kernel record + {lk, mul_k, rto, tile_off} of its segment
 
@@ -280,7 +280,7 @@ def lds_partition(prog: "Program") -> List[int]:
     return owner
 
 
-def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSchedule:
+def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -> IsSchedule:
     """Regroup a finalized fused-kernel program for the input-stationary kernel.  Input irrep blocks (per source set) are packed
     into phases whose staged rows fit the staging area; every item reading a staged block runs in that phase.  Raises
     NotImplementedError when the tiles of all output segments + a useful staging area do not fit IS_LDS_BYTES.
@@ -289,6 +289,18 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: bool = False) -> IsSched
     (tiles, phases, groups) and runs in its own workgroup (grid.y) -- the per-tile latency drops at the price of staging the input
     blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots.
     separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (IsSchedule.phase_cls)."""
+    if separate_mlp is None:
+        # default: per-generator phases (the kernel re-reads its resident hidden rows once per phase and wave instead of once per generator change
+        # inside a work group) when that costs less than 1 % of the estimated critical path -- programs with few phases (narrow irreps) lose
+        # more balance than the re-reads cost, data-gradient and lite_mode programs have no such form
+        plain = is_schedule(prog, parts, separate_mlp=False)
+        if parts != 1 or prog.hidden != 64:
+            return plain
+        try:
+            sep = is_schedule(prog, parts, separate_mlp=True)
+        except NotImplementedError:
+            return plain
+        return sep if sum(sep.part_cost) <= 1.01 * sum(plain.part_cost) else plain
     if separate_mlp and np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any():
         raise NotImplementedError("lite_mode programs have no per-generator phases")
     hp4 = prog.hidden_pad // 4
@@ -511,8 +523,8 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
                 by_seg.setdefault(prog.seg_key.get(int(rec[19]), int(rec[19])), []).append(r)
         if copy_stride:                                        # private tile copies: every item is its own work group
             units = [[r] for recs in by_seg.values() for r in recs]
-        else:
-            units = list(by_seg.values())
+        else:                                                  # a work group's items by radial generator: the kernel keeps the hidden rows of
+            units = [sorted(recs, key=lambda r: int(r[10]) if int(r[0]) == IT_TP else -1) for recs in by_seg.values()]      # ONE generator in registers
         if runs is not None and all(int(r[0]) == IT_LINM for recs in units for r in recs):
             units = [[run] for recs in units for run in _lite_runs(prog, recs, runs)]      # one run = one work group (disjoint rows of a tile)
         groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
@@ -523,7 +535,10 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             items += units[n]
         tot += sum(loads)
         crit += max(loads)
-        ptab.append([block_base + b0, block_base + len(btab), group_base + g0, group_base + len(gtab)])
+        # the generator whose hidden rows stay in registers during the phase: the one that carries most of its tensor-product work
+        w = [sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for recs in units for r in recs if int(r[0]) == IT_TP and int(r[10]) == c) for c in (0, 1)]
+        res_cls = -1 if not any(w) else int(w[1] > w[0])
+        ptab.append([block_base + b0, block_base + len(btab), group_base + g0, group_base + len(gtab), res_cls, 0, 0, 0])
         phase_cls.append(_cls(ph) or 0)
     if post_items:                                             # the last phase: nothing staged, one work group per segment's post-op, dearest first
         g0 = len(gtab)
@@ -537,7 +552,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             items.append(r)
         tot += sum(loads)
         crit += max(loads)
-        ptab.append([block_base + len(btab), block_base + len(btab), group_base + g0, group_base + len(gtab)])
+        ptab.append([block_base + len(btab), block_base + len(btab), group_base + g0, group_base + len(gtab), -1, 0, 0, 0])
         phase_cls.append(0)
     # ---- epilogue: Wigner blocks of the un-rotated segments staged in as few batches as fit the staging area (one block per l)
     need = {}

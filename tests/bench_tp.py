@@ -66,7 +66,8 @@ if os.environ.get("HG_PROF") and m._dp.sched is not None:
     L.hg_prof_is_read(buf, 1)
     launch()
     L.hg_prof_is_read(buf, 0)
-    names = ["dispatch", "radial scale", "GEMM1", "scale-mul + GEMM2 + write-back", "zero fill", "phase barrier (imbalance)", "staging", "epilogue"]
+    names = ["dispatch", "radial scale", "GEMM1", "scale-mul + GEMM2 + write-back", "zero fill", "phase barrier (imbalance)", "staging: wait + barrier", "epilogue",
+             "staging: plain rows (DMA issue)", "staging: gathered l=0", "staging: rotated l=1..3", "staging: rotated l>=4"]
     tot = float(buf[15])
     print(json.dumps({"prof_total_wave_cycles": tot, "balance": m._dp.sched.balance, **{n: round(buf[k] / tot, 4) for k, n in enumerate(names)}}))
 elif os.environ.get("HG_PROF"):

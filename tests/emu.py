@@ -217,7 +217,7 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
             for g in part_segs:
                 sgr = sched.seg_table[g]
                 tile_of[int(sgr[5]):int(sgr[5]) + int(sgr[1]) * ((2 * int(sgr[0]) + 1) * 16 + 4)] = g
-            for b0, b1, g0, g1 in sched.phase_table[ph0:ph0 + nph]:
+            for b0, b1, g0, g1 in sched.phase_table[ph0:ph0 + nph, :4]:
                 staged = {}
                 used = 0
                 for blk in sched.block_table[b0:b1]:

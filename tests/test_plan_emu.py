@@ -272,7 +272,7 @@ def test_input_stationary_schedule_shipped_irreps(which):
         assert sp.lds_floats * 4 <= P.IS_LDS_BYTES and len(sp.part_cost) == min(parts, sc.seg_table.shape[0])
         assert max(sp.part_cost) < 0.3 * sc.part_cost[0] and all(int(p[7]) > 0 for p in sp.part_table)
     seen = np.zeros(sc.item_table.shape[0], dtype=int)
-    for b0, b1, g0, g1 in sc.phase_table:
+    for b0, b1, g0, g1 in sc.phase_table[:, :4]:
         used, offs = 0, set()
         for blk in sc.block_table[b0:b1]:
             size = -(-((2 * int(blk[4]) + 1) * (int(blk[3]) // 4)) // 4) * 256 * int(blk[5])
