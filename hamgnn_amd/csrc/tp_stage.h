@@ -75,30 +75,36 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
     const int nw16 = (wend + 15) >> 4;
     const int U = NCO * nw16, per = (U + IS_NW - 1) / IS_NW;              // each wave takes a contiguous range of units (adjacent bytes of the row)
     const int u_begin = wave * per, u_end = (u_begin + per) < U ? (u_begin + per) : U;
+    // a lane owns FOUR consecutive channels of one (edge, component): 4 NCO tile reads in flight, one 16-byte store -- a wave writes 16 edges x
+    // 64 contiguous bytes per request (r3: a dword per lane, four requests for the same bytes)
     if (flags & SEG_UNROTATE) {
         const float* __restrict__ dl = dstage + el;
 #pragma unroll 1
         for (int u = u_begin; u < u_end; ++u) {
-            const int a = u / nw16, w0 = (u - a * nw16) * 16;
+            const int a = u / nw16, w = (u - a * nw16) * 16 + 4 * g;
+            if (w >= wend) continue;
             float dc[NCO];
 #pragma unroll
             for (int m = 0; m < NCO; ++m) dc[m] = dl[(m * NCO + a) * 16];
-#pragma unroll 1
-            for (int w = w0 + g; w < wend && w < w0 + 16; w += 4) {
-                const float* __restrict__ tw = tl + (w < mul_k ? w : 0) * rowstride;
-                float acc = 0.f;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int m = 0; m < NCO; ++m) acc = fmaf(dc[m], tw[m * 16], acc);
-                if (valid) ob[a * out_mulp + w] = w < mul_k ? acc : 0.f;
+            for (int k = 0; k < 4; ++k) {
+                const float* __restrict__ tw = tl + (w + k < mul_k ? w + k : 0) * rowstride;
+#pragma unroll
+                for (int m = 0; m < NCO; ++m) acc[k] = fmaf(dc[m], tw[m * 16], acc[k]);
+                acc[k] = w + k < mul_k ? acc[k] : 0.f;
             }
+            if (valid) *reinterpret_cast<f32x4*>(ob + a * out_mulp + w) = acc;
         }
     } else {
 #pragma unroll 1
         for (int u = u_begin; u < u_end; ++u) {
-            const int a = u / nw16, w0 = (u - a * nw16) * 16;
-#pragma unroll 1
-            for (int w = w0 + g; w < wend && w < w0 + 16; w += 4)
-                if (valid) ob[a * out_mulp + w] = w < mul_k ? tl[w * rowstride + a * 16] : 0.f;
+            const int a = u / nw16, w = (u - a * nw16) * 16 + 4 * g;
+            if (w >= wend) continue;
+            f32x4 acc;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = w + k < mul_k ? tl[(w + k) * rowstride + a * 16] : 0.f;
+            if (valid) *reinterpret_cast<f32x4*>(ob + a * out_mulp + w) = acc;
         }
     }
 }

@@ -240,11 +240,14 @@ def _item_rto(rec, segs, vsegs=()):
     return int(segs[int(rec[19])][2])
 
 
+ITEM_OVERHEAD = int(os.environ.get("HG_ITEM_OVH", "60"))
+
+
 def _item_cost(rec, segs, hp4, vsegs=()):
     if int(rec[0]) == IT_RUN:                                   # measured: a step costs ~860 cycles almost independently of its 4 rtm MFMAs (profiles/r03_lite.md)
         return int(rec[8]) * (6 + int(rec[9])) + 60
     typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
-    c = nsrc * int(rec[8]) * rtm * nc + 60                     # GEMM1 + a per-item latency allowance (in MFMA slots)
+    c = nsrc * int(rec[8]) * rtm * nc + ITEM_OVERHEAD          # GEMM1 + a per-item latency allowance (in MFMA slots)
     if typ == IT_TP:
         c += hp4 * rtm + _item_rto(rec, segs, vsegs) * int(rec[18]) * nc
     return c
