@@ -24,7 +24,7 @@ def test_tp_is_register_budget_and_no_scratch(tp_is):
     for k in ks:
         m = k["meta"]
         assert m["vgpr_spills"] == 0 and m["scratch"] == 0, (k["name"], m)
-        assert m["vgprs"] <= 240, (k["name"], m)                # 2 waves per SIMD need <= 256; 235 / 230 / 231 / 233 at the time of writing
+        assert m["vgprs"] <= 256, (k["name"], m)                # 2 waves per SIMD need <= 256; r4: 250 / 251 / 231 / 233 (16 of them hold the resident hidden rows)
 
 
 def test_lite_run_loop_keeps_its_ring_lookahead(tp_is):
