@@ -482,7 +482,9 @@ class HamGNNPlusPlusOut(nn.Module):
             data["band_energy"], data["wavefunction"], data["band_gap"], data["H_sym"] = tb, tw, tg, th
             if self.zero_point_shift:                                         # :3983-3985: the bands are aligned by their mean instead
                 be = be - torch.mean(be - tb)
-                result["_hamiltonian_unshifted"] = H.clone()                    # what the bands were computed from (the backward re-evaluates them; the shift below is in place)
+                # what the bands were computed from: a backward re-evaluates them (the shift below is in place).  Kept on the head -- not in the
+                # public result dict -- and only when a backward will follow (the representation carries the backbone's tape)
+                self._unshifted = H.clone() if "_tape" in rep else None
             result.update({"band_energy": be, "wavefunction": wf, "band_gap": gap, "H_sym": hs})
         if self.zero_point_shift:
             H = self._apply_zero_point_shift(data, H, edge_counts, False)

@@ -330,15 +330,26 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     return out
 
 
+_SCATTER_CACHE: dict = {}
+
+
 def scatter_rows(index: torch.Tensor, src: torch.Tensor, n: int) -> torch.Tensor:
     """out[i] = sum of the rows src[q] with index[q] == i, in a FIXED order (stable sort by index, then a segmented sum): the
     deterministic form of torch.zeros(n, ...).index_add_(0, index, src), whose float atomics make a training step differ from run to run.
     torch tensor ops (sort / segment_reduce), any device; edge-level glue of the backward passes, not a hot kernel."""
-    index = index.long()
     if src.shape[0] == 0:
         return src.new_zeros((n,) + tuple(src.shape[1:]))
-    order = torch.sort(index, stable=True).indices
-    counts = torch.bincount(index, minlength=n)
+    key = (index.data_ptr(), index._version, int(index.shape[0]), int(n), index.device)
+    hit = _SCATTER_CACHE.get(key)
+    if hit is None or hit[0] is not index:                     # the index tensors of the backward glue (tp_idx, l_idx, z, the contraction tables) are
+        order = torch.sort(index.long(), stable=True).indices  # constants of a model: sorted once (keyed on the tensor object and its version)
+        counts = torch.bincount(index.long(), minlength=n)
+        if counts.shape[0] != n:                               # an index >= n: index_add_ raised here, segment_reduce(unsafe=True) would return extra rows
+            raise IndexError(f"scatter_rows: index {int(index.max())} out of range for {n} rows")
+        if len(_SCATTER_CACHE) > 256:
+            _SCATTER_CACHE.clear()
+        hit = _SCATTER_CACHE[key] = (index, order, counts)
+    _, order, counts = hit
     return torch.segment_reduce(src[order].contiguous(), "sum", lengths=counts, axis=0, unsafe=True)
 
 

@@ -91,13 +91,7 @@ def head_training_step(model, batch, metric: str = "mae", target: Optional[torch
         p = params[k]
         g = g.reshape(p.shape).to(p.dtype)
         p.grad = g.clone() if p.grad is None else p.grad + g
-    for m in head.modules():                                   # the packed weight fragments are stale once the optimiser has stepped
-        if hasattr(m, "_dp"):
-            m._dp = None
-            if hasattr(m, "_dp_adj"):
-                m._dp_adj = None
-    head._compiled_for = None
-    head._adj_tabs = None
+    _invalidate(head)                                          # the packed weight fragments are stale once the optimiser has stepped
     return {"loss": loss, "representation": rep, "g_node_planar": g_node, "g_edge_planar_rot": g_edge}
 
 
@@ -165,6 +159,15 @@ def _invalidate(module):
             m._compiled_for = None
 
 
+def enable_row_programs(module):
+    """after training: let the HamLayers build their fused inference chains (csrc/rowprog.hip) again -- _invalidate switches them off while the
+    weights move, and the flag is sticky (validation / inference inside a training run stay on the separate kernels)"""
+    for m in module.modules():
+        if hasattr(m, "_rowprog_off"):
+            m._rowprog_off = False
+            m._rowprog = None
+
+
 @torch.no_grad()
 def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tensor] = None, losses=None) -> Dict[str, torch.Tensor]:
     """One loss / gradient evaluation of the WHOLE model (HamGNNConvE3 backbone + non-SOC HamGNNPlusPlusOut head): forward with the
@@ -215,14 +218,18 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
                 if out.get("band_energy") is None:
                     raise ValueError("a band_energy loss needs HamGNNPlusPlusOut(calculate_band_energy=True)")
                 be = out["band_energy"]
-                li, gbe = _loss_and_grad(be, gget(batch, spec.get("target", "band_energy")).to(be.dtype), spec["metric"])
+                if getattr(head, "soc_switch", False):
+                    # the band-energy adjoint (kspace.band_energy_backward) assembles the SPIN-FREE H(k); the spinor rows [2 (N + E), (2 nao)^2] of a
+                    # spin-orbit head need the adjoint of the eight spin-block assemblies of kspace.band_energies_soc, which is not built
+                    raise NotImplementedError("training_step: a band_energy loss on a spin-orbit head (soc_switch) is not built")
+                li, gbe = _loss_and_grad(be, gget(batch, spec.get("target", "band_energy").lower()).to(be.dtype), spec["metric"])
                 edge_counts = head._global_inverse(batch)[1]
                 Hb = H
                 if head.zero_point_shift:
                     # the bands were computed from the blocks BEFORE the shift (hamgnn_output.py:3802-3880 precede :3971-3981) and then aligned
                     # by their mean (:3983-3985): the forward kept the unshifted rows for this re-evaluation; adjoint of the alignment = g - mean(g)
                     gbe = gbe - gbe.mean()
-                    Hb = out["_hamiltonian_unshifted"]
+                    Hb = head._unshifted
                 on, off = head._split_by_crystal(batch, Hb, edge_counts)
                 g_on, g_off = kspace.band_energy_backward(head, on.contiguous(), off.contiguous(), batch, w * gbe)
                 gb = head._cat_by_crystal(batch, g_on, g_off, edge_counts)
