@@ -360,6 +360,28 @@ def main():
         per_rank = [None] * world
         torch.distributed.all_gather_object(per_rank, mine)
     assert torch.isfinite(out["hamiltonian"]).all()
+    sharded_check = None
+    if world > 1 and not args.no_accuracy:
+        # after the timed region: the SAME model on a bounded sub-crystal of the same generator, sharded over the ranks (the collective of the
+        # job: RCCL on a multi-GPU node) against the unsharded forward on rank 0 -- so that a scaling record also says the sharded rows are right
+        small = make_graph({"sio2_10k": "sio2_300", "si512": "si64", "mos2_1200": "mos2_48"}.get(args.workload, "sio2_300"), args.nao, soc=args.soc)
+        with torch.no_grad():
+            ss = parallel.shard_graph(small, rank, world).to(dev)
+            Hs = head(ss, model(ss))["hamiltonian"]
+        nn_ = small.num_nodes * (2 if args.soc else 1)
+        parts_ = [None] * world
+        torch.distributed.all_gather_object(parts_, (ss["_hg_edge_ids"].cpu(), Hs[nn_:].float().cpu(), Hs[:nn_].float().cpu()))
+        if rank == 0 and not args.soc:
+            with torch.no_grad():
+                sf = small.to(dev)
+                ref = head(sf, model(sf))["hamiltonian"].float().cpu()
+            off = torch.zeros(small.num_edges, ref.shape[1])
+            for ids, of, on in parts_:
+                off[ids] = of
+            full = torch.cat([parts_[0][2], off], 0)
+            sharded_check = {"rel_err": float((full - ref).abs().max() / ref.abs().max()), "sample": f"{small.num_nodes} atoms / {small.num_edges} edges of the same generator, "
+                             f"sharded x{world} vs unsharded on rank 0", "on_site_rows_agree": float(max((p[2] - parts_[0][2]).abs().max() for p in parts_))}
+            assert sharded_check["rel_err"] < 1e-5, sharded_check
 
     # ---- roofline of the dominant kernel: the fused MessagePackBlock launches (hg_tp_is; hg_tp_fused on the fallback path)
     mp = [(s.elapsed_time(e) * 1e-3, rows, tag) for (s, e, rows, tag) in events if tag == "message_pack"]
@@ -401,6 +423,7 @@ def main():
            "roofline": roofline, "compile_s": compile_s}
     if per_rank is not None:
         res["per_rank"] = per_rank
+        res["sharded_check"] = sharded_check
         res["ranks_seen"] = {"backend": "RCCL (torch.distributed 'nccl')" if backend == "nccl" else backend, "world_size": torch.distributed.get_world_size(),
                              "distinct_devices": len({(h, d) for h, d, _ in idents}), "max_over_mean_edges": max(r["edges"] for r in per_rank) * world / E_total}
     if rank == 0:
@@ -444,4 +467,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as exc:                               # a rank that dies says who it was before the launcher tears the job down
+        if not isinstance(exc, SystemExit) or exc.code not in (0, None):
+            print("BENCH_RANK_FAILURE " + json.dumps({"rank": os.environ.get("RANK", "0"), "local_rank": os.environ.get("LOCAL_RANK", "0"),
+                                                      "world_size": os.environ.get("WORLD_SIZE", "1"), "error": repr(exc)[:500]}), file=sys.stderr, flush=True)
+        raise

@@ -566,6 +566,74 @@ def check_test_stage(device="cuda", tmpdir="/tmp/hg_test_stage"):
             "finite": bool(np.isfinite(P_).all()), "same_as_returned": bool(np.array_equal(P_, preds["hamiltonian"]))}
 
 
+
+def check_front_door(device="cuda", tmpdir="/tmp/hg_front_door"):
+    """SURVEY 8f-1 on the GPU: the model enters through `Model.load_from_checkpoint` (a Lightning-layout .ckpt holding the reference-named weights
+    of the `backbone` and `head_openmx_19` fixtures under `representation.` / `output_module.`, plus the buffers a reference state_dict carries)
+    and the crystals through `NPZGraphDataset` (graph_data.npz) and `LMDBGraphDataset` (the store `npz_to_lmdb` writes) -- the reference's
+    hamgnn/main.py:527-537 + hamgnn/data/graph_data.py:23-128 call sequence on the shim's import paths -- and the HIP forward reproduces the
+    reference's own outputs of both fixtures."""
+    import shutil
+    from hamgnn.main import Model
+    from hamgnn.data.graph_data import NPZGraphDataset, LMDBGraphDataset
+    from hamgnn_amd.data import Graph
+    from hamgnn_amd.data.graph_data import save_graph_npz, npz_to_lmdb
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    fb, fh = load("backbone"), load("head_openmx_19")
+    cfg = json.loads(str(fb["meta"]["cfg"]))
+    shutil.rmtree(tmpdir, ignore_errors=True)
+    os.makedirs(tmpdir)
+    sd = {"representation." + k: torch.as_tensor(v) for k, v in fb["weights"].items()}
+    sd.update({"output_module." + k: torch.as_tensor(v) for k, v in fh["weights"].items()})
+    sd["representation.radial_basis_functions.freqs"] = torch.arange(8.0)       # buffers the reference keeps in its state_dict
+    sd["output_module.cg_calculator.cg_1_1_2"] = torch.zeros(3, 3, 5)
+    ckpt = os.path.join(tmpdir, "last.ckpt")
+    torch.save({"state_dict": sd, "epoch": 7, "pytorch-lightning_version": "1.9.0", "hyper_parameters": {}}, ckpt)
+
+    def host_graph(gd):
+        g = Graph()
+        for k, v in gd.items():
+            g[k] = torch.as_tensor(v)
+        return g
+    g_a = host_graph(fb["graph"])                              # the backbone fixture's crystal
+    gd_b = dict(fh["graph"])                                   # the head fixture's crystal: its own species / targets on the same geometry
+    for k in ("pos", "nbr_shift", "cell"):
+        gd_b[k] = fb["graph"][k]
+    g_b = host_graph(gd_b)
+    gd_c = dict(fb["graph"])                                   # the backbone's crystal with (zero) H0 blocks: what the whole model needs of a record
+    gd_c["Hon0"] = np.zeros((gd_c["z"].shape[0], 19 * 19), np.float32)
+    gd_c["Hoff0"] = np.zeros((gd_c["edge_index"].shape[1], 19 * 19), np.float32)
+    g_c = host_graph(gd_c)
+    npz = os.path.join(tmpdir, "graph_data.npz")
+    save_graph_npz([g_a, g_b, g_c], npz)
+    store = npz_to_lmdb(npz, os.path.join(tmpdir, "graph_data.lmdb"))
+    mk = lambda: dict(representation=HamGNNConvE3(cfg), output=HamGNNPlusPlusOut(MINI, MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True,
+                                                                                  add_H0=True, soc_switch=False, calculate_sparsity=True))
+    model = Model.load_from_checkpoint(checkpoint_path=ckpt, post_processing=None, losses=None, validation_metrics=None, lr=None, lr_decay=None,
+                                       lr_patience=None, **mk()).to(device)
+    out = {}
+    for tag, ds in (("npz", NPZGraphDataset(npz)), ("lmdb", LMDBGraphDataset(store))):
+        assert len(ds) == 3
+        ga, gb, gc = ds[0].to(device), ds[1].to(device), ds[2].to(device)
+        for g in (ga, gb, gc):
+            for k in list(g.keys()):
+                if torch.is_tensor(g[k]) and g[k].is_floating_point():
+                    g[k] = g[k].float()
+        with torch.no_grad():
+            rep = model.representation(ga)
+            res = model.output_module(gb, {"node_attr": torch.from_numpy(fh["inputs"]["node_attr"]).float().to(device),
+                                           "edge_attr": torch.from_numpy(fh["inputs"]["edge_attr"]).float().to(device)})
+            whole = model(gc)                                  # the model's own forward = output_module(batch, representation(batch))
+            two_step = model.output_module(gc, model.representation(gc))
+        torch.cuda.synchronize()
+        out[tag + "_backbone_node_rel_err"] = rel(rep["node_attr"], fb["outputs"]["node_attr"])
+        out[tag + "_backbone_edge_rel_err"] = rel(rep["edge_attr"], fb["outputs"]["edge_attr"])
+        out[tag + "_head_rel_err"] = rel(res["hamiltonian"], fh["outputs"]["hamiltonian"])
+        out[tag + "_whole_model_rel_err"] = rel(whole["hamiltonian"], two_step["hamiltonian"]) + float(not bool(torch.isfinite(whole["hamiltonian"]).all()))
+    return out
+
+
 def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):
     """backward of ResidualBlock (x + Lin2(Gate(Lin1(x)))): data gradient (hg_linear_planar on transposed blocks,
     hg_gate_backward) and the two Linear weight gradients (one GEMM per path) vs torch.autograd through the fp64 oracle"""
