@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--soc", action="store_true", help="SOC / so3 read-out (BASELINE config #3: MoS2 with spin-orbit coupling); the CPU baseline leg stays non-SOC")
     ap.add_argument("--no-mfma-probe", action="store_true", help="skip the 20 ms fp32-MFMA ceiling probe that follows the timed region (roofline.mfma_probe_tflops)")
     ap.add_argument("--lite", action="store_true", help="lite_mode MessagePackBlocks (message_passing.py:197-215: unweighted uvu products + o3.Linear + one combined radial scale); "
-                    "runs on the segment-stationary kernel, the roofline then counts the planner's executed flops (SURVEY 8d's figures are for the default block)")
+                    "runs on the lite instantiation of the input-stationary kernel (tp_is_kernel<., true>), the roofline then counts the planner's executed flops (SURVEY 8d's figures are for the default block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--accuracy-from", default=None, help=argparse.SUPPRESS)
