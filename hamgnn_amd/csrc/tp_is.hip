@@ -718,7 +718,8 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     //  49.6 ms per launch with and without it, profiles/r02_tp_is_experiments.md: the gathered node rows are not what the waves wait for)
     const int64_t e = (int64_t)blockIdx.x * 16 + (lane & 15);
     const bool valid = e < A0.rows;
-    const int64_t erow = valid ? e : A0.rows - 1;
+    const int64_t eslot = valid ? e : A0.rows - 1;
+    const int64_t erow = A0.eperm ? A0.eperm[eslot] : eslot;    // the edge whose rows this slot reads (receiver-major launches: hamgnn_amd/topo.py)
     // SPLIT = false: one part = the whole program, every schedule scalar comes straight from the kernel arguments (the large-graph path,
     // identical to the single-schedule kernel); SPLIT = true: blockIdx.y selects the part, its scalars replace the arguments'
     const int* __restrict__ PT = g_parts + (SPLIT ? blockIdx.y : 0) * IS_PART_I32;
@@ -879,6 +880,9 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     }
     // ---------------------------------------------------------------- epilogue: all four waves on one segment at a time; the Wigner
     // blocks of a batch of segments (one block per l, as many l as fit the staging area) are staged together by LDS-DMA
+    IsScan scan;                                               // fused scatter (tp_stage.h): the slots' runs of equal receivers
+    scan.last = true, scan.row = 0;
+    if (!SPLIT && A0.run_id) scan = is_scan_setup(valid ? A0.run_id[e] : -1 - (int)(lane & 15), lane & 15);
     for (int sg = seg0; sg < seg1; ++sg) {
 #ifdef HG_ABL_NOEPI
         if (A.rows > 0) continue;
@@ -912,13 +916,13 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
         const float* __restrict__ tile = lds + tile_off;
         const float* __restrict__ dst = stage + woff;
         switch (lk) {
-            case 0: epilogue_is<0>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
-            case 1: epilogue_is<1>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
-            case 2: epilogue_is<2>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
-            case 3: epilogue_is<3>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
-            case 4: epilogue_is<4>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
-            case 5: epilogue_is<5>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
-            case 6: epilogue_is<6>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane); break;
+            case 0: epilogue_is<0>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 1: epilogue_is<1>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 2: epilogue_is<2>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 3: epilogue_is<3>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 4: epilogue_is<4>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 5: epilogue_is<5>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 6: epilogue_is<6>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
             default: break;
         }
     }
@@ -948,7 +952,8 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
                         const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table,
                         const int32_t* item_table, const int32_t* part_table, const int32_t* part_table_host, int nparts,
                         const int32_t* row_table, int lds_bytes,
-                        const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream) {
+                        const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
+                        int64_t rows, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_is: nsrc must be 1..4");
@@ -981,6 +986,9 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     }
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
     A.rot_mask = rot_mask;
+    A.eperm = edge_perm;
+    A.run_id = run_id;
+    if (run_id && nparts != 1) return hg_fail(-2, "hg_tp_is: the fused scatter needs a single-part launch");
     if (rot_mask && !wig) return hg_fail(-2, "hg_tp_is: rotated sources need the Wigner rows");
     static unsigned char lds_attr_done[4][HG_MAX_DEVICES];     // once per device (not a stream operation: illegal during graph capture)
     if (int rc = hg_lds_attr_once(lds_attr_done[0], dev_guard.dev, (const void*)tp_is_kernel<false, false>, 160 * 1024)) return rc;

@@ -35,7 +35,45 @@ struct IsArgs {
     int tile_shift;              // split launches: this wave's private tile copy (floats added to every tile offset)
     const int64_t* idx[4];       // per source slot: row gather (NULL: row = edge)
     int rot_mask;                // bit i: source i holds GLOBAL-frame rows that are rotated into the edge frame while staged
+    const int64_t* eperm;        // tile slot -> edge (NULL: identity).  Receiver-major order for launches whose output is scattered onto the receivers
+    const int32_t* run_id;       // fused scatter (NULL: one output row per edge): slot -> index of its run of equal receivers inside the tile = the
+                                 // output row that takes the run's sum (convolution.py:147-149 as a segmented reduce in the epilogue); -1: no output
 };
+
+// Fused node scatter: the 16 slots of a tile lie along a DPP row (lane = 16 g + slot).  seg_masks: for the Hillis-Steele steps d = 1, 2, 4, 8 of a
+// segmented inclusive scan, 1.0 where slot el adds the partial sum of slot el - d (no run head in (el - d, el]), else 0.0; `last`: the slot closes
+// its run (its lane holds the run's sum after the scan).  Fixed order of additions: bit-reproducible, unlike the reference's atomics.
+struct IsScan {
+    float m[4];
+    bool last;
+    int row;
+};
+template <int CTRL>
+__device__ __forceinline__ int is_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL>
+__device__ __forceinline__ float is_dpp_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true)); }
+__device__ __forceinline__ IsScan is_scan_setup(int rid, int el) {
+    IsScan sc;
+    sc.row = rid;
+    const int prev = is_dpp_i<0x111>(rid), next = is_dpp_i<0x101>(rid);          // row_shr:1 / row_shl:1 (0 beyond the row's ends)
+    int f = (el == 0 || prev != rid) ? 1 : 0;                                     // run head
+    sc.last = el == 15 || next != rid;
+    sc.m[0] = f ? 0.f : 1.f;
+    int f1 = f | (el < 1 ? 1 : is_dpp_i<0x111>(f));
+    sc.m[1] = f1 ? 0.f : 1.f;
+    int f2 = f1 | (el < 2 ? 1 : is_dpp_i<0x112>(f1));
+    sc.m[2] = f2 ? 0.f : 1.f;
+    int f4 = f2 | (el < 4 ? 1 : is_dpp_i<0x114>(f2));
+    sc.m[3] = f4 ? 0.f : 1.f;
+    return sc;
+}
+__device__ __forceinline__ float is_seg_scan(float x, const IsScan& sc) {
+    x = fmaf(sc.m[0], is_dpp_f<0x111>(x), x);
+    x = fmaf(sc.m[1], is_dpp_f<0x112>(x), x);
+    x = fmaf(sc.m[2], is_dpp_f<0x114>(x), x);
+    x = fmaf(sc.m[3], is_dpp_f<0x118>(x), x);
+    return x;
+}
 
 #define SEG_UNROTATE 1
 
@@ -62,12 +100,16 @@ __device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* l
 // un-rotate (optional) + planar store of one segment, rows split over the four waves; D blocks staged in `dst` (see kernel)
 template <int LK>
 __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __restrict__ tile, const float* __restrict__ dstage, int mul_k,
-                                            int out_off, int out_mulp, int flags, int64_t e, bool valid, int wave, int lane) {
+                                            int out_off, int out_mulp, int flags, int64_t e, bool valid_in, int wave, int lane, const IsScan& sc) {
+    bool valid = valid_in;
     constexpr int NCO = 2 * LK + 1;
     const int g = lane >> 4, el = lane & 15;
     const int rowstride = NCO * 16 + 4;
     const float* __restrict__ tl = tile + el;
-    float* __restrict__ ob = A.out + e * A.ostride + out_off;
+    // fused scatter: the output row is the run's row, written by the slot that closes the run after the segmented scan over the 16 slots
+    const bool red = A.run_id != nullptr;
+    if (red) valid = sc.last && sc.row >= 0;
+    float* __restrict__ ob = A.out + (red ? (int64_t)(sc.row >= 0 ? sc.row : 0) : e) * A.ostride + out_off;
     const int wend = mul_k + ((flags >> 8) & 0xff);            // + channel-padding slots of the planar block (last chunk only)
     // work unit = (output component a, 16 consecutive channels): one wave writes 64 contiguous bytes per edge and component in four
     // back-to-back stores, so the memory side sees whole sectors (interleaving the channels of one component over the waves
@@ -94,6 +136,10 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
                 for (int m = 0; m < NCO; ++m) acc[k] = fmaf(dc[m], tw[m * 16], acc[k]);
                 acc[k] = w + k < mul_k ? acc[k] : 0.f;
             }
+            if (red) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = is_seg_scan(acc[k], sc);
+            }
             if (valid) *reinterpret_cast<f32x4*>(ob + a * out_mulp + w) = acc;
         }
     } else {
@@ -104,6 +150,10 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
             f32x4 acc;
 #pragma unroll
             for (int k = 0; k < 4; ++k) acc[k] = w + k < mul_k ? tl[(w + k) * rowstride + a * 16] : 0.f;
+            if (red) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] = is_seg_scan(acc[k], sc);
+            }
             if (valid) *reinterpret_cast<f32x4*>(ob + a * out_mulp + w) = acc;
         }
     }

@@ -297,8 +297,15 @@ class HamGNNConvE3(_BackboneBase):
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             skip = conv.skip_linear(node)
-            msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab)          # global frame (un-rotated in the epilogue)
-            agg = ops.segment_sum(msg, rowptr, perm, N)
+            if conv.conv_tp.can_reduce(geo.E):
+                # convolution.py:147-149 fused into the edge kernel: receiver-major tiles, the runs of equal receivers summed in the epilogue
+                # (about E / 13 rows instead of the [E, Dp] message tensor), then a segmented sum over each atom's contiguous rows
+                eperm, run_id, R, prow, ident = topo.receiver_major()
+                part = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab, reduce=(eperm, run_id, R))
+                agg = ops.segment_sum(part, prow, ident, N)
+            else:
+                msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab)      # global frame (un-rotated in the epilogue)
+                agg = ops.segment_sum(msg, rowptr, perm, N)
             parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
             if tape is not None:
                 tape.append(dict(node_in=node, f_in=f, agg=agg))

@@ -483,7 +483,11 @@ class MessagePackBlock(nn.Module):
         he = ops.radial_hidden_cached(geo, self._he, cst) if self._he is not None else None
         return ops.tp_fused(self._dp_for(geo.E), [xs_rot, xd_rot, f_rot], geo.E, hn, he, geo, tag="message_pack")
 
-    def run_nodes(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab):
+    def can_reduce(self, rows: int) -> bool:
+        """the fused node scatter is a feature of the single-part input-stationary launch (large graphs)"""
+        return self._dp.sched is not None and self._dp_for(rows).is_parts_for(rows) == 1 and os.environ.get("HG_FUSED_SCATTER", "1") != "0"
+
+    def run_nodes(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, reduce=None):
         """node_s / node_d: planar NODE rows (global frame) whose sender / receiver gathers feed the block
         (convolution.py:138-141, interaction_blocks.py:141-145).  Input-stationary schedule: gathered and rotated inside the kernel;
         otherwise through hg_rotate_gather."""
@@ -494,7 +498,7 @@ class MessagePackBlock(nn.Module):
         hn = ops.radial_hidden_cached(geo, self._hn, cst)
         he = ops.radial_hidden_cached(geo, self._he, cst) if self._he is not None else None
         return ops.tp_fused(self._dp_for(geo.E), [node_s, node_d, f_rot], geo.E, hn, he, geo, tag="message_pack", gather=[geo.src, geo.dst, None],
-                            rot_mask=0b011)
+                            rot_mask=0b011, reduce=reduce)
 
 
 class ResidualBlock(nn.Module):

@@ -292,17 +292,20 @@ PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, rows, 
 @_on_tensor_device
 def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h2e=None, geo: Optional[Geometry] = None,
              tag: str = "linear", gather: Optional[List[Optional[torch.Tensor]]] = None, rot_mask: int = 0,
-             res: Sequence[Optional[torch.Tensor]] = ()) -> torch.Tensor:
+             res: Sequence[Optional[torch.Tensor]] = (), reduce=None) -> torch.Tensor:
     """gather / rot_mask (input-stationary schedule only): srcs[i] holds global-frame node rows, gathered by gather[i] and rotated
     into the edge frame inside the kernel (bit i of rot_mask) instead of a separate hg_rotate_gather pass.
-    res: up to two residual row tensors in the output's planar layout, added in the epilogue (segment-stationary programs)."""
+    res: up to two residual row tensors in the output's planar layout, added in the epilogue (segment-stationary programs).
+    reduce = (eperm, run_id, R) of topo.Topology.receiver_major(): the launch walks the rows in the order eperm and writes the R run sums
+    instead of one row per edge (the fused node scatter; input-stationary single-part launches only)."""
     _require_gpu(srcs[0])
     assert (gather is None and rot_mask == 0) or dp.sched is not None
     res = [r for r in res if r is not None]
     assert len(res) <= 2 and (not res or dp.sched is None)
     for r in res:
         assert r.shape == (rows, dp.out_dim) and r.stride(1) == 1
-    out = torch.empty(rows, dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
+    assert reduce is None or (dp.sched is not None and dp.is_parts_for(rows) == 1)
+    out = torch.empty(rows if reduce is None else reduce[2], dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
     ss = (C.c_int64 * 4)(*([int(s.stride(0)) for s in srcs] + [0] * (4 - n)))
@@ -317,7 +320,8 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.is_weights(dp.is_parts_for(rows))), ptr(t_segs),
                              ptr(t_blocks), ptr(t_phases), ptr(t_groups), ptr(t_items), ptr(t_parts),
                              sc.part_table.ctypes.data_as(C.c_void_p), i32(sc.part_table.shape[0]), ptr(t_rowtab),
-                             i32(sc.lds_floats * 4), gp, i32(rot_mask), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
+                             i32(sc.lds_floats * 4), gp, i32(rot_mask), ptr(reduce[0]) if reduce is not None else C.c_void_p(0),
+                             ptr(reduce[1]) if reduce is not None else C.c_void_p(0), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
     else:
         check(lib().hg_tp_fused(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.weights), ptr(dp.segs),
                                 i32(dp.nseg), ptr(dp.items), ptr(out), i64(dp.out_dim), i64(rows), i32(dp.lds_bytes), i32(dp.flags),

@@ -73,6 +73,28 @@ class Topology:
             self._csr = (rowptr.contiguous(), perm)
         return self._csr
 
+    def receiver_major(self):
+        """The fused node scatter of the input-stationary edge kernel (csrc/tp_stage.h:is_seg_scan): the launch walks the edges in RECEIVER-major
+        order (`eperm`: tile slot -> edge, the stable receiver sort of receiver_csr), every run of equal receivers inside a 16-slot tile is summed
+        in the kernel's epilogue and written as ONE row.  Returns (eperm int64 [E], run_id int32 [E]: slot -> output row, R = number of rows,
+        rowptr int64 [N + 1]: the rows of node n are rowptr[n] .. rowptr[n + 1] - 1 -- contiguous, so the second stage is a plain segmented sum
+        over about E / 13 rows instead of E (a-SiO2 10k: 82 incoming edges per atom)."""
+        if getattr(self, "_rmaj", None) is None:
+            rowptr, perm = self.receiver_csr()
+            E = int(perm.shape[0])
+            recv = self.edge_index[1][perm]
+            slot = torch.arange(E, device=perm.device)
+            head = torch.ones(E, dtype=torch.bool, device=perm.device)
+            if E > 1:
+                head[1:] = (recv[1:] != recv[:-1]) | (slot[1:] % 16 == 0)
+            run_id = (torch.cumsum(head.to(torch.int64), 0) - 1)
+            R = int(run_id[-1].item()) + 1 if E else 0
+            runs_of = torch.bincount(recv[head], minlength=self.N) if E else torch.zeros(self.N, dtype=torch.int64, device=perm.device)
+            prow = torch.zeros(self.N + 1, dtype=torch.int64, device=perm.device)
+            prow[1:] = torch.cumsum(runs_of, 0)
+            self._rmaj = (perm, run_id.to(torch.int32).contiguous(), R, prow.contiguous(), torch.arange(R, dtype=torch.int64, device=perm.device))
+        return self._rmaj
+
     def sender_csr(self):
         """edges grouped by their SENDER (edge_index[0]): the scatter of the backward pass (gradient of the gathered sender rows)"""
         if getattr(self, "_csr_s", None) is None:

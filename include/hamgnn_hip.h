@@ -118,7 +118,8 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
              int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
              const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table, const int32_t* item_table,
              const int32_t* part_table, const int32_t* part_table_host, int nparts, const int32_t* row_table, int lds_bytes,
-             const int64_t* const* src_idx, int rot_mask, float* out, int64_t out_stride, int64_t rows, void* stream);
+             const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
+             int64_t rows, void* stream);
 
 /* Fused WEIGHT gradients of the weighted tensor-product branches of a MessagePackBlock (csrc/tp_wgrad.hip): what torch.autograd computes
  * for o3.TensorProduct.weight, LinearScaleWithWeights.linear_out.weight and the trailing o3.Linear of

@@ -103,7 +103,7 @@ def _rotate_blocks(x, D, lmax, blocks, slot):
     return out
 
 
-def tp_fused(dp, srcs, rows, h2n=None, h2e=None, geo=None, tag="linear", gather=None, rot_mask=0, res=()):
+def tp_fused(dp, srcs, rows, h2n=None, h2e=None, geo=None, tag="linear", gather=None, rot_mask=0, res=(), reduce=None):
     D = geo.D if geo is not None else None
     lmax = geo.lmax if geo is not None else None
     if dp.sched is not None:
@@ -121,6 +121,11 @@ def tp_fused(dp, srcs, rows, h2n=None, h2e=None, geo=None, tag="linear", gather=
     for r in res:
         if r is not None:
             out = out + _np(r)
+    if reduce is not None:                                     # the fused node scatter: run sums in slot order, added left to right as the kernel's scan does
+        eperm, run_id, R = _np(reduce[0]).astype(np.int64), _np(reduce[1]).astype(np.int64), int(reduce[2])
+        part = np.zeros((R, out.shape[1]), out.dtype)
+        np.add.at(part, run_id, out[eperm])
+        out = part
     return _t(out)
 
 

@@ -634,6 +634,39 @@ def check_front_door(device="cuda", tmpdir="/tmp/hg_front_door"):
     return out
 
 
+
+def check_fused_scatter(device="cuda", n_atoms=14, seed=5):
+    """the node scatter fused into the edge kernel's epilogue (receiver-major tiles + segmented scan over the 16 slots + a segmented sum over the
+    run rows; topo.Topology.receiver_major, csrc/tp_stage.h:is_seg_scan) against the unfused path (message rows + hg_segment_sum) on the same
+    model and crystal, single-part launches forced; also a ragged tail (E not a multiple of 16) and receivers whose runs straddle tiles"""
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    cfg = dict(num_types=96, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False)
+    torch.manual_seed(seed)
+    m = HamGNNConvE3(cfg)
+    g = S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004).to(device)
+    out = {}
+    os.environ["HG_IS_PARTS"] = "1"
+    try:
+        reps = {}
+        for flag in ("0", "1"):
+            os.environ["HG_FUSED_SCATTER"] = flag
+            with torch.no_grad():
+                reps[flag] = m(g)
+        if device != "cpu":
+            torch.cuda.synchronize()
+    finally:
+        os.environ.pop("HG_IS_PARTS", None)
+        os.environ.pop("HG_FUSED_SCATTER", None)
+    from hamgnn_amd.topo import Topology
+    out["node_rel_err"] = rel(reps["1"]["node_attr"], reps["0"]["node_attr"])
+    out["edge_rel_err"] = rel(reps["1"]["edge_attr"], reps["0"]["edge_attr"])
+    out["edges_mod_16"] = float(int(g.num_edges) % 16 == 0) * 1e-9
+    return out
+
+
 def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):
     """backward of ResidualBlock (x + Lin2(Gate(Lin1(x)))): data gradient (hg_linear_planar on transposed blocks,
     hg_gate_backward) and the two Linear weight gradients (one GEMM per path) vs torch.autograd through the fp64 oracle"""

@@ -87,6 +87,7 @@ _FORWARD_CASES = {
     "head_overlap_networks": lambda: G.check_head_overlap("cpu"),
     "conv_message_chain_backward": lambda: G.check_conv_message_backward("cpu", n_atoms=4),
     "front_door": lambda: G.check_front_door("cpu", tmpdir="/tmp/hg_front_door_cpu"),
+    "fused_scatter": lambda: G.check_fused_scatter("cpu", n_atoms=5),
 }
 
 

@@ -68,6 +68,12 @@ def test_front_door_checkpoint_and_datasets_reproduce_the_fixtures():
     assert all(v < G.TOL for v in r.values()), r
 
 
+def test_fused_node_scatter_equals_message_rows_plus_segment_sum():
+    r = G.check_fused_scatter()
+    print(r)
+    assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6, r
+
+
 def test_corr_product_block_golden():
     r = G.check_corr_product()
     print(r)
