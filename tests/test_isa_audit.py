@@ -54,3 +54,19 @@ def test_row_program_and_readout_register_budgets():
         assert ks, (src, kern)
         for k in ks:
             assert k["meta"]["vgpr_spills"] <= max_spill and k["meta"]["scratch"] <= 8 * max_spill, (k["name"], k["meta"])
+
+
+def test_segment_stationary_kernel_register_budget():
+    """tp_fused_kernel (embedding TP, plain Linear programs, the fallback of the MessagePackBlocks; <true>: lite_mode programs): no scratch"""
+    ks = [k for k in A.audit(os.path.join(CSRC, "tp_fused.hip")) if "tp_fused_kernel" in k["name"]]
+    assert len(ks) == 2
+    for k in ks:
+        assert k["meta"]["vgpr_spills"] == 0 and k["meta"]["scratch"] == 0 and k["meta"]["vgprs"] <= 256, (k["name"], k["meta"])
+
+
+@pytest.mark.skipif(os.environ.get("HG_SLOW_TESTS") != "1", reason="tp_wgrad.hip has 62 instantiations: ~100 s of compile time (HG_SLOW_TESTS=1)")
+def test_weight_gradient_kernel_register_budget():
+    ks = [k for k in A.audit(os.path.join(CSRC, "tp_wgrad.hip")) if "tp_wgrad_kernel" in k["name"]]
+    assert ks
+    worst = max(k["meta"]["scratch"] for k in ks)
+    assert worst <= 124, worst                                # r3: the 13-column instantiation spills 124 B / lane, the NC = 1 ones 2 VGPRs
