@@ -487,43 +487,41 @@ __device__ __forceinline__ void item_lite_m(const IsArgs& A, const float* __rest
     }
 }
 
-// lite_mode RUN (plan._lite_runs): all folded items of one (phase, output segment, row chunk) as ONE stream of steps ordered by tile column.
-// step t: RTM weight fragments at stream + t * RTM * 256 and a descriptor {B operand base / 64 | K-steps - 1 << 10 | first << 12 | last << 13 |
-// tile column << 16}; fragments AND descriptors of step t + RL_RING are requested at step t -- across what used to be item boundaries -- and
-// a column's accumulators persist across the items that feed it (one tile read-modify-write per column and run).
+// lite_mode RUN (plan._lite_runs): all folded items of one (phase, output segment, row chunk) as ONE stream of steps ordered by tile column (pair).
+// step t: RTM weight fragments at stream + t * RTM * 256 and a two-word descriptor
+//   d0 = B operand base / 64 | K-steps - 1 << 10 | first << 12 | last << 13 | tile column << 16
+//   d1 = 0 | for a PAIRED step: second B operand base / 64 | 1 << 14 | negate << 15 | second tile column << 16
+// Columns +m and -m of a folded (input irrep, output irrep) pair share their weight matrix up to a sign: a paired step issues the MFMAs of
+// BOTH columns on one fragment group (8 RTM MFMAs per weight request), the sign rides on the second B operand.  Fragments AND descriptors of
+// step t + RL_RING are requested at step t -- across what used to be item boundaries -- and a column's accumulators persist across the items
+// that feed it (one tile read-modify-write per column and run).
 #ifndef RL_RING
 #define RL_RING 6
 #endif
 template <int RTM>
 __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
+    // request ring: RL_RING steps for one or two row tiles, 3 for three or four (a step then carries 12-32 MFMAs; 96 ring registers spilled)
+    constexpr int RING = RTM >= 3 ? RL_RING / 2 : RL_RING;
     const int g = lane >> 4, el = lane & 15;
     const int nsteps = it[8], lk = it[20];                     // nsteps: a multiple of RL_RING (no-op steps at the end), RL_RING more slots behind
     const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23] + it[16];
     float* __restrict__ tbase = lds + A.tile_shift + (el - lk * 16);
     const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t, row tile rt: aw[(t * RTM + rt) * 64]
-#ifndef HG_RL_VDESC
     const int* __restrict__ dsc = reinterpret_cast<const int*>(Wb + it[12]);       // uniform address: the compiler makes these scalar loads
-#else
-    // A/B hook (r3): descriptors through the VECTOR memory path, RL_RING steps ahead like the fragments (an opaque zero makes the address
-    // formally divergent) instead of scalar loads issued at the end of an iteration and waited for at its head; measured SLOWER
-    // (5.41 vs 5.15 ms per 131 072 edges: one more vector-memory instruction per step), off
-    int lane0;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(lane0));
-    const int* __restrict__ dsc = reinterpret_cast<const int*>(Wb + it[12]) + lane0;
-#endif
     int roff[RTM][4];
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) roff[rt][r] = rtab[16 * rt + 4 * g + r];
-    f32x4 ring[RL_RING][RTM], acc[RTM], acc2[RTM];
-    int dring[RL_RING];
+    f32x4 ring[RING][RTM], acc[RTM], acc2[RTM];             // acc2: the second column of a paired step / the odd K-steps of a single column
+    int dring[RING], ering[RING];
 #pragma unroll
-    for (int j = 0; j < RL_RING; ++j) {
+    for (int j = 0; j < RING; ++j) {
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
-        dring[j] = dsc[j];
+        dring[j] = dsc[2 * j];
+        ering[j] = dsc[2 * j + 1];
         // slot order = request order: the scheduler issued these back to front, and the wait at the loop head -- one static instruction
         // for both the first and the later iterations -- became vmcnt(0)
         __builtin_amdgcn_sched_barrier(0);
@@ -531,65 +529,106 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // the B operands of step t + 1 are requested from LDS BEFORE the MFMAs of step t are issued (a wave issues in order: a read placed after
-    // a dependent MFMA chain waits for it); K-steps alternate between two accumulators (no back-to-back dependent MFMAs for RTM = 1)
-    float bn[4];
+    // a dependent MFMA chain waits for it).  The second operand is read for every step (unpaired: d1 = 0 -> the block at offset 0, unused)
+    float bn[4], bnb[4];
     {
-        const int d0 = __builtin_amdgcn_readfirstlane(dring[0]);
+        const int d0 = __builtin_amdgcn_readfirstlane(dring[0]), e0 = __builtin_amdgcn_readfirstlane(ering[0]);
         const float* __restrict__ fb = stage + (d0 & 1023) * 64;
+        const float* __restrict__ fc = stage + (e0 & 1023) * 64;
         const int nq = ((d0 >> 10) & 3) + 1;
+        const int sgn = (e0 << 16) & 0x80000000;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bn[q] = fb[(q < nq ? q : nq - 1) * 64];
+        for (int q = 0; q < 4; ++q) {
+            bn[q] = fb[(q < nq ? q : nq - 1) * 64];
+            bnb[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, fc[(q < nq ? q : nq - 1) * 64]) ^ sgn);
+        }
     }
 #pragma unroll 1
-    for (int t0 = 0; t0 < nsteps; t0 += RL_RING) {
+    for (int t0 = 0; t0 < nsteps; t0 += RING) {
 #pragma unroll
-        for (int j = 0; j < RL_RING; ++j) {
+        for (int j = 0; j < RING; ++j) {
             const int t = t0 + j;
             f32x4 av[RTM];
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
-            const int d = __builtin_amdgcn_readfirstlane(dring[j]);
-            dring[j] = dsc[t + RL_RING];
-            float b[4];
+            const int d = __builtin_amdgcn_readfirstlane(dring[j]), e1 = __builtin_amdgcn_readfirstlane(ering[j]);
+            dring[j] = dsc[2 * (t + RING)];
+            ering[j] = dsc[2 * (t + RING) + 1];
+            float b[4], bb[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b[q] = bn[q];
-            {                                                  // operands of the next step (slot j + 1 holds step t + 1; after the wrap: the slot refilled above)
-                const int dn = __builtin_amdgcn_readfirstlane(dring[(j + 1) % RL_RING]);
-                const float* __restrict__ fb = stage + (dn & 1023) * 64;
-                const int nq = ((dn >> 10) & 3) + 1;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bn[q] = fb[(q < nq ? q : nq - 1) * 64];
+            for (int q = 0; q < 4; ++q) {
+                b[q] = bn[q];
+                bb[q] = bnb[q];
             }
+            {                                                  // operands of the next step (slot j + 1 holds step t + 1; after the wrap: the slot refilled above)
+                const int dn = __builtin_amdgcn_readfirstlane(dring[(j + 1) % RING]), en = __builtin_amdgcn_readfirstlane(ering[(j + 1) % RING]);
+                const float* __restrict__ fb = stage + (dn & 1023) * 64;
+                const float* __restrict__ fc = stage + (en & 1023) * 64;
+                const int nq = ((dn >> 10) & 3) + 1;
+                const int sgn = (en << 16) & 0x80000000;
 #pragma unroll
-            for (int q = 0; q < 4; q += 2)
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) {
-                    acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
-                    acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q + 1], b[q + 1], acc2[rt], 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    bn[q] = fb[(q < nq ? q : nq - 1) * 64];
+                    bnb[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, fc[(q < nq ? q : nq - 1) * 64]) ^ sgn);
                 }
-            if (d & (1 << 13)) {                               // column complete: add into the tile
+            }
+            if (e1 & (1 << 14)) {                              // paired: both columns on this fragment group, two independent accumulator chains
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) {
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
+                        acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bb[q], acc2[rt], 0, 0, 0);
+                    }
+            } else {                                           // single column: K-steps alternate between the two chains (no back-to-back dependent MFMAs for RTM = 1)
+#pragma unroll
+                for (int q = 0; q < 4; q += 2)
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) {
+                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
+                        acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q + 1], b[q + 1], acc2[rt], 0, 0, 0);
+                    }
+            }
+            if (d & (1 << 13)) {                               // column (pair) complete: add into the tile
                 const int tc = (d >> 16) & 31;
-                float told[RTM][4];                            // all reads, then all writes (see item_lite)
+                if (e1 & (1 << 14)) {
+                    const int tcb = (e1 >> 16) & 31;
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt)
+                    for (int half = 0; half < 2; ++half) {     // one column at a time (register budget): all its reads, then all its writes
+                        const int col = half ? tcb : tc;
+                        float told[RTM][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + tc * 16];
+                        for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) {
-                    const f32x4 sum = acc[rt] + acc2[rt];
+                            for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + col * 16];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] = told[rt][r] + sum[r];
-                    acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // the next step starts a column
+                        for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + col * 16] = told[rt][r] + (half ? acc2[rt][r] : acc[rt][r]);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {
+                    float told[RTM][4];
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + tc * 16];
+#pragma unroll
+                    for (int rt = 0; rt < RTM; ++rt) {
+                        const f32x4 sum = acc[rt] + acc2[rt];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] = told[rt][r] + sum[r];
+                        acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // the next step starts a column
+                    }
                 }
             }
             // the fragment requests of step t + RL_RING: NO branch around them (streams are padded: plan._lite_runs), and issued AFTER the
             // step's MFMAs have read slot j -- requested before them, the new value cannot share the slot's registers, the compiler rotates
             // the whole ring with v_mov at the loop's back-edge and has to wait for EVERY outstanding load there (vmcnt(0) once per RL_RING
             // steps; ISA audit, profiles/r03_lite.md)
-#ifndef HG_ABL_RL_NOW
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RL_RING) * RTM + rt) * 64];
-#endif
+            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RING) * RTM + rt) * 64];
         }
     }
 }

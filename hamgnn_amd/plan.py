@@ -363,13 +363,19 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
 
 def _lite_runs(prog: "Program", recs, runs: dict):
     """lite_mode, input-stationary schedule: the IT_LINM items of one (phase, output segment) -- `recs`, stage offsets already in [1], [2] --
-    regrouped into RUNS (one per row chunk of the segment): a run is a linear stream of STEPS ordered by tile column, every step = one
-    fragment group (rtm x 64 x 4 weights) + a descriptor {B operand base / 64 floats into the staging area | K-steps - 1 << 10 | first step
-    of the column << 12 | last << 13 | tile column << 16}; the accumulators of a column persist across the items that feed it (one tile
-    read-modify-write per column and run instead of one per item and column), the fragments and descriptors of step t + ring are requested at
-    step t -- across what used to be item boundaries (csrc/tp_is.hip:run_lite).  Streams are appended to runs["w"] (floats; the descriptors
-    as int32 bit patterns); returns the runs as item records of type IT_RUN."""
+    regrouped into RUNS (one per row chunk of the segment): a run is a linear stream of STEPS, every step = one fragment group (rtm x 64 x 4
+    weights) + a descriptor of two words:
+        d0 = B operand base / 64 floats into the staging area | K-steps - 1 << 10 | first step of the column group << 12 | last << 13 | tile column << 16
+        d1 = 0, or for a PAIRED step: B operand base of the second column | 1 << 14 | negate << 15 | its tile column << 16
+    Columns +m and -m of an (input irrep, output irrep) pair carry the SAME folded weight matrix up to a sign (every path of the pair has the
+    parity of l_i + l_sh + l_k, so its aligned-frame coefficient is even or odd in m): a paired step feeds both columns from one fragment group
+    (8 rtm MFMAs per weight request instead of 4 rtm, about half the steps and weight bytes of r3), the sign rides on the second B operand; the
+    centre column of an odd pair is identically zero and is not issued at all.  The accumulators of a column (pair) persist across the items
+    that feed it (one tile read-modify-write per column and run), the fragments and descriptors of step t + ring are requested at step t --
+    across what used to be item boundaries (csrc/tp_is.hip:run_lite).  Streams are appended to runs["w"] (floats; the descriptors as int32 bit
+    patterns); returns the runs as item records of type IT_RUN."""
     Wt = prog.weights
+    pairing = os.environ.get("HG_LITE_PAIR", "1") != "0"
     by_chunk: Dict[Tuple[int, int], list] = {}
     for r in recs:
         by_chunk.setdefault((int(r[16]), int(r[9])), []).append(r)
@@ -377,34 +383,76 @@ def _lite_runs(prog: "Program", recs, runs: dict):
     for (row_off, rtm), items in by_chunk.items():
         seg = int(items[0][19])
         lk = int(prog.seg_table[seg][0])
+
+        def item_steps(r, m):
+            """steps of item r for output column m: (weights, B base / 64, K-steps) per (source, K group); None if the column is not fed"""
+            so0, so1, in_mulp, li, mm, neg, ksteps, a1, colstride = int(r[1]), int(r[2]), int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[11]), int(r[13])
+            if abs(m) > mm:
+                return None
+            c = m + mm
+            nsrc, ngrp, P1 = (2 if so1 >= 0 else 1), ceil_div(ksteps, 4), in_mulp // 4
+            cdir = -P1 if neg else P1
+            c0p = (li - mm) * P1 + ((2 * mm) * P1 if neg else 0)
+            st = []
+            for si in range(nsrc):
+                for G in range(ngrp):
+                    base = (so1 if si else so0) + (c0p + c * cdir + 4 * G) * 64
+                    assert base % 64 == 0 and 0 <= base // 64 < 1024
+                    woff = a1 + c * colstride + (si * ngrp + G) * rtm * 256
+                    st.append((Wt[woff:woff + rtm * 256], base // 64, min(4, ksteps - 4 * G)))
+            return st
+
         frags, desc = [], []
-        for tc in range(2 * lk + 1):
-            m = tc - lk
-            steps = []
-            for r in items:
-                so0, so1, in_mulp, li, mm, neg, ksteps, a1, colstride = int(r[1]), int(r[2]), int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[11]), int(r[13])
-                if abs(m) > mm:
-                    continue
-                c = m + mm
-                nsrc, ngrp, P1 = (2 if so1 >= 0 else 1), ceil_div(ksteps, 4), in_mulp // 4
-                cdir = -P1 if neg else P1
-                c0p = (li - mm) * P1 + ((2 * mm) * P1 if neg else 0)
-                for si in range(nsrc):
-                    for G in range(ngrp):
-                        base = (so1 if si else so0) + (c0p + c * cdir + 4 * G) * 64
-                        assert base % 64 == 0 and 0 <= base // 64 < 1024
-                        woff = a1 + c * colstride + (si * ngrp + G) * rtm * 256
-                        steps.append((Wt[woff:woff + rtm * 256], base // 64, min(4, ksteps - 4 * G)))
-            for n_, (w, b64, nq) in enumerate(steps):
+
+        def emit(steps):                                       # steps: (weights, d0 without first / last, d1)
+            for n_, (w, d0, d1) in enumerate(steps):
                 frags.append(w)
-                desc.append(b64 | ((nq - 1) << 10) | ((1 if n_ == 0 else 0) << 12) | ((1 if n_ == len(steps) - 1 else 0) << 13) | (tc << 16))
+                desc.append(d0 | ((1 if n_ == 0 else 0) << 12) | ((1 if n_ == len(steps) - 1 else 0) << 13))
+                desc.append(d1)
+
+        for m in range(0, lk + 1):
+            cols = {}
+            for sign_m in ((m,) if m == 0 else (m, -m)):
+                cols[sign_m] = [item_steps(r, sign_m) for r in items]
+            paired = pairing and m > 0
+            signs = []
+            if paired:                                         # W(-m) == +-W(m) for every item (always true for folded lite items; checked, not assumed)
+                for sa, sb in zip(cols[m], cols[-m]):
+                    if sa is None:
+                        signs.append(0)
+                        continue
+                    wa, wb = np.concatenate([x[0] for x in sa]), np.concatenate([x[0] for x in sb])
+                    if np.array_equal(wa, wb):
+                        signs.append(1)
+                    elif np.array_equal(wa, -wb):
+                        signs.append(-1)
+                    else:
+                        paired = False
+                        break
+            if paired:
+                steps = []
+                for sa, sb, sg_ in zip(cols[m], cols[-m], signs):
+                    if sa is None or not any(np.any(x[0]) for x in sa):
+                        continue
+                    for (w, ba, nq), (_, bb, _) in zip(sa, sb):
+                        steps.append((w, ba | ((nq - 1) << 10) | ((lk + m) << 16), bb | (1 << 14) | ((1 if sg_ < 0 else 0) << 15) | ((lk - m) << 16)))
+                emit(steps)
+            else:
+                for mm_ in cols:
+                    steps = []
+                    for sa in cols[mm_]:
+                        if sa is None or not any(np.any(x[0]) for x in sa):      # (the centre column of an odd pair: all-zero weights)
+                            continue
+                        steps += [(w, ba | ((nq - 1) << 10) | ((lk + mm_) << 16), 0) for (w, ba, nq) in sa]
+                    emit(steps)
         # the kernel's request ring runs LITE_RING steps ahead WITHOUT a branch around the loads (a conditional load makes the compiler wait for
         # every outstanding one at the join: vmcnt(0) per step): steps padded to a multiple of the ring with no-ops (zero weights, no column
         # boundary), LITE_RING more slots behind the last step for the requests that run past it
-        npad = (-len(desc)) % LITE_RING
-        nreal = len(desc) + npad
+        nst = len(desc) // 2
+        npad = (-nst) % LITE_RING
+        nreal = nst + npad
         frags += [np.zeros(rtm * 256)] * (npad + LITE_RING)
-        desc += [0] * (npad + LITE_RING)
+        desc += [0, 0] * (npad + LITE_RING)
         w_off = runs["base"] + sum(x.size for x in runs["w"])
         wblob = np.concatenate(frags).astype(np.float64)
         dblob = np.asarray(desc, dtype=np.int32).view(np.float32).astype(np.float64)       # bit patterns ride in the float blob (exact: float32 -> float64 -> float32)

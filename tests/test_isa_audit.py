@@ -30,10 +30,11 @@ def test_tp_is_register_budget_and_no_scratch(tp_is):
 def test_lite_run_loop_keeps_its_ring_lookahead(tp_is):
     lite = [k for k in tp_is if "tp_is_kernel" in k["name"] and "ELb1EEv" in k["name"] and "ILb0ELb1" in k["name"]]
     assert len(lite) == 1
-    steps = [(lab, s) for lab, _, s, _ in lite[0]["blocks"]     # a step of run_lite<RTM>: 4 RTM MFMAs, RTM fragment requests, 4 + write-back LDS reads
-             if s.count("M") in (4, 8, 12, 16) and 1 <= s.count("G") <= 4 and s.count("r") >= 8 and "S" not in s.replace("[", "")[:0]]
-    steps = [(lab, s) for lab, s in steps if s.count("G") * 4 == s.count("M")]
-    assert len(steps) >= 20, len(steps)                         # 6 unrolled steps x 4 row-tile counts
+    # a PAIRED step of run_lite<RTM> (r4: columns +m and -m on one fragment group): 8 RTM MFMAs, RTM fragment requests, 8 operand reads from LDS
+    steps = [(lab, s) for lab, _, s, _ in lite[0]["blocks"]
+             if s.count("M") in (8, 16, 24, 32) and 1 <= s.count("G") <= 4 and s.count("r") >= 8]
+    steps = [(lab, s) for lab, s in steps if s.count("G") * 8 == s.count("M")]
+    assert len(steps) >= 12, len(steps)                         # 6 / 3 unrolled steps x 4 row-tile counts
     for lab, s in steps:
         assert not re.search(r"\[v\(0\)", s), (lab, s)          # every fragment wait leaves younger requests in flight
     # the tile read-modify-write of a finished column: all reads, then all writes (was read -> wait -> write per element)
