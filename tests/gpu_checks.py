@@ -1754,6 +1754,99 @@ def check_band_cal(device="cuda"):
     return {"bands_rel_err": worst, "gap_abs_err_eV": max(gaps), "crystals": len(res)}
 
 
+
+def check_band_cal_spin(device="cuda"):
+    """hamgnn_amd.band_cal.band_structure, the spin-orbit (`soc_switch`, band_cal.py:101-283) and collinear (`spin_colinear`, :284-452) branches,
+    on the crystals of the SOC k-space fixture: bands along the path == dense numpy restatements of the script's own loops (four spin blocks
+    of H(k) + kron(1_2, S(k)), singly occupied bands; resp. one spin-free calculation per spin channel), rows given as a file and as targets"""
+    import scipy.linalg
+    from hamgnn_amd import band_cal
+    from hamgnn_amd.data import Graph
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load("band_energies_soc_openmx_13")
+    g = to_graph(f["graph"], "cpu")
+    Hon, Hoff, iHon, iHoff = (torch.from_numpy(f["inputs"][k]).float() for k in ("Hon", "Hoff", "iHon", "iHoff"))
+    nao, nk = 13, 7
+    nodes = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.5, 0.5, 0.0]]
+    ncs = g.node_counts.tolist()
+    ecs = torch.bincount(g.batch[g.edge_index[0]], minlength=len(ncs)).tolist()
+    graphs, rows, n0, e0 = [], [], 0, 0
+    for c, (n, e) in enumerate(zip(ncs, ecs)):
+        gc = Graph({"z": g.z[n0:n0 + n], "pos": g.pos[n0:n0 + n], "cell": g.cell[c:c + 1], "edge_index": g.edge_index[:, e0:e0 + e] - n0,
+                    "nbr_shift": g.nbr_shift[e0:e0 + e], "inv_edge_idx": g.inv_edge_idx[e0:e0 + e], "Son": g.Son[n0:n0 + n], "Soff": g.Soff[e0:e0 + e],
+                    "Hon": Hon[n0:n0 + n], "Hoff": Hoff[e0:e0 + e], "iHon": iHon[n0:n0 + n], "iHoff": iHoff[e0:e0 + e]})
+        graphs.append(gc)
+        rows += [Hon[n0:n0 + n], Hoff[e0:e0 + e], iHon[n0:n0 + n], iHoff[e0:e0 + e]]          # [real rows; imaginary rows] per crystal
+        n0, e0 = n0 + n, e0 + e
+    res = band_cal.band_structure(graphs, torch.cat(rows).numpy(), nao_max=nao, ham_type="openmx", k_path=nodes, nk=nk, device=device, soc_switch=True)
+    res_t = band_cal.band_structure(graphs, None, nao_max=nao, ham_type="openmx", k_path=nodes, nk=nk, device=device, soc_switch=True)
+    head = HamGNNPlusPlusOut("1x0e", "1x0e", nao_max=nao, ham_type="openmx", ham_only=True, soc_switch=False, calculate_sparsity=False)
+    mask = np.zeros((99, nao))
+    for Z, idx in head.basis_def.items():
+        mask[Z][list(idx)] = 1
+
+    def dense_k(gc, on, off, k):
+        """H(k) of the script's loop (phase-factor sums per edge, orbital mask) for spin-free rows on [n, nao, nao], off [e, nao, nao]"""
+        n = int(gc.z.shape[0])
+        om = mask[gc.z.numpy()].reshape(-1)
+        keep = np.outer(om, om) > 0
+        M = np.zeros((n, n, nao, nao), complex)
+        M[np.arange(n), np.arange(n)] = on
+        coe = np.exp(2j * np.pi * (gc.nbr_shift.double().numpy() @ k))
+        for ie in range(gc.edge_index.shape[1]):
+            M[int(gc.edge_index[0, ie]), int(gc.edge_index[1, ie])] += coe[ie] * off[ie]
+        M = M.swapaxes(1, 2).reshape(n * nao, n * nao)[keep]
+        m = int(round(np.sqrt(M.size)))
+        return M.reshape(m, m)
+    out = {}
+    worst, gaps = 0.0, []
+    for gc, r, rt in zip(graphs, res, res_t):
+        lat = gc.cell.double().numpy().reshape(3, 3)
+        k_cart = r["k_vec"] @ np.linalg.inv(lat).T
+        n, e = int(gc.z.shape[0]), int(gc.edge_index.shape[1])
+        Hc_on = (gc.Hon.double().numpy() + 1j * gc.iHon.double().numpy()).reshape(n, 2, nao, 2, nao)
+        Hc_off = (gc.Hoff.double().numpy() + 1j * gc.iHoff.double().numpy()).reshape(e, 2, nao, 2, nao)
+        eig = []
+        for k in k_cart:
+            S = dense_k(gc, gc.Son.double().numpy().reshape(n, nao, nao), gc.Soff.double().numpy().reshape(e, nao, nao), k)
+            blocks = [[dense_k(gc, Hc_on[:, a, :, b, :], Hc_off[:, a, :, b, :], k) for b in (0, 1)] for a in (0, 1)]
+            eig.append(scipy.linalg.eigh(np.block(blocks), np.kron(np.eye(2), S), eigvals_only=True))
+        eig = np.array(eig).T * band_cal.AU2EV
+        nel = sum(head.num_valence[int(Z)] for Z in gc.z.tolist())
+        vbm = eig[nel - 1].max()
+        worst = max(worst, float(np.abs((eig - vbm) - r["bands_eV"]).max() / np.abs(eig).max()), float(np.abs(r["bands_eV"] - rt["bands_eV"]).max()))
+        gaps.append(abs((eig[nel].min() - vbm) - r["band_gap_eV"]))
+    out["soc_bands_rel_err"], out["soc_gap_abs_err_eV"] = worst, max(gaps)
+    # collinear: rows [., spin, nao, nao]; the two channels = the uu and dd blocks of the same fixture's real rows
+    col_graphs, col_rows = [], []
+    for gc in graphs:
+        n, e = int(gc.z.shape[0]), int(gc.edge_index.shape[1])
+        pick = lambda t, rws: torch.stack([t.reshape(rws, 2, nao, 2, nao)[:, 0, :, 0, :], t.reshape(rws, 2, nao, 2, nao)[:, 1, :, 1, :]], 1).reshape(rws, 2 * nao * nao)
+        on2, off2 = pick(gc.Hon, n), pick(gc.Hoff, e)
+        g2 = Graph({k: gc[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "inv_edge_idx", "Son", "Soff")})
+        g2["Hon"], g2["Hoff"] = on2, off2
+        col_graphs.append(g2)
+        col_rows += [on2, off2]
+    rc = band_cal.band_structure(col_graphs, torch.cat(col_rows).numpy(), nao_max=nao, ham_type="openmx", k_path=nodes, nk=nk, device=device, spin_colinear=True)
+    worst = 0.0
+    for gc, r in zip(col_graphs, rc):
+        lat = gc.cell.double().numpy().reshape(3, 3)
+        k_cart = r["k_vec"] @ np.linalg.inv(lat).T
+        n, e = int(gc.z.shape[0]), int(gc.edge_index.shape[1])
+        nel = sum(head.num_valence[int(Z)] for Z in gc.z.tolist())
+        half = int(np.ceil(nel / 2))
+        for ispin in range(2):
+            on = gc.Hon.double().numpy().reshape(n, 2, nao, nao)[:, ispin]
+            off = gc.Hoff.double().numpy().reshape(e, 2, nao, nao)[:, ispin]
+            eig = np.array([scipy.linalg.eigh(dense_k(gc, on, off, k), dense_k(gc, gc.Son.double().numpy().reshape(n, nao, nao),
+                                                                                gc.Soff.double().numpy().reshape(e, nao, nao), k), eigvals_only=True) for k in k_cart]).T * band_cal.AU2EV
+            vbm = eig[half - 1].max()
+            worst = max(worst, float(np.abs((eig - vbm) - r["bands_eV"][ispin]).max() / np.abs(eig).max()),
+                        abs((eig[half].min() - vbm) - r["band_gap_eV"][ispin]) / np.abs(eig).max())
+    out["collinear_bands_rel_err"] = worst
+    return out
+
+
 def check_tp_wgrad_kernel(device="cuda", seed=0, irr=None, sh=None, E=150, nsplit=3):
     """hg_tp_wgrad through the C ABI vs its numpy twin (tests/emu.py:run_wgrad_fused) on the SAME tables and the same random edge-frame rows:
     accumulator blocks (every split / edge-tile copy) and the per-edge gs rows.  The twin itself is checked against autograd through the fp64

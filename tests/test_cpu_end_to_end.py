@@ -153,6 +153,12 @@ def test_band_cal_on_cpu(cpu_backend):
     assert r["bands_rel_err"] < 1e-4 and r["gap_abs_err_eV"] < 1e-2 and r["crystals"] == 2, r
 
 
+def test_band_cal_spin_branches_on_cpu(cpu_backend):
+    """the spin-orbit and collinear branches of DFT_interfaces/openmx/band_cal.py vs dense restatements of the script's loops"""
+    r = G.check_band_cal_spin("cpu")
+    assert r["soc_bands_rel_err"] < 1e-4 and r["soc_gap_abs_err_eV"] < 1e-2 and r["collinear_bands_rel_err"] < 1e-4, r
+
+
 def test_training_loop_on_cpu(cpu_backend):
     """a few optimiser steps of the whole model (training_step -> Adam -> device-side refresh of the packed weights at the next forward):
     the teacher-student loss falls monotonically"""

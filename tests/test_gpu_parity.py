@@ -481,6 +481,13 @@ def test_band_cal_along_a_k_path():
     assert r["bands_rel_err"] < 1e-4 and r["gap_abs_err_eV"] < 1e-2 and r["crystals"] == 2
 
 
+def test_band_cal_spin_orbit_and_collinear_branches():
+    """the `soc_switch` (band_cal.py:101-283) and `spin_colinear` (:284-452) branches of the post-processing script vs dense fp64 restatements of its loops"""
+    r = G.check_band_cal_spin()
+    print(r)
+    assert r["soc_bands_rel_err"] < 1e-4 and r["soc_gap_abs_err_eV"] < 1e-2 and r["collinear_bands_rel_err"] < 1e-4, r
+
+
 def test_attribute_style_graph_object():
     """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
     r = G.check_attribute_style_graph()
