@@ -177,6 +177,45 @@ def band_energies(head, onsite_hamiltonian, offsite_hamiltonian, data, k_vecs: O
     return torch.cat(energies, 0), torch.cat(waves, 0), torch.cat(gaps, 0), torch.cat(hsyms, 0)
 
 
+def band_energies_export(head, onsite_hamiltonian, offsite_hamiltonian, data, overlap=None, k_vecs: Optional[torch.Tensor] = None):
+    """The `export_reciprocal_values=True` form of the k-space step: calculate_band_energies(..., True) (hamgnn_output.py:1675-1996; `overlap`
+    None) and calculate_band_energies_with_overlap(..., True) (:1368-1673; `overlap` = the PREDICTED (onsite, offsite) overlap rows of the
+    overlap networks).  Returns (band_energy [sum_c bands_c, num_k], wavefunction [C, num_k, bands, M] normalised to <psi|S(k)|psi> = 1,
+    HK [C, num_k, M, M], SK [C, num_k, M, M] (the reference overlap, or the predicted one), dSK [C, num_k, M, M, 3] from data.dSon / dSoff,
+    band_gap [C]).  As in the reference the eigenproblem is always solved with the REFERENCE overlap (:1603), and the per-crystal results are
+    stacked, i.e. every crystal of the batch must have the same number of orbitals."""
+    nao = head.nao_max
+    dev = onsite_hamiltonian.device
+    k_vecs = gget(data, "k_vecs") if k_vecs is None else k_vecs
+    if k_vecs is None:
+        raise ValueError("band_energies_export: no k-vectors (data.k_vecs)")
+    k_vecs = k_vecs.to(dev)
+    z = data.z
+    orank_all = head._orank.to(dev)[z]
+    val = head._num_valence.to(dev)[z].to(torch.float64)
+    Son, Soff = data.Son.contiguous().float(), data.Soff.contiguous().float()
+    dSon, dSoff = data.dSon.float().reshape(Son.shape[0], nao * nao, 3), data.dSoff.float().reshape(Soff.shape[0], nao * nao, 3)
+    energies, waves, gaps, HKs, SKs, dSKs = [], [], [], [], [], []
+    for c, (n0, n, e0, e) in enumerate(_crystal_slices(data)):
+        Hk, M = assemble_k(onsite_hamiltonian, offsite_hamiltonian, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        Sk, _ = assemble_k(Son, Soff, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        Sp = Sk if overlap is None else assemble_k(overlap[0].contiguous().float(), overlap[1].contiguous().float(), data, k_vecs[c], n0, n, e0, e, orank_all, nao)[0]
+        dSk = torch.stack([assemble_k(dSon[..., d].contiguous(), dSoff[..., d].contiguous(), data, k_vecs[c], n0, n, e0, e, orank_all, nao)[0] for d in range(3)], -1)
+        evals, evecs, _, gap = _eig_chain(head, Hk, Sk, val[n0:n0 + n], z[n0:n0 + n])
+        norm = torch.einsum("nai,nij,naj->na", evecs.conj(), Sk, evecs).real
+        evecs = evecs * (1.0 / torch.sqrt(norm)).unsqueeze(-1)
+        energies.append(evals.transpose(-1, -2))
+        waves.append(evecs)
+        gaps.append(gap)
+        HKs.append(Hk)
+        SKs.append(Sp)
+        dSKs.append(dSk)
+    if len({tuple(w.shape) for w in waves}) != 1:
+        raise ValueError("export_reciprocal_values stacks the crystals' H(k) / S(k) / wavefunctions (hamgnn_output.py:1984-1990): every crystal of the "
+                         "batch must have the same number of orbitals and bands")
+    return torch.cat(energies, 0), torch.stack(waves, 0), torch.stack(HKs, 0), torch.stack(SKs, 0), torch.stack(dSKs, 0), torch.cat(gaps, 0)
+
+
 def band_energies_soc(head, real_onsite, imag_onsite, real_offsite, imag_offsite, data, k_vecs: Optional[torch.Tensor] = None):
     """calculate_band_energies_with_spin_orbit_coupling of the reference (hamgnn_output.py:1998-2286): spinor Hamiltonian rows
     [., (2 nao)^2] (real and imaginary part, on-site and off-site) -> (band_energy [sum_c bands_c, num_k], wavefunction (flattened)).

@@ -4,7 +4,7 @@ linear_transform}, ..._ksi_network, ..._overlap_network) and result dict.  In sc
 (:3772-3799) incl. overlap networks, SOC/so3 (:3026-3144), SOC/su2 (:3146-3178; E3TensorDecomposition.get_H,
 hamgnn/nn/tensor_decomposition.py:553-603), masks, symmetrisation, H0, per-crystal concatenation, sparsity ratio.
 The k-space step `calculate_band_energy` is built for the spin-free and the spin-orbit branches (hamgnn_amd/kspace.py).
-Out of scope (raise NotImplementedError): spin-constrained / collinear branches, export_reciprocal_values, forces."""
+Out of scope (raise NotImplementedError): spin-constrained / collinear branches, forces."""
 from __future__ import annotations
 
 import numpy as np
@@ -39,10 +39,12 @@ class HamGNNPlusPlusOut(nn.Module):
         self.calculate_band_energy, self.num_k, self.k_path, self.band_num_control = calculate_band_energy, num_k, k_path, band_num_control
         for flag, name in ((return_forces, "return_forces"),
                            (spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
-                           (export_reciprocal_values, "export_reciprocal_values"),
                            (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
             if flag:
                 raise NotImplementedError(f"HamGNNPlusPlusOut({name}) is outside the MI355X hot-path scope of this round")
+        self.export_reciprocal_values = export_reciprocal_values
+        if export_reciprocal_values and soc_switch:
+            raise NotImplementedError("HamGNNPlusPlusOut(export_reciprocal_values) with soc_switch: the reference exports H(k) / S(k) / dS(k) on its non-SOC branch only")
         if soc_switch and self.soc_basis not in ("so3", "su2"):
             raise NotImplementedError("Unsupported SOC basis")                  # hamgnn_output.py:3180-3181
         t = B.basis_table(self.ham_type, nao_max)
@@ -476,7 +478,13 @@ class HamGNNPlusPlusOut(nn.Module):
             # (`on` / `off` are views of H for a single crystal, and the shift below works in place)
             from .. import kspace
             data["k_vecs"] = kspace.make_k_vectors(self.k_path, self.num_k, data.cell).to(dev)
-            be, wf, gap, hs = kspace.band_energies(self, on, off, data)
+            if self.export_reciprocal_values:                                    # :3856-3869: H(k), S(k), dS(k) next to the bands, H_sym = None;
+                be, wf, HK, SK, dSK, gap = kspace.band_energies_export(           # with overlap networks S(k) is the PREDICTED overlap
+                    self, on, off, data, overlap=None if self.ham_only else (s_on, s_off))
+                hs = None
+                result.update({"HK": HK, "SK": SK, "dSK": dSK})
+            else:
+                be, wf, gap, hs = kspace.band_energies(self, on, off, data)
             with torch.no_grad():                                             # reference bands from the target blocks (:3876-3879)
                 tb, tw, tg, th = kspace.band_energies(self, f32c(data.Hon), f32c(data.Hoff), data)
             data["band_energy"], data["wavefunction"], data["band_gap"], data["H_sym"] = tb, tw, tg, th

@@ -681,6 +681,39 @@ def main():
               outputs=dict(hamiltonian=out_z["hamiltonian"], band_energy=out_z["band_energy"], band_energy_unshifted=out_z0["band_energy"],
                            hamiltonian_unshifted=out_z0["hamiltonian"], target_band_energy=gz_in["band_energy"]))
 
+    # ---- 6e. export_reciprocal_values: calculate_band_energies(..., True) (hamgnn_output.py:1675-1996) and calculate_band_energies_with_overlap(..., True)
+    # (:1368-1673) of the REFERENCE on a batch of two crystals of equal composition (the reference stacks the per-crystal H(k) / S(k) / dS(k))
+    gene = torch.Generator().manual_seed(90417)                # own stream: the sections around this one keep theirs
+    ge1, ge2 = S.random_cell(3, [6], seed=41, density=0.003), S.random_cell(3, [6], seed=42, density=0.003)
+    Ge = collate([ge1, ge2])
+    Ne, Ee = Ge.z.shape[0], Ge.edge_index.shape[1]
+    inv_e = torch.cat([ge1.inv_edge_idx, ge2.inv_edge_idx + ge1.edge_index.shape[1]])
+
+    def herm_e(n_on, scale, diag):
+        on = scale * torch.randn(n_on, nao, nao, generator=gene, dtype=torch.float64)
+        on = 0.5 * (on + on.transpose(1, 2)) + diag * torch.eye(nao, dtype=torch.float64)
+        off = scale * torch.randn(Ee, nao, nao, generator=gene, dtype=torch.float64)
+        off = 0.5 * (off + off[inv_e].transpose(1, 2))
+        return f32(on.reshape(n_on, -1)), f32(off.reshape(Ee, -1))
+    Ge = Graph({k: (f32(v) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in Ge.items()})
+    Ge["Son"], Ge["Soff"] = herm_e(Ne, 0.004, 1.0)
+    He_on, He_off = herm_e(Ne, 0.3, 0.0)
+    Sp_on, Sp_off = herm_e(Ne, 0.006, 1.0)                      # "predicted" overlaps of the overlap networks
+    Ge["dSon"] = f32(0.1 * torch.randn(Ne, nao * nao * 3, generator=gene, dtype=torch.float64))
+    Ge["dSoff"] = f32(0.1 * torch.randn(Ee, nao * nao * 3, generator=gene, dtype=torch.float64))
+    Ge["k_vecs"] = f32(torch.randn(2, 4, 3, generator=gene, dtype=torch.float64) * 0.05)
+    refe = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True,
+                                     add_H0=True, soc_switch=False, calculate_band_energy=False, calculate_sparsity=False)
+    refe.num_k, refe.band_num_control = 4, None
+    be_e, wf_e, HK_e, SK_e, dSK_e, gap_e = refe.calculate_band_energies(He_on, He_off, Graph(Ge), True)
+    be_o, wf_o, HK_o, SK_o, dSK_o, gap_o = refe.calculate_band_energies_with_overlap(He_on, He_off, Sp_on, Sp_off, Graph(Ge), True)
+    cplx = lambda t: torch.view_as_real(t.resolve_conj().contiguous())
+    keys_e = ("z", "pos", "cell", "edge_index", "nbr_shift", "inv_edge_idx", "batch", "node_counts", "Son", "Soff", "dSon", "dSoff", "k_vecs")
+    _save("band_energies_export_openmx_13", graph={k: (Ge[k].float() if Ge[k].is_floating_point() else Ge[k]) for k in keys_e},
+          inputs=dict(Hon=He_on.float(), Hoff=He_off.float(), Spred_on=Sp_on.float(), Spred_off=Sp_off.float()),
+          outputs=dict(band_energy=be_e, band_gap=gap_e, HK=cplx(HK_e), SK=cplx(SK_e), dSK=cplx(dSK_e), wavefunction_abs=wf_e.abs(),
+                       ov_band_energy=be_o, ov_band_gap=gap_o, ov_HK=cplx(HK_o), ov_SK=cplx(SK_o), ov_dSK=cplx(dSK_o), ov_wavefunction_abs=wf_o.abs()))
+
     # ---- 7. CorrProductBlock (optional MACE-style correlation product; interaction_blocks.py:168-260) ---------------
     print("CorrProductBlock")
     from oracle import mace_ref as M

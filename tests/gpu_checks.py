@@ -1847,6 +1847,67 @@ def check_band_cal_spin(device="cuda"):
     return out
 
 
+
+def check_band_energies_export(device="cuda"):
+    """export_reciprocal_values: kspace.band_energies_export (bands, normalised wavefunctions, H(k), S(k), dS(k)) vs the REFERENCE's
+    calculate_band_energies(..., True) and calculate_band_energies_with_overlap(..., True) (fixture band_energies_export_openmx_13: two crystals of
+    equal composition), and the head's result keys HK / SK / dSK with and without overlap networks"""
+    from hamgnn_amd import kspace
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    f = load("band_energies_export_openmx_13")
+    head = HamGNNPlusPlusOut("4x0e", "4x0e", nao_max=13, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, soc_switch=False,
+                             calculate_band_energy=True, num_k=4, k_path=None, calculate_sparsity=False, export_reciprocal_values=True)
+    head.compile(device)
+    g = to_graph(f["graph"], device)
+    t = lambda k: torch.from_numpy(f["inputs"][k]).float().to(device)
+    cx = lambda a: torch.view_as_complex(torch.from_numpy(np.ascontiguousarray(a)))
+    out = {}
+    for tag, ov in (("", None), ("ov_", (t("Spred_on"), t("Spred_off")))):
+        be, wf, HK, SK, dSK, gap = kspace.band_energies_export(head, t("Hon"), t("Hoff"), g, overlap=ov)
+        o = f["outputs"]
+        scale = float(np.abs(o[tag + "band_energy"]).max())
+        out[tag + "band_energy_err"] = float((be.double().cpu() - torch.from_numpy(o[tag + "band_energy"])).abs().max()) / scale
+        out[tag + "gap_err"] = float((gap.double().cpu() - torch.from_numpy(o[tag + "band_gap"])).abs().max()) / scale
+        for name, got in (("HK", HK), ("SK", SK), ("dSK", dSK)):
+            want = cx(o[tag + name])
+            out[tag + name + "_rel_err"] = float((got.cpu().to(want.dtype) - want).abs().max() / want.abs().max())
+        out[tag + "wf_abs_err"] = float((wf.abs().double().cpu() - torch.from_numpy(o[tag + "wavefunction_abs"])).abs().max())
+        # <psi|S(k)|psi> = 1 with the REFERENCE overlap
+        Sref = kspace.band_energies_export(head, t("Hon"), t("Hoff"), g)[3]
+        nrm = torch.einsum("cnai,cnij,cnaj->cna", wf.conj(), Sref, wf).real
+        out[tag + "norm_err"] = float((nrm - 1).abs().max())
+    # the head's forward with the flag: HK / SK / dSK in the result dict, H_sym = None; with overlap networks SK is the PREDICTED overlap
+    gd = dict(f["graph"])
+    gd["Hon"], gd["Hoff"] = f["inputs"]["Hon"], f["inputs"]["Hoff"]
+    for ham_only in (True, False):
+        torch.manual_seed(5)
+        hd = HamGNNPlusPlusOut(MINI, MINI, nao_max=13, ham_type="openmx", ham_only=ham_only, symmetrize=True, add_H0=False, soc_switch=False,
+                               calculate_band_energy=True, num_k=4, k_path=None, calculate_sparsity=False, export_reciprocal_values=True)
+        gg = to_graph(gd, device)
+        gen = torch.Generator().manual_seed(3)
+        from hamgnn_amd.so3 import Irreps
+        D = Irreps(MINI).dim
+        rep = {"node_attr": (0.3 * torch.randn(gg.z.shape[0], D, generator=gen)).to(device), "edge_attr": (0.3 * torch.randn(gg.edge_index.shape[1], D, generator=gen)).to(device)}
+        np.random.seed(0)
+        res = hd(gg, rep)
+        H = res["hamiltonian"]
+        N = int(gg.z.shape[0])
+        # the batch's rows are per crystal [on; off]: split them back the way the head does
+        inv_, ec = hd._global_inverse(gg)
+        on, off = hd._split_by_crystal(gg, H, ec)
+        ov = None
+        if not ham_only:
+            ov = hd._split_by_crystal(gg, res["overlap"], ec)
+        be, wf, HK, SK, dSK, gap = kspace.band_energies_export(hd, on.contiguous(), off.contiguous(), gg, overlap=ov)
+        tagh = "head_" + ("ham_only_" if ham_only else "overlap_")
+        out[tagh + "HK_rel_err"] = float((res["HK"] - HK).abs().max() / HK.abs().max())
+        out[tagh + "SK_rel_err"] = float((res["SK"] - SK).abs().max() / SK.abs().max())
+        out[tagh + "dSK_rel_err"] = float((res["dSK"] - dSK).abs().max() / dSK.abs().max())
+        out[tagh + "band_energy_err"] = float((res["band_energy"] - be).abs().max())
+        out[tagh + "H_sym_is_none"] = 0.0 if res["H_sym"] is None else 1.0
+    return out
+
+
 def check_tp_wgrad_kernel(device="cuda", seed=0, irr=None, sh=None, E=150, nsplit=3):
     """hg_tp_wgrad through the C ABI vs its numpy twin (tests/emu.py:run_wgrad_fused) on the SAME tables and the same random edge-frame rows:
     accumulator blocks (every split / edge-tile copy) and the per-edge gs rows.  The twin itself is checked against autograd through the fp64

@@ -159,6 +159,12 @@ def test_band_cal_spin_branches_on_cpu(cpu_backend):
     assert r["soc_bands_rel_err"] < 1e-4 and r["soc_gap_abs_err_eV"] < 1e-2 and r["collinear_bands_rel_err"] < 1e-4, r
 
 
+def test_band_energies_export_on_cpu(cpu_backend):
+    """export_reciprocal_values vs the reference's own outputs (fixture band_energies_export_openmx_13)"""
+    r = G.check_band_energies_export("cpu")
+    assert all(v < (2e-3 if k.endswith("wf_abs_err") else 2e-4) for k, v in r.items()), r
+
+
 def test_training_loop_on_cpu(cpu_backend):
     """a few optimiser steps of the whole model (training_step -> Adam -> device-side refresh of the packed weights at the next forward):
     the teacher-student loss falls monotonically"""

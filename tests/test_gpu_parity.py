@@ -488,6 +488,13 @@ def test_band_cal_spin_orbit_and_collinear_branches():
     assert r["soc_bands_rel_err"] < 1e-4 and r["soc_gap_abs_err_eV"] < 1e-2 and r["collinear_bands_rel_err"] < 1e-4, r
 
 
+def test_band_energies_export_reciprocal_values():
+    """export_reciprocal_values (hamgnn_output.py:1368-1673, 1675-1996 with the flag): H(k), S(k), dS(k), normalised wavefunctions vs the reference"""
+    r = G.check_band_energies_export()
+    print(r)
+    assert all(v < (2e-3 if k.endswith("wf_abs_err") else 2e-4) for k, v in r.items()), r
+
+
 def test_attribute_style_graph_object():
     """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
     r = G.check_attribute_style_graph()
