@@ -190,13 +190,28 @@ def run_uni8(args, dev):
              "batched_eager": {"ms_per_step": t_b * 1e3, "edges_per_s": E_total / t_b},
              "batched_graph_replay": {"ms_per_step": t_gb * 1e3, "edges_per_s": E_total / t_gb}}
     best = max(modes, key=lambda m: modes[m]["edges_per_s"])
+    # roofline of the dominant kernel at THIS size: the MessagePackBlock launches of the batched chain (HIP events on the launch stream, 12 per
+    # step: two models x three layers x two blocks), SURVEY 8(d)'s reference-formulation flop count per edge and block
+    ops.PROFILE_EVENTS = []
+    for _ in range(3):
+        batched()
+    torch.cuda.synchronize()
+    mp = [(s_.elapsed_time(e_) * 1e-3, rows) for (s_, e_, rows, tag) in ops.PROFILE_EVENTS if tag == "message_pack"]
+    all_ev = sum(s_.elapsed_time(e_) * 1e-3 for (s_, e_, rows, tag) in ops.PROFILE_EVENTS)
+    ops.PROFILE_EVENTS = None
+    avg_s = sum(t for t, _ in mp) / max(1, len(mp))
+    rows_l = sum(r for _, r in mp) / max(1, len(mp))
+    ach = REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_l / avg_s / 1e12
+    roofline = {"kernel": "tp_is_kernel (MessagePackBlock launches of the batched chain; split launches below 300 tiles)", "bound": "mfma", "achieved": ach,
+                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None, "avg_launch_ms": avg_s * 1e3,
+                "launches_timed": len(mp), "edges_per_launch": rows_l, "fused_program_launches_share_of_step": all_ev / 3 / t_b}
     res = {"metric": "edges/sec (equivariant MP forward)", "value": modes[best]["edges_per_s"], "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": modes[best]["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"uni8: Uni-HamGNN two-model chain (non-SOC -> SOC/so3, add_H_nonsoc), 8 mixed-Z crystals of {min(atoms)}-{max(atoms)} atoms "
                                   f"({sum(atoms)} atoms, {E_total} directed edges), irreps set-{args.irreps}, nao_max 26, 3 layers per model",
                       "parallelism": f"single GPU, issue mode = {best}"},
-           "modes": modes, "batch_rows_vs_per_crystal_rows": batch_vs_single, "atoms": atoms, "edges": edges}
+           "roofline": roofline, "modes": modes, "batch_rows_vs_per_crystal_rows": batch_vs_single, "atoms": atoms, "edges": edges}
     print(json.dumps(res), flush=True)
 
 
