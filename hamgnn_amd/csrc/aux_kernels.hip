@@ -39,6 +39,7 @@ extern "C" int64_t hg_scratch_bytes(const char* entry_point, int64_t rows, int a
     auto is = [&](const char* n) { const char* a = entry_point; while (*a && *a == *n) { ++a; ++n; } return *a == 0 && *n == 0; };
     if (is("hg_edge_geometry")) return rows * 4 * (int64_t)sizeof(float);              // ang_scratch [E][4]
     if (is("hg_zero_point_shift")) return 2 * (int64_t)(arg > 0 ? arg : 256) * (int64_t)sizeof(double);   // partial_scratch [2 nparts]
+    if (is("hg_linear_wgrad")) return ((rows + 1023) / 1024) * (int64_t)(arg > 0 ? arg : 0) * 1024 * (int64_t)sizeof(float);   // partial [chunks][arg = nunits][16][64]
     return 0;
 }
 

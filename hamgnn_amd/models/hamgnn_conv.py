@@ -114,9 +114,11 @@ class _BackboneBase(nn.Module):
     def _compile_common(self, dev):
         self.pair_embedding.compile(dev)
         lay = self.layout
-        self._imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(dev)
-        self._rot_tab = torch.from_numpy(P.rotate_table(lay)).to(dev)
-        self._jtab = torch.from_numpy(P.wigner_jtab(self.lmax)).to(dev)
+        if getattr(self, "_struct_for", None) != dev:          # structural tables: once per device (not per repack)
+            self._imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(dev)
+            self._rot_tab = torch.from_numpy(P.rotate_table(lay)).to(dev)
+            self._jtab = torch.from_numpy(P.wigner_jtab(self.lmax)).to(dev)
+            self._struct_for = dev
         # chemical embedding = row look-up of o3.Linear(num_types x 0e -> D) applied to one-hot rows (planar table)
         T = self.num_types
         W = self.chemical_embedding.linear.weight.detach().cpu().double().numpy()

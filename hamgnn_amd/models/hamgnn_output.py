@@ -86,6 +86,9 @@ class HamGNNPlusPlusOut(nn.Module):
             if isinstance(m, hnn.HamLayer):
                 m.compile(dev)
         su2 = self.soc_switch and self.soc_basis == "su2"
+        if getattr(self, "_struct_for", None) == dev:          # everything below is STRUCTURAL (basis tables, CG maps, layouts): built once per device;
+            self._compiled_for = dev                           # a recompile after an optimiser step only repacks the HamLayers' weights above
+            return self
         net = self.onsite_overlap_network if (su2 and not self.ham_only) else self.onsite_hamiltonian_network
         if not su2 or not self.ham_only:
             st, ptr, idx, val = P.ham_merge_tables(self.row, self.nao_max, self.index_change, self.minus_index, net.girr, net.slot_pos)
@@ -118,7 +121,7 @@ class HamGNNPlusPlusOut(nn.Module):
         self._lmax = max(self.edge_layout.irreps.lmax, self.hamiltonian_irreps.lmax, P.su2_irreps(self.row).lmax if su2 else 0)
         self._jtab = torch.from_numpy(P.wigner_jtab(self._lmax)).to(dev)
         self._blk = torch.from_numpy(P.shell_block_table(self.row, self.nao_max)).to(dev)
-        self._compiled_for = dev
+        self._compiled_for = self._struct_for = dev
         return self
 
     # -- index preparation (integer plumbing; hamgnn_output.py:2874-2914, 2985-2990, 1187-1229, 2784-2872)
@@ -365,10 +368,10 @@ class HamGNNPlusPlusOut(nn.Module):
         """adjoint of the CG merge + reorder (a CSR map applied transposed: hg_ham_merge with plan.ham_merge_adjoint_tables), of the
         off-site un-rotation (hg_rotate_gather) and of the two Hamiltonian HamLayers"""
         dev = g_on.device
+        # structural tables (CG merge maps: functions of the basis, not of the weights): built once per (key, table object) -- rebuilding them
+        # after every optimiser step put a device -> host copy in the middle of the step
         cache = self.__dict__.setdefault("_adj_tabs_by", {})
-        if getattr(self, "_adj_tabs", None) is None:           # compile() resets _adj_tabs: drop the derived tables with it
-            cache.clear()
-            self._adj_tabs = True
+        key = (key, id(tables[0]))
         if key not in cache:
             glay = P.PlanarLayout(self.onsite_hamiltonian_network.girr)
             st, ptr_, idx_, val_ = (t.cpu().numpy() for t in tables)

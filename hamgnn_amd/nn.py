@@ -32,6 +32,12 @@ def o3_linear_weight_grad(irreps_in, irreps_out, x_planar: torch.Tensor, gy_plan
     """d sum(y * gy) / d weight of an o3.Linear in e3nn's flat layout (paths (i_in, i_out), each [mul_in, mul_out], 1 / sqrt(fan_in)
     normalisation): per path one GEMM over (rows x components) on the planar blocks (rocBLAS / hipBLASLt: a library GEMM)."""
     irreps_in, irreps_out = Irreps(irreps_in), Irreps(irreps_out)
+    if x_planar.is_cuda and os.environ.get("HG_LINEAR_WGRAD", "1") != "0":
+        # all paths in one launch of csrc/linear_wgrad.hip (r4; the per-path library GEMMs on strided copies below were ~290 GEMMs + ~570 copy
+        # launches of a training step): same sums, added in a fixed order
+        xc = x_planar if x_planar.stride(1) == 1 else x_planar.contiguous()
+        gc = gy_planar if gy_planar.stride(1) == 1 else gy_planar.contiguous()
+        return ops.linear_wgrad(irreps_in, irreps_out, xc, gc)
     li, lo = P.PlanarLayout(irreps_in), P.PlanarLayout(irreps_out)
     paths = [(i, k) for i, (_, l1, p1) in enumerate(irreps_in) for k, (_, l2, p2) in enumerate(irreps_out) if (l1, p1) == (l2, p2)]
     fan = {}
@@ -739,7 +745,10 @@ class PairInteractionEmbeddingBlock(nn.Module):
         s = 1.0 / math.sqrt(T)
         self._Ts = (self.linear_up_src.weight.detach().double().reshape(T, T) * s).float().contiguous().to(device)
         self._Td = (self.linear_up_dst.weight.detach().double().reshape(T, T) * s).float().contiguous().to(device)
-        self._dp = ops.DeviceProgram(P.build_embedding_program(_np_sd(self.conv_tp), T, self.irreps_sh, self.irreps_out, self.lite_mode), device)
+        # the block's weights on the host, read HERE -- at the start of a step, when the device is idle -- and kept for backward(): read again
+        # there, the device -> host copy drained the whole forward + head backward queue in the middle of the step (61 of 155 ms on Si-512)
+        self._sd_np = _np_sd(self.conv_tp)
+        self._dp = ops.DeviceProgram(P.build_embedding_program(self._sd_np, T, self.irreps_sh, self.irreps_out, self.lite_mode), device)
         self._h = self.conv_tp.weight_generator.hidden_layers(device)
         self._Tp = P.PlanarLayout([(T, 0, 1)]).dim
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
@@ -753,7 +762,7 @@ class PairInteractionEmbeddingBlock(nn.Module):
         from . import backward_mp as BM
         dev, T = g_f.device, self.num_types
         if self._wgrad is None:
-            sd = _np_sd(self.conv_tp)
+            sd = getattr(self, "_sd_np", None) or _np_sd(self.conv_tp)
             wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T, self.lite_mode), self.irreps_sh, self.irreps_out)
             wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
             self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
@@ -847,6 +856,7 @@ class HamLayer(nn.Module):
         self._rowprog = None                                   # the fused chain (csrc/rowprog.hip) is built on first use, from the weights of that moment
         self._rowprog_off = getattr(self, "_rowprog_off", False)    # set by training._invalidate: separate kernels while the weights move
         W = self.linear_transform.weight.detach().cpu().double().numpy()
+        self._W_np = W                                         # kept for backward(): a device -> host copy there would drain the queue mid-step
         stream = os.environ.get("HG_LINEAR_KERNEL", "stream") != "seg"
         if all(m == 1 for m, _, _ in self.ham_irreps):         # hamiltonian irreps: regroup the multiplicity-1 outputs by (L,p)
             if stream:
@@ -868,8 +878,9 @@ class HamLayer(nn.Module):
         (g_x, {parameter name: gradient in the reference's flat layout})"""
         if not isinstance(self._dp, ops.DeviceLinear):
             raise NotImplementedError("HamLayer.backward: streaming Linear path only (HG_LINEAR_KERNEL=seg has no adjoint tables)")
+        W_host = lambda: self._W_np if getattr(self, "_W_np", None) is not None else self.linear_transform.weight.detach().cpu().double().numpy()
         if self.slot_pos is None:                               # xi networks: a plain o3.Linear (e.g. irreps_in -> nao^2 x 0e)
-            W = self.linear_transform.weight.detach().cpu().double().numpy()
+            W = W_host()
             if getattr(self, "_dp_adj", None) is None:
                 self._dp_adj = ops.DeviceLinear(P.build_linear_adjoint_tables(W, self.irreps_in, self.ham_irreps), x_planar.device)
             y = self.residual_block(x_planar)
@@ -878,7 +889,7 @@ class HamLayer(nn.Module):
             grads = {"linear_transform.weight": o3_linear_weight_grad(self.irreps_in, self.ham_irreps, y, g_out_planar)}
             grads.update({"residual_block." + k: v for k, v in g_res.items()})
             return g_x, grads
-        W = self.linear_transform.weight.detach().cpu().double().numpy()
+        W = W_host()
         mats, girr, slot_pos = P.ham_linear_mats(W, self.irreps_in, self.ham_irreps, self.keep)
         dev = x_planar.device
         if getattr(self, "_dp_adj", None) is None:

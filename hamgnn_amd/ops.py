@@ -154,6 +154,56 @@ def linear_planar(dl: DeviceLinear, x: torch.Tensor, res: Sequence[Optional[torc
     return out
 
 
+LW_ROWS = 1024                     # rows of a chunk of csrc/linear_wgrad.hip
+_LW_TABLES: dict = {}
+
+
+def linear_wgrad_tables(irreps_in, irreps_out, device):
+    """(units int32 [nunits, 8] on the device, gather index int64 [numel] into the summed partial blocks, scale float32 [numel]) of the weight
+    gradient of o3.Linear(irreps_in -> irreps_out): a unit = 16 input channels x <= 64 output channels of one path; the flat e3nn weight
+    (paths (i_in, i_out), each [mul_in, mul_out] row-major, 1 / sqrt(fan_in)) is a gather of the unit blocks.  Cached per signature."""
+    key = (str(irreps_in), str(irreps_out), str(device))
+    if key not in _LW_TABLES:
+        from .so3 import Irreps
+        ii, io = Irreps(irreps_in), Irreps(irreps_out)
+        li, lo = P.PlanarLayout(ii), P.PlanarLayout(io)
+        paths = [(i, k) for i, (_, l1, p1) in enumerate(ii) for k, (_, l2, p2) in enumerate(io) if (l1, p1) == (l2, p2)]
+        fan = {}
+        for i, k in paths:
+            fan[k] = fan.get(k, 0) + ii[i][0]
+        units, gather, scale = [], [], []
+        for i, k in paths:
+            mi, l, _ = ii[i]
+            mk = io[k][0]
+            ublock = {}
+            for u0 in range(0, mi, 16):
+                for v0 in range(0, mk, 64):
+                    ublock[(u0, v0)] = len(units)
+                    units.append([li.off[i], li.mulp[i], lo.off[k], lo.mulp[k], 2 * l + 1, u0, v0, min(64, mk - v0)])
+            for u in range(mi):
+                for v in range(mk):
+                    gather.append(ublock[(u - u % 16, v - v % 64)] * 1024 + (u % 16) * 64 + v % 64)
+                    scale.append(1.0 / math.sqrt(fan[k]))
+        _LW_TABLES[key] = (_dev(np.asarray(units if units else [[0] * 8], np.int32), device), len(units),
+                           torch.tensor(gather, dtype=torch.int64, device=device), torch.tensor(scale, dtype=torch.float32, device=device))
+    return _LW_TABLES[key]
+
+
+def linear_wgrad(irreps_in, irreps_out, x: torch.Tensor, gy: torch.Tensor) -> torch.Tensor:
+    """d sum(y * gy) / d weight of an o3.Linear in e3nn's flat layout, all paths in ONE launch of csrc/linear_wgrad.hip + a fixed-order sum over
+    the row chunks (x, gy: planar rows of the Linear's input and of the gradient of its output)"""
+    _require_gpu(x)
+    units, nunits, gather, scale = linear_wgrad_tables(irreps_in, irreps_out, x.device)
+    if nunits == 0:
+        return x.new_zeros(0)
+    rows = int(x.shape[0])
+    assert gy.shape[0] == rows and x.stride(1) == 1 and gy.stride(1) == 1
+    nchunk = (rows + LW_ROWS - 1) // LW_ROWS
+    part = torch.empty(nchunk, nunits * 1024, device=x.device, dtype=torch.float32)
+    check(lib().hg_linear_wgrad(ptr(x), i64(x.stride(0)), ptr(gy), i64(gy.stride(0)), i64(rows), ptr(units), i32(nunits), ptr(part), _stream()), "hg_linear_wgrad")
+    return part.sum(0)[gather] * scale
+
+
 def wig_offsets(lmax):
     offs, tot = P.wigner_offsets(lmax)
     arr = (C.c_int * 8)(*([int(o) for o in offs] + [0] * (8 - len(offs))))

@@ -121,6 +121,15 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
              const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
              int64_t rows, void* stream);
 
+/* Weight gradient of an o3.Linear on planar rows, all paths in one launch (csrc/linear_wgrad.hip): what torch.autograd computes for the weight of
+ * the e3nn o3.Linears of the path when the reference trains (hamgnn/models/Model.py:150-196; nn/interaction_blocks.py:332-358,
+ * nn/convolution.py:127, models/hamgnn_output.py:49-58).  units int32[nunits][8] = {x_off, x_mulp, g_off, g_mulp, 2 l + 1, first input channel,
+ * first output channel, output channels (<= 64)} (hamgnn_amd/ops.py:linear_wgrad_units); partial: [ceil(rows / 1024)][nunits][16][64] floats of
+ * scratch (hg_scratch_bytes), block (chunk, unit) = sum over the chunk's (row, component) of x[., u0 + a] g[., v0 + b]; the caller adds the
+ * chunks in a fixed order and applies 1 / sqrt(fan_in).                                                                                  */
+int hg_linear_wgrad(const float* x, int64_t x_stride, const float* g, int64_t g_stride, int64_t rows, const int32_t* units, int nunits,
+                    float* partial, void* stream);
+
 /* Fused WEIGHT gradients of the weighted tensor-product branches of a MessagePackBlock (csrc/tp_wgrad.hip): what torch.autograd computes
  * for o3.TensorProduct.weight, LinearScaleWithWeights.linear_out.weight and the trailing o3.Linear of
  * hamgnn/nn/message_passing.py:112-160, 191-231 (the reference has no hand-written backward).  Tables from hamgnn_amd/plan.py:

@@ -1908,6 +1908,33 @@ def check_band_energies_export(device="cuda"):
     return out
 
 
+
+def check_linear_wgrad_kernel(device="cuda", rows=2500, seed=0):
+    """csrc/linear_wgrad.hip (all paths of an o3.Linear's weight gradient in one launch) vs the per-path GEMMs in fp64, for the shipped node irreps
+    (877 -> gate input, multiplicities 2..64 and > 64 outputs) and a ragged row count"""
+    import bench
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    from hamgnn_amd.so3 import Irreps
+    res = {}
+    for tag, irr_in, irr_out in (("setA_to_gate", bench.IRREPS["A"], str(hnn.ResidualBlock(bench.IRREPS["A"], bench.IRREPS["A"]).gate_in)),
+                                 ("mini", MINI, MINI), ("setB_setB", bench.IRREPS["B"], bench.IRREPS["B"])):
+        g = torch.Generator().manual_seed(seed)
+        li, lo = P.PlanarLayout(irr_in), P.PlanarLayout(irr_out)
+        xin = torch.randn(rows, Irreps(irr_in).dim, generator=g, dtype=torch.float64)
+        gout = torch.randn(rows, Irreps(irr_out).dim, generator=g, dtype=torch.float64)
+        xp = torch.from_numpy(li.to_planar(xin.numpy())).float().to(device)
+        gp = torch.from_numpy(lo.to_planar(gout.numpy())).float().to(device)
+        got = hnn.o3_linear_weight_grad(irr_in, irr_out, xp, gp)
+        os.environ["HG_LINEAR_WGRAD"] = "0"
+        try:
+            want = hnn.o3_linear_weight_grad(irr_in, irr_out, xp.double(), gp.double())
+        finally:
+            os.environ.pop("HG_LINEAR_WGRAD", None)
+        res[tag + "_rel_err"] = rel(got, want)
+        res[tag + "_numel"] = float(got.numel() == want.numel()) * 0.0 + (0.0 if got.numel() == want.numel() else 1.0)
+    return res
+
+
 def check_tp_wgrad_kernel(device="cuda", seed=0, irr=None, sh=None, E=150, nsplit=3):
     """hg_tp_wgrad through the C ABI vs its numpy twin (tests/emu.py:run_wgrad_fused) on the SAME tables and the same random edge-frame rows:
     accumulator blocks (every split / edge-tile copy) and the per-edge gs rows.  The twin itself is checked against autograd through the fp64

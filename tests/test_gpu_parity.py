@@ -495,6 +495,13 @@ def test_band_energies_export_reciprocal_values():
     assert all(v < (2e-3 if k.endswith("wf_abs_err") else 2e-4) for k, v in r.items()), r
 
 
+def test_linear_weight_gradient_kernel():
+    """hg_linear_wgrad (csrc/linear_wgrad.hip): every path of an o3.Linear's weight gradient in one launch vs per-path fp64 GEMMs"""
+    r = G.check_linear_wgrad_kernel()
+    print(r)
+    assert all(v < 2e-6 for v in r.values()), r
+
+
 def test_attribute_style_graph_object():
     """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
     r = G.check_attribute_style_graph()
