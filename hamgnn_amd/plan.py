@@ -38,6 +38,8 @@ IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: ali
 IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
 LITE_RING = 6    # request ring of csrc/tp_is.hip:run_lite (RL_RING)
 IT_RUN = 5       # lite_mode, input-stationary schedule: ALL IT_LINM items of one (phase, segment, row chunk) as one stream of steps (plan._lite_runs)
+IT_STREAM = 6    # lite_mode, input-stationary schedule (r4): the folded items of one PHASE as IS_WAVES balanced streams of uniform steps (plan._lite_streams)
+LITE_SRING = 8   # request ring / descriptor block of csrc/tp_is.hip:stream_lite (SL_RING)
 IT_LINM = 4      # lite_mode, ALL paths (i, l_sh, k) of one (i, k) folded: one weight matrix per column, A_m = sum_paths cf_path[m] A_path (input-stationary kernel only)
 # segment flags
 SEG_UNROTATE = 1     # epilogue applies D^l(R_e)^T (messages go back to the global frame before the node scatter)
@@ -244,6 +246,8 @@ ITEM_OVERHEAD = int(os.environ.get("HG_ITEM_OVH", "60"))
 
 
 def _item_cost(rec, segs, hp4, vsegs=()):
+    if int(rec[0]) == IT_STREAM:
+        return int(rec[8]) * 7 + 60
     if int(rec[0]) == IT_RUN:                                   # measured: a step costs ~860 cycles almost independently of its 4 rtm MFMAs (profiles/r03_lite.md)
         return int(rec[8]) * (6 + int(rec[9])) + 60
     typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
@@ -465,6 +469,131 @@ def _lite_runs(prog: "Program", recs, runs: dict):
     return out
 
 
+def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool):
+    """the column tasks of one (segment, row chunk): for every output column m (or pair +-m) the list of steps (fragment group [rtm * 256], d0, d1)
+    over all folded items that feed it -- see _lite_runs for the descriptor words and the pairing rule"""
+    Wt = prog.weights
+
+    def item_steps(r, m):
+        so0, so1, in_mulp, li, mm, neg, ksteps, a1, colstride = int(r[1]), int(r[2]), int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[11]), int(r[13])
+        if abs(m) > mm:
+            return None
+        c = m + mm
+        nsrc, ngrp, P1 = (2 if so1 >= 0 else 1), ceil_div(ksteps, 4), in_mulp // 4
+        cdir = -P1 if neg else P1
+        c0p = (li - mm) * P1 + ((2 * mm) * P1 if neg else 0)
+        st = []
+        for si in range(nsrc):
+            for G in range(ngrp):
+                base = (so1 if si else so0) + (c0p + c * cdir + 4 * G) * 64
+                assert base % 64 == 0 and 0 <= base // 64 < 1024
+                woff = a1 + c * colstride + (si * ngrp + G) * rtm * 256
+                st.append((Wt[woff:woff + rtm * 256], base // 64, min(4, ksteps - 4 * G)))
+        return st
+
+    tasks = []
+    for m in range(0, lk + 1):
+        cols = {sm: [item_steps(r, sm) for r in items] for sm in ((m,) if m == 0 else (m, -m))}
+        paired, signs = pairing and m > 0, []
+        if paired:
+            for sa, sb in zip(cols[m], cols[-m]):
+                if sa is None:
+                    signs.append(0)
+                    continue
+                wa, wb = np.concatenate([x[0] for x in sa]), np.concatenate([x[0] for x in sb])
+                if np.array_equal(wa, wb):
+                    signs.append(1)
+                elif np.array_equal(wa, -wb):
+                    signs.append(-1)
+                else:
+                    paired = False
+                    break
+        if paired:
+            steps = []
+            for sa, sb, sg_ in zip(cols[m], cols[-m], signs):
+                if sa is None or not any(np.any(x[0]) for x in sa):
+                    continue
+                for (w, ba, nq), (_, bb, _) in zip(sa, sb):
+                    steps.append((w, ba | ((nq - 1) << 10) | ((16 + m) << 16), bb | (1 << 14) | ((1 if sg_ < 0 else 0) << 15) | ((16 - m) << 16)))
+            if steps:
+                tasks.append(steps)
+        else:
+            for mm_ in cols:
+                steps = []
+                for sa in cols[mm_]:
+                    if sa is None or not any(np.any(x[0]) for x in sa):
+                        continue
+                    steps += [(w, ba | ((nq - 1) << 10) | ((16 + mm_) << 16), 0) for (w, ba, nq) in sa]
+                if steps:
+                    tasks.append(steps)
+    return tasks
+
+
+def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
+    """lite_mode, input-stationary schedule, r4: ALL folded items (IT_LINM) of one phase -- `recs`, stage offsets in [1], [2] -- as IS_WAVES
+    balanced STREAMS of uniform steps, one work group each.  A TASK = (output segment, ONE 16-row tile, column m or column pair +-m): its steps
+    run over every item and K group that feeds it, accumulate in registers and add into the tile once.  A step = one fragment (64 lanes x 4:
+    16 output rows x 16 input channels, PERMUTED K: lane (g, i) word q = weight of channel 16 G + 4 g + q, so the B operand is ONE 16-byte LDS
+    read per lane) + two descriptor words
+        d0 = B operand base / 64 floats | valid pieces - 1 << 10 | first step of the task << 12 | last << 13 | (m + 16) << 16 | row-table index / 16 << 21
+        d1 = 0, or for a PAIRED step: B base of column -m | 1 << 14 | negate << 15 | (-m + 16) << 16
+    r3 / early r4 ran one stream per (phase, segment, row chunk) with rtm row tiles per step (_lite_runs): 147 streams per 16 edges whose first
+    requests were exposed each (~37 per wave), 20 % padding steps, and per-step instruction counts that did not shrink with rtm = 1 (71 % of the
+    steps).  Tasks of different segments and row tiles are independent (disjoint tile rows / columns), so the planner deals them to the waves
+    by LPT on their exact step counts: 4 streams per phase, padded once each.  Returns IT_STREAM item records."""
+    pairing = os.environ.get("HG_LITE_PAIR", "1") != "0"
+    by_chunk: Dict[Tuple[int, int, int], list] = {}
+    for r in recs:
+        by_chunk.setdefault((int(r[19]), int(r[16]), int(r[9])), []).append(r)
+    tasks = []                                                 # (steps [(frag 256, d0, d1)], seg)
+    for (seg, row_off, rtm), items in by_chunk.items():
+        lk = int(prog.seg_table[seg][0])
+        assert row_off % 16 == 0
+        for steps in _lite_column_steps(prog, items, lk, rtm, pairing):
+            for rt in range(rtm):
+                ridx = rt_base[seg] + row_off + 16 * rt
+                assert ridx % 16 == 0 and ridx // 16 < 2048
+                st = []
+                for w, d0, d1 in steps:
+                    f = np.asarray(w[rt * 256:(rt + 1) * 256]).reshape(4, 16, 4)       # natural K [q'][i][g'] ... stored [g][i][q]: word q of lane (g, i) = channel 4 (4 G + q) + g
+                    if not np.any(f):
+                        continue
+                    nv = ((d0 >> 10) & 3) + 1
+                    assert not np.any(f[:, :, nv:])                                     # K-steps beyond the block's pieces carry zero weights
+                    st.append((f.transpose(2, 1, 0).reshape(256), d0 | ((ridx // 16) << 21), d1))      # permuted K: word q of lane (g, i) = channel 4 (4 G + g) + q
+                if st:
+                    tasks.append((st, seg))
+    nw = min(IS_WAVES, max(1, len(tasks)))
+    loads, streams = [0] * nw, [[] for _ in range(nw)]
+    for st, seg in sorted(tasks, key=lambda t: -len(t[0])):
+        n = loads.index(min(loads))
+        loads[n] += len(st) + 2
+        streams[n].append((st, seg))
+    out = []
+    for stream in streams:
+        frags, desc = [], []
+        for st, _ in stream:
+            for n_, (w, d0, d1) in enumerate(st):
+                frags.append(w)
+                desc += [d0 | ((1 if n_ == 0 else 0) << 12) | ((1 if n_ == len(st) - 1 else 0) << 13), d1]
+        nst = len(frags)
+        npad = (-nst) % LITE_SRING
+        # padding steps: zero weights, no task boundary; LITE_SRING more slots behind the last step (the request ring and the descriptor blocks run ahead)
+        frags += [np.zeros(256)] * (npad + LITE_SRING)
+        desc += [0, 0] * (npad + LITE_SRING)
+        base = runs["base"] + sum(x.size for x in runs["w"])
+        lead = (-base) % 16                                    # fragments and descriptor blocks on 64-byte boundaries (s_load_dwordx16)
+        wblob = np.concatenate(frags).astype(np.float64)
+        dblob = np.asarray(desc, dtype=np.int32).view(np.float32).astype(np.float64)
+        assert (wblob.size % 16, dblob.size % 16) == (0, 0)
+        runs["w"] += [np.zeros(lead), wblob, dblob]
+        rec = np.zeros(ITEM_I32, dtype=np.int64)
+        rec[0], rec[8], rec[9], rec[11], rec[12], rec[19] = IT_STREAM, nst + npad, 1, base + lead, base + lead + wblob.size, stream[0][1]
+        rec[2] = -1
+        out.append(rec)
+    return out
+
+
 def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
                       split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None) -> dict:
     """sub-schedule of the output segments `members` (indices into prog.seg_table); all table indices are emitted as ABSOLUTE indices
@@ -577,7 +706,10 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         else:                                                  # a work group's items by radial generator: the kernel keeps the hidden rows of
             units = [sorted(recs, key=lambda r: int(r[10]) if int(r[0]) == IT_TP else -1) for recs in by_seg.values()]      # ONE generator in registers
         if runs is not None and all(int(r[0]) == IT_LINM for recs in units for r in recs):
-            units = [[run] for recs in units for run in _lite_runs(prog, recs, runs)]      # one run = one work group (disjoint rows of a tile)
+            if os.environ.get("HG_LITE_STREAMS", "1") != "0":  # r4: the phase's folded items as IS_WAVES balanced streams of uniform steps
+                units = [[st] for st in _lite_streams(prog, [r for recs in units for r in recs], runs, {sg: rt_base[n] for sg, n in local.items()})]
+            else:
+                units = [[run] for recs in units for run in _lite_runs(prog, recs, runs)]      # one run = one work group (disjoint rows of a tile)
         groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
         loads = [0] * IS_WAVES
         for c, n in groups:                                    # claim order = LPT order

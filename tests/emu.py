@@ -228,11 +228,63 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                     staged[o0] = (s0, s1, in_off, in_mulp, li)
                 assert used <= stage_floats
                 owner = set()
+                stream_cells = set()
                 for gi in range(g0, g1):
                     ib, ie = (int(v) for v in sched.group_table[gi])
                     touched = set()
                     for ii in range(ib, ie):
                         it = sched.item_table[ii].copy()
+                        if int(it[0]) == P.IT_STREAM:          # lite_mode stream (r4): uniform steps over the tasks (segment, row tile, column / pair) dealt to one wave
+                            assert ii not in seen
+                            seen.add(ii)
+                            Wall = np.concatenate([prog.weights.astype(dtype), sched.extra_weights.astype(dtype)])
+                            nst, w0, d0 = int(it[8]), int(it[11]), int(it[12])
+                            assert nst % P.LITE_SRING == 0 and w0 % 16 == 0 and d0 % 16 == 0
+                            desc = Wall[d0:d0 + 2 * (nst + P.LITE_SRING)].astype(np.float32).view(np.int32)
+                            assert not desc[2 * nst:].any() and not Wall[w0 + nst * 256:w0 + (nst + P.LITE_SRING) * 256].any()
+
+                            def piece(b64):
+                                """the float4 piece behind operand base b64 (64-float units into the staging area): [4 channels, 16 edges]"""
+                                o0 = max(o for o in staged if o <= b64 * 64)
+                                s0, s1, in_off, in_mulp, li = staged[o0]
+                                size = -(-((2 * li + 1) * (in_mulp // 4)) // 4) * 256
+                                src_i, rel_ = (s0, b64 * 64 - o0) if b64 * 64 - o0 < size else (s1, b64 * 64 - o0 - size)
+                                assert rel_ // 64 < (2 * li + 1) * (in_mulp // 4)
+                                a, s_ = divmod(rel_ // 64, in_mulp // 4)
+                                B = np.zeros((4, 16), dtype=dtype)
+                                for q in range(4):
+                                    B[q, :ne] = srcs[src_i][cols, in_off + a * in_mulp + 4 * s_ + q]
+                                return B
+                            acc = accb = None
+                            for t in range(nst):
+                                d, e1 = int(desc[2 * t]), int(desc[2 * t + 1])
+                                b64, nv, first, last, tc, ridx = d & 1023, ((d >> 10) & 3) + 1, (d >> 12) & 1, (d >> 13) & 1, ((d >> 16) & 31) - 16, ((d >> 21) & 2047) * 16
+                                pair, negb, bb64, tcb = (e1 >> 14) & 1, (e1 >> 15) & 1, e1 & 1023, ((e1 >> 16) & 31) - 16
+                                F = Wall[w0 + t * 256:w0 + (t + 1) * 256].reshape(4, 16, 4)                          # [g][i][q]: out row i, channel 16 G + 4 g + q
+                                if first:
+                                    acc = np.zeros((16, 16), dtype=dtype)
+                                    accb = np.zeros((16, 16), dtype=dtype)
+                                    key = (ridx, tc, tcb if pair else None)
+                                if not F.any():
+                                    assert not first and not last      # (padding step)
+                                    continue
+                                assert not F[nv:].any()                                    # pieces beyond the block carry zero weights (the kernel reads whatever follows)
+                                for g in range(nv):
+                                    acc += F[g] @ piece(b64 + g)
+                                    if pair:
+                                        accb += F[g] @ (-piece(bb64 + g) if negb else piece(bb64 + g))
+                                if last:
+                                    for col in ([tc, tcb] if pair else [tc]):
+                                        assert (ridx, col) not in stream_cells, "a (row tile, column) of a tile belongs to one task per phase"
+                                        stream_cells.add((ridx, col))
+                                    for i_ in range(16):
+                                        base = int(rowtab[ridx + i_])
+                                        lds[base + tc * 16:base + tc * 16 + 16] += acc[i_]
+                                        if pair:
+                                            lds[base + tcb * 16:base + tcb * 16 + 16] += accb[i_]
+                                    acc = accb = None
+                            assert acc is None
+                            continue
                         if int(it[0]) == P.IT_RUN:             # lite_mode run: a stream of steps over the items of one (phase, segment, row chunk)
                             assert ii not in seen
                             seen.add(ii)

@@ -125,7 +125,7 @@ def test_message_pack_lite_program_vs_golden(golden_dir):
     for pr in (prog, progf):
         for parts in (1, 3):
             sc = P.is_schedule(pr, parts)
-            assert (sc.item_table[:, 0] == P.IT_RUN).any() == (pr is progf)           # the folded items run as step streams (plan._lite_runs)
+            assert (sc.item_table[:, 0] == P.IT_STREAM).any() == (pr is progf)        # the folded items run as step streams (plan._lite_streams)
             assert (sc.item_table[:, 0] == P.IT_POST).sum() == pr.seg_table.shape[0] and sc.part_table[:, 11].all()
             assert not sc.part_table[:, 7].any()               # no private tile copies: the post-op runs on the shared tiles
             outi = emu.run_program_is(pr, sc, [xs, xd, fe], (h, None), D, 3)
