@@ -634,16 +634,16 @@ __device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restric
 }
 
 // lite_mode STREAM (plan._lite_streams, r4): the folded items of one phase dealt to the waves as streams of UNIFORM steps.  A task = (segment, one
-// 16-row tile, column m or pair +-m); a step = one fragment (16 rows x 16 input channels, permuted K: the B operand is ONE ds_read_b128 per
-// lane and column) + two descriptor words; 4 MFMAs (8 for a pair) per step, the accumulators of a task live in registers and are added into
-// the tile at its last step through the row table.  One instantiation for every row-tile count (run_lite<RTM>: four), so the request ring is
-// 8 deep at 8 x 4 registers; descriptors arrive in blocks of 8 steps by ONE scalar load a block ahead (run_lite: a scalar load per step, which
-// the step's MFMAs waited for -- a wave can only wait for scalar loads with lgkmcnt(0)).
+// 16-row tile, column m or pair +-m); a step = one fragment (16 rows x up to 16 input channels, natural K) + two descriptor words; only the
+// K-steps that hold channels are issued (1..4 MFMAs, twice that for a pair): the input irreps with 2-12 channels fill a quarter or three
+// quarters of a K group.  The accumulators of a task live in registers and are added into the tile at its last step through the row table.
+// One instantiation for every row-tile count (run_lite<RTM>: four), so the request ring is 8 deep at 8 x 4 registers; descriptors arrive in
+// blocks of 8 steps by ONE scalar load a block ahead (run_lite: a scalar load per step, which the step's MFMAs waited for -- a wave can only
+// wait for scalar loads with lgkmcnt(0)).
 #ifndef SL_RING
 #define SL_RING 8
 #endif
 typedef int i32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
     constexpr int RING = SL_RING;
     static_assert(RING == 8, "descriptor blocks are 16 dwords = 8 steps (plan.LITE_SRING)");
@@ -651,9 +651,9 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
     const int nsteps = it[8];                                  // a multiple of RING (no-op steps at the end), RING more slots behind
     const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + 4 * g;
     float* __restrict__ tbase = lds + A.tile_shift + (el - 256);          // column field = m + 16, row-table entries point at the centre column
-    // piece g of a K group, this lane's edge: pieces beyond the block (partial groups) are whatever follows in the staging area -- finite
-    // (zero-filled at kernel start, staged rows afterwards), multiplied by zero weights
-    const float* __restrict__ stage = lds + A.stage_off + g * 64 + el * 4;
+    // B operand of K-step q: channel g of piece q, this lane's edge.  All four pieces behind the base are read whether the step issues their
+    // K-steps or not (no clamp, no branch around the reads: what is not issued never reaches an accumulator)
+    const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t: aw[t * 64]
     const i32x16* __restrict__ dsc = reinterpret_cast<const i32x16*>(Wb + it[12]);            // uniform, 64-byte aligned: s_load_dwordx16
     f32x4 ring[RING];
@@ -665,11 +665,16 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
     i32x16 dc = dsc[0];
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
     int roff[4] = {0, 0, 0, 0};
-    f32x4 bn, bnb;
+    float bn[4], bnb[4];
     {
+        const float* __restrict__ fb = stage + (dc[0] & 1023) * 64;
+        const float* __restrict__ fc = stage + (dc[1] & 1023) * 64;
         const int sgn = (dc[1] << 16) & 0x80000000;
-        bn = *reinterpret_cast<const f32x4*>(stage + (dc[0] & 1023) * 64);
-        bnb = __builtin_bit_cast(f32x4, *reinterpret_cast<const i32x4*>(stage + (dc[1] & 1023) * 64) ^ (i32x4){sgn, sgn, sgn, sgn});
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bn[q] = fb[q * 64];
+            bnb[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, fc[q * 64]) ^ sgn);
+        }
     }
 #pragma unroll 1
     for (int t0 = 0; t0 < nsteps; t0 += RING) {
@@ -678,12 +683,22 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
         for (int j = 0; j < RING; ++j) {
             const f32x4 av = ring[j];
             const int d = dc[2 * j], e1 = dc[2 * j + 1];
-            const f32x4 b = bn, bb = bnb;
+            float b[4], bb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                b[q] = bn[q];
+                bb[q] = bnb[q];
+            }
             {                                                  // operands of the next step, requested before this step's MFMAs (a wave issues in order)
                 const int dn = j + 1 < RING ? dc[(2 * j + 2) & 15] : dnx[0], en = j + 1 < RING ? dc[(2 * j + 3) & 15] : dnx[1];
+                const float* __restrict__ fb = stage + (dn & 1023) * 64;
+                const float* __restrict__ fc = stage + (en & 1023) * 64;
                 const int sgn = (en << 16) & 0x80000000;
-                bn = *reinterpret_cast<const f32x4*>(stage + (dn & 1023) * 64);
-                bnb = __builtin_bit_cast(f32x4, *reinterpret_cast<const i32x4*>(stage + (en & 1023) * 64) ^ (i32x4){sgn, sgn, sgn, sgn});
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bn[q] = fb[q * 64];
+                    bnb[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, fc[q * 64]) ^ sgn);
+                }
             }
             if (d & (1 << 12)) {                               // first step of a task: its rows, fresh accumulators
                 const int* __restrict__ rp = rtab + ((d >> 21) << 4);
@@ -691,17 +706,30 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
                 for (int r = 0; r < 4; ++r) roff[r] = rp[r];
                 acc = acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            const int nq1 = (d >> 10) & 3;                     // K-steps - 1
             if (e1 & (1 << 14)) {                              // paired: both columns on this fragment, two independent accumulator chains
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], b[q], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bb[q], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bb[0], acc2, 0, 0, 0);
+                if (nq1 >= 1) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b[1], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bb[1], acc2, 0, 0, 0);
+                    if (nq1 >= 2) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b[2], acc, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bb[2], acc2, 0, 0, 0);
+                        if (nq1 >= 3) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b[3], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bb[3], acc2, 0, 0, 0);
+                        }
+                    }
                 }
             } else {                                           // single column: K-steps alternate between the two chains
-#pragma unroll
-                for (int q = 0; q < 4; q += 2) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], b[q], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q + 1], b[q + 1], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);
+                if (nq1 >= 1) {
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b[1], acc2, 0, 0, 0);
+                    if (nq1 >= 2) {
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b[2], acc, 0, 0, 0);
+                        if (nq1 >= 3) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b[3], acc2, 0, 0, 0);
+                    }
                 }
             }
             if (d & (1 << 13)) {                               // last step of the task: add into the tile (all reads of a column, then its writes)
@@ -890,9 +918,6 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
         int* __restrict__ rt_l = reinterpret_cast<int*>(lds + A.rowtab_off);
         const int* __restrict__ rt_g = g_rowtab + A.rowtab_begin;
         for (int i = threadIdx.x; i < A.rowtab_len; i += IS_NT) rt_l[i] = rt_g[i];
-    }
-    if (LITE) {                                                // lite streams read whole 16-channel groups: what lies behind a block must be finite
-        for (int i = A.stage_off + threadIdx.x; i < A.ctr_off; i += IS_NT) lds[i] = 0.f;
     }
     IS_T(4);                                                   // zero fill
 

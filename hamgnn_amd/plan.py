@@ -533,9 +533,9 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
     """lite_mode, input-stationary schedule, r4: ALL folded items (IT_LINM) of one phase -- `recs`, stage offsets in [1], [2] -- as IS_WAVES
     balanced STREAMS of uniform steps, one work group each.  A TASK = (output segment, ONE 16-row tile, column m or column pair +-m): its steps
     run over every item and K group that feeds it, accumulate in registers and add into the tile once.  A step = one fragment (64 lanes x 4:
-    16 output rows x 16 input channels, PERMUTED K: lane (g, i) word q = weight of channel 16 G + 4 g + q, so the B operand is ONE 16-byte LDS
-    read per lane) + two descriptor words
-        d0 = B operand base / 64 floats | valid pieces - 1 << 10 | first step of the task << 12 | last << 13 | (m + 16) << 16 | row-table index / 16 << 21
+    16 output rows x up to 16 input channels = 1..4 MFMA K-steps; only the K-steps that hold channels are issued: 38 % of the steps of set-A
+    feed 4 channels, a quarter of a K group) + two descriptor words
+        d0 = B operand base / 64 floats | K-steps - 1 << 10 | first step of the task << 12 | last << 13 | (m + 16) << 16 | row-table index / 16 << 21
         d1 = 0, or for a PAIRED step: B base of column -m | 1 << 14 | negate << 15 | (-m + 16) << 16
     r3 / early r4 ran one stream per (phase, segment, row chunk) with rtm row tiles per step (_lite_runs): 147 streams per 16 edges whose first
     requests were exposed each (~37 per wave), 20 % padding steps, and per-step instruction counts that did not shrink with rtm = 1 (71 % of the
@@ -555,12 +555,11 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
                 assert ridx % 16 == 0 and ridx // 16 < 2048
                 st = []
                 for w, d0, d1 in steps:
-                    f = np.asarray(w[rt * 256:(rt + 1) * 256]).reshape(4, 16, 4)       # natural K [q'][i][g'] ... stored [g][i][q]: word q of lane (g, i) = channel 4 (4 G + q) + g
+                    f = np.asarray(w[rt * 256:(rt + 1) * 256]).reshape(4, 16, 4)       # [g][i][q]: word q of lane (g, i) = weight of channel 4 (4 G + q) + g (natural K)
                     if not np.any(f):
                         continue
-                    nv = ((d0 >> 10) & 3) + 1
-                    assert not np.any(f[:, :, nv:])                                     # K-steps beyond the block's pieces carry zero weights
-                    st.append((f.transpose(2, 1, 0).reshape(256), d0 | ((ridx // 16) << 21), d1))      # permuted K: word q of lane (g, i) = channel 4 (4 G + g) + q
+                    assert not np.any(f[:, :, ((d0 >> 10) & 3) + 1:])                   # K-steps beyond the block's pieces carry zero weights: not issued
+                    st.append((f.reshape(256), d0 | ((ridx // 16) << 21), d1))
                 if st:
                     tasks.append((st, seg))
     nw = min(IS_WAVES, max(1, len(tasks)))

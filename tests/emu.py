@@ -260,7 +260,7 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                                 d, e1 = int(desc[2 * t]), int(desc[2 * t + 1])
                                 b64, nv, first, last, tc, ridx = d & 1023, ((d >> 10) & 3) + 1, (d >> 12) & 1, (d >> 13) & 1, ((d >> 16) & 31) - 16, ((d >> 21) & 2047) * 16
                                 pair, negb, bb64, tcb = (e1 >> 14) & 1, (e1 >> 15) & 1, e1 & 1023, ((e1 >> 16) & 31) - 16
-                                F = Wall[w0 + t * 256:w0 + (t + 1) * 256].reshape(4, 16, 4)                          # [g][i][q]: out row i, channel 16 G + 4 g + q
+                                F = Wall[w0 + t * 256:w0 + (t + 1) * 256].reshape(4, 16, 4)                          # [g][i][q]: out row i, channel 4 (4 G + q) + g
                                 if first:
                                     acc = np.zeros((16, 16), dtype=dtype)
                                     accb = np.zeros((16, 16), dtype=dtype)
@@ -268,11 +268,11 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                                 if not F.any():
                                     assert not first and not last      # (padding step)
                                     continue
-                                assert not F[nv:].any()                                    # pieces beyond the block carry zero weights (the kernel reads whatever follows)
-                                for g in range(nv):
-                                    acc += F[g] @ piece(b64 + g)
+                                assert not F[:, :, nv:].any()                              # K-steps beyond the block's pieces are not issued
+                                for q in range(nv):
+                                    acc += F[:, :, q].T @ piece(b64 + q)
                                     if pair:
-                                        accb += F[g] @ (-piece(bb64 + g) if negb else piece(bb64 + g))
+                                        accb += F[:, :, q].T @ (-piece(bb64 + q) if negb else piece(bb64 + q))
                                 if last:
                                     for col in ([tc, tcb] if pair else [tc]):
                                         assert (ridx, col) not in stream_cells, "a (row tile, column) of a tile belongs to one task per phase"
