@@ -402,244 +402,13 @@ __device__ __forceinline__ void item_lite(const IsArgs& A, const float* __restri
     }
 }
 
-// IT_LINM with a deep weight ring: the item's fragments are ONE linear stream [column][source][K group][row tile]; a step (column c, fragment f)
-// issues 4 RTM MFMAs -- far fewer than an L2 round trip lasts -- so the fragments of step t + LM_RING are requested when step t starts
-// (ring slots are fixed registers: no shifting).  Measured: one-step look-ahead 48.8 ms per 822 k-edge launch, this ring see profiles/r03_lite.md
-#ifndef LM_RING
-#define LM_RING 4
-#endif
-template <int RTM>
-__device__ __forceinline__ void item_lite_m(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
-    const int so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], mm = it[6], neg = it[7], ksteps = it[8];
-    const int g = lane >> 4, el = lane & 15;
-    const int nc = 2 * mm + 1;
-    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23] + it[16];
-    float* __restrict__ tbase = lds + A.tile_shift + (el - mm * 16);      // (split launches without a post-op: this wave's private tile copy)
-    const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
-    const int nsrc = so1 >= 0 ? 2 : 1;
-    const int ngrp = (ksteps + 3) >> 2;
-    const int P1 = in_mulp >> 2;
-    const int cdir = neg ? -P1 : P1;
-    const int c0p = (li - mm) * P1 + (neg ? (nc - 1) * P1 : 0);
-    const int nfr = nsrc * ngrp, nsteps = nc * nfr;
-    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t, row tile rt: aw[(t * RTM + rt) * 64]
-    int roff[RTM][4];
-#pragma unroll
-    for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) roff[rt][r] = rtab[16 * rt + 4 * g + r];
-    f32x4 ring[LM_RING][RTM], acc[RTM];
-#pragma unroll
-    for (int j = 0; j < LM_RING; ++j)
-        if (j < nsteps) {
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
-        }
-#pragma unroll
-    for (int rt = 0; rt < RTM; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int c = 0, f = 0;
-#pragma unroll 1
-    for (int t0 = 0; t0 < nsteps; t0 += LM_RING) {
-#pragma unroll
-        for (int j = 0; j < LM_RING; ++j) {
-            const int t = t0 + j;
-            if (t < nsteps) {                                  // uniform
-                f32x4 av[RTM];
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
-                if (t + LM_RING < nsteps) {
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + LM_RING) * RTM + rt) * 64];
-                }
-                const int si = f >= ngrp, G = f - si * ngrp;
-                const float* __restrict__ fb = stage + (si ? so1 : so0) + (c0p + c * cdir + 4 * G) * 64;
-                const int nq = ksteps - 4 * G;
-                float b[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) b[q] = q < nq ? fb[q * 64] : 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
-                if (++f == nfr) {                              // column complete: add into the tile
-#ifndef HG_ABL_LINM_NOWB
-                    float told[RTM][4];                        // all reads, then all writes (see item_lite)
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + c * 16];
-#endif
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) {
-#pragma unroll
-#ifndef HG_ABL_LINM_NOWB
-                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + c * 16] = told[rt][r] + acc[rt][r];
-#else
-                        if (acc[rt][0] == 1.2345f) tbase[roff[rt][0]] = 0.f;
-#endif
-                        acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    }
-                    f = 0;
-                    ++c;
-                }
-            }
-        }
-    }
-}
-
-// lite_mode RUN (plan._lite_runs): all folded items of one (phase, output segment, row chunk) as ONE stream of steps ordered by tile column (pair).
-// step t: RTM weight fragments at stream + t * RTM * 256 and a two-word descriptor
-//   d0 = B operand base / 64 | K-steps - 1 << 10 | first << 12 | last << 13 | tile column << 16
-//   d1 = 0 | for a PAIRED step: second B operand base / 64 | 1 << 14 | negate << 15 | second tile column << 16
-// Columns +m and -m of a folded (input irrep, output irrep) pair share their weight matrix up to a sign: a paired step issues the MFMAs of
-// BOTH columns on one fragment group (8 RTM MFMAs per weight request), the sign rides on the second B operand.  Fragments AND descriptors of
-// step t + RL_RING are requested at step t -- across what used to be item boundaries -- and a column's accumulators persist across the items
-// that feed it (one tile read-modify-write per column and run).
-#ifndef RL_RING
-#define RL_RING 6
-#endif
-template <int RTM>
-__device__ __forceinline__ void run_lite(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
-    // request ring: RL_RING steps for one or two row tiles, 3 for three or four (a step then carries 12-32 MFMAs; 96 ring registers spilled)
-    constexpr int RING = RTM >= 3 ? RL_RING / 2 : RL_RING;
-    const int g = lane >> 4, el = lane & 15;
-    const int nsteps = it[8], lk = it[20];                     // nsteps: a multiple of RL_RING (no-op steps at the end), RL_RING more slots behind
-    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + it[23] + it[16];
-    float* __restrict__ tbase = lds + A.tile_shift + (el - lk * 16);
-    const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
-    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t, row tile rt: aw[(t * RTM + rt) * 64]
-    const int* __restrict__ dsc = reinterpret_cast<const int*>(Wb + it[12]);       // uniform address: the compiler makes these scalar loads
-    int roff[RTM][4];
-#pragma unroll
-    for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) roff[rt][r] = rtab[16 * rt + 4 * g + r];
-    f32x4 ring[RING][RTM], acc[RTM], acc2[RTM];             // acc2: the second column of a paired step / the odd K-steps of a single column
-    int dring[RING], ering[RING];
-#pragma unroll
-    for (int j = 0; j < RING; ++j) {
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[(j * RTM + rt) * 64];
-        dring[j] = dsc[2 * j];
-        ering[j] = dsc[2 * j + 1];
-        // slot order = request order: the scheduler issued these back to front, and the wait at the loop head -- one static instruction
-        // for both the first and the later iterations -- became vmcnt(0)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int rt = 0; rt < RTM; ++rt) acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // the B operands of step t + 1 are requested from LDS BEFORE the MFMAs of step t are issued (a wave issues in order: a read placed after
-    // a dependent MFMA chain waits for it).  The second operand is read for every step (unpaired: d1 = 0 -> the block at offset 0, unused)
-    float bn[4], bnb[4];
-    {
-        const int d0 = __builtin_amdgcn_readfirstlane(dring[0]), e0 = __builtin_amdgcn_readfirstlane(ering[0]);
-        const float* __restrict__ fb = stage + (d0 & 1023) * 64;
-        const float* __restrict__ fc = stage + (e0 & 1023) * 64;
-        const int nq = ((d0 >> 10) & 3) + 1;
-        const int sgn = (e0 << 16) & 0x80000000;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bn[q] = fb[(q < nq ? q : nq - 1) * 64];
-            bnb[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, fc[(q < nq ? q : nq - 1) * 64]) ^ sgn);
-        }
-    }
-#pragma unroll 1
-    for (int t0 = 0; t0 < nsteps; t0 += RING) {
-#pragma unroll
-        for (int j = 0; j < RING; ++j) {
-            const int t = t0 + j;
-            f32x4 av[RTM];
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) av[rt] = ring[j][rt];
-            const int d = __builtin_amdgcn_readfirstlane(dring[j]), e1 = __builtin_amdgcn_readfirstlane(ering[j]);
-            dring[j] = dsc[2 * (t + RING)];
-            ering[j] = dsc[2 * (t + RING) + 1];
-            float b[4], bb[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                b[q] = bn[q];
-                bb[q] = bnb[q];
-            }
-            {                                                  // operands of the next step (slot j + 1 holds step t + 1; after the wrap: the slot refilled above)
-                const int dn = __builtin_amdgcn_readfirstlane(dring[(j + 1) % RING]), en = __builtin_amdgcn_readfirstlane(ering[(j + 1) % RING]);
-                const float* __restrict__ fb = stage + (dn & 1023) * 64;
-                const float* __restrict__ fc = stage + (en & 1023) * 64;
-                const int nq = ((dn >> 10) & 3) + 1;
-                const int sgn = (en << 16) & 0x80000000;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    bn[q] = fb[(q < nq ? q : nq - 1) * 64];
-                    bnb[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, fc[(q < nq ? q : nq - 1) * 64]) ^ sgn);
-                }
-            }
-            if (e1 & (1 << 14)) {                              // paired: both columns on this fragment group, two independent accumulator chains
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) {
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
-                        acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bb[q], acc2[rt], 0, 0, 0);
-                    }
-            } else {                                           // single column: K-steps alternate between the two chains (no back-to-back dependent MFMAs for RTM = 1)
-#pragma unroll
-                for (int q = 0; q < 4; q += 2)
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) {
-                        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[q], acc[rt], 0, 0, 0);
-                        acc2[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q + 1], b[q + 1], acc2[rt], 0, 0, 0);
-                    }
-            }
-            if (d & (1 << 13)) {                               // column (pair) complete: add into the tile
-                const int tc = (d >> 16) & 31;
-                if (e1 & (1 << 14)) {
-                    const int tcb = (e1 >> 16) & 31;
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {     // one column at a time (register budget): all its reads, then all its writes
-                        const int col = half ? tcb : tc;
-                        float told[RTM][4];
-#pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + col * 16];
-#pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + col * 16] = told[rt][r] + (half ? acc2[rt][r] : acc[rt][r]);
-                    }
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                } else {
-                    float told[RTM][4];
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) told[rt][r] = tbase[roff[rt][r] + tc * 16];
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) {
-                        const f32x4 sum = acc[rt] + acc2[rt];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) tbase[roff[rt][r] + tc * 16] = told[rt][r] + sum[r];
-                        acc[rt] = acc2[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};      // the next step starts a column
-                    }
-                }
-            }
-            // the fragment requests of step t + RL_RING: NO branch around them (streams are padded: plan._lite_runs), and issued AFTER the
-            // step's MFMAs have read slot j -- requested before them, the new value cannot share the slot's registers, the compiler rotates
-            // the whole ring with v_mov at the loop's back-edge and has to wait for EVERY outstanding load there (vmcnt(0) once per RL_RING
-            // steps; ISA audit, profiles/r03_lite.md)
-#pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) ring[j][rt] = aw[((t + RING) * RTM + rt) * 64];
-        }
-    }
-}
-
 // lite_mode STREAM (plan._lite_streams, r4): the folded items of one phase dealt to the waves as streams of UNIFORM steps.  A task = (segment, one
 // 16-row tile, column m or pair +-m); a step = one fragment (16 rows x up to 16 input channels, natural K) + two descriptor words; only the
 // K-steps that hold channels are issued (1..4 MFMAs, twice that for a pair): the input irreps with 2-12 channels fill a quarter or three
 // quarters of a K group.  The accumulators of a task live in registers and are added into the tile at its last step through the row table.
-// One instantiation for every row-tile count (run_lite<RTM>: four), so the request ring is 8 deep at 8 x 4 registers; descriptors arrive in
-// blocks of 8 steps by ONE scalar load a block ahead (run_lite: a scalar load per step, which the step's MFMAs waited for -- a wave can only
-// wait for scalar loads with lgkmcnt(0)).
+// One instantiation for every row-tile count, so the request ring is 8 deep at 8 x 4 registers; descriptors arrive in blocks of 8 steps by
+// ONE scalar load a block ahead (the r3 runs -- one stream per (phase, segment, row chunk), rtm row tiles per step, profiles/r03_lite.md --
+// carried a scalar load per step, which the step's MFMAs waited for: a wave can only wait for scalar loads with lgkmcnt(0)).
 #ifndef SL_RING
 #define SL_RING 8
 #endif
@@ -660,7 +429,7 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
         ring[j] = aw[j * 64];
-        __builtin_amdgcn_sched_barrier(0);                     // slot order = request order (see run_lite)
+        __builtin_amdgcn_sched_barrier(0);                     // slot order = request order (the scheduler issued the priming loads back to front otherwise, and the loop head's one static wait became vmcnt(0))
     }
     i32x16 dc = dsc[0];
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
@@ -722,13 +491,13 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
                         }
                     }
                 }
-            } else {                                           // single column: K-steps alternate between the two chains
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);
+            } else {                                           // single column: one chain (a conditionally updated second one comes back as
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);      // register copies behind an MFMA-latency wait at the join)
                 if (nq1 >= 1) {
-                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b[1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b[1], acc, 0, 0, 0);
                     if (nq1 >= 2) {
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b[2], acc, 0, 0, 0);
-                        if (nq1 >= 3) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b[3], acc2, 0, 0, 0);
+                        if (nq1 >= 3) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b[3], acc, 0, 0, 0);
                     }
                 }
             }
@@ -752,10 +521,11 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
 #pragma unroll
                     for (int r = 0; r < 4; ++r) told[r] = tbase[roff[r] + tc];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tbase[roff[r] + tc] = told[r] + (acc[r] + acc2[r]);
+                    for (int r = 0; r < 4; ++r) tbase[roff[r] + tc] = told[r] + acc[r];
                 }
             }
-            ring[j] = aw[(t0 + j + RING) * 64];                // after the step's MFMAs have read slot j (see run_lite)
+            ring[j] = aw[(t0 + j + RING) * 64];                // AFTER the step's MFMAs have read slot j: requested before them, the new value cannot share the slot's registers
+                                                               // and the compiler rotates the whole ring with v_mov at the back-edge, waiting vmcnt(0) there
         }
         dc = dnx;
     }
@@ -995,14 +765,6 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
                         else post_is<4>(A, g_W, it, lds, erow, lane);
                     }
                     else if (it[0] == 6) stream_lite(A, g_W, it, lds, lane);
-                    else if (it[0] == 5 && it[9] == 1) run_lite<1>(A, g_W, it, lds, lane);
-                    else if (it[0] == 5 && it[9] == 2) run_lite<2>(A, g_W, it, lds, lane);
-                    else if (it[0] == 5 && it[9] == 3) run_lite<3>(A, g_W, it, lds, lane);
-                    else if (it[0] == 5) run_lite<4>(A, g_W, it, lds, lane);
-                    else if (it[0] == 4 && it[9] == 1) item_lite_m<1>(A, g_W, it, lds, lane);
-                    else if (it[0] == 4 && it[9] == 2) item_lite_m<2>(A, g_W, it, lds, lane);
-                    else if (it[0] == 4 && it[9] == 3) item_lite_m<3>(A, g_W, it, lds, lane);
-                    else if (it[0] == 4) item_lite_m<4>(A, g_W, it, lds, lane);
                     else if (it[9] == 1) item_lite<1>(A, g_W, it, lds, lane);
                     else if (it[9] == 2) item_lite<2>(A, g_W, it, lds, lane);
                     else if (it[9] == 3) item_lite<3>(A, g_W, it, lds, lane);

@@ -36,8 +36,6 @@ IT_TP = 0        # GEMM1 -> radial scale * CG coef -> GEMM2 -> add into segment 
 IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, add into tile
 IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: aligned-frame CG coefficient per m)
 IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
-LITE_RING = 6    # request ring of csrc/tp_is.hip:run_lite (RL_RING)
-IT_RUN = 5       # lite_mode, input-stationary schedule: ALL IT_LINM items of one (phase, segment, row chunk) as one stream of steps (plan._lite_runs)
 IT_STREAM = 6    # lite_mode, input-stationary schedule (r4): the folded items of one PHASE as IS_WAVES balanced streams of uniform steps (plan._lite_streams)
 LITE_SRING = 8   # request ring / descriptor block of csrc/tp_is.hip:stream_lite (SL_RING)
 IT_LINM = 4      # lite_mode, ALL paths (i, l_sh, k) of one (i, k) folded: one weight matrix per column, A_m = sum_paths cf_path[m] A_path (input-stationary kernel only)
@@ -211,7 +209,7 @@ class IsSchedule:
     balance: float                 # LPT estimate: sum(cost) / (waves * sum over phases of max wave cost), worst part
     part_cost: List[int]           # estimated MFMA-slot cost of every part (critical path over its phases)
     phase_cls: List[int] = field(default_factory=list)   # per phase: the radial weight generator of its tensor-product items
-    extra_weights: Optional[np.ndarray] = None          # lite_mode runs (IT_RUN): their weight / descriptor streams, appended to Program.weights on the device
+    extra_weights: Optional[np.ndarray] = None          # lite_mode streams (IT_STREAM): their weight / descriptor streams, appended to Program.weights on the device
 
     # single-part views (the common large-graph case; tests)
     @property
@@ -248,8 +246,6 @@ ITEM_OVERHEAD = int(os.environ.get("HG_ITEM_OVH", "60"))
 def _item_cost(rec, segs, hp4, vsegs=()):
     if int(rec[0]) == IT_STREAM:
         return int(rec[8]) * 7 + 60
-    if int(rec[0]) == IT_RUN:                                   # measured: a step costs ~860 cycles almost independently of its 4 rtm MFMAs (profiles/r03_lite.md)
-        return int(rec[8]) * (6 + int(rec[9])) + 60
     typ, nsrc, nc, rtm = int(rec[0]), (2 if rec[2] >= 0 else 1), 2 * int(rec[6]) + 1, int(rec[9])
     c = nsrc * int(rec[8]) * rtm * nc + ITEM_OVERHEAD          # GEMM1 + a per-item latency allowance (in MFMA slots)
     if typ == IT_TP:
@@ -336,8 +332,8 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
             for m in range(nseg):
                 if key_of[m] == sg:
                     owner[m] = r
-    # lite_mode programs with folded items: runs (see _lite_runs) unless HG_LITE_RUNS=0
-    runs = dict(base=int(prog.weights.size), w=[]) if ((prog.item_table[:, 0] == IT_LINM).any() and os.environ.get("HG_LITE_RUNS", "1") != "0") else None
+    # lite_mode programs with folded items: their step streams (_lite_streams) are appended to the weight blob
+    runs = dict(base=int(prog.weights.size), w=[]) if (prog.item_table[:, 0] == IT_LINM).any() else None
     segs_all, btab, ptab, gtab, items_all, parttab, part_cost, rowtab_all = [], [], [], [], [], [], [], []
     phase_cls_all: List[int] = []
     lds_floats, worst_balance = 0, 1.0
@@ -365,113 +361,12 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
                       extra_weights=(np.concatenate(runs["w"]) if runs is not None and runs["w"] else None))
 
 
-def _lite_runs(prog: "Program", recs, runs: dict):
-    """lite_mode, input-stationary schedule: the IT_LINM items of one (phase, output segment) -- `recs`, stage offsets already in [1], [2] --
-    regrouped into RUNS (one per row chunk of the segment): a run is a linear stream of STEPS, every step = one fragment group (rtm x 64 x 4
-    weights) + a descriptor of two words:
-        d0 = B operand base / 64 floats into the staging area | K-steps - 1 << 10 | first step of the column group << 12 | last << 13 | tile column << 16
-        d1 = 0, or for a PAIRED step: B operand base of the second column | 1 << 14 | negate << 15 | its tile column << 16
-    Columns +m and -m of an (input irrep, output irrep) pair carry the SAME folded weight matrix up to a sign (every path of the pair has the
-    parity of l_i + l_sh + l_k, so its aligned-frame coefficient is even or odd in m): a paired step feeds both columns from one fragment group
-    (8 rtm MFMAs per weight request instead of 4 rtm, about half the steps and weight bytes of r3), the sign rides on the second B operand; the
-    centre column of an odd pair is identically zero and is not issued at all.  The accumulators of a column (pair) persist across the items
-    that feed it (one tile read-modify-write per column and run), the fragments and descriptors of step t + ring are requested at step t --
-    across what used to be item boundaries (csrc/tp_is.hip:run_lite).  Streams are appended to runs["w"] (floats; the descriptors as int32 bit
-    patterns); returns the runs as item records of type IT_RUN."""
-    Wt = prog.weights
-    pairing = os.environ.get("HG_LITE_PAIR", "1") != "0"
-    by_chunk: Dict[Tuple[int, int], list] = {}
-    for r in recs:
-        by_chunk.setdefault((int(r[16]), int(r[9])), []).append(r)
-    out = []
-    for (row_off, rtm), items in by_chunk.items():
-        seg = int(items[0][19])
-        lk = int(prog.seg_table[seg][0])
-
-        def item_steps(r, m):
-            """steps of item r for output column m: (weights, B base / 64, K-steps) per (source, K group); None if the column is not fed"""
-            so0, so1, in_mulp, li, mm, neg, ksteps, a1, colstride = int(r[1]), int(r[2]), int(r[4]), int(r[5]), int(r[6]), int(r[7]), int(r[8]), int(r[11]), int(r[13])
-            if abs(m) > mm:
-                return None
-            c = m + mm
-            nsrc, ngrp, P1 = (2 if so1 >= 0 else 1), ceil_div(ksteps, 4), in_mulp // 4
-            cdir = -P1 if neg else P1
-            c0p = (li - mm) * P1 + ((2 * mm) * P1 if neg else 0)
-            st = []
-            for si in range(nsrc):
-                for G in range(ngrp):
-                    base = (so1 if si else so0) + (c0p + c * cdir + 4 * G) * 64
-                    assert base % 64 == 0 and 0 <= base // 64 < 1024
-                    woff = a1 + c * colstride + (si * ngrp + G) * rtm * 256
-                    st.append((Wt[woff:woff + rtm * 256], base // 64, min(4, ksteps - 4 * G)))
-            return st
-
-        frags, desc = [], []
-
-        def emit(steps):                                       # steps: (weights, d0 without first / last, d1)
-            for n_, (w, d0, d1) in enumerate(steps):
-                frags.append(w)
-                desc.append(d0 | ((1 if n_ == 0 else 0) << 12) | ((1 if n_ == len(steps) - 1 else 0) << 13))
-                desc.append(d1)
-
-        for m in range(0, lk + 1):
-            cols = {}
-            for sign_m in ((m,) if m == 0 else (m, -m)):
-                cols[sign_m] = [item_steps(r, sign_m) for r in items]
-            paired = pairing and m > 0
-            signs = []
-            if paired:                                         # W(-m) == +-W(m) for every item (always true for folded lite items; checked, not assumed)
-                for sa, sb in zip(cols[m], cols[-m]):
-                    if sa is None:
-                        signs.append(0)
-                        continue
-                    wa, wb = np.concatenate([x[0] for x in sa]), np.concatenate([x[0] for x in sb])
-                    if np.array_equal(wa, wb):
-                        signs.append(1)
-                    elif np.array_equal(wa, -wb):
-                        signs.append(-1)
-                    else:
-                        paired = False
-                        break
-            if paired:
-                steps = []
-                for sa, sb, sg_ in zip(cols[m], cols[-m], signs):
-                    if sa is None or not any(np.any(x[0]) for x in sa):
-                        continue
-                    for (w, ba, nq), (_, bb, _) in zip(sa, sb):
-                        steps.append((w, ba | ((nq - 1) << 10) | ((lk + m) << 16), bb | (1 << 14) | ((1 if sg_ < 0 else 0) << 15) | ((lk - m) << 16)))
-                emit(steps)
-            else:
-                for mm_ in cols:
-                    steps = []
-                    for sa in cols[mm_]:
-                        if sa is None or not any(np.any(x[0]) for x in sa):      # (the centre column of an odd pair: all-zero weights)
-                            continue
-                        steps += [(w, ba | ((nq - 1) << 10) | ((lk + mm_) << 16), 0) for (w, ba, nq) in sa]
-                    emit(steps)
-        # the kernel's request ring runs LITE_RING steps ahead WITHOUT a branch around the loads (a conditional load makes the compiler wait for
-        # every outstanding one at the join: vmcnt(0) per step): steps padded to a multiple of the ring with no-ops (zero weights, no column
-        # boundary), LITE_RING more slots behind the last step for the requests that run past it
-        nst = len(desc) // 2
-        npad = (-nst) % LITE_RING
-        nreal = nst + npad
-        frags += [np.zeros(rtm * 256)] * (npad + LITE_RING)
-        desc += [0, 0] * (npad + LITE_RING)
-        w_off = runs["base"] + sum(x.size for x in runs["w"])
-        wblob = np.concatenate(frags).astype(np.float64)
-        dblob = np.asarray(desc, dtype=np.int32).view(np.float32).astype(np.float64)       # bit patterns ride in the float blob (exact: float32 -> float64 -> float32)
-        pad = (-len(desc)) % 4
-        runs["w"] += [wblob, dblob, np.zeros(pad)]
-        rec = np.zeros(ITEM_I32, dtype=np.int64)
-        rec[0], rec[8], rec[9], rec[11], rec[12], rec[16], rec[19] = IT_RUN, nreal, rtm, w_off, w_off + wblob.size, row_off, seg
-        rec[2] = -1
-        out.append(rec)
-    return out
-
-
 def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool):
     """the column tasks of one (segment, row chunk): for every output column m (or pair +-m) the list of steps (fragment group [rtm * 256], d0, d1)
-    over all folded items that feed it -- see _lite_runs for the descriptor words and the pairing rule"""
+    over all folded items that feed it (descriptor words: _lite_streams).  Columns +m and -m of an (input irrep, output irrep) pair carry the SAME
+    folded weight matrix up to a sign (every path of the pair has the parity of l_i + l_sh + l_k, so its aligned-frame coefficient is even or odd
+    in m): a PAIRED step feeds both columns from one fragment (checked per item, not assumed), the sign rides on the second B operand; the
+    centre column of an odd pair is identically zero and is not issued at all."""
     Wt = prog.weights
 
     def item_steps(r, m):
@@ -537,7 +432,7 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
     feed 4 channels, a quarter of a K group) + two descriptor words
         d0 = B operand base / 64 floats | K-steps - 1 << 10 | first step of the task << 12 | last << 13 | (m + 16) << 16 | row-table index / 16 << 21
         d1 = 0, or for a PAIRED step: B base of column -m | 1 << 14 | negate << 15 | (-m + 16) << 16
-    r3 / early r4 ran one stream per (phase, segment, row chunk) with rtm row tiles per step (_lite_runs): 147 streams per 16 edges whose first
+    r3 / early r4 ran one stream per (phase, segment, row chunk) with rtm row tiles per step (profiles/r03_lite.md): 147 streams per 16 edges whose first
     requests were exposed each (~37 per wave), 20 % padding steps, and per-step instruction counts that did not shrink with rtm = 1 (71 % of the
     steps).  Tasks of different segments and row tiles are independent (disjoint tile rows / columns), so the planner deals them to the waves
     by LPT on their exact step counts: 4 streams per phase, padded once each.  Returns IT_STREAM item records."""
@@ -705,10 +600,8 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         else:                                                  # a work group's items by radial generator: the kernel keeps the hidden rows of
             units = [sorted(recs, key=lambda r: int(r[10]) if int(r[0]) == IT_TP else -1) for recs in by_seg.values()]      # ONE generator in registers
         if runs is not None and all(int(r[0]) == IT_LINM for recs in units for r in recs):
-            if os.environ.get("HG_LITE_STREAMS", "1") != "0":  # r4: the phase's folded items as IS_WAVES balanced streams of uniform steps
-                units = [[st] for st in _lite_streams(prog, [r for recs in units for r in recs], runs, {sg: rt_base[n] for sg, n in local.items()})]
-            else:
-                units = [[run] for recs in units for run in _lite_runs(prog, recs, runs)]      # one run = one work group (disjoint rows of a tile)
+            # the phase's folded items as IS_WAVES balanced streams of uniform steps, one work group each (disjoint (row tile, column) cells of the tiles)
+            units = [[st] for st in _lite_streams(prog, [r for recs in units for r in recs], runs, {sg: rt_base[n] for sg, n in local.items()})]
         groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
         loads = [0] * IS_WAVES
         for c, n in groups:                                    # claim order = LPT order

@@ -285,55 +285,6 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                                     acc = accb = None
                             assert acc is None
                             continue
-                        if int(it[0]) == P.IT_RUN:             # lite_mode run: a stream of steps over the items of one (phase, segment, row chunk)
-                            assert ii not in seen
-                            seen.add(ii)
-                            sg = int(it[19])
-                            seg = sched.seg_table[sg]
-                            lk_, rtm_ = int(seg[0]), int(it[9])
-                            Wall = np.concatenate([prog.weights.astype(dtype), sched.extra_weights.astype(dtype)])
-                            nst, w0, d0 = int(it[8]), int(it[11]), int(it[12])
-                            assert nst % P.LITE_RING == 0                                     # padded with no-op steps; LITE_RING more slots follow
-                            desc = Wall[d0:d0 + 2 * (nst + P.LITE_RING)].astype(np.float32).view(np.int32)      # two words per step (plan._lite_runs)
-                            assert not desc[2 * nst:].any() and not Wall[w0 + nst * rtm_ * 256:w0 + (nst + P.LITE_RING) * rtm_ * 256].any()
-                            rt = rowtab[int(it[23]) + int(it[16]):int(it[23]) + int(it[16]) + 16 * rtm_]
-
-                            def operand(b64, q):
-                                """B operand rows [4 K slots, 16 edges] of K-step q behind operand base b64 (64-float units into the staging area)"""
-                                o0 = max(o for o in staged if o <= b64 * 64)
-                                s0, s1, in_off, in_mulp, li = staged[o0]
-                                size = -(-((2 * li + 1) * (in_mulp // 4)) // 4) * 256
-                                src_i, rel_ = (s0, b64 * 64 - o0) if b64 * 64 - o0 < size else (s1, b64 * 64 - o0 - size)
-                                a, s_ = divmod(rel_ // 64 + q, in_mulp // 4)
-                                B = np.zeros((4, 16), dtype=dtype)
-                                for g in range(4):
-                                    B[g, :ne] = srcs[src_i][cols, in_off + a * in_mulp + 4 * s_ + g]
-                                return B
-                            acc = accb = None
-                            for t in range(nst):
-                                d, e1 = int(desc[2 * t]), int(desc[2 * t + 1])
-                                b64, nq, first, last, tc = d & 1023, ((d >> 10) & 3) + 1, (d >> 12) & 1, (d >> 13) & 1, (d >> 16) & 31
-                                pair, negb, bb64, tcb = (e1 >> 14) & 1, (e1 >> 15) & 1, e1 & 1023, (e1 >> 16) & 31
-                                A1 = Wall[w0 + t * rtm_ * 256:w0 + (t + 1) * rtm_ * 256].reshape(rtm_, 4, 16, 4)      # [rt][g][i][q]
-                                if first:
-                                    acc = np.zeros((rtm_, 16, 16), dtype=dtype)
-                                    accb = np.zeros((rtm_, 16, 16), dtype=dtype)
-                                for q in range(nq):
-                                    B = operand(b64, q)
-                                    Bb = (-operand(bb64, q) if negb else operand(bb64, q)) if pair else None
-                                    for r_ in range(rtm_):
-                                        acc[r_] += A1[r_, :, :, q].T @ B
-                                        if pair:
-                                            accb[r_] += A1[r_, :, :, q].T @ Bb
-                                if last:
-                                    for r_ in range(rtm_):
-                                        for i_ in range(16):
-                                            base = int(rt[16 * r_ + i_])
-                                            lds[base + (tc - lk_) * 16:base + (tc - lk_) * 16 + 16] += acc[r_, i_]
-                                            if pair:
-                                                lds[base + (tcb - lk_) * 16:base + (tcb - lk_) * 16 + 16] += accb[r_, i_]
-                            touched.add(sg)
-                            continue
                         if int(it[0]) == P.IT_POST:            # lite_mode post-op of one segment (the part's last phase, nothing staged): in place on its tile
                             assert b0 == b1 and ii not in seen
                             seen.add(ii)

@@ -27,17 +27,18 @@ def test_tp_is_register_budget_and_no_scratch(tp_is):
         assert m["vgprs"] <= 256, (k["name"], m)                # 2 waves per SIMD need <= 256; r4: 250 / 251 / 231 / 233 (16 of them hold the resident hidden rows)
 
 
-def test_lite_run_loop_keeps_its_ring_lookahead(tp_is):
-    lite = [k for k in tp_is if "tp_is_kernel" in k["name"] and "ELb1EEv" in k["name"] and "ILb0ELb1" in k["name"]]
+def test_lite_stream_loop_keeps_its_ring_lookahead(tp_is):
+    lite = [k for k in tp_is if "tp_is_kernel" in k["name"] and "ILb0ELb1" in k["name"]]
     assert len(lite) == 1
-    # a PAIRED step of run_lite<RTM> (r4: columns +m and -m on one fragment group): 8 RTM MFMAs, RTM fragment requests, 8 operand reads from LDS
-    steps = [(lab, s) for lab, _, s, _ in lite[0]["blocks"]
-             if s.count("M") in (8, 16, 24, 32) and 1 <= s.count("G") <= 4 and s.count("r") >= 8]
-    steps = [(lab, s) for lab, s in steps if s.count("G") * 8 == s.count("M")]
-    assert len(steps) >= 12, len(steps)                         # 6 / 3 unrolled steps x 4 row-tile counts
-    for lab, s in steps:
-        assert not re.search(r"\[v\(0\)", s), (lab, s)          # every fragment wait leaves younger requests in flight
-    # the tile read-modify-write of a finished column: all reads, then all writes (was read -> wait -> write per element)
+    # stream_lite (r4): the blocks that issue a step's MFMAs (1..8 of them, behind one wait for the step's fragment): 8 unrolled steps x
+    # {paired, single}; the fragment wait leaves the 7 younger requests of the ring in flight, and no scalar load sits inside a step
+    # (the r3 runs: one per step, waited for with lgkmcnt(0) by the step's MFMAs)
+    step = [(lab, s) for lab, _, s, _ in lite[0]["blocks"] if re.fullmatch(r"(\[[^\]]*\])+M{1,8}(\[l\(\d+\)\]M{1,4})?", s)]
+    ring = [(lab, s) for lab, s in step if "v(7)" in s]
+    assert len(ring) >= 14, [s for _, s in step]
+    for lab, s in ring:
+        assert "v(0)" not in s and "S" not in s, (lab, s)
+    # the tile read-modify-write of a finished task: all reads, then all writes (was read -> wait -> write per element)
     for lab, _, s, f in lite[0]["blocks"]:
         assert "SERIAL-RMW" not in f, (lab, s)
 
