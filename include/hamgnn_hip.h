@@ -96,7 +96,8 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
  * the four waves, which claim the phase's work groups dynamically.
  *   seg_table   int32[nseg][8]   = {lk, mul_k, rto, out_off, out_mulp, tile_off, Wigner stage_off, flags (| 1<<16: new batch)}
  *   block_table int32[nblock][8] = {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
- *   phase_table int32[nphase][4] = {block_begin, block_end, group_begin, group_end};  group_table int32[ngroup][2] = item range
+ *   phase_table int32[nphase][8] = {block_begin, block_end, group_begin, group_end, radial generator (0 / 1) whose hidden rows the kernel
+ *               keeps in registers for the phase's items or -1, 0, 0, 0};  group_table int32[ngroup][2] = item range
  *   item_table  int32[nitems][24]: as for hg_tp_fused with [1], [2] = stage offsets of source 0 / 1 (-1), [19] = segment,
  *               [20..22] = {lk, mul_k, rto} of that segment, [23] = first row-table entry of the rows its GEMM2 writes
  *   row_table   int32: per part, for every output row (segment, 16-row tile, row) of GEMM2 the LDS float offset (relative to a tile
@@ -113,7 +114,13 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
  * src_idx[i] (nullable): row gather of source i; rot_mask bit i: source i holds GLOBAL-frame
  * node rows that are gathered and rotated by D^l(R_e) while staged -- the node_features[sender/receiver] gathers of
  * convolution.py:138-141 / interaction_blocks.py:141-145 fused into the operand staging (no hg_rotate_gather pass, no per-edge
- * copies of the node rows).                                                                                                */
+ * copies of the node rows).
+ * edge_perm (nullable): DEVICE int64[rows], tile slot -> edge whose rows the slot reads (receiver-major launch order); run_id (nullable,
+ * single-part launches only): DEVICE int32[rows], slot -> OUTPUT row that takes the sum of the slot's run of equal receivers (runs never
+ * cross a 16-slot tile; -1: padding slot) -- the receiver scatter of convolution.py:147-149 as a segmented reduce in the epilogue; `out`
+ * then holds one row per run (hamgnn_amd/topo.py:Topology.receiver_major), summed per receiver by hg_segment_sum.
+ * lite_mode programs: items of type 6 (IT_STREAM, plan._lite_streams) carry [8] = steps, [11] / [12] = float offsets of the fragment and
+ * descriptor streams inside `weights` (64-byte aligned).                                                                      */
 int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
              int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
              const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table, const int32_t* item_table,
