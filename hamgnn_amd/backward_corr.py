@@ -36,8 +36,9 @@ def _entries(tab: Dict, device):
 
 
 def sym_contraction_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W1: torch.Tensor, W2: torch.Tensor, C: int, g_out: torch.Tensor,
-                             chunk: int = 4096):
-    """h, g_out: planar hidden rows [N, Dp]; W1 [nel, K1, C], W2 [nel, K2, C].  Returns (g_h [N, Dp], g_W1, g_W2)."""
+                             chunk: int = 4096, per_node: bool = False):
+    """h, g_out: planar hidden rows [N, Dp]; W1 [nel, K1, C], W2 [nel, K2, C].  Returns (g_h [N, Dp], g_W1, g_W2).
+    per_node: W1 / W2 hold one weight block PER NODE (z = arange(N): the charge-doped attributes mix the element blocks, nn.CorrProductBlock)."""
     E = _entries(tab, h.device)
     N, Dp = h.shape
     dt = h.dtype
@@ -60,7 +61,10 @@ def sym_contraction_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W1: to
         t1 = G[:, E["o1"]] * E["v1"][None, :, None].to(dt)        # [n, E1, C]
         gH = ops.scatter_cols(E["x1"], t1 * W1[zc][:, E["k1"]], nell)
         p1 = ops.scatter_cols(E["k1"], t1 * H[:, E["x1"]], W1.shape[1])
-        gW1 += ops.scatter_rows(zc, p1, W1.shape[0])
+        if per_node:
+            gW1[sl] = p1
+        else:
+            gW1 += ops.scatter_rows(zc, p1, W1.shape[0])
         # nu = 2
         t2 = G[:, E["o2"]] * E["v2"][None, :, None].to(dt)        # [n, E2, C]
         hx, hi = H[:, E["x2"]], H[:, E["i2"]]
@@ -68,6 +72,9 @@ def sym_contraction_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W1: to
         gH = gH + ops.scatter_cols(E["x2"], tw * hi, nell)
         gH = gH + ops.scatter_cols(E["i2"], tw * hx, nell)
         p2 = ops.scatter_cols(E["k2"], t2 * hx * hi, W2.shape[1])
-        gW2 += ops.scatter_rows(zc, p2, W2.shape[0])
+        if per_node:
+            gW2[sl] = p2
+        else:
+            gW2 += ops.scatter_rows(zc, p2, W2.shape[0])
         g_h[sl].index_add_(1, hcol.reshape(-1), gH.reshape(n, -1))     # (distinct columns: nothing is summed here)
     return g_h, gW1, gW2

@@ -95,8 +95,6 @@ class _BackboneBase(nn.Module):
         self.use_gradient_checkpointing = bool(g("use_gradient_checkpointing", False))
         self.apply_charge_doping = bool(g("apply_charge_doping", False))                 # hamgnn_conv.py:147-153
         if self.apply_charge_doping:
-            if self.use_corr_prod:
-                raise NotImplementedError("apply_charge_doping with use_corr_prod: the symmetric contraction gathers element weights by z")
             self.atomic_embedding = hnn.ChargeEmbedding(self.num_types, int(g("num_charge_attr_feas", 8)))
         if g("edge_sh_normalization", "component") != "component" or not g("edge_sh_normalize", True):
             raise NotImplementedError("only component-normalised, normalised edge SH are supported")
@@ -218,12 +216,21 @@ class _BackboneBase(nn.Module):
                 grads[pre + k] = torch.zeros_like(p_).reshape(-1)
         return g_node, g_f
 
+    @staticmethod
+    def _add_g_delta(rep, g):
+        """gradient with respect to the charge-doping correction from a consumer other than the embeddings (the CorrProductBlocks)"""
+        if g is not None:
+            rep["_g_delta_extra"] = g if rep.get("_g_delta_extra") is None else rep["_g_delta_extra"] + g
+
     def _backward_embeddings(self, data, rep, geo, g_node, g_f, grads, chunk):
         """edge rows from the pair embedding, node rows = rows of the chemical embedding table (+ the charge-doping correction)"""
         z = data.z.contiguous()
         delta = rep.get("_charge_delta")                        # apply_charge_doping: node_attrs = one_hot(z) + delta
         g_emb = self.pair_embedding.backward(z, geo, g_f, chunk=chunk, delta=delta)
         g_delta = g_emb.pop("_g_delta", None)
+        extra = rep.pop("_g_delta_extra", None)
+        if extra is not None:
+            g_delta = extra if g_delta is None else g_delta + extra.to(g_delta.dtype)
         grads.update({"pair_embedding." + k: v for k, v in g_emb.items()})
         T, lay = self.num_types, self.layout
         gtab = ops.scatter_rows(z, g_node, T)                   # fixed summation order (no float atomics)
@@ -315,7 +322,7 @@ class HamGNNConvE3(_BackboneBase):
             if self.use_corr_prod:                              # CorrProductBlock.forward (interaction_blocks.py:234-260; hamgnn_conv.py:274-275)
                 if tape is not None:
                     tape[-1]["node_res"] = node                 # the ResidualBlock's output = the CorrProductBlock's input
-                node = self.corr_products[li](node, z)
+                node = self.corr_products[li](node, z, self._last_delta)
             if tape is not None:
                 tape[-1]["node_out"] = node
             f = self._run_pair(pair, node, f, geo)
@@ -354,7 +361,8 @@ class HamGNNConvE3(_BackboneBase):
             g_node, g_f = self._backward_pair(li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk, data)
             # ---- ConvBlockE3 (convolution.py:116-160): node_out = residual(agg) + skip(node_in), agg = scatter_dst MP(node_in[src], node_in[dst], f_in)
             if self.use_corr_prod:                              # CorrProductBlock between the ConvBlock's residual and the pair block
-                g_node, g_cp = self.corr_products[li].backward(t["node_res"], z, g_node)
+                g_node, g_cp = self.corr_products[li].backward(t["node_res"], z, g_node, delta=rep.get("_charge_delta"))
+                self._add_g_delta(rep, g_cp.pop("_g_delta", None))
                 put(f"corr_products.{li}.", g_cp)
             pre = f"convolutions.{li}."
             g_agg, g_res = conv.residual.backward(agg, g_node, extra_given=True)

@@ -64,7 +64,7 @@ class HamGNNTransformer(_BackboneBase):
             node = att.run(node, f, geo, self._rot_tab, rowptr, perm, data)        # AttentionBlockE3.forward (attention.py:315-360)
             if tape is not None:
                 tape[-1]["node_att"] = node
-            node = corr(node, z)                                                    # CorrProductBlock.forward (interaction_blocks.py:234-260)
+            node = corr(node, z, self._last_delta)                                  # CorrProductBlock.forward (interaction_blocks.py:234-260)
             if tape is not None:
                 tape[-1]["node_out"] = node
             f = self._run_pair(pair, node, f, geo)
@@ -88,7 +88,8 @@ class HamGNNTransformer(_BackboneBase):
         for li in reversed(range(self.num_layers)):
             att, corr, pair, t = self.orb_transformers[li], self.corr_products[li], self.pair_interactions[li], tape[li]
             g_node, g_f = self._backward_pair(li, pair, t["node_out"], t["f_in"], geo, topo, g_node, g_f, grads, chunk, data)
-            g_node, g_cp = corr.backward(t["node_att"], z, g_node)
+            g_node, g_cp = corr.backward(t["node_att"], z, g_node, delta=rep.get("_charge_delta"))
+            self._add_g_delta(rep, g_cp.pop("_g_delta", None))
             grads.update({f"corr_products.{li}." + k: v for k, v in g_cp.items()})
             g_node, g_f_att, g_at = att.backward(t["node_in"], t["f_in"], geo, self._rot_tab, topo, g_node, chunk=chunk, data=data)
             grads.update({f"orb_transformers.{li}." + k: v for k, v in g_at.items()})

@@ -1011,20 +1011,39 @@ class CorrProductBlock(nn.Module):
         self._hdim = P.PlanarLayout(self.irreps_hidden).dim
         return self
 
-    def backward(self, node_planar, z, g_out):
+    def _mixed(self, z, delta):
+        """apply_charge_doping: the reference contracts the element weights with node_attrs = one_hot(z) + delta (interaction_blocks.py:251,
+        symmetric_contraction.py einsum '...,ek'), i.e. every node gets its own mixture of the element blocks: W_eff[n] = W[z_n] + delta_n @ W.
+        Returns (attrs [N, T], per-node weights, node index as the 'element' index) for the same kernel."""
+        T = self._W1.shape[0]
+        A = torch.nn.functional.one_hot(z.long(), T).to(self._W1.dtype) + delta.to(self._W1.dtype)
+        W1e = (A @ self._W1.reshape(T, -1)).reshape(-1, *self._W1.shape[1:]).contiguous()
+        W2e = (A @ self._W2.reshape(T, -1)).reshape(-1, *self._W2.shape[1:]).contiguous()
+        return A, W1e, W2e, torch.arange(z.shape[0], device=z.device, dtype=z.dtype)
+
+    def backward(self, node_planar, z, g_out, delta=None):
         """gradient of forward(node, z) for the gradient g_out of the rows it returned: (g_node, {parameter name: gradient}).
-        Linears: streaming-kernel adjoints + GEMM weight gradients; the symmetric contraction: hamgnn_amd/backward_corr.py."""
+        Linears: streaming-kernel adjoints + GEMM weight gradients; the symmetric contraction: hamgnn_amd/backward_corr.py.
+        With the charge-doping correction `delta` the gradient with respect to it comes back under the key "_g_delta"."""
         from .backward_corr import sym_contraction_backward
         if self._tab is None:
             self.compile(node_planar.device)
         h = self.linear_pre(node_planar)
-        c = ops.sym_contraction(h, z, self.num_hidden, self._tab, self._W1, self._W2, self._hdim)
+        W1, W2, zi = self._W1, self._W2, z
+        if delta is not None:
+            A, W1, W2, zi = self._mixed(z, delta)
+        c = ops.sym_contraction(h, zi, self.num_hidden, self._tab, W1, W2, self._hdim)
         p = self.prod.linear(c)
         grads = {"linear_out.weight": self.linear_out.weight_grad(p, g_out), }
         g_p = self.linear_out.backward_data(g_out)
         grads["prod.linear.weight"] = self.prod.linear.weight_grad(c, g_p)
         g_c = self.prod.linear.backward_data(g_p)
-        g_h, gW1, gW2 = sym_contraction_backward(self._tab, h, z, self._W1, self._W2, self.num_hidden, g_c)
+        g_h, gW1, gW2 = sym_contraction_backward(self._tab, h, zi, W1, W2, self.num_hidden, g_c, per_node=delta is not None)
+        if delta is not None:                                  # per-node gradients back onto the element blocks and onto the attributes
+            T = self._W1.shape[0]
+            f1, f2 = gW1.reshape(gW1.shape[0], -1), gW2.reshape(gW2.shape[0], -1)
+            grads["_g_delta"] = f1 @ self._W1.reshape(T, -1).t() + f2 @ self._W2.reshape(T, -1).t()
+            gW1, gW2 = (A.t() @ f1).reshape(self._W1.shape), (A.t() @ f2).reshape(self._W2.shape)
         k1 = k2 = 0
         for i, con in enumerate(self.prod.symmetric_contractions.contractions):   # the concatenated weights back to one block per target irrep
             n1, n2 = con.weights[0].shape[1], con.weights_max.shape[1]
@@ -1040,11 +1059,16 @@ class CorrProductBlock(nn.Module):
             grads["linear_sc.weight"] = torch.zeros_like(self.linear_sc.weight).reshape(-1)
         return g_node, grads
 
-    def forward(self, node_planar, z):
-        """returns the new planar node rows (the reference writes them back into the graph dict)"""
+    def forward(self, node_planar, z, delta=None):
+        """returns the new planar node rows (the reference writes them back into the graph dict); delta: the charge-doping correction of
+        the node attributes [N, num_elements] or None"""
         if self._tab is None:
             self.compile(node_planar.device)
         h = self.linear_pre(node_planar)
-        c = ops.sym_contraction(h, z, self.num_hidden, self._tab, self._W1, self._W2, self._hdim)
+        if delta is not None:
+            _, W1, W2, zi = self._mixed(z, delta)
+            c = ops.sym_contraction(h, zi, self.num_hidden, self._tab, W1, W2, self._hdim)
+        else:
+            c = ops.sym_contraction(h, z, self.num_hidden, self._tab, self._W1, self._W2, self._hdim)
         skip = [self.linear_sc(node_planar)] if self.use_skip_connections else []
         return self.linear_out(self.prod.linear(c), res=skip)

@@ -782,6 +782,29 @@ def main():
     _save("backbone_charge_doping", weights={k: v for k, v in ref5.state_dict().items() if k in dict(mine5.named_parameters())},
           graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
           outputs=outs5, meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg5["HamGNN_pre"]).items()}))))
+    # apply_charge_doping together with use_corr_prod (the reference's default when the key is missing, main.py:216-217): the symmetric
+    # contraction mixes its element weights with the DOPED node attributes (interaction_blocks.py:251)
+    print("charge doping + CorrProductBlock")
+    cfg5c = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, apply_charge_doping=True, num_charge_attr_feas=8, use_corr_prod=True,
+                                                                 num_hidden_features=4).items() if k != 'radius_scale'}))
+    torch.manual_seed(23)
+    ref5c, mine5c = ref_conv.HamGNNConvE3(cfg5c), R.HamGNNConvE3(dict(cfg5c))
+    with torch.no_grad():
+        for p_ in ref5c.atomic_embedding.parameters():
+            p_.copy_(0.6 * torch.randn(p_.shape))
+    res = mine5c.load_state_dict(ref5c.state_dict(), strict=False)
+    assert not (set(res.missing_keys) & set(dict(mine5c.named_parameters()))), res.missing_keys
+    outs5c = {}
+    for tag, q in (("per_atom", torch.tensor([0.3, -2.0, 1.5])), ("neutral", torch.tensor(0.0))):
+        G5c = Graph(G)
+        G5c["doping_charge"] = q
+        r5c, o5c = ref5c(Graph(G5c)), mine5c(G5c)
+        _check(o5c["node_attr"], r5c["node_attr"], f"backbone charge doping + corr ({tag}) node_attr")
+        _check(o5c["edge_attr"], r5c["edge_attr"], f"backbone charge doping + corr ({tag}) edge_attr")
+        outs5c[f"q_{tag}"], outs5c[f"node_attr_{tag}"], outs5c[f"edge_attr_{tag}"] = q, r5c["node_attr"], r5c["edge_attr"]
+    _save("backbone_charge_doping_corr", weights={k: v for k, v in ref5c.state_dict().items() if k in dict(mine5c.named_parameters())},
+          graph={k: G[k] for k in ("z", "pos", "cell", "edge_index", "nbr_shift", "cell_shift", "inv_edge_idx", "batch", "node_counts")},
+          outputs=outs5c, meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg5c["HamGNN_pre"]).items()}))))
     # backbone with rbf_func="gaussian" (hamgnn_conv.py:123-125 GaussianSmearing; utils/basis_functions.py:211-224).  The other bases
     # (exp-gaussian, exp-bernstein, bernstein) carry float64 buffers and return a float64 edge embedding: usable with `precision: 64` only
     print("gaussian radial basis")

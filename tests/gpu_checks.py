@@ -862,6 +862,21 @@ def check_charge_doping(device="cuda"):
     return out
 
 
+def check_charge_doping_corr(device="cuda"):
+    """apply_charge_doping + use_corr_prod vs the reference fixture: per-node mixtures of the CorrProductBlock's element weights"""
+    m, f = build_backbone_from_fixture(device, "backbone_charge_doping_corr")
+    out = {}
+    for tag in ("per_atom", "neutral"):
+        g = to_graph(f["graph"], device)
+        g["doping_charge"] = torch.from_numpy(np.asarray(f["outputs"][f"q_{tag}"])).float().to(device)
+        rep = m(g)
+        torch.cuda.synchronize()
+        out[f"{tag}_node_rel_err"] = rel(rep["node_attr"], f["outputs"][f"node_attr_{tag}"])
+        out[f"{tag}_edge_rel_err"] = rel(rep["edge_attr"], f["outputs"][f"edge_attr_{tag}"])
+    out["effect_of_charge"] = rel(f["outputs"]["node_attr_per_atom"], f["outputs"]["node_attr_neutral"])
+    return out
+
+
 def check_transformer(device="cuda"):
     """HamGNNTransformer (attention backbone) vs the reference fixture, and one AttentionBlockE3 on its own"""
     from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer

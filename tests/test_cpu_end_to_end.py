@@ -30,11 +30,12 @@ def test_full_backward_whole_model_vs_autograd(cpu_backend):
     dict(crystals=3, n_atoms=2, metric="mae"),                         # ragged batch, per-crystal row order of the result
     dict(charge=True, crystals=2, n_atoms=2),                          # charge doping: embedding tables + the charge MLP
     dict(corr=True),                                                   # CorrProductBlock after every ConvBlock
+    dict(corr=True, charge=True, crystals=2, n_atoms=2),               # ... with doped node attributes: per-node mixtures of its element weights
     dict(soc="so3"), dict(soc="so3_nonsoc", crystals=2, n_atoms=2),    # SOC / so3 head, and the Uni-HamGNN SOC mode
     dict(transformer=True, irr="8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o"),  # HamGNNTransformer
     dict(lite=True), dict(lite=True, legacy=True, crystals=2, n_atoms=2),  # lite_mode: uvu products + combine post-op (CPU-validated only)
     dict(zps=True, crystals=2, n_atoms=2), dict(zps=True, soc="so3"),      # zero_point_shift (the universal non-SOC model trains with it)
-], ids=["legacy", "batch", "charge", "corr", "so3", "so3_nonsoc", "transformer", "lite", "lite_legacy_batch", "zero_point_shift", "zero_point_shift_soc"])
+], ids=["legacy", "batch", "charge", "corr", "corr_charge", "so3", "so3_nonsoc", "transformer", "lite", "lite_legacy_batch", "zero_point_shift", "zero_point_shift_soc"])
 def test_full_backward_variants_vs_autograd(cpu_backend, kw):
     kw = dict(dict(n_atoms=3, seed=5), **kw)
     r = G.check_full_backward(device="cpu", **kw)
@@ -71,6 +72,7 @@ _FORWARD_CASES = {
     "backbone_corr": lambda: G.check_backbone("cpu", "backbone_corr"),
     "backbone_gaussian_rbf": lambda: G.check_backbone("cpu", "backbone_gaussian_rbf"),
     "charge_doping": lambda: G.check_charge_doping("cpu"),
+    "charge_doping_corr": lambda: G.check_charge_doping_corr("cpu"),
     "transformer": lambda: G.check_transformer("cpu"),
     "corr_product": lambda: G.check_corr_product("cpu"),
     "head_openmx_19": lambda: G.check_head("cpu"),

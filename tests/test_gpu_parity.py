@@ -100,6 +100,14 @@ def test_backbone_charge_doping_golden():
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
 
+def test_backbone_charge_doping_with_corr_product_golden():
+    """apply_charge_doping + use_corr_prod (the reference's default when the key is missing): hg_sym_contraction on per-node weight mixtures"""
+    r = G.check_charge_doping_corr()
+    print(r)
+    assert r["effect_of_charge"] > 1e-3
+    assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
+
+
 def test_transformer_backbone_golden():
     r = G.check_transformer()
     print(r)
@@ -198,6 +206,14 @@ def test_full_model_backward_charge_doping():
     r = G.check_full_backward(n_atoms=4, seed=7, crystals=2, charge=True)
     print(r)
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] >= 78, r
+
+
+def test_full_model_backward_charge_doping_with_corr_product():
+    """both together: the gradient with respect to the doped attributes also flows through the CorrProductBlocks' weight mixtures"""
+    r = G.check_full_backward(n_atoms=4, seed=9, crystals=2, charge=True, corr=True)
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] > 94, r
+
 
 
 def test_full_model_backward_corr_product():
