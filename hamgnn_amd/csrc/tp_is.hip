@@ -422,7 +422,7 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
     float* __restrict__ tbase = lds + A.tile_shift + (el - 256);          // column field = m + 16, row-table entries point at the centre column
     // B operand of K-step q: channel g of piece q, this lane's edge.  All four pieces behind the base are read whether the step issues their
     // K-steps or not (no clamp, no branch around the reads: what is not issued never reaches an accumulator)
-    const float* __restrict__ stage = lds + A.stage_off + el * 4 + g;
+    const char* __restrict__ stage = reinterpret_cast<const char*>(lds + A.stage_off + el * 4 + g);      // + (descriptor & 0x3ff00): piece index << 8 = byte offset
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t: aw[t * 64]
     const i32x16* __restrict__ dsc = reinterpret_cast<const i32x16*>(Wb + it[12]);            // uniform, 64-byte aligned: s_load_dwordx16
     f32x4 ring[RING];
@@ -436,9 +436,9 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
     int roff[4] = {0, 0, 0, 0};
     float bn[4], bnb[4];
     {
-        const float* __restrict__ fb = stage + (dc[0] & 1023) * 64;
-        const float* __restrict__ fc = stage + (dc[1] & 1023) * 64;
-        const int sgn = (dc[1] << 16) & 0x80000000;
+        const float* __restrict__ fb = reinterpret_cast<const float*>(stage + (dc[0] & 0x3ff00));
+        const float* __restrict__ fc = reinterpret_cast<const float*>(stage + (dc[1] & 0x3ff00));
+        const int sgn = dc[1] << 31;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             bn[q] = fb[q * 64];
@@ -460,23 +460,23 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
             }
             {                                                  // operands of the next step, requested before this step's MFMAs (a wave issues in order)
                 const int dn = j + 1 < RING ? dc[(2 * j + 2) & 15] : dnx[0], en = j + 1 < RING ? dc[(2 * j + 3) & 15] : dnx[1];
-                const float* __restrict__ fb = stage + (dn & 1023) * 64;
-                const float* __restrict__ fc = stage + (en & 1023) * 64;
-                const int sgn = (en << 16) & 0x80000000;
+                const float* __restrict__ fb = reinterpret_cast<const float*>(stage + (dn & 0x3ff00));
+                const float* __restrict__ fc = reinterpret_cast<const float*>(stage + (en & 0x3ff00));
+                const int sgn = en << 31;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bn[q] = fb[q * 64];
                     bnb[q] = __builtin_bit_cast(float, __builtin_bit_cast(int, fc[q * 64]) ^ sgn);
                 }
             }
-            if (d & (1 << 12)) {                               // first step of a task: its rows, fresh accumulators
-                const int* __restrict__ rp = rtab + ((d >> 21) << 4);
+            if (d & 4) {                                       // first step of a task: its rows, fresh accumulators
+                const int* __restrict__ rp = rtab + ((d >> 23) << 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) roff[r] = rp[r];
                 acc = acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            const int nq1 = (d >> 10) & 3;                     // K-steps - 1
-            if (e1 & (1 << 14)) {                              // paired: both columns on this fragment, two independent accumulator chains
+            const int nq1 = d & 3;                             // K-steps - 1
+            if (e1 < 0) {                                      // paired: both columns on this fragment, two independent accumulator chains
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b[0], acc, 0, 0, 0);
                 acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bb[0], acc2, 0, 0, 0);
                 if (nq1 >= 1) {
@@ -501,10 +501,10 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
                     }
                 }
             }
-            if (d & (1 << 13)) {                               // last step of the task: add into the tile (all reads of a column, then its writes)
-                const int tc = ((d >> 16) & 31) * 16;
-                if (e1 & (1 << 14)) {
-                    const int tcb = ((e1 >> 16) & 31) * 16;
+            if (d & 8) {                                       // last step of the task: add into the tile (all reads of a column, then its writes)
+                const int tc = (d >> 14) & 0x1f0;              // (m + 16) * 16
+                if (e1 < 0) {
+                    const int tcb = (e1 >> 14) & 0x1f0;
                     float told[4], toldb[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {

@@ -409,7 +409,7 @@ def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool)
                 if sa is None or not any(np.any(x[0]) for x in sa):
                     continue
                 for (w, ba, nq), (_, bb, _) in zip(sa, sb):
-                    steps.append((w, ba | ((nq - 1) << 10) | ((16 + m) << 16), bb | (1 << 14) | ((1 if sg_ < 0 else 0) << 15) | ((16 - m) << 16)))
+                    steps.append((w, (ba << 8) | (nq - 1) | ((16 + m) << 18), (bb << 8) | (1 << 31) | (1 if sg_ < 0 else 0) | ((16 - m) << 18)))
             if steps:
                 tasks.append(steps)
         else:
@@ -418,7 +418,7 @@ def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool)
                 for sa in cols[mm_]:
                     if sa is None or not any(np.any(x[0]) for x in sa):
                         continue
-                    steps += [(w, ba | ((nq - 1) << 10) | ((16 + mm_) << 16), 0) for (w, ba, nq) in sa]
+                    steps += [(w, (ba << 8) | (nq - 1) | ((16 + mm_) << 18), 0) for (w, ba, nq) in sa]
                 if steps:
                     tasks.append(steps)
     return tasks
@@ -430,8 +430,9 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
     run over every item and K group that feeds it, accumulate in registers and add into the tile once.  A step = one fragment (64 lanes x 4:
     16 output rows x up to 16 input channels = 1..4 MFMA K-steps; only the K-steps that hold channels are issued: 38 % of the steps of set-A
     feed 4 channels, a quarter of a K group) + two descriptor words
-        d0 = B operand base / 64 floats | K-steps - 1 << 10 | first step of the task << 12 | last << 13 | (m + 16) << 16 | row-table index / 16 << 21
-        d1 = 0, or for a PAIRED step: B base of column -m | 1 << 14 | negate << 15 | (-m + 16) << 16
+        d0 = K-steps - 1 | first step of the task << 2 | last << 3 | B operand base (in 64-float pieces) << 8 | (m + 16) << 18 | row-table index / 16 << 23 (< 255)
+        d1 = 0, or for a PAIRED step: negate | B base of column -m << 8 | (-m + 16) << 18 | 1 << 31
+    (fields sit where the kernel needs them with one scalar instruction each: the piece index << 8 is the operand's byte offset)
     r3 / early r4 ran one stream per (phase, segment, row chunk) with rtm row tiles per step (profiles/r03_lite.md): 147 streams per 16 edges whose first
     requests were exposed each (~37 per wave), 20 % padding steps, and per-step instruction counts that did not shrink with rtm = 1 (71 % of the
     steps).  Tasks of different segments and row tiles are independent (disjoint tile rows / columns), so the planner deals them to the waves
@@ -447,14 +448,14 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
         for steps in _lite_column_steps(prog, items, lk, rtm, pairing):
             for rt in range(rtm):
                 ridx = rt_base[seg] + row_off + 16 * rt
-                assert ridx % 16 == 0 and ridx // 16 < 2048
+                assert ridx % 16 == 0 and ridx // 16 < 255        # (< 255: as a float32 bit pattern the word must not be a NaN -- the streams ride in the float blob)
                 st = []
                 for w, d0, d1 in steps:
                     f = np.asarray(w[rt * 256:(rt + 1) * 256]).reshape(4, 16, 4)       # [g][i][q]: word q of lane (g, i) = weight of channel 4 (4 G + q) + g (natural K)
                     if not np.any(f):
                         continue
-                    assert not np.any(f[:, :, ((d0 >> 10) & 3) + 1:])                   # K-steps beyond the block's pieces carry zero weights: not issued
-                    st.append((f.reshape(256), d0 | ((ridx // 16) << 21), d1))
+                    assert not np.any(f[:, :, (d0 & 3) + 1:])                           # K-steps beyond the block's pieces carry zero weights: not issued
+                    st.append((f.reshape(256), d0 | ((ridx // 16) << 23), d1))
                 if st:
                     tasks.append((st, seg))
     nw = min(IS_WAVES, max(1, len(tasks)))
@@ -469,7 +470,7 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
         for st, _ in stream:
             for n_, (w, d0, d1) in enumerate(st):
                 frags.append(w)
-                desc += [d0 | ((1 if n_ == 0 else 0) << 12) | ((1 if n_ == len(st) - 1 else 0) << 13), d1]
+                desc += [d0 | ((1 if n_ == 0 else 0) << 2) | ((1 if n_ == len(st) - 1 else 0) << 3), d1]
         nst = len(frags)
         npad = (-nst) % LITE_SRING
         # padding steps: zero weights, no task boundary; LITE_SRING more slots behind the last step (the request ring and the descriptor blocks run ahead)
@@ -478,8 +479,8 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
         base = runs["base"] + sum(x.size for x in runs["w"])
         lead = (-base) % 16                                    # fragments and descriptor blocks on 64-byte boundaries (s_load_dwordx16)
         wblob = np.concatenate(frags).astype(np.float64)
-        dblob = np.asarray(desc, dtype=np.int32).view(np.float32).astype(np.float64)
-        assert (wblob.size % 16, dblob.size % 16) == (0, 0)
+        dblob = np.asarray(desc, dtype=np.int64).astype(np.uint32).view(np.float32).astype(np.float64)      # bit patterns (exact: float32 -> float64 -> float32)
+        assert (wblob.size % 16, dblob.size % 16) == (0, 0) and np.array_equal(dblob.astype(np.float32).view(np.uint32), np.asarray(desc, dtype=np.int64).astype(np.uint32))
         runs["w"] += [np.zeros(lead), wblob, dblob]
         rec = np.zeros(ITEM_I32, dtype=np.int64)
         rec[0], rec[8], rec[9], rec[11], rec[12], rec[19] = IT_STREAM, nst + npad, 1, base + lead, base + lead + wblob.size, stream[0][1]

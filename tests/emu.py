@@ -258,8 +258,9 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                             acc = accb = None
                             for t in range(nst):
                                 d, e1 = int(desc[2 * t]), int(desc[2 * t + 1])
-                                b64, nv, first, last, tc, ridx = d & 1023, ((d >> 10) & 3) + 1, (d >> 12) & 1, (d >> 13) & 1, ((d >> 16) & 31) - 16, ((d >> 21) & 2047) * 16
-                                pair, negb, bb64, tcb = (e1 >> 14) & 1, (e1 >> 15) & 1, e1 & 1023, ((e1 >> 16) & 31) - 16
+                                d, e1 = d & 0xffffffff, e1 & 0xffffffff
+                                b64, nv, first, last, tc, ridx = (d >> 8) & 1023, (d & 3) + 1, (d >> 2) & 1, (d >> 3) & 1, ((d >> 18) & 31) - 16, (d >> 23) * 16
+                                pair, negb, bb64, tcb = e1 >> 31, e1 & 1, (e1 >> 8) & 1023, ((e1 >> 18) & 31) - 16
                                 F = Wall[w0 + t * 256:w0 + (t + 1) * 256].reshape(4, 16, 4)                          # [g][i][q]: out row i, channel 4 (4 G + q) + g
                                 if first:
                                     acc = np.zeros((16, 16), dtype=dtype)
