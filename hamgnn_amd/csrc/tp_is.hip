@@ -185,6 +185,9 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                         float b[NC];
 #pragma unroll
                         for (int c = 0; c < NC; ++c) b[c] = fb[(IS_COL(c) * cdir + 4 * G + q) * 64];
+                        // the NC operand reads stay together ahead of the MFMAs: left alone, the scheduler of the one-row-tile instantiations read every
+                        // operand into ONE register right before its MFMA -- an LDS round trip per MFMA (ISA audit: 334 of 4 096 static MFMAs)
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll

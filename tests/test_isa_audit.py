@@ -47,6 +47,8 @@ def test_default_kernel_has_no_serial_lds_read_modify_write(tp_is):
     base = [k for k in tp_is if "ILb0ELb0" in k["name"]]
     assert len(base) == 1
     assert not [lab for lab, _, s, f in base[0]["blocks"] if "SERIAL-RMW" in f]
+    # ... and no MFMA that waits for an LDS read issued right before it (r4: the natural-K GEMM1 of the one-row-tile items did)
+    assert not [lab for lab, _, s, f in base[0]["blocks"] if "SERIAL-r-M" in f]
 
 
 def test_row_program_and_readout_register_budgets():
