@@ -31,16 +31,20 @@ struct ProfIs { unsigned long long t[12]; unsigned long long last; };
 #define IS_PROF_PASS
 #define IS_T(k)
 #endif
-// broadcast lane q of every row of 16 lanes to that row (DPP row_newbcast, gfx90a+): lanes (g, *) <- lane (g, q)
-#define IS_BC_CASE(Q) case Q: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + Q, 0xf, 0xf, false));
-__device__ __forceinline__ float is_row_bcast(float v, int q) {      // q is a compile-time constant at every call site (unrolled loops)
+// broadcast of lane q of every row of 16 lanes to that row: DPP row_newbcast (gfx90a+): lanes (g, *) <- lane (g, q).
+// x * (lane q of v's row of 16 lanes) in ONE VALU instruction: v_mul_f32 with the DPP control on its first source (the compiler keeps the
+// broadcast as a separate v_mov_b32_dpp: 2 000 of them in the default instantiation)
+#define IS_MB_CASE(Q) case Q: asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:" #Q " row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "v"(x)); break;
+__device__ __forceinline__ float is_mul_bcast(float v, float x, int q) {
+    float o;
     switch (q) {
-        IS_BC_CASE(0) IS_BC_CASE(1) IS_BC_CASE(2) IS_BC_CASE(3) IS_BC_CASE(4) IS_BC_CASE(5) IS_BC_CASE(6) IS_BC_CASE(7)
-        IS_BC_CASE(8) IS_BC_CASE(9) IS_BC_CASE(10) IS_BC_CASE(11) IS_BC_CASE(12) IS_BC_CASE(13) IS_BC_CASE(14)
-        default: return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x15f, 0xf, 0xf, false));
+        IS_MB_CASE(0) IS_MB_CASE(1) IS_MB_CASE(2) IS_MB_CASE(3) IS_MB_CASE(4) IS_MB_CASE(5) IS_MB_CASE(6) IS_MB_CASE(7)
+        IS_MB_CASE(8) IS_MB_CASE(9) IS_MB_CASE(10) IS_MB_CASE(11) IS_MB_CASE(12) IS_MB_CASE(13) IS_MB_CASE(14)
+        default: asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "v"(x)); break;
     }
+    return o;
 }
-#undef IS_BC_CASE
+#undef IS_MB_CASE
 
 // One item on the workgroup's 16 edges.  stage: the phase's staged input block(s), image offset(piece p, row e) = 64 p + 4 e per
 // source (pieces of the FULL irrep block: component a, channel piece s -> p = a * P1 + s).
@@ -53,6 +57,8 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     constexpr int NCR = 2 * MM + 1;                            // real columns (fragment layouts of cf, tile columns)
     constexpr int NC = ODD ? 2 * MM : NCR;                     // column slots this item computes
 #define IS_COL(c) ((ODD && (c) >= MM) ? (c) + 1 : (c))
+// K-steps of GEMM2 beyond the item's rows are not issued; only the LAST row tile can hold such K-steps (rtm = ceil(rows / 16), plan._add_item)
+#define IS_NK2_OK(rt, r) ((rt) + 1 < RTM || 4 * (rt) + (r) < nk2)
     constexpr int CW = NC > 7 ? (NC + 1) / 2 : NC;             // GEMM2 column chunk (keeps its accumulators <= 28 VGPRs)
     const int typ = it[0], so0 = it[1], so1 = it[2], in_mulp = it[4], li = it[5], neg = it[7];     // [1], [2]: stage offsets of the sources
     const int ksteps = it[8], mlp = it[10], x4 = it[17], nk2 = it[18];
@@ -211,10 +217,10 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int p = rt * NCR + IS_COL(c);
-                f32x4 cb;
+                f32x4 t = mid[rt][c] * S[rt];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) cb[r] = is_row_bcast(cfv[p >> 4][r], p & 15);
-                mid[rt][c] = mid[rt][c] * S[rt] * cb;
+                for (int r = 0; r < 4; ++r) t[r] = is_mul_bcast(cfv[p >> 4][r], t[r], p & 15);
+                mid[rt][c] = t;
             }
 
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
@@ -249,13 +255,15 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                     for (int c = 0; c < NC; ++c)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc_n[c][r] = tnext[r][IS_COL(c) * 16];
+                        for (int r = 0; r < 4; ++r) {
+                            acc_n[c][r] = tnext[r][IS_COL(c) * 16];
+                        }
                 }
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (4 * rt + r < nk2) {                // trailing K-steps hold only padding rows: not issued
+                        if (IS_NK2_OK(rt, r)) {                // trailing K-steps hold only padding rows: not issued
 #pragma unroll
                             for (int c = 0; c < NC; ++c)
                                 acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][r], mid[rt][c][r], acc[c], 0, 0, 0);
@@ -291,7 +299,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                 for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (4 * rt + r < nk2) {                // trailing K-steps hold only padding rows: not issued
+                        if (IS_NK2_OK(rt, r)) {                // trailing K-steps hold only padding rows: not issued
 #pragma unroll
                             for (int c = 0; c < CW; ++c)
                                 if (c0 + c < NC)
@@ -328,6 +336,7 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     }
     IS_T(3);                                                    // scale-mul + GEMM2 + write-back
 #undef IS_COL
+#undef IS_NK2_OK
 }
 
 // lite_mode items (message_passing.py:197-206: unweighted uvu product folded with its o3.Linear block), rows = output channels:

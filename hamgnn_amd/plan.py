@@ -734,6 +734,7 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
     if typ != IT_POST and not (0 <= mm < len(KERNEL_RTM_MAX) and 1 <= rtm <= KERNEL_RTM_MAX[mm]):
         raise NotImplementedError(f"no kernel instantiation for an item with min(l_in, l_out) = {mm} and {rtm} row tiles")
     nk2 = 4 * rtm if nk2 is None else nk2                      # GEMM2 K-steps actually issued (item[18])
+    assert 4 * (rtm - 1) < nk2 <= 4 * rtm                      # only the last row tile holds K-steps that are not issued (csrc/tp_is.hip:IS_NK2_OK)
     if (2 * mm + 1) * in_mulp > 160:
         raise NotImplementedError(f"input irrep block too wide for the kernel's B staging ring: (2*{mm}+1) x {in_mulp} channels > 160")
     rec = [typ, srcs[0], srcs[1] if len(srcs) == 2 else -1, in_off, in_mulp, li, mm, neg, ksteps, rtm, mlp,
