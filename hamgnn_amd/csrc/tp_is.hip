@@ -146,60 +146,68 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const int P1 = in_mulp >> 2;                               // float4 pieces per component
     const int cdir = neg ? -P1 : P1;                           // column c -> component (neg ? a_hi - c : a_lo + c)
     const int c0p = (li - MM) * P1 + (neg ? (NCR - 1) * P1 : 0);
+    // ONE loop over (source, K group): as a loop nest with two alternative inner loops the accumulators came back as 64 + register copies per
+    // source at the loops' joins (ISA audit r4: 2 100 v_mov_b64 in the default instantiation)
+    const int ntot = nsrc * ngrp;
+    if (NCR <= 3 && x4) {                                      // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
+        const float* __restrict__ fb0 = stage + so0 + (c0p + g) * 64 + el * 4;
+        const float* __restrict__ fb1 = stage + so1 + (c0p + g) * 64 + el * 4;
 #pragma unroll
-    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
+        for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];              // (requested inside the branch: ahead of it, both loops got a copy)
 #pragma unroll 1
-    for (int si = 0; si < nsrc; ++si) {
-        const float* __restrict__ sbase = stage + (si ? so1 : so0);
-        const int abase = si * ngrp;
-        if (NCR <= 3 && x4) {                                  // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
-            const float* __restrict__ fb = sbase + (c0p + g) * 64 + el * 4;
+        for (int t = 0; t < ntot; ++t) {
+            const bool second = t >= ngrp;
+            const int G = second ? t - ngrp : t;
+            const float* __restrict__ fb = second ? fb1 : fb0;
+            f32x4 av[RTM], bv[NC];
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+            if (t + 1 < ntot) {
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (IS_COL(c) * cdir + 4 * G) * 64);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
+        }
+    } else {                                                   // natural K: element (c, 4 sl + g) = piece cbase + sl, component g
+        const float* __restrict__ fb0 = stage + so0 + c0p * 64 + el * 4 + g;
+        const float* __restrict__ fb1 = stage + so1 + c0p * 64 + el * 4 + g;
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
 #pragma unroll 1
-            for (int G = 0; G < ngrp; ++G) {
-                f32x4 av[RTM], bv[NC];
+        for (int t = 0; t < ntot; ++t) {
+            const bool second = t >= ngrp;
+            const int G = second ? t - ngrp : t;
+            const float* __restrict__ fb = second ? fb1 : fb0;
+            f32x4 av[RTM];
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
-                if (abase + G + 1 < nsrc * ngrp) {
+            for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
+            if (t + 1 < ntot) {
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
-                }
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
+            }
+            const int nq = ksteps - 4 * G;                     // K-steps in this group (>= 4 except in the tail group)
 #pragma unroll
-                for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (IS_COL(c) * cdir + 4 * G) * 64);
+            for (int q = 0; q < 4; ++q) {
+                if (q < nq) {
+                    float b[NC];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                    for (int c = 0; c < NC; ++c) b[c] = fb[(IS_COL(c) * cdir + 4 * G + q) * 64];
+                    // the NC operand reads stay together ahead of the MFMAs: left alone, the scheduler of the one-row-tile instantiations read every
+                    // operand into ONE register right before its MFMA -- an LDS round trip per MFMA (ISA audit: 334 of 4 096 static MFMAs)
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
                         for (int c = 0; c < NC; ++c)
-                            mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
-            }
-        } else {                                               // natural K: element (c, 4 sl + g) = piece cbase + sl, component g
-            const float* __restrict__ fb = sbase + c0p * 64 + el * 4 + g;
-#pragma unroll 1
-            for (int G = 0; G < ngrp; ++G) {
-                f32x4 av[RTM];
-#pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
-                if (abase + G + 1 < nsrc * ngrp) {
-#pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((abase + G + 1) * RTM + rt) * 64];
-                }
-                const int nq = ksteps - 4 * G;                 // K-steps in this group (>= 4 except in the tail group)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q < nq) {
-                        float b[NC];
-#pragma unroll
-                        for (int c = 0; c < NC; ++c) b[c] = fb[(IS_COL(c) * cdir + 4 * G + q) * 64];
-                        // the NC operand reads stay together ahead of the MFMAs: left alone, the scheduler of the one-row-tile instantiations read every
-                        // operand into ONE register right before its MFMA -- an LDS round trip per MFMA (ISA audit: 334 of 4 096 static MFMAs)
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-                            for (int c = 0; c < NC; ++c)
-                                mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
-                    }
+                            mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
                 }
             }
         }
@@ -256,8 +264,11 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                     for (int c = 0; c < NC; ++c)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            acc_n[c][r] = tnext[r][IS_COL(c) * 16];
+                            // (volatile: neighbouring columns off one base register would be merged into ds_read2_b32, whose register pairs
+                            //  then have to be split into the accumulator vectors with v_mov -- each behind a wait for the read just issued)
+                            acc_n[c][r] = *(volatile __attribute__((address_space(3))) float*)(tnext[r] + IS_COL(c) * 16);
                         }
+                    __builtin_amdgcn_sched_barrier(0);         // ... and requested ahead of this step's MFMAs
                 }
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
