@@ -34,11 +34,11 @@ SH = "0e+1o+2e+3o+4e+5o"
 # algorithmic cost of ONE fused MessagePackBlock per edge in the REFERENCE formulation (non-zero CG entries)
 REF_FLOPS_PER_EDGE_BLOCK = {"A": 4.55e6, "B": 1.73e6}
 REF_BYTES_PER_EDGE_BLOCK = {"A": 14432.0, "B": 7888.0}
-# HBM bytes per edge of one MessagePackBlock launch from the rocprofv3 PMC passes in profiles/r03_tp_is_pmc.md (= r02b_tp_is_hbm_pmc.md) / r01c_tp_fused_hbm_pmc.md
+# HBM bytes per edge of one MessagePackBlock launch from the rocprofv3 PMC passes in profiles/r04_tp_is_pmc.md (set-B: r02b_tp_is_hbm_pmc.md) / r01c_tp_fused_hbm_pmc.md
 # (separate --pmc FETCH_SIZE / WRITE_SIZE runs on tests/bench_tp.py, 131072 edges; FETCH_SIZE x 2: gfx950 correction for
 # 16-B/lane reads, MI355X_MICROARCH.md "HBM"): measured offline for this kernel build, scaled to the launch's edge count.
-# kernel "is" = input-stationary tp_is_kernel (profiles/r02_tp_is_hbm_pmc.md), "seg" = segment-stationary tp_fused_kernel
-PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 34.6e3, ("is", "B"): 14.2e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
+# kernel "is" = input-stationary tp_is_kernel (r4: 3.95 GB read + 0.51 GB written per 131 072-edge launch = 34.0 KB per edge), "seg" = segment-stationary tp_fused_kernel
+PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 34.0e3, ("is", "B"): 14.2e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
 
@@ -413,7 +413,7 @@ def main():
     pmc_bytes = PMC_HBM_BYTES_PER_EDGE_BLOCK[(kern, args.irreps)]
     roofline = {"kernel": ("tp_is_kernel (input-stationary" if kern == "is" else "tp_fused_kernel (segment-stationary") + " MessagePackBlock launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": pmc_bytes * rows_per_launch,
-                "traffic_unit": "bytes per launch (PMC, measured offline: profiles/r03_tp_is_pmc.md (r02b_tp_is_hbm_pmc.md), r01c_tp_fused_hbm_pmc.md)", "avg_launch_ms": avg_s * 1e3,
+                "traffic_unit": "bytes per launch (PMC, measured offline: profiles/r04_tp_is_pmc.md (set-B: r02b_tp_is_hbm_pmc.md), r01c_tp_fused_hbm_pmc.md)", "avg_launch_ms": avg_s * 1e3,
                 "launches_timed": len(mp), "edges_per_launch": rows_per_launch,
                 "executed_useful_tflops": useful / avg_s / 1e12, "issued_mfma_tflops": issued / avg_s / 1e12,
                 "hbm_algorithmic_GBs": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9,
