@@ -147,18 +147,23 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     const int cdir = neg ? -P1 : P1;                           // column c -> component (neg ? a_hi - c : a_lo + c)
     const int c0p = (li - MM) * P1 + (neg ? (NCR - 1) * P1 : 0);
     // ONE loop over (source, K group): as a loop nest with two alternative inner loops the accumulators came back as 64 + register copies per
-    // source at the loops' joins (ISA audit r4: 2 100 v_mov_b64 in the default instantiation)
+    // source at the loops' joins (ISA audit r4: 2 100 v_mov_b64 in the default instantiation).  The B operand of (column c, K group G) is read
+    // through a running pointer per column (+ one K group per iteration, a jump at the switch to the second source): the K-steps of a group
+    // are immediate offsets -- computed from (c, G, q) every K-step the addresses cost ~17 scalar + 5 vector instructions per NC MFMAs
     const int ntot = nsrc * ngrp;
+    const int src_jump = (so1 - so0) - ngrp * 256;             // floats, applied once when t reaches the second source
     if (NCR <= 3 && x4) {                                      // permuted K: fragment (c, G) = piece cbase + 4G + g of row el
-        const float* __restrict__ fb0 = stage + so0 + (c0p + g) * 64 + el * 4;
-        const float* __restrict__ fb1 = stage + so1 + (c0p + g) * 64 + el * 4;
+        const float* __restrict__ pc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) pc[c] = stage + so0 + (c0p + g + IS_COL(c) * cdir) * 64 + el * 4;
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];              // (requested inside the branch: ahead of it, both loops got a copy)
 #pragma unroll 1
         for (int t = 0; t < ntot; ++t) {
-            const bool second = t >= ngrp;
-            const int G = second ? t - ngrp : t;
-            const float* __restrict__ fb = second ? fb1 : fb0;
+            if (t == ngrp) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) pc[c] += src_jump;
+            }
             f32x4 av[RTM], bv[NC];
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
@@ -167,7 +172,10 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                 for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
             }
 #pragma unroll
-            for (int c = 0; c < NC; ++c) bv[c] = *reinterpret_cast<const f32x4*>(fb + (IS_COL(c) * cdir + 4 * G) * 64);
+            for (int c = 0; c < NC; ++c) {
+                bv[c] = *reinterpret_cast<const f32x4*>(pc[c]);
+                pc[c] += 256;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -177,15 +185,19 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                         mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], bv[c][q], mid[rt][c], 0, 0, 0);
         }
     } else {                                                   // natural K: element (c, 4 sl + g) = piece cbase + sl, component g
-        const float* __restrict__ fb0 = stage + so0 + c0p * 64 + el * 4 + g;
-        const float* __restrict__ fb1 = stage + so1 + c0p * 64 + el * 4 + g;
+        const float* __restrict__ pc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) pc[c] = stage + so0 + (c0p + IS_COL(c) * cdir) * 64 + el * 4 + g;
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
+        int nq = ksteps;                                       // K-steps left in this source (>= 4 except in its tail group)
 #pragma unroll 1
         for (int t = 0; t < ntot; ++t) {
-            const bool second = t >= ngrp;
-            const int G = second ? t - ngrp : t;
-            const float* __restrict__ fb = second ? fb1 : fb0;
+            if (t == ngrp) {
+                nq = ksteps;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) pc[c] += src_jump;
+            }
             f32x4 av[RTM];
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
@@ -193,13 +205,12 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
             }
-            const int nq = ksteps - 4 * G;                     // K-steps in this group (>= 4 except in the tail group)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (q < nq) {
                     float b[NC];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) b[c] = fb[(IS_COL(c) * cdir + 4 * G + q) * 64];
+                    for (int c = 0; c < NC; ++c) b[c] = pc[c][q * 64];
                     // the NC operand reads stay together ahead of the MFMAs: left alone, the scheduler of the one-row-tile instantiations read every
                     // operand into ONE register right before its MFMA -- an LDS round trip per MFMA (ISA audit: 334 of 4 096 static MFMAs)
                     __builtin_amdgcn_sched_barrier(0);
@@ -210,6 +221,9 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
                             mid[rt][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][q], b[c], mid[rt][c], 0, 0, 0);
                 }
             }
+            nq -= 4;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) pc[c] += 256;
         }
     }
 
