@@ -255,44 +255,3 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
         allreduce_gradients(model)                             # data-parallel runs: mean over ranks, one collective; else a no-op
     weights_changed(model)
     return {"loss": loss, "hamiltonian": H}
-
-
-class CapturedTrainingStep:
-    """training_step(model, batch, ...) of ONE batch as a captured HIP graph: the step issues ~3 000 launches (fused edge kernels, per-path
-    library GEMMs of the Linear weight gradients, the element-wise glue of the backward) and a third of its wall time is host time between
-    them; the replay has neither.  The step is capture-safe: no host synchronisation, every buffer from torch's allocator, the packed weights
-    refreshed ON THE DEVICE from the parameters' storage (so an in-place optimiser step between two replays is seen by the next one).
-
-        cap = CapturedTrainingStep(model, batch, losses=[...])     # warm-up steps (compile, caches), then one capture
-        for _ in range(n): loss = cap(); opt.step()                # `.grad` of every parameter is rewritten in place by each replay
-
-    The `.grad` tensors are the graph's own buffers: do not set them to None between replays (use `opt.zero_grad(set_to_none=False)` or
-    nothing at all -- each replay overwrites them), and pass the SAME batch object's tensors (write new values in place to train on other data of
-    the same shape)."""
-
-    def __init__(self, model, batch, warmup: int = 3, **kw):
-        if not torch.cuda.is_available():
-            raise RuntimeError("CapturedTrainingStep needs a GPU")
-        self.model, self.params = model, list(model.parameters())
-
-        def run():
-            for p in self.params:
-                p.grad = None
-            return training_step(model, batch, **kw)["loss"]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(2, warmup)):                    # the second step onwards takes the refresh path the replays need
-                run()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = run()
-        self.grads = [p.grad for p in self.params]
-
-    def __call__(self):
-        self.graph.replay()
-        for p, g in zip(self.params, self.grads):              # (a caller may have dropped them)
-            p.grad = g
-        return self.loss
