@@ -574,6 +574,7 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
 template <int RTO>
 __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds,
                                         int64_t erow, int lane) {
+    asm volatile("" : "+v"(erow));                             // (per-edge addresses are formed HERE: hoisted to the kernel's entry they were spilled)
     const int g = lane >> 4, el = lane & 15;
     const int lk = it[20], mul_k = it[21];
     const int nco = 2 * lk + 1;
@@ -587,11 +588,17 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
     f32x4 S[RTO];
 #pragma unroll
     for (int rt = 0; rt < RTO; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 av[RTO][RTO];                                         // the segment's Lc fragments, resident for all its columns; requested ahead of
-#pragma unroll                                                  // the radial phase (they were waited for right after their request)
-    for (int rtp = 0; rtp < RTO; ++rtp)
+    // the segment's Lc fragments: resident for all its columns and requested ahead of the radial phase for one or two row tiles; for three or four
+    // (64 registers; these segments have few columns) requested per output row tile inside the column loop -- the lite instantiation runs four
+    // waves per SIMD (128 registers) since r4
+    constexpr bool RES = RTO <= 2;
+    f32x4 av[RES ? RTO : 1][RTO];
+    if (RES) {
 #pragma unroll
-        for (int rt = 0; rt < RTO; ++rt) av[rtp][rt] = a2[(rtp * RTO + rt) * 64];
+        for (int rtp = 0; rtp < RTO; ++rtp)
+#pragma unroll
+            for (int rt = 0; rt < RTO; ++rt) av[RES ? rtp : 0][rt] = a2[(rtp * RTO + rt) * 64];
+    }
     const int hgrp = A.hidden >> 4;
 #pragma unroll
     for (int G = 0; G < 4; ++G) {
@@ -604,6 +611,7 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int rt = 0; rt < RTO; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[rt][q], hb[q], S[rt], 0, 0, 0);
+            if (RTO >= 3) __builtin_amdgcn_sched_barrier(0);   // (three or four row tiles: the requests of ONE hidden group in flight, not of all four)
         }
     }
     for (int G = 4; G < hgrp; ++G) {                           // (hidden > 64)
@@ -620,7 +628,7 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
     for (int rt = 0; rt < RTO; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) rowoff[rt][r] = rtab[16 * rt + 4 * g + r];
-    constexpr int CH = RTO >= 3 ? 2 : 4;                        // columns per chunk (register budget)
+    constexpr int CH = RTO == 1 ? 4 : (RTO == 2 ? 2 : 1);       // columns per chunk (register budget: 128 per wave)
 #pragma unroll 1
     for (int c0 = 0; c0 < nco; c0 += CH) {
         f32x4 md[RTO][CH];
@@ -635,23 +643,49 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (RES) {
 #pragma unroll
-        for (int rtp = 0; rtp < RTO; ++rtp) {
-            f32x4 acc[CH];
+            for (int rtp = 0; rtp < RTO; ++rtp) {
+                f32x4 acc[CH];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int rt = 0; rt < RTO; ++rt)
+                for (int rt = 0; rt < RTO; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rtp][rt][r], md[rt][c][r], acc[c], 0, 0, 0);
+                        for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rtp][rt][r], md[rt][c][r], acc[c], 0, 0, 0);
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if (c0 + c < nco) {
+                for (int c = 0; c < CH; ++c)
+                    if (c0 + c < nco) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tb[rowoff[rtp][r] + (c0 + c) * 16] = acc[c][r];
-                }
+                        for (int r = 0; r < 4; ++r) tb[rowoff[rtp][r] + (c0 + c) * 16] = acc[c][r];
+                    }
+            }
+        } else {
+#pragma unroll 1
+            for (int rtp = 0; rtp < RTO; ++rtp) {              // (not unrolled: all RTO x RTO fragment requests at once were 64 registers)
+                f32x4 avr[RTO], acc[CH];
+                int ro[4];
+#pragma unroll
+                for (int rt = 0; rt < RTO; ++rt) avr[rt] = a2[(rtp * RTO + rt) * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ro[r] = rtab[16 * rtp + 4 * g + r];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int rt = 0; rt < RTO; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avr[rt][r], md[rt][c][r], acc[c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+                    if (c0 + c < nco) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tb[ro[r] + (c0 + c) * 16] = acc[c][r];
+                    }
+            }
         }
     }
 }
@@ -681,12 +715,13 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
 #define IS_PART_I32 12
 
 template <bool SPLIT, bool LITE>
-__global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
+__global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE : IS_NW) / 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
                                                        const int* __restrict__ g_phases, const int* __restrict__ g_groups,
                                                        const int* __restrict__ g_items, const float* __restrict__ g_W,
                                                        const int* __restrict__ g_parts, const int* __restrict__ g_rowtab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NW = LITE ? IS_NW_LITE : IS_NW, NT = 64 * NW; // lite programs: 8 waves on the tile (four per SIMD at <= 128 VGPRs; the default
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63; // instantiation needs 219)
     const int g = lane >> 4;
     // (an XCD-aware tile order -- contiguous tile ranges per XCD, workgroup b -> XCD b % 8 -- was measured on the 10 k-atom crystal:
     //  49.6 ms per launch with and without it, profiles/r02_tp_is_experiments.md: the gathered node rows are not what the waves wait for)
@@ -720,11 +755,11 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
     const unsigned long long t_begin = prof.last;
 #endif
 
-    for (int i = threadIdx.x; i < A.rowtab_off; i += IS_NT) lds[i] = 0.f;            // all segment tiles (all copies) + trash rows
+    for (int i = threadIdx.x; i < A.rowtab_off; i += NT) lds[i] = 0.f;            // all segment tiles (all copies) + trash rows
     {
         int* __restrict__ rt_l = reinterpret_cast<int*>(lds + A.rowtab_off);
         const int* __restrict__ rt_g = g_rowtab + A.rowtab_begin;
-        for (int i = threadIdx.x; i < A.rowtab_len; i += IS_NT) rt_l[i] = rt_g[i];
+        for (int i = threadIdx.x; i < A.rowtab_len; i += NT) rt_l[i] = rt_g[i];
     }
     IS_T(4);                                                   // zero fill
 
@@ -753,13 +788,13 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
 #endif
             const int* __restrict__ B = g_blocks + b * 8;
             switch (B[4]) {
-                case 0: stage_block<0>(A, B, stage, erow, wave, lane); break;
-                case 1: stage_block<1>(A, B, stage, erow, wave, lane); break;
-                case 2: stage_block<2>(A, B, stage, erow, wave, lane); break;
-                case 3: stage_block<3>(A, B, stage, erow, wave, lane); break;
-                case 4: stage_block<4>(A, B, stage, erow, wave, lane); break;
-                case 5: stage_block<5>(A, B, stage, erow, wave, lane); break;
-                case 6: stage_block<6>(A, B, stage, erow, wave, lane); break;
+                case 0: stage_block<0, NW>(A, B, stage, erow, wave, lane); break;
+                case 1: stage_block<1, NW>(A, B, stage, erow, wave, lane); break;
+                case 2: stage_block<2, NW>(A, B, stage, erow, wave, lane); break;
+                case 3: stage_block<3, NW>(A, B, stage, erow, wave, lane); break;
+                case 4: stage_block<4, NW>(A, B, stage, erow, wave, lane); break;
+                case 5: stage_block<5, NW>(A, B, stage, erow, wave, lane); break;
+                case 6: stage_block<6, NW>(A, B, stage, erow, wave, lane); break;
                 default: break;
             }
 #ifdef HG_PROF                     // staging by kind: 8 = plain rows (LDS-DMA issue), 9 = gathered l = 0 rows, 10 = rotated l = 1..3, 11 = rotated l >= 4
@@ -838,10 +873,10 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
 
     if (SPLIT && copy_stride) {                                // split launch: fold the waves' private tile copies into copy 0
         __syncthreads();
-        for (int i = threadIdx.x; i < copy_stride; i += IS_NT) {
+        for (int i = threadIdx.x; i < copy_stride; i += NT) {
             float acc = lds[i];
 #pragma unroll
-            for (int k = 1; k < IS_NW; ++k) acc += lds[i + k * copy_stride];
+            for (int k = 1; k < NW; ++k) acc += lds[i + k * copy_stride];
             lds[i] = acc;
         }
     }
@@ -870,7 +905,7 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
                     const float* __restrict__ D = A.wig + erow * A.nW + is_pick_wig_off(A, l2);
                     const int nj = (nn + 3) >> 2;
 #pragma unroll 1
-                    for (int j = wave; j < nj; j += IS_NW) {   // image [m * NCO + a][edge]
+                    for (int j = wave; j < nj; j += NW) {      // image [m * NCO + a][edge]
                         int idx = 4 * j + g;
                         idx = idx < nn ? idx : nn - 1;
                         is_dma4(D + idx, stage + T8[6] + j * 64);
@@ -883,13 +918,13 @@ __global__ __launch_bounds__(IS_NT, IS_NW / 2) void tp_is_kernel(const IsArgs A0
         const float* __restrict__ tile = lds + tile_off;
         const float* __restrict__ dst = stage + woff;
         switch (lk) {
-            case 0: epilogue_is<0>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 1: epilogue_is<1>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 2: epilogue_is<2>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 3: epilogue_is<3>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 4: epilogue_is<4>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 5: epilogue_is<5>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 6: epilogue_is<6>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 0: epilogue_is<0, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 1: epilogue_is<1, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 2: epilogue_is<2, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 3: epilogue_is<3, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 4: epilogue_is<4, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 5: epilogue_is<5, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 6: epilogue_is<6, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
             default: break;
         }
     }
@@ -948,7 +983,7 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     if (!row_table) return hg_fail(-2, "hg_tp_is: no row table");
     for (int p = 0; p < nparts; ++p) {
         const int32_t* q = part_table_host + p * IS_PART_I32;
-        if (q[6] < q[5] || q[5] < q[8] + q[10] || q[8] < q[4] || lds_bytes < 4 * (q[6] + 1) || (q[7] && IS_NW * q[7] > q[8]))
+        if (q[6] < q[5] || q[5] < q[8] + q[10] || q[8] < q[4] || lds_bytes < 4 * (q[6] + 1) || (q[7] && (part_table_host[11] ? IS_NW_LITE : IS_NW) * q[7] > q[8]))
             return hg_fail(-2, "hg_tp_is: bad LDS layout");
     }
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
@@ -965,7 +1000,7 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     const unsigned grid = (unsigned)((rows + 15) / 16);
     const bool lite = p0[11] != 0;                             // part record [11]: the program holds lite_mode items (plan.is_schedule)
 #define IS_LAUNCH(SPLITv, LITEv, GRID) \
-    hipLaunchKernelGGL((tp_is_kernel<SPLITv, LITEv>), GRID, dim3(IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table, \
+    hipLaunchKernelGGL((tp_is_kernel<SPLITv, LITEv>), GRID, dim3(LITEv ? 64 * IS_NW_LITE : IS_NT), lds_bytes, (hipStream_t)stream, A, seg_table, block_table, phase_table, \
                        group_table, item_table, weights, part_table, row_table)
     if (nparts == 1) {
         if (lite) IS_LAUNCH(false, true, dim3(grid));

@@ -12,6 +12,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define IS_NW 4                  // waves of a workgroup (all on the same 16 edges); plan.py:IS_WAVES.  6 = three waves per SIMD (experiment)
 #endif
 #define IS_NT (64 * IS_NW)
+#ifndef IS_NW_LITE
+#define IS_NW_LITE 8             // lite_mode programs (tp_is_kernel<SPLIT, LITE = true>): 8 waves per workgroup = four waves per SIMD at 128 VGPRs;
+#endif                           // plan.py:IS_WAVES_LITE
 
 struct IsArgs {
     const float* src[4];
@@ -98,7 +101,7 @@ __device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* l
 }
 
 // un-rotate (optional) + planar store of one segment, rows split over the four waves; D blocks staged in `dst` (see kernel)
-template <int LK>
+template <int LK, int NW>
 __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __restrict__ tile, const float* __restrict__ dstage, int mul_k,
                                             int out_off, int out_mulp, int flags, int64_t e, bool valid_in, int wave, int lane, const IsScan& sc) {
     bool valid = valid_in;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
     // back-to-back stores, so the memory side sees whole sectors (interleaving the channels of one component over the waves
     // tripled the HBM write traffic: WRITE_SIZE 1.39 GB vs 0.46 GB of output per 131 072 edges)
     const int nw16 = (wend + 15) >> 4;
-    const int U = NCO * nw16, per = (U + IS_NW - 1) / IS_NW;              // each wave takes a contiguous range of units (adjacent bytes of the row)
+    const int U = NCO * nw16, per = (U + NW - 1) / NW;              // each wave takes a contiguous range of units (adjacent bytes of the row)
     const int u_begin = wave * per, u_end = (u_begin + per) < U ? (u_begin + per) : U;
     // a lane owns FOUR consecutive channels of one (edge, component): 4 NCO tile reads in flight, one 16-byte store -- a wave writes 16 edges x
     // 64 contiguous bytes per request (r3: a dword per lane, four requests for the same bytes)
@@ -177,8 +180,10 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
 //   rotated source: rows are node features in the global frame, gathered by idx[] and multiplied by D^l(R_e) on the way in
 //                   (x'[a] = sum_b D[a][b] x[b], hamgnn_amd/so3.py) -- ONCE per edge, input block and launch, which replaces the
 //                   separate hg_rotate_gather pass and the materialised per-edge copies xs', xd' of the node rows.
-template <int L>
+template <int L, int NW>
 __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restrict__ P, float* __restrict__ stage, int64_t erow, int wave, int lane) {
+    if constexpr (NW > 4) asm volatile("" : "+v"(erow));       // 128-register budget: the rows' addresses are formed per block (hoisted out of the
+                                                               // phase loop they were spilled: a scratch reload per staged piece)
     constexpr int N = 2 * L + 1;
     const int s0 = P[0], s1 = P[1], in_off = P[2], in_mulp = P[3], nsrc = P[5];
     const int g = lane >> 4, el = lane & 15;
@@ -187,7 +192,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
     const int Pfull = N * P1;
     const int nj = (Pfull + 3) >> 2;
     const bool rot0 = (A.rot_mask >> s0) & 1, rot1 = nsrc == 2 && ((A.rot_mask >> s1) & 1);
-    if (rot0 && rot1 && (IS_NW <= 4 || L <= 3) && L <= HG_STAGE_FUSE_LMAX) {
+    if (rot0 && rot1 && (NW <= 4 || L <= 3) && L <= HG_STAGE_FUSE_LMAX) {
         // sender and receiver rows of the node branch share the edge's Wigner row: one output piece t = a * P1 + p (component a,
         // channels 4p..4p+3) of BOTH sources per (wave, g) slot and step -- 2 N float4 loads of the node rows + the N entries of
         // row a in flight together, 2 N float4 FMAs, two ds_write_b128 straight into the operand images
@@ -204,12 +209,12 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
         // instead of one piece's
         constexpr int U = HG_STAGE_U(L);
 #pragma unroll 1
-        for (int t0 = 4 * wave + g; t0 < Pfull; t0 += 4 * IS_NW * U) {
+        for (int t0 = 4 * wave + g; t0 < Pfull; t0 += 4 * NW * U) {
             f32x4 v0[U][N], v1[U][N];
             float d[U][N];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                int t = t0 + 4 * IS_NW * u;
+                int t = t0 + 4 * NW * u;
                 t = t < Pfull ? t : t0;                        // tail: re-read the first piece (result dropped below)
                 const int a = HG_DIV_P1(t), p = t - a * P1;
 #pragma unroll
@@ -221,7 +226,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int t = t0 + 4 * IS_NW * u;
+                const int t = t0 + 4 * NW * u;
                 if (t < Pfull) {
                     f32x4 acc0 = d[u][0] * v0[u][0], acc1 = d[u][0] * v1[u][0];
 #pragma unroll
@@ -245,7 +250,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
         if (si ? rot1 : rot0) {
             const float* __restrict__ D = A.wig + erow * A.nW + A.wig_off[L];
 #pragma unroll 1
-            for (int t = 4 * wave + g; t < Pfull; t += 4 * IS_NW) {
+            for (int t = 4 * wave + g; t < Pfull; t += 4 * NW) {
                 const int a = HG_DIV_P1(t), p = t - a * P1;
                 f32x4 v[N];
                 float d[N];
@@ -261,7 +266,7 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
             }
         } else {
 #pragma unroll 1
-            for (int j = wave; j < nj; j += IS_NW) {           // the waves share the block's DMA instructions
+            for (int j = wave; j < nj; j += NW) {              // the waves share the block's DMA instructions
                 int p = 4 * j + g;
                 p = p < Pfull ? p : Pfull - 1;
                 is_dma16(row + 4 * p, dst + j * 256);

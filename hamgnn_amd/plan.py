@@ -36,7 +36,7 @@ IT_TP = 0        # GEMM1 -> radial scale * CG coef -> GEMM2 -> add into segment 
 IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, add into tile
 IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: aligned-frame CG coefficient per m)
 IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
-IT_STREAM = 6    # lite_mode, input-stationary schedule (r4): the folded items of one PHASE as IS_WAVES balanced streams of uniform steps (plan._lite_streams)
+IT_STREAM = 6    # lite_mode, input-stationary schedule (r4): the folded items of one PHASE as IS_WAVES_LITE balanced streams of uniform steps (plan._lite_streams)
 LITE_SRING = 8   # request ring / descriptor block of csrc/tp_is.hip:stream_lite (SL_RING)
 IT_LINM = 4      # lite_mode, ALL paths (i, l_sh, k) of one (i, k) folded: one weight matrix per column, A_m = sum_paths cf_path[m] A_path (input-stationary kernel only)
 # segment flags
@@ -184,6 +184,7 @@ class Program:
 
 # ---- input-stationary schedule (csrc/tp_is.hip): the SAME items, regrouped by input irrep block ------------------------------
 IS_WAVES = int(os.environ.get("HG_IS_WAVES", "4"))      # waves of a workgroup (= IS_NW of csrc/tp_is.hip); all on the same 16 edges
+IS_WAVES_LITE = int(os.environ.get("HG_LITE_WAVES", "8"))   # ... of the lite_mode instantiation (= IS_NW_LITE: four waves per SIMD at <= 128 VGPRs)
 IS_BLOCK_I32 = 8                   # {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
 IS_PHASE_I32 = 8                   # {block_begin, block_end, group_begin, group_end, radial generator whose hidden rows the kernel keeps resident (-1: none), 0..}
 IS_LDS_BYTES = 80 * 1024           # two workgroups per CU
@@ -340,7 +341,7 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
     for part in range(parts):
         members = [sg for sg in range(nseg) if owner[sg] == part]
         sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
-                                split=parts > 1, separate_mlp=separate_mlp, runs=runs)
+                                split=parts > 1, separate_mlp=separate_mlp, runs=runs, waves=IS_WAVES_LITE if lite_flag else IS_WAVES)
         parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
                         sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag])
         rowtab_all += sub["rowtab"]
@@ -424,8 +425,8 @@ def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool)
     return tasks
 
 
-def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
-    """lite_mode, input-stationary schedule, r4: ALL folded items (IT_LINM) of one phase -- `recs`, stage offsets in [1], [2] -- as IS_WAVES
+def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int], waves: int):
+    """lite_mode, input-stationary schedule, r4: ALL folded items (IT_LINM) of one phase -- `recs`, stage offsets in [1], [2] -- as `waves`
     balanced STREAMS of uniform steps, one work group each.  A TASK = (output segment, ONE 16-row tile, column m or column pair +-m): its steps
     run over every item and K group that feeds it, accumulate in registers and add into the tile once.  A step = one fragment (64 lanes x 4:
     16 output rows x up to 16 input channels = 1..4 MFMA K-steps; only the K-steps that hold channels are issued: 38 % of the steps of set-A
@@ -458,7 +459,7 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
                     st.append((f.reshape(256), d0 | ((ridx // 16) << 23), d1))
                 if st:
                     tasks.append((st, seg))
-    nw = min(IS_WAVES, max(1, len(tasks)))
+    nw = min(waves, max(1, len(tasks)))
     loads, streams = [0] * nw, [[] for _ in range(nw)]
     for st, seg in sorted(tasks, key=lambda t: -len(t[0])):
         n = loads.index(min(loads))
@@ -490,7 +491,7 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int]):
 
 
 def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
-                      split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None) -> dict:
+                      split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None, waves: int = IS_WAVES) -> dict:
     """sub-schedule of the output segments `members` (indices into prog.seg_table); all table indices are emitted as ABSOLUTE indices
     into the concatenated tables of the launch (bases given)."""
     segs = prog.seg_table[members].copy()
@@ -514,9 +515,9 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256
                    for r in prog.item_table if int(r[19]) in local)
         ntab = sum(int(s[2]) * 16 for s in segs) + 4 + 16 * sum(ceil_div(sum(int(prog.seg_table[m][1]) for m in v), 16) for v in prog.vsegs)
-        if IS_WAVES * (off + maxstride) + ntab + need + 4 <= IS_LDS_BYTES // 4:
+        if waves * (off + maxstride) + ntab + need + 4 <= IS_LDS_BYTES // 4:
             copy_stride = off + maxstride                      # every private copy carries its own trash row
-            tiles_end = IS_WAVES * copy_stride
+            tiles_end = waves * copy_stride
     trash_off = off
     # row table (see IsSchedule.rowtab): offsets relative to the start of a tile copy
     lmax_part = (maxstride - 4) // 32
@@ -601,10 +602,10 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         else:                                                  # a work group's items by radial generator: the kernel keeps the hidden rows of
             units = [sorted(recs, key=lambda r: int(r[10]) if int(r[0]) == IT_TP else -1) for recs in by_seg.values()]      # ONE generator in registers
         if runs is not None and all(int(r[0]) == IT_LINM for recs in units for r in recs):
-            # the phase's folded items as IS_WAVES balanced streams of uniform steps, one work group each (disjoint (row tile, column) cells of the tiles)
-            units = [[st] for st in _lite_streams(prog, [r for recs in units for r in recs], runs, {sg: rt_base[n] for sg, n in local.items()})]
+            # the phase's folded items as `waves` balanced streams of uniform steps, one work group each (disjoint (row tile, column) cells of the tiles)
+            units = [[st] for st in _lite_streams(prog, [r for recs in units for r in recs], runs, {sg: rt_base[n] for sg, n in local.items()}, waves)]
         groups = sorted(((sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for r in recs), n) for n, recs in enumerate(units)), reverse=True)
-        loads = [0] * IS_WAVES
+        loads = [0] * waves
         for c, n in groups:                                    # claim order = LPT order
             loads[loads.index(min(loads))] += c
             gtab.append([item_base + len(items), item_base + len(items) + len(units[n])])
@@ -619,7 +620,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     if post_items:                                             # the last phase: nothing staged, one work group per segment's post-op, dearest first
         g0 = len(gtab)
         pc = lambda r: int(prog.seg_table[int(r[19])][2]) * (hp4 + int(prog.seg_table[int(r[19])][2]) * 4 * (2 * int(prog.seg_table[int(r[19])][0]) + 1)) + 60
-        loads = [0] * IS_WAVES
+        loads = [0] * waves
         for rec in sorted(post_items, key=lambda r: -pc(r)):
             r = rec.copy()
             r[1], r[2], r[3] = 0, -1, 0
@@ -675,7 +676,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             wide[n, 22], wide[n, 23] = _item_rto(items[n], prog.seg_table, prog.vsegs), vt_base[v]
     ctr_off = stage_off + stage_floats
     return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off,
-                phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (IS_WAVES * crit) if crit else 1.0, crit=crit)
+                phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (waves * crit) if crit else 1.0, crit=crit)
 
 
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:

@@ -208,7 +208,8 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
             maxstride = max((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4 for g in part_segs)
             # LDS layout of a part: [tile copies (each: tiles, trash row)] [row table] [staging area] [claim counter]
             assert trash_off == tile_floats and copy_stride in (0, tile_floats + maxstride) and (ctr_off + 4) * 4 <= P.IS_LDS_BYTES
-            assert rowtab_off == (P.IS_WAVES * copy_stride if copy_stride else tile_floats + maxstride) and stage_off == rowtab_off + rtn
+            waves_ = P.IS_WAVES_LITE if int(sched.part_table[0][11]) else P.IS_WAVES          # wave count of the kernel instantiation (private tile copies)
+            assert rowtab_off == (waves_ * copy_stride if copy_stride else tile_floats + maxstride) and stage_off == rowtab_off + rtn
             assert stage_off % 4 == 0
             rowtab = sched.rowtab[rt0:rt0 + rtn]
             lds = np.zeros(tile_floats + maxstride, dtype=dtype)               # one tile copy + its trash row
