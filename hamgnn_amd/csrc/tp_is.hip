@@ -443,16 +443,16 @@ __device__ __forceinline__ void item_lite(const IsArgs& A, const float* __restri
 // 16-row tile, column m or pair +-m); a step = one fragment (16 rows x up to 16 input channels, natural K) + two descriptor words; only the
 // K-steps that hold channels are issued (1..4 MFMAs, twice that for a pair): the input irreps with 2-12 channels fill a quarter or three
 // quarters of a K group.  The accumulators of a task live in registers and are added into the tile at its last step through the row table.
-// One instantiation for every row-tile count, so the request ring is 8 deep at 8 x 4 registers; descriptors arrive in blocks of 8 steps by
+// One instantiation for every row-tile count, so the request ring is SL_RING deep at 4 registers per slot; descriptors arrive in blocks of SL_RING steps by
 // ONE scalar load a block ahead (the r3 runs -- one stream per (phase, segment, row chunk), rtm row tiles per step, profiles/r03_lite.md --
 // carried a scalar load per step, which the step's MFMAs waited for: a wave can only wait for scalar loads with lgkmcnt(0)).
 #ifndef SL_RING
-#define SL_RING 8
+#define SL_RING 4                // 4 (r4, with 8 waves per workgroup: streams of ~25 steps, less padding) or 8
 #endif
-typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32xd __attribute__((ext_vector_type(2 * SL_RING)));          // the descriptors of SL_RING steps: one scalar load
 __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it, float* __restrict__ lds, int lane) {
     constexpr int RING = SL_RING;
-    static_assert(RING == 8, "descriptor blocks are 16 dwords = 8 steps (plan.LITE_SRING)");
+    static_assert(RING == 8 || RING == 4, "descriptor blocks are 2 * RING dwords (plan.LITE_SRING): s_load_dwordx16 / x8");
     const int g = lane >> 4, el = lane & 15;
     const int nsteps = it[8];                                  // a multiple of RING (no-op steps at the end), RING more slots behind
     const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + 4 * g;
@@ -461,14 +461,14 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
     // K-steps or not (no clamp, no branch around the reads: what is not issued never reaches an accumulator)
     const char* __restrict__ stage = reinterpret_cast<const char*>(lds + A.stage_off + el * 4 + g);      // + (descriptor & 0x3ff00): piece index << 8 = byte offset
     const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + it[11]) + lane;       // step t: aw[t * 64]
-    const i32x16* __restrict__ dsc = reinterpret_cast<const i32x16*>(Wb + it[12]);            // uniform, 64-byte aligned: s_load_dwordx16
+    const i32xd* __restrict__ dsc = reinterpret_cast<const i32xd*>(Wb + it[12]);              // uniform, 64-byte aligned: s_load_dwordx16 / x8
     f32x4 ring[RING];
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
         ring[j] = aw[j * 64];
         __builtin_amdgcn_sched_barrier(0);                     // slot order = request order (the scheduler issued the priming loads back to front otherwise, and the loop head's one static wait became vmcnt(0))
     }
-    i32x16 dc = dsc[0];
+    i32xd dc = dsc[0];
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
     int roff[4] = {0, 0, 0, 0};
     float bn[4], bnb[4];
@@ -484,7 +484,7 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
     }
 #pragma unroll 1
     for (int t0 = 0; t0 < nsteps; t0 += RING) {
-        const i32x16 dnx = dsc[(t0 >> 3) + 1];
+        const i32xd dnx = dsc[t0 / RING + 1];
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
             const f32x4 av = ring[j];
@@ -496,7 +496,7 @@ __device__ __forceinline__ void stream_lite(const IsArgs& A, const float* __rest
                 bb[q] = bnb[q];
             }
             {                                                  // operands of the next step, requested before this step's MFMAs (a wave issues in order)
-                const int dn = j + 1 < RING ? dc[(2 * j + 2) & 15] : dnx[0], en = j + 1 < RING ? dc[(2 * j + 3) & 15] : dnx[1];
+                const int dn = j + 1 < RING ? dc[(2 * j + 2) % (2 * RING)] : dnx[0], en = j + 1 < RING ? dc[(2 * j + 3) % (2 * RING)] : dnx[1];
                 const float* __restrict__ fb = reinterpret_cast<const float*>(stage + (dn & 0x3ff00));
                 const float* __restrict__ fc = reinterpret_cast<const float*>(stage + (en & 0x3ff00));
                 const int sgn = en << 31;

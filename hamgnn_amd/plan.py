@@ -37,7 +37,7 @@ IT_LIN = 1       # GEMM1 only (plain o3.Linear path), rows = output channels, ad
 IT_LINC = 2      # IT_LIN with a per-column coefficient (lite_mode uvu path: aligned-frame CG coefficient per m)
 IT_POST = 3      # lite_mode segment post-op: tile <- Lc^T (s_e * tile)
 IT_STREAM = 6    # lite_mode, input-stationary schedule (r4): the folded items of one PHASE as IS_WAVES_LITE balanced streams of uniform steps (plan._lite_streams)
-LITE_SRING = 8   # request ring / descriptor block of csrc/tp_is.hip:stream_lite (SL_RING)
+LITE_SRING = int(os.environ.get("HG_LITE_SRING", "4"))   # request ring / descriptor block of csrc/tp_is.hip:stream_lite (SL_RING: 8 or 4)
 IT_LINM = 4      # lite_mode, ALL paths (i, l_sh, k) of one (i, k) folded: one weight matrix per column, A_m = sum_paths cf_path[m] A_path (input-stationary kernel only)
 # segment flags
 SEG_UNROTATE = 1     # epilogue applies D^l(R_e)^T (messages go back to the global frame before the node scatter)
@@ -481,7 +481,7 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int], wa
         lead = (-base) % 16                                    # fragments and descriptor blocks on 64-byte boundaries (s_load_dwordx16)
         wblob = np.concatenate(frags).astype(np.float64)
         dblob = np.asarray(desc, dtype=np.int64).astype(np.uint32).view(np.float32).astype(np.float64)      # bit patterns (exact: float32 -> float64 -> float32)
-        assert (wblob.size % 16, dblob.size % 16) == (0, 0) and np.array_equal(dblob.astype(np.float32).view(np.uint32), np.asarray(desc, dtype=np.int64).astype(np.uint32))
+        assert (wblob.size % 16, dblob.size % (2 * LITE_SRING)) == (0, 0) and np.array_equal(dblob.astype(np.float32).view(np.uint32), np.asarray(desc, dtype=np.int64).astype(np.uint32))
         runs["w"] += [np.zeros(lead), wblob, dblob]
         rec = np.zeros(ITEM_I32, dtype=np.int64)
         rec[0], rec[8], rec[9], rec[11], rec[12], rec[19] = IT_STREAM, nst + npad, 1, base + lead, base + lead + wblob.size, stream[0][1]

@@ -240,7 +240,7 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                             seen.add(ii)
                             Wall = np.concatenate([prog.weights.astype(dtype), sched.extra_weights.astype(dtype)])
                             nst, w0, d0 = int(it[8]), int(it[11]), int(it[12])
-                            assert nst % P.LITE_SRING == 0 and w0 % 16 == 0 and d0 % 16 == 0
+                            assert nst % P.LITE_SRING == 0 and w0 % 16 == 0 and d0 % (2 * P.LITE_SRING) == 0
                             desc = Wall[d0:d0 + 2 * (nst + P.LITE_SRING)].astype(np.float32).view(np.int32)
                             assert not desc[2 * nst:].any() and not Wall[w0 + nst * 256:w0 + (nst + P.LITE_SRING) * 256].any()
 
