@@ -74,28 +74,18 @@ struct Prof { unsigned long long t[12]; unsigned long long last; };
 
 // ablation hooks (timing experiments only, tests/build_variants.sh): HG_SINK keeps a value alive without using it
 #define HG_SINK(v) asm volatile("" ::"v"(v))
-#ifdef HG_ABL_NOA
-#define HG_LDA(p) ((f32x4){.1f, .2f, .3f, .4f})
-#else
 #define HG_LDA(p) (*(p))
-#endif
 #ifndef HG_DMA_AUX
 #define HG_DMA_AUX 2              // cache policy of the B-operand DMA: nt (streamed once per CU; keeps the shared A lines in L1; r1 A/B: -3 %)
 #endif
 // tiles and DMA rings are wave-private: the four waves of a workgroup never exchange data, so a wave-local LDS fence
 // (LDS ops of one wave retire in order) replaces workgroup barriers and the waves free-run (their DMA waits interleave).
-#ifdef HG_USE_BARRIER
-#define HG_WAVE_FENCE() __syncthreads()
-#else
 #define HG_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-#endif
 #define HG_STAGE_FLOATS 2816      // wave-private LDS-DMA ring for B operands: 11 KiB = 11 x 1-KiB (float4) or 44 x 256-B (dword) slots
 
 // LDS-DMA: per-lane global address -> LDS at (wave-uniform base + lane * size); no VGPR round trip, counted by vmcnt
 __device__ __forceinline__ void hg_dma16(const float* __restrict__ gsrc, float* lds_dst) {
-#ifndef HG_ABL_NOB
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, HG_DMA_AUX);
-#endif
 }
 __device__ __forceinline__ void hg_dma4(const float* __restrict__ gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
@@ -142,11 +132,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
     // per column bumped by a constant (the r1 ISA audit of the previous swizzled image showed 241 instructions per 14 MFMAs
     // in this loop -- issue-bound on address arithmetic, not memory-bound).  ds_read_b128 of 16 rows is conflict-free, the
     // dword reads of x1 mode are 2-way.
-#ifdef HG_ABL_NOG1
-    const int nsrc = 0;
-#else
     const int nsrc = s1 >= 0 ? 2 : 1;
-#endif
     const int ngrp = (ksteps + 3) >> 2;
     const int P1 = in_mulp >> 2;                               // float4 pieces per column
     const int P = NC * P1;                                     // pieces per row span (planner guarantees P <= 40)
@@ -175,11 +161,7 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
         for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float* __restrict__ hrow = (mlp ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
         const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + it[12]) + lane;
-#ifdef HG_ABL_NOSCALE
-        const int hgrp = 1;
-#else
         const int hgrp = A.hidden >> 4;
-#endif
 #pragma unroll 1
         for (int G0 = 0; G0 < hgrp; G0 += 4) {
             f32x4 hb[4], wv[4][RTM];
@@ -280,27 +262,14 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
         f32x4 a2_n[RTM];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = HG_LDA(a2 + rt * 64);
-#ifdef HG_ABL_NOSCALEMUL
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) HG_SINK(S[rt]);
-#else
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt)
 #pragma unroll
             for (int c = 0; c < NC; ++c) mid[rt][c] = mid[rt][c] * S[rt] * HG_LDA(cf + (rt * NC + c) * 4);
-#endif
 
         HG_T(4);                                                // mid *= S * cf (+ a2 / cf loads)
         // ------------------------------------------------------------ GEMM2: tile[w'', m] += L' fragments x mid
-#ifdef HG_ABL_NOG2
-        const int rto_run = 0;
-#pragma unroll
-        for (int rt = 0; rt < RTM; ++rt)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) HG_SINK(mid[rt][c]);
-#else
         const int rto_run = rto;
-#endif
 #pragma unroll 1
         for (int rtp = 0; rtp < rto_run; ++rtp) {
             f32x4 av[RTM];
@@ -324,12 +293,8 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
-#ifdef HG_ABL_NOWB
-                        acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#else
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[c][r] = trow[r][(c0 + c) * 16];
-#endif
                     }
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt)
@@ -344,12 +309,8 @@ __device__ __forceinline__ void item_body(const TpArgs& A, const float* __restri
 #pragma unroll
                 for (int c = 0; c < CW; ++c)
                     if (c0 + c < NC) {
-#ifdef HG_ABL_NOWB
-                        HG_SINK(acc[c]);
-#else
 #pragma unroll
                         for (int r = 0; r < 4; ++r) trow[r][(c0 + c) * 16] = acc[c][r];
-#endif
                     }
             }
         }
@@ -561,9 +522,7 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         const int nco = 2 * lk + 1;
         const int rowstride = nco * 16 + 4;
         const int tfl = (mul_k + 1) * rowstride;           // + trash row for padded fragment rows
-#ifndef HG_ABL_NOZERO
         for (int i = lane; i < tfl; i += 64) tile[i] = 0.f;
-#endif
         HG_WAVE_FENCE();
         HG_T(7);                                               // segment set-up: tile zeroing
         for (int ii = ib; ii < ie; ++ii) {
@@ -589,7 +548,6 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
             }
         }
         HG_WAVE_FENCE();
-#ifndef HG_ABL_NOEPI
         // opaque per segment: the row-derived pointers of the epilogue (output, residual rows, Wigner blocks) are rebuilt here instead of
         // being hoisted out of the segment loop and carried -- spilled, in the lite_mode instantiation -- through all items
         int64_t e_o = e, erow_o = erow;
@@ -608,7 +566,6 @@ __global__ __launch_bounds__(256, HG_TP_WAVES) void tp_fused_kernel(const TpArgs
         }
 #undef e
 #undef erow
-#endif
         HG_WAVE_FENCE();
         HG_T(8);                                               // epilogue
     }

@@ -690,21 +690,10 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
     }
 }
 
-#ifdef IS_ONLY               // ISA / register-pressure audit of ONE instantiation (compile-only experiment)
-#define IS_CASE(MMv, RTMv) \
-    case (MMv * 8 + RTMv): if (MMv * 8 + RTMv == IS_ONLY) item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
-#define IS_CASE_ODD(MMv, RTMv)
-#else
 #define IS_CASE(MMv, RTMv) \
     case (MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
-#ifdef HG_NO_ODD_SKIP                 // A/B hook: odd items through the full-column code
-#define IS_CASE_ODD(MMv, RTMv) \
-    case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, false>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
-#else
 #define IS_CASE_ODD(MMv, RTMv) \
     case (64 + MMv * 8 + RTMv): item_is<MMv, RTMv, SPLIT, true>(A, g_W, it, lds, erow, lane, hbr, hbr_cls IS_PROF_PASS); break;
-#endif
-#endif
 
 // A launch runs `nparts` sub-schedules (blockIdx.y) of the same program: every part owns a disjoint set of output segments and the
 // phases / groups / items that feed them (plan.py:is_schedule(parts=...)).  One part = the whole program (large edge counts); several
@@ -775,17 +764,11 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
 #pragma unroll
             for (int G = 0; G < 4; ++G) hbr[G] = hbr_cls >= 0 ? *reinterpret_cast<const f32x4*>(hrow + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-#ifdef HG_IS_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();                                       // every wave is done with the previous blocks (and the zero fill)
         IS_T(5);                                               // waiting for the slowest wave of the previous phase
         if (threadIdx.x == 0) *ctr = g0;
 #pragma unroll 1
         for (int b = b0; b < b1; ++b) {
-#ifdef HG_ABL_NOSTAGE
-            if (A.rows > 0) continue;
-#endif
             const int* __restrict__ B = g_blocks + b * 8;
             switch (B[4]) {
                 case 0: stage_block<0, NW>(A, B, stage, erow, wave, lane); break;
@@ -804,9 +787,6 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         IS_T(6);                                               // staging the phase's input blocks
-#ifdef HG_IS_PRIO
-        __builtin_amdgcn_s_setprio(HG_IS_PRIO);                // MFMA phases of this workgroup win issue arbitration over the other's staging
-#endif
         // work groups = all items of one (phase, output segment), claimed largest-first: dynamic balance, and a tile is only ever
         // updated by one wave between two barriers
         while (true) {
@@ -815,21 +795,10 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
             gi = __builtin_amdgcn_readfirstlane(gi);
             if (gi >= g1) break;
             const int ib = g_groups[2 * gi], ie = g_groups[2 * gi + 1];
-#ifdef HG_ABL_NOITEMS             // ablation: the launch without its items (wrong results; what the skeleton around them costs)
-            if (A.rows > 0) continue;
-#endif
             for (int ii = ib; ii < ie; ++ii) {
                 const int* __restrict__ it = g_items + ii * 24;
                 if (LITE) {                                    // lite_mode programs: their own (small) items, their own kernel instantiation
                     IS_T(0);                                   // dispatch / claim
-#ifdef HG_ABL_NOPOST
-                    if (it[0] == 3) continue;
-#endif
-#ifdef HG_ABL_NOLINM
-                    if (it[0] != 3) continue;
-#endif
-#ifdef HG_ABL_LINM_NOWB
-#endif
                     if (it[0] == 3) {                          // post-op of one segment (the part's last phase)
                         if (it[22] == 1) post_is<1>(A, g_W, it, lds, erow, lane);
                         else if (it[22] == 2) post_is<2>(A, g_W, it, lds, erow, lane);
@@ -845,12 +814,6 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
                     continue;
                 }
                 switch (it[6] * 8 + it[9] + ((it[0] == 0 && it[7]) ? 64 : 0)) {
-#if IS_NW > 4                      // three waves per SIMD: 168 VGPRs per wave, row-tile table 2,2,2,1,1,1,1 (HG_RTM)
-                    IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(3, 1) IS_CASE(4, 1) IS_CASE(5, 1)
-                    IS_CASE(6, 1)
-                    IS_CASE_ODD(1, 1) IS_CASE_ODD(1, 2) IS_CASE_ODD(2, 1) IS_CASE_ODD(2, 2) IS_CASE_ODD(3, 1) IS_CASE_ODD(4, 1) IS_CASE_ODD(5, 1)
-                    IS_CASE_ODD(6, 1)
-#else
                     IS_CASE(0, 1) IS_CASE(0, 2) IS_CASE(0, 3) IS_CASE(0, 4)
                     IS_CASE(1, 1) IS_CASE(1, 2) IS_CASE(1, 3) IS_CASE(1, 4)
                     IS_CASE(2, 1) IS_CASE(2, 2) IS_CASE(2, 3)              // row-tile table of plan.py:rtm_max (4,4,3,2,2,1,1): the r1 shapes
@@ -864,7 +827,6 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
                     IS_CASE_ODD(4, 1) IS_CASE_ODD(4, 2)
                     IS_CASE_ODD(5, 1)
                     IS_CASE_ODD(6, 1)
-#endif
                     default: break;
                 }
             }
@@ -886,9 +848,6 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
     scan.last = true, scan.row = 0;
     if (!SPLIT && A0.run_id) scan = is_scan_setup(valid ? A0.run_id[e] : -1 - (int)(lane & 15), lane & 15);
     for (int sg = seg0; sg < seg1; ++sg) {
-#ifdef HG_ABL_NOEPI
-        if (A.rows > 0) continue;
-#endif
         const int* __restrict__ S8 = g_segs + sg * 8;
         const int lk = S8[0], mul_k = S8[1], out_off = S8[3], out_mulp = S8[4], tile_off = S8[5], woff = S8[6], flags = S8[7];
         if (sg == seg0 || (flags & SEG_NEWBATCH)) {

@@ -167,11 +167,7 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
 #endif
 // piece index t -> (component a, channel piece p): t / P1 through the reciprocal (t < 2^9, P1 <= 16: (t + 0.5) / P1 is never within 0.03 of an
 // integer, so the float product rounds to the right side); an integer division per piece cost as much as the piece's own loads + FMAs at l = 0
-#ifndef HG_STAGE_IDIV
 #define HG_DIV_P1(t) ((int)(((float)(t) + 0.5f) * inv_P1))
-#else
-#define HG_DIV_P1(t) ((t) / P1)
-#endif
 #ifndef HG_STAGE_U
 #define HG_STAGE_U(L) 1          // measured (profiles/r02_tp_is_experiments.md): 2-4 pieces in flight per step are SLOWER (8.39 vs 8.13 ms)
 #endif
