@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import plan as P
+from . import ops
 from .ops import scatter_rows as _scatter_rows
 
 
@@ -203,6 +204,29 @@ class TPWeightGrad:
             if keys["lo"] is not None:
                 Lo_flat = self.param(keys["lo"], dev, dt).reshape(-1)
                 gLo = torch.zeros_like(Lo_flat)
+            if keys["lo"] is not None and dt == torch.float32 and ops.use_block_gemm(Ls_flat):
+                # the two products per output irrep as TWO launches of csrc/block_gemm.hip per branch (26 library GEMMs + their slicing before)
+                cache = self.__dict__.setdefault("_bg_finish", {})
+                if (name, dev) not in cache:
+                    ua, ub, seen_ = [], [], set()
+                    for c in self.chunks:
+                        sp = c["sp"]
+                        if c["branch"] != name or sp["k"] in seen_:
+                            continue
+                        seen_.add(sp["k"])
+                        (off, fan), lo_off, mk = sp["lin"], sp["lo_off"], sp["mk"]
+                        sc = 1.0 / (math.sqrt(fan) * math.sqrt(mk))
+                        ua.append((off, mk, 0, lo_off, mk, 1, off, mk, fan, mk, mk, sc))          # gLs_k = gL_k @ Lo_k^T
+                        ub.append((off, mk, 1, off, mk, 0, lo_off, mk, mk, mk, fan, sc))          # gLo_k = Ls_k^T @ gL_k
+                    cache[(name, dev)] = (ops.BlockGemm(ua, dev), ops.BlockGemm(ub, dev))
+                bga, bgb = cache[(name, dev)]
+                gL_flat = acc[f"{name}_L"].contiguous()
+                ops.block_gemm(bga, gL_flat, Lo_flat.contiguous(), gLs)
+                ops.block_gemm(bgb, Ls_flat.contiguous(), gL_flat, gLo)
+                out[keys["ls"]] = gLs
+                out[keys["lo"]] = gLo
+                out.update(gW3[name])
+                continue
             seen = set()
             for c in self.chunks:
                 sp = c["sp"]

@@ -310,7 +310,16 @@ class MessagePackBlock(nn.Module):
         lays = RP.mp_branch_layouts(self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
         args = (self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
         nskip = int(skip.numel()) if skip is not None else 0
-        src = RP.mp_sources(lambda k: params[k].double().reshape(-1), last, lays, None if skip is None else skip.detach().double().reshape(-1), lib=torch)
+        lp = None
+        dev0 = self._dp.weights.device
+        if ops.use_block_gemm(self._dp.weights):               # the 13 L' products of a branch in ONE launch (csrc/block_gemm.hip) instead of 13 GEMMs
+            if getattr(self, "_bg_lp", None) is None or self._bg_lp[0] != dev0:
+                self._bg_lp = (dev0, {name: (ops.BlockGemm(RP.lp_block_units(lay)[0], dev0), RP.lp_block_units(lay)[1]) for name, lay in lays})
+            lp = {}
+            for name, (bg, total) in self._bg_lp[1].items():
+                ls, lo = params[f"{name}_linear_scaler.linear_out.weight"].float().reshape(-1).contiguous(), params[f"{name}_linear_out.weight"].float().reshape(-1).contiguous()
+                lp[name] = ops.block_gemm(bg, ls, lo, torch.empty(total, device=dev0, dtype=torch.float64))
+        src = RP.mp_sources(lambda k: params[k].double().reshape(-1), last, lays, None if skip is None else skip.detach().double().reshape(-1), lib=torch, lp=lp)
 
         def packer(tag, fn, ns):
             if tag not in self._packers:

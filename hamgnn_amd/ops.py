@@ -204,6 +204,32 @@ def linear_wgrad(irreps_in, irreps_out, x: torch.Tensor, gy: torch.Tensor) -> to
     return part.sum(0)[gather] * scale
 
 
+class BlockGemm:
+    """unit table of csrc/block_gemm.hip on the device: units = [(a_off, a_ld, a_trans, b_off, b_ld, b_trans, c_off, c_ld, M, N, K, scale)]"""
+
+    def __init__(self, units, device):
+        arr = np.zeros((max(1, len(units)), 12), np.int32)
+        for n, u in enumerate(units):
+            arr[n, :11] = [int(v) for v in u[:11]]
+            arr[n, 11] = np.float32(u[11]).view(np.int32)
+        self.nunits = len(units)
+        self.max_tiles = max([-(-int(u[8]) // 64) * -(-int(u[9]) // 64) for u in units], default=1)
+        self.units_np, self.units = arr, _dev(arr, device)
+
+
+def use_block_gemm(t: torch.Tensor) -> bool:
+    """hg_block_gemm is a HIP entry point: device tensors only (the CPU suite swaps block_gemm for its numpy twin and takes it too)"""
+    return (t.is_cuda or block_gemm.__module__ != __name__) and os.environ.get("HG_BLOCK_GEMM", "1") != "0"
+
+
+def block_gemm(bg: BlockGemm, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """c[c_off + m * c_ld + n] = scale * sum_k op(a)[m, k] op(b)[k, n] for every unit of `bg` (a, b: flat fp32; c: flat fp32 or fp64, written in place)"""
+    _require_gpu(a)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and c.dtype in (torch.float32, torch.float64) and a.is_contiguous() and b.is_contiguous() and c.is_contiguous()
+    check(lib().hg_block_gemm(ptr(a), ptr(b), ptr(c), i32(1 if c.dtype == torch.float64 else 0), ptr(bg.units), i32(bg.nunits), i32(bg.max_tiles), _stream()), "hg_block_gemm")
+    return c
+
+
 def wig_offsets(lmax):
     offs, tot = P.wigner_offsets(lmax)
     arr = (C.c_int * 8)(*([int(o) for o in offs] + [0] * (8 - len(offs))))

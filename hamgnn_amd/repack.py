@@ -109,13 +109,27 @@ def mp_probe_state_dict(src: Dict[str, np.ndarray], sd_shapes, last_keys, layout
     return sd
 
 
-def mp_sources(get, last_keys, layouts, skip=None, lib=np):
+def lp_block_units(lay):
+    """csrc/block_gemm.hip units of one branch's L' products (flat layouts of linear_scaler.linear_out / linear_out): unit k writes
+    Ls_k [fan, mul_k] @ Lo_k [mul_k, mul_k] / sqrt(mul_k) behind the blocks before it"""
+    units, o = [], 0
+    for (k, off, fan, lo_off, mk) in lay:
+        units.append((off, mk, 0, lo_off, mk, 0, o, mk, fan, mk, mk, 1.0 / math.sqrt(mk)))
+        o += fan * mk
+    return units, o
+
+
+def mp_sources(get, last_keys, layouts, skip=None, lib=np, lp=None):
     """the real sources of a block from its parameters: `get(name)` -> flat array / tensor; lib = numpy or torch.
-    L' block of output irrep k, in linear_scaler's flat layout:  Ls_k @ Lo_k / sqrt(mul_k)  (the builder applies 1 / sqrt(fan))."""
+    L' block of output irrep k, in linear_scaler's flat layout:  Ls_k @ Lo_k / sqrt(mul_k)  (the builder applies 1 / sqrt(fan)).
+    lp: {branch: the concatenated L' blocks} when the caller has them already (one hg_block_gemm launch per branch on the device)."""
     out = {}
     for name, lay in layouts:
         out[f"{name}_tp"] = get(f"{name}_tensor_product.weight")
         out[f"{name}_w3"] = get(last_keys[name])
+        if lp is not None and name in lp:
+            out[f"{name}_lp"] = lp[name]
+            continue
         ls, lo = get(f"{name}_linear_scaler.linear_out.weight"), get(f"{name}_linear_out.weight")
         parts = []
         for (k, off, fan, lo_off, mk) in lay:

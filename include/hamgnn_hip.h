@@ -128,6 +128,15 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
              const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
              int64_t rows, void* stream);
 
+/* Many small independent matrix products in one launch (csrc/block_gemm.hip):  C_u = scale_u * op(A_u) @ op(B_u).  Replaces the per-irrep
+ * products of a MessagePackBlock's two trailing Linears -- linear_scaler.linear_out @ linear_out / sqrt(mul_k)
+ * (hamgnn/nn/message_passing.py:122-130, nn/tensor_products.py:118-140) -- in the device-side weight repack and, transposed, in the backward of
+ * those Linears: 13 irreps x 2 branches per block as library GEMMs before.  a, b: DEVICE fp32 buffers the units index into; c: DEVICE fp32 or
+ * fp64 (c_is_double) buffer; units int32[nunits][12] = {a_off, a_ld, a_trans, b_off, b_ld, b_trans, c_off, c_ld, M, N, K, scale (float bits)}
+ * (element offsets; a_trans: op(A)[m, k] = A[a_off + k * a_ld + m]); max_tiles = max over the units of ceil(M / 64) * ceil(N / 64).
+ * fp64 accumulation.                                                                                                            */
+int hg_block_gemm(const float* a, const float* b, void* c, int c_is_double, const int32_t* units, int nunits, int max_tiles, void* stream);
+
 /* Weight gradient of an o3.Linear on planar rows, all paths in one launch (csrc/linear_wgrad.hip): what torch.autograd computes for the weight of
  * the e3nn o3.Linears of the path when the reference trains (hamgnn/models/Model.py:150-196; nn/interaction_blocks.py:332-358,
  * nn/convolution.py:127, models/hamgnn_output.py:49-58).  units int32[nunits][8] = {x_off, x_mulp, g_off, g_mulp, 2 l + 1, first input channel,

@@ -157,6 +157,20 @@ def linear_planar(dl, x, res=(), tag="linear"):
     return _t(emu.run_linear_tables(tabs, _np(x), [_np(r) for r in res if r is not None]))
 
 
+def block_gemm(bg, a, b, c):
+    A, B = _np(a).reshape(-1).astype(np.float64), _np(b).reshape(-1).astype(np.float64)
+    out = _np(c).reshape(-1).copy()
+    for u in bg.units_np[:bg.nunits]:
+        a_off, a_ld, a_tr, b_off, b_ld, b_tr, c_off, c_ld, M, N, K = (int(v) for v in u[:11])
+        scale = float(u[11:12].view(np.float32)[0])
+        m, n, k = np.arange(M)[:, None], np.arange(N)[None, :], np.arange(K)
+        Am = A[a_off + (k[None, :] * a_ld + m if a_tr else m * a_ld + k[None, :])]
+        Bm = B[b_off + (n * b_ld + k[:, None] if b_tr else k[:, None] * b_ld + n)]
+        out[c_off + (m * c_ld + n)] = scale * (Am @ Bm)
+    c.copy_(torch.from_numpy(out).reshape(c.shape).to(c.dtype))
+    return c
+
+
 def segment_sum(msg, rowptr, perm, N):
     out = torch.zeros(N, msg.shape[1])
     seg = torch.repeat_interleave(torch.arange(N), rowptr[1:] - rowptr[:-1])
@@ -375,5 +389,5 @@ def install(mp):
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
     for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "row_program", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
                  "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "block_mean", "soc_assemble", "attention_aggregate",
-                 "attention_logits", "hk_assemble", "zero_point_shift"):
+                 "attention_logits", "hk_assemble", "zero_point_shift", "block_gemm"):
         mp.setattr(ops, name, globals()[name])
