@@ -877,6 +877,39 @@ def check_charge_doping_corr(device="cuda"):
     return out
 
 
+def check_block_gemm(device="cuda"):
+    """hg_block_gemm (a table of small independent products, fp64 accumulation) vs float64 matmuls: plain / transposed operands, ragged sizes,
+    K beyond one chunk, fp32 and fp64 results"""
+    from hamgnn_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    a, b = torch.randn(200000, generator=gen), torch.randn(200000, generator=gen)
+    shapes = [(832, 64, 64, 0, 0), (64, 64, 832, 1, 0), (13, 9, 5, 0, 1), (70, 3, 130, 1, 1), (1, 1, 1, 0, 0), (100, 65, 17, 0, 0)]
+    units, want, ao, bo, co = [], [], 0, 0, 0
+    for M, N, K, ta, tb in shapes:
+        a_ld, b_ld, c_ld, sc = (M if ta else K) + 3, (K if tb else N) + 2, N + 1, 0.37 + 0.1 * len(units)
+        A = a[ao:ao + (K if ta else M) * a_ld].reshape(-1, a_ld).double()
+        B = b[bo:bo + (N if tb else K) * b_ld].reshape(-1, b_ld).double()
+        opA = A[:K, :M].t() if ta else A[:M, :K]
+        opB = B[:N, :K].t() if tb else B[:K, :N]
+        units.append((ao, a_ld, ta, bo, b_ld, tb, co, c_ld, M, N, K, sc))
+        want.append((co, c_ld, M, N, float(np.float32(sc)) * (opA @ opB)))
+        ao, bo, co = ao + A.numel(), bo + B.numel(), co + M * c_ld
+    bg = ops.BlockGemm(units, device)
+    out = {}
+    for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+        c = torch.full((co,), 7.0, dtype=dt, device=device)
+        ops.block_gemm(bg, a.to(device), b.to(device), c)
+        torch.cuda.synchronize()
+        cc = c.double().cpu()
+        err = 0.0
+        for o, ld, M, N, W in want:
+            got = cc[o:o + M * ld].reshape(M, ld)
+            err = max(err, float((got[:, :N] - W).abs().max() / W.abs().max()))
+            assert bool((got[:, N:] == 7.0).all())                  # nothing outside the unit's block is written
+        out[f"{tag}_rel_err"] = err
+    return out
+
+
 def check_transformer(device="cuda"):
     """HamGNNTransformer (attention backbone) vs the reference fixture, and one AttentionBlockE3 on its own"""
     from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer

@@ -167,6 +167,12 @@ def test_band_energies_export_on_cpu(cpu_backend):
     assert all(v < (2e-3 if k.endswith("wf_abs_err") else 2e-4) for k, v in r.items()), r
 
 
+def test_block_gemm_tables_on_cpu(cpu_backend):
+    """the unit tables of hg_block_gemm through the numpy twin of the kernel (same check as on the GPU)"""
+    r = G.check_block_gemm("cpu")
+    assert r["f64_rel_err"] < 1e-13 and r["f32_rel_err"] < 2e-7, r
+
+
 def test_training_loop_on_cpu(cpu_backend):
     """a few optimiser steps of the whole model (training_step -> Adam -> device-side refresh of the packed weights at the next forward):
     the teacher-student loss falls monotonically"""

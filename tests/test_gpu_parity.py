@@ -108,6 +108,13 @@ def test_backbone_charge_doping_with_corr_product_golden():
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
 
+def test_block_gemm_kernel_vs_float64_matmuls():
+    """hg_block_gemm: plain / transposed operands, ragged sizes, fp32 and fp64 results (fp64 accumulation)"""
+    r = G.check_block_gemm()
+    print(r)
+    assert r["f64_rel_err"] < 1e-13 and r["f32_rel_err"] < 2e-7, r
+
+
 def test_transformer_backbone_golden():
     r = G.check_transformer()
     print(r)
