@@ -968,35 +968,46 @@ class HamLayer(nn.Module):
 # ------------------------------------------------------------------------------------------------ correlation product (a21)
 class _Contraction(nn.Module):
     """parameter holder of one MACE Contraction (toolbox/mace/modules/symmetric_contraction.py:101-233): weights_max for nu =
-    correlation, weights[0] for nu = 1; shapes [num_elements, num_paths, num_features]."""
+    correlation, weights[0], weights[1], ... for nu = correlation - 1, ..., 1; shapes [num_elements, num_paths, num_features]."""
 
-    def __init__(self, num_elements, k1, k2, num_features):
+    def __init__(self, num_elements, ks, num_features):
         super().__init__()
-        self.weights_max = nn.Parameter(torch.randn(num_elements, k2, num_features) / max(1, k2))
-        self.weights = nn.ParameterList([nn.Parameter(torch.randn(num_elements, k1, num_features) / max(1, k1))])
+        mk = lambda k: nn.Parameter(torch.randn(num_elements, k, num_features) / max(1, k))
+        self.weights_max = mk(ks[-1])                          # ks: number of paths for nu = 1 ... correlation
+        self.weights = nn.ParameterList([mk(k) for k in reversed(ks[:-1])])
+
+    def by_nu(self, nu):
+        corr = len(self.weights) + 1
+        return self.weights_max if nu == corr else self.weights[corr - 1 - nu]
+
+    def name_of(self, nu):
+        corr = len(self.weights) + 1
+        return "weights_max" if nu == corr else f"weights.{corr - 1 - nu}"
 
 
 class _SymmetricContraction(nn.Module):
-    def __init__(self, num_elements, K1, K2, num_features):
+    def __init__(self, num_elements, Ks, num_features):
         super().__init__()
-        self.contractions = nn.ModuleList([_Contraction(num_elements, k1, k2, num_features) for k1, k2 in zip(K1, K2)])
+        self.contractions = nn.ModuleList([_Contraction(num_elements, ks, num_features) for ks in zip(*Ks)])
 
 
 class _ProductBasis(nn.Module):
-    def __init__(self, irreps_hidden, num_elements, K1, K2, num_features):
+    def __init__(self, irreps_hidden, num_elements, Ks, num_features):
         super().__init__()
-        self.symmetric_contractions = _SymmetricContraction(num_elements, K1, K2, num_features)
+        self.symmetric_contractions = _SymmetricContraction(num_elements, Ks, num_features)
         self.linear = E3Linear(irreps_hidden, irreps_hidden)
 
 
 class CorrProductBlock(nn.Module):
-    """Drop-in for hamgnn/nn/interaction_blocks.py:168-260 (correlation 2): linear_pre -> symmetric contraction with element-
-    dependent weights -> prod.linear -> linear_out (+ linear_sc skip), all on planar node rows; same parameter names."""
+    """Drop-in for hamgnn/nn/interaction_blocks.py:168-260 (correlation 1, 2 -- the reference default -- or 3): linear_pre -> symmetric
+    contraction with element-dependent weights -> prod.linear -> linear_out (+ linear_sc skip), all on planar node rows; same parameter
+    names.  The nu <= 2 part of the contraction is the hg_sym_contraction kernel, the nu = 3 term hamgnn_amd/corr3.py."""
 
     def __init__(self, irreps_node_feats, num_hidden_features, correlation, num_elements, use_skip_connections=True):
         super().__init__()
-        if correlation != 2:
-            raise NotImplementedError("CorrProductBlock: correlation 2 (the reference default) is built")
+        if correlation not in (1, 2, 3):
+            raise NotImplementedError("CorrProductBlock: correlation 1, 2 (the reference default) and 3 are built")
+        self.correlation = correlation
         self.irreps = Irreps(irreps_node_feats)
         if len({(l, p) for _, l, p in self.irreps}) != len(self.irreps):
             raise NotImplementedError("CorrProductBlock expects simplified node irreps (one entry per (l, p))")
@@ -1005,7 +1016,8 @@ class CorrProductBlock(nn.Module):
         self._tab_np = P.sym_contraction_tables(self.irreps_hidden, correlation)
         self.linear_pre = E3Linear(self.irreps, self.irreps_hidden)
         self.linear_sc = E3Linear(self.irreps, self.irreps)
-        self.prod = _ProductBasis(self.irreps_hidden, num_elements, self._tab_np["K1"], self._tab_np["K2"], num_hidden_features)
+        Ks = [self._tab_np[f"K{nu}"] for nu in range(1, correlation + 1)]
+        self.prod = _ProductBasis(self.irreps_hidden, num_elements, Ks, num_hidden_features)
         self.linear_out = E3Linear(self.irreps_hidden, self.irreps)
         self._tab = None
 
@@ -1015,20 +1027,29 @@ class CorrProductBlock(nn.Module):
         t = self._tab_np
         self._tab = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in t.items()}
         cons = self.prod.symmetric_contractions.contractions
-        self._W2 = torch.cat([c.weights_max.detach() for c in cons], dim=1).float().contiguous().to(device)
-        self._W1 = torch.cat([c.weights[0].detach() for c in cons], dim=1).float().contiguous().to(device)
+        cat = lambda nu: torch.cat([c.by_nu(nu).detach() for c in cons], dim=1).float().contiguous().to(device)
+        self._W1 = cat(1)
+        # correlation 1: the kernel's nu = 2 loop runs over empty entry lists; it still wants a weight pointer
+        self._W2 = cat(2) if self.correlation >= 2 else torch.zeros(self._W1.shape[0], 1, self._W1.shape[2], device=device)
+        self._W3 = cat(3) if self.correlation >= 3 else None
         self._hdim = P.PlanarLayout(self.irreps_hidden).dim
         return self
+
+    def _contract(self, h, zi, W1, W2, W3):
+        c = ops.sym_contraction(h, zi, self.num_hidden, self._tab, W1, W2, self._hdim)
+        if W3 is not None:
+            from .corr3 import sym3_forward
+            c = sym3_forward(self._tab, h, zi, W3, self.num_hidden, c)
+        return c
 
     def _mixed(self, z, delta):
         """apply_charge_doping: the reference contracts the element weights with node_attrs = one_hot(z) + delta (interaction_blocks.py:251,
         symmetric_contraction.py einsum '...,ek'), i.e. every node gets its own mixture of the element blocks: W_eff[n] = W[z_n] + delta_n @ W.
-        Returns (attrs [N, T], per-node weights, node index as the 'element' index) for the same kernel."""
+        Returns (attrs [N, T], per-node weights of nu = 1, 2, 3, node index as the 'element' index) for the same kernel."""
         T = self._W1.shape[0]
         A = torch.nn.functional.one_hot(z.long(), T).to(self._W1.dtype) + delta.to(self._W1.dtype)
-        W1e = (A @ self._W1.reshape(T, -1)).reshape(-1, *self._W1.shape[1:]).contiguous()
-        W2e = (A @ self._W2.reshape(T, -1)).reshape(-1, *self._W2.shape[1:]).contiguous()
-        return A, W1e, W2e, torch.arange(z.shape[0], device=z.device, dtype=z.dtype)
+        mix = lambda W: None if W is None else (A @ W.reshape(T, -1)).reshape(-1, *W.shape[1:]).contiguous()
+        return A, mix(self._W1), mix(self._W2), mix(self._W3), torch.arange(z.shape[0], device=z.device, dtype=z.dtype)
 
     def backward(self, node_planar, z, g_out, delta=None):
         """gradient of forward(node, z) for the gradient g_out of the rows it returned: (g_node, {parameter name: gradient}).
@@ -1038,27 +1059,35 @@ class CorrProductBlock(nn.Module):
         if self._tab is None:
             self.compile(node_planar.device)
         h = self.linear_pre(node_planar)
-        W1, W2, zi = self._W1, self._W2, z
+        W1, W2, W3, zi = self._W1, self._W2, self._W3, z
         if delta is not None:
-            A, W1, W2, zi = self._mixed(z, delta)
-        c = ops.sym_contraction(h, zi, self.num_hidden, self._tab, W1, W2, self._hdim)
+            A, W1, W2, W3, zi = self._mixed(z, delta)
+        c = self._contract(h, zi, W1, W2, W3)
         p = self.prod.linear(c)
         grads = {"linear_out.weight": self.linear_out.weight_grad(p, g_out), }
         g_p = self.linear_out.backward_data(g_out)
         grads["prod.linear.weight"] = self.prod.linear.weight_grad(c, g_p)
         g_c = self.prod.linear.backward_data(g_p)
         g_h, gW1, gW2 = sym_contraction_backward(self._tab, h, zi, W1, W2, self.num_hidden, g_c, per_node=delta is not None)
+        gW = [gW1, gW2]
+        if W3 is not None:
+            from .corr3 import sym3_backward
+            g_h3, gW3 = sym3_backward(self._tab, h, zi, W3, self.num_hidden, g_c, per_node=delta is not None)
+            g_h = g_h + g_h3
+            gW.append(gW3)
+        gW = gW[:self.correlation]
         if delta is not None:                                  # per-node gradients back onto the element blocks and onto the attributes
             T = self._W1.shape[0]
-            f1, f2 = gW1.reshape(gW1.shape[0], -1), gW2.reshape(gW2.shape[0], -1)
-            grads["_g_delta"] = f1 @ self._W1.reshape(T, -1).t() + f2 @ self._W2.reshape(T, -1).t()
-            gW1, gW2 = (A.t() @ f1).reshape(self._W1.shape), (A.t() @ f2).reshape(self._W2.shape)
-        k1 = k2 = 0
-        for i, con in enumerate(self.prod.symmetric_contractions.contractions):   # the concatenated weights back to one block per target irrep
-            n1, n2 = con.weights[0].shape[1], con.weights_max.shape[1]
-            grads[f"prod.symmetric_contractions.contractions.{i}.weights.0"] = gW1[:, k1:k1 + n1]
-            grads[f"prod.symmetric_contractions.contractions.{i}.weights_max"] = gW2[:, k2:k2 + n2]
-            k1, k2 = k1 + n1, k2 + n2
+            Wel = [self._W1, self._W2, self._W3][:self.correlation]
+            flat = [g.reshape(g.shape[0], -1) for g in gW]
+            grads["_g_delta"] = sum(f @ W.reshape(T, -1).t() for f, W in zip(flat, Wel))
+            gW = [(A.t() @ f).reshape(W.shape) for f, W in zip(flat, Wel)]
+        for nu, g in enumerate(gW, start=1):                   # the concatenated weights back to one block per target irrep
+            k0 = 0
+            for i, con in enumerate(self.prod.symmetric_contractions.contractions):
+                n = con.by_nu(nu).shape[1]
+                grads[f"prod.symmetric_contractions.contractions.{i}.{con.name_of(nu)}"] = g[:, k0:k0 + n]
+                k0 += n
         grads["linear_pre.weight"] = self.linear_pre.weight_grad(node_planar, g_h)
         g_node = self.linear_pre.backward_data(g_h)
         if self.use_skip_connections:
@@ -1075,9 +1104,9 @@ class CorrProductBlock(nn.Module):
             self.compile(node_planar.device)
         h = self.linear_pre(node_planar)
         if delta is not None:
-            _, W1, W2, zi = self._mixed(z, delta)
-            c = ops.sym_contraction(h, zi, self.num_hidden, self._tab, W1, W2, self._hdim)
+            _, W1, W2, W3, zi = self._mixed(z, delta)
+            c = self._contract(h, zi, W1, W2, W3)
         else:
-            c = ops.sym_contraction(h, z, self.num_hidden, self._tab, self._W1, self._W2, self._hdim)
+            c = self._contract(h, z, self._W1, self._W2, self._W3)
         skip = [self.linear_sc(node_planar)] if self.use_skip_connections else []
         return self.linear_out(self.prod.linear(c), res=skip)

@@ -2313,17 +2313,22 @@ def corr_hidden_irreps(irreps_node, num_hidden) -> Irreps:
 
 
 def sym_contraction_tables(irreps_hidden: Irreps, correlation: int = 2):
-    """Sparse coupling tables of the MACE symmetric contraction with correlation <= 2 on `num_hidden x irreps`
-    (hamgnn/toolbox/mace/tools/cg.py:16-131 U_matrix_real, modules/symmetric_contraction.py:101-233), for hg_sym_contraction:
-        out_k[c, w] = sum_x ( sum_kap U1_k[w, x, kap] W1_k[z, kap, c]  +  sum_{i, kap} U2_k[w, x, i, kap] W2_k[z, kap, c] x[c, i] ) x[c, x]
+    """Sparse coupling tables of the MACE symmetric contraction with correlation <= 3 on `num_hidden x irreps`
+    (hamgnn/toolbox/mace/tools/cg.py:16-131 U_matrix_real, modules/symmetric_contraction.py:101-233):
+        out_k[c, w] = sum_x ( sum_kap U1_k[w, x, kap] W1_k[z, kap, c]
+                              + sum_i ( sum_kap U2_k[w, x, i, kap] W2_k[z, kap, c]
+                                        + sum_{j, kap} U3_k[w, x, i, j, kap] W3_k[z, kap, c] x[c, j] ) x[c, i] ) x[c, x]
     The coupling irreps are one copy of every hidden irrep, component index "ell" running over them in order.  U_nu stacks, for the
-    target irrep, every coupling path in enumeration order (left irrep, right irrep) -- cg.py sorts by output irrep only, stably --
-    with 'component' normalisation sqrt(2L+1) w3j(L, l_left, l_right).
-    Returns dict(ell_off, out_off, ptr1, ent1, ptr2, ent2, K1 (per target), K2 (per target), num_ell, nout) with
+    target irrep, every coupling path in the reference's enumeration order with 'component' normalisation:
+      nu = 2: (left a, right b), C = sqrt(2L+1) w3j(L, l_a, l_b);
+      nu = 3: the pairs (a, b) coupled to EVERY intermediate irrep of a x b (no filter), that list sorted stably by the intermediate
+              irrep (tuple order (l, p): odd before even), then the third factor c:  C = sum_m sqrt(2l_mid+1) w3j(l_mid, l_a, l_b)[m]
+              sqrt(2L+1) w3j(L, l_mid, l_c)[., m, .]   (cg.py:46-87).
+    Returns dict(ell_off, out_off, ptr1, ent1, ptr2, ent2, K1, K2 (per target), num_ell, nout [, ptr3, ent3, K3]) with
       ell_off[i]  planar offset of ell component i (channel 0) in the hidden layout,   out_off[o] same for output element o = (k, w)
-      ent1 rows (x, kappa_global, value-bits), ent2 rows (x, i, kappa_global, value-bits); kappa_global indexes the concatenated
-      weights of all targets."""
-    assert correlation in (1, 2), "correlation > 2 is not built"
+      ent1 rows (x, kappa_global, value-bits), ent2 rows (x, i, kappa_global, value-bits), ent3 rows (x, i, j, kappa_global, value-bits);
+      kappa_global indexes the concatenated weights of all targets.  ent1 / ent2 feed hg_sym_contraction, ent3 hamgnn_amd/corr3.py."""
+    assert correlation in (1, 2, 3), "correlation > 3 is not built"
     lay = PlanarLayout(irreps_hidden)
     irs = [(l, p) for _, l, p in irreps_hidden]
     sl, o = [], 0
@@ -2335,15 +2340,25 @@ def sym_contraction_tables(irreps_hidden: Irreps, correlation: int = 2):
     for j, (l, p) in enumerate(irs):
         for m in range(2 * l + 1):
             ell_off[sl[j][0] + m] = lay.off[j] + m * lay.mulp[j]
-    out_off, ptr1, ent1, ptr2, ent2, K1, K2 = [], [0], [], [0], [], [], []
-    k1g = k2g = 0
+    ok = lambda l1, l2, l3: abs(l1 - l2) <= l3 <= l1 + l2
+    pairs = [(a, b) for a in range(len(irs)) for b in range(len(irs))]
+    # nu = 3: the (intermediate irrep, a, b) list in the order wigner_nj([.., ..]) returns it (sorted by the irrep, stably)
+    left3 = sorted(((lm, irs[a][1] * irs[b][1]), a, b) for a, b in pairs for lm in range(abs(irs[a][0] - irs[b][0]), irs[a][0] + irs[b][0] + 1)) \
+        if correlation >= 3 else []
+    out_off, ptr1, ent1, ptr2, ent2, ptr3, ent3, K1, K2, K3 = [], [0], [], [0], [], [0], [], [], [], []
+    k1g = k2g = k3g = 0
     for k, (L, pL) in enumerate(irs):
         # nu = 1: identity block of the target irrep (one path)
         paths1 = [j for j, ir in enumerate(irs) if ir == (L, pL)]
         # nu = 2: (left a, right b) with (L, pL) in a x b
-        paths2 = [(a, b) for a, (la, pa) in enumerate(irs) for b, (lb, pb) in enumerate(irs)
-                  if pa * pb == pL and abs(la - lb) <= L <= la + lb] if correlation == 2 else []
+        paths2 = [(a, b) for a, b in pairs if irs[a][1] * irs[b][1] == pL and ok(irs[a][0], irs[b][0], L)] if correlation >= 2 else []
         cg = {ab: math.sqrt(2 * L + 1) * so3.wigner_3j(L, irs[ab[0]][0], irs[ab[1]][0]) for ab in paths2}
+        paths3 = [(mid, a, b, c) for mid, a, b in left3 for c in range(len(irs)) if mid[1] * irs[c][1] == pL and ok(mid[0], irs[c][0], L)]
+        cg3 = []
+        for (lm, pm), a, b, c in paths3:
+            cl = math.sqrt(2 * lm + 1) * so3.wigner_3j(lm, irs[a][0], irs[b][0])              # [mid, a, b]
+            cr = math.sqrt(2 * L + 1) * so3.wigner_3j(L, lm, irs[c][0])                       # [w, mid, c]
+            cg3.append(np.einsum("mab,wmc->wabc", cl, cr))
         for w in range(2 * L + 1):
             out_off.append(lay.off[k] + w * lay.mulp[k])
             for kap, j in enumerate(paths1):
@@ -2354,19 +2369,29 @@ def sym_contraction_tables(irreps_hidden: Irreps, correlation: int = 2):
                 for ma, mb in zip(*np.nonzero(np.abs(C) > 1e-14)):
                     ent2.append((sl[a][0] + ma, sl[b][0] + mb, k2g + kap, C[ma, mb]))
             ptr2.append(len(ent2))
+            for kap, (mid, a, b, c) in enumerate(paths3):
+                C = cg3[kap][w]
+                for ma, mb, mc in zip(*np.nonzero(np.abs(C) > 1e-14)):
+                    ent3.append((sl[a][0] + ma, sl[b][0] + mb, sl[c][0] + mc, k3g + kap, C[ma, mb, mc]))
+            ptr3.append(len(ent3))
         K1.append(len(paths1))
         K2.append(len(paths2))
+        K3.append(len(paths3))
         k1g += len(paths1)
         k2g += len(paths2)
+        k3g += len(paths3)
 
-    def pack(ents, ncols):
-        arr = np.zeros((max(1, len(ents)), 4), np.int32)
+    def pack(ents, ncols, width=4):
+        arr = np.zeros((max(1, len(ents)), width), np.int32)
         for r, e in enumerate(ents):
             arr[r, :ncols] = e[:ncols]
-            arr[r, 3] = np.float32(e[-1]).view(np.int32)
+            arr[r, width - 1] = np.float32(e[-1]).view(np.int32)
         return arr
-    return dict(ell_off=ell_off, out_off=np.asarray(out_off, np.int32), ptr1=np.asarray(ptr1, np.int32), ent1=pack(ent1, 2),
-                ptr2=np.asarray(ptr2, np.int32), ent2=pack(ent2, 3), K1=K1, K2=K2, num_ell=num_ell, nout=len(out_off))
+    tab = dict(ell_off=ell_off, out_off=np.asarray(out_off, np.int32), ptr1=np.asarray(ptr1, np.int32), ent1=pack(ent1, 2),
+               ptr2=np.asarray(ptr2, np.int32), ent2=pack(ent2, 3), K1=K1, K2=K2, num_ell=num_ell, nout=len(out_off))
+    if correlation >= 3:
+        tab.update(ptr3=np.asarray(ptr3, np.int32), ent3=pack(ent3, 4, 5), K3=K3)
+    return tab
 
 
 # ------------------------------------------------------------------------------------------------ host-side cost of a (re)pack

@@ -241,8 +241,9 @@ int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t* inv, const
                   float* H, void* stream);
 
 /* CorrProductBlock's symmetric contraction (hamgnn/nn/interaction_blocks.py:234-260 -> toolbox/mace/modules/
- * symmetric_contraction.py:212-230 with U_matrix_real of toolbox/mace/tools/cg.py:89-131), correlation <= 2, on planar
- * hidden node rows h [N, .] (num_hidden x every node irrep):
+ * symmetric_contraction.py:212-230 with U_matrix_real of toolbox/mace/tools/cg.py:89-131), the nu <= 2 terms, on planar hidden
+ * node rows h [N, .] (num_hidden x every node irrep); a `correlation: 3` block adds its nu = 3 term with device tensor ops
+ * (hamgnn_amd/corr3.py):
  *   out[o, c] = sum_x ( sum_kap U1[o, x, kap] W1[z, kap, c] + sum_{i, kap} U2[o, x, i, kap] W2[z, kap, c] x[c, i] ) x[c, x]
  * with the U tensors given sparsely (plan.py:sym_contraction_tables): ell_off / out_off = planar offsets of the input
  * components / output elements, ptr1/ent1 {x, kappa, -, value bits} and ptr2/ent2 {x, i, kappa, value bits} CSR rows per output

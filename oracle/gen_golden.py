@@ -742,6 +742,29 @@ def main():
             _save("corr_product_block", weights={k: v for k, v in sdc.items() if k in dict(minec.named_parameters())},
                   inputs=dict(node_features=xn, z=zc), outputs=dict(node_features=gd["node_features"]),
                   meta=dict(irreps=np.array(irr), num_hidden=np.array(nh), num_elements=np.array(8)))
+    # correlation 3 and 1 (config key `correlation`; 2 is the reference's default): smaller irreps, the nu = 3 coupling tables grow fast
+    irr3 = "4x0e+2x0o+3x1o+2x1e+2x2e"
+    for corr_, tag in ((3, "corr_product_block_nu3"), (1, "corr_product_block_nu1")):
+        torch.manual_seed(29 + corr_)
+        refc = ref_ib.CorrProductBlock(irreps_node_feats=e3.Irreps(irr3), num_hidden_features=3, correlation=corr_, num_elements=5,
+                                       use_skip_connections=True)
+        minec = M.CorrProductBlock(irr3, 3, corr_, 5, True)
+        sdc = {k: v for k, v in refc.state_dict().items()}
+        res = minec.load_state_dict(sdc, strict=False)
+        assert not (set(res.missing_keys) & set(dict(minec.named_parameters()))), res.missing_keys
+        for k, cm in enumerate(minec.prod.symmetric_contractions.contractions):
+            cr = refc.prod.symmetric_contractions.contractions[k]
+            for nu in range(1, corr_ + 1):
+                _check(cm.U(nu), cr.U_tensors(nu), f"U_matrix_{nu} of target {k} (correlation {corr_})", tol=1e-12)
+        xn = torch.randn(6, e3.Irreps(irr3).dim, generator=gen)
+        zc = torch.tensor([1, 4, 0, 2, 3, 4])
+        onehot = torch.nn.functional.one_hot(zc, 5).to(xn.dtype)
+        gd = {"node_features": xn.clone(), "node_attrs": onehot}
+        refc(gd)
+        _check(minec(xn, onehot), gd["node_features"], f"CorrProductBlock correlation {corr_}")
+        _save(tag, weights={k: v for k, v in sdc.items() if k in dict(minec.named_parameters())},
+              inputs=dict(node_features=xn, z=zc), outputs=dict(node_features=gd["node_features"]),
+              meta=dict(irreps=np.array(irr3), num_hidden=np.array(3), num_elements=np.array(5), correlation=np.array(corr_)))
     # backbone with use_corr_prod=True (hamgnn_conv.py:193-218, 274-275)
     cfg4 = _EasyDict(HamGNN_pre=_EasyDict({k: v for k, v in dict(cfg.HamGNN_pre, use_corr_prod=True, num_hidden_features=4).items() if k != 'radius_scale'}))
     torch.manual_seed(15)

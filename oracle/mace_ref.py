@@ -62,11 +62,13 @@ def u_matrix_real(irreps_in, ir_out: Irrep, correlation: int, dtype=None) -> tor
 
 
 class Contraction(nn.Module):
-    """symmetric_contraction.py:101-233 (correlation <= 2 written out; the reference's generated einsums for nu = 2, 1)."""
+    """symmetric_contraction.py:101-233 for any correlation: the reference generates one einsum per nu (main: "[w] x.. i k, ekc, bci, be ->
+    bc [w] x.."; then per lower nu "[w] x.. k, ekc, be -> bc [w] x.." added to the running tensor, whose last component index is
+    contracted with x again) and lets opt_einsum_fx reorder them; here they are evaluated as written."""
 
     def __init__(self, irreps_in: Irreps, ir_out: Irrep, correlation: int, num_elements: int):
         super().__init__()
-        assert correlation in (1, 2), "oracle covers correlation <= 2 (reference default: 2)"
+        assert 1 <= correlation <= 4
         self.num_features = sum(mul for mul, ir in irreps_in if ir.l == 0 and ir.p == 1)
         coupling = Irreps([(1, ir) for _, ir in irreps_in])
         self.correlation, self.scalar_out = correlation, ir_out.l == 0
@@ -81,14 +83,15 @@ class Contraction(nn.Module):
         return getattr(self, f"U_matrix_{nu}")
 
     def forward(self, x, y):
-        """x: [b, c, num_ell]; y: one-hot [b, num_elements] -> [b, c * (2L+1)]"""
+        """x: [b, c, num_ell]; y: node attributes [b, num_elements] (one-hot, or the charge-doped mixture) -> [b, c * (2L+1)]"""
         w = "" if self.scalar_out else "w"
-        if self.correlation == 2:
-            out = torch.einsum(f"{w}xik,ekc,bci,be->bc{w}x", self.U(2), self.weights_max, x, y)
-            c = torch.einsum(f"{w}xk,ekc,be->bc{w}x", self.U(1), self.weights[0], y) + out
-        else:
-            c = torch.einsum(f"{w}xk,ekc,be->bc{w}x", self.U(1), self.weights_max, y)
-        out = torch.einsum(f"bc{w}x,bcx->bc{w}", c, x)
+        free = "xvuts"[:self.correlation - 1]                       # the component indices that stay open after the main contraction
+        out = torch.einsum(f"{w}{free}ik,ekc,bci,be->bc{w}{free}", self.U(self.correlation), self.weights_max, x, y)
+        for j, weight in enumerate(self.weights):                   # nu = correlation - 1 ... 1
+            nu = self.correlation - 1 - j
+            idx = "xvuts"[:nu]
+            c = torch.einsum(f"{w}{idx}k,ekc,be->bc{w}{idx}", self.U(nu), weight, y) + out
+            out = torch.einsum(f"bc{w}{idx[:-1]}i,bci->bc{w}{idx[:-1]}", c, x)
         return out.reshape(out.shape[0], -1)
 
 

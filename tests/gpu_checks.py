@@ -307,8 +307,8 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
                radial_MLP=list(radial), correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
     if charge:
         cfg.update(apply_charge_doping=True, num_charge_attr_feas=8)
-    if corr:
-        cfg.update(use_corr_prod=True)
+    if corr:                                                   # True: the default correlation 2; an int: that correlation
+        cfg.update(use_corr_prod=True, correlation=2 if corr is True else int(corr))
     if lite:
         cfg.update(lite_mode=True)
     if transformer:                                            # HamGNNTransformer: attention blocks, CorrProductBlock always on
@@ -419,7 +419,7 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
             want = refp[k].grad if refp[k].grad is not None else torch.zeros_like(refp[k])
             worst[k] = float((p.grad.double().cpu().reshape(want.shape) - want).abs().max()) / max(float(want.abs().max()), 1e-6)
     k = max(worst, key=worst.get)
-    out.update(n_params=len(worst), max_rel_err=worst[k], worst=k)
+    out.update(n_params=len(worst), max_rel_err=worst[k], worst=k, top=sorted(worst.items(), key=lambda kv: -kv[1])[:5])
     return out
 
 
@@ -973,12 +973,14 @@ def check_transformer_vs_oracle(device="cuda", n_atoms=12, seed=3, heads=4, nao=
             "edge_rel_err": rel(rep["edge_attr"], rep_ref["edge_attr"]), "H_rel_err": rel(H, H_ref)}
 
 
-def check_corr_product(device="cuda"):
-    """CorrProductBlock (a21) vs the reference fixture: linear_pre -> symmetric contraction -> prod.linear -> linear_out + skip."""
+def check_corr_product(device="cuda", name="corr_product_block"):
+    """CorrProductBlock (a21) vs the reference fixture: linear_pre -> symmetric contraction -> prod.linear -> linear_out + skip.
+    name: corr_product_block (correlation 2, the default), corr_product_block_nu3 / _nu1 (config key `correlation` = 3 / 1)."""
     from hamgnn_amd import nn as hnn, ops, plan as P
-    f = load("corr_product_block")
+    f = load(name)
     irr, nh, nel = str(f["meta"]["irreps"]), int(f["meta"]["num_hidden"]), int(f["meta"]["num_elements"])
-    m = load_weights(hnn.CorrProductBlock(irr, nh, 2, nel, True), f["weights"])
+    corr = int(f["meta"]["correlation"]) if "correlation" in f["meta"] else 2
+    m = load_weights(hnn.CorrProductBlock(irr, nh, corr, nel, True), f["weights"])
     lay = P.PlanarLayout(irr)
     imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
     x = ops.to_planar(torch.from_numpy(f["inputs"]["node_features"]).float().to(device), imap, lay.dim)

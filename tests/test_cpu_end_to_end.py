@@ -31,11 +31,13 @@ def test_full_backward_whole_model_vs_autograd(cpu_backend):
     dict(charge=True, crystals=2, n_atoms=2),                          # charge doping: embedding tables + the charge MLP
     dict(corr=True),                                                   # CorrProductBlock after every ConvBlock
     dict(corr=True, charge=True, crystals=2, n_atoms=2),               # ... with doped node attributes: per-node mixtures of its element weights
+    dict(corr=3, charge=True, crystals=2, n_atoms=2, irr="6x0e+3x0o+3x1o+2x1e+2x2e", nao=13, seed=6),   # correlation 3: the nu = 3 term (hamgnn_amd/corr3.py)
+    dict(corr=1, n_atoms=2),                                           # correlation 1
     dict(soc="so3"), dict(soc="so3_nonsoc", crystals=2, n_atoms=2),    # SOC / so3 head, and the Uni-HamGNN SOC mode
     dict(transformer=True, irr="8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o"),  # HamGNNTransformer
     dict(lite=True), dict(lite=True, legacy=True, crystals=2, n_atoms=2),  # lite_mode: uvu products + combine post-op (CPU-validated only)
     dict(zps=True, crystals=2, n_atoms=2), dict(zps=True, soc="so3"),      # zero_point_shift (the universal non-SOC model trains with it)
-], ids=["legacy", "batch", "charge", "corr", "corr_charge", "so3", "so3_nonsoc", "transformer", "lite", "lite_legacy_batch", "zero_point_shift", "zero_point_shift_soc"])
+], ids=["legacy", "batch", "charge", "corr", "corr_charge", "corr_nu3_charge", "corr_nu1", "so3", "so3_nonsoc", "transformer", "lite", "lite_legacy_batch", "zero_point_shift", "zero_point_shift_soc"])
 def test_full_backward_variants_vs_autograd(cpu_backend, kw):
     kw = dict(dict(n_atoms=3, seed=5), **kw)
     r = G.check_full_backward(device="cpu", **kw)
@@ -75,6 +77,8 @@ _FORWARD_CASES = {
     "charge_doping_corr": lambda: G.check_charge_doping_corr("cpu"),
     "transformer": lambda: G.check_transformer("cpu"),
     "corr_product": lambda: G.check_corr_product("cpu"),
+    "corr_product_nu3": lambda: G.check_corr_product("cpu", "corr_product_block_nu3"),
+    "corr_product_nu1": lambda: G.check_corr_product("cpu", "corr_product_block_nu1"),
     "head_openmx_19": lambda: G.check_head("cpu"),
     "head_abacus_13": lambda: G.check_head("cpu", "head_abacus_13", "abacus", 13),
     "head_from_planar_rows": lambda: G.check_head("cpu", use_planar_path=True),

@@ -80,6 +80,14 @@ def test_corr_product_block_golden():
     assert r["corr_product_rel_err"] < G.TOL
 
 
+@pytest.mark.parametrize("name", ["corr_product_block_nu3", "corr_product_block_nu1"])
+def test_corr_product_block_other_correlations_golden(name):
+    """config key `correlation` = 3 (hg_sym_contraction + the nu = 3 term of hamgnn_amd/corr3.py) and 1, against the reference's outputs"""
+    r = G.check_corr_product(name=name)
+    print(r)
+    assert r["corr_product_rel_err"] < G.TOL
+
+
 def test_backbone_use_corr_prod_golden():
     r = G.check_backbone(name="backbone_corr")
     print(r)
@@ -228,6 +236,13 @@ def test_full_model_backward_corr_product():
     r = G.check_full_backward(n_atoms=5, seed=8, corr=True)
     print(r)
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] > 90, r
+
+
+def test_full_model_backward_corr_product_correlation_3():
+    """correlation 3 with doped node attributes: forward and every gradient through the nu = 3 term"""
+    r = G.check_full_backward(n_atoms=2, seed=6, crystals=2, charge=True, corr=3, irr="6x0e+3x0o+3x1o+2x1e+2x2e", nao=13)
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL and r["n_params"] > 100, r
 
 
 def test_full_model_backward_transformer():

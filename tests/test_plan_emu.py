@@ -428,6 +428,55 @@ def test_sym_contraction_backward_vs_autograd(golden_dir):
     assert rel(gW2.numpy(), want2.numpy()) < 1e-6 and rel(gW1.numpy(), want1.numpy()) < 1e-6
 
 
+def test_sym_contraction_nu3_term_vs_oracle_and_autograd(golden_dir):
+    """correlation 3: plan.sym_contraction_tables' sparse U_3 entries + hamgnn_amd/corr3.py (forward and backward of the nu = 3 term) against the
+    oracle's dense einsum chain (pinned on the reference's own U matrices and outputs by the corr_product_block_nu3 fixture) and autograd"""
+    import torch
+    from oracle import mace_ref as M
+    from hamgnn_amd.corr3 import sym3_forward, sym3_backward
+    from hamgnn_amd.backward_corr import sym_contraction_backward
+    f = load(golden_dir, "corr_product_block_nu3")
+    irr, nh, nel = str(f["meta"]["irreps"]), int(f["meta"]["num_hidden"]), int(f["meta"]["num_elements"])
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        blk = M.CorrProductBlock(irr, nh, 3, nel, True)
+    finally:
+        torch.set_default_dtype(prev)
+    blk.load_state_dict({k: torch.as_tensor(v) for k, v in f["weights"].items()}, strict=False)
+    hid = P.corr_hidden_irreps(irr, nh)
+    tab = P.sym_contraction_tables(hid, 3)
+    cons = blk.prod.symmetric_contractions.contractions
+    assert all(tab[f"K{nu}"] == [c.U(nu).shape[-1] for c in cons] for nu in (1, 2, 3))
+    lay = P.PlanarLayout(hid)
+    rng = np.random.default_rng(5)
+    N = 7
+    h = torch.from_numpy(rng.standard_normal((N, sum(m * (2 * l + 1) for m, l, _ in hid)))).requires_grad_()
+    z = torch.from_numpy(rng.integers(0, nel, size=N))
+    out = blk.prod.symmetric_contractions(M.reshape_irreps(blk.irreps_hidden, h), torch.nn.functional.one_hot(z, nel).double())
+    Gm = torch.from_numpy(rng.standard_normal(tuple(out.shape)))
+    (out * Gm).sum().backward()
+    W3 = torch.cat([c.weights_max.detach() for c in cons], 1)
+    W2 = torch.cat([c.weights[0].detach() for c in cons], 1)
+    W1 = torch.cat([c.weights[1].detach() for c in cons], 1)
+    hp = torch.from_numpy(lay.to_planar(h.detach().numpy()))
+    gp = torch.from_numpy(lay.to_planar(Gm.numpy()))
+    low = torch.from_numpy(emu.sym_contraction(tab, hp.numpy(), z.numpy(), W1.numpy(), W2.numpy(), nh, lay.dim))
+    got = sym3_forward(tab, hp, z, W3, nh, low.clone(), chunk=3)
+    assert rel(lay.from_planar(got.numpy()), out.detach().numpy()) < 1e-6            # (the tables hold their coefficients in fp32)
+    assert rel(got.numpy(), low.numpy()) > 1e-2                                       # the nu = 3 term is not negligible in this check
+    g_h, gW1, gW2 = sym_contraction_backward(tab, hp, z, W1, W2, nh, gp, chunk=3)
+    g_h3, gW3 = sym3_backward(tab, hp, z, W3, nh, gp, chunk=2)
+    assert rel(lay.from_planar((g_h + g_h3).numpy()), h.grad.numpy()) < 1e-6
+    for g, want in ((gW3, [c.weights_max.grad for c in cons]), (gW2, [c.weights[0].grad for c in cons]), (gW1, [c.weights[1].grad for c in cons])):
+        assert rel(g.numpy(), torch.cat(want, 1).numpy()) < 1e-6
+    # per-node weight blocks (the charge-doped attributes): same gradients, one block per node
+    g_hn, gWn = sym3_backward(tab, hp, torch.arange(N), W3[z], nh, gp, per_node=True)
+    assert rel(g_hn.numpy(), g_h3.numpy()) < 1e-12
+    acc = torch.zeros_like(W3).index_add_(0, z, gWn)
+    assert rel(acc.numpy(), gW3.numpy()) < 1e-12
+
+
 def _random_irreps(rng, lmax):
     """random simplified irreps (distinct (l, p), sorted like the reference's configs: by l, odd/even in random order)"""
     out = []
