@@ -234,19 +234,10 @@ def band_energies_soc(head, real_onsite, imag_onsite, real_offsite, imag_offsite
     orank_all = head._orank.to(dev)[z]
     val = head._num_valence.to(dev)[z].to(torch.float64)
     Son, Soff = data.Son.contiguous().float(), data.Soff.contiguous().float()
-    blk = lambda t, a, b: t.reshape(-1, 2, nao, 2, nao)[:, a, :, b, :].reshape(-1, nao * nao).contiguous().float()
     energies, waves = [], []
     for c, (n0, n, e0, e) in enumerate(_crystal_slices(data)):
         Sk, M = assemble_k(Son, Soff, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
-        rows = []
-        for a in (0, 1):
-            cols = []
-            for b in (0, 1):
-                Hr, _ = assemble_k(blk(real_onsite, a, b), blk(real_offsite, a, b), data, k_vecs[c], n0, n, e0, e, orank_all, nao)
-                Hi, _ = assemble_k(blk(imag_onsite, a, b), blk(imag_offsite, a, b), data, k_vecs[c], n0, n, e0, e, orank_all, nao)
-                cols.append(Hr + 1j * Hi)
-            rows.append(torch.cat(cols, -1))
-        Hk = torch.cat(rows, -2)                               # [nk, 2 M, 2 M]
+        Hk = _soc_hk(real_onsite, imag_onsite, real_offsite, imag_offsite, data, k_vecs[c], n0, n, e0, e, orank_all, nao)   # [nk, 2 M, 2 M]
         Ssoc = torch.zeros_like(Hk)
         Ssoc[:, :M, :M] = Sk
         Ssoc[:, M:, M:] = Sk
@@ -295,3 +286,68 @@ def band_energy_backward(head, onsite_hamiltonian, offsite_hamiltonian, data, co
         g_on[n0:n0 + n] = a
         g_off[e0:e0 + e] = b
     return g_on, g_off
+
+
+def _soc_hk(real_onsite, imag_onsite, real_offsite, imag_offsite, data, k_vecs_c, n0, n, e0, e, orank_all, nao):
+    """spinor H(k) [nk, 2 M, 2 M] of one crystal: four spin blocks, each the assembly of its real part + i x the assembly of its imaginary part"""
+    blk = lambda t, a, b: t.reshape(-1, 2, nao, 2, nao)[:, a, :, b, :].reshape(-1, nao * nao).contiguous().float()
+    rows = []
+    for a in (0, 1):
+        cols = []
+        for b in (0, 1):
+            Hr, _ = assemble_k(blk(real_onsite, a, b), blk(real_offsite, a, b), data, k_vecs_c, n0, n, e0, e, orank_all, nao)
+            Hi, _ = assemble_k(blk(imag_onsite, a, b), blk(imag_offsite, a, b), data, k_vecs_c, n0, n, e0, e, orank_all, nao)
+            cols.append(Hr + 1j * Hi)
+        rows.append(torch.cat(cols, -1))
+    return torch.cat(rows, -2)
+
+
+def band_energy_backward_soc(head, real_onsite, imag_onsite, real_offsite, imag_offsite, data, cotangent, k_vecs: Optional[torch.Tensor] = None):
+    """gradient of sum(band_energy * cotangent) of band_energies_soc with respect to the four spinor row sets (a band-energy loss on a
+    spin-orbit head; Model.py:150-196 with prediction: band_energy, bands from hamgnn_output.py:1998-2286).  As band_energy_backward: the
+    Cholesky / eigh chain on the stacked [2 M, 2 M] H(k) is differentiated by torch.autograd (library solvers), then every spin block of
+    the gradient G goes through the assembly's adjoint -- G_ab for the real rows, -i G_ab for the imaginary rows (H_ab = A(real) + i A(imag)
+    with the real-linear assembly A).  Returns (g_real_on, g_imag_on, g_real_off, g_imag_off) in the rows' [., 2, nao, 2, nao] layout."""
+    nao = head.nao_max
+    dev = real_onsite.device
+    k_vecs = (gget(data, "k_vecs") if k_vecs is None else k_vecs).to(dev)
+    z = data.z
+    orank_all = head._orank.to(dev)[z]
+    val = head._num_valence.to(dev)[z].to(torch.float64)
+    Son, Soff = data.Son.contiguous().float(), data.Soff.contiguous().float()
+    g = [torch.zeros(t.shape[0], 2, nao, 2, nao, device=dev, dtype=torch.float32) for t in (real_onsite, imag_onsite, real_offsite, imag_offsite)]
+    row = 0
+    for c, (n0, n, e0, e) in enumerate(_crystal_slices(data)):
+        Sk, M = assemble_k(Son, Soff, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        Hk = _soc_hk(real_onsite, imag_onsite, real_offsite, imag_offsite, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+        Ssoc = torch.zeros_like(Hk)
+        Ssoc[:, :M, :M] = Sk
+        Ssoc[:, M:, M:] = Sk
+        with torch.enable_grad():
+            Hk = Hk.detach().requires_grad_()
+            L = torch.linalg.cholesky(Ssoc)
+            Linv = torch.linalg.inv(L)
+            LHinv = torch.linalg.inv(L.conj().transpose(-1, -2))
+            evals = torch.linalg.eigvalsh(torch.bmm(torch.bmm(Linv, Hk), LHinv))
+            bnc = head.band_num_control
+            if bnc is not None:
+                if isinstance(bnc, dict):
+                    nb = int(sum(int(bnc.get(int(zz), bnc.get(str(int(zz)), 0))) for zz in z[n0:n0 + n].tolist()))
+                    evals = evals[:, :nb]
+                else:
+                    nval = int(val[n0:n0 + n].sum())
+                    evals = evals[:, nval - int(bnc):nval + int(bnc)]
+            evals = evals.transpose(-1, -2)                    # [bands, nk]
+            nb = evals.shape[0]
+            (G,) = torch.autograd.grad((evals * cotangent[row:row + nb].to(evals.dtype)).sum(), Hk)
+        row += nb
+        for a in (0, 1):
+            for b in (0, 1):
+                Gab = G[:, a * M:(a + 1) * M, b * M:(b + 1) * M]
+                r_on, r_off = assemble_k_adjoint(Gab, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+                i_on, i_off = assemble_k_adjoint(-1j * Gab, data, k_vecs[c], n0, n, e0, e, orank_all, nao)
+                g[0][n0:n0 + n, a, :, b, :] = r_on.reshape(n, nao, nao)
+                g[1][n0:n0 + n, a, :, b, :] = i_on.reshape(n, nao, nao)
+                g[2][e0:e0 + e, a, :, b, :] = r_off.reshape(e, nao, nao)
+                g[3][e0:e0 + e, a, :, b, :] = i_off.reshape(e, nao, nao)
+    return tuple(t.reshape(t.shape[0], -1) for t in g)

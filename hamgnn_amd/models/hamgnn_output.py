@@ -437,6 +437,8 @@ class HamGNNPlusPlusOut(nn.Module):
             Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
             be, wf = self._soc_bands(data, on_r, on_i, off_r, off_i, dev)    # from the blocks BEFORE the shift (hamgnn_output.py:3642-3662)
             if self.zero_point_shift:
+                # a training step with a band-energy loss re-evaluates the bands from the unshifted rows (training.training_step)
+                self._unshifted = torch.cat([Hr, Hi], 0) if (self.calculate_band_energy and "_tape" in rep) else None
                 Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
             result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": be,
                            "wavefunction": wf})
@@ -460,6 +462,8 @@ class HamGNNPlusPlusOut(nn.Module):
             Hi = self._cat_by_crystal(data, on_i, off_i, edge_counts)
             be, wf = self._soc_bands(data, on_r, on_i, off_r, off_i, dev)    # from the blocks BEFORE the shift (hamgnn_output.py:3642-3662)
             if self.zero_point_shift:
+                # a training step with a band-energy loss re-evaluates the bands from the unshifted rows (training.training_step)
+                self._unshifted = torch.cat([Hr, Hi], 0) if (self.calculate_band_energy and "_tape" in rep) else None
                 Hr = self._apply_zero_point_shift(data, Hr, edge_counts, True)
             result.update({"hamiltonian": torch.cat([Hr, Hi], 0), "hamiltonian_real": Hr, "hamiltonian_imag": Hi, "band_energy": be,
                            "wavefunction": wf})

@@ -218,10 +218,6 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
                 if out.get("band_energy") is None:
                     raise ValueError("a band_energy loss needs HamGNNPlusPlusOut(calculate_band_energy=True)")
                 be = out["band_energy"]
-                if getattr(head, "soc_switch", False):
-                    # the band-energy adjoint (kspace.band_energy_backward) assembles the SPIN-FREE H(k); the spinor rows [2 (N + E), (2 nao)^2] of a
-                    # spin-orbit head need the adjoint of the eight spin-block assemblies of kspace.band_energies_soc, which is not built
-                    raise NotImplementedError("training_step: a band_energy loss on a spin-orbit head (soc_switch) is not built")
                 li, gbe = _loss_and_grad(be, gget(batch, spec.get("target", "band_energy").lower()).to(be.dtype), spec["metric"])
                 edge_counts = head._global_inverse(batch)[1]
                 Hb = H
@@ -230,9 +226,17 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
                     # by their mean (:3983-3985): the forward kept the unshifted rows for this re-evaluation; adjoint of the alignment = g - mean(g)
                     gbe = gbe - gbe.mean()
                     Hb = head._unshifted
-                on, off = head._split_by_crystal(batch, Hb, edge_counts)
-                g_on, g_off = kspace.band_energy_backward(head, on.contiguous(), off.contiguous(), batch, w * gbe)
-                gb = head._cat_by_crystal(batch, g_on, g_off, edge_counts)
+                if getattr(head, "soc_switch", False):
+                    # spin-orbit head: rows [real (N + E); imaginary (N + E)] of width (2 nao)^2, the bands of the stacked spinor H(k)
+                    half = Hb.shape[0] // 2
+                    on_r, off_r = head._split_by_crystal(batch, Hb[:half], edge_counts)
+                    on_i, off_i = head._split_by_crystal(batch, Hb[half:], edge_counts)
+                    gs = kspace.band_energy_backward_soc(head, on_r.contiguous(), on_i.contiguous(), off_r.contiguous(), off_i.contiguous(), batch, w * gbe)
+                    gb = torch.cat([head._cat_by_crystal(batch, gs[0], gs[2], edge_counts), head._cat_by_crystal(batch, gs[1], gs[3], edge_counts)], 0)
+                else:
+                    on, off = head._split_by_crystal(batch, Hb, edge_counts)
+                    g_on, g_off = kspace.band_energy_backward(head, on.contiguous(), off.contiguous(), batch, w * gbe)
+                    gb = head._cat_by_crystal(batch, g_on, g_off, edge_counts)
                 g_unshifted = gb if g_unshifted is None else g_unshifted + gb
             else:
                 raise ValueError(f"training_step: losses on {pred!r} are not built (hamiltonian | hamiltonian_real | hamiltonian_imag | band_energy)")

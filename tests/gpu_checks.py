@@ -338,17 +338,18 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     kpath, nk = [[0.0, 0.0, 0.0], [0.5, 0.0, 0.0], [0.5, 0.5, 0.0]], 5
     if bands:                                                  # band-energy loss: Hermitian overlaps with S(k) positive definite, fixed k-path
         from hamgnn_amd import kspace
-        assert crystals == 1 and not soc
+        assert crystals == 1 and soc in (None, "so3")
         gen_s = torch.Generator().manual_seed(seed + 71)
         inv_ = g.inv_edge_idx
         so = 0.004 * torch.randn(g.num_edges, nao, nao, generator=gen_s)
         g["Soff"] = (0.5 * (so + so[inv_].transpose(1, 2))).reshape(g.num_edges, -1)
         sn = 0.004 * torch.randn(g.num_nodes, nao, nao, generator=gen_s)
         g["Son"] = (torch.eye(nao) + 0.5 * (sn + sn.transpose(1, 2))).reshape(g.num_nodes, -1)
-        ho = g["Hoff"].reshape(-1, nao, nao)
-        g["Hoff"] = (0.5 * (ho + ho[inv_].transpose(1, 2))).reshape(g.num_edges, -1)         # Hermitian targets: real target bands
-        hn = g["Hon"].reshape(-1, nao, nao)
-        g["Hon"] = (0.5 * (hn + hn.transpose(1, 2))).reshape(g.num_nodes, -1)
+        if not soc:                                            # (SOC: eigh reads the lower triangle of the random spinor targets on both sides)
+            ho = g["Hoff"].reshape(-1, nao, nao)
+            g["Hoff"] = (0.5 * (ho + ho[inv_].transpose(1, 2))).reshape(g.num_edges, -1)     # Hermitian targets: real target bands
+            hn = g["Hon"].reshape(-1, nao, nao)
+            g["Hon"] = (0.5 * (hn + hn.transpose(1, 2))).reshape(g.num_nodes, -1)
         g["k_vecs"] = kspace.make_k_vectors(kpath, nk, g.cell)
     if soc == "so3_nonsoc":                                    # the frozen non-SOC model's prediction (Uni-HamGNN chain): an input here
         gen_ = torch.Generator().manual_seed(seed + 50)
@@ -373,12 +374,21 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
         Hu = rh(g64, rb(g64))["hamiltonian"]
         rh.zero_point_shift = zps
         N_ = g.num_nodes
-        be = rh.calculate_band_energies(Hu[:N_], Hu[N_:], g64)[0]
-        with torch.no_grad():
-            tb = rh.calculate_band_energies(g64["Hon"], g64["Hoff"], g64)[0]
+        if soc:                                                # spinor rows [real (N + E); imaginary (N + E)] (hamgnn_output.py:3621-3662)
+            h_ = Hu.shape[0] // 2
+            be = rh.calculate_band_energies_with_spin_orbit_coupling(Hu[:N_], Hu[h_:h_ + N_], Hu[N_:h_], Hu[h_ + N_:], g64)[0]
+            with torch.no_grad():
+                tb = rh.calculate_band_energies_with_spin_orbit_coupling(g64["Hon"], g64["iHon"], g64["Hoff"], g64["iHoff"], g64)[0]
+        else:
+            be = rh.calculate_band_energies(Hu[:N_], Hu[N_:], g64)[0]
+            with torch.no_grad():
+                tb = rh.calculate_band_energies(g64["Hon"], g64["Hoff"], g64)[0]
         if zps:
             be = be - torch.mean(be - tb)
-        target = g64["hamiltonian"] if "hamiltonian" in g64 else torch.cat([g64["Hon"], g64["Hoff"]], 0)
+        if soc:
+            target = torch.cat([g64["Hon"], g64["Hoff"], g64["iHon"], g64["iHoff"]], 0)
+        else:
+            target = g64["hamiltonian"] if "hamiltonian" in g64 else torch.cat([g64["Hon"], g64["Hoff"]], 0)
         diff = Href - target
         loss_ref = lf(diff) + 0.3 * lf(be - tb)
         losses = [dict(metric=metric, prediction="hamiltonian", target="hamiltonian", loss_weight=1.0),

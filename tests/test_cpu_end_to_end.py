@@ -129,6 +129,14 @@ def test_band_energy_loss_with_zero_point_shift_on_cpu(cpu_backend, zps):
     assert r["loss_rel_err"] < 1e-4 and r["max_rel_err"] < 5e-4, r
 
 
+@pytest.mark.parametrize("zps", [False, True])
+def test_band_energy_loss_on_a_spin_orbit_head_on_cpu(cpu_backend, zps):
+    """hamiltonian + band_energy losses on a SOC / so3 head: the bands of the stacked spinor H(k) (kspace.band_energy_backward_soc: eigh chain by
+    autograd, the four spin blocks through the assembly's adjoint, real and imaginary rows) vs autograd through the oracle"""
+    r = G.check_full_backward(device="cpu", n_atoms=2, num_layers=1, nao=13, metric="mse", zps=zps, bands=True, soc="so3")
+    assert r["loss_rel_err"] < 1e-5 and r["max_rel_err"] < 5e-5, r
+
+
 @pytest.mark.parametrize("tag", ["batch", "single"])
 def test_head_bands_with_zero_point_shift_on_cpu(cpu_backend, tag):
     """calculate_band_energy + zero_point_shift (the default of build_hamgnn_model) vs the reference's forward: bands from the unshifted

@@ -282,6 +282,14 @@ def test_band_energy_loss_with_zero_point_shift(zps):
     assert r["loss_rel_err"] < 1e-4 and r["max_rel_err"] < 2e-3
 
 
+@pytest.mark.parametrize("zps", [False, True])
+def test_band_energy_loss_on_a_spin_orbit_head(zps):
+    """the same two-loss step on a SOC / so3 head: bands of the stacked spinor H(k), gradient through the four spin blocks' assembly adjoints"""
+    r = G.check_full_backward(n_atoms=2, num_layers=1, nao=13, metric="mse", zps=zps, bands=True, soc="so3")
+    print(r)
+    assert r["loss_rel_err"] < 1e-4 and r["max_rel_err"] < 2e-3
+
+
 def test_full_model_backward_default_irreps():
     """one layer at the reference's default irreps (set A: 877 channels, l <= 6, SH to l = 5, 64-wide radial MLPs), 4-atom cell"""
     r = G.check_full_backward(n_atoms=4, seed=5, num_layers=1, irr=G_IRREPS_A, sh="0e+1o+2e+3o+4e+5o", radial=(64, 64), num_radial=64)
