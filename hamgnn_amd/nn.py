@@ -1024,8 +1024,9 @@ class CorrProductBlock(nn.Module):
     def compile(self, device):
         for m in (self.linear_pre, self.linear_sc, self.prod.linear, self.linear_out):
             m.compile(device)
-        t = self._tab_np
-        self._tab = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in t.items()}
+        d, cur = torch.device(device), (self._tab["ell_off"].device if self._tab is not None else None)
+        if cur is None or cur.type != d.type or (d.index is not None and d.index != cur.index):   # structural: uploaded once per device, not per refresh
+            self._tab = {k: (torch.from_numpy(v).to(device) if isinstance(v, np.ndarray) else v) for k, v in self._tab_np.items()}
         cons = self.prod.symmetric_contractions.contractions
         cat = lambda nu: torch.cat([c.by_nu(nu).detach() for c in cons], dim=1).float().contiguous().to(device)
         self._W1 = cat(1)
