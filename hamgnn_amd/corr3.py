@@ -1,13 +1,12 @@
-"""The nu = 3 term of the MACE symmetric contraction (CorrProductBlock with `correlation: 3`; reference:
-hamgnn/toolbox/mace/modules/symmetric_contraction.py:101-233, tools/cg.py:16-131), forward and backward.
+"""Backward of the nu = 3 term of the MACE symmetric contraction (CorrProductBlock with `correlation: 3`; reference:
+hamgnn/toolbox/mace/modules/symmetric_contraction.py:101-233, tools/cg.py:16-131).  Forward (hg_sym_contraction3, csrc/corr3.hip):
 
     out[n, o, c] += sum_{(x, i, j, kap, v) in ent3[o]} v W3[z_n, kap, c] h[n, x, c] h[n, i, c] h[n, j, c]
 
-on top of the nu <= 2 part that hg_sym_contraction computes (plan.sym_contraction_tables lists the sparse entries of U_3 in the
-reference's path order).  `correlation: 3` is not the reference's default (2) and the block itself is optional (use_corr_prod); a
-node-level operation on N rows, written as gathers, products and fixed-order segmented sums (ops.scatter_cols) on the device -- torch
-tensor ops like the backward of the nu <= 2 part (hamgnn_amd/backward_corr.py), in chunks of nodes sized to the entry list.  Device-agnostic:
-the CPU suite checks it against the oracle's dense einsums and autograd through them."""
+on top of the nu <= 2 part of hg_sym_contraction (plan.sym_contraction_tables lists the sparse entries of U_3 in the reference's path
+order).  As for the nu <= 2 part (hamgnn_amd/backward_corr.py) the gradients of this node-level operation are gathers, products and
+fixed-order segmented sums (ops.scatter_cols) on the device, in chunks of nodes sized to the entry list.  Device-agnostic: the CPU suite
+checks them against autograd through the oracle's dense einsums."""
 from __future__ import annotations
 
 from typing import Dict
@@ -35,25 +34,6 @@ def _entries3(tab: Dict, device):
 def _chunk(E, C, chunk):
     """nodes per pass: the [n, entries, C] temporaries stay below ~2^25 elements each"""
     return max(1, min(int(chunk), (1 << 25) // max(1, int(E["o"].shape[0]) * C)))
-
-
-def sym3_forward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W3: torch.Tensor, C: int, out: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
-    """adds the nu = 3 term to the planar hidden rows `out` [N, Dp] (in place; returned).  h [N, Dp] planar, W3 [nel, K3, C]."""
-    E = _entries3(tab, h.device)
-    ch = torch.arange(C, device=h.device)
-    hcol = E["ell_off"][:, None] + ch[None, :]
-    ocol = (E["out_off"][:, None] + ch[None, :]).reshape(-1)
-    nout = int(E["out_off"].shape[0])
-    zl = z.long()
-    step = _chunk(E, C, chunk)
-    v = E["v"][None, :, None].to(h.dtype)
-    for n0 in range(0, h.shape[0], step):
-        sl = slice(n0, min(h.shape[0], n0 + step))
-        H = h[sl][:, hcol]                                        # [n, num_ell, C]
-        t = H[:, E["x"]] * H[:, E["i"]] * H[:, E["j"]] * v * W3[zl[sl]][:, E["k"]]
-        add = ops.scatter_cols(E["o"], t, nout)                   # [n, nout, C], fixed summation order
-        out[sl] = out[sl].index_add(1, ocol, add.reshape(add.shape[0], -1).to(out.dtype))     # (distinct columns)
-    return out
 
 
 def sym3_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W3: torch.Tensor, C: int, g_out: torch.Tensor, chunk: int = 4096,

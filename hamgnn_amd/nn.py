@@ -1001,7 +1001,7 @@ class _ProductBasis(nn.Module):
 class CorrProductBlock(nn.Module):
     """Drop-in for hamgnn/nn/interaction_blocks.py:168-260 (correlation 1, 2 -- the reference default -- or 3): linear_pre -> symmetric
     contraction with element-dependent weights -> prod.linear -> linear_out (+ linear_sc skip), all on planar node rows; same parameter
-    names.  The nu <= 2 part of the contraction is the hg_sym_contraction kernel, the nu = 3 term hamgnn_amd/corr3.py."""
+    names.  The nu <= 2 part of the contraction is the hg_sym_contraction kernel, the nu = 3 term hg_sym_contraction3 (backward: hamgnn_amd/corr3.py)."""
 
     def __init__(self, irreps_node_feats, num_hidden_features, correlation, num_elements, use_skip_connections=True):
         super().__init__()
@@ -1038,9 +1038,8 @@ class CorrProductBlock(nn.Module):
 
     def _contract(self, h, zi, W1, W2, W3):
         c = ops.sym_contraction(h, zi, self.num_hidden, self._tab, W1, W2, self._hdim)
-        if W3 is not None:
-            from .corr3 import sym3_forward
-            c = sym3_forward(self._tab, h, zi, W3, self.num_hidden, c)
+        if W3 is not None:                                     # correlation 3: its own kernel adds the nu = 3 term onto the same rows
+            c = ops.sym_contraction3(h, zi, self.num_hidden, self._tab, W3, c)
         return c
 
     def _mixed(self, z, delta):

@@ -703,6 +703,16 @@ def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
 
 
 @_on_tensor_device
+def sym_contraction3(h, z, C, tab, W3, out):
+    """adds the nu = 3 term of a `correlation: 3` block to the rows `out` that sym_contraction returned (in place; csrc/corr3.hip)"""
+    _require_gpu(h)
+    check(lib().hg_sym_contraction3(ptr(h), i64(h.stride(0)), ptr(z), i64(h.shape[0]), i32(C), i32(tab["num_ell"]), ptr(tab["ell_off"]), i32(tab["nout"]),
+                                    ptr(tab["out_off"]), ptr(tab["ptr3"]), ptr(tab["ent3"]), ptr(W3), i32(W3.shape[1]), ptr(out), i64(out.stride(0)),
+                                    _stream()), "hg_sym_contraction3")
+    return out
+
+
+@_on_tensor_device
 def sym_contraction(h, z, C, tab, W1, W2, out_dim):
     """tab: device tensors of plan.sym_contraction_tables; W1 [nel, K1, C], W2 [nel, K2, C]; returns planar hidden rows [N, out_dim]"""
     _require_gpu(h)

@@ -242,8 +242,7 @@ int hg_ham_finish(const float* Hraw, int64_t h_stride, const int64_t* inv, const
 
 /* CorrProductBlock's symmetric contraction (hamgnn/nn/interaction_blocks.py:234-260 -> toolbox/mace/modules/
  * symmetric_contraction.py:212-230 with U_matrix_real of toolbox/mace/tools/cg.py:89-131), the nu <= 2 terms, on planar hidden
- * node rows h [N, .] (num_hidden x every node irrep); a `correlation: 3` block adds its nu = 3 term with device tensor ops
- * (hamgnn_amd/corr3.py):
+ * node rows h [N, .] (num_hidden x every node irrep); a `correlation: 3` block adds its nu = 3 term with hg_sym_contraction3:
  *   out[o, c] = sum_x ( sum_kap U1[o, x, kap] W1[z, kap, c] + sum_{i, kap} U2[o, x, i, kap] W2[z, kap, c] x[c, i] ) x[c, x]
  * with the U tensors given sparsely (plan.py:sym_contraction_tables): ell_off / out_off = planar offsets of the input
  * components / output elements, ptr1/ent1 {x, kappa, -, value bits} and ptr2/ent2 {x, i, kappa, value bits} CSR rows per output
@@ -252,6 +251,14 @@ int hg_sym_contraction(const float* h, int64_t h_stride, const int64_t* z, int64
                        int nout, const int32_t* out_off, const int32_t* ptr1, const int32_t* ent1, const int32_t* ptr2,
                        const int32_t* ent2, const float* W1, int K1, const float* W2, int K2, float* out, int64_t out_stride,
                        void* stream);
+
+/* The nu = 3 term of the same contraction for a block built with `correlation: 3` (symmetric_contraction.py:148-230: the main einsum over
+ * U_matrix_real(.., correlation = 3), cg.py:16-131), ADDED onto the rows hg_sym_contraction wrote (csrc/corr3.hip):
+ *   out[o, c] += sum_{(x, i, j, kap, v) in ent3[o]} v W3[z, kap, c] h[c, x] h[c, i] h[c, j]
+ * ptr3 int32[nout + 1], ent3 int32[.][5] = {x, i, j, kappa, value bits} (plan.py:sym_contraction_tables), W3 [num_elements][K3][C].           */
+int hg_sym_contraction3(const float* h, int64_t h_stride, const int64_t* z, int64_t N, int C, int num_ell, const int32_t* ell_off,
+                        int nout, const int32_t* out_off, const int32_t* ptr3, const int32_t* ent3, const float* W3, int K3,
+                        float* out, int64_t out_stride, void* stream);
 
 /* zero-point energy shift (hamgnn_output.py:3971-3981; SOC spin-diagonal real blocks :3892-3913), in place:
  *   dE = sum_{S>thr}(H - Href) / sum_{S>thr} S ;  H -= dE * S    -- one dE per call (= per batch, as the reference).

@@ -286,6 +286,12 @@ def sym_contraction(h, z, C, tab, W1, W2, out_dim):
     return _t(emu.sym_contraction(t, _np(h), z.cpu().numpy(), _np(W1), _np(W2), C, out_dim))
 
 
+def sym_contraction3(h, z, C, tab, W3, out):
+    t = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in tab.items() if not str(k).startswith("_")}
+    out.copy_(_t(emu.sym_contraction3(t, _np(h), z.cpu().numpy(), _np(W3), C, _np(out))))
+    return out
+
+
 def block_mean(x, tab, nao):
     """hg_block_mean: every element -> the mean over its (row shell, col shell) block; tab[q] = {r0, r1, c0, c1}"""
     X = x[:, :nao * nao].double().reshape(-1, nao, nao)
@@ -388,6 +394,6 @@ def install(mp):
     mp.setattr(ops, "Geometry", Geometry)
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
     for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "row_program", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
-                 "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "block_mean", "soc_assemble", "attention_aggregate",
+                 "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "sym_contraction3", "block_mean", "soc_assemble", "attention_aggregate",
                  "attention_logits", "hk_assemble", "zero_point_shift", "block_gemm"):
         mp.setattr(ops, name, globals()[name])

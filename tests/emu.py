@@ -401,6 +401,21 @@ def sym_contraction(tab, hp, z, W1, W2, C, out_dim):
     return out
 
 
+def sym_contraction3(tab, hp, z, W3, C, out):
+    """numpy twin of hg_sym_contraction3 (hamgnn_amd/csrc/corr3.hip): ADDS the nu = 3 term to the planar rows `out` [N, Dp] (float64 copy returned)"""
+    out = np.array(out, dtype=np.float64)
+    x = np.stack([hp[:, tab["ell_off"] + c] for c in range(C)], axis=1).astype(np.float64)     # [N, C, num_ell]
+    ent, ptr = tab["ent3"], tab["ptr3"]
+    val = np.ascontiguousarray(ent[:, 4]).view(np.float32).astype(np.float64)
+    for o in range(tab["nout"]):
+        e = slice(ptr[o], ptr[o + 1])
+        if e.stop == e.start:
+            continue
+        t = val[e][None, None, :] * np.transpose(W3[z][:, ent[e, 3], :], (0, 2, 1)) * x[:, :, ent[e, 0]] * x[:, :, ent[e, 1]] * x[:, :, ent[e, 2]]
+        out[:, tab["out_off"][o] + np.arange(C)] += t.sum(-1)
+    return out
+
+
 def _unfrag_natural(frag, K, rows):
     """inverse of plan._frag_A(mat[K, rows], K // 4, rows // 16, x4=False) for ONE row tile: frag [G, 64, 4] -> mat [K, 16]"""
     G = frag.shape[0]

@@ -429,11 +429,11 @@ def test_sym_contraction_backward_vs_autograd(golden_dir):
 
 
 def test_sym_contraction_nu3_term_vs_oracle_and_autograd(golden_dir):
-    """correlation 3: plan.sym_contraction_tables' sparse U_3 entries + hamgnn_amd/corr3.py (forward and backward of the nu = 3 term) against the
+    """correlation 3: plan.sym_contraction_tables' sparse U_3 entries (forward: the numpy twin of hg_sym_contraction3; backward: hamgnn_amd/corr3.py) against the
     oracle's dense einsum chain (pinned on the reference's own U matrices and outputs by the corr_product_block_nu3 fixture) and autograd"""
     import torch
     from oracle import mace_ref as M
-    from hamgnn_amd.corr3 import sym3_forward, sym3_backward
+    from hamgnn_amd.corr3 import sym3_backward
     from hamgnn_amd.backward_corr import sym_contraction_backward
     f = load(golden_dir, "corr_product_block_nu3")
     irr, nh, nel = str(f["meta"]["irreps"]), int(f["meta"]["num_hidden"]), int(f["meta"]["num_elements"])
@@ -462,7 +462,7 @@ def test_sym_contraction_nu3_term_vs_oracle_and_autograd(golden_dir):
     hp = torch.from_numpy(lay.to_planar(h.detach().numpy()))
     gp = torch.from_numpy(lay.to_planar(Gm.numpy()))
     low = torch.from_numpy(emu.sym_contraction(tab, hp.numpy(), z.numpy(), W1.numpy(), W2.numpy(), nh, lay.dim))
-    got = sym3_forward(tab, hp, z, W3, nh, low.clone(), chunk=3)
+    got = torch.from_numpy(emu.sym_contraction3(tab, hp.numpy(), z.numpy(), W3.numpy(), nh, low.numpy()))      # the table-exact twin of csrc/corr3.hip
     assert rel(lay.from_planar(got.numpy()), out.detach().numpy()) < 1e-6            # (the tables hold their coefficients in fp32)
     assert rel(got.numpy(), low.numpy()) > 1e-2                                       # the nu = 3 term is not negligible in this check
     g_h, gW1, gW2 = sym_contraction_backward(tab, hp, z, W1, W2, nh, gp, chunk=3)
