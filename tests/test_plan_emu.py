@@ -477,6 +477,57 @@ def test_sym_contraction_nu3_term_vs_oracle_and_autograd(golden_dir):
     assert rel(acc.numpy(), gW3.numpy()) < 1e-12
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_sym_contraction_tables_random_irreps_vs_dense_u_matrices(seed):
+    """the sparse U_1 / U_2 / U_3 entry lists of plan.sym_contraction_tables == the oracle's dense U_matrix_real (whose values and path
+    order the reference's own cg.py confirmed on the fixture irreps, oracle/gen_golden.py) on random irreps: both parities of an l in
+    either order, missing l, targets that only some couplings reach"""
+    import torch
+    from oracle import mace_ref as M
+    from oracle.e3 import Irrep, Irreps as OIrreps
+    rng = np.random.default_rng(100 + seed)
+    cand = [(l, p) for l in range(3) for p in (1, -1)]
+    while True:
+        pick = [c for c in cand if rng.random() < 0.6]
+        if (0, 1) not in pick:
+            pick.insert(0, (0, 1))                              # (the contraction takes its channel count from the even scalars)
+        by_l = {}
+        for l, p in pick:
+            by_l.setdefault(l, []).append(p)
+        irr = []
+        for l in sorted(by_l):
+            ps = by_l[l]
+            rng.shuffle(ps)
+            irr += [f"2x{l}{'e' if p == 1 else 'o'}" for p in ps]
+        if sum(2 * int(t[2]) + 1 for t in irr) <= 14:
+            break
+    irr = "+".join(irr)
+    hid = P.corr_hidden_irreps(irr, 2)
+    tab = P.sym_contraction_tables(hid, 3)
+    coupling = OIrreps([(1, ir) for _, ir in OIrreps(irr)])
+    num_ell = tab["num_ell"]
+    o = 0
+    kg = {1: 0, 2: 0, 3: 0}
+    for k, (_, ir) in enumerate(OIrreps(irr)):
+        dense = {}
+        for nu in (1, 2, 3):
+            U = M.u_matrix_real(coupling, ir, nu, dtype=torch.float64).numpy()
+            dense[nu] = U if ir.l > 0 else U[None]                # [w, ell.., paths]
+            assert tab[f"K{nu}"][k] == U.shape[-1], (irr, k, nu)
+        for w in range(ir.dim):
+            for nu, ncol in ((1, 1), (2, 2), (3, 3)):
+                ent, ptr = tab[f"ent{nu}"], tab[f"ptr{nu}"]
+                D = np.zeros(dense[nu].shape[1:])
+                for r in range(ptr[o], ptr[o + 1]):
+                    idx = tuple(int(v) for v in ent[r, :ncol]) + (int(ent[r, ncol]) - kg[nu],)
+                    D[idx] += float(ent[r, -1:].view(np.float32)[0])
+                assert np.abs(D - dense[nu][w]).max() < 1e-6, (irr, k, w, nu)
+            o += 1
+        for nu in (1, 2, 3):
+            kg[nu] += tab[f"K{nu}"][k]
+    assert o == tab["nout"] and num_ell == coupling.dim
+
+
 def _random_irreps(rng, lmax):
     """random simplified irreps (distinct (l, p), sorted like the reference's configs: by l, odd/even in random order)"""
     out = []
