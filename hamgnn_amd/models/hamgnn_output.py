@@ -4,7 +4,7 @@ linear_transform}, ..._ksi_network, ..._overlap_network) and result dict.  In sc
 (:3772-3799) incl. overlap networks, SOC/so3 (:3026-3144), SOC/su2 (:3146-3178; E3TensorDecomposition.get_H,
 hamgnn/nn/tensor_decomposition.py:553-603), masks, symmetrisation, H0, per-crystal concatenation, sparsity ratio.
 The k-space step `calculate_band_energy` is built for the spin-free and the spin-orbit branches (hamgnn_amd/kspace.py).
-Out of scope (raise NotImplementedError): spin-constrained / collinear branches, forces."""
+Out of scope (raise NotImplementedError): spin-constrained / collinear branches; return_forces is carried, as in the reference it computes nothing."""
 from __future__ import annotations
 
 import numpy as np
@@ -37,8 +37,9 @@ class HamGNNPlusPlusOut(nn.Module):
         self.calculate_sparsity = calculate_sparsity
         self.get_nonzero_mask_tensor = get_nonzero_mask_tensor
         self.calculate_band_energy, self.num_k, self.k_path, self.band_num_control = calculate_band_energy, num_k, k_path, band_num_control
-        for flag, name in ((return_forces, "return_forces"),
-                           (spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
+        # return_forces / create_graph: stored as `derivative` / `create_graph` and read by nothing in the reference's head (hamgnn_output.py:127-128);
+        # its Model only switches autograd on for `pos` (Model.py:103, 227, 285, 459-460) -- no force is computed anywhere: accepted, no effect
+        for flag, name in ((spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
                            (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
             if flag:
                 raise NotImplementedError(f"HamGNNPlusPlusOut({name}) is outside the MI355X hot-path scope of this round")

@@ -86,9 +86,9 @@ class Model(nn.Module):
         self.losses, self.metrics = losses, validation_metrics
         self.lr, self.lr_decay, self.lr_patience, self.lr_monitor = lr, lr_decay, lr_patience, lr_monitor
         self.post_processing = post_processing
-        self.requires_derivatives = getattr(self.output_module, "derivative", False)
-        if self.requires_derivatives:
-            raise NotImplementedError("forces (return_forces=True) need the backward pass: outside this round's scope")
+        # return_forces: the reference only enables autograd on batch.pos in its Lightning steps (Model.py:227, 285, 459-460) and computes no
+        # force anywhere; the flag is carried for interface parity and changes nothing here either
+        self.requires_derivatives = bool(getattr(self.output_module, "derivative", False))
 
     def forward(self, batch):
         representation = self.representation(batch)

@@ -58,6 +58,23 @@ def test_missing_use_corr_prod_defaults_to_true_like_the_reference():
     assert rep.use_corr_prod and hasattr(rep, "corr_products")                  # main.py:216-217
 
 
+def test_return_forces_is_accepted_and_carried_like_the_reference():
+    """HamGNNPlusPlusOut(return_forces=True) only sets `derivative` (hamgnn_output.py:127), the Model's `requires_derivatives` (Model.py:103): the
+    reference computes no force anywhere, so the flag must not be an error and must not change the modules that are built"""
+    from hamgnn.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn.models.Model import Model
+    cfg = _config()
+    kw = dict(irreps_in_node=MINI, irreps_in_edge=MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True, soc_switch=False)
+    a, b = HamGNNPlusPlusOut(return_forces=True, create_graph=True, **kw), HamGNNPlusPlusOut(**kw)
+    assert a.derivative is True and b.derivative is False
+    assert [k for k, _ in a.named_parameters()] == [k for k, _ in b.named_parameters()]
+    m = Model(HamGNNConvE3(cfg.representation_nets), a)
+    assert m.requires_derivatives is True
+    with pytest.raises(NotImplementedError):                   # what is NOT built still fails loudly at construction
+        HamGNNPlusPlusOut(spin_constrained=True, **kw)
+
+
 def test_transformer_backbone_through_build_hamgnn_model_and_verified_loading():
     """GNN_Net: HamGNNTransformer (main.py:219-220): module tree / parameter names of the reference, weights load verified"""
     from hamgnn.main import build_hamgnn_model
