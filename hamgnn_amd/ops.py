@@ -48,6 +48,10 @@ def _require_gpu(t: torch.Tensor):
         raise RuntimeError("hamgnn_amd: the MI355X hot path needs CUDA(ROCm) tensors; there is no CPU fallback")
 
 
+WIDE_MODE = os.environ.get("HG_MP_WIDE", "1")             # "0": never, "1": launches with >= WIDE_MIN_TILES 16-edge tiles, "force": whenever the program has a wide form
+WIDE_MIN_TILES = int(os.environ.get("HG_WIDE_MIN_TILES", "512"))
+
+
 class DeviceProgram:
     """A plan.Program uploaded to the GPU."""
 
@@ -69,6 +73,8 @@ class DeviceProgram:
         self._device = device
         self._is_tables = {}                                   # parts -> (IsSchedule, device tables)
         self._is_weights = {}                                  # parts -> weight blob with the schedule's own streams appended (lite_mode runs)
+        self._wide = None                                      # (WideSchedule, device tables, host layout array) or False: no wide form (csrc/tp_wide.hip)
+        self._wide_weights = None
         if prog.vsegs and schedule not in ("is", "is_parts"):
             raise ValueError("a program with merged items runs on the input-stationary kernel only")
         self.fixed_parts = None                                # "lds": the tiles of all output segments need several workgroups per 16 edges
@@ -85,6 +91,7 @@ class DeviceProgram:
     def weights_changed(self):
         """after the packed weight blob was rewritten in place (nn.MessagePackBlock.refresh): rebuild what is derived from it"""
         self._is_weights.clear()                               # (lite programs are recompiled, not refreshed; kept consistent anyway)
+        self._wide_weights = None                              # (the schedule's coefficient blocks ride behind the refreshed blob)
         self._is_tables = {k: v for k, v in self._is_tables.items() if v[0].extra_weights is None}
 
     def is_tables(self, parts):
@@ -96,6 +103,34 @@ class DeviceProgram:
             if sc.extra_weights is not None:                   # lite_mode runs: their step streams ride behind the program's weights
                 self._is_weights[parts] = torch.cat([self.weights, _dev(sc.extra_weights, self._device, torch.float32)])
         return self._is_tables[parts]
+
+    def wide_tables(self):
+        """(WideSchedule, device tables, host layout) of csrc/tp_wide.hip for this program, or None when it has no wide form"""
+        if self._wide is None:
+            try:
+                ws = P.wide_schedule(self.prog)
+                lay = ws.lay
+                host = np.ascontiguousarray(np.asarray([ws.seg_table.shape[0], ws.nphase, lay["trash_off"], lay["rowtab_off"], len(ws.rowtab), lay["stage_off"],
+                                                        lay["stage_floats"], lay["sbuf_off"], lay["sbuf_slots"], lay["flag_off"], lay["ctr_off"], lay["lds_floats"]], np.int32))
+                self._wide = (ws, tuple(_dev(t, self._device) for t in (ws.seg_table, ws.block_table, ws.pool_table, ws.chain_table, ws.task_table, ws.rowtab)), host)
+            except NotImplementedError:
+                self._wide = False
+        return self._wide or None
+
+    def wide_weights(self) -> torch.Tensor:
+        if self._wide_weights is None:
+            self._wide_weights = torch.cat([self.weights, _dev(self._wide[0].extra_weights, self._device, torch.float32)])
+        return self._wide_weights
+
+    def use_wide(self, rows: int, gather, res) -> bool:
+        """large single-part launches of tensor-product programs take the wide schedule (one 16-wave workgroup per CU); HG_MP_WIDE=0 restores hg_tp_is"""
+        if self.sched is None or self.fixed_parts is not None or res or WIDE_MODE == "0":
+            return False
+        if int(self.sched.part_table[0][11]) or self.is_parts_for(rows) != 1:
+            return False
+        if WIDE_MODE != "force" and (rows + 15) // 16 < WIDE_MIN_TILES:
+            return False
+        return self.wide_tables() is not None
 
     def is_weights(self, parts) -> torch.Tensor:
         """the weight blob a launch with `parts` sub-schedules reads"""
@@ -389,7 +424,15 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     if PROFILE_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
-    if dp.sched is not None:
+    if dp.sched is not None and dp.use_wide(rows, gather, res):
+        ws, (t_segs, t_blocks, t_pools, t_chains, t_tasks, t_rowtab), lay_host = dp.wide_tables()
+        gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
+        gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
+        check(lib().hg_tp_wide(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.wide_weights()), ptr(t_segs), ptr(t_blocks),
+                               ptr(t_pools), ptr(t_chains), ptr(t_tasks), ptr(t_rowtab), lay_host.ctypes.data_as(C.c_void_p), gp, i32(rot_mask),
+                               ptr(reduce[0]) if reduce is not None else C.c_void_p(0), ptr(reduce[1]) if reduce is not None else C.c_void_p(0),
+                               ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_wide")
+    elif dp.sched is not None:
         sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts, t_rowtab) = dp.is_tables(dp.is_parts_for(rows))
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])

@@ -362,6 +362,241 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
                       extra_weights=(np.concatenate(runs["w"]) if runs is not None and runs["w"] else None))
 
 
+# ---- wide schedule (csrc/tp_wide.hip, r5): ONE workgroup of WIDE_WAVES waves per CU on one 16-edge tile -----------------------------------------
+# Why: the input-stationary kernel keeps 56 KB of output tiles + 19 KB of staged rows per 16 edges in LDS, so a CU holds two tiles, and a tile offers only as
+# many conflict-free work groups per phase as it has output segments (8 after merging) -- ~8 busy waves per CU, the matrix pipe 50 % busy for four rounds
+# (profiles/r04_tp_is_experiments.md).  Column windows of an item ARE conflict-free, but each would recompute the item's radial scale S = W3^T h (27 % of all
+# MFMAs: + 21 ... 50 %, measured on paper in profiles/r05_tp_wide.md).  Here the LDS of the whole CU belongs to one tile: S fragments are produced ONCE per
+# item by "S tasks" into an LDS buffer and read by the item's column-window tasks, the staging area is double-buffered (the next phase's rows are gathered /
+# rotated by tasks of THIS phase's pool), and 16 waves (four per SIMD, <= 128 VGPRs) claim the tasks of a phase from one ordered list:
+#     pool(ph) = [staging tasks of phase ph + 1 | S tasks of phase ph | compute tasks of phase ph, largest first]      one barrier per phase
+# A compute task waits for its item's S through a flag in LDS (its producer was claimed earlier in the same list and never waits: no deadlock).
+WIDE_WAVES = int(os.environ.get("HG_WIDE_WAVES", "16"))   # = WD_NW of csrc/tp_wide.hip
+WIDE_LDS_BYTES = 160 * 1024
+WIDE_TASK_I32 = 32
+WT_STAGE, WT_S, WT_COMPUTE = 0, 1, 2
+WIDE_ACC_CAP = int(os.environ.get("HG_WIDE_ACC_CAP", "10"))    # accumulator fragments (row tiles x columns) of a compute task: 40 VGPRs
+WIDE_NCW_MAX = 7                                          # column-window instantiations of csrc/tp_wide.hip (WD_CASE)
+WIDE_TASKS_PER_WAVE = float(os.environ.get("HG_WIDE_TPW", "2.5"))   # compute tasks per wave and phase the splitting aims for
+WIDE_FLAGS = 128                                          # S-ready flags (items of one phase)
+
+
+def wide_ncw_cap(rtm: int) -> int:
+    return max(1, min(WIDE_NCW_MAX, WIDE_ACC_CAP // rtm))
+
+
+@dataclass
+class WideSchedule:
+    seg_table: np.ndarray          # as IsSchedule.seg_table (epilogue)
+    block_table: np.ndarray        # as IsSchedule.block_table (stage offsets relative to a staging buffer)
+    phase_blocks: np.ndarray       # int32[nphase][2] = {block_begin, block_end}
+    pool_table: np.ndarray         # int32[nphase + 1][2] = {chain_begin, chain_end}: pool 0 = the staging tasks of phase 0 (prologue), pool ph + 1 = pool(ph) above
+    chain_table: np.ndarray        # int32[nchain][2] = {record_begin, record_end}: what a wave claims; staging shares and S tasks are chains of one record
+    task_table: np.ndarray         # int32[nrec][32], see wide_schedule
+    item_table: np.ndarray         # the IS item records the tasks were cut from (emulator / tests)
+    rowtab: np.ndarray
+    extra_weights: np.ndarray      # per-task packed CG coefficient blocks, appended to Program.weights on the device
+    lay: Dict[str, int]            # LDS float offsets: trash_off, rowtab_off, stage_off (buffer b at + b * stage_floats), stage_floats, sbuf_off, sbuf_slots,
+    #                                flag_off, ctr_off, lds_floats
+    nphase: int
+    balance: float                 # LPT estimate over WIDE_WAVES waves (compute + S tasks), like IsSchedule.balance
+    crit: float                    # estimated critical path (MFMA slots per wave, summed over the phases)
+    mfma_tasks: int                # MFMAs the tasks issue per 16 edges (= the program's: nothing is recomputed)
+
+
+def _wide_group_windows(recs, col_cost, target: float) -> List[Tuple[int, int]]:
+    """column windows [m_lo, m_hi] of one work group (= all items of one (phase, output segment key)): contiguous in m, together all columns any item
+    touches, balanced by the items' per-column cost, as many as the group's cost asks for (cost / target, at most one per column)"""
+    M = max(int(r[6]) for r in recs)
+    cm = []
+    for m in range(-M, M + 1):
+        c = 0.0
+        for r in recs:
+            mm = int(r[6])
+            if abs(m) <= mm and not (m == 0 and int(r[0]) == IT_TP and int(r[7]) and mm > 0):
+                c += col_cost(r)
+        cm.append(c)
+    tot = sum(cm)
+    nwin = int(max(1, min(2 * M + 1, round(tot / target))))
+    out, lo, acc, done = [], -M, 0.0, 0
+    for i, m in enumerate(range(-M, M + 1)):
+        acc += cm[i]
+        left_cols = M - m                                       # columns after m
+        left_wins = nwin - len(out) - 1                         # windows still to open after the current one
+        if left_wins > 0 and (acc >= (len(out) + 1) * tot / nwin - 1e-9 or left_cols <= left_wins) and left_cols >= left_wins:
+            out.append((lo, m))
+            lo = m + 1
+    out.append((lo, M))
+    return out
+
+
+def wide_schedule(prog: "Program") -> WideSchedule:
+    """Cut a finalized tensor-product program into the task pools of csrc/tp_wide.hip.  Raises NotImplementedError when the program has no wide form
+    (lite_mode items, tiles + two staging buffers + a useful S buffer beyond the CU's LDS).
+    A tile cell (row of an output segment, column m) may be updated by ONE wave per phase (read-modify-write in LDS), and several items of a phase feed the
+    same segment: the unit of compute work is therefore a CHAIN = all items of one (phase, segment key) restricted to a window of columns m, run one after
+    the other by the wave that claims it.  An item whose share of the window exceeds the register budget (wide_ncw_cap), or straddles the centre column an
+    odd item skips, appears as several records of the chain."""
+    hp4 = prog.hidden_pad // 4
+    if np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST, IT_STREAM)).any():
+        raise NotImplementedError("wide schedule: lite_mode programs run on the input-stationary kernel")
+    if prog.hidden_pad > 64 and (prog.item_table[:, 0] == IT_TP).any():
+        raise NotImplementedError("wide schedule: radial hidden layers wider than 64")
+    nseg = prog.seg_table.shape[0]
+    members = list(range(nseg))
+    probe = _is_schedule_part(prog, members, hp4, 0, 0, 0, 0, waves=WIDE_WAVES, stage_floats_fixed=1 << 28)
+    base = int(probe["stage_off"])                               # tiles + trash row + row table
+    need = max(int(b[5]) * ceil_div((2 * int(b[4]) + 1) * (int(b[3]) // 4), 4) * 256 for b in probe["btab"])
+    total = WIDE_LDS_BYTES // 4
+    sf = need
+    slots = (total - base - 2 * sf - WIDE_FLAGS - 64) // 256
+    if slots < 8:
+        raise NotImplementedError("wide schedule: the output tiles and two staging buffers leave no room for the radial-scale buffer")
+    sub = _is_schedule_part(prog, members, hp4, 0, 0, 0, 0, waves=WIDE_WAVES, stage_floats_fixed=sf, srt_cap=slots, wig_floats=2 * sf + 256 * slots)
+    assert int(sub["stage_off"]) == base and not sub["copy_stride"]
+    items = sub["items"]                                        # IS item records, phase by phase, work group by work group
+    ptab, gtab = sub["ptab"], sub["gtab"]
+    nphase = len(ptab)
+    stage_off = base
+    sbuf_off = stage_off + 2 * sf
+    flag_off = sbuf_off + slots * 256
+    ctr_off = flag_off + WIDE_FLAGS
+    lay = dict(trash_off=int(sub["trash_off"]), rowtab_off=int(sub["rowtab_off"]), stage_off=stage_off, stage_floats=sf, sbuf_off=sbuf_off, sbuf_slots=slots,
+               flag_off=flag_off, ctr_off=ctr_off, lds_floats=ctr_off + 64)
+    assert lay["lds_floats"] <= total
+    if nphase + 1 > 64:
+        raise NotImplementedError("wide schedule: more than 63 phases")
+    wts = prog.weights
+    extra: List[np.ndarray] = []
+    xbase = int(wts.size)
+    xoff = 0
+    tasks: List[List[int]] = []
+    chains: List[List[int]] = []
+    pools: List[List[int]] = []
+
+    def stage_chains(ph: int):
+        b0, b1 = int(ptab[ph][0]), int(ptab[ph][1])
+        for b in range(b0, b1):
+            s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in sub["btab"][b])
+            pieces = (2 * li + 1) * (in_mulp // 4)
+            steps = ceil_div(pieces, 4)                         # one step = four pieces (one per 16-lane row) of every source
+            per = 2 if li <= 1 else 1                           # steps per share: a step of a rotated block holds 2 (2 l + 1) float4 loads per lane
+            nsub = ceil_div(steps, per)
+            for t in range(nsub):
+                rec = [0] * WIDE_TASK_I32
+                rec[0], rec[1], rec[2], rec[3], rec[4], rec[5] = WT_STAGE, b, t, nsub, li, ph & 1
+                chains.append([len(tasks), len(tasks) + 1])
+                tasks.append(rec)
+
+    def col_cost(r):
+        nsrc = 2 if int(r[2]) >= 0 else 1
+        return nsrc * int(r[8]) * int(r[9]) + (int(r[22]) * int(r[18]) if int(r[0]) == IT_TP else 0)
+
+    def ncols(r):
+        mm = int(r[6])
+        return 2 * mm if (int(r[0]) == IT_TP and int(r[7]) and mm > 0) else 2 * mm + 1
+
+    pools.append([len(chains), 0])
+    stage_chains(0)
+    pools[-1][1] = len(chains)
+    tot_cost, crit_cost, mfma_tasks = 0.0, 0.0, 0
+    for ph in range(nphase):
+        g0, g1 = int(ptab[ph][2]), int(ptab[ph][3])
+        groups = [[items[i] for i in range(int(gtab[gi][0]), int(gtab[gi][1]))] for gi in range(g0, g1)]
+        nrec = sum(len(g) for g in groups)
+        if nrec > WIDE_FLAGS:
+            raise NotImplementedError("wide schedule: more items in one phase than S-ready flags")
+        pool = [len(chains), 0]
+        if ph + 1 < nphase:
+            stage_chains(ph + 1)
+        ctot = sum(col_cost(r) * ncols(r) + 40 for g in groups for r in g)
+        target = max(ctot / (WIDE_WAVES * WIDE_TASKS_PER_WAVE), 48.0)
+        s_tasks, c_chains = [], []
+        slot, fi = 0, 0
+        for recs in groups:
+            info = []
+            for r in recs:
+                typ, mm, rtm = int(r[0]), int(r[6]), int(r[9])
+                my_slot = -1
+                if typ == IT_TP:
+                    my_slot = slot
+                    slot += rtm
+                    rec = [0] * WIDE_TASK_I32
+                    rec[0], rec[1], rec[2], rec[3], rec[4], rec[5] = WT_S, int(r[12]), rtm, int(r[10]), my_slot, fi
+                    s_tasks.append((col_cost(r) * ncols(r), rec))
+                    mfma_tasks += hp4 * rtm
+                info.append((r, my_slot, fi))
+                fi += 1
+            for (m_lo, m_hi) in _wide_group_windows(recs, col_cost, target):
+                chain, ccost = [], 0.0
+                for r, my_slot, my_fi in info:
+                    typ, mm, rtm = int(r[0]), int(r[6]), int(r[9])
+                    odd = bool(typ == IT_TP and int(r[7]) and mm > 0)
+                    lo, hi = max(m_lo, -mm), min(m_hi, mm)
+                    if lo > hi:
+                        continue
+                    runs = [(lo, hi)]
+                    if odd and lo <= 0 <= hi:                  # the centre column of an odd item is structurally zero: not computed
+                        runs = [(a, b) for a, b in ((lo, -1), (1, hi)) if a <= b]
+                    cap = wide_ncw_cap(rtm)
+                    cfull = wts[int(r[13]):int(r[13]) + rtm * (2 * mm + 1) * 16].reshape(rtm, 2 * mm + 1, 4, 4) if typ == IT_TP else None   # [rt][c][g][r]
+                    for a, b in runs:
+                        n = b - a + 1
+                        k = ceil_div(n, cap)
+                        base_n, rem = divmod(n, k)
+                        o = a
+                        for j in range(k):
+                            ncw = base_n + (1 if j < rem else 0)
+                            c0 = o + mm                        # first real column of the record
+                            o += ncw
+                            rec = [0] * WIDE_TASK_I32
+                            rec[0] = WT_COMPUTE
+                            rec[1] = int(r[1]) + (ph & 1) * sf                 # stage offsets inside the phase's buffer
+                            rec[2] = int(r[2]) + (ph & 1) * sf if int(r[2]) >= 0 else -1
+                            rec[3] = my_slot
+                            for q in (4, 5, 6, 7, 8, 9, 11, 14, 16, 17, 18, 22, 23):
+                                rec[q] = int(r[q])
+                            rec[10] = my_fi
+                            rec[13], rec[15], rec[19] = c0, ncw, typ
+                            if typ == IT_TP:                   # the record's CG coefficients, packed: lane (g, p = rt * ncw + j) holds the float4 over r
+                                pk = np.zeros((4, 16, 4), dtype=wts.dtype)
+                                for rt in range(rtm):
+                                    for jj in range(ncw):
+                                        pk[:, rt * ncw + jj, :] = cfull[rt, c0 + jj]
+                                extra.append(pk.reshape(-1))
+                                rec[12] = xbase + xoff
+                                xoff += 256
+                            cc = col_cost(r) * ncw
+                            mfma_tasks += cc
+                            ccost += cc + 40
+                            chain.append(rec)
+                if chain:
+                    c_chains.append((ccost, chain))
+        assert slot <= slots
+        s_tasks.sort(key=lambda t: -t[0])
+        c_chains.sort(key=lambda t: -t[0])
+        for _, rec in s_tasks:
+            chains.append([len(tasks), len(tasks) + 1])
+            tasks.append(rec)
+        for _, ch in c_chains:
+            chains.append([len(tasks), len(tasks) + len(ch)])
+            tasks += ch
+        pool[1] = len(chains)
+        pools.append(pool)
+        loads = [0.0] * WIDE_WAVES
+        for c in [hp4 * t[1][2] + 40 for t in s_tasks] + [t[0] for t in c_chains]:
+            loads[loads.index(min(loads))] += c
+        tot_cost += sum(loads)
+        crit_cost += max(loads)
+    return WideSchedule(seg_table=sub["segs"], block_table=np.asarray(sub["btab"], np.int32).reshape(-1, IS_BLOCK_I32),
+                        phase_blocks=np.asarray([[int(p[0]), int(p[1])] for p in ptab], np.int32).reshape(-1, 2),
+                        pool_table=np.asarray(pools, np.int32).reshape(-1, 2), chain_table=np.asarray(chains, np.int32).reshape(-1, 2),
+                        task_table=np.asarray(tasks, np.int32).reshape(-1, WIDE_TASK_I32),
+                        item_table=np.asarray(items, np.int32).reshape(-1, IS_ITEM_I32), rowtab=np.asarray(sub["rowtab"], np.int32),
+                        extra_weights=(np.concatenate(extra) if extra else np.zeros(4, wts.dtype)), lay=lay, nphase=nphase,
+                        balance=tot_cost / (WIDE_WAVES * crit_cost) if crit_cost else 1.0, crit=crit_cost, mfma_tasks=int(mfma_tasks))
+
+
 def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool):
     """the column tasks of one (segment, row chunk): for every output column m (or pair +-m) the list of steps (fragment group [rtm * 256], d0, d1)
     over all folded items that feed it (descriptor words: _lite_streams).  Columns +m and -m of an (input irrep, output irrep) pair carry the SAME
@@ -491,9 +726,12 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int], wa
 
 
 def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
-                      split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None, waves: int = IS_WAVES) -> dict:
+                      split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None, waves: int = IS_WAVES,
+                      stage_floats_fixed: Optional[int] = None, srt_cap: Optional[int] = None, wig_floats: Optional[int] = None) -> dict:
     """sub-schedule of the output segments `members` (indices into prog.seg_table); all table indices are emitted as ABSOLUTE indices
-    into the concatenated tables of the launch (bases given)."""
+    into the concatenated tables of the launch (bases given).
+    stage_floats_fixed / srt_cap (wide schedule, plan.wide_schedule): the staging area's size is given instead of "what the LDS leaves", and a
+    phase holds at most srt_cap 16-row tiles of radial scales (the S fragments of its tensor-product items travel through an LDS buffer)."""
     segs = prog.seg_table[members].copy()
     local = {old: n for n, old in enumerate(members)}
     off, maxstride = 0, 0
@@ -546,7 +784,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     rowtab += [0] * ((-len(rowtab)) % 4)
     rowtab_off = tiles_end
     stage_off = rowtab_off + len(rowtab)
-    stage_floats = IS_LDS_BYTES // 4 - stage_off - 4
+    stage_floats = IS_LDS_BYTES // 4 - stage_off - 4 if stage_floats_fixed is None else int(stage_floats_fixed)
     # ---- input blocks read by this part's items
     blocks: Dict[Tuple[int, int, int], dict] = {}
     for rec in prog.item_table:
@@ -566,6 +804,9 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         b["cls"] = cls.pop() if len(cls) == 1 else None        # None: plain Linear items only (no radial scale) / not separated
         b["src_floats"] = ceil_div((2 * b["li"] + 1) * (b["in_mulp"] // 4), 4) * 256
         b["floats"] = b["nsrc"] * b["src_floats"]
+        b["srt"] = sum(int(r[9]) for r in b["items"] if int(r[0]) == IT_TP)
+        if srt_cap is not None and b["srt"] > srt_cap:
+            raise NotImplementedError(f"wide schedule: one input block carries {b['srt']} row tiles of radial scales, the LDS buffer holds {srt_cap}")
         if b["floats"] > stage_floats:
             raise NotImplementedError(f"input-stationary schedule: LDS staging area of {stage_floats * 4} B is smaller than an input block")
     # the staging area only needs to hold the largest phase: parts with small tiles keep the LDS small as well
@@ -577,7 +818,8 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     for b in sorted(blocks.values(), key=lambda b: -b["floats"]):
         for ph in phases:
             if sum(x["floats"] for x in ph) + b["floats"] <= stage_floats and (
-                    not separate_mlp or b["cls"] is None or _cls(ph) is None or _cls(ph) == b["cls"]):
+                    not separate_mlp or b["cls"] is None or _cls(ph) is None or _cls(ph) == b["cls"]) and (
+                    srt_cap is None or sum(x["srt"] for x in ph) + b["srt"] <= srt_cap):
                 ph.append(b)
                 break
         else:
@@ -637,11 +879,12 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         if int(sg[7]) & SEG_UNROTATE:
             need[int(sg[0])] = ceil_div((2 * int(sg[0]) + 1) ** 2, 4) * 64
     batches: List[List[int]] = []
+    wig_cap = stage_floats if wig_floats is None else int(wig_floats)     # (wide schedule: the epilogue owns both staging buffers and the S buffer)
     for l in sorted(need, key=lambda l: -need[l]):
-        if need[l] > stage_floats:
+        if need[l] > wig_cap:
             raise NotImplementedError("input-stationary schedule: staging area smaller than a Wigner block")
         for bt in batches:
-            if sum(need[x] for x in bt) + need[l] <= stage_floats:
+            if sum(need[x] for x in bt) + need[l] <= wig_cap:
                 bt.append(l)
                 break
         else:

@@ -128,6 +128,29 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
              const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
              int64_t rows, void* stream);
 
+/* The same whole MessagePackBlock.forward as hg_tp_is (hamgnn/nn/message_passing.py:191-231 incl. the node gathers of convolution.py:138-141 /
+ * interaction_blocks.py:141-145 and, with run_id, the receiver scatter convolution.py:147-149), on the WIDE schedule (csrc/tp_wide.hip, r5; plan.py:
+ * wide_schedule): ONE workgroup of 16 waves per 16-edge tile owns the CU's LDS -- output tiles, two staging buffers, a buffer of radial-scale
+ * fragments and their ready flags -- and claims the tasks of a phase from one ordered list (pool): staging shares of the NEXT phase's input
+ * blocks, one radial-scale ("S") task per item, column-window compute tasks (GEMM1 -> scale -> GEMM2 on 1..7 columns of an item).  Single-part,
+ * non-lite programs with a 64-wide radial hidden layer only; same `weights` blob as hg_tp_is with the schedule's packed coefficient blocks appended.
+ *   seg_table, block_table, row_table: as for hg_tp_is (one part)
+ *   pool_table  int32[nphase + 1][2] = {chain_begin, chain_end}: pool 0 = staging of phase 0, pool p + 1 = [staging of p + 1 | S of p | compute of p]
+ *   chain_table int32[nchain][2] = {record_begin, record_end}: the records one wave runs back to back (a staging share, an S task, or every item of
+ *               one (phase, output segment) restricted to a window of columns: a tile cell is updated by one wave per phase)
+ *   task_table  int32[nrec][32]: [0] = kind.  0 (staging): [1] block, [2] share, [3] shares, [4] l of the block, [5] staging buffer (0 / 1);
+ *               1 (S): [1] float offset of the item's W3 fragments, [2] row tiles, [3] radial generator (0 node / 1 edge), [4] first S slot, [5] flag;
+ *               2 (compute): the item's record fields at their hg_tp_is positions ([1], [2] stage offsets incl. the buffer, [4..9], [11], [14], [16..18],
+ *               [22], [23]) and [3] first S slot, [10] flag, [12] float offset of the window's packed CG coefficients, [13] first real column,
+ *               [15] columns of the window, [19] item type (0 tensor product, 1 plain Linear)
+ *   lay_host    HOST int32[12] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off,
+ *               lds_floats}: float offsets inside the workgroup's LDS (validated)                                                              */
+int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge, int hidden,
+               const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table, const int32_t* block_table,
+               const int32_t* pool_table, const int32_t* chain_table, const int32_t* task_table, const int32_t* row_table, const int32_t* lay_host,
+               const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
+               int64_t rows, void* stream);
+
 /* Many small independent matrix products in one launch (csrc/block_gemm.hip):  C_u = scale_u * op(A_u) @ op(B_u).  Replaces the per-irrep
  * products of a MessagePackBlock's two trailing Linears -- linear_scaler.linear_out @ linear_out / sqrt(mul_k)
  * (hamgnn/nn/message_passing.py:122-130, nn/tensor_products.py:118-140) -- in the device-side weight repack and, transposed, in the backward of

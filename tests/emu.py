@@ -353,6 +353,194 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
     return out
 
 
+def run_program_wide(prog, ws, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64, order="list"):
+    """the wide schedule (plan.wide_schedule, csrc/tp_wide.hip), fragment-exact: per 16-edge tile one LDS image [tiles | trash row | row table |
+    staging buffer 0 | staging buffer 1 | S buffer | flags | counters]; pool 0 stages phase 0, pool p + 1 = [staging shares of phase p + 1 | one S
+    task per item of phase p | its column-window compute tasks].  Staging shares write the staged image piece by piece exactly as csrc/tp_wide.hip:
+    wd_stage deals the pieces (share `sub` of `nsub`: pieces 4 sub + g + 4 nsub k), compute tasks read their B operands FROM that image, their S
+    fragments from the S buffer and their coefficients from the task's packed block.  Checked on the way: LDS layout and budget, every piece of every
+    block staged exactly once before it is read, S slots disjoint inside a phase and written before they are read (list order: the deadlock-freedom
+    argument of the kernel), flags unique per phase, every (item, column) computed exactly once (odd items: never the centre column), every tile cell
+    updated by at most one task per phase.  order = "list": tasks in list order; "reverse_compute": the compute tasks of a pool in reverse order (the
+    result must not depend on the claim order)."""
+    E = srcs[0].shape[0]
+    Wt = np.concatenate([prog.weights.astype(dtype), ws.extra_weights.astype(dtype)])
+    out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
+    woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
+    lay = ws.lay
+    H, Hp = prog.hidden, prog.hidden_pad
+    nseg = ws.seg_table.shape[0]
+    tile_floats = sum(int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) for s in ws.seg_table)
+    maxstride = max((2 * int(s[0]) + 1) * 16 + 4 for s in ws.seg_table)
+    sf, slots = lay["stage_floats"], lay["sbuf_slots"]
+    assert lay["trash_off"] == tile_floats and lay["rowtab_off"] == tile_floats + maxstride and lay["stage_off"] == lay["rowtab_off"] + len(ws.rowtab)
+    assert lay["stage_off"] % 4 == 0 and lay["sbuf_off"] == lay["stage_off"] + 2 * sf and lay["flag_off"] == lay["sbuf_off"] + 256 * slots
+    assert lay["ctr_off"] == lay["flag_off"] + P.WIDE_FLAGS and lay["lds_floats"] == lay["ctr_off"] + 64 and lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES
+    assert ws.pool_table.shape[0] == ws.nphase + 1 <= 64 and ws.pool_table[0][0] == 0 and ws.pool_table[-1][1] == ws.chain_table.shape[0]
+    assert all(int(ws.pool_table[k][1]) == int(ws.pool_table[k + 1][0]) for k in range(ws.nphase))
+    assert ws.chain_table[0][0] == 0 and ws.chain_table[-1][1] == ws.task_table.shape[0]
+    assert all(int(ws.chain_table[k][1]) == int(ws.chain_table[k + 1][0]) and ws.chain_table[k][0] < ws.chain_table[k][1] for k in range(ws.chain_table.shape[0] - 1))
+    tile_of = np.full(tile_floats + maxstride, -1)
+    for gi, sgr in enumerate(ws.seg_table):
+        tile_of[int(sgr[5]):int(sgr[5]) + int(sgr[1]) * ((2 * int(sgr[0]) + 1) * 16 + 4)] = gi
+    hh = [None, None]
+    for k in (0, 1):
+        if h2[k] is not None:
+            hh[k] = np.zeros((E, Hp), dtype=dtype)
+            hh[k][:, :H] = h2[k]
+    col_seen = {}
+    for e0 in range(0, E, 16):
+        ne = min(16, E - e0)
+        cols = np.arange(e0, e0 + ne)
+        lds = np.zeros(tile_floats + maxstride, dtype=dtype)
+        stage = np.full((2, sf), np.nan, dtype=dtype)                                  # NaN = not staged (a read of it poisons the result)
+        first_tile = e0 == 0
+        for pl in range(ws.nphase + 1):
+            t0, t1 = (int(v) for v in ws.pool_table[pl])
+            chains = [[ws.task_table[t] for t in range(int(ws.chain_table[c][0]), int(ws.chain_table[c][1]))] for c in range(t0, t1)]
+            kinds = [int(ch[0][0]) for ch in chains]
+            assert kinds == sorted(kinds), "pool order: staging shares, S tasks, compute chains"
+            assert all(len({int(t[0]) for t in ch}) == 1 and (len(ch) == 1 or int(ch[0][0]) == P.WT_COMPUTE) for ch in chains)
+            if order == "reverse_compute":
+                chains = [ch for ch in chains if int(ch[0][0]) != P.WT_COMPUTE] + [ch for ch in chains if int(ch[0][0]) == P.WT_COMPUTE][::-1]
+            ph = pl - 1
+            sbuf, flags, cells = {}, set(), {}
+            staged_next = {}
+            for chain_id, T in ((ci, T) for ci, ch in enumerate(chains) for T in ch):
+                kind = int(T[0])
+                if kind == P.WT_STAGE:
+                    b, sub, nsub, li_t, buf = (int(v) for v in T[1:6])
+                    assert buf == (ph + 1) & 1 and ph + 1 < ws.nphase
+                    pb0, pb1 = (int(v) for v in ws.phase_blocks[ph + 1])
+                    assert pb0 <= b < pb1
+                    s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in ws.block_table[b])
+                    assert li == li_t and 0 <= sub < nsub
+                    P1 = in_mulp // 4
+                    pfull = (2 * li + 1) * P1
+                    size = -(-pfull // 4) * 256
+                    assert o0 + nsrc * size <= sf and (o1 == o0 + size if nsrc == 2 else o1 == -1)
+                    for si, (sidx, o) in enumerate([(s0, o0), (s1, o1)][:nsrc]):
+                        for t in range(pfull):
+                            if (t // 4) % nsub != sub:                                 # piece t = 4 j + g belongs to share j % nsub
+                                continue
+                            a, p_ = divmod(t, P1)
+                            key = (b, si, t)
+                            assert key not in staged_next
+                            staged_next[key] = 1
+                            for q in range(4):
+                                v = np.zeros(16, dtype=dtype)
+                                v[:ne] = srcs[sidx][cols, in_off + a * in_mulp + 4 * p_ + q]
+                                stage[buf, o + 64 * t + 4 * np.arange(16) + q] = v
+                elif kind == P.WT_S:
+                    w3, rtm, mlp, slot, fi = (int(v) for v in T[1:6])
+                    assert 0 <= slot and slot + rtm <= slots and fi not in flags and 0 <= fi < P.WIDE_FLAGS
+                    flags.add(fi)
+                    W3 = Wt[w3:w3 + (Hp // 16) * rtm * 256].reshape(Hp // 16, rtm, 4, 16, 4)
+                    S = np.zeros((rtm, 16, 16), dtype=dtype)
+                    for G in range(Hp // 16):
+                        for q in range(4):
+                            B = np.zeros((4, 16), dtype=dtype)
+                            for g in range(4):
+                                B[g, :ne] = hh[mlp][cols, 16 * G + 4 * g + q]
+                            for rt in range(rtm):
+                                S[rt] += W3[G, rt, :, :, q].T @ B
+                    for rt in range(rtm):
+                        assert slot + rt not in sbuf
+                        sbuf[slot + rt] = (S[rt], fi)
+                else:
+                    assert kind == P.WT_COMPUTE and ph >= 0
+                    so0, so1, sslot, in_mulp, li, mm, neg, ksteps, rtm, fi, a1 = (int(v) for v in T[1:12])
+                    cf, c0, a2, ncw, row0, x4, nk2, typ = (int(v) for v in T[12:20])
+                    rto, rtb = int(T[22]), int(T[23])
+                    assert 1 <= ncw <= P.WIDE_NCW_MAX and rtm * ncw <= P.WIDE_ACC_CAP and 0 <= c0 and c0 + ncw <= 2 * mm + 1
+                    odd = typ == P.IT_TP and neg and mm > 0
+                    assert not (odd and c0 <= mm < c0 + ncw), "a window of an odd item holds its centre column"
+                    nsrc = 2 if so1 >= 0 else 1
+                    ngrp = -(-ksteps // 4)
+                    P1 = in_mulp // 4
+                    buf = ph & 1
+                    assert buf * sf <= so0 and (so1 < 0 or so1 < (buf + 1) * sf)
+                    for j in range(ncw):
+                        key = (ph, a1, c0 + j)
+                        assert key not in col_seen or not first_tile
+                        if first_tile:
+                            col_seen[key] = (mm, odd)
+                    A1 = Wt[a1:a1 + nsrc * ngrp * rtm * 256].reshape(nsrc, ngrp, rtm, 4, 16, 4)
+                    mid = np.zeros((rtm, ncw, 16, 16), dtype=dtype)
+                    flat = stage.reshape(-1)
+                    for si, so in enumerate([so0, so1][:nsrc]):
+                        for j in range(ncw):
+                            m = c0 + j - mm
+                            a = li + (-m if neg else m)
+                            for G in range(ngrp):
+                                for q in range(4):
+                                    if not x4 and 4 * G + q >= ksteps:
+                                        continue
+                                    B = np.zeros((4, 16), dtype=dtype)
+                                    for g in range(4):
+                                        u = 16 * G + 4 * g + q if x4 else 4 * (4 * G + q) + g
+                                        piece, comp = divmod(u, 4)
+                                        B[g] = flat[so + 64 * (a * P1 + piece) + 4 * np.arange(16) + comp]
+                                    for rt in range(rtm):
+                                        mid[rt, j] += A1[si, G, rt, :, :, q].T @ B
+                    rt_ = ws.rowtab[rtb:rtb + 16 * rto] if typ == P.IT_TP else None
+                    if typ == P.IT_TP:
+                        assert fi in flags, "S task of the item precedes its compute tasks in the pool's list"
+                        S = np.stack([sbuf[sslot + rt][0] for rt in range(rtm)])
+                        assert all(sbuf[sslot + rt][1] == fi for rt in range(rtm))
+                        pk = Wt[cf:cf + 256].reshape(4, 16, 4)                                        # [g][p][r]
+                        CF = np.zeros((rtm, ncw, 16), dtype=dtype)
+                        for rt in range(rtm):
+                            for j in range(ncw):
+                                CF[rt, j] = pk[:, rt * ncw + j, :].reshape(16)                        # row 4 g + r
+                        mid = mid * S[:, None, :, :] * CF[:, :, :, None]
+                        A2 = Wt[a2:a2 + rto * rtm * 256].reshape(rto, rtm, 4, 16, 4)
+                        for rtp in range(rto):
+                            for j in range(ncw):
+                                acc = np.zeros((16, 16), dtype=dtype)
+                                for rt in range(rtm):
+                                    for r in range(4):
+                                        if 4 * rt + r >= nk2:
+                                            continue
+                                        acc += A2[rtp, rt, :, :, r].T @ mid[rt, j][r::4, :]
+                                for i_ in range(16):
+                                    base = int(rt_[16 * rtp + i_]) + (c0 + j - mm) * 16
+                                    assert 0 <= base and base + 16 <= tile_floats + maxstride
+                                    if tile_of[base] >= 0:
+                                        assert cells.setdefault(base, chain_id) == chain_id, "a tile cell is updated by one chain (wave) per phase"
+                                    lds[base:base + 16] += acc[i_]
+                    else:
+                        assert typ == P.IT_LIN
+                        rl = ws.rowtab[rtb:rtb + 16 * rto]
+                        for rt in range(rtm):
+                            for j in range(ncw):
+                                for i_ in range(16):
+                                    base = int(rl[row0 + 16 * rt + i_]) + (c0 + j - mm) * 16
+                                    if tile_of[base] >= 0:
+                                        assert cells.setdefault(base, chain_id) == chain_id
+                                    lds[base:base + 16] += mid[rt, j][i_]
+            # every piece of every block of the next phase was staged by exactly one share
+            if ph + 1 < ws.nphase:
+                pb0, pb1 = (int(v) for v in ws.phase_blocks[ph + 1])
+                want = sum(int(ws.block_table[b][5]) * (2 * int(ws.block_table[b][4]) + 1) * (int(ws.block_table[b][3]) // 4) for b in range(pb0, pb1))
+                assert len(staged_next) == want
+        for sg in range(nseg):
+            seg = ws.seg_table[sg]
+            lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
+            strd = (2 * lk_ + 1) * 16 + 4
+            tile = np.zeros((rto_ * 16, 2 * lk_ + 1, 16), dtype=dtype)
+            tile[:mul_] = lds[toff_:toff_ + mul_ * strd].reshape(mul_, strd)[:, :(2 * lk_ + 1) * 16].reshape(mul_, 2 * lk_ + 1, 16)
+            _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)
+    # every column of every item exactly once (odd items: all but the centre)
+    per_item = {}
+    for (ph, a1, c), (mm, odd) in col_seen.items():
+        per_item.setdefault((ph, a1), (mm, odd, set()))[2].add(c)
+    assert len(per_item) == ws.item_table.shape[0]
+    for (mm, odd, cs) in per_item.values():
+        assert cs == set(range(2 * mm + 1)) - ({mm} if odd else set())
+    return out
+
+
 def run_linear_tables(tabs, x, res=(), dtype=np.float64):
     """csrc/linear.hip on plan.LinearTables, fragment-exact: per unit (<= 64 output channels of one irrep block) and 16 pair-rows
     (row, component), the A fragments [G][rt][lane = 16 g + i][q] hold W^T[16 rt + i][16 G + 4 g + q]; the B operand of lane (g, n) is the
