@@ -14,11 +14,13 @@
 //   [ output tiles | trash row | row table | staging buffer 0 | staging buffer 1 | S buffer | S-ready flags | claim counters ]
 //   * S fragments are produced ONCE per item by an "S task" into the S buffer (1 KB per 16 rows) and read by the item's column-window tasks;
 //   * the staging area is double-buffered: the rows of phase p + 1 are gathered / rotated by tasks of phase p's pool;
-//   * the 16 waves claim CHAINS of tasks from ONE ordered list per phase, pool(p) = [staging of p + 1 | S tasks of p | compute chains of p, largest first]
-//     (a compute chain = all items of one (phase, output segment key) on one window of columns: a tile cell is updated by one wave per phase):
-//     memory latency of one wave (node-row gathers, weight fragments, task records) runs under the MFMAs of the other three on its SIMD;
-//     one workgroup barrier per phase.  A compute task waits for its item's S through a flag (value = pool index) -- the producer was claimed
-//     earlier from the same list and never waits, so this cannot deadlock.
+//   * the work of a phase -- pool(p) = S tasks of p, compute chains of p (a chain = all items of one (phase, output segment key) on one window of
+//     columns: a tile cell is updated by one wave per phase), staging shares of p + 1 -- is dealt to the 16 waves by the planner (LPT on a cost model,
+//     plan.wide_schedule): a wave runs ITS stream of 64-byte records back to back, so the next record is requested while the current one runs
+//     (first version: dynamic claims from one list -- three dependent round trips per record, 3 k cycles of waits per ~600 cycles of MFMAs:
+//     profiles/r05_tp_wide.md); memory latency of one wave runs under the MFMAs of the other three on its SIMD; one workgroup barrier per phase.
+//     A compute record waits for its item's S through a flag (value = pool index): every wave runs its S tasks first and S tasks never wait, so this
+//     cannot deadlock.
 // Sums into a tile cell are still made by exactly one task per phase, phases are separated by barriers: the result is bit-reproducible
 // and equal to tp_is's up to the order of the additions inside GEMM2's accumulator init (none: the tile value is the accumulator init there as here).
 #include "tp_stage.h"
@@ -27,7 +29,53 @@
 #define WD_NW 16                 // waves of the workgroup = plan.WIDE_WAVES
 #endif
 #define WD_NT (64 * WD_NW)
-#define WD_TASK_I32 32
+#ifndef WD_A2_EARLY
+#define WD_A2_EARLY 6            // accumulator fragments (row tiles x columns) up to which a record requests GEMM2's first fragments with GEMM1's
+#endif
+#define WD_REC_I32 16             // packed record (plan.wide_pack_record): one s_load_dwordx16
+typedef int wd_rec_t __attribute__((ext_vector_type(16)));
+// w0 = kind | rtm << 2 | ncw << 5 | (typ / radial generator / staging buffer) << 8 | x4 << 9 | neg << 10 | l << 11 | mm << 14 | rto << 17 | nk2 << 21 | c0 << 26
+#define WD_KIND(R) ((R)[0] & 3)
+#define WD_RTM(R) (((R)[0] >> 2) & 7)
+#define WD_NCW(R) (((R)[0] >> 5) & 7)
+#define WD_BIT8(R) (((R)[0] >> 8) & 1)
+#define WD_X4(R) (((R)[0] >> 9) & 1)
+#define WD_NEG(R) (((R)[0] >> 10) & 1)
+#define WD_L(R) (((R)[0] >> 11) & 7)
+#define WD_MM(R) (((R)[0] >> 14) & 7)
+#define WD_RTO(R) (((R)[0] >> 17) & 15)
+#define WD_NK2(R) (((R)[0] >> 21) & 31)
+#define WD_C0(R) (((R)[0] >> 26) & 15)
+
+// phase profiler (HG_PROF builds only, tests/bench_tp.py): per-wave shader-clock time between probes, summed over all waves
+#ifdef HG_PROF
+__device__ unsigned long long hg_prof_wd_acc[16];
+struct ProfWd { unsigned long long t[12]; unsigned long long last; };
+#ifdef HG_PROF_LITE
+#define WD_PROF_ARG
+#define WD_PROF_PASS
+#else
+#define WD_PROF_ARG , ProfWd& prof
+#define WD_PROF_PASS , prof
+#endif
+#define WD_TPROBE(k)                                                 \
+    do {                                                             \
+        const unsigned long long t_ = __builtin_readcyclecounter();  \
+        prof.t[k] += t_ - prof.last;                                 \
+        prof.last = t_;                                              \
+    } while (0)
+#define WD_TL(k) WD_TPROBE(k)
+#ifdef HG_PROF_LITE               // only the probes around the pools' barriers, the zero fill and the epilogue (~30 per wave and tile: no distortion)
+#define WD_T(k)
+#else
+#define WD_T(k) WD_TPROBE(k)
+#endif
+#else
+#define WD_PROF_ARG
+#define WD_PROF_PASS
+#define WD_T(k)
+#define WD_TL(k)
+#endif
 
 struct WdLay {
     int sbuf_off;                // S buffer: slot s at + 256 s floats, lane's float4 at + 4 lane
@@ -37,6 +85,23 @@ struct WdLay {
 };
 
 typedef volatile __attribute__((address_space(3))) int* wd_vint_p;
+
+// ablation builds (timing attribution only, wrong results): operand loads replaced by lane-dependent constants
+#ifdef WD_ABL_NOA1
+#define WD_LDA1(p) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
+#else
+#define WD_LDA1(p) (*(p))
+#endif
+#ifdef WD_ABL_NOA2
+#define WD_LDA2(p) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
+#else
+#define WD_LDA2(p) (*(p))
+#endif
+#ifdef WD_ABL_NOW3
+#define WD_LDW3(p) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
+#else
+#define WD_LDW3(p) (*(p))
+#endif
 
 #define WD_MB_CASE(Q) case Q: asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:" #Q " row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "v"(x)); break;
 __device__ __forceinline__ float wd_mul_bcast(float v, float x, int q) {       // x * (lane q of v's row of 16 lanes), one VALU instruction (see tp_is.hip)
@@ -133,11 +198,11 @@ __device__ __forceinline__ void wd_stage(const IsArgs& A, const int* __restrict_
 // radial scale of ONE item, s_e = W3^T h2 (last layer of the radial MLP, message_passing.py:186-189 / tensor_products.py:25-47), all its RTM row
 // tiles: 16 RTM MFMAs on RTM independent accumulators; the C fragments (lane (edge, g): rows 4 g + r) go to the S buffer as they are.
 template <int RTM>
-__device__ __forceinline__ void wd_task_S(const IsArgs& A, const WdLay& Ly, const float* __restrict__ Wb, const int* __restrict__ T, float* __restrict__ lds,
+__device__ __forceinline__ void wd_task_S(const IsArgs& A, const WdLay& Ly, const float* __restrict__ Wb, const wd_rec_t& T, float* __restrict__ lds,
                                           int64_t erow, int lane, int stamp) {
     asm volatile("" : "+v"(erow));
     const int g = lane >> 4;
-    const float* __restrict__ hrow = (T[3] ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
+    const float* __restrict__ hrow = (WD_BIT8(T) ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
     const f32x4* __restrict__ w3 = reinterpret_cast<const f32x4*>(Wb + T[1]) + lane;       // [G][rt][lane]
     const int hg = __builtin_amdgcn_readfirstlane(A.hidden) >> 4;       // K groups of 16 hidden units (1..4; 4 for the shipped 64-wide layers)
     f32x4 hb[4], wv[4][RTM], S[RTM];
@@ -146,7 +211,7 @@ __device__ __forceinline__ void wd_task_S(const IsArgs& A, const WdLay& Ly, cons
         if (G < hg) {
             hb[G] = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[(G * RTM + rt) * 64];
+            for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = WD_LDW3(w3 + (G * RTM + rt) * 64);
         }
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -158,11 +223,11 @@ __device__ __forceinline__ void wd_task_S(const IsArgs& A, const WdLay& Ly, cons
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hb[G][q], S[rt], 0, 0, 0);
         }
-    float* __restrict__ sb = lds + Ly.sbuf_off + T[4] * 256 + lane * 4;
+    float* __restrict__ sb = lds + Ly.sbuf_off + (T[7] & 0xffff) * 256 + lane * 4;
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) *reinterpret_cast<f32x4*>(sb + rt * 256) = S[rt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the fragments are in the LDS before the flag is
-    if (lane == 0) *(wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + T[5]) = stamp;
+    if (lane == 0) *(wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16)) = stamp;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- compute task
@@ -170,20 +235,31 @@ __device__ __forceinline__ void wd_task_S(const IsArgs& A, const WdLay& Ly, cons
 // accumulator init (IT_TP), or GEMM1 added into the tile (IT_LIN: the PairInteractionBlock's skip o3.Linear).  Arithmetic per column exactly
 // as tp_is.hip:item_is.
 template <int NCW, int RTM>
-__device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly, const float* __restrict__ Wb, const int* __restrict__ T,
-                                                float* __restrict__ lds, int lane, int stamp) {
+__device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly, const float* __restrict__ Wb, const wd_rec_t& T,
+                                                float* __restrict__ lds, int lane, int stamp WD_PROF_ARG) {
 #define WD_NK2_OK(rt, r) ((rt) + 1 < RTM || 4 * (rt) + (r) < nk2)
-    const int so0 = T[1], so1 = T[2], in_mulp = T[4], li = T[5], mm = T[6], neg = T[7], ksteps = T[8];
-    const int c0 = T[13], x4 = T[17], nk2 = T[18], typ = T[19], rto = T[22];
+    const int so0 = T[1], so1 = T[2], in_mulp = T[3] & 0xffff, li = WD_L(T), mm = WD_MM(T), neg = WD_NEG(T), ksteps = T[3] >> 16;
+    const int c0 = WD_C0(T), x4 = WD_X4(T), nk2 = WD_NK2(T), typ = WD_BIT8(T), rto = WD_RTO(T);
     const int g = lane >> 4, el = lane & 15;
-    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + T[23];
+    const int* __restrict__ rtab = reinterpret_cast<const int*>(lds + A.rowtab_off) + T[9];
     float* __restrict__ tbase = lds + (el + (c0 - mm) * 16);    // + row-table entry (the row's centre column) + 16 j for window column j
     const float* __restrict__ stage = lds + A.stage_off;
     const int nsrc = so1 >= 0 ? 2 : 1;
     const int ngrp = (ksteps + 3) >> 2;
-    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + T[11]) + lane;        // [src][G][rt][lane]
+    const f32x4* __restrict__ aw = reinterpret_cast<const f32x4*>(Wb + T[4]) + lane;         // [src][G][rt][lane]
+    const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + T[6]) + lane;         // [rt'][rt][lane]
     f32x4 cfv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (typ == 0) cfv = reinterpret_cast<const f32x4*>(Wb + T[12])[lane];                    // the window's packed CG coefficients (plan.wide_schedule)
+    f32x4 a2_n[RTM];
+    // every fragment the record needs first -- GEMM1's first K group, the coefficients, GEMM2's first row tile -- is requested HERE, in one round trip
+    // (GEMM2's fragments after GEMM1: a second exposed L2 latency per record; a record holds ~20 MFMAs)
+    constexpr bool A2_EARLY = RTM * NCW <= WD_A2_EARLY;        // (register budget: 128; the large shapes request GEMM2's fragments after GEMM1)
+    if (typ == 0) {
+        cfv = reinterpret_cast<const f32x4*>(Wb + T[5])[lane];                               // the window's packed CG coefficients (plan.wide_schedule)
+        if constexpr (A2_EARLY) {
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = WD_LDA2(a2 + rt * 64);
+        }
+    }
     f32x4 mid[RTM][NCW];
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt)
@@ -196,7 +272,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
     const int src_jump = (so1 - so0) - ngrp * 256;
     f32x4 av_n[RTM];
 #pragma unroll
-    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
+    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = WD_LDA1(aw + rt * 64);
     if (NCW <= 3 && x4) {                                      // permuted K: fragment (c, G) = piece cbase + 4 G + g of row el
         const float* __restrict__ pc[NCW];
 #pragma unroll
@@ -212,7 +288,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
             for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
             if (t + 1 < ntot) {
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = WD_LDA1(aw + ((t + 1) * RTM + rt) * 64);
             }
 #pragma unroll
             for (int c = 0; c < NCW; ++c) {
@@ -244,7 +320,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
             for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
             if (t + 1 < ntot) {
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = WD_LDA1(aw + ((t + 1) * RTM + rt) * 64);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -265,18 +341,28 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
             for (int c = 0; c < NCW; ++c) pc[c] += 256;
         }
     }
+    WD_T(3);                                                    // GEMM1
     if (typ == 0) {
-        const f32x4* __restrict__ a2 = reinterpret_cast<const f32x4*>(Wb + T[14]) + lane;    // [rt'][rt][lane]
-        f32x4 a2_n[RTM];
+        if constexpr (!A2_EARLY) {
 #pragma unroll
-        for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];
-        // the item's S fragments: produced by its S task, claimed earlier from this pool's list
+            for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = WD_LDA2(a2 + rt * 64);
+        }
+        // the item's S fragments: produced by its S task (at the head of some wave's stream of this pool)
         {
-            wd_vint_p fl = (wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + T[10]);
-            while (*fl != stamp) __builtin_amdgcn_s_sleep(1);
+            wd_vint_p fl = (wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16));
+            int spin = 0;
+#ifdef WD_ABL_NOFLAG
+            spin = 1 << 19;
+#endif
+            while (*fl != stamp && spin < (1 << 18)) {         // (bounded: a schedule whose S task does not precede its consumers would otherwise hang the
+                __builtin_amdgcn_s_sleep(1);                   //  GPU; the bound is ~10 ms, then the rows come out as NaN instead)
+                ++spin;
+            }
+            if (spin == (1 << 18)) cfv = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
             asm volatile("" ::: "memory");
         }
-        const float* __restrict__ sb = lds + Ly.sbuf_off + T[3] * 256 + lane * 4;
+        WD_T(4);                                                // waiting for the item's S fragments
+        const float* __restrict__ sb = lds + Ly.sbuf_off + (T[7] & 0xffff) * 256 + lane * 4;
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) {
             const f32x4 S = *reinterpret_cast<const f32x4*>(sb + rt * 256);
@@ -298,7 +384,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
             for (int rt = 0; rt < RTM; ++rt) av[rt] = a2_n[rt];
             if (rtp + 1 < rto) {
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
+                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = WD_LDA2(a2 + ((rtp + 1) * RTM + rt) * 64);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) trow[r] = tbase + rtab[16 * rtp + 4 * g + r];
@@ -321,7 +407,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
                 for (int r = 0; r < 4; ++r) trow[r][c * 16] = acc[c][r];
         }
     } else {
-        const int row0 = T[16];
+        const int row0 = T[8];
 #pragma unroll
         for (int rt = 0; rt < RTM; ++rt) {
             float* __restrict__ t0[4];
@@ -338,13 +424,14 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
                 for (int c = 0; c < NCW; ++c) t0[r][c * 16] = told[r][c] + mid[rt][c][r];
         }
     }
+    WD_T(5);                                                    // scale + GEMM2 + write-back
 #undef WD_NK2_OK
 }
 
-#define WD_CASE(NCWv, RTMv) case (NCWv * 8 + RTMv): wd_task_compute<NCWv, RTMv>(A, Ly, g_W, T, lds, lane, pl); break;
+#define WD_CASE(NCWv, RTMv) case (NCWv * 8 + RTMv): wd_task_compute<NCWv, RTMv>(A, Ly, g_W, T, lds, lane, pl WD_PROF_PASS); break;
 
 __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const WdLay Ly, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
-                                                           const int* __restrict__ g_pools, const int* __restrict__ g_chains, const int* __restrict__ g_tasks,
+                                                           const int* __restrict__ g_streams, const int* __restrict__ g_recs,
                                                            const float* __restrict__ g_W, const int* __restrict__ g_rowtab) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = WD_NW, NT = WD_NT;
@@ -355,71 +442,92 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
     const int64_t eslot = valid ? e : A.rows - 1;
     const int64_t erow = A.eperm ? A.eperm[eslot] : eslot;      // the edge whose rows this slot reads (receiver-major launches: hamgnn_amd/topo.py)
     float* __restrict__ stage = lds + A.stage_off;
+#ifdef HG_PROF
+    ProfWd prof;
+    for (int k = 0; k < 12; ++k) prof.t[k] = 0;
+    prof.last = __builtin_readcyclecounter();
+    const unsigned long long t_begin = prof.last;
+#endif
 
     for (int i = threadIdx.x; i < A.rowtab_off; i += NT) lds[i] = 0.f;                    // all segment tiles + the trash row
     {
         int* __restrict__ rt_l = reinterpret_cast<int*>(lds + A.rowtab_off);
         for (int i = threadIdx.x; i < A.rowtab_len; i += NT) rt_l[i] = g_rowtab[i];
         int* __restrict__ fl = reinterpret_cast<int*>(lds + Ly.flag_off);
-        for (int i = threadIdx.x; i < Ly.nflag + 64; i += NT) fl[i] = 0;                  // S-ready flags, then the pools' claim counters (A.ctr_off = flag_off + nflag)
+        for (int i = threadIdx.x; i < Ly.nflag; i += NT) fl[i] = 0;                       // S-ready flags
     }
     __syncthreads();
+    WD_TL(8);                                                   // zero fill
     const int npool = A.nphase + 1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // (uniform by construction; says so to the compiler: the records travel in SGPRs)
     for (int pl = 0; pl < npool; ++pl) {
-        const int t0 = g_pools[2 * pl], t1 = g_pools[2 * pl + 1];
-        int* __restrict__ ctr = reinterpret_cast<int*>(lds + A.ctr_off) + pl;
-        while (true) {
-            int ci = 0;
-            if (lane == 0) ci = atomicAdd(ctr, 1);
-            ci = __builtin_amdgcn_readfirstlane(ci) + t0;
-            if (ci >= t1) break;
-            // a chain = the records one wave runs back to back: one staging share, one S task, or all items of one (phase, output segment key)
-            // restricted to a window of columns -- the tile cells of that window belong to this wave until the phase's barrier
-            const int r0 = g_chains[2 * ci], r1 = g_chains[2 * ci + 1];
+        // this wave's records of the pool: [S tasks | compute chains | staging shares of the next phase], back to back; the next record is requested
+        // (one s_load_dwordx16) before the current one runs
+        const int r0 = g_streams[2 * (pl * NW + wave_u)], r1 = g_streams[2 * (pl * NW + wave_u) + 1];
+        const wd_rec_t* __restrict__ recs = reinterpret_cast<const wd_rec_t*>(g_recs);
+        wd_rec_t T = recs[r0 < r1 ? r0 : 0];
 #pragma unroll 1
-            for (int ri = r0; ri < r1; ++ri) {
-                const int* __restrict__ T = g_tasks + ri * WD_TASK_I32;
-                const int kind = T[0];
-                if (kind == 0) {                               // a share of one input block of the next phase -> the other staging buffer
-                    const int* __restrict__ B = g_blocks + T[1] * 8;
-                    float* __restrict__ sbuf = stage + T[5] * Ly.stage_floats;
-                    switch (T[4]) {
-                        case 0: wd_stage<0>(A, B, sbuf, erow, T[2], T[3], lane); break;
-                        case 1: wd_stage<1>(A, B, sbuf, erow, T[2], T[3], lane); break;
-                        case 2: wd_stage<2>(A, B, sbuf, erow, T[2], T[3], lane); break;
-                        case 3: wd_stage<3>(A, B, sbuf, erow, T[2], T[3], lane); break;
-                        case 4: wd_stage<4>(A, B, sbuf, erow, T[2], T[3], lane); break;
-                        case 5: wd_stage<5>(A, B, sbuf, erow, T[2], T[3], lane); break;
-                        case 6: wd_stage<6>(A, B, sbuf, erow, T[2], T[3], lane); break;
-                        default: break;
-                    }
-                } else if (kind == 1) {
-                    switch (T[2]) {
-                        case 1: wd_task_S<1>(A, Ly, g_W, T, lds, erow, lane, pl); break;
-                        case 2: wd_task_S<2>(A, Ly, g_W, T, lds, erow, lane, pl); break;
-                        case 3: wd_task_S<3>(A, Ly, g_W, T, lds, erow, lane, pl); break;
-                        default: wd_task_S<4>(A, Ly, g_W, T, lds, erow, lane, pl); break;
-                    }
-                } else {
-                    switch (T[15] * 8 + T[9]) {
-                        WD_CASE(1, 1) WD_CASE(1, 2) WD_CASE(1, 3) WD_CASE(1, 4)
-                        WD_CASE(2, 1) WD_CASE(2, 2) WD_CASE(2, 3) WD_CASE(2, 4)
-                        WD_CASE(3, 1) WD_CASE(3, 2) WD_CASE(3, 3)
-                        WD_CASE(4, 1) WD_CASE(4, 2)
-                        WD_CASE(5, 1) WD_CASE(5, 2)
-                        WD_CASE(6, 1)
-                        WD_CASE(7, 1)
-                        default: break;
-                    }
+        for (int ri = r0; ri < r1; ++ri) {
+            const wd_rec_t Tn = recs[ri + 1 < r1 ? ri + 1 : ri];
+            const int kind = WD_KIND(T);
+            WD_T(0);                                            // record
+            if (kind == 0) {                                   // a share of one input block of the next phase -> the other staging buffer
+#ifndef WD_ABL_NOSTAGE                                          // (ablation builds: timing attribution only, wrong results)
+                const int* __restrict__ B = g_blocks + T[1] * 8;
+                float* __restrict__ sbuf = stage + WD_BIT8(T) * Ly.stage_floats;
+                switch (WD_L(T)) {
+                    case 0: wd_stage<0>(A, B, sbuf, erow, T[2], T[3], lane); break;
+                    case 1: wd_stage<1>(A, B, sbuf, erow, T[2], T[3], lane); break;
+                    case 2: wd_stage<2>(A, B, sbuf, erow, T[2], T[3], lane); break;
+                    case 3: wd_stage<3>(A, B, sbuf, erow, T[2], T[3], lane); break;
+                    case 4: wd_stage<4>(A, B, sbuf, erow, T[2], T[3], lane); break;
+                    case 5: wd_stage<5>(A, B, sbuf, erow, T[2], T[3], lane); break;
+                    case 6: wd_stage<6>(A, B, sbuf, erow, T[2], T[3], lane); break;
+                    default: break;
                 }
+#endif
+                WD_T(1);                                        // staging share
+            } else if (kind == 1) {
+#ifdef WD_ABL_NOS
+                if (lane == 0) *(wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16)) = pl;
+#else
+                switch (WD_RTM(T)) {
+                    case 1: wd_task_S<1>(A, Ly, g_W, T, lds, erow, lane, pl); break;
+                    case 2: wd_task_S<2>(A, Ly, g_W, T, lds, erow, lane, pl); break;
+                    case 3: wd_task_S<3>(A, Ly, g_W, T, lds, erow, lane, pl); break;
+                    default: wd_task_S<4>(A, Ly, g_W, T, lds, erow, lane, pl); break;
+                }
+#endif
+                WD_T(2);                                        // S task
+            } else {
+#ifndef WD_ABL_NOCOMPUTE
+                switch (WD_NCW(T) * 8 + WD_RTM(T)) {
+                    WD_CASE(1, 1) WD_CASE(1, 2) WD_CASE(1, 3) WD_CASE(1, 4)
+                    WD_CASE(2, 1) WD_CASE(2, 2) WD_CASE(2, 3) WD_CASE(2, 4)
+                    WD_CASE(3, 1) WD_CASE(3, 2) WD_CASE(3, 3)
+                    WD_CASE(4, 1) WD_CASE(4, 2)
+                    WD_CASE(5, 1) WD_CASE(5, 2)
+                    WD_CASE(6, 1)
+                    WD_CASE(7, 1)
+                    default: break;
+                }
+#endif
             }
+            T = Tn;
         }
+        WD_TL(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA of the next phase's rows has landed
+#ifndef WD_ABL_NOBAR
         __syncthreads();
+#endif
+        WD_TL(6);                                               // waiting for the slowest wave of the pool
     }
 
     // ---------------------------------------------------------------- epilogue (as tp_is.hip): all waves on one segment at a time; the Wigner
     // blocks of a batch of segments are staged together by LDS-DMA into staging buffer 0
+#ifdef WD_ABL_NOEPI
+    return;
+#endif
     IsScan scan;
     scan.last = true, scan.row = 0;
     if (A.run_id) scan = is_scan_setup(valid ? A.run_id[e] : -1 - (int)(lane & 15), lane & 15);
@@ -461,19 +569,38 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
             default: break;
         }
     }
+    WD_TL(7);                                                   // epilogue
+#ifdef HG_PROF
+    if (lane == 0) {
+        for (int k = 0; k < 12; ++k) atomicAdd(&hg_prof_wd_acc[k], prof.t[k]);
+        atomicAdd(&hg_prof_wd_acc[15], prof.last - t_begin);
+    }
+#endif
 }
+
+#ifdef HG_PROF
+extern "C" int hg_prof_wd_read(unsigned long long* out16, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out16, HIP_SYMBOL(hg_prof_wd_acc), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long z[16] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(hg_prof_wd_acc), z, sizeof(z));
+    }
+    return 0;
+}
+#endif
 
 // lay_host, int32[12] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off, lds_floats}
 extern "C" int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge, int hidden,
                           const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table, const int32_t* block_table,
-                          const int32_t* pool_table, const int32_t* chain_table, const int32_t* task_table, const int32_t* row_table, const int32_t* lay_host,
+                          const int32_t* stream_table, const int32_t* rec_table, const int32_t* row_table, const int32_t* lay_host,
                           const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
                           int64_t rows, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (rows <= 0) return 0;
     if (nsrc < 1 || nsrc > 4) return hg_fail(-2, "hg_tp_wide: nsrc must be 1..4");
     if (hidden < 0 || hidden > 64 || (hidden & 15)) return hg_fail(-2, "hg_tp_wide: the (padded) hidden width of the radial MLP must be 0, 16, 32, 48 or 64");
-    if (!lay_host || !row_table || !pool_table || !chain_table || !task_table) return hg_fail(-2, "hg_tp_wide: missing table");
+    if (!lay_host || !row_table || !stream_table || !rec_table) return hg_fail(-2, "hg_tp_wide: missing table");
     const int32_t* q = lay_host;
     const int lds_bytes = 4 * q[11];
     if (lds_bytes <= 0 || lds_bytes > 160 * 1024) return hg_fail(-2, "hg_tp_wide: bad LDS size");
@@ -505,7 +632,7 @@ extern "C" int hg_tp_wide(const float* const* src, const int64_t* src_stride, in
     static unsigned char lds_attr_done[HG_MAX_DEVICES];
     if (int rc = hg_lds_attr_once(lds_attr_done, dev_guard.dev, (const void*)tp_wide_kernel, 160 * 1024)) return rc;
     const unsigned grid = (unsigned)((rows + 15) / 16);
-    hipLaunchKernelGGL(tp_wide_kernel, dim3(grid), dim3(WD_NT), lds_bytes, (hipStream_t)stream, A, Ly, seg_table, block_table, pool_table, chain_table, task_table,
+    hipLaunchKernelGGL(tp_wide_kernel, dim3(grid), dim3(WD_NT), lds_bytes, (hipStream_t)stream, A, Ly, seg_table, block_table, stream_table, rec_table,
                        weights, row_table);
     return hg_check_launch("hg_tp_wide");
 }

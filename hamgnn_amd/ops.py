@@ -48,7 +48,8 @@ def _require_gpu(t: torch.Tensor):
         raise RuntimeError("hamgnn_amd: the MI355X hot path needs CUDA(ROCm) tensors; there is no CPU fallback")
 
 
-WIDE_MODE = os.environ.get("HG_MP_WIDE", "1")             # "0": never, "1": launches with >= WIDE_MIN_TILES 16-edge tiles, "force": whenever the program has a wide form
+# the wide schedule (csrc/tp_wide.hip, r5) is an opt-in experiment: measured 8.5 ms against hg_tp_is's 6.8 ms per 131 072-edge set-A launch (profiles/r05_tp_wide.md)
+WIDE_MODE = os.environ.get("HG_MP_WIDE", "0")             # "0": never (default), "1": launches with >= WIDE_MIN_TILES 16-edge tiles, "force": whenever the program has a wide form
 WIDE_MIN_TILES = int(os.environ.get("HG_WIDE_MIN_TILES", "512"))
 
 
@@ -112,7 +113,7 @@ class DeviceProgram:
                 lay = ws.lay
                 host = np.ascontiguousarray(np.asarray([ws.seg_table.shape[0], ws.nphase, lay["trash_off"], lay["rowtab_off"], len(ws.rowtab), lay["stage_off"],
                                                         lay["stage_floats"], lay["sbuf_off"], lay["sbuf_slots"], lay["flag_off"], lay["ctr_off"], lay["lds_floats"]], np.int32))
-                self._wide = (ws, tuple(_dev(t, self._device) for t in (ws.seg_table, ws.block_table, ws.pool_table, ws.chain_table, ws.task_table, ws.rowtab)), host)
+                self._wide = (ws, tuple(_dev(t, self._device) for t in (ws.seg_table, ws.block_table, ws.stream_table, ws.rec_table, ws.rowtab)), host)
             except NotImplementedError:
                 self._wide = False
         return self._wide or None
@@ -425,11 +426,11 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     if dp.sched is not None and dp.use_wide(rows, gather, res):
-        ws, (t_segs, t_blocks, t_pools, t_chains, t_tasks, t_rowtab), lay_host = dp.wide_tables()
+        ws, (t_segs, t_blocks, t_streams, t_recs, t_rowtab), lay_host = dp.wide_tables()
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
         check(lib().hg_tp_wide(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.wide_weights()), ptr(t_segs), ptr(t_blocks),
-                               ptr(t_pools), ptr(t_chains), ptr(t_tasks), ptr(t_rowtab), lay_host.ctypes.data_as(C.c_void_p), gp, i32(rot_mask),
+                               ptr(t_streams), ptr(t_recs), ptr(t_rowtab), lay_host.ctypes.data_as(C.c_void_p), gp, i32(rot_mask),
                                ptr(reduce[0]) if reduce is not None else C.c_void_p(0), ptr(reduce[1]) if reduce is not None else C.c_void_p(0),
                                ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_wide")
     elif dp.sched is not None:

@@ -373,11 +373,15 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
 # A compute task waits for its item's S through a flag in LDS (its producer was claimed earlier in the same list and never waits: no deadlock).
 WIDE_WAVES = int(os.environ.get("HG_WIDE_WAVES", "16"))   # = WD_NW of csrc/tp_wide.hip
 WIDE_LDS_BYTES = 160 * 1024
-WIDE_TASK_I32 = 32
+WIDE_TASK_I32 = 32                                        # logical record (planner, emulator)
+WIDE_REC_I32 = 16                                         # packed device record: ONE s_load_dwordx16 (wide_pack_record)
 WT_STAGE, WT_S, WT_COMPUTE = 0, 1, 2
+WIDE_COST_REC = float(os.environ.get("HG_WIDE_COST_REC", "24"))      # cost model of the static streams, in MFMA slots: per record,
+WIDE_COST_STAGE = float(os.environ.get("HG_WIDE_COST_STAGE", "60"))  # per staging share (latency-bound: gathered node rows)
+WIDE_STAGE_POS = os.environ.get("HG_WIDE_STAGE_POS", "end")          # where a wave's staging shares sit in its stream: "end" (under the other waves' compute tails) / "begin"
 WIDE_ACC_CAP = int(os.environ.get("HG_WIDE_ACC_CAP", "10"))    # accumulator fragments (row tiles x columns) of a compute task: 40 VGPRs
 WIDE_NCW_MAX = 7                                          # column-window instantiations of csrc/tp_wide.hip (WD_CASE)
-WIDE_TASKS_PER_WAVE = float(os.environ.get("HG_WIDE_TPW", "2.5"))   # compute tasks per wave and phase the splitting aims for
+WIDE_TASKS_PER_WAVE = float(os.environ.get("HG_WIDE_TPW", "1.0"))   # compute tasks per wave and phase the splitting aims for
 WIDE_FLAGS = 128                                          # S-ready flags (items of one phase)
 
 
@@ -390,9 +394,12 @@ class WideSchedule:
     seg_table: np.ndarray          # as IsSchedule.seg_table (epilogue)
     block_table: np.ndarray        # as IsSchedule.block_table (stage offsets relative to a staging buffer)
     phase_blocks: np.ndarray       # int32[nphase][2] = {block_begin, block_end}
-    pool_table: np.ndarray         # int32[nphase + 1][2] = {chain_begin, chain_end}: pool 0 = the staging tasks of phase 0 (prologue), pool ph + 1 = pool(ph) above
-    chain_table: np.ndarray        # int32[nchain][2] = {record_begin, record_end}: what a wave claims; staging shares and S tasks are chains of one record
-    task_table: np.ndarray         # int32[nrec][32], see wide_schedule
+    stream_table: np.ndarray       # int32[nphase + 1][WIDE_WAVES][2] = {record_begin, record_end}: the records wave w runs in pool p, back to back (static LPT deal:
+    #                                the wave knows its next record's address, so records and first fragments are requested ahead).  Pool 0 = the staging shares
+    #                                of phase 0 (prologue), pool ph + 1 = [S tasks of ph | compute chains of ph | staging shares of ph + 1] per wave
+    chain_table: np.ndarray        # int32[nchain][3] = {record_begin, record_end, pool}: a staging share, an S task, or a compute chain (records of one wave)
+    task_table: np.ndarray         # int32[nrec][32] logical records, see wide_schedule
+    rec_table: np.ndarray          # int32[nrec][16] the same records packed for the device (wide_pack_record)
     item_table: np.ndarray         # the IS item records the tasks were cut from (emulator / tests)
     rowtab: np.ndarray
     extra_weights: np.ndarray      # per-task packed CG coefficient blocks, appended to Program.weights on the device
@@ -430,13 +437,69 @@ def _wide_group_windows(recs, col_cost, target: float) -> List[Tuple[int, int]]:
     return out
 
 
+def wide_pack_record(rec) -> List[int]:
+    """logical record (32 ints, see wide_schedule) -> the 16 ints the kernel reads with one scalar load:
+    w0 = kind | rtm << 2 | ncw << 5 | (typ / radial generator / staging buffer) << 8 | x4 << 9 | neg << 10 | l << 11 | mm << 14 | rto << 17 | nk2 << 21 | c0 << 26
+    w1 = stage offset of source 0 / block / W3 fragments   w2 = stage offset of source 1 (-1) / share   w3 = in_mulp | ksteps << 16 / shares
+    w4 = A1 fragments   w5 = packed coefficients   w6 = A2 fragments   w7 = first S slot | flag << 16   w8 = first output row (IT_LIN)   w9 = row-table base"""
+    kind = int(rec[0])
+    w = [0] * WIDE_REC_I32
+    if kind == WT_STAGE:
+        w[0] = kind | (int(rec[5]) << 8) | (int(rec[4]) << 11)
+        w[1], w[2], w[3] = int(rec[1]), int(rec[2]), int(rec[3])
+    elif kind == WT_S:
+        assert 1 <= int(rec[2]) <= 4 and int(rec[4]) < (1 << 16) and int(rec[5]) < (1 << 15)
+        w[0] = kind | (int(rec[2]) << 2) | (int(rec[3]) << 8)
+        w[1] = int(rec[1])
+        w[7] = int(rec[4]) | (int(rec[5]) << 16)
+    else:
+        rtm, ncw, typ, x4, neg, li, mm, rto, nk2, c0 = (int(rec[k]) for k in (9, 15, 19, 17, 7, 5, 6, 22, 18, 13))
+        assert 1 <= rtm <= 4 and 1 <= ncw <= 7 and typ in (0, 1) and li < 8 and mm < 8 and rto < 16 and nk2 < 32 and c0 < 16
+        w[0] = kind | (rtm << 2) | (ncw << 5) | (typ << 8) | ((1 if x4 else 0) << 9) | ((1 if neg else 0) << 10) | (li << 11) | (mm << 14) | (rto << 17) | (nk2 << 21) | (c0 << 26)
+        assert int(rec[4]) < (1 << 16) and int(rec[8]) < (1 << 15)
+        w[1], w[2], w[3] = int(rec[1]), int(rec[2]), int(rec[4]) | (int(rec[8]) << 16)
+        w[4], w[5], w[6] = int(rec[11]), int(rec[12]), int(rec[14])
+        slot = int(rec[3]) if int(rec[3]) >= 0 else 0
+        assert slot < (1 << 16) and int(rec[10]) < (1 << 15)
+        w[7] = slot | (int(rec[10]) << 16)
+        w[8], w[9] = int(rec[16]), int(rec[23])
+    assert all(-(1 << 31) <= v < (1 << 31) for v in w)
+    return w
+
+
+def wide_unpack_record(w) -> List[int]:
+    """inverse of wide_pack_record (tests: the device format carries every field the emulator's logical record has)"""
+    w = [int(v) for v in w]
+    kind = w[0] & 3
+    rec = [0] * WIDE_TASK_I32
+    rec[0] = kind
+    if kind == WT_STAGE:
+        rec[1], rec[2], rec[3], rec[4], rec[5] = w[1], w[2], w[3], (w[0] >> 11) & 7, (w[0] >> 8) & 1
+    elif kind == WT_S:
+        rec[1], rec[2], rec[3], rec[4], rec[5] = w[1], (w[0] >> 2) & 7, (w[0] >> 8) & 1, w[7] & 0xffff, w[7] >> 16
+    else:
+        rec[9], rec[15], rec[19], rec[17], rec[7] = (w[0] >> 2) & 7, (w[0] >> 5) & 7, (w[0] >> 8) & 1, (w[0] >> 9) & 1, (w[0] >> 10) & 1
+        rec[5], rec[6], rec[22], rec[18], rec[13] = (w[0] >> 11) & 7, (w[0] >> 14) & 7, (w[0] >> 17) & 15, (w[0] >> 21) & 31, (w[0] >> 26) & 15
+        rec[1], rec[2], rec[4], rec[8] = w[1], w[2], w[3] & 0xffff, w[3] >> 16
+        rec[11], rec[12], rec[14] = w[4], w[5], w[6]
+        rec[3], rec[10] = (w[7] & 0xffff) if rec[19] == IT_TP else -1, w[7] >> 16
+        rec[16], rec[23] = w[8], w[9]
+    return rec
+
+
 def wide_schedule(prog: "Program") -> WideSchedule:
-    """Cut a finalized tensor-product program into the task pools of csrc/tp_wide.hip.  Raises NotImplementedError when the program has no wide form
-    (lite_mode items, tiles + two staging buffers + a useful S buffer beyond the CU's LDS).
+    """Cut a finalized tensor-product program into the per-wave record streams of csrc/tp_wide.hip.  Raises NotImplementedError when the program has no wide
+    form (lite_mode items, tiles + two staging buffers + a useful S buffer beyond the CU's LDS).
     A tile cell (row of an output segment, column m) may be updated by ONE wave per phase (read-modify-write in LDS), and several items of a phase feed the
     same segment: the unit of compute work is therefore a CHAIN = all items of one (phase, segment key) restricted to a window of columns m, run one after
-    the other by the wave that claims it.  An item whose share of the window exceeds the register budget (wide_ncw_cap), or straddles the centre column an
-    odd item skips, appears as several records of the chain."""
+    the other by one wave.  An item whose share of the window exceeds the register budget (wide_ncw_cap), or straddles the centre column an odd item
+    skips, appears as several records of the chain.  The chains, S tasks and staging shares of a pool are dealt to the waves by LPT on a cost model (MFMAs
+    + WIDE_COST_REC per record; WIDE_COST_STAGE per staging share); a wave's stream is [its S tasks | its compute chains | its staging shares of the next
+    phase]: S tasks never wait, so a compute record that waits for another wave's S fragments cannot deadlock.
+    Logical record (int32[32]), [0] = kind.  WT_STAGE: [1] block, [2] share, [3] shares, [4] l of the block, [5] staging buffer.  WT_S: [1] float offset of
+    the item's W3 fragments, [2] row tiles, [3] radial generator, [4] first S slot, [5] flag.  WT_COMPUTE: the item's record fields at their IS positions
+    ([1], [2] stage offsets incl. the buffer, [4..9], [11], [14], [16..18], [22], [23]) and [3] first S slot, [10] flag, [12] float offset of the record's
+    packed CG coefficients, [13] first real column, [15] columns, [19] item type."""
     hp4 = prog.hidden_pad // 4
     if np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST, IT_STREAM)).any():
         raise NotImplementedError("wide schedule: lite_mode programs run on the input-stationary kernel")
@@ -470,11 +533,10 @@ def wide_schedule(prog: "Program") -> WideSchedule:
     extra: List[np.ndarray] = []
     xbase = int(wts.size)
     xoff = 0
-    tasks: List[List[int]] = []
-    chains: List[List[int]] = []
-    pools: List[List[int]] = []
+    W = WIDE_WAVES
 
-    def stage_chains(ph: int):
+    def stage_units(ph: int):
+        out = []
         b0, b1 = int(ptab[ph][0]), int(ptab[ph][1])
         for b in range(b0, b1):
             s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in sub["btab"][b])
@@ -485,8 +547,8 @@ def wide_schedule(prog: "Program") -> WideSchedule:
             for t in range(nsub):
                 rec = [0] * WIDE_TASK_I32
                 rec[0], rec[1], rec[2], rec[3], rec[4], rec[5] = WT_STAGE, b, t, nsub, li, ph & 1
-                chains.append([len(tasks), len(tasks) + 1])
-                tasks.append(rec)
+                out.append((WIDE_COST_STAGE, [rec]))
+        return out
 
     def col_cost(r):
         nsrc = 2 if int(r[2]) >= 0 else 1
@@ -496,22 +558,45 @@ def wide_schedule(prog: "Program") -> WideSchedule:
         mm = int(r[6])
         return 2 * mm if (int(r[0]) == IT_TP and int(r[7]) and mm > 0) else 2 * mm + 1
 
-    pools.append([len(chains), 0])
-    stage_chains(0)
-    pools[-1][1] = len(chains)
+    tasks: List[List[int]] = []
+    chains: List[List[int]] = []
+    streams: List[List[List[int]]] = []
     tot_cost, crit_cost, mfma_tasks = 0.0, 0.0, 0
+
+    def deal(pool_index: int, s_units, c_units, st_units):
+        """LPT over the waves (largest unit first onto the least loaded wave); a wave's stream = its S tasks, its compute chains (dearest first), its
+        staging shares"""
+        nonlocal tot_cost, crit_cost
+        loads = [0.0] * W
+        mine = [([], [], []) for _ in range(W)]
+        allu = [(c, 0, u) for c, u in s_units] + [(c, 1, u) for c, u in c_units] + [(c, 2, u) for c, u in st_units]
+        for c, cls, u in sorted(allu, key=lambda t: -t[0]):
+            w = loads.index(min(loads))
+            loads[w] += c
+            mine[w][cls].append((c, u))
+        row = []
+        for w in range(W):
+            r0 = len(tasks)
+            order = (mine[w][2] + mine[w][0] + mine[w][1]) if WIDE_STAGE_POS == "begin" else (mine[w][0] + mine[w][1] + mine[w][2])
+            for c, u in order:
+                chains.append([len(tasks), len(tasks) + len(u), pool_index])
+                tasks.extend(u)
+            row.append([r0, len(tasks)])
+        streams.append(row)
+        if pool_index > 0:
+            tot_cost += sum(loads)
+            crit_cost += max(loads)
+
+    deal(0, [], [], stage_units(0))
     for ph in range(nphase):
         g0, g1 = int(ptab[ph][2]), int(ptab[ph][3])
         groups = [[items[i] for i in range(int(gtab[gi][0]), int(gtab[gi][1]))] for gi in range(g0, g1)]
         nrec = sum(len(g) for g in groups)
         if nrec > WIDE_FLAGS:
             raise NotImplementedError("wide schedule: more items in one phase than S-ready flags")
-        pool = [len(chains), 0]
-        if ph + 1 < nphase:
-            stage_chains(ph + 1)
-        ctot = sum(col_cost(r) * ncols(r) + 40 for g in groups for r in g)
-        target = max(ctot / (WIDE_WAVES * WIDE_TASKS_PER_WAVE), 48.0)
-        s_tasks, c_chains = [], []
+        ctot = sum(col_cost(r) * ncols(r) + WIDE_COST_REC for g in groups for r in g)
+        target = max(ctot / (W * WIDE_TASKS_PER_WAVE), 48.0)
+        s_units, c_units = [], []
         slot, fi = 0, 0
         for recs in groups:
             info = []
@@ -523,7 +608,7 @@ def wide_schedule(prog: "Program") -> WideSchedule:
                     slot += rtm
                     rec = [0] * WIDE_TASK_I32
                     rec[0], rec[1], rec[2], rec[3], rec[4], rec[5] = WT_S, int(r[12]), rtm, int(r[10]), my_slot, fi
-                    s_tasks.append((col_cost(r) * ncols(r), rec))
+                    s_units.append((hp4 * rtm + WIDE_COST_REC, [rec]))
                     mfma_tasks += hp4 * rtm
                 info.append((r, my_slot, fi))
                 fi += 1
@@ -537,14 +622,14 @@ def wide_schedule(prog: "Program") -> WideSchedule:
                         continue
                     runs = [(lo, hi)]
                     if odd and lo <= 0 <= hi:                  # the centre column of an odd item is structurally zero: not computed
-                        runs = [(a, b) for a, b in ((lo, -1), (1, hi)) if a <= b]
+                        runs = [(a_, b_) for a_, b_ in ((lo, -1), (1, hi)) if a_ <= b_]
                     cap = wide_ncw_cap(rtm)
                     cfull = wts[int(r[13]):int(r[13]) + rtm * (2 * mm + 1) * 16].reshape(rtm, 2 * mm + 1, 4, 4) if typ == IT_TP else None   # [rt][c][g][r]
-                    for a, b in runs:
-                        n = b - a + 1
+                    for a_, b_ in runs:
+                        n = b_ - a_ + 1
                         k = ceil_div(n, cap)
                         base_n, rem = divmod(n, k)
-                        o = a
+                        o = a_
                         for j in range(k):
                             ncw = base_n + (1 if j < rem else 0)
                             c0 = o + mm                        # first real column of the record
@@ -568,33 +653,20 @@ def wide_schedule(prog: "Program") -> WideSchedule:
                                 xoff += 256
                             cc = col_cost(r) * ncw
                             mfma_tasks += cc
-                            ccost += cc + 40
+                            ccost += cc + WIDE_COST_REC
                             chain.append(rec)
                 if chain:
-                    c_chains.append((ccost, chain))
+                    c_units.append((ccost, chain))
         assert slot <= slots
-        s_tasks.sort(key=lambda t: -t[0])
-        c_chains.sort(key=lambda t: -t[0])
-        for _, rec in s_tasks:
-            chains.append([len(tasks), len(tasks) + 1])
-            tasks.append(rec)
-        for _, ch in c_chains:
-            chains.append([len(tasks), len(tasks) + len(ch)])
-            tasks += ch
-        pool[1] = len(chains)
-        pools.append(pool)
-        loads = [0.0] * WIDE_WAVES
-        for c in [hp4 * t[1][2] + 40 for t in s_tasks] + [t[0] for t in c_chains]:
-            loads[loads.index(min(loads))] += c
-        tot_cost += sum(loads)
-        crit_cost += max(loads)
+        deal(ph + 1, s_units, c_units, stage_units(ph + 1) if ph + 1 < nphase else [])
+    tasks_np = np.asarray(tasks, np.int32).reshape(-1, WIDE_TASK_I32)
     return WideSchedule(seg_table=sub["segs"], block_table=np.asarray(sub["btab"], np.int32).reshape(-1, IS_BLOCK_I32),
                         phase_blocks=np.asarray([[int(p[0]), int(p[1])] for p in ptab], np.int32).reshape(-1, 2),
-                        pool_table=np.asarray(pools, np.int32).reshape(-1, 2), chain_table=np.asarray(chains, np.int32).reshape(-1, 2),
-                        task_table=np.asarray(tasks, np.int32).reshape(-1, WIDE_TASK_I32),
+                        stream_table=np.asarray(streams, np.int32).reshape(nphase + 1, W, 2), chain_table=np.asarray(chains, np.int32).reshape(-1, 3),
+                        task_table=tasks_np, rec_table=np.asarray([wide_pack_record(t) for t in tasks], np.int32).reshape(-1, WIDE_REC_I32),
                         item_table=np.asarray(items, np.int32).reshape(-1, IS_ITEM_I32), rowtab=np.asarray(sub["rowtab"], np.int32),
                         extra_weights=(np.concatenate(extra) if extra else np.zeros(4, wts.dtype)), lay=lay, nphase=nphase,
-                        balance=tot_cost / (WIDE_WAVES * crit_cost) if crit_cost else 1.0, crit=crit_cost, mfma_tasks=int(mfma_tasks))
+                        balance=tot_cost / (W * crit_cost) if crit_cost else 1.0, crit=crit_cost, mfma_tasks=int(mfma_tasks))
 
 
 def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool):

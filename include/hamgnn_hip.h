@@ -131,23 +131,25 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
 /* The same whole MessagePackBlock.forward as hg_tp_is (hamgnn/nn/message_passing.py:191-231 incl. the node gathers of convolution.py:138-141 /
  * interaction_blocks.py:141-145 and, with run_id, the receiver scatter convolution.py:147-149), on the WIDE schedule (csrc/tp_wide.hip, r5; plan.py:
  * wide_schedule): ONE workgroup of 16 waves per 16-edge tile owns the CU's LDS -- output tiles, two staging buffers, a buffer of radial-scale
- * fragments and their ready flags -- and claims the tasks of a phase from one ordered list (pool): staging shares of the NEXT phase's input
- * blocks, one radial-scale ("S") task per item, column-window compute tasks (GEMM1 -> scale -> GEMM2 on 1..7 columns of an item).  Single-part,
- * non-lite programs with a 64-wide radial hidden layer only; same `weights` blob as hg_tp_is with the schedule's packed coefficient blocks appended.
+ * fragments and their ready flags.  The work of a phase is dealt to the 16 waves by the host planner (static LPT): staging shares of the NEXT
+ * phase's input blocks, one radial-scale ("S") task per item, compute chains (all items of one (phase, output segment) on a window of columns:
+ * GEMM1 -> scale -> GEMM2 on 1..7 columns of an item per record; a tile cell is updated by one wave per phase).  Single-part, non-lite programs with
+ * radial hidden layers up to 64 wide only; same `weights` blob as hg_tp_is with the schedule's packed coefficient blocks appended.
  *   seg_table, block_table, row_table: as for hg_tp_is (one part)
- *   pool_table  int32[nphase + 1][2] = {chain_begin, chain_end}: pool 0 = staging of phase 0, pool p + 1 = [staging of p + 1 | S of p | compute of p]
- *   chain_table int32[nchain][2] = {record_begin, record_end}: the records one wave runs back to back (a staging share, an S task, or every item of
- *               one (phase, output segment) restricted to a window of columns: a tile cell is updated by one wave per phase)
- *   task_table  int32[nrec][32]: [0] = kind.  0 (staging): [1] block, [2] share, [3] shares, [4] l of the block, [5] staging buffer (0 / 1);
- *               1 (S): [1] float offset of the item's W3 fragments, [2] row tiles, [3] radial generator (0 node / 1 edge), [4] first S slot, [5] flag;
- *               2 (compute): the item's record fields at their hg_tp_is positions ([1], [2] stage offsets incl. the buffer, [4..9], [11], [14], [16..18],
- *               [22], [23]) and [3] first S slot, [10] flag, [12] float offset of the window's packed CG coefficients, [13] first real column,
- *               [15] columns of the window, [19] item type (0 tensor product, 1 plain Linear)
+ *   stream_table int32[nphase + 1][16][2] = {record_begin, record_end}: the records wave w runs in pool p back to back; pool 0 = staging of phase 0,
+ *               pool p + 1 = [S tasks of p | compute chains of p | staging shares of p + 1] per wave
+ *   rec_table   int32[nrec][16], one 64-byte record (plan.wide_pack_record):
+ *               w0 = kind | rtm << 2 | ncw << 5 | (item type / radial generator / staging buffer) << 8 | x4 << 9 | neg << 10 | l << 11 | mm << 14 |
+ *                    rto << 17 | nk2 << 21 | c0 << 26        kind 0 = staging share, 1 = S task, 2 = compute record
+ *               w1 = stage offset of source 0 (incl. the buffer) / block / float offset of the item's W3 fragments
+ *               w2 = stage offset of source 1 (-1) / share        w3 = in_mulp | ksteps << 16 / shares
+ *               w4, w5, w6 = float offsets of the A1 fragments, the record's packed CG coefficients, the A2 fragments
+ *               w7 = first S slot | flag << 16    w8 = first output row (plain Linear items)    w9 = first row-table entry of GEMM2's rows
  *   lay_host    HOST int32[12] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off,
  *               lds_floats}: float offsets inside the workgroup's LDS (validated)                                                              */
 int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge, int hidden,
                const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table, const int32_t* block_table,
-               const int32_t* pool_table, const int32_t* chain_table, const int32_t* task_table, const int32_t* row_table, const int32_t* lay_host,
+               const int32_t* stream_table, const int32_t* rec_table, const int32_t* row_table, const int32_t* lay_host,
                const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
                int64_t rows, void* stream);
 

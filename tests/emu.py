@@ -376,10 +376,18 @@ def run_program_wide(prog, ws, srcs, h2=(None, None), D=None, lmax=None, dtype=n
     assert lay["trash_off"] == tile_floats and lay["rowtab_off"] == tile_floats + maxstride and lay["stage_off"] == lay["rowtab_off"] + len(ws.rowtab)
     assert lay["stage_off"] % 4 == 0 and lay["sbuf_off"] == lay["stage_off"] + 2 * sf and lay["flag_off"] == lay["sbuf_off"] + 256 * slots
     assert lay["ctr_off"] == lay["flag_off"] + P.WIDE_FLAGS and lay["lds_floats"] == lay["ctr_off"] + 64 and lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES
-    assert ws.pool_table.shape[0] == ws.nphase + 1 <= 64 and ws.pool_table[0][0] == 0 and ws.pool_table[-1][1] == ws.chain_table.shape[0]
-    assert all(int(ws.pool_table[k][1]) == int(ws.pool_table[k + 1][0]) for k in range(ws.nphase))
-    assert ws.chain_table[0][0] == 0 and ws.chain_table[-1][1] == ws.task_table.shape[0]
-    assert all(int(ws.chain_table[k][1]) == int(ws.chain_table[k + 1][0]) and ws.chain_table[k][0] < ws.chain_table[k][1] for k in range(ws.chain_table.shape[0] - 1))
+    W = P.WIDE_WAVES
+    assert ws.stream_table.shape == (ws.nphase + 1, W, 2) and ws.nphase + 1 <= 64
+    flat = ws.stream_table.reshape(-1, 2)
+    assert flat[0][0] == 0 and flat[-1][1] == ws.task_table.shape[0] and all(int(flat[k][1]) == int(flat[k + 1][0]) for k in range(flat.shape[0] - 1))
+    assert ws.rec_table.shape == (ws.task_table.shape[0], P.WIDE_REC_I32)
+    used = {P.WT_STAGE: (0, 1, 2, 3, 4, 5), P.WT_S: (0, 1, 2, 3, 4, 5), P.WT_COMPUTE: (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 22, 23)}
+    for t, w in zip(ws.task_table, ws.rec_table):               # the device records carry every field of the logical ones
+        u = P.wide_unpack_record(w)
+        for k in used[int(t[0])]:
+            if int(t[0]) == P.WT_COMPUTE and int(t[19]) != P.IT_TP and k in (3, 12):      # (no S slot / coefficients for plain Linear items)
+                continue
+            assert u[k] == int(t[k]) or (k == 17 and bool(u[k]) == bool(t[k])), (k, t, w)
     tile_of = np.full(tile_floats + maxstride, -1)
     for gi, sgr in enumerate(ws.seg_table):
         tile_of[int(sgr[5]):int(sgr[5]) + int(sgr[1]) * ((2 * int(sgr[0]) + 1) * 16 + 4)] = gi
@@ -396,17 +404,19 @@ def run_program_wide(prog, ws, srcs, h2=(None, None), D=None, lmax=None, dtype=n
         stage = np.full((2, sf), np.nan, dtype=dtype)                                  # NaN = not staged (a read of it poisons the result)
         first_tile = e0 == 0
         for pl in range(ws.nphase + 1):
-            t0, t1 = (int(v) for v in ws.pool_table[pl])
-            chains = [[ws.task_table[t] for t in range(int(ws.chain_table[c][0]), int(ws.chain_table[c][1]))] for c in range(t0, t1)]
-            kinds = [int(ch[0][0]) for ch in chains]
-            assert kinds == sorted(kinds), "pool order: staging shares, S tasks, compute chains"
-            assert all(len({int(t[0]) for t in ch}) == 1 and (len(ch) == 1 or int(ch[0][0]) == P.WT_COMPUTE) for ch in chains)
+            per_wave = [[ws.task_table[t] for t in range(int(ws.stream_table[pl][w][0]), int(ws.stream_table[pl][w][1]))] for w in range(W)]
+            for recs_w in per_wave:                              # deadlock freedom: a wave runs ALL its S tasks before its first compute record (S tasks never wait)
+                ks = [int(t[0]) for t in recs_w if int(t[0]) != P.WT_STAGE]
+                assert ks == sorted(ks)
+            # S tasks and staging shares of all waves first, then the compute records wave by wave (any interleaving that respects the S flags is equivalent)
+            seq = [(w, T) for w, recs_w in enumerate(per_wave) for T in recs_w if int(T[0]) != P.WT_COMPUTE]
+            comp = [(w, T) for w, recs_w in enumerate(per_wave) for T in recs_w if int(T[0]) == P.WT_COMPUTE]
             if order == "reverse_compute":
-                chains = [ch for ch in chains if int(ch[0][0]) != P.WT_COMPUTE] + [ch for ch in chains if int(ch[0][0]) == P.WT_COMPUTE][::-1]
+                comp = [(w, T) for w in reversed(range(W)) for T in per_wave[w] if int(T[0]) == P.WT_COMPUTE]
             ph = pl - 1
             sbuf, flags, cells = {}, set(), {}
             staged_next = {}
-            for chain_id, T in ((ci, T) for ci, ch in enumerate(chains) for T in ch):
+            for chain_id, T in seq + comp:
                 kind = int(T[0])
                 if kind == P.WT_STAGE:
                     b, sub, nsub, li_t, buf = (int(v) for v in T[1:6])
@@ -507,7 +517,7 @@ def run_program_wide(prog, ws, srcs, h2=(None, None), D=None, lmax=None, dtype=n
                                     base = int(rt_[16 * rtp + i_]) + (c0 + j - mm) * 16
                                     assert 0 <= base and base + 16 <= tile_floats + maxstride
                                     if tile_of[base] >= 0:
-                                        assert cells.setdefault(base, chain_id) == chain_id, "a tile cell is updated by one chain (wave) per phase"
+                                        assert cells.setdefault(base, chain_id) == chain_id, "a tile cell is updated by one wave per phase"
                                     lds[base:base + 16] += acc[i_]
                     else:
                         assert typ == P.IT_LIN

@@ -176,7 +176,7 @@ def _message_pack_random_run(m, device, irr, sh, lmax, lsh, n, rbf, src, dst, ef
     torch.cuda.synchronize()
     scale = out.abs().max().item()
     dp = m._dp_for(E)
-    kern = "seg" if dp.sched is None else "is"
+    kern = "seg" if dp.sched is None else ("wide" if dp.use_wide(E, None, ()) else "is")
     return {"irreps": irr, "sh": sh, "kernel": kern, "rel_err": 0.0 if scale < 1e-12 else rel(y, out)}
 
 
@@ -675,6 +675,41 @@ def check_fused_scatter(device="cuda", n_atoms=14, seed=5):
     out["edge_rel_err"] = rel(reps["1"]["edge_attr"], reps["0"]["edge_attr"])
     out["edges_mod_16"] = float(int(g.num_edges) % 16 == 0) * 1e-9
     return out
+
+
+def check_wide_vs_is(device="cuda", E=4099, nodes=301):
+    """one node-fed set-A MessagePackBlock launch (gather + rotation fused, ragged tail) on the wide schedule vs the input-stationary kernel, and the
+    wide launch repeated (bit-identical: the claim order of the chains must not matter)"""
+    import bench
+    from hamgnn_amd import nn as hnn, ops, plan as P
+    irr = bench.IRREPS["A"]
+    torch.manual_seed(0)
+    m = hnn.MessagePackBlock(irr, irr, bench.SH, irr, 64, [64, 64])
+    m.compile(device, unrotate=True)
+    lay = P.PlanarLayout(irr)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    pos = torch.zeros(2, 3, device=device)
+    ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.long)]).to(device)
+    shift = (torch.randn(E, 3, generator=g) * 4).to(device)
+    geo = ops.Geometry(pos, ei, shift, 26.0, 64, 6, torch.from_numpy(P.wigner_jtab(6)).to(device))
+    fe = torch.randn(E, lay.dim, generator=g).to(device)
+    node = torch.randn(nodes, lay.dim, generator=g).to(device)
+    geo.src = torch.randint(0, nodes, (E,), generator=g).to(device)
+    geo.dst = torch.randint(0, nodes, (E,), generator=g).to(device)
+    rot = torch.from_numpy(P.rotate_table(lay)).to(device)
+    old = ops.WIDE_MODE
+    os.environ["HG_IS_PARTS"] = "1"
+    try:
+        ops.WIDE_MODE = "0"
+        a = m.run_nodes(node, node, fe, geo, rot).clone()
+        ops.WIDE_MODE = "force"
+        b = m.run_nodes(node, node, fe, geo, rot).clone()
+        c = m.run_nodes(node, node, fe, geo, rot).clone()
+        torch.cuda.synchronize()
+    finally:
+        ops.WIDE_MODE = old
+        os.environ.pop("HG_IS_PARTS", None)
+    return {"wide_vs_is": rel(b, a), "wide_repeat_max_abs": float((b - c).abs().max()), "nan": float(torch.isnan(b).any())}
 
 
 def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):

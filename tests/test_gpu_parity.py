@@ -59,6 +59,48 @@ def test_message_pack_single_part_vs_oracle(case):
     assert r["kernel"] == "is" and r["rel_err"] < G.TOL
 
 
+@pytest.fixture
+def force_wide(monkeypatch):
+    """every eligible launch (single part, tensor-product program) on the wide schedule (csrc/tp_wide.hip), whatever its size"""
+    from hamgnn_amd import ops
+    monkeypatch.setattr(ops, "WIDE_MODE", "force")
+    monkeypatch.setenv("HG_IS_PARTS", "1")
+
+
+@pytest.mark.parametrize("case", list(range(6)) + ["A", "B"])
+def test_message_pack_wide_schedule_vs_oracle(case, force_wide):
+    """r5: the wide schedule (one 16-wave workgroup per 16-edge tile, S fragments through the LDS, column-window chains, staging shares as tasks)
+    forced on small inputs: random irreps sets with 16- and 64-wide radial layers and the two shipped sets, vs the fp64 oracle"""
+    import bench
+    kw = dict(irr=bench.IRREPS[case], sh=bench.SH, seed=7, E=37, radial=(64, 64)) if isinstance(case, str) else dict(seed=case, radial=(64, 64) if case % 2 else (16, 16))
+    r = G.check_message_pack_random(**kw)
+    print(r)
+    assert r["kernel"] == "wide" and r["rel_err"] < G.TOL
+
+
+def test_backbone_golden_wide_schedule(force_wide):
+    """whole backbone (reference fixture) with every MessagePackBlock launch on the wide schedule: node-fed launches (gather + rotation in the
+    staging shares), the fused receiver scatter in the epilogue, the PairInteractionBlock's skip Linear as IT_LIN chains"""
+    r = G.check_backbone()
+    print(r)
+    assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
+
+
+def test_fused_node_scatter_wide_schedule(force_wide):
+    r = G.check_fused_scatter()
+    print(r)
+    assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6, r
+
+
+def test_wide_schedule_equals_input_stationary_bitwise():
+    """same items, same fragments, one task per tile cell and phase, the tile value as GEMM2's accumulator init in both kernels: the two schedules
+    must agree to the last bit when the order of the items inside a (phase, segment) is the same -- checked to 1e-6 (the phases differ), and the wide
+    launch against itself bit for bit (claim order must not matter)"""
+    r = G.check_wide_vs_is()
+    print(r)
+    assert r["wide_vs_is"] < 2e-6 and r["wide_repeat_max_abs"] == 0.0
+
+
 def test_front_door_checkpoint_and_datasets_reproduce_the_fixtures():
     """SURVEY 8f-1 through the front door: Model.load_from_checkpoint(.ckpt) + NPZGraphDataset / LMDBGraphDataset -> HIP forward == the
     reference's outputs of the backbone and head fixtures (tests/gpu_checks.py:check_front_door).  Files written by real liblmdb / Lightning

@@ -1097,7 +1097,9 @@ def test_wide_schedule_shipped_irreps(which):
     T = ws.task_table
     comp = T[T[:, 0] == P.WT_COMPUTE]
     assert (comp[:, 15] * comp[:, 9] <= P.WIDE_ACC_CAP).all() and (comp[:, 15] <= P.WIDE_NCW_MAX).all()
-    for a, b in ws.pool_table[1:]:
-        heads = T[ws.chain_table[a:b, 0]]
+    for pl in range(1, ws.nphase + 1):
+        heads = T[[int(c[0]) for c in ws.chain_table if int(c[2]) == pl]]
         assert (heads[:, 0] == P.WT_COMPUTE).sum() >= 8                        # compute chains per phase
         assert sum(int(t[2]) for t in heads if int(t[0]) == P.WT_S) <= ws.lay["sbuf_slots"]
+        busy = sum(int(ws.stream_table[pl][w][1]) > int(ws.stream_table[pl][w][0]) for w in range(P.WIDE_WAVES))
+        assert busy >= P.WIDE_WAVES - 2                                        # (nearly) every wave has work in every pool
