@@ -64,7 +64,7 @@ def sym_contraction_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W1: to
         if per_node:
             gW1[sl] = p1
         else:
-            gW1 += ops.scatter_rows(zc, p1, W1.shape[0])
+            gW1 += ops.scatter_rows(zc, p1, W1.shape[0], persistent=False)
         # nu = 2
         t2 = G[:, E["o2"]] * E["v2"][None, :, None].to(dt)        # [n, E2, C]
         hx, hi = H[:, E["x2"]], H[:, E["i2"]]
@@ -75,6 +75,6 @@ def sym_contraction_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W1: to
         if per_node:
             gW2[sl] = p2
         else:
-            gW2 += ops.scatter_rows(zc, p2, W2.shape[0])
+            gW2 += ops.scatter_rows(zc, p2, W2.shape[0], persistent=False)
         g_h[sl].index_add_(1, hcol.reshape(-1), gH.reshape(n, -1))     # (distinct columns: nothing is summed here)
     return g_h, gW1, gW2

@@ -153,7 +153,7 @@ def weight_grads_from_rows(wg, ArowsT: torch.Tensor, BrowsT: torch.Tensor, srcsT
             lay_dim = xcat[name][0].shape[0] // len(xcat[name][1])
             for t, sl in enumerate(xcat[name][1]):                                 # rows of slot t of the concatenated sources
                 sel = (rows >= t * lay_dim) & (rows < (t + 1) * lay_dim)
-                gxT[sl] += _scatter_rows(rows[sel] - t * lay_dim, GX[sel], gxT[sl].shape[0])      # fixed summation order (no float atomics)
+                gxT[sl] += _scatter_rows(rows[sel] - t * lay_dim, GX[sel], gxT[sl].shape[0], persistent=False)      # fixed summation order (no float atomics)
 
 
 class TPWeightGrad:

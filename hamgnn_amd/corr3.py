@@ -64,6 +64,6 @@ def sym3_backward(tab: Dict, h: torch.Tensor, z: torch.Tensor, W3: torch.Tensor,
         if per_node:
             gW3[sl] = p
         else:
-            gW3 += ops.scatter_rows(zc, p, W3.shape[0])
+            gW3 += ops.scatter_rows(zc, p, W3.shape[0], persistent=False)
         g_h[sl] = g_h[sl].index_add(1, hcol.reshape(-1), gH.reshape(n, -1))
     return g_h, gW3

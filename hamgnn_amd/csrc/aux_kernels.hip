@@ -661,6 +661,76 @@ extern "C" int hg_gate_backward(const float* x, int64_t x_stride, const float* g
     return hg_check_launch("hg_gate_backward");
 }
 
+// e3nn NormActivation of a ResidualBlock with nonlinearity_type = "norm" (hamgnn/nn/interaction_blocks.py:311-330: scalar nonlinearity ssp AS GIVEN,
+// normalize = True, epsilon = 1e-8, no bias) on planar rows: every irrep copy (channel u of block b: components x[off + a * mulp + u], a < 2 l + 1) is
+// scaled by ssp(n) / n with n = sqrt(max(sum_a x_a^2, eps^2)).  chan_tab int32[nchan][2] = {offset of the channel's first component, component
+// stride (mulp) | ncomp << 16}; the channel-padding slots of a planar row (no table entry) are written as zeros.  One thread per (row, channel).
+__device__ __forceinline__ float hg_ssp(float x) { return (x > 20.f ? x : log1pf(__expf(x))) - 0.69314718055994531f; }
+__global__ void norm_act_kernel(const float* __restrict__ x, int64_t xs, const int2* __restrict__ chan_tab, int nchan, float eps2, int64_t rows,
+                                float* __restrict__ out, int64_t os) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nchan) return;
+    const int64_t r = i / nchan;
+    const int2 t = chan_tab[(int)(i - r * nchan)];
+    const int st = t.y & 0xffff, nc = t.y >> 16;
+    const float* __restrict__ xr = x + r * xs + t.x;
+    float n2 = 0.f;
+    for (int a = 0; a < nc; ++a) n2 = fmaf(xr[a * st], xr[a * st], n2);
+    n2 = n2 < eps2 ? eps2 : n2;
+    const float n = sqrtf(n2), sc = hg_ssp(n) / n;
+    float* __restrict__ o = out + r * os + t.x;
+    for (int a = 0; a < nc; ++a) o[a * st] = sc * xr[a * st];
+}
+
+extern "C" int hg_norm_act(const float* x, int64_t x_stride, const int32_t* chan_tab, int nchan, float eps, int64_t rows, float* out,
+                           int64_t out_stride, int D, void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (rows <= 0) return 0;
+    if (nchan <= 0 || D <= 0) return hg_fail(-2, "hg_norm_act: bad table sizes");
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)rows * (size_t)out_stride, (hipStream_t)stream) != hipSuccess)      // channel-padding slots
+        return hg_fail(-3, "hg_norm_act: memset failed");
+    const int64_t n = rows * nchan;
+    norm_act_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, x_stride, (const int2*)chan_tab, nchan, eps * eps, rows, out, out_stride);
+    return hg_check_launch("hg_norm_act");
+}
+
+// its data gradient: y_a = s(n) / n * x_a  =>  gx_a = s / n * gy_a + x_a (sum_b gy_b x_b) (s'(n) - s / n) / n^2   (n > eps; below the clamp n is a
+// constant and only the first term is left); s = ssp, s' = sigmoid
+__global__ void norm_act_backward_kernel(const float* __restrict__ x, int64_t xs, const float* __restrict__ gy, int64_t gs, const int2* __restrict__ chan_tab,
+                                         int nchan, float eps2, int64_t rows, float* __restrict__ gx, int64_t gxs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * nchan) return;
+    const int64_t r = i / nchan;
+    const int2 t = chan_tab[(int)(i - r * nchan)];
+    const int st = t.y & 0xffff, nc = t.y >> 16;
+    const float* __restrict__ xr = x + r * xs + t.x;
+    const float* __restrict__ gr = gy + r * gs + t.x;
+    float n2 = 0.f, dot = 0.f;
+    for (int a = 0; a < nc; ++a) {
+        n2 = fmaf(xr[a * st], xr[a * st], n2);
+        dot = fmaf(gr[a * st], xr[a * st], dot);
+    }
+    const bool clamped = n2 < eps2;
+    n2 = clamped ? eps2 : n2;
+    const float n = sqrtf(n2), s = hg_ssp(n), sc = s / n;
+    const float k = clamped ? 0.f : dot * (1.f / (1.f + __expf(-n)) - sc) / n2;
+    float* __restrict__ o = gx + r * gxs + t.x;
+    for (int a = 0; a < nc; ++a) o[a * st] = fmaf(k, xr[a * st], sc * gr[a * st]);
+}
+
+extern "C" int hg_norm_act_backward(const float* x, int64_t x_stride, const float* gy, int64_t gy_stride, const int32_t* chan_tab, int nchan, float eps,
+                                    int64_t rows, float* gx, int64_t gx_stride, int D, void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (rows <= 0) return 0;
+    if (nchan <= 0 || D <= 0) return hg_fail(-2, "hg_norm_act_backward: bad table sizes");
+    if (hipMemsetAsync(gx, 0, sizeof(float) * (size_t)rows * (size_t)gx_stride, (hipStream_t)stream) != hipSuccess)
+        return hg_fail(-3, "hg_norm_act_backward: memset failed");
+    const int64_t n = rows * nchan;
+    norm_act_backward_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, x_stride, gy, gy_stride, (const int2*)chan_tab, nchan,
+                                                                                               eps * eps, rows, gx, gx_stride);
+    return hg_check_launch("hg_norm_act_backward");
+}
+
 __global__ void add_rows_kernel(const float* __restrict__ a, int64_t sa, const float* __restrict__ b, int64_t sb,
                                 const float* __restrict__ c, int64_t sc, int64_t rows, int D, float* __restrict__ out, int64_t so) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -908,6 +908,19 @@ extern "C" int hg_prof_is_read(unsigned long long* out16, int reset) {
 }
 #endif
 
+// Compile-time shape of the loaded library, for the host planner to check its own settings against (plan.IS_WAVES / IS_WAVES_LITE / LITE_SRING /
+// WIDE_WAVES are environment-tunable for A/B builds; a schedule dealt to 8 streams would be misread by a 4-wave kernel -- ADVICE r4).
+extern "C" int hg_wide_waves(void);                            // csrc/tp_wide.hip
+extern "C" int hg_build_config(int what) {
+    switch (what) {
+        case 0: return IS_NW;
+        case 1: return IS_NW_LITE;
+        case 2: return SL_RING;
+        case 3: return hg_wide_waves();
+        default: return -1;
+    }
+}
+
 extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge,
                         int hidden, const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table,
                         const int32_t* block_table, const int32_t* phase_table, const int32_t* group_table,

@@ -590,6 +590,8 @@ extern "C" int hg_prof_wd_read(unsigned long long* out16, int reset) {
 }
 #endif
 
+extern "C" int hg_wide_waves(void) { return WD_NW; }
+
 // lay_host, int32[12] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off, lds_floats}
 extern "C" int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge, int hidden,
                           const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table, const int32_t* block_table,

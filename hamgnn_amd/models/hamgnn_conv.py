@@ -132,6 +132,7 @@ class _BackboneBase(nn.Module):
 
     def _embed(self, data):
         """-> (z, topology, geometry, node [N, Dp] planar, f [E, Dp] planar in the edge frame)"""
+        ops.require_fp32(self, data)                           # `precision: 64` raises instead of returning fp32-accurate rows
         dev = data.pos.device
         if getattr(self, "_pending_refresh", False):           # an optimiser stepped since the last forward (training.weights_changed)
             self._pending_refresh = False
@@ -305,7 +306,8 @@ class HamGNNConvE3(_BackboneBase):
         tape = [] if save_for_backward else None
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
-            skip = conv.skip_linear(node)
+            row_shard = tape is None and parallel.node_shard_enabled(data)      # HG_NODE_SHARD=1: the node-level chain on this rank's block of rows only
+            skip = None if row_shard else conv.skip_linear(node)
             if conv.conv_tp.can_reduce(geo.E):
                 # convolution.py:147-149 fused into the edge kernel: receiver-major tiles, the runs of equal receivers summed in the epilogue
                 # (about E / 13 rows instead of the [E, Dp] message tensor), then a segmented sum over each atom's contiguous rows
@@ -315,6 +317,16 @@ class HamGNNConvE3(_BackboneBase):
             else:
                 msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab)      # global frame (un-rotated in the epilogue)
                 agg = ops.segment_sum(msg, rowptr, perm, N)
+            if row_shard:
+                # reduce-scatter of the partial aggregates, skip Linear / ResidualBlock / CorrProductBlock on N / world rows, all-gather of the new rows
+                r0, r1, _ = parallel.node_rows(data, N)
+                agg_r = parallel.reduce_scatter_nodes(agg, data)
+                part = conv.residual(agg_r, extra=conv.skip_linear(node[r0:r1].contiguous()))
+                if self.use_corr_prod:
+                    part = self.corr_products[li](part, z[r0:r1].contiguous(), None if self._last_delta is None else self._last_delta[r0:r1].contiguous())
+                node = parallel.allgather_nodes(part, data, N)
+                f = self._run_pair(pair, node, f, geo)
+                continue
             parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
             if tape is not None:
                 tape.append(dict(node_in=node, f_in=f, agg=agg))

@@ -39,8 +39,9 @@ class HamGNNPlusPlusOut(nn.Module):
         self.calculate_band_energy, self.num_k, self.k_path, self.band_num_control = calculate_band_energy, num_k, k_path, band_num_control
         # return_forces / create_graph: stored as `derivative` / `create_graph` and read by nothing in the reference's head (hamgnn_output.py:127-128);
         # its Model only switches autograd on for `pos` (Model.py:103, 227, 285, 459-460) -- no force is computed anywhere: accepted, no effect
-        for flag, name in ((spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin"),
-                           (nonlinearity_type != "gate", "nonlinearity_type!='gate'")):
+        assert nonlinearity_type in ("gate", "norm"), "Invalid nonlinearity_type. Choose either 'gate' or 'norm'."      # interaction_blocks.py:289-290
+        self.nonlinearity_type = nt = nonlinearity_type                     # of every HamLayer's ResidualBlock (hamgnn_output.py:38-58, 847)
+        for flag, name in ((spin_constrained, "spin_constrained"), (collinear_spin, "collinear_spin")):
             if flag:
                 raise NotImplementedError(f"HamGNNPlusPlusOut({name}) is outside the MI355X hot-path scope of this round")
         self.export_reciprocal_values = export_reciprocal_values
@@ -63,21 +64,21 @@ class HamGNNPlusPlusOut(nn.Module):
                 raise NotImplementedError("su2 SOC head: features beyond l = 6 / couplings beyond l = 7 are not instantiated")
             self.hamiltonian_irreps_su2 = Irreps(list(half) * 2)
             keep = [c in (0, 2) for c in range(4) for _ in range(len(half))]
-            self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, Irreps(list(half) * 4), keep)
-            self.offsite_hamiltonian_network = hnn.HamLayer(irreps_in_edge, Irreps(list(half) * 4), keep)
+            self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, Irreps(list(half) * 4), keep, nonlinearity_type=nt)
+            self.offsite_hamiltonian_network = hnn.HamLayer(irreps_in_edge, Irreps(list(half) * 4), keep, nonlinearity_type=nt)
             if not ham_only:
-                self.onsite_overlap_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
-                self.offsite_overlap_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
+                self.onsite_overlap_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps, nonlinearity_type=nt)
+                self.offsite_overlap_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps, nonlinearity_type=nt)
             return
-        self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
-        self.offsite_hamiltonian_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
+        self.onsite_hamiltonian_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps, nonlinearity_type=nt)
+        self.offsite_hamiltonian_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps, nonlinearity_type=nt)
         if soc_switch:
             ksi = Irreps([(nao_max ** 2, 0, 1)])
-            self.onsite_ksi_network = hnn.HamLayer(irreps_in_node, ksi)
-            self.offsite_ksi_network = hnn.HamLayer(irreps_in_edge, ksi)
+            self.onsite_ksi_network = hnn.HamLayer(irreps_in_node, ksi, nonlinearity_type=nt)
+            self.offsite_ksi_network = hnn.HamLayer(irreps_in_edge, ksi, nonlinearity_type=nt)
         if not ham_only:
-            self.onsite_overlap_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps)
-            self.offsite_overlap_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps)
+            self.onsite_overlap_network = hnn.HamLayer(irreps_in_node, self.hamiltonian_irreps, nonlinearity_type=nt)
+            self.offsite_overlap_network = hnn.HamLayer(irreps_in_edge, self.hamiltonian_irreps, nonlinearity_type=nt)
 
     # ------------------------------------------------------------------------------------------------------------
     def compile(self, device):
@@ -292,6 +293,7 @@ class HamGNNPlusPlusOut(nn.Module):
         if not self.ham_only:
             raise NotImplementedError("head backward: ham_only=True (reference overlaps)")
         rep = graph_representation
+        ops.require_fp32(self, data)                           # `precision: 64` raises instead of returning fp32-accurate rows
         dev = data.z.device
         if self._compiled_for != dev:
             self.compile(dev)
@@ -372,7 +374,7 @@ class HamGNNPlusPlusOut(nn.Module):
         # structural tables (CG merge maps: functions of the basis, not of the weights): built once per (key, table object) -- rebuilding them
         # after every optimiser step put a device -> host copy in the middle of the step
         cache = self.__dict__.setdefault("_adj_tabs_by", {})
-        key = (key, id(tables[0]))
+        key = (key, str(tables[0].device))                     # (per device: an id()-keyed entry outlives its tables and could be recycled)
         if key not in cache:
             glay = P.PlanarLayout(self.onsite_hamiltonian_network.girr)
             st, ptr_, idx_, val_ = (t.cpu().numpy() for t in tables)
@@ -390,6 +392,7 @@ class HamGNNPlusPlusOut(nn.Module):
 
     def forward(self, data, graph_representation=None):
         rep = graph_representation
+        ops.require_fp32(self, data)                           # `precision: 64` raises instead of returning fp32-accurate rows
         dev = data.z.device
         if self._compiled_for != dev:
             self.compile(dev)

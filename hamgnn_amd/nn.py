@@ -517,10 +517,19 @@ class MessagePackBlock(nn.Module):
 
 
 class ResidualBlock(nn.Module):
-    def __init__(self, irreps_in, feature_irreps_hidden, resnet=True):
+    def __init__(self, irreps_in, feature_irreps_hidden, resnet=True, nonlinearity_type="gate"):
+        """interaction_blocks.py:262-358.  nonlinearity_type "gate" (e3nn Gate; every block of the backbone, the head's default) or "norm" (e3nn
+        NormActivation with ShiftedSoftPlus as given, normalize, epsilon 1e-8: the head's HamLayers under `nonlinearity_type: norm`, :311-330)"""
         super().__init__()
+        if nonlinearity_type not in ("gate", "norm"):
+            raise AssertionError("Invalid nonlinearity_type. Choose either 'gate' or 'norm'.")      # (the reference asserts, :289-290)
         self.irreps_in = Irreps(irreps_in)
-        self.gate_in, self.gate_out, self._tab_np = P.gate_tables(feature_irreps_hidden)
+        self.nonlinearity_type = nonlinearity_type
+        if nonlinearity_type == "norm":
+            self.gate_in = self.gate_out = Irreps(feature_irreps_hidden)
+            self._tab_np = P.norm_act_table(self.gate_in)
+        else:
+            self.gate_in, self.gate_out, self._tab_np = P.gate_tables(feature_irreps_hidden)
         self.linear1 = E3Linear(self.irreps_in, self.gate_in)
         self.linear2 = E3Linear(self.gate_out, self.irreps_in)
         self.resnet = resnet
@@ -529,16 +538,25 @@ class ResidualBlock(nn.Module):
     def compile(self, device):
         self.linear1.compile(device)
         self.linear2.compile(device)
-        self._tab = tuple(torch.from_numpy(t).contiguous().to(device) for t in P.gate_tables_compact(self._tab_np))
+        if self.nonlinearity_type == "norm":
+            self._tab = torch.from_numpy(self._tab_np).contiguous().to(device)
+        else:
+            self._tab = tuple(torch.from_numpy(t).contiguous().to(device) for t in P.gate_tables_compact(self._tab_np))
         self._cst = torch.from_numpy(P.ACT_CONSTS).to(device)
         return self
+
+    def _act(self, y1):
+        return ops.norm_act(y1, self._tab) if self.nonlinearity_type == "norm" else ops.gate(y1, self._tab, self._cst)
+
+    def _act_backward(self, y1, g_y2):
+        return ops.norm_act_backward(y1, g_y2, self._tab) if self.nonlinearity_type == "norm" else ops.gate_backward(y1, g_y2, self._tab, self._cst)
 
     def forward(self, x_planar, extra=None):
         """x + Lin2(Gate(Lin1(x))) [+ extra]  on planar rows."""
         if self._tab is None:
             self.compile(x_planar.device)
         res = ([x_planar] if self.resnet else []) + ([extra] if extra is not None else [])
-        return self.linear2(ops.gate(self.linear1(x_planar), self._tab, self._cst), res=res)      # adds fused into linear2's epilogue
+        return self.linear2(self._act(self.linear1(x_planar)), res=res)      # adds fused into linear2's epilogue
 
 
     def backward(self, x_planar, gy_planar, extra_given: bool = False):
@@ -548,10 +566,10 @@ class ResidualBlock(nn.Module):
         if self._tab is None:
             self.compile(x_planar.device)
         y1 = self.linear1(x_planar)                            # gate input rows
-        y2 = ops.gate(y1, self._tab, self._cst)
+        y2 = self._act(y1)
         g_w2 = self.linear2.weight_grad(y2, gy_planar)
         g_y2 = self.linear2.backward_data(gy_planar)
-        g_y1 = ops.gate_backward(y1, g_y2, self._tab, self._cst)
+        g_y1 = self._act_backward(y1, g_y2)
         g_w1 = self.linear1.weight_grad(x_planar, g_y1)
         g_x = self.linear1.backward_data(g_y1)
         if self.resnet:
@@ -851,12 +869,12 @@ class ChargeEmbedding(nn.Module):
 
 
 class HamLayer(nn.Module):
-    def __init__(self, irreps_in, ham_irreps: Irreps, keep=None):
+    def __init__(self, irreps_in, ham_irreps: Irreps, keep=None, nonlinearity_type="gate"):
         """keep: optional bool per output irrep -- outputs the caller never reads (they keep their weights, for checkpoint
-        compatibility, but no GEMM rows are spent on them; SOC/su2 head)."""
+        compatibility, but no GEMM rows are spent on them; SOC/su2 head).  nonlinearity_type: of the ResidualBlock (hamgnn_output.py:38-58)."""
         super().__init__()
         self.irreps_in, self.ham_irreps, self.keep = Irreps(irreps_in), ham_irreps, keep
-        self.residual_block = ResidualBlock(irreps_in, irreps_in)
+        self.residual_block = ResidualBlock(irreps_in, irreps_in, nonlinearity_type=nonlinearity_type)
         self.linear_transform = E3Linear(irreps_in, ham_irreps)
 
     def compile(self, device):
@@ -937,7 +955,8 @@ class HamLayer(nn.Module):
         kernel form (HG_ROWPROG=0, channel counts beyond the kernel's unit shape, LDS)"""
         if getattr(self, "_rowprog", None) is None:
             self._rowprog = False
-            if os.environ.get("HG_ROWPROG", "1") != "0" and not getattr(self, "_rowprog_off", False) and isinstance(self._dp, ops.DeviceLinear):
+            if (os.environ.get("HG_ROWPROG", "1") != "0" and not getattr(self, "_rowprog_off", False) and isinstance(self._dp, ops.DeviceLinear)
+                    and self.residual_block.nonlinearity_type == "gate"):      # (the row program has a gate stage only: "norm" runs Linear / hg_norm_act / Linear)
                 rb = self.residual_block
                 w = lambda m: m.weight.detach().cpu().double().numpy()
                 li, lgi, lgo = P.PlanarLayout(self.irreps_in), P.PlanarLayout(rb.gate_in), P.PlanarLayout(rb.gate_out)
@@ -1042,14 +1061,30 @@ class CorrProductBlock(nn.Module):
             c = ops.sym_contraction3(h, zi, self.num_hidden, self._tab, W3, c)
         return c
 
+    MIX_BYTES = 256 << 20          # per-node weight mixtures held at once (charge doping): [chunk, K_nu, C] floats over all nu
+
+    def _mix_chunks(self, N):
+        """node ranges whose per-node weight mixtures W[z_n] + delta_n @ W (all nu) stay below MIX_BYTES: with correlation 3 a node's blocks reach
+        thousands of K x C floats, so N x that -- several times over in the backward -- is what an un-chunked pass would allocate"""
+        per = 4 * sum(int(W[0].numel()) for W in (self._W1, self._W2, self._W3) if W is not None)
+        step = max(64, int(self.MIX_BYTES // max(per, 1)))
+        return [(a, min(N, a + step)) for a in range(0, N, step)]
+
     def _mixed(self, z, delta):
         """apply_charge_doping: the reference contracts the element weights with node_attrs = one_hot(z) + delta (interaction_blocks.py:251,
         symmetric_contraction.py einsum '...,ek'), i.e. every node gets its own mixture of the element blocks: W_eff[n] = W[z_n] + delta_n @ W.
-        Returns (attrs [N, T], per-node weights of nu = 1, 2, 3, node index as the 'element' index) for the same kernel."""
+        Returns (attrs [N, T], per-node weights of nu = 1, 2, 3, node index as the 'element' index) for the same kernel.  Callers pass node CHUNKS."""
         T = self._W1.shape[0]
         A = torch.nn.functional.one_hot(z.long(), T).to(self._W1.dtype) + delta.to(self._W1.dtype)
         mix = lambda W: None if W is None else (A @ W.reshape(T, -1)).reshape(-1, *W.shape[1:]).contiguous()
         return A, mix(self._W1), mix(self._W2), mix(self._W3), torch.arange(z.shape[0], device=z.device, dtype=z.dtype)
+
+    def _contract_doped(self, h, z, delta):
+        out = []
+        for a, b in self._mix_chunks(int(z.shape[0])):
+            _, W1, W2, W3, zi = self._mixed(z[a:b], delta[a:b])
+            out.append(self._contract(h[a:b].contiguous(), zi, W1, W2, W3))
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def backward(self, node_planar, z, g_out, delta=None):
         """gradient of forward(node, z) for the gradient g_out of the rows it returned: (g_node, {parameter name: gradient}).
@@ -1059,29 +1094,39 @@ class CorrProductBlock(nn.Module):
         if self._tab is None:
             self.compile(node_planar.device)
         h = self.linear_pre(node_planar)
-        W1, W2, W3, zi = self._W1, self._W2, self._W3, z
-        if delta is not None:
-            A, W1, W2, W3, zi = self._mixed(z, delta)
-        c = self._contract(h, zi, W1, W2, W3)
+        c = self._contract(h, z, self._W1, self._W2, self._W3) if delta is None else self._contract_doped(h, z, delta)
         p = self.prod.linear(c)
         grads = {"linear_out.weight": self.linear_out.weight_grad(p, g_out), }
         g_p = self.linear_out.backward_data(g_out)
         grads["prod.linear.weight"] = self.prod.linear.weight_grad(c, g_p)
         g_c = self.prod.linear.backward_data(g_p)
-        g_h, gW1, gW2 = sym_contraction_backward(self._tab, h, zi, W1, W2, self.num_hidden, g_c, per_node=delta is not None)
-        gW = [gW1, gW2]
-        if W3 is not None:
-            from .corr3 import sym3_backward
-            g_h3, gW3 = sym3_backward(self._tab, h, zi, W3, self.num_hidden, g_c, per_node=delta is not None)
-            g_h = g_h + g_h3
-            gW.append(gW3)
-        gW = gW[:self.correlation]
-        if delta is not None:                                  # per-node gradients back onto the element blocks and onto the attributes
+
+        def contraction_grads(hc, zi, W1, W2, W3, gc, per_node):
+            g_h_, gW1, gW2 = sym_contraction_backward(self._tab, hc, zi, W1, W2, self.num_hidden, gc, per_node=per_node)
+            gW_ = [gW1, gW2]
+            if W3 is not None:
+                from .corr3 import sym3_backward
+                g_h3, gW3 = sym3_backward(self._tab, hc, zi, W3, self.num_hidden, gc, per_node=per_node)
+                g_h_ = g_h_ + g_h3
+                gW_.append(gW3)
+            return g_h_, gW_[:self.correlation]
+
+        if delta is None:
+            g_h, gW = contraction_grads(h, z, self._W1, self._W2, self._W3, g_c, False)
+        else:                                                  # per-node gradients back onto the element blocks and onto the attributes, chunk by chunk
             T = self._W1.shape[0]
             Wel = [self._W1, self._W2, self._W3][:self.correlation]
-            flat = [g.reshape(g.shape[0], -1) for g in gW]
-            grads["_g_delta"] = sum(f @ W.reshape(T, -1).t() for f, W in zip(flat, Wel))
-            gW = [(A.t() @ f).reshape(W.shape) for f, W in zip(flat, Wel)]
+            g_h_parts, g_delta_parts, gW = [], [], [torch.zeros_like(W) for W in Wel]
+            for a, b in self._mix_chunks(int(z.shape[0])):
+                A, W1, W2, W3, zi = self._mixed(z[a:b], delta[a:b])
+                g_h_c, gW_c = contraction_grads(h[a:b].contiguous(), zi, W1, W2, W3, g_c[a:b].contiguous(), True)
+                flat = [g.reshape(g.shape[0], -1) for g in gW_c]
+                g_h_parts.append(g_h_c)
+                g_delta_parts.append(sum(f @ W.reshape(T, -1).t() for f, W in zip(flat, Wel)))
+                for acc, f, W in zip(gW, flat, Wel):
+                    acc += (A.t() @ f).reshape(W.shape)
+            g_h = g_h_parts[0] if len(g_h_parts) == 1 else torch.cat(g_h_parts, 0)
+            grads["_g_delta"] = g_delta_parts[0] if len(g_delta_parts) == 1 else torch.cat(g_delta_parts, 0)
         for nu, g in enumerate(gW, start=1):                   # the concatenated weights back to one block per target irrep
             k0 = 0
             for i, con in enumerate(self.prod.symmetric_contractions.contractions):
@@ -1104,8 +1149,7 @@ class CorrProductBlock(nn.Module):
             self.compile(node_planar.device)
         h = self.linear_pre(node_planar)
         if delta is not None:
-            _, W1, W2, W3, zi = self._mixed(z, delta)
-            c = self._contract(h, zi, W1, W2, W3)
+            c = self._contract_doped(h, z, delta)
         else:
             c = self._contract(h, z, self._W1, self._W2, self._W3)
         skip = [self.linear_sc(node_planar)] if self.use_skip_connections else []

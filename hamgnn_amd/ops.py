@@ -43,6 +43,23 @@ def _dev(arr: np.ndarray, device, dtype=None):
     return t.to(device)
 
 
+def require_fp32(module, data=None):
+    """The HIP path computes in fp32 (tables, kernels, outputs).  The reference's `precision: 64` flow -- torch.set_default_dtype(float64) + model.to(float64)
+    + float64 graph tensors (hamgnn/main.py:469-474, hamgnn/models/hamgnn_conv.py:248-250) -- must not silently come back as fp32-accurate rows: refuse it."""
+    why = None
+    if torch.get_default_dtype() == torch.float64:
+        why = "torch.get_default_dtype() is float64"
+    elif module is not None and any(p.dtype == torch.float64 for p in module.parameters()):
+        why = "the model's parameters are float64"
+    elif data is not None:
+        pos = data["pos"] if isinstance(data, dict) else getattr(data, "pos", None)
+        if torch.is_tensor(pos) and pos.dtype == torch.float64:
+            why = "data.pos is float64"
+    if why:
+        raise NotImplementedError(f"precision: 64 is not built ({why}): the MI355X path computes in fp32 and does not down-cast silently "
+                                  "(reference: hamgnn/main.py:469-474)")
+
+
 def _require_gpu(t: torch.Tensor):
     if not t.is_cuda:
         raise RuntimeError("hamgnn_amd: the MI355X hot path needs CUDA(ROCm) tensors; there is no CPU fallback")
@@ -51,6 +68,24 @@ def _require_gpu(t: torch.Tensor):
 # the wide schedule (csrc/tp_wide.hip, r5) is an opt-in experiment: measured 8.5 ms against hg_tp_is's 6.8 ms per 131 072-edge set-A launch (profiles/r05_tp_wide.md)
 WIDE_MODE = os.environ.get("HG_MP_WIDE", "0")             # "0": never (default), "1": launches with >= WIDE_MIN_TILES 16-edge tiles, "force": whenever the program has a wide form
 WIDE_MIN_TILES = int(os.environ.get("HG_WIDE_MIN_TILES", "512"))
+
+
+_BUILD_CONFIG_OK = False
+
+
+def check_build_config():
+    """the planner's wave / ring counts against the compiled ones of the loaded library (once per process; raises on a mismatch instead of launching a
+    schedule the kernel would misread -- the counts are environment-tunable for the A/B scripts under tools/)"""
+    global _BUILD_CONFIG_OK
+    if _BUILD_CONFIG_OK:
+        return
+    L = lib()
+    want = {0: ("HG_IS_WAVES", P.IS_WAVES), 1: ("HG_LITE_WAVES", P.IS_WAVES_LITE), 2: ("HG_LITE_SRING", P.LITE_SRING), 3: ("HG_WIDE_WAVES", P.WIDE_WAVES)}
+    for what, (name, val) in want.items():
+        got = int(L.hg_build_config(what))
+        if got != int(val):
+            raise RuntimeError(f"{name}={val} does not match the loaded library (compiled with {got}): rebuild the variant or unset the variable")
+    _BUILD_CONFIG_OK = True
 
 
 class DeviceProgram:
@@ -234,6 +269,7 @@ def linear_wgrad(irreps_in, irreps_out, x: torch.Tensor, gy: torch.Tensor) -> to
         return x.new_zeros(0)
     rows = int(x.shape[0])
     assert gy.shape[0] == rows and x.stride(1) == 1 and gy.stride(1) == 1
+    assert x.dtype == torch.float32 and gy.dtype == torch.float32, "hg_linear_wgrad reads fp32 rows (raw pointers: any other dtype would be misread)"
     nchunk = (rows + LW_ROWS - 1) // LW_ROWS
     part = torch.empty(nchunk, nunits * 1024, device=x.device, dtype=torch.float32)
     check(lib().hg_linear_wgrad(ptr(x), i64(x.stride(0)), ptr(gy), i64(gy.stride(0)), i64(rows), ptr(units), i32(nunits), ptr(part), _stream()), "hg_linear_wgrad")
@@ -425,6 +461,8 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     if PROFILE_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
+    if dp.sched is not None:
+        check_build_config()
     if dp.sched is not None and dp.use_wide(rows, gather, res):
         ws, (t_segs, t_blocks, t_streams, t_recs, t_rowtab), lay_host = dp.wide_tables()
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
@@ -454,25 +492,37 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     return out
 
 
-_SCATTER_CACHE: dict = {}
+import collections
+
+_SCATTER_CACHE: "collections.OrderedDict" = collections.OrderedDict()     # LRU over (sort order, counts) of index tensors, bounded in entries AND bytes
+_SCATTER_CACHE_MAX_ENTRIES = 64
+_SCATTER_CACHE_MAX_BYTES = 256 << 20
 
 
-def scatter_rows(index: torch.Tensor, src: torch.Tensor, n: int) -> torch.Tensor:
+def scatter_rows(index: torch.Tensor, src: torch.Tensor, n: int, persistent: bool = True) -> torch.Tensor:
     """out[i] = sum of the rows src[q] with index[q] == i, in a FIXED order (stable sort by index, then a segmented sum): the
     deterministic form of torch.zeros(n, ...).index_add_(0, index, src), whose float atomics make a training step differ from run to run.
-    torch tensor ops (sort / segment_reduce), any device; edge-level glue of the backward passes, not a hot kernel."""
+    torch tensor ops (sort / segment_reduce), any device; edge-level glue of the backward passes, not a hot kernel.
+    persistent = False: `index` is a throw-away view (not a constant of the model or the graph): its sort order is not cached.  The cache holds strong
+    references to what it keeps, so it is a small LRU with a byte cap -- the edge-level indices of graphs already discarded do not pin device memory
+    (13 MB per 822 k-edge index, 257 entries before)."""
     if src.shape[0] == 0:
         return src.new_zeros((n,) + tuple(src.shape[1:]))
     key = (index.data_ptr(), index._version, int(index.shape[0]), int(n), index.device)
-    hit = _SCATTER_CACHE.get(key)
+    hit = _SCATTER_CACHE.get(key) if persistent else None
     if hit is None or hit[0] is not index:                     # the index tensors of the backward glue (tp_idx, l_idx, z, the contraction tables) are
         order = torch.sort(index.long(), stable=True).indices  # constants of a model: sorted once (keyed on the tensor object and its version)
         counts = torch.bincount(index.long(), minlength=n)
         if counts.shape[0] != n:                               # an index >= n: index_add_ raised here, segment_reduce(unsafe=True) would return extra rows
             raise IndexError(f"scatter_rows: index {int(index.max())} out of range for {n} rows")
-        if len(_SCATTER_CACHE) > 256:
-            _SCATTER_CACHE.clear()
-        hit = _SCATTER_CACHE[key] = (index, order, counts)
+        hit = (index, order, counts)
+        if persistent:
+            _SCATTER_CACHE[key] = hit
+            size = lambda h: sum(t.numel() * t.element_size() for t in h)
+            while len(_SCATTER_CACHE) > _SCATTER_CACHE_MAX_ENTRIES or (len(_SCATTER_CACHE) > 1 and sum(size(h) for h in _SCATTER_CACHE.values()) > _SCATTER_CACHE_MAX_BYTES):
+                _SCATTER_CACHE.popitem(last=False)
+    elif persistent:
+        _SCATTER_CACHE.move_to_end(key)
     _, order, counts = hit
     return torch.segment_reduce(src[order].contiguous(), "sum", lengths=counts, axis=0, unsafe=True)
 
@@ -611,6 +661,30 @@ def gate(x: torch.Tensor, tabs, consts: torch.Tensor) -> torch.Tensor:
     check(lib().hg_gate(ptr(x), i64(x.stride(0)), ptr(act_tab), i32(act_tab.shape[0]), ptr(out_tab), i32(Dout), ptr(consts), i64(rows), ptr(out),
                         i64(Dout), _stream()), "hg_gate")
     return out
+
+
+NORM_ACT_EPS = 1e-8          # epsilon of the reference's NormActivation (interaction_blocks.py:329)
+
+
+def norm_act(x: torch.Tensor, chan_tab: torch.Tensor) -> torch.Tensor:
+    """e3nn NormActivation (ssp, normalize, eps 1e-8) on planar rows; chan_tab = plan.norm_act_table(irreps) on the device"""
+    _require_gpu(x)
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    rows, D = x.shape
+    out = torch.empty(rows, D, device=x.device, dtype=torch.float32)
+    check(lib().hg_norm_act(ptr(x), i64(x.stride(0)), ptr(chan_tab), i32(chan_tab.shape[0]), f32(NORM_ACT_EPS), i64(rows), ptr(out), i64(D), i32(D), _stream()),
+          "hg_norm_act")
+    return out
+
+
+def norm_act_backward(x: torch.Tensor, gy: torch.Tensor, chan_tab: torch.Tensor) -> torch.Tensor:
+    _require_gpu(x)
+    assert x.dtype == torch.float32 and gy.dtype == torch.float32 and x.stride(1) == 1 and gy.stride(1) == 1 and gy.shape == x.shape
+    rows, D = x.shape
+    gx = torch.empty(rows, D, device=x.device, dtype=torch.float32)
+    check(lib().hg_norm_act_backward(ptr(x), i64(x.stride(0)), ptr(gy), i64(gy.stride(0)), ptr(chan_tab), i32(chan_tab.shape[0]), f32(NORM_ACT_EPS), i64(rows),
+                                     ptr(gx), i64(D), i32(D), _stream()), "hg_norm_act_backward")
+    return gx
 
 
 @_on_tensor_device

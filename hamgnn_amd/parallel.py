@@ -78,7 +78,68 @@ def allreduce_nodes(t: torch.Tensor, data) -> torch.Tensor:
     return t
 
 
-PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, bytes) around every node all-reduce
+PROFILE_EVENTS = None        # bench.py sets this to a list: (start, end, bytes) around every node all-reduce / reduce-scatter / all-gather
+
+
+# ---- row-sharded node-level work (off by default: HG_NODE_SHARD=1).  After the edge kernel every rank holds partial node aggregates
+# [N, Dp]; the default sums them on every rank (all-reduce) and runs the node-level chain of the ConvBlock (skip Linear, ResidualBlock, CorrProductBlock:
+# convolution.py:116-160) redundantly on all N rows.  With the flag each rank receives the SUM of ITS block of rows (reduce-scatter), runs the chain on
+# N / world rows and the blocks are all-gathered: the same wire traffic as a ring all-reduce (2 (W - 1) / W of the tensor), the node-level compute
+# divided by the world size.  At 10 k atoms that compute is ~1.5 ms of a ~37 ms step at 8 ranks: the flag exists so that the
+# first multi-GPU run can A/B it, not because it is expected to matter.
+def node_shard_enabled(data) -> bool:
+    import os
+    return is_sharded(data) and os.environ.get("HG_NODE_SHARD", "0") == "1"
+
+
+def node_rows(data, N: int):
+    """(first row, end row, rows per rank incl. padding) of this rank's block of the N node rows"""
+    rank, world = data.get("_hg_shard")
+    chunk = -(-N // world)
+    return min(N, rank * chunk), min(N, (rank + 1) * chunk), chunk
+
+
+def reduce_scatter_nodes(t: torch.Tensor, data) -> torch.Tensor:
+    """sum of the ranks' partial aggregates, this rank's block of rows only -> [rows of the block, Dp]"""
+    import torch.distributed as dist
+    N, D = t.shape
+    rank, world = data.get("_hg_shard")
+    r0, r1, chunk = node_rows(data, N)
+    ev = None
+    if PROFILE_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    if dist.get_backend() == "nccl":
+        pad = t if N == chunk * world else torch.cat([t, t.new_zeros(chunk * world - N, D)], 0)
+        out = t.new_empty(chunk, D)
+        dist.reduce_scatter_tensor(out, pad.contiguous(), op=dist.ReduceOp.SUM)
+        out = out[:r1 - r0]
+    else:                                                      # gloo (the CPU / shared-device tests) has no reduce-scatter: all-reduce, keep the block
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out = t[r0:r1].contiguous()
+    if ev is not None:
+        ev[1].record()
+        PROFILE_EVENTS.append((ev[0], ev[1], int(t.numel()) * t.element_size()))
+    return out
+
+
+def allgather_nodes(part: torch.Tensor, data, N: int) -> torch.Tensor:
+    """the ranks' row blocks back to the full [N, Dp] node tensor on every rank"""
+    import torch.distributed as dist
+    rank, world = data.get("_hg_shard")
+    r0, r1, chunk = node_rows(data, N)
+    D = part.shape[1]
+    buf = part if part.shape[0] == chunk else torch.cat([part, part.new_zeros(chunk - part.shape[0], D)], 0)
+    out = part.new_empty(chunk * world, D)
+    ev = None
+    if PROFILE_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    dist.all_gather_into_tensor(out, buf.contiguous())
+    if ev is not None:
+        ev[1].record()
+        PROFILE_EVENTS.append((ev[0], ev[1], int(out.numel()) * out.element_size()))
+    return out[:N]
 
 
 # ---- training on an edge-sharded crystal (model-parallel; hamgnn_amd.training): which parameter gradients are sums over the edges

@@ -2017,6 +2017,18 @@ def gate_tables(feature_irreps):
     return irr_in, irr_out, tab
 
 
+def norm_act_table(irreps) -> np.ndarray:
+    """int32[nchan][2] = {offset of the irrep copy's first component in the planar row, component stride | components << 16} of csrc/aux_kernels.hip:
+    norm_act_kernel (e3nn NormActivation: one norm per irrep COPY)"""
+    lay = PlanarLayout(irreps)
+    out = []
+    for i, (mul, l, _) in enumerate(lay.irreps):
+        assert lay.mulp[i] < (1 << 16)
+        for u in range(mul):
+            out.append([lay.off[i] + u, lay.mulp[i] | ((2 * l + 1) << 16)])
+    return np.asarray(out, np.int32).reshape(-1, 2)
+
+
 def gate_tables_compact(tab: np.ndarray):
     """tables of hg_gate from gate_tables' [Dout][4] = {src, act, gate, gate act}: the distinct (input, activation) pairs are listed once
     (act_tab) and the outputs refer to them by slot, so a gate channel's activation is evaluated once per row instead of once per

@@ -153,6 +153,22 @@ int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, con
                const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
                int64_t rows, void* stream);
 
+/* e3nn NormActivation of a ResidualBlock with nonlinearity_type = "norm" (hamgnn/nn/interaction_blocks.py:311-330 -> e3nn.nn.NormActivation with the
+ * scalar nonlinearity ShiftedSoftPlus as given, normalize = True, epsilon = 1e-8, no bias; the head's HamLayers, hamgnn/models/hamgnn_output.py:38-58)
+ * on planar rows: every irrep copy is scaled by ssp(n) / n, n = max(|x|, eps).  chan_tab int32[nchan][2] = {float offset of the copy's first
+ * component, component stride | components << 16}; D = row width (channel-padding slots come out as zeros).  hg_norm_act_backward: its data
+ * gradient for the gradient rows gy of the output (training: Model.py:150-196).                                                              */
+int hg_norm_act(const float* x, int64_t x_stride, const int32_t* chan_tab, int nchan, float eps, int64_t rows, float* out, int64_t out_stride, int D,
+                void* stream);
+int hg_norm_act_backward(const float* x, int64_t x_stride, const float* gy, int64_t gy_stride, const int32_t* chan_tab, int nchan, float eps,
+                         int64_t rows, float* gx, int64_t gx_stride, int D, void* stream);
+
+/* Compile-time shape of the loaded library (no reference counterpart; host-only): what = 0 waves per workgroup of hg_tp_is, 1 ... of its lite_mode
+ * instantiation, 2 request-ring depth of the lite_mode streams, 3 waves per workgroup of hg_tp_wide; -1 for anything else.  The host planner
+ * (hamgnn_amd/plan.py) deals work to that many streams / waves and refuses to launch when its settings differ.  hg_wide_waves() = what 3.      */
+int hg_build_config(int what);
+int hg_wide_waves(void);
+
 /* Many small independent matrix products in one launch (csrc/block_gemm.hip):  C_u = scale_u * op(A_u) @ op(B_u).  Replaces the per-irrep
  * products of a MessagePackBlock's two trailing Linears -- linear_scaler.linear_out @ linear_out / sqrt(mul_k)
  * (hamgnn/nn/message_passing.py:122-130, nn/tensor_products.py:118-140) -- in the device-side weight repack and, transposed, in the backward of

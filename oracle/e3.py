@@ -673,9 +673,44 @@ class FullyConnectedNet(torch.nn.Sequential):
             setattr(self, f"layer{i}", _FCLayer(h1, h2, act if i < n - 1 else None))
 
 
-class NormActivation(torch.nn.Module):  # only so that `from e3nn.nn import NormActivation` resolves
-    def __init__(self, *a, **k):
-        raise NotImplementedError("NormActivation (nonlinearity_type='norm') is outside the hot-path scope")
+class NormActivation(torch.nn.Module):
+    """e3nn.nn.NormActivation (e3nn 0.5.0, nn/_normact.py) [e3nn-recall]: every irrep COPY (channel) is scaled by f(|x|) / |x| (normalize=True), the
+    norm clamped from below at epsilon: norms = o3.Norm(irreps, squared=True)(x); norms[norms < eps^2] = eps^2; norms = sqrt(norms);
+    scalings = f(norms [+ bias]) / norms; out = ElementwiseTensorProduct(norms' irreps (0e per channel), irreps)(scalings, x) -- whose 0e x l -> l
+    "uuu" path has coefficient sqrt(2 l + 1) * w3j(0, l, l) = 1 under e3nn's default component normalisation, i.e. a plain product.  The scalar
+    nonlinearity is applied AS GIVEN (no normalize2mom wrapper, unlike Gate / Activation).  irreps_out = irreps_in."""
+
+    def __init__(self, irreps_in, scalar_nonlinearity, normalize=True, epsilon=None, bias=False):
+        super().__init__()
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_in)
+        if epsilon is None and normalize:
+            epsilon = 1e-8
+        elif epsilon is not None and not normalize:
+            raise ValueError("epsilon and normalize = False don't make sense together")
+        self._eps_squared = epsilon * epsilon if epsilon is not None else 0.0
+        self.scalar_nonlinearity = scalar_nonlinearity
+        self.normalize = normalize
+        self.bias = bias
+        if bias:
+            self.biases = torch.nn.Parameter(torch.zeros(self.irreps_in.num_irreps))
+
+    def forward(self, features):
+        out = []
+        ch = 0
+        for (mul, ir), sl in zip(self.irreps_in, self.irreps_in.slices()):
+            x = features[..., sl].reshape(*features.shape[:-1], mul, ir.dim)
+            n2 = (x * x).sum(-1)
+            if self._eps_squared > 0:
+                n2 = torch.where(n2 < self._eps_squared, torch.full_like(n2, self._eps_squared), n2)
+            n = n2.sqrt()
+            arg = n + self.biases[ch:ch + mul] if self.bias else n
+            ch += mul
+            sc = self.scalar_nonlinearity(arg)
+            if self.normalize:
+                sc = sc / n
+            out.append((x * sc[..., None]).reshape(*features.shape[:-1], mul * ir.dim))
+        return torch.cat(out, dim=-1)
 
 
 def compile_mode(mode):

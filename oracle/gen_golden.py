@@ -882,6 +882,31 @@ def main():
           outputs=dict(node_attr=r6["node_attr"], edge_attr=r6["edge_attr"]),
           block=dict(node_features=xn6, edge_features=xe6, out=gd["node_features"]),
           meta=dict(cfg=np.array(json.dumps({k: v for k, v in dict(cfg6["HamGNN_pre"]).items()}))))
+    # ---- r5: nonlinearity_type = "norm" of the head's ResidualBlocks (interaction_blocks.py:311-330 -> e3nn NormActivation, restated in oracle/e3.py):
+    # appended last, own generator, so that every older fixture regenerates byte for byte
+    print("HamGNNPlusPlusOut, nonlinearity_type='norm'")
+    genn = torch.Generator().manual_seed(31)
+    nao = 19
+    Gn = Graph(G)
+    Gn.z = torch.tensor((14, 8, 42))
+    for k, n in (("Hon0", N), ("Hoff0", E), ("Hon", N), ("Hoff", E), ("Son", N), ("Soff", E)):
+        Gn[k] = 0.1 * torch.randn(n, nao * nao, generator=genn)
+    xn_n, xe_n = torch.randn(N, D, generator=genn), torch.randn(E, D, generator=genn)
+    xn_n[0, :3] = 0.0                                                         # a channel with |x| below epsilon: the clamp branch of NormActivation
+    torch.manual_seed(32)
+    refn = ref_out.HamGNNPlusPlusOut(irreps_in_node=mini, irreps_in_edge=mini, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
+                                     soc_switch=False, calculate_band_energy=False, calculate_sparsity=False, nonlinearity_type="norm")
+    minen = R.HamGNNPlusPlusOut(mini, mini, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True, nonlinearity_type="norm")
+    sdn = {k: v for k, v in refn.state_dict().items() if not k.startswith("cg_calculator")}
+    assert not minen.load_state_dict(sdn, strict=False).missing_keys
+    on_ref = refn(Graph(Gn), {"node_attr": xn_n, "edge_attr": xe_n})
+    on_mine = minen(Gn, {"node_attr": xn_n, "edge_attr": xe_n})
+    _check(on_mine["hamiltonian"], on_ref["hamiltonian"], "head nonlinearity_type='norm' hamiltonian")
+    rb_r, rb_m = refn.offsite_hamiltonian_network.residual_block, minen.offsite_hamiltonian_network.residual_block
+    _check(rb_m(xe_n), rb_r(xe_n), "ResidualBlock nonlinearity_type='norm'")
+    assert str(rb_r.linear1.irreps_out) == str(e3.Irreps(mini)) and str(rb_r.linear2.irreps_in) == str(e3.Irreps(mini))
+    _save("head_norm_openmx_19", weights=sdn, graph={k: Gn[k] for k in ("z", "edge_index", "inv_edge_idx", "batch", "Hon0", "Hoff0")},
+          inputs=dict(node_attr=xn_n, edge_attr=xe_n), outputs=dict(hamiltonian=on_ref["hamiltonian"], residual_block_edge=rb_r(xe_n)))
     print("ALL WIRING CHECKS PASSED")
 
 

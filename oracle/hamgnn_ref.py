@@ -165,10 +165,17 @@ def irreps2gate(irreps, act_scalars={1: "ssp", -1: "tanh"}, act_gates={1: "ssp",
 
 
 class ResidualBlock(nn.Module):
-    def __init__(self, irreps_in, feature_irreps_hidden, resnet=True):
+    def __init__(self, irreps_in, feature_irreps_hidden, resnet=True, nonlinearity_type="gate"):
+        """interaction_blocks.py:262-358; nonlinearity_type "norm": e3nn NormActivation with the even-scalar nonlinearity (ssp) AS GIVEN, normalize=True,
+        epsilon=1e-8, no bias (:311-330)"""
         super().__init__()
-        s, g, gd, a_s, a_g = irreps2gate(feature_irreps_hidden)
-        self.equivariant_nonlin = Gate(s, a_s, g, a_g, gd)
+        assert nonlinearity_type in ("gate", "norm")
+        if nonlinearity_type == "norm":
+            from .e3 import NormActivation
+            self.equivariant_nonlin = NormActivation(Irreps(feature_irreps_hidden), ACTS["ssp"], normalize=True, epsilon=1e-8, bias=False)
+        else:
+            s, g, gd, a_s, a_g = irreps2gate(feature_irreps_hidden)
+            self.equivariant_nonlin = Gate(s, a_s, g, a_g, gd)
         self.linear1 = Linear(irreps_in, self.equivariant_nonlin.irreps_in)
         self.linear2 = Linear(self.equivariant_nonlin.irreps_out, irreps_in)
         self.resnet = resnet
@@ -507,9 +514,9 @@ def load_basis_tables():
 
 
 class HamLayer(nn.Module):
-    def __init__(self, irreps_in, irreps_out):
+    def __init__(self, irreps_in, irreps_out, nonlinearity_type="gate"):
         super().__init__()
-        self.residual_block = ResidualBlock(irreps_in, irreps_in)
+        self.residual_block = ResidualBlock(irreps_in, irreps_in, nonlinearity_type=nonlinearity_type)
         self.linear_transform = Linear(irreps_in, irreps_out)
 
     def forward(self, x):
@@ -537,8 +544,9 @@ class HamGNNPlusPlusOut(nn.Module):
     """Non-SOC branch and SOC/so3 branch of the reference head; ham_only=True; band/k-space code out of scope."""
 
     def __init__(self, irreps_in_node, irreps_in_edge, nao_max=19, ham_type="openmx", symmetrize=True, add_H0=True,
-                 soc_switch=False, soc_basis="so3", add_H_nonsoc=False, zero_point_shift=False, ham_only=True):
+                 soc_switch=False, soc_basis="so3", add_H_nonsoc=False, zero_point_shift=False, ham_only=True, nonlinearity_type="gate"):
         super().__init__()
+        self.nonlinearity_type = nonlinearity_type
         self.nao_max, self.ham_type = nao_max, ham_type.lower()
         self.symmetrize, self.add_H0, self.soc_switch, self.add_H_nonsoc = symmetrize, add_H0, soc_switch, add_H_nonsoc
         self.zero_point_shift = zero_point_shift
@@ -559,23 +567,23 @@ class HamGNNPlusPlusOut(nn.Module):
         self.hamiltonian_irreps = irr
         self.ham_only = ham_only
         if not ham_only:                                        # hamgnn_output.py:247-256
-            self.onsite_overlap_network = HamLayer(irreps_in_node, irr)
-            self.offsite_overlap_network = HamLayer(irreps_in_edge, irr)
+            self.onsite_overlap_network = HamLayer(irreps_in_node, irr, nonlinearity_type)
+            self.offsite_overlap_network = HamLayer(irreps_in_edge, irr, nonlinearity_type)
         if soc_switch and self.soc_basis == "su2":
             # E3TensorDecomposition(spinful=True).required_irreps_out (tensor_decomposition.py:463-527) is already the doubled
             # (re, im) list; the head doubles it once more (hamgnn_output.py:193,197) -- only copies 0 and 2 are ever read
             self.su2_required = su2_required_irreps(self.row)
             net = self.su2_required + self.su2_required
             net = net + net
-            self.onsite_hamiltonian_network = HamLayer(irreps_in_node, net)
-            self.offsite_hamiltonian_network = HamLayer(irreps_in_edge, net)
+            self.onsite_hamiltonian_network = HamLayer(irreps_in_node, net, nonlinearity_type)
+            self.offsite_hamiltonian_network = HamLayer(irreps_in_edge, net, nonlinearity_type)
             return
-        self.onsite_hamiltonian_network = HamLayer(irreps_in_node, irr)
-        self.offsite_hamiltonian_network = HamLayer(irreps_in_edge, irr)
+        self.onsite_hamiltonian_network = HamLayer(irreps_in_node, irr, nonlinearity_type)
+        self.offsite_hamiltonian_network = HamLayer(irreps_in_edge, irr, nonlinearity_type)
         if soc_switch:
             ksi = Irreps([(nao_max ** 2, (0, 1))])
-            self.onsite_ksi_network = HamLayer(irreps_in_node, ksi)
-            self.offsite_ksi_network = HamLayer(irreps_in_edge, ksi)
+            self.onsite_ksi_network = HamLayer(irreps_in_node, ksi, nonlinearity_type)
+            self.offsite_ksi_network = HamLayer(irreps_in_edge, ksi, nonlinearity_type)
 
     # -- pieces
     def merge_tensor_components(self, coeff):

@@ -226,6 +226,27 @@ def gate_backward(x, gy, tabs, consts):
     return g.float()
 
 
+def norm_act(x, chan_tab, eps=1e-8):
+    """hg_norm_act on plan.norm_act_table: per irrep copy (offset, stride | components << 16): y = ssp(n) / n * x, n = sqrt(max(sum x^2, eps^2));
+    padding slots 0"""
+    tab = chan_tab.cpu().numpy()
+    out = torch.zeros_like(x)
+    for off, w in tab:
+        st, nc = int(w) & 0xffff, int(w) >> 16
+        cols = [int(off) + a * st for a in range(nc)]
+        v = x[:, cols]
+        n = torch.sqrt(torch.clamp((v * v).sum(1), min=eps * eps))
+        out[:, cols] = v * ((torch.nn.functional.softplus(n) - math.log(2.0)) / n)[:, None]
+    return out
+
+
+def norm_act_backward(x, gy, chan_tab):
+    with torch.enable_grad():
+        xr = x.detach().double().requires_grad_()
+        (g,) = torch.autograd.grad(norm_act(xr, chan_tab), xr, grad_outputs=gy.double())
+    return g.float()
+
+
 def ham_merge(coeff, geo, slot_tab, cg_ptr, cg_idx, cg_val, nout):
     """hg_ham_merge: slots {L, a, base, stride} (un-rotated with D^L(e)^T when a geometry is given), then the CSR expansion"""
     c = _np(coeff)
@@ -394,6 +415,6 @@ def install(mp):
     mp.setattr(ops, "Geometry", Geometry)
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
     for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "row_program", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
-                 "gate_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "sym_contraction3", "block_mean", "soc_assemble", "attention_aggregate",
+                 "gate_backward", "norm_act", "norm_act_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "sym_contraction3", "block_mean", "soc_assemble", "attention_aggregate",
                  "attention_logits", "hk_assemble", "zero_point_shift", "block_gemm"):
         mp.setattr(ops, name, globals()[name])

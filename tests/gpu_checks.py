@@ -742,7 +742,7 @@ def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):
             "g_w2_rel_err": rel(gw["linear2.weight"], ref.linear2.weight.grad)}
 
 
-def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None):
+def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None, nonlinearity_type="gate"):
     """backward of the non-SOC read-out head (K6 + HamLayer): gradient of sum(H * G) with respect to the representation
     (node_attr, edge_attr) and every head parameter vs torch.autograd through the fp64 oracle"""
     from oracle import hamgnn_ref as R
@@ -754,7 +754,7 @@ def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None):
     prev = torch.get_default_dtype()
     torch.set_default_dtype(torch.float64)
     try:
-        ref = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True)
+        ref = R.HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", symmetrize=True, add_H0=True, nonlinearity_type=nonlinearity_type)
     finally:
         torch.set_default_dtype(prev)
     g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004), nao, seed=seed)
@@ -767,7 +767,8 @@ def check_head_backward(device="cuda", n_atoms=6, seed=1, nao=19, irr=None):
     g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
     (ref(g64, {"node_attr": node, "edge_attr": edge})["hamiltonian"] * G_).sum().backward()
     hip = load_weights(HamGNNPlusPlusOut(irr, irr, nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
-                                         soc_switch=False, calculate_sparsity=False, zero_point_shift=False), dict(ref.state_dict()))
+                                         soc_switch=False, calculate_sparsity=False, zero_point_shift=False, nonlinearity_type=nonlinearity_type),
+                       dict(ref.state_dict()))
     hip.compile(device)
     gd = g.to(device)
     lay = P.PlanarLayout(irr)
@@ -1035,11 +1036,11 @@ def check_corr_product(device="cuda", name="corr_product_block"):
     return {"corr_product_rel_err": rel(y, f["outputs"]["node_features"])}
 
 
-def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, use_planar_path=False):
+def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, use_planar_path=False, nonlinearity_type="gate"):
     from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
     f = load(name)
     m = load_weights(HamGNNPlusPlusOut(MINI, MINI, nao_max=nao, ham_type=ham_type, ham_only=True, symmetrize=True, add_H0=True,
-                                       soc_switch=False, calculate_sparsity=True), f["weights"])
+                                       soc_switch=False, calculate_sparsity=True, nonlinearity_type=nonlinearity_type), f["weights"])
     bb = load("backbone")["graph"]
     gd = dict(f["graph"])
     for k in ("pos", "nbr_shift", "cell"):
@@ -1048,7 +1049,15 @@ def check_head(device="cuda", name="head_openmx_19", ham_type="openmx", nao=19, 
     rep = {"node_attr": torch.from_numpy(f["inputs"]["node_attr"]).float().to(device),
            "edge_attr": torch.from_numpy(f["inputs"]["edge_attr"]).float().to(device)}
     out = m(g, rep)
-    torch.cuda.synchronize()
+    if device != "cpu":
+        torch.cuda.synchronize()
+    if "sparsity_ratio" not in f["outputs"]:                   # (nonlinearity_type = "norm" fixture: the rows, and the edge ResidualBlock on its own)
+        from hamgnn_amd import ops, plan as P
+        lay = P.PlanarLayout(MINI)
+        imap = torch.from_numpy(lay.index_map().astype(np.int32)).to(device)
+        rb = m.offsite_hamiltonian_network.residual_block
+        y = ops.from_planar(rb(ops.to_planar(rep["edge_attr"], imap, lay.dim)), imap)
+        return {name + "_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"]), "residual_block_rel_err": rel(y, f["outputs"]["residual_block_edge"])}
     return {name + "_rel_err": rel(out["hamiltonian"], f["outputs"]["hamiltonian"]), "sparsity_ratio": float(out["sparsity_ratio"]),
             "sparsity_ratio_reference": float(f["outputs"]["sparsity_ratio"][0])}
 
@@ -1227,10 +1236,12 @@ def oracle_vs_hip_random(device="cuda", irreps=MINI, sh=SH, n_atoms=6, seed=0, n
             "H_rel_err": rel(H, H_ref), "H_mae": (H.double().cpu() - H_ref).abs().mean().item()}
 
 
-def check_default_irreps_si2(device="cuda", which="A", graph="si2"):
+def check_default_irreps_si2(device="cuda", which="A", graph="si2", soc=False):
     """BASELINE config #1: Si diamond 2-atom cell (172 edges) with the shipped default irreps (set-A, D=877, l<=6, sh lmax 5,
     64 radial, MLP [64,64], 3 layers, nao 19) -- full HIP forward vs the fp64 oracle.  Exercises every kernel instantiation.
-    graph="sio2_<n>": the generator of BASELINE config #4 (amorphous SiO2) at a size the fp64 oracle affords."""
+    graph="sio2_<n>": the generator of BASELINE config #4 (amorphous SiO2) at a size the fp64 oracle affords;
+    graph="mos2_<k>" with soc=True: BASELINE config #3 (MoS2 monolayer, k x k cells, SOC / so3 read-out hamgnn_output.py:3026-3144) -- the rows
+    compared are [real | imaginary] of the (2 nao)^2 spin blocks."""
     import bench
     from oracle import hamgnn_ref as R
     from hamgnn_amd.data import synthetic as S
@@ -1244,13 +1255,20 @@ def check_default_irreps_si2(device="cuda", which="A", graph="si2"):
     torch.set_default_dtype(torch.float64)
     try:
         ref = R.HamGNNConvE3(cfg)
-        ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", symmetrize=True, add_H0=True)
+        ref_head = R.HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", symmetrize=True, add_H0=True,
+                                       **(dict(soc_switch=True, soc_basis="so3") if soc else {}))
     finally:
         torch.set_default_dtype(prev)
-    g = S.add_random_targets(S.si_diamond(primitive=True) if graph == "si2" else S.amorphous_sio2(int(graph.split("_")[1]), seed=1), 19, seed=0)
+    if graph == "si2":
+        base = S.si_diamond(primitive=True)
+    elif graph.startswith("mos2_"):
+        base = S.mos2_monolayer(int(graph.split("_")[1]), int(graph.split("_")[1]))
+    else:
+        base = S.amorphous_sio2(int(graph.split("_")[1]), seed=1)
+    g = S.add_random_targets(base, 19, seed=0, soc=soc)
     hip = load_weights(HamGNNConvE3(cfg), dict(ref.state_dict()))
     hip_head = load_weights(HamGNNPlusPlusOut(irreps, irreps, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
-                                              soc_switch=False), dict(ref_head.state_dict()))
+                                              soc_switch=soc, soc_basis="so3"), dict(ref_head.state_dict()))
     g64 = type(g)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in g.items()})
     with torch.no_grad():
         rep_ref = ref(g64)
@@ -1263,7 +1281,8 @@ def check_default_irreps_si2(device="cuda", which="A", graph="si2"):
         hip_head.add_H0 = False
         Hn_ref = ref_head(g64, rep_ref)["hamiltonian"]
         Hn = hip_head(gd, rep)["hamiltonian"]
-    torch.cuda.synchronize()
+    if device != "cpu":
+        torch.cuda.synchronize()
     return {"irreps": which, "E": g.num_edges, "Hnet_rel_err": rel(Hn, Hn_ref), "Hnet_absmax": Hn_ref.abs().max().item(), "node_rel_err": rel(rep["node_attr"], rep_ref["node_attr"]),
             "edge_rel_err": rel(rep["edge_attr"], rep_ref["edge_attr"]), "H_rel_err": rel(H, H_ref),
             "H_mae": (H.double().cpu() - H_ref).abs().mean().item(), "H_absmax": H_ref.abs().max().item()}
@@ -1347,6 +1366,20 @@ def check_full_size_properties(device="cuda", workload="si512", which="B", soc=F
         g3 = type(g)(g)
         g3["pos"] = g.pos + torch.tensor([0.37, -1.21, 2.05])
         res["translation_err"] = (run(g3) - H).abs().max().item() / scale
+        # rotation: the spin-diagonal REAL block is the network's spin-free H (real = [[H, A_y], [A_y, H]], hamgnn_output.py:3076-3144),
+        # which does not read the L matrices: under a rigid rotation of the crystal it goes to D H D^T, so its on-site eigenvalues and off-site singular
+        # values are invariant -- every Wigner block / CG path of the SOC run end to end, without rotating the input L data
+        Rm = e3.rand_rotation(torch.Generator().manual_seed(7)).float()
+        g2 = type(g)(g)
+        g2["pos"], g2["nbr_shift"], g2["cell"] = g.pos @ Rm.T, g.nbr_shift @ Rm.T, g.cell @ Rm.T
+        H2 = run(g2)
+        Huu, H2uu = H.real[:, :nao, :nao], H2.real[:, :nao, :nao]
+        s_uu = Huu.abs().max().item()
+        ev, ev2 = torch.linalg.eigvalsh(0.5 * (Huu[:N] + Huu[:N].transpose(1, 2))), torch.linalg.eigvalsh(0.5 * (H2uu[:N] + H2uu[:N].transpose(1, 2)))
+        res["rot_onsite_eig_err"] = (ev - ev2).abs().max().item() / s_uu
+        sel = torch.linspace(0, E - 1, min(E, n_sv), device=device).long()
+        res["rot_offsite_sv_err"] = (torch.linalg.svdvals(Huu[N:][sel]) - torch.linalg.svdvals(H2uu[N:][sel])).abs().max().item() / s_uu
+        res["rot_changes_H"] = (H2uu - Huu).abs().max().item() / s_uu
         torch.cuda.synchronize()
         return res
     Rm = e3.rand_rotation(torch.Generator().manual_seed(7)).float()

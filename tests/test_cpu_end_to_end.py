@@ -82,6 +82,8 @@ _FORWARD_CASES = {
     "head_openmx_19": lambda: G.check_head("cpu"),
     "head_abacus_13": lambda: G.check_head("cpu", "head_abacus_13", "abacus", 13),
     "head_from_planar_rows": lambda: G.check_head("cpu", use_planar_path=True),
+    "head_norm_openmx_19": lambda: G.check_head("cpu", "head_norm_openmx_19", nonlinearity_type="norm"),      # r5: nonlinearity_type = "norm" (NormActivation)
+    "head_backward_norm": lambda: G.check_head_backward("cpu", nonlinearity_type="norm"),
     "head_soc_so3": lambda: G.check_head_soc("cpu"),
     "head_soc_su2": lambda: G.check_head_su2("cpu"),
     "residual_block_backward": lambda: G.check_residual_block_backward("cpu"),

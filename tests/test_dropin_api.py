@@ -301,3 +301,32 @@ def test_checkpoint_round_trip(tmp_path):
     b = Model.load_from_checkpoint(path, **mk())
     for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
         assert ka == kb and torch.equal(va, vb), ka
+
+
+def test_precision_64_raises_instead_of_running_fp32():
+    """the reference's `precision: 64` flow (main.py:469-474: set_default_dtype(float64), model.to(float64), float64 graphs) is not built; it must
+    raise -- on the backbone and on the head, before any tensor is cast down -- rather than return fp32-accurate rows (VERDICT r4, weak #3)"""
+    from hamgnn.main import build_hamgnn_model
+    from hamgnn_amd.data import synthetic as S
+    rep, out, _ = build_hamgnn_model(_config())
+    g = S.random_cell(4, [14, 8], seed=0, density=0.004)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        with pytest.raises(NotImplementedError, match="precision: 64"):
+            rep(g)
+        with pytest.raises(NotImplementedError, match="precision: 64"):
+            out(g, {"node_attr": None, "edge_attr": None})
+    finally:
+        torch.set_default_dtype(prev)
+    rep64, out64, _ = build_hamgnn_model(_config())
+    rep64.double()
+    out64.double()
+    with pytest.raises(NotImplementedError, match="parameters are float64"):
+        rep64(g)
+    with pytest.raises(NotImplementedError, match="parameters are float64"):
+        out64(g, {"node_attr": None, "edge_attr": None})
+    g64 = S.random_cell(4, [14, 8], seed=0, density=0.004)
+    g64.pos = g64.pos.double()
+    with pytest.raises(NotImplementedError, match="data.pos is float64"):
+        rep(g64)

@@ -163,10 +163,12 @@ def test_gradient_allreduce_two_ranks_gloo(tmp_path):
         assert json.load(open(os.path.join(tmp, f"g{r}.json")))["ok"]
 
 
-def _worker_product(rank, world, port, tmp, transformer=False):
+def _worker_product(rank, world, port, tmp, transformer=False, node_shard=False):
     """the PRODUCT's own sharded forward (parallel.shard_graph + the all-reduce hook inside HamGNNConvE3.forward + the head on the local
     edges) on the CPU stand-ins of the kernels, vs the unsharded run"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if node_shard:
+        os.environ["HG_NODE_SHARD"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     from tests import cpu_ops
@@ -181,7 +183,7 @@ def _worker_product(rank, world, port, tmp, transformer=False):
     cpu_ops.install(_MP)
     cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
                cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
-               correlation=2, num_hidden_features=4, use_corr_prod=False)
+               correlation=2, num_hidden_features=4, use_corr_prod=bool(node_shard))
     torch.manual_seed(666)
     irr = MINI
     if transformer:                                             # attention backbone: the soft-max of a node spans the edges of both ranks
@@ -237,6 +239,20 @@ def test_product_sharded_forward_on_cpu_stand_ins_gloo(tmp_path):
     mp.spawn(_worker_product, args=(2, port, tmp), nprocs=2, join=True)
     r = json.loads(open(tmp).read())
     assert r["err"] < 1e-5 and r["on_err"] < 1e-5 and len(r["edges_per_rank"]) == 2 and min(r["edges_per_rank"]) > 0, r
+
+
+def test_product_sharded_forward_row_sharded_node_level_gloo(tmp_path):
+    """HG_NODE_SHARD=1: the node-level chain of every ConvBlock (skip Linear, ResidualBlock, CorrProductBlock) on this rank's block of
+    rows, reduce-scatter before / all-gather after (gloo: all-reduce + slice) -- three ranks on a 5-atom cell (ragged last block) == the unsharded run"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    tmp = str(tmp_path / "prod_ns.json")
+    mp.spawn(_worker_product, args=(3, port, tmp, False, True), nprocs=3, join=True)
+    r = json.loads(open(tmp).read())
+    assert r["err"] < 1e-5 and r["on_err"] < 1e-5 and len(r["edges_per_rank"]) == 3, r
 
 
 def _worker_ddp(rank, world, port, tmp):
