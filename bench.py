@@ -37,8 +37,11 @@ REF_BYTES_PER_EDGE_BLOCK = {"A": 14432.0, "B": 7888.0}
 # HBM bytes per edge of one MessagePackBlock launch from the rocprofv3 PMC passes in profiles/r04_tp_is_pmc.md (set-B: r02b_tp_is_hbm_pmc.md) / r01c_tp_fused_hbm_pmc.md
 # (separate --pmc FETCH_SIZE / WRITE_SIZE runs on tests/bench_tp.py, 131072 edges; FETCH_SIZE x 2: gfx950 correction for
 # 16-B/lane reads, MI355X_MICROARCH.md "HBM"): measured offline for this kernel build, scaled to the launch's edge count.
-# kernel "is" = input-stationary tp_is_kernel (r4: 3.95 GB read + 0.51 GB written per 131 072-edge launch = 34.0 KB per edge), "seg" = segment-stationary tp_fused_kernel
-PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 34.0e3, ("is", "B"): 14.2e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
+# kernel "is" = input-stationary tp_is_kernel, "seg" = segment-stationary tp_fused_kernel.  r5: ("is", "A") is measured ON THE BENCHMARKED LAUNCHES (FETCH_SIZE /
+# WRITE_SIZE passes over `python bench.py`, sio2_10k: profiles/r05_tp_is_pmc.md): fused-scatter ConvBlock launches 21.68 GB read + 0.24 GB written = 26.7 KB per
+# edge, PairInteractionBlock launches (one row per edge) 19.99 GB + 3.19 GB = 28.2 KB per edge; the mean of the two kinds is used (the synthetic bench_tp launch with
+# random sender / receiver indices measured 34.0 KB per edge in r4: the real crystal's neighbour locality keeps more node rows in L2 / Infinity Cache)
+PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 27.4e3, ("is", "B"): 14.2e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
 # ms per million edges of ONE MessagePackBlock launch on one MI355X at full size (profiles/r04_bench_sio2_10k_setA_final.json: 41.95 ms per 822 350 edges;
 # r04_bench_si512_setB.json): the yardstick of the N > 1 lines (per_rank.tp_is_efficiency_vs_1gpu = edge-proportional time at that rate / measured time)
 REF_TP_MS_PER_MEDGE_LAUNCH = {"A": 51.02, "B": 21.49}
@@ -74,7 +77,7 @@ def make_graph(workload, nao, soc=False):
     return S.add_random_targets(g, nao, seed=0, soc=soc)
 
 
-def cpu_baseline(workload, irreps_key, nao, budget_s=40.0, lite=False, soc=False, reps=3):
+def cpu_baseline(workload, irreps_key, nao, budget_s=30.0, lite=False, soc=False, reps=3):
     """Oracle (unfused torch port of the reference op graph: one einsum chain per e3nn instruction, materialised `mid`, index_add_ scatter) on the
     host cores, on a BOUNDED sample of the same workload: the largest crystal of the workload's generator whose forward fits budget_s / (reps + 1)
     seconds, `reps` timed forwards (median reported, all times listed), the thread count picked from 8 ... all host threads by a calibration run.
@@ -110,13 +113,14 @@ def cpu_baseline(workload, irreps_key, nao, budget_s=40.0, lite=False, soc=False
     g0 = graph(12)
     run(g0)                                    # warm-up (first touch, thread pool, the cached 3j tensors)
     tried = {}
-    for c in cand:                             # these small ops scale poorly with threads: try every count, keep the fastest, report all
-        torch.set_num_threads(c)
-        tried[c] = min(run(g0), run(g0))
+    for c in cand:                             # these small ops scale poorly with threads: try the counts in rising order, stop at the first that is slower
+        torch.set_num_threads(c)               # than the one before it (measured on the 256-thread host: beyond 32 threads the port gets slower), keep the fastest
+        tried[c] = run(g0)
+        if len(tried) > 1 and tried[c] > 1.15 * min(tried.values()):
+            break
     cores = min(tried, key=tried.get)
     torch.set_num_threads(cores)
-    per_edge = tried[cores] / g0.num_edges
-    per_rep = budget_s / (reps + 1)
+    per_rep = max(2.0, (budget_s - sum(tried.values())) / (reps + 0.5))
     n_atoms = max(12, min(int(g0.num_nodes * per_rep / tried[cores]), 4000))
     g = graph(n_atoms) if n_atoms > g0.num_nodes else g0
     times = [run(g) for _ in range(reps)]
@@ -125,7 +129,8 @@ def cpu_baseline(workload, irreps_key, nao, budget_s=40.0, lite=False, soc=False
             "seconds_per_forward": [round(t, 2) for t in times], "threads_tried": {str(k): round(g0.num_edges / v, 1) for k, v in tried.items()},
             "host_threads": ncpu,
             "sample": f"{workload}-like crystal, {g.num_nodes} atoms / {g.num_edges} directed edges{', SOC/so3 head' if soc else ''}, median of {reps} forwards, fp32, "
-                      f"torch {cores} threads (fastest of {sorted(tried)} on a {g0.num_edges}-edge calibration crystal: edges/s per count in threads_tried)"}
+                      f"torch {cores} threads (fastest of {sorted(tried)} tried in rising order on a {g0.num_edges}-edge calibration crystal, stopping at the first slower count: "
+                      f"edges/s per count in threads_tried)"}
 
 
 # BASELINE config #5 (Uni-HamGNN universal model, mixed-Z periodic-table batch): Z drawn from the 26-orbital OpenMX table -- light ... heavy,
@@ -440,7 +445,8 @@ def main():
     pmc_bytes = PMC_HBM_BYTES_PER_EDGE_BLOCK[(kern, args.irreps)]
     roofline = {"kernel": ("tp_is_kernel (input-stationary" if kern == "is" else "tp_fused_kernel (segment-stationary") + " MessagePackBlock launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": pmc_bytes * rows_per_launch,
-                "traffic_unit": "bytes per launch (PMC, measured offline: profiles/r04_tp_is_pmc.md (set-B: r02b_tp_is_hbm_pmc.md), r01c_tp_fused_hbm_pmc.md)", "avg_launch_ms": avg_s * 1e3,
+                "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, measured offline on the benchmarked launches of this kernel build: profiles/r05_tp_is_pmc.md; "
+                                "set-B: r02b_tp_is_hbm_pmc.md, segment-stationary kernel: r01c_tp_fused_hbm_pmc.md), scaled to this launch's edge count", "avg_launch_ms": avg_s * 1e3,
                 "launches_timed": len(mp), "edges_per_launch": rows_per_launch,
                 "executed_useful_tflops": useful / avg_s / 1e12, "issued_mfma_tflops": issued / avg_s / 1e12,
                 "hbm_algorithmic_GBs": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9,
