@@ -81,7 +81,8 @@ struct WdLay {
     int sbuf_off;                // S buffer: slot s at + 256 s floats, lane's float4 at + 4 lane
     int flag_off;                // S-ready flags (ints)
     int stage_floats;            // staging buffer b at A.stage_off + b * stage_floats
-    int nflag;
+    int nflag;                   // ints between flag_off and the end of the LDS image (flags + counters): zeroed at kernel start
+    int own;                     // 1: "own" schedule (plan.wide_schedule(mode="own")): one record stream per wave for the whole tile, counters instead of barriers
 };
 
 typedef volatile __attribute__((address_space(3))) int* wd_vint_p;
@@ -228,6 +229,25 @@ __device__ __forceinline__ void wd_task_S(const IsArgs& A, const WdLay& Ly, cons
     for (int rt = 0; rt < RTM; ++rt) *reinterpret_cast<f32x4*>(sb + rt * 256) = S[rt];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the fragments are in the LDS before the flag is
     if (lane == 0) *(wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16)) = stamp;
+}
+
+// "own" schedule: synchronisation records.  Monotonic counters in LDS (zeroed per tile): done[p] = waves that finished their compute records of phase p,
+// staged[p] = waves whose staging shares of phase p have landed.  A wait spins (bounded: a broken schedule poisons the tile with NaN instead of hanging the GPU).
+__device__ __forceinline__ void wd_sync_record(const IsArgs& A, const wd_rec_t& T, float* __restrict__ lds, int lane) {
+    wd_vint_p c = (wd_vint_p)(reinterpret_cast<int*>(lds + A.ctr_off) + T[1]);
+    if (T[0] & 4) {                                            // signal
+        if (T[2]) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the LDS-DMA of this wave's staging shares has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads / writes so far are complete
+        if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<int*>(lds + A.ctr_off) + T[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        int spin = 0;
+        while (*c < T[2] && spin < (1 << 18)) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spin;
+        }
+        if (spin >= (1 << 18) && lane == 0) lds[0] = __builtin_nanf("");
+        asm volatile("" ::: "memory");
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- compute task
@@ -428,7 +448,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
 #undef WD_NK2_OK
 }
 
-#define WD_CASE(NCWv, RTMv) case (NCWv * 8 + RTMv): wd_task_compute<NCWv, RTMv>(A, Ly, g_W, T, lds, lane, pl WD_PROF_PASS); break;
+#define WD_CASE(NCWv, RTMv) case (NCWv * 8 + RTMv): wd_task_compute<NCWv, RTMv>(A, Ly, g_W, T, lds, lane, T[10] WD_PROF_PASS); break;
 
 __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const WdLay Ly, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
                                                            const int* __restrict__ g_streams, const int* __restrict__ g_recs,
@@ -454,13 +474,14 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
         int* __restrict__ rt_l = reinterpret_cast<int*>(lds + A.rowtab_off);
         for (int i = threadIdx.x; i < A.rowtab_len; i += NT) rt_l[i] = g_rowtab[i];
         int* __restrict__ fl = reinterpret_cast<int*>(lds + Ly.flag_off);
-        for (int i = threadIdx.x; i < Ly.nflag; i += NT) fl[i] = 0;                       // S-ready flags
+        for (int i = threadIdx.x; i < Ly.nflag; i += NT) fl[i] = 0;                       // S-ready flags (+ the counters of the own schedule)
     }
     __syncthreads();
     WD_TL(8);                                                   // zero fill
     const int npool = A.nphase + 1;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // (uniform by construction; says so to the compiler: the records travel in SGPRs)
-    for (int pl = 0; pl < npool; ++pl) {
+    const int npool_run = Ly.own ? 1 : npool;                   // own schedule: ONE stream per wave for the whole tile, no barrier between phases
+    for (int pl = 0; pl < npool_run; ++pl) {
         // this wave's records of the pool: [S tasks | compute chains | staging shares of the next phase], back to back; the next record is requested
         // (one s_load_dwordx16) before the current one runs
         const int r0 = g_streams[2 * (pl * NW + wave_u)], r1 = g_streams[2 * (pl * NW + wave_u) + 1];
@@ -471,7 +492,10 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
             const wd_rec_t Tn = recs[ri + 1 < r1 ? ri + 1 : ri];
             const int kind = WD_KIND(T);
             WD_T(0);                                            // record
-            if (kind == 0) {                                   // a share of one input block of the next phase -> the other staging buffer
+            if (kind == 3) {
+                wd_sync_record(A, T, lds, lane);
+                WD_T(6);
+            } else if (kind == 0) {                                   // a share of one input block of the next phase -> the other staging buffer
 #ifndef WD_ABL_NOSTAGE                                          // (ablation builds: timing attribution only, wrong results)
                 const int* __restrict__ B = g_blocks + T[1] * 8;
                 float* __restrict__ sbuf = stage + WD_BIT8(T) * Ly.stage_floats;
@@ -489,13 +513,13 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
                 WD_T(1);                                        // staging share
             } else if (kind == 1) {
 #ifdef WD_ABL_NOS
-                if (lane == 0) *(wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16)) = pl;
+                if (lane == 0) *(wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16)) = T[10];
 #else
                 switch (WD_RTM(T)) {
-                    case 1: wd_task_S<1>(A, Ly, g_W, T, lds, erow, lane, pl); break;
-                    case 2: wd_task_S<2>(A, Ly, g_W, T, lds, erow, lane, pl); break;
-                    case 3: wd_task_S<3>(A, Ly, g_W, T, lds, erow, lane, pl); break;
-                    default: wd_task_S<4>(A, Ly, g_W, T, lds, erow, lane, pl); break;
+                    case 1: wd_task_S<1>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
+                    case 2: wd_task_S<2>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
+                    case 3: wd_task_S<3>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
+                    default: wd_task_S<4>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
                 }
 #endif
                 WD_T(2);                                        // S task
@@ -592,7 +616,7 @@ extern "C" int hg_prof_wd_read(unsigned long long* out16, int reset) {
 
 extern "C" int hg_wide_waves(void) { return WD_NW; }
 
-// lay_host, int32[12] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off, lds_floats}
+// lay_host, int32[16] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off, lds_floats, own, 0, 0, 0}
 extern "C" int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge, int hidden,
                           const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table, const int32_t* block_table,
                           const int32_t* stream_table, const int32_t* rec_table, const int32_t* row_table, const int32_t* lay_host,
@@ -606,7 +630,7 @@ extern "C" int hg_tp_wide(const float* const* src, const int64_t* src_stride, in
     const int32_t* q = lay_host;
     const int lds_bytes = 4 * q[11];
     if (lds_bytes <= 0 || lds_bytes > 160 * 1024) return hg_fail(-2, "hg_tp_wide: bad LDS size");
-    if (q[1] < 1 || q[1] + 1 > 64 || q[10] - q[9] < 1 || q[11] < q[10] + 64 || q[9] < q[7] + 256 * q[8] || q[7] < q[5] + 2 * q[6] || q[5] < q[3] + q[4] || q[3] < q[2])
+    if (q[1] < 1 || q[1] + 1 > 64 || q[10] - q[9] < 1 || q[11] < q[10] + (q[12] ? 128 : 1) || q[9] < q[7] + 256 * q[8] || q[7] < q[5] + 2 * q[6] || q[5] < q[3] + q[4] || q[3] < q[2])
         return hg_fail(-2, "hg_tp_wide: bad LDS layout");
     IsArgs A;
     for (int i = 0; i < 4; ++i) {
@@ -625,7 +649,7 @@ extern "C" int hg_tp_wide(const float* const* src, const int64_t* src_stride, in
     A.tile_shift = 0;
     A.nseg = q[0], A.nphase = q[1], A.trash_off = q[2], A.rowtab_off = q[3], A.rowtab_begin = 0, A.rowtab_len = q[4], A.stage_off = q[5], A.ctr_off = q[10];
     WdLay Ly;
-    Ly.stage_floats = q[6], Ly.sbuf_off = q[7], Ly.flag_off = q[9], Ly.nflag = q[10] - q[9];
+    Ly.stage_floats = q[6], Ly.sbuf_off = q[7], Ly.flag_off = q[9], Ly.nflag = q[11] - q[9], Ly.own = q[12] ? 1 : 0;
     for (int i = 0; i < 4; ++i) A.idx[i] = (src_idx && i < nsrc) ? src_idx[i] : nullptr;
     A.rot_mask = rot_mask;
     A.eperm = edge_perm;

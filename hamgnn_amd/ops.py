@@ -147,7 +147,7 @@ class DeviceProgram:
                 ws = P.wide_schedule(self.prog)
                 lay = ws.lay
                 host = np.ascontiguousarray(np.asarray([ws.seg_table.shape[0], ws.nphase, lay["trash_off"], lay["rowtab_off"], len(ws.rowtab), lay["stage_off"],
-                                                        lay["stage_floats"], lay["sbuf_off"], lay["sbuf_slots"], lay["flag_off"], lay["ctr_off"], lay["lds_floats"]], np.int32))
+                                                        lay["stage_floats"], lay["sbuf_off"], lay["sbuf_slots"], lay["flag_off"], lay["ctr_off"], lay["lds_floats"], lay.get("own", 0), 0, 0, 0], np.int32))
                 self._wide = (ws, tuple(_dev(t, self._device) for t in (ws.seg_table, ws.block_table, ws.stream_table, ws.rec_table, ws.rowtab)), host)
             except NotImplementedError:
                 self._wide = False

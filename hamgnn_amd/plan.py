@@ -375,7 +375,10 @@ WIDE_WAVES = int(os.environ.get("HG_WIDE_WAVES", "16"))   # = WD_NW of csrc/tp_w
 WIDE_LDS_BYTES = 160 * 1024
 WIDE_TASK_I32 = 32                                        # logical record (planner, emulator)
 WIDE_REC_I32 = 16                                         # packed device record: ONE s_load_dwordx16 (wide_pack_record)
-WT_STAGE, WT_S, WT_COMPUTE = 0, 1, 2
+WT_STAGE, WT_S, WT_COMPUTE, WT_WAIT, WT_SIGNAL = 0, 1, 2, 3, 4
+WIDE_MODE_SCHED = os.environ.get("HG_WIDE_SCHED", "pools")   # "pools": one barrier per phase, the phase's work dealt to the waves per pool; "own": every wave OWNS fixed
+#                                                            (segment key, column window) cells for the whole tile, no barriers between phases (counters in LDS)
+WIDE_COUNTERS = 192                                       # own mode: done[phase] at + 0, staged[phase] at + 64 (ints behind the flags)
 WIDE_COST_REC = float(os.environ.get("HG_WIDE_COST_REC", "24"))      # cost model of the static streams, in MFMA slots: per record,
 WIDE_COST_STAGE = float(os.environ.get("HG_WIDE_COST_STAGE", "60"))  # per staging share (latency-bound: gathered node rows)
 WIDE_STAGE_POS = os.environ.get("HG_WIDE_STAGE_POS", "end")          # where a wave's staging shares sit in its stream: "end" (under the other waves' compute tails) / "begin"
@@ -444,7 +447,10 @@ def wide_pack_record(rec) -> List[int]:
     w4 = A1 fragments   w5 = packed coefficients   w6 = A2 fragments   w7 = first S slot | flag << 16   w8 = first output row (IT_LIN)   w9 = row-table base"""
     kind = int(rec[0])
     w = [0] * WIDE_REC_I32
-    if kind == WT_STAGE:
+    if kind in (WT_WAIT, WT_SIGNAL):                           # own mode: w1 = counter (int index behind ctr_off), w2 = value to wait for / 1: drain the vector-memory queue first
+        w[0] = 3 | ((1 << 2) if kind == WT_SIGNAL else 0)      # (the kind field has two bits: 3 = synchronisation record, bit 2 set = signal)
+        w[1], w[2] = int(rec[1]), int(rec[2])
+    elif kind == WT_STAGE:
         w[0] = kind | (int(rec[5]) << 8) | (int(rec[4]) << 11)
         w[1], w[2], w[3] = int(rec[1]), int(rec[2]), int(rec[3])
     elif kind == WT_S:
@@ -452,6 +458,7 @@ def wide_pack_record(rec) -> List[int]:
         w[0] = kind | (int(rec[2]) << 2) | (int(rec[3]) << 8)
         w[1] = int(rec[1])
         w[7] = int(rec[4]) | (int(rec[5]) << 16)
+        w[10] = int(rec[6])                                    # stamp the flag takes
     else:
         rtm, ncw, typ, x4, neg, li, mm, rto, nk2, c0 = (int(rec[k]) for k in (9, 15, 19, 17, 7, 5, 6, 22, 18, 13))
         assert 1 <= rtm <= 4 and 1 <= ncw <= 7 and typ in (0, 1) and li < 8 and mm < 8 and rto < 16 and nk2 < 32 and c0 < 16
@@ -463,6 +470,7 @@ def wide_pack_record(rec) -> List[int]:
         assert slot < (1 << 16) and int(rec[10]) < (1 << 15)
         w[7] = slot | (int(rec[10]) << 16)
         w[8], w[9] = int(rec[16]), int(rec[23])
+        w[10] = int(rec[20])                                   # stamp the item's S flag carries when its fragments are there
     assert all(-(1 << 31) <= v < (1 << 31) for v in w)
     return w
 
@@ -472,34 +480,48 @@ def wide_unpack_record(w) -> List[int]:
     w = [int(v) for v in w]
     kind = w[0] & 3
     rec = [0] * WIDE_TASK_I32
+    if kind == 3:
+        rec[0] = WT_SIGNAL if (w[0] >> 2) & 1 else WT_WAIT
+        rec[1], rec[2] = w[1], w[2]
+        return rec
     rec[0] = kind
     if kind == WT_STAGE:
         rec[1], rec[2], rec[3], rec[4], rec[5] = w[1], w[2], w[3], (w[0] >> 11) & 7, (w[0] >> 8) & 1
     elif kind == WT_S:
-        rec[1], rec[2], rec[3], rec[4], rec[5] = w[1], (w[0] >> 2) & 7, (w[0] >> 8) & 1, w[7] & 0xffff, w[7] >> 16
+        rec[1], rec[2], rec[3], rec[4], rec[5], rec[6] = w[1], (w[0] >> 2) & 7, (w[0] >> 8) & 1, w[7] & 0xffff, w[7] >> 16, w[10]
     else:
         rec[9], rec[15], rec[19], rec[17], rec[7] = (w[0] >> 2) & 7, (w[0] >> 5) & 7, (w[0] >> 8) & 1, (w[0] >> 9) & 1, (w[0] >> 10) & 1
         rec[5], rec[6], rec[22], rec[18], rec[13] = (w[0] >> 11) & 7, (w[0] >> 14) & 7, (w[0] >> 17) & 15, (w[0] >> 21) & 31, (w[0] >> 26) & 15
         rec[1], rec[2], rec[4], rec[8] = w[1], w[2], w[3] & 0xffff, w[3] >> 16
         rec[11], rec[12], rec[14] = w[4], w[5], w[6]
         rec[3], rec[10] = (w[7] & 0xffff) if rec[19] == IT_TP else -1, w[7] >> 16
-        rec[16], rec[23] = w[8], w[9]
+        rec[16], rec[23], rec[20] = w[8], w[9], w[10]
     return rec
 
 
-def wide_schedule(prog: "Program") -> WideSchedule:
+def wide_schedule(prog: "Program", mode: Optional[str] = None) -> WideSchedule:
     """Cut a finalized tensor-product program into the per-wave record streams of csrc/tp_wide.hip.  Raises NotImplementedError when the program has no wide
     form (lite_mode items, tiles + two staging buffers + a useful S buffer beyond the CU's LDS).
     A tile cell (row of an output segment, column m) may be updated by ONE wave per phase (read-modify-write in LDS), and several items of a phase feed the
     same segment: the unit of compute work is therefore a CHAIN = all items of one (phase, segment key) restricted to a window of columns m, run one after
     the other by one wave.  An item whose share of the window exceeds the register budget (wide_ncw_cap), or straddles the centre column an odd item
-    skips, appears as several records of the chain.  The chains, S tasks and staging shares of a pool are dealt to the waves by LPT on a cost model (MFMAs
-    + WIDE_COST_REC per record; WIDE_COST_STAGE per staging share); a wave's stream is [its S tasks | its compute chains | its staging shares of the next
-    phase]: S tasks never wait, so a compute record that waits for another wave's S fragments cannot deadlock.
+    skips, appears as several records of the chain.
+    mode "pools" (default): the chains, S tasks and staging shares of a phase are dealt to the waves by LPT on a cost model (MFMAs + WIDE_COST_REC per record;
+    WIDE_COST_STAGE per staging share); a wave's stream of the pool is [its S tasks | its compute chains | its staging shares of the next phase]; one workgroup barrier
+    per phase.  S tasks never wait, so a compute record that waits for another wave's S fragments cannot deadlock.
+    mode "own": the column windows of a segment key are FIXED for the whole tile and every window belongs to one wave (LPT on its cost over all phases), so no tile
+    cell is ever touched by two waves and the phases need no barrier: a wave's stream for the whole tile is, phase by phase,
+        [wait done[p-2] == W] its S tasks of p (S buffer p & 1)  [wait staged[p] == n_p] its compute records of p  [signal done[p]]
+        [wait done[p-1] == W] its staging shares of p + 1 (staging buffer (p + 1) & 1)  [drain + signal staged[p+1]]
+    with monotonic counters in LDS (WT_WAIT / WT_SIGNAL records): the waves drift by up to a phase or two and only their TOTAL loads have to balance.  Every wait
+    points at records of earlier phases of other streams: no cycle.  The S buffer and the S flags are double-buffered by phase parity.
     Logical record (int32[32]), [0] = kind.  WT_STAGE: [1] block, [2] share, [3] shares, [4] l of the block, [5] staging buffer.  WT_S: [1] float offset of
-    the item's W3 fragments, [2] row tiles, [3] radial generator, [4] first S slot, [5] flag.  WT_COMPUTE: the item's record fields at their IS positions
+    the item's W3 fragments, [2] row tiles, [3] radial generator, [4] first S slot, [5] flag, [6] stamp.  WT_COMPUTE: the item's record fields at their IS positions
     ([1], [2] stage offsets incl. the buffer, [4..9], [11], [14], [16..18], [22], [23]) and [3] first S slot, [10] flag, [12] float offset of the record's
-    packed CG coefficients, [13] first real column, [15] columns, [19] item type."""
+    packed CG coefficients, [13] first real column, [15] columns, [19] item type, [20] stamp of the S flag.  WT_WAIT / WT_SIGNAL: [1] counter, [2] value / drain."""
+    mode = mode or WIDE_MODE_SCHED
+    assert mode in ("pools", "own")
+    own = mode == "own"
     hp4 = prog.hidden_pad // 4
     if np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST, IT_STREAM)).any():
         raise NotImplementedError("wide schedule: lite_mode programs run on the input-stationary kernel")
@@ -512,10 +534,15 @@ def wide_schedule(prog: "Program") -> WideSchedule:
     need = max(int(b[5]) * ceil_div((2 * int(b[4]) + 1) * (int(b[3]) // 4), 4) * 256 for b in probe["btab"])
     total = WIDE_LDS_BYTES // 4
     sf = need
-    slots = (total - base - 2 * sf - WIDE_FLAGS - 64) // 256
-    if slots < 8:
+    nflag = 2 * WIDE_FLAGS if own else WIDE_FLAGS
+    nctr = WIDE_COUNTERS if own else 64
+    slots = (total - base - 2 * sf - nflag - nctr) // 256
+    if own:
+        slots -= slots % 2
+    cap_slots = slots // 2 if own else slots                    # row tiles of scales one phase may hold
+    if cap_slots < 8:
         raise NotImplementedError("wide schedule: the output tiles and two staging buffers leave no room for the radial-scale buffer")
-    sub = _is_schedule_part(prog, members, hp4, 0, 0, 0, 0, waves=WIDE_WAVES, stage_floats_fixed=sf, srt_cap=slots, wig_floats=2 * sf + 256 * slots)
+    sub = _is_schedule_part(prog, members, hp4, 0, 0, 0, 0, waves=WIDE_WAVES, stage_floats_fixed=sf, srt_cap=cap_slots, wig_floats=2 * sf + 256 * slots)
     assert int(sub["stage_off"]) == base and not sub["copy_stride"]
     items = sub["items"]                                        # IS item records, phase by phase, work group by work group
     ptab, gtab = sub["ptab"], sub["gtab"]
@@ -523,9 +550,9 @@ def wide_schedule(prog: "Program") -> WideSchedule:
     stage_off = base
     sbuf_off = stage_off + 2 * sf
     flag_off = sbuf_off + slots * 256
-    ctr_off = flag_off + WIDE_FLAGS
+    ctr_off = flag_off + nflag
     lay = dict(trash_off=int(sub["trash_off"]), rowtab_off=int(sub["rowtab_off"]), stage_off=stage_off, stage_floats=sf, sbuf_off=sbuf_off, sbuf_slots=slots,
-               flag_off=flag_off, ctr_off=ctr_off, lds_floats=ctr_off + 64)
+               flag_off=flag_off, ctr_off=ctr_off, lds_floats=ctr_off + nctr, own=int(own))
     assert lay["lds_floats"] <= total
     if nphase + 1 > 64:
         raise NotImplementedError("wide schedule: more than 63 phases")
@@ -558,115 +585,245 @@ def wide_schedule(prog: "Program") -> WideSchedule:
         mm = int(r[6])
         return 2 * mm if (int(r[0]) == IT_TP and int(r[7]) and mm > 0) else 2 * mm + 1
 
+    def col_has(r, m):
+        mm = int(r[6])
+        return abs(m) <= mm and not (m == 0 and int(r[0]) == IT_TP and int(r[7]) and mm > 0)
+
+    phase_groups = []                                           # per phase: the work groups (items of one segment key)
+    for ph in range(nphase):
+        g0, g1 = int(ptab[ph][2]), int(ptab[ph][3])
+        phase_groups.append([[items[i] for i in range(int(gtab[gi][0]), int(gtab[gi][1]))] for gi in range(g0, g1)])
+        if sum(len(g) for g in phase_groups[-1]) > WIDE_FLAGS:
+            raise NotImplementedError("wide schedule: more items in one phase than S-ready flags")
+    unmap = {new: old for old, new in sub["remap"].items()}      # schedule segment index -> program segment index
+    key_of = lambda recs: int(prog.seg_key.get(unmap[int(recs[0][19])], unmap[int(recs[0][19])]))      # the work-group key (merged items: the group's first member)
+
     tasks: List[List[int]] = []
     chains: List[List[int]] = []
-    streams: List[List[List[int]]] = []
-    tot_cost, crit_cost, mfma_tasks = 0.0, 0.0, 0
+    mfma_tasks = 0
 
-    def deal(pool_index: int, s_units, c_units, st_units):
-        """LPT over the waves (largest unit first onto the least loaded wave); a wave's stream = its S tasks, its compute chains (dearest first), its
-        staging shares"""
-        nonlocal tot_cost, crit_cost
+    def window_records(ph, info, m_lo, m_hi):
+        """the records of the items `info` = [(item, S slot, flag)] restricted to the columns m_lo..m_hi -> (cost, [records])"""
+        nonlocal xoff, mfma_tasks
+        chain, ccost = [], 0.0
+        for r, my_slot, my_fi in info:
+            typ, mm, rtm = int(r[0]), int(r[6]), int(r[9])
+            odd = bool(typ == IT_TP and int(r[7]) and mm > 0)
+            lo, hi = max(m_lo, -mm), min(m_hi, mm)
+            if lo > hi:
+                continue
+            runs = [(lo, hi)]
+            if odd and lo <= 0 <= hi:                          # the centre column of an odd item is structurally zero: not computed
+                runs = [(a_, b_) for a_, b_ in ((lo, -1), (1, hi)) if a_ <= b_]
+            cap = wide_ncw_cap(rtm)
+            cfull = wts[int(r[13]):int(r[13]) + rtm * (2 * mm + 1) * 16].reshape(rtm, 2 * mm + 1, 4, 4) if typ == IT_TP else None   # [rt][c][g][r]
+            for a_, b_ in runs:
+                n = b_ - a_ + 1
+                k = ceil_div(n, cap)
+                base_n, rem = divmod(n, k)
+                o = a_
+                for j in range(k):
+                    ncw = base_n + (1 if j < rem else 0)
+                    c0 = o + mm                                # first real column of the record
+                    o += ncw
+                    rec = [0] * WIDE_TASK_I32
+                    rec[0] = WT_COMPUTE
+                    rec[1] = int(r[1]) + (ph & 1) * sf                 # stage offsets inside the phase's buffer
+                    rec[2] = int(r[2]) + (ph & 1) * sf if int(r[2]) >= 0 else -1
+                    rec[3] = my_slot
+                    for q in (4, 5, 6, 7, 8, 9, 11, 14, 16, 17, 18, 22, 23):
+                        rec[q] = int(r[q])
+                    rec[10] = my_fi
+                    rec[13], rec[15], rec[19], rec[20] = c0, ncw, typ, ph + 1
+                    if typ == IT_TP:                           # the record's CG coefficients, packed: lane (g, p = rt * ncw + j) holds the float4 over r
+                        pk = np.zeros((4, 16, 4), dtype=wts.dtype)
+                        for rt in range(rtm):
+                            for jj in range(ncw):
+                                pk[:, rt * ncw + jj, :] = cfull[rt, c0 + jj]
+                        extra.append(pk.reshape(-1))
+                        rec[12] = xbase + xoff
+                        xoff += 256
+                    cc = col_cost(r) * ncw
+                    mfma_tasks += cc
+                    ccost += cc + WIDE_COST_REC
+                    chain.append(rec)
+        return ccost, chain
+
+    def phase_s_units(ph):
+        """(S task units, per group [(item, S slot, flag)]) of a phase"""
+        nonlocal mfma_tasks
+        s_units, infos = [], []
+        slot, fi = 0, 0
+        sbase = (ph & 1) * cap_slots if own else 0
+        fbase = (ph & 1) * WIDE_FLAGS if own else 0
+        for recs in phase_groups[ph]:
+            info = []
+            for r in recs:
+                typ, rtm = int(r[0]), int(r[9])
+                my_slot = -1
+                if typ == IT_TP:
+                    my_slot = sbase + slot
+                    slot += rtm
+                    rec = [0] * WIDE_TASK_I32
+                    rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6] = WT_S, int(r[12]), rtm, int(r[10]), my_slot, fbase + fi, ph + 1
+                    s_units.append((hp4 * rtm + WIDE_COST_REC, [rec]))
+                    mfma_tasks += hp4 * rtm
+                info.append((r, my_slot, fbase + fi))
+                fi += 1
+            infos.append(info)
+        assert slot <= cap_slots
+        return s_units, infos
+
+    if not own:
+        # ---------------------------------------------------------------- pools: one barrier per phase, every pool dealt on its own
+        streams: List[List[List[int]]] = []
+        tot_cost, crit_cost = 0.0, 0.0
+
+        def deal(pool_index: int, s_units, c_units, st_units):
+            """LPT over the waves (largest unit first onto the least loaded wave); a wave's stream = its S tasks, its compute chains (dearest first), its
+            staging shares"""
+            nonlocal tot_cost, crit_cost
+            loads = [0.0] * W
+            mine = [([], [], []) for _ in range(W)]
+            allu = [(c, 0, u) for c, u in s_units] + [(c, 1, u) for c, u in c_units] + [(c, 2, u) for c, u in st_units]
+            for c, cls, u in sorted(allu, key=lambda t: -t[0]):
+                w = loads.index(min(loads))
+                loads[w] += c
+                mine[w][cls].append((c, u))
+            row = []
+            for w in range(W):
+                r0 = len(tasks)
+                order = (mine[w][2] + mine[w][0] + mine[w][1]) if WIDE_STAGE_POS == "begin" else (mine[w][0] + mine[w][1] + mine[w][2])
+                for c, u in order:
+                    chains.append([len(tasks), len(tasks) + len(u), pool_index])
+                    tasks.extend(u)
+                row.append([r0, len(tasks)])
+            streams.append(row)
+            if pool_index > 0:
+                tot_cost += sum(loads)
+                crit_cost += max(loads)
+
+        deal(0, [], [], stage_units(0))
+        for ph in range(nphase):
+            groups = phase_groups[ph]
+            ctot = sum(col_cost(r) * ncols(r) + WIDE_COST_REC for g in groups for r in g)
+            target = max(ctot / (W * WIDE_TASKS_PER_WAVE), 48.0)
+            s_units, infos = phase_s_units(ph)
+            c_units = []
+            for recs, info in zip(groups, infos):
+                for (m_lo, m_hi) in _wide_group_windows(recs, col_cost, target):
+                    ccost, chain = window_records(ph, info, m_lo, m_hi)
+                    if chain:
+                        c_units.append((ccost, chain))
+            deal(ph + 1, s_units, c_units, stage_units(ph + 1) if ph + 1 < nphase else [])
+        stream_np = np.asarray(streams, np.int32).reshape(nphase + 1, W, 2)
+        balance = tot_cost / (W * crit_cost) if crit_cost else 1.0
+        crit = crit_cost
+    else:
+        # ---------------------------------------------------------------- own: fixed (segment key, column window) -> wave for the whole tile
+        keycost: Dict[int, Dict[int, float]] = {}              # key -> column m -> cost over all phases
+        for ph in range(nphase):
+            for recs in phase_groups[ph]:
+                d = keycost.setdefault(key_of(recs), {})
+                for r in recs:
+                    for m in range(-int(r[6]), int(r[6]) + 1):
+                        if col_has(r, m):
+                            d[m] = d.get(m, 0.0) + col_cost(r) + WIDE_COST_REC / max(1, ncols(r))
+        grand = sum(sum(d.values()) for d in keycost.values())
+        target = grand / (W * WIDE_TASKS_PER_WAVE)              # cost of one ownership piece
+        pieces = []                                            # (cost, key, m_lo, m_hi)
+        for key, d in keycost.items():
+            ms = sorted(d)
+            tot_k = sum(d.values())
+            nwin = int(max(1, min(len(ms), round(tot_k / target))))
+            lo_i, acc, made = 0, 0.0, 0
+            for i, m in enumerate(ms):
+                acc += d[m]
+                left_cols, left_wins = len(ms) - 1 - i, nwin - made - 1
+                if left_wins > 0 and (acc >= (made + 1) * tot_k / nwin - 1e-9 or left_cols <= left_wins) and left_cols >= left_wins:
+                    pieces.append((sum(d[x] for x in ms[lo_i:i + 1]), key, ms[lo_i], m))
+                    lo_i, made = i + 1, made + 1
+            pieces.append((sum(d[x] for x in ms[lo_i:]), key, ms[lo_i], ms[-1]))
         loads = [0.0] * W
-        mine = [([], [], []) for _ in range(W)]
-        allu = [(c, 0, u) for c, u in s_units] + [(c, 1, u) for c, u in c_units] + [(c, 2, u) for c, u in st_units]
-        for c, cls, u in sorted(allu, key=lambda t: -t[0]):
+        owner: Dict[Tuple[int, int, int], int] = {}
+        for c, key, m_lo, m_hi in sorted(pieces, key=lambda t: -t[0]):
             w = loads.index(min(loads))
             loads[w] += c
-            mine[w][cls].append((c, u))
+            owner[(key, m_lo, m_hi)] = w
+        wins_of_key: Dict[int, List[Tuple[int, int, int]]] = {}
+        for (key, m_lo, m_hi), w in owner.items():
+            wins_of_key.setdefault(key, []).append((m_lo, m_hi, w))
+        wave_recs: List[List[List[int]]] = [[] for _ in range(W)]
+
+        def sync(kind, counter, value):
+            rec = [0] * WIDE_TASK_I32
+            rec[0], rec[1], rec[2] = kind, counter, value
+            return rec
+        DONE, STAGED = 0, 64
+        # prologue: the staging shares of phase 0
+        st0 = stage_units(0)
+        mine0 = [[] for _ in range(W)]
+        for c, u in st0:
+            w = loads.index(min(loads))
+            loads[w] += c
+            mine0[w].append(u)
+        n_staged = [0] * (nphase + 1)
+        n_staged[0] = sum(1 for w in range(W) if mine0[w])
+        for w in range(W):
+            for u in mine0[w]:
+                wave_recs[w] += u
+            if mine0[w]:
+                wave_recs[w].append(sync(WT_SIGNAL, STAGED + 0, 1))
+        for ph in range(nphase):
+            s_units, infos = phase_s_units(ph)
+            comp = [[] for _ in range(W)]
+            for recs, info in zip(phase_groups[ph], infos):
+                for (m_lo, m_hi, w) in wins_of_key[key_of(recs)]:
+                    _, chain = window_records(ph, info, m_lo, m_hi)
+                    comp[w] += chain
+            smine = [[] for _ in range(W)]
+            for c, u in sorted(s_units, key=lambda t: -t[0]):   # S tasks and staging shares are not tied to cells: onto the least loaded wave (running totals)
+                w = loads.index(min(loads))
+                loads[w] += c
+                smine[w] += u
+            stmine = [[] for _ in range(W)]
+            if ph + 1 < nphase:
+                for c, u in stage_units(ph + 1):
+                    w = loads.index(min(loads))
+                    loads[w] += c
+                    stmine[w] += u
+                n_staged[ph + 1] = sum(1 for w in range(W) if stmine[w])
+            for w in range(W):
+                if smine[w]:
+                    if ph >= 2:
+                        wave_recs[w].append(sync(WT_WAIT, DONE + ph - 2, W))
+                    wave_recs[w] += smine[w]
+                if comp[w]:
+                    wave_recs[w].append(sync(WT_WAIT, STAGED + ph, n_staged[ph]))
+                    wave_recs[w] += comp[w]
+                wave_recs[w].append(sync(WT_SIGNAL, DONE + ph, 0))
+                if stmine[w]:
+                    if ph >= 1:
+                        wave_recs[w].append(sync(WT_WAIT, DONE + ph - 1, W))
+                    wave_recs[w] += stmine[w]
+                    wave_recs[w].append(sync(WT_SIGNAL, STAGED + ph + 1, 1))
         row = []
         for w in range(W):
             r0 = len(tasks)
-            order = (mine[w][2] + mine[w][0] + mine[w][1]) if WIDE_STAGE_POS == "begin" else (mine[w][0] + mine[w][1] + mine[w][2])
-            for c, u in order:
-                chains.append([len(tasks), len(tasks) + len(u), pool_index])
-                tasks.extend(u)
+            chains.append([r0, r0 + len(wave_recs[w]), 0])
+            tasks.extend(wave_recs[w])
             row.append([r0, len(tasks)])
-        streams.append(row)
-        if pool_index > 0:
-            tot_cost += sum(loads)
-            crit_cost += max(loads)
-
-    deal(0, [], [], stage_units(0))
-    for ph in range(nphase):
-        g0, g1 = int(ptab[ph][2]), int(ptab[ph][3])
-        groups = [[items[i] for i in range(int(gtab[gi][0]), int(gtab[gi][1]))] for gi in range(g0, g1)]
-        nrec = sum(len(g) for g in groups)
-        if nrec > WIDE_FLAGS:
-            raise NotImplementedError("wide schedule: more items in one phase than S-ready flags")
-        ctot = sum(col_cost(r) * ncols(r) + WIDE_COST_REC for g in groups for r in g)
-        target = max(ctot / (W * WIDE_TASKS_PER_WAVE), 48.0)
-        s_units, c_units = [], []
-        slot, fi = 0, 0
-        for recs in groups:
-            info = []
-            for r in recs:
-                typ, mm, rtm = int(r[0]), int(r[6]), int(r[9])
-                my_slot = -1
-                if typ == IT_TP:
-                    my_slot = slot
-                    slot += rtm
-                    rec = [0] * WIDE_TASK_I32
-                    rec[0], rec[1], rec[2], rec[3], rec[4], rec[5] = WT_S, int(r[12]), rtm, int(r[10]), my_slot, fi
-                    s_units.append((hp4 * rtm + WIDE_COST_REC, [rec]))
-                    mfma_tasks += hp4 * rtm
-                info.append((r, my_slot, fi))
-                fi += 1
-            for (m_lo, m_hi) in _wide_group_windows(recs, col_cost, target):
-                chain, ccost = [], 0.0
-                for r, my_slot, my_fi in info:
-                    typ, mm, rtm = int(r[0]), int(r[6]), int(r[9])
-                    odd = bool(typ == IT_TP and int(r[7]) and mm > 0)
-                    lo, hi = max(m_lo, -mm), min(m_hi, mm)
-                    if lo > hi:
-                        continue
-                    runs = [(lo, hi)]
-                    if odd and lo <= 0 <= hi:                  # the centre column of an odd item is structurally zero: not computed
-                        runs = [(a_, b_) for a_, b_ in ((lo, -1), (1, hi)) if a_ <= b_]
-                    cap = wide_ncw_cap(rtm)
-                    cfull = wts[int(r[13]):int(r[13]) + rtm * (2 * mm + 1) * 16].reshape(rtm, 2 * mm + 1, 4, 4) if typ == IT_TP else None   # [rt][c][g][r]
-                    for a_, b_ in runs:
-                        n = b_ - a_ + 1
-                        k = ceil_div(n, cap)
-                        base_n, rem = divmod(n, k)
-                        o = a_
-                        for j in range(k):
-                            ncw = base_n + (1 if j < rem else 0)
-                            c0 = o + mm                        # first real column of the record
-                            o += ncw
-                            rec = [0] * WIDE_TASK_I32
-                            rec[0] = WT_COMPUTE
-                            rec[1] = int(r[1]) + (ph & 1) * sf                 # stage offsets inside the phase's buffer
-                            rec[2] = int(r[2]) + (ph & 1) * sf if int(r[2]) >= 0 else -1
-                            rec[3] = my_slot
-                            for q in (4, 5, 6, 7, 8, 9, 11, 14, 16, 17, 18, 22, 23):
-                                rec[q] = int(r[q])
-                            rec[10] = my_fi
-                            rec[13], rec[15], rec[19] = c0, ncw, typ
-                            if typ == IT_TP:                   # the record's CG coefficients, packed: lane (g, p = rt * ncw + j) holds the float4 over r
-                                pk = np.zeros((4, 16, 4), dtype=wts.dtype)
-                                for rt in range(rtm):
-                                    for jj in range(ncw):
-                                        pk[:, rt * ncw + jj, :] = cfull[rt, c0 + jj]
-                                extra.append(pk.reshape(-1))
-                                rec[12] = xbase + xoff
-                                xoff += 256
-                            cc = col_cost(r) * ncw
-                            mfma_tasks += cc
-                            ccost += cc + WIDE_COST_REC
-                            chain.append(rec)
-                if chain:
-                    c_units.append((ccost, chain))
-        assert slot <= slots
-        deal(ph + 1, s_units, c_units, stage_units(ph + 1) if ph + 1 < nphase else [])
+        stream_np = np.asarray([row], np.int32).reshape(1, W, 2)
+        balance = sum(loads) / (W * max(loads)) if max(loads) else 1.0
+        crit = max(loads)
     tasks_np = np.asarray(tasks, np.int32).reshape(-1, WIDE_TASK_I32)
     return WideSchedule(seg_table=sub["segs"], block_table=np.asarray(sub["btab"], np.int32).reshape(-1, IS_BLOCK_I32),
                         phase_blocks=np.asarray([[int(p[0]), int(p[1])] for p in ptab], np.int32).reshape(-1, 2),
-                        stream_table=np.asarray(streams, np.int32).reshape(nphase + 1, W, 2), chain_table=np.asarray(chains, np.int32).reshape(-1, 3),
+                        stream_table=stream_np, chain_table=np.asarray(chains, np.int32).reshape(-1, 3),
                         task_table=tasks_np, rec_table=np.asarray([wide_pack_record(t) for t in tasks], np.int32).reshape(-1, WIDE_REC_I32),
                         item_table=np.asarray(items, np.int32).reshape(-1, IS_ITEM_I32), rowtab=np.asarray(sub["rowtab"], np.int32),
                         extra_weights=(np.concatenate(extra) if extra else np.zeros(4, wts.dtype)), lay=lay, nphase=nphase,
-                        balance=tot_cost / (W * crit_cost) if crit_cost else 1.0, crit=crit_cost, mfma_tasks=int(mfma_tasks))
+                        balance=balance, crit=crit, mfma_tasks=int(mfma_tasks))
 
 
 def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool):
@@ -990,7 +1147,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         if v >= 0:                                             # merged item: rows of all members, through the virtual segment's table range
             wide[n, 22], wide[n, 23] = _item_rto(items[n], prog.seg_table, prog.vsegs), vt_base[v]
     ctr_off = stage_off + stage_floats
-    return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off,
+    return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off, remap=remap,
                 phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (waves * crit) if crit else 1.0, crit=crit)
 
 

@@ -145,8 +145,11 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
  *               w2 = stage offset of source 1 (-1) / share        w3 = in_mulp | ksteps << 16 / shares
  *               w4, w5, w6 = float offsets of the A1 fragments, the record's packed CG coefficients, the A2 fragments
  *               w7 = first S slot | flag << 16    w8 = first output row (plain Linear items)    w9 = first row-table entry of GEMM2's rows
- *   lay_host    HOST int32[12] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off,
- *               lds_floats}: float offsets inside the workgroup's LDS (validated)                                                              */
+ *   lay_host    HOST int32[16] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off,
+ *               lds_floats, own, 0, 0, 0}: float offsets inside the workgroup's LDS (validated).  own = 1 (plan.wide_schedule(mode="own")): stream_table is
+ *               int32[1][16][2], one record stream per wave for the whole tile; kind 3 records synchronise through counters in LDS (bit 2 of w0 set: signal
+ *               counter w1 (after draining the vector-memory queue if w2), else: wait until counter w1 >= w2) and no barrier separates the phases;
+ *               w10 of S / compute records = the value the item's S flag takes                                                                  */
 int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge, int hidden,
                const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table, const int32_t* block_table,
                const int32_t* stream_table, const int32_t* rec_table, const int32_t* row_table, const int32_t* lay_host,

@@ -1047,6 +1047,23 @@ def test_wide_schedule_vs_golden(golden_dir):
         P.WIDE_TASKS_PER_WAVE, P.WIDE_ACC_CAP = old
 
 
+def test_wide_schedule_own_mode_vs_golden(golden_dir):
+    """plan.wide_schedule(mode="own"): every wave owns fixed (segment key, column window) cells for the whole tile, counters instead of barriers -- the
+    emulator interleaves the 16 streams two ways (round-robin, maximally skewed) and checks the hazards on the data (tests/emu.py:_run_program_wide_own)"""
+    f, sd, lay, lmax, D, srcs, h2 = _wide_inputs(golden_dir)
+    skip = np.random.default_rng(3).standard_normal(sum(m * m for m, _, _ in so3.Irreps(MINI)))
+    for prog in (P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=True),
+                 P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=False, skip_weight=skip)):
+        ws = P.wide_schedule(prog, mode="own")
+        assert ws.lay["own"] == 1 and ws.mfma_tasks == prog.mfma_per_wave - prog.mfma_odd_skipped and ws.balance > 0.8
+        kinds = set(int(t[0]) for t in ws.task_table)
+        assert {P.WT_WAIT, P.WT_SIGNAL, P.WT_S, P.WT_COMPUTE, P.WT_STAGE} <= kinds
+        ref = emu.run_program(prog, list(srcs), h2, D, lmax)
+        a = emu.run_program_wide(prog, ws, list(srcs), h2, D, lmax)
+        b = emu.run_program_wide(prog, ws, list(srcs), h2, D, lmax, order="reverse_compute")
+        assert rel(a, ref) < 1e-12 and rel(b, ref) < 1e-12
+
+
 def test_wide_schedule_merged_items_random_irreps():
     """merged items (rows of several small output segments in one MFMA row tile) on the wide schedule, random weights vs the oracle's block"""
     import torch
@@ -1091,7 +1108,9 @@ def test_wide_schedule_shipped_irreps(which):
     m = hnn.MessagePackBlock(irr, irr, bench.SH, irr, 64, [64, 64])
     groups = P.choose_merge_groups(irr, irr, bench.SH, irr, 64)
     prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, bench.SH, irr, True, None, merge_groups=groups)
-    ws = P.wide_schedule(prog)
+    wo = P.wide_schedule(prog, mode="own")                                      # whole-tile ownership: the TOTAL loads balance (no per-phase barrier)
+    assert wo.lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES and wo.mfma_tasks == prog.mfma_per_wave - prog.mfma_odd_skipped and wo.balance > 0.9
+    ws = P.wide_schedule(prog, mode="pools")
     assert ws.lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES and ws.mfma_tasks == prog.mfma_per_wave - prog.mfma_odd_skipped
     assert ws.balance > 0.7
     T = ws.task_table
