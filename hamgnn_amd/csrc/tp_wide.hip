@@ -87,23 +87,6 @@ struct WdLay {
 
 typedef volatile __attribute__((address_space(3))) int* wd_vint_p;
 
-// ablation builds (timing attribution only, wrong results): operand loads replaced by lane-dependent constants
-#ifdef WD_ABL_NOA1
-#define WD_LDA1(p) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
-#else
-#define WD_LDA1(p) (*(p))
-#endif
-#ifdef WD_ABL_NOA2
-#define WD_LDA2(p) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
-#else
-#define WD_LDA2(p) (*(p))
-#endif
-#ifdef WD_ABL_NOW3
-#define WD_LDW3(p) ((f32x4){(float)lane, 1.f, 2.f, 3.f})
-#else
-#define WD_LDW3(p) (*(p))
-#endif
-
 #define WD_MB_CASE(Q) case Q: asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:" #Q " row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "v"(x)); break;
 __device__ __forceinline__ float wd_mul_bcast(float v, float x, int q) {       // x * (lane q of v's row of 16 lanes), one VALU instruction (see tp_is.hip)
     float o;
@@ -212,7 +195,7 @@ __device__ __forceinline__ void wd_task_S(const IsArgs& A, const WdLay& Ly, cons
         if (G < hg) {
             hb[G] = *reinterpret_cast<const f32x4*>(hrow + 16 * G);
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = WD_LDW3(w3 + (G * RTM + rt) * 64);
+            for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[(G * RTM + rt) * 64];
         }
 #pragma unroll
     for (int rt = 0; rt < RTM; ++rt) S[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -277,7 +260,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
         cfv = reinterpret_cast<const f32x4*>(Wb + T[5])[lane];                               // the window's packed CG coefficients (plan.wide_schedule)
         if constexpr (A2_EARLY) {
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = WD_LDA2(a2 + rt * 64);
+            for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];
         }
     }
     f32x4 mid[RTM][NCW];
@@ -292,7 +275,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
     const int src_jump = (so1 - so0) - ngrp * 256;
     f32x4 av_n[RTM];
 #pragma unroll
-    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = WD_LDA1(aw + rt * 64);
+    for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[rt * 64];
     if (NCW <= 3 && x4) {                                      // permuted K: fragment (c, G) = piece cbase + 4 G + g of row el
         const float* __restrict__ pc[NCW];
 #pragma unroll
@@ -308,7 +291,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
             for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
             if (t + 1 < ntot) {
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = WD_LDA1(aw + ((t + 1) * RTM + rt) * 64);
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
             }
 #pragma unroll
             for (int c = 0; c < NCW; ++c) {
@@ -340,7 +323,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
             for (int rt = 0; rt < RTM; ++rt) av[rt] = av_n[rt];
             if (t + 1 < ntot) {
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = WD_LDA1(aw + ((t + 1) * RTM + rt) * 64);
+                for (int rt = 0; rt < RTM; ++rt) av_n[rt] = aw[((t + 1) * RTM + rt) * 64];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -365,20 +348,17 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
     if (typ == 0) {
         if constexpr (!A2_EARLY) {
 #pragma unroll
-            for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = WD_LDA2(a2 + rt * 64);
+            for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[rt * 64];
         }
         // the item's S fragments: produced by its S task (at the head of some wave's stream of this pool)
         {
             wd_vint_p fl = (wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16));
             int spin = 0;
-#ifdef WD_ABL_NOFLAG
-            spin = 1 << 19;
-#endif
             while (*fl != stamp && spin < (1 << 18)) {         // (bounded: a schedule whose S task does not precede its consumers would otherwise hang the
                 __builtin_amdgcn_s_sleep(1);                   //  GPU; the bound is ~10 ms, then the rows come out as NaN instead)
                 ++spin;
             }
-            if (spin == (1 << 18)) cfv = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            if (spin >= (1 << 18)) cfv = (f32x4){__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
             asm volatile("" ::: "memory");
         }
         WD_T(4);                                                // waiting for the item's S fragments
@@ -404,7 +384,7 @@ __device__ __forceinline__ void wd_task_compute(const IsArgs& A, const WdLay& Ly
             for (int rt = 0; rt < RTM; ++rt) av[rt] = a2_n[rt];
             if (rtp + 1 < rto) {
 #pragma unroll
-                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = WD_LDA2(a2 + ((rtp + 1) * RTM + rt) * 64);
+                for (int rt = 0; rt < RTM; ++rt) a2_n[rt] = a2[((rtp + 1) * RTM + rt) * 64];
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) trow[r] = tbase + rtab[16 * rtp + 4 * g + r];
@@ -496,7 +476,6 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
                 wd_sync_record(A, T, lds, lane);
                 WD_T(6);
             } else if (kind == 0) {                                   // a share of one input block of the next phase -> the other staging buffer
-#ifndef WD_ABL_NOSTAGE                                          // (ablation builds: timing attribution only, wrong results)
                 const int* __restrict__ B = g_blocks + T[1] * 8;
                 float* __restrict__ sbuf = stage + WD_BIT8(T) * Ly.stage_floats;
                 switch (WD_L(T)) {
@@ -509,22 +488,16 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
                     case 6: wd_stage<6>(A, B, sbuf, erow, T[2], T[3], lane); break;
                     default: break;
                 }
-#endif
                 WD_T(1);                                        // staging share
             } else if (kind == 1) {
-#ifdef WD_ABL_NOS
-                if (lane == 0) *(wd_vint_p)(reinterpret_cast<int*>(lds + Ly.flag_off) + (T[7] >> 16)) = T[10];
-#else
                 switch (WD_RTM(T)) {
                     case 1: wd_task_S<1>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
                     case 2: wd_task_S<2>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
                     case 3: wd_task_S<3>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
                     default: wd_task_S<4>(A, Ly, g_W, T, lds, erow, lane, T[10]); break;
                 }
-#endif
                 WD_T(2);                                        // S task
             } else {
-#ifndef WD_ABL_NOCOMPUTE
                 switch (WD_NCW(T) * 8 + WD_RTM(T)) {
                     WD_CASE(1, 1) WD_CASE(1, 2) WD_CASE(1, 3) WD_CASE(1, 4)
                     WD_CASE(2, 1) WD_CASE(2, 2) WD_CASE(2, 3) WD_CASE(2, 4)
@@ -535,23 +508,17 @@ __global__ __launch_bounds__(WD_NT, 1) void tp_wide_kernel(const IsArgs A, const
                     WD_CASE(7, 1)
                     default: break;
                 }
-#endif
             }
             T = Tn;
         }
         WD_TL(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's LDS-DMA of the next phase's rows has landed
-#ifndef WD_ABL_NOBAR
         __syncthreads();
-#endif
         WD_TL(6);                                               // waiting for the slowest wave of the pool
     }
 
     // ---------------------------------------------------------------- epilogue (as tp_is.hip): all waves on one segment at a time; the Wigner
     // blocks of a batch of segments are staged together by LDS-DMA into staging buffer 0
-#ifdef WD_ABL_NOEPI
-    return;
-#endif
     IsScan scan;
     scan.last = true, scan.row = 0;
     if (A.run_id) scan = is_scan_setup(valid ? A.run_id[e] : -1 - (int)(lane & 15), lane & 15);

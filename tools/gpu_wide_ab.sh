@@ -1,8 +1,8 @@
 #!/bin/bash
 # r5: same-call A/B of variant libraries of the wide kernel (csrc/tp_wide.hip) against hg_tp_is on bench_tp (131 072 edges, set-A, node-fed), each with its own
 # environment (planner knobs):      tools/gpu_wide_ab.sh <tag> "lib:ENV=..,ENV=.. lib2:.. ..." [tests]
-#   libraries: HG_VARIANT_FILES=tp_wide tools/build_variants.sh nw16: nw12:"-DWD_NW=12" noaw:"-DWD_ABL_NOA1 -DWD_ABL_NOA2 -DWD_ABL_NOW3" ...   (WD_ABL_*: ablation
-#   builds, wrong results by construction -- NEVER -DWD_ABL_NOBAR: without the pool barriers the bounded S-flag spins time out record by record, minutes per launch)
+#   libraries: HG_VARIANT_FILES=tp_wide tools/build_variants.sh nw16: nw12:"-DWD_NW=12" a2e0:"-DWD_A2_EARLY=0" ...   (the ablation hooks -DWD_ABL_* behind the table in
+#   profiles/r05_tp_wide.md were removed from the source once the question was answered: commits c8418b7..7e1e420 have them)
 #   environment: HG_WIDE_SCHED=pools|own, HG_WIDE_TPW, HG_WIDE_COST_REC, HG_WIDE_COST_STAGE, HG_WIDE_STAGE_POS, HG_WIDE_WAVES (must match -DWD_NW)
 #   a third argument `tests` runs the wide parity tests first (under the first spec's HG_WIDE_SCHED)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; out=gpurun_out/${1:-wideab}; mkdir -p $out
