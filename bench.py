@@ -436,23 +436,50 @@ def main():
     n_launch = max(1, len(mp))
     avg_s = sum(t for t, _, _ in mp) / n_launch
     rows_per_launch = sum(r for _, r, _ in mp) / n_launch
-    useful = model.convolutions[0].conv_tp._dp.prog.flops_per_row * rows_per_launch
-    flops_launch = useful if args.lite else REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_per_launch
-    dp0 = model.convolutions[0].conv_tp._dp
-    issued = (dp0.prog.mfma_per_wave - (dp0.prog.mfma_odd_skipped if dp0.sched is not None else 0)) * 2048.0 / 16.0 * rows_per_launch
-    ach = flops_launch / avg_s / 1e12
-    kern = "is" if model.convolutions[0].conv_tp._dp.sched is not None else "seg"
+    # the programs of a step in launch order (ConvBlock, PairInteractionBlock per layer).  r5: the FIRST layer's programs drop the super-paths that read
+    # structurally zero input irreps (node rows out of the 0e embedding Linear, edge rows out of the 0e x Y^l pair embedding: hamgnn_conv._mark_structural_zeros),
+    # so the launches of a step are not all the same program any more: flops are summed program by program
+    dps = []
+    for conv, pair in zip(model.convolutions, model.pair_interactions):
+        dps.append(conv.conv_tp._dp_for(E_local, True))        # the program the launch ran (first layer: the reduced one)
+        if pair.use_skip_connections or not pair.legacy_edge_update:
+            dps.append(pair.conv_tp._dp_for(E_local, True))
+    full = dps[-1].prog
+    full_of = [dps[-2].prog if (len(dps) >= 2 and k % 2 == 0 and len(dps) % 2 == 0) else dps[-1].prog for k in range(len(dps))]      # the complete program of the same kind (ConvBlock / PairInteractionBlock + skip Linear)
+    issued_of = lambda dp: (dp.prog.mfma_per_wave - (dp.prog.mfma_odd_skipped if dp.sched is not None else 0)) * 2048.0 / 16.0
+    t_tot = sum(t for t, _, _ in mp)
+    useful_tot = sum(dps[k % len(dps)].prog.flops_per_row * r for k, (_, r, _) in enumerate(mp))
+    issued_tot = sum(issued_of(dps[k % len(dps)]) * r for k, (_, r, _) in enumerate(mp))
+    share = [dp.prog.flops_per_row / fo.flops_per_row for dp, fo in zip(dps, full_of)]           # non-zero share of the reference formulation's flops, per launch of a step
+    ref_tot = sum(REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * r for _, r, _ in mp)
+    ref_nonzero_tot = sum(REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * share[k % len(dps)] * r for k, (_, r, _) in enumerate(mp))
+    flops_tot = useful_tot if args.lite else ref_tot
+    ach = flops_tot / t_tot / 1e12
+    kern = "is" if dps[-1].sched is not None else "seg"
     pmc_bytes = PMC_HBM_BYTES_PER_EDGE_BLOCK[(kern, args.irreps)]
+    per_kind = {}
+    for k, (t, r, _) in enumerate(mp):
+        per_kind.setdefault(k % len(dps), []).append(t)
+    full_t = [t for k, (t, r, _) in enumerate(mp) if share[k % len(dps)] > 0.999]
     roofline = {"kernel": ("tp_is_kernel (input-stationary" if kern == "is" else "tp_fused_kernel (segment-stationary") + " MessagePackBlock launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": pmc_bytes * rows_per_launch,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, measured offline on the benchmarked launches of this kernel build: profiles/r05_tp_is_pmc.md; "
                                 "set-B: r02b_tp_is_hbm_pmc.md, segment-stationary kernel: r01c_tp_fused_hbm_pmc.md), scaled to this launch's edge count", "avg_launch_ms": avg_s * 1e3,
                 "launches_timed": len(mp), "edges_per_launch": rows_per_launch,
-                "executed_useful_tflops": useful / avg_s / 1e12, "issued_mfma_tflops": issued / avg_s / 1e12,
+                # `achieved` counts the reference formulation's flops of EVERY block (4.55 MFLOP per edge and block for set-A) -- including the ones the
+                # reference spends multiplying the structurally zero input irreps of the first layer, which this build does not issue.  The figure that excludes
+                # them, and the one of the launches that run the complete program, stand next to it:
+                "frac_without_structural_zero_flops": (ref_nonzero_tot / t_tot / 1e12 / PEAK_FP32_TFLOPS if not args.lite else None),
+                "frac_full_program_launches": (REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / (sum(full_t) / max(1, len(full_t))) / 1e12 / PEAK_FP32_TFLOPS
+                                               if full_t and not args.lite else None),
+                "launch_ms_by_position_in_step": [round(1e3 * sum(v) / len(v), 3) for _, v in sorted(per_kind.items())],
+                "nonzero_flop_share_by_position": [round(x, 4) for x in share],
+                "executed_useful_tflops": useful_tot / t_tot / 1e12, "issued_mfma_tflops": issued_tot / t_tot / 1e12,
                 "hbm_algorithmic_GBs": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9,
                 "hbm_frac": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9 / PEAK_HBM_GBS,
                 "hbm_measured_GBs": pmc_bytes * rows_per_launch / avg_s / 1e9,
                 "fused_program_launches_share_of_step": all_tp / dt}
+    issued, useful = issued_tot / n_launch, useful_tot / n_launch
     if not args.no_mfma_probe:
         # what the fp32 matrix pipe sustains on this device right now (random operands, two waves per SIMD, nothing but MFMAs; after the
         # timed region): the chip clocks to its power budget, so the nominal peak above is not attainable on non-trivial data.  Reported

@@ -6,6 +6,8 @@ from __future__ import annotations
 import math
 
 import numpy as np
+import os
+
 import torch
 from torch import nn
 
@@ -66,6 +68,16 @@ def _cfg_get(c, k, default=None):
 class _BackboneBase(nn.Module):
     """What HamGNNConvE3 and HamGNNTransformer share (hamgnn_conv.py:89-190 == hamgnn_transformer.py:37-112): config keys, atomic /
     pair / chemical embedding, per-edge geometry, and the lazily converted result dict."""
+
+    def _structural_zero_sets(self):
+        """(node irreps, edge irreps) that are STRUCTURALLY zero in the rows the first layer reads: the chemical embedding is an o3.Linear from
+        `num_types x 0e` (toolbox/nequip/nn/_atomwise.py:55-57; charge doping adds to the same 0e attributes) -- only 0e blocks of the node rows can be
+        non-zero -- and the pair embedding is 0e (x) Y^l followed by same-irrep Linears (nn/embeddings.py:310-337) -- only the irreps of the spherical
+        harmonics can be non-zero in the edge rows"""
+        from ..so3 import Irreps
+        irr = Irreps(self.irreps_node_features)
+        sh = {(l, p) for _, l, p in Irreps(self.irreps_edge_sh)}
+        return (tuple(i for i, (_, l, p) in enumerate(irr) if (l, p) != (0, 1)), tuple(i for i, (_, l, p) in enumerate(irr) if (l, p) not in sh))
 
     def _init_common(self, config):
         c = _cfg_get(config, "HamGNN_pre", config)
@@ -180,7 +192,8 @@ class _BackboneBase(nn.Module):
     def _run_pair(self, pair, node, f, geo):
         """PairInteractionBlock.forward (interaction_blocks.py:130-164)"""
         if pair.use_skip_connections or not pair.legacy_edge_update:               # legacy layer-0: edge features kept (:154-156)
-            mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab)   # edge frame (+ fused skip linear)
+            # (structural_zeros: inside a backbone's forward the rows are what set_structural_zeros was told about -- a first-layer block runs its reduced program)
+            mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab, structural_zeros=True)   # edge frame (+ fused skip linear)
             if self.lite_mode and pair.use_skip_connections:
                 mix = pair.skip_linear(f, res=[mix])
             f = mix
@@ -263,6 +276,20 @@ class HamGNNConvE3(_BackboneBase):
             self.convolutions.append(hnn.ConvBlockE3(D, sh, R, mlp, self.lite_mode))
             skip = (i > 0) if self.legacy_edge_update else True
             self.pair_interactions.append(hnn.PairInteractionBlock(D, sh, R, mlp, skip, self.legacy_edge_update, self.lite_mode))
+        self._mark_structural_zeros()
+
+    def _mark_structural_zeros(self):
+        """tell the message blocks of the leading layers which of their inputs are structurally zero (r5: the reference multiplies those zeros through all
+        255 paths of both tensor products, message_passing.py:216-229; here the planner drops the super-paths that read them -- 74 % of the first
+        ConvBlock launch and 20 % of the first PairInteractionBlock launch for the shipped irreps).  The node rows are full after the first ConvBlock,
+        the edge rows after the first PairInteractionBlock that updates them (a legacy layer-0 block does not: interaction_blocks.py:154-160)."""
+        zero_node, zero_edge = self._structural_zero_sets()
+        for conv, pair in zip(self.convolutions, self.pair_interactions):
+            conv.conv_tp.set_structural_zeros(node=zero_node, edge=zero_edge)
+            zero_node = ()
+            if pair.use_skip_connections or not pair.legacy_edge_update:
+                pair.conv_tp.set_structural_zeros(node=(), edge=zero_edge)
+                zero_edge = ()
 
     # ------------------------------------------------------------------------------------------------------------
     def compile(self, device):
@@ -302,6 +329,12 @@ class HamGNNConvE3(_BackboneBase):
         """save_for_backward: keep the layer inputs (node rows, edge rows, aggregated messages) on the result (`_tape`) for `backward`"""
         z, topo, geo, node, f = self._embed(data)
         N = z.shape[0]
+        if os.environ.get("HG_CHECK_STRUCT_ZEROS") == "1":     # (tests) the blocks the first layer's programs treat as structural zeros ARE zero
+            zn, ze = self._structural_zero_sets()
+            for rows, idx in ((node, zn), (f, ze)):
+                for i in idx:
+                    o, w = self.layout.off[i], (2 * self.layout.irreps[i][1] + 1) * self.layout.mulp[i]
+                    assert float(rows[:, o:o + w].abs().max()) == 0.0, ("structural zero violated", i)
         rowptr, perm = topo.receiver_csr()
         tape = [] if save_for_backward else None
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
@@ -312,10 +345,10 @@ class HamGNNConvE3(_BackboneBase):
                 # convolution.py:147-149 fused into the edge kernel: receiver-major tiles, the runs of equal receivers summed in the epilogue
                 # (about E / 13 rows instead of the [E, Dp] message tensor), then a segmented sum over each atom's contiguous rows
                 eperm, run_id, R, prow, ident = topo.receiver_major()
-                part = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab, reduce=(eperm, run_id, R))
+                part = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab, reduce=(eperm, run_id, R), structural_zeros=True)
                 agg = ops.segment_sum(part, prow, ident, N)
             else:
-                msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab)      # global frame (un-rotated in the epilogue)
+                msg = conv.conv_tp.run_nodes(node, node, f, geo, self._rot_tab, structural_zeros=True)      # global frame (un-rotated in the epilogue)
                 agg = ops.segment_sum(msg, rowptr, perm, N)
             if row_shard:
                 # reduce-scatter of the partial aggregates, skip Linear / ResidualBlock / CorrProductBlock on N / world rows, all-gather of the new rows

@@ -30,6 +30,11 @@ class HamGNNTransformer(_BackboneBase):
             self.orb_transformers.append(hnn.AttentionBlockE3(D, sh, R, self.num_heads, self.cutoff, mlp))
             self.corr_products.append(hnn.CorrProductBlock(D, int(g("num_hidden_features")), int(g("correlation")), self.num_types, True))
             self.pair_interactions.append(hnn.PairInteractionBlock(D, sh, R, mlp, True, self.legacy_edge_update, False))
+        # structural zeros of the first layer (see HamGNNConvE3._mark_structural_zeros): the value block reads linear_up_src / _tar (node) and linear_up_edge (f),
+        # same-irrep o3.Linears that keep zero blocks zero (attention.py:339-352); the first pair block reads full node rows and the embedding's edge rows
+        zero_node, zero_edge = self._structural_zero_sets()
+        self.orb_transformers[0].conv_tp_value.set_structural_zeros(node=zero_node, edge=zero_edge)
+        self.pair_interactions[0].conv_tp.set_structural_zeros(node=(), edge=zero_edge)
 
     def compile(self, device):
         dev = torch.device(device)
@@ -61,7 +66,7 @@ class HamGNNTransformer(_BackboneBase):
         for att, corr, pair in zip(self.orb_transformers, self.corr_products, self.pair_interactions):
             if tape is not None:
                 tape.append(dict(node_in=node, f_in=f))
-            node = att.run(node, f, geo, self._rot_tab, rowptr, perm, data)        # AttentionBlockE3.forward (attention.py:315-360)
+            node = att.run(node, f, geo, self._rot_tab, rowptr, perm, data, structural_zeros=True)        # AttentionBlockE3.forward (attention.py:315-360)
             if tape is not None:
                 tape[-1]["node_att"] = node
             node = corr(node, z, self._last_delta)                                  # CorrProductBlock.forward (interaction_blocks.py:234-260)

@@ -240,8 +240,23 @@ class MessagePackBlock(nn.Module):
             self.edge_linear_out = E3Linear(self.irreps_out, self.irreps_out)
         self._dp = None
 
+    def set_structural_zeros(self, node=(), edge=()):
+        """irreps (indices into irreps_node / irreps_edge) whose rows are STRUCTURALLY zero where this block runs (the first layer: node rows out of an
+        o3.Linear from 0e scalars, edge rows out of the pair embedding's 0e x Y^l product): the forward program drops the super-paths that read them
+        (plan.build_message_pack_program).  Takes effect at the next compile(); the backward programs stay complete (they produce the zeros)."""
+        self._zeros = (tuple(sorted(int(i) for i in node)), tuple(sorted(int(i) for i in edge)))
+        return self
+
+    def _zero_kw(self):
+        zn, ze = getattr(self, "_zeros", ((), ()))
+        if os.environ.get("HG_STRUCT_ZEROS", "1") == "0" or self.lite_mode:
+            return {}
+        return {"zero_node": zn, "zero_edge": ze} if (zn or ze) else {}
+
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
+        zkw = self._zero_kw()
+        self._dp_z = self._dp_z_plain = None                    # programs for rows with structurally zero irreps (set_structural_zeros), built next to the generic ones
         self._compile_args = (bool(unrotate), skip_weight is not None, None)      # (unrotate, fused skip Linear, merge groups)
         self._lite_bw = None
         self._packers = getattr(self, "_packers", None) or {}                     # structural: survive recompiles of the same block
@@ -280,6 +295,9 @@ class MessagePackBlock(nn.Module):
                                                             skip_weight, merge_groups=groups)
                         self._dp = ops.DeviceProgram(prog, device, schedule="is")
                         self._compile_args = (bool(unrotate), skip_weight is not None, groups)
+                        if zkw:                                # the same block for rows whose marked irreps are structurally zero (first layer of a backbone)
+                            self._dp_z = ops.DeviceProgram(P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate,
+                                                                                       skip_weight, merge_groups=groups, **zkw), device, schedule="is")
                         # launches with fewer 16-edge tiles than workgroup slots run the PLAIN program split over one workgroup per output
                         # segment: merging trades parts (9 instead of 13 for set-A) for MFMAs, the wrong trade when latency is all there is
                         # (Si 2-atom cell: 0.113 -> 0.110 ms per launch); built on first use
@@ -289,6 +307,9 @@ class MessagePackBlock(nn.Module):
                     except NotImplementedError:
                         pass
             prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
+            if zkw:
+                self._dp_z = ops.DeviceProgram(P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight, **zkw),
+                                               device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
         self._plain_args = None
         # HG_MP_KERNEL = seg | is | auto: which schedule of the fused MessagePackBlock program runs (default: see DESIGN.md section 5)
         self._dp = ops.DeviceProgram(prog, device, schedule=os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT))
@@ -333,10 +354,16 @@ class MessagePackBlock(nn.Module):
             dp.weights.copy_(blob)
             dp.weights_changed()
 
-        fwd = lambda g_: (lambda d, sk: P.build_message_pack_program(d, *args, unrotate, sk, **({"merge_groups": g_} if g_ else {})).weights)
+        zkw = self._zero_kw()
+        ztag = (zkw.get("zero_node", ()), zkw.get("zero_edge", ()))
+        fwd = lambda g_, z_=None: (lambda d, sk: P.build_message_pack_program(d, *args, unrotate, sk, **({"merge_groups": g_} if g_ else {}), **(z_ or {})).weights)
         update(self._dp, ("fwd", unrotate, has_skip, bool(groups)), fwd(groups), nskip)
         if getattr(self, "_dp_plain", None) is not None and self._dp_plain is not self._dp:
             update(self._dp_plain, ("fwd", unrotate, has_skip, False), fwd(None), nskip)
+        if getattr(self, "_dp_z", None) is not None:
+            update(self._dp_z, ("fwd", unrotate, has_skip, bool(groups), ztag), fwd(groups, zkw), nskip)
+        if getattr(self, "_dp_z_plain", None) is not None and self._dp_z_plain is not self._dp_z:
+            update(self._dp_z_plain, ("fwd", unrotate, has_skip, False, ztag), fwd(None, zkw), nskip)
         if getattr(self, "_dp_adj", None) is not None:
             update(self._dp_adj, ("adj",), lambda d, sk: P.build_message_pack_adjoint_program(d, *args).weights, 0)
         if getattr(self, "_wgrad", None) is not None:
@@ -393,21 +420,25 @@ class MessagePackBlock(nn.Module):
         ims, imd, ime = self._adj_maps
         return ops.from_planar(g, ims), ops.from_planar(g, imd), ops.from_planar(g, ime)      # column gathers (-1 = padding slot -> 0)
 
-    def _dp_for(self, rows: int):
-        """the program a launch of `rows` edges runs: the merged one, or -- split launches of small crystals -- the plain one"""
-        if getattr(self, "_plain_args", None) is None or self._dp.is_parts_for(rows) == 1:
-            return self._dp
-        if self._dp_plain is None:
+    def _dp_for(self, rows: int, structural_zeros: bool = False):
+        """the program a launch of `rows` edges runs: the merged one, or -- split launches of small crystals -- the plain one; structural_zeros: the caller
+        vouches that the irreps marked by set_structural_zeros are zero in the rows it passes (the backbone's first layer): the reduced program"""
+        z = structural_zeros and getattr(self, "_dp_z", None) is not None
+        dp = self._dp_z if z else self._dp
+        if getattr(self, "_plain_args", None) is None or dp.is_parts_for(rows) == 1:
+            return dp
+        slot = "_dp_z_plain" if z else "_dp_plain"
+        if getattr(self, slot, None) is None:
             _, unrotate, skip_weight, device = self._plain_args
             sd = _np_sd(self)                                  # the CURRENT weights (the merged program may have been refreshed since compile())
             if skip_weight is not None and getattr(self, "_skip_source", None) is not None:
                 skip_weight = self._skip_source[0].weight.detach().cpu().double().numpy()
-            prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight)
+            prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight, **(self._zero_kw() if z else {}))
             try:
-                self._dp_plain = ops.DeviceProgram(prog, device, schedule="is")
+                setattr(self, slot, ops.DeviceProgram(prog, device, schedule="is"))
             except NotImplementedError:
-                self._dp_plain = self._dp
-        return self._dp_plain
+                setattr(self, slot, dp)
+        return getattr(self, slot)
 
     def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 65536, gather=None):
         """gradients of every parameter of this block for the output gradient `grad_out` (frame and `gather` as in backward_data), first
@@ -502,7 +533,7 @@ class MessagePackBlock(nn.Module):
         """the fused node scatter is a feature of the single-part input-stationary launch (large graphs)"""
         return self._dp.sched is not None and self._dp_for(rows).is_parts_for(rows) == 1 and os.environ.get("HG_FUSED_SCATTER", "1") != "0"
 
-    def run_nodes(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, reduce=None):
+    def run_nodes(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, reduce=None, structural_zeros: bool = False):
         """node_s / node_d: planar NODE rows (global frame) whose sender / receiver gathers feed the block
         (convolution.py:138-141, interaction_blocks.py:141-145).  Input-stationary schedule: gathered and rotated inside the kernel;
         otherwise through hg_rotate_gather."""
@@ -512,7 +543,7 @@ class MessagePackBlock(nn.Module):
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
         hn = ops.radial_hidden_cached(geo, self._hn, cst)
         he = ops.radial_hidden_cached(geo, self._he, cst) if self._he is not None else None
-        return ops.tp_fused(self._dp_for(geo.E), [node_s, node_d, f_rot], geo.E, hn, he, geo, tag="message_pack", gather=[geo.src, geo.dst, None],
+        return ops.tp_fused(self._dp_for(geo.E, structural_zeros), [node_s, node_d, f_rot], geo.E, hn, he, geo, tag="message_pack", gather=[geo.src, geo.dst, None],
                             rot_mask=0b011, reduce=reduce)
 
 
@@ -625,13 +656,13 @@ class AttentionBlockE3(nn.Module):
             self.conv_tp_value.compile(device, unrotate=True)
         self._cut = self.cutoff_func.cut_param.detach().float().reshape(1).contiguous().to(device)
 
-    def run(self, node, f, geo: ops.Geometry, rot_tab, rowptr, perm, data=None):
+    def run(self, node, f, geo: ops.Geometry, rot_tab, rowptr, perm, data=None, structural_zeros: bool = False):
         """node [N, Dp] planar (global frame), f [E, Dp] planar edge features (edge frame) -> new node rows (attention.py:315-360).
-        data: the graph, for edge-sharded runs (the soft-max of a node then spans the edges of several ranks)"""
+        data: the graph, for edge-sharded runs (the soft-max of a node then spans the edges of several ranks); structural_zeros: see MessagePackBlock._dp_for"""
         from . import parallel
         sc = self.skip_linear(node)
         K = self.linear_key(node)
-        value = self.conv_tp_value.run_nodes(self.linear_up_src(node), self.linear_up_tar(node), self.linear_up_edge(f), geo, rot_tab)
+        value = self.conv_tp_value.run_nodes(self.linear_up_src(node), self.linear_up_tar(node), self.linear_up_edge(f), geo, rot_tab, structural_zeros=structural_zeros)
         agg = ops.attention_aggregate(K, value, geo, rowptr, perm, self._head_tab, self.num_heads, self.head_dim, self._cut, self.cutoff)
         if data is not None and parallel.is_sharded(data):
             agg = self._merge_sharded_softmax(agg, K, geo)

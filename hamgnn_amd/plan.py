@@ -979,8 +979,8 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     # shared copy of the tiles: no private copies then
     post_items = [rec for rec in prog.item_table if int(rec[19]) in local and int(rec[0]) == IT_POST]
     if split and not post_items:
-        need = max((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256
-                   for r in prog.item_table if int(r[19]) in local)
+        need = max(((2 if int(r[2]) >= 0 else 1) * ceil_div((2 * int(r[5]) + 1) * (int(r[4]) // 4), 4) * 256
+                    for r in prog.item_table if int(r[19]) in local), default=0)      # (a segment nothing feeds -- structural-zero inputs -- keeps a zero tile)
         ntab = sum(int(s[2]) * 16 for s in segs) + 4 + 16 * sum(ceil_div(sum(int(prog.seg_table[m][1]) for m in v), 16) for v in prog.vsegs)
         if waves * (off + maxstride) + ntab + need + 4 <= IS_LDS_BYTES // 4:
             copy_stride = off + maxstride                      # every private copy carries its own trash row
@@ -1343,8 +1343,10 @@ def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps
 
 def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
                  irreps_sh: Irreps, irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray,
-                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False, merge_groups: Sequence[Sequence[int]] = ()):
+                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False, merge_groups: Sequence[Sequence[int]] = (), zero_inputs: Sequence[int] = ()):
     """Items of ONE reference tensor-product branch (node or edge) of a MessagePackBlock / embedding TP.
+    zero_inputs: input irreps (indices into in_layout.irreps) whose rows are STRUCTURALLY zero for this block -- every super-path that reads one of
+    them contributes exactly nothing and is dropped (see build_message_pack_program).
     merge_groups: lists of output irreps k whose super-paths from one input irrep are stacked into ONE item (see Program.vsegs):
     the rows of a 16-row MFMA tile are then filled by several small output irreps instead of one (4x5o alone uses 12 of 16 rows of
     GEMM1 / the radial scale and 4 of 16 rows of GEMM2's output).  Only super-paths with l_i <= min l_k of the group are stacked (same
@@ -1372,7 +1374,10 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
             prog.seg_key[sg] = members[0]
     stacked: Dict[Tuple[int, int], List[dict]] = {}
     plain: List[dict] = []
+    zero_inputs = set(int(i) for i in zero_inputs)
     for sp in _tp_superpaths(nsrc, in_layout, irreps_sh, irreps_out, tp_weight, w3, lin_scale_w, lin_out_w, uvu):
+        if sp["i"] in zero_inputs:
+            continue
         gi = group_of.get(sp["k"])
         if gi is not None and sp["li"] <= lmin[gi]:
             stacked.setdefault((sp["i"], gi), []).append(sp)
@@ -1487,8 +1492,10 @@ def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_
 
 
 def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, src: int, irreps_out: Irreps,
-                     weight: np.ndarray, extra_scale: float = 1.0):
-    """Items of one o3.Linear(irreps_in -> irreps_out) (e3nn: paths ordered by (i_in, i_out), 1/sqrt(fan_in))."""
+                     weight: np.ndarray, extra_scale: float = 1.0, zero_inputs: Sequence[int] = ()):
+    """Items of one o3.Linear(irreps_in -> irreps_out) (e3nn: paths ordered by (i_in, i_out), 1/sqrt(fan_in)); zero_inputs: structurally zero input
+    irreps whose paths are dropped (the weights are still walked: the flat layout is the reference's)."""
+    zero_inputs = set(int(i) for i in zero_inputs)
     irr_in = in_layout.irreps
     paths = [(i, k) for i, (_, li, pi) in enumerate(irr_in) for k, (_, lk, pk) in enumerate(irreps_out) if (li, pi) == (lk, pk)]
     fan = {}
@@ -1500,6 +1507,8 @@ def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarL
         mk = irreps_out[k][0]
         Wfull = weight[off:off + mi * mk].reshape(mi, mk).astype(np.float64) * (extra_scale / math.sqrt(fan[k]))
         off += mi * mk
+        if i in zero_inputs:
+            continue
         ksteps = in_layout.mulp[i] // 4
         # rows chunked like TP items so that the per-wave register budget is the same
         nc = 2 * li + 1
@@ -1698,9 +1707,15 @@ def choose_merge_groups(irreps_node, irreps_edge, irreps_sh, irreps_out, hidden:
 
 
 def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool,
-                               skip_weight: Optional[np.ndarray] = None, merge_groups: Sequence[Sequence[int]] = ()) -> Program:
+                               skip_weight: Optional[np.ndarray] = None, merge_groups: Sequence[Sequence[int]] = (),
+                               zero_node: Sequence[int] = (), zero_edge: Sequence[int] = ()) -> Program:
     """MessagePackBlock (non-lite, message_passing.py:216-229) [+ the PairInteractionBlock skip o3.Linear on the edge
-    features, interaction_blocks.py:151-152] as ONE fused-kernel program.  `sd`: reference-named arrays of the block."""
+    features, interaction_blocks.py:151-152] as ONE fused-kernel program.  `sd`: reference-named arrays of the block.
+    zero_node / zero_edge (r5): irreps of the node / edge feature rows that are STRUCTURALLY zero where this block runs -- the first layer reads node rows
+    that come out of an o3.Linear from `num_types x 0e` (only 0e blocks can be non-zero: _atomwise.py:55-57) and edge rows that come out of the pair embedding's
+    0e (x) Y^l product (only the irreps of the spherical harmonics: embeddings.py:310-337).  The reference multiplies those zeros through every path
+    (message_passing.py:216-229); here the super-paths (and skip-Linear paths) that read them are not emitted: same rows, bit for bit in exact arithmetic,
+    because a dropped item would have added +0.0 to its tile cells."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
     _, w3n = _last_layer(sd, "node_weight_generator")
     _, w3e = _last_layer(sd, "edge_weight_generator")
@@ -1710,13 +1725,13 @@ def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_ed
     add_tp_items(prog, seg_of_k, PlanarLayout(irreps_node), 2, [SRC_XS, SRC_XD], irreps_sh, irreps_out,
                  np.asarray(sd["node_tensor_product.weight"]), w3n / math.sqrt(H),
                  np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]), mlp=0,
-                 merge_groups=merge_groups)
+                 merge_groups=merge_groups, zero_inputs=zero_node)
     add_tp_items(prog, seg_of_k, PlanarLayout(irreps_edge), 1, [SRC_F], irreps_sh, irreps_out,
                  np.asarray(sd["edge_tensor_product.weight"]), w3e / math.sqrt(H),
                  np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]), mlp=1,
-                 merge_groups=merge_groups)
+                 merge_groups=merge_groups, zero_inputs=zero_edge)
     if skip_weight is not None:
-        add_linear_items(prog, seg_of_k, PlanarLayout(irreps_edge), SRC_F, irreps_out, np.asarray(skip_weight))
+        add_linear_items(prog, seg_of_k, PlanarLayout(irreps_edge), SRC_F, irreps_out, np.asarray(skip_weight), zero_inputs=zero_edge)
     return prog.finalize()
 
 

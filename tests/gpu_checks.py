@@ -712,6 +712,42 @@ def check_wide_vs_is(device="cuda", E=4099, nodes=301):
     return {"wide_vs_is": rel(b, a), "wide_repeat_max_abs": float((b - c).abs().max()), "nan": float(torch.isnan(b).any())}
 
 
+def check_structural_zeros(device="cuda", legacy=False, n_atoms=9, seed=11):
+    """r5: the first layer's programs drop the super-paths that read structurally zero input irreps (hamgnn_conv._mark_structural_zeros).  (1) the blocks
+    they treat as zero ARE zero in the rows the embeddings produce (HG_CHECK_STRUCT_ZEROS asserts it inside the forward); (2) the backbone's rows equal those
+    of the same model compiled WITHOUT the shortcut (HG_STRUCT_ZEROS=0: every path of the reference issued); (3) the programs did shrink."""
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    cfg = dict(num_types=96, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=MINI, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
+    torch.manual_seed(seed)
+    m = HamGNNConvE3(cfg)
+    g = S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004).to(device)
+    out = {}
+    os.environ["HG_CHECK_STRUCT_ZEROS"] = "1"
+    try:
+        with torch.no_grad():
+            a = m(g)
+        mf = lambda blk: int(blk.conv_tp._dp_for(int(g.num_edges), True).prog.mfma_per_wave)
+        small = [mf(m.convolutions[0]), mf(m.convolutions[-1])]
+        os.environ["HG_STRUCT_ZEROS"] = "0"
+        m.compile(torch.device(device))
+        with torch.no_grad():
+            b = m(g)
+        full = [mf(m.convolutions[0]), mf(m.convolutions[-1])]
+    finally:
+        os.environ.pop("HG_CHECK_STRUCT_ZEROS", None)
+        os.environ.pop("HG_STRUCT_ZEROS", None)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    out["node_rel_err"] = rel(a["node_attr"], b["node_attr"])
+    out["edge_rel_err"] = rel(a["edge_attr"], b["edge_attr"])
+    out["first_layer_mfma_ratio"] = small[0] / full[0]
+    out["last_layer_mfma_ratio"] = small[1] / full[1]
+    return out
+
+
 def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):
     """backward of ResidualBlock (x + Lin2(Gate(Lin1(x)))): data gradient (hg_linear_planar on transposed blocks,
     hg_gate_backward) and the two Linear weight gradients (one GEMM per path) vs torch.autograd through the fp64 oracle"""

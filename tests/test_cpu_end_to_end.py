@@ -96,6 +96,8 @@ _FORWARD_CASES = {
     "conv_message_chain_backward": lambda: G.check_conv_message_backward("cpu", n_atoms=4),
     "front_door": lambda: G.check_front_door("cpu", tmpdir="/tmp/hg_front_door_cpu"),
     "fused_scatter": lambda: G.check_fused_scatter("cpu", n_atoms=5),
+    "structural_zeros": lambda: G.check_structural_zeros("cpu", n_atoms=4),
+    "structural_zeros_legacy": lambda: G.check_structural_zeros("cpu", legacy=True, n_atoms=4),
 }
 
 

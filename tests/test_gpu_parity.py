@@ -116,6 +116,15 @@ def test_fused_node_scatter_equals_message_rows_plus_segment_sum():
     assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6, r
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_structural_zero_inputs_of_the_first_layer(legacy):
+    """r5: the programs of the leading layers skip the super-paths whose input irreps are structurally zero (node rows out of the 0e embedding Linear, edge rows
+    out of the 0e x Y^l pair embedding; with legacy_edge_update the edge rows stay the embedding's for one more layer): same rows as the complete programs"""
+    r = G.check_structural_zeros(legacy=legacy)
+    print(r)
+    assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6 and r["first_layer_mfma_ratio"] < 0.6 and (legacy or r["last_layer_mfma_ratio"] == 1.0), r
+
+
 def test_corr_product_block_golden():
     r = G.check_corr_product()
     print(r)
