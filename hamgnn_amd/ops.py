@@ -49,7 +49,7 @@ def require_fp32(module, data=None):
     why = None
     if torch.get_default_dtype() == torch.float64:
         why = "torch.get_default_dtype() is float64"
-    elif module is not None and any(p.dtype == torch.float64 for p in module.parameters()):
+    elif module is not None and next((p.dtype for p in module.parameters()), None) == torch.float64:      # (model.to(float64) converts every parameter: the first one tells; O(1) per forward)
         why = "the model's parameters are float64"
     elif data is not None:
         pos = data["pos"] if isinstance(data, dict) else getattr(data, "pos", None)
