@@ -332,6 +332,9 @@ def main():
     model = HamGNNConvE3(make_cfg(irreps, args.lite))
     head = HamGNNPlusPlusOut(irreps, irreps, nao_max=args.nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True,
                              soc_switch=args.soc, soc_basis="so3", calculate_sparsity=True, zero_point_shift=False)   # the reference's defaults
+    # the reference runs the two as Model(representation, output): the output module is the representation's only reader (Model.py:459-465), which lets the
+    # backbone's last PairInteractionBlock skip the irreps the head never reads (hamgnn_amd.models.model.Model does this call in its constructor)
+    model.declare_consumer(head)
     g = make_graph(args.workload, args.nao, soc=args.soc)
     E_total, N_atoms = g.num_edges, g.num_nodes
     if world > 1:
@@ -440,13 +443,14 @@ def main():
     # the programs of a step in launch order (ConvBlock, PairInteractionBlock per layer).  r5: the FIRST layer's programs drop the super-paths that read
     # structurally zero input irreps (node rows out of the 0e embedding Linear, edge rows out of the 0e x Y^l pair embedding: hamgnn_conv._mark_structural_zeros),
     # so the launches of a step are not all the same program any more: flops are summed program by program
-    dps = []
+    # r5b: ... and the LAST PairInteractionBlock drops the output irreps the read-out head never reads (HamGNNConvE3.declare_consumer).
+    dps, full_of = [], []
     for conv, pair in zip(model.convolutions, model.pair_interactions):
-        dps.append(conv.conv_tp._dp_for(E_local, True))        # the program the launch ran (first layer: the reduced one)
+        dps.append(conv.conv_tp._dp_for(E_local, True))        # the program the launch ran (first layer / last pair block: the reduced one)
+        full_of.append(conv.conv_tp._dp_for(E_local, False).prog)      # the complete program of the same block (every path of the reference)
         if pair.use_skip_connections or not pair.legacy_edge_update:
             dps.append(pair.conv_tp._dp_for(E_local, True))
-    full = dps[-1].prog
-    full_of = [dps[-2].prog if (len(dps) >= 2 and k % 2 == 0 and len(dps) % 2 == 0) else dps[-1].prog for k in range(len(dps))]      # the complete program of the same kind (ConvBlock / PairInteractionBlock + skip Linear)
+            full_of.append(pair.conv_tp._dp_for(E_local, False).prog)
     issued_of = lambda dp: (dp.prog.mfma_per_wave - (dp.prog.mfma_odd_skipped if dp.sched is not None else 0)) * 2048.0 / 16.0
     t_tot = sum(t for t, _, _ in mp)
     useful_tot = sum(dps[k % len(dps)].prog.flops_per_row * r for k, (_, r, _) in enumerate(mp))

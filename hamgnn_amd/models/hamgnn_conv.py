@@ -180,20 +180,35 @@ class _BackboneBase(nn.Module):
                 gens += [g for g in (m._hn, m._he) if g is not None]
         return gens
 
-    def _representation(self, node, f, geo):
+    def _representation(self, node, f, geo, full_edge_rows=None):
+        """full_edge_rows: None, or -- when `f` holds only the irreps the declared consumer reads (declare_consumer) -- a thunk that evaluates the COMPLETE
+        edge rows; the public `edge_attr` goes through it, so anything but the declared head sees exactly what the reference returns"""
         rep = Representation()
         imap, rot_tab = self._imap, self._rot_tab
         rep.set_lazy("node_attr", lambda: ops.from_planar(node, imap))
-        rep.set_lazy("edge_attr", lambda: ops.from_planar(ops.rotate_gather(f, None, geo, rot_tab, transpose=True), imap))
+        if full_edge_rows is None:
+            rep.set_lazy("edge_attr", lambda: ops.from_planar(ops.rotate_gather(f, None, geo, rot_tab, transpose=True), imap))
+        else:
+            rep["_edge_alive"] = self._edge_alive
+            rep.set_lazy("_edge_planar_rot_full", full_edge_rows)
+            rep.set_lazy("edge_attr", lambda: ops.from_planar(ops.rotate_gather(rep["_edge_planar_rot_full"], None, geo, rot_tab, transpose=True), imap))
         # extras for the MI355X head: skip the layout/frame round trip
         rep["_node_planar"], rep["_edge_planar_rot"], rep["_geometry"] = node, f, geo
         return rep
 
-    def _run_pair(self, pair, node, f, geo):
-        """PairInteractionBlock.forward (interaction_blocks.py:130-164)"""
+    # ---- unread irreps of the last PairInteractionBlock (r5)
+    _edge_alive = None
+
+    def declare_consumer(self, head):
+        """(backbones that can leave out unread irreps override this: HamGNNConvE3)"""
+        return []
+
+    def _run_pair(self, pair, node, f, geo, reduced=True):
+        """PairInteractionBlock.forward (interaction_blocks.py:130-164).  reduced: the block may run its reduced program (structurally zero inputs of a first
+        layer, unread outputs of a last layer whose consumer was declared)"""
         if pair.use_skip_connections or not pair.legacy_edge_update:               # legacy layer-0: edge features kept (:154-156)
             # (structural_zeros: inside a backbone's forward the rows are what set_structural_zeros was told about -- a first-layer block runs its reduced program)
-            mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab, structural_zeros=True)   # edge frame (+ fused skip linear)
+            mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab, structural_zeros=reduced)   # edge frame (+ fused skip linear)
             if self.lite_mode and pair.use_skip_connections:
                 mix = pair.skip_linear(f, res=[mix])
             f = mix
@@ -291,6 +306,29 @@ class HamGNNConvE3(_BackboneBase):
                 pair.conv_tp.set_structural_zeros(node=(), edge=zero_edge)
                 zero_edge = ()
 
+    def declare_consumer(self, head):
+        """Tell the backbone that `head` is the ONLY reader of the representation it returns (what `Model(representation, output)` wires: Model.py:459-465 of
+        the reference passes the representation to the output module and nowhere else).  If the head can say which (l, p) classes of the edge rows it reads
+        (HamGNNPlusPlusOut.edge_irreps_read), the LAST PairInteractionBlock stops computing the others: its reduced program drops their super-paths
+        (plan.build_message_pack_program dead_out; set-A with nao_max 19: 0o, 4o, 5o, 5e, 6e = 15 % of that launch's MFMAs).  What the reference API promises
+        stays true: `rep["edge_attr"]` (and a head that reads more than the declared one) gets the complete rows -- the block's inputs are kept on the
+        representation and the complete program runs on first access.  Training forwards (save_for_backward) always run the complete program.
+        HG_DEAD_OUT=0 disables.  Returns the list of dropped irreps (indices into irreps_node_features)."""
+        self._edge_alive = None
+        pairs = getattr(self, "pair_interactions", None)
+        if pairs is None or self.lite_mode or not hasattr(head, "edge_irreps_read") or os.environ.get("HG_DEAD_OUT", "1") == "0":
+            return []
+        last = pairs[-1]
+        if not (last.use_skip_connections or not last.legacy_edge_update):      # a legacy single-layer backbone: the block is not evaluated at all
+            return []
+        need = head.edge_irreps_read()
+        dead = [k for k, (m, l, p) in enumerate(self.irreps_node_features) if (int(l), int(p)) not in need]
+        last.conv_tp.set_dead_outputs(dead)
+        if dead:
+            self._edge_alive = frozenset((int(l), int(p)) for k, (m, l, p) in enumerate(self.irreps_node_features) if k not in dead)
+        self._compiled_for = None                                # the reduced program is built at the next compile()
+        return dead
+
     # ------------------------------------------------------------------------------------------------------------
     def compile(self, device):
         """(Re)pack all weights into MFMA fragment order and upload.  Call again after changing parameters."""
@@ -337,6 +375,11 @@ class HamGNNConvE3(_BackboneBase):
                     assert float(rows[:, o:o + w].abs().max()) == 0.0, ("structural zero violated", i)
         rowptr, perm = topo.receiver_csr()
         tape = [] if save_for_backward else None
+        # the last PairInteractionBlock may leave out the irreps its declared consumer never reads (declare_consumer) -- not while training: a block with
+        # declared dead outputs then runs its complete program
+        last = self.pair_interactions[-1]
+        has_dead = "dead_out" in last.conv_tp._zero_kw()
+        skip_dead = has_dead and tape is None and self._edge_alive is not None
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             row_shard = tape is None and parallel.node_shard_enabled(data)      # HG_NODE_SHARD=1: the node-level chain on this rank's block of rows only
@@ -358,7 +401,7 @@ class HamGNNConvE3(_BackboneBase):
                 if self.use_corr_prod:
                     part = self.corr_products[li](part, z[r0:r1].contiguous(), None if self._last_delta is None else self._last_delta[r0:r1].contiguous())
                 node = parallel.allgather_nodes(part, data, N)
-                f = self._run_pair(pair, node, f, geo)
+                f_in, f = f, self._run_pair(pair, node, f, geo, reduced=(pair is not last) or skip_dead or not has_dead)
                 continue
             parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
             if tape is not None:
@@ -370,8 +413,8 @@ class HamGNNConvE3(_BackboneBase):
                 node = self.corr_products[li](node, z, self._last_delta)
             if tape is not None:
                 tape[-1]["node_out"] = node
-            f = self._run_pair(pair, node, f, geo)
-        rep = self._representation(node, f, geo)
+            f_in, f = f, self._run_pair(pair, node, f, geo, reduced=(pair is not last) or skip_dead or not has_dead)
+        rep = self._representation(node, f, geo, (lambda: self._run_pair(last, node, f_in, geo, reduced=False)) if skip_dead else None)
         if tape is not None:
             rep["_tape"] = tape
             if self._last_delta is not None:

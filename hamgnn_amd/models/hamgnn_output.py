@@ -298,7 +298,7 @@ class HamGNNPlusPlusOut(nn.Module):
         if self._compiled_for != dev:
             self.compile(dev)
         geo = rep["_geometry"]
-        node_pl, edge_rot = rep["_node_planar"], rep["_edge_planar_rot"]
+        node_pl, edge_rot = rep["_node_planar"], self._edge_rows_of(rep)
         inv, edge_counts = self._global_inverse(data)
         n = self.nao_max
         gH = grad_hamiltonian.float()
@@ -390,6 +390,24 @@ class HamGNNPlusPlusOut(nn.Module):
         grads.update({"offsite_hamiltonian_network." + k: v for k, v in gw_off.items()})
         return g_node, g_edge, grads
 
+    def edge_irreps_read(self):
+        """the (l, parity) classes of the representation's EDGE rows this head's result depends on: the union over its off-site networks
+        (HamLayer.input_irreps_read).  A backbone that knows its only consumer (HamGNNConvE3.declare_consumer, called by Model) need not compute the others
+        in its last PairInteractionBlock; e.g. openmx nao_max 19 (s3 p2 d2): l <= 4 with parity (-1)^l ... never 0o, 4o, 5o, 5e, 6e of the shipped features."""
+        nets = [n_ for n_ in (getattr(self, k, None) for k in ("offsite_hamiltonian_network", "offsite_overlap_network", "offsite_ksi_network")) if n_ is not None]
+        return frozenset().union(*(n_.input_irreps_read() for n_ in nets))
+
+    def _edge_rows_of(self, rep):
+        """the planar edge-frame rows of the representation, complete in every irrep this head reads.  A backbone that skipped unread irreps says which
+        ones it did compute (`_edge_alive`); if that does not cover this head (another head than the declared consumer), the complete rows are asked for
+        (`_edge_planar_rot_full`: evaluated on first access)."""
+        if not hasattr(rep, "get"):
+            return None
+        alive = rep.get("_edge_alive")
+        if alive is not None and not (self.edge_irreps_read() & frozenset((int(l), int(p)) for _, l, p in self.edge_layout.irreps)) <= alive:
+            return rep["_edge_planar_rot_full"]
+        return rep.get("_edge_planar_rot")
+
     def forward(self, data, graph_representation=None):
         rep = graph_representation
         ops.require_fp32(self, data)                           # `precision: 64` raises instead of returning fp32-accurate rows
@@ -404,7 +422,7 @@ class HamGNNPlusPlusOut(nn.Module):
         node_pl = rep.get("_node_planar") if hasattr(rep, "get") else None
         if node_pl is None:
             node_pl = ops.to_planar(rep["node_attr"], self._n_imap, self.node_layout.dim)
-        edge_rot = rep.get("_edge_planar_rot") if hasattr(rep, "get") else None
+        edge_rot = self._edge_rows_of(rep)
         if edge_rot is None:
             edge_rot = ops.rotate_gather(ops.to_planar(rep["edge_attr"], self._e_imap, self.edge_layout.dim), None, geo, self._rot_tab)
         inv, edge_counts = self._global_inverse(data)

@@ -89,6 +89,9 @@ class Model(nn.Module):
         # return_forces: the reference only enables autograd on batch.pos in its Lightning steps (Model.py:227, 285, 459-460) and computes no
         # force anywhere; the flag is carried for interface parity and changes nothing here either
         self.requires_derivatives = bool(getattr(self.output_module, "derivative", False))
+        # forward() hands the representation to the output module and to nobody else (Model.py:459-465): the backbone may skip what that head never reads
+        if hasattr(self.representation, "declare_consumer"):
+            self.representation.declare_consumer(self.output_module)
 
     def forward(self, batch):
         representation = self.representation(batch)

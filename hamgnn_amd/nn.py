@@ -247,11 +247,25 @@ class MessagePackBlock(nn.Module):
         self._zeros = (tuple(sorted(int(i) for i in node)), tuple(sorted(int(i) for i in edge)))
         return self
 
+    def set_dead_outputs(self, out=()):
+        """irreps (indices into irreps_out) of this block's result that NOBODY reads where it runs (the last PairInteractionBlock of a backbone whose only
+        consumer is a read-out head that declared what it reads: HamGNNConvE3.declare_consumer).  The reduced program (`structural_zeros=True` launches) drops
+        their super-paths and writes zeros there; the generic program stays complete.  Takes effect at the next compile()."""
+        self._dead = tuple(sorted(int(k) for k in out))
+        return self
+
     def _zero_kw(self):
+        """what the REDUCED forward program of this block may assume (plan.build_message_pack_program): structurally zero input irreps, unread output irreps"""
         zn, ze = getattr(self, "_zeros", ((), ()))
-        if os.environ.get("HG_STRUCT_ZEROS", "1") == "0" or self.lite_mode:
+        dead = getattr(self, "_dead", ())
+        if self.lite_mode:
             return {}
-        return {"zero_node": zn, "zero_edge": ze} if (zn or ze) else {}
+        kw = {}
+        if os.environ.get("HG_STRUCT_ZEROS", "1") != "0" and (zn or ze):
+            kw.update(zero_node=zn, zero_edge=ze)
+        if os.environ.get("HG_DEAD_OUT", "1") != "0" and dead:
+            kw["dead_out"] = dead
+        return kw
 
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
@@ -295,9 +309,13 @@ class MessagePackBlock(nn.Module):
                                                             skip_weight, merge_groups=groups)
                         self._dp = ops.DeviceProgram(prog, device, schedule="is")
                         self._compile_args = (bool(unrotate), skip_weight is not None, groups)
-                        if zkw:                                # the same block for rows whose marked irreps are structurally zero (first layer of a backbone)
+                        if zkw:                                # the same block for rows whose marked irreps are structurally zero (first layer of a backbone) /
+                            gz = groups                        # whose marked output irreps nobody reads (last PairInteractionBlock): those leave the row-tile groups
+                            if zkw.get("dead_out"):
+                                gz = P.choose_merge_groups(self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, self._hn[-1].shape[1], dead_out=zkw["dead_out"])
+                            self._groups_z = gz
                             self._dp_z = ops.DeviceProgram(P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate,
-                                                                                       skip_weight, merge_groups=groups, **zkw), device, schedule="is")
+                                                                                       skip_weight, merge_groups=gz, **zkw), device, schedule="is")
                         # launches with fewer 16-edge tiles than workgroup slots run the PLAIN program split over one workgroup per output
                         # segment: merging trades parts (9 instead of 13 for set-A) for MFMAs, the wrong trade when latency is all there is
                         # (Si 2-atom cell: 0.113 -> 0.110 ms per launch); built on first use
@@ -355,13 +373,14 @@ class MessagePackBlock(nn.Module):
             dp.weights_changed()
 
         zkw = self._zero_kw()
-        ztag = (zkw.get("zero_node", ()), zkw.get("zero_edge", ()))
+        ztag = (zkw.get("zero_node", ()), zkw.get("zero_edge", ()), zkw.get("dead_out", ()))
         fwd = lambda g_, z_=None: (lambda d, sk: P.build_message_pack_program(d, *args, unrotate, sk, **({"merge_groups": g_} if g_ else {}), **(z_ or {})).weights)
         update(self._dp, ("fwd", unrotate, has_skip, bool(groups)), fwd(groups), nskip)
         if getattr(self, "_dp_plain", None) is not None and self._dp_plain is not self._dp:
             update(self._dp_plain, ("fwd", unrotate, has_skip, False), fwd(None), nskip)
         if getattr(self, "_dp_z", None) is not None:
-            update(self._dp_z, ("fwd", unrotate, has_skip, bool(groups), ztag), fwd(groups, zkw), nskip)
+            gz = getattr(self, "_groups_z", groups) if groups else groups
+            update(self._dp_z, ("fwd", unrotate, has_skip, bool(gz), ztag), fwd(gz, zkw), nskip)
         if getattr(self, "_dp_z_plain", None) is not None and self._dp_z_plain is not self._dp_z:
             update(self._dp_z_plain, ("fwd", unrotate, has_skip, False, ztag), fwd(None, zkw), nskip)
         if getattr(self, "_dp_adj", None) is not None:
@@ -422,7 +441,8 @@ class MessagePackBlock(nn.Module):
 
     def _dp_for(self, rows: int, structural_zeros: bool = False):
         """the program a launch of `rows` edges runs: the merged one, or -- split launches of small crystals -- the plain one; structural_zeros: the caller
-        vouches that the irreps marked by set_structural_zeros are zero in the rows it passes (the backbone's first layer): the reduced program"""
+        vouches that the irreps marked by set_structural_zeros are zero in the rows it passes (the backbone's first layer) AND that nobody reads the output
+        irreps marked by set_dead_outputs (they come back as zeros): the reduced program"""
         z = structural_zeros and getattr(self, "_dp_z", None) is not None
         dp = self._dp_z if z else self._dp
         if getattr(self, "_plain_args", None) is None or dp.is_parts_for(rows) == 1:
@@ -907,6 +927,14 @@ class HamLayer(nn.Module):
         self.irreps_in, self.ham_irreps, self.keep = Irreps(irreps_in), ham_irreps, keep
         self.residual_block = ResidualBlock(irreps_in, irreps_in, nonlinearity_type=nonlinearity_type)
         self.linear_transform = E3Linear(irreps_in, ham_irreps)
+
+    def input_irreps_read(self):
+        """the (l, parity) classes of the INPUT rows this network's result depends on.  Every map of the chain connects equal (l, p) only -- o3.Linear by
+        construction, the Gate multiplies an irrep by a 0e gate scalar, NormActivation rescales an irrep by a function of its own norm (hamgnn_output.py:38-58;
+        e3nn nn/_gate.py, nn/_normact.py) -- so an output irrep (L, p) sees the input blocks (L, p) and, through the gates, (0, +1); nothing else.
+        (tests: perturbing any other input block leaves the result bit-identical.)"""
+        keep = self.keep if self.keep is not None else [True] * len(self.ham_irreps)
+        return frozenset((int(l), int(p)) for (m, l, p), kp in zip(self.ham_irreps, keep) if kp and m > 0) | {(0, 1)}
 
     def compile(self, device):
         self.residual_block.compile(device)

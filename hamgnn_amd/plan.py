@@ -324,12 +324,13 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
     else:
         parts = max(1, min(int(parts), nkeys))
     if parts > 1 and not owner.any():
-        load = [0.0] * parts
+        load, held = [0.0] * parts, [0] * parts
         for sg in np.argsort(-seg_cost, kind="stable"):
             if key_of[sg] != sg:
                 continue
-            r = load.index(min(load))
+            r = min(range(parts), key=lambda q: (load[q], held[q], q))      # (segments without items -- dead outputs -- must not pile up and leave a part empty)
             load[r] += seg_cost[sg]
+            held[r] += 1
             for m in range(nseg):
                 if key_of[m] == sg:
                     owner[m] = r
@@ -1343,8 +1344,11 @@ def _tp_superpaths(nsrc: int, in_layout: PlanarLayout, irreps_sh: Irreps, irreps
 
 def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, nsrc: int, srcs: Sequence[int],
                  irreps_sh: Irreps, irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray,
-                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False, merge_groups: Sequence[Sequence[int]] = (), zero_inputs: Sequence[int] = ()):
+                 lin_out_w: Optional[np.ndarray], mlp: int, uvu: bool = False, merge_groups: Sequence[Sequence[int]] = (), zero_inputs: Sequence[int] = (),
+                 dead_out: Sequence[int] = ()):
     """Items of ONE reference tensor-product branch (node or edge) of a MessagePackBlock / embedding TP.
+    dead_out: output irreps (indices into irreps_out) nobody reads where this block runs -- their super-paths are dropped and their tiles are written as
+    zeros (see build_message_pack_program); a merge group must not contain one (choose_merge_groups(dead_out=...)).
     zero_inputs: input irreps (indices into in_layout.irreps) whose rows are STRUCTURALLY zero for this block -- every super-path that reads one of
     them contributes exactly nothing and is dropped (see build_message_pack_program).
     merge_groups: lists of output irreps k whose super-paths from one input irrep are stacked into ONE item (see Program.vsegs):
@@ -1375,8 +1379,10 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
     stacked: Dict[Tuple[int, int], List[dict]] = {}
     plain: List[dict] = []
     zero_inputs = set(int(i) for i in zero_inputs)
+    dead_out = set(int(k) for k in dead_out)
+    assert not (dead_out & set(group_of)), "a merge group holds a dead output irrep"
     for sp in _tp_superpaths(nsrc, in_layout, irreps_sh, irreps_out, tp_weight, w3, lin_scale_w, lin_out_w, uvu):
-        if sp["i"] in zero_inputs:
+        if sp["i"] in zero_inputs or sp["k"] in dead_out:
             continue
         gi = group_of.get(sp["k"])
         if gi is not None and sp["li"] <= lmin[gi]:
@@ -1492,10 +1498,11 @@ def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_
 
 
 def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayout, src: int, irreps_out: Irreps,
-                     weight: np.ndarray, extra_scale: float = 1.0, zero_inputs: Sequence[int] = ()):
+                     weight: np.ndarray, extra_scale: float = 1.0, zero_inputs: Sequence[int] = (), dead_out: Sequence[int] = ()):
     """Items of one o3.Linear(irreps_in -> irreps_out) (e3nn: paths ordered by (i_in, i_out), 1/sqrt(fan_in)); zero_inputs: structurally zero input
-    irreps whose paths are dropped (the weights are still walked: the flat layout is the reference's)."""
+    irreps, dead_out: output irreps nobody reads -- their paths are dropped (the weights are still walked: the flat layout is the reference's)."""
     zero_inputs = set(int(i) for i in zero_inputs)
+    dead_out = set(int(k) for k in dead_out)
     irr_in = in_layout.irreps
     paths = [(i, k) for i, (_, li, pi) in enumerate(irr_in) for k, (_, lk, pk) in enumerate(irreps_out) if (li, pi) == (lk, pk)]
     fan = {}
@@ -1507,7 +1514,7 @@ def add_linear_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarL
         mk = irreps_out[k][0]
         Wfull = weight[off:off + mi * mk].reshape(mi, mk).astype(np.float64) * (extra_scale / math.sqrt(fan[k]))
         off += mi * mk
-        if i in zero_inputs:
+        if i in zero_inputs or k in dead_out:
             continue
         ksteps = in_layout.mulp[i] // 4
         # rows chunked like TP items so that the per-wave register budget is the same
@@ -1653,11 +1660,13 @@ def _last_layer(sd, prefix):
     return ks, np.asarray(sd[ks[-1]], dtype=np.float64)
 
 
-def choose_merge_groups(irreps_node, irreps_edge, irreps_sh, irreps_out, hidden: int) -> List[List[int]]:
+def choose_merge_groups(irreps_node, irreps_edge, irreps_sh, irreps_out, hidden: int, dead_out: Sequence[int] = ()) -> List[List[int]]:
     """Which small output irreps share their MFMA row tiles (add_tp_items merge_groups): per parity class (l + [p odd]) mod 2, the
     partition of the irreps with <= 16 channels that minimises the issued MFMAs of the block (exhaustive over the handful of
-    candidates; cost = the planner's own count: radial scale + GEMM1 + GEMM2 per super-path, node and edge branch)."""
+    candidates; cost = the planner's own count: radial scale + GEMM1 + GEMM2 per super-path, node and edge branch).  dead_out: output irreps the
+    program does not compute (build_message_pack_program): never grouped."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
+    dead_out = set(int(k) for k in dead_out)
     H4 = ceil_div(hidden, 16) * 4
     branches = []
     for nsrc, irr in ((2, irreps_node), (1, irreps_edge)):
@@ -1698,7 +1707,7 @@ def choose_merge_groups(irreps_node, irreps_edge, irreps_sh, irreps_out, hidden:
 
     out: List[List[int]] = []
     for cls in (0, 1):
-        cand = [k for k, (m, l, p) in enumerate(irreps_out) if m <= 16 and (l + (p == -1)) % 2 == cls and m <= seg_rows_cap(l)]
+        cand = [k for k, (m, l, p) in enumerate(irreps_out) if m <= 16 and (l + (p == -1)) % 2 == cls and m <= seg_rows_cap(l) and k not in dead_out]
         if len(cand) < 2 or len(cand) > 7:
             continue
         best = min((p for p in partitions(cand) if all(sum(irreps_out[k][0] for k in G) <= 64 for G in p)), key=cost)
@@ -1708,14 +1717,19 @@ def choose_merge_groups(irreps_node, irreps_edge, irreps_sh, irreps_out, hidden:
 
 def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out, unrotate: bool,
                                skip_weight: Optional[np.ndarray] = None, merge_groups: Sequence[Sequence[int]] = (),
-                               zero_node: Sequence[int] = (), zero_edge: Sequence[int] = ()) -> Program:
+                               zero_node: Sequence[int] = (), zero_edge: Sequence[int] = (), dead_out: Sequence[int] = ()) -> Program:
     """MessagePackBlock (non-lite, message_passing.py:216-229) [+ the PairInteractionBlock skip o3.Linear on the edge
     features, interaction_blocks.py:151-152] as ONE fused-kernel program.  `sd`: reference-named arrays of the block.
     zero_node / zero_edge (r5): irreps of the node / edge feature rows that are STRUCTURALLY zero where this block runs -- the first layer reads node rows
     that come out of an o3.Linear from `num_types x 0e` (only 0e blocks can be non-zero: _atomwise.py:55-57) and edge rows that come out of the pair embedding's
     0e (x) Y^l product (only the irreps of the spherical harmonics: embeddings.py:310-337).  The reference multiplies those zeros through every path
     (message_passing.py:216-229); here the super-paths (and skip-Linear paths) that read them are not emitted: same rows, bit for bit in exact arithmetic,
-    because a dropped item would have added +0.0 to its tile cells."""
+    because a dropped item would have added +0.0 to its tile cells.
+    dead_out (r5): output irreps whose rows NOBODY reads where this block runs -- the edge rows of the last PairInteractionBlock feed only the read-out head,
+    whose o3.Linear / Gate chain connects equal (l, p) only (hamgnn_output.py:38-58: it reads the irreps of the Hamiltonian blocks + the 0e gate scalars;
+    e.g. 0o, 4o, 5o, 5e, 6e of the shipped set are never read for nao_max 19).  Their super-paths and skip-Linear paths are not emitted and their blocks of
+    the output rows are written as ZEROS: a caller may use such a program only if it can hand the complete rows to anyone who asks later
+    (HamGNNConvE3.declare_consumer keeps the inputs and re-runs the complete program on first access of the public `edge_attr`)."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
     _, w3n = _last_layer(sd, "node_weight_generator")
     _, w3e = _last_layer(sd, "edge_weight_generator")
@@ -1725,13 +1739,13 @@ def build_message_pack_program(sd: Dict[str, np.ndarray], irreps_node, irreps_ed
     add_tp_items(prog, seg_of_k, PlanarLayout(irreps_node), 2, [SRC_XS, SRC_XD], irreps_sh, irreps_out,
                  np.asarray(sd["node_tensor_product.weight"]), w3n / math.sqrt(H),
                  np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]), mlp=0,
-                 merge_groups=merge_groups, zero_inputs=zero_node)
+                 merge_groups=merge_groups, zero_inputs=zero_node, dead_out=dead_out)
     add_tp_items(prog, seg_of_k, PlanarLayout(irreps_edge), 1, [SRC_F], irreps_sh, irreps_out,
                  np.asarray(sd["edge_tensor_product.weight"]), w3e / math.sqrt(H),
                  np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]), mlp=1,
-                 merge_groups=merge_groups, zero_inputs=zero_edge)
+                 merge_groups=merge_groups, zero_inputs=zero_edge, dead_out=dead_out)
     if skip_weight is not None:
-        add_linear_items(prog, seg_of_k, PlanarLayout(irreps_edge), SRC_F, irreps_out, np.asarray(skip_weight), zero_inputs=zero_edge)
+        add_linear_items(prog, seg_of_k, PlanarLayout(irreps_edge), SRC_F, irreps_out, np.asarray(skip_weight), zero_inputs=zero_edge, dead_out=dead_out)
     return prog.finalize()
 
 

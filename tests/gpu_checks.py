@@ -748,6 +748,86 @@ def check_structural_zeros(device="cuda", legacy=False, n_atoms=9, seed=11):
     return out
 
 
+def check_dead_outputs(device="cuda", n_atoms=9, seed=12, num_layers=2, soc=False, nao=19, irr=None, nonlinearity_type="gate", workload=None):
+    """r5: a backbone that knows its only consumer (HamGNNConvE3.declare_consumer; Model does the call) leaves out, in its LAST PairInteractionBlock, the
+    output irreps the head never reads.  (1) the head's rows are the same as without the shortcut; (2) the head's claim is true: its result does not move
+    when the unread blocks of the edge rows are filled with noise; (3) the public `edge_attr` is still the complete tensor (lazy complete re-run), and a head
+    that reads MORE than the declared one is served the complete rows; (4) a training forward (save_for_backward) runs the complete program; (5) the reduced
+    program is smaller and writes zeros into the unread blocks."""
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    irr = irr or MINI
+    cfg = dict(num_types=96, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=num_layers, irreps_node_features=irr, use_kan=False, radial_MLP=[16, 16],
+               correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=False)
+    torch.manual_seed(seed)
+    back = HamGNNConvE3(cfg)
+    hkw = dict(nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, zero_point_shift=False, soc_switch=bool(soc), soc_basis="su2" if soc == "su2" else "so3",
+               nonlinearity_type=nonlinearity_type)
+    head = HamGNNPlusPlusOut(irr, irr, **hkw)
+    if workload is not None:                                   # one of bench.py's crystals (e.g. sio2_300: enough 16-edge tiles for the single-part launch)
+        import bench
+        g = bench.make_graph(workload, nao)
+    else:
+        g = S.random_cell(n_atoms, [14, 8, 6, 1], seed=seed, density=0.004)
+    if soc and soc != "su2":
+        gen = torch.Generator().manual_seed(seed)
+        N, E = g.num_nodes, g.num_edges
+        g["Lon"] = torch.randn(N, 3 * nao * nao, generator=gen)
+        g["Loff"] = torch.randn(E, 3 * nao * nao, generator=gen)
+    g = g.to(device)
+    dev = torch.device(device)
+    out = {}
+    with torch.no_grad():
+        rep0 = back.to(dev)(g)                                  # no consumer declared: complete rows
+        H0 = head.to(dev)(g, rep0)["hamiltonian"].clone()
+        full_edge = rep0["edge_attr"].clone()
+        full_rows = rep0["_edge_planar_rot"].clone()
+        model = Model(back, head)                               # declares the head as the only reader
+        dead = list(back.pair_interactions[-1].conv_tp._dead)
+        out["dead_irreps"] = len(dead)
+        rep1 = back(g)
+        H1 = model.output_module(g, rep1)["hamiltonian"].clone()
+        out["alive_declared"] = float(rep1.get("_edge_alive") is not None)
+        out["ham_rel_err"] = rel(H1, H0)
+        rows1 = rep1["_edge_planar_rot"]
+        lay = back.layout
+        zmax, amax = 0.0, 0.0
+        noisy = full_rows.clone()
+        for k in dead:
+            o, w = lay.off[k], (2 * lay.irreps[k][1] + 1) * lay.mulp[k]
+            zmax = max(zmax, float(rows1[:, o:o + w].abs().max()))
+            amax = max(amax, float(full_rows[:, o:o + w].abs().max()))
+            noisy[:, o:o + w] = torch.randn(noisy.shape[0], w, device=dev) * 3.0
+        out["dead_blocks_max_abs"] = zmax                      # written as zeros
+        out["dead_blocks_full_max_abs"] = amax                 # ... where the complete program has values
+        # (2) the head does not read them
+        rep_n = type(rep0)()
+        rep_n["_node_planar"], rep_n["_edge_planar_rot"], rep_n["_geometry"] = rep0["_node_planar"], noisy, rep0["_geometry"]
+        out["ham_noise_max_abs"] = float((head(g, rep_n)["hamiltonian"] - H0).abs().max())
+        # (3) the public tensor, and a wider head
+        out["edge_attr_rel_err"] = rel(rep1["edge_attr"], full_edge)
+        class _Narrow:                                          # a consumer that reads less than the real head
+            edge_irreps_read = staticmethod(lambda: frozenset({(0, 1), (1, -1)}))
+        back.declare_consumer(_Narrow())
+        rep2 = back(g)                                          # (recompiles: the reduced program changed)
+        out["narrow_alive"] = len(rep2["_edge_alive"])
+        out["wider_head_rel_err"] = rel(head(g, rep2)["hamiltonian"], H0)      # the head reads more than was declared: served the complete rows
+        back.declare_consumer(head)
+        back.compile(dev)
+        mf = lambda z: int(back.pair_interactions[-1].conv_tp._dp_for(int(g.num_edges), z).prog.mfma_per_wave)
+        out["last_pair_mfma_ratio"] = mf(True) / mf(False)
+    # (4) training forward: complete rows
+    rep_t = back(g, save_for_backward=True)
+    out["training_rows_rel_err"] = rel(rep_t["_edge_planar_rot"], full_rows)
+    out["training_alive_declared"] = float(rep_t.get("_edge_alive") is not None)
+    if device != "cpu":
+        torch.cuda.synchronize()
+    return out
+
+
 def check_residual_block_backward(device="cuda", irr=None, rows=37, seed=0):
     """backward of ResidualBlock (x + Lin2(Gate(Lin1(x)))): data gradient (hg_linear_planar on transposed blocks,
     hg_gate_backward) and the two Linear weight gradients (one GEMM per path) vs torch.autograd through the fp64 oracle"""

@@ -115,6 +115,28 @@ def test_gpu_check_functions_on_the_cpu_stand_ins(cpu_backend, name):
         assert abs(r["sparsity_ratio"] - r["sparsity_ratio_reference"]) < 1e-6 * r["sparsity_ratio_reference"]
 
 
+def _assert_dead_outputs(r, min_dead, nonzero=True):
+    if min_dead == 0:                                          # a head that reads every irrep (SOC / su2): nothing is skipped, nothing changes
+        assert r["dead_irreps"] == 0 and r["alive_declared"] == 0.0 and r["last_pair_mfma_ratio"] == 1.0, r
+        assert r["ham_rel_err"] == 0.0 and r["edge_attr_rel_err"] == 0.0 and r["wider_head_rel_err"] < 1e-6, r
+        return
+    assert r["dead_irreps"] >= min_dead and r["alive_declared"] == 1.0, r
+    assert r["ham_rel_err"] < 1e-6 and r["ham_noise_max_abs"] == 0.0, r                     # same result; the unread blocks really are unread
+    assert r["dead_blocks_max_abs"] == 0.0 and (r["dead_blocks_full_max_abs"] > 0.0 or not nonzero), r      # written as zeros where the complete program has values
+    assert r["edge_attr_rel_err"] < 1e-6 and r["wider_head_rel_err"] < 1e-6, r              # the public tensor / a head that reads more: complete rows
+    assert r["last_pair_mfma_ratio"] < 1.0, r
+    assert r["training_rows_rel_err"] < 1e-6 and r["training_alive_declared"] == 0.0, r     # training forwards run the complete program
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(num_layers=1), dict(soc=True), dict(soc="su2", n_atoms=3), dict(nonlinearity_type="norm"),
+                                dict(irr="8x0e+4x0o+4x1o+2x1e+2x2o+3x2e+2x3o+2x3e+2x4o+2x4e", n_atoms=3)],
+                         ids=["mini", "one_layer", "soc_so3", "soc_su2", "norm_activation", "l4"])
+def test_unread_irreps_of_the_last_pair_block(cpu_backend, kw):
+    """r5: HamGNNConvE3.declare_consumer (Model does the call): the last PairInteractionBlock skips the output irreps the read-out head never reads"""
+    r = G.check_dead_outputs("cpu", **dict(dict(n_atoms=4), **kw))
+    _assert_dead_outputs(r, 0 if kw.get("soc") == "su2" else 2 if "irr" in kw else 1, nonzero=kw.get("num_layers") != 1)       # (one layer: 0o is still structurally zero after the first pair block)
+
+
 def test_reference_loss_semantics_on_cpu(cpu_backend):
     """the reference's calculate_loss (hamgnn/models/Model.py:150-166): hamiltonian-type losses are multiplied by the head's sparsity_ratio
     (calculate_sparsity=True is the head's default), SOC models train on hamiltonian_real + hamiltonian_imag with their own weights --

@@ -125,6 +125,27 @@ def test_structural_zero_inputs_of_the_first_layer(legacy):
     assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6 and r["first_layer_mfma_ratio"] < 0.6 and (legacy or r["last_layer_mfma_ratio"] == 1.0), r
 
 
+SET_A = "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e"
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(num_layers=1), dict(soc=True), dict(soc="su2", n_atoms=5), dict(nonlinearity_type="norm"),
+                                dict(irr=SET_A, n_atoms=6), dict(irr=SET_A, workload="sio2_300")],
+                         ids=["mini", "one_layer", "soc_so3", "soc_su2_reads_all", "norm_activation", "setA", "setA_single_part"])
+def test_unread_irreps_of_the_last_pair_block(kw):
+    """r5: Model(representation, output) tells the backbone that the head is its only reader (HamGNNConvE3.declare_consumer): the last PairInteractionBlock
+    leaves out the output irreps the head never reads (set-A, nao_max 19: 0o, 4o, 5o, 5e, 6e).  Same Hamiltonian rows; the head's claim holds bit for bit
+    (noise in the unread blocks changes nothing); `edge_attr`, a wider head and training forwards get the complete rows."""
+    r = G.check_dead_outputs(**kw)
+    print(r)
+    if kw.get("soc") == "su2":
+        assert r["dead_irreps"] == 0 and r["alive_declared"] == 0.0 and r["ham_rel_err"] == 0.0 and r["edge_attr_rel_err"] == 0.0 and r["wider_head_rel_err"] < 2e-6, r
+        return
+    assert r["dead_irreps"] >= (5 if "irr" in kw else 1) and r["alive_declared"] == 1.0, r
+    assert r["ham_rel_err"] < 2e-6 and r["ham_noise_max_abs"] == 0.0 and r["dead_blocks_max_abs"] == 0.0, r
+    assert r["edge_attr_rel_err"] < 2e-6 and r["wider_head_rel_err"] < 2e-6 and r["last_pair_mfma_ratio"] < (0.9 if "irr" in kw else 1.0), r
+    assert r["training_rows_rel_err"] < 2e-6 and r["training_alive_declared"] == 0.0, r
+
+
 def test_corr_product_block_golden():
     r = G.check_corr_product()
     print(r)
