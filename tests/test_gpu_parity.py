@@ -138,7 +138,7 @@ def test_unread_irreps_of_the_last_pair_block(kw):
     r = G.check_dead_outputs(**kw)
     print(r)
     if kw.get("soc") == "su2":
-        assert r["dead_irreps"] == 0 and r["alive_declared"] == 0.0 and r["ham_rel_err"] == 0.0 and r["edge_attr_rel_err"] == 0.0 and r["wider_head_rel_err"] < 2e-6, r
+        assert r["dead_irreps"] == 0 and r["alive_declared"] == 0.0 and r["ham_rel_err"] < 2e-6 and r["edge_attr_rel_err"] < 2e-6 and r["wider_head_rel_err"] < 2e-6, r
         return
     assert r["dead_irreps"] >= (5 if "irr" in kw else 1) and r["alive_declared"] == 1.0, r
     assert r["ham_rel_err"] < 2e-6 and r["ham_noise_max_abs"] == 0.0 and r["dead_blocks_max_abs"] == 0.0, r
