@@ -226,7 +226,8 @@ class _BackboneBase(nn.Module):
         pre = f"pair_interactions.{li}."
         if pair.use_skip_connections or not pair.legacy_edge_update:
             up_s, up_t = pair.linear_up_src(node_out), pair.linear_up_tar(node_out)
-            gs, gd, ge, g_tp = pair.conv_tp.backward(up_s, up_t, f_in, geo, self._rot_tab, g_f, out_is_global=False, chunk=chunk)
+            # (structural_zeros: as in the forward -- a first-layer block skips the paths that read structurally zero input irreps: zero weight gradients, unread data gradients)
+            gs, gd, ge, g_tp = pair.conv_tp.backward(up_s, up_t, f_in, geo, self._rot_tab, g_f, out_is_global=False, chunk=chunk, structural_zeros=True)
             grads.update({pre + "conv_tp." + k: v for k, v in g_tp.items()})
             g_up_s = ops.segment_sum(gs, rp_s, pm_s, N)
             g_up_t = ops.segment_sum(gd, rp_r, pm_r, N)
@@ -457,7 +458,7 @@ class HamGNNConvE3(_BackboneBase):
             put(pre + "residual.", g_res)
             grads[pre + "skip_linear.weight"] = conv.skip_linear.weight_grad(node_in, g_node)
             g_node_in = conv.skip_linear.backward_data(g_node)
-            gs, gd, ge, g_tp = conv.conv_tp.backward(node_in, node_in, f_in, geo, rot, g_agg, out_is_global=True, gather=geo.dst, chunk=chunk)
+            gs, gd, ge, g_tp = conv.conv_tp.backward(node_in, node_in, f_in, geo, rot, g_agg, out_is_global=True, gather=geo.dst, chunk=chunk, structural_zeros=True)
             put(pre + "conv_tp.", g_tp)
             part = ops.segment_sum(gs, rp_s, pm_s, N) + ops.segment_sum(gd, rp_r, pm_r, N)
             parallel.allreduce_nodes(part, data)               # edge-sharded: this rank's edges only -> all edges

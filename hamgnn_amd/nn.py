@@ -267,6 +267,11 @@ class MessagePackBlock(nn.Module):
             kw["dead_out"] = dead
         return kw
 
+    def _zero_inputs_kw(self):
+        """the structurally zero INPUT irreps alone (what the backward programs may assume: paths that read zeros have zero weight gradients, and nobody
+        reads the gradient of a structurally zero input)"""
+        return {k: v for k, v in self._zero_kw().items() if k in ("zero_node", "zero_edge")}
+
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
         zkw = self._zero_kw()
@@ -274,9 +279,9 @@ class MessagePackBlock(nn.Module):
         self._compile_args = (bool(unrotate), skip_weight is not None, None)      # (unrotate, fused skip Linear, merge groups)
         self._lite_bw = None
         self._packers = getattr(self, "_packers", None) or {}                     # structural: survive recompiles of the same block
-        self._dp_adj = None                                    # the data-gradient program is packed from the same weights
+        self._dp_adj = self._dp_adj_z = None                   # the data-gradient programs are packed from the same weights
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
-        self._wgrad_fused = None                               # (tables hold the weights: rebuilt on first use)
+        self._wgrad_fused = self._wgrad_fused_z = None         # (tables hold the weights: rebuilt on first use)
         if self.lite_mode:
             if skip_weight is not None:                        # PairInteractionBlock skip o3.Linear: must come AFTER the combine post-op
                 raise NotImplementedError
@@ -385,6 +390,9 @@ class MessagePackBlock(nn.Module):
             update(self._dp_z_plain, ("fwd", unrotate, has_skip, False, ztag), fwd(None, zkw), nskip)
         if getattr(self, "_dp_adj", None) is not None:
             update(self._dp_adj, ("adj",), lambda d, sk: P.build_message_pack_adjoint_program(d, *args).weights, 0)
+        zin = self._zero_inputs_kw()
+        if getattr(self, "_dp_adj_z", None) is not None:
+            update(self._dp_adj_z, ("adj", ztag[:2]), lambda d, sk: P.build_message_pack_adjoint_program(d, *args, **zin).weights, 0)
         if getattr(self, "_wgrad", None) is not None:
             wg, dpA, dpB = self._wgrad
             if dpA is not None:
@@ -396,38 +404,49 @@ class MessagePackBlock(nn.Module):
                 irr = (self.irreps_node, self.irreps_edge)
                 fused = lambda d, sk: P.build_tp_wgrad_fused(P.message_pack_wgrad_branches(d, *irr), self.irreps_sh, self.irreps_out, dwf.wf.hidden).weights
                 dwf.weights.copy_(packer(("wgF",), fused, 0).apply({k: v for k, v in src.items() if k != "skip"}))
+            dwz = getattr(self, "_wgrad_fused_z", None)
+            if dwz:
+                irr = (self.irreps_node, self.irreps_edge)
+                zi = {"node": zin.get("zero_node", ()), "edge": zin.get("zero_edge", ())}
+                fused_z = lambda d, sk: P.build_tp_wgrad_fused(P.message_pack_wgrad_branches(d, *irr), self.irreps_sh, self.irreps_out, dwz.wf.hidden, zero_inputs=zi).weights
+                dwz.weights.copy_(packer(("wgF", ztag[:2]), fused_z, 0).apply({k: v for k, v in src.items() if k != "skip"}))
         dev = self._dp.weights.device
         self._hn = self.node_weight_generator.hidden_layers(dev)
         self._he = self.edge_weight_generator.hidden_layers(dev)
         return True
 
     # ---- backward: data gradient as an adjoint program, weight gradients through backward_mp
-    def compile_adjoint(self, device):
-        """upload the data-gradient program of this block (plan.build_message_pack_adjoint_program): same kernels, same weights"""
+    def compile_adjoint(self, device, structural_zeros: bool = False):
+        """upload the data-gradient program of this block (plan.build_message_pack_adjoint_program): same kernels, same weights.  structural_zeros: the
+        variant that does not compute the gradient of the structurally zero input irreps (set_structural_zeros; nobody reads it)"""
         if self.lite_mode:
             raise NotImplementedError("data gradient of a lite_mode MessagePackBlock")
-        prog = P.build_message_pack_adjoint_program(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out)
+        zin = self._zero_inputs_kw() if structural_zeros else {}
+        prog = P.build_message_pack_adjoint_program(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, **zin)
         try:
-            self._dp_adj = ops.DeviceProgram(prog, device, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
+            dp = ops.DeviceProgram(prog, device, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
         except NotImplementedError:                            # tiles / staging do not fit even split over workgroups: segment-stationary kernel
-            self._dp_adj = ops.DeviceProgram(prog, device, schedule="seg")
+            dp = ops.DeviceProgram(prog, device, schedule="seg")
+        setattr(self, "_dp_adj_z" if zin else "_dp_adj", dp)
         _, maps = P.message_pack_adjoint_layout(self.irreps_node, self.irreps_edge)
         self._adj_maps = tuple(torch.from_numpy(m).to(device) for m in maps)
         return self
 
-    def backward_data(self, grad_out, geo: ops.Geometry, out_is_global: bool, gather=None):
+    def backward_data(self, grad_out, geo: ops.Geometry, out_is_global: bool, gather=None, structural_zeros: bool = False):
         """grad_out [E, planar(irreps_out)]: gradient with respect to the rows this block's forward returned (global frame if the block
         was compiled with unrotate=True, else edge frame); or, with `gather` = an [E] index tensor, NODE rows whose gather is that
         per-edge gradient (the backward of the receiver scatter of a ConvBlockE3 is the gather grad_agg[receiver]; it is fused into the
         kernel's staging like the forward's node gathers).  Returns per-edge gradients (g_src_rows, g_dst_rows, g_edge_rows), planar:
         the first two in the GLOBAL frame, to be summed over the edges of each sender / receiver (ops.segment_sum over the sender /
         receiver CSR) for the gradient of the gathered node rows; the third in the edge frame, where the forward read the edge rows."""
-        if getattr(self, "_dp_adj", None) is None:
-            self.compile_adjoint(grad_out.device)
+        z = bool(structural_zeros and self._zero_inputs_kw())   # (the caller vouches as for run_nodes: the marked input irreps are zero, their gradient unread)
+        slot = "_dp_adj_z" if z else "_dp_adj"
+        if getattr(self, slot, None) is None:
+            self.compile_adjoint(grad_out.device, structural_zeros=z)
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
         hn = ops.radial_hidden_cached(geo, self._hn, cst)
         he = ops.radial_hidden_cached(geo, self._he, cst)
-        dp = self._dp_adj
+        dp = getattr(self, slot)
         if dp.sched is not None:
             g = ops.tp_fused(dp, [grad_out], geo.E, hn, he, geo, tag="message_pack_adjoint", gather=[gather], rot_mask=1 if out_is_global else 0)
         else:
@@ -460,7 +479,8 @@ class MessagePackBlock(nn.Module):
                 setattr(self, slot, dp)
         return getattr(self, slot)
 
-    def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 65536, gather=None):
+    def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 65536, gather=None,
+                         structural_zeros: bool = False):
         """gradients of every parameter of this block for the output gradient `grad_out` (frame and `gather` as in backward_data), first
         version (hamgnn_amd/backward_mp.py): two materialisation programs on the fused kernels + library GEMMs over the edges.
         node_s / node_d: planar NODE rows gathered by sender / receiver as in run_nodes; f_rot: planar edge rows (edge frame).
@@ -481,7 +501,7 @@ class MessagePackBlock(nn.Module):
         else:
             g = grad_out if gather is None else grad_out[gather].contiguous()
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
-        dwf = self._wgrad_fused_for(wg, dev)
+        dwf = self._wgrad_fused_for(wg, dev, structural_zeros)
         if dwf is not None:                                    # fused kernel (csrc/tp_wgrad.hip): nothing per edge is materialised but gs
             hidden = {"node": ops.radial_hidden_cached(geo, self._hn, cst), "edge": ops.radial_hidden_cached(geo, self._he, cst)}
             run = lambda srcs, g_, hn, he: ops.tp_wgrad(dwf, srcs, g_, hn, he)
@@ -491,27 +511,34 @@ class MessagePackBlock(nn.Module):
             self._wgrad[1:] = [dpA, dpB]
         return BM.block_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), xs, xd, f_rot, g, geo.rbf, cst, chunk=chunk)
 
-    def _wgrad_fused_for(self, wg, dev):
+    def _wgrad_fused_for(self, wg, dev, structural_zeros: bool = False):
         """the fused weight-gradient tables of this block on the device, or None (HG_WGRAD=rows, or no kernel instantiation for these irreps:
-        the materialisation route then)"""
+        the materialisation route then).  structural_zeros: the tables without the row tiles of super-paths that read structurally zero input irreps
+        (their gradients are exactly zero: plan.build_tp_wgrad_fused)"""
         if os.environ.get("HG_WGRAD", "fused") != "fused":
             return None
-        cur = getattr(self, "_wgrad_fused", None)
+        zin = self._zero_inputs_kw() if structural_zeros else {}
+        slot = "_wgrad_fused_z" if zin else "_wgrad_fused"
+        cur = getattr(self, slot, None)
         if cur is None:
             try:
-                wf = P.build_tp_wgrad_fused(wg.branches, self.irreps_sh, self.irreps_out, wg.H)
+                zi = {"node": zin.get("zero_node", ()), "edge": zin.get("zero_edge", ())} if zin else None
+                wf = P.build_tp_wgrad_fused(wg.branches, self.irreps_sh, self.irreps_out, wg.H, zero_inputs=zi)
                 cur = ops.DeviceWgFused(wf, dev)
             except NotImplementedError:
                 cur = False
-            self._wgrad_fused = cur
+            setattr(self, slot, cur)
         return cur or None
 
-    def backward(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, gather=None, chunk: int = 65536):
+    def backward(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, gather=None, chunk: int = 65536,
+                 structural_zeros: bool = False):
         """data AND weight gradients of the block in one call: (g_src_rows, g_dst_rows, g_edge_rows, {parameter name: gradient}); arguments
-        as backward_data / backward_weights.  lite_mode blocks go through hamgnn_amd/backward_lite.py (nothing large to materialise)."""
+        as backward_data / backward_weights.  lite_mode blocks go through hamgnn_amd/backward_lite.py (nothing large to materialise).
+        structural_zeros: as run_nodes -- the caller vouches that the input irreps marked by set_structural_zeros are zero in the rows it passes AND that
+        it does not read their gradient (a backbone's first layer): weight gradients of the paths that read them are exactly zero and not computed."""
         if not self.lite_mode:
-            grads = self.backward_weights(node_s, node_d, f_rot, geo, rot_tab, grad_out, out_is_global, chunk=chunk, gather=gather)
-            return self.backward_data(grad_out, geo, out_is_global, gather=gather) + (grads,)
+            grads = self.backward_weights(node_s, node_d, f_rot, geo, rot_tab, grad_out, out_is_global, chunk=chunk, gather=gather, structural_zeros=structural_zeros)
+            return self.backward_data(grad_out, geo, out_is_global, gather=gather, structural_zeros=structural_zeros) + (grads,)
         from . import backward_lite as BL
         dev = grad_out.device
         if getattr(self, "_lite_bw", None) is None:

@@ -1451,7 +1451,7 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
 
 def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_g: int, gout_layout: PlanarLayout, irreps_sh: Irreps,
                          irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray, lin_out_w: Optional[np.ndarray],
-                         mlp: int, target_base: int):
+                         mlp: int, target_base: int, skip_inputs: Sequence[int] = ()):
     """DATA-GRADIENT items of one tensor-product branch: the adjoint of add_tp_items with respect to the branch's input rows, on the
     SAME kernels.  With out[k] = sum_rows L^T (cf s (W x_i)) the gradient is  g_x[i] = sum_rows W^T (cf' s (L g_out[k]))  -- the same
     item shape with the roles of the two weight matrices swapped: GEMM1 contracts the staged g_out block of irrep k (source slot
@@ -1459,9 +1459,14 @@ def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_
     and accumulates into the tile of the program's output irrep `target_base + i` = the (nsrc * mul_i) x l_i block of the input
     gradient (sender channels first, then receiver: the reference's doubled input).  Column bookkeeping: the forward reads input
     component l_i - mm + c (par = 0) or l_i + mm - c (par = 1) for output column l_k - mm + c; the adjoint reads g_out component
-    l_k - mm + c' resp. l_k + mm - c' for its output column l_i - mm + c', i.e. the same `neg` flag with c' = c resp. 2 mm - c."""
+    l_k - mm + c' resp. l_k + mm - c' for its output column l_i - mm + c', i.e. the same `neg` flag with c' = c resp. 2 mm - c.
+    skip_inputs: input irreps whose gradient nobody reads (structurally zero inputs of a first layer: their producers only have the other irreps) -- the
+    items that would compute it are not emitted, those blocks of the result are zeros."""
     H = prog.hidden
+    skip_inputs = set(int(i) for i in skip_inputs)
     for sp in _tp_superpaths(nsrc, in_layout, irreps_sh, irreps_out, tp_weight, w3, lin_scale_w, lin_out_w, False):
+        if sp["i"] in skip_inputs:
+            continue
         i, k, mi, li, mk, lk, mm, par = sp["i"], sp["k"], sp["mi"], sp["li"], sp["mk"], sp["lk"], sp["mm"], sp["par"]
         nc = 2 * mm + 1
         rows_W, rows_ch, rows_L = sp["W"], sp["ch"], sp["L"]
@@ -1770,13 +1775,16 @@ def message_pack_adjoint_layout(irreps_node, irreps_edge):
     return adj, (imap_s, imap_d, imap_e)
 
 
-def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out) -> Program:
+def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out,
+                                       zero_node: Sequence[int] = (), zero_edge: Sequence[int] = ()) -> Program:
     """DATA GRADIENT of a (non-lite) MessagePackBlock forward (message_passing.py:191-231) as a program for the same fused kernels:
     source slot 0 = the gradient with respect to the block's output rows [E, planar(irreps_out)] in the edge-aligned frame, output rows =
     [gradient of the doubled node-branch input | gradient of the edge-feature input] (message_pack_adjoint_layout), the node part
     un-rotated to the global frame in the epilogue (the adjoint of the rotation the forward applies while staging the gathered node
     rows), the edge part left in the edge frame (where the forward read it).  The radial hidden activations are those of the forward.
-    Weight gradients are NOT part of this program."""
+    Weight gradients are NOT part of this program.
+    zero_node / zero_edge: structurally zero input irreps of the forward (build_message_pack_program) -- what produced those rows (the 0e chemical embedding,
+    the 0e x Y^l pair embedding) has no path into them, so nobody reads their gradient: the items that compute it are dropped (zeros in those blocks)."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
     _, w3n = _last_layer(sd, "node_weight_generator")
     _, w3e = _last_layer(sd, "edge_weight_generator")
@@ -1787,10 +1795,10 @@ def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, i
     gl = PlanarLayout(irreps_out)
     add_tp_adjoint_items(prog, PlanarLayout(irreps_node), 2, 0, gl, irreps_sh, irreps_out, np.asarray(sd["node_tensor_product.weight"]),
                          w3n / math.sqrt(H), np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]),
-                         mlp=0, target_base=0)
+                         mlp=0, target_base=0, skip_inputs=zero_node)
     add_tp_adjoint_items(prog, PlanarLayout(irreps_edge), 1, 0, gl, irreps_sh, irreps_out, np.asarray(sd["edge_tensor_product.weight"]),
                          w3e / math.sqrt(H), np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]),
-                         mlp=1, target_base=nb)
+                         mlp=1, target_base=nb, skip_inputs=zero_edge)
     return prog.finalize()
 
 
@@ -1924,8 +1932,11 @@ class WgFused:
     bytes_per_edge: float = 0.0             # staged bytes per edge, all units
 
 
-def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
-    """see WgFused; branches as build_tp_wgrad_programs (weighted branches only)"""
+def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int, zero_inputs: Optional[Dict[str, Sequence[int]]] = None) -> WgFused:
+    """see WgFused; branches as build_tp_wgrad_programs (weighted branches only).  zero_inputs: {branch name: input irreps whose rows are structurally
+    zero} -- every gradient a super-path that reads one of them feeds (g_W = x^T ..., g_L = g^T (s cf W x), gs = sum cf (W x)(L g)) is exactly zero, so its
+    row tiles are not built: the parameters keep the zero slot, the radial channels stay at the zero fill (gs_complete is False then)."""
+    zero_inputs = {k: set(int(i) for i in v) for k, v in (zero_inputs or {}).items()}
     irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
     gl = PlanarLayout(irreps_out)
     if H != 64:
@@ -1948,6 +1959,8 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
         by_i: Dict[int, list] = {}
         for sp in _tp_superpaths(nsrc, lay, irreps_sh, irreps_out, np.asarray(b["tp_w"]), w3, np.asarray(b["ls_w"]),
                                  None if b["lo_w"] is None else np.asarray(b["lo_w"]), False):
+            if sp["i"] in zero_inputs.get(b["name"], ()):
+                continue
             nc = 2 * sp["mm"] + 1
             g1, g2 = ceil_div(lay.mulp[sp["i"]], 16), ceil_div(gl.mulp[sp["k"]], 16)
             if not wg_shape_ok(nc, g1, g2):
@@ -2047,9 +2060,10 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int) -> WgFused:
                 units.append(rec)
                 lds_max = max(lds_max, 2 * ET * 16 * RS * 4)
                 total_bytes += used * 4.0
-        tp_pos.append((np.concatenate(tpp_t), np.concatenate(tpp_p), tp_size))
+        cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, np.int64)      # (a branch whose every input irrep is structurally zero has no row tile)
+        tp_pos.append((cat(tpp_t), cat(tpp_p), tp_size))
         tp_scale.append(tps)
-        l_pos.append((np.concatenate(lpp_t), np.concatenate(lpp_p), ls_size))
+        l_pos.append((cat(lpp_t), cat(lpp_p), ls_size))
         seen_ch.append(set(int(c) for sp_ in by_i.values() for (sp__, t_, *_) in sp_ for c in sp__["ch"][16 * t_:16 * t_ + 16]))
     zero = accoff                                              # one spare slot that stays zero
     def table(pairs):                                          # [n parameters, 4]: the (<= 4) edge-tile copies of every parameter's slot, padded with the zero slot

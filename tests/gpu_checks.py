@@ -2309,6 +2309,45 @@ def check_new_kernels_full_size(device="cuda", rows=822350, edges=131072):
     return res
 
 
+def check_structural_zeros_backward(device="cuda", n_atoms=40, legacy=False):
+    """r5: the backward of a first-layer block skips the super-paths that read structurally zero input irreps -- their weight gradients are exactly zero
+    (fused weight-gradient tables without those row tiles: plan.build_tp_wgrad_fused zero_inputs) and nobody reads the data gradient of those inputs
+    (adjoint program without those items).  Loss and EVERY parameter gradient of a training step equal those of the same model with the shortcut off
+    (HG_STRUCT_ZEROS=0); 64-wide radial layers: the fused weight-gradient kernel is the route that runs."""
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    from hamgnn_amd.training import training_step
+    irr = MINI
+    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+               cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=irr, use_kan=False,
+               radial_MLP=[16, 64], correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
+    g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=11, density=0.004), 19, seed=11).to(device)
+    runs, sizes = [], []
+    for env in ("1", "0"):
+        os.environ["HG_STRUCT_ZEROS"] = env
+        try:
+            torch.manual_seed(3)
+            model = Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False,
+                                                               soc_switch=False, calculate_sparsity=True, zero_point_shift=False)).to(device)
+            out = training_step(model, g, metric="mae")
+            if device != "cpu":
+                torch.cuda.synchronize()
+            runs.append((out["loss"].detach().clone(), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}))
+            mp = model.representation.convolutions[0].conv_tp
+            zslot = getattr(mp, "_wgrad_fused_z", None) or getattr(mp, "_wgrad_fused", None)
+            sizes.append((float(zslot.wf.mfma_per_tile) if zslot else 0.0, int(getattr(mp, "_dp_adj_z", None).prog.mfma_per_wave if getattr(mp, "_dp_adj_z", None) is not None
+                                                                                    else mp._dp_adj.prog.mfma_per_wave)))
+        finally:
+            os.environ.pop("HG_STRUCT_ZEROS", None)
+    (l1, g1), (l0, g0) = runs
+    errs = {k: float((g1[k].double() - g0[k].double()).abs().max() / max(float(g0[k].abs().max()), 1e-6)) for k in g0}
+    worst = max(errs, key=errs.get)
+    return {"loss_rel_err": float((l1 - l0).abs() / l0.abs()), "grad_max_rel_err": errs[worst], "worst": worst, "n_params": len(g0), "fused_route": float(sizes[0][0] > 0),
+            "first_conv_wgrad_mfma_ratio": (sizes[0][0] / sizes[1][0]) if sizes[1][0] else 1.0, "first_conv_adjoint_mfma_ratio": sizes[0][1] / sizes[1][1]}
+
+
 def check_training_step_reproducible(device="cuda", transformer=False, n_atoms=260):
     """two evaluations of hamgnn_amd.training.training_step on the same model and batch give BIT-identical losses and gradients: the node
     scatter (hg_segment_sum), the fused weight-gradient kernel (split / copy blocks added in a fixed order) and the row scatters of the

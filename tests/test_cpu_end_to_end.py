@@ -137,6 +137,15 @@ def test_unread_irreps_of_the_last_pair_block(cpu_backend, kw):
     _assert_dead_outputs(r, 0 if kw.get("soc") == "su2" else 2 if "irr" in kw else 1, nonzero=kw.get("num_layers") != 1)       # (one layer: 0o is still structurally zero after the first pair block)
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_backward_skips_structural_zero_inputs(cpu_backend, legacy):
+    """r5: first-layer blocks leave out, in their backward too, the super-paths that read structurally zero input irreps (fused weight-gradient tables,
+    adjoint program): same loss, same gradient for every parameter as with the shortcut off"""
+    r = G.check_structural_zeros_backward("cpu", n_atoms=5 if not legacy else 4, legacy=legacy)
+    assert r["loss_rel_err"] < 1e-9 and r["grad_max_rel_err"] < 1e-8 and r["fused_route"] == 1.0, r
+    assert r["first_conv_wgrad_mfma_ratio"] < 0.6 and r["first_conv_adjoint_mfma_ratio"] < 0.6, r
+
+
 def test_reference_loss_semantics_on_cpu(cpu_backend):
     """the reference's calculate_loss (hamgnn/models/Model.py:150-166): hamiltonian-type losses are multiplied by the head's sparsity_ratio
     (calculate_sparsity=True is the head's default), SOC models train on hamiltonian_real + hamiltonian_imag with their own weights --

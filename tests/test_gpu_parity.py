@@ -735,6 +735,16 @@ def test_round3_kernels_full_size_properties():
     assert r["wgrad_linearity_acc"] < 2e-5 and r["wgrad_linearity_gs"] < 2e-5 and r["wgrad_splits"] < 2e-5 and r["wgrad_halves"] < 2e-5
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_backward_skips_structural_zero_inputs(legacy):
+    """r5: the backward of the first-layer blocks without the super-paths that read structurally zero input irreps (hg_tp_wgrad tables without their row
+    tiles, adjoint program without their items): loss and every parameter gradient of a training step as with the shortcut off"""
+    r = G.check_structural_zeros_backward(legacy=legacy)
+    print(r)
+    assert r["loss_rel_err"] < 1e-6 and r["grad_max_rel_err"] < 2e-5 and r["fused_route"] == 1.0, r
+    assert r["first_conv_wgrad_mfma_ratio"] < 0.6 and r["first_conv_adjoint_mfma_ratio"] < 0.6, r
+
+
 def test_training_step_is_bit_reproducible():
     """the default model's training step has a fixed summation order everywhere: loss and every gradient bit-identical between two runs"""
     r = G.check_training_step_reproducible()
