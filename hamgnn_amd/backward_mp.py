@@ -324,6 +324,20 @@ def tp_weight_grads_fused(wg: TPWeightGrad, wf, run_wgrad, srcs: Sequence[torch.
         gkeys[b["name"]] = sorted(k for k in sd if k.startswith(pre + ".layer") and k.endswith(".weight"))
         gen[b["name"]] = [wg.param(k, dev, dt).clone().requires_grad_() for k in gkeys[b["name"]]]
     names = [b["name"] for b in wg.branches]
+    plan_wf = getattr(wf, "wf", wf)
+    alive = getattr(wf, "_alive_idx", None)                     # per branch: None (all channels) or the written channels as an index tensor
+    if alive is None or alive[0] != str(dev):
+        rngs = getattr(plan_wf, "ch_ranges", None)
+        idxs = []
+        for bi in range(len(wg.branches)):
+            n_alive = sum(b_ - a_ for a_, b_ in rngs[bi]) if rngs is not None else plan_wf.nch[bi]
+            idxs.append(None if n_alive > 0.9 * plan_wf.nch[bi] else torch.tensor([c for a_, b_ in rngs[bi] for c in range(a_, b_)], dtype=torch.long, device=dev))
+        alive = (str(dev), idxs)
+        try:
+            wf._alive_idx = alive
+        except AttributeError:
+            pass
+    alive = alive[1]
     gW3 = {name: {} for name in gen}
     gh_hidden = {name: torch.zeros(E, H, device=dev, dtype=dt) for name in gen}
     gW3_last = {name: torch.zeros_like(gen[name][-1]) for name in gen}
@@ -337,8 +351,17 @@ def tp_weight_grads_fused(wg: TPWeightGrad, wf, run_wgrad, srcs: Sequence[torch.
             part = acc.sum(0)
             flat = part if flat is None else flat + part
             for bi, name in enumerate(names):
-                gW3_last[name] += h[name].t() @ gs[bi] / math.sqrt(H)
-                gh_hidden[name][sl] = gs[bi] @ (gen[name][-1].detach().t() / math.sqrt(H))
+                # the last radial layer: g_W3 = h^T gs, g_h = gs W3^T -- over the radial channels some row tile wrote (tables built without the super-paths
+                # of structurally zero inputs leave most columns of gs at zero: plan.build_tp_wgrad_fused zero_inputs; first ConvBlock of set-A: 152 of 3 589)
+                W3 = gen[name][-1].detach()
+                idx = alive[bi]
+                if idx is None:
+                    gW3_last[name] += h[name].t() @ gs[bi] / math.sqrt(H)
+                    gh_hidden[name][sl] = gs[bi] @ (W3.t() / math.sqrt(H))
+                else:
+                    gsc = gs[bi].index_select(1, idx)
+                    gW3_last[name].index_add_(1, idx, h[name].t() @ gsc / math.sqrt(H))          # (distinct columns: no two terms meet, the order is fixed)
+                    gh_hidden[name][sl] = gsc @ (W3.index_select(1, idx).t() / math.sqrt(H))
     for name in gen:                                           # hidden layers of the radial MLPs: two dense layers per edge, torch.autograd
         hid, ks = gen[name][:-1], gkeys[name]
         if hid:

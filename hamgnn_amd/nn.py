@@ -985,6 +985,40 @@ class HamLayer(nn.Module):
             prog = P.build_linear_program(W, self.irreps_in, self.ham_irreps)
         self._dp = ops.DeviceProgram(prog, device)
 
+    def _slot_gather(self, girr, slot_pos, dev):
+        """(index into [flat weight gradient of o3.Linear(irreps_in -> girr) | 0], scale) that give linear_transform.weight's gradient: the reference's
+        paths (i_in, slot) are columns of the (i_in, group) blocks, normalised by the slot's fan-in instead of the group's.  Structure only: cached."""
+        cur = getattr(self, "_slot_gather_tab", None)
+        if cur is None or cur[0] != str(dev):
+            girr = Irreps(girr)
+            paths = [(i, g) for i, (_, l1, p1) in enumerate(self.irreps_in) for g, (_, l2, p2) in enumerate(girr) if (l1, p1) == (l2, p2)]
+            off, fan_g, o = {}, {}, 0
+            for i, g in paths:
+                off[(i, g)] = o
+                o += self.irreps_in[i][0] * girr[g][0]
+                fan_g[g] = fan_g.get(g, 0) + self.irreps_in[i][0]
+            fan = {}
+            for i, (mi, l1, p1) in enumerate(self.irreps_in):
+                for s_, (_, L, p) in enumerate(self.ham_irreps):
+                    if (l1, p1) == (L, p):
+                        fan[s_] = fan.get(s_, 0) + mi
+            idx, scale = [], []
+            for i, (mi, l1, p1) in enumerate(self.irreps_in):
+                for s_, (_, L, p) in enumerate(self.ham_irreps):
+                    if (l1, p1) != (L, p):
+                        continue
+                    pos = slot_pos[s_]
+                    for u in range(mi):
+                        if pos is None:                          # an output the caller never reads (keep): zero gradient
+                            idx.append(o)
+                            scale.append(0.0)
+                        else:
+                            idx.append(off[(i, pos[0])] + u * girr[pos[0]][0] + pos[1])
+                            scale.append(math.sqrt(fan_g[pos[0]] / fan[s_]))
+            cur = (str(dev), torch.tensor(idx, dtype=torch.int64, device=dev), torch.tensor(scale, dtype=torch.float32, device=dev))
+            self._slot_gather_tab = cur
+        return cur[1], cur[2]
+
     # ---- backward (SURVEY 8f-3)
     def backward(self, x_planar, g_out_planar):
         """gradient of forward(x) = linear_transform(residual_block(x)) for the gradient of its (grouped planar) output rows: returns
@@ -1002,34 +1036,19 @@ class HamLayer(nn.Module):
             grads = {"linear_transform.weight": o3_linear_weight_grad(self.irreps_in, self.ham_irreps, y, g_out_planar)}
             grads.update({"residual_block." + k: v for k, v in g_res.items()})
             return g_x, grads
-        W = W_host()
-        mats, girr, slot_pos = P.ham_linear_mats(W, self.irreps_in, self.ham_irreps, self.keep)
+        girr, slot_pos = self.girr, self.slot_pos              # (structure: as compile() found it)
         dev = x_planar.device
         if getattr(self, "_dp_adj", None) is None:
+            mats = P.ham_linear_mats(W_host(), self.irreps_in, self.ham_irreps, self.keep)[0]
             self._dp_adj = ops.DeviceLinear(P.linear_tables({(g, i): M.T for (i, g), M in mats.items()}, P.PlanarLayout(girr),
                                                             P.PlanarLayout(self.irreps_in)), dev)
         y = self.residual_block(x_planar)
-        # weight gradient of linear_transform in e3nn's flat layout: for i_in, for i_out (matching ir): block (mul_in, 1) / sqrt(fan_in)
-        li, lg = P.PlanarLayout(self.irreps_in), P.PlanarLayout(girr)
-        rows = x_planar.shape[0]
-        fan = {}
-        for i, (mi, l1, p1) in enumerate(self.irreps_in):
-            for s_, (_, L, p) in enumerate(self.ham_irreps):
-                if (l1, p1) == (L, p):
-                    fan[s_] = fan.get(s_, 0) + mi
-        blocks = {}
-        for (i, g) in mats:
-            mi, l, _ = self.irreps_in[i]
-            n = 2 * l + 1
-            X = y[:, li.off[i]:li.off[i] + n * li.mulp[i]].reshape(rows * n, li.mulp[i])[:, :mi]
-            G = g_out_planar[:, lg.off[g]:lg.off[g] + n * lg.mulp[g]].reshape(rows * n, lg.mulp[g])[:, :girr[g][0]]
-            blocks[(i, g)] = X.t() @ G                          # [mul_in, outputs of the group]
-        gw = []
-        for i, (mi, l1, p1) in enumerate(self.irreps_in):
-            for s_, (_, L, p) in enumerate(self.ham_irreps):
-                if (l1, p1) == (L, p):
-                    pos = slot_pos[s_]
-                    gw.append(blocks[(i, pos[0])][:, pos[1]] / math.sqrt(fan[s_]) if pos is not None else y.new_zeros(mi))
+        # weight gradient of linear_transform in e3nn's flat layout: for i_in, for i_out (matching ir): block (mul_in, 1) / sqrt(fan_in).  The slots of one
+        # (L, p) are the channels of a group irrep: ONE o3.Linear(irreps_in -> girr) weight gradient (hg_linear_wgrad: all paths in one launch) and a
+        # gather with the slots' own normalisation (r5; before: one GEMM on strided copies per path and one slice per slot -- ~500 launches per network)
+        flat = o3_linear_weight_grad(self.irreps_in, girr, y, g_out_planar)
+        idx, scale = self._slot_gather(girr, slot_pos, dev)
+        gw = [torch.cat([flat, flat.new_zeros(1)])[idx] * scale]
         g_y = ops.linear_planar(self._dp_adj, g_out_planar, tag="linear_adjoint")
         g_x, g_res = self.residual_block.backward(x_planar, g_y)
         grads = {"linear_transform.weight": torch.cat(gw)}

@@ -1928,6 +1928,7 @@ class WgFused:
     l_pos: List[np.ndarray]                 # per branch: [ls_size, 4]
     lds_bytes: int
     gs_complete: bool = False               # every radial channel of every branch is written by some row tile (gs needs no zero fill)
+    ch_ranges: Optional[List[List[Tuple[int, int]]]] = None      # per branch: the contiguous ranges of radial channels some row tile writes (the others stay 0)
     mfma_per_tile: float = 0.0              # issued MFMAs per 16 edges, all units
     bytes_per_edge: float = 0.0             # staged bytes per edge, all units
 
@@ -2076,12 +2077,20 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int, zero_inputs: O
         out = np.full((n_, 4), zero, np.int64)
         out[tgt, col] = pos
         return out
+    def ranges(chs):
+        out = []
+        for c in sorted(chs):
+            if out and out[-1][1] == c:
+                out[-1][1] = c + 1
+            else:
+                out.append([c, c + 1])
+        return [tuple(r) for r in out]
     U = np.asarray(units, dtype=np.int64)
     order = np.argsort(-U[:, 13], kind="stable")               # dearest units first (the hardware hands workgroups out in order)
     return WgFused(units=U[order].astype(np.int32), weights=np.concatenate(wparts), chtab=np.concatenate(chparts).astype(np.int32), acc_floats=accoff + 1,
                    hidden=H, branch_names=[b["name"] for b in branches], nch=nchs, tp_pos=[table(t) for t in tp_pos], tp_scale=tp_scale,
                    l_pos=[table(t) for t in l_pos], lds_bytes=lds_max, gs_complete=all(s_ == set(range(n_)) for s_, n_ in zip(seen_ch, nchs)),
-                   mfma_per_tile=total_cost, bytes_per_edge=total_bytes)
+                   ch_ranges=[ranges(s_) for s_ in seen_ch], mfma_per_tile=total_cost, bytes_per_edge=total_bytes)
 
 
 def message_pack_wgrad_branches(sd: Dict[str, np.ndarray], irreps_node, irreps_edge):
