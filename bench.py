@@ -472,8 +472,9 @@ def main():
                                 "set-B: r02b_tp_is_hbm_pmc.md, segment-stationary kernel: r01c_tp_fused_hbm_pmc.md), scaled to this launch's edge count", "avg_launch_ms": avg_s * 1e3,
                 "launches_timed": len(mp), "edges_per_launch": rows_per_launch,
                 # `achieved` counts the reference formulation's flops of EVERY block (4.55 MFLOP per edge and block for set-A) -- including the ones the
-                # reference spends multiplying the structurally zero input irreps of the first layer, which this build does not issue.  The figure that excludes
-                # them, and the one of the launches that run the complete program, stand next to it:
+                # reference spends multiplying the structurally zero input irreps of the first layer and computing the output irreps of the last pair block that
+                # the read-out head never reads, which this build does not issue.  The figure that excludes them (`..._without_...`: only
+                # the share of each launch's flops that its program still holds), and the one of the launches that run the complete program, stand next to it:
                 "frac_without_structural_zero_flops": (ref_nonzero_tot / t_tot / 1e12 / PEAK_FP32_TFLOPS if not args.lite else None),
                 "frac_full_program_launches": (REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / (sum(full_t) / max(1, len(full_t))) / 1e12 / PEAK_FP32_TFLOPS
                                                if full_t and not args.lite else None),

@@ -200,8 +200,33 @@ class _BackboneBase(nn.Module):
     _edge_alive = None
 
     def declare_consumer(self, head):
-        """(backbones that can leave out unread irreps override this: HamGNNConvE3)"""
-        return []
+        """Tell the backbone that `head` is the ONLY reader of the representation it returns (what `Model(representation, output)` wires: Model.py:459-465 of
+        the reference passes the representation to the output module and nowhere else).  If the head can say which (l, p) classes of the edge rows it reads
+        (HamGNNPlusPlusOut.edge_irreps_read), the LAST PairInteractionBlock (of either backbone) stops computing the others: its reduced program drops their super-paths
+        (plan.build_message_pack_program dead_out; set-A with nao_max 19: 0o, 4o, 5o, 5e, 6e = 15 % of that launch's MFMAs).  What the reference API promises
+        stays true: `rep["edge_attr"]` (and a head that reads more than the declared one) gets the complete rows -- the block's inputs are kept on the
+        representation and the complete program runs on first access.  Training forwards (save_for_backward) always run the complete program.
+        HG_DEAD_OUT=0 disables.  Returns the list of dropped irreps (indices into irreps_node_features)."""
+        self._edge_alive = None
+        pairs = getattr(self, "pair_interactions", None)
+        if pairs is None or self.lite_mode or not hasattr(head, "edge_irreps_read") or os.environ.get("HG_DEAD_OUT", "1") == "0":
+            return []
+        last = pairs[-1]
+        if not (last.use_skip_connections or not last.legacy_edge_update):      # a legacy single-layer backbone: the block is not evaluated at all
+            return []
+        need = head.edge_irreps_read()
+        dead = [k for k, (m, l, p) in enumerate(self.irreps_node_features) if (int(l), int(p)) not in need]
+        last.conv_tp.set_dead_outputs(dead)
+        if dead:
+            self._edge_alive = frozenset((int(l), int(p)) for k, (m, l, p) in enumerate(self.irreps_node_features) if k not in dead)
+        self._compiled_for = None                                # the reduced program is built at the next compile()
+        return dead
+
+    def _dead_plan(self, tape):
+        """(the last pair block has declared dead outputs, this forward may skip them).  Not while training: a block with declared dead outputs then runs
+        its complete program."""
+        has_dead = "dead_out" in self.pair_interactions[-1].conv_tp._zero_kw()
+        return has_dead, has_dead and tape is None and self._edge_alive is not None
 
     def _run_pair(self, pair, node, f, geo, reduced=True):
         """PairInteractionBlock.forward (interaction_blocks.py:130-164).  reduced: the block may run its reduced program (structurally zero inputs of a first
@@ -307,29 +332,6 @@ class HamGNNConvE3(_BackboneBase):
                 pair.conv_tp.set_structural_zeros(node=(), edge=zero_edge)
                 zero_edge = ()
 
-    def declare_consumer(self, head):
-        """Tell the backbone that `head` is the ONLY reader of the representation it returns (what `Model(representation, output)` wires: Model.py:459-465 of
-        the reference passes the representation to the output module and nowhere else).  If the head can say which (l, p) classes of the edge rows it reads
-        (HamGNNPlusPlusOut.edge_irreps_read), the LAST PairInteractionBlock stops computing the others: its reduced program drops their super-paths
-        (plan.build_message_pack_program dead_out; set-A with nao_max 19: 0o, 4o, 5o, 5e, 6e = 15 % of that launch's MFMAs).  What the reference API promises
-        stays true: `rep["edge_attr"]` (and a head that reads more than the declared one) gets the complete rows -- the block's inputs are kept on the
-        representation and the complete program runs on first access.  Training forwards (save_for_backward) always run the complete program.
-        HG_DEAD_OUT=0 disables.  Returns the list of dropped irreps (indices into irreps_node_features)."""
-        self._edge_alive = None
-        pairs = getattr(self, "pair_interactions", None)
-        if pairs is None or self.lite_mode or not hasattr(head, "edge_irreps_read") or os.environ.get("HG_DEAD_OUT", "1") == "0":
-            return []
-        last = pairs[-1]
-        if not (last.use_skip_connections or not last.legacy_edge_update):      # a legacy single-layer backbone: the block is not evaluated at all
-            return []
-        need = head.edge_irreps_read()
-        dead = [k for k, (m, l, p) in enumerate(self.irreps_node_features) if (int(l), int(p)) not in need]
-        last.conv_tp.set_dead_outputs(dead)
-        if dead:
-            self._edge_alive = frozenset((int(l), int(p)) for k, (m, l, p) in enumerate(self.irreps_node_features) if k not in dead)
-        self._compiled_for = None                                # the reduced program is built at the next compile()
-        return dead
-
     # ------------------------------------------------------------------------------------------------------------
     def compile(self, device):
         """(Re)pack all weights into MFMA fragment order and upload.  Call again after changing parameters."""
@@ -376,11 +378,9 @@ class HamGNNConvE3(_BackboneBase):
                     assert float(rows[:, o:o + w].abs().max()) == 0.0, ("structural zero violated", i)
         rowptr, perm = topo.receiver_csr()
         tape = [] if save_for_backward else None
-        # the last PairInteractionBlock may leave out the irreps its declared consumer never reads (declare_consumer) -- not while training: a block with
-        # declared dead outputs then runs its complete program
+        # the last PairInteractionBlock may leave out the irreps its declared consumer never reads (declare_consumer)
         last = self.pair_interactions[-1]
-        has_dead = "dead_out" in last.conv_tp._zero_kw()
-        skip_dead = has_dead and tape is None and self._edge_alive is not None
+        has_dead, skip_dead = self._dead_plan(tape)
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             row_shard = tape is None and parallel.node_shard_enabled(data)      # HG_NODE_SHARD=1: the node-level chain on this rank's block of rows only

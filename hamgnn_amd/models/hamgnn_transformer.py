@@ -63,6 +63,8 @@ class HamGNNTransformer(_BackboneBase):
         from .. import parallel
         rowptr, perm = topo.receiver_csr()
         tape = [] if save_for_backward else None
+        last = self.pair_interactions[-1]
+        has_dead, skip_dead = self._dead_plan(tape)             # (unread irreps of the last pair block: _BackboneBase.declare_consumer)
         for att, corr, pair in zip(self.orb_transformers, self.corr_products, self.pair_interactions):
             if tape is not None:
                 tape.append(dict(node_in=node, f_in=f))
@@ -72,8 +74,8 @@ class HamGNNTransformer(_BackboneBase):
             node = corr(node, z, self._last_delta)                                  # CorrProductBlock.forward (interaction_blocks.py:234-260)
             if tape is not None:
                 tape[-1]["node_out"] = node
-            f = self._run_pair(pair, node, f, geo)
-        rep = self._representation(node, f, geo)
+            f_in, f = f, self._run_pair(pair, node, f, geo, reduced=(pair is not last) or skip_dead or not has_dead)
+        rep = self._representation(node, f, geo, (lambda: self._run_pair(last, node, f_in, geo, reduced=False)) if skip_dead else None)
         if tape is not None:
             rep["_tape"] = tape
             if self._last_delta is not None:

@@ -748,7 +748,7 @@ def check_structural_zeros(device="cuda", legacy=False, n_atoms=9, seed=11):
     return out
 
 
-def check_dead_outputs(device="cuda", n_atoms=9, seed=12, num_layers=2, soc=False, nao=19, irr=None, nonlinearity_type="gate", workload=None):
+def check_dead_outputs(device="cuda", n_atoms=9, seed=12, num_layers=2, soc=False, nao=19, irr=None, nonlinearity_type="gate", workload=None, transformer=False):
     """r5: a backbone that knows its only consumer (HamGNNConvE3.declare_consumer; Model does the call) leaves out, in its LAST PairInteractionBlock, the
     output irreps the head never reads.  (1) the head's rows are the same as without the shortcut; (2) the head's claim is true: its result does not move
     when the unread blocks of the edge rows are filled with noise; (3) the public `edge_attr` is still the complete tensor (lazy complete re-run), and a head
@@ -763,7 +763,13 @@ def check_dead_outputs(device="cuda", n_atoms=9, seed=12, num_layers=2, soc=Fals
                cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=num_layers, irreps_node_features=irr, use_kan=False, radial_MLP=[16, 16],
                correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=False)
     torch.manual_seed(seed)
-    back = HamGNNConvE3(cfg)
+    if transformer:
+        from hamgnn_amd.models.hamgnn_transformer import HamGNNTransformer
+        irr = "8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o"             # (channel counts divisible by the head count)
+        cfg.update(irreps_node_features=irr, num_heads=2)
+        back = HamGNNTransformer(cfg)
+    else:
+        back = HamGNNConvE3(cfg)
     hkw = dict(nao_max=nao, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, zero_point_shift=False, soc_switch=bool(soc), soc_basis="su2" if soc == "su2" else "so3",
                nonlinearity_type=nonlinearity_type)
     head = HamGNNPlusPlusOut(irr, irr, **hkw)

@@ -128,9 +128,9 @@ def _assert_dead_outputs(r, min_dead, nonzero=True):
     assert r["training_rows_rel_err"] < 1e-6 and r["training_alive_declared"] == 0.0, r     # training forwards run the complete program
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(num_layers=1), dict(soc=True), dict(soc="su2", n_atoms=3), dict(nonlinearity_type="norm"),
+@pytest.mark.parametrize("kw", [dict(), dict(num_layers=1), dict(soc=True), dict(soc="su2", n_atoms=3), dict(nonlinearity_type="norm"), dict(transformer=True),
                                 dict(irr="8x0e+4x0o+4x1o+2x1e+2x2o+3x2e+2x3o+2x3e+2x4o+2x4e", n_atoms=3)],
-                         ids=["mini", "one_layer", "soc_so3", "soc_su2", "norm_activation", "l4"])
+                         ids=["mini", "one_layer", "soc_so3", "soc_su2", "norm_activation", "transformer", "l4"])
 def test_unread_irreps_of_the_last_pair_block(cpu_backend, kw):
     """r5: HamGNNConvE3.declare_consumer (Model does the call): the last PairInteractionBlock skips the output irreps the read-out head never reads"""
     r = G.check_dead_outputs("cpu", **dict(dict(n_atoms=4), **kw))

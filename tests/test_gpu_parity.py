@@ -128,9 +128,9 @@ def test_structural_zero_inputs_of_the_first_layer(legacy):
 SET_A = "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e"
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(num_layers=1), dict(soc=True), dict(soc="su2", n_atoms=5), dict(nonlinearity_type="norm"),
+@pytest.mark.parametrize("kw", [dict(), dict(num_layers=1), dict(soc=True), dict(soc="su2", n_atoms=5), dict(nonlinearity_type="norm"), dict(transformer=True),
                                 dict(irr=SET_A, n_atoms=6), dict(irr=SET_A, workload="sio2_300")],
-                         ids=["mini", "one_layer", "soc_so3", "soc_su2_reads_all", "norm_activation", "setA", "setA_single_part"])
+                         ids=["mini", "one_layer", "soc_so3", "soc_su2_reads_all", "norm_activation", "transformer", "setA", "setA_single_part"])
 def test_unread_irreps_of_the_last_pair_block(kw):
     """r5: Model(representation, output) tells the backbone that the head is its only reader (HamGNNConvE3.declare_consumer): the last PairInteractionBlock
     leaves out the output irreps the head never reads (set-A, nao_max 19: 0o, 4o, 5o, 5e, 6e).  Same Hamiltonian rows; the head's claim holds bit for bit
