@@ -146,6 +146,39 @@ def test_backward_skips_structural_zero_inputs(cpu_backend, legacy):
     assert r["first_conv_wgrad_mfma_ratio"] < 0.6 and r["first_conv_adjoint_mfma_ratio"] < 0.6, r
 
 
+def test_representation_is_released_by_reference_counting(cpu_backend):
+    """the lazy entries of a representation must not close over the representation itself: a reference cycle keeps every row of a forward (~9 GB at
+    0.82 M edges) alive until the cycle collector runs -- on the GPU that showed as one 500 ms step in five (allocator growth + a stalled free)"""
+    import gc
+    import weakref
+    from hamgnn_amd.data import synthetic as S
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    from hamgnn_amd.models.hamgnn_output import HamGNNPlusPlusOut
+    from hamgnn_amd.models.model import Model
+    cfg = dict(num_types=96, irreps_edge_sh=G.SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False, cutoff=26.0, rbf_func="bessel",
+               num_radial=8, num_layers=2, irreps_node_features=G.MINI, use_kan=False, radial_MLP=[16, 16], correlation=2, num_hidden_features=4, use_corr_prod=False,
+               legacy_edge_update=False)
+    m = Model(HamGNNConvE3(cfg), HamGNNPlusPlusOut(G.MINI, G.MINI, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False, soc_switch=False,
+                                                    zero_point_shift=False))
+    g = S.random_cell(4, [14, 8, 6, 1], seed=1, density=0.004)
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for declared in (True, False):
+            if not declared:
+                m.representation.declare_consumer(object())     # nothing declared: the plain lazy entries
+            with torch.no_grad():
+                rep = m.representation(g)
+                assert (rep.get("_edge_alive") is not None) == declared
+                w = weakref.ref(rep["_edge_planar_rot"])
+                m.output_module(g, rep)
+                del rep
+            assert w() is None, ("rows kept alive by a reference cycle", declared)
+    finally:
+        if was:
+            gc.enable()
+
+
 def test_reference_loss_semantics_on_cpu(cpu_backend):
     """the reference's calculate_loss (hamgnn/models/Model.py:150-166): hamiltonian-type losses are multiplied by the head's sparsity_ratio
     (calculate_sparsity=True is the head's default), SOC models train on hamiltonian_real + hamiltonian_imag with their own weights --
