@@ -38,14 +38,14 @@ REF_BYTES_PER_EDGE_BLOCK = {"A": 14432.0, "B": 7888.0}
 # (separate --pmc FETCH_SIZE / WRITE_SIZE runs on tests/bench_tp.py, 131072 edges; FETCH_SIZE x 2: gfx950 correction for
 # 16-B/lane reads, MI355X_MICROARCH.md "HBM"): measured offline for this kernel build, scaled to the launch's edge count.
 # kernel "is" = input-stationary tp_is_kernel, "seg" = segment-stationary tp_fused_kernel.  r5: ("is", "A") is measured ON THE BENCHMARKED LAUNCHES (FETCH_SIZE /
-# WRITE_SIZE passes over `python bench.py`, sio2_10k: profiles/r05_tp_is_pmc.md), launch by launch of a forward: 6.5 (first ConvBlock: reduced program) / 24.0 (first
-# PairInteractionBlock) / 26.6 (ConvBlock, fused scatter) / 28.2 (PairInteractionBlock, one row per edge) / 26.6 / 28.2 KB per edge; their mean is used (the synthetic
+# WRITE_SIZE passes over `python bench.py`, sio2_10k: profiles/r05_tp_is_pmc.md), launch by launch of a forward: 6.6 (first ConvBlock: reduced program) / 24.0 (first
+# PairInteractionBlock) / 26.6 (ConvBlock, fused scatter) / 28.2 (PairInteractionBlock, one row per edge) / 26.7 / 26.4 (last pair block: unread irreps left out) KB per edge; their mean is used (the synthetic
 # bench_tp launch with random sender / receiver indices measured 34.0 KB per edge in r4: the real crystal's neighbour locality keeps more node rows in L2 / Infinity Cache)
-PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 23.4e3, ("is", "B"): 14.2e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
-# ms per million edges of ONE MessagePackBlock launch on one MI355X at full size, mean over the six launches of a forward (profiles/r05_bench_sio2_10k_setA.json: 35.59 ms
-# per 822 350 edges; r05_bench_si512_setB.json: 0.833 ms per 44 032 edges): the yardstick of the N > 1 lines (per_rank.tp_is_efficiency_vs_1gpu = edge-proportional time
+PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 23.6e3, ("is", "B"): 14.2e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
+# ms per million edges of ONE MessagePackBlock launch on one MI355X at full size, mean over the six launches of a forward (profiles/r05_bench_sio2_10k_setA.json: 34.52 ms
+# per 822 350 edges; r05_bench_si512_setB.json: 0.835 ms per 44 032 edges): the yardstick of the N > 1 lines (per_rank.tp_is_efficiency_vs_1gpu = edge-proportional time
 # at that rate / measured time)
-REF_TP_MS_PER_MEDGE_LAUNCH = {"A": 43.28, "B": 18.92}
+REF_TP_MS_PER_MEDGE_LAUNCH = {"A": 41.98, "B": 18.96}
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
 
