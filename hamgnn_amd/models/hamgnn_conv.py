@@ -237,7 +237,7 @@ class _BackboneBase(nn.Module):
     def _dead_plan(self, tape):
         """(the last pair block has declared dead outputs, this forward may skip them).  Not while training: a block with declared dead outputs then runs
         its complete program."""
-        has_dead = "dead_out" in self.pair_interactions[-1].conv_tp._zero_kw()
+        has_dead = "dead_out" in getattr(self.pair_interactions[-1].conv_tp, "_zkw_compiled", {})     # (as compiled: the reduced program that would run)
         return has_dead, has_dead and tape is None and self._edge_alive is not None
 
     def _run_pair(self, pair, node, f, geo, reduced=True):

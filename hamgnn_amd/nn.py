@@ -275,6 +275,7 @@ class MessagePackBlock(nn.Module):
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
         zkw = self._zero_kw()
+        self._zkw_compiled = dict(zkw)                         # what the reduced program of THIS compile assumes (callers plan with it, not with the environment of the moment)
         self._dp_z = self._dp_z_plain = None                    # programs for rows with structurally zero irreps (set_structural_zeros), built next to the generic ones
         self._compile_args = (bool(unrotate), skip_weight is not None, None)      # (unrotate, fused skip Linear, merge groups)
         self._lite_bw = None
