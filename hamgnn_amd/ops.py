@@ -601,7 +601,9 @@ def tp_wgrad(dwf: DeviceWgFused, srcs: Sequence[Optional[torch.Tensor]], g: torc
     alloc = torch.empty if wf.gs_complete else torch.zeros      # (every channel of every row is written by exactly one wave when the row tiles cover all channels)
     gs = [alloc(rows, n, device=g.device, dtype=torch.float32) for n in wf.nch]
     n = len(srcs)
-    keep = [t.contiguous() if t is not None else None for t in srcs]
+    keep = [(t if t.stride(1) == 1 else t.contiguous()) if t is not None else None for t in srcs]      # (column windows of wider rows pass as they are: pointer + row stride)
+    for t in keep:
+        assert t is None or (t.dtype == torch.float32 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0), "hg_tp_wgrad stages float4 pieces of fp32 rows"
     sp = (C.c_void_p * 4)(*([(t.data_ptr() if t is not None else 0) for t in keep] + [0] * (4 - n)))
     ss = (C.c_int64 * 4)(*([(t.stride(0) if t is not None else 0) for t in keep] + [0] * (4 - n)))
     g = g.contiguous()

@@ -2114,6 +2114,29 @@ def embedding_wgrad_branches(sd: Dict[str, np.ndarray], num_types: int, lite_mod
                  w3=w3, ls_w=sd[keys["ls"]], lo_w=None, uvu=lite_mode)]
 
 
+def embedding_wgrad_branches_split(sd: Dict[str, np.ndarray], num_types: int):
+    """the embedding TP's branch for the FUSED weight-gradient kernel (late r5): its num_types x 0e input is wider than the four 16-channel tiles a wave of
+    csrc/tp_wgrad.hip holds, so the row is presented as TWO sources of num_types / 2 channels -- exactly the layout of a MessagePackBlock's node branch
+    ((2 mul) x ir = sender channels, then receiver channels): same flat parameter indices, same fan-in.  num_types / 2 must be a multiple of 4."""
+    if num_types % 8:
+        raise NotImplementedError("fused weight gradients of the embedding TP: num_types must be a multiple of 8")
+    b = embedding_wgrad_branches(sd, num_types, False)[0]
+    return [dict(b, nsrc=2, srcs=[0, 1], lay=PlanarLayout([(num_types // 2, 0, 1)]))]
+
+
+def build_embedding_adjoint_program(sd: Dict[str, np.ndarray], num_types: int, irreps_sh, irreps_out) -> Program:
+    """data gradient of PairInteractionEmbeddingBlock.conv_tp with respect to its num_types x 0e input rows (what linear_up_src / linear_up_dst backpropagate),
+    as a program for the fused kernels: source slot 0 = the gradient of the block's edge rows (edge frame), output = planar [E, num_types] (0e: frame-free)"""
+    irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
+    _, w3 = _last_layer(sd, "weight_generator")
+    H = w3.shape[0]
+    adj = Irreps([(num_types, 0, 1)])
+    prog, _ = new_program(adj, H)
+    add_tp_adjoint_items(prog, PlanarLayout(adj), 1, 0, PlanarLayout(irreps_out), irreps_sh, irreps_out, np.asarray(sd["tensor_product.weight"]),
+                         w3 / math.sqrt(H), np.asarray(sd["linear_scaler.linear_out.weight"]), None, mlp=0, target_base=0)
+    return prog.finalize()
+
+
 def build_message_pack_wgrad_programs(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out):
     br = message_pack_wgrad_branches(sd, irreps_node, irreps_edge)
     return build_tp_wgrad_programs(br, irreps_sh, irreps_out, br[0]["w3"].shape[0])

@@ -291,7 +291,7 @@ def check_message_pack_weight_grads(device="cuda", seed=0, irr=None, sh=None, E=
     return {"irreps": irr, "sh": sh, "max_rel_err": max(errs.values()), "worst": max(errs, key=errs.get)}
 
 
-def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False, lite=False, zps=False, sparsity=False, split_losses=False, bands=False):
+def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_layers=2, nao=19, metric="mse", irr=None, sh=None, radial=(16, 16), num_radial=8, crystals=1, soc=None, charge=False, corr=False, transformer=False, lite=False, zps=False, sparsity=False, split_losses=False, bands=False, num_types=20):
     """the whole model (HamGNNConvE3 + non-SOC HamGNNPlusPlusOut), loss(hamiltonian, target) -> gradient of EVERY
     parameter by hamgnn_amd.training.training_step (all block-level backwards chained on the HIP kernels) vs torch.autograd through the
     fp64 oracle with the same weights"""
@@ -302,7 +302,7 @@ def check_full_backward(device="cuda", n_atoms=6, seed=4, legacy=False, num_laye
     from hamgnn_amd.models.model import Model
     from hamgnn_amd.training import training_step
     irr, sh = irr or MINI, sh or SH
-    cfg = dict(num_types=20, irreps_edge_sh=sh, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+    cfg = dict(num_types=num_types, irreps_edge_sh=sh, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
                cutoff=26.0, rbf_func="bessel", num_radial=num_radial, num_layers=num_layers, irreps_node_features=irr, use_kan=False,
                radial_MLP=list(radial), correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
     if charge:
@@ -2326,7 +2326,7 @@ def check_structural_zeros_backward(device="cuda", n_atoms=40, legacy=False):
     from hamgnn_amd.models.model import Model
     from hamgnn_amd.training import training_step
     irr = MINI
-    cfg = dict(num_types=20, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
+    cfg = dict(num_types=24, irreps_edge_sh=SH, edge_sh_normalization="component", edge_sh_normalize=True, build_internal_graph=False,
                cutoff=26.0, rbf_func="bessel", num_radial=8, num_layers=2, irreps_node_features=irr, use_kan=False,
                radial_MLP=[16, 64], correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=legacy)
     g = S.add_random_targets(S.random_cell(n_atoms, [14, 8, 6, 1], seed=11, density=0.004), 19, seed=11).to(device)
@@ -2350,7 +2350,9 @@ def check_structural_zeros_backward(device="cuda", n_atoms=40, legacy=False):
     (l1, g1), (l0, g0) = runs
     errs = {k: float((g1[k].double() - g0[k].double()).abs().max() / max(float(g0[k].abs().max()), 1e-6)) for k in g0}
     worst = max(errs, key=errs.get)
-    return {"loss_rel_err": float((l1 - l0).abs() / l0.abs()), "grad_max_rel_err": errs[worst], "worst": worst, "n_params": len(g0), "fused_route": float(sizes[0][0] > 0),
+    emb = model.representation.pair_embedding
+    fused_emb = float(getattr(emb, "_fused_bw", (None, None))[1] is not None)      # the embedding TP's gradients took the fused kernel + adjoint program (num_types 24 = 2 x 12 channels)
+    return {"embedding_fused_route": fused_emb, "loss_rel_err": float((l1 - l0).abs() / l0.abs()), "grad_max_rel_err": errs[worst], "worst": worst, "n_params": len(g0), "fused_route": float(sizes[0][0] > 0),
             "first_conv_wgrad_mfma_ratio": (sizes[0][0] / sizes[1][0]) if sizes[1][0] else 1.0, "first_conv_adjoint_mfma_ratio": sizes[0][1] / sizes[1][1]}
 
 

@@ -37,7 +37,10 @@ def test_full_backward_whole_model_vs_autograd(cpu_backend):
     dict(transformer=True, irr="8x0e+4x0o+4x1o+2x1e+2x2o+4x2e+2x3o"),  # HamGNNTransformer
     dict(lite=True), dict(lite=True, legacy=True, crystals=2, n_atoms=2),  # lite_mode: uvu products + combine post-op (CPU-validated only)
     dict(zps=True, crystals=2, n_atoms=2), dict(zps=True, soc="so3"),      # zero_point_shift (the universal non-SOC model trains with it)
-], ids=["legacy", "batch", "charge", "corr", "corr_charge", "corr_nu3_charge", "corr_nu1", "so3", "so3_nonsoc", "transformer", "lite", "lite_legacy_batch", "zero_point_shift", "zero_point_shift_soc"])
+    dict(radial=(16, 64), num_types=24, n_atoms=2),                        # 64-wide radial layers: the FUSED weight-gradient kernel's tables (message blocks with the structural-zero
+    dict(radial=(16, 64), num_types=24, n_atoms=2, charge=True, crystals=2),   # shortcut; the embedding TP as two 12-channel sources + its adjoint program), incl. doped node attributes
+], ids=["legacy", "batch", "charge", "corr", "corr_charge", "corr_nu3_charge", "corr_nu1", "so3", "so3_nonsoc", "transformer", "lite", "lite_legacy_batch", "zero_point_shift", "zero_point_shift_soc",
+        "fused_wgrad_route", "fused_wgrad_route_charge"])
 def test_full_backward_variants_vs_autograd(cpu_backend, kw):
     kw = dict(dict(n_atoms=3, seed=5), **kw)
     r = G.check_full_backward(device="cpu", **kw)

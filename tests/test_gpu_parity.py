@@ -272,6 +272,16 @@ def test_full_model_backward_materialisation_route(monkeypatch):
     assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(charge=True, crystals=2), dict(legacy=True)], ids=["plain", "charge", "legacy"])
+def test_full_model_backward_fused_routes_vs_autograd(kw):
+    """64-wide radial layers (the shipped width): every weight gradient of the message blocks through hg_tp_wgrad with the structural-zero shortcut in the
+    first layer, the embedding TP's through the same kernel (its 24-channel 0e row as two 12-channel sources) + its adjoint program (late r5) -- loss and
+    all parameter gradients vs torch.autograd through the fp64 oracle"""
+    r = G.check_full_backward(**dict(dict(radial=(16, 64), num_types=24, n_atoms=4, seed=10), **kw))
+    print(r)
+    assert r["loss_rel_err"] < G.TOL and r["max_rel_err"] < G.TOL, r
+
+
 def test_full_model_backward_batch_of_crystals():
     """three crystals of different sizes in one batch (per-crystal [on-site; off-site] row order of the result, batch-global inverse edges)"""
     r = G.check_full_backward(n_atoms=3, seed=8, crystals=3, metric="mae")

@@ -825,6 +825,56 @@ def test_embedding_tp_weight_and_input_gradients_vs_autograd(seed):
     assert float((gx[0][:, :T] - x.grad).abs().max()) < 2e-6 * max(float(x.grad.abs().max()), 1e-3)
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_embedding_tp_gradients_on_the_fused_route_vs_autograd(seed):
+    """late r5: the embedding TP's weight gradients through the FUSED kernel's tables (its num_types x 0e row presented as two sources of num_types / 2
+    channels: plan.embedding_wgrad_branches_split) and its input gradient as an adjoint program (plan.build_embedding_adjoint_program), numpy twins of
+    both kernels, every parameter and the input rows' gradient vs torch.autograd through the fp64 oracle"""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import backward_mp as BM
+    T = 8 if seed == 0 else 16
+    lsh = 2 + seed
+    sh = "+".join(f"{l}{'e' if l % 2 == 0 else 'o'}" for l in range(lsh + 1))
+    irr = "6x0e+5x1o+3x2e" + ("+2x3o" if lsh >= 3 else "") + "+3x1e"          # (1e: an output irrep the product cannot reach -- its block of the gradient is never read)
+    torch.manual_seed(seed)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.RadialTensorProduct(f"{T}x0e", sh, irr, "8x0e", [16, 64], lite_mode=False)
+        E = 21
+        g_ = torch.Generator().manual_seed(seed)
+        x = torch.randn(E, T, generator=g_).requires_grad_()
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g_), dim=-1)
+        shv = e3.spherical_harmonics(list(range(lsh + 1)), n, True, "component")
+        rbf = torch.randn(E, 8, generator=g_)
+        G = torch.randn(E, P.Irreps(irr).dim, generator=g_)
+        (ref(x, shv, rbf) * G).sum().backward()
+        want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay, lin = P.PlanarLayout(irr), P.PlanarLayout([(T, 0, 1)])
+    D = emu.edge_wigner_all(n.numpy(), lsh)
+    grot = torch.from_numpy(emu.rotate_rows(lay.to_planar(G.numpy()), lay, D, lsh))
+    wg = BM.TPWeightGrad(sd, P.embedding_wgrad_branches(sd, T, False), sh, irr)
+    wf = P.build_tp_wgrad_fused(P.embedding_wgrad_branches_split(sd, T), sh, irr, wg.H)
+    xp = torch.from_numpy(lin.to_planar(x.detach().numpy()))
+    h = torch.from_numpy(emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "weight_generator", emu.SILU_CST)))
+
+    def run(srcs, g, hn, he):
+        acc, gs = emu.run_wgrad_fused(wf, [np.ascontiguousarray(t.numpy()) for t in srcs], g.numpy(), (hn.numpy(), hn.numpy()), nsplit=1 + seed)
+        return torch.from_numpy(acc), [torch.from_numpy(a) for a in gs]
+    got = BM.tp_weight_grads_fused(wg, wf, run, [xp[:, :T // 2], xp[:, T // 2:T]], grot, rbf, emu.SILU_CST, hidden={"emb": h[:, :wg.H]})
+    assert set(got) == set(want), sorted(set(got) ^ set(want))
+    for k in want:
+        scale = max(float(want[k].abs().max()), 1e-3)
+        assert float((got[k].reshape(want[k].shape) - want[k]).abs().max()) < 2e-6 * scale, k
+    adj = P.build_embedding_adjoint_program(sd, T, sh, irr)
+    gx = emu.run_program(adj, [grot.numpy()], (h.numpy(), h.numpy()))
+    assert float(np.abs(gx[:, :T] - x.grad.numpy()).max()) < 2e-6 * max(float(x.grad.abs().max()), 1e-3)
+
+
 def _adjoint_case(irr, sh, lmax, lsh, seed, E=17, radial=(16, 16)):
     """oracle MessagePackBlock + torch.autograd: gradients of sum(out * G) with respect to the three inputs; and the emulator inputs"""
     import torch
