@@ -505,7 +505,13 @@ def main():
            "config": {"workload": f"{args.workload}: {N_atoms} atoms, {E_total} directed edges, irreps set-{args.irreps} (D={model.irreps_node_features.dim}), "
                                   f"sh lmax 5, 3 layers, nao_max {args.nao}, {'SOC (so3 head)' if args.soc else 'no SOC'}{', lite_mode' if args.lite else ''}, backbone+head forward",
                       "parallelism": "single GPU" if world == 1 else f"pair-sharded edges x{world} + RCCL all-reduce of node aggregates"},
-           "roofline": roofline, "compile_s": compile_s}
+           "roofline": roofline, "compile_s": compile_s,
+           # what this build does NOT compute that the reference's op graph does, with identical results (each has a test that compares against the
+           # complete programs); same-call A/B on sio2_10k (profiles/r05_shortcuts_ab.md): 3.098 M edges/s without them (HG_STRUCT_ZEROS=0 HG_DEAD_OUT=0: round 4's programs), 3.613 M with the first only, 3.711 M with both
+           "exact_shortcuts": {"structurally_zero_input_irreps_of_the_first_layer": os.environ.get("HG_STRUCT_ZEROS", "1") != "0" and not args.lite,
+                               "output_irreps_the_declared_head_never_reads_in_the_last_pair_block": [str(model.irreps_node_features[k][0]) + "x" + str(model.irreps_node_features[k][1]) + ("e" if model.irreps_node_features[k][2] == 1 else "o")
+                                                                                                    for k in getattr(model.pair_interactions[-1].conv_tp, "_zkw_compiled", {}).get("dead_out", ())],
+                               "disable": "HG_STRUCT_ZEROS=0 HG_DEAD_OUT=0"}}
     if per_rank is not None:
         res["per_rank"] = per_rank
         res["sharded_check"] = sharded_check
