@@ -825,7 +825,20 @@ def check_dead_outputs(device="cuda", n_atoms=9, seed=12, num_layers=2, soc=Fals
         back.compile(dev)
         mf = lambda z: int(back.pair_interactions[-1].conv_tp._dp_for(int(g.num_edges), z).prog.mfma_per_wave)
         out["last_pair_mfma_ratio"] = mf(True) / mf(False)
+        # (6) after an optimiser step the reduced program is repacked on the device like the others (refresh_weights): same rows as a fresh compile
+        for p_ in back.parameters():
+            p_.mul_(1.0 + 0.05 * torch.randn_like(p_))
+        back.refresh_weights()
+        Ha = head(g, back(g))["hamiltonian"].clone()
+        back.compile(dev)
+        out["refresh_rel_err"] = rel(Ha, head(g, back(g))["hamiltonian"])
+        full_rows = None                                        # (the weights moved: recomputed below)
     # (4) training forward: complete rows
+    if full_rows is None:
+        back.declare_consumer(object())
+        with torch.no_grad():
+            full_rows = back(g)["_edge_planar_rot"].clone()
+        back.declare_consumer(head)
     rep_t = back(g, save_for_backward=True)
     out["training_rows_rel_err"] = rel(rep_t["_edge_planar_rot"], full_rows)
     out["training_alive_declared"] = float(rep_t.get("_edge_alive") is not None)

@@ -129,6 +129,7 @@ def _assert_dead_outputs(r, min_dead, nonzero=True):
     assert r["edge_attr_rel_err"] < 1e-6 and r["wider_head_rel_err"] < 1e-6, r              # the public tensor / a head that reads more: complete rows
     assert r["last_pair_mfma_ratio"] < 1.0, r
     assert r["training_rows_rel_err"] < 1e-6 and r["training_alive_declared"] == 0.0, r     # training forwards run the complete program
+    assert r["refresh_rel_err"] < 1e-6, r                                                   # the reduced program is repacked on the device like the others
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(num_layers=1), dict(soc=True), dict(soc="su2", n_atoms=3), dict(nonlinearity_type="norm"), dict(transformer=True),

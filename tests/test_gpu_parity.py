@@ -143,7 +143,7 @@ def test_unread_irreps_of_the_last_pair_block(kw):
     assert r["dead_irreps"] >= (5 if "irr" in kw else 1) and r["alive_declared"] == 1.0, r
     assert r["ham_rel_err"] < 2e-6 and r["ham_noise_max_abs"] == 0.0 and r["dead_blocks_max_abs"] == 0.0, r
     assert r["edge_attr_rel_err"] < 2e-6 and r["wider_head_rel_err"] < 2e-6 and r["last_pair_mfma_ratio"] < (0.9 if "irr" in kw else 1.0), r
-    assert r["training_rows_rel_err"] < 2e-6 and r["training_alive_declared"] == 0.0, r
+    assert r["training_rows_rel_err"] < 2e-6 and r["training_alive_declared"] == 0.0 and r["refresh_rel_err"] < 2e-6, r
 
 
 def test_corr_product_block_golden():
