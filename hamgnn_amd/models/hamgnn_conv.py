@@ -240,12 +240,13 @@ class _BackboneBase(nn.Module):
         has_dead = "dead_out" in getattr(self.pair_interactions[-1].conv_tp, "_zkw_compiled", {})     # (as compiled: the reduced program that would run)
         return has_dead, has_dead and tape is None and self._edge_alive is not None
 
-    def _run_pair(self, pair, node, f, geo, reduced=True):
+    def _run_pair(self, pair, node, f, geo, reduced=True, merged_up=False):
         """PairInteractionBlock.forward (interaction_blocks.py:130-164).  reduced: the block may run its reduced program (structurally zero inputs of a first
         layer, unread outputs of a last layer whose consumer was declared)"""
         if pair.use_skip_connections or not pair.legacy_edge_update:               # legacy layer-0: edge features kept (:154-156)
             # (structural_zeros: inside a backbone's forward the rows are what set_structural_zeros was told about -- a first-layer block runs its reduced program)
-            mix = pair.conv_tp.run_nodes(pair.linear_up_src(node), pair.linear_up_tar(node), f, geo, self._rot_tab, structural_zeros=reduced)   # edge frame (+ fused skip linear)
+            up_s, up_t = pair.linear_up_both(node) if (merged_up and pair.conv_tp._dp.sched is not None) else (pair.linear_up_src(node), pair.linear_up_tar(node))
+            mix = pair.conv_tp.run_nodes(up_s, up_t, f, geo, self._rot_tab, structural_zeros=reduced)   # edge frame (+ fused skip linear)
             if self.lite_mode and pair.use_skip_connections:
                 mix = pair.skip_linear(f, res=[mix])
             f = mix
@@ -396,7 +397,8 @@ class HamGNNConvE3(_BackboneBase):
         for li, (conv, pair) in enumerate(zip(self.convolutions, self.pair_interactions)):
             # ---- ConvBlockE3.forward (convolution.py:116-160)
             row_shard = tape is None and parallel.node_shard_enabled(data)      # HG_NODE_SHARD=1: the node-level chain on this rank's block of rows only
-            skip = None if row_shard else conv.skip_linear(node)
+            infer = tape is None                                # (inference: ResidualBlock as one row program + the skip Linear with the add in its epilogue, the two
+            skip = None if (row_shard or infer) else conv.skip_linear(node)     #  linear_up Linears as one launch -- small crystals are launch-bound; training keeps the separate stages)
             if conv.conv_tp.can_reduce(geo.E):
                 # convolution.py:147-149 fused into the edge kernel: receiver-major tiles, the runs of equal receivers summed in the epilogue
                 # (about E / 13 rows instead of the [E, Dp] message tensor), then a segmented sum over each atom's contiguous rows
@@ -410,23 +412,23 @@ class HamGNNConvE3(_BackboneBase):
                 # reduce-scatter of the partial aggregates, skip Linear / ResidualBlock / CorrProductBlock on N / world rows, all-gather of the new rows
                 r0, r1, _ = parallel.node_rows(data, N)
                 agg_r = parallel.reduce_scatter_nodes(agg, data)
-                part = conv.residual(agg_r, extra=conv.skip_linear(node[r0:r1].contiguous()))
+                part = conv.residual(agg_r, skip=(conv.skip_linear, node[r0:r1].contiguous()))
                 if self.use_corr_prod:
                     part = self.corr_products[li](part, z[r0:r1].contiguous(), None if self._last_delta is None else self._last_delta[r0:r1].contiguous())
                 node = parallel.allgather_nodes(part, data, N)
-                f_in, f = f, self._run_pair(pair, node, f, geo, reduced=(pair is not last) or skip_dead or not has_dead)
+                f_in, f = f, self._run_pair(pair, node, f, geo, reduced=(pair is not last) or skip_dead or not has_dead, merged_up=True)
                 continue
             parallel.allreduce_nodes(agg, data)                                      # edge-sharded runs: RCCL sum over ranks
             if tape is not None:
                 tape.append(dict(node_in=node, f_in=f, agg=agg))
-            node = conv.residual(agg, extra=skip)
+            node = conv.residual(agg, skip=(conv.skip_linear, node)) if infer else conv.residual(agg, extra=skip)
             if self.use_corr_prod:                              # CorrProductBlock.forward (interaction_blocks.py:234-260; hamgnn_conv.py:274-275)
                 if tape is not None:
                     tape[-1]["node_res"] = node                 # the ResidualBlock's output = the CorrProductBlock's input
                 node = self.corr_products[li](node, z, self._last_delta)
             if tape is not None:
                 tape[-1]["node_out"] = node
-            f_in, f = f, self._run_pair(pair, node, f, geo, reduced=(pair is not last) or skip_dead or not has_dead)
+            f_in, f = f, self._run_pair(pair, node, f, geo, reduced=(pair is not last) or skip_dead or not has_dead, merged_up=infer)
         rep = self._representation(node, f, geo, (lambda: self._run_pair(last, node, f_in, geo, reduced=False)) if skip_dead else None)
         if tape is not None:
             rep["_tape"] = tape

@@ -117,6 +117,7 @@ class HamGNNPlusPlusOut(nn.Module):
         for Z, orb in self.basis_def.items():
             norb[Z], defined[Z] = len(orb), True
         self._norb, self._defined = torch.from_numpy(norb).to(dev), torch.from_numpy(defined).to(dev)
+        self._basis_sig = hash((self.nao_max, norb.tobytes(), defined.tobytes()))      # (key of per-graph memos that depend on the basis tables only)
         self._n_imap = torch.from_numpy(self.node_layout.index_map().astype(np.int32)).to(dev)
         self._e_imap = torch.from_numpy(self.edge_layout.index_map().astype(np.int32)).to(dev)
         self._rot_tab = torch.from_numpy(P.rotate_table(self.edge_layout)).to(dev)
@@ -253,6 +254,16 @@ class HamGNNPlusPlusOut(nn.Module):
         return self._cat_by_crystal(data, on.repeat(1, 2, 2).reshape(-1, n2), off.repeat(1, 2, 2).reshape(-1, n2), edge_counts)
 
     def calculate_sparsity_ratio(self, data):
+        """hamgnn_output.py:2894-2930: a function of the graph's z / edge_index and this head's basis tables only -- kept on the graph's Topology
+        (re-evaluated when z or edge_index are replaced or mutated: topo.get_topology), 19 element-wise launches per forward otherwise"""
+        topo = get_topology(data)
+        memo = topo.__dict__.setdefault("_sparsity", {})
+        key = (self._basis_sig, str(data.z.device))
+        if key not in memo:
+            memo[key] = self._sparsity_ratio(data)
+        return memo[key]
+
+    def _sparsity_ratio(self, data):
         z = data.z
         n2 = self.nao_max ** 2
         src, dst = data.edge_index

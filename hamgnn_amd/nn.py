@@ -622,7 +622,27 @@ class ResidualBlock(nn.Module):
         else:
             self._tab = tuple(torch.from_numpy(t).contiguous().to(device) for t in P.gate_tables_compact(self._tab_np))
         self._cst = torch.from_numpy(P.ACT_CONSTS).to(device)
+        self._rowprog = None                                   # the fused inference chain is built on first use, from the weights of that moment
+        self._rowprog_off = getattr(self, "_rowprog_off", False)   # set by training._invalidate: separate kernels while the weights move
         return self
+
+    def _row_program(self, device):
+        """Linear1 -> Gate -> Linear2 (+ x) as ONE row program (csrc/rowprog.hip; late r5: the node-level chain of a ConvBlock is launch-bound on small
+        crystals -- three launches become one), or False (HG_ROWPROG=0 / HG_NODE_ROWPROG=0, "norm" activation, no kernel form, weights moving)"""
+        if getattr(self, "_rowprog", None) is None:
+            self._rowprog = False
+            if (os.environ.get("HG_ROWPROG", "1") != "0" and os.environ.get("HG_NODE_ROWPROG", "1") != "0" and not getattr(self, "_rowprog_off", False)
+                    and self.nonlinearity_type == "gate" and isinstance(self.linear1._dp, ops.DeviceLinear)):
+                w = lambda m: m.weight.detach().cpu().double().numpy()
+                li, lgi, lgo = P.PlanarLayout(self.irreps_in), P.PlanarLayout(self.gate_in), P.PlanarLayout(self.gate_out)
+                try:
+                    rp = P.build_row_program([("linear", P.o3_linear_mats(w(self.linear1), self.irreps_in, self.gate_in), li, lgi, False),
+                                              ("gate", self._tab_np, lgi.dim, lgo.dim),
+                                              ("linear", P.o3_linear_mats(w(self.linear2), self.gate_out, self.irreps_in), lgo, li, bool(self.resnet))], li.dim)
+                    self._rowprog = ops.DeviceRowProgram(rp, device)
+                except NotImplementedError:
+                    pass
+        return self._rowprog
 
     def _act(self, y1):
         return ops.norm_act(y1, self._tab) if self.nonlinearity_type == "norm" else ops.gate(y1, self._tab, self._cst)
@@ -630,10 +650,15 @@ class ResidualBlock(nn.Module):
     def _act_backward(self, y1, g_y2):
         return ops.norm_act_backward(y1, g_y2, self._tab) if self.nonlinearity_type == "norm" else ops.gate_backward(y1, g_y2, self._tab, self._cst)
 
-    def forward(self, x_planar, extra=None):
-        """x + Lin2(Gate(Lin1(x))) [+ extra]  on planar rows."""
+    def forward(self, x_planar, extra=None, skip=None):
+        """x + Lin2(Gate(Lin1(x))) [+ extra]  on planar rows.  skip = (a Linear, its input rows): extra = that Linear's result."""
         if self._tab is None:
             self.compile(x_planar.device)
+        if skip is not None:                                   # (Linear, its input rows): `extra` = that Linear's result, evaluated where it is cheapest
+            rp = self._row_program(x_planar.device)
+            if rp:
+                return skip[0](skip[1], res=[ops.row_program(rp, x_planar, tag="residual_block")])     # two launches: the chain, the skip Linear with the add in its epilogue
+            extra = skip[0](skip[1])
         res = ([x_planar] if self.resnet else []) + ([extra] if extra is not None else [])
         return self.linear2(self._act(self.linear1(x_planar)), res=res)      # adds fused into linear2's epilogue
 
@@ -795,6 +820,7 @@ class PairInteractionBlock(nn.Module):
             self.skip_linear = E3Linear(irreps, irreps)
 
     def compile(self, device):
+        self._up_both = None
         self.linear_up_src.compile(device)
         self.linear_up_tar.compile(device)
         skip = self.skip_linear.weight.detach().cpu().double().numpy() if self.use_skip_connections else None
@@ -809,8 +835,30 @@ class PairInteractionBlock(nn.Module):
                 self.skip_linear._stale = True                 # its forward is fused above; only the backward uses the module's own (adjoint) tables
 
 
+    def linear_up_both(self, node):
+        """(linear_up_src(node), linear_up_tar(node)) as ONE launch: an o3.Linear into the doubled irreps, the two results are the halves of its rows
+        (views with the doubled row stride -- the edge kernel gathers node rows by pointer + stride).  Inference only: built from the weights of the moment,
+        dropped by compile() / refresh() (late r5: small crystals are launch-bound)."""
+        if getattr(self, "_up_both", None) is None:
+            self._up_both = False
+            if os.environ.get("HG_NODE_ROWPROG", "1") != "0" and isinstance(self.linear_up_src._dp, ops.DeviceLinear):
+                irr = self.linear_up_src.irreps_in
+                w = lambda m: m.weight.detach().cpu().double().numpy()
+                ms, mt = P.o3_linear_mats(w(self.linear_up_src), irr, irr), P.o3_linear_mats(w(self.linear_up_tar), irr, irr)
+                K = len(irr)
+                mats = dict(ms)
+                mats.update({(i, K + k): M for (i, k), M in mt.items()})
+                both = Irreps(list(irr) + list(irr))
+                self._up_both = ops.DeviceLinear(P.linear_tables(mats, P.PlanarLayout(irr), P.PlanarLayout(both)), node.device)
+        if not self._up_both:
+            return self.linear_up_src(node), self.linear_up_tar(node)
+        y = ops.linear_planar(self._up_both, node)
+        half = y.shape[1] // 2
+        return y[:, :half], y[:, half:]
+
     def refresh(self, device):
         """after an optimiser step: the two linear_up tables (host, < 1 ms) and the message block's programs (device repack)"""
+        self._up_both = None
         self.linear_up_src.compile(device)
         self.linear_up_tar.compile(device)
         skip = self.skip_linear.weight if (self.use_skip_connections and not self.lite_mode) else None
