@@ -877,13 +877,13 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
         const float* __restrict__ tile = lds + tile_off;
         const float* __restrict__ dst = stage + woff;
         switch (lk) {
-            case 0: epilogue_is<0, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 1: epilogue_is<1, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 2: epilogue_is<2, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 3: epilogue_is<3, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 4: epilogue_is<4, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 5: epilogue_is<5, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
-            case 6: epilogue_is<6, NW>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 0: epilogue_is<0, NW, SPLIT>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 1: epilogue_is<1, NW, SPLIT>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 2: epilogue_is<2, NW, SPLIT>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 3: epilogue_is<3, NW, SPLIT>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 4: epilogue_is<4, NW, SPLIT>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 5: epilogue_is<5, NW, SPLIT>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
+            case 6: epilogue_is<6, NW, SPLIT>(A, tile, dst, mul_k, out_off, out_mulp, flags, e, valid, wave, lane, scan); break;
             default: break;
         }
     }

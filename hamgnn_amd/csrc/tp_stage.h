@@ -79,6 +79,8 @@ __device__ __forceinline__ float is_seg_scan(float x, const IsScan& sc) {
 }
 
 #define SEG_UNROTATE 1
+#define SEG_ATOMIC 2             // (split launches only) the segment is one of TWO copies that share an output block: each adds its half of the items' sum
+                                 // (plan.split_heavy_segments: the heaviest output irreps of a small crystal's launch on two workgroups; the rows are zero-filled by the host)
 
 __device__ __forceinline__ const float* is_pick_src(const IsArgs& A, int i) {
     return i == 0 ? A.src[0] : (i == 1 ? A.src[1] : (i == 2 ? A.src[2] : A.src[3]));
@@ -100,8 +102,21 @@ __device__ __forceinline__ void is_dma4(const float* __restrict__ gsrc, float* l
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
 }
 
+// the four channels of a lane go out as one 16-byte store -- or, AT (split launches) and the segment flagged SEG_ATOMIC, as four hardware float adds
+template <bool AT>
+__device__ __forceinline__ void is_store4(float* __restrict__ p, f32x4 v, int flags) {
+    if constexpr (AT) {
+        if (flags & SEG_ATOMIC) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) unsafeAtomicAdd(p + k, v[k]);
+            return;
+        }
+    }
+    *reinterpret_cast<f32x4*>(p) = v;
+}
+
 // un-rotate (optional) + planar store of one segment, rows split over the four waves; D blocks staged in `dst` (see kernel)
-template <int LK, int NW>
+template <int LK, int NW, bool AT = false>
 __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __restrict__ tile, const float* __restrict__ dstage, int mul_k,
                                             int out_off, int out_mulp, int flags, int64_t e, bool valid_in, int wave, int lane, const IsScan& sc) {
     bool valid = valid_in;
@@ -143,7 +158,7 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[k] = is_seg_scan(acc[k], sc);
             }
-            if (valid) *reinterpret_cast<f32x4*>(ob + a * out_mulp + w) = acc;
+            if (valid) is_store4<AT>(ob + a * out_mulp + w, acc, flags);
         }
     } else {
 #pragma unroll 1
@@ -157,7 +172,7 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
 #pragma unroll
                 for (int k = 0; k < 4; ++k) acc[k] = is_seg_scan(acc[k], sc);
             }
-            if (valid) *reinterpret_cast<f32x4*>(ob + a * out_mulp + w) = acc;
+            if (valid) is_store4<AT>(ob + a * out_mulp + w, acc, flags);
         }
     }
 }

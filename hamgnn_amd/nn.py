@@ -474,6 +474,8 @@ class MessagePackBlock(nn.Module):
             if skip_weight is not None and getattr(self, "_skip_source", None) is not None:
                 skip_weight = self._skip_source[0].weight.detach().cpu().double().numpy()
             prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight, **(self._zero_kw() if z else {}))
+            if os.environ.get("HG_SPLIT_SEGMENTS", "1") != "0":
+                prog = P.split_heavy_segments(prog)            # late r5: the heaviest output irreps of a split launch on two workgroups each (same weight blob)
             try:
                 setattr(self, slot, ops.DeviceProgram(prog, device, schedule="is"))
             except NotImplementedError:

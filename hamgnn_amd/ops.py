@@ -453,7 +453,8 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     for r in res:
         assert r.shape == (rows, dp.out_dim) and r.stride(1) == 1
     assert reduce is None or (dp.sched is not None and dp.is_parts_for(rows) == 1)
-    out = torch.empty(rows if reduce is None else reduce[2], dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
+    alloc = torch.zeros if getattr(dp.prog, "atomic_out", False) else torch.empty      # (split segments add into zero-filled rows: plan.split_heavy_segments)
+    out = alloc(rows if reduce is None else reduce[2], dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
     ss = (C.c_int64 * 4)(*([int(s.stride(0)) for s in srcs] + [0] * (4 - n)))

@@ -254,6 +254,60 @@ def _item_cost(rec, segs, hp4, vsegs=()):
     return c
 
 
+SEG_ATOMIC = 2       # (split launches) one of the copies of an output segment that share its block of the rows: the epilogue ADDS (csrc/tp_stage.h)
+
+
+def split_heavy_segments(prog: "Program", ratio: float = 1.2, copies: int = 2) -> "Program":
+    """For the split launches of small crystals (one workgroup per output segment and 16-edge tile: DeviceProgram.is_parts_for): the launch takes as long as
+    its heaviest segment's items on ONE workgroup (set-A: 64x0e 2 497 slots of 15 583, mean 1 199).  Every segment whose items cost more than `ratio` x the mean
+    is given `copies` (= 2) records with the same output block; its items are dealt to the copies by cost (LPT), the copies are flagged SEG_ATOMIC: their
+    epilogues add into rows the host has zero-filled.  Two addends commute, so the result does not depend on which workgroup comes first.  Items, weights
+    and every other segment are unchanged (the weight blob is shared with the unsplit program: device refreshes stay valid)."""
+    assert copies == 2 and not prog.vsegs
+    hp4 = prog.hidden_pad // 4
+    segs, items = prog.seg_table, prog.item_table
+    nseg = segs.shape[0]
+    cost = np.zeros(nseg)
+    by_seg: List[List[int]] = [[] for _ in range(nseg)]
+    for n, rec in enumerate(items):
+        sg = int(rec[19])
+        by_seg[sg].append(n)
+        cost[sg] += _item_cost(rec, segs, hp4)
+    if nseg < 2 or not cost.any():
+        return prog
+    mean = cost.sum() / max(1, int((cost > 0).sum()))
+    new_segs, new_items = [], []
+    for sg in range(nseg):
+        idx = by_seg[sg]
+        if cost[sg] > ratio * mean and len(idx) >= 2:
+            shares: List[List[int]] = [[] for _ in range(copies)]
+            load = [0.0] * copies
+            for n in sorted(idx, key=lambda n_: -_item_cost(items[n_], segs, hp4)):
+                c = load.index(min(load))
+                shares[c].append(n)
+                load[c] += _item_cost(items[n], segs, hp4)
+            shares = [sorted(sh) for sh in shares]             # (the planner's item order inside a segment is kept)
+        else:
+            shares = [idx]
+        for sh in shares:
+            rec = [int(v) for v in segs[sg]]
+            if len(shares) > 1:
+                rec[7] |= SEG_ATOMIC
+            rec[5], rec[6] = len(new_items), len(new_items) + len(sh)
+            for n in sh:
+                it = items[n].copy()
+                it[19] = len(new_segs)
+                new_items.append(it)
+            new_segs.append(rec)
+    import copy
+    out = copy.copy(prog)
+    out.seg_table = np.asarray(new_segs, dtype=np.int32).reshape(-1, SEG_I32)
+    out.item_table = np.asarray(new_items, dtype=np.int32).reshape(-1, ITEM_I32)
+    out.seg_key = {}
+    out.atomic_out = bool((out.seg_table[:, 7] & SEG_ATOMIC).any())
+    return out
+
+
 def lds_partition(prog: "Program") -> List[int]:
     """owner part of every output segment when the tiles of ALL segments do not fit one workgroup's LDS (the data-gradient programs:
     three feature rows of output per edge): first-fit decreasing on the tile sizes, capacity = the LDS minus the trash row, the largest

@@ -158,8 +158,12 @@ def _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype):
         Dl = D[cols, woffs[lk]:woffs[lk] + nco * nco].reshape(ne, nco, nco)
         t = np.einsum("ema,wme->wae", Dl, t)                                              # out[a] = sum_m D[m][a] t[m]
     npad = (flags >> 8) & 0xff                                 # channel-padding slots the (last) chunk of a planar block zero-fills
+    atomic = bool(flags & getattr(P, "SEG_ATOMIC", 2))          # one of the copies of a split segment (plan.split_heavy_segments): ADDS into zero-filled rows
     for a in range(nco):                                       # like the kernel epilogue: out[a * mulp + w], w < mul_k of THIS chunk
         o = out_off + a * out_mulp
+        if atomic:
+            out[np.ix_(cols, np.arange(o, o + mul_k))] += t[:, a, :].T
+            continue
         out[np.ix_(cols, np.arange(o, o + mul_k))] = t[:, a, :].T
         out[np.ix_(cols, np.arange(o + mul_k, o + mul_k + npad))] = 0
 

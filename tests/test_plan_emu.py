@@ -251,6 +251,16 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     s2 = P.is_schedule(prog2)
     a = emu.run_program_is(prog2, s2, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(a, emu.run_program(prog2, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
+    # late r5: the heaviest output segments of a split launch as TWO copies each that add into zero-filled rows (plan.split_heavy_segments)
+    for pr, want in ((prog, outp), (prog2, a)):
+        sp2 = P.split_heavy_segments(pr, ratio=0.8)
+        nsplit = int(((sp2.seg_table[:, 7] & P.SEG_ATOMIC) != 0).sum())
+        assert sp2.atomic_out and nsplit >= 2 and nsplit % 2 == 0 and sp2.seg_table.shape[0] == pr.seg_table.shape[0] + nsplit // 2
+        assert sp2.item_table.shape == pr.item_table.shape and sp2.weights is pr.weights
+        assert sorted(map(tuple, np.delete(sp2.item_table, 19, 1))) == sorted(map(tuple, np.delete(pr.item_table, 19, 1)))      # every item once, only its segment id moved
+        for parts in (sp2.seg_table.shape[0], 3):
+            assert rel(emu.run_program_is(sp2, P.is_schedule(sp2, parts), [xs, xd, fe], (hn, he), D, lmax), want) < 1e-12
+    assert P.split_heavy_segments(prog, ratio=100.0) is prog or not getattr(P.split_heavy_segments(prog, ratio=100.0), "atomic_out", False)
 
 
 @pytest.mark.parametrize("which", ["A", "B"])
