@@ -701,7 +701,7 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
 // part record, int32[8]: {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off (float offsets in the LDS),
 // copy_stride}.  copy_stride > 0: each of the four waves accumulates into its own copy of the part's tiles (copy w at + w * copy_stride),
 // so all waves can work on one output segment at once; the copies are summed before the epilogue.
-#define IS_PART_I32 12
+#define IS_PART_I32 16
 
 template <bool SPLIT, bool LITE>
 __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE : IS_NW) / 2) void tp_is_kernel(const IsArgs A0, const int* __restrict__ g_segs, const int* __restrict__ g_blocks,
@@ -873,6 +873,10 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
             }
+        }
+        if constexpr (SPLIT) {                                 // phase parts (plan.is_schedule "phases"): a workgroup adds only the segments its phases fed
+            const int b_ = sg - seg0;
+            if (b_ < 64 && !(((b_ < 32 ? PT[12] : PT[13]) >> (b_ & 31)) & 1)) continue;
         }
         const float* __restrict__ tile = lds + tile_off;
         const float* __restrict__ dst = stage + woff;

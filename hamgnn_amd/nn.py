@@ -465,7 +465,7 @@ class MessagePackBlock(nn.Module):
         irreps marked by set_dead_outputs (they come back as zeros): the reduced program"""
         z = structural_zeros and getattr(self, "_dp_z", None) is not None
         dp = self._dp_z if z else self._dp
-        if getattr(self, "_plain_args", None) is None or dp.is_parts_for(rows) == 1:
+        if getattr(self, "_plain_args", None) is None or dp.is_parts_for(rows) in (1, "phases"):     # (phase parts hold all tiles per workgroup: the merged program)
             return dp
         slot = "_dp_z_plain" if z else "_dp_plain"
         if getattr(self, slot, None) is None:
@@ -474,8 +474,6 @@ class MessagePackBlock(nn.Module):
             if skip_weight is not None and getattr(self, "_skip_source", None) is not None:
                 skip_weight = self._skip_source[0].weight.detach().cpu().double().numpy()
             prog = P.build_message_pack_program(sd, self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, unrotate, skip_weight, **(self._zero_kw() if z else {}))
-            if os.environ.get("HG_SPLIT_SEGMENTS", "1") != "0":
-                prog = P.split_heavy_segments(prog)            # late r5: the heaviest output irreps of a split launch on two workgroups each (same weight blob)
             try:
                 setattr(self, slot, ops.DeviceProgram(prog, device, schedule="is"))
             except NotImplementedError:

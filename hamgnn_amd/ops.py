@@ -68,6 +68,7 @@ def _require_gpu(t: torch.Tensor):
 # the wide schedule (csrc/tp_wide.hip, r5) is an opt-in experiment: measured 8.5 ms against hg_tp_is's 6.8 ms per 131 072-edge set-A launch (profiles/r05_tp_wide.md)
 WIDE_MODE = os.environ.get("HG_MP_WIDE", "0")             # "0": never (default), "1": launches with >= WIDE_MIN_TILES 16-edge tiles, "force": whenever the program has a wide form
 WIDE_MIN_TILES = int(os.environ.get("HG_WIDE_MIN_TILES", "512"))
+PHASE_PARTS_TILES = int(os.environ.get("HG_PHASE_PARTS_TILES", "1024"))      # phase parts while tiles x 16 workgroups stay below this (two rounds of the chip's 512 slots)
 
 
 _BUILD_CONFIG_OK = False
@@ -172,6 +173,16 @@ class DeviceProgram:
         """the weight blob a launch with `parts` sub-schedules reads"""
         return self._is_weights.get(parts, self.weights)
 
+    def phase_parts_ok(self) -> bool:
+        """the program has a phase-parts schedule (plan.is_schedule "phases": not lite_mode, <= 64 segments, everything fits one workgroup's LDS)"""
+        if getattr(self, "_phase_ok", None) is None:
+            try:
+                self.is_tables("phases")
+                self._phase_ok = True
+            except NotImplementedError:
+                self._phase_ok = False
+        return self._phase_ok
+
     def is_parts_for(self, rows: int) -> int:
         """How many workgroups share one 16-edge tile.  The chip holds 512 workgroups of this kernel (2 per CU); a launch with fewer
         tiles than that is a latency problem -- every workgroup walks the whole program serially -- so the output segments are spread
@@ -183,6 +194,8 @@ class DeviceProgram:
             return max(1, int(forced))
         tiles = (rows + 15) // 16
         nseg = int(self.prog.seg_table.shape[0])
+        if tiles * P.PHASE_PARTS_MAX <= PHASE_PARTS_TILES and os.environ.get("HG_PHASE_PARTS", "1") != "0" and self.phase_parts_ok():
+            return "phases"                                    # the smallest crystals: the PHASES of a tile on separate workgroups (late r5)
         if tiles * nseg <= 512:
             return nseg
         if tiles <= 300 and nseg >= 8:
@@ -453,7 +466,8 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
     for r in res:
         assert r.shape == (rows, dp.out_dim) and r.stride(1) == 1
     assert reduce is None or (dp.sched is not None and dp.is_parts_for(rows) == 1)
-    alloc = torch.zeros if getattr(dp.prog, "atomic_out", False) else torch.empty      # (split segments add into zero-filled rows: plan.split_heavy_segments)
+    parts_ = dp.is_parts_for(rows) if (dp.sched is not None and reduce is None) else 1
+    alloc = torch.zeros if parts_ == "phases" else torch.empty  # (phase parts ADD their tiles into zero-filled rows: plan.is_schedule "phases")
     out = alloc(rows if reduce is None else reduce[2], dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))

@@ -200,8 +200,8 @@ class IsSchedule:
     #                                dynamically by the waves (largest first), so no two waves update one tile between barriers
     item_table: np.ndarray         # int32[nitems][24]: Program.item_table records with [1], [2] = stage offsets of source 0 / 1 (-1),
     #                                [20..23] = {lk, mul_k, rto, tile_off} of the item's segment
-    part_table: np.ndarray         # int32[nparts][12] = {seg_begin, nseg, phase_begin, nphase, trash_off, stage_off, ctr_off, copy_stride,
-    #                                rowtab_off (LDS float offset of the part's row table), rowtab_begin, rowtab_len, 0}
+    part_table: np.ndarray         # int32[nparts][16] = {seg_begin, nseg, phase_begin, nphase, trash_off, stage_off, ctr_off, copy_stride,
+    #                                rowtab_off (LDS float offset of the part's row table), rowtab_begin, rowtab_len, lite flag, segment mask lo, hi, 0, 0}
     #                                copy_stride > 0: every wave owns a private copy of the part's tiles (floats between copies)
     rowtab: np.ndarray             # int32: per part, for every (segment, row tile, row) of GEMM2's output the LDS float offset of that
     #                                row's CENTRE column (m = 0) inside its segment tile; rows beyond mul_k -> the shared trash row.
@@ -211,6 +211,7 @@ class IsSchedule:
     part_cost: List[int]           # estimated MFMA-slot cost of every part (critical path over its phases)
     phase_cls: List[int] = field(default_factory=list)   # per phase: the radial weight generator of its tensor-product items
     extra_weights: Optional[np.ndarray] = None          # lite_mode streams (IT_STREAM): their weight / descriptor streams, appended to Program.weights on the device
+    atomic_out: bool = False                            # phase parts: the workgroups of a tile ADD their tiles into rows the host has zero-filled
 
     # single-part views (the common large-graph case; tests)
     @property
@@ -231,7 +232,7 @@ class IsSchedule:
 
 
 SEG_NEWBATCH = 1 << 16             # IS epilogue: this segment starts a new Wigner staging batch
-IS_PART_I32 = 12
+IS_PART_I32 = 16                   # [12], [13]: bit s = the part's phases feed its s-th segment (SEG_ATOMIC parts skip the epilogue of the others)
 
 
 def _item_rto(rec, segs, vsegs=()):
@@ -255,57 +256,6 @@ def _item_cost(rec, segs, hp4, vsegs=()):
 
 
 SEG_ATOMIC = 2       # (split launches) one of the copies of an output segment that share its block of the rows: the epilogue ADDS (csrc/tp_stage.h)
-
-
-def split_heavy_segments(prog: "Program", ratio: float = 1.2, copies: int = 2) -> "Program":
-    """For the split launches of small crystals (one workgroup per output segment and 16-edge tile: DeviceProgram.is_parts_for): the launch takes as long as
-    its heaviest segment's items on ONE workgroup (set-A: 64x0e 2 497 slots of 15 583, mean 1 199).  Every segment whose items cost more than `ratio` x the mean
-    is given `copies` (= 2) records with the same output block; its items are dealt to the copies by cost (LPT), the copies are flagged SEG_ATOMIC: their
-    epilogues add into rows the host has zero-filled.  Two addends commute, so the result does not depend on which workgroup comes first.  Items, weights
-    and every other segment are unchanged (the weight blob is shared with the unsplit program: device refreshes stay valid)."""
-    assert copies == 2 and not prog.vsegs
-    hp4 = prog.hidden_pad // 4
-    segs, items = prog.seg_table, prog.item_table
-    nseg = segs.shape[0]
-    cost = np.zeros(nseg)
-    by_seg: List[List[int]] = [[] for _ in range(nseg)]
-    for n, rec in enumerate(items):
-        sg = int(rec[19])
-        by_seg[sg].append(n)
-        cost[sg] += _item_cost(rec, segs, hp4)
-    if nseg < 2 or not cost.any():
-        return prog
-    mean = cost.sum() / max(1, int((cost > 0).sum()))
-    new_segs, new_items = [], []
-    for sg in range(nseg):
-        idx = by_seg[sg]
-        if cost[sg] > ratio * mean and len(idx) >= 2:
-            shares: List[List[int]] = [[] for _ in range(copies)]
-            load = [0.0] * copies
-            for n in sorted(idx, key=lambda n_: -_item_cost(items[n_], segs, hp4)):
-                c = load.index(min(load))
-                shares[c].append(n)
-                load[c] += _item_cost(items[n], segs, hp4)
-            shares = [sorted(sh) for sh in shares]             # (the planner's item order inside a segment is kept)
-        else:
-            shares = [idx]
-        for sh in shares:
-            rec = [int(v) for v in segs[sg]]
-            if len(shares) > 1:
-                rec[7] |= SEG_ATOMIC
-            rec[5], rec[6] = len(new_items), len(new_items) + len(sh)
-            for n in sh:
-                it = items[n].copy()
-                it[19] = len(new_segs)
-                new_items.append(it)
-            new_segs.append(rec)
-    import copy
-    out = copy.copy(prog)
-    out.seg_table = np.asarray(new_segs, dtype=np.int32).reshape(-1, SEG_I32)
-    out.item_table = np.asarray(new_items, dtype=np.int32).reshape(-1, ITEM_I32)
-    out.seg_key = {}
-    out.atomic_out = bool((out.seg_table[:, 7] & SEG_ATOMIC).any())
-    return out
 
 
 def lds_partition(prog: "Program") -> List[int]:
@@ -346,7 +296,14 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
     parts > 1: the output segments are split into `parts` sets of equal estimated cost (LPT); each set gets its own sub-schedule
     (tiles, phases, groups) and runs in its own workgroup (grid.y) -- the per-tile latency drops at the price of staging the input
     blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots.
+    parts = "phases" (late r5, the smallest crystals): ONE sub-schedule of all segments whose PHASES are dealt to the workgroups of a tile -- every
+    workgroup holds all tiles, stages the input blocks of its one or two phases, runs their items and ADDS its tiles to zero-filled rows (all segments
+    SEG_ATOMIC; the part record's mask names the segments its phases feed).  The launch then takes one phase + one epilogue instead of all phases in a row
+    (set-A, Si 2-atom cell: 12 phases at ~5 us each).  The order of the adds is not fixed: sums differ between runs at fp32 rounding level (as the split
+    launches' private tile copies already do).
     separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (IsSchedule.phase_cls)."""
+    if parts == "phases":
+        return _is_schedule_phases(prog)
     if separate_mlp is None:
         # default: per-generator phases (the kernel re-reads its resident hidden rows once per phase and wave instead of once per generator change
         # inside a work group) when that costs less than 1 % of the estimated critical path -- programs with few phases (narrow irreps) lose
@@ -398,7 +355,7 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
         sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
                                 split=parts > 1, separate_mlp=separate_mlp, runs=runs, waves=IS_WAVES_LITE if lite_flag else IS_WAVES)
         parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
-                        sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag])
+                        sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, -1, -1, 0, 0])
         rowtab_all += sub["rowtab"]
         phase_cls_all += sub["phase_cls"]
         segs_all += list(sub["segs"])
@@ -415,6 +372,49 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
                       np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), np.asarray(rowtab_all, np.int32),
                       lds_floats, worst_balance, part_cost, phase_cls_all,
                       extra_weights=(np.concatenate(runs["w"]) if runs is not None and runs["w"] else None))
+
+
+PHASE_PARTS_MAX = 16
+
+
+def _is_schedule_phases(prog: "Program") -> IsSchedule:
+    """is_schedule(prog, "phases"): see there"""
+    if np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any():
+        raise NotImplementedError("phase parts: lite_mode programs end with a post-op on the complete tiles")
+    hp4 = prog.hidden_pad // 4
+    nseg = prog.seg_table.shape[0]
+    if nseg > 64:
+        raise NotImplementedError("phase parts: more than 64 output segments")
+    sub = _is_schedule_part(prog, list(range(nseg)), hp4, 0, 0, 0, 0, split=False, separate_mlp=False, waves=IS_WAVES)
+    nph = len(sub["ptab"])
+    K = max(1, min(nph, PHASE_PARTS_MAX))
+    bins: List[List[int]] = [[] for _ in range(K)]
+    load = [0] * K
+    for ph in sorted(range(nph), key=lambda p_: -sub["phase_crit"][p_]):       # LPT on the phases' critical paths (+ a constant per phase: staging, barriers)
+        b = min(range(K), key=lambda q: (load[q], q))
+        bins[b].append(ph)
+        load[b] += sub["phase_crit"][ph] + 150
+    bins = [b for b in bins if b]
+    segs = sub["segs"].copy()
+    segs[:, 7] |= SEG_ATOMIC
+    local_of = {int(old): int(new) for old, new in sub["remap"].items()}        # program segment -> position in the schedule's segment table
+    ptab, parttab, cls = [], [], []
+    for b in bins:
+        mask = 0
+        for ph in b:
+            for sg in sub["phase_touch"][ph]:
+                mask |= 1 << local_of[sg]
+        parttab.append([0, nseg, len(ptab), len(b), sub["trash_off"], sub["stage_off"], sub["ctr_off"], 0, sub["rowtab_off"], 0, len(sub["rowtab"]), 0,
+                        int(np.int32(np.uint32(mask & 0xffffffff))), int(np.int32(np.uint32((mask >> 32) & 0xffffffff))), 0, 0])
+        for ph in b:
+            ptab.append(sub["ptab"][ph])
+            cls.append(sub["phase_cls"][ph])
+    sc = IsSchedule(segs.astype(np.int32).reshape(-1, SEG_I32), np.asarray(sub["btab"], np.int32).reshape(-1, IS_BLOCK_I32),
+                    np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(sub["gtab"], np.int32).reshape(-1, 2),
+                    np.asarray(sub["items"], np.int32).reshape(-1, IS_ITEM_I32), np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)),
+                    np.asarray(sub["rowtab"], np.int32), sub["ctr_off"] + 4, sub["balance"], [int(x) for x in load[:len(bins)]], cls)
+    sc.atomic_out = True
+    return sc
 
 
 # ---- wide schedule (csrc/tp_wide.hip, r5): ONE workgroup of WIDE_WAVES waves per CU on one 16-edge tile -----------------------------------------
@@ -1110,6 +1110,8 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             phases.append([b])
     btab, ptab, gtab, items, tot, crit = [], [], [], [], 0, 0
     phase_cls: List[int] = []
+    phase_crit: List[int] = []                                 # per phase: the dearest wave's load (phase parts, see is_schedule)
+    phase_touch: List[set] = []                                # per phase: the output segments (program indices) its items write
     for ph in phases:
         ph.sort(key=lambda b: -b["key"][0])                    # edge-row blocks (plain LDS-DMA) first: their latency runs under the
         b0, g0, o = len(btab), len(gtab), 0                    # rotation work of the node-row blocks
@@ -1138,6 +1140,8 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             items += units[n]
         tot += sum(loads)
         crit += max(loads)
+        phase_crit.append(max(loads))
+        phase_touch.append({int(m_) for recs in units for r in recs for m_ in ([int(r[19])] if not (int(r[0]) == IT_TP and int(r[16]) > 0) else prog.vsegs[int(r[16]) - 1])})
         # the generator whose hidden rows stay in registers during the phase: the one that carries most of its tensor-product work
         w = [sum(_item_cost(r, prog.seg_table, hp4, prog.vsegs) for recs in units for r in recs if int(r[0]) == IT_TP and int(r[10]) == c) for c in (0, 1)]
         res_cls = -1 if not any(w) else int(w[1] > w[0])
@@ -1203,7 +1207,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
             wide[n, 22], wide[n, 23] = _item_rto(items[n], prog.seg_table, prog.vsegs), vt_base[v]
     ctr_off = stage_off + stage_floats
     return dict(segs=segs2.astype(np.int32), btab=btab, ptab=ptab, gtab=gtab, items=wide, trash_off=trash_off, stage_off=stage_off, remap=remap,
-                phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (waves * crit) if crit else 1.0, crit=crit)
+                phase_crit=phase_crit, phase_touch=phase_touch, phase_cls=phase_cls, rowtab=rowtab, rowtab_off=rowtab_off, ctr_off=ctr_off, copy_stride=copy_stride, balance=tot / (waves * crit) if crit else 1.0, crit=crit)
 
 
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:

@@ -203,11 +203,17 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
         ne = min(16, E - e0)
         cols = np.arange(e0, e0 + ne)
         seen, seg_seen = set(), set()
-        for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _ in (tuple(int(v) for v in p) for p in sched.part_table):
+        atomic_parts = bool(getattr(sched, "atomic_out", False))       # phase parts (plan.is_schedule "phases"): every part holds ALL segments and adds its tiles
+        for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _, mask_lo, mask_hi in (tuple(int(v) for v in p[:14]) for p in sched.part_table):
             stage_floats = ctr_off - stage_off
             part_segs = set(range(sg0, sg0 + nsg))
-            assert not (part_segs & seg_seen)
+            if atomic_parts:
+                assert all(int(sched.seg_table[g][7]) & P.SEG_ATOMIC for g in part_segs) and copy_stride == 0
+            else:
+                assert not (part_segs & seg_seen)
             seg_seen |= part_segs
+            part_mask = (mask_lo & 0xffffffff) | ((mask_hi & 0xffffffff) << 32)
+            fed = set()
             tile_floats = sum(int(sched.seg_table[g][1]) * ((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4) for g in part_segs)
             maxstride = max((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4 for g in part_segs)
             # LDS layout of a part: [tile copies (each: tiles, trash row)] [row table] [staging area] [claim counter]
@@ -343,6 +349,7 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                             for c in range(2 * mm + 1):
                                 lds[base + (c - mm) * 16:base + (c - mm) * 16 + 16] += tmp[r, c]
                     touched.discard(-1)
+                    fed |= touched
                     if not copy_stride:
                         assert not (touched & owner), "a shared tile must belong to exactly one work group per phase"
                     owner |= touched
@@ -350,6 +357,12 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                 seg = sched.seg_table[sg]
                 lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
                 strd = (2 * lk_ + 1) * 16 + 4
+                if atomic_parts:                               # the kernel skips the epilogue of the segments the part's mask does not name: they must be untouched
+                    named = bool((part_mask >> (sg - sg0)) & 1)
+                    assert named == (sg in fed), ("segment mask of a phase part", sg, named)
+                    if not named:
+                        assert not lds[toff_:toff_ + mul_ * strd].any()
+                        continue
                 tile = np.zeros((rto_ * 16, 2 * lk_ + 1, 16), dtype=dtype)
                 tile[:mul_] = lds[toff_:toff_ + mul_ * strd].reshape(mul_, strd)[:, :(2 * lk_ + 1) * 16].reshape(mul_, 2 * lk_ + 1, 16)
                 _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)

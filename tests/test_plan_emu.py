@@ -251,16 +251,12 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     s2 = P.is_schedule(prog2)
     a = emu.run_program_is(prog2, s2, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(a, emu.run_program(prog2, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
-    # late r5: the heaviest output segments of a split launch as TWO copies each that add into zero-filled rows (plan.split_heavy_segments)
+    # late r5: phase parts (the smallest crystals) -- all segments in every workgroup, the PHASES dealt to the workgroups of a tile, tiles added into zero-filled rows
     for pr, want in ((prog, outp), (prog2, a)):
-        sp2 = P.split_heavy_segments(pr, ratio=0.8)
-        nsplit = int(((sp2.seg_table[:, 7] & P.SEG_ATOMIC) != 0).sum())
-        assert sp2.atomic_out and nsplit >= 2 and nsplit % 2 == 0 and sp2.seg_table.shape[0] == pr.seg_table.shape[0] + nsplit // 2
-        assert sp2.item_table.shape == pr.item_table.shape and sp2.weights is pr.weights
-        assert sorted(map(tuple, np.delete(sp2.item_table, 19, 1))) == sorted(map(tuple, np.delete(pr.item_table, 19, 1)))      # every item once, only its segment id moved
-        for parts in (sp2.seg_table.shape[0], 3):
-            assert rel(emu.run_program_is(sp2, P.is_schedule(sp2, parts), [xs, xd, fe], (hn, he), D, lmax), want) < 1e-12
-    assert P.split_heavy_segments(prog, ratio=100.0) is prog or not getattr(P.split_heavy_segments(prog, ratio=100.0), "atomic_out", False)
+        sp2 = P.is_schedule(pr, "phases")
+        assert sp2.atomic_out and 1 <= sp2.part_table.shape[0] <= P.PHASE_PARTS_MAX and sp2.part_table.shape[1] == P.IS_PART_I32
+        assert sorted(int(x) for p_ in sp2.part_table for x in range(p_[2], p_[2] + p_[3])) == list(range(sp2.phase_table.shape[0]))      # every phase in exactly one part
+        assert rel(emu.run_program_is(pr, sp2, [xs, xd, fe], (hn, he), D, lmax), want) < 1e-12
 
 
 @pytest.mark.parametrize("which", ["A", "B"])
@@ -351,6 +347,10 @@ def test_merged_items_shipped_irreps(which):
     for parts in (3, 8):                                      # the members of a merged item stay in one part
         sp = P.is_schedule(merged, parts)
         assert rel(lay.from_planar(emu.run_program_is(merged, sp, [xs, xd, fe], (hn, he), D, 6)), want) < 1e-6
+    # late r5: phase parts of the merged program (the smallest crystals): several phases per set, each workgroup adds the segments its phases feed
+    spp = P.is_schedule(merged, "phases")
+    assert spp.atomic_out and spp.part_table.shape[0] >= (8 if which == "A" else 2) and (which == "B" or max(spp.part_cost) < 0.3 * sum(sc.part_cost))
+    assert rel(lay.from_planar(emu.run_program_is(merged, spp, [xs, xd, fe], (hn, he), D, 6)), want) < 1e-6
     # with the PairInteractionBlock skip Linear (plain IT_LIN items into tiles that merged items write as well)
     m2 = P.build_message_pack_program(sd, irr, irr, sh, irr, False, skip, merge_groups=groups)
     p2 = P.build_message_pack_program(sd, irr, irr, sh, irr, False, skip)
