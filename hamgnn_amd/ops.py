@@ -194,8 +194,11 @@ class DeviceProgram:
             return max(1, int(forced))
         tiles = (rows + 15) // 16
         nseg = int(self.prog.seg_table.shape[0])
-        if tiles * P.PHASE_PARTS_MAX <= PHASE_PARTS_TILES and os.environ.get("HG_PHASE_PARTS", "1") != "0" and self.phase_parts_ok():
-            return "phases"                                    # the smallest crystals: the PHASES of a tile on separate workgroups (late r5)
+        mode = os.environ.get("HG_PHASE_PARTS", "0")           # late r5 experiments, off by default (measured: no gain, profiles/r05_small_graphs.md)
+        if mode == "1" and tiles * P.PHASE_PARTS_MAX <= PHASE_PARTS_TILES and self.phase_parts_ok():
+            return "phases"                                    # the PHASES of a tile on separate workgroups, every workgroup holds all tiles
+        if mode.startswith("2d") and tiles * nseg * int(mode[2:] or 3) <= PHASE_PARTS_TILES and not int(self.sched.part_table[0][11]):
+            return ("2d", nseg, int(mode[2:] or 3))            # one workgroup per (output segment, third of its phases)
         if tiles * nseg <= 512:
             return nseg
         if tiles <= 300 and nseg >= 8:
@@ -467,7 +470,7 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         assert r.shape == (rows, dp.out_dim) and r.stride(1) == 1
     assert reduce is None or (dp.sched is not None and dp.is_parts_for(rows) == 1)
     parts_ = dp.is_parts_for(rows) if (dp.sched is not None and reduce is None) else 1
-    alloc = torch.zeros if parts_ == "phases" else torch.empty  # (phase parts ADD their tiles into zero-filled rows: plan.is_schedule "phases")
+    alloc = torch.zeros if (parts_ == "phases" or isinstance(parts_, tuple)) else torch.empty  # (phase parts ADD their tiles into zero-filled rows: plan.is_schedule "phases" / "2d")
     out = alloc(rows if reduce is None else reduce[2], dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))

@@ -302,13 +302,18 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
     (set-A, Si 2-atom cell: 12 phases at ~5 us each).  The order of the adds is not fixed: sums differ between runs at fp32 rounding level (as the split
     launches' private tile copies already do).
     separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (IsSchedule.phase_cls)."""
+    # parts = ("2d", P, K): the P segment sets of a split launch, each on K workgroups that take a share of the set's PHASES and add their tiles (SEG_ATOMIC)
     if parts == "phases":
         return _is_schedule_phases(prog)
+    phase_chunks = 1
+    if isinstance(parts, tuple):
+        assert parts[0] == "2d"
+        parts, phase_chunks = int(parts[1]), max(1, int(parts[2]))
     if separate_mlp is None:
         # default: per-generator phases (the kernel re-reads its resident hidden rows once per phase and wave instead of once per generator change
         # inside a work group) when that costs less than 1 % of the estimated critical path -- programs with few phases (narrow irreps) lose
         # more balance than the re-reads cost, data-gradient and lite_mode programs have no such form
-        plain = is_schedule(prog, parts, separate_mlp=False)
+        plain = is_schedule(prog, parts if phase_chunks == 1 else ("2d", parts, phase_chunks), separate_mlp=False)
         if parts != 1 or prog.hidden != 64:
             return plain
         try:
@@ -350,12 +355,33 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
     segs_all, btab, ptab, gtab, items_all, parttab, part_cost, rowtab_all = [], [], [], [], [], [], [], []
     phase_cls_all: List[int] = []
     lds_floats, worst_balance = 0, 1.0
+    atomic_any = False
     for part in range(parts):
         members = [sg for sg in range(nseg) if owner[sg] == part]
         sub = _is_schedule_part(prog, members, hp4, seg_base=len(segs_all), block_base=len(btab), group_base=len(gtab), item_base=len(items_all),
                                 split=parts > 1, separate_mlp=separate_mlp, runs=runs, waves=IS_WAVES_LITE if lite_flag else IS_WAVES)
-        parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
-                        sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, -1, -1, 0, 0])
+        nph_ = len(sub["ptab"])
+        K_ = min(phase_chunks, nph_) if (phase_chunks > 1 and parts > 1 and not lite_flag) else 1
+        if K_ > 1:                                             # the part's phases dealt to K workgroups (LPT on the phases' critical paths), each adds its tiles
+            bins_: List[List[int]] = [[] for _ in range(K_)]
+            ld_ = [0] * K_
+            for ph in sorted(range(nph_), key=lambda p_: -sub["phase_crit"][p_]):
+                b_ = min(range(K_), key=lambda q: (ld_[q], q))
+                bins_[b_].append(ph)
+                ld_[b_] += sub["phase_crit"][ph] + 150
+            order_ = [ph for b_ in bins_ for ph in b_]
+            sub["ptab"] = [sub["ptab"][ph] for ph in order_]
+            sub["phase_cls"] = [sub["phase_cls"][ph] for ph in order_]
+            sub["segs"][:, 7] |= SEG_ATOMIC
+            o_ = 0
+            for b_ in bins_:
+                parttab.append([len(segs_all), len(sub["segs"]), len(ptab) + o_, len(b_), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
+                                sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, -1, -1, 0, 0])
+                o_ += len(b_)
+            atomic_any = True
+        else:
+            parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
+                            sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, -1, -1, 0, 0])
         rowtab_all += sub["rowtab"]
         phase_cls_all += sub["phase_cls"]
         segs_all += list(sub["segs"])
@@ -371,7 +397,7 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
                       np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(gtab, np.int32).reshape(-1, 2), items,
                       np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), np.asarray(rowtab_all, np.int32),
                       lds_floats, worst_balance, part_cost, phase_cls_all,
-                      extra_weights=(np.concatenate(runs["w"]) if runs is not None and runs["w"] else None))
+                      extra_weights=(np.concatenate(runs["w"]) if runs is not None and runs["w"] else None), atomic_out=atomic_any)
 
 
 PHASE_PARTS_MAX = 16

@@ -207,9 +207,8 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
         for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _, mask_lo, mask_hi in (tuple(int(v) for v in p[:14]) for p in sched.part_table):
             stage_floats = ctr_off - stage_off
             part_segs = set(range(sg0, sg0 + nsg))
-            if atomic_parts:
-                assert all(int(sched.seg_table[g][7]) & P.SEG_ATOMIC for g in part_segs) and copy_stride == 0
-            else:
+            part_atomic = all(int(sched.seg_table[g][7]) & P.SEG_ATOMIC for g in part_segs)
+            if not part_atomic:
                 assert not (part_segs & seg_seen)
             seg_seen |= part_segs
             part_mask = (mask_lo & 0xffffffff) | ((mask_hi & 0xffffffff) << 32)
@@ -357,9 +356,9 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                 seg = sched.seg_table[sg]
                 lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
                 strd = (2 * lk_ + 1) * 16 + 4
-                if atomic_parts:                               # the kernel skips the epilogue of the segments the part's mask does not name: they must be untouched
-                    named = bool((part_mask >> (sg - sg0)) & 1)
-                    assert named == (sg in fed), ("segment mask of a phase part", sg, named)
+                if part_atomic and atomic_parts:               # the kernel skips the epilogue of the segments the part's mask does not name: they must be untouched
+                    named = bool((part_mask >> (sg - sg0)) & 1) if sg - sg0 < 64 else True
+                    assert named or sg not in fed, ("segment mask of a phase part", sg, named)
                     if not named:
                         assert not lds[toff_:toff_ + mul_ * strd].any()
                         continue

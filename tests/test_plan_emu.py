@@ -251,6 +251,11 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     s2 = P.is_schedule(prog2)
     a = emu.run_program_is(prog2, s2, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(a, emu.run_program(prog2, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
+    # late r5 (experiment, off by default): one workgroup per (segment set, share of its phases), tiles added into zero-filled rows
+    for pr, want in ((prog, outp), (prog2, a)):
+        s2d = P.is_schedule(pr, ("2d", 3, 2))
+        assert 3 <= s2d.part_table.shape[0] <= 6
+        assert rel(emu.run_program_is(pr, s2d, [xs, xd, fe], (hn, he), D, lmax), want) < 1e-12
     # late r5: phase parts (the smallest crystals) -- all segments in every workgroup, the PHASES dealt to the workgroups of a tile, tiles added into zero-filled rows
     for pr, want in ((prog, outp), (prog2, a)):
         sp2 = P.is_schedule(pr, "phases")
@@ -347,6 +352,9 @@ def test_merged_items_shipped_irreps(which):
     for parts in (3, 8):                                      # the members of a merged item stay in one part
         sp = P.is_schedule(merged, parts)
         assert rel(lay.from_planar(emu.run_program_is(merged, sp, [xs, xd, fe], (hn, he), D, 6)), want) < 1e-6
+    s2d = P.is_schedule(plain, ("2d", plain.seg_table.shape[0], 3))      # (experiment) every output segment's phases on three workgroups
+    assert s2d.atomic_out and s2d.part_table.shape[0] > (2 if which == "A" else 1) * plain.seg_table.shape[0]
+    assert rel(lay.from_planar(emu.run_program_is(plain, s2d, [xs, xd, fe], (hn, he), D, 6)), want) < 1e-6
     # late r5: phase parts of the merged program (the smallest crystals): several phases per set, each workgroup adds the segments its phases feed
     spp = P.is_schedule(merged, "phases")
     assert spp.atomic_out and spp.part_table.shape[0] >= (8 if which == "A" else 2) and (which == "B" or max(spp.part_cost) < 0.3 * sum(sc.part_cost))
