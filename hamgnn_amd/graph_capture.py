@@ -17,17 +17,25 @@ class CapturedForward:
     def __init__(self, fn, warmup: int = 2):
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedForward needs a GPU: HIP graphs replay device work")
+        from . import ops
         self._fn = fn
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(max(1, warmup)):                    # compiles programs, builds the topology cache, sets kernel attributes
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()                    # == hipGraph on ROCm
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.out = fn()
+        # a replayed forward has no host launch cost, so the edge kernel of the smallest crystals is spread finer than an eager forward would pay for:
+        # one workgroup per (output segment, quarter of its phases) instead of one per segment (ops.DeviceProgram.is_parts_for; Si 2-atom cell, set-A:
+        # replay 0.74 -> 0.51 ms, while the same split makes the eager forward slower, 0.74 -> 0.80 ms: one memset more per launch on a host-bound path)
+        prev, ops.REPLAY_SPLIT = ops.REPLAY_SPLIT, True
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(max(1, warmup)):                # compiles programs, builds the topology cache and the schedules' tables, sets kernel attributes
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()                # == hipGraph on ROCm
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.out = fn()
+        finally:
+            ops.REPLAY_SPLIT = prev
 
     def __call__(self):
         self.graph.replay()

@@ -68,6 +68,7 @@ def _require_gpu(t: torch.Tensor):
 # the wide schedule (csrc/tp_wide.hip, r5) is an opt-in experiment: measured 8.5 ms against hg_tp_is's 6.8 ms per 131 072-edge set-A launch (profiles/r05_tp_wide.md)
 WIDE_MODE = os.environ.get("HG_MP_WIDE", "0")             # "0": never (default), "1": launches with >= WIDE_MIN_TILES 16-edge tiles, "force": whenever the program has a wide form
 WIDE_MIN_TILES = int(os.environ.get("HG_WIDE_MIN_TILES", "512"))
+REPLAY_SPLIT = False         # set by graph_capture.CapturedForward while it warms up and captures: launches of the smallest crystals take the finer 2d split
 PHASE_PARTS_TILES = int(os.environ.get("HG_PHASE_PARTS_TILES", "1024"))      # phase parts while tiles x 16 workgroups stay below this (two rounds of the chip's 512 slots)
 
 
@@ -194,7 +195,7 @@ class DeviceProgram:
             return max(1, int(forced))
         tiles = (rows + 15) // 16
         nseg = int(self.prog.seg_table.shape[0])
-        mode = os.environ.get("HG_PHASE_PARTS", "0")           # late r5 experiments, off by default (measured: no gain, profiles/r05_small_graphs.md)
+        mode = os.environ.get("HG_PHASE_PARTS", "2d4" if REPLAY_SPLIT else "0")      # eager: off (measured: no gain on a host-bound path); under graph capture: "2d4"
         if mode == "1" and tiles * P.PHASE_PARTS_MAX <= PHASE_PARTS_TILES and self.phase_parts_ok():
             return "phases"                                    # the PHASES of a tile on separate workgroups, every workgroup holds all tiles
         if mode.startswith("2d") and tiles * nseg * int(mode[2:] or 3) <= PHASE_PARTS_TILES and not int(self.sched.part_table[0][11]):
