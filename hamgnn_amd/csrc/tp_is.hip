@@ -698,9 +698,11 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
 // A launch runs `nparts` sub-schedules (blockIdx.y) of the same program: every part owns a disjoint set of output segments and the
 // phases / groups / items that feed them (plan.py:is_schedule(parts=...)).  One part = the whole program (large edge counts); several
 // parts spread ONE 16-edge tile's serial 34 k-MFMA pass over several workgroups when there are fewer tiles than CUs (small crystals).
-// part record, int32[8]: {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off (float offsets in the LDS),
-// copy_stride}.  copy_stride > 0: each of the four waves accumulates into its own copy of the part's tiles (copy w at + w * copy_stride),
-// so all waves can work on one output segment at once; the copies are summed before the epilogue.
+// part record, int32[16]: {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off (float offsets in the LDS),
+// copy_stride, rowtab_off, rowtab_begin, rowtab_len, lite, segment mask lo, hi, 0, 0}.  copy_stride > 0: each of the four waves accumulates
+// into its own copy of the part's tiles (copy w at + w * copy_stride), so all waves can work on one output segment at once; the copies are
+// summed before the epilogue.  r5: several parts may share a segment range and split its PHASES (plan.is_schedule ("2d", P, K) / "phases"):
+// their segments are flagged SEG_ATOMIC, the epilogues add into zero-filled rows, [12] / [13] name the segments the part's phases feed.
 #define IS_PART_I32 16
 
 template <bool SPLIT, bool LITE>

@@ -102,15 +102,19 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
  *               [20..22] = {lk, mul_k, rto} of that segment, [23] = first row-table entry of the rows its GEMM2 writes
  *   row_table   int32: per part, for every output row (segment, 16-row tile, row) of GEMM2 the LDS float offset (relative to a tile
  *               copy) of that row's centre column; rows beyond the segment's multiplicity point at the trash row
- *   part_table  int32[nparts][12] = {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off, copy_stride,
- *               rowtab_off (LDS float offset of the part's copy of the row table), rowtab_begin, rowtab_len, 0}: the launch runs
+ *   part_table  int32[nparts][16] = {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off, copy_stride,
+ *               rowtab_off (LDS float offset of the part's copy of the row table), rowtab_begin, rowtab_len, lite flag, segment mask lo,
+ *               segment mask hi, 0, 0}: the launch runs
  *               nparts sub-schedules (grid.y) that own disjoint sets of output segments; one part = the whole program, several
  *               parts spread a 16-edge tile's serial pass over several workgroups when there are fewer tiles than CUs (small
  *               crystals: BASELINE configs #1 and #5).  trash_off / stage_off / ctr_off: float offsets of the padding-row sink,
  *               the staging area and the claim counter inside the workgroup's LDS (lds_bytes = the largest part's need);
  *               [7] = copy_stride > 0: every wave accumulates into a private copy of the part's tiles.  part_table_host: the
  *               same table in HOST memory (one of the tiny host arrays; validated, and a single part's scalars travel as
- *               kernel arguments).
+ *               kernel arguments).  r5: parts may SHARE a segment range and take different phase ranges of it; the shared
+ *               segments carry flag bit 1 (SEG_ATOMIC) in seg_table[.][7], their epilogues ADD into `out`, which the caller has
+ *               zero-filled; [12] / [13]: bit s set = the part's phases feed its s-th segment (the others are skipped; -1 = all).
+ *               The order of those adds is not fixed: sums differ between runs at fp32 rounding level.
  * src_idx[i] (nullable): row gather of source i; rot_mask bit i: source i holds GLOBAL-frame
  * node rows that are gathered and rotated by D^l(R_e) while staged -- the node_features[sender/receiver] gathers of
  * convolution.py:138-141 / interaction_blocks.py:141-145 fused into the operand staging (no hg_rotate_gather pass, no per-edge
