@@ -197,11 +197,16 @@ def _worker_product(rank, world, port, tmp, transformer=False, node_shard=False)
     g = S.add_random_targets(S.random_cell(5, [14, 8, 6, 1], seed=7, density=0.004), 19, seed=7)
     N, E = g.num_nodes, g.num_edges
     sg = parallel.shard_graph(g, rank, world)
+    dead = model.declare_consumer(head)                         # (r5) what Model(...) does: the last pair block leaves out the irreps the head never reads
+    assert dead, "the MINI irreps hold 0o, which an openmx nao 19 head never reads"
     with torch.no_grad():
-        out = head(sg, model(sg))["hamiltonian"]
+        rep = model(sg)
+        assert rep.get("_edge_alive") is not None
+        out = head(sg, rep)["hamiltonian"]
     gathered = [None] * world
     dist.all_gather_object(gathered, (sg["_hg_edge_ids"], out[:N], out[N:]))
     if rank == 0:
+        model.declare_consumer(object())                        # the unsharded reference runs the COMPLETE programs
         with torch.no_grad():
             ref = head(g, model(g))["hamiltonian"]
         off = torch.zeros(E, out.shape[1])
