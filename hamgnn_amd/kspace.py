@@ -45,20 +45,61 @@ def k_path_points(kpts, nk: int, lat: np.ndarray):
     return k_vec, np.linalg.inv(cellm).T
 
 
-def make_k_vectors(k_path, num_k: int, cell: torch.Tensor, rng=np.random) -> torch.Tensor:
+AU2ANG = 0.5291772083       # hamgnn/utils/constants.py:2
+
+
+def auto_k_path_nodes(lat_bohr: np.ndarray, pos_bohr: np.ndarray, z) -> list:
+    """k_path='auto' of the reference (hamgnn_output.py:3812-3833): the high-symmetry path of the crystal from pymatgen's KPathSeek -- a Structure in
+    Angstrom with the species' symbols, the labels of all path segments in a row with consecutive repeats dropped, their reduced coordinates as nodes.
+    pymatgen is a third-party dependency of the reference (imported at :19-21) that this image does not have: without it the call raises."""
+    try:
+        from pymatgen.core.periodic_table import Element
+        from pymatgen.core.structure import Structure
+        from pymatgen.symmetry.kpath import KPathSeek
+    except ImportError as e:
+        raise NotImplementedError("k_path='auto' needs pymatgen (Structure / Element / KPathSeek), as in the reference (hamgnn_output.py:19-21, 3812-3837); "
+                                  "give a list of reduced k-points or None (random) instead") from e
+    structure = Structure(lattice=np.asarray(lat_bohr) * AU2ANG, species=[Element.from_Z(int(k)).symbol for k in z], coords=np.asarray(pos_bohr) * AU2ANG,
+                          coords_are_cartesian=True)
+    seek = KPathSeek(structure=structure)
+    labels = [lab for group in seek.kpath["path"] for lab in group]
+    unique = [labels[0]]
+    for x in labels[1:]:
+        if x != unique[-1]:
+            unique.append(x)
+    return [seek.kpath["kpoints"][k] for k in unique]
+
+
+def make_k_vectors(k_path, num_k: int, cell: torch.Tensor, rng=np.random, data=None) -> torch.Tensor:
     """data.k_vecs of the reference (:3802-3854): [n_crystals, num_k, 3] Cartesian-reciprocal k-vectors (no 2 pi: it sits in the phase).
-    k_path: list of nodes in reduced coordinates, or None -> uniformly random reduced k in [-1, 1)^3 (numpy's global RNG, as the reference).
-    ('auto' needs pymatgen's KPathSeek in the reference and is not available here.)"""
+    k_path: list of nodes in reduced coordinates; None -> uniformly random reduced k in [-1, 1)^3 (numpy's global RNG, as the reference); 'auto' -> the
+    crystal's high-symmetry path (auto_k_path_nodes; needs `data` for positions / species and pymatgen; as in the reference a path that cannot be sampled
+    falls back to random points)."""
     out = []
     cells = cell.detach().cpu().double().numpy().reshape(-1, 3, 3)
-    for lat in cells:
+    auto = isinstance(k_path, str) and k_path.lower() == "auto"
+    if auto:
+        if data is None:
+            raise ValueError("k_path='auto' needs the graph (positions and species of every crystal)")
+        counts = gget(data, "node_counts")
+        counts = [int(c) for c in counts.tolist()] if counts is not None else [int(data.z.shape[0])]
+        pos_all, z_all = data.pos.detach().cpu().double().numpy(), data.z.detach().cpu().numpy()
+        starts = np.concatenate([[0], np.cumsum(counts)])
+    for ci, lat in enumerate(cells):
         if isinstance(k_path, (list, tuple)):
             k_vec, lat_per_inv = k_path_points(k_path, num_k, lat)
+        elif auto:
+            nodes = auto_k_path_nodes(lat, pos_all[starts[ci]:starts[ci + 1]], z_all[starts[ci]:starts[ci + 1]])
+            try:
+                k_vec, lat_per_inv = k_path_points(nodes, num_k, lat)
+            except Exception:                                  # noqa: BLE001  (the reference's bare except, :3709-3713 / :3838-3841: random k-points)
+                lat_per_inv = np.linalg.inv(lat).T
+                k_vec = 2.0 * rng.rand(num_k, 3) - 1.0
         elif k_path is None:
             lat_per_inv = np.linalg.inv(lat).T
             k_vec = 2.0 * rng.rand(num_k, 3) - 1.0
         else:
-            raise NotImplementedError(f"k_path={k_path!r}: give a list of reduced k-points or None (random); 'auto' needs pymatgen")
+            raise NotImplementedError(f"k_path={k_path!r}: a list of reduced k-points, 'auto' or None (random)")
         out.append(torch.from_numpy(k_vec.dot(lat_per_inv[np.newaxis, :, :]).reshape(-1, 3)).float())
     return torch.stack(out, 0)
 

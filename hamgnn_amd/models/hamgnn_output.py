@@ -163,7 +163,7 @@ class HamGNNPlusPlusOut(nn.Module):
             return None, None
         from .. import kspace
         f32c = lambda t: t.contiguous().float()
-        data["k_vecs"] = kspace.make_k_vectors(self.k_path if self.k_path is not None else None, self.num_k, data.cell).to(dev)
+        data["k_vecs"] = kspace.make_k_vectors(self.k_path if self.k_path is not None else None, self.num_k, data.cell, data=data).to(dev)
         be, wf = kspace.band_energies_soc(self, on_r, on_i, off_r, off_i, data)
         with torch.no_grad():
             tb, tw = kspace.band_energies_soc(self, f32c(data.Hon), f32c(data.iHon), f32c(data.Hoff), f32c(data.iHoff), data)
@@ -517,7 +517,7 @@ class HamGNNPlusPlusOut(nn.Module):
             # BEFORE the zero-point shift, as the reference (:3802-3880 precede :3971-3981): the bands come from the unshifted blocks
             # (`on` / `off` are views of H for a single crystal, and the shift below works in place)
             from .. import kspace
-            data["k_vecs"] = kspace.make_k_vectors(self.k_path, self.num_k, data.cell).to(dev)
+            data["k_vecs"] = kspace.make_k_vectors(self.k_path, self.num_k, data.cell, data=data).to(dev)
             if self.export_reciprocal_values:                                    # :3856-3869: H(k), S(k), dS(k) next to the bands, H_sym = None;
                 be, wf, HK, SK, dSK, gap = kspace.band_energies_export(           # with overlap networks S(k) is the PREDICTED overlap
                     self, on, off, data, overlap=None if self.ham_only else (s_on, s_off))
