@@ -9,7 +9,7 @@
 Per crystal the script builds H(k), S(k) by phase-factor sums over the edges, masks them to the atoms' orbitals and solves the generalised
 eigenproblem through the Cholesky factor of S(k); here that is `kspace.band_energies` (the `hg_hk_assemble` kernel + hipSOLVER through
 `torch.linalg`), the k-path is `kspace.k_path_points`, energies come out in eV relative to the valence-band maximum exactly as the script prints
-them.  `auto_mode` (pymatgen's KPathSeek) is not available: pass the nodes.
+them.  `auto_mode=True` (script :135-145) takes the nodes of every crystal from pymatgen's KPathSeek (`kspace.auto_k_path`; raises where pymatgen is not installed).
 
     band_structure(..., soc_switch=True):    H_rows per crystal = [real rows (N + E); imaginary rows (N + E)] of width (2 nao)^2, as the SOC heads
         write them (hamgnn_output.py:3621-3626) or Hon / Hoff / iHon / iHoff of the graphs; four spin blocks of H(k), kron(1_2, S(k)),
@@ -31,13 +31,13 @@ AU2EV = 27.211386245988        # Hartree -> eV (DFT_interfaces/openmx/utils.py: 
 
 
 def band_structure(graphs: Sequence, hamiltonian_rows=None, nao_max: int = 19, ham_type: str = "openmx", k_path=None, nk: int = 120,
-                   device: str = "cuda", soc_switch: bool = False, spin_colinear: bool = False) -> List[dict]:
+                   device: str = "cuda", soc_switch: bool = False, spin_colinear: bool = False, auto_mode: bool = False) -> List[dict]:
     """one dict per crystal: {"k_vec" [nk, 3] reduced, "k_dist" [nk], "k_node" [nodes], "bands_eV" [nbands, nk] (0 = valence-band maximum),
-    "vbm_eV", "band_gap_eV"}"""
-    if not isinstance(k_path, (list, tuple)) or len(k_path) < 2:
-        raise ValueError("band_structure: pass the k-path nodes in reduced coordinates (auto_mode needs pymatgen's KPathSeek)")
+    "vbm_eV", "band_gap_eV"} (+ "k_labels" with auto_mode)"""
+    if not auto_mode and (not isinstance(k_path, (list, tuple)) or len(k_path) < 2):
+        raise ValueError("band_structure: pass the k-path nodes in reduced coordinates, or auto_mode=True (pymatgen's KPathSeek)")
     head = HamGNNPlusPlusOut("1x0e", "1x0e", nao_max=nao_max, ham_type=ham_type, ham_only=True, symmetrize=True, add_H0=False, soc_switch=False,
-                             calculate_band_energy=True, num_k=nk, k_path=list(k_path), calculate_sparsity=False)
+                             calculate_band_energy=True, num_k=nk, k_path=None if auto_mode else list(k_path), calculate_sparsity=False)
     head.compile(torch.device(device))                        # only its basis tables are used (orbital ranks, valence electrons)
     if soc_switch and spin_colinear:
         raise ValueError("band_structure: soc_switch and spin_colinear exclude each other (the script's if / elif)")
@@ -59,6 +59,9 @@ def band_structure(graphs: Sequence, hamiltonian_rows=None, nao_max: int = 19, h
             r0 += N + E
         gd = g.to(device)
         lat = gd.cell.detach().cpu().double().numpy().reshape(3, 3)
+        labels = None
+        if auto_mode:                                          # script :135-145 (and :322-332, :491-501): the crystal's own high-symmetry path
+            labels, k_path = kspace.auto_k_path(lat, g.pos.detach().cpu().double().numpy(), g.z.detach().cpu().numpy())
         k_red, lat_per_inv = kspace.k_path_points(k_path, nk, lat)
         nodes = np.asarray(k_path, dtype=np.float64)
         metric = np.linalg.inv(lat @ lat.T)
@@ -70,6 +73,8 @@ def band_structure(graphs: Sequence, hamiltonian_rows=None, nao_max: int = 19, h
         k_cart = torch.from_numpy(k_red @ lat_per_inv).float().reshape(1, nk, 3)
         nel = float(head._num_valence[g.z.cpu()].sum())
         base = {"k_vec": k_red, "k_dist": k_dist, "k_node": k_node}
+        if labels is not None:
+            base["k_labels"] = labels
         dv = lambda t: t.to(device).contiguous()
         if soc_switch:
             be = kspace.band_energies_soc(head, dv(on), dv(ion), dv(off), dv(ioff), gd, k_vecs=k_cart)[0]

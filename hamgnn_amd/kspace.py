@@ -49,7 +49,11 @@ AU2ANG = 0.5291772083       # hamgnn/utils/constants.py:2
 
 
 def auto_k_path_nodes(lat_bohr: np.ndarray, pos_bohr: np.ndarray, z) -> list:
-    """k_path='auto' of the reference (hamgnn_output.py:3812-3833): the high-symmetry path of the crystal from pymatgen's KPathSeek -- a Structure in
+    return auto_k_path(lat_bohr, pos_bohr, z)[1]
+
+
+def auto_k_path(lat_bohr: np.ndarray, pos_bohr: np.ndarray, z):
+    """-> (labels, nodes).  k_path='auto' of the reference (hamgnn_output.py:3812-3833): the high-symmetry path of the crystal from pymatgen's KPathSeek -- a Structure in
     Angstrom with the species' symbols, the labels of all path segments in a row with consecutive repeats dropped, their reduced coordinates as nodes.
     pymatgen is a third-party dependency of the reference (imported at :19-21) that this image does not have: without it the call raises."""
     try:
@@ -67,7 +71,7 @@ def auto_k_path_nodes(lat_bohr: np.ndarray, pos_bohr: np.ndarray, z) -> list:
     for x in labels[1:]:
         if x != unique[-1]:
             unique.append(x)
-    return [seek.kpath["kpoints"][k] for k in unique]
+    return unique, [seek.kpath["kpoints"][k] for k in unique]
 
 
 def make_k_vectors(k_path, num_k: int, cell: torch.Tensor, rng=np.random, data=None) -> torch.Tensor:

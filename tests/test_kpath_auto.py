@@ -62,6 +62,19 @@ def test_auto_k_path_follows_the_reference_wiring(monkeypatch):
     assert kv2.shape == (1, 3, 3) and torch.isfinite(kv2).all()
 
 
+def test_band_cal_auto_mode_labels_and_nodes(monkeypatch):
+    """band_cal's auto_mode (DFT_interfaces/openmx/band_cal.py:135-145): labels with adjacent duplicates removed + their nodes, per crystal"""
+    record = []
+    _stub_pymatgen(monkeypatch, record, [["GAMMA", "X"], ["X", "M"], ["M", "GAMMA"]], {"GAMMA": [0, 0, 0], "X": [0.5, 0, 0], "M": [0.5, 0.5, 0]})
+    g = S.si_diamond(1, 1, 1)
+    labels, nodes = kspace.auto_k_path(g.cell.reshape(3, 3).double().numpy(), g.pos.double().numpy(), g.z.numpy())
+    assert labels == ["GAMMA", "X", "M", "GAMMA"] and nodes == [[0, 0, 0], [0.5, 0, 0], [0.5, 0.5, 0], [0, 0, 0]]
+    assert kspace.auto_k_path_nodes(g.cell.reshape(3, 3).double().numpy(), g.pos.double().numpy(), g.z.numpy()) == nodes
+    from hamgnn_amd import band_cal
+    with pytest.raises(ValueError, match="auto_mode"):                    # neither nodes nor auto_mode
+        band_cal.band_structure([g], None, k_path=None, device="cpu")
+
+
 def test_auto_k_path_without_pymatgen_raises(monkeypatch):
     for k in [m for m in sys.modules if m.startswith("pymatgen")]:
         monkeypatch.delitem(sys.modules, k)
