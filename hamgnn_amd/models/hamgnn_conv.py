@@ -206,7 +206,6 @@ class _BackboneBase(nn.Module):
 
     # ---- unread irreps of the last PairInteractionBlock (r5)
     _edge_alive = None
-    _consumer_id = None
 
     def declare_consumer(self, head):
         """Tell the backbone that `head` is the ONLY reader of the representation it returns (what `Model(representation, output)` wires: Model.py:459-465 of
@@ -217,7 +216,6 @@ class _BackboneBase(nn.Module):
         representation and the complete program runs on first access.  Training forwards (save_for_backward) always run the complete program.
         HG_DEAD_OUT=0 disables.  Returns the list of dropped irreps (indices into irreps_node_features)."""
         self._edge_alive = None
-        self._consumer_id = None
         pairs = getattr(self, "pair_interactions", None)
         if pairs is None or self.lite_mode:
             return []
@@ -231,7 +229,6 @@ class _BackboneBase(nn.Module):
         need = head.edge_irreps_read()
         dead = [k for k, (m, l, p) in enumerate(self.irreps_node_features) if (int(l), int(p)) not in need]
         last.conv_tp.set_dead_outputs(dead)
-        self._consumer_id = id(head) if dead else None
         if dead:
             self._edge_alive = frozenset((int(l), int(p)) for k, (m, l, p) in enumerate(self.irreps_node_features) if k not in dead)
         self._compiled_for = None                                # the reduced program is built at the next compile()
@@ -257,7 +254,7 @@ class _BackboneBase(nn.Module):
 
 
     # ---- backward pieces shared by the two backbones
-    def _backward_pair(self, li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk, data=None, dead_gradient=False):
+    def _backward_pair(self, li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk, data=None):
         """PairInteractionBlock (interaction_blocks.py:130-164): f_out = MP(up_src(node_out)[src], up_tar(node_out)[dst], f_in) + skip(f_in).
         g_node: gradient of node_out so far, g_f: gradient of f_out (edge frame).  Returns (g_node, gradient of f_in); parameter
         gradients go into `grads`."""
@@ -268,9 +265,7 @@ class _BackboneBase(nn.Module):
         if pair.use_skip_connections or not pair.legacy_edge_update:
             up_s, up_t = pair.linear_up_src(node_out), pair.linear_up_tar(node_out)
             # (structural_zeros: as in the forward -- a first-layer block skips the paths that read structurally zero input irreps: zero weight gradients, unread data gradients)
-            # (dead_gradient: the last block, g_f straight from the declared head -- zero in the irreps it never read: the paths that would read them are left out)
-            gs, gd, ge, g_tp = pair.conv_tp.backward(up_s, up_t, f_in, geo, self._rot_tab, g_f, out_is_global=False, chunk=chunk, structural_zeros=True,
-                                                     dead_gradient=dead_gradient)
+            gs, gd, ge, g_tp = pair.conv_tp.backward(up_s, up_t, f_in, geo, self._rot_tab, g_f, out_is_global=False, chunk=chunk, structural_zeros=True)
             grads.update({pre + "conv_tp." + k: v for k, v in g_tp.items()})
             g_up_s = ops.segment_sum(gs, rp_s, pm_s, N)
             g_up_t = ops.segment_sum(gd, rp_r, pm_r, N)
@@ -442,10 +437,8 @@ class HamGNNConvE3(_BackboneBase):
         return rep
 
     # ------------------------------------------------------------------------------------------------------------ backward
-    def backward(self, data, rep, g_node, g_edge_rot, chunk: int = 65536, head_gradient: bool = False):
-        """(head_gradient: the caller vouches that g_edge_rot is what the DECLARED consumer's backward returned -- zero in the irreps that head never reads; the last
-        PairInteractionBlock's backward then leaves out the super-paths that would read those zeros.  training.training_step sets it.)
-        Gradients of EVERY backbone parameter for the gradients of the representation the forward returned: g_node [N, Dp] (planar node
+    def backward(self, data, rep, g_node, g_edge_rot, chunk: int = 65536):
+        """Gradients of EVERY backbone parameter for the gradients of the representation the forward returned: g_node [N, Dp] (planar node
         rows) and g_edge_rot [E, Dp] (planar edge rows in the edge frame) -- what HamGNNPlusPlusOut.backward hands back.  `rep` must come
         from forward(data, save_for_backward=True).  Chains the block-level backwards (all on the HIP kernels + library GEMMs):
         per layer, last to first:  PairInteractionBlock (message block data + weight gradients, sender / receiver segment sums, the two
@@ -468,8 +461,7 @@ class HamGNNConvE3(_BackboneBase):
         for li in reversed(range(self.num_layers)):
             conv, pair, t = self.convolutions[li], self.pair_interactions[li], tape[li]
             node_in, f_in, agg, node_out = t["node_in"], t["f_in"], t["agg"], t["node_out"]
-            g_node, g_f = self._backward_pair(li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk, data,
-                                              dead_gradient=bool(head_gradient and li == self.num_layers - 1 and self._edge_alive is not None))
+            g_node, g_f = self._backward_pair(li, pair, node_out, f_in, geo, topo, g_node, g_f, grads, chunk, data)
             # ---- ConvBlockE3 (convolution.py:116-160): node_out = residual(agg) + skip(node_in), agg = scatter_dst MP(node_in[src], node_in[dst], f_in)
             if self.use_corr_prod:                              # CorrProductBlock between the ConvBlock's residual and the pair block
                 g_node, g_cp = self.corr_products[li].backward(t["node_res"], z, g_node, delta=rep.get("_charge_delta"))

@@ -272,14 +272,6 @@ class MessagePackBlock(nn.Module):
         reads the gradient of a structurally zero input)"""
         return {k: v for k, v in self._zero_kw().items() if k in ("zero_node", "zero_edge")}
 
-    def _backward_kw(self, structural_zeros: bool, dead_gradient: bool = False):
-        """what the backward tables of this call may leave out: the super-paths that read structurally zero inputs (structural_zeros: as the forward) and those whose
-        block of the incoming gradient is zero because the declared head never read that output irrep (dead_gradient: the caller vouches that grad_out comes from it)"""
-        kw = dict(self._zero_inputs_kw()) if structural_zeros else {}
-        if dead_gradient and not self.lite_mode and os.environ.get("HG_DEAD_OUT", "1") != "0" and getattr(self, "_dead", ()):
-            kw["zero_gout"] = tuple(self._dead)
-        return kw
-
     def compile(self, device, unrotate: bool, skip_weight=None):
         sd = _np_sd(self)
         zkw = self._zero_kw()
@@ -288,7 +280,7 @@ class MessagePackBlock(nn.Module):
         self._compile_args = (bool(unrotate), skip_weight is not None, None)      # (unrotate, fused skip Linear, merge groups)
         self._lite_bw = None
         self._packers = getattr(self, "_packers", None) or {}                     # structural: survive recompiles of the same block
-        self._dp_adj = self._dp_adj_z = self._adj_kw_z = self._wgf_kw_z = None      # the data-gradient programs are packed from the same weights
+        self._dp_adj = self._dp_adj_z = None                   # the data-gradient programs are packed from the same weights
         self._wgrad_prev, self._wgrad = (getattr(self, "_wgrad", None) or getattr(self, "_wgrad_prev", None)), None
         self._wgrad_fused = self._wgrad_fused_z = None         # (tables hold the weights: rebuilt on first use)
         if self.lite_mode:
@@ -399,9 +391,9 @@ class MessagePackBlock(nn.Module):
             update(self._dp_z_plain, ("fwd", unrotate, has_skip, False, ztag), fwd(None, zkw), nskip)
         if getattr(self, "_dp_adj", None) is not None:
             update(self._dp_adj, ("adj",), lambda d, sk: P.build_message_pack_adjoint_program(d, *args).weights, 0)
-        zin = getattr(self, "_adj_kw_z", None) or self._zero_inputs_kw()
+        zin = self._zero_inputs_kw()
         if getattr(self, "_dp_adj_z", None) is not None:
-            update(self._dp_adj_z, ("adj", tuple(sorted((k, tuple(v)) for k, v in zin.items()))), lambda d, sk: P.build_message_pack_adjoint_program(d, *args, **zin).weights, 0)
+            update(self._dp_adj_z, ("adj", ztag[:2]), lambda d, sk: P.build_message_pack_adjoint_program(d, *args, **zin).weights, 0)
         if getattr(self, "_wgrad", None) is not None:
             wg, dpA, dpB = self._wgrad
             if dpA is not None:
@@ -416,25 +408,21 @@ class MessagePackBlock(nn.Module):
             dwz = getattr(self, "_wgrad_fused_z", None)
             if dwz:
                 irr = (self.irreps_node, self.irreps_edge)
-                zw = getattr(self, "_wgf_kw_z", None) or zin
-                zi = {"node": zw.get("zero_node", ()), "edge": zw.get("zero_edge", ())}
-                fused_z = lambda d, sk: P.build_tp_wgrad_fused(P.message_pack_wgrad_branches(d, *irr), self.irreps_sh, self.irreps_out, dwz.wf.hidden, zero_inputs=zi,
-                                                               zero_gout=zw.get("zero_gout", ())).weights
-                dwz.weights.copy_(packer(("wgF", tuple(sorted((k, tuple(v)) for k, v in zw.items()))), fused_z, 0).apply({k: v for k, v in src.items() if k != "skip"}))
+                zi = {"node": zin.get("zero_node", ()), "edge": zin.get("zero_edge", ())}
+                fused_z = lambda d, sk: P.build_tp_wgrad_fused(P.message_pack_wgrad_branches(d, *irr), self.irreps_sh, self.irreps_out, dwz.wf.hidden, zero_inputs=zi).weights
+                dwz.weights.copy_(packer(("wgF", ztag[:2]), fused_z, 0).apply({k: v for k, v in src.items() if k != "skip"}))
         dev = self._dp.weights.device
         self._hn = self.node_weight_generator.hidden_layers(dev)
         self._he = self.edge_weight_generator.hidden_layers(dev)
         return True
 
     # ---- backward: data gradient as an adjoint program, weight gradients through backward_mp
-    def compile_adjoint(self, device, structural_zeros: bool = False, kw=None):
-        """upload the data-gradient program of this block (plan.build_message_pack_adjoint_program): same kernels, same weights.  structural_zeros / kw
-        (_backward_kw): the variant without the items whose result nobody reads or whose input gradient block is zero"""
+    def compile_adjoint(self, device, structural_zeros: bool = False):
+        """upload the data-gradient program of this block (plan.build_message_pack_adjoint_program): same kernels, same weights.  structural_zeros: the
+        variant that does not compute the gradient of the structurally zero input irreps (set_structural_zeros; nobody reads it)"""
         if self.lite_mode:
             raise NotImplementedError("data gradient of a lite_mode MessagePackBlock")
-        zin = dict(kw) if kw is not None else (self._zero_inputs_kw() if structural_zeros else {})
-        if zin:
-            self._adj_kw_z = dict(zin)
+        zin = self._zero_inputs_kw() if structural_zeros else {}
         prog = P.build_message_pack_adjoint_program(_np_sd(self), self.irreps_node, self.irreps_edge, self.irreps_sh, self.irreps_out, **zin)
         try:
             dp = ops.DeviceProgram(prog, device, schedule="is_parts" if os.environ.get("HG_MP_KERNEL", MP_KERNEL_DEFAULT) != "seg" else "seg")
@@ -445,17 +433,17 @@ class MessagePackBlock(nn.Module):
         self._adj_maps = tuple(torch.from_numpy(m).to(device) for m in maps)
         return self
 
-    def backward_data(self, grad_out, geo: ops.Geometry, out_is_global: bool, gather=None, structural_zeros: bool = False, dead_gradient: bool = False):
+    def backward_data(self, grad_out, geo: ops.Geometry, out_is_global: bool, gather=None, structural_zeros: bool = False):
         """grad_out [E, planar(irreps_out)]: gradient with respect to the rows this block's forward returned (global frame if the block
         was compiled with unrotate=True, else edge frame); or, with `gather` = an [E] index tensor, NODE rows whose gather is that
         per-edge gradient (the backward of the receiver scatter of a ConvBlockE3 is the gather grad_agg[receiver]; it is fused into the
         kernel's staging like the forward's node gathers).  Returns per-edge gradients (g_src_rows, g_dst_rows, g_edge_rows), planar:
         the first two in the GLOBAL frame, to be summed over the edges of each sender / receiver (ops.segment_sum over the sender /
         receiver CSR) for the gradient of the gathered node rows; the third in the edge frame, where the forward read the edge rows."""
-        kw = self._backward_kw(structural_zeros, dead_gradient)  # (the caller vouches as for run_nodes: the marked input irreps are zero, their gradient unread)
-        slot = "_dp_adj_z" if kw else "_dp_adj"
-        if getattr(self, slot, None) is None or (kw and getattr(self, "_adj_kw_z", None) != kw):
-            self.compile_adjoint(grad_out.device, kw=kw)
+        z = bool(structural_zeros and self._zero_inputs_kw())   # (the caller vouches as for run_nodes: the marked input irreps are zero, their gradient unread)
+        slot = "_dp_adj_z" if z else "_dp_adj"
+        if getattr(self, slot, None) is None:
+            self.compile_adjoint(grad_out.device, structural_zeros=z)
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
         hn = ops.radial_hidden_cached(geo, self._hn, cst)
         he = ops.radial_hidden_cached(geo, self._he, cst)
@@ -493,7 +481,7 @@ class MessagePackBlock(nn.Module):
         return getattr(self, slot)
 
     def backward_weights(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, chunk: int = 65536, gather=None,
-                         structural_zeros: bool = False, dead_gradient: bool = False):
+                         structural_zeros: bool = False):
         """gradients of every parameter of this block for the output gradient `grad_out` (frame and `gather` as in backward_data), first
         version (hamgnn_amd/backward_mp.py): two materialisation programs on the fused kernels + library GEMMs over the edges.
         node_s / node_d: planar NODE rows gathered by sender / receiver as in run_nodes; f_rot: planar edge rows (edge frame).
@@ -514,7 +502,7 @@ class MessagePackBlock(nn.Module):
         else:
             g = grad_out if gather is None else grad_out[gather].contiguous()
         cst = float(P.ACT_CONSTS[P.ACT_SILU])
-        dwf = self._wgrad_fused_for(wg, dev, structural_zeros, dead_gradient)
+        dwf = self._wgrad_fused_for(wg, dev, structural_zeros)
         if dwf is not None:                                    # fused kernel (csrc/tp_wgrad.hip): nothing per edge is materialised but gs
             hidden = {"node": ops.radial_hidden_cached(geo, self._hn, cst), "edge": ops.radial_hidden_cached(geo, self._he, cst)}
             run = lambda srcs, g_, hn, he: ops.tp_wgrad(dwf, srcs, g_, hn, he)
@@ -524,21 +512,19 @@ class MessagePackBlock(nn.Module):
             self._wgrad[1:] = [dpA, dpB]
         return BM.block_weight_grads(wg, _wgrad_runner(wg, dpA, dpB), xs, xd, f_rot, g, geo.rbf, cst, chunk=chunk)
 
-    def _wgrad_fused_for(self, wg, dev, structural_zeros: bool = False, dead_gradient: bool = False):
+    def _wgrad_fused_for(self, wg, dev, structural_zeros: bool = False):
         """the fused weight-gradient tables of this block on the device, or None (HG_WGRAD=rows, or no kernel instantiation for these irreps:
         the materialisation route then).  structural_zeros: the tables without the row tiles of super-paths that read structurally zero input irreps
         (their gradients are exactly zero: plan.build_tp_wgrad_fused)"""
         if os.environ.get("HG_WGRAD", "fused") != "fused":
             return None
-        zin = self._backward_kw(structural_zeros, dead_gradient)
+        zin = self._zero_inputs_kw() if structural_zeros else {}
         slot = "_wgrad_fused_z" if zin else "_wgrad_fused"
         cur = getattr(self, slot, None)
-        if cur is None or (zin and getattr(self, "_wgf_kw_z", None) != zin):
+        if cur is None:
             try:
                 zi = {"node": zin.get("zero_node", ()), "edge": zin.get("zero_edge", ())} if zin else None
-                if zin:
-                    self._wgf_kw_z = dict(zin)
-                wf = P.build_tp_wgrad_fused(wg.branches, self.irreps_sh, self.irreps_out, wg.H, zero_inputs=zi, zero_gout=zin.get("zero_gout", ()))
+                wf = P.build_tp_wgrad_fused(wg.branches, self.irreps_sh, self.irreps_out, wg.H, zero_inputs=zi)
                 cur = ops.DeviceWgFused(wf, dev)
             except NotImplementedError:
                 cur = False
@@ -546,15 +532,14 @@ class MessagePackBlock(nn.Module):
         return cur or None
 
     def backward(self, node_s, node_d, f_rot, geo: ops.Geometry, rot_tab, grad_out, out_is_global: bool, gather=None, chunk: int = 65536,
-                 structural_zeros: bool = False, dead_gradient: bool = False):
+                 structural_zeros: bool = False):
         """data AND weight gradients of the block in one call: (g_src_rows, g_dst_rows, g_edge_rows, {parameter name: gradient}); arguments
         as backward_data / backward_weights.  lite_mode blocks go through hamgnn_amd/backward_lite.py (nothing large to materialise).
         structural_zeros: as run_nodes -- the caller vouches that the input irreps marked by set_structural_zeros are zero in the rows it passes AND that
         it does not read their gradient (a backbone's first layer): weight gradients of the paths that read them are exactly zero and not computed."""
         if not self.lite_mode:
-            grads = self.backward_weights(node_s, node_d, f_rot, geo, rot_tab, grad_out, out_is_global, chunk=chunk, gather=gather, structural_zeros=structural_zeros,
-                                          dead_gradient=dead_gradient)
-            return self.backward_data(grad_out, geo, out_is_global, gather=gather, structural_zeros=structural_zeros, dead_gradient=dead_gradient) + (grads,)
+            grads = self.backward_weights(node_s, node_d, f_rot, geo, rot_tab, grad_out, out_is_global, chunk=chunk, gather=gather, structural_zeros=structural_zeros)
+            return self.backward_data(grad_out, geo, out_is_global, gather=gather, structural_zeros=structural_zeros) + (grads,)
         from . import backward_lite as BL
         dev = grad_out.device
         if getattr(self, "_lite_bw", None) is None:

@@ -1535,7 +1535,7 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
 
 def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_g: int, gout_layout: PlanarLayout, irreps_sh: Irreps,
                          irreps_out: Irreps, tp_weight: np.ndarray, w3: np.ndarray, lin_scale_w: np.ndarray, lin_out_w: Optional[np.ndarray],
-                         mlp: int, target_base: int, skip_inputs: Sequence[int] = (), zero_gout: Sequence[int] = ()):
+                         mlp: int, target_base: int, skip_inputs: Sequence[int] = ()):
     """DATA-GRADIENT items of one tensor-product branch: the adjoint of add_tp_items with respect to the branch's input rows, on the
     SAME kernels.  With out[k] = sum_rows L^T (cf s (W x_i)) the gradient is  g_x[i] = sum_rows W^T (cf' s (L g_out[k]))  -- the same
     item shape with the roles of the two weight matrices swapped: GEMM1 contracts the staged g_out block of irrep k (source slot
@@ -1548,9 +1548,8 @@ def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_
     items that would compute it are not emitted, those blocks of the result are zeros."""
     H = prog.hidden
     skip_inputs = set(int(i) for i in skip_inputs)
-    zero_gout = set(int(k) for k in zero_gout)                 # output irreps whose gradient block is zero (nobody read them): items that would read it add nothing
     for sp in _tp_superpaths(nsrc, in_layout, irreps_sh, irreps_out, tp_weight, w3, lin_scale_w, lin_out_w, False):
-        if sp["i"] in skip_inputs or sp["k"] in zero_gout:
+        if sp["i"] in skip_inputs:
             continue
         i, k, mi, li, mk, lk, mm, par = sp["i"], sp["k"], sp["mi"], sp["li"], sp["mk"], sp["lk"], sp["mm"], sp["par"]
         nc = 2 * mm + 1
@@ -1861,7 +1860,7 @@ def message_pack_adjoint_layout(irreps_node, irreps_edge):
 
 
 def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, irreps_edge, irreps_sh, irreps_out,
-                                       zero_node: Sequence[int] = (), zero_edge: Sequence[int] = (), zero_gout: Sequence[int] = ()) -> Program:
+                                       zero_node: Sequence[int] = (), zero_edge: Sequence[int] = ()) -> Program:
     """DATA GRADIENT of a (non-lite) MessagePackBlock forward (message_passing.py:191-231) as a program for the same fused kernels:
     source slot 0 = the gradient with respect to the block's output rows [E, planar(irreps_out)] in the edge-aligned frame, output rows =
     [gradient of the doubled node-branch input | gradient of the edge-feature input] (message_pack_adjoint_layout), the node part
@@ -1869,9 +1868,7 @@ def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, i
     rows), the edge part left in the edge frame (where the forward read it).  The radial hidden activations are those of the forward.
     Weight gradients are NOT part of this program.
     zero_node / zero_edge: structurally zero input irreps of the forward (build_message_pack_program) -- what produced those rows (the 0e chemical embedding,
-    the 0e x Y^l pair embedding) has no path into them, so nobody reads their gradient: the items that compute it are dropped (zeros in those blocks).
-    zero_gout: output irreps of the forward whose block of the incoming gradient is zero -- the last PairInteractionBlock when the gradient comes from the declared
-    head, which never read them (build_message_pack_program dead_out): the items that read those blocks are dropped."""
+    the 0e x Y^l pair embedding) has no path into them, so nobody reads their gradient: the items that compute it are dropped (zeros in those blocks)."""
     irreps_node, irreps_edge, irreps_sh, irreps_out = Irreps(irreps_node), Irreps(irreps_edge), Irreps(irreps_sh), Irreps(irreps_out)
     _, w3n = _last_layer(sd, "node_weight_generator")
     _, w3e = _last_layer(sd, "edge_weight_generator")
@@ -1882,10 +1879,10 @@ def build_message_pack_adjoint_program(sd: Dict[str, np.ndarray], irreps_node, i
     gl = PlanarLayout(irreps_out)
     add_tp_adjoint_items(prog, PlanarLayout(irreps_node), 2, 0, gl, irreps_sh, irreps_out, np.asarray(sd["node_tensor_product.weight"]),
                          w3n / math.sqrt(H), np.asarray(sd["node_linear_scaler.linear_out.weight"]), np.asarray(sd["node_linear_out.weight"]),
-                         mlp=0, target_base=0, skip_inputs=zero_node, zero_gout=zero_gout)
+                         mlp=0, target_base=0, skip_inputs=zero_node)
     add_tp_adjoint_items(prog, PlanarLayout(irreps_edge), 1, 0, gl, irreps_sh, irreps_out, np.asarray(sd["edge_tensor_product.weight"]),
                          w3e / math.sqrt(H), np.asarray(sd["edge_linear_scaler.linear_out.weight"]), np.asarray(sd["edge_linear_out.weight"]),
-                         mlp=1, target_base=nb, skip_inputs=zero_edge, zero_gout=zero_gout)
+                         mlp=1, target_base=nb, skip_inputs=zero_edge)
     return prog.finalize()
 
 
@@ -2020,12 +2017,11 @@ class WgFused:
     bytes_per_edge: float = 0.0             # staged bytes per edge, all units
 
 
-def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int, zero_inputs: Optional[Dict[str, Sequence[int]]] = None, zero_gout: Sequence[int] = ()) -> WgFused:
+def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int, zero_inputs: Optional[Dict[str, Sequence[int]]] = None) -> WgFused:
     """see WgFused; branches as build_tp_wgrad_programs (weighted branches only).  zero_inputs: {branch name: input irreps whose rows are structurally
     zero} -- every gradient a super-path that reads one of them feeds (g_W = x^T ..., g_L = g^T (s cf W x), gs = sum cf (W x)(L g)) is exactly zero, so its
     row tiles are not built: the parameters keep the zero slot, the radial channels stay at the zero fill (gs_complete is False then)."""
     zero_inputs = {k: set(int(i) for i in v) for k, v in (zero_inputs or {}).items()}
-    zero_gout = set(int(k) for k in zero_gout)                 # output irreps whose gradient block is zero: g_W = x^T (s cf L g), g_L = g^T (...), gs = sum cf (W x)(L g) all vanish
     irreps_sh, irreps_out = Irreps(irreps_sh), Irreps(irreps_out)
     gl = PlanarLayout(irreps_out)
     if H != 64:
@@ -2048,7 +2044,7 @@ def build_tp_wgrad_fused(branches, irreps_sh, irreps_out, H: int, zero_inputs: O
         by_i: Dict[int, list] = {}
         for sp in _tp_superpaths(nsrc, lay, irreps_sh, irreps_out, np.asarray(b["tp_w"]), w3, np.asarray(b["ls_w"]),
                                  None if b["lo_w"] is None else np.asarray(b["lo_w"]), False):
-            if sp["i"] in zero_inputs.get(b["name"], ()) or sp["k"] in zero_gout:
+            if sp["i"] in zero_inputs.get(b["name"], ()):
                 continue
             nc = 2 * sp["mm"] + 1
             g1, g2 = ceil_div(lay.mulp[sp["i"]], 16), ceil_div(gl.mulp[sp["k"]], 16)

@@ -242,9 +242,7 @@ def training_step(model, batch, metric: str = "mae", target: Optional[torch.Tens
                 raise ValueError(f"training_step: losses on {pred!r} are not built (hamiltonian | hamiltonian_real | hamiltonian_imag | band_energy)")
             loss = loss + w * li
     g_node, g_edge, g_head = head.backward(batch, rep, gH, grad_unshifted=g_unshifted if losses is not None and not sharded else None)
-    # (the edge gradient comes straight from the head the backbone was told about: zero in the irreps that head never reads -- ConvE3 backbones skip those paths)
-    vouch = getattr(backbone, "_consumer_id", None) is not None and backbone._consumer_id == id(head) and "head_gradient" in backbone.backward.__code__.co_varnames
-    g_back = backbone.backward(batch, rep, g_node, g_edge, **({"head_gradient": True} if vouch else {}))
+    g_back = backbone.backward(batch, rep, g_node, g_edge)
     if sharded:                                                # per-edge parameters: sum the ranks' partial gradients (one flat bucket each)
         parallel.allreduce_edge_summed_gradients(g_head, batch)
         parallel.allreduce_edge_summed_gradients(g_back, batch)
