@@ -790,11 +790,20 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
         __syncthreads();
         IS_T(6);                                               // staging the phase's input blocks
         // work groups = all items of one (phase, output segment), claimed largest-first: dynamic balance, and a tile is only ever
-        // updated by one wave between two barriers
+        // updated by one wave between two barriers (the order of the adds into a tile cell is the program's: phases, then a group's items).
+        // Parts with private tile copies (split launches of small crystals): every item is its own group and the groups are DEALT, not claimed
+        // (r6) -- group g0 + k * NW + w is the k-th of wave w (planner: LPT on its cost model) -- so the content of every copy, and with the
+        // fixed fold below the launch's whole summation order, does not depend on which wave was faster: two forwards agree bit for bit
+        int gi_dealt = g0 + wave;
         while (true) {
             int gi = 0;
-            if (lane == 0) gi = atomicAdd(ctr, 1);
-            gi = __builtin_amdgcn_readfirstlane(gi);
+            if (SPLIT && copy_stride) {
+                gi = __builtin_amdgcn_readfirstlane(gi_dealt);
+                gi_dealt += NW;
+            } else {
+                if (lane == 0) gi = atomicAdd(ctr, 1);
+                gi = __builtin_amdgcn_readfirstlane(gi);
+            }
             if (gi >= g1) break;
             const int ib = g_groups[2 * gi], ie = g_groups[2 * gi + 1];
             for (int ii = ib; ii < ie; ++ii) {

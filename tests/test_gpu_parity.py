@@ -113,7 +113,8 @@ def test_front_door_checkpoint_and_datasets_reproduce_the_fixtures():
 def test_fused_node_scatter_equals_message_rows_plus_segment_sum():
     r = G.check_fused_scatter()
     print(r)
-    assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6, r
+    # (two summation orders of the receivers' sums: G.SAME_MATH_TOL; the edge rows downstream inherit the node rows' rounding)
+    assert r["node_rel_err"] < G.SAME_MATH_TOL and r["edge_rel_err"] < G.SAME_MATH_TOL, r
 
 
 @pytest.mark.parametrize("legacy", [False, True])
@@ -122,7 +123,8 @@ def test_structural_zero_inputs_of_the_first_layer(legacy):
     out of the 0e x Y^l pair embedding; with legacy_edge_update the edge rows stay the embedding's for one more layer): same rows as the complete programs"""
     r = G.check_structural_zeros(legacy=legacy)
     print(r)
-    assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6 and r["first_layer_mfma_ratio"] < 0.6 and (legacy or r["last_layer_mfma_ratio"] == 1.0), r
+    # (a reduced program deals its items to the waves differently from the complete one: another order of the same sums, G.SAME_MATH_TOL)
+    assert r["node_rel_err"] < G.SAME_MATH_TOL and r["edge_rel_err"] < G.SAME_MATH_TOL and r["first_layer_mfma_ratio"] < 0.6 and (legacy or r["last_layer_mfma_ratio"] == 1.0), r
 
 
 SET_A = "64x0e+64x0o+32x1o+16x1e+12x2o+25x2e+18x3o+9x3e+4x4o+9x4e+4x5o+4x5e+2x6e"
@@ -137,13 +139,16 @@ def test_unread_irreps_of_the_last_pair_block(kw):
     (noise in the unread blocks changes nothing); `edge_attr`, a wider head and training forwards get the complete rows."""
     r = G.check_dead_outputs(**kw)
     print(r)
+    # the COMPLETE program run again on the same rows (`edge_attr` after a reduced forward, a head that reads more than was declared): the same launches as
+    # the undeclared forward -> bit-identical since r6; reduced vs complete program, device repack vs fresh compile, training vs inference launches: other
+    # orders of the same fp32 sums -> G.SAME_MATH_TOL (derived in tests/gpu_checks.py)
     if kw.get("soc") == "su2":
-        assert r["dead_irreps"] == 0 and r["alive_declared"] == 0.0 and r["ham_rel_err"] < 2e-6 and r["edge_attr_rel_err"] < 2e-6 and r["wider_head_rel_err"] < 2e-6, r
+        assert r["dead_irreps"] == 0 and r["alive_declared"] == 0.0 and r["ham_rel_err"] == 0.0 and r["edge_attr_rel_err"] == 0.0 and r["wider_head_rel_err"] == 0.0, r
         return
     assert r["dead_irreps"] >= (5 if "irr" in kw else 1) and r["alive_declared"] == 1.0, r
-    assert r["ham_rel_err"] < 2e-6 and r["ham_noise_max_abs"] == 0.0 and r["dead_blocks_max_abs"] == 0.0, r
-    assert r["edge_attr_rel_err"] < 2e-6 and r["wider_head_rel_err"] < 2e-6 and r["last_pair_mfma_ratio"] < (0.9 if "irr" in kw else 1.0), r
-    assert r["training_rows_rel_err"] < 2e-6 and r["training_alive_declared"] == 0.0 and r["refresh_rel_err"] < 2e-6, r
+    assert r["ham_rel_err"] < G.SAME_MATH_TOL and r["ham_noise_max_abs"] == 0.0 and r["dead_blocks_max_abs"] == 0.0, r
+    assert r["edge_attr_rel_err"] == 0.0 and r["wider_head_rel_err"] == 0.0 and r["last_pair_mfma_ratio"] < (0.9 if "irr" in kw else 1.0), r
+    assert r["training_rows_rel_err"] < G.SAME_MATH_TOL and r["training_alive_declared"] == 0.0 and r["refresh_rel_err"] < G.SAME_MATH_TOL, r
 
 
 def test_corr_product_block_golden():
@@ -753,6 +758,23 @@ def test_backward_skips_structural_zero_inputs(legacy):
     print(r)
     assert r["loss_rel_err"] < 1e-6 and r["grad_max_rel_err"] < 2e-5 and r["fused_route"] == 1.0, r
     assert r["first_conv_wgrad_mfma_ratio"] < 0.6 and r["first_conv_adjoint_mfma_ratio"] < 0.6, r
+
+
+@pytest.mark.parametrize("which,graph", [("A", "si2"), ("B", "si2"), ("A", "cell9")], ids=["si2_setA", "si2_setB", "cell9_mini"])
+def test_small_graph_forward_is_bit_reproducible(which, graph):
+    """r6: BASELINE config #1 (and the 9-atom cell GPUTEST_r05 went red on) evaluated four times eagerly: node rows, edge rows and Hamiltonian blocks agree
+    BIT FOR BIT.  Every edge launch of these crystals is a split launch with private tile copies per wave -- their work is dealt statically since r6."""
+    r = G.check_small_graph_forward_reproducible(which=which, graph=graph)
+    print(r)
+    assert r["parts"] != ["1"], r                              # the split launches are what is being tested
+    assert r["node_max_abs_diff"] == 0.0 and r["edge_max_abs_diff"] == 0.0 and r["H_max_abs_diff"] == 0.0, r
+
+
+def test_training_step_on_a_small_crystal_is_bit_reproducible():
+    """the same guarantee for the training step of a 6-atom cell: split forward launches, data-gradient programs spread over several workgroups per tile"""
+    r = G.check_training_step_reproducible(n_atoms=6)
+    print(r)
+    assert r["loss_diff"] == 0.0 and r["max_grad_diff"] == 0.0 and r["n_params"] > 60, r
 
 
 def test_training_step_is_bit_reproducible():

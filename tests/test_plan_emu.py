@@ -309,6 +309,51 @@ def test_input_stationary_schedule_shipped_irreps(which):
 
 
 @pytest.mark.parametrize("which", ["A", "B"])
+def test_split_launch_work_groups_are_dealt_not_claimed(which):
+    """r6: a part with private tile copies per wave deals its work groups statically -- group g0 + k * waves + w is the k-th of wave w,
+    short streams end with empty groups -- so which wave adds an item into which copy does not depend on a run's timing: one summation order per launch.
+    Checks the table form the kernel relies on (csrc/tp_is.hip: gi = g0 + wave, += NW), that every item is still issued exactly once, that the dealing is
+    the LPT one (no wave above the list-scheduling bound) and that the emulator agrees with the single-part schedule on the same inputs."""
+    import torch
+    import bench
+    from hamgnn_amd import nn as hnn
+    irr = bench.IRREPS[which]
+    torch.manual_seed(0)
+    m = hnn.MessagePackBlock(irr, irr, bench.SH, irr, 64, [64, 64])
+    skip = np.zeros(sum(mm * mm for mm, _, _ in so3.Irreps(irr)))
+    prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, bench.SH, irr, True, skip)
+    hp4 = prog.hidden_pad // 4
+
+    def cost_of(it):                                           # plan._item_cost on a schedule record ([22] = row tiles of GEMM2's output)
+        nsrc, nc, rtm = (2 if it[2] >= 0 else 1), 2 * int(it[6]) + 1, int(it[9])
+        return nsrc * int(it[8]) * rtm * nc + P.ITEM_OVERHEAD + ((hp4 * rtm + int(it[22]) * int(it[18]) * nc) if int(it[0]) == P.IT_TP else 0)
+
+    for parts in (8, prog.seg_table.shape[0]):
+        sp = P.is_schedule(prog, parts)
+        seen = np.zeros(sp.item_table.shape[0], dtype=int)
+        for pt in sp.part_table:
+            assert int(pt[7]) > 0                              # every part of the shipped sets keeps private copies
+            for b0, b1, g0, g1 in sp.phase_table[int(pt[2]):int(pt[2]) + int(pt[3]), :4]:
+                assert (g1 - g0) % P.IS_WAVES == 0
+                G = sp.group_table[g0:g1].reshape(-1, P.IS_WAVES, 2)
+                cost = np.zeros(P.IS_WAVES)
+                for k in range(G.shape[0]):
+                    for w in range(P.IS_WAVES):
+                        ib, ie = (int(v) for v in G[k, w])
+                        assert ie - ib in (0, 1)                # an item is its own work group; an empty group ends a short stream ...
+                        if ie == ib:
+                            assert all(int(G[k2, w, 1]) == int(G[k2, w, 0]) for k2 in range(k, G.shape[0]))      # ... and nothing follows it
+                        seen[ib:ie] += 1
+                        cost[w] += sum(cost_of(sp.item_table[i]) for i in range(ib, ie))
+                dearest = max((cost_of(sp.item_table[int(ib)]) for ib, ie in sp.group_table[g0:g1] if ie > ib), default=0)
+                assert cost.max() <= cost.sum() / P.IS_WAVES + dearest      # list-scheduling bound
+        assert (seen == 1).all()
+        # twice the same tables: the planner itself is deterministic
+        sp2 = P.is_schedule(prog, parts)
+        assert np.array_equal(sp.group_table, sp2.group_table) and np.array_equal(sp.item_table, sp2.item_table)
+
+
+@pytest.mark.parametrize("which", ["A", "B"])
 def test_merged_items_shipped_irreps(which):
     """small output irreps of one parity class share MFMA row tiles (plan.choose_merge_groups / Program.vsegs): fewer issued MFMAs and
     items, the same results (emulated through the row table on a few edges, single- and multi-part schedules), LDS budget kept"""
