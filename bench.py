@@ -263,6 +263,26 @@ def accuracy_vs_oracle(path):
                       f"fp32 HIP vs fp64 oracle ({time.perf_counter() - t0:.1f} s on the host)"}
 
 
+class _LauncherExit(SystemExit):
+    """exit of the process that only launched the ranks (not a rank's own failure)"""
+
+
+def self_launch(n_gpus: int) -> int:
+    """run `sys.argv` again as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py ...` and
+    return the launcher's exit code"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,6 +296,7 @@ def main():
     ap.add_argument("--lite", action="store_true", help="lite_mode MessagePackBlocks (message_passing.py:197-215: unweighted uvu products + o3.Linear + one combined radial scale); "
                     "runs on the lite instantiation of the input-stationary kernel (tp_is_kernel<., true>), the roofline then counts the planner's executed flops (SURVEY 8d's figures are for the default block)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-complete-pass", action="store_true", help="skip the extra pass with every path of the reference's op graph issued (value_complete_programs; N = 1 only, after the timed region)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--accuracy-from", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy leg (fp64 oracle on a bounded sub-crystal, host cores)")
@@ -287,12 +308,19 @@ def main():
         print("CPU_BASELINE " + json.dumps(cpu_baseline(args.workload, args.irreps, args.nao, lite=args.lite, soc=args.soc)), flush=True)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` as ONE command (the reference's multi-GPU entry is one too: Lightning spawns the ranks, hamgnn/main.py:316-321): re-run this very
+        # command line under torch.distributed.run, one process per GPU, static rendezvous on 127.0.0.1 (the container's hostname may not resolve); rank 0 prints the
+        # JSON line on the inherited stdout, a failing rank makes the launcher -- and this process -- exit non-zero
+        rc = self_launch(args.gpus)
+        if rc:
+            print("BENCH_LAUNCH_FAILURE " + json.dumps({"gpus": args.gpus, "launcher_rc": rc, "see": "the BENCH_RANK_FAILURE line(s) of the rank(s) that died first"}), file=sys.stderr, flush=True)
+        raise _LauncherExit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): pass --gpus {world}, or run `python bench.py --gpus {args.gpus}` without a launcher")
     same_device = os.environ.get("HG_BENCH_SAME_DEVICE") == "1"
     if same_device:                                        # test hook: validate the N>1 script path on a 1-GPU box (gloo, shared device)
         local_rank = 0
@@ -462,7 +490,10 @@ def main():
     share = [dp.prog.flops_per_row / fo.flops_per_row for dp, fo in zip(dps, full_of)]           # non-zero share of the reference formulation's flops, per launch of a step
     ref_tot = sum(REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * r for _, r, _ in mp)
     ref_nonzero_tot = sum(REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * share[k % len(dps)] * r for k, (_, r, _) in enumerate(mp))
-    flops_tot = useful_tot if args.lite else ref_tot
+    # r6: the headline `achieved` / `frac` count, per launch, only the share of the reference formulation's flops that the launched PROGRAM still holds
+    # (a first-layer launch that drops the super-paths reading structurally zero irreps is credited with 27 % of 4.55 MFLOP per edge, not with all of it); the
+    # figure that credits every launch with the reference op graph's full flops is reported as `frac_vs_reference_op_graph`, clearly named
+    flops_tot = useful_tot if args.lite else ref_nonzero_tot
     ach = flops_tot / t_tot / 1e12
     kern = "is" if dps[-1].sched is not None else "seg"
     pmc_bytes = PMC_HBM_BYTES_PER_EDGE_BLOCK[(kern, args.irreps)]
@@ -472,14 +503,14 @@ def main():
     full_t = [t for k, (t, r, _) in enumerate(mp) if share[k % len(dps)] > 0.999]
     roofline = {"kernel": ("tp_is_kernel (input-stationary" if kern == "is" else "tp_fused_kernel (segment-stationary") + " MessagePackBlock launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": pmc_bytes * rows_per_launch,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, measured offline on the benchmarked launches of this kernel build: profiles/r05_tp_is_pmc.md; "
+                "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, measured offline on the benchmarked launches of this kernel: profiles/r05_tp_is_pmc.md; "
                                 "set-B: r02b_tp_is_hbm_pmc.md, segment-stationary kernel: r01c_tp_fused_hbm_pmc.md), scaled to this launch's edge count", "avg_launch_ms": avg_s * 1e3,
                 "launches_timed": len(mp), "edges_per_launch": rows_per_launch,
-                # `achieved` counts the reference formulation's flops of EVERY block (4.55 MFLOP per edge and block for set-A) -- including the ones the
-                # reference spends multiplying the structurally zero input irreps of the first layer and computing the output irreps of the last pair block that
-                # the read-out head never reads, which this build does not issue.  The figure that excludes them (`..._without_...`: only
-                # the share of each launch's flops that its program still holds), and the one of the launches that run the complete program, stand next to it:
-                "frac_without_structural_zero_flops": (ref_nonzero_tot / t_tot / 1e12 / PEAK_FP32_TFLOPS if not args.lite else None),
+                # `achieved` / `frac`: reference-formulation flops (4.55 MFLOP per edge and block for set-A) of the paths each launched program HOLDS.
+                # `frac_vs_reference_op_graph` credits every launch with the complete block -- incl. the flops the reference spends multiplying the structurally zero
+                # input irreps of the first layer and computing output irreps the read-out head never reads, which this build does not issue:
+                # a throughput-equivalent, NOT a utilisation.  `frac_full_program_launches`: the launches that run a complete program, alone.
+                "frac_vs_reference_op_graph": (ref_tot / t_tot / 1e12 / PEAK_FP32_TFLOPS if not args.lite else None),
                 "frac_full_program_launches": (REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / (sum(full_t) / max(1, len(full_t))) / 1e12 / PEAK_FP32_TFLOPS
                                                if full_t and not args.lite else None),
                 "launch_ms_by_position_in_step": [round(1e3 * sum(v) / len(v), 3) for _, v in sorted(per_kind.items())],
@@ -540,6 +571,31 @@ def main():
                     res["accuracy"] = json.loads(line[len("ACCURACY "):])
             except Exception as exc:
                 res["accuracy"] = {"rel_max": None, "mae": None, "sample": f"failed: {exc!r}"[:200]}
+        if world == 1 and not args.lite and not args.no_complete_pass:
+            # the like-for-like figure against the reference's op graph: the SAME model with every path of every block issued (HG_STRUCT_ZEROS=0 HG_DEAD_OUT=0:
+            # no structural-zero shortcut, no unread-irreps shortcut), recompiled and timed AFTER the timed region -- `value` is never this pass
+            prev_env = {k: os.environ.get(k) for k in ("HG_STRUCT_ZEROS", "HG_DEAD_OUT")}
+            os.environ["HG_STRUCT_ZEROS"], os.environ["HG_DEAD_OUT"] = "0", "0"
+            try:
+                model.declare_consumer(head)                     # (HG_DEAD_OUT=0: drops the declaration)
+                model.compile(dev)
+                nst = max(1, min(args.steps, 5))
+                step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(nst):
+                    step()
+                torch.cuda.synchronize()
+                dt_c = (time.perf_counter() - t1) / nst
+                res["value_complete_programs"] = E_total / dt_c
+                res["complete_programs"] = {"ms_per_step": dt_c * 1e3, "steps": nst, "what": "every path of the reference's op graph issued (HG_STRUCT_ZEROS=0 HG_DEAD_OUT=0), "
+                                            "same model and crystal, timed after the timed region"}
+            finally:
+                for k, v in prev_env.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
         if world == 1 and not args.no_cpu_baseline:
             import subprocess
             try:
@@ -559,6 +615,8 @@ if __name__ == "__main__":
     try:
         main()
     except BaseException as exc:                               # a rank that dies says who it was before the launcher tears the job down
+        if isinstance(exc, _LauncherExit):
+            raise
         if not isinstance(exc, SystemExit) or exc.code not in (0, None):
             print("BENCH_RANK_FAILURE " + json.dumps({"rank": os.environ.get("RANK", "0"), "local_rank": os.environ.get("LOCAL_RANK", "0"),
                                                       "world_size": os.environ.get("WORLD_SIZE", "1"), "error": repr(exc)[:500]}), file=sys.stderr, flush=True)

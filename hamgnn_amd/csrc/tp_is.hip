@@ -699,10 +699,10 @@ __device__ __forceinline__ void post_is(const IsArgs& A, const float* __restrict
 // phases / groups / items that feed them (plan.py:is_schedule(parts=...)).  One part = the whole program (large edge counts); several
 // parts spread ONE 16-edge tile's serial 34 k-MFMA pass over several workgroups when there are fewer tiles than CUs (small crystals).
 // part record, int32[16]: {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off (float offsets in the LDS),
-// copy_stride, rowtab_off, rowtab_begin, rowtab_len, lite, segment mask lo, hi, 0, 0}.  copy_stride > 0: each of the four waves accumulates
+// copy_stride, rowtab_off, rowtab_begin, rowtab_len, lite, 0, 0, 0, 0}.  copy_stride > 0: each of the four waves accumulates
 // into its own copy of the part's tiles (copy w at + w * copy_stride), so all waves can work on one output segment at once; the copies are
-// summed before the epilogue.  r5: several parts may share a segment range and split its PHASES (plan.is_schedule ("2d", P, K) / "phases"):
-// their segments are flagged SEG_ATOMIC, the epilogues add into zero-filled rows, [12] / [13] name the segments the part's phases feed.
+// summed before the epilogue.  r5: several parts may share a segment range and split its PHASES (plan.is_schedule ("2d", P, K); replayed hipGraphs only):
+// their segments are flagged SEG_ATOMIC, the epilogues add into zero-filled rows.
 #define IS_PART_I32 16
 
 template <bool SPLIT, bool LITE>
@@ -794,11 +794,11 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
         // Parts with private tile copies (split launches of small crystals): every item is its own group and the groups are DEALT, not claimed
         // (r6) -- group g0 + k * NW + w is the k-th of wave w (planner: LPT on its cost model) -- so the content of every copy, and with the
         // fixed fold below the launch's whole summation order, does not depend on which wave was faster: two forwards agree bit for bit
-        int gi_dealt = g0 + wave;
+        int gi_dealt = g0 + __builtin_amdgcn_readfirstlane(wave);      // (scalar: as a vector register it spilled in the <SPLIT, LITE> instantiation)
         while (true) {
             int gi = 0;
             if (SPLIT && copy_stride) {
-                gi = __builtin_amdgcn_readfirstlane(gi_dealt);
+                gi = gi_dealt;
                 gi_dealt += NW;
             } else {
                 if (lane == 0) gi = atomicAdd(ctr, 1);
@@ -885,10 +885,6 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
                 __syncthreads();
             }
         }
-        if constexpr (SPLIT) {                                 // phase parts (plan.is_schedule "phases"): a workgroup adds only the segments its phases fed
-            const int b_ = sg - seg0;
-            if (b_ < 64 && !(((b_ < 32 ? PT[12] : PT[13]) >> (b_ & 31)) & 1)) continue;
-        }
         const float* __restrict__ tile = lds + tile_off;
         const float* __restrict__ dst = stage + woff;
         switch (lk) {
@@ -923,15 +919,13 @@ extern "C" int hg_prof_is_read(unsigned long long* out16, int reset) {
 }
 #endif
 
-// Compile-time shape of the loaded library, for the host planner to check its own settings against (plan.IS_WAVES / IS_WAVES_LITE / LITE_SRING /
-// WIDE_WAVES are environment-tunable for A/B builds; a schedule dealt to 8 streams would be misread by a 4-wave kernel -- ADVICE r4).
-extern "C" int hg_wide_waves(void);                            // csrc/tp_wide.hip
+// Compile-time shape of the loaded library, for the host planner to check its own settings against (plan.IS_WAVES / IS_WAVES_LITE / LITE_SRING
+// are environment-tunable for A/B builds; a schedule dealt to 8 streams would be misread by a 4-wave kernel -- ADVICE r4).
 extern "C" int hg_build_config(int what) {
     switch (what) {
         case 0: return IS_NW;
         case 1: return IS_NW_LITE;
         case 2: return SL_RING;
-        case 3: return hg_wide_waves();
         default: return -1;
     }
 }

@@ -71,7 +71,9 @@ def export_tp_is(dp, path: str, rows: int) -> dict:
     """tables of the hg_tp_is launch `ops.tp_fused(dp, ..., rows)` would make (dp: ops.DeviceProgram with an input-stationary schedule)"""
     parts = dp.is_parts_for(rows)
     sc = dp.is_tables(parts)[0]
-    w = dp.prog.weights if sc.extra_weights is None else np.concatenate([dp.prog.weights, sc.extra_weights])
+    # the blob the launch READS: the device copy (after nn.MessagePackBlock.refresh -- the device-side repack that follows an optimiser step -- only that one is
+    # current; dp.prog.weights is the host blob of compile time: ADVICE r5), with the schedule's own streams behind it
+    w = dp.is_weights(parts).detach().cpu().numpy()
     scalars = {"entry": "hg_tp_is", "hidden": int(dp.hidden), "out_dim": int(dp.out_dim), "lds_bytes": int(sc.lds_floats * 4), "nparts": int(sc.part_table.shape[0]),
                "zero_fill_out": bool(getattr(sc, "atomic_out", False)), "rows_planned_for": int(rows)}
     return write_container(path, tp_is_arrays(dp.prog, sc, w), scalars)

@@ -371,8 +371,7 @@ class HamGNNConvE3(_BackboneBase):
             for c in self.corr_products:
                 c.compile(dev)                                 # four Linear tables + the concatenated element weights (host, ~ms)
         for conv, pair in zip(self.convolutions, self.pair_interactions):
-            conv.residual.linear1.compile(dev)                 # (not residual.compile: its gate tables are structural)
-            conv.residual.linear2.compile(dev)
+            conv.residual.refresh(dev)                         # (its two Linears + the cached fused chain; the gate tables are structural)
             conv.skip_linear.compile(dev)
             if not conv.conv_tp.refresh():
                 conv.conv_tp.compile(dev, unrotate=True)

@@ -465,7 +465,7 @@ class MessagePackBlock(nn.Module):
         irreps marked by set_dead_outputs (they come back as zeros): the reduced program"""
         z = structural_zeros and getattr(self, "_dp_z", None) is not None
         dp = self._dp_z if z else self._dp
-        if getattr(self, "_plain_args", None) is None or dp.is_parts_for(rows) in (1, "phases"):     # (phase parts hold all tiles per workgroup: the merged program)
+        if getattr(self, "_plain_args", None) is None or dp.is_parts_for(rows) == 1:
             return dp
         slot = "_dp_z_plain" if z else "_dp_plain"
         if getattr(self, slot, None) is None:
@@ -626,6 +626,13 @@ class ResidualBlock(nn.Module):
         self._rowprog_off = getattr(self, "_rowprog_off", False)   # set by training._invalidate: separate kernels while the weights move
         return self
 
+    def refresh(self, device):
+        """after an optimiser step: the two Linears' tables rebuilt on the host (the gate tables are structural) and the cached fused chain DROPPED -- it was
+        built from the weights of its moment, so validate -> step -> validate ran the pre-step weights through it"""
+        self.linear1.compile(device)
+        self.linear2.compile(device)
+        self._rowprog = None
+
     def _row_program(self, device):
         """Linear1 -> Gate -> Linear2 (+ x) as ONE row program (csrc/rowprog.hip; late r5: the node-level chain of a ConvBlock is launch-bound on small
         crystals -- three launches become one), or False (HG_ROWPROG=0 / HG_NODE_ROWPROG=0, "norm" activation, no kernel form, weights moving)"""
@@ -722,9 +729,9 @@ class AttentionBlockE3(nn.Module):
     def refresh(self, device):
         """after an optimiser step: the Linear tables and the cutoff parameter on the host (< 1 ms each), the value block's programs on
         the device (hamgnn_amd/repack.py)"""
-        for m in (self.linear_up_src, self.linear_up_tar, self.linear_up_edge, self.residual.linear1, self.residual.linear2, self.linear_key,
-                  self.skip_linear):
+        for m in (self.linear_up_src, self.linear_up_tar, self.linear_up_edge, self.linear_key, self.skip_linear):
             m.compile(device)
+        self.residual.refresh(device)
         if not self.conv_tp_value.refresh():
             self.conv_tp_value.compile(device, unrotate=True)
         self._cut = self.cutoff_func.cut_param.detach().float().reshape(1).contiguous().to(device)

@@ -65,11 +65,8 @@ def _require_gpu(t: torch.Tensor):
         raise RuntimeError("hamgnn_amd: the MI355X hot path needs CUDA(ROCm) tensors; there is no CPU fallback")
 
 
-# the wide schedule (csrc/tp_wide.hip, r5) is an opt-in experiment: measured 8.5 ms against hg_tp_is's 6.8 ms per 131 072-edge set-A launch (profiles/r05_tp_wide.md)
-WIDE_MODE = os.environ.get("HG_MP_WIDE", "0")             # "0": never (default), "1": launches with >= WIDE_MIN_TILES 16-edge tiles, "force": whenever the program has a wide form
-WIDE_MIN_TILES = int(os.environ.get("HG_WIDE_MIN_TILES", "512"))
 REPLAY_SPLIT = False         # set by graph_capture.CapturedForward while it warms up and captures: launches of the smallest crystals take the finer 2d split
-PHASE_PARTS_TILES = int(os.environ.get("HG_PHASE_PARTS_TILES", "1024"))      # phase parts while tiles x 16 workgroups stay below this (two rounds of the chip's 512 slots)
+REPLAY_SPLIT_TILES = int(os.environ.get("HG_REPLAY_SPLIT_TILES", "1024"))    # the 2d split while tiles x segments x phase shares stay below this (two rounds of the chip's 512 slots)
 
 
 _BUILD_CONFIG_OK = False
@@ -82,7 +79,7 @@ def check_build_config():
     if _BUILD_CONFIG_OK:
         return
     L = lib()
-    want = {0: ("HG_IS_WAVES", P.IS_WAVES), 1: ("HG_LITE_WAVES", P.IS_WAVES_LITE), 2: ("HG_LITE_SRING", P.LITE_SRING), 3: ("HG_WIDE_WAVES", P.WIDE_WAVES)}
+    want = {0: ("HG_IS_WAVES", P.IS_WAVES), 1: ("HG_LITE_WAVES", P.IS_WAVES_LITE), 2: ("HG_LITE_SRING", P.LITE_SRING)}
     for what, (name, val) in want.items():
         got = int(L.hg_build_config(what))
         if got != int(val):
@@ -111,8 +108,6 @@ class DeviceProgram:
         self._device = device
         self._is_tables = {}                                   # parts -> (IsSchedule, device tables)
         self._is_weights = {}                                  # parts -> weight blob with the schedule's own streams appended (lite_mode runs)
-        self._wide = None                                      # (WideSchedule, device tables, host layout array) or False: no wide form (csrc/tp_wide.hip)
-        self._wide_weights = None
         if prog.vsegs and schedule not in ("is", "is_parts"):
             raise ValueError("a program with merged items runs on the input-stationary kernel only")
         self.fixed_parts = None                                # "lds": the tiles of all output segments need several workgroups per 16 edges
@@ -129,7 +124,6 @@ class DeviceProgram:
     def weights_changed(self):
         """after the packed weight blob was rewritten in place (nn.MessagePackBlock.refresh): rebuild what is derived from it"""
         self._is_weights.clear()                               # (lite programs are recompiled, not refreshed; kept consistent anyway)
-        self._wide_weights = None                              # (the schedule's coefficient blocks ride behind the refreshed blob)
         self._is_tables = {k: v for k, v in self._is_tables.items() if v[0].extra_weights is None}
 
     def is_tables(self, parts):
@@ -142,47 +136,9 @@ class DeviceProgram:
                 self._is_weights[parts] = torch.cat([self.weights, _dev(sc.extra_weights, self._device, torch.float32)])
         return self._is_tables[parts]
 
-    def wide_tables(self):
-        """(WideSchedule, device tables, host layout) of csrc/tp_wide.hip for this program, or None when it has no wide form"""
-        if self._wide is None:
-            try:
-                ws = P.wide_schedule(self.prog)
-                lay = ws.lay
-                host = np.ascontiguousarray(np.asarray([ws.seg_table.shape[0], ws.nphase, lay["trash_off"], lay["rowtab_off"], len(ws.rowtab), lay["stage_off"],
-                                                        lay["stage_floats"], lay["sbuf_off"], lay["sbuf_slots"], lay["flag_off"], lay["ctr_off"], lay["lds_floats"], lay.get("own", 0), 0, 0, 0], np.int32))
-                self._wide = (ws, tuple(_dev(t, self._device) for t in (ws.seg_table, ws.block_table, ws.stream_table, ws.rec_table, ws.rowtab)), host)
-            except NotImplementedError:
-                self._wide = False
-        return self._wide or None
-
-    def wide_weights(self) -> torch.Tensor:
-        if self._wide_weights is None:
-            self._wide_weights = torch.cat([self.weights, _dev(self._wide[0].extra_weights, self._device, torch.float32)])
-        return self._wide_weights
-
-    def use_wide(self, rows: int, gather, res) -> bool:
-        """large single-part launches of tensor-product programs take the wide schedule (one 16-wave workgroup per CU); HG_MP_WIDE=0 restores hg_tp_is"""
-        if self.sched is None or self.fixed_parts is not None or res or WIDE_MODE == "0":
-            return False
-        if int(self.sched.part_table[0][11]) or self.is_parts_for(rows) != 1:
-            return False
-        if WIDE_MODE != "force" and (rows + 15) // 16 < WIDE_MIN_TILES:
-            return False
-        return self.wide_tables() is not None
-
     def is_weights(self, parts) -> torch.Tensor:
         """the weight blob a launch with `parts` sub-schedules reads"""
         return self._is_weights.get(parts, self.weights)
-
-    def phase_parts_ok(self) -> bool:
-        """the program has a phase-parts schedule (plan.is_schedule "phases": not lite_mode, <= 64 segments, everything fits one workgroup's LDS)"""
-        if getattr(self, "_phase_ok", None) is None:
-            try:
-                self.is_tables("phases")
-                self._phase_ok = True
-            except NotImplementedError:
-                self._phase_ok = False
-        return self._phase_ok
 
     def is_parts_for(self, rows: int) -> int:
         """How many workgroups share one 16-edge tile.  The chip holds 512 workgroups of this kernel (2 per CU); a launch with fewer
@@ -195,11 +151,11 @@ class DeviceProgram:
             return max(1, int(forced))
         tiles = (rows + 15) // 16
         nseg = int(self.prog.seg_table.shape[0])
-        mode = os.environ.get("HG_PHASE_PARTS", "2d4" if REPLAY_SPLIT else "0")      # eager: off (measured: no gain on a host-bound path); under graph capture: "2d4"
-        if mode == "1" and tiles * P.PHASE_PARTS_MAX <= PHASE_PARTS_TILES and self.phase_parts_ok():
-            return "phases"                                    # the PHASES of a tile on separate workgroups, every workgroup holds all tiles
-        if mode.startswith("2d") and tiles * nseg * int(mode[2:] or 3) <= PHASE_PARTS_TILES and not int(self.sched.part_table[0][11]):
-            return ("2d", nseg, int(mode[2:] or 3))            # one workgroup per (output segment, third of its phases)
+        # under hipGraph capture only (graph_capture.CapturedForward; HG_REPLAY_SPLIT = "2d<K>" forces it, "0" forbids it): one workgroup per (output segment,
+        # K-th of its phases), tiles ADDED into zero-filled rows -- the one schedule without a fixed summation order, hence never the eager default
+        mode = os.environ.get("HG_REPLAY_SPLIT", "2d4" if REPLAY_SPLIT else "0")
+        if mode.startswith("2d") and tiles * nseg * int(mode[2:] or 3) <= REPLAY_SPLIT_TILES and not int(self.sched.part_table[0][11]):
+            return ("2d", nseg, int(mode[2:] or 3))
         if tiles * nseg <= 512:
             return nseg
         if tiles <= 300 and nseg >= 8:
@@ -471,7 +427,7 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         assert r.shape == (rows, dp.out_dim) and r.stride(1) == 1
     assert reduce is None or (dp.sched is not None and dp.is_parts_for(rows) == 1)
     parts_ = dp.is_parts_for(rows) if (dp.sched is not None and reduce is None) else 1
-    alloc = torch.zeros if (parts_ == "phases" or isinstance(parts_, tuple)) else torch.empty  # (phase parts ADD their tiles into zero-filled rows: plan.is_schedule "phases" / "2d")
+    alloc = torch.zeros if isinstance(parts_, tuple) else torch.empty  # (the 2d split ADDS its tiles into zero-filled rows: plan.is_schedule ("2d", P, K))
     out = alloc(rows if reduce is None else reduce[2], dp.out_dim, device=srcs[0].device, dtype=torch.float32)      # the kernel writes every slot incl. zero channel padding
     n = len(srcs)
     sp = (C.c_void_p * 4)(*([s.data_ptr() for s in srcs] + [0] * (4 - n)))
@@ -482,15 +438,7 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     if dp.sched is not None:
         check_build_config()
-    if dp.sched is not None and dp.use_wide(rows, gather, res):
-        ws, (t_segs, t_blocks, t_streams, t_recs, t_rowtab), lay_host = dp.wide_tables()
-        gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
-        gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
-        check(lib().hg_tp_wide(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.wide_weights()), ptr(t_segs), ptr(t_blocks),
-                               ptr(t_streams), ptr(t_recs), ptr(t_rowtab), lay_host.ctypes.data_as(C.c_void_p), gp, i32(rot_mask),
-                               ptr(reduce[0]) if reduce is not None else C.c_void_p(0), ptr(reduce[1]) if reduce is not None else C.c_void_p(0),
-                               ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_wide")
-    elif dp.sched is not None:
+    if dp.sched is not None:
         sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts, t_rowtab) = dp.is_tables(dp.is_parts_for(rows))
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])

@@ -232,7 +232,7 @@ class IsSchedule:
 
 
 SEG_NEWBATCH = 1 << 16             # IS epilogue: this segment starts a new Wigner staging batch
-IS_PART_I32 = 16                   # [12], [13]: bit s = the part's phases feed its s-th segment (SEG_ATOMIC parts skip the epilogue of the others)
+IS_PART_I32 = 16                   # [12..15] unused (r5's phase-parts experiment kept a segment mask there; removed in r6, the record size stays)
 
 
 def _item_rto(rec, segs, vsegs=()):
@@ -296,15 +296,10 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
     parts > 1: the output segments are split into `parts` sets of equal estimated cost (LPT); each set gets its own sub-schedule
     (tiles, phases, groups) and runs in its own workgroup (grid.y) -- the per-tile latency drops at the price of staging the input
     blocks once per part.  Used when a launch has fewer 16-edge tiles than the chip has workgroup slots.
-    parts = "phases" (late r5, the smallest crystals): ONE sub-schedule of all segments whose PHASES are dealt to the workgroups of a tile -- every
-    workgroup holds all tiles, stages the input blocks of its one or two phases, runs their items and ADDS its tiles to zero-filled rows (all segments
-    SEG_ATOMIC; the part record's mask names the segments its phases feed).  The launch then takes one phase + one epilogue instead of all phases in a row
-    (set-A, Si 2-atom cell: 12 phases at ~5 us each).  The order of the adds is not fixed: sums differ between runs at fp32 rounding level (as the split
-    launches' private tile copies already do).
+    parts = ("2d", P, K) (late r5, replayed hipGraphs of the smallest crystals only: graph_capture.CapturedForward): the P segment sets of a split launch,
+    each on K workgroups that take a share of the set's PHASES and ADD their tiles into zero-filled rows (segments flagged SEG_ATOMIC).  The order of those
+    adds is NOT fixed -- the one schedule whose sums may differ between runs at fp32 rounding level; every other launch has one summation order (r6).
     separate_mlp: a phase only stages blocks whose tensor-product items use ONE radial weight generator (IsSchedule.phase_cls)."""
-    # parts = ("2d", P, K): the P segment sets of a split launch, each on K workgroups that take a share of the set's PHASES and add their tiles (SEG_ATOMIC)
-    if parts == "phases":
-        return _is_schedule_phases(prog)
     phase_chunks = 1
     if isinstance(parts, tuple):
         assert parts[0] == "2d"
@@ -398,513 +393,6 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
                       np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)), np.asarray(rowtab_all, np.int32),
                       lds_floats, worst_balance, part_cost, phase_cls_all,
                       extra_weights=(np.concatenate(runs["w"]) if runs is not None and runs["w"] else None), atomic_out=atomic_any)
-
-
-PHASE_PARTS_MAX = 16
-
-
-def _is_schedule_phases(prog: "Program") -> IsSchedule:
-    """is_schedule(prog, "phases"): see there"""
-    if np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any():
-        raise NotImplementedError("phase parts: lite_mode programs end with a post-op on the complete tiles")
-    hp4 = prog.hidden_pad // 4
-    nseg = prog.seg_table.shape[0]
-    if nseg > 64:
-        raise NotImplementedError("phase parts: more than 64 output segments")
-    sub = _is_schedule_part(prog, list(range(nseg)), hp4, 0, 0, 0, 0, split=False, separate_mlp=False, waves=IS_WAVES)
-    nph = len(sub["ptab"])
-    K = max(1, min(nph, PHASE_PARTS_MAX))
-    bins: List[List[int]] = [[] for _ in range(K)]
-    load = [0] * K
-    for ph in sorted(range(nph), key=lambda p_: -sub["phase_crit"][p_]):       # LPT on the phases' critical paths (+ a constant per phase: staging, barriers)
-        b = min(range(K), key=lambda q: (load[q], q))
-        bins[b].append(ph)
-        load[b] += sub["phase_crit"][ph] + 150
-    bins = [b for b in bins if b]
-    segs = sub["segs"].copy()
-    segs[:, 7] |= SEG_ATOMIC
-    local_of = {int(old): int(new) for old, new in sub["remap"].items()}        # program segment -> position in the schedule's segment table
-    ptab, parttab, cls = [], [], []
-    for b in bins:
-        mask = 0
-        for ph in b:
-            for sg in sub["phase_touch"][ph]:
-                mask |= 1 << local_of[sg]
-        parttab.append([0, nseg, len(ptab), len(b), sub["trash_off"], sub["stage_off"], sub["ctr_off"], 0, sub["rowtab_off"], 0, len(sub["rowtab"]), 0,
-                        int(np.int32(np.uint32(mask & 0xffffffff))), int(np.int32(np.uint32((mask >> 32) & 0xffffffff))), 0, 0])
-        for ph in b:
-            ptab.append(sub["ptab"][ph])
-            cls.append(sub["phase_cls"][ph])
-    sc = IsSchedule(segs.astype(np.int32).reshape(-1, SEG_I32), np.asarray(sub["btab"], np.int32).reshape(-1, IS_BLOCK_I32),
-                    np.asarray(ptab, np.int32).reshape(-1, IS_PHASE_I32), np.asarray(sub["gtab"], np.int32).reshape(-1, 2),
-                    np.asarray(sub["items"], np.int32).reshape(-1, IS_ITEM_I32), np.ascontiguousarray(np.asarray(parttab, np.int32).reshape(-1, IS_PART_I32)),
-                    np.asarray(sub["rowtab"], np.int32), sub["ctr_off"] + 4, sub["balance"], [int(x) for x in load[:len(bins)]], cls)
-    sc.atomic_out = True
-    return sc
-
-
-# ---- wide schedule (csrc/tp_wide.hip, r5): ONE workgroup of WIDE_WAVES waves per CU on one 16-edge tile -----------------------------------------
-# Why: the input-stationary kernel keeps 56 KB of output tiles + 19 KB of staged rows per 16 edges in LDS, so a CU holds two tiles, and a tile offers only as
-# many conflict-free work groups per phase as it has output segments (8 after merging) -- ~8 busy waves per CU, the matrix pipe 50 % busy for four rounds
-# (profiles/r04_tp_is_experiments.md).  Column windows of an item ARE conflict-free, but each would recompute the item's radial scale S = W3^T h (27 % of all
-# MFMAs: + 21 ... 50 %, measured on paper in profiles/r05_tp_wide.md).  Here the LDS of the whole CU belongs to one tile: S fragments are produced ONCE per
-# item by "S tasks" into an LDS buffer and read by the item's column-window tasks, the staging area is double-buffered (the next phase's rows are gathered /
-# rotated by tasks of THIS phase's pool), and 16 waves (four per SIMD, <= 128 VGPRs) claim the tasks of a phase from one ordered list:
-#     pool(ph) = [staging tasks of phase ph + 1 | S tasks of phase ph | compute tasks of phase ph, largest first]      one barrier per phase
-# A compute task waits for its item's S through a flag in LDS (its producer was claimed earlier in the same list and never waits: no deadlock).
-WIDE_WAVES = int(os.environ.get("HG_WIDE_WAVES", "16"))   # = WD_NW of csrc/tp_wide.hip
-WIDE_LDS_BYTES = 160 * 1024
-WIDE_TASK_I32 = 32                                        # logical record (planner, emulator)
-WIDE_REC_I32 = 16                                         # packed device record: ONE s_load_dwordx16 (wide_pack_record)
-WT_STAGE, WT_S, WT_COMPUTE, WT_WAIT, WT_SIGNAL = 0, 1, 2, 3, 4
-WIDE_MODE_SCHED = os.environ.get("HG_WIDE_SCHED", "pools")   # "pools": one barrier per phase, the phase's work dealt to the waves per pool; "own": every wave OWNS fixed
-#                                                            (segment key, column window) cells for the whole tile, no barriers between phases (counters in LDS)
-WIDE_COUNTERS = 192                                       # own mode: done[phase] at + 0, staged[phase] at + 64 (ints behind the flags)
-WIDE_COST_REC = float(os.environ.get("HG_WIDE_COST_REC", "24"))      # cost model of the static streams, in MFMA slots: per record,
-WIDE_COST_STAGE = float(os.environ.get("HG_WIDE_COST_STAGE", "60"))  # per staging share (latency-bound: gathered node rows)
-WIDE_STAGE_POS = os.environ.get("HG_WIDE_STAGE_POS", "end")          # where a wave's staging shares sit in its stream: "end" (under the other waves' compute tails) / "begin"
-WIDE_ACC_CAP = int(os.environ.get("HG_WIDE_ACC_CAP", "10"))    # accumulator fragments (row tiles x columns) of a compute task: 40 VGPRs
-WIDE_NCW_MAX = 7                                          # column-window instantiations of csrc/tp_wide.hip (WD_CASE)
-WIDE_TASKS_PER_WAVE = float(os.environ.get("HG_WIDE_TPW", "1.0"))   # compute tasks per wave and phase the splitting aims for
-WIDE_FLAGS = 128                                          # S-ready flags (items of one phase)
-
-
-def wide_ncw_cap(rtm: int) -> int:
-    return max(1, min(WIDE_NCW_MAX, WIDE_ACC_CAP // rtm))
-
-
-@dataclass
-class WideSchedule:
-    seg_table: np.ndarray          # as IsSchedule.seg_table (epilogue)
-    block_table: np.ndarray        # as IsSchedule.block_table (stage offsets relative to a staging buffer)
-    phase_blocks: np.ndarray       # int32[nphase][2] = {block_begin, block_end}
-    stream_table: np.ndarray       # int32[nphase + 1][WIDE_WAVES][2] = {record_begin, record_end}: the records wave w runs in pool p, back to back (static LPT deal:
-    #                                the wave knows its next record's address, so records and first fragments are requested ahead).  Pool 0 = the staging shares
-    #                                of phase 0 (prologue), pool ph + 1 = [S tasks of ph | compute chains of ph | staging shares of ph + 1] per wave
-    chain_table: np.ndarray        # int32[nchain][3] = {record_begin, record_end, pool}: a staging share, an S task, or a compute chain (records of one wave)
-    task_table: np.ndarray         # int32[nrec][32] logical records, see wide_schedule
-    rec_table: np.ndarray          # int32[nrec][16] the same records packed for the device (wide_pack_record)
-    item_table: np.ndarray         # the IS item records the tasks were cut from (emulator / tests)
-    rowtab: np.ndarray
-    extra_weights: np.ndarray      # per-task packed CG coefficient blocks, appended to Program.weights on the device
-    lay: Dict[str, int]            # LDS float offsets: trash_off, rowtab_off, stage_off (buffer b at + b * stage_floats), stage_floats, sbuf_off, sbuf_slots,
-    #                                flag_off, ctr_off, lds_floats
-    nphase: int
-    balance: float                 # LPT estimate over WIDE_WAVES waves (compute + S tasks), like IsSchedule.balance
-    crit: float                    # estimated critical path (MFMA slots per wave, summed over the phases)
-    mfma_tasks: int                # MFMAs the tasks issue per 16 edges (= the program's: nothing is recomputed)
-
-
-def _wide_group_windows(recs, col_cost, target: float) -> List[Tuple[int, int]]:
-    """column windows [m_lo, m_hi] of one work group (= all items of one (phase, output segment key)): contiguous in m, together all columns any item
-    touches, balanced by the items' per-column cost, as many as the group's cost asks for (cost / target, at most one per column)"""
-    M = max(int(r[6]) for r in recs)
-    cm = []
-    for m in range(-M, M + 1):
-        c = 0.0
-        for r in recs:
-            mm = int(r[6])
-            if abs(m) <= mm and not (m == 0 and int(r[0]) == IT_TP and int(r[7]) and mm > 0):
-                c += col_cost(r)
-        cm.append(c)
-    tot = sum(cm)
-    nwin = int(max(1, min(2 * M + 1, round(tot / target))))
-    out, lo, acc, done = [], -M, 0.0, 0
-    for i, m in enumerate(range(-M, M + 1)):
-        acc += cm[i]
-        left_cols = M - m                                       # columns after m
-        left_wins = nwin - len(out) - 1                         # windows still to open after the current one
-        if left_wins > 0 and (acc >= (len(out) + 1) * tot / nwin - 1e-9 or left_cols <= left_wins) and left_cols >= left_wins:
-            out.append((lo, m))
-            lo = m + 1
-    out.append((lo, M))
-    return out
-
-
-def wide_pack_record(rec) -> List[int]:
-    """logical record (32 ints, see wide_schedule) -> the 16 ints the kernel reads with one scalar load:
-    w0 = kind | rtm << 2 | ncw << 5 | (typ / radial generator / staging buffer) << 8 | x4 << 9 | neg << 10 | l << 11 | mm << 14 | rto << 17 | nk2 << 21 | c0 << 26
-    w1 = stage offset of source 0 / block / W3 fragments   w2 = stage offset of source 1 (-1) / share   w3 = in_mulp | ksteps << 16 / shares
-    w4 = A1 fragments   w5 = packed coefficients   w6 = A2 fragments   w7 = first S slot | flag << 16   w8 = first output row (IT_LIN)   w9 = row-table base"""
-    kind = int(rec[0])
-    w = [0] * WIDE_REC_I32
-    if kind in (WT_WAIT, WT_SIGNAL):                           # own mode: w1 = counter (int index behind ctr_off), w2 = value to wait for / 1: drain the vector-memory queue first
-        w[0] = 3 | ((1 << 2) if kind == WT_SIGNAL else 0)      # (the kind field has two bits: 3 = synchronisation record, bit 2 set = signal)
-        w[1], w[2] = int(rec[1]), int(rec[2])
-    elif kind == WT_STAGE:
-        w[0] = kind | (int(rec[5]) << 8) | (int(rec[4]) << 11)
-        w[1], w[2], w[3] = int(rec[1]), int(rec[2]), int(rec[3])
-    elif kind == WT_S:
-        assert 1 <= int(rec[2]) <= 4 and int(rec[4]) < (1 << 16) and int(rec[5]) < (1 << 15)
-        w[0] = kind | (int(rec[2]) << 2) | (int(rec[3]) << 8)
-        w[1] = int(rec[1])
-        w[7] = int(rec[4]) | (int(rec[5]) << 16)
-        w[10] = int(rec[6])                                    # stamp the flag takes
-    else:
-        rtm, ncw, typ, x4, neg, li, mm, rto, nk2, c0 = (int(rec[k]) for k in (9, 15, 19, 17, 7, 5, 6, 22, 18, 13))
-        assert 1 <= rtm <= 4 and 1 <= ncw <= 7 and typ in (0, 1) and li < 8 and mm < 8 and rto < 16 and nk2 < 32 and c0 < 16
-        w[0] = kind | (rtm << 2) | (ncw << 5) | (typ << 8) | ((1 if x4 else 0) << 9) | ((1 if neg else 0) << 10) | (li << 11) | (mm << 14) | (rto << 17) | (nk2 << 21) | (c0 << 26)
-        assert int(rec[4]) < (1 << 16) and int(rec[8]) < (1 << 15)
-        w[1], w[2], w[3] = int(rec[1]), int(rec[2]), int(rec[4]) | (int(rec[8]) << 16)
-        w[4], w[5], w[6] = int(rec[11]), int(rec[12]), int(rec[14])
-        slot = int(rec[3]) if int(rec[3]) >= 0 else 0
-        assert slot < (1 << 16) and int(rec[10]) < (1 << 15)
-        w[7] = slot | (int(rec[10]) << 16)
-        w[8], w[9] = int(rec[16]), int(rec[23])
-        w[10] = int(rec[20])                                   # stamp the item's S flag carries when its fragments are there
-    assert all(-(1 << 31) <= v < (1 << 31) for v in w)
-    return w
-
-
-def wide_unpack_record(w) -> List[int]:
-    """inverse of wide_pack_record (tests: the device format carries every field the emulator's logical record has)"""
-    w = [int(v) for v in w]
-    kind = w[0] & 3
-    rec = [0] * WIDE_TASK_I32
-    if kind == 3:
-        rec[0] = WT_SIGNAL if (w[0] >> 2) & 1 else WT_WAIT
-        rec[1], rec[2] = w[1], w[2]
-        return rec
-    rec[0] = kind
-    if kind == WT_STAGE:
-        rec[1], rec[2], rec[3], rec[4], rec[5] = w[1], w[2], w[3], (w[0] >> 11) & 7, (w[0] >> 8) & 1
-    elif kind == WT_S:
-        rec[1], rec[2], rec[3], rec[4], rec[5], rec[6] = w[1], (w[0] >> 2) & 7, (w[0] >> 8) & 1, w[7] & 0xffff, w[7] >> 16, w[10]
-    else:
-        rec[9], rec[15], rec[19], rec[17], rec[7] = (w[0] >> 2) & 7, (w[0] >> 5) & 7, (w[0] >> 8) & 1, (w[0] >> 9) & 1, (w[0] >> 10) & 1
-        rec[5], rec[6], rec[22], rec[18], rec[13] = (w[0] >> 11) & 7, (w[0] >> 14) & 7, (w[0] >> 17) & 15, (w[0] >> 21) & 31, (w[0] >> 26) & 15
-        rec[1], rec[2], rec[4], rec[8] = w[1], w[2], w[3] & 0xffff, w[3] >> 16
-        rec[11], rec[12], rec[14] = w[4], w[5], w[6]
-        rec[3], rec[10] = (w[7] & 0xffff) if rec[19] == IT_TP else -1, w[7] >> 16
-        rec[16], rec[23], rec[20] = w[8], w[9], w[10]
-    return rec
-
-
-def wide_schedule(prog: "Program", mode: Optional[str] = None) -> WideSchedule:
-    """Cut a finalized tensor-product program into the per-wave record streams of csrc/tp_wide.hip.  Raises NotImplementedError when the program has no wide
-    form (lite_mode items, tiles + two staging buffers + a useful S buffer beyond the CU's LDS).
-    A tile cell (row of an output segment, column m) may be updated by ONE wave per phase (read-modify-write in LDS), and several items of a phase feed the
-    same segment: the unit of compute work is therefore a CHAIN = all items of one (phase, segment key) restricted to a window of columns m, run one after
-    the other by one wave.  An item whose share of the window exceeds the register budget (wide_ncw_cap), or straddles the centre column an odd item
-    skips, appears as several records of the chain.
-    mode "pools" (default): the chains, S tasks and staging shares of a phase are dealt to the waves by LPT on a cost model (MFMAs + WIDE_COST_REC per record;
-    WIDE_COST_STAGE per staging share); a wave's stream of the pool is [its S tasks | its compute chains | its staging shares of the next phase]; one workgroup barrier
-    per phase.  S tasks never wait, so a compute record that waits for another wave's S fragments cannot deadlock.
-    mode "own": the column windows of a segment key are FIXED for the whole tile and every window belongs to one wave (LPT on its cost over all phases), so no tile
-    cell is ever touched by two waves and the phases need no barrier: a wave's stream for the whole tile is, phase by phase,
-        [wait done[p-2] == W] its S tasks of p (S buffer p & 1)  [wait staged[p] == n_p] its compute records of p  [signal done[p]]
-        [wait done[p-1] == W] its staging shares of p + 1 (staging buffer (p + 1) & 1)  [drain + signal staged[p+1]]
-    with monotonic counters in LDS (WT_WAIT / WT_SIGNAL records): the waves drift by up to a phase or two and only their TOTAL loads have to balance.  Every wait
-    points at records of earlier phases of other streams: no cycle.  The S buffer and the S flags are double-buffered by phase parity.
-    Logical record (int32[32]), [0] = kind.  WT_STAGE: [1] block, [2] share, [3] shares, [4] l of the block, [5] staging buffer.  WT_S: [1] float offset of
-    the item's W3 fragments, [2] row tiles, [3] radial generator, [4] first S slot, [5] flag, [6] stamp.  WT_COMPUTE: the item's record fields at their IS positions
-    ([1], [2] stage offsets incl. the buffer, [4..9], [11], [14], [16..18], [22], [23]) and [3] first S slot, [10] flag, [12] float offset of the record's
-    packed CG coefficients, [13] first real column, [15] columns, [19] item type, [20] stamp of the S flag.  WT_WAIT / WT_SIGNAL: [1] counter, [2] value / drain."""
-    mode = mode or WIDE_MODE_SCHED
-    assert mode in ("pools", "own")
-    own = mode == "own"
-    hp4 = prog.hidden_pad // 4
-    if np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST, IT_STREAM)).any():
-        raise NotImplementedError("wide schedule: lite_mode programs run on the input-stationary kernel")
-    if prog.hidden_pad > 64 and (prog.item_table[:, 0] == IT_TP).any():
-        raise NotImplementedError("wide schedule: radial hidden layers wider than 64")
-    nseg = prog.seg_table.shape[0]
-    members = list(range(nseg))
-    probe = _is_schedule_part(prog, members, hp4, 0, 0, 0, 0, waves=WIDE_WAVES, stage_floats_fixed=1 << 28)
-    base = int(probe["stage_off"])                               # tiles + trash row + row table
-    need = max(int(b[5]) * ceil_div((2 * int(b[4]) + 1) * (int(b[3]) // 4), 4) * 256 for b in probe["btab"])
-    total = WIDE_LDS_BYTES // 4
-    sf = need
-    nflag = 2 * WIDE_FLAGS if own else WIDE_FLAGS
-    nctr = WIDE_COUNTERS if own else 64
-    slots = (total - base - 2 * sf - nflag - nctr) // 256
-    if own:
-        slots -= slots % 2
-    cap_slots = slots // 2 if own else slots                    # row tiles of scales one phase may hold
-    if cap_slots < 8:
-        raise NotImplementedError("wide schedule: the output tiles and two staging buffers leave no room for the radial-scale buffer")
-    sub = _is_schedule_part(prog, members, hp4, 0, 0, 0, 0, waves=WIDE_WAVES, stage_floats_fixed=sf, srt_cap=cap_slots, wig_floats=2 * sf + 256 * slots)
-    assert int(sub["stage_off"]) == base and not sub["copy_stride"]
-    items = sub["items"]                                        # IS item records, phase by phase, work group by work group
-    ptab, gtab = sub["ptab"], sub["gtab"]
-    nphase = len(ptab)
-    stage_off = base
-    sbuf_off = stage_off + 2 * sf
-    flag_off = sbuf_off + slots * 256
-    ctr_off = flag_off + nflag
-    lay = dict(trash_off=int(sub["trash_off"]), rowtab_off=int(sub["rowtab_off"]), stage_off=stage_off, stage_floats=sf, sbuf_off=sbuf_off, sbuf_slots=slots,
-               flag_off=flag_off, ctr_off=ctr_off, lds_floats=ctr_off + nctr, own=int(own))
-    assert lay["lds_floats"] <= total
-    if nphase + 1 > 64:
-        raise NotImplementedError("wide schedule: more than 63 phases")
-    wts = prog.weights
-    extra: List[np.ndarray] = []
-    xbase = int(wts.size)
-    xoff = 0
-    W = WIDE_WAVES
-
-    def stage_units(ph: int):
-        out = []
-        b0, b1 = int(ptab[ph][0]), int(ptab[ph][1])
-        for b in range(b0, b1):
-            s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in sub["btab"][b])
-            pieces = (2 * li + 1) * (in_mulp // 4)
-            steps = ceil_div(pieces, 4)                         # one step = four pieces (one per 16-lane row) of every source
-            per = 2 if li <= 1 else 1                           # steps per share: a step of a rotated block holds 2 (2 l + 1) float4 loads per lane
-            nsub = ceil_div(steps, per)
-            for t in range(nsub):
-                rec = [0] * WIDE_TASK_I32
-                rec[0], rec[1], rec[2], rec[3], rec[4], rec[5] = WT_STAGE, b, t, nsub, li, ph & 1
-                out.append((WIDE_COST_STAGE, [rec]))
-        return out
-
-    def col_cost(r):
-        nsrc = 2 if int(r[2]) >= 0 else 1
-        return nsrc * int(r[8]) * int(r[9]) + (int(r[22]) * int(r[18]) if int(r[0]) == IT_TP else 0)
-
-    def ncols(r):
-        mm = int(r[6])
-        return 2 * mm if (int(r[0]) == IT_TP and int(r[7]) and mm > 0) else 2 * mm + 1
-
-    def col_has(r, m):
-        mm = int(r[6])
-        return abs(m) <= mm and not (m == 0 and int(r[0]) == IT_TP and int(r[7]) and mm > 0)
-
-    phase_groups = []                                           # per phase: the work groups (items of one segment key)
-    for ph in range(nphase):
-        g0, g1 = int(ptab[ph][2]), int(ptab[ph][3])
-        phase_groups.append([[items[i] for i in range(int(gtab[gi][0]), int(gtab[gi][1]))] for gi in range(g0, g1)])
-        if sum(len(g) for g in phase_groups[-1]) > WIDE_FLAGS:
-            raise NotImplementedError("wide schedule: more items in one phase than S-ready flags")
-    unmap = {new: old for old, new in sub["remap"].items()}      # schedule segment index -> program segment index
-    key_of = lambda recs: int(prog.seg_key.get(unmap[int(recs[0][19])], unmap[int(recs[0][19])]))      # the work-group key (merged items: the group's first member)
-
-    tasks: List[List[int]] = []
-    chains: List[List[int]] = []
-    mfma_tasks = 0
-
-    def window_records(ph, info, m_lo, m_hi):
-        """the records of the items `info` = [(item, S slot, flag)] restricted to the columns m_lo..m_hi -> (cost, [records])"""
-        nonlocal xoff, mfma_tasks
-        chain, ccost = [], 0.0
-        for r, my_slot, my_fi in info:
-            typ, mm, rtm = int(r[0]), int(r[6]), int(r[9])
-            odd = bool(typ == IT_TP and int(r[7]) and mm > 0)
-            lo, hi = max(m_lo, -mm), min(m_hi, mm)
-            if lo > hi:
-                continue
-            runs = [(lo, hi)]
-            if odd and lo <= 0 <= hi:                          # the centre column of an odd item is structurally zero: not computed
-                runs = [(a_, b_) for a_, b_ in ((lo, -1), (1, hi)) if a_ <= b_]
-            cap = wide_ncw_cap(rtm)
-            cfull = wts[int(r[13]):int(r[13]) + rtm * (2 * mm + 1) * 16].reshape(rtm, 2 * mm + 1, 4, 4) if typ == IT_TP else None   # [rt][c][g][r]
-            for a_, b_ in runs:
-                n = b_ - a_ + 1
-                k = ceil_div(n, cap)
-                base_n, rem = divmod(n, k)
-                o = a_
-                for j in range(k):
-                    ncw = base_n + (1 if j < rem else 0)
-                    c0 = o + mm                                # first real column of the record
-                    o += ncw
-                    rec = [0] * WIDE_TASK_I32
-                    rec[0] = WT_COMPUTE
-                    rec[1] = int(r[1]) + (ph & 1) * sf                 # stage offsets inside the phase's buffer
-                    rec[2] = int(r[2]) + (ph & 1) * sf if int(r[2]) >= 0 else -1
-                    rec[3] = my_slot
-                    for q in (4, 5, 6, 7, 8, 9, 11, 14, 16, 17, 18, 22, 23):
-                        rec[q] = int(r[q])
-                    rec[10] = my_fi
-                    rec[13], rec[15], rec[19], rec[20] = c0, ncw, typ, ph + 1
-                    if typ == IT_TP:                           # the record's CG coefficients, packed: lane (g, p = rt * ncw + j) holds the float4 over r
-                        pk = np.zeros((4, 16, 4), dtype=wts.dtype)
-                        for rt in range(rtm):
-                            for jj in range(ncw):
-                                pk[:, rt * ncw + jj, :] = cfull[rt, c0 + jj]
-                        extra.append(pk.reshape(-1))
-                        rec[12] = xbase + xoff
-                        xoff += 256
-                    cc = col_cost(r) * ncw
-                    mfma_tasks += cc
-                    ccost += cc + WIDE_COST_REC
-                    chain.append(rec)
-        return ccost, chain
-
-    def phase_s_units(ph):
-        """(S task units, per group [(item, S slot, flag)]) of a phase"""
-        nonlocal mfma_tasks
-        s_units, infos = [], []
-        slot, fi = 0, 0
-        sbase = (ph & 1) * cap_slots if own else 0
-        fbase = (ph & 1) * WIDE_FLAGS if own else 0
-        for recs in phase_groups[ph]:
-            info = []
-            for r in recs:
-                typ, rtm = int(r[0]), int(r[9])
-                my_slot = -1
-                if typ == IT_TP:
-                    my_slot = sbase + slot
-                    slot += rtm
-                    rec = [0] * WIDE_TASK_I32
-                    rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], rec[6] = WT_S, int(r[12]), rtm, int(r[10]), my_slot, fbase + fi, ph + 1
-                    s_units.append((hp4 * rtm + WIDE_COST_REC, [rec]))
-                    mfma_tasks += hp4 * rtm
-                info.append((r, my_slot, fbase + fi))
-                fi += 1
-            infos.append(info)
-        assert slot <= cap_slots
-        return s_units, infos
-
-    if not own:
-        # ---------------------------------------------------------------- pools: one barrier per phase, every pool dealt on its own
-        streams: List[List[List[int]]] = []
-        tot_cost, crit_cost = 0.0, 0.0
-
-        def deal(pool_index: int, s_units, c_units, st_units):
-            """LPT over the waves (largest unit first onto the least loaded wave); a wave's stream = its S tasks, its compute chains (dearest first), its
-            staging shares"""
-            nonlocal tot_cost, crit_cost
-            loads = [0.0] * W
-            mine = [([], [], []) for _ in range(W)]
-            allu = [(c, 0, u) for c, u in s_units] + [(c, 1, u) for c, u in c_units] + [(c, 2, u) for c, u in st_units]
-            for c, cls, u in sorted(allu, key=lambda t: -t[0]):
-                w = loads.index(min(loads))
-                loads[w] += c
-                mine[w][cls].append((c, u))
-            row = []
-            for w in range(W):
-                r0 = len(tasks)
-                order = (mine[w][2] + mine[w][0] + mine[w][1]) if WIDE_STAGE_POS == "begin" else (mine[w][0] + mine[w][1] + mine[w][2])
-                for c, u in order:
-                    chains.append([len(tasks), len(tasks) + len(u), pool_index])
-                    tasks.extend(u)
-                row.append([r0, len(tasks)])
-            streams.append(row)
-            if pool_index > 0:
-                tot_cost += sum(loads)
-                crit_cost += max(loads)
-
-        deal(0, [], [], stage_units(0))
-        for ph in range(nphase):
-            groups = phase_groups[ph]
-            ctot = sum(col_cost(r) * ncols(r) + WIDE_COST_REC for g in groups for r in g)
-            target = max(ctot / (W * WIDE_TASKS_PER_WAVE), 48.0)
-            s_units, infos = phase_s_units(ph)
-            c_units = []
-            for recs, info in zip(groups, infos):
-                for (m_lo, m_hi) in _wide_group_windows(recs, col_cost, target):
-                    ccost, chain = window_records(ph, info, m_lo, m_hi)
-                    if chain:
-                        c_units.append((ccost, chain))
-            deal(ph + 1, s_units, c_units, stage_units(ph + 1) if ph + 1 < nphase else [])
-        stream_np = np.asarray(streams, np.int32).reshape(nphase + 1, W, 2)
-        balance = tot_cost / (W * crit_cost) if crit_cost else 1.0
-        crit = crit_cost
-    else:
-        # ---------------------------------------------------------------- own: fixed (segment key, column window) -> wave for the whole tile
-        keycost: Dict[int, Dict[int, float]] = {}              # key -> column m -> cost over all phases
-        for ph in range(nphase):
-            for recs in phase_groups[ph]:
-                d = keycost.setdefault(key_of(recs), {})
-                for r in recs:
-                    for m in range(-int(r[6]), int(r[6]) + 1):
-                        if col_has(r, m):
-                            d[m] = d.get(m, 0.0) + col_cost(r) + WIDE_COST_REC / max(1, ncols(r))
-        grand = sum(sum(d.values()) for d in keycost.values())
-        target = grand / (W * WIDE_TASKS_PER_WAVE)              # cost of one ownership piece
-        pieces = []                                            # (cost, key, m_lo, m_hi)
-        for key, d in keycost.items():
-            ms = sorted(d)
-            tot_k = sum(d.values())
-            nwin = int(max(1, min(len(ms), round(tot_k / target))))
-            lo_i, acc, made = 0, 0.0, 0
-            for i, m in enumerate(ms):
-                acc += d[m]
-                left_cols, left_wins = len(ms) - 1 - i, nwin - made - 1
-                if left_wins > 0 and (acc >= (made + 1) * tot_k / nwin - 1e-9 or left_cols <= left_wins) and left_cols >= left_wins:
-                    pieces.append((sum(d[x] for x in ms[lo_i:i + 1]), key, ms[lo_i], m))
-                    lo_i, made = i + 1, made + 1
-            pieces.append((sum(d[x] for x in ms[lo_i:]), key, ms[lo_i], ms[-1]))
-        loads = [0.0] * W
-        owner: Dict[Tuple[int, int, int], int] = {}
-        for c, key, m_lo, m_hi in sorted(pieces, key=lambda t: -t[0]):
-            w = loads.index(min(loads))
-            loads[w] += c
-            owner[(key, m_lo, m_hi)] = w
-        wins_of_key: Dict[int, List[Tuple[int, int, int]]] = {}
-        for (key, m_lo, m_hi), w in owner.items():
-            wins_of_key.setdefault(key, []).append((m_lo, m_hi, w))
-        wave_recs: List[List[List[int]]] = [[] for _ in range(W)]
-
-        def sync(kind, counter, value):
-            rec = [0] * WIDE_TASK_I32
-            rec[0], rec[1], rec[2] = kind, counter, value
-            return rec
-        DONE, STAGED = 0, 64
-        # prologue: the staging shares of phase 0
-        st0 = stage_units(0)
-        mine0 = [[] for _ in range(W)]
-        for c, u in st0:
-            w = loads.index(min(loads))
-            loads[w] += c
-            mine0[w].append(u)
-        n_staged = [0] * (nphase + 1)
-        n_staged[0] = sum(1 for w in range(W) if mine0[w])
-        for w in range(W):
-            for u in mine0[w]:
-                wave_recs[w] += u
-            if mine0[w]:
-                wave_recs[w].append(sync(WT_SIGNAL, STAGED + 0, 1))
-        for ph in range(nphase):
-            s_units, infos = phase_s_units(ph)
-            comp = [[] for _ in range(W)]
-            for recs, info in zip(phase_groups[ph], infos):
-                for (m_lo, m_hi, w) in wins_of_key[key_of(recs)]:
-                    _, chain = window_records(ph, info, m_lo, m_hi)
-                    comp[w] += chain
-            smine = [[] for _ in range(W)]
-            for c, u in sorted(s_units, key=lambda t: -t[0]):   # S tasks and staging shares are not tied to cells: onto the least loaded wave (running totals)
-                w = loads.index(min(loads))
-                loads[w] += c
-                smine[w] += u
-            stmine = [[] for _ in range(W)]
-            if ph + 1 < nphase:
-                for c, u in stage_units(ph + 1):
-                    w = loads.index(min(loads))
-                    loads[w] += c
-                    stmine[w] += u
-                n_staged[ph + 1] = sum(1 for w in range(W) if stmine[w])
-            for w in range(W):
-                if smine[w]:
-                    if ph >= 2:
-                        wave_recs[w].append(sync(WT_WAIT, DONE + ph - 2, W))
-                    wave_recs[w] += smine[w]
-                if comp[w]:
-                    wave_recs[w].append(sync(WT_WAIT, STAGED + ph, n_staged[ph]))
-                    wave_recs[w] += comp[w]
-                wave_recs[w].append(sync(WT_SIGNAL, DONE + ph, 0))
-                if stmine[w]:
-                    if ph >= 1:
-                        wave_recs[w].append(sync(WT_WAIT, DONE + ph - 1, W))
-                    wave_recs[w] += stmine[w]
-                    wave_recs[w].append(sync(WT_SIGNAL, STAGED + ph + 1, 1))
-        row = []
-        for w in range(W):
-            r0 = len(tasks)
-            chains.append([r0, r0 + len(wave_recs[w]), 0])
-            tasks.extend(wave_recs[w])
-            row.append([r0, len(tasks)])
-        stream_np = np.asarray([row], np.int32).reshape(1, W, 2)
-        balance = sum(loads) / (W * max(loads)) if max(loads) else 1.0
-        crit = max(loads)
-    tasks_np = np.asarray(tasks, np.int32).reshape(-1, WIDE_TASK_I32)
-    return WideSchedule(seg_table=sub["segs"], block_table=np.asarray(sub["btab"], np.int32).reshape(-1, IS_BLOCK_I32),
-                        phase_blocks=np.asarray([[int(p[0]), int(p[1])] for p in ptab], np.int32).reshape(-1, 2),
-                        stream_table=stream_np, chain_table=np.asarray(chains, np.int32).reshape(-1, 3),
-                        task_table=tasks_np, rec_table=np.asarray([wide_pack_record(t) for t in tasks], np.int32).reshape(-1, WIDE_REC_I32),
-                        item_table=np.asarray(items, np.int32).reshape(-1, IS_ITEM_I32), rowtab=np.asarray(sub["rowtab"], np.int32),
-                        extra_weights=(np.concatenate(extra) if extra else np.zeros(4, wts.dtype)), lay=lay, nphase=nphase,
-                        balance=balance, crit=crit, mfma_tasks=int(mfma_tasks))
 
 
 def _lite_column_steps(prog: "Program", items, lk: int, rtm: int, pairing: bool):
@@ -1036,12 +524,9 @@ def _lite_streams(prog: "Program", recs, runs: dict, rt_base: Dict[int, int], wa
 
 
 def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: int, block_base: int, group_base: int, item_base: int,
-                      split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None, waves: int = IS_WAVES,
-                      stage_floats_fixed: Optional[int] = None, srt_cap: Optional[int] = None, wig_floats: Optional[int] = None) -> dict:
+                      split: bool = False, separate_mlp: bool = False, runs: Optional[dict] = None, waves: int = IS_WAVES) -> dict:
     """sub-schedule of the output segments `members` (indices into prog.seg_table); all table indices are emitted as ABSOLUTE indices
-    into the concatenated tables of the launch (bases given).
-    stage_floats_fixed / srt_cap (wide schedule, plan.wide_schedule): the staging area's size is given instead of "what the LDS leaves", and a
-    phase holds at most srt_cap 16-row tiles of radial scales (the S fragments of its tensor-product items travel through an LDS buffer)."""
+    into the concatenated tables of the launch (bases given)."""
     segs = prog.seg_table[members].copy()
     local = {old: n for n, old in enumerate(members)}
     off, maxstride = 0, 0
@@ -1094,7 +579,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     rowtab += [0] * ((-len(rowtab)) % 4)
     rowtab_off = tiles_end
     stage_off = rowtab_off + len(rowtab)
-    stage_floats = IS_LDS_BYTES // 4 - stage_off - 4 if stage_floats_fixed is None else int(stage_floats_fixed)
+    stage_floats = IS_LDS_BYTES // 4 - stage_off - 4
     # ---- input blocks read by this part's items
     blocks: Dict[Tuple[int, int, int], dict] = {}
     for rec in prog.item_table:
@@ -1114,9 +599,6 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         b["cls"] = cls.pop() if len(cls) == 1 else None        # None: plain Linear items only (no radial scale) / not separated
         b["src_floats"] = ceil_div((2 * b["li"] + 1) * (b["in_mulp"] // 4), 4) * 256
         b["floats"] = b["nsrc"] * b["src_floats"]
-        b["srt"] = sum(int(r[9]) for r in b["items"] if int(r[0]) == IT_TP)
-        if srt_cap is not None and b["srt"] > srt_cap:
-            raise NotImplementedError(f"wide schedule: one input block carries {b['srt']} row tiles of radial scales, the LDS buffer holds {srt_cap}")
         if b["floats"] > stage_floats:
             raise NotImplementedError(f"input-stationary schedule: LDS staging area of {stage_floats * 4} B is smaller than an input block")
     # the staging area only needs to hold the largest phase: parts with small tiles keep the LDS small as well
@@ -1128,8 +610,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
     for b in sorted(blocks.values(), key=lambda b: -b["floats"]):
         for ph in phases:
             if sum(x["floats"] for x in ph) + b["floats"] <= stage_floats and (
-                    not separate_mlp or b["cls"] is None or _cls(ph) is None or _cls(ph) == b["cls"]) and (
-                    srt_cap is None or sum(x["srt"] for x in ph) + b["srt"] <= srt_cap):
+                    not separate_mlp or b["cls"] is None or _cls(ph) is None or _cls(ph) == b["cls"]):
                 ph.append(b)
                 break
         else:
@@ -1209,7 +690,7 @@ def _is_schedule_part(prog: "Program", members: List[int], hp4: int, seg_base: i
         if int(sg[7]) & SEG_UNROTATE:
             need[int(sg[0])] = ceil_div((2 * int(sg[0]) + 1) ** 2, 4) * 64
     batches: List[List[int]] = []
-    wig_cap = stage_floats if wig_floats is None else int(wig_floats)     # (wide schedule: the epilogue owns both staging buffers and the S buffer)
+    wig_cap = stage_floats
     for l in sorted(need, key=lambda l: -need[l]):
         if need[l] > wig_cap:
             raise NotImplementedError("input-stationary schedule: staging area smaller than a Wigner block")

@@ -93,7 +93,7 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
 /* Input-stationary schedule of the same fused MessagePackBlock (same reference ops as hg_tp_fused: message_passing.py:191-231
  * [+ interaction_blocks.py:151-152]); csrc/tp_is.hip.  One workgroup = 16 edges with the tiles of ALL output segments in LDS;
  * outer loop over phases (plan.py:is_schedule): the input irrep blocks of a phase are staged once per 16 edges and shared by
- * the four waves, which claim the phase's work groups dynamically.
+ * the four waves, which claim the phase's work groups dynamically (a shared tile is updated by one wave per phase: fixed order).
  *   seg_table   int32[nseg][8]   = {lk, mul_k, rto, out_off, out_mulp, tile_off, Wigner stage_off, flags (| 1<<16: new batch)}
  *   block_table int32[nblock][8] = {s0, s1, in_off, in_mulp, li, nsrc, stage_off0, stage_off1}
  *   phase_table int32[nphase][8] = {block_begin, block_end, group_begin, group_end, radial generator (0 / 1) whose hidden rows the kernel
@@ -103,18 +103,19 @@ int hg_tp_fused(const float* const* src, const int64_t* src_stride, int nsrc, co
  *   row_table   int32: per part, for every output row (segment, 16-row tile, row) of GEMM2 the LDS float offset (relative to a tile
  *               copy) of that row's centre column; rows beyond the segment's multiplicity point at the trash row
  *   part_table  int32[nparts][16] = {first segment, segments, first phase, phases, trash_off, stage_off, ctr_off, copy_stride,
- *               rowtab_off (LDS float offset of the part's copy of the row table), rowtab_begin, rowtab_len, lite flag, segment mask lo,
- *               segment mask hi, 0, 0}: the launch runs
+ *               rowtab_off (LDS float offset of the part's copy of the row table), rowtab_begin, rowtab_len, lite flag, 0, 0, 0, 0}: the launch runs
  *               nparts sub-schedules (grid.y) that own disjoint sets of output segments; one part = the whole program, several
  *               parts spread a 16-edge tile's serial pass over several workgroups when there are fewer tiles than CUs (small
  *               crystals: BASELINE configs #1 and #5).  trash_off / stage_off / ctr_off: float offsets of the padding-row sink,
  *               the staging area and the claim counter inside the workgroup's LDS (lds_bytes = the largest part's need);
- *               [7] = copy_stride > 0: every wave accumulates into a private copy of the part's tiles.  part_table_host: the
+ *               [7] = copy_stride > 0: every wave accumulates into a private copy of the part's tiles; such a part's work groups are DEALT,
+ *               not claimed (r6): group_begin + k * waves + w is the k-th work group of wave w (empty groups end a short stream), the
+ *               copies are folded in a fixed order -- one summation order per launch, bit-identical results between runs.  part_table_host: the
  *               same table in HOST memory (one of the tiny host arrays; validated, and a single part's scalars travel as
  *               kernel arguments).  r5: parts may SHARE a segment range and take different phase ranges of it; the shared
  *               segments carry flag bit 1 (SEG_ATOMIC) in seg_table[.][7], their epilogues ADD into `out`, which the caller has
- *               zero-filled; [12] / [13]: bit s set = the part's phases feed its s-th segment (the others are skipped; -1 = all).
- *               The order of those adds is not fixed: sums differ between runs at fp32 rounding level.
+ *               zero-filled.  The order of THOSE adds is not fixed (sums differ between runs at fp32 rounding level): the host uses this
+ *               form under hipGraph capture only (graph_capture.CapturedForward), never for eager forwards.
  * src_idx[i] (nullable): row gather of source i; rot_mask bit i: source i holds GLOBAL-frame
  * node rows that are gathered and rotated by D^l(R_e) while staged -- the node_features[sender/receiver] gathers of
  * convolution.py:138-141 / interaction_blocks.py:141-145 fused into the operand staging (no hg_rotate_gather pass, no per-edge
@@ -132,34 +133,6 @@ int hg_tp_is(const float* const* src, const int64_t* src_stride, int nsrc, const
              const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
              int64_t rows, void* stream);
 
-/* The same whole MessagePackBlock.forward as hg_tp_is (hamgnn/nn/message_passing.py:191-231 incl. the node gathers of convolution.py:138-141 /
- * interaction_blocks.py:141-145 and, with run_id, the receiver scatter convolution.py:147-149), on the WIDE schedule (csrc/tp_wide.hip, r5; plan.py:
- * wide_schedule): ONE workgroup of 16 waves per 16-edge tile owns the CU's LDS -- output tiles, two staging buffers, a buffer of radial-scale
- * fragments and their ready flags.  The work of a phase is dealt to the 16 waves by the host planner (static LPT): staging shares of the NEXT
- * phase's input blocks, one radial-scale ("S") task per item, compute chains (all items of one (phase, output segment) on a window of columns:
- * GEMM1 -> scale -> GEMM2 on 1..7 columns of an item per record; a tile cell is updated by one wave per phase).  Single-part, non-lite programs with
- * radial hidden layers up to 64 wide only; same `weights` blob as hg_tp_is with the schedule's packed coefficient blocks appended.
- *   seg_table, block_table, row_table: as for hg_tp_is (one part)
- *   stream_table int32[nphase + 1][16][2] = {record_begin, record_end}: the records wave w runs in pool p back to back; pool 0 = staging of phase 0,
- *               pool p + 1 = [S tasks of p | compute chains of p | staging shares of p + 1] per wave
- *   rec_table   int32[nrec][16], one 64-byte record (plan.wide_pack_record):
- *               w0 = kind | rtm << 2 | ncw << 5 | (item type / radial generator / staging buffer) << 8 | x4 << 9 | neg << 10 | l << 11 | mm << 14 |
- *                    rto << 17 | nk2 << 21 | c0 << 26        kind 0 = staging share, 1 = S task, 2 = compute record
- *               w1 = stage offset of source 0 (incl. the buffer) / block / float offset of the item's W3 fragments
- *               w2 = stage offset of source 1 (-1) / share        w3 = in_mulp | ksteps << 16 / shares
- *               w4, w5, w6 = float offsets of the A1 fragments, the record's packed CG coefficients, the A2 fragments
- *               w7 = first S slot | flag << 16    w8 = first output row (plain Linear items)    w9 = first row-table entry of GEMM2's rows
- *   lay_host    HOST int32[16] = {nseg, nphase, trash_off, rowtab_off, rowtab_len, stage_off, stage_floats, sbuf_off, sbuf_slots, flag_off, ctr_off,
- *               lds_floats, own, 0, 0, 0}: float offsets inside the workgroup's LDS (validated).  own = 1 (plan.wide_schedule(mode="own")): stream_table is
- *               int32[1][16][2], one record stream per wave for the whole tile; kind 3 records synchronise through counters in LDS (bit 2 of w0 set: signal
- *               counter w1 (after draining the vector-memory queue if w2), else: wait until counter w1 >= w2) and no barrier separates the phases;
- *               w10 of S / compute records = the value the item's S flag takes                                                                  */
-int hg_tp_wide(const float* const* src, const int64_t* src_stride, int nsrc, const float* h2_node, const float* h2_edge, int hidden,
-               const float* wig, int nW, const int32_t* wig_off, const float* weights, const int32_t* seg_table, const int32_t* block_table,
-               const int32_t* stream_table, const int32_t* rec_table, const int32_t* row_table, const int32_t* lay_host,
-               const int64_t* const* src_idx, int rot_mask, const int64_t* edge_perm, const int32_t* run_id, float* out, int64_t out_stride,
-               int64_t rows, void* stream);
-
 /* e3nn NormActivation of a ResidualBlock with nonlinearity_type = "norm" (hamgnn/nn/interaction_blocks.py:311-330 -> e3nn.nn.NormActivation with the
  * scalar nonlinearity ShiftedSoftPlus as given, normalize = True, epsilon = 1e-8, no bias; the head's HamLayers, hamgnn/models/hamgnn_output.py:38-58)
  * on planar rows: every irrep copy is scaled by ssp(n) / n, n = max(|x|, eps).  chan_tab int32[nchan][2] = {float offset of the copy's first
@@ -171,10 +144,9 @@ int hg_norm_act_backward(const float* x, int64_t x_stride, const float* gy, int6
                          int64_t rows, float* gx, int64_t gx_stride, int D, void* stream);
 
 /* Compile-time shape of the loaded library (no reference counterpart; host-only): what = 0 waves per workgroup of hg_tp_is, 1 ... of its lite_mode
- * instantiation, 2 request-ring depth of the lite_mode streams, 3 waves per workgroup of hg_tp_wide; -1 for anything else.  The host planner
- * (hamgnn_amd/plan.py) deals work to that many streams / waves and refuses to launch when its settings differ.  hg_wide_waves() = what 3.      */
+ * instantiation, 2 request-ring depth of the lite_mode streams; -1 for anything else.  The host planner
+ * (hamgnn_amd/plan.py) deals work to that many streams / waves and refuses to launch when its settings differ.                                 */
 int hg_build_config(int what);
-int hg_wide_waves(void);
 
 /* Many small independent matrix products in one launch (csrc/block_gemm.hip):  C_u = scale_u * op(A_u) @ op(B_u).  Replaces the per-irrep
  * products of a MessagePackBlock's two trailing Linears -- linear_scaler.linear_out @ linear_out / sqrt(mul_k)

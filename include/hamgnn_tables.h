@@ -51,13 +51,16 @@ static int hg__array(const HgProgFile* f, const char* hdr, const char* name, HgA
     a->shape[1] = (*sh == ',') ? strtoll(sh + 1, NULL, 10) : 1;
     a->is_f32 = strstr(p, "\"dtype\": \"f32\"") != NULL && strstr(p, "\"dtype\": \"f32\"") < strstr(p, "\"shape\"");
     long long off = hg__int_after(hdr, p, "\"offset\""), nb = hg__int_after(hdr, p, "\"nbytes\"");
-    if (off < 0 || nb < 0 || off + nb > f->file_bytes || (off & 63)) return -1;
+    if (off < 0 || nb < 0 || off > f->file_bytes || nb > f->file_bytes - off || (off & 63)) return -1;       /* (no off + nb: cannot wrap) */
+    if (a->shape[0] < 0 || a->shape[1] < 1 || (a->shape[0] && a->shape[1] > (INT64_MAX / 4) / a->shape[0]) || nb != a->shape[0] * a->shape[1] * 4) return -1;   /* nbytes == shape product x 4 */
     a->data = f->file + off;
     a->nbytes = nb;
     return 0;
 }
 
-/* 0 on success; negative: cannot open / not a container / truncated */
+static void hg_prog_free(HgProgFile* f) { free(f->file); memset(f, 0, sizeof *f); }
+
+/* 0 on success; negative: cannot open / not a container / truncated or inconsistent (nothing stays allocated on failure) */
 static int hg_prog_load(const char* path, HgProgFile* f) {
     memset(f, 0, sizeof *f);
     FILE* fp = fopen(path, "rb");
@@ -65,14 +68,16 @@ static int hg_prog_load(const char* path, HgProgFile* f) {
     fseek(fp, 0, SEEK_END);
     f->file_bytes = ftell(fp);
     fseek(fp, 0, SEEK_SET);
+    if (f->file_bytes < 0) { fclose(fp); return -2; }
     f->file = (unsigned char*)malloc((size_t)f->file_bytes + 1);
-    if (!f->file || fread(f->file, 1, (size_t)f->file_bytes, fp) != (size_t)f->file_bytes) { fclose(fp); return -2; }
+    if (!f->file || fread(f->file, 1, (size_t)f->file_bytes, fp) != (size_t)f->file_bytes) { fclose(fp); hg_prog_free(f); return -2; }
     fclose(fp);
-    if (f->file_bytes < 16 || memcmp(f->file, "HGPROG1\0", 8)) return -3;
+    if (f->file_bytes < 16 || memcmp(f->file, "HGPROG1\0", 8)) { hg_prog_free(f); return -3; }
     uint64_t hlen = 0;
     for (int i = 7; i >= 0; --i) hlen = (hlen << 8) | f->file[8 + i];
-    if (16 + hlen > (uint64_t)f->file_bytes) return -4;
-    char* hdr = (char*)malloc(hlen + 1);
+    if (hlen > (uint64_t)f->file_bytes - 16) { hg_prog_free(f); return -4; }      /* (not 16 + hlen: a corrupt length must not wrap) */
+    char* hdr = (char*)malloc((size_t)hlen + 1);
+    if (!hdr) { hg_prog_free(f); return -2; }
     memcpy(hdr, f->file + 16, hlen);
     hdr[hlen] = 0;
     f->hidden = (int)hg__int_after(hdr, NULL, "\"hidden\"");
@@ -84,8 +89,7 @@ static int hg_prog_load(const char* path, HgProgFile* f) {
              hg__array(f, hdr, "phase_table", &f->phase_table) | hg__array(f, hdr, "group_table", &f->group_table) | hg__array(f, hdr, "item_table", &f->item_table) |
              hg__array(f, hdr, "part_table", &f->part_table) | hg__array(f, hdr, "row_table", &f->row_table);
     free(hdr);
-    return rc ? -5 : 0;
+    if (rc) { hg_prog_free(f); return -5; }
+    return 0;
 }
-
-static void hg_prog_free(HgProgFile* f) { free(f->file); memset(f, 0, sizeof *f); }
 #endif

@@ -55,23 +55,10 @@ for _ in range(a.reps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.reps
 prog = m._dp_adj.prog if a.adjoint else m._dp.prog
-print(json.dumps({"tag": a.tag, "kernel": ("wide" if m._dp.use_wide(E, None, ()) else "is") if m._dp.sched is not None else "seg", "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
+print(json.dumps({"tag": a.tag, "kernel": "is" if m._dp.sched is not None else "seg", "lib": os.path.basename(os.environ.get("HG_LIB_PATH", "default")), "irreps": a.irreps, "E": E, "ms": dt * 1e3,
                   "issued_TF": (prog.mfma_per_wave - (prog.mfma_odd_skipped if (m._dp_adj if a.adjoint else m._dp).sched is not None else 0)) * 2048 / 16 * E / dt / 1e12, "useful_TF": prog.flops_per_row * E / dt / 1e12,
                   "Medges_s": E / dt / 1e6, "checksum": float(out.double().abs().mean())}))
-if os.environ.get("HG_PROF") and m._dp.sched is not None and m._dp.use_wide(E, None, ()):
-    import ctypes as C
-    from hamgnn_amd import _lib
-    L = _lib.lib()
-    buf = (C.c_ulonglong * 16)()
-    L.hg_prof_wd_read(buf, 1)
-    launch()
-    L.hg_prof_wd_read(buf, 0)
-    names = ["record", "staging shares", "S tasks", "GEMM1", "wait for S", "scale + GEMM2 + write-back", "pool barrier", "epilogue", "zero fill"]
-    tot = float(buf[15])
-    ws = m._dp.wide_tables()[0]
-    print(json.dumps({"prof_total_wave_cycles": tot, "waves": P.WIDE_WAVES, "balance": ws.balance, "chains": int(ws.chain_table.shape[0]), "records": int(ws.task_table.shape[0]),
-                      **{n: round(buf[k] / tot, 4) for k, n in enumerate(names)}}))
-elif os.environ.get("HG_PROF") and m._dp.sched is not None:
+if os.environ.get("HG_PROF") and m._dp.sched is not None:
     import ctypes as C
     from hamgnn_amd import _lib
     L = _lib.lib()

@@ -203,15 +203,13 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
         ne = min(16, E - e0)
         cols = np.arange(e0, e0 + ne)
         seen, seg_seen = set(), set()
-        atomic_parts = bool(getattr(sched, "atomic_out", False))       # phase parts (plan.is_schedule "phases"): every part holds ALL segments and adds its tiles
-        for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _, mask_lo, mask_hi in (tuple(int(v) for v in p[:14]) for p in sched.part_table):
+        for sg0, nsg, ph0, nph, trash_off, stage_off, ctr_off, copy_stride, rowtab_off, rt0, rtn, _ in (tuple(int(v) for v in p[:12]) for p in sched.part_table):
             stage_floats = ctr_off - stage_off
             part_segs = set(range(sg0, sg0 + nsg))
             part_atomic = all(int(sched.seg_table[g][7]) & P.SEG_ATOMIC for g in part_segs)
             if not part_atomic:
                 assert not (part_segs & seg_seen)
             seg_seen |= part_segs
-            part_mask = (mask_lo & 0xffffffff) | ((mask_hi & 0xffffffff) << 32)
             fed = set()
             tile_floats = sum(int(sched.seg_table[g][1]) * ((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4) for g in part_segs)
             maxstride = max((2 * int(sched.seg_table[g][0]) + 1) * 16 + 4 for g in part_segs)
@@ -239,6 +237,8 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                 assert used <= stage_floats
                 owner = set()
                 stream_cells = set()
+                if copy_stride:                                # private tile copies: the work groups are dealt to the waves (group g0 + k * waves + w), see plan._is_schedule_part
+                    assert (g1 - g0) % waves_ == 0
                 for gi in range(g0, g1):
                     ib, ie = (int(v) for v in sched.group_table[gi])
                     touched = set()
@@ -356,429 +356,10 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                 seg = sched.seg_table[sg]
                 lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
                 strd = (2 * lk_ + 1) * 16 + 4
-                if part_atomic and atomic_parts:               # the kernel skips the epilogue of the segments the part's mask does not name: they must be untouched
-                    named = bool((part_mask >> (sg - sg0)) & 1) if sg - sg0 < 64 else True
-                    assert named or sg not in fed, ("segment mask of a phase part", sg, named)
-                    if not named:
-                        assert not lds[toff_:toff_ + mul_ * strd].any()
-                        continue
                 tile = np.zeros((rto_ * 16, 2 * lk_ + 1, 16), dtype=dtype)
                 tile[:mul_] = lds[toff_:toff_ + mul_ * strd].reshape(mul_, strd)[:, :(2 * lk_ + 1) * 16].reshape(mul_, 2 * lk_ + 1, 16)
                 _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)
         assert len(seen) == sched.item_table.shape[0] and len(seg_seen) == sched.seg_table.shape[0]
-    return out
-
-
-def _run_program_wide_own(prog, ws, srcs, h2, D, lmax, dtype, order):
-    """the "own" form of the wide schedule (plan.wide_schedule(mode="own")): ONE record stream per wave for the whole tile, no barriers between the phases --
-    WT_WAIT / WT_SIGNAL records on monotonic counters.  The 16 streams are interleaved by a scheduler (order = "list": round-robin, one record at a time;
-    "reverse_compute": the highest runnable wave first, each running until it blocks -- a maximally skewed interleaving); a wave blocks at an unsatisfied
-    wait or at a compute record whose S flag is not set; nobody runnable before all streams ended = deadlock.  Hazards are checked on the DATA, not on the
-    counters: every staged piece and every S slot carries the phase that wrote it, a compute record must find its own phase there (a buffer overwritten too
-    early or read too early fails), every tile cell belongs to one wave for the whole tile, every (item, column) is computed once."""
-    E = srcs[0].shape[0]
-    W = P.WIDE_WAVES
-    Wt = np.concatenate([prog.weights.astype(dtype), ws.extra_weights.astype(dtype)])
-    out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
-    woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
-    lay = ws.lay
-    H, Hp = prog.hidden, prog.hidden_pad
-    nseg = ws.seg_table.shape[0]
-    tile_floats = sum(int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) for s in ws.seg_table)
-    maxstride = max((2 * int(s[0]) + 1) * 16 + 4 for s in ws.seg_table)
-    sf, slots = lay["stage_floats"], lay["sbuf_slots"]
-    assert lay["trash_off"] == tile_floats and lay["rowtab_off"] == tile_floats + maxstride and lay["stage_off"] == lay["rowtab_off"] + len(ws.rowtab)
-    assert lay["sbuf_off"] == lay["stage_off"] + 2 * sf and lay["flag_off"] == lay["sbuf_off"] + 256 * slots and slots % 2 == 0
-    assert lay["ctr_off"] == lay["flag_off"] + 2 * P.WIDE_FLAGS and lay["lds_floats"] == lay["ctr_off"] + P.WIDE_COUNTERS and lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES
-    assert ws.stream_table.shape == (1, W, 2) and ws.nphase <= 63
-    flat = ws.stream_table.reshape(-1, 2)
-    assert flat[0][0] == 0 and flat[-1][1] == ws.task_table.shape[0] and all(int(flat[k][1]) == int(flat[k + 1][0]) for k in range(W - 1))
-    for t, w in zip(ws.task_table, ws.rec_table):
-        u = P.wide_unpack_record(w)
-        ks = {P.WT_STAGE: (0, 1, 2, 3, 4, 5), P.WT_S: (0, 1, 2, 3, 4, 5, 6), P.WT_WAIT: (0, 1, 2), P.WT_SIGNAL: (0, 1, 2),
-              P.WT_COMPUTE: (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 23)}[int(t[0])]
-        for k in ks:
-            if int(t[0]) == P.WT_COMPUTE and int(t[19]) != P.IT_TP and k in (3, 12):
-                continue
-            assert u[k] == int(t[k]) or (k == 17 and bool(u[k]) == bool(t[k])), (k, t, w)
-    tile_of = np.full(tile_floats + maxstride, -1)
-    for gi, sgr in enumerate(ws.seg_table):
-        tile_of[int(sgr[5]):int(sgr[5]) + int(sgr[1]) * ((2 * int(sgr[0]) + 1) * 16 + 4)] = gi
-    hh = [None, None]
-    for k in (0, 1):
-        if h2[k] is not None:
-            hh[k] = np.zeros((E, Hp), dtype=dtype)
-            hh[k][:, :H] = h2[k]
-    streams = [[ws.task_table[t] for t in range(int(ws.stream_table[0][w][0]), int(ws.stream_table[0][w][1]))] for w in range(W)]
-    cell_owner = {}
-    col_seen = {}
-    for e0 in range(0, E, 16):
-        ne = min(16, E - e0)
-        cols = np.arange(e0, e0 + ne)
-        lds = np.zeros(tile_floats + maxstride, dtype=dtype)
-        stage = np.full((2, sf), np.nan, dtype=dtype)
-        stage_tag = np.full((2, sf), -1)                        # phase that staged every float
-        sbuf = {}                                              # slot -> (fragment, flag index, stamp)
-        flags = {}
-        counters = np.zeros(P.WIDE_COUNTERS, dtype=np.int64)
-        pos = [0] * W
-        first_tile = e0 == 0
-
-        def runnable(w):
-            if pos[w] >= len(streams[w]):
-                return False
-            T = streams[w][pos[w]]
-            if int(T[0]) == P.WT_WAIT:
-                return counters[int(T[1])] >= int(T[2])
-            if int(T[0]) == P.WT_COMPUTE and int(T[19]) == P.IT_TP:
-                return flags.get(int(T[10])) == int(T[20])
-            return True
-
-        def execute(w, T):
-            kind = int(T[0])
-            if kind == P.WT_SIGNAL:
-                counters[int(T[1])] += 1
-            elif kind == P.WT_WAIT:
-                pass
-            elif kind == P.WT_STAGE:
-                b, sub_, nsub, li_t, buf = (int(v) for v in T[1:6])
-                ph = next(p_ for p_ in range(ws.nphase) if int(ws.phase_blocks[p_][0]) <= b < int(ws.phase_blocks[p_][1]))
-                assert buf == ph & 1
-                s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in ws.block_table[b])
-                P1 = in_mulp // 4
-                pfull = (2 * li + 1) * P1
-                size = -(-pfull // 4) * 256
-                assert li == li_t and o0 + nsrc * size <= sf
-                for si, (sidx, o) in enumerate([(s0, o0), (s1, o1)][:nsrc]):
-                    for t in range(pfull):
-                        if (t // 4) % nsub != sub_:
-                            continue
-                        a, p_ = divmod(t, P1)
-                        for q in range(4):
-                            v = np.zeros(16, dtype=dtype)
-                            v[:ne] = srcs[sidx][cols, in_off + a * in_mulp + 4 * p_ + q]
-                            idx = o + 64 * t + 4 * np.arange(16) + q
-                            assert (stage_tag[buf, idx] != ph).all(), "a piece is staged once"
-                            stage[buf, idx] = v
-                            stage_tag[buf, idx] = ph
-            elif kind == P.WT_S:
-                w3, rtm, mlp, slot, fi, stamp = (int(v) for v in T[1:7])
-                ph = stamp - 1
-                assert (ph & 1) * (slots // 2) <= slot and slot + rtm <= (ph & 1) * (slots // 2) + slots // 2 and (ph & 1) * P.WIDE_FLAGS <= fi < ((ph & 1) + 1) * P.WIDE_FLAGS
-                W3 = Wt[w3:w3 + (Hp // 16) * rtm * 256].reshape(Hp // 16, rtm, 4, 16, 4)
-                S = np.zeros((rtm, 16, 16), dtype=dtype)
-                for G in range(Hp // 16):
-                    for q in range(4):
-                        B = np.zeros((4, 16), dtype=dtype)
-                        for g in range(4):
-                            B[g, :ne] = hh[mlp][cols, 16 * G + 4 * g + q]
-                        for rt in range(rtm):
-                            S[rt] += W3[G, rt, :, :, q].T @ B
-                for rt in range(rtm):
-                    sbuf[slot + rt] = (S[rt], fi, stamp)
-                flags[fi] = stamp
-            else:
-                so0, so1, sslot, in_mulp, li, mm, neg, ksteps, rtm, fi, a1 = (int(v) for v in T[1:12])
-                cf, c0, a2, ncw, row0, x4, nk2, typ, stamp = (int(v) for v in T[12:21])
-                rto, rtb = int(T[22]), int(T[23])
-                ph = stamp - 1
-                assert 1 <= ncw <= P.WIDE_NCW_MAX and rtm * ncw <= P.WIDE_ACC_CAP and 0 <= c0 and c0 + ncw <= 2 * mm + 1
-                odd = typ == P.IT_TP and neg and mm > 0
-                assert not (odd and c0 <= mm < c0 + ncw)
-                nsrc = 2 if so1 >= 0 else 1
-                ngrp = -(-ksteps // 4)
-                P1 = in_mulp // 4
-                buf = ph & 1
-                for j in range(ncw):
-                    key = (ph, a1, c0 + j)
-                    assert key not in col_seen or not first_tile
-                    if first_tile:
-                        col_seen[key] = (mm, odd)
-                A1 = Wt[a1:a1 + nsrc * ngrp * rtm * 256].reshape(nsrc, ngrp, rtm, 4, 16, 4)
-                mid = np.zeros((rtm, ncw, 16, 16), dtype=dtype)
-                flat_s, flat_t = stage.reshape(-1), stage_tag.reshape(-1)
-                for si, so in enumerate([so0, so1][:nsrc]):
-                    assert buf * sf <= so < (buf + 1) * sf
-                    for j in range(ncw):
-                        m = c0 + j - mm
-                        a = li + (-m if neg else m)
-                        for G in range(ngrp):
-                            for q in range(4):
-                                if not x4 and 4 * G + q >= ksteps:
-                                    continue
-                                B = np.zeros((4, 16), dtype=dtype)
-                                for g in range(4):
-                                    u = 16 * G + 4 * g + q if x4 else 4 * (4 * G + q) + g
-                                    piece, comp = divmod(u, 4)
-                                    idx = so + 64 * (a * P1 + piece) + 4 * np.arange(16) + comp
-                                    assert (flat_t[idx] == ph).all(), "staged rows of another phase (buffer read too early or overwritten too early)"
-                                    B[g] = flat_s[idx]
-                                for rt in range(rtm):
-                                    mid[rt, j] += A1[si, G, rt, :, :, q].T @ B
-                if typ == P.IT_TP:
-                    for rt in range(rtm):
-                        assert sbuf[sslot + rt][1:] == (fi, stamp), "S fragments of another item / phase"
-                    S = np.stack([sbuf[sslot + rt][0] for rt in range(rtm)])
-                    pk = Wt[cf:cf + 256].reshape(4, 16, 4)
-                    CF = np.zeros((rtm, ncw, 16), dtype=dtype)
-                    for rt in range(rtm):
-                        for j in range(ncw):
-                            CF[rt, j] = pk[:, rt * ncw + j, :].reshape(16)
-                    mid = mid * S[:, None, :, :] * CF[:, :, :, None]
-                    A2 = Wt[a2:a2 + rto * rtm * 256].reshape(rto, rtm, 4, 16, 4)
-                    rt_ = ws.rowtab[rtb:rtb + 16 * rto]
-                    for rtp in range(rto):
-                        for j in range(ncw):
-                            acc = np.zeros((16, 16), dtype=dtype)
-                            for rt in range(rtm):
-                                for r in range(4):
-                                    if 4 * rt + r >= nk2:
-                                        continue
-                                    acc += A2[rtp, rt, :, :, r].T @ mid[rt, j][r::4, :]
-                            for i_ in range(16):
-                                base = int(rt_[16 * rtp + i_]) + (c0 + j - mm) * 16
-                                assert 0 <= base and base + 16 <= tile_floats + maxstride
-                                if tile_of[base] >= 0:
-                                    assert cell_owner.setdefault(base, w) == w, "a tile cell belongs to one wave for the whole tile"
-                                lds[base:base + 16] += acc[i_]
-                else:
-                    rl = ws.rowtab[rtb:rtb + 16 * rto]
-                    for rt in range(rtm):
-                        for j in range(ncw):
-                            for i_ in range(16):
-                                base = int(rl[row0 + 16 * rt + i_]) + (c0 + j - mm) * 16
-                                if tile_of[base] >= 0:
-                                    assert cell_owner.setdefault(base, w) == w
-                                lds[base:base + 16] += mid[rt, j][i_]
-
-        while any(pos[w] < len(streams[w]) for w in range(W)):
-            cand = [w for w in (range(W) if order == "list" else reversed(range(W))) if runnable(w)]
-            assert cand, "deadlock: no wave can run"
-            if order == "list":
-                for w in cand:                                 # round-robin, one record each
-                    if runnable(w):
-                        execute(w, streams[w][pos[w]])
-                        pos[w] += 1
-            else:
-                w = cand[0]                                    # skewed: the highest runnable wave runs until it blocks
-                while runnable(w):
-                    execute(w, streams[w][pos[w]])
-                    pos[w] += 1
-        for sg in range(nseg):
-            seg = ws.seg_table[sg]
-            lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
-            strd = (2 * lk_ + 1) * 16 + 4
-            tile = np.zeros((rto_ * 16, 2 * lk_ + 1, 16), dtype=dtype)
-            tile[:mul_] = lds[toff_:toff_ + mul_ * strd].reshape(mul_, strd)[:, :(2 * lk_ + 1) * 16].reshape(mul_, 2 * lk_ + 1, 16)
-            _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)
-    per_item = {}
-    for (ph, a1, c), (mm, odd) in col_seen.items():
-        per_item.setdefault((ph, a1), (mm, odd, set()))[2].add(c)
-    assert len(per_item) == ws.item_table.shape[0]
-    for (mm, odd, cs) in per_item.values():
-        assert cs == set(range(2 * mm + 1)) - ({mm} if odd else set())
-    return out
-
-
-def run_program_wide(prog, ws, srcs, h2=(None, None), D=None, lmax=None, dtype=np.float64, order="list"):
-    """the wide schedule (plan.wide_schedule, csrc/tp_wide.hip), fragment-exact: per 16-edge tile one LDS image [tiles | trash row | row table |
-    staging buffer 0 | staging buffer 1 | S buffer | flags | counters]; pool 0 stages phase 0, pool p + 1 = [staging shares of phase p + 1 | one S
-    task per item of phase p | its column-window compute tasks].  Staging shares write the staged image piece by piece exactly as csrc/tp_wide.hip:
-    wd_stage deals the pieces (share `sub` of `nsub`: pieces 4 sub + g + 4 nsub k), compute tasks read their B operands FROM that image, their S
-    fragments from the S buffer and their coefficients from the task's packed block.  Checked on the way: LDS layout and budget, every piece of every
-    block staged exactly once before it is read, S slots disjoint inside a phase and written before they are read (list order: the deadlock-freedom
-    argument of the kernel), flags unique per phase, every (item, column) computed exactly once (odd items: never the centre column), every tile cell
-    updated by at most one task per phase.  order = "list": tasks in list order; "reverse_compute": the compute tasks of a pool in reverse order (the
-    result must not depend on the claim order)."""
-    E = srcs[0].shape[0]
-    Wt = np.concatenate([prog.weights.astype(dtype), ws.extra_weights.astype(dtype)])
-    out = np.zeros((E, prog.out_layout.dim), dtype=dtype)
-    woffs = P.wigner_offsets(lmax)[0] if lmax is not None else None
-    lay = ws.lay
-    H, Hp = prog.hidden, prog.hidden_pad
-    nseg = ws.seg_table.shape[0]
-    tile_floats = sum(int(s[1]) * ((2 * int(s[0]) + 1) * 16 + 4) for s in ws.seg_table)
-    maxstride = max((2 * int(s[0]) + 1) * 16 + 4 for s in ws.seg_table)
-    sf, slots = lay["stage_floats"], lay["sbuf_slots"]
-    assert lay["trash_off"] == tile_floats and lay["rowtab_off"] == tile_floats + maxstride and lay["stage_off"] == lay["rowtab_off"] + len(ws.rowtab)
-    assert lay["stage_off"] % 4 == 0 and lay["sbuf_off"] == lay["stage_off"] + 2 * sf and lay["flag_off"] == lay["sbuf_off"] + 256 * slots
-    nflag_, nctr_ = (2 * P.WIDE_FLAGS, P.WIDE_COUNTERS) if ws.lay.get("own", 0) else (P.WIDE_FLAGS, 64)
-    assert lay["ctr_off"] == lay["flag_off"] + nflag_ and lay["lds_floats"] == lay["ctr_off"] + nctr_ and lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES
-    W = P.WIDE_WAVES
-    own = bool(ws.lay.get("own", 0))
-    if own:
-        return _run_program_wide_own(prog, ws, srcs, h2, D, lmax, dtype, order)
-    assert ws.stream_table.shape == (ws.nphase + 1, W, 2) and ws.nphase + 1 <= 64
-    flat = ws.stream_table.reshape(-1, 2)
-    assert flat[0][0] == 0 and flat[-1][1] == ws.task_table.shape[0] and all(int(flat[k][1]) == int(flat[k + 1][0]) for k in range(flat.shape[0] - 1))
-    assert ws.rec_table.shape == (ws.task_table.shape[0], P.WIDE_REC_I32)
-    used = {P.WT_STAGE: (0, 1, 2, 3, 4, 5), P.WT_S: (0, 1, 2, 3, 4, 5), P.WT_COMPUTE: (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 22, 23)}
-    for t, w in zip(ws.task_table, ws.rec_table):               # the device records carry every field of the logical ones
-        u = P.wide_unpack_record(w)
-        for k in used[int(t[0])]:
-            if int(t[0]) == P.WT_COMPUTE and int(t[19]) != P.IT_TP and k in (3, 12):      # (no S slot / coefficients for plain Linear items)
-                continue
-            assert u[k] == int(t[k]) or (k == 17 and bool(u[k]) == bool(t[k])), (k, t, w)
-    tile_of = np.full(tile_floats + maxstride, -1)
-    for gi, sgr in enumerate(ws.seg_table):
-        tile_of[int(sgr[5]):int(sgr[5]) + int(sgr[1]) * ((2 * int(sgr[0]) + 1) * 16 + 4)] = gi
-    hh = [None, None]
-    for k in (0, 1):
-        if h2[k] is not None:
-            hh[k] = np.zeros((E, Hp), dtype=dtype)
-            hh[k][:, :H] = h2[k]
-    col_seen = {}
-    for e0 in range(0, E, 16):
-        ne = min(16, E - e0)
-        cols = np.arange(e0, e0 + ne)
-        lds = np.zeros(tile_floats + maxstride, dtype=dtype)
-        stage = np.full((2, sf), np.nan, dtype=dtype)                                  # NaN = not staged (a read of it poisons the result)
-        first_tile = e0 == 0
-        for pl in range(ws.nphase + 1):
-            per_wave = [[ws.task_table[t] for t in range(int(ws.stream_table[pl][w][0]), int(ws.stream_table[pl][w][1]))] for w in range(W)]
-            for recs_w in per_wave:                              # deadlock freedom: a wave runs ALL its S tasks before its first compute record (S tasks never wait)
-                ks = [int(t[0]) for t in recs_w if int(t[0]) != P.WT_STAGE]
-                assert ks == sorted(ks)
-            # S tasks and staging shares of all waves first, then the compute records wave by wave (any interleaving that respects the S flags is equivalent)
-            seq = [(w, T) for w, recs_w in enumerate(per_wave) for T in recs_w if int(T[0]) != P.WT_COMPUTE]
-            comp = [(w, T) for w, recs_w in enumerate(per_wave) for T in recs_w if int(T[0]) == P.WT_COMPUTE]
-            if order == "reverse_compute":
-                comp = [(w, T) for w in reversed(range(W)) for T in per_wave[w] if int(T[0]) == P.WT_COMPUTE]
-            ph = pl - 1
-            sbuf, flags, cells = {}, set(), {}
-            staged_next = {}
-            for chain_id, T in seq + comp:
-                kind = int(T[0])
-                if kind == P.WT_STAGE:
-                    b, sub, nsub, li_t, buf = (int(v) for v in T[1:6])
-                    assert buf == (ph + 1) & 1 and ph + 1 < ws.nphase
-                    pb0, pb1 = (int(v) for v in ws.phase_blocks[ph + 1])
-                    assert pb0 <= b < pb1
-                    s0, s1, in_off, in_mulp, li, nsrc, o0, o1 = (int(v) for v in ws.block_table[b])
-                    assert li == li_t and 0 <= sub < nsub
-                    P1 = in_mulp // 4
-                    pfull = (2 * li + 1) * P1
-                    size = -(-pfull // 4) * 256
-                    assert o0 + nsrc * size <= sf and (o1 == o0 + size if nsrc == 2 else o1 == -1)
-                    for si, (sidx, o) in enumerate([(s0, o0), (s1, o1)][:nsrc]):
-                        for t in range(pfull):
-                            if (t // 4) % nsub != sub:                                 # piece t = 4 j + g belongs to share j % nsub
-                                continue
-                            a, p_ = divmod(t, P1)
-                            key = (b, si, t)
-                            assert key not in staged_next
-                            staged_next[key] = 1
-                            for q in range(4):
-                                v = np.zeros(16, dtype=dtype)
-                                v[:ne] = srcs[sidx][cols, in_off + a * in_mulp + 4 * p_ + q]
-                                stage[buf, o + 64 * t + 4 * np.arange(16) + q] = v
-                elif kind == P.WT_S:
-                    w3, rtm, mlp, slot, fi = (int(v) for v in T[1:6])
-                    assert 0 <= slot and slot + rtm <= slots and fi not in flags and 0 <= fi < P.WIDE_FLAGS
-                    flags.add(fi)
-                    W3 = Wt[w3:w3 + (Hp // 16) * rtm * 256].reshape(Hp // 16, rtm, 4, 16, 4)
-                    S = np.zeros((rtm, 16, 16), dtype=dtype)
-                    for G in range(Hp // 16):
-                        for q in range(4):
-                            B = np.zeros((4, 16), dtype=dtype)
-                            for g in range(4):
-                                B[g, :ne] = hh[mlp][cols, 16 * G + 4 * g + q]
-                            for rt in range(rtm):
-                                S[rt] += W3[G, rt, :, :, q].T @ B
-                    for rt in range(rtm):
-                        assert slot + rt not in sbuf
-                        sbuf[slot + rt] = (S[rt], fi)
-                else:
-                    assert kind == P.WT_COMPUTE and ph >= 0
-                    so0, so1, sslot, in_mulp, li, mm, neg, ksteps, rtm, fi, a1 = (int(v) for v in T[1:12])
-                    cf, c0, a2, ncw, row0, x4, nk2, typ = (int(v) for v in T[12:20])
-                    rto, rtb = int(T[22]), int(T[23])
-                    assert 1 <= ncw <= P.WIDE_NCW_MAX and rtm * ncw <= P.WIDE_ACC_CAP and 0 <= c0 and c0 + ncw <= 2 * mm + 1
-                    odd = typ == P.IT_TP and neg and mm > 0
-                    assert not (odd and c0 <= mm < c0 + ncw), "a window of an odd item holds its centre column"
-                    nsrc = 2 if so1 >= 0 else 1
-                    ngrp = -(-ksteps // 4)
-                    P1 = in_mulp // 4
-                    buf = ph & 1
-                    assert buf * sf <= so0 and (so1 < 0 or so1 < (buf + 1) * sf)
-                    for j in range(ncw):
-                        key = (ph, a1, c0 + j)
-                        assert key not in col_seen or not first_tile
-                        if first_tile:
-                            col_seen[key] = (mm, odd)
-                    A1 = Wt[a1:a1 + nsrc * ngrp * rtm * 256].reshape(nsrc, ngrp, rtm, 4, 16, 4)
-                    mid = np.zeros((rtm, ncw, 16, 16), dtype=dtype)
-                    flat = stage.reshape(-1)
-                    for si, so in enumerate([so0, so1][:nsrc]):
-                        for j in range(ncw):
-                            m = c0 + j - mm
-                            a = li + (-m if neg else m)
-                            for G in range(ngrp):
-                                for q in range(4):
-                                    if not x4 and 4 * G + q >= ksteps:
-                                        continue
-                                    B = np.zeros((4, 16), dtype=dtype)
-                                    for g in range(4):
-                                        u = 16 * G + 4 * g + q if x4 else 4 * (4 * G + q) + g
-                                        piece, comp = divmod(u, 4)
-                                        B[g] = flat[so + 64 * (a * P1 + piece) + 4 * np.arange(16) + comp]
-                                    for rt in range(rtm):
-                                        mid[rt, j] += A1[si, G, rt, :, :, q].T @ B
-                    rt_ = ws.rowtab[rtb:rtb + 16 * rto] if typ == P.IT_TP else None
-                    if typ == P.IT_TP:
-                        assert fi in flags, "S task of the item precedes its compute tasks in the pool's list"
-                        S = np.stack([sbuf[sslot + rt][0] for rt in range(rtm)])
-                        assert all(sbuf[sslot + rt][1] == fi for rt in range(rtm))
-                        pk = Wt[cf:cf + 256].reshape(4, 16, 4)                                        # [g][p][r]
-                        CF = np.zeros((rtm, ncw, 16), dtype=dtype)
-                        for rt in range(rtm):
-                            for j in range(ncw):
-                                CF[rt, j] = pk[:, rt * ncw + j, :].reshape(16)                        # row 4 g + r
-                        mid = mid * S[:, None, :, :] * CF[:, :, :, None]
-                        A2 = Wt[a2:a2 + rto * rtm * 256].reshape(rto, rtm, 4, 16, 4)
-                        for rtp in range(rto):
-                            for j in range(ncw):
-                                acc = np.zeros((16, 16), dtype=dtype)
-                                for rt in range(rtm):
-                                    for r in range(4):
-                                        if 4 * rt + r >= nk2:
-                                            continue
-                                        acc += A2[rtp, rt, :, :, r].T @ mid[rt, j][r::4, :]
-                                for i_ in range(16):
-                                    base = int(rt_[16 * rtp + i_]) + (c0 + j - mm) * 16
-                                    assert 0 <= base and base + 16 <= tile_floats + maxstride
-                                    if tile_of[base] >= 0:
-                                        assert cells.setdefault(base, chain_id) == chain_id, "a tile cell is updated by one wave per phase"
-                                    lds[base:base + 16] += acc[i_]
-                    else:
-                        assert typ == P.IT_LIN
-                        rl = ws.rowtab[rtb:rtb + 16 * rto]
-                        for rt in range(rtm):
-                            for j in range(ncw):
-                                for i_ in range(16):
-                                    base = int(rl[row0 + 16 * rt + i_]) + (c0 + j - mm) * 16
-                                    if tile_of[base] >= 0:
-                                        assert cells.setdefault(base, chain_id) == chain_id
-                                    lds[base:base + 16] += mid[rt, j][i_]
-            # every piece of every block of the next phase was staged by exactly one share
-            if ph + 1 < ws.nphase:
-                pb0, pb1 = (int(v) for v in ws.phase_blocks[ph + 1])
-                want = sum(int(ws.block_table[b][5]) * (2 * int(ws.block_table[b][4]) + 1) * (int(ws.block_table[b][3]) // 4) for b in range(pb0, pb1))
-                assert len(staged_next) == want
-        for sg in range(nseg):
-            seg = ws.seg_table[sg]
-            lk_, mul_, rto_, toff_ = int(seg[0]), int(seg[1]), int(seg[2]), int(seg[5])
-            strd = (2 * lk_ + 1) * 16 + 4
-            tile = np.zeros((rto_ * 16, 2 * lk_ + 1, 16), dtype=dtype)
-            tile[:mul_] = lds[toff_:toff_ + mul_ * strd].reshape(mul_, strd)[:, :(2 * lk_ + 1) * 16].reshape(mul_, 2 * lk_ + 1, 16)
-            _write_segment(prog, seg, tile, out, cols, ne, D, woffs, dtype)
-    # every column of every item exactly once (odd items: all but the centre)
-    per_item = {}
-    for (ph, a1, c), (mm, odd) in col_seen.items():
-        per_item.setdefault((ph, a1), (mm, odd, set()))[2].add(c)
-    assert len(per_item) == ws.item_table.shape[0]
-    for (mm, odd, cs) in per_item.values():
-        assert cs == set(range(2 * mm + 1)) - ({mm} if odd else set())
     return out
 
 

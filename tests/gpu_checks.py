@@ -182,7 +182,7 @@ def _message_pack_random_run(m, device, irr, sh, lmax, lsh, n, rbf, src, dst, ef
     torch.cuda.synchronize()
     scale = out.abs().max().item()
     dp = m._dp_for(E)
-    kern = "seg" if dp.sched is None else ("wide" if dp.use_wide(E, None, ()) else "is")
+    kern = "seg" if dp.sched is None else "is"
     return {"irreps": irr, "sh": sh, "kernel": kern, "rel_err": 0.0 if scale < 1e-12 else rel(y, out)}
 
 
@@ -494,6 +494,8 @@ def check_refresh_equals_recompile(device="cuda", legacy=False, transformer=Fals
     a = mk().to(device)
     g = S.add_random_targets(S.random_cell(6, [14, 8, 6, 1], seed=2, density=0.004), 19, seed=2).to(device)
     target = 0.1 * torch.randn(g.num_nodes + g.num_edges, 19 * 19, generator=torch.Generator().manual_seed(3)).to(device)
+    with torch.no_grad():
+        H_pre = a(g)["hamiltonian"].clone()                     # an INFERENCE forward first: builds the cached fused chains (ResidualBlock / HamLayer row programs)
     training_step(a, g, metric="mse", target=target)            # builds every program (forward, adjoint, weight-gradient), marks them stale
     gen = torch.Generator().manual_seed(4)
     with torch.no_grad():
@@ -505,10 +507,15 @@ def check_refresh_equals_recompile(device="cuda", legacy=False, transformer=Fals
     ra = training_step(a, g, metric="mse", target=target)
     refreshed = sum(len(m._packers) for m in a.modules() if hasattr(m, "_packers"))
     rb = training_step(b, g, metric="mse", target=target)
+    # validate -> step -> validate: an inference forward of the stepped model must use the NEW weights everywhere, also in the chains that
+    # were cached by the inference forward before the step
+    with torch.no_grad():
+        Ha, Hb = a(g)["hamiltonian"].clone(), b(g)["hamiltonian"].clone()
     torch.cuda.synchronize()
     pa, pb = dict(a.named_parameters()), dict(b.named_parameters())
     worst = max(float((pa[k].grad - pb[k].grad).abs().max()) / max(float(pb[k].grad.abs().max()), 1e-6) for k in pb)
-    return {"packers": refreshed, "loss_rel_diff": abs(float(ra["loss"]) - float(rb["loss"])) / abs(float(rb["loss"])), "grad_max_rel_diff": worst}
+    return {"packers": refreshed, "loss_rel_diff": abs(float(ra["loss"]) - float(rb["loss"])) / abs(float(rb["loss"])), "grad_max_rel_diff": worst,
+            "inference_rel_diff": rel(Ha, Hb), "step_moved_H": rel(H_pre, Hb)}
 
 
 def check_conv_message_backward(device="cuda", n_atoms=10, seed=2):
@@ -681,41 +688,6 @@ def check_fused_scatter(device="cuda", n_atoms=14, seed=5):
     out["edge_rel_err"] = rel(reps["1"]["edge_attr"], reps["0"]["edge_attr"])
     out["edges_mod_16"] = float(int(g.num_edges) % 16 == 0) * 1e-9
     return out
-
-
-def check_wide_vs_is(device="cuda", E=4099, nodes=301):
-    """one node-fed set-A MessagePackBlock launch (gather + rotation fused, ragged tail) on the wide schedule vs the input-stationary kernel, and the
-    wide launch repeated (bit-identical: the claim order of the chains must not matter)"""
-    import bench
-    from hamgnn_amd import nn as hnn, ops, plan as P
-    irr = bench.IRREPS["A"]
-    torch.manual_seed(0)
-    m = hnn.MessagePackBlock(irr, irr, bench.SH, irr, 64, [64, 64])
-    m.compile(device, unrotate=True)
-    lay = P.PlanarLayout(irr)
-    g = torch.Generator(device="cpu").manual_seed(1)
-    pos = torch.zeros(2, 3, device=device)
-    ei = torch.stack([torch.zeros(E, dtype=torch.long), torch.ones(E, dtype=torch.long)]).to(device)
-    shift = (torch.randn(E, 3, generator=g) * 4).to(device)
-    geo = ops.Geometry(pos, ei, shift, 26.0, 64, 6, torch.from_numpy(P.wigner_jtab(6)).to(device))
-    fe = torch.randn(E, lay.dim, generator=g).to(device)
-    node = torch.randn(nodes, lay.dim, generator=g).to(device)
-    geo.src = torch.randint(0, nodes, (E,), generator=g).to(device)
-    geo.dst = torch.randint(0, nodes, (E,), generator=g).to(device)
-    rot = torch.from_numpy(P.rotate_table(lay)).to(device)
-    old = ops.WIDE_MODE
-    os.environ["HG_IS_PARTS"] = "1"
-    try:
-        ops.WIDE_MODE = "0"
-        a = m.run_nodes(node, node, fe, geo, rot).clone()
-        ops.WIDE_MODE = "force"
-        b = m.run_nodes(node, node, fe, geo, rot).clone()
-        c = m.run_nodes(node, node, fe, geo, rot).clone()
-        torch.cuda.synchronize()
-    finally:
-        ops.WIDE_MODE = old
-        os.environ.pop("HG_IS_PARTS", None)
-    return {"wide_vs_is": rel(b, a), "wide_repeat_max_abs": float((b - c).abs().max()), "nan": float(torch.isnan(b).any())}
 
 
 def check_structural_zeros(device="cuda", legacy=False, n_atoms=9, seed=11):
@@ -2397,7 +2369,7 @@ def check_small_graph_forward_reproducible(device="cuda", which="A", graph="si2"
                    correlation=2, num_hidden_features=4, use_corr_prod=False, legacy_edge_update=False)
         g = S.add_random_targets(S.random_cell(9, [14, 8, 6, 1], seed=12, density=0.004), 19, seed=12)
     back = HamGNNConvE3(cfg)
-    head = HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=True)
+    head = HamGNNPlusPlusOut(irr, irr, nao_max=19, ham_type="openmx", ham_only=True, symmetrize=True, add_H0=False)
     model = Model(back, head).to(device)
     g = g.to(device)
     runs = []

@@ -58,11 +58,13 @@ def test_device_repack_equals_recompile_on_cpu(cpu_backend):
     """hamgnn_amd/repack.py through the product's own refresh path (training_step -> weights_changed -> refresh_weights)"""
     r = G.check_refresh_equals_recompile(device="cpu")
     assert r["packers"] >= 8 and r["loss_rel_diff"] < 1e-6 and r["grad_max_rel_diff"] < 1e-5, r
+    assert r["inference_rel_diff"] < 1e-6 and r["step_moved_H"] > 1e-3, r      # validate -> step -> validate uses the new weights (ADVICE r5: stale ResidualBlock row program)
 
 
 def test_device_repack_equals_recompile_attention_backbone(cpu_backend):
     r = G.check_refresh_equals_recompile(device="cpu", transformer=True)
     assert r["packers"] >= 8 and r["loss_rel_diff"] < 1e-6 and r["grad_max_rel_diff"] < 1e-5, r
+    assert r["inference_rel_diff"] < 1e-6 and r["step_moved_H"] > 1e-3, r
 
 
 def test_band_energy_loss_backward_on_cpu(cpu_backend):

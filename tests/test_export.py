@@ -73,3 +73,47 @@ def test_container_round_trip_and_c_loader(tmp_path, parts):
         a = back[k]
         assert name == k and int(is_f32) == int(a.dtype.kind == "f") and int(s0) == a.shape[0] and int(s1) == (a.shape[1] if a.ndim > 1 else 1)
         assert int(nbytes) == a.nbytes and int(h) == _fnv(a.tobytes()), k
+
+
+def test_c_loader_refuses_corrupt_containers(tmp_path):
+    """a corrupt header length must not wrap `16 + hlen`, an array's byte count must equal its shape product x 4, offsets must lie inside the
+    file -- the loader returns an error (and frees what it allocated: run under the sanitizers when gcc has them) instead of reading out of bounds"""
+    import struct
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not found")
+    prog = _program()
+    sc = P.is_schedule(prog, 1)
+    good = str(tmp_path / "good.hgprog")
+    X.write_container(good, X.tp_is_arrays(prog, sc, prog.weights), {"entry": "hg_tp_is", "hidden": 16, "out_dim": 8, "lds_bytes": 1024, "nparts": 1, "zero_fill_out": False})
+    data = open(good, "rb").read()
+    (hlen,) = struct.unpack("<Q", data[8:16])
+    hdr = data[16:16 + hlen].decode()
+    cases = {"good": data,
+             "hlen_wraps": data[:8] + struct.pack("<Q", 2 ** 64 - 8) + data[16:],
+             "hlen_past_eof": data[:8] + struct.pack("<Q", len(data)) + data[16:],
+             "truncated": data[:len(data) // 2],
+             "bad_magic": b"HGPROG2\0" + data[8:]}
+    e = json_entry = None
+    import json
+    h = json.loads(hdr)
+    e = h["arrays"][1]
+    for name, (key, val) in {"nbytes_ne_shape": ("nbytes", e["nbytes"] - 4), "offset_past_eof": ("offset", (len(data) + 64) // 64 * 64)}.items():
+        h2 = json.loads(hdr)
+        h2["arrays"][1][key] = val
+        raw = json.dumps(h2).encode()
+        assert len(raw) <= hlen
+        cases[name] = data[:16] + raw + b" " * (hlen - len(raw)) + data[16 + hlen:]
+    src = tmp_path / "main.c"
+    src.write_text(C_MAIN)
+    exe = str(tmp_path / "loader")
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+    if subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror"] + san + ["-I", os.path.join(ROOT, "include"), str(src), "-o", exe], capture_output=True).returncode:
+        subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    for name, blob in cases.items():
+        pth = str(tmp_path / (name + ".hgprog"))
+        open(pth, "wb").write(blob)
+        cp = subprocess.run([exe, pth], capture_output=True, text=True)
+        if name == "good":
+            assert cp.returncode == 0, cp.stdout + cp.stderr
+        else:
+            assert cp.returncode == 1 and "load failed" in cp.stdout and "ERROR" not in cp.stderr, (name, cp.stdout, cp.stderr[-600:])

@@ -59,48 +59,6 @@ def test_message_pack_single_part_vs_oracle(case):
     assert r["kernel"] == "is" and r["rel_err"] < G.TOL
 
 
-@pytest.fixture
-def force_wide(monkeypatch):
-    """every eligible launch (single part, tensor-product program) on the wide schedule (csrc/tp_wide.hip), whatever its size"""
-    from hamgnn_amd import ops
-    monkeypatch.setattr(ops, "WIDE_MODE", "force")
-    monkeypatch.setenv("HG_IS_PARTS", "1")
-
-
-@pytest.mark.parametrize("case", list(range(6)) + ["A", "B"])
-def test_message_pack_wide_schedule_vs_oracle(case, force_wide):
-    """r5: the wide schedule (one 16-wave workgroup per 16-edge tile, S fragments through the LDS, column-window chains, staging shares as tasks)
-    forced on small inputs: random irreps sets with 16- and 64-wide radial layers and the two shipped sets, vs the fp64 oracle"""
-    import bench
-    kw = dict(irr=bench.IRREPS[case], sh=bench.SH, seed=7, E=37, radial=(64, 64)) if isinstance(case, str) else dict(seed=case, radial=(64, 64) if case % 2 else (16, 16))
-    r = G.check_message_pack_random(**kw)
-    print(r)
-    assert r["kernel"] == "wide" and r["rel_err"] < G.TOL
-
-
-def test_backbone_golden_wide_schedule(force_wide):
-    """whole backbone (reference fixture) with every MessagePackBlock launch on the wide schedule: node-fed launches (gather + rotation in the
-    staging shares), the fused receiver scatter in the epilogue, the PairInteractionBlock's skip Linear as IT_LIN chains"""
-    r = G.check_backbone()
-    print(r)
-    assert r["backbone_node_rel_err"] < G.TOL and r["backbone_edge_rel_err"] < G.TOL
-
-
-def test_fused_node_scatter_wide_schedule(force_wide):
-    r = G.check_fused_scatter()
-    print(r)
-    assert r["node_rel_err"] < 2e-6 and r["edge_rel_err"] < 2e-6, r
-
-
-def test_wide_schedule_equals_input_stationary_bitwise():
-    """same items, same fragments, one task per tile cell and phase, the tile value as GEMM2's accumulator init in both kernels: the two schedules
-    must agree to the last bit when the order of the items inside a (phase, segment) is the same -- checked to 1e-6 (the phases differ), and the wide
-    launch against itself bit for bit (claim order must not matter)"""
-    r = G.check_wide_vs_is()
-    print(r)
-    assert r["wide_vs_is"] < 2e-6 and r["wide_repeat_max_abs"] == 0.0
-
-
 def test_front_door_checkpoint_and_datasets_reproduce_the_fixtures():
     """SURVEY 8f-1 through the front door: Model.load_from_checkpoint(.ckpt) + NPZGraphDataset / LMDBGraphDataset -> HIP forward == the
     reference's outputs of the backbone and head fixtures (tests/gpu_checks.py:check_front_door).  Files written by real liblmdb / Lightning
@@ -147,7 +105,10 @@ def test_unread_irreps_of_the_last_pair_block(kw):
         return
     assert r["dead_irreps"] >= (5 if "irr" in kw else 1) and r["alive_declared"] == 1.0, r
     assert r["ham_rel_err"] < G.SAME_MATH_TOL and r["ham_noise_max_abs"] == 0.0 and r["dead_blocks_max_abs"] == 0.0, r
-    assert r["edge_attr_rel_err"] == 0.0 and r["wider_head_rel_err"] == 0.0 and r["last_pair_mfma_ratio"] < (0.9 if "irr" in kw else 1.0), r
+    # (one layer: the last pair block is also the FIRST -- its forward launch takes the structural-zero shortcut, the lazy complete re-run does not: two programs)
+    same_launches = kw.get("num_layers") != 1
+    assert (r["edge_attr_rel_err"] == 0.0 and r["wider_head_rel_err"] == 0.0) if same_launches else max(r["edge_attr_rel_err"], r["wider_head_rel_err"]) < G.SAME_MATH_TOL, r
+    assert r["last_pair_mfma_ratio"] < (0.9 if "irr" in kw else 1.0), r
     assert r["training_rows_rel_err"] < G.SAME_MATH_TOL and r["training_alive_declared"] == 0.0 and r["refresh_rel_err"] < G.SAME_MATH_TOL, r
 
 
@@ -388,7 +349,9 @@ def test_full_model_backward_default_irreps():
 def test_device_repack_equals_recompile(legacy):
     r = G.check_refresh_equals_recompile(legacy=legacy)
     print(r)
-    assert r["packers"] >= 8 and r["loss_rel_diff"] < 1e-6 and r["grad_max_rel_diff"] < 1e-5, r
+    # (device repack: hg_block_gemm forms the L' products in fp64 in its own order, one fp64 ulp from the host's BLAS -> fp32 weights that may differ in the last bit)
+    assert r["packers"] >= 8 and r["loss_rel_diff"] < G.SAME_MATH_TOL and r["grad_max_rel_diff"] < G.TOL, r
+    assert r["inference_rel_diff"] < G.SAME_MATH_TOL and r["step_moved_H"] > 1e-3, r      # inference -> step -> inference: no stale cached chain
 
 
 def test_full_model_training_loss_falls():
@@ -533,23 +496,41 @@ def test_rccl_backend_single_rank():
     assert cp.returncode == 0 and "RCCL_OK" in cp.stdout, cp.stdout[-1500:] + cp.stderr[-1500:]
 
 
-def test_bench_script_two_rank_path_on_one_gpu():
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one process per rank), on a 1-GPU box: both ranks
-    share cuda:0 and talk over gloo (HG_BENCH_SAME_DEVICE / HG_BENCH_BACKEND test hooks; RCCL refuses two ranks on one device).
-    Checks the sharded N > 1 code path of the benchmark itself: one JSON line from rank 0, whole-job edge count, n_gpus."""
+@pytest.mark.parametrize("launcher", ["bare", "torchrun"])
+def test_bench_script_two_rank_path_on_one_gpu(launcher):
+    """`bench.py --gpus 2` on a 1-GPU box: both ranks share cuda:0 and talk over gloo (HG_BENCH_SAME_DEVICE / HG_BENCH_BACKEND test hooks; RCCL refuses two
+    ranks on one device).  "bare": the ONE command `python bench.py --gpus 2` -- the script launches its own ranks (r6; VERDICT r5 #2: the first 8-GPU
+    invocation must not die in argument handling); "torchrun": exactly as the driver launches it (torch.distributed.run, one process per rank).
+    Checks the sharded N > 1 code path of the benchmark itself: one JSON line from rank 0, whole-job edge count, n_gpus, return code."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HG_BENCH_SAME_DEVICE="1", HG_BENCH_BACKEND="gloo")
-    cp = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                         "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                         "--workload", "si512", "--irreps", "B"], capture_output=True, text=True, timeout=600, env=env)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "si512", "--irreps", "B"]
+    head = [sys.executable] if launcher == "bare" else [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                         "--master-port", "29547"]
+    cp = subprocess.run(head + tail, capture_output=True, text=True, timeout=600, env=env)
     assert cp.returncode == 0, cp.stdout[-1500:] + cp.stderr[-1500:]
     lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, cp.stdout[-1500:]
     r = json.loads(lines[0])
     print({k: r[k] for k in ("value", "n_gpus", "ms_per_step", "scaling")})
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["value"] > 0 and r["scaling"] == "strong" and "cpu_baseline" not in r
-    assert "pair-sharded" in r["config"]["parallelism"]
+    assert "pair-sharded" in r["config"]["parallelism"] and r["sharded_check"]["rel_err"] < 1e-5
+
+
+def test_bench_script_propagates_a_failing_rank():
+    """a rank that cannot run (here: --gpus 2 without the shared-device hook on a 1-GPU box -> LOCAL_RANK 1 has no device) makes the ONE-command form exit
+    non-zero and say which rank it was, instead of hanging or printing a line"""
+    import os, subprocess, sys
+    if torch.cuda.device_count() > 1:
+        pytest.skip("needs a box with exactly one GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HG_BENCH_SAME_DEVICE")}
+    cp = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "si64", "--irreps", "B"],
+                        capture_output=True, text=True, timeout=300, env=env)
+    assert cp.returncode != 0 and "BENCH_RANK_FAILURE" in cp.stderr and not [l for l in cp.stdout.splitlines() if l.startswith("{")], cp.stdout[-800:] + cp.stderr[-800:]
 
 
 def test_multi_crystal_batch_vs_oracle():
@@ -651,7 +632,7 @@ def test_attribute_style_graph_object():
     """a non-dict graph object (PyG Data look-alike) through backbone and head; the topology cache is stored on the object"""
     r = G.check_attribute_style_graph()
     print(r)
-    assert r["node_attr"] < 1e-6 and r["edge_attr"] < 1e-6 and r["node_vs_fixture"] < G.TOL and r["head_vs_fixture"] < G.TOL      # (split launches: claim-order rounding)
+    assert r["node_attr"] == 0.0 and r["edge_attr"] == 0.0 and r["node_vs_fixture"] < G.TOL and r["head_vs_fixture"] < G.TOL      # (the same launches on the same rows: bit-identical since r6)
     assert r["cache_reused"]
     assert abs(r["sparsity_ratio"] - r["sparsity_ratio_fixture"]) < 1e-6 * r["sparsity_ratio_fixture"]
 
@@ -660,8 +641,9 @@ def test_captured_forward_replay_si2():
     """BASELINE config #1 as a HIP graph: replay == eager (also after an in-place position update), and faster than eager launches"""
     r = G.check_captured_forward_si2()
     print(r)
-    # (split launches accumulate a segment's items in claim order: run-to-run differences at fp32 rounding level)
-    assert r["replay_vs_eager"] < 5e-6 and r["replay_vs_eager_moved"] < 5e-6 and r["moved_changes_H"] > 1e-4
+    # (the replayed graph holds the finer 2d split: a workgroup per (segment, share of its phases) ADDING its tiles -- another order of the same sums than the
+    #  eager launches', and the one schedule whose own order is not fixed: G.SAME_MATH_TOL)
+    assert r["replay_vs_eager"] < G.SAME_MATH_TOL and r["replay_vs_eager_moved"] < G.SAME_MATH_TOL and r["moved_changes_H"] > 1e-4
     assert r["replay_ms"] < 1.1 * r["eager_ms"] and r["replay_ms"] < 2.0     # r1: 4.4-4.8 ms per forward, eager or replayed
 
 
@@ -739,14 +721,14 @@ def test_row_program_kernel_vs_separate_kernels_and_twin(seed):
     import bench
     r = G.check_row_program_kernel(seed=seed, **({"irr": bench.IRREPS["A"], "nao": 19, "rows": 45} if seed == 3 else {}))
     print(r)
-    assert r["used"] and r["vs_separate_rel_err"] < 5e-6 and r["vs_twin_rel_err"] < 5e-6, r
+    assert r["used"] and r["vs_separate_rel_err"] < G.SAME_MATH_TOL and r["vs_twin_rel_err"] < G.SAME_MATH_TOL, r      # (K order of the fused Linear units vs the streaming Linear's)
 
 
 def test_round3_kernels_full_size_properties():
     """hg_row_program at 822 350 rows and hg_tp_wgrad at 131 072 edges (set-A): size-independent properties, see the check"""
     r = G.check_new_kernels_full_size()
     print(r)
-    assert r["rowprog_vs_separate"] < 5e-6 and r["rowprog_subrange"] < 1e-6
+    assert r["rowprog_vs_separate"] < G.SAME_MATH_TOL and r["rowprog_subrange"] == 0.0      # (a sub-range of the rows through the same kernel: the same sums)
     assert r["wgrad_linearity_acc"] < 2e-5 and r["wgrad_linearity_gs"] < 2e-5 and r["wgrad_splits"] < 2e-5 and r["wgrad_halves"] < 2e-5
 
 

@@ -251,17 +251,11 @@ def test_input_stationary_schedule_vs_golden(golden_dir):
     s2 = P.is_schedule(prog2)
     a = emu.run_program_is(prog2, s2, [xs, xd, fe], (hn, he), D, lmax)
     assert rel(a, emu.run_program(prog2, [xs, xd, fe], (hn, he), D, lmax)) < 1e-12
-    # late r5 (experiment, off by default): one workgroup per (segment set, share of its phases), tiles added into zero-filled rows
+    # replayed hipGraphs only (graph_capture.CapturedForward): one workgroup per (segment set, share of its phases), tiles added into zero-filled rows
     for pr, want in ((prog, outp), (prog2, a)):
         s2d = P.is_schedule(pr, ("2d", 3, 2))
         assert 3 <= s2d.part_table.shape[0] <= 6
         assert rel(emu.run_program_is(pr, s2d, [xs, xd, fe], (hn, he), D, lmax), want) < 1e-12
-    # late r5: phase parts (the smallest crystals) -- all segments in every workgroup, the PHASES dealt to the workgroups of a tile, tiles added into zero-filled rows
-    for pr, want in ((prog, outp), (prog2, a)):
-        sp2 = P.is_schedule(pr, "phases")
-        assert sp2.atomic_out and 1 <= sp2.part_table.shape[0] <= P.PHASE_PARTS_MAX and sp2.part_table.shape[1] == P.IS_PART_I32
-        assert sorted(int(x) for p_ in sp2.part_table for x in range(p_[2], p_[2] + p_[3])) == list(range(sp2.phase_table.shape[0]))      # every phase in exactly one part
-        assert rel(emu.run_program_is(pr, sp2, [xs, xd, fe], (hn, he), D, lmax), want) < 1e-12
 
 
 @pytest.mark.parametrize("which", ["A", "B"])
@@ -400,10 +394,6 @@ def test_merged_items_shipped_irreps(which):
     s2d = P.is_schedule(plain, ("2d", plain.seg_table.shape[0], 3))      # (experiment) every output segment's phases on three workgroups
     assert s2d.atomic_out and s2d.part_table.shape[0] > (2 if which == "A" else 1) * plain.seg_table.shape[0]
     assert rel(lay.from_planar(emu.run_program_is(plain, s2d, [xs, xd, fe], (hn, he), D, 6)), want) < 1e-6
-    # late r5: phase parts of the merged program (the smallest crystals): several phases per set, each workgroup adds the segments its phases feed
-    spp = P.is_schedule(merged, "phases")
-    assert spp.atomic_out and spp.part_table.shape[0] >= (8 if which == "A" else 2) and (which == "B" or max(spp.part_cost) < 0.3 * sum(sc.part_cost))
-    assert rel(lay.from_planar(emu.run_program_is(merged, spp, [xs, xd, fe], (hn, he), D, 6)), want) < 1e-6
     # with the PairInteractionBlock skip Linear (plain IT_LIN items into tiles that merged items write as well)
     m2 = P.build_message_pack_program(sd, irr, irr, sh, irr, False, skip, merge_groups=groups)
     p2 = P.build_message_pack_program(sd, irr, irr, sh, irr, False, skip)
@@ -1148,125 +1138,3 @@ def test_lite_mode_message_pack_backward_vs_autograd(seed):
         for k in want_w:
             scale = max(float(want_w[k].abs().max()), 1e-3)
             assert float((grads[k].reshape(want_w[k].shape) - want_w[k]).abs().max()) < 2e-6 * scale, (k, irr, sh)
-
-
-
-
-def _wide_inputs(golden_dir):
-    f = load(golden_dir, "message_pack_block")
-    sd, i = f["weights"], f["inputs"]
-    lay = P.PlanarLayout(MINI)
-    lmax = 3
-    n = i["sh"][:, 1:4] / math.sqrt(3.0)
-    D = emu.edge_wigner_all(n, lmax)
-    xs, xd, fe = (emu.rotate_rows(lay.to_planar(i[k]), lay, D, lmax) for k in ("src", "dst", "edge_feats"))
-    hn = emu.radial_hidden(i["rbf"], P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
-    he = emu.radial_hidden(i["rbf"], P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
-    return f, sd, lay, lmax, D, (xs, xd, fe), (hn, he)
-
-
-def test_wide_schedule_vs_golden(golden_dir):
-    """plan.wide_schedule (csrc/tp_wide.hip, r5): the same items cut into S tasks + column-window compute tasks + staging shares -> the reference
-    fixture's rows and, to rounding, the input-stationary schedule's; the emulator checks the schedule's invariants on the way (tests/emu.py)."""
-    f, sd, lay, lmax, D, srcs, h2 = _wide_inputs(golden_dir)
-    prog = P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=True)
-    ws = P.wide_schedule(prog)
-    assert ws.mfma_tasks == prog.mfma_per_wave - prog.mfma_odd_skipped         # nothing is recomputed: the S fragments travel through the LDS
-    outw = emu.run_program_wide(prog, ws, list(srcs), h2, D, lmax)
-    assert rel(lay.from_planar(outw), f["outputs"]["out"]) < 1e-6
-    outi = emu.run_program_is(prog, P.is_schedule(prog), list(srcs), h2, D, lmax)
-    assert rel(outw, outi) < 1e-12
-    assert rel(emu.run_program_wide(prog, ws, list(srcs), h2, D, lmax, order="reverse_compute"), outw) < 1e-12      # claim order does not matter
-    # with the PairInteractionBlock skip o3.Linear folded in (IT_LIN compute tasks, no S)
-    skip = np.random.default_rng(3).standard_normal(sum(m * m for m, _, _ in so3.Irreps(MINI)))
-    prog2 = P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=False, skip_weight=skip)
-    w2 = P.wide_schedule(prog2)
-    assert (w2.task_table[:, 19][w2.task_table[:, 0] == P.WT_COMPUTE] == P.IT_LIN).any()
-    a = emu.run_program_wide(prog2, w2, list(srcs), h2, D, lmax)
-    assert rel(a, emu.run_program(prog2, list(srcs), h2, D, lmax)) < 1e-12
-    # splitting harder (more, narrower windows) changes nothing
-    old = P.WIDE_TASKS_PER_WAVE, P.WIDE_ACC_CAP
-    try:
-        P.WIDE_TASKS_PER_WAVE, P.WIDE_ACC_CAP = 40.0, 4
-        w3 = P.wide_schedule(prog)
-        assert w3.task_table.shape[0] > ws.task_table.shape[0]
-        assert rel(emu.run_program_wide(prog, w3, list(srcs), h2, D, lmax), outw) < 1e-12
-    finally:
-        P.WIDE_TASKS_PER_WAVE, P.WIDE_ACC_CAP = old
-
-
-def test_wide_schedule_own_mode_vs_golden(golden_dir):
-    """plan.wide_schedule(mode="own"): every wave owns fixed (segment key, column window) cells for the whole tile, counters instead of barriers -- the
-    emulator interleaves the 16 streams two ways (round-robin, maximally skewed) and checks the hazards on the data (tests/emu.py:_run_program_wide_own)"""
-    f, sd, lay, lmax, D, srcs, h2 = _wide_inputs(golden_dir)
-    skip = np.random.default_rng(3).standard_normal(sum(m * m for m, _, _ in so3.Irreps(MINI)))
-    for prog in (P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=True),
-                 P.build_message_pack_program(sd, MINI, MINI, SH, MINI, unrotate=False, skip_weight=skip)):
-        ws = P.wide_schedule(prog, mode="own")
-        assert ws.lay["own"] == 1 and ws.mfma_tasks == prog.mfma_per_wave - prog.mfma_odd_skipped and ws.balance > 0.8
-        kinds = set(int(t[0]) for t in ws.task_table)
-        assert {P.WT_WAIT, P.WT_SIGNAL, P.WT_S, P.WT_COMPUTE, P.WT_STAGE} <= kinds
-        ref = emu.run_program(prog, list(srcs), h2, D, lmax)
-        a = emu.run_program_wide(prog, ws, list(srcs), h2, D, lmax)
-        b = emu.run_program_wide(prog, ws, list(srcs), h2, D, lmax, order="reverse_compute")
-        assert rel(a, ref) < 1e-12 and rel(b, ref) < 1e-12
-
-
-def test_wide_schedule_merged_items_random_irreps():
-    """merged items (rows of several small output segments in one MFMA row tile) on the wide schedule, random weights vs the oracle's block"""
-    import torch
-    from oracle import e3, hamgnn_ref as R
-    irr, sh = "6x0e+3x0o+5x1o+2x1e+3x2e+2x2o+2x3o+1x3e+2x4e+1x5o", "0e+1o+2e+3o+4e+5o"
-    groups = P.choose_merge_groups(irr, irr, sh, irr, 16)
-    assert groups
-    prev = torch.get_default_dtype()
-    torch.set_default_dtype(torch.float64)
-    try:
-        torch.manual_seed(5)
-        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[16, 16])
-        E = 19
-        g = torch.Generator().manual_seed(2)
-        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
-        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
-        shv = e3.spherical_harmonics(list(range(6)), n, True, "component")
-        rbf = torch.randn(E, 8, generator=g)
-        want = ref(src, dst, ef, shv, rbf).detach().numpy()
-    finally:
-        torch.set_default_dtype(prev)
-    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
-    lay = P.PlanarLayout(irr)
-    D = emu.edge_wigner_all(n.numpy(), 6)
-    xs, xd, fe = (emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, 6) for t in (src, dst, ef))
-    hn = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
-    he = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
-    merged = P.build_message_pack_program(sd, irr, irr, sh, irr, True, merge_groups=groups)
-    ws = P.wide_schedule(merged)
-    got = emu.run_program_wide(merged, ws, [xs, xd, fe], (hn, he), D, 6)
-    assert rel(lay.from_planar(got), want) < 1e-6
-
-
-@pytest.mark.parametrize("which", ["A", "B"])
-def test_wide_schedule_shipped_irreps(which):
-    """the wide schedule of the shipped irreps sets: LDS budget of a whole CU, as many MFMAs as the program has, enough tasks per pool for 16 waves"""
-    import torch
-    import bench
-    from hamgnn_amd import nn as hnn
-    irr = bench.IRREPS[which]
-    torch.manual_seed(0)
-    m = hnn.MessagePackBlock(irr, irr, bench.SH, irr, 64, [64, 64])
-    groups = P.choose_merge_groups(irr, irr, bench.SH, irr, 64)
-    prog = P.build_message_pack_program(hnn._np_sd(m), irr, irr, bench.SH, irr, True, None, merge_groups=groups)
-    wo = P.wide_schedule(prog, mode="own")                                      # whole-tile ownership: the TOTAL loads balance (no per-phase barrier)
-    assert wo.lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES and wo.mfma_tasks == prog.mfma_per_wave - prog.mfma_odd_skipped and wo.balance > 0.9
-    ws = P.wide_schedule(prog, mode="pools")
-    assert ws.lay["lds_floats"] * 4 <= P.WIDE_LDS_BYTES and ws.mfma_tasks == prog.mfma_per_wave - prog.mfma_odd_skipped
-    assert ws.balance > 0.7
-    T = ws.task_table
-    comp = T[T[:, 0] == P.WT_COMPUTE]
-    assert (comp[:, 15] * comp[:, 9] <= P.WIDE_ACC_CAP).all() and (comp[:, 15] <= P.WIDE_NCW_MAX).all()
-    for pl in range(1, ws.nphase + 1):
-        heads = T[[int(c[0]) for c in ws.chain_table if int(c[2]) == pl]]
-        assert (heads[:, 0] == P.WT_COMPUTE).sum() >= 8                        # compute chains per phase
-        assert sum(int(t[2]) for t in heads if int(t[0]) == P.WT_S) <= ws.lay["sbuf_slots"]
-        busy = sum(int(ws.stream_table[pl][w][1]) > int(ws.stream_table[pl][w][0]) for w in range(P.WIDE_WAVES))
-        assert busy >= P.WIDE_WAVES - 2                                        # (nearly) every wave has work in every pool

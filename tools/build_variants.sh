@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../hamgnn_amd/csrc"
 make -j8 > /dev/null
 mkdir -p ../lib/variants
 FILES=${HG_VARIANT_FILES:-tp_is}
-ALL="tp_fused tp_is tp_wide tp_wgrad aux_kernels head attention linear linear_wgrad rowprog block_gemm corr3"
+ALL="tp_fused tp_is tp_wgrad aux_kernels head attention linear linear_wgrad rowprog block_gemm corr3"
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   ( objs=""

@@ -5,7 +5,7 @@ V=hamgnn_amd/lib/variants
 rm -f $out/bench.log
 for rep in 1 2 3; do
   for n in $2; do
-    HG_MP_WIDE=0 HG_LIB_PATH=$PWD/$V/lib_$n.so timeout 60 python tests/bench_tp.py --nodes 16384 --reps 8 --tag $n 2>&1 | tail -1 >> $out/bench.log
+    HG_LIB_PATH=$PWD/$V/lib_$n.so timeout 60 python tests/bench_tp.py --nodes 16384 --reps 8 --tag $n 2>&1 | tail -1 >> $out/bench.log
   done
 done
 python - <<PY
