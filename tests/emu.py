@@ -43,6 +43,26 @@ def radial_hidden(rbf, layers):
     return h
 
 
+S_SPLIT = None      # (terms of W3, terms of h, highest kept order i + j): emulate the radial scale on bf16 MFMAs with operands split into bf16 terms
+
+
+S_SPLIT_FMT = "bf16"
+
+
+def bf16_terms(x, n):
+    """x = t0 + t1 + ... (+ residual): n bf16 (or, S_SPLIT_FMT = "f16", IEEE half) terms by repeated round-to-nearest-even of the remainder"""
+    out, rem = [], np.asarray(x, dtype=np.float64)
+    for _ in range(n):
+        if S_SPLIT_FMT == "f16":
+            t = rem.astype(np.float32).astype(np.float16).astype(np.float64)
+        else:
+            u = rem.astype(np.float32).view(np.uint32)
+            t = ((u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000).astype(np.uint32).view(np.float32).astype(np.float64)
+        out.append(t)
+        rem = rem - t
+    return out
+
+
 def _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype):
     """one item record on one 16-edge column tile, fragment-exact (tile: [rto*16, nco, 16], updated in place / returned)."""
     E = srcs[0].shape[0]
@@ -120,13 +140,21 @@ def _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype):
         S = np.zeros((rtm, 16, 16), dtype=dtype)
         hh = np.zeros((E, Hp), dtype=dtype)
         hh[:, :H] = h2[mlp]
+        split = S_SPLIT                                                               # pricing aid (profiles/r06_tp_is.md): S on bf16 MFMAs with split operands
         for G in range(Hp // 16):
             for q in range(4):
                 B = np.zeros((4, 16), dtype=dtype)
                 for g in range(4):
                     B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
                 for rt in range(rtm):
-                    S[rt] += W3[G, rt, :, :, q].T @ B
+                    if split is None:
+                        S[rt] += W3[G, rt, :, :, q].T @ B
+                    else:
+                        wt, bt = bf16_terms(W3[G, rt, :, :, q].T, split[0]), bf16_terms(B, split[1])
+                        for i_, w_ in enumerate(wt):
+                            for j_, b_ in enumerate(bt):
+                                if i_ + j_ <= split[2]:
+                                    S[rt] += w_ @ b_
         CF = Wt[cf:cf + rtm * nc * 16].reshape(rtm, nc, 16)                           # [rt][c][row = 4g + r]
         mid = mid * S[:, None, :, :] * CF[:, :, :, None]
         A2 = Wt[a2:a2 + rto * rtm * 4 * 64].reshape(rto, rtm, 4, 16, 4)               # [rt'][rt][k=g][i][r]

@@ -54,6 +54,13 @@ def test_soc_head_backward_vs_autograd(cpu_backend, kw):
     assert all(v < G.TOL for k, v in r.items() if k.endswith("rel_err")), r
 
 
+def test_small_graph_reproducibility_check_runs_on_the_stand_ins(cpu_backend):
+    """the r6 GPU check (split launches bit-reproducible) through the host code on the CPU stand-ins: the launches it means to test ARE split launches
+    (the stand-ins are deterministic by construction: what is pinned here is the check's plumbing and the dispatch decision)"""
+    r = G.check_small_graph_forward_reproducible(device="cpu", graph="cell9", reps=2)
+    assert r["parts"] != ["1"] and r["H_max_abs_diff"] == 0.0 and r["H_absmax"] > 0, r
+
+
 def test_device_repack_equals_recompile_on_cpu(cpu_backend):
     """hamgnn_amd/repack.py through the product's own refresh path (training_step -> weights_changed -> refresh_weights)"""
     r = G.check_refresh_equals_recompile(device="cpu")
