@@ -78,13 +78,24 @@ def make_graph(workload, nao, soc=False):
     return S.add_random_targets(g, nao, seed=0, soc=soc)
 
 
-def cpu_baseline(workload, irreps_key, nao, budget_s=30.0, lite=False, soc=False, reps=3):
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, irreps_key, nao, budget_s=30.0, lite=False, soc=False, reps=3, full=False):
     """Oracle (unfused torch port of the reference op graph: one einsum chain per e3nn instruction, materialised `mid`, index_add_ scatter) on the
     host cores, on a BOUNDED sample of the same workload: the largest crystal of the workload's generator whose forward fits budget_s / (reps + 1)
     seconds, `reps` timed forwards (median reported, all times listed), the thread count picked from 8 ... all host threads by a calibration run.
     A reported baseline, not the target: the GPU / CPU ratio says the port is slow, not that the kernel is good (roofline.frac is the figure of merit)."""
-    from oracle import hamgnn_ref as R
+    from oracle import e3, hamgnn_ref as R
     from hamgnn_amd.data import synthetic as S
+    e3.CONTRACTION = "optimized"               # the timed port contracts weights first (what opt_einsum_fx does for e3nn's generated code); the parity oracle keeps the naive order
     ncpu = os.cpu_count() or 1
     cand = [int(os.environ["HG_CPU_THREADS"])] if "HG_CPU_THREADS" in os.environ else sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)})
     torch.set_num_threads(cand[0])
@@ -111,6 +122,21 @@ def cpu_baseline(workload, irreps_key, nao, budget_s=30.0, lite=False, soc=False
             head(g, model(g))
         return time.perf_counter() - t0
 
+    if full:
+        # the whole configuration instead of a bounded sample (BASELINE config #2 is the one the port finishes in seconds: si512, set-B, 43 k edges): every
+        # thread count up to the host's, `reps` forwards each, median per count -- minutes of host time, NOT part of the default run (tools/cpu_baseline_full.sh)
+        g = make_graph(workload, nao, soc=soc)
+        run(graph(12))
+        sweep = {}
+        for c in cand:
+            torch.set_num_threads(c)
+            run(g)
+            sweep[c] = sorted(run(g) for _ in range(reps))[reps // 2]
+        cores = min(sweep, key=sweep.get)
+        return {"value": g.num_edges / sweep[cores], "unit": "edges/s", "cores": cores, "kind": "port", "reps": reps, "cpu_model": cpu_model(), "host_threads": ncpu,
+                "edges_per_s_by_threads": {str(k): round(g.num_edges / v, 1) for k, v in sweep.items()}, "seconds_per_forward_by_threads": {str(k): round(v, 3) for k, v in sweep.items()},
+                "contraction": e3.CONTRACTION,
+                "sample": f"the WHOLE {workload} crystal ({g.num_nodes} atoms / {g.num_edges} directed edges), irreps set-{irreps_key}, median of {reps} forwards per thread count, fp32"}
     g0 = graph(12)
     run(g0)                                    # warm-up (first touch, thread pool, the cached 3j tensors)
     tried = {}
@@ -128,7 +154,7 @@ def cpu_baseline(workload, irreps_key, nao, budget_s=30.0, lite=False, soc=False
     med = sorted(times)[len(times) // 2]
     return {"value": g.num_edges / med, "unit": "edges/s", "cores": cores, "kind": "port", "reps": reps,
             "seconds_per_forward": [round(t, 2) for t in times], "threads_tried": {str(k): round(g0.num_edges / v, 1) for k, v in tried.items()},
-            "host_threads": ncpu,
+            "host_threads": ncpu, "cpu_model": cpu_model(), "contraction": e3.CONTRACTION,
             "sample": f"{workload}-like crystal, {g.num_nodes} atoms / {g.num_edges} directed edges{', SOC/so3 head' if soc else ''}, median of {reps} forwards, fp32, "
                       f"torch {cores} threads (fastest of {sorted(tried)} tried in rising order on a {g0.num_edges}-edge calibration crystal, stopping at the first slower count: "
                       f"edges/s per count in threads_tried)"}
@@ -298,6 +324,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-complete-pass", action="store_true", help="skip the extra pass with every path of the reference's op graph issued (value_complete_programs; N = 1 only, after the timed region)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="with --cpu-baseline-only: the port on the WHOLE workload with a thread sweep (minutes; meant for --workload si512 --irreps B)")
     ap.add_argument("--accuracy-from", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy leg (fp64 oracle on a bounded sub-crystal, host cores)")
     args = ap.parse_args()
@@ -305,7 +332,7 @@ def main():
         if args.accuracy_from:
             print("ACCURACY " + json.dumps(accuracy_vs_oracle(args.accuracy_from)), flush=True)
             return
-        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.workload, args.irreps, args.nao, lite=args.lite, soc=args.soc)), flush=True)
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.workload, args.irreps, args.nao, lite=args.lite, soc=args.soc, full=args.cpu_baseline_full)), flush=True)
         return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:

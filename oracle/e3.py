@@ -362,6 +362,9 @@ class SphericalHarmonics(torch.nn.Module):
 Instruction = collections.namedtuple("Instruction", "i_in1 i_in2 i_out connection_mode has_weight path_weight path_shape")
 
 
+CONTRACTION = "outer"      # "optimized": the contraction order opt_einsum_fx would pick for the uvw paths (TensorProduct.forward); timing only, see there
+
+
 class TensorProduct(torch.nn.Module):
     def __init__(self, irreps_in1, irreps_in2, irreps_out, instructions, in1_var=None, in2_var=None, out_var=None,
                  irrep_normalization="component", path_normalization="element", internal_weights=None,
@@ -433,6 +436,16 @@ class TensorProduct(torch.nn.Module):
                 off += n
             zw = "z" if batch_w else ""
             mode = ins.connection_mode
+            if CONTRACTION == "optimized" and mode == "uvw" and m2 == 1 and w is not None and not batch_w:
+                # TIMING form (bench.py's cpu_baseline leg only; the parity oracle keeps the naive order below): e3nn 0.5.0 hands its generated einsums to
+                # opt_einsum_fx, which reorders `uvw,ijk,zuvij->zwk` for the example shapes -- with one copy of the second operand (the spherical harmonics: v = 1)
+                # and shared weights the cheap order is weights first, 3j tensor with the harmonics second, and no [Z, u, v, i, j] outer product is ever formed
+                t = torch.einsum("zui,uw->zwi", x1, w[:, 0, :])
+                cy = torch.einsum("zj,ijk->zik", x2[:, 0, :], C)
+                r = torch.bmm(t, cy)
+                r = ins.path_weight * r.flatten(1)
+                outs[ins.i_out] = r if outs[ins.i_out] is None else outs[ins.i_out] + r
+                continue
             # contraction order of e3nn's generated code: outer product of the inputs, then the 3j tensor, then the weights
             if mode == "uvw":
                 xx = torch.einsum("zui,zvj->zuvij", x1, x2)

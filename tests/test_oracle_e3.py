@@ -152,3 +152,27 @@ def test_message_pack_shapes_set_A():
     sh = e3.Irreps("0e+1o+2e+3o+4e+5o")
     mid, ins = tp_instructions(A, sh, A)
     assert len(ins) == 255 and mid.dim == 17523 and mid.num_irreps == 3589 and len(mid.simplify()) == 13
+
+
+def test_timed_contraction_order_equals_the_parity_order():
+    """bench.py's cpu_baseline leg times the port with the uvw paths contracted weights-first (e3.CONTRACTION = "optimized": what opt_einsum_fx does to e3nn's
+    generated einsums); the parity oracle keeps the naive outer-product order.  Same numbers."""
+    import torch
+    from oracle import e3
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        i1, i2, io = e3.Irreps("5x0e+3x1o+2x2e"), e3.Irreps("0e+1o+2e"), e3.Irreps("4x0e+2x1o+3x1e+2x2e")
+        ins = [(a, b, c, "uvw", True) for a, (_, ir1) in enumerate(i1) for b, (_, ir2) in enumerate(i2) for c, (_, iro) in enumerate(io) if iro in ir1 * ir2]
+        tp = e3.TensorProduct(i1, i2, io, ins, internal_weights=True, shared_weights=True)
+        x, y = torch.randn(7, i1.dim), torch.randn(7, i2.dim)
+        a = tp(x, y)
+        e3.CONTRACTION = "optimized"
+        try:
+            b = tp(x, y)
+        finally:
+            e3.CONTRACTION = "outer"
+    finally:
+        torch.set_default_dtype(prev)
+    assert len(ins) > 10 and float((a - b).abs().max()) < 1e-12 * float(a.abs().max())
