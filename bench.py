@@ -97,7 +97,12 @@ def cpu_baseline(workload, irreps_key, nao, budget_s=30.0, lite=False, soc=False
     from hamgnn_amd.data import synthetic as S
     e3.CONTRACTION = "optimized"               # the timed port contracts weights first (what opt_einsum_fx does for e3nn's generated code); the parity oracle keeps the naive order
     ncpu = os.cpu_count() or 1
-    cand = [int(os.environ["HG_CPU_THREADS"])] if "HG_CPU_THREADS" in os.environ else sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)})
+    if "HG_CPU_THREADS" in os.environ:
+        cand = sorted({min(ncpu, int(c)) for c in os.environ["HG_CPU_THREADS"].split(",")})
+    elif full:                                 # (beyond 32 threads the port gets slower on every host measured: the sweep stops at 64 -- a 256-thread forward takes minutes)
+        cand = sorted({min(ncpu, c) for c in (8, 16, 32, 64)})
+    else:
+        cand = sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)})
     torch.set_num_threads(cand[0])
     irreps = IRREPS[irreps_key]
     torch.manual_seed(666)
