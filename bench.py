@@ -38,7 +38,7 @@ REF_BYTES_PER_EDGE_BLOCK = {"A": 14432.0, "B": 7888.0}
 # (separate --pmc FETCH_SIZE / WRITE_SIZE runs on tests/bench_tp.py, 131072 edges; FETCH_SIZE x 2: gfx950 correction for
 # 16-B/lane reads, MI355X_MICROARCH.md "HBM"): measured offline for this kernel build, scaled to the launch's edge count.
 # kernel "is" = input-stationary tp_is_kernel, "seg" = segment-stationary tp_fused_kernel.  r5: ("is", "A") is measured ON THE BENCHMARKED LAUNCHES (FETCH_SIZE /
-# WRITE_SIZE passes over `python bench.py`, sio2_10k: profiles/r05_tp_is_pmc.md), launch by launch of a forward: 6.6 (first ConvBlock: reduced program) / 24.0 (first
+# WRITE_SIZE passes over `python bench.py`, sio2_10k: profiles/r05_tp_is_pmc.md, re-measured in r6: r06_tp_is_pmc.md), launch by launch of a forward: 6.6 (first ConvBlock: reduced program) / 24.0 (first
 # PairInteractionBlock) / 26.6 (ConvBlock, fused scatter) / 28.2 (PairInteractionBlock, one row per edge) / 26.7 / 26.4 (last pair block: unread irreps left out) KB per edge; their mean is used (the synthetic
 # bench_tp launch with random sender / receiver indices measured 34.0 KB per edge in r4: the real crystal's neighbour locality keeps more node rows in L2 / Infinity Cache)
 PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 23.6e3, ("is", "B"): 14.2e3, ("seg", "A"): 173.2e3, ("seg", "B"): 59.9e3}
@@ -535,7 +535,7 @@ def main():
     full_t = [t for k, (t, r, _) in enumerate(mp) if share[k % len(dps)] > 0.999]
     roofline = {"kernel": ("tp_is_kernel (input-stationary" if kern == "is" else "tp_fused_kernel (segment-stationary") + " MessagePackBlock launches)", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": pmc_bytes * rows_per_launch,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, measured offline on the benchmarked launches of this kernel: profiles/r05_tp_is_pmc.md; "
+                "traffic_unit": "bytes per launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, measured offline on the benchmarked launches of this kernel: profiles/r06_tp_is_pmc.md; "
                                 "set-B: r02b_tp_is_hbm_pmc.md, segment-stationary kernel: r01c_tp_fused_hbm_pmc.md), scaled to this launch's edge count", "avg_launch_ms": avg_s * 1e3,
                 "launches_timed": len(mp), "edges_per_launch": rows_per_launch,
                 # `achieved` / `frac`: reference-formulation flops (4.55 MFLOP per edge and block for set-A) of the paths each launched program HOLDS.
@@ -612,7 +612,8 @@ def main():
                 model.declare_consumer(head)                     # (HG_DEAD_OUT=0: drops the declaration)
                 model.compile(dev)
                 nst = max(1, min(args.steps, 5))
-                step()
+                for _ in range(3):                               # (the recompiled model builds its cached chains -- row programs, merged Linears -- on its first forwards)
+                    step()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(nst):

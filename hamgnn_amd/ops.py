@@ -325,6 +325,10 @@ def _gaussian_offsets(cutoff, num_radial, dev):
 
 @_on_tensor_device
 def radial_hidden(rbf: torch.Tensor, layers: Sequence[torch.Tensor], act_cst: float) -> torch.Tensor:
+    """hidden activations of a FullyConnectedNet (every hidden layer: x @ W / sqrt(fan_in) folded into W, normalised SiLU); the kernel holds up to three
+    layers per launch, deeper radial MLPs (`radial_MLP` with more than three entries; r6) chain launches -- every layer of the list is a hidden one"""
+    if len(layers) > 3:
+        return radial_hidden(radial_hidden(rbf, layers[:3], act_cst), layers[3:], act_cst)
     E = rbf.shape[0]
     dims = [int(layers[0].shape[0])] + [int(w.shape[1]) for w in layers]
     W = torch.cat([w.reshape(-1) for w in layers]).contiguous()

@@ -30,7 +30,7 @@ GPU_ORDER = [
          "test_head_overlap", "test_head_soc_so3_golden", "test_head_soc_su2", "test_zero_point_shift", "test_backbone_", "test_transformer_backbone_golden",
          "test_corr_product_block", "test_attribute_style_graph", "test_model_test_stage")),
     (1, ("test_si2_default_irreps_vs_oracle", "test_sio2_setA_vs_oracle", "test_mos2_soc_setA_vs_oracle", "test_uni_hamgnn_chain_vs_oracle", "test_uni_hamgnn_style_batch",
-         "test_full_forward_vs_oracle", "test_multi_crystal_batch", "test_ragged_batch", "test_transformer_vs_oracle")),
+         "test_full_forward_vs_oracle", "test_multi_crystal_batch", "test_ragged_batch", "test_transformer_vs_oracle", "test_radial_mlp_with")),
     (2, ("test_full_size_properties", "test_uni_hamgnn_chain_full_size", "test_uni_hamgnn_chain_on_a_batch", "test_round3_kernels_full_size")),
     (3, ("test_small_graph_forward_is_bit_reproducible", "test_training_step_is_bit_reproducible", "test_training_step_on_a_small_crystal")),
     (4, ("test_message_pack_random", "test_message_pack_single_part", "test_fused_node_scatter", "test_structural_zero_inputs", "test_unread_irreps", "test_sharded_forward",

@@ -533,6 +533,17 @@ def test_bench_script_propagates_a_failing_rank():
     assert cp.returncode != 0 and "BENCH_RANK_FAILURE" in cp.stderr and not [l for l in cp.stdout.splitlines() if l.startswith("{")], cp.stdout[-800:] + cp.stderr[-800:]
 
 
+def test_radial_mlp_with_five_hidden_layers_vs_oracle():
+    """r6: `radial_MLP` deeper than the three layers one hg_radial_hidden launch holds (chained launches): forward vs the fp64 oracle, and the training step's
+    gradients vs autograd through it"""
+    r = G.oracle_vs_hip_random(n_atoms=5, seed=4, radial=(8, 16, 24, 16, 32))
+    print(r)
+    assert r["node_rel_err"] < G.TOL and r["edge_rel_err"] < G.TOL and r["H_rel_err"] < G.TOL
+    b = G.check_full_backward(n_atoms=3, seed=4, radial=(8, 16, 24, 16, 32))
+    print(b)
+    assert b["loss_rel_err"] < G.TOL and b["max_rel_err"] < G.TOL, b
+
+
 def test_multi_crystal_batch_vs_oracle():
     r = G.oracle_vs_hip_random(n_graphs=3, seed=5)
     print(r)
