@@ -14,7 +14,10 @@ import torch
 
 
 class CapturedForward:
-    def __init__(self, fn, warmup: int = 2):
+    def __init__(self, fn, warmup: int = 2, fine_split: bool = True):
+        """fine_split=False: the captured launches are the eager ones -- replays are then bit-identical to eager forwards and to each other; the default spreads the
+        smallest crystals' edge launches finer (one workgroup per (segment, share of its phases), tiles ADDED with hardware atomics: the one schedule of this
+        library without a fixed summation order, results within fp32 rounding of the eager ones)"""
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedForward needs a GPU: HIP graphs replay device work")
         from . import ops
@@ -22,7 +25,7 @@ class CapturedForward:
         # a replayed forward has no host launch cost, so the edge kernel of the smallest crystals is spread finer than an eager forward would pay for:
         # one workgroup per (output segment, quarter of its phases) instead of one per segment (ops.DeviceProgram.is_parts_for; Si 2-atom cell, set-A:
         # replay 0.74 -> 0.51 ms, while the same split makes the eager forward slower, 0.74 -> 0.80 ms: one memset more per launch on a host-bound path)
-        prev, ops.REPLAY_SPLIT = ops.REPLAY_SPLIT, True
+        prev, ops.REPLAY_SPLIT = ops.REPLAY_SPLIT, bool(fine_split)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

@@ -1686,6 +1686,14 @@ def check_captured_forward_si2(device="cuda"):
     with torch.no_grad():
         res["eager_ms"] = timeit(lambda: head(g, model(g)))
     res["replay_ms"] = timeit(fwd)
+    # fine_split=False: the eager launches captured as they are -- replay == eager bit for bit, replay == replay
+    det = CapturedForward(lambda: head(g, model(g)), fine_split=False)
+    a = det()["hamiltonian"].clone()
+    b = det()["hamiltonian"].clone()
+    torch.cuda.synchronize()
+    res["deterministic_replay_vs_eager_max_abs"] = float((a - ref2).abs().max())
+    res["deterministic_replay_repeat_max_abs"] = float((a - b).abs().max())
+    res["deterministic_replay_ms"] = timeit(det)
     return res
 
 

@@ -656,6 +656,8 @@ def test_captured_forward_replay_si2():
     #  eager launches', and the one schedule whose own order is not fixed: G.SAME_MATH_TOL)
     assert r["replay_vs_eager"] < G.SAME_MATH_TOL and r["replay_vs_eager_moved"] < G.SAME_MATH_TOL and r["moved_changes_H"] > 1e-4
     assert r["replay_ms"] < 1.1 * r["eager_ms"] and r["replay_ms"] < 2.0     # r1: 4.4-4.8 ms per forward, eager or replayed
+    # CapturedForward(fine_split=False): the eager launches replayed -- bit-identical to the eager forward and to itself
+    assert r["deterministic_replay_vs_eager_max_abs"] == 0.0 and r["deterministic_replay_repeat_max_abs"] == 0.0 and r["deterministic_replay_ms"] < 1.1 * r["eager_ms"], r
 
 
 def test_backbone_lite_mode_golden():
