@@ -38,6 +38,25 @@ __device__ __forceinline__ void burst_f16(f32x4 (&acc)[4], f16x8 a, f16x8 b, int
     }
 }
 
+// mode 4: the pattern of the edge kernel's GEMM2 -- accumulators initialised FROM the LDS, one short chain of fp32-input MFMAs, results stored straight back to the LDS
+// (the compiler's wait states between the MFMA and the ds_write are all that separates them) -- interleaved with bursts of half-precision MFMAs, per wave
+__device__ __forceinline__ void rmw_f32(float* __restrict__ tile, float a, float b, int n, int lane) {
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[k][r] = tile[(k * 4 + r) * 64 + lane] * 0.75f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a + 0.125f * k, b, acc[k], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(k * 4 + r) * 64 + lane] = acc[k][r];
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void mix_kernel(int mode, int iters, float* __restrict__ out) {
     extern __shared__ float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -50,6 +69,17 @@ __global__ __launch_bounds__(256, 2) void mix_kernel(int mode, int iters, float*
     const int par = blockIdx.x & 1;
     if (mode == 0) burst_f32(accF, a, b, iters);
     else if (mode == 1) burst_f16(accH, a8, b8, iters);
+    else if (mode == 4) {
+        float* tile = lds + 64 + wave * 1024;
+        for (int i = lane; i < 1024; i += 64) tile[i] = 0.f;
+        const int nf = 2 + wave + par, nh = 4 - wave + 2 * par;
+        for (int r = 0; r < iters / 8; ++r) {
+            rmw_f32(tile, a, b, nf, lane);
+            burst_f16(accH, a8, b8, nh);
+        }
+        for (int k = 0; k < 4; ++k)
+            for (int r = 0; r < 4; ++r) accF[k][r] = tile[(k * 4 + r) * 64 + lane];
+    }
     else if (mode == 2) { if (par) burst_f16(accH, a8, b8, iters); else burst_f32(accF, a, b, iters / 2); }
     else {
         const int nf = 3 + wave + 2 * par, nh = 5 - wave + par;  // burst lengths differ per wave and workgroup parity: the two waves of a SIMD drift against each other
@@ -70,8 +100,9 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&d, n * sizeof(float)));
     CHECK(hipFuncSetAttribute((const void*)mix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     std::vector<float> ref(n), got(n);
-    const char* names[4] = {"all fp32-input MFMAs", "all half-precision MFMAs", "even workgroups fp32 / odd half precision", "every wave alternates bursts of both kinds"};
-    for (int mode = 0; mode < 4; ++mode) {
+    const char* names[5] = {"all fp32-input MFMAs", "all half-precision MFMAs", "even workgroups fp32 / odd half precision", "every wave alternates bursts of both kinds",
+                            "fp32 MFMA chains that read-modify-write an LDS tile, interleaved with half-precision bursts"};
+    for (int mode = 0; mode < 5; ++mode) {
         hipLaunchKernelGGL(mix_kernel, dim3(grid), dim3(256), 160 * 1024, 0, mode, iters, d);
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(ref.data(), d, n * sizeof(float), hipMemcpyDeviceToHost));
