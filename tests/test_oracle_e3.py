@@ -175,4 +175,5 @@ def test_timed_contraction_order_equals_the_parity_order():
             e3.CONTRACTION = "outer"
     finally:
         torch.set_default_dtype(prev)
+    a, b = a.detach(), b.detach()
     assert len(ins) > 10 and float((a - b).abs().max()) < 1e-12 * float(a.abs().max())
