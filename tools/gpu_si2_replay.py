@@ -1,4 +1,4 @@
-"""Si 2-atom cell forward (set-A, 3 layers, head): eager launches vs hipGraph replay (hamgnn_amd.graph_capture.CapturedForward), per HG_PHASE_PARTS mode of the process.
+"""Si 2-atom cell forward (set-A, 3 layers, head): eager launches vs hipGraph replay (hamgnn_amd.graph_capture.CapturedForward), per HG_REPLAY_SPLIT mode of the process.
 python tools/gpu_si2_replay.py [--workload si2] [--steps 300]"""
 import argparse, os, sys, time
 import torch
@@ -37,4 +37,4 @@ out = cap()
 torch.cuda.synchronize()
 err = float((out - ref).abs().max() / ref.abs().max())
 tr = timed(cap)
-print(f"HG_PHASE_PARTS={os.environ.get('HG_PHASE_PARTS', '0')} {a.workload}: eager {te:.3f} ms, graph replay {tr:.3f} ms per forward (replay vs eager rows {err:.1e}); E = {g.num_edges}")
+print(f"HG_REPLAY_SPLIT={os.environ.get('HG_REPLAY_SPLIT', '')} {a.workload}: eager {te:.3f} ms, graph replay {tr:.3f} ms per forward (replay vs eager rows {err:.1e}); E = {g.num_edges}")
