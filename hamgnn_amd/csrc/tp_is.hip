@@ -797,8 +797,10 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
         int gi_dealt = g0 + __builtin_amdgcn_readfirstlane(wave);      // (scalar: as a vector register it spilled in the <SPLIT, LITE> instantiation)
         while (true) {
             int gi = 0;
-#ifdef IS_DYNAMIC_CLAIM                                         /* A/B builds only (profiles/r06_tp_is.md section 5): the dynamic claims of rounds 2-5 */
+#if defined(IS_DYNAMIC_CLAIM)                                   /* A/B builds only (profiles/r06_tp_is.md section 5): the dynamic claims of rounds 2-5 */
             if (false) {
+#elif defined(IS_DEAL_ALL)                                      /* A/B builds only (section 7): single-part launches dealt round-robin as well -- the four waves start in lock step */
+            if (true) {
 #else
             if (SPLIT && copy_stride) {
 #endif
