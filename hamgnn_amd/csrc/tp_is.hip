@@ -137,6 +137,104 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
     }
 
     IS_T(1);                                                    // radial scale
+#if defined(K_XDL_DUMMY) || defined(K_SMFMA_DUMMY)
+    // A/B builds only (profiles/r06_tp_is.md section 8): MFMAs whose result nobody reads, on operands that have nothing to do with the item -- 6 per row tile in two chains,
+    // where the round's half-precision experiment had its radial scale.  K_XDL_DUMMY: v_mfma_f32_16x16x32_f16 (K_XD_OP: another opcode of that pipe); K_SMFMA_DUMMY: the fp32
+    // kind (control).  The launch's result must not change by a bit.  K_XD_DRAIN: no memory operation of the wave in flight around them; K_XD_ONE: one instead of 6 per row
+    // tile; K_XD_NOPS: 64 idle cycles behind them; K_XD_ROLE: only the workgroups with bit 8 of their index set issue them (workgroups j and j + 256 share a CU).
+#ifdef K_XD_ROLE
+    if (typ == 0 && ((blockIdx.x >> 8) & 1)) {
+#else
+    if (typ == 0) {
+#endif
+        f32x4 dA[RTM], dB[RTM];
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) dA[rt] = dB[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef K_XD_DRAIN
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef K_XDL_DUMMY
+#if !defined(K_XD_OP) || K_XD_OP == 0
+        typedef _Float16 k_vec __attribute__((ext_vector_type(8)));
+#define K_XD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define K_XD_VAL(x) (_Float16)(x)
+#define K_XD_N 8
+#elif K_XD_OP == 1
+        typedef __bf16 k_vec __attribute__((ext_vector_type(8)));
+#define K_XD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define K_XD_VAL(x) (__bf16)(x)
+#define K_XD_N 8
+#else
+        typedef _Float16 k_vec __attribute__((ext_vector_type(4)));
+#define K_XD_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
+#define K_XD_VAL(x) (_Float16)(x)
+#define K_XD_N 4
+#endif
+        k_vec xa, xb;
+#pragma unroll
+        for (int s_ = 0; s_ < K_XD_N; ++s_) { xa[s_] = K_XD_VAL(0.01f * (float)((lane + 3 * s_) & 15) - 0.07f); xb[s_] = K_XD_VAL(0.02f * (float)((lane * 3 + s_) & 7) - 0.06f); }
+#if defined(K_XD_ONE)
+        dA[0] = K_XD_MFMA(xa, xb, dA[0]);
+#elif defined(K_XD_TWO)                                         /* two per row tile, independent */
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) dA[rt] = K_XD_MFMA(xa, xb, dA[rt]);
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) dB[rt] = K_XD_MFMA(xb, xa, dB[rt]);
+#elif defined(K_XD_INDEP6)                                      /* 6 per row tile, every one on its own zero accumulator, summed on the VALU */
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) {
+            const f32x4 z4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 m0 = K_XD_MFMA(xa, xb, z4), m1 = K_XD_MFMA(xb, xa, z4), m2 = K_XD_MFMA(xa, xa, z4), m3 = K_XD_MFMA(xb, xb, z4), m4 = K_XD_MFMA(xa, xa + xb, z4), m5 = K_XD_MFMA(xa + xb, xb, z4);
+            dA[rt] = m0 + m1;
+            dB[rt] = (m2 + m3) + (m4 + m5);
+        }
+#elif defined(K_XD_CHAIN)                                       /* 6 in ONE back-to-back dependent chain */
+#pragma unroll
+        for (int t = 0; t < 6; ++t) dA[0] = K_XD_MFMA(xa, xb, dA[0]);
+#elif defined(K_XD_SIX)                                         /* 6 per item, independent pairs at distance 2 */
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { dA[0] = K_XD_MFMA(xa, xb, dA[0]); dB[0] = K_XD_MFMA(xb, xa, dB[0]); }
+#else
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) dA[rt] = K_XD_MFMA(xa, xb, dA[rt]);
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) dB[rt] = K_XD_MFMA(xb, xa, dB[rt]);
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) dB[rt] = K_XD_MFMA(xa, xa, dB[rt]);
+        }
+#endif
+#else
+        const float xa = 0.01f * (float)(lane & 15) - 0.07f, xb = 0.02f * (float)(lane & 7) - 0.06f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) dA[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xb, dA[rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) dB[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xb, xa, dB[rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) dB[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, xa, dB[rt], 0, 0, 0);
+        }
+#endif
+#if defined(K_XD_DRAIN) || defined(K_XD_NOPS)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#ifdef K_XD_LONG                                                /* K_XD_LONG x 64 idle cycles more */
+#pragma unroll 1
+        for (int w_ = 0; w_ < K_XD_LONG; ++w_) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+        for (int rt = 0; rt < RTM; ++rt) asm volatile("" :: "v"(dA[rt]), "v"(dB[rt]));
+#if defined(K_XD_DRAIN)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#endif
     // ---------------------------------------------------------------- GEMM1: mid = A1 fragments x staged block
     f32x4 mid[RTM][NC];
 #pragma unroll

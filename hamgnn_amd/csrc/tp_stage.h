@@ -177,12 +177,51 @@ __device__ __forceinline__ void epilogue_is(const IsArgs& A, const float* __rest
     }
 }
 
+
+// A/B builds only (profiles/r06_tp_is.md section 8): the rotated staging without packed fp32 VALU instructions (K_ST_NOPK) / without 128-bit LDS writes (K_ST_W32)
+__device__ __forceinline__ f32x4 st_mul(float d, f32x4 v) {
+#ifdef K_ST_NOPK
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(o[k]) : "v"(d), "v"(v[k]));
+    return o;
+#else
+    return d * v;
+#endif
+}
+__device__ __forceinline__ void st_fma(f32x4& acc, float d, f32x4 v) {
+#ifdef K_ST_PKASM                /* the packed instruction, but issued through the same kind of asm statement as K_ST_NOPK (same ordering constraints) */
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ lo = {acc[0], acc[1]}, hi = {acc[2], acc[3]};
+    const f32x2_ vlo = {v[0], v[1]}, vhi = {v[2], v[3]}, dd = {d, d};
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(lo) : "v"(dd), "v"(vlo));
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(hi) : "v"(dd), "v"(vhi));
+    acc = (f32x4){lo[0], lo[1], hi[0], hi[1]};
+#elif defined(K_ST_NOPK)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[k]) : "v"(d), "v"(v[k]));
+#else
+    acc += d * v;
+#endif
+}
+__device__ __forceinline__ void st_write4(float* p, f32x4 v) {
+#ifdef K_ST_W32
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<volatile float*>(p)[k] = v[k];
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
 #ifndef HG_STAGE_FUSE_LMAX
 #define HG_STAGE_FUSE_LMAX 6     // both node sources rotated in one pass up to this l 
 #endif
 // piece index t -> (component a, channel piece p): t / P1 through the reciprocal (t < 2^9, P1 <= 16: (t + 0.5) / P1 is never within 0.03 of an
 // integer, so the float product rounds to the right side); an integer division per piece cost as much as the piece's own loads + FMAs at l = 0
+#ifdef K_ST_IDIV                 /* A/B builds only (profiles/r06_tp_is.md section 8) */
+#define HG_DIV_P1(t) ((t) / P1)
+#else
 #define HG_DIV_P1(t) ((int)(((float)(t) + 0.5f) * inv_P1))
+#endif
 #ifndef HG_STAGE_U
 #define HG_STAGE_U(L) 1          // measured (profiles/r02_tp_is_experiments.md): 2-4 pieces in flight per step are SLOWER (8.39 vs 8.13 ms)
 #endif
@@ -239,14 +278,14 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + 4 * NW * u;
                 if (t < Pfull) {
-                    f32x4 acc0 = d[u][0] * v0[u][0], acc1 = d[u][0] * v1[u][0];
+                    f32x4 acc0 = st_mul(d[u][0], v0[u][0]), acc1 = st_mul(d[u][0], v1[u][0]);
 #pragma unroll
                     for (int b = 1; b < N; ++b) {
-                        acc0 += d[u][b] * v0[u][b];
-                        acc1 += d[u][b] * v1[u][b];
+                        st_fma(acc0, d[u][b], v0[u][b]);
+                        st_fma(acc1, d[u][b], v1[u][b]);
                     }
-                    *reinterpret_cast<f32x4*>(d0 + t * 64) = acc0;
-                    *reinterpret_cast<f32x4*>(d1 + t * 64) = acc1;
+                    st_write4(d0 + t * 64, acc0);
+                    st_write4(d1 + t * 64, acc1);
                 }
             }
         }
@@ -270,10 +309,10 @@ __device__ __forceinline__ void stage_block(const IsArgs& A, const int* __restri
                     v[b] = *reinterpret_cast<const f32x4*>(row + b * in_mulp + 4 * p);
                     d[b] = D[a * N + b];
                 }
-                f32x4 acc = d[0] * v[0];
+                f32x4 acc = st_mul(d[0], v[0]);
 #pragma unroll
-                for (int b = 1; b < N; ++b) acc += d[b] * v[b];
-                *reinterpret_cast<f32x4*>(dst + t * 64 + el * 4) = acc;
+                for (int b = 1; b < N; ++b) st_fma(acc, d[b], v[b]);
+                st_write4(dst + t * 64 + el * 4, acc);
             }
         } else {
 #pragma unroll 1
