@@ -34,7 +34,7 @@ GPU_ORDER = [
     (2, ("test_full_size_properties", "test_uni_hamgnn_chain_full_size", "test_uni_hamgnn_chain_on_a_batch", "test_round3_kernels_full_size")),
     (3, ("test_small_graph_forward_is_bit_reproducible", "test_training_step_is_bit_reproducible", "test_training_step_on_a_small_crystal")),
     (4, ("test_message_pack_random", "test_message_pack_single_part", "test_fused_node_scatter", "test_structural_zero_inputs", "test_unread_irreps", "test_sharded_forward",
-         "test_rccl_backend", "test_bench_script", "test_captured_forward", "test_row_program_kernel", "test_block_gemm", "test_precision_64")),
+         "test_rccl_backend", "test_bench_script", "test_captured_forward", "test_row_program_kernel", "test_block_gemm", "test_precision_64", "test_edge_kernel_is_not_disturbed")),
     (6, ("test_band_", "test_head_bands")),
     (5, ("test_message_pack_data_gradient", "test_message_pack_weight_gradients", "test_conv_message_chain", "test_residual_block_backward", "test_full_model_", "test_reference_loss",
          "test_device_repack", "test_soc_head_backward", "test_soc_su2_head_backward", "test_head_backward", "test_head_finetune", "test_two_rank_training", "test_linear_weight_gradient",

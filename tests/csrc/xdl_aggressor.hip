@@ -1,6 +1,6 @@
 // xdl_aggressor.hip -- a SEPARATE kernel that does nothing but issue MFMAs in registers (no LDS, no memory traffic, <= 64 VGPRs: one of its waves fits on a SIMD next to
 // two waves of the edge kernel), launched on a side stream while the UNMODIFIED shipped library computes (tools/gpu_aggressor.py; profiles/r06_tp_is.md section 8).
-//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/xdl_aggressor.hip -o /tmp/libxdl_aggressor.so
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tests/csrc/xdl_aggressor.hip -o /tmp/libxdl_aggressor.so
 // mode 0: dependent chains of v_mfma_f32_16x16x32_f16   1: the same MFMAs on 6 independent accumulators   2: dependent chains of v_mfma_f32_16x16x16_f16
 // mode 3: dependent chains of v_mfma_f32_16x16x4_f32 (control)   4: dependent chains of v_mfma_f32_16x16x32_bf16   5: no MFMA at all (VALU only, control)
 #include <hip/hip_runtime.h>

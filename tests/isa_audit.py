@@ -17,11 +17,12 @@ import argparse, os, re, subprocess, sys, tempfile
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]      # as hamgnn_amd/csrc/Makefile (tests/test_isa_audit.py checks that the two agree)
 
 
 def compile_to_asm(src, defines=()):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, src]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", *NOPK, "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, src]
     cmd += ["-D" + d for d in defines]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = open(out).read()

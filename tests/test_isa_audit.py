@@ -75,3 +75,20 @@ def test_weight_gradient_kernel_register_budget():
     assert ks
     worst = max(k["meta"]["scratch"] for k in ks)
     assert worst <= 124, worst                                # r3: the 13-column instantiation spills 124 B / lane, the NC = 1 ones 2 VGPRs
+
+
+def test_no_kernel_of_the_library_holds_packed_fp32_instructions():
+    """profiles/r06_tp_is.md section 8: on gfx950 the packed fp32 VALU instructions the compiler emits for scalar x vector products return wrong results while another
+    wave of the SIMD executes v_mfma_f32_16x16x32_f16 / _bf16 (a co-running half-precision GEMM is enough; 33 000 of 41 000 tiles of an edge-kernel launch were wrong).
+    The library is built without them (csrc/Makefile: NOPK); this pins the flag and its effect on every source file."""
+    from concurrent.futures import ThreadPoolExecutor
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert " ".join(A.NOPK) in mk and "$(NOPK)" in mk.split("FLAGS :=", 1)[1].split("\n", 1)[0]
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    assert len(srcs) >= 11
+    with ThreadPoolExecutor(4) as ex:
+        texts = list(ex.map(lambda f: A.compile_to_asm(os.path.join(CSRC, f)), srcs))
+    for f, text in zip(srcs, texts):
+        hits = re.findall(r"^\s+(v_pk_(?:fma|mul|add)_f32)\b", text, flags=re.M)
+        assert not hits, (f, len(hits))
+        assert re.search(r"^\s+v_(?:fma|mul|add)_f32", text, flags=re.M) or f in ("block_gemm.hip",), f      # (the audit did look at code)

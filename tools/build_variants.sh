@@ -13,7 +13,7 @@ for spec in "$@"; do
   ( objs=""
     for f in $ALL; do
       if [[ " $FILES " == *" $f "* ]]; then
-        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I../../include $flags -c $f.hip -o ../lib/variants/${f}_$name.o
+        hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value ${HG_VARIANT_NOPK--Xclang -target-feature -Xclang -packed-fp32-ops} -I../../include $flags -c $f.hip -o ../lib/variants/${f}_$name.o
         objs="$objs ../lib/variants/${f}_$name.o"
       else
         objs="$objs ../lib/$f.o"

@@ -1,5 +1,5 @@
 """The UNMODIFIED shipped edge kernel (one node-fed MessagePackBlock launch, 131 072 edges) while a SEPARATE kernel that only issues MFMAs in registers runs on a side stream
-(tools/xdl_aggressor.hip: no LDS, no memory traffic, <= 50 VGPRs -- its waves fit on the SIMDs next to the edge kernel's two).  profiles/r06_tp_is.md section 8.
+(tests/csrc/xdl_aggressor.hip: no LDS, no memory traffic, <= 50 VGPRs -- its waves fit on the SIMDs next to the edge kernel's two).  profiles/r06_tp_is.md section 8.
     python tools/gpu_aggressor.py /tmp/libxdl_aggressor.so [--launches 6]"""
 import argparse, ctypes, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,4 @@
-"""Which kernels are disturbed by a co-running kernel that only issues v_mfma_f32_16x16x32_f16 (tools/xdl_aggressor.hip)?  Victims: one launch each of the shipped library's
+"""Which kernels are disturbed by a co-running kernel that only issues v_mfma_f32_16x16x32_f16 (tests/csrc/xdl_aggressor.hip)?  Victims: one launch each of the shipped library's
 edge kernel (default / lite_mode / the older segment-stationary kernel), its row program / linear kernels through a ResidualBlock, its weight-gradient kernel path is left out;
 and the vendor library's fp32 and bf16 GEMMs through torch.  profiles/r06_tp_is.md section 8.     python tools/gpu_aggressor2.py /tmp/libxdl_aggressor.so"""
 import argparse, ctypes, json, os, sys, time
