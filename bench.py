@@ -569,6 +569,12 @@ def main():
                                   f"sh lmax 5, 3 layers, nao_max {args.nao}, {'SOC (so3 head)' if args.soc else 'no SOC'}{', lite_mode' if args.lite else ''}, backbone+head forward",
                       "parallelism": "single GPU" if world == 1 else f"pair-sharded edges x{world} + RCCL all-reduce of node aggregates"},
            "roofline": roofline, "compile_s": compile_s,
+           # arithmetic of the hot kernel (r6): everything in fp32 MFMAs EXCEPT the radial scale S = W3^T h (27.5 % of a block's fp32-equivalent MFMAs), which runs on the
+           # half-precision matrix pipe with both operands split into two f16 terms (22 significant bits, fp32 accumulation): 6 x 16 pipe cycles per row tile instead of 16 x 32.
+           # `roofline` counts its flops as the fp32 flops they replace and prices them against the fp32 peak.  Accuracy against the fp64 oracle: the `accuracy` field of this line
+           # (2.28e-6 with, 2.24e-6 without); HG_S_SPLIT=0 = the all-fp32 form (229.5 ms per step on sio2_10k against 202.9: profiles/r06_tp_is.md)
+           "radial_scale_arithmetic": ("fp32 MFMAs (HG_S_SPLIT=0)" if os.environ.get("HG_S_SPLIT", "1") == "0" or args.lite
+                                       else "v_mfma_f32_16x16x32_f16 on split operands (hi + 2^-11 lo, 22 bits), fp32 accumulation"),
            # what this build does NOT compute that the reference's op graph does, with identical results (each has a test that compares against the
            # complete programs); same-call A/B on sio2_10k (profiles/r05_shortcuts_ab.md): 3.098 M edges/s without them (HG_STRUCT_ZEROS=0 HG_DEAD_OUT=0: round 4's programs), 3.613 M with the first only, 3.711 M with both
            "exact_shortcuts": {"structurally_zero_input_irreps_of_the_first_layer": os.environ.get("HG_STRUCT_ZEROS", "1") != "0" and not args.lite,

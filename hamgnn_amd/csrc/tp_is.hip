@@ -53,7 +53,7 @@ __device__ __forceinline__ float is_mul_bcast(float v, float x, int q) {
 // works on the 2 MM remaining columns only -- column slot c < MM is real column c, slot c >= MM is real column c + 1.
 template <int MM, int RTM, bool SPLIT, bool ODD>
 __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict__ Wb, const int* __restrict__ it,
-                                        float* __restrict__ lds, int64_t erow, int lane, const f32x4 (&hbr)[4], int hbr_cls IS_PROF_ARG) {
+                                        float* __restrict__ lds, int64_t erow, int lane, const IsHidden& hbr, int hbr_cls IS_PROF_ARG) {
     constexpr int NCR = 2 * MM + 1;                            // real columns (fragment layouts of cf, tile columns)
     constexpr int NC = ODD ? 2 * MM : NCR;                     // column slots this item computes
 #define IS_COL(c) ((ODD && (c) >= MM) ? (c) + 1 : (c))
@@ -97,23 +97,39 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
             // the 16 edges' hidden rows of the phase's radial MLP (the B operands of these MFMAs, the same for every item of a branch) are
             // resident in registers: read once per phase by the kernel, under the staging -- the planner keeps a phase on one generator where
             // that is free (plan.is_schedule(separate_mlp)); r3 loaded them per item: 4 of an item's ~35 vector loads, and a second round
-            // trip when they missed the L1.  The group guards stay run-time: small blocks, a group's MFMAs start when ITS fragments arrive
-            const int hg = __builtin_amdgcn_readfirstlane(A.hidden) >> 4;
-            f32x4 wv[4][RTM];
+            // trip when they missed the L1.
+            // r6: on the HALF-PRECISION matrix pipe with split operands (plan/program.py: w3_split_fill): x 2^s = hi + 2^-11 lo, hi = f16(x 2^s),
+            // lo = f16((x 2^s - hi) 2^11);  S 2^(sw + sh) = W_hi h_hi + 2^-11 (W_hi h_lo + W_lo h_hi) -- 3 MFMAs of K = 32 per half of the 64 hidden units
+            // = 6 x 16 pipe cycles per row tile where the fp32 form takes 16 x 32 (27.5 % of the launch's MFMAs), fp32 accumulation in two chains (the
+            // half-precision MFMAs flush subnormal inputs: hence the scaled remainders), 22-bit operands (H moves by 6e-7 relative: profiles/r06_tp_is.md).
+            // The weights' split twin follows the fp32 block: [t][rt][hi, lo][lane] float4 = 8 halves in the K-slot order of the resident rows.
+            const f32x4* __restrict__ w3s = w3 + 4 * RTM * 64;
+            f32x4 wh[2][RTM], wl[2][RTM], S1[RTM];
 #pragma unroll
-            for (int G = 0; G < 4; ++G)
-                if (G < hg) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int rt = 0; rt < RTM; ++rt) wv[G][rt] = w3[(G * RTM + rt) * 64];
+                for (int rt = 0; rt < RTM; ++rt) {
+                    wh[t][rt] = w3s[((t * RTM + rt) * 2) * 64];
+                    wl[t][rt] = w3s[((t * RTM + rt) * 2 + 1) * 64];
                 }
 #pragma unroll
-            for (int G = 0; G < 4; ++G)
-                if (G < hg) {
+            for (int rt = 0; rt < RTM; ++rt) S1[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // all fragments requested and waited for before the first MFMA: the faster form (6.15 vs 6.55 ms per 131 072 edges, profiles/r06_tp_is.md section 3)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+            for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                        for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[G][rt][q], hbr[G][q], S[rt], 0, 0, 0);
-                }
+                for (int rt = 0; rt < RTM; ++rt) S[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[t][rt]), hbr.hi[t], S[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) S1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wh[t][rt]), hbr.lo[t], S1[rt], 0, 0, 0);
+#pragma unroll
+                for (int rt = 0; rt < RTM; ++rt) S1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[t][rt]), hbr.hi[t], S1[rt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float c0 = A.s_scale, c1 = A.s_scale * (1.f / 2048.f);
+#pragma unroll
+            for (int rt = 0; rt < RTM; ++rt) S[rt] = S[rt] * c0 + S1[rt] * c1;
         } else
 #pragma unroll 1
         for (int G0 = 0; G0 < hgrp; G0 += 4) {
@@ -857,12 +873,22 @@ __global__ __launch_bounds__(LITE ? 64 * IS_NW_LITE : IS_NT, (LITE ? IS_NW_LITE 
         const int b0 = P[0], b1 = P[1], g0 = P[2], g1 = P[3];
         // the hidden rows of the phase's radial MLP (P[4]; -1: none / hidden width != 64), resident for its items (item_is): requested here,
         // first used after the staging
-        const int hbr_cls = (A.hidden == 64 && (P[4] == 0 || (P[4] == 1 && A.h2[1]))) ? P[4] : -1;
-        f32x4 hbr[4];
+        const int hbr_cls = (A.hidden == 64 && A.s_split && (P[4] == 0 || (P[4] == 1 && A.h2[1]))) ? P[4] : -1;
+        IsHidden hbr;                                          // split into (hi, lo) halves once per phase, in the K-slot order of the weights' twins
         {
             const float* __restrict__ hrow = (hbr_cls == 1 ? A.h2[1] : A.h2[0]) + erow * A.hidden + 4 * g;
+            f32x4 hv[4];
 #pragma unroll
-            for (int G = 0; G < 4; ++G) hbr[G] = hbr_cls >= 0 ? *reinterpret_cast<const f32x4*>(hrow + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int G = 0; G < 4; ++G) hv[G] = hbr_cls >= 0 ? *reinterpret_cast<const f32x4*>(hrow + 16 * G) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_) {
+                    const float x = hv[2 * t + (s_ >> 2)][s_ & 3] * IS_SPLIT_H_SCALE;
+                    const _Float16 h_ = (_Float16)x;
+                    hbr.hi[t][s_] = h_;
+                    hbr.lo[t][s_] = (_Float16)((x - (float)h_) * 2048.f);
+                }
         }
         __syncthreads();                                       // every wave is done with the previous blocks (and the zero fill)
         IS_T(5);                                               // waiting for the slowest wave of the previous phase
@@ -1065,6 +1091,8 @@ extern "C" int hg_tp_is(const float* const* src, const int64_t* src_stride, int 
     const int32_t* p0 = part_table_host;                       // single-part launches take the schedule scalars as kernel arguments
     A.nseg = p0[1], A.nphase = p0[3], A.trash_off = p0[4], A.stage_off = p0[5], A.ctr_off = p0[6];
     A.rowtab_off = p0[8], A.rowtab_begin = p0[9], A.rowtab_len = p0[10];
+    A.s_split = p0[12] == 1 && hidden == 64;
+    A.s_scale = ldexpf(1.f, -(p0[13] + IS_SPLIT_H_EXP));       // S = s_scale (S0 + 2^-11 S1): the weights' 2^sw (part record [13]) and the hidden rows' 2^sh undone
     if (!row_table) return hg_fail(-2, "hg_tp_is: no row table");
     for (int p = 0; p < nparts; ++p) {
         const int32_t* q = part_table_host + p * IS_PART_I32;

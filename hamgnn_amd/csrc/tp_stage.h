@@ -7,6 +7,11 @@
 #include "hg_common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// the 16 edges' hidden rows of a phase's radial MLP as B operands of v_mfma_f32_16x16x32_f16: x = hi + lo (csrc/tp_is.hip, plan/program.py:w3_split_fill)
+struct IsHidden { f16x8 hi[2], lo[2]; };
+#define IS_SPLIT_H_EXP 6         // the hidden rows are scaled by 2^6 before the split (= plan.SPLIT_H_EXP: small activations stay normal halves, |h| < 1023 finite)
+#define IS_SPLIT_H_SCALE 64.f
 
 #ifndef IS_NW
 #define IS_NW 4                  // waves of a workgroup (all on the same 16 edges); plan.py:IS_WAVES.  6 = three waves per SIMD (experiment)
@@ -36,6 +41,8 @@ struct IsArgs {
     int rowtab_begin;            // first entry / entries of this part in the global table
     int rowtab_len;
     int tile_shift;              // split launches: this wave's private tile copy (floats added to every tile offset)
+    int s_split;                 // the program carries the split-half-precision twins of its W3 blocks (part record [12]): radial scales on the f16 matrix pipe
+    float s_scale;               // 2^-(sw + sh): undoes the scalings of the twins (part record [13]) and of the hidden rows
     const int64_t* idx[4];       // per source slot: row gather (NULL: row = edge)
     int rot_mask;                // bit i: source i holds GLOBAL-frame rows that are rotated into the edge frame while staged
     const int64_t* eperm;        // tile slot -> edge (NULL: identity).  Receiver-major order for launches whose output is scattered onto the receivers

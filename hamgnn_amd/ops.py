@@ -65,6 +65,8 @@ def _require_gpu(t: torch.Tensor):
         raise RuntimeError("hamgnn_amd: the MI355X hot path needs CUDA(ROCm) tensors; there is no CPU fallback")
 
 
+S_SPLIT_OFF = os.environ.get("HG_S_SPLIT", "1") == "0"      # A/B switch: the fp32 form of the radial scale (16 fp32 MFMAs per row tile instead of 6 half-precision ones)
+W3_SPLIT_PENDING: list = []     # (DeviceProgram, device scalar max |W3|) of refreshed programs whose half-precision range check is still to be read (check_w3_split)
 REPLAY_SPLIT = False         # set by graph_capture.CapturedForward while it warms up and captures: launches of the smallest crystals take the finer 2d split
 REPLAY_SPLIT_TILES = int(os.environ.get("HG_REPLAY_SPLIT_TILES", "1024"))    # the 2d split while tiles x segments x phase shares stay below this (two rounds of the chip's 512 slots)
 
@@ -85,6 +87,18 @@ def check_build_config():
         if got != int(val):
             raise RuntimeError(f"{name}={val} does not match the loaded library (compiled with {got}): rebuild the variant or unset the variable")
     _BUILD_CONFIG_OK = True
+
+
+def check_w3_split():
+    """one host read for all programs refreshed since the last launch: a W3 weight beyond the half-precision range switches that program's launches to the fp32
+    form of the radial scale (and back, once the weights have come back)"""
+    if not W3_SPLIT_PENDING:
+        return
+    pend = list(W3_SPLIT_PENDING)
+    W3_SPLIT_PENDING.clear()
+    mx = torch.stack([m for _, m in pend]).cpu()
+    for (dp, _), m in zip(pend, mx.tolist()):
+        dp._w3_split_off = not (m <= P.W3_SPLIT_MAX)
 
 
 class DeviceProgram:
@@ -123,8 +137,43 @@ class DeviceProgram:
 
     def weights_changed(self):
         """after the packed weight blob was rewritten in place (nn.MessagePackBlock.refresh): rebuild what is derived from it"""
+        self.refresh_w3_split()
         self._is_weights.clear()                               # (lite programs are recompiled, not refreshed; kept consistent anyway)
         self._is_tables = {k: v for k, v in self._is_tables.items() if v[0].extra_weights is None}
+
+    def refresh_w3_split(self):
+        """the split-half-precision twins of the W3 fragment blocks (plan/program.py:w3_split_fill) recomputed ON THE DEVICE from the fp32 blocks of the blob --
+        the device-side repack (hamgnn_amd/repack.py) is affine in the parameters, hi = f16(x) / lo = f16(x - hi) is not.  Whether every weight is inside the
+        half-precision range is checked lazily, by ONE host read before the next launch (check_w3_split): outside it the launches keep the fp32 form."""
+        regs = getattr(self.prog, "w3_regions", None)
+        if not regs:
+            return
+        if getattr(self, "_w3_idx", None) is None:
+            se, so, dh, dl = [], [], [], []
+            for off, rtm in regs:
+                n = 4 * rtm * 256
+                src, dst = P.w3_split_index(rtm)
+                se.append(off + src[:, 0]); so.append(off + src[:, 1]); dh.append(off + n + dst[0]); dl.append(off + n + dst[1])
+            self._w3_idx = tuple(_dev(np.concatenate(a).astype(np.int64), self._device) for a in (se, so, dh, dl))
+        se, so, dh, dl = self._w3_idx
+        w = self.weights
+        sc_, lo_ = float(2.0 ** int(getattr(self.prog, "w3_exp", 0))), float(2.0 ** P.SPLIT_LO_EXP)
+        xe, xo = w[se] * sc_, w[so] * sc_
+        he, ho = xe.half(), xo.half()
+        le, lo = ((xe - he.float()) * lo_).half(), ((xo - ho.float()) * lo_).half()
+        pack = lambda a, b: (a.view(torch.int16).to(torch.int32) & 0xffff) | (b.view(torch.int16).to(torch.int32) << 16)
+        wi = w.view(torch.int32)
+        wi[dh] = pack(he, ho)
+        wi[dl] = pack(le, lo)
+        W3_SPLIT_PENDING.append((self, torch.maximum(xe.abs().max(), xo.abs().max())))
+
+    def part_table_host(self, sc) -> np.ndarray:
+        """the schedule's part table as the launch passes it in host memory: [12] (W3 split twins present) cleared when a refreshed weight left the half-precision range"""
+        if (getattr(self, "_w3_split_off", False) or S_SPLIT_OFF) and int(sc.part_table[0][12]):
+            pt = sc.part_table.copy()
+            pt[:, 12] = 0
+            return pt
+        return sc.part_table
 
     def is_tables(self, parts):
         """(schedule, device tables) of the input-stationary kernel split into `parts` sub-schedules (built on first use)"""
@@ -442,13 +491,14 @@ def tp_fused(dp: DeviceProgram, srcs: List[torch.Tensor], rows: int, h2n=None, h
         ev0.record()                                   # torch's current stream == the launch stream (see _stream())
     if dp.sched is not None:
         check_build_config()
+        check_w3_split()
     if dp.sched is not None:
         sc, (t_segs, t_blocks, t_phases, t_groups, t_items, t_parts, t_rowtab) = dp.is_tables(dp.is_parts_for(rows))
         gl = list(gather) + [None] * (4 - len(gather)) if gather is not None else [None] * 4
         gp = (C.c_void_p * 4)(*[(t.data_ptr() if t is not None else 0) for t in gl])
         check(lib().hg_tp_is(sp, ss, i32(n), ptr(h2n), ptr(h2e), i32(dp.hidden), wig, i32(nW), woff, ptr(dp.is_weights(dp.is_parts_for(rows))), ptr(t_segs),
                              ptr(t_blocks), ptr(t_phases), ptr(t_groups), ptr(t_items), ptr(t_parts),
-                             sc.part_table.ctypes.data_as(C.c_void_p), i32(sc.part_table.shape[0]), ptr(t_rowtab),
+                             np.ascontiguousarray(dp.part_table_host(sc)).ctypes.data_as(C.c_void_p), i32(sc.part_table.shape[0]), ptr(t_rowtab),
                              i32(sc.lds_floats * 4), gp, i32(rot_mask), ptr(reduce[0]) if reduce is not None else C.c_void_p(0),
                              ptr(reduce[1]) if reduce is not None else C.c_void_p(0), ptr(out), i64(dp.out_dim), i64(rows), _stream()), "hg_tp_is")
     else:

@@ -51,6 +51,8 @@ class Program:
     # fragments address the concatenated channels of the members.  seg_key[s] = the segment whose work group owns segment s's tile.
     vsegs: List[List[int]] = field(default_factory=list)
     seg_key: Dict[int, int] = field(default_factory=dict)
+    # r6: radial-scale operands in SPLIT HALF PRECISION (see w3_split_fill): (float offset of a W3 fragment block, row tiles); its split twin follows it directly
+    w3_regions: List[Tuple[int, int]] = field(default_factory=list)
 
     def add_weights(self, arr: np.ndarray) -> int:
         arr = np.ascontiguousarray(arr, dtype=_WEIGHT_DTYPE[0]).reshape(-1)
@@ -65,6 +67,9 @@ class Program:
 
     def finalize(self):
         self.weights = np.concatenate(self.chunks) if self.chunks else np.zeros(4, np.float32)
+        if self.weights.dtype == np.float32:                   # (probe_dtype runs leave the split twins zero: they are not affine in the sources, repack.py fills them on the device)
+            self.w3_exp = w3_split_exp(self.weights, self.w3_regions)
+            self.w3_split_ok = w3_split_fill(self.weights, self.w3_regions, self.w3_exp)
         items = []
         for seg, lst in zip(self.segs, self.seg_items):
             seg[5] = len(items)
@@ -74,6 +79,76 @@ class Program:
         self.item_table = np.asarray(items, dtype=np.int32).reshape(-1, ITEM_I32)
         del self.chunks
         return self
+
+
+# ---- the radial scale S = W3^T h on v_mfma_f32_16x16x32_f16 with SPLIT operands (r6, csrc/tp_is.hip) ----------------------------------------
+# 27.5 % of a MessagePackBlock's MFMAs compute the per-edge radial scales S[(l_sh, w), e] = sum_h W3[h, row] h2[e, h] (K = the 64 hidden units).  On the
+# fp32 matrix pipe that is 16 MFMAs of 32 cycles per 16-row tile.  With every operand written as a pair of halves,
+#       x 2^s = hi + 2^-11 lo,      hi = f16(x 2^s),   lo = f16((x 2^s - hi) 2^11)                       (22 significant bits)
+# S 2^(sw + sh) = W_hi h_hi + 2^-11 (W_hi h_lo + W_lo h_hi) is 3 half-precision MFMAs of K = 32 per half of the hidden units: 6 MFMAs of 16 cycles per row
+# tile, fp32 accumulation in two chains, same operand bytes; the dropped lo * lo term is 2^-22 of a product.  Measured end to end on the emulator (Si2, set-A,
+# 3 layers): + 6e-7 relative on H (profiles/r06_tp_is.md).  Why the scalings: the half-precision MFMAs FLUSH SUBNORMAL INPUTS -- an unscaled lo = f16(x - hi)
+# of a weight around 0.1 is below 2^-14 and vanishes (measured: 9e-5 on H); with the remainder scaled by 2^11 the lo terms live in the range of the hi terms,
+# and 2^sw (per program: the largest |W3| lands in [2^12, 2^13)) / 2^sh (the kernel's constant for the hidden rows) keep small values normal.
+# The weights are split HERE (no VALU work in the kernel): every W3 fragment block [G = 4][rt][lane][q] (fp32, read by the segment-stationary kernel, the
+# emulators and the hidden != 64 path) is followed by its twin [t = 2][rt][term = hi, lo][lane][4 dwords], dword d of lane (g, i) = the K-slots (2d, 2d + 1)
+# of half t packed as two f16 (low half-word first), slot s = 4 (G - 2t) + q: the SAME (lane, slot) -> hidden unit map as the fp32 fragments, so the kernel's
+# resident hidden rows pair up with it without a shuffle.  Only for 64 (padded) hidden units.
+W3_SPLIT_MAX = 6.0e4          # a scaled weight above this is beyond the half-precision range: the launches keep the fp32 form (Program.w3_split_ok, ops.check_w3_split)
+SPLIT_LO_EXP = 11             # the remainder is scaled by 2^11 before it is rounded to half precision
+SPLIT_H_EXP = 6               # sh: the kernel scales the hidden rows by 2^6 (|h| < 1023 stays finite; hidden activations are O(1))
+
+
+def w3_split_index(rtm: int):
+    """(source float offsets [n, 2], term-major destination dword offsets [2][n]) of ONE block, relative to the block's / its twin's start"""
+    t, rt, lane, d = np.meshgrid(np.arange(2), np.arange(rtm), np.arange(64), np.arange(4), indexing="ij")
+    src = lambda s_: (((2 * t + s_ // 4) * rtm + rt) * 64 + lane) * 4 + s_ % 4
+    even, odd = src(2 * d), src(2 * d + 1)
+    dst = lambda term: (((t * rtm + rt) * 2 + term) * 64 + lane) * 4 + d
+    return np.stack([even.reshape(-1), odd.reshape(-1)], 1), np.stack([dst(0).reshape(-1), dst(1).reshape(-1)])
+
+
+def f16_split(x: np.ndarray, exp: int = 0):
+    """x (float32) -> (hi, lo) float16 with x 2^exp = hi + 2^-11 lo to 22 bits: hi = f16(x 2^exp), lo = f16((x 2^exp - hi) 2^11)"""
+    x = np.asarray(x, dtype=np.float32) * np.float32(2.0 ** exp)
+    with np.errstate(over="ignore", invalid="ignore"):         # (beyond the half-precision range: inf -- such a program keeps the fp32 form, w3_split_fill)
+        hi = x.astype(np.float16)
+        lo = ((x - hi.astype(np.float32)) * np.float32(2.0 ** SPLIT_LO_EXP)).astype(np.float16)
+    return hi, lo
+
+
+def w3_split_exp(weights: np.ndarray, regions) -> int:
+    """sw of a program: the largest |W3| of its blocks lands in [2^12, 2^13) (a factor 8 below the half-precision maximum: room for an optimiser's steps)"""
+    mx = max((float(np.abs(weights[off:off + 4 * rtm * 256]).max(initial=0.0)) for off, rtm in regions), default=0.0)
+    if not np.isfinite(mx) or mx <= 0.0:
+        return 0
+    return int(np.clip(12 - int(np.floor(np.log2(mx))), -40, 40))
+
+
+def w3_split_fill(weights: np.ndarray, regions, exp: int) -> bool:
+    """write the split twins of all W3 fragment blocks of a float32 blob, in place; False: a scaled weight is beyond the half-precision range (the launches then
+    keep the fp32 form: part record [12] = 0)"""
+    ok = True
+    for off, rtm in regions:
+        n = 4 * rtm * 256
+        src, dst = w3_split_index(rtm)
+        blk = weights[off:off + n]
+        hi_e, lo_e = f16_split(blk[src[:, 0]], exp)
+        hi_o, lo_o = f16_split(blk[src[:, 1]], exp)
+        twin = weights[off + n:off + 2 * n].view(np.uint32)
+        twin[dst[0]] = hi_e.view(np.uint16).astype(np.uint32) | (hi_o.view(np.uint16).astype(np.uint32) << 16)
+        twin[dst[1]] = lo_e.view(np.uint16).astype(np.uint32) | (lo_o.view(np.uint16).astype(np.uint32) << 16)
+        ok = ok and bool(np.abs(blk).max(initial=0.0) * 2.0 ** exp <= W3_SPLIT_MAX)
+    return ok
+
+
+def _add_w3(prog: "Program", w3p: np.ndarray, rtm: int) -> int:
+    """the W3 fragment block of an item (+ its split twin when the program has 64 hidden units); returns the block's offset"""
+    off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
+    if prog.hidden_pad == 64:
+        prog.add_weights(np.zeros(4 * rtm * 256))
+        prog.w3_regions.append((off, rtm))
+    return off
 
 
 def _frag_A(mat_kxr: np.ndarray, ksteps: int, rtm: int, x4: bool) -> np.ndarray:
@@ -360,7 +435,7 @@ def add_tp_items(prog: Program, seg_of_k: Dict[int, int], in_layout: PlanarLayou
             a1_off = prog.add_weights(np.stack(a1))
             w3p = np.zeros((w3.shape[0], R))
             w3p[:, phys] = w3[:, rows_ch[r0:r1]]
-            w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
+            w3_off = _add_w3(prog, w3p, rtm)
             cfp = np.zeros((R, nc))
             cfp[phys] = rows_cf[r0:r1]
             cf_off = prog.add_weights(_cf_block(cfp, rtm, nc))       # [rt][c][g][r]
@@ -414,7 +489,7 @@ def add_tp_adjoint_items(prog: Program, in_layout: PlanarLayout, nsrc: int, src_
                 a1_off = prog.add_weights(_frag_A(Lk, ksteps, rtm, x4)[None])
                 w3p = np.zeros((w3.shape[0], R))
                 w3p[:, phys] = w3[:, rows_ch[r0:r1]]
-                w3_off = prog.add_weights(_frag_A(w3p, prog.hidden_pad // 4, rtm, True))
+                w3_off = _add_w3(prog, w3p, rtm)
                 cfp = np.zeros((R, nc))
                 cfp[phys] = rows_cf[r0:r1]
                 cf_off = prog.add_weights(_cf_block(cfp, rtm, nc))

@@ -29,7 +29,7 @@ class IsSchedule:
     item_table: np.ndarray         # int32[nitems][24]: Program.item_table records with [1], [2] = stage offsets of source 0 / 1 (-1),
     #                                [20..23] = {lk, mul_k, rto, tile_off} of the item's segment
     part_table: np.ndarray         # int32[nparts][16] = {seg_begin, nseg, phase_begin, nphase, trash_off, stage_off, ctr_off, copy_stride,
-    #                                rowtab_off (LDS float offset of the part's row table), rowtab_begin, rowtab_len, lite flag, segment mask lo, hi, 0, 0}
+    #                                rowtab_off (LDS float offset of the part's row table), rowtab_begin, rowtab_len, lite flag, W3 split twins (0 / 1), their exponent sw, 0, 0}
     #                                copy_stride > 0: every wave owns a private copy of the part's tiles (floats between copies)
     rowtab: np.ndarray             # int32: per part, for every (segment, row tile, row) of GEMM2's output the LDS float offset of that
     #                                row's CENTRE column (m = 0) inside its segment tile; rows beyond mul_k -> the shared trash row.
@@ -60,7 +60,7 @@ class IsSchedule:
 
 
 SEG_NEWBATCH = 1 << 16             # IS epilogue: this segment starts a new Wigner staging batch
-IS_PART_I32 = 16                   # [12..15] unused (r5's phase-parts experiment kept a segment mask there; removed in r6, the record size stays)
+IS_PART_I32 = 16                   # [12] = 1: the program's W3 blocks are followed by their split-half-precision twins, scaled by 2^[13] (plan/program.py:w3_split_fill); [14], [15] unused
 
 
 def _item_rto(rec, segs, vsegs=()):
@@ -138,7 +138,7 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
         # inside a work group) when that costs less than 1 % of the estimated critical path -- programs with few phases (narrow irreps) lose
         # more balance than the re-reads cost, data-gradient and lite_mode programs have no such form
         plain = is_schedule(prog, parts if phase_chunks == 1 else ("2d", parts, phase_chunks), separate_mlp=False)
-        if parts != 1 or prog.hidden != 64:
+        if (parts != 1 and os.environ.get("HG_SEP_PARTS") != "1") or prog.hidden != 64:
             return plain
         try:
             sep = is_schedule(prog, parts, separate_mlp=True)
@@ -150,6 +150,8 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
     hp4 = prog.hidden_pad // 4
     nseg = prog.seg_table.shape[0]
     lite_flag = int(np.isin(prog.item_table[:, 0], (IT_LINC, IT_LINM, IT_POST)).any())      # lite_mode items run in their own kernel instantiation
+    s_split = int(bool(getattr(prog, "w3_regions", None)) and getattr(prog, "w3_split_ok", True))      # part record [12]: W3 blocks carry their split-half-precision twins,
+    s_exp = int(getattr(prog, "w3_exp", 0))                                                              # [13]: scaled by 2^[13] (plan/program.py:w3_split_fill)
     if lite_flag and np.isin(prog.item_table[:, 0], (IT_TP, IT_LIN)).any():
         raise NotImplementedError("input-stationary schedule: a program mixes lite_mode items with tensor-product / Linear items")
     key_of = [prog.seg_key.get(sg, sg) for sg in range(nseg)]   # segments written by merged items share one work-group key
@@ -200,12 +202,12 @@ def is_schedule(prog: "Program", parts=1, separate_mlp: Optional[bool] = None) -
             o_ = 0
             for b_ in bins_:
                 parttab.append([len(segs_all), len(sub["segs"]), len(ptab) + o_, len(b_), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
-                                sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, -1, -1, 0, 0])
+                                sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, s_split, s_exp, 0, 0])
                 o_ += len(b_)
             atomic_any = True
         else:
             parttab.append([len(segs_all), len(sub["segs"]), len(ptab), len(sub["ptab"]), sub["trash_off"], sub["stage_off"], sub["ctr_off"],
-                            sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, -1, -1, 0, 0])
+                            sub["copy_stride"], sub["rowtab_off"], len(rowtab_all), len(sub["rowtab"]), lite_flag, s_split, s_exp, 0, 0])
         rowtab_all += sub["rowtab"]
         phase_cls_all += sub["phase_cls"]
         segs_all += list(sub["segs"])

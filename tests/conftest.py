@@ -32,7 +32,7 @@ GPU_ORDER = [
     (1, ("test_si2_default_irreps_vs_oracle", "test_sio2_setA_vs_oracle", "test_mos2_soc_setA_vs_oracle", "test_uni_hamgnn_chain_vs_oracle", "test_uni_hamgnn_style_batch",
          "test_full_forward_vs_oracle", "test_multi_crystal_batch", "test_ragged_batch", "test_transformer_vs_oracle", "test_radial_mlp_with")),
     (2, ("test_full_size_properties", "test_uni_hamgnn_chain_full_size", "test_uni_hamgnn_chain_on_a_batch", "test_round3_kernels_full_size")),
-    (3, ("test_small_graph_forward_is_bit_reproducible", "test_training_step_is_bit_reproducible", "test_training_step_on_a_small_crystal")),
+    (3, ("test_split_radial_scale", "test_small_graph_forward_is_bit_reproducible", "test_training_step_is_bit_reproducible", "test_training_step_on_a_small_crystal")),
     (4, ("test_message_pack_random", "test_message_pack_single_part", "test_fused_node_scatter", "test_structural_zero_inputs", "test_unread_irreps", "test_sharded_forward",
          "test_rccl_backend", "test_bench_script", "test_captured_forward", "test_row_program_kernel", "test_block_gemm", "test_precision_64", "test_edge_kernel_is_not_disturbed")),
     (6, ("test_band_", "test_head_bands")),

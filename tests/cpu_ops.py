@@ -412,6 +412,7 @@ def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
 def install(mp):
     """monkeypatch hamgnn_amd.ops with the stand-ins above (pytest's `monkeypatch` fixture: undone after the test)"""
     mp.setattr(ops, "_require_gpu", lambda t: None)
+    mp.setattr(emu, "S_F16", True)                             # the radial scales as csrc/tp_is.hip forms them (split half precision from the twin tables)
     mp.setattr(ops, "Geometry", Geometry)
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
     for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "row_program", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",

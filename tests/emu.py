@@ -43,7 +43,38 @@ def radial_hidden(rbf, layers):
     return h
 
 
-def _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype):
+# csrc/tp_is.hip computes the radial scales of programs with 64 hidden units on the half-precision matrix pipe with split operands (plan/program.py:
+# w3_split_fill).  S_F16 = True makes the emulator of the input-stationary schedule do the same arithmetic from the SAME table bytes
+# (the split twin behind every W3 block) -- what the CPU
+# stand-ins of the product's end-to-end tests run; False (default): the exact fp32-table form (the segment-stationary kernel's, and the 1e-12 planner tests').
+S_F16 = False
+
+
+def _split_scale(prog, Wt32, w3, rtm, hh_cols, ne, dtype):
+    """S[rt][row][edge] of one item as the kernel forms it: twin block [t][rt][hi, lo][lane][4 dwords of two halves] x the hidden rows split the same way;
+    SUBNORMAL halves count as zero (the half-precision MFMAs flush them), two accumulation chains, S = 2^-(sw + sh) (S0 + 2^-11 S1)"""
+    n = 4 * rtm * 256
+    tw = Wt32[w3 + n:w3 + 2 * n].view(np.uint32).reshape(2, rtm, 2, 64, 4)
+    halves = np.stack([(tw & 0xffff).astype(np.uint16), (tw >> 16).astype(np.uint16)], -1).reshape(2, rtm, 2, 64, 8).view(np.float16).astype(dtype)   # [t][rt][term][lane][slot]
+    halves[np.abs(halves) < 2.0 ** -14] = 0.0
+    S0, S1 = np.zeros((rtm, 16, 16), dtype=dtype), np.zeros((rtm, 16, 16), dtype=dtype)
+    for t in range(2):
+        # B operand of lane (g, el), slot s: hidden unit 16 (2t + s // 4) + 4 g + s % 4 of edge el
+        B = np.zeros((2, 4, 8, 16), dtype=dtype)                                          # [term][g][slot][edge]
+        for g in range(4):
+            for s_ in range(8):
+                hi, lo = P.f16_split(hh_cols[:, 16 * (2 * t + s_ // 4) + 4 * g + s_ % 4], P.SPLIT_H_EXP)
+                B[0, g, s_, :ne], B[1, g, s_, :ne] = hi.astype(dtype), lo.astype(dtype)
+        B[np.abs(B) < 2.0 ** -14] = 0.0
+        for rt in range(rtm):
+            A = halves[t, rt].reshape(2, 4, 16, 8)                                        # [term][g][i][slot]
+            S0[rt] += np.einsum("gis,gse->ie", A[0], B[0])
+            S1[rt] += np.einsum("gis,gse->ie", A[0], B[1]) + np.einsum("gis,gse->ie", A[1], B[0])
+    c0 = 2.0 ** -(int(getattr(prog, "w3_exp", 0)) + P.SPLIT_H_EXP)
+    return c0 * S0 + (c0 * 2.0 ** -P.SPLIT_LO_EXP) * S1
+
+
+def _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype, split_scale=False):
     """one item record on one 16-edge column tile, fragment-exact (tile: [rto*16, nco, 16], updated in place / returned)."""
     E = srcs[0].shape[0]
     H = prog.hidden
@@ -120,13 +151,16 @@ def _apply_item(prog, Wt, it, srcs, h2, cols, ne, tile, lk, rto, dtype):
         S = np.zeros((rtm, 16, 16), dtype=dtype)
         hh = np.zeros((E, Hp), dtype=dtype)
         hh[:, :H] = h2[mlp]
-        for G in range(Hp // 16):
-            for q in range(4):
-                B = np.zeros((4, 16), dtype=dtype)
-                for g in range(4):
-                    B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
-                for rt in range(rtm):
-                    S[rt] += W3[G, rt, :, :, q].T @ B
+        if split_scale and Hp == 64 and any(o == w3 for o, _ in getattr(prog, "w3_regions", ())):
+            S = _split_scale(prog, prog.weights, w3, rtm, hh[cols], ne, dtype)
+        else:
+            for G in range(Hp // 16):
+                for q in range(4):
+                    B = np.zeros((4, 16), dtype=dtype)
+                    for g in range(4):
+                        B[g, :ne] = hh[cols, 16 * G + 4 * g + q]
+                    for rt in range(rtm):
+                        S[rt] += W3[G, rt, :, :, q].T @ B
         CF = Wt[cf:cf + rtm * nc * 16].reshape(rtm, nc, 16)                           # [rt][c][row = 4g + r]
         mid = mid * S[:, None, :, :] * CF[:, :, :, None]
         A2 = Wt[a2:a2 + rto * rtm * 4 * 64].reshape(rto, rtm, 4, 16, 4)               # [rt'][rt][k=g][i][r]
@@ -339,7 +373,8 @@ def run_program_is(prog, sched, srcs, h2=(None, None), D=None, lmax=None, dtype=
                         rec = it[:P.ITEM_I32].copy()
                         if merged:
                             rec[16] = 0
-                        tmp = _apply_item(prog, Wt, rec, srcs, h2, cols, ne, tmp, mm, rto_i, dtype)
+                        # (the kernel takes the split-half-precision form of the radial scale when the part record says the twins are there)
+                        tmp = _apply_item(prog, Wt, rec, srcs, h2, cols, ne, tmp, mm, rto_i, dtype, split_scale=S_F16 and int(sched.part_table[0][12]) == 1)
                         if int(it[0]) == P.IT_TP and int(it[7]) and mm > 0:
                             # odd super-path: the kernel does not compute the centre column -- it has to vanish identically
                             assert not tmp[:, mm, :].any(), "centre column of an odd item is not structurally zero"

@@ -2394,6 +2394,51 @@ def check_small_graph_forward_reproducible(device="cuda", which="A", graph="si2"
             "H_absmax": float(runs[0][2].abs().max())}
 
 
+def check_split_radial_scale(device="cuda", workload="sio2_10k", reps=3):
+    """r6: the radial scales of single-part launches on the half-precision matrix pipe with split operands (csrc/tp_is.hip, plan/program.py:w3_split_fill).
+    On the BENCHMARK crystal (51 k tiles per launch, node-fed, fused scatter) and on a small crystal (split launches: several workgroups per tile, rotated
+    staging): (1) `reps` forwards bit-identical -- the first form of this code was not, a few tiles per launch came out wrong whenever two workgroups shared
+    a CU (loads into a fragment's registers right behind the MFMA that reads it: profiles/r06_tp_is.md section 4); (2) the backbone's rows agree with the fp32
+    form of the same build (HG_S_SPLIT=0 -> ops.S_SPLIT_OFF) to the same-math tolerance."""
+    import bench
+    from hamgnn_amd import ops
+    from hamgnn_amd.models.hamgnn_conv import HamGNNConvE3
+    irr = bench.IRREPS["A"]
+    torch.manual_seed(666)
+    m = HamGNNConvE3(bench.make_cfg(irr)).to(device)
+    out = {}
+    old = ops.S_SPLIT_OFF
+    try:
+        for name, wl in (("big", workload), ("small", "mos2_48")):
+            g = bench.make_graph(wl, 19).to(device)
+            runs = {}
+            for off in (False, True):
+                ops.S_SPLIT_OFF = off
+                with torch.no_grad():
+                    rs = []
+                    for _ in range((reps if name == "big" else 12) if not off else 1):
+                        rep = m(g)
+                        rs.append((rep["_node_planar"].clone(), rep["_edge_planar_rot"].clone()))
+                        del rep
+                runs[off] = rs
+            torch.cuda.synchronize()
+            on, offr = runs[False], runs[True][0]
+            sc = [float(t.abs().max()) for t in offr]
+            out[name + "_split_vs_fp32_node"] = float((on[0][0] - offr[0]).abs().max()) / sc[0]
+            out[name + "_split_vs_fp32_edge"] = float((on[0][1] - offr[1]).abs().max()) / sc[1]
+            out[name + "_repeat_max_abs"] = max(float((r[i] - on[0][i]).abs().max()) for r in on[1:] for i in (0, 1))
+            if name == "small":
+                out["small_split_launch"] = float(all(blk.conv_tp._dp_for(int(g.num_edges), True).is_parts_for(int(g.num_edges)) != 1 for blk in m.convolutions))
+            if name == "big":
+                out["E"] = int(g.num_edges)
+                out["single_part"] = float(all(blk.conv_tp._dp_for(int(g.num_edges), True).is_parts_for(int(g.num_edges)) == 1 for blk in m.convolutions))
+                out["twins_flagged"] = float(all(int(blk.conv_tp._dp.sched.part_table[0][12]) == 1 for blk in m.convolutions))
+            del runs, on, offr
+    finally:
+        ops.S_SPLIT_OFF = old
+    return out
+
+
 def check_training_step_reproducible(device="cuda", transformer=False, n_atoms=260):
     """two evaluations of hamgnn_amd.training.training_step on the same model and batch give BIT-identical losses and gradients: the node
     scatter (hg_segment_sum), the fused weight-gradient kernel (split / copy blocks added in a fixed order) and the row scatters of the

@@ -755,6 +755,18 @@ def test_backward_skips_structural_zero_inputs(legacy):
     assert r["first_conv_wgrad_mfma_ratio"] < 0.6 and r["first_conv_adjoint_mfma_ratio"] < 0.6, r
 
 
+def test_split_radial_scale_full_size():
+    """r6: the radial scales on the half-precision matrix pipe with split operands (27.5 % of a MessagePackBlock's MFMAs: 6 x 16 pipe cycles per row tile instead of
+    16 x 32) on the 10 002-atom benchmark crystal and on a 48-atom MoS2 sheet (split launches): repeated forwards bit-identical, the rows within the same-math
+    tolerance of the fp32 form of the same build"""
+    r = G.check_split_radial_scale()
+    print(r)
+    assert r["single_part"] == 1.0 and r["twins_flagged"] == 1.0 and r["E"] > 800000 and r["small_split_launch"] == 1.0, r
+    assert r["big_repeat_max_abs"] == 0.0 and r["small_repeat_max_abs"] == 0.0, r
+    for k in ("big_split_vs_fp32_node", "big_split_vs_fp32_edge", "small_split_vs_fp32_node", "small_split_vs_fp32_edge"):
+        assert 0.0 < r[k] < G.SAME_MATH_TOL, (k, r)
+
+
 @pytest.mark.parametrize("which,graph", [("A", "si2"), ("B", "si2"), ("A", "cell9")], ids=["si2_setA", "si2_setB", "cell9_mini"])
 def test_small_graph_forward_is_bit_reproducible(which, graph):
     """r6: BASELINE config #1 (and the 9-atom cell GPUTEST_r05 went red on) evaluated four times eagerly: node rows, edge rows and Hamiltonian blocks agree

@@ -106,6 +106,88 @@ def test_message_pack_program_x4_path_vs_oracle():
     assert rel(lay.from_planar(outp), out) < 1e-6
 
 
+def test_radial_scale_split_half_precision_twins_vs_oracle():
+    """r6: programs with 64 hidden units carry, behind every W3 fragment block, its split-half-precision twin (hi = f16(w), lo = f16(w - hi), K-slots paired as
+    the kernel's resident hidden rows are).  (1) hi + lo reproduces the fp32 weight to 2^-21; (2) the device-side refresh (ops.DeviceProgram.refresh_w3_split,
+    torch) writes the same bytes as the host packer; (3) the emulator fed from the TWINS (the kernel's arithmetic: W_lo h_hi + W_hi h_lo + W_hi h_hi) agrees
+    with the fp64 oracle to 3e-6 and with the exact-table form to 2e-6 -- but not to 1e-9: the path is exercised; (4) a weight beyond the half-precision
+    range clears the part record's flag."""
+    import torch
+    from oracle import hamgnn_ref as R, e3
+    from hamgnn_amd import ops
+    irr, sh = "16x0e+12x0o+32x1o+4x1e+7x2e", "0e+1o+2e"
+    torch.manual_seed(0)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        ref = R.MessagePackBlock(irr, irr, sh, irr, "8x0e", radial_MLP=[64, 64])
+        E = 19
+        g = torch.Generator().manual_seed(1)
+        src, dst, ef = (torch.randn(E, ref.irreps_node_feats.dim, generator=g) for _ in range(3))
+        n = torch.nn.functional.normalize(torch.randn(E, 3, generator=g), dim=-1)
+        shv = e3.spherical_harmonics([0, 1, 2], n, True, "component")
+        rbf = torch.randn(E, 8, generator=g)
+        out = ref(src, dst, ef, shv, rbf).detach().numpy()
+    finally:
+        torch.set_default_dtype(prev)
+    sd = {k: v.detach().numpy() for k, v in ref.state_dict().items()}
+    lay = P.PlanarLayout(irr)
+    D = emu.edge_wigner_all(n.numpy(), 2)
+    xs, xd, fe = (emu.rotate_rows(lay.to_planar(t.numpy()), lay, D, 2) for t in (src, dst, ef))
+    hn = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "node_weight_generator", emu.SILU_CST))
+    he = emu.radial_hidden(rbf.numpy(), P.radial_hidden_weights(sd, "edge_weight_generator", emu.SILU_CST))
+    prog = P.build_message_pack_program(sd, irr, irr, sh, irr, unrotate=True)
+    assert prog.hidden_pad == 64 and prog.w3_regions and prog.w3_split_ok
+    n_tp = int((prog.item_table[:, 0] == P.IT_TP).sum())
+    assert len(prog.w3_regions) == n_tp and sorted(o for o, _ in prog.w3_regions) == sorted(int(it[12]) for it in prog.item_table if int(it[0]) == P.IT_TP)
+    # (1) the twins decode to the weights: w 2^sw = hi + 2^-11 lo to 22 bits, every half normal or zero where it matters, the largest scaled weight in [2^12, 2^13)
+    sw = prog.w3_exp
+    big_ = max(float(np.abs(prog.weights[off:off + 4 * rtm * 256]).max()) for off, rtm in prog.w3_regions) * 2.0 ** sw
+    assert 2.0 ** 12 <= big_ < 2.0 ** 13
+    for off, rtm in prog.w3_regions:
+        nfl = 4 * rtm * 256
+        srcidx, dstidx = P.w3_split_index(rtm)
+        tw = prog.weights[off + nfl:off + 2 * nfl].view(np.uint32)
+        dec = lambda term, half: ((tw[dstidx[term]] >> (16 * half)) & 0xffff).astype(np.uint16).view(np.float16).astype(np.float64)
+        for half in (0, 1):
+            w = prog.weights[off + srcidx[:, half]].astype(np.float64) * 2.0 ** sw
+            hi, lo = dec(0, half), dec(1, half)
+            hi[np.abs(hi) < 2.0 ** -14], lo[np.abs(lo) < 2.0 ** -14] = 0.0, 0.0          # what the matrix pipe sees
+            # 22 bits relative; below the halves' normal range an absolute floor of 2^-24 in scaled units = 2^-36 of the largest weight
+            assert (np.abs(hi + lo * 2.0 ** -11 - w) <= 2.0 ** -21 * np.abs(w) + 2.0 ** -24).all()
+    # (2) device-side refresh == host packer, byte for byte
+    dp = ops.DeviceProgram(prog, torch.device("cpu"), schedule="is")
+    want = prog.weights.copy()
+    for off, rtm in prog.w3_regions:
+        dp.weights[off + 4 * rtm * 256:off + 8 * rtm * 256] = 0.0
+    dp.refresh_w3_split()
+    assert np.array_equal(dp.weights.numpy().view(np.uint32), want.view(np.uint32))
+    ops.check_w3_split()
+    sc = P.is_schedule(prog)
+    assert int(sc.part_table[0][12]) == 1 and int(dp.part_table_host(sc)[0][12]) == 1
+    # (3) the kernel's arithmetic from the twins
+    exact = emu.run_program_is(prog, sc, [xs, xd, fe], (hn, he), D, 2)
+    emu.S_F16 = True
+    try:
+        split = emu.run_program_is(prog, sc, [xs, xd, fe], (hn, he), D, 2)
+    finally:
+        emu.S_F16 = False
+    assert rel(lay.from_planar(exact), out) < 1e-6
+    assert rel(lay.from_planar(split), out) < 3e-6 and 1e-9 < rel(split, exact) < 2e-6, (rel(lay.from_planar(split), out), rel(split, exact))
+    # (4) out of the half-precision range: the fp32 form
+    sd_big = dict(sd)
+    k_last = sorted(k for k in sd if k.startswith("node_weight_generator.layer") and k.endswith(".weight"))[-1]
+    sd_big[k_last] = sd[k_last] * 1e6                          # (a uniformly larger layer only moves the exponent: still split)
+    big = P.build_message_pack_program(sd_big, irr, irr, sh, irr, unrotate=True)
+    assert big.w3_split_ok and big.w3_exp < prog.w3_exp - 15 and int(P.is_schedule(big).part_table[0][13]) == big.w3_exp
+    sd_big[k_last] = sd[k_last] * float("inf")
+    assert not P.build_message_pack_program({**sd, k_last: np.where(np.arange(sd[k_last].size).reshape(sd[k_last].shape) == 0, np.inf, sd[k_last])}, irr, irr, sh, irr, unrotate=True).w3_split_ok
+    dp.weights[prog.w3_regions[0][0]] = 1e6                   # a weight that outgrew the program's exponent after a refresh on the device: the fp32 form
+    dp.refresh_w3_split()
+    ops.check_w3_split()
+    assert int(dp.part_table_host(sc)[0][12]) == 0
+
+
 def test_message_pack_lite_program_vs_golden(golden_dir):
     f = load(golden_dir, "message_pack_block_lite")
     sd, i = f["weights"], f["inputs"]
