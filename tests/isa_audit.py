@@ -20,6 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]      # as hamgnn_amd/csrc/Makefile (tests/test_isa_audit.py checks that the two agree)
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)      # (one compile per (file, defines) and test session: tp_is.hip alone takes 20 s)
 def compile_to_asm(src, defines=()):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", *NOPK, "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out, src]

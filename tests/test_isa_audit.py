@@ -86,7 +86,7 @@ def test_no_kernel_of_the_library_holds_packed_fp32_instructions():
     assert " ".join(A.NOPK) in mk and "$(NOPK)" in mk.split("FLAGS :=", 1)[1].split("\n", 1)[0]
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     assert len(srcs) >= 11
-    with ThreadPoolExecutor(4) as ex:
+    with ThreadPoolExecutor(8) as ex:
         texts = list(ex.map(lambda f: A.compile_to_asm(os.path.join(CSRC, f)), srcs))
     for f, text in zip(srcs, texts):
         hits = re.findall(r"^\s+(v_pk_(?:fma|mul|add)_f32)\b", text, flags=re.M)
