@@ -13,7 +13,7 @@ _lib = None
 EXPORTS = ["hg_last_error", "hg_version", "hg_scratch_bytes", "hg_edge_geometry", "hg_radial_basis", "hg_radial_hidden", "hg_rotate_gather", "hg_tp_fused", "hg_tp_is", "hg_tp_wgrad", "hg_row_program",
            "hg_segment_sum", "hg_gate", "hg_add_rows", "hg_to_planar", "hg_from_planar", "hg_embed_lookup", "hg_ham_merge",
            "hg_ham_finish", "hg_ham_readout", "hg_block_mean", "hg_soc_assemble", "hg_zero_point_shift", "hg_sym_contraction", "hg_sym_contraction3", "hg_hk_assemble",
-           "hg_attn_logits", "hg_attn_aggregate", "hg_linear_planar", "hg_linear_wgrad", "hg_block_gemm", "hg_gate_backward", "hg_radial_hidden_multi", "hg_mfma_probe", "hg_build_config", "hg_norm_act", "hg_norm_act_backward"]
+           "hg_attn_logits", "hg_attn_aggregate", "hg_linear_planar", "hg_linear_wgrad", "hg_block_gemm", "hg_gate_backward", "hg_radial_hidden_multi", "hg_mfma_probe", "hg_build_config", "hg_norm_act", "hg_norm_act_backward", "hg_w3_split_refill"]
 
 
 def build(verbose=False):

@@ -826,6 +826,38 @@ __global__ __launch_bounds__(256, 2) void mfma_probe_kernel(const float* __restr
     out[tid] = s[0] + s[1] + s[2] + s[3];
 }
 
+// ---- split-half-precision twins of the radial weights (csrc/tp_is.hip: radial scale on v_mfma_f32_16x16x32_f16; plan/program.py:w3_split_fill) refilled ON THE DEVICE after a
+// device-side repack (training): pair k = the two fp32 weights w[se[k]], w[so[k]] that share a dword of the twin; hi = f16(x 2^s), lo = f16((x 2^s - hi) 2^11), written as packed
+// pairs at dh[k] / dl[k]; max |x 2^s| into maxabs (non-negative floats order like their bit patterns) for the host's range check.  One launch per program (the torch-op version: 18).
+__global__ __launch_bounds__(256) void w3_split_refill_kernel(float* __restrict__ w, const int64_t* __restrict__ se, const int64_t* __restrict__ so, const int64_t* __restrict__ dh,
+                                                              const int64_t* __restrict__ dl, int64_t n, float scale, float lo_scale, float* __restrict__ maxabs) {
+    float m = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const float xe = w[se[k]] * scale, xo = w[so[k]] * scale;
+        const _Float16 he = (_Float16)xe, ho = (_Float16)xo;
+        const _Float16 le = (_Float16)((xe - (float)he) * lo_scale), lo = (_Float16)((xo - (float)ho) * lo_scale);
+        unsigned short a, b;
+        __builtin_memcpy(&a, &he, 2); __builtin_memcpy(&b, &ho, 2);
+        reinterpret_cast<unsigned*>(w)[dh[k]] = (unsigned)a | ((unsigned)b << 16);
+        __builtin_memcpy(&a, &le, 2); __builtin_memcpy(&b, &lo, 2);
+        reinterpret_cast<unsigned*>(w)[dl[k]] = (unsigned)a | ((unsigned)b << 16);
+        m = fmaxf(m, fmaxf(fabsf(xe), fabsf(xo)));
+    }
+    if (!(m == m)) m = __int_as_float(0x7f800000);              // NaN weights: beyond any range
+    atomicMax(reinterpret_cast<unsigned*>(maxabs), __float_as_uint(m));
+}
+
+extern "C" int hg_w3_split_refill(float* weights, const int64_t* src_even, const int64_t* src_odd, const int64_t* dst_hi, const int64_t* dst_lo, int64_t npairs,
+                                  float scale, float lo_scale, float* maxabs, void* stream) {
+    HgDeviceGuard dev_guard(stream);
+    if (npairs <= 0) return 0;
+    if (!weights || !src_even || !src_odd || !dst_hi || !dst_lo || !maxabs) return hg_fail(-2, "hg_w3_split_refill: null pointer");
+    if (hipMemsetAsync(maxabs, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return hg_fail(-3, "hg_w3_split_refill: memset failed");
+    const int64_t blocks = (npairs + 255) / 256;
+    w3_split_refill_kernel<<<dim3((unsigned)(blocks < 1024 ? blocks : 1024)), 256, 0, (hipStream_t)stream>>>(weights, src_even, src_odd, dst_hi, dst_lo, npairs, scale, lo_scale, maxabs);
+    return hg_check_launch("hg_w3_split_refill");
+}
+
 extern "C" int hg_mfma_probe(const float* in65536, float* out, int nblocks, int iters, void* stream) {
     HgDeviceGuard dev_guard(stream);
     if (nblocks <= 0 || iters <= 0) return hg_fail(-2, "hg_mfma_probe: nblocks and iters must be positive");

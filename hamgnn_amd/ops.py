@@ -89,6 +89,16 @@ def check_build_config():
     _BUILD_CONFIG_OK = True
 
 
+def w3_split_refill(w: torch.Tensor, se, so, dh, dl, scale: float, lo_scale: float) -> torch.Tensor:
+    """the split-half-precision twins of the fp32 W3 blocks of the packed weight blob `w`, rewritten IN PLACE by one launch (csrc/aux_kernels.hip:hg_w3_split_refill; index
+    tensors: DeviceProgram.refresh_w3_split); returns the device scalar max |w 2^s| for the lazy range check (check_w3_split)"""
+    _require_gpu(w)
+    assert w.dtype == torch.float32 and w.is_contiguous() and all(t.dtype == torch.int64 and t.is_contiguous() for t in (se, so, dh, dl))
+    mx = torch.empty(1, device=w.device, dtype=torch.float32)
+    check(lib().hg_w3_split_refill(ptr(w), ptr(se), ptr(so), ptr(dh), ptr(dl), i64(se.numel()), C.c_float(scale), C.c_float(lo_scale), ptr(mx), _stream()), "hg_w3_split_refill")
+    return mx[0]
+
+
 def check_w3_split():
     """one host read for all programs refreshed since the last launch: a W3 weight beyond the half-precision range switches that program's launches to the fp32
     form of the radial scale (and back, once the weights have come back)"""
@@ -156,16 +166,8 @@ class DeviceProgram:
                 se.append(off + src[:, 0]); so.append(off + src[:, 1]); dh.append(off + n + dst[0]); dl.append(off + n + dst[1])
             self._w3_idx = tuple(_dev(np.concatenate(a).astype(np.int64), self._device) for a in (se, so, dh, dl))
         se, so, dh, dl = self._w3_idx
-        w = self.weights
         sc_, lo_ = float(2.0 ** int(getattr(self.prog, "w3_exp", 0))), float(2.0 ** P.SPLIT_LO_EXP)
-        xe, xo = w[se] * sc_, w[so] * sc_
-        he, ho = xe.half(), xo.half()
-        le, lo = ((xe - he.float()) * lo_).half(), ((xo - ho.float()) * lo_).half()
-        pack = lambda a, b: (a.view(torch.int16).to(torch.int32) & 0xffff) | (b.view(torch.int16).to(torch.int32) << 16)
-        wi = w.view(torch.int32)
-        wi[dh] = pack(he, ho)
-        wi[dl] = pack(le, lo)
-        W3_SPLIT_PENDING.append((self, torch.maximum(xe.abs().max(), xo.abs().max())))
+        W3_SPLIT_PENDING.append((self, w3_split_refill(self.weights, se, so, dh, dl, sc_, lo_)))
 
     def part_table_host(self, sc) -> np.ndarray:
         """the schedule's part table as the launch passes it in host memory: [12] (W3 split twins present) cleared when a refreshed weight left the half-precision range"""

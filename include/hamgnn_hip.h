@@ -157,6 +157,13 @@ int hg_build_config(int what);
  * fp64 accumulation.                                                                                                            */
 int hg_block_gemm(const float* a, const float* b, void* c, int c_is_double, const int32_t* units, int nunits, int max_tiles, void* stream);
 
+/* r6: the split-half-precision twins of the radial weights inside a packed weight blob (hamgnn_amd/plan/program.py:w3_split_fill; read by hg_tp_is when the part record's
+ * field [12] is set) recomputed on the device after the fp32 blocks were rewritten in place (training: hamgnn_amd/repack.py).  Pair k: hi / lo halves of
+ * weights[src_even[k]] and weights[src_odd[k]] (x scale), packed into the dwords dst_hi[k] / dst_lo[k]; *maxabs = max |x scale| (the caller keeps the fp32 form of the
+ * radial scale while it exceeds the f16 range).  No counterpart in the reference (the reference has no packed weights); replaces 18 torch launches per program and step. */
+int hg_w3_split_refill(float* weights, const int64_t* src_even, const int64_t* src_odd, const int64_t* dst_hi, const int64_t* dst_lo, int64_t npairs,
+                       float scale, float lo_scale, float* maxabs, void* stream);
+
 /* Weight gradient of an o3.Linear on planar rows, all paths in one launch (csrc/linear_wgrad.hip): what torch.autograd computes for the weight of
  * the e3nn o3.Linears of the path when the reference trains (hamgnn/models/Model.py:150-196; nn/interaction_blocks.py:332-358,
  * nn/convolution.py:127, models/hamgnn_output.py:49-58).  units int32[nunits][8] = {x_off, x_mulp, g_off, g_mulp, 2 l + 1, first input channel,

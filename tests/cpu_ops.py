@@ -409,6 +409,18 @@ def zero_point_shift(H, Href, S, nao, soc=False, threshold=1e-6):
     return dE.float().reshape(1)
 
 
+def w3_split_refill(w, se, so, dh, dl, scale, lo_scale):
+    """ops.w3_split_refill in torch ops (the arithmetic of csrc/aux_kernels.hip:w3_split_refill_kernel)"""
+    xe, xo = w[se] * scale, w[so] * scale
+    he, ho = xe.half(), xo.half()
+    le, lo = ((xe - he.float()) * lo_scale).half(), ((xo - ho.float()) * lo_scale).half()
+    pack = lambda a, b: (a.view(torch.int16).to(torch.int32) & 0xffff) | (b.view(torch.int16).to(torch.int32) << 16)
+    wi = w.view(torch.int32)
+    wi[dh] = pack(he, ho)
+    wi[dl] = pack(le, lo)
+    return torch.maximum(xe.abs().max(), xo.abs().max())
+
+
 def install(mp):
     """monkeypatch hamgnn_amd.ops with the stand-ins above (pytest's `monkeypatch` fixture: undone after the test)"""
     mp.setattr(ops, "_require_gpu", lambda t: None)
@@ -417,5 +429,5 @@ def install(mp):
     mp.setattr(ops, "prefill_radial_hidden", lambda geo, gens, cst: False)
     for name in ("radial_hidden", "embed_lookup", "rotate_gather", "tp_fused", "tp_wgrad", "row_program", "linear_planar", "segment_sum", "to_planar", "from_planar", "gate",
                  "gate_backward", "norm_act", "norm_act_backward", "ham_merge", "ham_finish", "ham_readout", "sym_contraction", "sym_contraction3", "block_mean", "soc_assemble", "attention_aggregate",
-                 "attention_logits", "hk_assemble", "zero_point_shift", "block_gemm"):
+                 "attention_logits", "hk_assemble", "zero_point_shift", "block_gemm", "w3_split_refill"):
         mp.setattr(ops, name, globals()[name])

@@ -801,3 +801,12 @@ def test_edge_kernel_is_not_disturbed_by_a_co_running_half_precision_mfma_kernel
     for name in ("fp32_mfma_control", "f16_16x16x32_chains", "f16_16x16x32_independent", "bf16_16x16x32_chains"):
         assert r[name]["launches_overlapped"] >= 3, r
         assert r[name]["wrong_tiles"] == 0, r
+
+
+@pytest.mark.gpu
+def test_split_radial_scale_twins_refilled_on_the_device_equal_the_planner():
+    """hg_w3_split_refill vs plan/program.py:w3_split_fill on a set-A MessagePackBlock: bit for bit"""
+    r = G.check_w3_twins_device_refill()
+    assert r["regions"] > 100 and r["twin_dwords"] > 100000, r
+    assert r["dwords_different"] == 0 and r["wiped_dwords_left"] == 0, r
+    assert abs(r["maxabs_device"] - r["maxabs_host"]) <= 1e-6 * r["maxabs_host"] and not r["split_off_after_check"], r
