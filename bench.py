@@ -48,6 +48,7 @@ PMC_HBM_BYTES_PER_EDGE_BLOCK = {("is", "A"): 23.6e3, ("is", "B"): 14.2e3, ("seg"
 REF_TP_MS_PER_MEDGE_LAUNCH = {"A": 41.98, "B": 18.96}
 PEAK_FP32_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector == fp32-input MFMA peak
 PEAK_HBM_GBS = 8000.0
+PEAK_F16_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense BF16 / FP16 MFMA peak (16 x the fp32-input rate); prices the radial scale's half-precision products in `frac_of_mixed_pipe_floor`
 
 
 def make_cfg(irreps, lite=False):
@@ -519,6 +520,8 @@ def main():
     t_tot = sum(t for t, _, _ in mp)
     useful_tot = sum(dps[k % len(dps)].prog.flops_per_row * r for k, (_, r, _) in enumerate(mp))
     issued_tot = sum(issued_of(dps[k % len(dps)]) * r for k, (_, r, _) in enumerate(mp))
+    radial_tot = sum(getattr(dps[k % len(dps)].prog, "mfma_radial", 0) * 2048.0 / 16.0 * r for k, (_, r, _) in enumerate(mp))
+    split_on = os.environ.get("HG_S_SPLIT", "1") != "0" and not args.lite
     share = [dp.prog.flops_per_row / fo.flops_per_row for dp, fo in zip(dps, full_of)]           # non-zero share of the reference formulation's flops, per launch of a step
     ref_tot = sum(REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * r for _, r, _ in mp)
     ref_nonzero_tot = sum(REF_FLOPS_PER_EDGE_BLOCK[args.irreps] * share[k % len(dps)] * r for k, (_, r, _) in enumerate(mp))
@@ -548,6 +551,11 @@ def main():
                 "launch_ms_by_position_in_step": [round(1e3 * sum(v) / len(v), 3) for _, v in sorted(per_kind.items())],
                 "nonzero_flop_share_by_position": [round(x, 4) for x in share],
                 "executed_useful_tflops": useful_tot / t_tot / 1e12, "issued_mfma_tflops": issued_tot / t_tot / 1e12,
+                # r6: the radial scales (this share of the fp32-equivalent MFMAs the programs issue) run as 3 half-precision products of K = 32 on the f16 pipe; the floor of a
+                # launch that spends exactly its fp32 MFMAs at the fp32 peak and those products at the f16 peak, over the measured time -- `frac` above prices ALL flops at fp32
+                "radial_scale_share_of_issued_mfma": radial_tot / issued_tot if issued_tot else None,
+                "frac_of_mixed_pipe_floor": ((issued_tot - radial_tot) / (PEAK_FP32_TFLOPS * 1e12) + 3.0 * radial_tot / (PEAK_F16_TFLOPS * 1e12)) / t_tot * (flops_tot / issued_tot)
+                                            if (issued_tot and split_on) else None,
                 "hbm_algorithmic_GBs": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9,
                 "hbm_frac": REF_BYTES_PER_EDGE_BLOCK[args.irreps] * rows_per_launch / avg_s / 1e9 / PEAK_HBM_GBS,
                 "hbm_measured_GBs": pmc_bytes * rows_per_launch / avg_s / 1e9,

@@ -45,6 +45,7 @@ class Program:
     tile_floats: int = 0                              # dynamic LDS floats per workgroup (4 wave-private tiles)
     flops_per_row: float = 0.0                        # algorithmic (unpadded) flops per edge/row
     mfma_per_wave: int = 0                            # issued MFMAs per 16-row wave tile (padded)
+    mfma_radial: int = 0                              # ... of which the radial scales S = W3^T h, counted as fp32 MFMAs of K = 4 (the kernel issues 6 half-precision ones per row tile instead of H / 4)
     mfma_odd_skipped: int = 0                         # of those, the centre-column MFMAs of odd items that csrc/tp_is.hip does not issue
     # merged items (input-stationary kernel only): an item whose GEMM2 rows span SEVERAL output segments.  vsegs[v] = the member
     # segments in row order; such an item is filed under its first member, carries v + 1 in its row_off field (item[16]) and its L'
@@ -221,6 +222,7 @@ def _add_item(prog: Program, seg, typ, srcs, in_off, in_mulp, li, mm, neg, kstep
         n = (prog.hidden_pad // 4) * rto + rto * rto * 4 * (2 * prog.segs[seg][0] + 1)
     if typ == IT_TP:
         n += (prog.hidden_pad // 4) * rtm + rto * nk2 * nc
+        prog.mfma_radial += (prog.hidden_pad // 4) * rtm
         if neg and mm > 0:                                     # odd super-path: the input-stationary kernel skips the (zero) centre column
             prog.mfma_odd_skipped += len(srcs) * ksteps * rtm + rto * nk2
     prog.mfma_per_wave += n

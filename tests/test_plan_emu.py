@@ -106,15 +106,17 @@ def test_message_pack_program_x4_path_vs_oracle():
     assert rel(lay.from_planar(outp), out) < 1e-6
 
 
-def test_radial_scale_split_half_precision_twins_vs_oracle():
+def test_radial_scale_split_half_precision_twins_vs_oracle(monkeypatch):
     """r6: programs with 64 hidden units carry, behind every W3 fragment block, its split-half-precision twin (hi = f16(w), lo = f16(w - hi), K-slots paired as
-    the kernel's resident hidden rows are).  (1) hi + lo reproduces the fp32 weight to 2^-21; (2) the device-side refresh (ops.DeviceProgram.refresh_w3_split,
-    torch) writes the same bytes as the host packer; (3) the emulator fed from the TWINS (the kernel's arithmetic: W_lo h_hi + W_hi h_lo + W_hi h_hi) agrees
+    the kernel's resident hidden rows are).  (1) hi + lo reproduces the fp32 weight to 2^-21; (2) the device-side refresh (ops.DeviceProgram.refresh_w3_split
+    with the torch twin of hg_w3_split_refill) writes the same bytes as the host packer; (3) the emulator fed from the TWINS (the kernel's arithmetic: W_lo h_hi + W_hi h_lo + W_hi h_hi) agrees
     with the fp64 oracle to 3e-6 and with the exact-table form to 2e-6 -- but not to 1e-9: the path is exercised; (4) a weight beyond the half-precision
     range clears the part record's flag."""
     import torch
     from oracle import hamgnn_ref as R, e3
     from hamgnn_amd import ops
+    from tests import cpu_ops
+    monkeypatch.setattr(ops, "w3_split_refill", cpu_ops.w3_split_refill)      # (the product's refill is one HIP launch: hg_w3_split_refill; its torch twin here, the GPU suite compares the kernel)
     irr, sh = "16x0e+12x0o+32x1o+4x1e+7x2e", "0e+1o+2e"
     torch.manual_seed(0)
     prev = torch.get_default_dtype()
