@@ -115,8 +115,10 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) S1[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
             // all fragments requested and waited for before the first MFMA: the faster form (6.15 vs 6.55 ms per 131 072 edges, profiles/r06_tp_is.md section 3)
+#ifndef K_S_NOBATCH               /* A/B builds only: the compiler's own placement of the waits */
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -126,7 +128,9 @@ __device__ __forceinline__ void item_is(const IsArgs& A, const float* __restrict
 #pragma unroll
                 for (int rt = 0; rt < RTM; ++rt) S1[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wl[t][rt]), hbr.hi[t], S1[rt], 0, 0, 0);
             }
+#ifndef K_S_NOBATCH
             __builtin_amdgcn_sched_barrier(0);
+#endif
             const float c0 = A.s_scale, c1 = A.s_scale * (1.f / 2048.f);
 #pragma unroll
             for (int rt = 0; rt < RTM; ++rt) S[rt] = S[rt] * c0 + S1[rt] * c1;
