@@ -1,12 +1,13 @@
-// pkfma_repro.hip -- SELF-CONTAINED reproducer (nothing of the library): packed fp32 VALU instructions of one kernel return wrong results while ANOTHER kernel issues
-// v_mfma_f32_16x16x32_f16 on the same SIMDs (gfx950 / MI355X, ROCm 7.2).  profiles/r06_tp_is.md section 8.
+// pkfma_repro.hip -- SELF-CONTAINED reproducer (nothing of the library): on gfx950 (MI355X, ROCm 7.2) the packed fp32 FMA  v_pk_fma_f32 ... op_sel:[0,1,0]  (the HIGH dword of the
+// src1 register pair broadcast to both lanes) returns wrong results while ANOTHER kernel issues v_mfma_f32_16x16x32_f16 on the same SIMDs.  profiles/r06_tp_is.md section 8.
 //
-//   hipcc --offload-arch=gfx950 -O3 tools/pkfma_repro.hip -o /tmp/pkfma_repro                                                       && /tmp/pkfma_repro   # packed instructions
-//   hipcc --offload-arch=gfx950 -O3 -Xclang -target-feature -Xclang -packed-fp32-ops tools/pkfma_repro.hip -o /tmp/pkfma_repro_nopk && /tmp/pkfma_repro_nopk
+//   hipcc --offload-arch=gfx950 -O3 -DFORM=3 tools/pkfma_repro.hip -o /tmp/pkfma_repro && /tmp/pkfma_repro [rows] [launches] [aggressor workgroups]
+//       -> 77 % of the victim's rows wrong next to chains of v_mfma_f32_16x16x32_f16, none next to v_mfma_f32_16x16x16_f16 or v_mfma_f32_16x16x4_f32 chains
+//   -DFORM=1 / 2 / 4 (the other three broadcast encodings), -DFORM=0 (what the compiler makes of the C loop: op_sel_hi:[0,1,1]), -DPAD=150 (victim padded to 228 VGPRs): 0 wrong rows;
+//   built with -Xclang -target-feature -Xclang -packed-fp32-ops the C loop holds no packed instruction at all (what hamgnn_amd/csrc/Makefile does for the whole library).
 //
-// VICTIM: the edge kernel's rotated staging, reduced: per lane N float4 rows v[b] gathered from a table and N scalars d[b], acc = sum_b d[b] * v[b], written out.  The compiler
-// turns `acc += d * v` into v_pk_fma_f32 / v_pk_mul_f32 with op_sel broadcasts of d.  No MFMA, no LDS.  AGGRESSOR: dependent chains of one MFMA kind in registers, nothing
-// else.  The victim's output with the aggressor on a second stream is compared with its output on an idle GPU, bit for bit.
+// VICTIM: the edge kernel's rotated staging, reduced: per lane N float4 rows v[b] gathered from a table and N scalars d[b], acc = sum_b d[b] * v[b], written out.  No MFMA, no LDS.
+// AGGRESSOR: dependent chains of one MFMA kind in registers, nothing else, on a second stream.  The victim's output is compared with its own output on an idle GPU, bit for bit.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -76,9 +77,40 @@ __global__ __launch_bounds__(256) void victim(const float* __restrict__ rows, co
             v[b] = *reinterpret_cast<const f32x4*>(row + b * mulp + 4 * p);
             d[b] = D[a * N + b];
         }
+#if !defined(FORM) || FORM == 0
         f32x4 acc = d[0] * v[0];
 #pragma unroll
         for (int b = 1; b < N; ++b) acc += d[b] * v[b];
+#else
+        // the packed FMA written out, one encoding of the broadcast per FORM (the edge kernel's ISA holds all four; the compiler's choice for the loop above is form 1):
+        //   1: src0 = pair (d, x), low half broadcast  op_sel_hi:[0,1,1]      2: src1 = pair (d, x), low half broadcast  op_sel_hi:[1,0,1]
+        //   3: src1 = pair (x, d), HIGH half broadcast op_sel:[0,1,0]         4: src0 = pair (x, d), HIGH half broadcast op_sel:[1,0,0]
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        f32x2_ lo = {0.f, 0.f}, hi = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+            const float other = d[(b + 1) % N];
+            const f32x2_ vlo = {v[b][0], v[b][1]}, vhi = {v[b][2], v[b][3]};
+#if FORM == 1
+            const f32x2_ dp = {d[b], other};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(lo) : "v"(dp), "v"(vlo));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(hi) : "v"(dp), "v"(vhi));
+#elif FORM == 2
+            const f32x2_ dp = {d[b], other};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(lo) : "v"(vlo), "v"(dp));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(hi) : "v"(vhi), "v"(dp));
+#elif FORM == 3
+            const f32x2_ dp = {other, d[b]};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(lo) : "v"(vlo), "v"(dp));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(hi) : "v"(vhi), "v"(dp));
+#else
+            const f32x2_ dp = {other, d[b]};
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(lo) : "v"(dp), "v"(vlo));
+            asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(hi) : "v"(dp), "v"(vhi));
+#endif
+        }
+        const f32x4 acc = {lo[0], lo[1], hi[0], hi[1]};
+#endif
         *reinterpret_cast<f32x4*>(o + a * mulp + 4 * p) = acc;
     }
 #if PAD > 0
