@@ -309,6 +309,20 @@ def tp_weight_grads(wg: TPWeightGrad, run_program, srcs: Sequence[torch.Tensor],
     return (out, gx) if want_gx else out
 
 
+def _ht_times(h: torch.Tensor, gs: torch.Tensor) -> torch.Tensor:
+    """h^T gs ([H, E] @ [E, C]) for the last radial layer's weight gradient.  With E = 44 k and H = 64 the library's single GEMM has nothing to parallelise over but the long K:
+    16 batched partial products + a fixed-order sum run at 2.9 instead of 1.8 TB/s of gs (profiles/r06_training.md); deterministic (no split-K atomics)."""
+    E = h.shape[0]
+    if E < 4096:
+        return h.t() @ gs
+    k = 16
+    Ek = E // k * k
+    out = torch.bmm(h[:Ek].reshape(k, Ek // k, h.shape[1]).transpose(1, 2), gs[:Ek].reshape(k, Ek // k, gs.shape[1])).sum(0)
+    if Ek < E:
+        out = out + h[Ek:].t() @ gs[Ek:]
+    return out
+
+
 def tp_weight_grads_fused(wg: TPWeightGrad, wf, run_wgrad, srcs: Sequence[torch.Tensor], g, rbf, act_cst: float, chunk: int = 1 << 20, hidden=None):
     """the same gradients as tp_weight_grads through the FUSED kernel (csrc/tp_wgrad.hip, plan.WgFused `wf`): nothing per edge is
     materialised except gs (the gradient with respect to the last radial layer's output).  run_wgrad(srcs_by_slot, g, h_node, h_edge) ->
@@ -356,11 +370,11 @@ def tp_weight_grads_fused(wg: TPWeightGrad, wf, run_wgrad, srcs: Sequence[torch.
                 W3 = gen[name][-1].detach()
                 idx = alive[bi]
                 if idx is None:
-                    gW3_last[name] += h[name].t() @ gs[bi] / math.sqrt(H)
+                    gW3_last[name] += _ht_times(h[name], gs[bi]) / math.sqrt(H)
                     gh_hidden[name][sl] = gs[bi] @ (W3.t() / math.sqrt(H))
                 else:
                     gsc = gs[bi].index_select(1, idx)
-                    gW3_last[name].index_add_(1, idx, h[name].t() @ gsc / math.sqrt(H))          # (distinct columns: no two terms meet, the order is fixed)
+                    gW3_last[name].index_add_(1, idx, _ht_times(h[name], gsc) / math.sqrt(H))     # (distinct columns: no two terms meet, the order is fixed)
                     gh_hidden[name][sl] = gsc @ (W3.index_select(1, idx).t() / math.sqrt(H))
     for name in gen:                                           # hidden layers of the radial MLPs: two dense layers per edge, torch.autograd
         hid, ks = gen[name][:-1], gkeys[name]
